@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- training videos/sec of the hot path on N MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] -- MoeModel (2 mixtures) on video-level features
+(D=1152 -> V=4716 labels), batch 1024 PER GPU, fp32, full training step:
+    L2-normalise -> MoE head (2 GEMMs + mixing) -> CrossEntropyLoss -> backward (2 dW GEMMs, bias sums)
+    -> [RCCL gradient all-reduce for N>1] -> + l2*w -> per-tensor clip -> TF-Adam.
+Inputs are synthetic and already resident in HBM (a pool of distinct batches cycled through).
+One "step" = one such pass over one batch.  N>1: one process per GPU (torchrun contract), weak scaling.
+
+Extra legs (rank 0):
+  roofline     : hipEvent timing of the dominant kernel family (gemm_f32) inside the library, in a separate
+                 pass after the timed region; algorithmic FLOPs per launch / average launch duration vs the fp32
+                 matrix peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline : the torch-CPU fp32 restatement of the same step (oracle/torch_ref.py, kind "port") on the host
+                 cores, bounded sample; N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__  # noqa: E402
+
+D_IN, VOCAB, MIX = 1152, 4716, 2
+PEAK_F32_MATRIX_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def make_pool(n, B, dev, seed):
+    """Video-level synthetic inputs: x = mean over frames of dequantised uint8 ~ N(0.008, small) is
+    too degenerate to train on, so use a wide spread in the dequantised range [-2, 2]; labels ~ Bernoulli(3.4/4716)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    xs, ys = [], []
+    for _ in range(n):
+        xs.append((torch.rand((B, D_IN), device=dev, generator=gen) * 4.0 - 2.0))
+        ys.append((torch.rand((B, VOCAB), device=dev, generator=gen) < (3.4 / VOCAB)))
+    return xs, ys
+
+
+def cpu_baseline(B, seconds):
+    from oracle import torch_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
+    y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
+    st.step(x, y)                                   # warm-up (allocations, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        st.step(x, y)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same B=%d fp32 MoeModel step on torch-CPU (oracle/torch_ref.py), %.1f s" % (n, B, el)}
+
+
+def main():
+    a = parse()
+    __graft_entry__.load_package()
+    import yt8m_amd._lib as L
+    import yt8m_amd.parallel as parallel
+    import yt8m_amd.train as train
+    import yt8m_amd.video_level_models as vlm
+    from yt8m_amd.variables import reset_default_graph
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_from_env()
+    if world != a.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the measured path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    L.lib()
+
+    B = a.batch
+    g = reset_default_graph(device=dev, seed=0)
+    reducer = parallel.GradReducer() if world > 1 else None
+    tg = train.TrainGraph(vlm.MoeModel(), batch_size=B * world, graph=g, reducer=reducer)
+    xs, ys = make_pool(a.pool, B, dev, seed=1234 + rank)
+
+    def run(k, base):
+        for i in range(k):
+            j = (base + i) % a.pool
+            tg.step(xs[j], ys[j])
+
+    run(max(a.warmup, 1), 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps, a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        lib = L.lib()
+        import ctypes
+        lib.yt8m_prof_reset()
+        lib.yt8m_prof_enable(1)
+    if not a.no_roofline:
+        # every rank runs the same extra steps (the all-reduce is collective); only rank 0 records events
+        run(min(a.steps, 20), 0)
+        torch.cuda.synchronize()
+    if rank == 0 and not a.no_roofline:
+        lib.yt8m_prof_enable(0)
+        n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        lib.yt8m_prof_get(0, ctypes.byref(n), ctypes.byref(ms))
+        steps_p = min(a.steps, 20)
+        # algorithmic FLOPs of the GEMM launches of one step: fwd x.Wg, x.We; bwd x^T.dZg, x^T.dZe
+        flops_step = 2.0 * 2.0 * B * D_IN * VOCAB * (2 * MIX + 1)
+        launches_step = n.value / float(steps_p) if steps_p else 0
+        avg_ms = ms.value / max(n.value, 1)
+        flops_launch = flops_step / max(launches_step, 1)
+        ach = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach,
+                "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
+                "traffic": None, "launches_per_step": launches_step, "avg_launch_ms": avg_ms,
+                "algorithmic_flops_per_launch": flops_launch}
+        fam = {}
+        for fid, name in [(2, "elementwise"), (3, "optimizer")]:
+            lib.yt8m_prof_get(fid, ctypes.byref(n), ctypes.byref(ms))
+            fam[name] = {"launches_per_step": n.value / float(steps_p), "ms_per_step": ms.value / steps_p}
+        roof["other_families"] = fam
+        roof["gemm_ms_per_step"] = avg_ms * launches_step
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(B, a.cpu_seconds)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {"metric": "training videos/sec", "value": a.steps * B * world / el, "unit": "videos/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: MoeModel (2 mixtures) on video-level features, D=1152, V=4716, "
+                                      "fp32 training step (fwd+bwd+clip+Adam%s)" % ("+RCCL all-reduce" if world > 1 else ""),
+                          "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "params": 27173592},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

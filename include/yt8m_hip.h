@@ -1,0 +1,171 @@
+/* yt8m_hip.h -- C ABI of libyt8m_hip.so: the MI355X (gfx950) hot path of wangheda/youtube-8m.
+ *
+ * The reference has NO native code and NO FFI: every entry point below replaces the
+ * stock TensorFlow-1.0 kernels that the cited reference line invokes.  Paths are relative to
+ * /root/reference/youtube-8m-wangheda/ (W).  All pointers are DEVICE pointers unless marked host;
+ * matrices are row-major; sizes are int64_t; every launch goes to the caller's hipStream_t
+ * (passed as void*; NULL = default stream).  Functions are re-entrant, never throw / abort, and return
+ * 0 on success or a negative yt8m_status (message via yt8m_last_error(), thread-local).
+ */
+#ifndef YT8M_HIP_H
+#define YT8M_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* yt8m_stream_t; /* hipStream_t */
+
+enum yt8m_status { YT8M_OK = 0, YT8M_E_BADARG = -1, YT8M_E_SHAPE = -2, YT8M_E_HIP = -3, YT8M_E_RCCL = -4 };
+enum yt8m_label_dtype { YT8M_LABEL_U8 = 0, YT8M_LABEL_F32 = 1 };
+
+int yt8m_abi_version(void);
+const char* yt8m_last_error(void);
+/* name of the gfx target the device code was built for ("gfx950") */
+const char* yt8m_built_arch(void);
+
+/* ---- profiling hooks used by bench.py (roofline leg): per-kernel-family hipEvent timing -------- */
+/* family ids: 0 gemm_f32, 1 moe_head_fused, 2 elementwise, 3 optimizer, 4 lstm, 5 netvlad */
+int yt8m_prof_enable(int on);
+int yt8m_prof_reset(void);
+/* synchronises the device; returns launches and total ms for a family */
+int yt8m_prof_get(int family, int64_t* launches, double* total_ms);
+
+/* ---- GEMM: C[M,N] = op(A)[M,K] . op(B)[K,N] (+ bias[N]) (+ beta*C), exact fp32 on v_mfma_f32_32x32x2_f32.
+ * Replaces tf.matmul / slim.fully_connected's MatMul+BiasAdd (W/all_video_models/moe_model.py:40-52,
+ * logistic_model.py:23-25, deep_combine_chain_model.py:29-34, BasicLSTMCell _linear) and their
+ * autodiff transposes.  transA=0: A is [M,K] (lda>=K); transA=1: A is [K,M] (lda>=M).
+ * transB=0: B is [K,N] (ldb>=N); transB=1: B is [N,K] (ldb>=K).  beta must be 0 or 1.
+ * bias may be NULL.  colsum (optional, [N]) : NULL, reserved. */
+int yt8m_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                  const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float* C, int64_t ldc, const float* bias, float beta, yt8m_stream_t stream);
+
+/* batched form (no bias): problem i uses A + i*strideA, B + i*strideB, C + i*strideC.  Used for the per-video
+ * aggregation GEMMs (NetVLAD a^T.x, attention pooling w^T.out; SURVEY.md Appendix B,
+ * W/all_frame_models/lstm_attention_max_pooling_model.py:63). */
+int yt8m_gemm_f32_batched(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                          const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB,
+                          float* C, int64_t ldc, int64_t strideC, float beta, int64_t batch, yt8m_stream_t stream);
+
+/* ---- input transform ---------------------------------------------------------------------------
+ * yt8m_l2norm_*: tf.nn.l2_normalize on the last axis (W/all_feature_transform/default_transformer.py:4-8,
+ * deep_combine_chain_model.py:44): y = x * rsqrt(max(sum x^2, eps)).  bwd per SURVEY.md Appendix G. */
+int yt8m_l2norm_fwd_f32(const float* x, float* y, int64_t rows, int64_t cols, float eps, yt8m_stream_t stream);
+int yt8m_l2norm_bwd_f32(const float* x, const float* dy, float* dx, int64_t rows, int64_t cols, float eps,
+                        yt8m_stream_t stream);
+/* yt8m_dequant_l2norm_u8: readers.py:178-187 + utils.py:23-38 + default_transformer.py:7 in one pass over
+ * the raw uint8 frame block q[B,F,D]: x = l2norm(q*(4/255) + (4/512-2)); rows f >= num_frames[b] are 0.
+ * num_frames may be NULL (all F frames valid). */
+int yt8m_dequant_l2norm_u8(const uint8_t* q, const int32_t* num_frames, float* x,
+                           int64_t B, int64_t F, int64_t D, float eps, yt8m_stream_t stream);
+/* video-level: mean over valid frames of the dequantised features (readers.py:69-71 "average of
+ * dequantized values") then L2-normalise: q[B,F,D] -> x[B,D] */
+int yt8m_dequant_mean_l2norm_u8(const uint8_t* q, const int32_t* num_frames, float* x,
+                                int64_t B, int64_t F, int64_t D, float eps, yt8m_stream_t stream);
+
+/* ---- MoE head (W/all_video_models/moe_model.py:54-64) ------------------------------------------
+ * Zg [B, V*(M+1)] gate logits (label-major, mixture-minor; gate M = dummy expert), Ze [B, V*M] expert
+ * logits (bias already added).  p[b,l] = sum_{m<M} softmax(Zg[b,l,:])[m] * sigmoid(Ze[b,l,m]). */
+int yt8m_moe_mix_fwd(const float* Zg, const float* Ze, float* p, int64_t B, int64_t V, int M,
+                     yt8m_stream_t stream);
+/* in-place backward: Zg <- dL/dZg, Ze <- dL/dZe given dp = dL/dp [B,V].
+ * (the expert-bias gradient is yt8m_colsum_f32 of the returned dL/dZe) */
+int yt8m_moe_mix_bwd(float* Zg, float* Ze, const float* dp, int64_t B, int64_t V, int M,
+                     yt8m_stream_t stream);
+
+/* ---- elementwise activations + column sums (bias gradients) ------------------------------------ */
+enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8M_ACT_TANH = 3, YT8M_ACT_ELU = 4 };
+int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream);
+/* dx = dy * act'(.) expressed from the OUTPUT y (sigmoid/tanh/relu/relu6/elu all admit it) */
+int yt8m_act_bwd_f32(int act, const float* y, const float* dy, float* dx, int64_t n, yt8m_stream_t stream);
+/* out[n] (beta=0) or out[n] += (beta=1): sum over rows of X[rows, cols]; deterministic */
+int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta,
+                    yt8m_stream_t stream);
+
+/* ---- loss: CrossEntropyLoss (W/losses.py:110-130), probability space, eps = 1e-5 ---------------
+ * loss = mean_b sum_l -[y log(p+eps) + (1-y) log(1-p+eps)] * (w_b);  dp = dloss/dp * upstream.
+ * labels: uint8 {0,1} or float32 (smoothed labels, losses.py:46-54).  weights [B] optional (NULL).
+ * loss_out: device float[1].  dp may be NULL (eval).  workspace: device, >= yt8m_xent_workspace_bytes(). */
+int64_t yt8m_xent_workspace_bytes(int64_t B, int64_t V);
+int yt8m_xent_fwd_bwd(const float* p, const void* labels, int label_dtype, const float* weights,
+                      float* loss_out, float* dp, int64_t B, int64_t V, float eps, float upstream,
+                      void* workspace, yt8m_stream_t stream);
+
+/* backward only: dp = dL/dp * upstream * (upstream_dev ? *upstream_dev : 1)  (upstream_dev: device float[1]) */
+int yt8m_xent_bwd(const float* p, const void* labels, int label_dtype, const float* weights,
+                  const float* upstream_dev, float* dp, int64_t B, int64_t V, float eps, float upstream,
+                  yt8m_stream_t stream);
+
+/* ---- optimiser slice of build_graph (W/train.py:435-466, W/utils.py:164-174, tf.train.AdamOptimizer)
+ * The parameters live in one flat fp32 arena; `chunks` (device, int32[nchunks*4]) describes it as
+ * {offset, count, tensor_id, unused} with no chunk spanning two tensors; count <= 4096.
+ * g_eff = g*gscale + l2[tensor]*w  (gscale = 1/world for the all-reduce mean; l2 = 1e-8 for
+ * regularised weights, 0 otherwise: slim.l2_regularizer gradient).
+ * sqnorm: norms[tensor] = sum g_eff^2  (deterministic two-stage reduction; partial: float[nchunks]).
+ * adam:   g_c = g_eff * clip/max(sqrt(norms[t]), clip) (clip<=0: no clipping);
+ *         m = b1 m + (1-b1) g_c; v = b2 v + (1-b2) g_c^2; w -= lr_t * m / (sqrt(v) + eps)   [TF-1 form] */
+int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* chunks, int64_t nchunks,
+                      const float* l2, float gscale, float* partial, float* norms, int64_t ntensors,
+                      yt8m_stream_t stream);
+int yt8m_adam_multi(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
+                    const float* l2, float gscale, const float* norms, float clip,
+                    float lr_t, float beta1, float beta2, float eps, yt8m_stream_t stream);
+
+/* ---- BasicLSTMCell gate block (tf.contrib.rnn.BasicLSTMCell via W/all_frame_models/lstm_model.py:34-47)
+ * z [B,4H] = pre-activations in the order i, j, f, o.  live[b] = (t < num_frames[b]) implements
+ * dynamic_rnn's copy-through (Z/rnn_residual.py:61-188): dead rows keep (c,h) and emit out = 0.
+ * fwd: c_new, h_new, out (may alias h_new when no dead rows matter; out may be NULL).
+ * z is overwritten with the ACTIVATED gates (sigmoid(i), tanh(j), sigmoid(f+fb), sigmoid(o)) for bwd. */
+int yt8m_lstm_gates_fwd(float* z, const float* c_prev, const float* h_prev, float* c_new, float* h_new,
+                        float* out, const int32_t* num_frames, int32_t t, int64_t B, int64_t H,
+                        float forget_bias, yt8m_stream_t stream);
+/* bwd of one step.  gates = activated gates saved by fwd; c_prev, c_new saved.  dh, dc are the incoming
+ * gradients wrt the carried state (h_new, c_new); dout (may be NULL) is the gradient wrt the emitted
+ * output of this step (only live rows emitted h_new; dead rows emitted the constant 0).
+ * Outputs: dz [B,4H] (pre-activation grads, 0 on dead rows), dc_prev, dh_prev (dead rows: dh flows
+ * straight through; live rows get 0 here and receive dh_prev from dz . W^T by the caller's GEMM, beta=1). */
+int yt8m_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh,
+                        const float* dc, const float* dout, float* dz, float* dc_prev, float* dh_prev,
+                        const int32_t* num_frames, int32_t t, int64_t B, int64_t H, yt8m_stream_t stream);
+
+/* One BasicLSTM layer over all F steps of tf.nn.dynamic_rnn, TIME-MAJOR buffers.
+ * z [F,B,4H]: in = hoisted input projection x_t.W_x + b (one GEMM over all steps); out = activated gates.
+ * Wh: the recurrent rows of the cell's "weights" variable ([H,4H] block, row stride ldw).
+ * cs, hs [F+1,B,H]: state history, slot 0 = initial state (caller zero-fills), slot t+1 = state after step t.
+ * out [F,B,H] (may be NULL): emitted outputs, 0 on dead rows.  The time loop runs inside the library
+ * (one recurrent GEMM accumulate + one gate kernel per step). */
+int yt8m_lstm_layer_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
+                        const int32_t* num_frames, int64_t F, int64_t B, int64_t H, float forget_bias,
+                        yt8m_stream_t stream);
+/* BPTT of one layer.  gates [F,B,4H] from fwd; dout [F,B,H] or NULL; dc_final/dh_final [B,H] or NULL (gradient
+ * wrt the final carried state).  Writes dz [F,B,4H] (pre-activation gradients; the caller turns them into
+ * dW_x, dW_h, db, dX with four hoisted GEMMs/column sums).  work: device scratch of 4*B*H floats. */
+int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout,
+                        const float* dc_final, const float* dh_final, float* dz, float* work,
+                        const int32_t* num_frames, int64_t F, int64_t B, int64_t H, yt8m_stream_t stream);
+
+/* ---- masked softmax over frames + renormalise (lstm_attention_max_pooling_model.py:59-60) -------
+ * act [B,F,A] -> w [B,F,A]: w = mask * softmax_F(act) / sum_F(mask * softmax_F(act)).  bwd: dact from dw. */
+int yt8m_attn_softmax_fwd(const float* act, const int32_t* num_frames, float* w, int64_t B, int64_t F,
+                          int64_t A, yt8m_stream_t stream);
+int yt8m_attn_softmax_bwd(const float* w, const float* dw, const int32_t* num_frames, float* dact,
+                          int64_t B, int64_t F, int64_t A, yt8m_stream_t stream);
+
+/* ---- row softmax over the last axis with an optional frame mask (NetVLAD assignment, Appendix B) ---
+ * s [rows, K] -> a = softmax_K(s) * (f < num_frames[b]); rows = B*F. */
+int yt8m_softmax_rows_fwd(const float* s, const int32_t* num_frames, float* a, int64_t B, int64_t F,
+                          int64_t K, yt8m_stream_t stream);
+int yt8m_softmax_rows_bwd(const float* a, const float* da, const int32_t* num_frames, float* ds,
+                          int64_t B, int64_t F, int64_t K, yt8m_stream_t stream);
+
+/* ---- per-row top-k for the GAP@20 eval path (W/eval_util.py:123-165 top_k_triplets) -------------
+ * p [B,V] -> vals [B,k] (descending), idx [B,k] int32; ties broken towards the LOWER class index. k<=64 */
+int yt8m_topk_rows(const float* p, int64_t B, int64_t V, int k, float* vals, int32_t* idx,
+                   yt8m_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YT8M_HIP_H */

@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- second, independent restatement in torch-CPU.
+
+Purpose: (1) gradients by autograd (float64) for backward-parity tests of the HIP kernels,
+(2) cross-check of oracle/np_ref.py (two restatements must agree), (3) the `cpu_baseline` "port" leg
+of bench.py (float32, all host cores).  **Parity unpinned** (see oracle/__init__.py).
+
+Citations: W = /root/reference/youtube-8m-wangheda/, "A.n" = SURVEY.md Appendix A.
+"""
+import math
+
+import torch
+
+XENT_EPS = 10e-6  # W/losses.py:115
+
+
+def dequantize(q, dtype=torch.float32):
+    """W/utils.py:23-38."""
+    return q.to(dtype) * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)
+
+
+def l2_normalize(x, dim=-1, eps=1e-12):
+    """A.9."""
+    return x * torch.rsqrt(torch.clamp((x * x).sum(dim, keepdim=True), min=eps))
+
+
+def moe(x, Wg, We, be, M):
+    """W/all_video_models/moe_model.py:40-64."""
+    B = x.shape[0]
+    V = We.shape[1] // M
+    g = torch.softmax((x @ Wg).view(B, V, M + 1), dim=2)
+    e = torch.sigmoid((x @ We + be).view(B, V, M))
+    return (g[:, :, :M] * e).sum(2)
+
+
+def logistic(x, W, b):
+    """W/all_video_models/logistic_model.py:23-25."""
+    return torch.sigmoid(x @ W + b)
+
+
+def deep_combine_chain(x, P, L, M, relu_type="relu"):
+    """W/all_video_models/deep_combine_chain_model.py:12-85."""
+    cur, sup = x, []
+    for i in range(L):
+        s = "prediction-%d" % i
+        sp = moe(cur, P["gates-%s/weights" % s], P["experts-%s/weights" % s], P["experts-%s/biases" % s], M)
+        a = sp @ P["relu-%d/weights" % i] + P["relu-%d/biases" % i]
+        r = torch.nn.functional.elu(a) if relu_type == "elu" else torch.relu(a)
+        cur = torch.cat([cur, l2_normalize(r, 1)], 1)
+        sup.append(sp)
+    main = moe(cur, P["gates--main/weights"], P["experts--main/weights"], P["experts--main/biases"], M)
+    return main, torch.cat(sup, 1)
+
+
+def lstm_stack(x, num_frames, layers, forget_bias=1.0):
+    """A.3-A.5 (BasicLSTMCell / MultiRNNCell / dynamic_rnn with copy-through; Z/rnn_residual.py:61-188)."""
+    B, F, _ = x.shape
+    H = layers[0][1].numel() // 4
+    c = [x.new_zeros(B, H) for _ in layers]
+    h = [x.new_zeros(B, H) for _ in layers]
+    outs = []
+    for t in range(F):
+        live = (t < num_frames).unsqueeze(1)
+        inp = x[:, t]
+        for l, (W, b) in enumerate(layers):
+            z = torch.cat([inp, h[l]], 1) @ W + b
+            i, j, f, o = z.chunk(4, 1)
+            cn = c[l] * torch.sigmoid(f + forget_bias) + torch.sigmoid(i) * torch.tanh(j)
+            hn = torch.tanh(cn) * torch.sigmoid(o)
+            c[l] = torch.where(live, cn, c[l])
+            h[l] = torch.where(live, hn, h[l])
+            inp = hn
+        outs.append(torch.where(live, inp, torch.zeros_like(inp)))
+    return torch.stack(outs, 1), c, h
+
+
+def lstm_model_state(x, num_frames, layers):
+    """W/all_frame_models/lstm_model.py:34-52: [c0||h0||c1||h1]."""
+    _, c, h = lstm_stack(x, num_frames, layers)
+    return torch.cat([t for pair in zip(c, h) for t in pair], 1)
+
+
+def attention_pool(x, outputs, num_frames, Wa, ba):
+    """W/all_frame_models/lstm_attention_max_pooling_model.py:34,51-63."""
+    F = x.shape[1]
+    mask = (torch.arange(F)[None, :] < num_frames[:, None]).to(x.dtype)
+    act = torch.cat([x, outputs], 2) @ Wa + ba
+    w = torch.softmax(act, dim=1) * mask[:, :, None]           # [B,F,A]
+    w = w / w.sum(1, keepdim=True)
+    return torch.einsum("bfh,bfa->bah", outputs, w)
+
+
+def lstm_attention_max_pooling(x, num_frames, layers, Wa, ba, Wg, We, be, M):
+    outputs, _, _ = lstm_stack(x, num_frames, layers)
+    pooled = attention_pool(x, outputs, num_frames, Wa, ba)
+    B, A, H = pooled.shape
+    return moe(pooled.reshape(B * A, H), Wg, We, be, M).view(B, A, -1).max(1).values
+
+
+def netvlad(x, num_frames, Wc, bc, centres, eps=1e-12):
+    """SURVEY.md Appendix B (not in the reference)."""
+    B, F, D = x.shape
+    mask = (torch.arange(F)[None, :] < num_frames[:, None]).to(x.dtype)
+    a = torch.softmax(x @ Wc + bc, dim=2) * mask[:, :, None]
+    vlad = torch.einsum("bfk,bfd->bkd", a, x) - a.sum(1)[:, :, None] * centres[None]
+    vlad = l2_normalize(vlad, 2, eps)
+    return l2_normalize(vlad.reshape(B, -1), 1, eps)
+
+
+def netvlad_hidden(x, num_frames, Wc, bc, centres, Wh, bh, Wgate=None, bgate=None):
+    h = netvlad(x, num_frames, Wc, bc, centres) @ Wh + bh
+    if Wgate is not None:
+        h = h * torch.sigmoid(h @ Wgate + bgate)
+    return h
+
+
+def dbof_hidden(xs, Wc, bc, Wh, bh, pooling="max"):
+    """W/all_frame_models/dbof_model.py:57-116, add_batch_norm=False."""
+    B, S, D = xs.shape
+    act = torch.clamp(xs.reshape(-1, D) @ Wc + bc, 0, 6).view(B, S, -1)
+    pooled = act.max(1).values if pooling == "max" else act.mean(1)
+    return torch.clamp(pooled @ Wh + bh, 0, 6)
+
+
+def cross_entropy(p, y, weights=None, eps=XENT_EPS):
+    """W/losses.py:114-130."""
+    y = y.to(p.dtype)
+    ce = -(y * torch.log(p + eps) + (1 - y) * torch.log(1 - p + eps))
+    if weights is not None:
+        ce = ce * weights[:, None]
+    return ce.sum(1).mean()
+
+
+def exponential_decay(base_lr, step, batch, decay_examples=4000000, decay=0.95):
+    """A.7 / W/train.py:303-308."""
+    return base_lr * decay ** math.floor(step * batch / float(decay_examples))
+
+
+class TFAdam:
+    """A.6 + W/train.py:435-466 + W/utils.py:164-174: grad of (label_loss + sum l2*0.5*|W|^2), per-tensor
+    clip_by_norm, TF-1 Adam (eps outside sqrt, bias correction folded into lr_t)."""
+
+    def __init__(self, params, regularised, base_lr=0.01, batch_size=1024, l2=1e-8, clip=1.0,
+                 decay_examples=4000000, decay=0.95, b1=0.9, b2=0.999, eps=1e-8):
+        self.params = params                  # dict name -> tensor (requires_grad leaf)
+        self.reg = set(regularised)
+        self.base_lr, self.batch, self.l2, self.clip = base_lr, batch_size, l2, clip
+        self.de, self.decay, self.b1, self.b2, self.eps = decay_examples, decay, b1, b2, eps
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.step_no = 0
+
+    @torch.no_grad()
+    def step(self):
+        lr = exponential_decay(self.base_lr, self.step_no, self.batch, self.de, self.decay)
+        t = self.step_no + 1
+        lr_t = lr * math.sqrt(1 - self.b2 ** t) / (1 - self.b1 ** t)
+        for k, w in self.params.items():
+            g = w.grad
+            if k in self.reg:
+                g = g + self.l2 * w
+            if self.clip > 0:
+                g = g * (self.clip / torch.clamp(g.norm(), min=self.clip))
+            self.m[k].mul_(self.b1).add_(g, alpha=1 - self.b1)
+            self.v[k].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            w.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
+            w.grad = None
+        self.step_no += 1
+
+
+def xavier_uniform_(t, gen):
+    """A.1: slim default weights initialiser, uniform +-sqrt(6/(fan_in+fan_out))."""
+    lim = math.sqrt(6.0 / (t.shape[0] + t.shape[1]))
+    return t.uniform_(-lim, lim, generator=gen)
+
+
+def make_moe_params(D, V, M, dtype=torch.float32, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    P = {"gates/weights": xavier_uniform_(torch.empty(D, V * (M + 1), dtype=dtype), gen),
+         "experts/weights": xavier_uniform_(torch.empty(D, V * M, dtype=dtype), gen),
+         "experts/biases": torch.zeros(V * M, dtype=dtype)}
+    return P
+
+
+class MoeTrainStepCPU:
+    """Whole training step of BASELINE config[1] (MoeModel M=2 on video-level features) on the
+    host: transform (W/train.py:343-344) -> MoeModel -> CrossEntropyLoss -> reg -> clip -> Adam."""
+
+    def __init__(self, D=1152, V=4716, M=2, batch_size=1024, dtype=torch.float32, seed=0, base_lr=0.01):
+        self.M = M
+        self.P = {k: v.requires_grad_(True) for k, v in make_moe_params(D, V, M, dtype, seed).items()}
+        self.opt = TFAdam(self.P, ["gates/weights", "experts/weights"], base_lr=base_lr, batch_size=batch_size)
+
+    def step(self, x_raw, labels):
+        x = l2_normalize(x_raw, 1)
+        p = moe(x, self.P["gates/weights"], self.P["experts/weights"], self.P["experts/biases"], self.M)
+        loss = cross_entropy(p, labels)
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), p.detach()

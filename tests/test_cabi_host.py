@@ -1,0 +1,146 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/yt8m_hip.h declares, and rejects bad arguments with status codes (no compute, no GPU needed);
+the Python plugin surface behaves like the reference's (names, lookup, error types)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import yt8m_amd._lib as L
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "yt8m_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(yt8m_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    names = _declared()
+    assert len(names) >= 30
+    assert set(names) == set(L.SIGNATURES), (set(names) ^ set(L.SIGNATURES))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for n in _declared():
+        assert hasattr(raw, n), n
+    assert lib.yt8m_abi_version() == 1
+    assert lib.yt8m_built_arch() == b"gfx950"
+
+
+def test_argument_validation_without_device():
+    lib = L.lib()
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    assert lib.yt8m_gemm_f32(0, 0, 4, 4, 4, one, 4, one, 4, one, 4, None, 0.5, None) == -1   # beta not 0/1
+    assert b"beta" in lib.yt8m_last_error()
+    assert lib.yt8m_gemm_f32(0, 0, -1, 4, 4, one, 4, one, 4, one, 4, None, 0.0, None) == -2   # negative dim
+    assert lib.yt8m_gemm_f32(0, 0, 4, 4, 4, one, 2, one, 4, one, 4, None, 0.0, None) == -2    # lda < K
+    assert lib.yt8m_gemm_f32(0, 0, 4, 4, 4, None, 4, one, 4, one, 4, None, 0.0, None) == -1   # null operand
+    assert lib.yt8m_gemm_f32(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0.0, None) == 0  # empty problem is a no-op
+    assert lib.yt8m_moe_mix_fwd(one, one, one, 2, 3, 0, None) == -1                            # M out of range
+    assert lib.yt8m_moe_mix_fwd(one, one, one, 2, 3, 17, None) == -1
+    assert lib.yt8m_moe_mix_fwd(None, None, None, 0, 3, 2, None) == 0
+    assert lib.yt8m_xent_fwd_bwd(one, one, 0, None, one, None, 0, 5, 1e-5, 1.0, one, None) == -2  # empty batch
+    assert lib.yt8m_xent_fwd_bwd(one, one, 7, None, one, None, 2, 5, 1e-5, 1.0, one, None) == -1  # label dtype
+    assert lib.yt8m_topk_rows(one, 2, 10, 0, one, one, None) == -1
+    assert lib.yt8m_topk_rows(one, 2, 10, 11, one, one, None) == -1
+    assert lib.yt8m_act_fwd_f32(9, one, one, 4, None) == -1
+    assert lib.yt8m_xent_workspace_bytes(1024, 4716) == 4 * (1024 * 5 + 1)
+    with pytest.raises(ValueError):
+        L.check(-2)
+    with pytest.raises(L.Yt8mHipError):
+        L.check(-3)
+
+
+def test_ops_fail_loudly_on_host_tensors():
+    """No CPU fallback: a host tensor is an error, never a silent eager path."""
+    import yt8m_amd.ops as ops
+    a = torch.zeros(4, 4)
+    with pytest.raises(L.Yt8mHipError):
+        ops.gemm(a, a)
+    with pytest.raises(L.Yt8mHipError):
+        ops.l2norm_fwd(a)
+    with pytest.raises(L.Yt8mHipError):
+        ops.xent_fwd(a, a)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.Yt8mHipError, match="no CPU fallback"):
+        L.lib()
+
+
+def test_plugin_surface(flags):
+    import yt8m_amd.models as models
+    import yt8m_amd.video_level_models as vlm
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.losses as losses
+    import yt8m_amd.train as train
+    with pytest.raises(NotImplementedError):
+        models.BaseModel().create_model(None)
+    with pytest.raises(NotImplementedError):
+        losses.BaseLoss().calculate_loss(None, None)
+    # W/train.py:212-215,703-708
+    assert train.find_class_by_name("MoeModel", [flm, vlm]) is vlm.MoeModel
+    assert train.find_class_by_name("LstmModel", [flm, vlm]) is flm.LstmModel
+    assert train.find_class_by_name("CrossEntropyLoss", [losses]) is losses.CrossEntropyLoss
+    with pytest.raises(StopIteration):
+        train.find_class_by_name("NoSuchModel", [flm, vlm])
+    for name in ["LogisticModel", "MoeModel", "DeepCombineChainModel"]:
+        assert issubclass(getattr(vlm, name), models.BaseModel)
+    for name in ["LstmModel", "LstmMemoryModel", "LstmAttentionMaxPoolingModel", "DbofModel", "FrameLevelLogisticModel",
+                 "NetVLADModel", "GatedNetVLADModel"]:
+        assert issubclass(getattr(flm, name), models.BaseModel), name
+    # reference flag names / defaults
+    assert flags.moe_num_mixtures == 2 and flags.deep_chain_layers == 3 and flags.deep_chain_relu_cells == 200
+    assert flags.lstm_cells == "1024" and flags.lstm_layers == 2 and flags.lstm_attentions == 8
+    assert flags.video_level_classifier_model == "MoeModel" and flags.dbof_cluster_size == 8192
+    assert flags.batch_size == 1024 and flags.base_learning_rate == 0.01 and flags.clip_gradient_norm == 1.0
+    assert flags.learning_rate_decay == 0.95 and flags.learning_rate_decay_examples == 4000000
+    assert flags.label_loss == "CrossEntropyLoss" and flags.num_classes == 4716 and flags.support_loss_percent == 0.1
+    rest = flags.parse(["--moe_num_mixtures=4", "--lstm_cells", "512", "--multitask", "x.txt", "--nolabel_smoothing"])
+    assert flags.moe_num_mixtures == 4 and flags.lstm_cells == "512" and flags.multitask is True and rest == ["x.txt"]
+    with pytest.raises(ValueError):
+        flags.parse(["--no_such_flag=1"])
+
+
+def test_lr_schedule_and_variable_store(flags):
+    import yt8m_amd.train as train
+    from yt8m_amd.variables import Graph, xavier_uniform, zeros, CHUNK
+    assert train.exponential_decay(0.01, 3906, 1024, 4000000, 0.95) == 0.01
+    assert train.exponential_decay(0.01, 3907, 1024, 4000000, 0.95) == pytest.approx(0.0095)
+    g = Graph(device="cpu", seed=1)
+    with g.variable_scope("RNN"):
+        w = g.get_variable("cell/weights", (5000, 3), xavier_uniform, l2=1e-8)
+    b = g.get_variable("experts/biases", (7,), zeros)
+    assert w.name == "RNN/cell/weights" and g.get_variable("experts/biases", (7,)) is b
+    with pytest.raises(ValueError):
+        g.get_variable("experts/biases", (8,))
+    g.begin_step()
+    a0 = g.anonymous_variable((2, 2), zeros)
+    a1 = g.anonymous_variable((3,), zeros)
+    assert (a0.name, a1.name) == ("Variable", "Variable_1")
+    g.begin_step()
+    assert g.anonymous_variable((2, 2), zeros) is a0
+    before = w.data.clone()
+    g.finalize()
+    assert torch.equal(w.data, before) and w.data.data_ptr() == g.params.data_ptr()
+    assert w.offset == 0 and b.offset % 64 == 0 and b.offset >= 15000
+    ch = g.chunks.tolist()
+    assert g.nchunks == 4 + 1 + 1 + 1 and ch[0] == [0, CHUNK, 0, 0] and ch[3] == [3 * CHUNK, 15000 - 3 * CHUNK, 0, 0]
+    assert ch[4] == [b.offset, 7, 1, 0] and g.l2.tolist() == pytest.approx([1e-8, 0, 0, 0])
+    assert w.grad.shape == (5000, 3) and w.grad_beta() == 0.0 and w.grad_beta() == 1.0
+    g.begin_step()
+    assert w.grad_beta() == 0.0
+    with pytest.raises(RuntimeError):
+        g.get_variable("late", (1,))
+    sd = g.state_dict()
+    assert set(sd) == {"RNN/cell/weights", "experts/biases", "Variable", "Variable_1"}
+    lim = (6.0 / (5000 + 3)) ** 0.5
+    assert float(w.data.abs().max()) <= lim and float(w.data.abs().max()) > 0.9 * lim

@@ -1,0 +1,311 @@
+"""-m gpu: parity of every C-ABI kernel (called through the ctypes boundary) against the oracle on seeded
+inputs, including the edge cases the domain has: ragged / empty num_frames, non-multiple-of-tile shapes,
+unaligned leading dimensions, saturated probabilities, ties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+import yt8m_amd.ops as ops
+import yt8m_amd.seq_ops as seq_ops
+import yt8m_amd._lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def D(a, dev, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dtype)
+
+
+def H(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 257, 33), (64, 300, 1152), (257, 129, 100), (3, 4716 * 3, 40)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_all_layouts(dev, M, N, K, tA, tB):
+    rs = np.random.RandomState(M * 7 + N * 3 + K + tA * 2 + tB)
+    A = rs.randn(*((K, M) if tA else (M, K))).astype(np.float32)
+    B = rs.randn(*((N, K) if tB else (K, N))).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    ref = (A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64)
+    scale = np.abs(A).max() * np.abs(B).max() * K
+    C = ops.gemm(D(A, dev), D(B, dev), transA=bool(tA), transB=bool(tB))
+    assert np.abs(H(C) - ref).max() <= 2e-6 * scale
+    C2 = ops.gemm(D(A, dev), D(B, dev), transA=bool(tA), transB=bool(tB), bias=D(bias, dev))
+    assert np.abs(H(C2) - (ref + bias)).max() <= 2e-6 * scale
+    ops.gemm(D(A, dev), D(B, dev), out=C2, transA=bool(tA), transB=bool(tB), beta=1.0)     # accumulate
+    assert np.abs(H(C2) - (2 * ref + bias)).max() <= 4e-6 * scale
+
+
+def test_gemm_strided_views_and_transpose_detection(dev):
+    """Unaligned leading dimensions (scalar-load path) + an A = I check with an ASYMMETRIC B (row/col swap detector)."""
+    rs = np.random.RandomState(0)
+    big = rs.randn(70, 91).astype(np.float32)
+    A = D(big, dev)[3:40, 5:70]                # ld = 91 (odd), offset pointer => unaligned
+    Bm = D(rs.randn(65, 37).astype(np.float32), dev)
+    out = torch.zeros((37, 50), device=dev)[:, 2:39]
+    ops.gemm(A, Bm, out=out)
+    assert np.abs(H(out) - big[3:40, 5:70].astype(np.float64) @ H(Bm)).max() < 1e-4
+    n = 96
+    Bas = np.arange(n * n, dtype=np.float32).reshape(n, n) / 100.0
+    C = ops.gemm(torch.eye(n, device=dev), D(Bas, dev))
+    assert np.array_equal(H(C), Bas.astype(np.float64))
+    # fp32 MFMA is an exact fmaf chain: identity times anything is bit exact, and K-order is sequential
+    C = ops.gemm(D(Bas, dev), torch.eye(n, device=dev), transA=True)
+    assert np.array_equal(H(C), Bas.T.astype(np.float64))
+
+
+def test_gemm_batched(dev):
+    rs = np.random.RandomState(1)
+    A = rs.randn(5, 30, 8).astype(np.float32)       # [b, F, A]
+    X = rs.randn(5, 30, 70).astype(np.float32)      # [b, F, H]
+    C = ops.gemm_batched(D(A, dev), D(X, dev), transA=True)
+    assert np.abs(H(C) - np.einsum("bfa,bfh->bah", A.astype(np.float64), X.astype(np.float64))).max() < 1e-4
+    dC = rs.randn(5, 8, 70).astype(np.float32)
+    dA = ops.gemm_batched(D(X, dev), D(dC, dev), transB=True)
+    assert np.abs(H(dA) - np.einsum("bfh,bah->bfa", X.astype(np.float64), dC.astype(np.float64))).max() < 1e-4
+
+
+def test_gemm_error_paths(dev):
+    a = torch.zeros(4, 4, device=dev)
+    with pytest.raises(ValueError):
+        ops.gemm(a, torch.zeros(5, 4, device=dev))
+    with pytest.raises(ValueError):
+        ops.gemm(a, a, out=torch.zeros(3, 4, device=dev))
+    with pytest.raises(ValueError):
+        ops.gemm(a, a, beta=1.0)
+    assert ops.gemm(torch.zeros(0, 4, device=dev), a).shape == (0, 4)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 8, 16])
+def test_moe_mix_fwd_bwd(dev, M):
+    rs = np.random.RandomState(M)
+    B, V = 7, 53
+    Zg = (rs.randn(B, V * (M + 1)) * 3).astype(np.float32)
+    Ze = (rs.randn(B, V * M) * 3).astype(np.float32)
+    Zg[0, :M + 1] = [80.0] + [-80.0] * M        # saturated softmax / sigmoid
+    Ze[0, :M] = 90.0
+    Ze[1, :M] = -90.0
+    g = np_ref.softmax(Zg.astype(np.float64).reshape(B, V, M + 1), axis=2)
+    e = np_ref.sigmoid(Ze.astype(np.float64).reshape(B, V, M))
+    p_ref = (g[:, :, :M] * e).sum(2)
+    p = ops.moe_mix_fwd(D(Zg, dev), D(Ze, dev), V, M)
+    assert np.abs(H(p) - p_ref).max() < 2e-6
+    dp = rs.randn(B, V).astype(np.float32)
+    epad = np.concatenate([e, np.zeros((B, V, 1))], axis=2)
+    dG = dp[:, :, None] * g * (epad - p_ref[:, :, None])
+    dE = dp[:, :, None] * g[:, :, :M] * e * (1 - e)
+    zg, ze = D(Zg, dev), D(Ze, dev)
+    ops.moe_mix_bwd_(zg, ze, D(dp, dev), V, M)
+    assert np.abs(H(zg) - dG.reshape(B, -1)).max() < 2e-6
+    assert np.abs(H(ze) - dE.reshape(B, -1)).max() < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["sigmoid", "relu", "relu6", "tanh", "elu"])
+def test_activations(dev, kind):
+    x = np.linspace(-9, 9, 1001).astype(np.float32)
+    x64 = x.astype(np.float64)
+    ref = {"sigmoid": 1 / (1 + np.exp(-x64)), "relu": np.maximum(x64, 0), "relu6": np.clip(x64, 0, 6), "tanh": np.tanh(x64),
+           "elu": np.where(x64 > 0, x64, np.exp(np.minimum(x64, 0)) - 1)}[kind]
+    y = ops.act_fwd(kind, D(x, dev))
+    assert np.abs(H(y) - ref).max() < 1e-6
+    dref = {"sigmoid": ref * (1 - ref), "relu": (x64 > 0) * 1.0, "relu6": ((x64 > 0) & (x64 < 6)) * 1.0,
+            "tanh": 1 - ref ** 2, "elu": np.where(x64 > 0, 1.0, ref + 1)}[kind]
+    dx = ops.act_bwd(kind, y, torch.full_like(y, 2.0))
+    assert np.abs(H(dx) - 2 * dref).max() < 1e-5
+
+
+def test_colsum(dev):
+    rs = np.random.RandomState(2)
+    for rows, cols in [(1, 1), (1024, 9432 // 8), (33, 130), (300, 64), (0, 5)]:
+        X = rs.randn(rows, cols).astype(np.float32)
+        out = torch.full((cols,), 5.0, device=dev)
+        ops.colsum(D(X, dev).reshape(rows, cols), out, beta=0.0)
+        assert np.abs(H(out) - X.astype(np.float64).sum(0)).max() < 1e-4
+        ops.colsum(D(X, dev).reshape(rows, cols), out, beta=1.0)
+        assert np.abs(H(out) - 2 * X.astype(np.float64).sum(0)).max() < 2e-4
+
+
+@pytest.mark.parametrize("label_kind", ["bool", "u8", "f32"])
+def test_cross_entropy_fwd_bwd(dev, label_kind):
+    rs = np.random.RandomState(3)
+    B, V = 9, 4716
+    p = (rs.rand(B, V) * 0.98 + 0.01).astype(np.float32)
+    p[0, 0], p[0, 1], p[0, 2], p[0, 3] = 0.0, 1.0, 1.0, 0.0          # eps guards (W/losses.py:115)
+    y = rs.rand(B, V) < 3.4 / V
+    y[0, :4] = [True, True, False, False]
+    w = rs.rand(B).astype(np.float32)
+    if label_kind == "f32":
+        ylab = np_ref.label_smoothing(y, 0.1)
+        yd = D(ylab.astype(np.float32), dev)
+    else:
+        ylab = y
+        yd = torch.from_numpy(y).to(dev) if label_kind == "bool" else torch.from_numpy(y.astype(np.uint8)).to(dev)
+    p64 = p.astype(np.float64)
+    for weights in (None, w):
+        ref = np_ref.cross_entropy_loss(p64, ylab.astype(np.float64), weights)
+        dref = np_ref.cross_entropy_loss_bwd(p64, ylab.astype(np.float64), weights, upstream=0.7)
+        wd = None if weights is None else D(weights, dev)
+        loss, dp = ops.xent_fwd(D(p, dev), yd, wd, want_dp=True, upstream=0.7)
+        assert abs(float(loss) - ref) < 2e-5 * abs(ref)
+        # 1/(p+eps) amplifies fp32 rounding of (p + eps): compare relative to each element
+        assert np.abs(H(dp) - dref).max() <= 2e-5 * np.abs(dref).max()
+        up = torch.tensor([0.35], device=dev)
+        dp2 = ops.xent_bwd(D(p, dev), yd, wd, up, upstream=2.0)
+        assert np.abs(H(dp2) - dref).max() <= 2e-5 * np.abs(dref).max()
+    with pytest.raises(ValueError):
+        ops.xent_fwd(D(p, dev), yd[:, :-1])
+    with pytest.raises(ValueError):
+        ops.xent_fwd(torch.zeros(0, 5, device=dev), torch.zeros(0, 5, device=dev))
+
+
+def test_l2norm_fwd_bwd(dev):
+    rs = np.random.RandomState(4)
+    for rows, cols in [(5, 1152), (3, 7), (64, 128), (2, 73728), (1, 1)]:
+        x = rs.randn(rows, cols).astype(np.float32)
+        if rows > 1:
+            x[1] = 0.0                                 # zero rows stay zero (A.9)
+        dy = rs.randn(rows, cols).astype(np.float32)
+        y = ops.l2norm_fwd(D(x, dev))
+        assert np.abs(H(y) - np_ref.l2_normalize(x.astype(np.float64))).max() < 1e-6
+        dx = ops.l2norm_bwd(D(x, dev), D(dy, dev))
+        ref = np_ref.l2_normalize_bwd(x.astype(np.float64), dy.astype(np.float64))
+        assert np.abs(H(dx) - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_dequant_l2norm(dev):
+    rs = np.random.RandomState(5)
+    B, F, Dm = 4, 12, 1152
+    q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+    q[0, 0] = 0
+    q[0, 1] = 255
+    nf = np.array([12, 1, 7, 0], dtype=np.int32)
+    ref = np_ref.dequant_l2norm_folded(q, nf)
+    x = ops.dequant_l2norm(torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev))
+    assert np.abs(H(x) - ref).max() < 1e-6
+    assert (H(x)[1, 1:] == 0).all() and (H(x)[3] == 0).all()          # padding rows are exactly 0 (readers.py:186)
+    x2 = ops.dequant_l2norm(torch.from_numpy(q).to(dev), None)
+    assert np.abs(H(x2) - np_ref.dequant_l2norm_folded(q)).max() < 1e-6
+    xm = ops.dequant_mean_l2norm(torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev))
+    refm = np.stack([np_ref.l2_normalize(np_ref.dequantize(q[b, :nf[b]]).mean(0)) if nf[b] > 0 else np.zeros(Dm) for b in range(B)])
+    assert np.abs(H(xm) - refm).max() < 1e-6
+    with pytest.raises(TypeError):
+        ops.dequant_l2norm(torch.zeros(2, 3, 4, device=dev))
+
+
+def test_topk_rows(dev):
+    rs = np.random.RandomState(6)
+    B, V = 33, 4716
+    p = rs.rand(B, V).astype(np.float32)
+    p[0, 10] = p[0, 20] = p[0, 5] = 2.0                                # ties -> lower index first
+    vals, idx = ops.topk_rows(D(p, dev), 20)
+    order = np.lexsort((np.arange(V)[None, :].repeat(B, 0), -p), axis=1)[:, :20]
+    assert np.array_equal(idx.cpu().numpy(), order)                    # index selection is integer work: bit exact
+    assert np.array_equal(H(vals), np.take_along_axis(p, order, 1).astype(np.float64))
+    assert idx[0, :3].tolist() == [5, 10, 20]
+    v2, i2 = ops.topk_rows(D(p[:, :7], dev), 20)                       # k > V clamps like eval_util.top_k_triplets
+    assert v2.shape == (B, 7)
+
+
+def test_lstm_layer_fwd_bwd(dev):
+    """Whole-layer recurrence (ragged num_frames incl. 0 and F) vs the oracle, gradients vs torch autograd fp64."""
+    from oracle import torch_ref
+    from yt8m_amd.variables import reset_default_graph, xavier_uniform, zeros
+    rs = np.random.RandomState(7)
+    B, F, Din, Hh = 5, 9, 6, 4
+    x = rs.randn(B, F, Din).astype(np.float32)
+    nf = np.array([9, 1, 4, 0, 9], dtype=np.int32)
+    W = (rs.randn(Din + Hh, 4 * Hh) * 0.4).astype(np.float32)
+    b = (rs.randn(4 * Hh) * 0.1).astype(np.float32)
+    g = reset_default_graph(device=dev)
+    g.begin_step()
+    Wv = g.get_variable("w", W.shape, xavier_uniform)
+    bv = g.get_variable("b", b.shape, zeros)
+    g.finalize()
+    Wv.data.copy_(D(W, dev)); bv.data.copy_(D(b, dev))
+    xt = D(x, dev).transpose(0, 1).contiguous().requires_grad_(True)
+    out, c, h = seq_ops.lstm_layer(xt, Wv, bv, torch.from_numpy(nf).to(dev))
+    ro, fin = np_ref.dynamic_rnn_lstm(x.astype(np.float64), nf, [(W.astype(np.float64), b.astype(np.float64))])
+    assert np.abs(H(out).transpose(1, 0, 2) - ro).max() < 1e-5
+    assert np.abs(H(c) - fin[0][0]).max() < 1e-5 and np.abs(H(h) - fin[0][1]).max() < 1e-5
+    go, gc, gh = rs.randn(F, B, Hh).astype(np.float32), rs.randn(B, Hh).astype(np.float32), rs.randn(B, Hh).astype(np.float32)
+    ((out * D(go, dev)).sum() + (c * D(gc, dev)).sum() + (h * D(gh, dev)).sum()).backward()
+    tx = torch.from_numpy(x.astype(np.float64)).requires_grad_(True)
+    tW = torch.from_numpy(W.astype(np.float64)).requires_grad_(True)
+    tb = torch.from_numpy(b.astype(np.float64)).requires_grad_(True)
+    to, tc, th = torch_ref.lstm_stack(tx, torch.from_numpy(nf), [(tW, tb)])
+    ((to * torch.from_numpy(go.astype(np.float64)).transpose(0, 1)).sum() + (tc[0] * torch.from_numpy(gc.astype(np.float64))).sum()
+     + (th[0] * torch.from_numpy(gh.astype(np.float64))).sum()).backward()
+    assert np.abs(H(Wv.grad) - tW.grad.numpy()).max() < 1e-4
+    assert np.abs(H(bv.grad) - tb.grad.numpy()).max() < 1e-4
+    assert np.abs(H(xt.grad).transpose(1, 0, 2) - tx.grad.numpy()).max() < 1e-4
+
+
+def test_attention_and_assignment_softmax(dev):
+    rs = np.random.RandomState(8)
+    B, F, A = 4, 11, 3
+    act = (rs.randn(B, F, A) * 2).astype(np.float32)
+    nf = np.array([11, 1, 5, 11], dtype=np.int32)
+    mask = (np.arange(F)[None, :] < nf[:, None]).astype(np.float64)
+    sm = np_ref.softmax(act.astype(np.float64), axis=1) * mask[:, :, None]
+    wref = sm / sm.sum(1, keepdims=True)
+    a = D(act, dev).requires_grad_(True)
+    w = seq_ops.attention_weights(a, torch.from_numpy(nf).to(dev))
+    assert np.abs(H(w) - wref).max() < 1e-6
+    dw = rs.randn(B, F, A).astype(np.float32)
+    w.backward(D(dw, dev))
+    ta = torch.from_numpy(act.astype(np.float64)).requires_grad_(True)
+    tw = torch.softmax(ta, 1) * torch.from_numpy(mask)[:, :, None]
+    (tw / tw.sum(1, keepdim=True)).backward(torch.from_numpy(dw.astype(np.float64)))
+    assert np.abs(H(a.grad) - ta.grad.numpy()).max() < 1e-5
+    # num_frames = 0 -> 0/0 = NaN in the reference (no guard): same here
+    w0 = seq_ops.attention_weights(D(act[:1], dev), torch.zeros(1, dtype=torch.int32, device=dev))
+    assert torch.isnan(w0).all()
+    # NetVLAD assignment softmax over K with frame mask
+    K = 64
+    s = (rs.randn(B, F, K) * 3).astype(np.float32)
+    sd = D(s, dev).requires_grad_(True)
+    av = seq_ops.masked_softmax_rows(sd, torch.from_numpy(nf).to(dev))
+    aref = np_ref.softmax(s.astype(np.float64), axis=2) * mask[:, :, None]
+    assert np.abs(H(av) - aref).max() < 1e-6
+    da = rs.randn(B, F, K).astype(np.float32)
+    av.backward(D(da, dev))
+    ts = torch.from_numpy(s.astype(np.float64)).requires_grad_(True)
+    (torch.softmax(ts, 2) * torch.from_numpy(mask)[:, :, None]).backward(torch.from_numpy(da.astype(np.float64)))
+    assert np.abs(H(sd.grad) - ts.grad.numpy()).max() < 1e-5
+
+
+def test_sqnorm_and_adam_multi(dev):
+    """Per-tensor clip on (g*gscale + l2 w) + TF-Adam over the arena vs the oracle, incl. ragged tensor sizes that
+    exercise chunk tails, and bitwise reproducibility of the reduction."""
+    from yt8m_amd.variables import reset_default_graph, random_normal, zeros
+    rs = np.random.RandomState(9)
+    g = reset_default_graph(device=dev, seed=3)
+    g.begin_step()
+    shapes = {"a/weights": (37, 131), "a/biases": (131,), "b/weights": (4097, 3), "c/weights": (1, 1)}
+    vs = {k: g.get_variable(k, s, random_normal(0.5), l2=1e-2 if k.endswith("weights") else 0.0) for k, s in shapes.items()}
+    g.finalize()
+    params = {k: H(v.data) for k, v in vs.items()}
+    state = {}
+    for step in range(3):
+        grads = {k: rs.randn(*s) * (5.0 if step == 0 else 0.01) for k, s in shapes.items()}
+        for k, v in vs.items():
+            v.grad.copy_(D(grads[k] * 2.0, dev))                 # stored as the SUM over 2 ranks; gscale = 1/2
+        lr = np_ref.exponential_decay(0.01, step, 8)
+        t = step + 1
+        ops.sqnorm_and_adam(g, lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t), gscale=0.5, clip=1.0)
+        n1 = g.norms.clone()
+        ops._lib.check(ops._lib.lib().yt8m_sqnorm_multi(ops._p(g.params), ops._p(g.grads), ops._p(g.chunks), g.nchunks,
+                                                          ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 4, ops._stream()))
+        params, state = np_ref.train_step_update(params, grads, state, step, 0.01, 8,
+                                                 {k for k in shapes if k.endswith("weights")}, l2_penalty=1e-2, clip=1.0)
+        for k, v in vs.items():
+            assert np.abs(H(v.data) - params[k]).max() < 2e-6, (step, k)
+    a = g.norms.clone()
+    ops._lib.check(ops._lib.lib().yt8m_sqnorm_multi(ops._p(g.params), ops._p(g.grads), ops._p(g.chunks), g.nchunks,
+                                                      ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 4, ops._stream()))
+    assert torch.equal(a, g.norms)                               # fixed-order reduction: bitwise reproducible

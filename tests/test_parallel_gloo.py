@@ -1,0 +1,112 @@
+"""world_size-2 `gloo` tests (CPU) of the data-parallel path: parameter broadcast, bucketed / overlapped gradient
+all-reduce over the arena, equal sharding, and the SURVEY.md 8e identity "N-rank step on shards == 1-rank step on
+the global batch" (checked with the CPU restatement: mean of per-shard gradients == global-batch gradient)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, overlap, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        __graft_entry__.load_package()
+        from yt8m_amd import parallel
+        from yt8m_amd.variables import Graph, random_normal, zeros
+        from oracle import torch_ref
+        r, w, _ = parallel.init_from_env(backend="gloo")
+        assert (r, w) == (rank, world)
+        g = Graph(device="cpu", seed=100 + rank)               # different init per rank on purpose
+        g.begin_step()
+        shapes = {"gates/weights": (40, 90), "experts/weights": (40, 60), "experts/biases": (60,), "tiny": (3,)}
+        vs = {k: g.get_variable(k, s, random_normal(0.1)) for k, s in shapes.items()}
+        g.finalize()
+        red = parallel.GradReducer(bucket_bytes=4 * 2000, overlap=overlap)
+        red.attach(g)
+        # 1. broadcast: every rank now holds rank 0's parameters
+        ref = Graph(device="cpu", seed=100)
+        ref.begin_step()
+        for k, s in shapes.items():
+            ref.get_variable(k, s, random_normal(0.1))
+        for k in shapes:
+            assert torch.equal(vs[k].data, ref.vars[k].data), k
+        # 2. all-reduce with grad-ready hooks fired in reverse creation order (as backward does)
+        for step in range(2):
+            red.begin_step()
+            for k in reversed(list(shapes)):
+                vs[k].grad.fill_(float(rank + 1) * (step + 1))
+                vs[k].grad_done()
+            gscale = red.finish()
+            assert gscale == 0.5
+            for k in shapes:
+                assert torch.all(vs[k].grad == 3.0 * (step + 1)), (k, vs[k].grad.flatten()[:3])
+        # 3. DP identity on the real math (CPU restatement): mean over ranks of shard gradients == global gradient
+        torch.manual_seed(0)
+        B, Dm, V, M = 8, 12, 10, 2
+        x = torch.randn(B, Dm, dtype=torch.float64)
+        y = torch.rand(B, V) < 0.3
+        P = torch_ref.make_moe_params(Dm, V, M, torch.float64, seed=1)
+        lo, hi = parallel.shard_batch(B, rank, world)
+
+        def grads(xs, ys):
+            Pl = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            torch_ref.cross_entropy(torch_ref.moe(torch_ref.l2_normalize(xs, 1), Pl["gates/weights"], Pl["experts/weights"],
+                                                  Pl["experts/biases"], M), ys).backward()
+            return torch.cat([Pl[k].grad.reshape(-1) for k in sorted(Pl)])
+        gl = grads(x[lo:hi], y[lo:hi])
+        dist.all_reduce(gl)
+        gl *= gscale
+        assert torch.allclose(gl, grads(x, y), atol=1e-12)
+        with pytest.raises(ValueError):
+            parallel.shard_batch(7, rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_gloo(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_single_process_reducer_is_identity():
+    __graft_entry__.load_package()
+    from yt8m_amd import parallel
+    from yt8m_amd.variables import Graph, zeros
+    g = Graph(device="cpu")
+    g.begin_step()
+    v = g.get_variable("w", (4,), zeros)
+    g.finalize()
+    red = parallel.GradReducer()
+    red.attach(g)
+    red.begin_step()
+    v.grad.fill_(2.0)
+    v.grad_done()
+    assert red.finish() == 1.0 and torch.all(v.grad == 2.0)
+    assert parallel.shard_batch(8, 1, 4) == (2, 4)

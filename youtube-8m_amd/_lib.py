@@ -1,0 +1,79 @@
+"""ctypes binding of libyt8m_hip.so (include/yt8m_hip.h).  Fails loudly when the library is missing:
+the product has no CPU / eager-PyTorch fallback for any hot op."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyt8m_hip.so")
+
+c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+P = c_void_p
+
+# name -> (restype, argtypes); one row per function declared in include/yt8m_hip.h
+SIGNATURES = {
+    "yt8m_abi_version": (c_int, []),
+    "yt8m_last_error": (ctypes.c_char_p, []),
+    "yt8m_built_arch": (ctypes.c_char_p, []),
+    "yt8m_prof_enable": (c_int, [c_int]),
+    "yt8m_prof_reset": (c_int, []),
+    "yt8m_prof_get": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
+    "yt8m_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P]),
+    "yt8m_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64,
+                                      P, c_int64, c_int64, c_float, c_int64, P]),
+    "yt8m_l2norm_fwd_f32": (c_int, [P, P, c_int64, c_int64, c_float, P]),
+    "yt8m_l2norm_bwd_f32": (c_int, [P, P, P, c_int64, c_int64, c_float, P]),
+    "yt8m_dequant_l2norm_u8": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_dequant_mean_l2norm_u8": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_moe_mix_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int, P]),
+    "yt8m_moe_mix_bwd": (c_int, [P, P, P, c_int64, c_int64, c_int, P]),
+    "yt8m_act_fwd_f32": (c_int, [c_int, P, P, c_int64, P]),
+    "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),
+    "yt8m_colsum_f32": (c_int, [P, c_int64, c_int64, c_int64, P, c_float, P]),
+    "yt8m_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "yt8m_xent_fwd_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P, P]),
+    "yt8m_xent_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P]),
+    "yt8m_sqnorm_multi": (c_int, [P, P, P, c_int64, P, c_float, P, P, c_int64, P]),
+    "yt8m_adam_multi": (c_int, [P, P, P, P, P, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float, P]),
+    "yt8m_lstm_gates_fwd": (c_int, [P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, c_float, P]),
+    "yt8m_lstm_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, P]),
+    "yt8m_lstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_lstm_layer_bwd": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_attn_softmax_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_attn_softmax_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_softmax_rows_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_softmax_rows_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_topk_rows": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
+}
+
+_lib = None
+
+
+class Yt8mHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Returns the loaded CDLL; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Yt8mHipError(
+                "libyt8m_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C youtube-8m_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+_STATUS = {-1: "YT8M_E_BADARG", -2: "YT8M_E_SHAPE", -3: "YT8M_E_HIP", -4: "YT8M_E_RCCL"}
+
+
+def check(status):
+    if status != 0:
+        msg = lib().yt8m_last_error().decode("utf-8", "replace")
+        exc = ValueError if status in (-1, -2) else Yt8mHipError
+        raise exc("%s: %s" % (_STATUS.get(status, status), msg))

@@ -1,0 +1,89 @@
+// common.h -- shared host-side helpers for libyt8m_hip.so (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/yt8m_hip.h"
+
+namespace yt8m {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+  return code;
+}
+
+#define YT8M_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      snprintf(yt8m::g_err, sizeof(yt8m::g_err), "%s failed: %s (%s:%d)", #expr,          \
+               hipGetErrorString(_e), __FILE__, __LINE__);                                \
+      return YT8M_E_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define YT8M_REQUIRE(cond, code, msg)                                                     \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      snprintf(yt8m::g_err, sizeof(yt8m::g_err), "%s: requirement failed: %s", __func__, msg); \
+      return code;                                                                        \
+    }                                                                                     \
+  } while (0)
+
+// ---- per-family hipEvent profiling (bench.py roofline leg) -----------------------------------
+enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LSTM = 4, F_NETVLAD = 5, F_COUNT = 6 };
+
+struct ProfScope {
+  int fam;
+  hipStream_t s;
+  bool on;
+  hipEvent_t e0, e1;
+  ProfScope(int family, hipStream_t stream);
+  ~ProfScope();
+};
+
+inline hipStream_t as_stream(yt8m_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "launch of %s failed: %s", what, hipGetErrorString(e));
+    return YT8M_E_HIP;
+  }
+  return YT8M_OK;
+}
+
+}  // namespace yt8m
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in all threads
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }

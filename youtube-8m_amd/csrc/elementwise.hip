@@ -1,0 +1,410 @@
+// elementwise.hip -- HBM-bound kernels of the head / loss / input-transform slice (gfx950, wave64).
+// All of them are one pass over their operands with lane-consecutive (coalesced) addressing and
+// wave-shuffle reductions; none is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// MoE mixing: p[b,l] = sum_{m<M} softmax(Zg[b,l,0..M])[m] * sigmoid(Ze[b,l,m])
+// W/all_video_models/moe_model.py:54-64.  One thread per (b,l); a wave touches (M+1)*64 and M*64
+// consecutive floats, so every fetched line is fully used.
+constexpr int MAXM = 16;
+
+template <int MT>
+__global__ __launch_bounds__(256) void moe_mix_fwd_kernel(const float* __restrict__ Zg, const float* __restrict__ Ze,
+                                                          float* __restrict__ p, int64_t BV, int Mrt) {
+  const int M = MT > 0 ? MT : Mrt;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BV) return;
+  const float* g = Zg + i * (M + 1);
+  const float* e = Ze + i * M;
+  float gl[MT > 0 ? MT + 1 : MAXM + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) { gl[m] = g[m]; mx = fmaxf(mx, gl[m]); }
+  float den = 0.f, num = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) {
+    const float ex = expf(gl[m] - mx);
+    den += ex;
+    if (m < M) num += ex * (1.0f / (1.0f + expf(-e[m])));
+  }
+  p[i] = num / den;
+}
+
+// in-place backward: Zg <- dL/dZg, Ze <- dL/dZe  
+template <int MT>
+__global__ __launch_bounds__(256) void moe_mix_bwd_kernel(float* __restrict__ Zg, float* __restrict__ Ze,
+                                                          const float* __restrict__ dp, int64_t BV, int Mrt) {
+  const int M = MT > 0 ? MT : Mrt;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BV) return;
+  float* g = Zg + i * (M + 1);
+  float* e = Ze + i * M;
+  float gs[MT > 0 ? MT + 1 : MAXM + 1], es[MT > 0 ? MT + 1 : MAXM + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) { gs[m] = g[m]; mx = fmaxf(mx, gs[m]); }
+  float den = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) { gs[m] = expf(gs[m] - mx); den += gs[m]; }
+  const float inv = 1.0f / den;
+  float pv = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) {
+    gs[m] *= inv;
+    es[m] = (m < M) ? 1.0f / (1.0f + expf(-e[m])) : 0.f;
+    pv += gs[m] * es[m];
+  }
+  const float d = dp[i];
+#pragma unroll
+  for (int m = 0; m <= M; ++m) {
+    g[m] = d * gs[m] * (es[m] - pv);
+    if (m < M) e[m] = d * gs[m] * es[m] * (1.0f - es[m]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case YT8M_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case YT8M_ACT_RELU: return fmaxf(x, 0.f);
+    case YT8M_ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
+    case YT8M_ACT_TANH: return tanhf(x);
+    default: return x > 0.f ? x : expf(x) - 1.0f;  // ELU
+  }
+}
+__device__ __forceinline__ float act_grad_from_out(int act, float y) {
+  switch (act) {
+    case YT8M_ACT_SIGMOID: return y * (1.0f - y);
+    case YT8M_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case YT8M_ACT_RELU6: return (y > 0.f && y < 6.f) ? 1.f : 0.f;
+    case YT8M_ACT_TANH: return 1.0f - y * y;
+    default: return y > 0.f ? 1.f : y + 1.0f;  // ELU
+  }
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(int act, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = act_apply(act, x[i]);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dx[i] = dy[i] * act_grad_from_out(act, y[i]);
+}
+
+// column sums (bias gradients): 1024 threads = 64 columns x 16 row groups; fixed-order LDS tree => deterministic
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
+                                                      float* __restrict__ out, int accumulate) {
+  __shared__ float red[16][65];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (col < cols) {
+    int64_t r = rg;
+    for (; r + 48 < rows; r += 64) {
+      const float a = X[r * ldx + col], b = X[(r + 16) * ldx + col], d = X[(r + 32) * ldx + col], e = X[(r + 48) * ldx + col];
+      s += (a + b) + (d + e);
+    }
+    for (; r < rows; r += 16) s += X[r * ldx + col];
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && col < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    out[col] = accumulate ? out[col] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CrossEntropyLoss, W/losses.py:110-130 (probability space, eps = 10e-6), fused forward + dL/dp.
+// grid = (ceil(V/1024), B); per-block partial sums -> fixed-order final reduction (deterministic).
+template <typename LT>
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ p, const LT* __restrict__ y,
+                                                   const float* __restrict__ w, float* __restrict__ dp,
+                                                   float* __restrict__ partial, int64_t V, float eps, float dscale,
+                                                   const float* __restrict__ up_dev) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.y;
+  const float wb = w ? w[b] : 1.0f;
+  if (up_dev) dscale *= up_dev[0];
+  const int64_t base = b * V;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t l = (int64_t)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+    if (l < V) {
+      const float pv = p[base + l];
+      const float yv = (float)y[base + l];
+      const float a = pv + eps, c = 1.0f - pv + eps;
+      s -= yv * logf(a) + (1.0f - yv) * logf(c);
+      if (dp) dp[base + l] = -(yv / a - (1.0f - yv) / c) * (wb * dscale);
+    }
+  }
+  if (partial) {
+    s = block_sum_256(s * wb, red);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partial, int64_t n, float scale,
+                                                        float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tf.nn.l2_normalize on the last axis: one wave per row, 4 rows per workgroup.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+                                                         int64_t cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * cols;
+  float ss = 0.f;
+  for (int64_t c = lane; c < cols; c += 64) { const float v = xr[c]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(fmaxf(ss, eps));
+  float* yr = y + row * cols;
+  for (int64_t c = lane; c < cols; c += 64) yr[c] = xr[c] * r;
+}
+
+// dx = r*(dy - y*(y.dy)) if ss > eps else r*dy      
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int64_t rows, int64_t cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * cols;
+  const float* gr = dy + row * cols;
+  float ss = 0.f, xd = 0.f;
+  for (int64_t c = lane; c < cols; c += 64) { const float v = xr[c]; ss += v * v; xd += v * gr[c]; }
+  ss = wave_sum(ss);
+  xd = wave_sum(xd);
+  const float r = rsqrtf(fmaxf(ss, eps));
+  const float k = ss > eps ? xd * r * r : 0.f;  // y.dy * r = (x.dy) r^2 ; applied to x below
+  float* dr = dx + row * cols;
+  for (int64_t c = lane; c < cols; c += 64) dr[c] = r * (gr[c] - xr[c] * k);
+}
+
+// readers.py:178-187 + utils.py:23-38 + default_transformer.py:7: one wave per frame row of raw uint8.
+__global__ __launch_bounds__(256) void dequant_l2norm_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
+                                                             float* __restrict__ x, int64_t B, int64_t F, int64_t D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * F) return;
+  const int64_t b = row / F, f = row - b * F;
+  float* xr = x + row * D;
+  const bool live = nf ? (f < (int64_t)nf[b]) : true;
+  if (!live) {
+    for (int64_t c = lane; c < D; c += 64) xr[c] = 0.f;
+    return;
+  }
+  const uint8_t* qr = q + row * D;
+  const float s = 4.0f / 255.0f, bias = 4.0f / 512.0f - 2.0f;
+  float ss = 0.f;
+  for (int64_t c = lane; c < D; c += 64) { const float v = fmaf((float)qr[c], s, bias); ss += v * v; }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(fmaxf(ss, eps));
+  for (int64_t c = lane; c < D; c += 64) xr[c] = fmaf((float)qr[c], s, bias) * r;
+}
+
+// video-level features: mean over valid frames of the dequantised rows, then L2-normalise.  One workgroup per video.
+__global__ __launch_bounds__(256) void dequant_mean_l2norm_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
+                                                                  float* __restrict__ x, int64_t F, int64_t D, float eps) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.x;
+  const int64_t n = nf ? (int64_t)min((int64_t)nf[b], F) : F;
+  const uint8_t* qb = q + b * F * D;
+  const float s = 4.0f / 255.0f, bias = 4.0f / 512.0f - 2.0f;
+  float ss = 0.f;
+  for (int64_t c = threadIdx.x; c < D; c += 256) {
+    unsigned int acc = 0;
+    for (int64_t f = 0; f < n; ++f) acc += qb[f * D + c];
+    const float mean = n > 0 ? fmaf((float)acc / (float)n, s, bias) : 0.f;
+    x[b * D + c] = mean;
+    ss += mean * mean;
+  }
+  ss = block_sum_256(ss, red);
+  const float r = rsqrtf(fmaxf(ss, eps));
+  for (int64_t c = threadIdx.x; c < D; c += 256) x[b * D + c] *= r;
+}
+
+inline unsigned grid_for(int64_t n, int per_block, int64_t cap = 1 << 20) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+using namespace yt8m;
+
+extern "C" int yt8m_moe_mix_fwd(const float* Zg, const float* Ze, float* p, int64_t B, int64_t V, int M,
+                                yt8m_stream_t stream) {
+  YT8M_REQUIRE(M >= 1 && M <= MAXM, YT8M_E_BADARG, "num_mixtures must be in [1,16]");
+  YT8M_REQUIRE(B >= 0 && V >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(Zg && Ze && p, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t BV = B * V;
+  dim3 grid((unsigned)((BV + 255) / 256)), block(256);
+  switch (M) {
+    case 1: hipLaunchKernelGGL((moe_mix_fwd_kernel<1>), grid, block, 0, s, Zg, Ze, p, BV, M); break;
+    case 2: hipLaunchKernelGGL((moe_mix_fwd_kernel<2>), grid, block, 0, s, Zg, Ze, p, BV, M); break;
+    case 4: hipLaunchKernelGGL((moe_mix_fwd_kernel<4>), grid, block, 0, s, Zg, Ze, p, BV, M); break;
+    case 8: hipLaunchKernelGGL((moe_mix_fwd_kernel<8>), grid, block, 0, s, Zg, Ze, p, BV, M); break;
+    default: hipLaunchKernelGGL((moe_mix_fwd_kernel<0>), grid, block, 0, s, Zg, Ze, p, BV, M); break;
+  }
+  return launch_status("moe_mix_fwd_kernel");
+}
+
+extern "C" int yt8m_moe_mix_bwd(float* Zg, float* Ze, const float* dp, int64_t B, int64_t V, int M,
+                                yt8m_stream_t stream) {
+  YT8M_REQUIRE(M >= 1 && M <= MAXM, YT8M_E_BADARG, "num_mixtures must be in [1,16]");
+  YT8M_REQUIRE(B >= 0 && V >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(Zg && Ze && dp, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t BV = B * V;
+  dim3 grid((unsigned)((BV + 255) / 256)), block(256);
+  switch (M) {
+    case 1: hipLaunchKernelGGL((moe_mix_bwd_kernel<1>), grid, block, 0, s, Zg, Ze, dp, BV, M); break;
+    case 2: hipLaunchKernelGGL((moe_mix_bwd_kernel<2>), grid, block, 0, s, Zg, Ze, dp, BV, M); break;
+    case 4: hipLaunchKernelGGL((moe_mix_bwd_kernel<4>), grid, block, 0, s, Zg, Ze, dp, BV, M); break;
+    case 8: hipLaunchKernelGGL((moe_mix_bwd_kernel<8>), grid, block, 0, s, Zg, Ze, dp, BV, M); break;
+    default: hipLaunchKernelGGL((moe_mix_bwd_kernel<0>), grid, block, 0, s, Zg, Ze, dp, BV, M); break;
+  }
+  return launch_status("moe_mix_bwd_kernel");
+}
+
+extern "C" int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream) {
+  YT8M_REQUIRE(act >= 0 && act <= YT8M_ACT_ELU, YT8M_E_BADARG, "unknown activation");
+  if (n <= 0) return n == 0 ? YT8M_OK : fail(YT8M_E_SHAPE, "yt8m_act_fwd_f32: negative n%s", "");
+  YT8M_REQUIRE(x && y, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, act, x, y, n);
+  return launch_status("act_fwd_kernel");
+}
+
+extern "C" int yt8m_act_bwd_f32(int act, const float* y, const float* dy, float* dx, int64_t n, yt8m_stream_t stream) {
+  YT8M_REQUIRE(act >= 0 && act <= YT8M_ACT_ELU, YT8M_E_BADARG, "unknown activation");
+  if (n <= 0) return n == 0 ? YT8M_OK : fail(YT8M_E_SHAPE, "yt8m_act_bwd_f32: negative n%s", "");
+  YT8M_REQUIRE(y && dy && dx, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, act, y, dy, dx, n);
+  return launch_status("act_bwd_kernel");
+}
+
+extern "C" int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta,
+                               yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0 && ldx >= cols, YT8M_E_SHAPE, "bad shape");
+  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  if (cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(out && (X || rows == 0), YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, s, X, rows, cols, ldx, out,
+                     beta != 0.f ? 1 : 0);
+  return launch_status("colsum_kernel");
+}
+
+extern "C" int64_t yt8m_xent_workspace_bytes(int64_t B, int64_t V) {
+  if (B < 0 || V < 0) return 0;
+  return (int64_t)sizeof(float) * (B * ((V + 1023) / 1024) + 1);
+}
+
+extern "C" int yt8m_xent_fwd_bwd(const float* p, const void* labels, int label_dtype, const float* weights,
+                                 float* loss_out, float* dp, int64_t B, int64_t V, float eps, float upstream,
+                                 void* workspace, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B > 0 && V > 0, YT8M_E_SHAPE, "empty batch: reduce_mean over 0 rows is undefined");
+  YT8M_REQUIRE(B <= 65535, YT8M_E_SHAPE, "B > 65535");
+  YT8M_REQUIRE(p && labels && loss_out && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(label_dtype == YT8M_LABEL_U8 || label_dtype == YT8M_LABEL_F32, YT8M_E_BADARG, "label dtype");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  float* partial = static_cast<float*>(workspace);
+  dim3 grid((unsigned)((V + 1023) / 1024), (unsigned)B), block(256);
+  const float dscale = upstream / (float)B;
+  if (label_dtype == YT8M_LABEL_U8)
+    hipLaunchKernelGGL((xent_kernel<uint8_t>), grid, block, 0, s, p, static_cast<const uint8_t*>(labels), weights, dp,
+                       partial, V, eps, dscale, (const float*)nullptr);
+  else
+    hipLaunchKernelGGL((xent_kernel<float>), grid, block, 0, s, p, static_cast<const float*>(labels), weights, dp, partial,
+                       V, eps, dscale, (const float*)nullptr);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)grid.x * grid.y, 1.0f / (float)B, loss_out);
+  return launch_status("xent_kernel");
+}
+
+extern "C" int yt8m_xent_bwd(const float* p, const void* labels, int label_dtype, const float* weights,
+                             const float* upstream_dev, float* dp, int64_t B, int64_t V, float eps, float upstream,
+                             yt8m_stream_t stream) {
+  YT8M_REQUIRE(B > 0 && V > 0, YT8M_E_SHAPE, "empty batch");
+  YT8M_REQUIRE(B <= 65535, YT8M_E_SHAPE, "B > 65535");
+  YT8M_REQUIRE(p && labels && dp, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(label_dtype == YT8M_LABEL_U8 || label_dtype == YT8M_LABEL_F32, YT8M_E_BADARG, "label dtype");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  dim3 grid((unsigned)((V + 1023) / 1024), (unsigned)B), block(256);
+  const float dscale = upstream / (float)B;
+  if (label_dtype == YT8M_LABEL_U8)
+    hipLaunchKernelGGL((xent_kernel<uint8_t>), grid, block, 0, s, p, static_cast<const uint8_t*>(labels), weights, dp,
+                       (float*)nullptr, V, eps, dscale, upstream_dev);
+  else
+    hipLaunchKernelGGL((xent_kernel<float>), grid, block, 0, s, p, static_cast<const float*>(labels), weights, dp,
+                       (float*)nullptr, V, eps, dscale, upstream_dev);
+  return launch_status("xent_kernel(bwd)");
+}
+
+extern "C" int yt8m_l2norm_fwd_f32(const float* x, float* y, int64_t rows, int64_t cols, float eps, yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (rows * cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(x && y, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, rows, cols, eps);
+  return launch_status("l2norm_fwd_kernel");
+}
+
+extern "C" int yt8m_l2norm_bwd_f32(const float* x, const float* dy, float* dx, int64_t rows, int64_t cols, float eps,
+                                   yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (rows * cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(x && dy && dx, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, dy, dx, rows, cols, eps);
+  return launch_status("l2norm_bwd_kernel");
+}
+
+extern "C" int yt8m_dequant_l2norm_u8(const uint8_t* q, const int32_t* num_frames, float* x, int64_t B, int64_t F,
+                                      int64_t D, float eps, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * D == 0) return YT8M_OK;
+  YT8M_REQUIRE(q && x, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(dequant_l2norm_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, x, B, F, D, eps);
+  return launch_status("dequant_l2norm_kernel");
+}
+
+extern "C" int yt8m_dequant_mean_l2norm_u8(const uint8_t* q, const int32_t* num_frames, float* x, int64_t B, int64_t F,
+                                           int64_t D, float eps, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * D == 0) return YT8M_OK;
+  YT8M_REQUIRE(q && x, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(dequant_mean_l2norm_kernel, dim3((unsigned)B), dim3(256), 0, s, q, num_frames, x, F, D, eps);
+  return launch_status("dequant_mean_l2norm_kernel");
+}

@@ -1,0 +1,244 @@
+"""Frame-level models on [B, F<=300, D] + num_frames; class names, flags and TF variable names mirror
+W/frame_level_models.py + W/all_frame_models/ (W = /root/reference/youtube-8m-wangheda).
+NetVLADModel / GatedNetVLADModel are NOT in the reference; they follow SURVEY.md Appendix B.
+"""
+import math
+
+import torch
+
+from . import models, model_utils, ops, seq_ops, video_level_models
+from .flags import FLAGS, DEFINE_integer, DEFINE_bool, DEFINE_string
+from .variables import get_default_graph, xavier_uniform, zeros, ones, random_normal
+
+# W/frame_level_models.py:20-84 (hot-path subset)
+DEFINE_integer("iterations", 30, "Number of frames per batch for DBoF.")
+DEFINE_bool("dbof_add_batch_norm", True, "Adds batch normalization to the DBoF model.")
+DEFINE_bool("sample_random_frames", True, "If true samples random frames (for frame level models). If false, a random"
+            "sequence of frames is sampled instead.")
+DEFINE_integer("dbof_cluster_size", 8192, "Number of units in the DBoF cluster layer.")
+DEFINE_integer("dbof_hidden_size", 1024, "Number of units in the DBoF hidden layer.")
+DEFINE_string("dbof_pooling_method", "max", "The pooling method used in the DBoF cluster layer. Choices are 'average' and 'max'.")
+DEFINE_string("video_level_classifier_model", "MoeModel", "Some Frame-Level models can be decomposed into a "
+              "generalized pooling operation followed by a classifier layer")
+DEFINE_bool("rnn_swap_memory", False, "If true, swap_memory = True.  (No numerical effect; ignored: 288 GB HBM.)")
+DEFINE_string("lstm_cells", "1024", "Number of LSTM cells.")
+DEFINE_integer("lstm_layers", 2, "Number of LSTM layers.")
+DEFINE_integer("lstm_attentions", 8, "Attention size in lstm_attention_max_pooling_model.")
+DEFINE_bool("is_training", False, "used in batch normalization.")
+# new (Appendix B)
+DEFINE_integer("netvlad_cluster_size", 64, "Number of NetVLAD clusters.")
+DEFINE_integer("netvlad_hidden_size", 1024, "Width of the FC after the VLAD descriptor.")
+DEFINE_bool("netvlad_gating", False, "Context gating after the hidden FC.")
+DEFINE_bool("netvlad_add_batch_norm", False, "Kept False so examples stay independent under data parallelism.")
+
+
+def _head(name=None):
+    return getattr(video_level_models, name or FLAGS.video_level_classifier_model)
+
+
+def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers):
+    """MultiRNNCell([BasicLSTMCell(H, forget_bias=1.0)] * L) under tf.nn.dynamic_rnn inside variable_scope("RNN")
+    (W/all_frame_models/lstm_model.py:34-47).  TF-1.0 variable names:
+    RNN/multi_rnn_cell/cell_<l>/basic_lstm_cell/{weights,biases}.  Returns time-major outputs of the top layer
+    and the per-layer final (c, h)."""
+    g = get_default_graph()
+    x_tm = model_input.transpose(0, 1).contiguous()          # [F,B,D]   (layout glue)
+    finals = []
+    inp = x_tm
+    with g.variable_scope("RNN"):
+        for l in range(number_of_layers):
+            d_in = inp.shape[2]
+            scope = "multi_rnn_cell/cell_%d/basic_lstm_cell" % l
+            W = g.get_variable(scope + "/weights", (d_in + lstm_size, 4 * lstm_size), xavier_uniform)
+            b = g.get_variable(scope + "/biases", (4 * lstm_size,), zeros)
+            inp, c, h = seq_ops.lstm_layer(inp, W, b, num_frames, forget_bias=1.0)
+            finals.append((c, h))
+    return inp, finals
+
+
+class FrameLevelLogisticModel(models.BaseModel):
+    """W/all_frame_models/logistic_model.py:13-46: logistic classifier over the num_frames-average of the frames."""
+
+    def create_model(self, model_input, vocab_size, num_frames, **unused_params):
+        denominators = num_frames.to(torch.float32).unsqueeze(1)
+        avg_pooled = model_input.sum(dim=1) / denominators     # input is data: no gradient flows here
+        output = video_level_models.fully_connected(avg_pooled, vocab_size, "fully_connected", activation="sigmoid",
+                                                    l2_penalty=1e-8)
+        return {"predictions": output}
+
+
+class LstmModel(models.BaseModel):
+    """W/all_frame_models/lstm_model.py:13-57: the head reads the whole final state [c0||h0||c1||h1]
+    (state_is_tuple=False), 4H wide for two layers."""
+
+    def create_model(self, model_input, vocab_size, num_frames, **unused_params):
+        lstm_size = int(FLAGS.lstm_cells)
+        number_of_layers = FLAGS.lstm_layers
+        _, finals = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers)
+        state = torch.cat([t for pair in finals for t in pair], dim=1)
+        return _head()().create_model(model_input=state, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
+
+
+class LstmMemoryModel(models.BaseModel):
+    """W/all_frame_models/lstm_memory_model.py:13-73: the head reads the concatenated c states (2H)."""
+
+    def create_model(self, model_input, vocab_size, num_frames, dropout=False, keep_prob=None, noise_level=None,
+                     **unused_params):
+        if dropout:
+            raise NotImplementedError("DropoutWrapper is out of scope this round (SURVEY.md 8f item 3)")
+        lstm_size = int(FLAGS.lstm_cells)
+        number_of_layers = FLAGS.lstm_layers
+        _, finals = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers)
+        final_state = torch.cat([c for c, _ in finals], dim=1)
+        if noise_level is not None:
+            final_state = final_state + torch.randn_like(final_state) * noise_level
+        return _head()().create_model(model_input=final_state, original_input=model_input, vocab_size=vocab_size,
+                                      num_frames=num_frames, **unused_params)
+
+
+class LstmAttentionMaxPoolingModel(models.BaseModel):
+    """W/all_frame_models/lstm_attention_max_pooling_model.py:10-98: LSTM outputs -> A attention poolings ->
+    MoE per attention -> max over attentions."""
+
+    def create_model(self, model_input, vocab_size, num_frames, num_mixtures=None, l2_penalty=1e-8, sub_scope="",
+                     original_input=None, **unused_params):
+        lstm_size = int(FLAGS.lstm_cells)
+        number_of_layers = FLAGS.lstm_layers
+        num_attentions = FLAGS.lstm_attentions
+        out_tm, _ = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers)
+        outputs = out_tm.transpose(0, 1).contiguous()                               # [B,F,H]
+        attention_activations = video_level_models.fully_connected(
+            torch.cat([model_input, outputs], dim=2), num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
+        attention_weights = seq_ops.attention_weights(attention_activations, num_frames)   # [B,F,A]
+        attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
+        moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")
+        predictions = moe_predictions.view(-1, num_attentions, vocab_size)
+        max_predictions = predictions.max(dim=1).values
+        return {"predictions": max_predictions}
+
+    def sub_moe(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", **unused_params):
+        num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
+        return video_level_models.moe_block(model_input, vocab_size, num_mixtures, l2_penalty,
+                                            "gates-" + sub_scope, "experts-" + sub_scope)
+
+
+def _batch_norm(x, scope, is_training, eps=1e-3, decay=0.999):
+    """slim.batch_norm(center=True, scale=True).  DBoF only -- not on any BASELINE config; the
+    statistics are plain torch reductions (couples the examples of the local batch, like the reference)."""
+    g = get_default_graph()
+    n = x.shape[-1]
+    gamma = g.get_variable(scope + "/gamma", (n,), ones)
+    beta = g.get_variable(scope + "/beta", (n,), zeros)
+    mm = g.get_variable(scope + "/moving_mean", (n,), zeros, trainable=False)
+    mv = g.get_variable(scope + "/moving_variance", (n,), ones, trainable=False)
+    return _BatchNorm.apply(x, ops._token(g), gamma, beta, mm, mv, is_training, eps, decay)
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, gamma, beta, mm, mv, is_training, eps, decay):
+        if is_training:
+            mu, var = x.mean(0), x.var(0, unbiased=False)
+            mm.data.mul_(decay).add_(mu, alpha=1 - decay)
+            mv.data.mul_(decay).add_(var, alpha=1 - decay)
+        else:
+            mu, var = mm.data, mv.data
+        rstd = torch.rsqrt(var + eps)
+        xhat = (x - mu) * rstd
+        ctx.save_for_backward(xhat, rstd)
+        ctx.vars = (gamma, beta, is_training)
+        return xhat * gamma.data + beta.data
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd = ctx.saved_tensors
+        gamma, beta, is_training = ctx.vars
+        if gamma.grad is not None:
+            gg = (dy * xhat).sum(0)
+            gamma.grad.copy_(gg) if gamma.grad_beta() == 0.0 else gamma.grad.add_(gg)
+        if beta.grad is not None:
+            gb = dy.sum(0)
+            beta.grad.copy_(gb) if beta.grad_beta() == 0.0 else beta.grad.add_(gb)
+        dxhat = dy * gamma.data
+        if is_training:
+            dx = rstd * (dxhat - dxhat.mean(0) - xhat * (dxhat * xhat).mean(0))
+        else:
+            dx = dxhat * rstd
+        return dx, None, None, None, None, None, None, None, None
+
+
+class DbofModel(models.BaseModel):
+    """W/all_frame_models/dbof_model.py:13-124: sample frames -> cluster FC -> (BN) -> relu6 -> pool over frames ->
+    hidden FC -> (BN) -> relu6 -> head.  Weight variables are anonymous tf.Variable()s in the reference."""
+
+    def create_model(self, model_input, vocab_size, num_frames, iterations=None, add_batch_norm=None,
+                     sample_random_frames=None, cluster_size=None, hidden_size=None, is_training=True,
+                     **unused_params):
+        iterations = iterations or FLAGS.iterations
+        add_batch_norm = add_batch_norm or FLAGS.dbof_add_batch_norm
+        random_frames = sample_random_frames or FLAGS.sample_random_frames
+        cluster_size = cluster_size or FLAGS.dbof_cluster_size
+        hidden1_size = hidden_size or FLAGS.dbof_hidden_size
+        g = get_default_graph()
+        nf = num_frames.to(torch.float32).unsqueeze(1)
+        if random_frames:
+            model_input = model_utils.SampleRandomFrames(model_input, nf, iterations)
+        else:
+            model_input = model_utils.SampleRandomSequence(model_input, nf, iterations)
+        max_frames, feature_size = model_input.shape[1], model_input.shape[2]
+        reshaped_input = model_input.reshape(-1, feature_size)
+        if add_batch_norm:
+            reshaped_input = _batch_norm(reshaped_input, "input_bn", is_training)
+        cluster_weights = g.anonymous_variable((feature_size, cluster_size), random_normal(1 / math.sqrt(feature_size)))
+        if add_batch_norm:
+            activation = ops.linear(reshaped_input, cluster_weights)
+            activation = _batch_norm(activation, "cluster_bn", is_training)
+        else:
+            cluster_biases = g.anonymous_variable((cluster_size,), random_normal(1 / math.sqrt(feature_size)))
+            activation = ops.linear(reshaped_input, cluster_weights, cluster_biases)
+        activation = ops.activation(activation, "relu6")
+        activation = activation.view(-1, max_frames, cluster_size)
+        activation = model_utils.FramePooling(activation, FLAGS.dbof_pooling_method)
+        hidden1_weights = g.anonymous_variable((cluster_size, hidden1_size), random_normal(1 / math.sqrt(cluster_size)))
+        if add_batch_norm:
+            activation = ops.linear(activation, hidden1_weights)
+            activation = _batch_norm(activation, "hidden1_bn", is_training)
+        else:
+            hidden1_biases = g.anonymous_variable((hidden1_size,), random_normal(0.01))
+            activation = ops.linear(activation, hidden1_weights, hidden1_biases)
+        activation = ops.activation(activation, "relu6")
+        return _head()().create_model(model_input=activation, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
+
+
+class NetVLADModel(models.BaseModel):
+    """soft-assignment + residual aggregation + intra-norm + L2 + hidden FC (+ context gating)."""
+    gating = None
+
+    def create_model(self, model_input, vocab_size, num_frames, cluster_size=None, hidden_size=None, gating=None,
+                     **unused_params):
+        K = cluster_size or FLAGS.netvlad_cluster_size
+        Hfc = hidden_size or FLAGS.netvlad_hidden_size
+        gating = (self.gating if self.gating is not None else FLAGS.netvlad_gating) if gating is None else gating
+        g = get_default_graph()
+        B, F, D = model_input.shape
+        Wc = g.get_variable("netvlad/cluster_weights", (D, K), random_normal(1 / math.sqrt(D)))
+        bc = g.get_variable("netvlad/cluster_biases", (K,), zeros)
+        centres = g.get_variable("netvlad/centres", (K, D), random_normal(1 / math.sqrt(D)))
+        s = ops.linear(model_input, Wc, bc)                               # [B,F,K] assignment logits
+        a = seq_ops.masked_softmax_rows(s, num_frames)                    # softmax_k * mask
+        agg = seq_ops.pool_tn(a, model_input)                             # [B,K,D] = a^T x per video
+        vlad = seq_ops.vlad_residual(agg, a, centres)                     # - n * c
+        vlad = ops.l2_normalize(vlad)                                     # intra-normalisation (per cluster)
+        v = ops.l2_normalize(vlad.reshape(B, K * D))
+        h = video_level_models.fully_connected(v, Hfc, "netvlad/hidden")
+        if gating:
+            gate = video_level_models.fully_connected(h, Hfc, "netvlad/gating", activation="sigmoid")
+            h = h * gate
+        return _head()().create_model(model_input=h, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
+
+
+class GatedNetVLADModel(NetVLADModel):
+    gating = True

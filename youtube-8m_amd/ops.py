@@ -1,0 +1,384 @@
+"""Thin Python wrappers + autograd plumbing over the C ABI (include/yt8m_hip.h).
+
+torch is used for device memory, streams and the autograd tape only; every FLOP of the hot path is a
+HIP kernel in libyt8m_hip.so.  No op has a CPU / eager fallback: host tensors raise.
+
+Gradient routing: parameters are NOT autograd leaves.  Each op's backward writes dW directly into the
+variable's slice of the gradient arena (GEMM beta = 0 on first write, 1 afterwards) and returns None for
+it.  A dummy requires-grad scalar (``graph.token``) is threaded through every op so that backward runs
+even when the op's data input is plain data (first layer).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .variables import get_default_graph
+
+ACT = {"sigmoid": 0, "relu": 1, "relu6": 2, "tanh": 3, "elu": 4}
+XENT_EPS = 10e-6  # W/losses.py:115
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.Yt8mHipError("yt8m_amd ops run on the MI355X only (got a %s tensor); there is no CPU fallback"
+                                    % t.device.type)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rowmajor2d(t):
+    """Accepts 2-D tensors whose inner stride is 1 (row-major with an arbitrary leading dimension)."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D tensor")
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    if ld < t.shape[1]:
+        t = t.contiguous()
+        ld = t.shape[1]
+    return t, ld
+
+
+# ------------------------------------------------------------------------------------------ raw kernels
+def gemm(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
+    """out[M,N] = op(A) . op(B) (+ bias) (+ out if beta == 1).  yt8m_gemm_f32."""
+    _dev(A, B, out, bias)
+    A, lda = _rowmajor2d(A)
+    B, ldb = _rowmajor2d(B)
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if transB else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, K2))
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an output tensor")
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if out.dtype != torch.float32 or out.dim() != 2 or tuple(out.shape) != (M, N) or (out.stride(1) != 1 and N != 1):
+        raise ValueError("gemm: bad output tensor")
+    ldc = out.stride(0) if M > 1 else max(N, 1)
+    if bias is not None:
+        bias = _f32c(bias)
+        if bias.numel() != N:
+            raise ValueError("bias size mismatch")
+    _lib.check(_lib.lib().yt8m_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
+                                        _p(bias), float(beta), _stream()))
+    return out
+
+
+def gemm_batched(A, B, out=None, transA=False, transB=False, beta=0.0):
+    """Batched over dim 0 of 3-D contiguous tensors.  yt8m_gemm_f32_batched."""
+    _dev(A, B, out)
+    A, B = _f32c(A), _f32c(B)
+    nb = A.shape[0]
+    M, K = (A.shape[2], A.shape[1]) if transA else (A.shape[1], A.shape[2])
+    K2, N = (B.shape[2], B.shape[1]) if transB else (B.shape[1], B.shape[2])
+    if K != K2 or B.shape[0] != nb:
+        raise ValueError("gemm_batched: shape mismatch")
+    if out is None:
+        out = torch.empty((nb, M, N), dtype=torch.float32, device=A.device)
+    if not out.is_contiguous() or tuple(out.shape) != (nb, M, N):
+        raise ValueError("gemm_batched: bad output tensor")
+    _lib.check(_lib.lib().yt8m_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), A.shape[2], A.shape[1] * A.shape[2],
+                                                _p(B), B.shape[2], B.shape[1] * B.shape[2], _p(out), N, M * N,
+                                                float(beta), nb, _stream()))
+    return out
+
+
+def colsum(X, out, beta=0.0):
+    _dev(X, out)
+    X, ld = _rowmajor2d(X)
+    _lib.check(_lib.lib().yt8m_colsum_f32(_p(X), X.shape[0], X.shape[1], ld, _p(out), float(beta), _stream()))
+    return out
+
+
+def act_fwd(kind, x):
+    _dev(x)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().yt8m_act_fwd_f32(ACT[kind], _p(x), _p(y), x.numel(), _stream()))
+    return y
+
+
+def act_bwd(kind, y, dy):
+    _dev(y, dy)
+    y, dy = _f32c(y), _f32c(dy)
+    dx = torch.empty_like(y)
+    _lib.check(_lib.lib().yt8m_act_bwd_f32(ACT[kind], _p(y), _p(dy), _p(dx), y.numel(), _stream()))
+    return dx
+
+
+def l2norm_fwd(x, eps=1e-12):
+    _dev(x)
+    x = _f32c(x)
+    cols = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().yt8m_l2norm_fwd_f32(_p(x), _p(y), x.numel() // max(cols, 1), cols, eps, _stream()))
+    return y
+
+
+def l2norm_bwd(x, dy, eps=1e-12):
+    _dev(x, dy)
+    x, dy = _f32c(x), _f32c(dy)
+    cols = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().yt8m_l2norm_bwd_f32(_p(x), _p(dy), _p(dx), x.numel() // max(cols, 1), cols, eps, _stream()))
+    return dx
+
+
+def dequant_l2norm(q, num_frames=None, eps=1e-12):
+    """uint8 [B,F,D] -> float32 [B,F,D]: dequantise, zero the padding rows, L2-normalise each frame."""
+    _dev(q, num_frames)
+    if q.dtype != torch.uint8 or q.dim() != 3:
+        raise TypeError("expected uint8 [B,F,D]")
+    q = q.contiguous()
+    B, F, D = q.shape
+    x = torch.empty((B, F, D), dtype=torch.float32, device=q.device)
+    nf = None if num_frames is None else num_frames.to(torch.int32).contiguous()
+    _lib.check(_lib.lib().yt8m_dequant_l2norm_u8(_p(q), _p(nf), _p(x), B, F, D, eps, _stream()))
+    return x
+
+
+def dequant_mean_l2norm(q, num_frames=None, eps=1e-12):
+    """uint8 [B,F,D] -> float32 [B,D]: mean of the dequantised valid frames, L2-normalised."""
+    _dev(q, num_frames)
+    if q.dtype != torch.uint8 or q.dim() != 3:
+        raise TypeError("expected uint8 [B,F,D]")
+    q = q.contiguous()
+    B, F, D = q.shape
+    x = torch.empty((B, D), dtype=torch.float32, device=q.device)
+    nf = None if num_frames is None else num_frames.to(torch.int32).contiguous()
+    _lib.check(_lib.lib().yt8m_dequant_mean_l2norm_u8(_p(q), _p(nf), _p(x), B, F, D, eps, _stream()))
+    return x
+
+
+def moe_mix_fwd(Zg, Ze, V, M):
+    _dev(Zg, Ze)
+    B = Zg.shape[0]
+    p = torch.empty((B, V), dtype=torch.float32, device=Zg.device)
+    _lib.check(_lib.lib().yt8m_moe_mix_fwd(_p(Zg), _p(Ze), _p(p), B, V, M, _stream()))
+    return p
+
+
+def moe_mix_bwd_(Zg, Ze, dp, V, M):
+    _dev(Zg, Ze, dp)
+    dp = _f32c(dp)
+    _lib.check(_lib.lib().yt8m_moe_mix_bwd(_p(Zg), _p(Ze), _p(dp), Zg.shape[0], V, M, _stream()))
+    return Zg, Ze
+
+
+def _labels_arg(labels):
+    if labels.dtype == torch.bool:
+        labels = labels.view(torch.uint8)
+    if labels.dtype == torch.uint8:
+        return labels.contiguous(), 0
+    if labels.dtype == torch.float32:
+        return labels.contiguous(), 1
+    raise TypeError("labels must be bool / uint8 / float32, got %s" % labels.dtype)
+
+
+def xent_fwd(p, labels, weights=None, want_dp=False, eps=XENT_EPS, upstream=1.0):
+    _dev(p, labels, weights)
+    p = _f32c(p)
+    B, V = p.shape
+    lab, ldt = _labels_arg(labels)
+    if tuple(lab.shape) != (B, V):
+        raise ValueError("labels shape %s != predictions shape %s" % (tuple(lab.shape), (B, V)))
+    L = _lib.lib()
+    ws = torch.empty((L.yt8m_xent_workspace_bytes(B, V) + 3) // 4, dtype=torch.float32, device=p.device)
+    loss = torch.empty((), dtype=torch.float32, device=p.device)
+    dp = torch.empty_like(p) if want_dp else None
+    w = None if weights is None else _f32c(weights)
+    _lib.check(L.yt8m_xent_fwd_bwd(_p(p), _p(lab), ldt, _p(w), _p(loss), _p(dp), B, V, eps, upstream, _p(ws), _stream()))
+    return loss, dp
+
+
+def xent_bwd(p, labels, weights, upstream_dev, eps=XENT_EPS, upstream=1.0):
+    _dev(p, labels, weights, upstream_dev)
+    p = _f32c(p)
+    B, V = p.shape
+    lab, ldt = _labels_arg(labels)
+    dp = torch.empty_like(p)
+    w = None if weights is None else _f32c(weights)
+    up = None if upstream_dev is None else _f32c(upstream_dev)
+    _lib.check(_lib.lib().yt8m_xent_bwd(_p(p), _p(lab), ldt, _p(w), _p(up), _p(dp), B, V, eps, upstream, _stream()))
+    return dp
+
+
+def topk_rows(p, k=20):
+    _dev(p)
+    p = _f32c(p)
+    B, V = p.shape
+    k = min(k, V)
+    vals = torch.empty((B, k), dtype=torch.float32, device=p.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=p.device)
+    _lib.check(_lib.lib().yt8m_topk_rows(_p(p), B, V, k, _p(vals), _p(idx), _stream()))
+    return vals, idx
+
+
+def sqnorm_and_adam(graph, lr_t, gscale=1.0, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Per-tensor clip + TF-Adam over the whole arena (two multi-tensor passes)."""
+    _dev(graph.params)
+    L = _lib.lib()
+    s = _stream()
+    if clip > 0:
+        _lib.check(L.yt8m_sqnorm_multi(_p(graph.params), _p(graph.grads), _p(graph.chunks), graph.nchunks, _p(graph.l2),
+                                       gscale, _p(graph.partial), _p(graph.norms), len(graph.trainable_variables()), s))
+    _lib.check(L.yt8m_adam_multi(_p(graph.params), _p(graph.adam_m), _p(graph.adam_v), _p(graph.grads), _p(graph.chunks),
+                                 graph.nchunks, _p(graph.l2), gscale, _p(graph.norms), clip, lr_t, beta1, beta2, eps, s))
+
+
+# ------------------------------------------------------------------------------------------ autograd ops
+def _token(graph=None):
+    g = graph or get_default_graph()
+    if g.token is None:
+        g.begin_step()
+    return g.token
+
+
+class _Linear(torch.autograd.Function):
+    """y = x.W (+ b) for a 2-D x.  slim.fully_connected without activation."""
+
+    @staticmethod
+    def forward(ctx, x, token, W, b):
+        x2 = _f32c(x)
+        y = gemm(x2, W.data, bias=None if b is None else b.data)
+        ctx.save_for_backward(x2)
+        ctx.W, ctx.b = W, b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        dy = _f32c(dy)
+        if W.trainable and W.grad is not None:
+            gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta())
+        if b is not None and b.trainable and b.grad is not None:
+            colsum(dy, b.grad.view(-1), beta=b.grad_beta())
+        dx = gemm(dy, W.data, transB=True) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None
+
+
+def linear(x, W, b=None):
+    """Rank-N input is flattened on the leading dims like slim.fully_connected."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), _token(W._graph), W, b)
+    return y.view(*lead, y.shape[-1])
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        y = act_fwd(kind, x)
+        ctx.kind = kind
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return act_bwd(ctx.kind, y, dy), None
+
+
+def activation(x, kind):
+    return _Act.apply(x, kind)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _f32c(x)
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return l2norm_fwd(x, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return l2norm_bwd(x, dy, ctx.eps), None
+
+
+def l2_normalize(x, eps=1e-12):
+    """tf.nn.l2_normalize on the last axis (differentiable)."""
+    return _L2Norm.apply(x, eps)
+
+
+class _MoeHead(torch.autograd.Function):
+    """MoE block of W/all_video_models/moe_model.py:40-64: two GEMMs + mixing kernel; backward per Appendix G."""
+
+    @staticmethod
+    def forward(ctx, x, token, Wg, We, be, V, M):
+        x2 = _f32c(x)
+        Zg = gemm(x2, Wg.data)
+        Ze = gemm(x2, We.data, bias=be.data)
+        p = moe_mix_fwd(Zg, Ze, V, M)
+        ctx.save_for_backward(x2)
+        ctx.Z = (Zg, Ze)
+        ctx.vars = (Wg, We, be)
+        ctx.VM = (V, M)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (x,) = ctx.saved_tensors
+        Zg, Ze = ctx.Z
+        Wg, We, be = ctx.vars
+        V, M = ctx.VM
+        ctx.Z = None
+        moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
+        if Wg.grad is not None:
+            gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta())
+            Wg.grad_done()
+        if We.grad is not None:
+            gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta())
+            We.grad_done()
+        if be.grad is not None:
+            colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
+            be.grad_done()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(Zg, Wg.data, transB=True)
+            gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
+        return dx, None, None, None, None, None, None
+
+
+def moe_head(x, Wg, We, be, vocab_size, num_mixtures):
+    return _MoeHead.apply(x, _token(Wg._graph), Wg, We, be, vocab_size, num_mixtures)
+
+
+class _Xent(torch.autograd.Function):
+    """CrossEntropyLoss (W/losses.py:110-130); backward recomputes dL/dp from (p, y) with the upstream scalar read
+    on the device, so no host sync and no extra elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, p, labels, weights, scale):
+        loss, _ = xent_fwd(p, labels, weights, want_dp=False, upstream=1.0)
+        ctx.save_for_backward(p)
+        ctx.labels, ctx.weights, ctx.scale = labels, weights, scale
+        return loss * scale if scale != 1.0 else loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (p,) = ctx.saved_tensors
+        dp = xent_bwd(p, ctx.labels, ctx.weights, dloss.reshape(1), upstream=ctx.scale)
+        return dp, None, None, None
+
+
+def cross_entropy(p, labels, weights=None, scale=1.0):
+    return _Xent.apply(p, labels, weights, float(scale))

@@ -1,0 +1,116 @@
+"""Synchronous data parallelism: one process per GPU, batch sharded on dim 0, parameters replicated, gradients
+summed with RCCL (torch.distributed backend "nccl" on ROCm) over xGMI; the 1/world mean is folded into the
+fused clip+Adam pass (gscale), so the reduced arena is consumed in place.
+
+The reference has no synchronous mode (async parameter server over gRPC, W/train.py:624-639,731-776;
+SURVEY.md 2.3); SURVEY.md 8e defines this replacement: the N-rank step on shards of a global batch equals the
+1-rank step on the whole batch (mean-of-means with equal shards), and the LR staircase uses the GLOBAL batch.
+
+Overlap: ops call Variable.grad_done() as soon as a parameter's gradient slice is final; contiguous finished
+slices are all-reduced asynchronously (bucketed, >= bucket_bytes) while backward continues.  xGMI is point-to-point
+(7 links x ~153 GB/s per GPU), so few large messages beat many small ones: default bucket 32 MiB.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract); returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(n_global, rank, world):
+    """Rows [lo, hi) of the global batch owned by `rank` (equal shards)."""
+    if n_global % world != 0:
+        raise ValueError("global batch %d is not divisible by world size %d" % (n_global, world))
+    per = n_global // world
+    return rank * per, (rank + 1) * per
+
+
+class GradReducer(object):
+    """All-reduces the gradient arena of a variables.Graph; SUM over ranks, mean applied later via gscale."""
+
+    def __init__(self, group=None, bucket_bytes=32 << 20, overlap=True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.overlap = overlap
+        self.graph = None
+        self._handles = []
+        self._ready = None
+        self._launched = None
+
+    def attach(self, graph):
+        """Hooks the graph and makes every rank start from rank 0's parameters."""
+        self.graph = graph
+        graph.grad_ready_hook = self._on_ready if (self.overlap and self.world > 1) else None
+        if self.world > 1:
+            dist.broadcast(graph.params, src=0, group=self.group)
+        nv = len(graph.trainable_variables())
+        self._ready = [False] * nv
+        self._launched = [False] * nv
+
+    def begin_step(self):
+        self._handles = []
+        for i in range(len(self._ready)):
+            self._ready[i] = False
+            self._launched[i] = False
+
+    def _span(self, i, j):
+        tv = self.graph.trainable_variables()
+        lo = tv[i].offset
+        hi = tv[j].offset + tv[j].numel()
+        return lo, hi
+
+    def _on_ready(self, var):
+        """Marks var ready; launches an async all-reduce for every maximal run of ready, unlaunched, adjacent
+        variables whose size reaches the bucket threshold."""
+        self._ready[var.index] = True
+        self._flush(final=False)
+
+    def _flush(self, final):
+        n = len(self._ready)
+        i = 0
+        while i < n:
+            if self._launched[i] or not (self._ready[i] or final):
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and not self._launched[j + 1] and (self._ready[j + 1] or final):
+                j += 1
+            lo, hi = self._span(i, j)
+            if final or hi - lo >= self.bucket_elems:
+                # split very large runs so that several rings/links are in flight
+                pos = lo
+                while pos < hi:
+                    end = min(hi, pos + 4 * self.bucket_elems)
+                    h = dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._handles.append(h)
+                    pos = end
+                for k in range(i, j + 1):
+                    self._launched[k] = True
+            i = j + 1
+
+    def finish(self):
+        """Blocks (stream-wise) until every gradient is reduced; returns gscale = 1/world."""
+        if self.world > 1:
+            self._flush(final=True)
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+        return 1.0 / self.world

@@ -1,0 +1,190 @@
+"""Frame-axis autograd ops over the C ABI: BasicLSTM layer (whole recurrence in one call), attention weights,
+NetVLAD assignment / aggregation, batched pooling GEMMs.  See include/yt8m_hip.h for the kernel contracts."""
+import torch
+
+from . import _lib, ops
+from .ops import _p, _stream, _dev, _f32c, _token
+
+
+def _nf(num_frames):
+    return None if num_frames is None else num_frames.to(torch.int32).contiguous()
+
+
+class _LstmLayer(torch.autograd.Function):
+    """One BasicLSTMCell layer under tf.nn.dynamic_rnn, time-major.
+
+    x_tm [F,B,in]; W "weights" [in+H, 4H] (rows 0..in-1 act on x_t, the rest on h); b "biases" [4H].
+    Returns (out_tm [F,B,H], c_final [B,H], h_final [B,H]).  Forward = one hoisted input GEMM over all steps +
+    yt8m_lstm_layer_fwd; backward = yt8m_lstm_layer_bwd + four hoisted GEMMs / column sums."""
+
+    @staticmethod
+    def forward(ctx, x_tm, token, W, b, num_frames, forget_bias):
+        x_tm = _f32c(x_tm)
+        _dev(x_tm)
+        F, B, Din = x_tm.shape
+        H = W.data.shape[1] // 4
+        assert W.data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
+        z = torch.empty((F, B, 4 * H), dtype=torch.float32, device=x_tm.device)
+        ops.gemm(x_tm.view(F * B, Din), W.data[:Din], out=z.view(F * B, 4 * H), bias=b.data)
+        cs = torch.empty((F + 1, B, H), dtype=torch.float32, device=x_tm.device)
+        hs = torch.empty((F + 1, B, H), dtype=torch.float32, device=x_tm.device)
+        cs[0].zero_()
+        hs[0].zero_()
+        out = torch.empty((F, B, H), dtype=torch.float32, device=x_tm.device)
+        nf = _nf(num_frames)
+        Wh = W.data[Din:]
+        _lib.check(_lib.lib().yt8m_lstm_layer_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nf), F, B, H,
+                                                  float(forget_bias), _stream()))
+        ctx.save_for_backward(x_tm)
+        ctx.state = (z, cs, hs, nf, W, b)
+        ctx.set_materialize_grads(False)
+        return out, cs[F], hs[F]
+
+    @staticmethod
+    def backward(ctx, dout, dc_final, dh_final):
+        (x_tm,) = ctx.saved_tensors
+        gates, cs, hs, nf, W, b = ctx.state
+        ctx.state = None
+        F, B, Din = x_tm.shape
+        H = W.data.shape[1] // 4
+        dev = x_tm.device
+        dz = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
+        work = torch.empty((4, B, H), dtype=torch.float32, device=dev)
+        dout = None if dout is None else _f32c(dout)
+        dc_final = None if dc_final is None else _f32c(dc_final)
+        dh_final = None if dh_final is None else _f32c(dh_final)
+        Wh = W.data[Din:]
+        _lib.check(_lib.lib().yt8m_lstm_layer_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dc_final), _p(dh_final),
+                                                  _p(dz), _p(work), _p(nf), F, B, H, _stream()))
+        dz2 = dz.view(F * B, 4 * H)
+        if W.grad is not None:
+            beta = W.grad_beta()
+            ops.gemm(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=beta)
+            ops.gemm(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=beta)
+            W.grad_done()
+        if b.grad is not None:
+            ops.colsum(dz2, b.grad.view(-1), beta=b.grad_beta())
+            b.grad_done()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dz2, W.data[:Din], transB=True).view(F, B, Din)
+        return dx, None, None, None, None, None
+
+
+def lstm_layer(x_tm, W, b, num_frames, forget_bias=1.0):
+    return _LstmLayer.apply(x_tm, _token(W._graph), W, b, num_frames, forget_bias)
+
+
+class _AttnSoftmax(torch.autograd.Function):
+    """mask * softmax over frames, renormalised (lstm_attention_max_pooling_model.py:59-60).  act, w: [B,F,A]."""
+
+    @staticmethod
+    def forward(ctx, act, num_frames):
+        act = _f32c(act)
+        _dev(act)
+        B, F, A = act.shape
+        w = torch.empty_like(act)
+        nf = _nf(num_frames)
+        _lib.check(_lib.lib().yt8m_attn_softmax_fwd(_p(act), _p(nf), _p(w), B, F, A, _stream()))
+        ctx.save_for_backward(w)
+        ctx.nf = nf
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (w,) = ctx.saved_tensors
+        dw = _f32c(dw)
+        B, F, A = w.shape
+        dact = torch.empty_like(w)
+        _lib.check(_lib.lib().yt8m_attn_softmax_bwd(_p(w), _p(dw), _p(ctx.nf), _p(dact), B, F, A, _stream()))
+        return dact, None
+
+
+def attention_weights(act, num_frames):
+    return _AttnSoftmax.apply(act, num_frames)
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    """a = softmax over the last axis, zeroed on padding frames (NetVLAD assignment)."""
+
+    @staticmethod
+    def forward(ctx, s, num_frames):
+        s = _f32c(s)
+        _dev(s)
+        B, F, K = s.shape
+        a = torch.empty_like(s)
+        nf = _nf(num_frames)
+        _lib.check(_lib.lib().yt8m_softmax_rows_fwd(_p(s), _p(nf), _p(a), B, F, K, _stream()))
+        ctx.save_for_backward(a)
+        ctx.nf = nf
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (a,) = ctx.saved_tensors
+        da = _f32c(da)
+        B, F, K = a.shape
+        ds = torch.empty_like(a)
+        _lib.check(_lib.lib().yt8m_softmax_rows_bwd(_p(a), _p(da), _p(ctx.nf), _p(ds), B, F, K, _stream()))
+        return ds, None
+
+
+def masked_softmax_rows(s, num_frames):
+    return _SoftmaxRows.apply(s, num_frames)
+
+
+class _PoolTN(torch.autograd.Function):
+    """C[b] = w[b]^T . x[b]   (w [B,F,A], x [B,F,H] -> [B,A,H]): attention pooling
+    (lstm_attention_max_pooling_model.py:63) and NetVLAD aggregation (Appendix B) as one batched GEMM."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        w, x = _f32c(w), _f32c(x)
+        ctx.save_for_backward(w, x)
+        return ops.gemm_batched(w, x, transA=True)
+
+    @staticmethod
+    def backward(ctx, dC):
+        w, x = ctx.saved_tensors
+        dC = _f32c(dC)
+        dw = ops.gemm_batched(x, dC, transB=True) if ctx.needs_input_grad[0] else None   # [F,H].[H,A]
+        dx = ops.gemm_batched(w, dC) if ctx.needs_input_grad[1] else None                # [F,A].[A,H]
+        return dw, dx
+
+
+def pool_tn(w, x):
+    return _PoolTN.apply(w, x)
+
+
+class _VladResidual(torch.autograd.Function):
+    """vlad[b,k,:] = agg[b,k,:] - (sum_f a[b,f,k]) * c[k,:]   (SURVEY.md Appendix B); c is a Variable."""
+
+    @staticmethod
+    def forward(ctx, agg, a, token, centres):
+        n = a.sum(dim=1)                                       # [B,K]
+        ctx.save_for_backward(n)
+        ctx.centres = centres
+        ctx.F = a.shape[1]
+        return agg - n.unsqueeze(2) * centres.data.unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (n,) = ctx.saved_tensors
+        c = ctx.centres
+        dout = _f32c(dout)
+        if c.grad is not None:
+            B, K, D = dout.shape
+            # dc[k,:] = -sum_b n[b,k] dout[b,k,:]  as a batched GEMM over k would need a transpose; K*D is small
+            gc = -(n.unsqueeze(2) * dout).sum(dim=0)
+            if c.grad_beta() == 0.0:
+                c.grad.copy_(gc)
+            else:
+                c.grad.add_(gc)
+            c.grad_done()
+        dn = -(dout * c.data.unsqueeze(0)).sum(dim=2)          # [B,K]
+        da = dn.unsqueeze(1).expand(-1, ctx.F, -1) if ctx.needs_input_grad[1] else None
+        return dout, da, None, None
+
+
+def vlad_residual(agg, a, centres):
+    return _VladResidual.apply(agg, a, _token(centres._graph), centres)

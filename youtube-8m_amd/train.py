@@ -1,0 +1,141 @@
+"""Training-step slice of W/train.py (W = /root/reference/youtube-8m-wangheda): plugin lookup
+(find_class_by_name, :212-215), and build_graph (:262-479) re-expressed as an eager step:
+
+    transform (:343-344) -> model.create_model (:361-377) -> label loss (:384-430) -> backward
+    -> [RCCL mean all-reduce] -> + l2*w (:435-459) -> per-tensor clip (:463-465) -> Adam (:466)
+
+TF queues / Supervisor / Saver / summaries (the control plane) are out of scope.
+"""
+import math
+
+import torch
+
+from . import feature_transform, losses, ops
+from .flags import FLAGS, DEFINE_integer, DEFINE_float, DEFINE_string, DEFINE_bool
+from .variables import Graph, get_default_graph, set_default_graph
+
+# W/train.py:73-137 (only the flags the hot path reads)
+DEFINE_string("model", "LogisticModel", "Which architecture to use for the model.")
+DEFINE_integer("batch_size", 1024, "How many examples to process per batch for training.")
+DEFINE_string("label_loss", "CrossEntropyLoss", "Which loss function to use for training the model.")
+DEFINE_float("regularization_penalty", 1, "How much weight to give to the regularization loss (the label loss has a weight of 1).")
+DEFINE_float("base_learning_rate", 0.01, "Which learning rate to start with.")
+DEFINE_float("learning_rate_decay", 0.95, "Learning rate decay factor to be applied every learning_rate_decay_examples.")
+DEFINE_float("learning_rate_decay_examples", 4000000, "Multiply current learning rate by learning_rate_decay every learning_rate_decay_examples.")
+DEFINE_string("optimizer", "AdamOptimizer", "What optimizer class to use.")
+DEFINE_float("clip_gradient_norm", 1.0, "Norm to clip gradients to.")
+DEFINE_bool("multitask", False, "Whether to consider support_predictions")
+DEFINE_string("feature_names", "mean_rgb", "Name of the feature to use for training.")
+DEFINE_string("feature_sizes", "1024", "Length of the feature vectors.")
+DEFINE_bool("frame_features", False, "If set, then --train_data_pattern must be frame-level features.")
+
+
+def find_class_by_name(name, modules):
+    """W/train.py:212-215: the first module that has the attribute wins; a missing class raises StopIteration."""
+    modules = [getattr(module, name, None) for module in modules]
+    return next(a for a in modules if a)
+
+
+def exponential_decay(base_lr, global_step, batch_size, decay_examples, decay):
+    """tf.train.exponential_decay(staircase=True) as called at W/train.py:303-308."""
+    return base_lr * decay ** math.floor(global_step * batch_size / float(decay_examples))
+
+
+class TrainGraph(object):
+    """What build_graph() wires, as an object with an eager ``step``."""
+
+    def __init__(self, model, label_loss_fn=None, batch_size=1024, base_learning_rate=0.01,
+                 learning_rate_decay_examples=4000000, learning_rate_decay=0.95, transformer_class=None,
+                 clip_gradient_norm=1.0, regularization_penalty=1, multitask=None, graph=None, reducer=None,
+                 beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.model = model
+        self.label_loss_fn = label_loss_fn or losses.CrossEntropyLoss()
+        self.batch_size = batch_size                      # GLOBAL batch (drives the LR staircase, :305)
+        self.base_learning_rate = base_learning_rate
+        self.decay_examples = learning_rate_decay_examples
+        self.decay = learning_rate_decay
+        self.transformer = (transformer_class or feature_transform.DefaultTransformer)()
+        self.clip = clip_gradient_norm
+        self.reg_penalty = regularization_penalty
+        self.multitask = FLAGS.multitask if multitask is None else multitask
+        self.graph = graph or get_default_graph()
+        self.reducer = reducer                            # parallel.GradReducer or None
+        self.global_step = 0
+        self.b1, self.b2, self.eps = beta1, beta2, epsilon
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, model_input_raw, labels_batch=None, num_frames=None, is_training=True):
+        g = set_default_graph(self.graph)
+        g.begin_step()
+        model_input, num_frames = self.transformer.transform(model_input_raw, num_frames=num_frames)
+        kw = {} if is_training else {"is_training": False}
+        result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=FLAGS.num_classes
+                                         if labels_batch is None else labels_batch.shape[1],
+                                         labels=labels_batch, distillation_predictions=None, noise_level=None, **kw)
+        return result
+
+    def loss(self, result, labels_batch, weights=None):
+        predictions = result["predictions"]
+        if "loss" in result:                                      # W/train.py:384-385
+            return result["loss"]
+        if self.multitask:                                        # W/train.py:394-413
+            return self.label_loss_fn.calculate_loss(predictions, result["support_predictions"], labels_batch, weights=weights)
+        return self.label_loss_fn.calculate_loss(predictions, labels_batch, weights=weights)
+
+    # ---- one optimisation step -----------------------------------------------------------------------
+    def step(self, model_input_raw, labels_batch, num_frames=None, weights=None):
+        g = self.graph
+        result = self.forward(model_input_raw, labels_batch, num_frames)
+        label_loss = self.loss(result, labels_batch, weights)
+        if not g.finalized:
+            g.finalize()
+            if self.reg_penalty != 1:
+                g.l2.mul_(float(self.reg_penalty))
+            if self.reducer is not None:
+                self.reducer.attach(g)
+        if self.reducer is not None:
+            self.reducer.begin_step()
+        label_loss.backward()
+        for v in g.trainable_variables():                       # variables the step did not touch: TF skips them
+            if not v.grad_written:                              # (None gradient); here their gradient is zero
+                v.grad.zero_()
+                v.grad_written = True
+        gscale = 1.0
+        if self.reducer is not None:
+            gscale = self.reducer.finish()                      # all grads summed over ranks; mean folded into gscale
+        lr = exponential_decay(self.base_learning_rate, self.global_step, self.batch_size, self.decay_examples, self.decay)
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        ops.sqnorm_and_adam(g, lr_t, gscale=gscale, clip=self.clip, beta1=self.b1, beta2=self.b2, eps=self.eps)
+        self.global_step += 1
+        return {"loss": label_loss.detach(), "predictions": result["predictions"].detach(),
+                "global_step": self.global_step, "learning_rate": lr}
+
+    @torch.no_grad()
+    def predict(self, model_input_raw, num_frames=None, vocab_size=None):
+        g = set_default_graph(self.graph)
+        g.begin_step()
+        model_input, num_frames = self.transformer.transform(model_input_raw, num_frames=num_frames)
+        result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=vocab_size or FLAGS.num_classes,
+                                         is_training=False)
+        return result["predictions"]
+
+    def regularization_loss(self):
+        """sum_W l2 * 0.5 * |W|^2 (W/train.py:435-445); reporting only -- its gradient l2*w is applied in the
+        fused optimiser pass."""
+        tot = 0.0
+        for v in self.graph.trainable_variables():
+            if v.l2 > 0:
+                tot = tot + self.reg_penalty * v.l2 * 0.5 * float((v.data.double() ** 2).sum())
+        return tot
+
+
+def build_graph(model, label_loss_fn=None, batch_size=None, **kw):
+    """Name-compatible entry: returns the TrainGraph configured from FLAGS like W/train.py:679-728 does."""
+    return TrainGraph(model, label_loss_fn=label_loss_fn,
+                      batch_size=batch_size or FLAGS.batch_size,
+                      base_learning_rate=kw.pop("base_learning_rate", FLAGS.base_learning_rate),
+                      learning_rate_decay_examples=kw.pop("learning_rate_decay_examples", FLAGS.learning_rate_decay_examples),
+                      learning_rate_decay=kw.pop("learning_rate_decay", FLAGS.learning_rate_decay),
+                      clip_gradient_norm=kw.pop("clip_gradient_norm", FLAGS.clip_gradient_norm),
+                      regularization_penalty=kw.pop("regularization_penalty", FLAGS.regularization_penalty), **kw)
