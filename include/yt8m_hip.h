@@ -32,6 +32,11 @@ int yt8m_prof_reset(void);
 /* synchronises the device; returns launches and total ms for a family */
 int yt8m_prof_get(int family, int64_t* launches, double* total_ms);
 
+/* hardware probes (measured ceilings of THIS box, printed next to the roofline numbers):
+ * mfma: register-only v_mfma_f32_32x32x2_f32 loop; FLOPs = blocks*4*iters*32*4096.  copy: float4 stream, n%4==0. */
+int yt8m_probe_mfma_f32(int iters, int blocks, float* sink, yt8m_stream_t stream);
+int yt8m_probe_copy_f32(const float* src, float* dst, int64_t n, yt8m_stream_t stream);
+
 /* ---- GEMM: C[M,N] = op(A)[M,K] . op(B)[K,N] (+ bias[N]) (+ beta*C), exact fp32 on v_mfma_f32_32x32x2_f32.
  * Replaces tf.matmul / slim.fully_connected's MatMul+BiasAdd (W/all_video_models/moe_model.py:40-52,
  * logistic_model.py:23-25, deep_combine_chain_model.py:29-34, BasicLSTMCell _linear) and their
@@ -48,6 +53,23 @@ int yt8m_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
 int yt8m_gemm_f32_batched(int transA, int transB, int64_t M, int64_t N, int64_t K,
                           const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB,
                           float* C, int64_t ldc, int64_t strideC, float beta, int64_t batch, yt8m_stream_t stream);
+
+/* grouped / persistent form: up to 4 problems with the same transA/transB share ONE launch of 768 resident
+ * workgroups (3 per CU).  Whole rounds of tiles run data-parallel; the remainder tiles are split along K into
+ * `workspace` and summed by a deterministic fix-up pass, so the chip has no wave-quantisation tail (the MoE head's
+ * gate + expert GEMMs -- moe_model.py:40-52 -- are 888 + 592 tiles on 768 slots).  workspace >=
+ * yt8m_gemm_workspace_bytes() enables the split (NULL: remainder tiles run whole). */
+typedef struct yt8m_gemm_problem {
+  int64_t M, N, K;
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  const float* bias;  /* may be NULL */
+  float beta;         /* 0 or 1 */
+} yt8m_gemm_problem;
+int64_t yt8m_gemm_workspace_bytes(void);
+int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+                          int64_t workspace_bytes, yt8m_stream_t stream);
 
 /* ---- input transform ---------------------------------------------------------------------------
  * yt8m_l2norm_*: tf.nn.l2_normalize on the last axis (W/all_feature_transform/default_transformer.py:4-8,

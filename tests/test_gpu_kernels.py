@@ -35,6 +35,8 @@ def test_gemm_all_layouts(dev, M, N, K, tA, tB):
     scale = np.abs(A).max() * np.abs(B).max() * K
     C = ops.gemm(D(A, dev), D(B, dev), transA=bool(tA), transB=bool(tB))
     assert np.abs(H(C) - ref).max() <= 2e-6 * scale
+    Cs = ops.gemm_simple(D(A, dev), D(B, dev), transA=bool(tA), transB=bool(tB))       # plain launch, same contract
+    assert np.abs(H(Cs) - ref).max() <= 2e-6 * scale
     C2 = ops.gemm(D(A, dev), D(B, dev), transA=bool(tA), transB=bool(tB), bias=D(bias, dev))
     assert np.abs(H(C2) - (ref + bias)).max() <= 2e-6 * scale
     ops.gemm(D(A, dev), D(B, dev), out=C2, transA=bool(tA), transB=bool(tB), beta=1.0)     # accumulate
@@ -57,6 +59,40 @@ def test_gemm_strided_views_and_transpose_detection(dev):
     # fp32 MFMA is an exact fmaf chain: identity times anything is bit exact, and K-order is sequential
     C = ops.gemm(D(Bas, dev), torch.eye(n, device=dev), transA=True)
     assert np.array_equal(H(C), Bas.T.astype(np.float64))
+
+
+def test_gemm_grouped_persistent_and_splitk(dev):
+    """Persistent grouped launch: several problems in one tile space; covers whole rounds (T > 768 tiles), the
+    split-K remainder + deterministic fix-up, the T < slots split, bias / beta per problem and ragged edges."""
+    rs = np.random.RandomState(11)
+    x = rs.randn(1024, 256).astype(np.float32)
+    Wg = rs.randn(256, 14148).astype(np.float32)        # 8 x 111 tiles
+    We = rs.randn(256, 9432).astype(np.float32)         # 8 x 74 tiles  -> 1480 tiles = 1 round + 712 remainder (S = 1)
+    be = rs.randn(9432).astype(np.float32)
+    Zg, Ze = ops.gemm_grouped([dict(A=D(x, dev), B=D(Wg, dev)), dict(A=D(x, dev), B=D(We, dev), bias=D(be, dev))])
+    x64 = x.astype(np.float64)
+    assert np.abs(H(Zg) - x64 @ Wg).max() < 2e-3 and np.abs(H(Ze) - (x64 @ We + be)).max() < 2e-3
+    # dW shapes: 9 x 111 + 9 x 74 = 1665 tiles = 2 rounds + 129 remainder tiles split S = 5 ways (K = 1024 -> 64 steps)
+    dZg = rs.randn(1024, 14148).astype(np.float32)
+    dZe = rs.randn(1024, 9432).astype(np.float32)
+    x2 = rs.randn(1024, 1152).astype(np.float32)
+    g0 = torch.full((1152, 14148), 7.0, device=dev)
+    g1 = torch.full((1152, 9432), 1.0, device=dev)
+    ops.gemm_grouped([dict(A=D(x2, dev), B=D(dZg, dev), out=g0, beta=0.0), dict(A=D(x2, dev), B=D(dZe, dev), out=g1, beta=1.0)], transA=True)
+    r0 = x2.astype(np.float64).T @ dZg
+    r1 = x2.astype(np.float64).T @ dZe + 1.0
+    assert np.abs(H(g0) - r0).max() < 5e-3 and np.abs(H(g1) - r1).max() < 5e-3
+    g0b = torch.empty_like(g0)
+    ops.gemm_grouped([dict(A=D(x2, dev), B=D(dZg, dev), out=g0b)], transA=True)
+    ops.gemm_grouped([dict(A=D(x2, dev), B=D(dZg, dev), out=g0)], transA=True)
+    assert torch.equal(g0, g0b)                        # fixed-order fix-up: bitwise reproducible
+    # few tiles, long K: split-K fills the chip (LstmModel head at B = 128)
+    a = rs.randn(100, 4096).astype(np.float32)
+    w = rs.randn(4096, 1000).astype(np.float32)
+    bb = rs.randn(1000).astype(np.float32)
+    c = ops.gemm(D(a, dev), D(w, dev), bias=D(bb, dev))
+    assert np.abs(H(c) - (a.astype(np.float64) @ w + bb)).max() < 5e-3
+    assert np.abs(H(ops.gemm_simple(D(a, dev), D(w, dev), bias=D(bb, dev))) - H(c)).max() < 2e-3
 
 
 def test_gemm_batched(dev):

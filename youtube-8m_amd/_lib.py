@@ -4,10 +4,16 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyt8m_hip.so")
+LIB_PATH = os.environ.get("YT8M_LIB", os.path.join(_HERE, "libyt8m_hip.so"))  # YT8M_LIB: A/B builds (tools/)
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 P = c_void_p
+
+class GemmProblem(ctypes.Structure):
+    """yt8m_gemm_problem (include/yt8m_hip.h)."""
+    _fields_ = [("M", c_int64), ("N", c_int64), ("K", c_int64), ("A", c_void_p), ("lda", c_int64), ("B", c_void_p),
+                ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64), ("bias", c_void_p), ("beta", c_float)]
+
 
 # name -> (restype, argtypes); one row per function declared in include/yt8m_hip.h
 SIGNATURES = {
@@ -17,7 +23,11 @@ SIGNATURES = {
     "yt8m_prof_enable": (c_int, [c_int]),
     "yt8m_prof_reset": (c_int, []),
     "yt8m_prof_get": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
+    "yt8m_probe_mfma_f32": (c_int, [c_int, c_int, P, P]),
+    "yt8m_probe_copy_f32": (c_int, [P, P, c_int64, P]),
     "yt8m_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P]),
+    "yt8m_gemm_workspace_bytes": (c_int64, []),
+    "yt8m_gemm_f32_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64,
                                       P, c_int64, c_int64, c_float, c_int64, P]),
     "yt8m_l2norm_fwd_f32": (c_int, [P, P, c_int64, c_int64, c_float, P]),

@@ -7,27 +7,21 @@
 // at the 157 TFLOP/s fp32 peak and leaves the VALU free for the epilogue.
 //
 // Tiling (wave64, 4 waves / workgroup):
-//   workgroup tile 128 x 128, K-step 16, waves arranged 2 (M) x 2 (N), each wave owns 64 x 64 =
-//   2 x 2 MFMA tiles of 32 x 32 (4 accumulators x 16 VGPR).  Per K-step a wave issues 32 MFMAs
-//   (2048 matrix-pipe cycles) against 32 ds_read_b32 -- the kernel is matrix-pipe bound by design.
-//   LDS holds both operands K-major ([k][m] / [k][n]) so that an MFMA operand fetch (lane l reads
-//   element (k = l>>5, i = l&31)) is 32 consecutive floats per half-wave: conflict-free.
-//   Operands that are K-contiguous in HBM (A of x.W, B of dZ.W^T) are read as float4 along K
-//   (16 rows x 64 B per wave instruction) and transposed on the LDS write; row stride 130 floats makes
-//   the 4 x ds_write_b32 conflict-free (4*130 mod 32 = 8).  Operands that are M/N-contiguous are read
-//   as float4 along N and written with ds_write_b128 (row stride 132 floats, 16-B aligned).
-//   Two LDS buffers + register prefetch of the next K-step: one barrier per K-step.
-//   XCD-aware rasterisation: consecutive workgroup ids land on different XCDs (id % 8), so the grid is
-//   remapped such that each XCD walks a contiguous strip of N-tiles and re-uses its B panel from its
-//   own 4 MiB L2 across the M-tiles.
+//   workgroup tile 128 x 128, K-step 16, waves arranged 2 (M) x 2 (N), each wave owns 64 x 64 = 2 x 2 MFMA tiles of
+//   32 x 32 (4 accumulators x 16 AGPR).  Per K-step a wave issues 32 MFMAs = 2048 matrix-pipe cycles.
+//   Operand tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass, issued a
+//   whole K-step ahead, two LDS buffers, ONE barrier per K-step).  The LDS image is lane-linear as the DMA requires;
+//   K-contiguous operands are XOR-swizzled through the SOURCE address so their ds_read_b128 fragment fetch is
+//   conflict-free, N-contiguous operands are read with conflict-free ds_read_b32 (32 consecutive floats / half-wave).
+//   Edge tiles, unaligned leading dimensions and K % 16 != 0 take a guarded register-staged path with the same image.
+//   XCD-aware rasterisation: consecutive workgroup ids land on different XCDs (id % 8), so the grid is remapped such
+//   that each XCD walks a contiguous strip of tiles and re-uses its B panel from its own 4 MiB L2 across M-tiles.
 #include "common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_KC = 130;  // row stride (floats) of a tile whose source is K-contiguous
-constexpr int LDS_XC = 132;  // row stride (floats) of a tile whose source is M/N-contiguous
-constexpr int TILE_FLOATS = BK * LDS_XC;
+constexpr int TILE_FLOATS = BK * 128;  // one operand tile in LDS (8 KiB), no padding
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -44,82 +38,187 @@ struct GemmArgs {
   int64_t strideA, strideB, strideC;  // batched form: blockIdx.y selects the problem
 };
 
-// global -> registers for one [BK x 128] operand tile.  KC: element (x, k) at P[x*ld + k]; else P[k*ld + x].
+// ---- LDS image of a [BK x 128] operand tile (same image whichever way it is filled) --------------------------
+// Thread slot idx in [0,512) owns the 16 bytes at float offset idx*4 (lane-linear, which is what the LDS-DMA
+// form of global_load requires: destination = wave-uniform base + lane*16).
+//   KC source (operand rows are K-contiguous in HBM, e.g. x[B,D] of x.W): slot -> row x = idx>>2, chunk slot
+//     cs = idx&3; the slot holds the row's k-chunk c = cs ^ ((x>>2)&3)  (XOR swizzle applied on the SOURCE
+//     address, so the 16-lane groups of the ds_read_b128 fragment fetch hit 16 distinct 16-B bank slots).
+//   XC source (operand is M/N-contiguous, e.g. W[D,N]): slot -> k = idx>>5, x = (idx&31)*4; image = [k][128].
 template <bool KC>
-__device__ __forceinline__ void gload(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, int K,
-                                      bool vec, int tid, float4 (&r)[2]) {
+__device__ __forceinline__ const float* slot_src(const float* __restrict__ P, int64_t ld, int x0, int k0, int idx,
+                                                  int& gx, int& gk) {
+  if (KC) {
+    const int x = idx >> 2;
+    gx = x0 + x;
+    gk = k0 + 4 * ((idx & 3) ^ ((x >> 2) & 3));
+    return P + (int64_t)gx * ld + gk;
+  } else {
+    gk = k0 + (idx >> 5);
+    gx = x0 + (idx & 31) * 4;
+    return P + (int64_t)gk * ld + gx;
+  }
+}
+
+// asynchronous fill of one tile by LDS-DMA (interior tiles of 16-byte aligned operands only)
+template <bool KC>
+__device__ __forceinline__ void fill_dma(const float* __restrict__ P, int64_t ld, int x0, int k0, float* S, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * 256;
-    if (KC) {
-      const int gx = x0 + (idx >> 2), gk = k0 + (idx & 3) * 4;
-      const float* p = P + (int64_t)gx * ld + gk;
-      if (vec && gx < X && gk + 3 < K) {
-        r[i] = *reinterpret_cast<const float4*>(p);
-      } else {
-        const bool okx = gx < X;
-        r[i].x = (okx && gk + 0 < K) ? p[0] : 0.f;
-        r[i].y = (okx && gk + 1 < K) ? p[1] : 0.f;
-        r[i].z = (okx && gk + 2 < K) ? p[2] : 0.f;
-        r[i].w = (okx && gk + 3 < K) ? p[3] : 0.f;
-      }
+    int gx, gk;
+    const float* src = slot_src<KC>(P, ld, x0, k0, idx, gx, gk);
+    float* dst = S + (idx & ~63) * 4;  // wave-uniform base; the hardware adds lane*16 bytes
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
+// guarded register fill (edge tiles, unaligned leading dimensions, K tails): same image, zero padded
+template <bool KC>
+__device__ __forceinline__ float4 load_guarded(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, int K,
+                                               bool vec, int idx) {
+  int gx, gk;
+  const float* p = slot_src<KC>(P, ld, x0, k0, idx, gx, gk);
+  float4 r;
+  if (KC) {
+    if (vec && gx < X && gk + 3 < K) {
+      r = *reinterpret_cast<const float4*>(p);
     } else {
-      const int gk = k0 + (idx >> 5), gx = x0 + (idx & 31) * 4;
-      const float* p = P + (int64_t)gk * ld + gx;
-      if (vec && gk < K && gx + 3 < X) {
-        r[i] = *reinterpret_cast<const float4*>(p);
+      const bool ok = gx < X;
+      r.x = (ok && gk + 0 < K) ? p[0] : 0.f;
+      r.y = (ok && gk + 1 < K) ? p[1] : 0.f;
+      r.z = (ok && gk + 2 < K) ? p[2] : 0.f;
+      r.w = (ok && gk + 3 < K) ? p[3] : 0.f;
+    }
+  } else {
+    if (vec && gk < K && gx + 3 < X) {
+      r = *reinterpret_cast<const float4*>(p);
+    } else {
+      const bool ok = gk < K;
+      r.x = (ok && gx + 0 < X) ? p[0] : 0.f;
+      r.y = (ok && gx + 1 < X) ? p[1] : 0.f;
+      r.z = (ok && gx + 2 < X) ? p[2] : 0.f;
+      r.w = (ok && gx + 3 < X) ? p[3] : 0.f;
+    }
+  }
+  return r;
+}
+
+// ---- MFMA operand fragments -------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 takes, per lane, ONE A value A[i = lane&31][k = lane>>5] and one B value.  Which two k of
+// the K-step an MFMA reduces is free as long as A and B agree, so step (h, j), h in {0,1}, j in {0..3}, uses
+//   k = 8h + j (lanes 0-31)  and  k = 8h + 4 + j (lanes 32-63):
+// a KC operand then needs ONE ds_read_b128 per (tile t, h): lane (li, lk) fetches chunk c = 2h + lk of its row
+// and register component j feeds step (h, j); an XC operand reads row k = 8h + 4*lk + j with ds_read_b32.
+struct Frag {
+  float v[2][2][4];  // [t: 32-row sub-tile][h][j]
+};
+
+template <bool KC>
+__device__ __forceinline__ void load_frag(const float* __restrict__ S, int xo, int li, int lk, Frag& f) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (KC) {
+        const int row = xo + t * 32 + li;
+        const float4 q = *reinterpret_cast<const float4*>(&S[row * 16 + 4 * ((2 * h + lk) ^ ((row >> 2) & 3))]);
+        f.v[t][h][0] = q.x; f.v[t][h][1] = q.y; f.v[t][h][2] = q.z; f.v[t][h][3] = q.w;
       } else {
-        const bool okk = gk < K;
-        r[i].x = (okk && gx + 0 < X) ? p[0] : 0.f;
-        r[i].y = (okk && gx + 1 < X) ? p[1] : 0.f;
-        r[i].z = (okk && gx + 2 < X) ? p[2] : 0.f;
-        r[i].w = (okk && gx + 3 < X) ? p[3] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.v[t][h][j] = S[(8 * h + 4 * lk + j) * 128 + xo + t * 32 + li];
       }
     }
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void sstore(float* __restrict__ S, int tid, const float4 (&r)[2]) {
+__device__ __forceinline__ void mma_step(const Frag& fa, const Frag& fb, f32x16 (&acc)[2][2]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + i * 256;
-    if (KC) {
-      const int x = idx >> 2, kq = (idx & 3) * 4;
-      S[(kq + 0) * LDS_KC + x] = r[i].x;
-      S[(kq + 1) * LDS_KC + x] = r[i].y;
-      S[(kq + 2) * LDS_KC + x] = r[i].z;
-      S[(kq + 3) * LDS_KC + x] = r[i].w;
-    } else {
-      const int k = idx >> 5, xq = (idx & 31) * 4;
-      *reinterpret_cast<float4*>(&S[k * LDS_XC + xq]) = r[i];
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[0][h][j], fb.v[0][h][j], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[0][h][j], fb.v[1][h][j], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[1][h][j], fb.v[0][h][j], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[1][h][j], fb.v[1][h][j], acc[1][1], 0, 0, 0);
     }
   }
 }
 
-// A_KC: A stored [M,K] (transA = 0).  B_KC: B stored [N,K] (transB = 1).
+// One pass over K for a workgroup tile.
+//  DMA path   : the next K-step is issued as LDS-DMA at the TOP of the iteration (side-effecting => it stays there),
+//               lands during the 32 MFMAs (2048 matrix-pipe cycles) and is waited for by the barrier's vmcnt(0).
+//  guarded path: register staging; used by edge tiles / unaligned operands / K % 16 != 0.
+// In both, every fragment of the K-step is fetched from LDS before the first MFMA (sched_barrier pins the order) so
+// the LDS latency is paid once per K-step and the MFMAs stream.
+template <bool A_KC, bool B_KC, bool DMA>
+__device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restrict__ Ap, const float* __restrict__ Bp,
+                                         float* __restrict__ As, float* __restrict__ Bs, int m0, int n0, int kb, int ke,
+                                         int tid, int wm, int wn, int li, int lk, f32x16 (&acc)[2][2]) {
+  // K-steps [kb, ke) of this tile (a split-K part of a remainder tile processes a sub-range)
+  float4 ra0, ra1, rb0, rb1;
+  if (DMA) {
+    fill_dma<A_KC>(Ap, g.lda, m0, kb * BK, As, tid);
+    fill_dma<B_KC>(Bp, g.ldb, n0, kb * BK, Bs, tid);
+  } else {
+    ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid);
+    ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid + 256);
+    rb0 = load_guarded<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, g.K, g.vecB, tid);
+    rb1 = load_guarded<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, g.K, g.vecB, tid + 256);
+    *reinterpret_cast<float4*>(&As[tid * 4]) = ra0;
+    *reinterpret_cast<float4*>(&As[(tid + 256) * 4]) = ra1;
+    *reinterpret_cast<float4*>(&Bs[tid * 4]) = rb0;
+    *reinterpret_cast<float4*>(&Bs[(tid + 256) * 4]) = rb1;
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kb; kt < ke; ++kt) {
+    const bool more = kt + 1 < ke;
+    float* An = As + (cur ^ 1) * TILE_FLOATS;
+    float* Bn = Bs + (cur ^ 1) * TILE_FLOATS;
+    if (DMA) {
+      if (more) {
+        fill_dma<A_KC>(Ap, g.lda, m0, (kt + 1) * BK, An, tid);
+        fill_dma<B_KC>(Bp, g.ldb, n0, (kt + 1) * BK, Bn, tid);
+      }
+    } else {
+      const int kn = (more ? kt + 1 : kt) * BK;
+      ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kn, g.M, g.K, g.vecA, tid);
+      ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kn, g.M, g.K, g.vecA, tid + 256);
+      rb0 = load_guarded<B_KC>(Bp, g.ldb, n0, kn, g.N, g.K, g.vecB, tid);
+      rb1 = load_guarded<B_KC>(Bp, g.ldb, n0, kn, g.N, g.K, g.vecB, tid + 256);
+    }
+    Frag fa, fb;
+    load_frag<A_KC>(As + cur * TILE_FLOATS, wm, li, lk, fa);
+    load_frag<B_KC>(Bs + cur * TILE_FLOATS, wn, li, lk, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(fa, fb, acc);
+    // pin again: hipcc otherwise hoists the barrier (and its vmcnt(0) drain of the in-flight DMA) above the
+    // register-only MFMAs, which would expose the whole memory latency every K-step
+    __builtin_amdgcn_sched_barrier(0);
+    if (!DMA) {
+      *reinterpret_cast<float4*>(&An[tid * 4]) = ra0;
+      *reinterpret_cast<float4*>(&An[(tid + 256) * 4]) = ra1;
+      *reinterpret_cast<float4*>(&Bn[tid * 4]) = rb0;
+      *reinterpret_cast<float4*>(&Bn[(tid + 256) * 4]) = rb1;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---- one workgroup tile: K-steps [kb, ke) -> accumulators -> epilogue --------------------------------------------
+// mode 0: full reduction, C = acc (+ bias) (+ C).  mode 1: split-K part, raw accumulators to the workspace slot `ws`
+// (tile-local [128][128] image); the fix-up kernel adds the parts in a fixed order.
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+__device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __restrict__ Ap, const float* __restrict__ Bp,
+                                             float* __restrict__ Cp, float* __restrict__ smem, int tm, int tn, int kb,
+                                             int ke, float* __restrict__ ws) {
   float* const As = smem;                     // As + buf * TILE_FLOATS
   float* const Bs = smem + 2 * TILE_FLOATS;   // Bs + buf * TILE_FLOATS
-  constexpr int SA = A_KC ? LDS_KC : LDS_XC;
-  constexpr int SB = B_KC ? LDS_KC : LDS_XC;
-
-  // XCD-aware rasterisation (bijective for any grid size): wg -> (xcd, slot) -> linear tile id where each
-  // XCD owns a contiguous range; within the range M-tiles are fastest so neighbours share the B panel.
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int wg = blockIdx.x;
-  const int xcd = wg & 7, slot = wg >> 3;
-  const int q = nwg >> 3, rem = nwg & 7;
-  const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
-  const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-
-  const float* __restrict__ Ap = g.A + (int64_t)blockIdx.y * g.strideA;
-  const float* __restrict__ Bp = g.B + (int64_t)blockIdx.y * g.strideB;
-  float* __restrict__ Cp = g.C + (int64_t)blockIdx.y * g.strideC;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -133,41 +232,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[2];
-  const int nk = (g.K + BK - 1) / BK;
-  gload<A_KC>(Ap, g.lda, m0, 0, g.M, g.K, g.vecA, tid, ra);
-  gload<B_KC>(Bp, g.ldb, n0, 0, g.N, g.K, g.vecB, tid, rb);
-  sstore<A_KC>(As, tid, ra);
-  sstore<B_KC>(Bs, tid, rb);
-  __syncthreads();
+  // interior tiles of aligned operands take the LDS-DMA path (wave-uniform choice)
+  const bool dma = g.vecA && g.vecB && (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.K % BK == 0);
+  if (dma) mainloop<A_KC, B_KC, true>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
+  else mainloop<A_KC, B_KC, false>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
 
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      gload<A_KC>(Ap, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.vecA, tid, ra);
-      gload<B_KC>(Bp, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.vecB, tid, rb);
-    }
-    const float* as = As + cur * TILE_FLOATS + lk * SA + wm + li;
-    const float* bs = Bs + cur * TILE_FLOATS + lk * SB + wn + li;
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (ws) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = as[kk * SA], a1 = as[kk * SA + 32];
-      const float b0 = bs[kk * SB], b1 = bs[kk * SB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (more) {
-      sstore<A_KC>(As + (cur ^ 1) * TILE_FLOATS, tid, ra);
-      sstore<B_KC>(Bs + (cur ^ 1) * TILE_FLOATS, tid, rb);
-    }
-    __syncthreads();
-    cur ^= 1;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ws[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + wn + j * 32 + li] = acc[i][j][r];
+    return;
   }
-
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn + j * 32 + li;
@@ -189,41 +269,221 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   }
 }
 
+// XCD-aware bijective remap of a linear id: consecutive hardware workgroup ids land on different XCDs (id % 8), so
+// give each XCD a contiguous range of logical ids (neighbouring tiles then share operand panels in ONE 4 MiB L2).
+__device__ __forceinline__ int xcd_remap(int wg, int n) {
+  const int xcd = wg & 7, slot = wg >> 3;
+  const int q = n >> 3, rem = n & 7;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+}
+
+// ---- simple data-parallel kernel: one tile per workgroup; blockIdx.y = batch ---------------------------------------
+// A_KC: A stored [M,K] (transA = 0).  B_KC: B stored [N,K] (transB = 1).
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;  // M-tiles fastest: neighbours share the B panel
+  process_tile<A_KC, B_KC>(g, g.A + (int64_t)blockIdx.y * g.strideA, g.B + (int64_t)blockIdx.y * g.strideB,
+                           g.C + (int64_t)blockIdx.y * g.strideC, smem, tm, tn, 0, (g.K + BK - 1) / BK, nullptr);
+}
+
+// ---- persistent grouped kernel ----------------------------------------------------------------------------------------
+// Up to 4 problems with the same layout flags share one tile space of T tiles; P = 768 resident slots (3 per CU).
+//   whole-tile rounds  : the first floor(T / P) * P tiles, one per workgroup, whole K, K-synchronised across the chip so
+//                        operand panels are re-used out of L2;
+//   remainder (T % P)  : each tile is split along K into S = P / remainder parts; part s of remainder tile r parks its
+//                        raw accumulators in ws[(r*S + s)][128][128]; splitk_fixup_kernel then sums the S parts in a
+//                        fixed order (deterministic).
+// This removes the wave-quantisation tail (e.g. 888 tiles on 768 slots = 58 % -> 98 % slot utilisation).
+constexpr int MAX_GROUP = 4;
+struct GroupArgs {
+  GemmArgs p[MAX_GROUP];
+  int tile_base[MAX_GROUP + 1];
+  int nprob;
+  int T, P, full_rounds, rem, S;
+  float* ws;
+};
+
+__device__ __forceinline__ int find_problem(const GroupArgs& G, int tile) {
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_GROUP; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  return q;
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupArgs G) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  // One work item per workgroup; the grid is full_rounds*P whole tiles followed by rem*S split-K parts.  The hardware
+  // dispatcher hands out workgroups in id order, 3 resident per CU, so the whole-tile rounds run K-synchronised and the
+  // parts backfill the slots freed by the last round.
+  const int full = G.full_rounds * G.P;
+  const int id = blockIdx.x;
+  int tile, part = 0, nparts = 1, slot = 0;
+  if (id < full) {
+    const int round = id / G.P;
+    tile = round * G.P + xcd_remap(id - round * G.P, G.P);
+  } else {
+    slot = xcd_remap(id - full, G.rem * G.S);
+    const int rt = slot / G.S;
+    part = slot - rt * G.S;
+    nparts = G.S;
+    tile = full + rt;
+  }
+  const int q = find_problem(G, tile);
+  const GemmArgs& g = G.p[q];
+  const int lt = tile - G.tile_base[q];
+  const int nk = (g.K + BK - 1) / BK;
+  const int kb = (int)((int64_t)nk * part / nparts), ke = (int)((int64_t)nk * (part + 1) / nparts);
+  process_tile<A_KC, B_KC>(g, g.A, g.B, g.C, smem, lt % g.tiles_m, lt / g.tiles_m, kb, ke,
+                           nparts > 1 ? G.ws + (int64_t)slot * (BM * BN) : nullptr);
+}
+
+// sums the S split-K parts of each remainder tile (fixed order) and applies the normal epilogue
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(const GroupArgs G) {
+  const int rt = blockIdx.x;
+  const int tile = G.full_rounds * G.P + rt;
+  const int q = find_problem(G, tile);
+  const GemmArgs& g = G.p[q];
+  const int lt = tile - G.tile_base[q];
+  const int m0 = (lt % g.tiles_m) * BM, n0 = (lt / g.tiles_m) * BN;
+  const float* base = G.ws + (int64_t)rt * G.S * (BM * BN);
+  for (int e = threadIdx.x * 4; e < BM * BN; e += 256 * 4) {
+    float4 v = *reinterpret_cast<const float4*>(base + e);
+    for (int s = 1; s < G.S; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * (BM * BN) + e);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int row = m0 + e / BN, col = n0 + (e % BN);
+    if (row >= g.M) continue;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float* c = g.C + (int64_t)row * g.ldc + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (col + k < g.N) {
+        float o = vv[k] + (g.bias ? g.bias[col + k] : 0.f);
+        if (g.accumulate) o += c[k];
+        c[k] = o;
+      }
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+constexpr int RESIDENT_PER_CU = 3;   // 76 VGPR + 64 AGPR, 32 KiB LDS => 3 workgroups per CU
+constexpr int NUM_CU = 256;
+constexpr int SLOTS = RESIDENT_PER_CU * NUM_CU;
+
 }  // namespace
+
+static int fill_problem(GemmArgs& g, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                        const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, float beta) {
+  using namespace yt8m;
+  YT8M_REQUIRE(M >= 0 && N >= 0 && K >= 0, YT8M_E_SHAPE, "negative dimension");
+  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  YT8M_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), YT8M_E_SHAPE, "dimension >= 2^31");
+  YT8M_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, YT8M_E_SHAPE, "leading dimension too small");
+  if (M > 0 && N > 0) YT8M_REQUIRE(A && B && C, YT8M_E_BADARG, "null operand");
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.strideA = g.strideB = g.strideC = 0;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.tiles_m = (int)((M + BM - 1) / BM);
+  g.tiles_n = (int)((N + BN - 1) / BN);
+  g.vecA = (lda % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && aligned16(B);
+  g.accumulate = beta != 0.f;
+  return YT8M_OK;
+}
+
+template <typename KernelArgs>
+static void launch_by_layout(int transA, int transB, void (*k00)(KernelArgs), void (*k10)(KernelArgs), void (*k01)(KernelArgs),
+                             void (*k11)(KernelArgs), dim3 grid, hipStream_t s, const KernelArgs& a) {
+  void (*k)(KernelArgs) = (!transA && !transB) ? k00 : (transA && !transB) ? k10 : (!transA && transB) ? k01 : k11;
+  hipLaunchKernelGGL(k, grid, dim3(256), 0, s, a);
+}
 
 static int gemm_launch(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                        int64_t strideC, const float* bias, float beta, int64_t batch, yt8m_stream_t stream) {
   using namespace yt8m;
-  YT8M_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, YT8M_E_SHAPE, "negative dimension");
-  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
-  if (M == 0 || N == 0 || batch == 0) return YT8M_OK;
-  YT8M_REQUIRE(A && B && C, YT8M_E_BADARG, "null operand");
-  YT8M_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), YT8M_E_SHAPE, "dimension >= 2^31");
-  YT8M_REQUIRE(batch <= 65535, YT8M_E_SHAPE, "batch > 65535");
-  YT8M_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, YT8M_E_SHAPE, "leading dimension too small");
+  YT8M_REQUIRE(batch >= 0 && batch <= 65535, YT8M_E_SHAPE, "batch out of range");
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
-  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  int rc = fill_problem(g, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta);
+  if (rc != YT8M_OK) return rc;
+  if (M == 0 || N == 0 || batch == 0) return YT8M_OK;
   g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
-  g.M = (int)M; g.N = (int)N; g.K = (int)K;
-  g.tiles_m = (int)((M + BM - 1) / BM);
-  g.tiles_n = (int)((N + BN - 1) / BN);
-  g.vecA = (lda % 4 == 0) && aligned16(A) && (strideA % 4 == 0);
-  g.vecB = (ldb % 4 == 0) && aligned16(B) && (strideB % 4 == 0);
-  g.accumulate = beta != 0.f;
+  g.vecA = g.vecA && (strideA % 4 == 0);
+  g.vecB = g.vecB && (strideB % 4 == 0);
   const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
   YT8M_REQUIRE(nwg < (1LL << 31), YT8M_E_SHAPE, "grid too large");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);
-  dim3 grid((unsigned)nwg, (unsigned)batch), block(256);
-  if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
-  else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
-  else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g);
+  launch_by_layout<GemmArgs>(transA, transB, gemm_f32_kernel<true, false>, gemm_f32_kernel<false, false>,
+                             gemm_f32_kernel<true, true>, gemm_f32_kernel<false, true>,
+                             dim3((unsigned)nwg, (unsigned)batch), s, g);
   return launch_status("gemm_f32_kernel");
+}
+
+extern "C" int64_t yt8m_gemm_workspace_bytes(void) { return (int64_t)SLOTS * BM * BN * (int64_t)sizeof(float); }
+
+extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+                                     int64_t workspace_bytes, yt8m_stream_t stream) {
+  using namespace yt8m;
+  YT8M_REQUIRE(nprob >= 1 && nprob <= MAX_GROUP && probs, YT8M_E_BADARG, "1..4 problems");
+  GroupArgs G;
+  G.nprob = 0;
+  int64_t T = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    GemmArgs g;
+    int rc = fill_problem(g, transA, transB, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.bias, q.beta);
+    if (rc != YT8M_OK) return rc;
+    if (q.M == 0 || q.N == 0) continue;
+    G.p[G.nprob] = g;
+    G.tile_base[G.nprob] = (int)T;
+    T += (int64_t)g.tiles_m * g.tiles_n;
+    ++G.nprob;
+  }
+  if (G.nprob == 0) return YT8M_OK;
+  YT8M_REQUIRE(T < (1LL << 30), YT8M_E_SHAPE, "too many tiles");
+  for (int i = G.nprob; i <= MAX_GROUP; ++i) G.tile_base[i] = (int)T;
+  for (int i = G.nprob; i < MAX_GROUP; ++i) G.p[i] = G.p[0];
+  G.T = (int)T;
+  G.P = T < SLOTS ? (int)T : SLOTS;
+  G.full_rounds = (int)(T / G.P);
+  G.rem = (int)(T - (int64_t)G.full_rounds * G.P);
+  G.S = 1;
+  G.ws = static_cast<float*>(workspace);
+  if (T < SLOTS) {  // fewer tiles than slots: everything is "remainder" and may be split along K to fill the chip
+    G.P = SLOTS;
+    G.full_rounds = 0;
+    G.rem = (int)T;
+  }
+  if (G.rem > 0) {
+    int S = G.P / G.rem;
+    int min_nk = 1 << 30;
+    for (int i = 0; i < G.nprob; ++i) {
+      const int nk = (G.p[i].K + BK - 1) / BK;
+      if (nk < min_nk) min_nk = nk;
+    }
+    if (S > min_nk / 8) S = min_nk / 8;     // keep >= 8 K-steps per part (pipeline fill + epilogue amortisation)
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+    if (S > 1 && (!workspace || workspace_bytes < (int64_t)G.rem * S * BM * BN * (int64_t)sizeof(float))) S = 1;
+    G.S = S;
+  }
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int64_t grid = (int64_t)G.full_rounds * G.P + (int64_t)G.rem * G.S;
+  launch_by_layout<GroupArgs>(transA, transB, gemm_f32_grouped_kernel<true, false>, gemm_f32_grouped_kernel<false, false>,
+                              gemm_f32_grouped_kernel<true, true>, gemm_f32_grouped_kernel<false, true>,
+                              dim3((unsigned)grid), s, G);
+  if (G.S > 1) hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)G.rem), dim3(256), 0, s, G);
+  return launch_status("gemm_f32_grouped_kernel");
 }
 
 extern "C" int yt8m_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,

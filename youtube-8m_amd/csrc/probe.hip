@@ -1,0 +1,49 @@
+// probe.hip -- hardware probes used by bench.py / tools to put measured ceilings next to the roofline numbers.
+//   yt8m_probe_mfma_f32 : register-only v_mfma_f32_32x32x2_f32 loop (4 independent accumulators per wave),
+//                         i.e. the matrix-pipe ceiling of THIS box at its sustained clock.
+//   yt8m_probe_copy_f32 : float4 streaming copy (HBM ceiling).
+#include "common.h"
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mfma_probe_kernel(int iters, float* __restrict__ sink) {
+  f32x16 a0, a1, a2, a3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+  float x = (float)(threadIdx.x & 7) * 0.125f + 0.5f, y = (float)(threadIdx.x & 3) * 0.25f - 0.3f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  if (s == 123.456f) sink[0] = s;  // keep the chain live
+}
+
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
+using namespace yt8m;
+
+// FLOPs executed = blocks * 4 waves * iters * 32 MFMAs * (2*32*32*2)
+extern "C" int yt8m_probe_mfma_f32(int iters, int blocks, float* sink, yt8m_stream_t stream) {
+  YT8M_REQUIRE(iters > 0 && blocks > 0 && sink, YT8M_E_BADARG, "bad probe arguments");
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), iters, sink);
+  return launch_status("mfma_probe_kernel");
+}
+
+extern "C" int yt8m_probe_copy_f32(const float* src, float* dst, int64_t n, yt8m_stream_t stream) {
+  YT8M_REQUIRE(n >= 0 && n % 4 == 0 && src && dst, YT8M_E_BADARG, "bad probe arguments");
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), n / 4);
+  return launch_status("copy_probe_kernel");
+}

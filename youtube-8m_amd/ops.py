@@ -56,9 +56,19 @@ def _rowmajor2d(t):
 
 
 # ------------------------------------------------------------------------------------------ raw kernels
-def gemm(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
-    """out[M,N] = op(A) . op(B) (+ bias) (+ out if beta == 1).  yt8m_gemm_f32."""
-    _dev(A, B, out, bias)
+_WS = {}
+
+
+def _workspace(device):
+    """Split-K workspace of the persistent GEMM (one per device; ~48 MiB of the 288 GB)."""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = torch.empty(_lib.lib().yt8m_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def _problem(A, B, out, transA, transB, bias, beta):
     A, lda = _rowmajor2d(A)
     B, ldb = _rowmajor2d(B)
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -76,8 +86,38 @@ def gemm(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
         bias = _f32c(bias)
         if bias.numel() != N:
             raise ValueError("bias size mismatch")
-    _lib.check(_lib.lib().yt8m_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc,
-                                        _p(bias), float(beta), _stream()))
+    pr = _lib.GemmProblem(M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc,
+                          bias.data_ptr() if bias is not None else None, float(beta))
+    return pr, out, (A, B, bias)
+
+
+def gemm_grouped(items, transA=False, transB=False):
+    """items: list of dicts(A=, B=, out=None, bias=None, beta=0.0) sharing transA/transB -> list of outputs.
+    One persistent launch (yt8m_gemm_f32_grouped): no wave-quantisation tail across the group."""
+    probs, outs, keep = [], [], []
+    for it in items:
+        _dev(it["A"], it["B"], it.get("out"), it.get("bias"))
+        pr, out, k = _problem(it["A"], it["B"], it.get("out"), transA, transB, it.get("bias"), it.get("beta", 0.0))
+        probs.append(pr)
+        outs.append(out)
+        keep.append(k)
+    arr = (_lib.GemmProblem * len(probs))(*probs)
+    ws = _workspace(outs[0].device)
+    _lib.check(_lib.lib().yt8m_gemm_f32_grouped(int(transA), int(transB), len(probs), arr, _p(ws), ws.numel() * 4, _stream()))
+    return outs
+
+
+def gemm(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
+    """out[M,N] = op(A) . op(B) (+ bias) (+ out if beta == 1), through the persistent scheduler."""
+    return gemm_grouped([dict(A=A, B=B, out=out, bias=bias, beta=beta)], transA, transB)[0]
+
+
+def gemm_simple(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
+    """Same contract through the plain one-tile-per-workgroup launch (yt8m_gemm_f32)."""
+    _dev(A, B, out, bias)
+    pr, out, keep = _problem(A, B, out, transA, transB, bias, beta)
+    _lib.check(_lib.lib().yt8m_gemm_f32(int(transA), int(transB), pr.M, pr.N, pr.K, pr.A, pr.lda, pr.B, pr.ldb, pr.C, pr.ldc,
+                                        pr.bias, float(beta), _stream()))
     return out
 
 
@@ -325,8 +365,7 @@ class _MoeHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, token, Wg, We, be, V, M):
         x2 = _f32c(x)
-        Zg = gemm(x2, Wg.data)
-        Ze = gemm(x2, We.data, bias=be.data)
+        Zg, Ze = gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)])
         p = moe_mix_fwd(Zg, Ze, V, M)
         ctx.save_for_backward(x2)
         ctx.Z = (Zg, Ze)
@@ -342,11 +381,10 @@ class _MoeHead(torch.autograd.Function):
         V, M = ctx.VM
         ctx.Z = None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
-        if Wg.grad is not None:
-            gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta())
+        if Wg.grad is not None and We.grad is not None:
+            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
+                          dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True)
             Wg.grad_done()
-        if We.grad is not None:
-            gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta())
             We.grad_done()
         if be.grad is not None:
             colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
