@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
@@ -57,14 +57,27 @@ def make_pool(n, B, dev, seed):
 
 
 def cpu_baseline(B, seconds):
+    """Times the torch-CPU fp32 restatement of the same step on the host cores (a reported baseline, not a target).
+    Thread count: the best of {all usable cores, half, quarter} on one probe step each (oversubscribed MKL is slower)."""
     from oracle import torch_ref
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(1)
     x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
     y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
-    st.step(x, y)                                   # warm-up (allocations, thread pool)
+    st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+    best, best_t = None, None
+    t_begin = time.perf_counter()
+    for cores in sorted({usable, max(usable // 2, 1), max(usable // 4, 1)}, reverse=True):
+        torch.set_num_threads(cores)
+        st.step(x, y)                               # warm-up at this thread count
+        t0 = time.perf_counter()
+        st.step(x, y)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = cores, dt
+        if time.perf_counter() - t_begin > seconds:
+            break
+    torch.set_num_threads(best)
     n, t0 = 0, time.perf_counter()
     while True:
         st.step(x, y)
@@ -72,8 +85,9 @@ def cpu_baseline(B, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 200:
             break
-    return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the same B=%d fp32 MoeModel step on torch-CPU (oracle/torch_ref.py), %.1f s" % (n, B, el)}
+    return {"value": n * B / el, "unit": "videos/s", "cores": best, "kind": "port",
+            "sample": "%d steps of the same B=%d fp32 MoeModel training step on torch-CPU (oracle/torch_ref.py, TF1 itself "
+                      "is not runnable here), %.1f s, %d usable cores" % (n, B, el, usable)}
 
 
 def main():

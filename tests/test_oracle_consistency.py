@@ -23,6 +23,7 @@ def test_moe_forward_and_layout(M):
     p = np_ref.moe_model(x, Wg, We, be, M)
     pt = torch_ref.moe(T(x), T(Wg), T(We), T(be), M).numpy()
     assert np.abs(p - pt).max() < 1e-14
+    assert np.abs(p - torch_ref.moe_fast(T(x), T(Wg), T(We), T(be), M).numpy()).max() < 1e-14
     # label-major / mixture-minor bookkeeping: column l*(M+1)+m is gate m of label l (moe_model.py:40-64)
     for b in (0, B - 1):
         for l in (0, 3, V - 1):

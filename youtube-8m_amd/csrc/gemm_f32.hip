@@ -60,14 +60,17 @@ __device__ __forceinline__ const float* slot_src(const float* __restrict__ P, in
   }
 }
 
-// asynchronous fill of one tile by LDS-DMA (interior tiles of 16-byte aligned operands only)
+// asynchronous fill of one tile by LDS-DMA (16-byte aligned operands, K % 16 == 0).  Rows / columns of an EDGE tile that
+// lie beyond the matrix (gx >= X) are redirected to the last valid row / 16-byte column chunk: they only ever feed
+// output rows / columns >= M / N, which the epilogue never stores, so edge tiles run at full DMA speed too.
 template <bool KC>
-__device__ __forceinline__ void fill_dma(const float* __restrict__ P, int64_t ld, int x0, int k0, float* S, int tid) {
+__device__ __forceinline__ void fill_dma(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, float* S, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * 256;
     int gx, gk;
     const float* src = slot_src<KC>(P, ld, x0, k0, idx, gx, gk);
+    if (gx >= X) src -= KC ? (int64_t)(gx - (X - 1)) * ld : (int64_t)(gx - ((X - 1) & ~3));
     float* dst = S + (idx & ~63) * 4;  // wave-uniform base; the hardware adds lane*16 bytes
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -159,8 +162,8 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
   // K-steps [kb, ke) of this tile (a split-K part of a remainder tile processes a sub-range)
   float4 ra0, ra1, rb0, rb1;
   if (DMA) {
-    fill_dma<A_KC>(Ap, g.lda, m0, kb * BK, As, tid);
-    fill_dma<B_KC>(Bp, g.ldb, n0, kb * BK, Bs, tid);
+    fill_dma<A_KC>(Ap, g.lda, m0, kb * BK, g.M, As, tid);
+    fill_dma<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, Bs, tid);
   } else {
     ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid);
     ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid + 256);
@@ -180,8 +183,8 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
     float* Bn = Bs + (cur ^ 1) * TILE_FLOATS;
     if (DMA) {
       if (more) {
-        fill_dma<A_KC>(Ap, g.lda, m0, (kt + 1) * BK, An, tid);
-        fill_dma<B_KC>(Bp, g.ldb, n0, (kt + 1) * BK, Bn, tid);
+        fill_dma<A_KC>(Ap, g.lda, m0, (kt + 1) * BK, g.M, An, tid);
+        fill_dma<B_KC>(Bp, g.ldb, n0, (kt + 1) * BK, g.N, Bn, tid);
       }
     } else {
       const int kn = (more ? kt + 1 : kt) * BK;
@@ -232,8 +235,8 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // interior tiles of aligned operands take the LDS-DMA path (wave-uniform choice)
-  const bool dma = g.vecA && g.vecB && (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.K % BK == 0);
+  // aligned operands with K % 16 == 0 take the LDS-DMA path (edge tiles included: see fill_dma); wave-uniform choice
+  const bool dma = g.vecA && g.vecB && (g.K % BK == 0);
   if (dma) mainloop<A_KC, B_KC, true>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
   else mainloop<A_KC, B_KC, false>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
 
@@ -343,14 +346,14 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupArgs G
 
 // sums the S split-K parts of each remainder tile (fixed order) and applies the normal epilogue
 __global__ __launch_bounds__(256) void splitk_fixup_kernel(const GroupArgs G) {
-  const int rt = blockIdx.x;
+  const int rt = blockIdx.x >> 2, quarter = blockIdx.x & 3;   // 4 workgroups per remainder tile (32 rows each)
   const int tile = G.full_rounds * G.P + rt;
   const int q = find_problem(G, tile);
   const GemmArgs& g = G.p[q];
   const int lt = tile - G.tile_base[q];
   const int m0 = (lt % g.tiles_m) * BM, n0 = (lt / g.tiles_m) * BN;
   const float* base = G.ws + (int64_t)rt * G.S * (BM * BN);
-  for (int e = threadIdx.x * 4; e < BM * BN; e += 256 * 4) {
+  for (int e = quarter * (BM * BN / 4) + threadIdx.x * 4; e < (quarter + 1) * (BM * BN / 4); e += 256 * 4) {
     float4 v = *reinterpret_cast<const float4*>(base + e);
     for (int s = 1; s < G.S; ++s) {
       const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * (BM * BN) + e);
@@ -482,7 +485,7 @@ extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt
   launch_by_layout<GroupArgs>(transA, transB, gemm_f32_grouped_kernel<true, false>, gemm_f32_grouped_kernel<false, false>,
                               gemm_f32_grouped_kernel<true, true>, gemm_f32_grouped_kernel<false, true>,
                               dim3((unsigned)grid), s, G);
-  if (G.S > 1) hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)G.rem), dim3(256), 0, s, G);
+  if (G.S > 1) hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)G.rem * 4), dim3(256), 0, s, G);
   return launch_status("gemm_f32_grouped_kernel");
 }
 
