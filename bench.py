@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-reducer", action="store_true", help="exercise the RCCL reducer even at world size 1 (test aid)")
     return ap.parse_args()
 
 
@@ -111,7 +112,7 @@ def main():
 
     B = a.batch
     g = reset_default_graph(device=dev, seed=0)
-    reducer = parallel.GradReducer() if world > 1 else None
+    reducer = parallel.GradReducer() if (world > 1 or a.force_reducer) else None
     tg = train.TrainGraph(vlm.MoeModel(), batch_size=B * world, graph=g, reducer=reducer)
     xs, ys = make_pool(a.pool, B, dev, seed=1234 + rank)
 
@@ -166,6 +167,17 @@ def main():
         for fid, name in [(2, "elementwise"), (3, "optimizer")]:
             lib.yt8m_prof_get(fid, ctypes.byref(n), ctypes.byref(ms))
             fam[name] = {"launches_per_step": n.value / float(steps_p), "ms_per_step": ms.value / steps_p}
+        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_traffic.md:
+        # separate FETCH_SIZE / WRITE_SIZE passes, calibrated on the copy probe); rocprofv3 cannot run inside bench.py.
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_f32_grouped_kernel")]
+            if ks and B == 1024:
+                roof["traffic"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / len(ks)
+                roof["traffic_unit"] = "bytes/launch (L2-miss side, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.md)"
+                roof["algorithmic_bytes_per_launch"] = 4.0 * (B * D_IN + D_IN * VOCAB * (2 * MIX + 1) + B * VOCAB * (2 * MIX + 1))
+        except Exception:
+            pass
         roof["other_families"] = fam
         roof["gemm_ms_per_step"] = avg_ms * launches_step
 

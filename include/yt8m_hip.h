@@ -157,16 +157,18 @@ int yt8m_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c_
  * Wh: the recurrent rows of the cell's "weights" variable ([H,4H] block, row stride ldw).
  * cs, hs [F+1,B,H]: state history, slot 0 = initial state (caller zero-fills), slot t+1 = state after step t.
  * out [F,B,H] (may be NULL): emitted outputs, 0 on dead rows.  The time loop runs inside the library
- * (one recurrent GEMM accumulate + one gate kernel per step). */
+ * (one recurrent GEMM accumulate + one gate kernel per step).  gemm_workspace (>= yt8m_gemm_workspace_bytes(), may be
+ * NULL) lets the small per-step GEMMs ([B,H] x [H,4H]: 32 tiles) be split along K across the whole chip. */
 int yt8m_lstm_layer_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                         const int32_t* num_frames, int64_t F, int64_t B, int64_t H, float forget_bias,
-                        yt8m_stream_t stream);
+                        void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream);
 /* BPTT of one layer.  gates [F,B,4H] from fwd; dout [F,B,H] or NULL; dc_final/dh_final [B,H] or NULL (gradient
  * wrt the final carried state).  Writes dz [F,B,4H] (pre-activation gradients; the caller turns them into
  * dW_x, dW_h, db, dX with four hoisted GEMMs/column sums).  work: device scratch of 4*B*H floats. */
 int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout,
                         const float* dc_final, const float* dh_final, float* dz, float* work,
-                        const int32_t* num_frames, int64_t F, int64_t B, int64_t H, yt8m_stream_t stream);
+                        const int32_t* num_frames, int64_t F, int64_t B, int64_t H,
+                        void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream);
 
 /* ---- masked softmax over frames + renormalise (lstm_attention_max_pooling_model.py:59-60) -------
  * act [B,F,A] -> w [B,F,A]: w = mask * softmax_F(act) / sum_F(mask * softmax_F(act)).  bwd: dact from dw. */

@@ -46,8 +46,8 @@ SIGNATURES = {
     "yt8m_adam_multi": (c_int, [P, P, P, P, P, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float, P]),
     "yt8m_lstm_gates_fwd": (c_int, [P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, c_float, P]),
     "yt8m_lstm_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, P]),
-    "yt8m_lstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, P]),
-    "yt8m_lstm_layer_bwd": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_lstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_lstm_layer_bwd": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_attn_softmax_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_attn_softmax_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_softmax_rows_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),

@@ -474,7 +474,7 @@ extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt
       if (nk < min_nk) min_nk = nk;
     }
     if (S > min_nk / 8) S = min_nk / 8;     // keep >= 8 K-steps per part (pipeline fill + epilogue amortisation)
-    if (S > 8) S = 8;
+    if (S > 32) S = 32;
     if (S < 1) S = 1;
     if (S > 1 && (!workspace || workspace_bytes < (int64_t)G.rem * S * BM * BN * (int64_t)sizeof(float))) S = 1;
     G.S = S;

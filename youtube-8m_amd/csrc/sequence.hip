@@ -216,7 +216,7 @@ extern "C" int yt8m_lstm_gates_bwd(const float* gates, const float* c_prev, cons
 // ---- whole-layer drivers: the time loop lives here (host side of the library), not in Python -------------
 extern "C" int yt8m_lstm_layer_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                                    const int32_t* num_frames, int64_t F, int64_t B, int64_t H, float forget_bias,
-                                   yt8m_stream_t stream) {
+                                   void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(F >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   if (F * B * H == 0) return YT8M_OK;
   YT8M_REQUIRE(z && Wh && cs && hs, YT8M_E_BADARG, "null operand");
@@ -225,7 +225,8 @@ extern "C" int yt8m_lstm_layer_fwd(float* z, const float* Wh, int64_t ldw, float
   for (int64_t t = 0; t < F; ++t) {
     float* zt = z + t * B * 4 * H;
     // z_t += h_{t-1} . Wh        [B,H] x [H,4H]
-    int rc = yt8m_gemm_f32(0, 0, B, 4 * H, H, hs + t * BH, H, Wh, ldw, zt, 4 * H, nullptr, 1.0f, stream);
+    yt8m_gemm_problem pr = {B, 4 * H, H, hs + t * BH, H, Wh, ldw, zt, 4 * H, nullptr, 1.0f};
+    int rc = yt8m_gemm_f32_grouped(0, 0, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
     if (rc != YT8M_OK) return rc;
     rc = yt8m_lstm_gates_fwd(zt, cs + t * BH, hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH,
                              out ? out + t * BH : nullptr, num_frames, (int32_t)t, B, H, forget_bias, stream);
@@ -236,7 +237,8 @@ extern "C" int yt8m_lstm_layer_fwd(float* z, const float* Wh, int64_t ldw, float
 
 extern "C" int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout,
                                    const float* dc_final, const float* dh_final, float* dz, float* work,
-                                   const int32_t* num_frames, int64_t F, int64_t B, int64_t H, yt8m_stream_t stream) {
+                                   const int32_t* num_frames, int64_t F, int64_t B, int64_t H, void* gemm_workspace,
+                                   int64_t gemm_workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(F >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   if (F * B * H == 0) return YT8M_OK;
   YT8M_REQUIRE(gates && Wh && cs && dz && work, YT8M_E_BADARG, "null operand");
@@ -257,7 +259,8 @@ extern "C" int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t 
                                  dout ? dout + t * BH : nullptr, dzt, dc_prev, dh_prev, num_frames, (int32_t)t, B, H, stream);
     if (rc != YT8M_OK) return rc;
     // dh_{t-1} += dz_t . Wh^T    [B,4H] x [4H,H]   (Wh stored [H,4H] => transB)
-    rc = yt8m_gemm_f32(0, 1, B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f, stream);
+    yt8m_gemm_problem pr = {B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f};
+    rc = yt8m_gemm_f32_grouped(0, 1, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
     if (rc != YT8M_OK) return rc;
     float* tmp = dh_cur; dh_cur = dh_prev; dh_prev = tmp;
     tmp = dc_cur; dc_cur = dc_prev; dc_prev = tmp;

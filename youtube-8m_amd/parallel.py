@@ -54,12 +54,14 @@ class GradReducer(object):
         self._handles = []
         self._ready = None
         self._launched = None
+        self.active = False
 
     def attach(self, graph):
         """Hooks the graph and makes every rank start from rank 0's parameters."""
         self.graph = graph
-        graph.grad_ready_hook = self._on_ready if (self.overlap and self.world > 1) else None
-        if self.world > 1:
+        self.active = dist.is_initialized()
+        graph.grad_ready_hook = self._on_ready if (self.overlap and self.active) else None
+        if self.active:
             dist.broadcast(graph.params, src=0, group=self.group)
         nv = len(graph.trainable_variables())
         self._ready = [False] * nv
@@ -108,7 +110,7 @@ class GradReducer(object):
 
     def finish(self):
         """Blocks (stream-wise) until every gradient is reduced; returns gscale = 1/world."""
-        if self.world > 1:
+        if self.active:
             self._flush(final=True)
             for h in self._handles:
                 h.wait()

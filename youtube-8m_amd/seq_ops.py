@@ -33,8 +33,9 @@ class _LstmLayer(torch.autograd.Function):
         out = torch.empty((F, B, H), dtype=torch.float32, device=x_tm.device)
         nf = _nf(num_frames)
         Wh = W.data[Din:]
+        ws = ops._workspace(x_tm.device)
         _lib.check(_lib.lib().yt8m_lstm_layer_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nf), F, B, H,
-                                                  float(forget_bias), _stream()))
+                                                  float(forget_bias), _p(ws), ws.numel() * 4, _stream()))
         ctx.save_for_backward(x_tm)
         ctx.state = (z, cs, hs, nf, W, b)
         ctx.set_materialize_grads(False)
@@ -54,8 +55,9 @@ class _LstmLayer(torch.autograd.Function):
         dc_final = None if dc_final is None else _f32c(dc_final)
         dh_final = None if dh_final is None else _f32c(dh_final)
         Wh = W.data[Din:]
+        ws = ops._workspace(dev)
         _lib.check(_lib.lib().yt8m_lstm_layer_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dc_final), _p(dh_final),
-                                                  _p(dz), _p(work), _p(nf), F, B, H, _stream()))
+                                                  _p(dz), _p(work), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _stream()))
         dz2 = dz.view(F * B, 4 * H)
         if W.grad is not None:
             beta = W.grad_beta()
