@@ -125,12 +125,15 @@ int yt8m_xent_bwd(const float* p, const void* labels, int label_dtype, const flo
  * {offset, count, tensor_id, unused} with no chunk spanning two tensors; count <= 4096.
  * g_eff = g*gscale + l2[tensor]*w  (gscale = 1/world for the all-reduce mean; l2 = 1e-8 for
  * regularised weights, 0 otherwise: slim.l2_regularizer gradient).
+ * Both calls may be given a SUB-RANGE of the chunk table (chunks pointer advanced, nchunks = range length) covering
+ * the tensors [tensor_base, tensor_base + ntensors): the data-parallel step updates each gradient bucket as soon as
+ * its all-reduce has landed, while later buckets are still on the wire.
  * sqnorm: norms[tensor] = sum g_eff^2  (deterministic two-stage reduction; partial: float[nchunks]).
  * adam:   g_c = g_eff * clip/max(sqrt(norms[t]), clip) (clip<=0: no clipping);
  *         m = b1 m + (1-b1) g_c; v = b2 v + (1-b2) g_c^2; w -= lr_t * m / (sqrt(v) + eps)   [TF-1 form] */
 int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* chunks, int64_t nchunks,
-                      const float* l2, float gscale, float* partial, float* norms, int64_t ntensors,
-                      yt8m_stream_t stream);
+                      const float* l2, float gscale, float* partial, float* norms, int64_t tensor_base,
+                      int64_t ntensors, yt8m_stream_t stream);
 int yt8m_adam_multi(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
                     const float* l2, float gscale, const float* norms, float clip,
                     float lr_t, float beta1, float beta2, float eps, yt8m_stream_t stream);

@@ -279,3 +279,38 @@ def test_uint8_input_path_and_eval(dev, flags):
     em.accumulate_device(p, torch.from_numpy(y).to(dev), 1.0)
     assert em.get()["gap"] == pytest.approx(eu.calculate_gap(H(p), y.astype(np.float64), 20), abs=1e-9)
     assert em.get()["avg_hit_at_one"] == pytest.approx(eu.calculate_hit_at_one(H(p), y.astype(np.float64)))
+
+
+def test_data_parallel_step_single_rank_rccl(dev, flags):
+    """The data-parallel step (RCCL all-reduce per bucket as gradients finish, per-bucket clip+Adam, un-grouped dW
+    GEMMs) on a 1-rank `nccl` group must reproduce the plain single-process step: same loss, same weights."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import yt8m_amd.parallel as parallel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        rs = np.random.RandomState(8)
+        B, Dm, V = 256, 384, 1000
+        xs = [(rs.randn(B, Dm)).astype(np.float32) for _ in range(3)]
+        ys = [rs.rand(B, V) < 0.01 for _ in range(3)]
+        outs = []
+        for use_dp in (False, True):
+            g = reset_default_graph(device=dev, seed=11)
+            red = parallel.GradReducer(bucket_bytes=1 << 20) if use_dp else None
+            tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g, reducer=red)
+            ls = [float(tg.step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))["loss"]) for x, y in zip(xs, ys)]
+            outs.append((ls, {k: v.data.clone() for k, v in g.vars.items()}))
+            if use_dp:
+                assert red.active and red.gscale == 1.0
+        assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)
+        for k in outs[0][1]:
+            assert float((outs[0][1][k] - outs[1][1][k]).abs().max()) < 1e-6, k
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -50,7 +50,10 @@ def _worker(rank, world, port, overlap, q):
             for k in reversed(list(shapes)):
                 vs[k].grad.fill_(float(rank + 1) * (step + 1))
                 vs[k].grad_done()
-            gscale = red.finish()
+            order = list(red.finished_buckets())            # buckets complete in launch order, covering every variable once
+            assert sorted(i for lo, hi in order for i in range(lo, hi)) == list(range(len(shapes)))
+            assert len(order) >= 2 if overlap else len(order) == 1
+            gscale = red.gscale
             assert gscale == 0.5
             for k in shapes:
                 assert torch.all(vs[k].grad == 3.0 * (step + 1)), (k, vs[k].grad.flatten()[:3])

@@ -271,16 +271,24 @@ def topk_rows(p, k=20):
     return vals, idx
 
 
-def sqnorm_and_adam(graph, lr_t, gscale=1.0, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
-    """Per-tensor clip + TF-Adam over the whole arena (two multi-tensor passes)."""
+def sqnorm_and_adam(graph, lr_t, gscale=1.0, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8, tensors=None):
+    """Per-tensor clip + TF-Adam over the arena (two multi-tensor passes).  tensors = (lo, hi) restricts the update
+    to trainable variables lo..hi-1 (a contiguous slice of the chunk table)."""
     _dev(graph.params)
     L = _lib.lib()
     s = _stream()
+    nt = len(graph.trainable_variables())
+    lo, hi = (0, nt) if tensors is None else tensors
+    if hi <= lo:
+        return
+    c0, c1 = graph.chunk_start[lo], graph.chunk_start[hi]
+    chunks = ctypes.c_void_p(graph.chunks.data_ptr() + 16 * c0)
+    partial = ctypes.c_void_p(graph.partial.data_ptr() + 4 * c0)
     if clip > 0:
-        _lib.check(L.yt8m_sqnorm_multi(_p(graph.params), _p(graph.grads), _p(graph.chunks), graph.nchunks, _p(graph.l2),
-                                       gscale, _p(graph.partial), _p(graph.norms), len(graph.trainable_variables()), s))
-    _lib.check(L.yt8m_adam_multi(_p(graph.params), _p(graph.adam_m), _p(graph.adam_v), _p(graph.grads), _p(graph.chunks),
-                                 graph.nchunks, _p(graph.l2), gscale, _p(graph.norms), clip, lr_t, beta1, beta2, eps, s))
+        _lib.check(L.yt8m_sqnorm_multi(_p(graph.params), _p(graph.grads), chunks, c1 - c0, _p(graph.l2), gscale, partial,
+                                       _p(graph.norms), lo, hi - lo, s))
+    _lib.check(L.yt8m_adam_multi(_p(graph.params), _p(graph.adam_m), _p(graph.adam_v), _p(graph.grads), chunks, c1 - c0,
+                                 _p(graph.l2), gscale, _p(graph.norms), clip, lr_t, beta1, beta2, eps, s))
 
 
 # ------------------------------------------------------------------------------------------ autograd ops
@@ -381,10 +389,17 @@ class _MoeHead(torch.autograd.Function):
         V, M = ctx.VM
         ctx.Z = None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
-        if Wg.grad is not None and We.grad is not None:
+        overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
+        if Wg.grad is not None and We.grad is not None and not overlap:
             gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
                           dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True)
             Wg.grad_done()
+            We.grad_done()
+        elif Wg.grad is not None and We.grad is not None:
+            # data-parallel: finish the big gate gradient first so its all-reduce rides under the expert GEMM
+            gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta())
+            Wg.grad_done()
+            gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta())
             We.grad_done()
         if be.grad is not None:
             colsum(Ze, be.grad.view(-1), beta=be.grad_beta())

@@ -99,20 +99,37 @@ class GradReducer(object):
             if final or hi - lo >= self.bucket_elems:
                 # split very large runs so that several rings/links are in flight
                 pos = lo
+                hs = []
                 while pos < hi:
                     end = min(hi, pos + 4 * self.bucket_elems)
-                    h = dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    self._handles.append(h)
+                    hs.append(dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     pos = end
+                self._handles.append((i, j + 1, hs))      # trainable variables [i, j+1) ride on these handles
                 for k in range(i, j + 1):
                     self._launched[k] = True
             i = j + 1
 
-    def finish(self):
-        """Blocks (stream-wise) until every gradient is reduced; returns gscale = 1/world."""
-        if self.active:
-            self._flush(final=True)
-            for h in self._handles:
+    def finished_buckets(self):
+        """Yields (lo, hi) ranges of trainable-variable indices in the order their all-reduces were launched, each
+        after waiting (stream-wise for RCCL) for that bucket only -- the caller runs clip+Adam on the bucket while later
+        buckets are still on the wire.  Without an initialised process group: one bucket with everything."""
+        n = len(self._ready) if self._ready is not None else len(self.graph.trainable_variables())
+        if not self.active:
+            yield (0, n)
+            return
+        self._flush(final=True)
+        for lo, hi, hs in self._handles:
+            for h in hs:
                 h.wait()
-            self._handles = []
+            yield (lo, hi)
+        self._handles = []
+
+    @property
+    def gscale(self):
         return 1.0 / self.world
+
+    def finish(self):
+        """Waits for every bucket; returns gscale = 1/world (the mean is folded into the optimiser pass)."""
+        for _ in self.finished_buckets():
+            pass
+        return self.gscale

@@ -100,13 +100,17 @@ class TrainGraph(object):
             if not v.grad_written:                              # (None gradient); here their gradient is zero
                 v.grad.zero_()
                 v.grad_written = True
-        gscale = 1.0
-        if self.reducer is not None:
-            gscale = self.reducer.finish()                      # all grads summed over ranks; mean folded into gscale
         lr = exponential_decay(self.base_learning_rate, self.global_step, self.batch_size, self.decay_examples, self.decay)
         t = self.global_step + 1
         lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
-        ops.sqnorm_and_adam(g, lr_t, gscale=gscale, clip=self.clip, beta1=self.b1, beta2=self.b2, eps=self.eps)
+        if self.reducer is None:
+            ops.sqnorm_and_adam(g, lr_t, gscale=1.0, clip=self.clip, beta1=self.b1, beta2=self.b2, eps=self.eps)
+        else:
+            # gradients are SUMMED over ranks bucket by bucket; the 1/world mean is folded into the optimiser pass, and
+            # each bucket is clipped + updated as soon as ITS all-reduce has landed (later buckets still on the wire)
+            for lo, hi in self.reducer.finished_buckets():
+                ops.sqnorm_and_adam(g, lr_t, gscale=self.reducer.gscale, clip=self.clip, beta1=self.b1, beta2=self.b2,
+                                    eps=self.eps, tensors=(lo, hi))
         self.global_step += 1
         return {"loss": label_loss.detach(), "predictions": result["predictions"].detach(),
                 "global_step": self.global_step, "learning_rate": lr}

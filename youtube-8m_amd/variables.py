@@ -159,7 +159,9 @@ class Graph(object):
         self.adam_m = torch.zeros_like(self.params)
         self.adam_v = torch.zeros_like(self.params)
         chunks, l2 = [], []
+        self.chunk_start = []          # first chunk of tensor i; chunk_start[ntensors] = nchunks
         for v in tv:
+            self.chunk_start.append(len(chunks))
             n = v.numel()
             dst = self.params[v.offset:v.offset + n].view(v.data.shape)
             dst.copy_(v.data)
@@ -169,6 +171,7 @@ class Graph(object):
             for c0 in range(0, n, CHUNK):
                 chunks.append((v.offset + c0, min(CHUNK, n - c0), v.index, 0))
         self.nchunks = len(chunks)
+        self.chunk_start.append(len(chunks))
         self.chunks = torch.tensor(chunks if chunks else [(0, 0, 0, 0)], dtype=torch.int32).to(dev).contiguous()
         self.l2 = torch.tensor(l2 if l2 else [0.0], dtype=torch.float32).to(dev)
         self.norms = torch.zeros(max(len(tv), 1), dtype=torch.float32, device=dev)
