@@ -247,15 +247,18 @@ def test_topk_rows(dev):
     assert v2.shape == (B, 7)
 
 
-def test_lstm_layer_fwd_bwd(dev):
-    """Whole-layer recurrence (ragged num_frames incl. 0 and F) vs the oracle, gradients vs torch autograd fp64."""
+@pytest.mark.parametrize("B,F,Din,Hh", [(5, 9, 6, 4), (37, 6, 20, 128), (64, 4, 16, 256)])
+def test_lstm_layer_fwd_bwd(dev, B, F, Din, Hh):
+    """Whole-layer recurrence (ragged num_frames incl. 0 and F) vs the oracle, gradients vs torch autograd fp64.
+    H = 4 takes the generic per-step GEMM path, H = 128 / 256 the fused one-launch-per-step kernels (lstm_fused.hip),
+    with B not a multiple of the 32 / 16 row tiles."""
     from oracle import torch_ref
     from yt8m_amd.variables import reset_default_graph, xavier_uniform, zeros
     rs = np.random.RandomState(7)
-    B, F, Din, Hh = 5, 9, 6, 4
     x = rs.randn(B, F, Din).astype(np.float32)
-    nf = np.array([9, 1, 4, 0, 9], dtype=np.int32)
-    W = (rs.randn(Din + Hh, 4 * Hh) * 0.4).astype(np.float32)
+    nf = rs.randint(0, F + 1, size=B).astype(np.int32)
+    nf[:5] = [F, 1, min(4, F), 0, F]
+    W = (rs.randn(Din + Hh, 4 * Hh) * (0.4 if Hh < 64 else 0.08)).astype(np.float32)
     b = (rs.randn(4 * Hh) * 0.1).astype(np.float32)
     g = reset_default_graph(device=dev)
     g.begin_step()

@@ -22,6 +22,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int TILE_FLOATS = BK * 128;  // one operand tile in LDS (8 KiB), no padding
+constexpr int STAGES = 3;               // LDS-DMA pipeline depth (3 x 16 KiB per workgroup, 3 workgroups per CU = 144 KiB)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -108,6 +109,21 @@ __device__ __forceinline__ float4 load_guarded(const float* __restrict__ P, int6
   return r;
 }
 
+// fill of K-step kt into a stage: LDS-DMA when the step lies wholly inside K, guarded zero-padded store for the K tail
+// (K % 16 != 0: e.g. the 300-frame reduction of the NetVLAD / attention aggregation, the 4716-wide chain FC)
+template <bool KC>
+__device__ __forceinline__ void fill_step(const float* __restrict__ P, int64_t ld, int x0, int kt, int X, int K, float* S,
+                                          int tid) {
+  if ((kt + 1) * BK <= K) {
+    fill_dma<KC>(P, ld, x0, kt * BK, X, S, tid);
+  } else {
+    const float4 r0 = load_guarded<KC>(P, ld, x0, kt * BK, X, K, true, tid);
+    const float4 r1 = load_guarded<KC>(P, ld, x0, kt * BK, X, K, true, tid + 256);
+    *reinterpret_cast<float4*>(&S[tid * 4]) = r0;
+    *reinterpret_cast<float4*>(&S[(tid + 256) * 4]) = r1;
+  }
+}
+
 // ---- MFMA operand fragments -------------------------------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32 takes, per lane, ONE A value A[i = lane&31][k = lane>>5] and one B value.  Which two k of
 // the K-step an MFMA reduces is free as long as A and B agree, so step (h, j), h in {0,1}, j in {0..3}, uses
@@ -150,9 +166,12 @@ __device__ __forceinline__ void mma_step(const Frag& fa, const Frag& fb, f32x16 
 }
 
 // One pass over K for a workgroup tile.
-//  DMA path   : the next K-step is issued as LDS-DMA at the TOP of the iteration (side-effecting => it stays there),
-//               lands during the 32 MFMAs (2048 matrix-pipe cycles) and is waited for by the barrier's vmcnt(0).
-//  guarded path: register staging; used by edge tiles / unaligned operands / K % 16 != 0.
+//  DMA path    : 3 LDS stages.  K-step kt+2 is issued as LDS-DMA at the TOP of iteration kt (side-effecting => it stays
+//                there) and has two MFMA blocks (2 x 2048 matrix-pipe cycles) to land; the wait before the barrier is a
+//                COUNTED vmcnt(4) -- each lane has exactly 4 DMA instructions per K-step in flight order -- so only
+//                K-step kt+1 is waited for, kt+2 stays on the wire across the barrier (raw s_barrier: __syncthreads()
+//                would drain vmcnt(0)).  A stage is re-filled two barriers after its last ds_read.
+//  guarded path: register staging, 2 stages; used for unaligned operands / K % 16 != 0.
 // In both, every fragment of the K-step is fetched from LDS before the first MFMA (sched_barrier pins the order) so
 // the LDS latency is paid once per K-step and the MFMAs stream.
 template <bool A_KC, bool B_KC, bool DMA>
@@ -160,53 +179,70 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
                                          float* __restrict__ As, float* __restrict__ Bs, int m0, int n0, int kb, int ke,
                                          int tid, int wm, int wn, int li, int lk, f32x16 (&acc)[2][2]) {
   // K-steps [kb, ke) of this tile (a split-K part of a remainder tile processes a sub-range)
-  float4 ra0, ra1, rb0, rb1;
   if (DMA) {
-    fill_dma<A_KC>(Ap, g.lda, m0, kb * BK, g.M, As, tid);
-    fill_dma<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, Bs, tid);
-  } else {
-    ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid);
-    ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid + 256);
-    rb0 = load_guarded<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, g.K, g.vecB, tid);
-    rb1 = load_guarded<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, g.K, g.vecB, tid + 256);
-    *reinterpret_cast<float4*>(&As[tid * 4]) = ra0;
-    *reinterpret_cast<float4*>(&As[(tid + 256) * 4]) = ra1;
-    *reinterpret_cast<float4*>(&Bs[tid * 4]) = rb0;
-    *reinterpret_cast<float4*>(&Bs[(tid + 256) * 4]) = rb1;
+    fill_step<A_KC>(Ap, g.lda, m0, kb, g.M, g.K, As, tid);
+    fill_step<B_KC>(Bp, g.ldb, n0, kb, g.N, g.K, Bs, tid);
+    if (kb + 1 < ke) {
+      fill_step<A_KC>(Ap, g.lda, m0, kb + 1, g.M, g.K, As + TILE_FLOATS, tid);
+      fill_step<B_KC>(Bp, g.ldb, n0, kb + 1, g.N, g.K, Bs + TILE_FLOATS, tid);
+    }
+    // the K-tail step (if any) is the LAST one: whenever it has been stored above there is nothing younger in flight, so
+    // a full drain is exact; otherwise leave K-step kb+1's 4 DMAs on the wire
+    if (kb + 2 < ke || (kb + 1 < ke && (ke * BK <= g.K))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = kb; kt < ke; ++kt) {
+      const int nxt2 = cur >= 1 ? cur - 1 : 2;           // (cur + 2) % 3
+      if (kt + 2 < ke) {
+        fill_step<A_KC>(Ap, g.lda, m0, kt + 2, g.M, g.K, As + nxt2 * TILE_FLOATS, tid);
+        fill_step<B_KC>(Bp, g.ldb, n0, kt + 2, g.N, g.K, Bs + nxt2 * TILE_FLOATS, tid);
+      }
+      Frag fa, fb;
+      load_frag<A_KC>(As + cur * TILE_FLOATS, wm, li, lk, fa);
+      load_frag<B_KC>(Bs + cur * TILE_FLOATS, wn, li, lk, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(fa, fb, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      // K-step kt+1 must have landed; kt+2 may stay in flight -- unless kt+2 was the guarded K-tail store (then it is
+      // not a DMA: nothing younger than kt+1 is in flight, drain everything incl. the ds_writes)
+      if (kt + 2 < ke && (kt + 3) * BK <= g.K) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    return;
   }
+  float4 ra0, ra1, rb0, rb1;
+  ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid);
+  ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kb * BK, g.M, g.K, g.vecA, tid + 256);
+  rb0 = load_guarded<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, g.K, g.vecB, tid);
+  rb1 = load_guarded<B_KC>(Bp, g.ldb, n0, kb * BK, g.N, g.K, g.vecB, tid + 256);
+  *reinterpret_cast<float4*>(&As[tid * 4]) = ra0;
+  *reinterpret_cast<float4*>(&As[(tid + 256) * 4]) = ra1;
+  *reinterpret_cast<float4*>(&Bs[tid * 4]) = rb0;
+  *reinterpret_cast<float4*>(&Bs[(tid + 256) * 4]) = rb1;
   __syncthreads();
-
   int cur = 0;
   for (int kt = kb; kt < ke; ++kt) {
     const bool more = kt + 1 < ke;
     float* An = As + (cur ^ 1) * TILE_FLOATS;
     float* Bn = Bs + (cur ^ 1) * TILE_FLOATS;
-    if (DMA) {
-      if (more) {
-        fill_dma<A_KC>(Ap, g.lda, m0, (kt + 1) * BK, g.M, An, tid);
-        fill_dma<B_KC>(Bp, g.ldb, n0, (kt + 1) * BK, g.N, Bn, tid);
-      }
-    } else {
-      const int kn = (more ? kt + 1 : kt) * BK;
-      ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kn, g.M, g.K, g.vecA, tid);
-      ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kn, g.M, g.K, g.vecA, tid + 256);
-      rb0 = load_guarded<B_KC>(Bp, g.ldb, n0, kn, g.N, g.K, g.vecB, tid);
-      rb1 = load_guarded<B_KC>(Bp, g.ldb, n0, kn, g.N, g.K, g.vecB, tid + 256);
-    }
+    const int kn = (more ? kt + 1 : kt) * BK;
+    ra0 = load_guarded<A_KC>(Ap, g.lda, m0, kn, g.M, g.K, g.vecA, tid);
+    ra1 = load_guarded<A_KC>(Ap, g.lda, m0, kn, g.M, g.K, g.vecA, tid + 256);
+    rb0 = load_guarded<B_KC>(Bp, g.ldb, n0, kn, g.N, g.K, g.vecB, tid);
+    rb1 = load_guarded<B_KC>(Bp, g.ldb, n0, kn, g.N, g.K, g.vecB, tid + 256);
     Frag fa, fb;
     load_frag<A_KC>(As + cur * TILE_FLOATS, wm, li, lk, fa);
     load_frag<B_KC>(Bs + cur * TILE_FLOATS, wn, li, lk, fb);
     __builtin_amdgcn_sched_barrier(0);
     mma_step(fa, fb, acc);
-    // pin again: hipcc otherwise hoists the barrier (and its vmcnt(0) drain of the in-flight DMA) above the
-    // register-only MFMAs, which would expose the whole memory latency every K-step
     __builtin_amdgcn_sched_barrier(0);
-    if (!DMA) {
-      *reinterpret_cast<float4*>(&An[tid * 4]) = ra0;
-      *reinterpret_cast<float4*>(&An[(tid + 256) * 4]) = ra1;
-      *reinterpret_cast<float4*>(&Bn[tid * 4]) = rb0;
-      *reinterpret_cast<float4*>(&Bn[(tid + 256) * 4]) = rb1;
-    }
+    *reinterpret_cast<float4*>(&An[tid * 4]) = ra0;
+    *reinterpret_cast<float4*>(&An[(tid + 256) * 4]) = ra1;
+    *reinterpret_cast<float4*>(&Bn[tid * 4]) = rb0;
+    *reinterpret_cast<float4*>(&Bn[(tid + 256) * 4]) = rb1;
     __syncthreads();
     cur ^= 1;
   }
@@ -219,8 +255,8 @@ template <bool A_KC, bool B_KC>
 __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __restrict__ Ap, const float* __restrict__ Bp,
                                              float* __restrict__ Cp, float* __restrict__ smem, int tm, int tn, int kb,
                                              int ke, float* __restrict__ ws) {
-  float* const As = smem;                     // As + buf * TILE_FLOATS
-  float* const Bs = smem + 2 * TILE_FLOATS;   // Bs + buf * TILE_FLOATS
+  float* const As = smem;                          // As + stage * TILE_FLOATS
+  float* const Bs = smem + STAGES * TILE_FLOATS;   // Bs + stage * TILE_FLOATS
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -235,8 +271,8 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // aligned operands with K % 16 == 0 take the LDS-DMA path (edge tiles included: see fill_dma); wave-uniform choice
-  const bool dma = g.vecA && g.vecB && (g.K % BK == 0);
+  // 16-byte aligned operands take the LDS-DMA path (edge tiles and the K tail included: see fill_dma / fill_step)
+  const bool dma = g.vecA && g.vecB;
   if (dma) mainloop<A_KC, B_KC, true>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
   else mainloop<A_KC, B_KC, false>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
 
@@ -284,7 +320,7 @@ __device__ __forceinline__ int xcd_remap(int wg, int n) {
 // A_KC: A stored [M,K] (transA = 0).  B_KC: B stored [N,K] (transB = 1).
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGES * TILE_FLOATS];
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;  // M-tiles fastest: neighbours share the B panel
   process_tile<A_KC, B_KC>(g, g.A + (int64_t)blockIdx.y * g.strideA, g.B + (int64_t)blockIdx.y * g.strideB,
@@ -318,7 +354,7 @@ __device__ __forceinline__ int find_problem(const GroupArgs& G, int tile) {
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupArgs G) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGES * TILE_FLOATS];
   // One work item per workgroup; the grid is full_rounds*P whole tiles followed by rem*S split-K parts.  The hardware
   // dispatcher hands out workgroups in id order, 3 resident per CU, so the whole-tile rounds run K-synchronised and the
   // parts backfill the slots freed by the last round.

@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 
 using namespace yt8m;
 
+namespace yt8m {  // lstm_fused.hip
+bool lstm_fused_supported(int64_t B, int64_t H, int64_t workspace_bytes);
+int lstm_pack(const float* Wh, int64_t ldw, float* Wp, float* Wq, int64_t H, hipStream_t s);
+int lstm_step_fwd(float* z, const float* Wp, const float* c_prev, const float* h_prev, float* c_new, float* h_new, float* out,
+                  const int32_t* nf, int t, int64_t B, int64_t H, float fb, hipStream_t s);
+int lstm_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, hipStream_t s);
+}  // namespace yt8m
+
 extern "C" int yt8m_lstm_gates_fwd(float* z, const float* c_prev, const float* h_prev, float* c_new, float* h_new,
                                    float* out, const int32_t* num_frames, int32_t t, int64_t B, int64_t H,
                                    float forget_bias, yt8m_stream_t stream) {
@@ -222,6 +230,16 @@ extern "C" int yt8m_lstm_layer_fwd(float* z, const float* Wh, int64_t ldw, float
   YT8M_REQUIRE(z && Wh && cs && hs, YT8M_E_BADARG, "null operand");
   YT8M_REQUIRE(ldw >= 4 * H, YT8M_E_SHAPE, "ldw < 4H");
   const int64_t BH = B * H;
+  if (gemm_workspace && lstm_fused_supported(B, H, gemm_workspace_bytes)) {
+    // fused path: one launch per step (recurrent product + gates + copy-through), W_h re-packed once per call
+    ProfScope prof(F_LSTM, as_stream(stream));
+    float* Wp = static_cast<float*>(gemm_workspace);
+    int rc = lstm_pack(Wh, ldw, Wp, nullptr, H, as_stream(stream));
+    for (int64_t t = 0; t < F && rc == YT8M_OK; ++t)
+      rc = lstm_step_fwd(z + t * B * 4 * H, Wp, cs + t * BH, hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH,
+                         out ? out + t * BH : nullptr, num_frames, (int)t, B, H, forget_bias, as_stream(stream));
+    return rc;
+  }
   for (int64_t t = 0; t < F; ++t) {
     float* zt = z + t * B * 4 * H;
     // z_t += h_{t-1} . Wh        [B,H] x [H,4H]
@@ -253,14 +271,24 @@ extern "C" int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t 
   else YT8M_HIP_CHECK(hipMemsetAsync(dh_cur, 0, BH * sizeof(float), s));
   if (dc_final) YT8M_HIP_CHECK(hipMemcpyAsync(dc_cur, dc_final, BH * sizeof(float), hipMemcpyDeviceToDevice, s));
   else YT8M_HIP_CHECK(hipMemsetAsync(dc_cur, 0, BH * sizeof(float), s));
+  const bool fused = gemm_workspace && lstm_fused_supported(B, H, gemm_workspace_bytes);
+  float* Wq = static_cast<float*>(gemm_workspace);
+  if (fused) {
+    int rc = lstm_pack(Wh, ldw, nullptr, Wq, H, s);
+    if (rc != YT8M_OK) return rc;
+  }
   for (int64_t t = F - 1; t >= 0; --t) {
     float* dzt = dz + t * B * 4 * H;
     int rc = yt8m_lstm_gates_bwd(gates + t * B * 4 * H, cs + t * BH, cs + (t + 1) * BH, dh_cur, dc_cur,
                                  dout ? dout + t * BH : nullptr, dzt, dc_prev, dh_prev, num_frames, (int32_t)t, B, H, stream);
     if (rc != YT8M_OK) return rc;
     // dh_{t-1} += dz_t . Wh^T    [B,4H] x [4H,H]   (Wh stored [H,4H] => transB)
-    yt8m_gemm_problem pr = {B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f};
-    rc = yt8m_gemm_f32_grouped(0, 1, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
+    if (fused) {
+      rc = lstm_step_bwd(dzt, Wq, dh_prev, B, H, s);
+    } else {
+      yt8m_gemm_problem pr = {B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f};
+      rc = yt8m_gemm_f32_grouped(0, 1, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
+    }
     if (rc != YT8M_OK) return rc;
     float* tmp = dh_cur; dh_cur = dh_prev; dh_prev = tmp;
     tmp = dc_cur; dc_cur = dc_prev; dc_prev = tmp;
