@@ -111,6 +111,9 @@ def main():
     L.lib()
 
     B = a.batch
+    if os.environ.get("YT8M_FUSED_HEAD_LOSS") == "0":     # A/B aid
+        from yt8m_amd.flags import FLAGS
+        FLAGS.fused_head_loss = False
     g = reset_default_graph(device=dev, seed=0)
     reducer = parallel.GradReducer() if (world > 1 or a.force_reducer) else None
     tg = train.TrainGraph(vlm.MoeModel(), batch_size=B * world, graph=g, reducer=reducer)

@@ -97,6 +97,17 @@ int yt8m_moe_mix_fwd(const float* Zg, const float* Ze, float* p, int64_t B, int6
 int yt8m_moe_mix_bwd(float* Zg, float* Ze, const float* dp, int64_t B, int64_t V, int M,
                      yt8m_stream_t stream);
 
+/* MoE mixing fused with CrossEntropyLoss (W/losses.py:110-130 applied to MoeModel's output; the reference lets a
+ * model return its own "loss", W/train.py:384-385): fwd writes p AND loss = mean_b sum_l CE(p, y) in one pass over Z;
+ * bwd forms dL/dp from the recomputed p and the labels in registers and overwrites Zg/Ze with dL/dZ (no dp tensor).
+ * workspace >= yt8m_moe_mix_xent_workspace_bytes(B, V).  upstream_dev: device float[1] or NULL. */
+int64_t yt8m_moe_mix_xent_workspace_bytes(int64_t B, int64_t V);
+int yt8m_moe_mix_xent_fwd(const float* Zg, const float* Ze, const void* labels, int label_dtype, float* p,
+                          float* loss_out, int64_t B, int64_t V, int M, float eps, void* workspace,
+                          yt8m_stream_t stream);
+int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev,
+                          int64_t B, int64_t V, int M, float eps, float upstream, yt8m_stream_t stream);
+
 /* ---- elementwise activations + column sums (bias gradients) ------------------------------------ */
 enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8M_ACT_TANH = 3, YT8M_ACT_ELU = 4 };
 int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream);

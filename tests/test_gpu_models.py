@@ -314,3 +314,39 @@ def test_data_parallel_step_single_rank_rccl(dev, flags):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("label_kind", ["bool", "f32"])
+def test_fused_head_loss_equals_unfused(dev, flags, label_kind):
+    """MoeModel's fused mixing + CrossEntropyLoss path (returns its own "loss", W/train.py:384-385) against the
+    unfused model -> losses.CrossEntropyLoss path and the fp64 oracle: loss, predictions and every gradient."""
+    rs = np.random.RandomState(12)
+    B, Dm, V, M = 37, 50, 301, 2
+    x = rs.randn(B, Dm).astype(np.float32)
+    y = rs.rand(B, V) < 0.03
+    ylab = y if label_kind == "bool" else (y * 0.9 + 0.01).astype(np.float32)        # soft labels take the f32 kernel
+    res = {}
+    for fused in (True, False):
+        flags.fused_head_loss = fused
+        g, r, loss, P = run_model(vlm.MoeModel(), x, ylab, dev, rs=np.random.RandomState(5))
+        assert ("loss" in r) == fused
+        res[fused] = (float(loss), H(r["predictions"]), grads_of(g), P)
+    assert res[True][0] == pytest.approx(res[False][0], rel=1e-6)
+    assert np.abs(res[True][1] - res[False][1]).max() < 1e-7
+    for k in res[True][2]:
+        assert np.abs(res[True][2][k] - res[False][2][k]).max() <= 1e-6 * max(1.0, np.abs(res[False][2][k]).max()), k
+    P = res[True][3]
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    pr = torch_ref.moe(T(x), tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], M)
+    lr = torch_ref.cross_entropy(pr, T(np.asarray(ylab, dtype=np.float64)))
+    lr.backward()
+    assert abs(res[True][0] - lr.item()) < 1e-4 * abs(lr.item())
+    for k, t in tp.items():
+        assert np.abs(res[True][2][k] - t.grad.numpy()).max() <= 2e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k
+    # per-example weights are a loss-side feature: the trainer turns the fusion off for that call
+    g = reset_default_graph(device=dev, seed=0)
+    flags.fused_head_loss = True
+    tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g)
+    w = torch.rand(B, device=dev)
+    out = tg.step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), weights=w)
+    assert torch.isfinite(out["loss"])

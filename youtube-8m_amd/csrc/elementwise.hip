@@ -65,6 +65,74 @@ __global__ __launch_bounds__(256) void moe_mix_bwd_kernel(float* __restrict__ Zg
   }
 }
 
+// ---- MoE mixing fused with CrossEntropyLoss (W/losses.py:110-130): the head's probabilities never make an extra
+// HBM round trip.  fwd: p and the per-workgroup loss partials in one pass over Z; bwd: dL/dp is formed from the
+// recomputed p and the labels in registers and folded straight into dL/dZ (in place).
+template <int MT, typename LT>
+__global__ __launch_bounds__(256) void moe_mix_xent_fwd_kernel(const float* __restrict__ Zg, const float* __restrict__ Ze,
+                                                               const LT* __restrict__ y, float* __restrict__ p,
+                                                               float* __restrict__ partial, int64_t BV, int Mrt, float eps) {
+  __shared__ float red[4];
+  const int M = MT > 0 ? MT : Mrt;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float ce = 0.f;
+  if (i < BV) {
+    const float* g = Zg + i * (M + 1);
+    const float* e = Ze + i * M;
+    float gl[MT > 0 ? MT + 1 : MAXM + 1];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m <= M; ++m) { gl[m] = g[m]; mx = fmaxf(mx, gl[m]); }
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int m = 0; m <= M; ++m) {
+      const float ex = expf(gl[m] - mx);
+      den += ex;
+      if (m < M) num += ex * (1.0f / (1.0f + expf(-e[m])));
+    }
+    const float pv = num / den;
+    p[i] = pv;
+    const float yv = (float)y[i];
+    ce = -(yv * logf(pv + eps) + (1.0f - yv) * logf(1.0f - pv + eps));
+  }
+  ce = block_sum_256(ce, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = ce;
+}
+
+template <int MT, typename LT>
+__global__ __launch_bounds__(256) void moe_mix_xent_bwd_kernel(float* __restrict__ Zg, float* __restrict__ Ze,
+                                                               const LT* __restrict__ y, int64_t BV, int Mrt, float eps,
+                                                               float dscale, const float* __restrict__ up_dev) {
+  const int M = MT > 0 ? MT : Mrt;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BV) return;
+  if (up_dev) dscale *= up_dev[0];
+  float* g = Zg + i * (M + 1);
+  float* e = Ze + i * M;
+  float gs[MT > 0 ? MT + 1 : MAXM + 1], es[MT > 0 ? MT + 1 : MAXM + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) { gs[m] = g[m]; mx = fmaxf(mx, gs[m]); }
+  float den = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) { gs[m] = expf(gs[m] - mx); den += gs[m]; }
+  const float inv = 1.0f / den;
+  float pv = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) {
+    gs[m] *= inv;
+    es[m] = (m < M) ? 1.0f / (1.0f + expf(-e[m])) : 0.f;
+    pv += gs[m] * es[m];
+  }
+  const float yv = (float)y[i];
+  const float d = -(yv / (pv + eps) - (1.0f - yv) / (1.0f - pv + eps)) * dscale;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) {
+    g[m] = d * gs[m] * (es[m] - pv);
+    if (m < M) e[m] = d * gs[m] * es[m] * (1.0f - es[m]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {
@@ -149,13 +217,20 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ p, 
   }
 }
 
-__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partial, int64_t n, float scale,
-                                                        float* __restrict__ out) {
-  __shared__ float red[4];
+// fixed-order final reduction of the per-workgroup partials (any blockDim that is a multiple of 64, <= 1024)
+__global__ __launch_bounds__(1024) void final_sum_kernel(const float* __restrict__ partial, int64_t n, float scale,
+                                                         float* __restrict__ out) {
+  __shared__ float red[16];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += partial[i];
-  s = block_sum_256(s, red);
-  if (threadIdx.x == 0) out[0] = s * scale;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    out[0] = t * scale;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,6 +359,60 @@ extern "C" int yt8m_moe_mix_bwd(float* Zg, float* Ze, const float* dp, int64_t B
     default: hipLaunchKernelGGL((moe_mix_bwd_kernel<0>), grid, block, 0, s, Zg, Ze, dp, BV, M); break;
   }
   return launch_status("moe_mix_bwd_kernel");
+}
+
+#define YT8M_DISPATCH_M(KERNEL, LT, ...)                                                                 \
+  switch (M) {                                                                                          \
+    case 1: hipLaunchKernelGGL((KERNEL<1, LT>), grid, block, 0, s, __VA_ARGS__); break;                  \
+    case 2: hipLaunchKernelGGL((KERNEL<2, LT>), grid, block, 0, s, __VA_ARGS__); break;                  \
+    case 4: hipLaunchKernelGGL((KERNEL<4, LT>), grid, block, 0, s, __VA_ARGS__); break;                  \
+    case 8: hipLaunchKernelGGL((KERNEL<8, LT>), grid, block, 0, s, __VA_ARGS__); break;                  \
+    default: hipLaunchKernelGGL((KERNEL<0, LT>), grid, block, 0, s, __VA_ARGS__); break;                 \
+  }
+
+extern "C" int64_t yt8m_moe_mix_xent_workspace_bytes(int64_t B, int64_t V) {
+  if (B < 0 || V < 0) return 0;
+  return (int64_t)sizeof(float) * ((B * V + 255) / 256 + 1);
+}
+
+extern "C" int yt8m_moe_mix_xent_fwd(const float* Zg, const float* Ze, const void* labels, int label_dtype, float* p,
+                                     float* loss_out, int64_t B, int64_t V, int M, float eps, void* workspace,
+                                     yt8m_stream_t stream) {
+  YT8M_REQUIRE(M >= 1 && M <= MAXM, YT8M_E_BADARG, "num_mixtures must be in [1,16]");
+  YT8M_REQUIRE(B > 0 && V > 0, YT8M_E_SHAPE, "empty batch: reduce_mean over 0 rows is undefined");
+  YT8M_REQUIRE(Zg && Ze && labels && p && loss_out && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(label_dtype == YT8M_LABEL_U8 || label_dtype == YT8M_LABEL_F32, YT8M_E_BADARG, "label dtype");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t BV = B * V;
+  dim3 grid((unsigned)((BV + 255) / 256)), block(256);
+  float* partial = static_cast<float*>(workspace);
+  if (label_dtype == YT8M_LABEL_U8) {
+    YT8M_DISPATCH_M(moe_mix_xent_fwd_kernel, uint8_t, Zg, Ze, static_cast<const uint8_t*>(labels), p, partial, BV, M, eps)
+  } else {
+    YT8M_DISPATCH_M(moe_mix_xent_fwd_kernel, float, Zg, Ze, static_cast<const float*>(labels), p, partial, BV, M, eps)
+  }
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(1024), 0, s, partial, (int64_t)grid.x, 1.0f / (float)B, loss_out);
+  return launch_status("moe_mix_xent_fwd_kernel");
+}
+
+extern "C" int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev,
+                                     int64_t B, int64_t V, int M, float eps, float upstream, yt8m_stream_t stream) {
+  YT8M_REQUIRE(M >= 1 && M <= MAXM, YT8M_E_BADARG, "num_mixtures must be in [1,16]");
+  YT8M_REQUIRE(B > 0 && V > 0, YT8M_E_SHAPE, "empty batch");
+  YT8M_REQUIRE(Zg && Ze && labels, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(label_dtype == YT8M_LABEL_U8 || label_dtype == YT8M_LABEL_F32, YT8M_E_BADARG, "label dtype");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t BV = B * V;
+  dim3 grid((unsigned)((BV + 255) / 256)), block(256);
+  const float dscale = upstream / (float)B;
+  if (label_dtype == YT8M_LABEL_U8) {
+    YT8M_DISPATCH_M(moe_mix_xent_bwd_kernel, uint8_t, Zg, Ze, static_cast<const uint8_t*>(labels), BV, M, eps, dscale, upstream_dev)
+  } else {
+    YT8M_DISPATCH_M(moe_mix_xent_bwd_kernel, float, Zg, Ze, static_cast<const float*>(labels), BV, M, eps, dscale, upstream_dev)
+  }
+  return launch_status("moe_mix_xent_bwd_kernel");
 }
 
 extern "C" int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream) {

@@ -389,26 +389,75 @@ class _MoeHead(torch.autograd.Function):
         V, M = ctx.VM
         ctx.Z = None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
-        overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
-        if Wg.grad is not None and We.grad is not None and not overlap:
-            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
-                          dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True)
-            Wg.grad_done()
-            We.grad_done()
-        elif Wg.grad is not None and We.grad is not None:
-            # data-parallel: finish the big gate gradient first so its all-reduce rides under the expert GEMM
-            gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta())
-            Wg.grad_done()
-            gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta())
-            We.grad_done()
-        if be.grad is not None:
-            colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
-            be.grad_done()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = gemm(Zg, Wg.data, transB=True)
-            gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
+        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
         return dx, None, None, None, None, None, None
+
+
+class _MoeHeadXent(torch.autograd.Function):
+    """MoE block + CrossEntropyLoss in one op: returns (p, loss).  The head's GEMMs are the same grouped launches as
+    _MoeHead; mixing+loss and (dL/dp -> dL/dZ) are single fused passes (yt8m_moe_mix_xent_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, token, Wg, We, be, labels, V, M):
+        x2 = _f32c(x)
+        Zg, Ze = gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)])
+        B = x2.shape[0]
+        lab, ldt = _labels_arg(labels)
+        if tuple(lab.shape) != (B, V):
+            raise ValueError("labels shape %s != predictions shape %s" % (tuple(lab.shape), (B, V)))
+        L = _lib.lib()
+        ws = torch.empty((L.yt8m_moe_mix_xent_workspace_bytes(B, V) + 3) // 4, dtype=torch.float32, device=x2.device)
+        p = torch.empty((B, V), dtype=torch.float32, device=x2.device)
+        loss = torch.empty((), dtype=torch.float32, device=x2.device)
+        _lib.check(L.yt8m_moe_mix_xent_fwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(p), _p(loss), B, V, M, XENT_EPS, _p(ws), _stream()))
+        ctx.save_for_backward(x2)
+        ctx.Z = (Zg, Ze)
+        ctx.vars = (Wg, We, be)
+        ctx.lab = (lab, ldt)
+        ctx.VM = (V, M)
+        ctx.mark_non_differentiable(p)          # predictions leave through the loss only on this path
+        return p, loss
+
+    @staticmethod
+    def backward(ctx, dp_unused, dloss):
+        (x,) = ctx.saved_tensors
+        Zg, Ze = ctx.Z
+        Wg, We, be = ctx.vars
+        lab, ldt = ctx.lab
+        V, M = ctx.VM
+        ctx.Z = None
+        _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
+                                                    XENT_EPS, 1.0, _stream()))
+        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
+        return dx, None, None, None, None, None, None, None
+
+
+def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
+    """dW_g = x^T dZ_g, dW_e = x^T dZ_e, db_e = colsum(dZ_e), dx = dZ_g W_g^T + dZ_e W_e^T."""
+    dx = None
+    if ctx.needs_input_grad[0]:                    # before the weights' gradient slots are released to an optimiser
+        dx = gemm(Zg, Wg.data, transB=True)
+        gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
+    overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
+    if Wg.grad is not None and We.grad is not None and not overlap:
+        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
+                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True)
+        Wg.grad_done()
+        We.grad_done()
+    elif Wg.grad is not None and We.grad is not None:
+        # data-parallel: finish the big gate gradient first so its all-reduce rides under the expert GEMM
+        gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta())
+        Wg.grad_done()
+        gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta())
+        We.grad_done()
+    if be.grad is not None:
+        colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
+        be.grad_done()
+    return dx
+
+
+def moe_head_xent(x, Wg, We, be, labels, vocab_size, num_mixtures):
+    return _MoeHeadXent.apply(x, _token(Wg._graph), Wg, We, be, labels, vocab_size, num_mixtures)
 
 
 def moe_head(x, Wg, We, be, vocab_size, num_mixtures):

@@ -64,11 +64,13 @@ class TrainGraph(object):
         self.b1, self.b2, self.eps = beta1, beta2, epsilon
 
     # ---- forward -----------------------------------------------------------------------------------
-    def forward(self, model_input_raw, labels_batch=None, num_frames=None, is_training=True):
+    def forward(self, model_input_raw, labels_batch=None, num_frames=None, is_training=True, fuse_loss=True):
         g = set_default_graph(self.graph)
         g.begin_step()
         model_input, num_frames = self.transformer.transform(model_input_raw, num_frames=num_frames)
         kw = {} if is_training else {"is_training": False}
+        if not fuse_loss:
+            kw["fuse_loss"] = False
         result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=FLAGS.num_classes
                                          if labels_batch is None else labels_batch.shape[1],
                                          labels=labels_batch, distillation_predictions=None, noise_level=None, **kw)
@@ -85,7 +87,7 @@ class TrainGraph(object):
     # ---- one optimisation step -----------------------------------------------------------------------
     def step(self, model_input_raw, labels_batch, num_frames=None, weights=None):
         g = self.graph
-        result = self.forward(model_input_raw, labels_batch, num_frames)
+        result = self.forward(model_input_raw, labels_batch, num_frames, fuse_loss=weights is None)
         label_loss = self.loss(result, labels_batch, weights)
         if not g.finalized:
             g.finalize()

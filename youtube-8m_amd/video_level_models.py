@@ -16,6 +16,9 @@ DEFINE_integer("deep_chain_layers", 3, "The number of layers used for DeepChainM
 DEFINE_integer("deep_chain_relu_cells", 200, "The number of relu cells used for DeepChainModel")
 DEFINE_string("deep_chain_relu_type", "relu", "The type of relu cells used for DeepChainModel (options are elu and relu)")
 DEFINE_bool("deep_chain_use_length", False, "unused by DeepCombineChainModel (kept for flag compatibility)")
+# new: MoeModel may return its own "loss" (W/train.py:384-385 honours it) computed by the fused mixing+cross-entropy pass
+DEFINE_bool("fused_head_loss", True, "MoeModel returns {'loss': CrossEntropyLoss(predictions, labels)} from a fused kernel "
+            "when labels are given, --label_loss=CrossEntropyLoss, no label smoothing and no --multitask.")
 
 
 def fully_connected(x, num_outputs, scope, activation=None, use_bias=True, l2_penalty=0.0):
@@ -53,8 +56,19 @@ class MoeModel(models.BaseModel):
     """W/all_video_models/moe_model.py:9-65: per-class softmax over (num_mixtures + 1) logistic experts."""
 
     def create_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="",
-                     original_input=None, **unused_params):
+                     original_input=None, labels=None, fuse_loss=True, **unused_params):
         num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
+        fused = (labels is not None and fuse_loss and FLAGS.fused_head_loss and FLAGS.label_loss == "CrossEntropyLoss"
+                 and not FLAGS.label_smoothing and not FLAGS.multitask and torch.is_grad_enabled()
+                 and model_input.dim() == 2 and tuple(labels.shape) == (model_input.shape[0], vocab_size))
+        if fused:
+            g = get_default_graph()
+            d_in, M = model_input.shape[-1], num_mixtures
+            Wg = g.get_variable("gates" + sub_scope + "/weights", (d_in, vocab_size * (M + 1)), xavier_uniform, l2=l2_penalty)
+            We = g.get_variable("experts" + sub_scope + "/weights", (d_in, vocab_size * M), xavier_uniform, l2=l2_penalty)
+            be = g.get_variable("experts" + sub_scope + "/biases", (vocab_size * M,), zeros)
+            p, loss = ops.moe_head_xent(model_input, Wg, We, be, labels, vocab_size, M)
+            return {"predictions": p, "loss": loss}
         p = moe_block(model_input, vocab_size, num_mixtures, l2_penalty, "gates" + sub_scope, "experts" + sub_scope)
         return {"predictions": p}
 
