@@ -59,26 +59,27 @@ def make_pool(n, B, dev, seed):
 
 def cpu_baseline(B, seconds):
     """Times the torch-CPU fp32 restatement of the same step on the host cores (a reported baseline, not a target).
-    Thread count: the best of {all usable cores, half, quarter} on one probe step each (oversubscribed MKL is slower)."""
+    Thread count: the best of {all usable cores, 64, 32, 16} on a cheap B=128 probe (oversubscribed MKL is far slower)."""
     from oracle import torch_ref
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     gen = torch.Generator().manual_seed(1)
     x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
     y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
-    st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+    # pick the thread count on a cheap B=128 probe (MKL/OpenMP with every hardware thread of a 256-thread host is an
+    # order of magnitude SLOWER than with 32-64 on this step); candidates: all, 64, 32, 16
+    probe = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=128, dtype=torch.float32, seed=0)
     best, best_t = None, None
-    t_begin = time.perf_counter()
-    for cores in sorted({usable, max(usable // 2, 1), max(usable // 4, 1)}, reverse=True):
+    for cores in sorted({c for c in (usable, 64, 32, 16) if 1 <= c <= usable}, reverse=True):
         torch.set_num_threads(cores)
-        st.step(x, y)                               # warm-up at this thread count
+        probe.step(x[:128], y[:128])                 # warm-up at this thread count
         t0 = time.perf_counter()
-        st.step(x, y)
+        probe.step(x[:128], y[:128])
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best, best_t = cores, dt
-        if time.perf_counter() - t_begin > seconds:
-            break
+    st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
     torch.set_num_threads(best)
+    st.step(x, y)                                    # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
         st.step(x, y)

@@ -140,11 +140,14 @@ int yt8m_xent_bwd(const float* p, const void* labels, int label_dtype, const flo
  * the tensors [tensor_base, tensor_base + ntensors): the data-parallel step updates each gradient bucket as soon as
  * its all-reduce has landed, while later buckets are still on the wire.
  * sqnorm: norms[tensor] = sum g_eff^2  (deterministic two-stage reduction; partial: float[nchunks]).
+ *         tensor_chunk_start (optional, device int32[all tensors + 1], ABSOLUTE chunk indices; chunk_base = absolute
+ *         index of chunks[0]) lets the second stage read only its own partials instead of scanning the chunk table.
  * adam:   g_c = g_eff * clip/max(sqrt(norms[t]), clip) (clip<=0: no clipping);
  *         m = b1 m + (1-b1) g_c; v = b2 v + (1-b2) g_c^2; w -= lr_t * m / (sqrt(v) + eps)   [TF-1 form] */
 int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* chunks, int64_t nchunks,
                       const float* l2, float gscale, float* partial, float* norms, int64_t tensor_base,
-                      int64_t ntensors, yt8m_stream_t stream);
+                      int64_t ntensors, const int32_t* tensor_chunk_start, int64_t chunk_base,
+                      yt8m_stream_t stream);
 int yt8m_adam_multi(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
                     const float* l2, float gscale, const float* norms, float clip,
                     float lr_t, float beta1, float beta2, float eps, yt8m_stream_t stream);

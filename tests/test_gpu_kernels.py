@@ -339,12 +339,12 @@ def test_sqnorm_and_adam_multi(dev):
         ops.sqnorm_and_adam(g, lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t), gscale=0.5, clip=1.0)
         n1 = g.norms.clone()
         ops._lib.check(ops._lib.lib().yt8m_sqnorm_multi(ops._p(g.params), ops._p(g.grads), ops._p(g.chunks), g.nchunks,
-                                                          ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 0, 4, ops._stream()))
+                                                          ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 0, 4, None, 0, ops._stream()))
         params, state = np_ref.train_step_update(params, grads, state, step, 0.01, 8,
                                                  {k for k in shapes if k.endswith("weights")}, l2_penalty=1e-2, clip=1.0)
         for k, v in vs.items():
             assert np.abs(H(v.data) - params[k]).max() < 2e-6, (step, k)
     a = g.norms.clone()
     ops._lib.check(ops._lib.lib().yt8m_sqnorm_multi(ops._p(g.params), ops._p(g.grads), ops._p(g.chunks), g.nchunks,
-                                                      ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 0, 4, ops._stream()))
+                                                      ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 0, 4, None, 0, ops._stream()))
     assert torch.equal(a, g.norms)                               # fixed-order reduction: bitwise reproducible

@@ -45,7 +45,7 @@ SIGNATURES = {
     "yt8m_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_xent_fwd_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P, P]),
     "yt8m_xent_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P]),
-    "yt8m_sqnorm_multi": (c_int, [P, P, P, c_int64, P, c_float, P, P, c_int64, c_int64, P]),
+    "yt8m_sqnorm_multi": (c_int, [P, P, P, c_int64, P, c_float, P, P, c_int64, c_int64, P, c_int64, P]),
     "yt8m_adam_multi": (c_int, [P, P, P, P, P, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float, P]),
     "yt8m_lstm_gates_fwd": (c_int, [P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, c_float, P]),
     "yt8m_lstm_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, P]),

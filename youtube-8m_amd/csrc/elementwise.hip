@@ -249,6 +249,19 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
   for (int64_t c = lane; c < cols; c += 64) yr[c] = xr[c] * r;
 }
 
+// long rows (>= 512 columns, few rows: the video-level [B,1152] batch): one 256-thread workgroup per row
+__global__ __launch_bounds__(256) void l2norm_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t cols,
+                                                             float eps) {
+  __shared__ float red[4];
+  const float* xr = x + (int64_t)blockIdx.x * cols;
+  float* yr = y + (int64_t)blockIdx.x * cols;
+  float ss = 0.f;
+  for (int64_t c = threadIdx.x; c < cols; c += 256) { const float v = xr[c]; ss += v * v; }
+  ss = block_sum_256(ss, red);
+  const float r = rsqrtf(fmaxf(ss, eps));
+  for (int64_t c = threadIdx.x; c < cols; c += 256) yr[c] = xr[c] * r;
+}
+
 // dx = r*(dy - y*(y.dy)) if ss > eps else r*dy      
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ dx, int64_t rows, int64_t cols, float eps) {
@@ -501,7 +514,10 @@ extern "C" int yt8m_l2norm_fwd_f32(const float* x, float* y, int64_t rows, int64
   YT8M_REQUIRE(x && y, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, rows, cols, eps);
+  if (cols >= 512 && rows <= 16384)
+    hipLaunchKernelGGL(l2norm_fwd_row_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, y, cols, eps);
+  else
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, rows, cols, eps);
   return launch_status("l2norm_fwd_kernel");
 }
 

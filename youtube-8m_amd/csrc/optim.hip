@@ -43,12 +43,17 @@ __global__ __launch_bounds__(256) void sqnorm_chunk_kernel(const float* __restri
 // one workgroup per tensor; thread j sums chunks j, j+256, ... of its tensor in order; fixed tree after.
 __global__ __launch_bounds__(256) void sqnorm_final_kernel(const int4* __restrict__ chunks, int nchunks,
                                                            const float* __restrict__ partial, float* __restrict__ norms,
-                                                           int tensor_base) {
+                                                           int tensor_base, const int32_t* __restrict__ tcs, int chunk_base) {
   __shared__ double red[256];
   const int t = tensor_base + blockIdx.x;
   double s = 0.0;
-  for (int i = threadIdx.x; i < nchunks; i += 256)
-    if (chunks[i].z == t) s += (double)partial[i];
+  if (tcs) {  // this tensor's partials are partial[tcs[t] - chunk_base, tcs[t+1] - chunk_base)
+    const int lo = tcs[t] - chunk_base, hi = tcs[t + 1] - chunk_base;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += (double)partial[i];
+  } else {
+    for (int i = threadIdx.x; i < nchunks; i += 256)
+      if (chunks[i].z == t) s += (double)partial[i];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -108,7 +113,7 @@ using namespace yt8m;
 
 extern "C" int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* chunks, int64_t nchunks, const float* l2,
                                  float gscale, float* partial, float* norms, int64_t tensor_base, int64_t ntensors,
-                                 yt8m_stream_t stream) {
+                                 const int32_t* tensor_chunk_start, int64_t chunk_base, yt8m_stream_t stream) {
   YT8M_REQUIRE(nchunks >= 0 && ntensors >= 0 && tensor_base >= 0 && nchunks < (1LL << 31), YT8M_E_SHAPE, "bad chunk/tensor count");
   if (ntensors == 0) return YT8M_OK;
   YT8M_REQUIRE(w && g && chunks && l2 && partial && norms, YT8M_E_BADARG, "null operand");
@@ -120,7 +125,8 @@ extern "C" int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* 
     hipLaunchKernelGGL(sqnorm_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, w, g,
                        reinterpret_cast<const int4*>(chunks), l2, gscale, partial);
   hipLaunchKernelGGL(sqnorm_final_kernel, dim3((unsigned)ntensors), dim3(256), 0, s,
-                     reinterpret_cast<const int4*>(chunks), (int)nchunks, partial, norms, (int)tensor_base);
+                     reinterpret_cast<const int4*>(chunks), (int)nchunks, partial, norms, (int)tensor_base,
+                     tensor_chunk_start, (int)chunk_base);
   return launch_status("sqnorm kernels");
 }
 

@@ -286,7 +286,7 @@ def sqnorm_and_adam(graph, lr_t, gscale=1.0, clip=1.0, beta1=0.9, beta2=0.999, e
     partial = ctypes.c_void_p(graph.partial.data_ptr() + 4 * c0)
     if clip > 0:
         _lib.check(L.yt8m_sqnorm_multi(_p(graph.params), _p(graph.grads), chunks, c1 - c0, _p(graph.l2), gscale, partial,
-                                       _p(graph.norms), lo, hi - lo, s))
+                                       _p(graph.norms), lo, hi - lo, _p(graph.chunk_start_dev), c0, s))
     _lib.check(L.yt8m_adam_multi(_p(graph.params), _p(graph.adam_m), _p(graph.adam_v), _p(graph.grads), chunks, c1 - c0,
                                  _p(graph.l2), gscale, _p(graph.norms), clip, lr_t, beta1, beta2, eps, s))
 
@@ -416,6 +416,7 @@ class _MoeHeadXent(torch.autograd.Function):
         ctx.lab = (lab, ldt)
         ctx.VM = (V, M)
         ctx.mark_non_differentiable(p)          # predictions leave through the loss only on this path
+        ctx.set_materialize_grads(False)        # no [B,V] zero-fill for the unused dL/dp slot
         return p, loss
 
     @staticmethod
@@ -426,6 +427,8 @@ class _MoeHeadXent(torch.autograd.Function):
         lab, ldt = ctx.lab
         V, M = ctx.VM
         ctx.Z = None
+        if dloss is None:
+            return (None,) * 8
         _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
                                                     XENT_EPS, 1.0, _stream()))
         dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)

@@ -172,6 +172,7 @@ class Graph(object):
                 chunks.append((v.offset + c0, min(CHUNK, n - c0), v.index, 0))
         self.nchunks = len(chunks)
         self.chunk_start.append(len(chunks))
+        self.chunk_start_dev = torch.tensor(self.chunk_start, dtype=torch.int32).to(dev)
         self.chunks = torch.tensor(chunks if chunks else [(0, 0, 0, 0)], dtype=torch.int32).to(dev).contiguous()
         self.l2 = torch.tensor(l2 if l2 else [0.0], dtype=torch.float32).to(dev)
         self.norms = torch.zeros(max(len(tv), 1), dtype=torch.float32, device=dev)
