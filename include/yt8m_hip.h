@@ -201,6 +201,16 @@ int yt8m_softmax_rows_fwd(const float* s, const int32_t* num_frames, float* a, i
 int yt8m_softmax_rows_bwd(const float* a, const float* da, const int32_t* num_frames, float* ds,
                           int64_t B, int64_t F, int64_t K, yt8m_stream_t stream);
 
+/* ---- NetVLAD residual aggregation + intra-normalisation (not in the reference) -------------
+ * agg [B,K,D] = a^T x per video (batched GEMM), a [B,F,K] masked assignment, centres [K,D]:
+ * n = sum_f a;  vlad = l2norm_D(agg - n*c).  One pass over the rows.  n_out [B,K] is saved for the backward.
+ * bwd: dagg [B,K,D], dn [B,K] (to be broadcast over frames into da), dcentres [K,D] (beta 0/1; may be NULL). */
+int yt8m_vlad_finish_fwd(const float* agg, const float* a, const float* centres, float* vlad, float* n_out,
+                         int64_t B, int64_t F, int64_t K, int64_t D, float eps, yt8m_stream_t stream);
+int yt8m_vlad_finish_bwd(const float* agg, const float* n_in, const float* centres, const float* dvlad, float* dagg,
+                         float* dn, float* dcentres, float dcentres_beta, int64_t B, int64_t K, int64_t D, float eps,
+                         yt8m_stream_t stream);
+
 /* ---- per-row top-k for the GAP@20 eval path (W/eval_util.py:123-165 top_k_triplets) -------------
  * p [B,V] -> vals [B,k] (descending), idx [B,k] int32; ties broken towards the LOWER class index. k<=64 */
 int yt8m_topk_rows(const float* p, int64_t B, int64_t V, int k, float* vals, int32_t* idx,

@@ -55,6 +55,8 @@ SIGNATURES = {
     "yt8m_attn_softmax_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_softmax_rows_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_softmax_rows_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
+    "yt8m_vlad_finish_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_vlad_finish_bwd": (c_int, [P, P, P, P, P, P, P, c_float, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_topk_rows": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
 }
 

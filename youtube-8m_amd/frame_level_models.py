@@ -229,8 +229,7 @@ class NetVLADModel(models.BaseModel):
         s = ops.linear(model_input, Wc, bc)                               # [B,F,K] assignment logits
         a = seq_ops.masked_softmax_rows(s, num_frames)                    # softmax_k * mask
         agg = seq_ops.pool_tn(a, model_input)                             # [B,K,D] = a^T x per video
-        vlad = seq_ops.vlad_residual(agg, a, centres)                     # - n * c
-        vlad = ops.l2_normalize(vlad)                                     # intra-normalisation (per cluster)
+        vlad = seq_ops.vlad_finish(agg, a, centres)                       # (agg - n*c), intra-normalised per cluster
         v = ops.l2_normalize(vlad.reshape(B, K * D))
         h = video_level_models.fully_connected(v, Hfc, "netvlad/hidden")
         if gating:

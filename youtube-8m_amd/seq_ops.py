@@ -158,35 +158,40 @@ def pool_tn(w, x):
     return _PoolTN.apply(w, x)
 
 
-class _VladResidual(torch.autograd.Function):
-    """vlad[b,k,:] = agg[b,k,:] - (sum_f a[b,f,k]) * c[k,:]   (SURVEY.md Appendix B); c is a Variable."""
+class _VladFinish(torch.autograd.Function):
+    """vlad[b,k,:] = l2norm_D(agg[b,k,:] - (sum_f a[b,f,k]) * c[k,:])   (residual aggregation +
+    intra-normalisation in one pass, yt8m_vlad_finish_fwd/bwd); c is a Variable."""
 
     @staticmethod
-    def forward(ctx, agg, a, token, centres):
-        n = a.sum(dim=1)                                       # [B,K]
-        ctx.save_for_backward(n)
-        ctx.centres = centres
-        ctx.F = a.shape[1]
-        return agg - n.unsqueeze(2) * centres.data.unsqueeze(0)
+    def forward(ctx, agg, a, token, centres, eps):
+        agg, a = _f32c(agg), _f32c(a)
+        _dev(agg, a)
+        B, K, D = agg.shape
+        F = a.shape[1]
+        vlad = torch.empty_like(agg)
+        n = torch.empty((B, K), dtype=torch.float32, device=agg.device)
+        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), _p(a), _p(centres.data), _p(vlad), _p(n), B, F, K, D, eps, _stream()))
+        ctx.save_for_backward(agg, n)
+        ctx.centres, ctx.F, ctx.eps = centres, F, eps
+        return vlad
 
     @staticmethod
-    def backward(ctx, dout):
-        (n,) = ctx.saved_tensors
+    def backward(ctx, dvlad):
+        agg, n = ctx.saved_tensors
         c = ctx.centres
-        dout = _f32c(dout)
-        if c.grad is not None:
-            B, K, D = dout.shape
-            # dc[k,:] = -sum_b n[b,k] dout[b,k,:]  as a batched GEMM over k would need a transpose; K*D is small
-            gc = -(n.unsqueeze(2) * dout).sum(dim=0)
-            if c.grad_beta() == 0.0:
-                c.grad.copy_(gc)
-            else:
-                c.grad.add_(gc)
+        dvlad = _f32c(dvlad)
+        B, K, D = agg.shape
+        dagg = torch.empty_like(agg)
+        dn = torch.empty((B, K), dtype=torch.float32, device=agg.device)
+        dc = c.grad if c.grad is not None else None
+        beta = c.grad_beta() if dc is not None else 0.0
+        _lib.check(_lib.lib().yt8m_vlad_finish_bwd(_p(agg), _p(n), _p(c.data), _p(dvlad), _p(dagg), _p(dn), _p(dc), beta, B, K, D,
+                                                   ctx.eps, _stream()))
+        if dc is not None:
             c.grad_done()
-        dn = -(dout * c.data.unsqueeze(0)).sum(dim=2)          # [B,K]
-        da = dn.unsqueeze(1).expand(-1, ctx.F, -1) if ctx.needs_input_grad[1] else None
-        return dout, da, None, None
+        da = dn.unsqueeze(1).expand(-1, ctx.F, -1) if ctx.needs_input_grad[1] else None   # broadcast view, no copy
+        return dagg, da, None, None, None
 
 
-def vlad_residual(agg, a, centres):
-    return _VladResidual.apply(agg, a, _token(centres._graph), centres)
+def vlad_finish(agg, a, centres, eps=1e-12):
+    return _VladFinish.apply(agg, a, _token(centres._graph), centres, eps)
