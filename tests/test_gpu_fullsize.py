@@ -157,6 +157,11 @@ def test_topk_and_gap_full_size(dev):
     assert torch.equal(torch.gather(p, 1, idx.long()), vals)                            # indices address their values
     kth = vals[:, -1:]
     assert int((p > kth).sum(1).max()) <= 19                                            # nothing above the k-th was missed
+    import yt8m_amd.inference as inference
+    ids = ["v%d" % i for i in range(4)]
+    dev_lines = list(inference.format_lines(ids, p[:4], 20))                            # device top-k path
+    host_lines = list(inference.format_lines(ids, H(p[:4]).astype(np.float32), 20))     # W/inference.py:76-89 on the host
+    assert dev_lines == host_lines and dev_lines[0].startswith("v0,") and dev_lines[0].count(" ") == 39
     em = eu.EvaluationMetrics(V, 20)
     em.accumulate_device(p, y, 0.0)
     ref = eu.calculate_gap(H(p).astype(np.float32), H(y).astype(np.float32), 20)

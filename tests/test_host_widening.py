@@ -1,0 +1,51 @@
+"""CPU tests of the section-8f widening pieces that are pure host logic: CSV line format and checkpoint round trip."""
+import numpy as np
+import torch
+
+import yt8m_amd.checkpoint as checkpoint
+import yt8m_amd.inference as inference
+import yt8m_amd.train as train
+from yt8m_amd.variables import Graph, random_normal, zeros
+
+
+def test_format_lines_host_path():
+    p = np.array([[0.1, 0.9, 0.5, 0.7], [0.25, 0.125, 0.75, 0.5]], dtype=np.float32)
+    lines = list(inference.format_lines([b"abc", "xyz"], p, 2))
+    assert lines == ["abc,1 0.900000 3 0.700000\n", "xyz,2 0.750000 3 0.500000\n"]
+    assert inference.CSV_HEADER == "VideoId,LabelConfidencePairs\n"
+
+
+def test_checkpoint_round_trip_and_rotation(tmp_path):
+    class TG(object):
+        pass
+
+    def make(seed):
+        g = Graph(device="cpu", seed=seed)
+        g.begin_step()
+        g.get_variable("gates/weights", (6, 9), random_normal(0.3), l2=1e-8)
+        g.get_variable("experts/biases", (9,), zeros)
+        g.get_variable("bn/moving_mean", (9,), zeros, trainable=False)
+        g.finalize()
+        tg = TG()
+        tg.graph, tg.global_step = g, 0
+        return tg
+    a = make(1)
+    a.graph.adam_m.normal_()
+    a.graph.adam_v.uniform_()
+    for step in (10, 20, 30, 40):
+        a.global_step = step
+        path = checkpoint.save(a, str(tmp_path), max_to_keep=3)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["model.ckpt-20.safetensors", "model.ckpt-30.safetensors",
+                                                         "model.ckpt-40.safetensors"]
+    assert checkpoint.latest_checkpoint(str(tmp_path)) == path
+    b = make(2)
+    assert not torch.equal(b.graph.vars["gates/weights"].data, a.graph.vars["gates/weights"].data)
+    checkpoint.restore(b, path)
+    assert b.global_step == 40
+    for k in a.graph.vars:
+        assert torch.equal(b.graph.vars[k].data, a.graph.vars[k].data)
+    assert torch.equal(b.graph.adam_m[:54], a.graph.adam_m[:54]) and torch.equal(b.graph.adam_v[:54], a.graph.adam_v[:54])
+    from safetensors.torch import load_file
+    sd = load_file(path)
+    assert {"gates/weights", "gates/weights/Adam", "gates/weights/Adam_1", "experts/biases", "global_step"} <= set(sd)
+    assert tuple(sd["gates/weights"].shape) == (6, 9)
