@@ -216,6 +216,24 @@ int yt8m_vlad_finish_bwd(const float* agg, const float* n_in, const float* centr
 int yt8m_topk_rows(const float* p, int64_t B, int64_t V, int k, float* vals, int32_t* idx,
                    yt8m_stream_t stream);
 
+/* ---- native input reader (HOST buffers) ----------------------------------------------
+ * TFRecord framing (u64 length | masked crc32c | payload | masked crc32c) + tf.train.SequenceExample / tf.train.Example
+ * wire-format decode for YT8MFrameFeatureReader (W/readers.py:189-259) and YT8MAggregatedFeatureReader (:94-125).
+ * Frame batches stay RAW uint8 (the device transform dequantises); rows >= num_frames are zero bytes; labels become a
+ * uint8 multi-hot (duplicates / order irrelevant).  *n_read < max_records means end of file.  Errors: missing file or
+ * feature, wrong feature size, corrupt CRC, malformed protobuf -> negative status + yt8m_last_error(). */
+uint32_t yt8m_crc32c(const void* data, int64_t n);
+uint32_t yt8m_crc32c_masked(const void* data, int64_t n);
+int yt8m_tfrecord_open(const char* path, int check_crc, void** reader_out);
+int yt8m_tfrecord_close(void* reader);
+int yt8m_tfrecord_read_frame_batch(void* reader, const char* const* feature_names, const int32_t* feature_sizes, int nfeat,
+                                   int64_t max_frames, int64_t num_classes, int64_t max_records, uint8_t* q,
+                                   int32_t* num_frames, uint8_t* labels, char* video_ids, int64_t id_stride,
+                                   int64_t* n_read);
+int yt8m_tfrecord_read_video_batch(void* reader, const char* const* feature_names, const int32_t* feature_sizes, int nfeat,
+                                   int64_t num_classes, int64_t max_records, float* x, uint8_t* labels, char* video_ids,
+                                   int64_t id_stride, int64_t* n_read);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,3 +350,33 @@ def test_fused_head_loss_equals_unfused(dev, flags, label_kind):
     w = torch.rand(B, device=dev)
     out = tg.step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), weights=w)
     assert torch.isfinite(out["loss"])
+
+
+def test_tfrecord_to_training_step(dev, flags, tmp_path):
+    """End to end through the widened path: fabricated frame-level TFRecord shard -> native reader -> pinned host ->
+    device uint8 -> fused dequantise/normalise -> LstmModel step; the transform is checked against the oracle on the
+    bytes that came out of the file."""
+    from oracle import tfrecord_ref as tr
+    import yt8m_amd.readers as readers
+    import yt8m_amd.ops as ops
+    rs = np.random.RandomState(21)
+    names, sizes = ["rgb", "audio"], [24, 8]
+    vids = [dict(video_id=("v%d" % i).encode(), labels=[int(rs.randint(0, 50))],
+                 frames={n: rs.randint(0, 256, size=(int(rs.randint(1, 12)), s)).astype(np.uint8) for n, s in zip(names, sizes)})
+            for i in range(6)]
+    p = str(tmp_path / "train.tfrecord")
+    tr.write_frame_shard(p, vids, names)
+    rd = readers.YT8MFrameFeatureReader(num_classes=50, feature_sizes=sizes, feature_names=names, max_frames=10)
+    flags.lstm_cells, flags.lstm_layers = "8", 1
+    g = reset_default_graph(device=dev, seed=2)
+    tg = train.TrainGraph(flm.LstmModel(), batch_size=6, graph=g)
+    n = 0
+    for ids, q, lab, nf in rd.prepare_reader(p, batch_size=6, device=dev):
+        eq, enf, elab = tr.expected_frame_batch(vids, names, sizes, 10, 50)
+        assert q.is_cuda and np.array_equal(q.cpu().numpy(), eq) and np.array_equal(nf.cpu().numpy(), enf)
+        x = ops.dequant_l2norm(q, nf)
+        assert np.abs(H(x) - np_ref.dequant_l2norm_folded(eq, enf)).max() < 1e-6
+        out = tg.step(q, lab, nf)
+        assert torch.isfinite(out["loss"]) and out["predictions"].shape == (6, 50)
+        n += len(ids)
+    assert n == 6

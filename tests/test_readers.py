@@ -1,0 +1,108 @@
+"""CPU tests of the native TFRecord / Example reader (csrc/tfrecord.hip via the C ABI) against the pure-Python
+restatement and writer in oracle/tfrecord_ref.py.  Byte / integer work: every comparison is bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tfrecord_ref as tr
+import yt8m_amd._lib as L
+import yt8m_amd.readers as readers
+
+
+def test_crc32c_known_answers():
+    """RFC 3720 B.4 check values pin the oracle; the native CRC (slicing-by-8) must match it on ragged lengths."""
+    assert tr.crc32c(b"123456789") == 0xE3069283
+    assert tr.crc32c(bytes(32)) == 0x8A9136AA
+    assert tr.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert tr.crc32c(bytes(range(32))) == 0x46DD794E
+    lib = L.lib()
+    rs = np.random.RandomState(0)
+    for n in [0, 1, 7, 8, 9, 63, 64, 65, 1000, 4097]:
+        b = rs.randint(0, 256, size=n).astype(np.uint8).tobytes()
+        buf = ctypes.create_string_buffer(b, len(b))
+        assert lib.yt8m_crc32c(buf, len(b)) == tr.crc32c(b)
+        assert lib.yt8m_crc32c_masked(buf, len(b)) == tr.masked_crc(b)
+
+
+def _videos(rs, n, names, sizes, max_len):
+    vids = []
+    for i in range(n):
+        k = int(rs.randint(1, max_len + 1))
+        vids.append(dict(video_id=("vid%04d" % i).encode(), labels=sorted(set(rs.randint(0, 4716, size=rs.randint(0, 6)).tolist())),
+                         frames={nm: rs.randint(0, 256, size=(k, s)).astype(np.uint8) for nm, s in zip(names, sizes)},
+                         features={("mean_" + nm): rs.randn(s).astype(np.float32) for nm, s in zip(names, sizes)}))
+    return vids
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_frame_reader_bit_exact(tmp_path, packed):
+    rs = np.random.RandomState(1)
+    names, sizes = ["rgb", "audio"], [1024, 128]
+    vids = _videos(rs, 11, names, sizes, max_len=40)
+    vids[3]["frames"] = {nm: rs.randint(0, 256, size=(45, s)).astype(np.uint8) for nm, s in zip(names, sizes)}   # > max_frames: truncated
+    vids[5]["labels"] = [7, 7, 3, 4715]                                                                          # duplicates
+    vids[6]["labels"] = []                                                                                       # no labels
+    p1, p2 = str(tmp_path / "a.tfrecord"), str(tmp_path / "b.tfrecord")
+    tr.write_frame_shard(p1, vids[:7], names, packed)
+    tr.write_frame_shard(p2, vids[7:], names, packed)
+    rd = readers.YT8MFrameFeatureReader(num_classes=4716, feature_sizes=sizes, feature_names=names, max_frames=30)
+    got = list(rd.prepare_reader([p1, p2], batch_size=4))
+    assert [len(b[0]) for b in got] == [4, 3, 4]                       # per-file read_up_to semantics
+    ids = [i for b in got for i in b[0]]
+    q = torch.cat([b[1] for b in got]).numpy()
+    lab = torch.cat([b[2] for b in got]).numpy()
+    nf = torch.cat([b[3] for b in got]).numpy()
+    eq, enf, elab = tr.expected_frame_batch(vids, names, sizes, 30, 4716)
+    assert ids == [v["video_id"] for v in vids]
+    assert np.array_equal(q, eq) and np.array_equal(nf, enf) and np.array_equal(lab, elab)
+    assert q.dtype == np.uint8 and nf[3] == 30 and lab[5].sum() == 3 and lab[6].sum() == 0
+    # glob pattern form + IOError for no match (W/train.py:193-195)
+    assert sum(len(b[0]) for b in rd.prepare_reader(str(tmp_path / "*.tfrecord"), batch_size=64)) == 11
+    with pytest.raises(IOError):
+        list(rd.prepare_reader(str(tmp_path / "nope*.tfrecord")))
+
+
+def test_video_reader_bit_exact(tmp_path):
+    rs = np.random.RandomState(2)
+    names, sizes = ["mean_rgb", "mean_audio"], [1024, 128]
+    vids = _videos(rs, 9, ["rgb", "audio"], sizes, max_len=3)
+    p = str(tmp_path / "v.tfrecord")
+    tr.write_video_shard(p, vids, names)
+    rd = readers.YT8MAggregatedFeatureReader(num_classes=4716, feature_sizes=sizes, feature_names=names)
+    got = list(rd.prepare_reader(p, batch_size=1024))
+    assert len(got) == 1
+    ids, x, lab, ones = got[0]
+    ex = np.stack([np.concatenate([v["features"][n] for n in names]) for v in vids])
+    assert np.array_equal(x.numpy(), ex) and x.dtype == torch.float32 and ids[8] == b"vid0008"
+    for i, v in enumerate(vids):
+        assert sorted(np.nonzero(lab[i].numpy())[0].tolist()) == sorted(set(v["labels"]))
+    assert torch.equal(ones, torch.ones(9))
+
+
+def test_reader_errors(tmp_path):
+    rs = np.random.RandomState(3)
+    names, sizes = ["rgb"], [16]
+    vids = _videos(rs, 3, names, sizes, max_len=5)
+    p = str(tmp_path / "f.tfrecord")
+    tr.write_frame_shard(p, vids, names)
+    raw = bytearray(open(p, "rb").read())
+    raw[40] ^= 0xFF                                                  # flip a payload byte -> CRC mismatch
+    bad = str(tmp_path / "bad.tfrecord")
+    open(bad, "wb").write(bytes(raw))
+    rd = readers.YT8MFrameFeatureReader(num_classes=4716, feature_sizes=sizes, feature_names=names, max_frames=8)
+    with pytest.raises(ValueError, match="crc"):
+        list(rd.prepare_reader(bad))
+    assert len(list(rd.prepare_reader(p))[0][0]) == 3
+    with pytest.raises(ValueError, match="missing"):                 # feature name not in the file
+        list(readers.YT8MFrameFeatureReader(4716, [16], ["audio"], 8).prepare_reader(p))
+    with pytest.raises(ValueError, match="bytes, expected"):         # wrong feature size
+        list(readers.YT8MFrameFeatureReader(4716, [8], ["rgb"], 8).prepare_reader(p))
+    open(str(tmp_path / "trunc.tfrecord"), "wb").write(open(p, "rb").read()[:-3])
+    with pytest.raises(ValueError, match="truncated"):
+        list(rd.prepare_reader(str(tmp_path / "trunc.tfrecord")))
+    with pytest.raises(AssertionError):
+        readers.YT8MFrameFeatureReader(4716, [16, 4], ["rgb"], 8)
+    with pytest.raises(NotImplementedError):
+        readers.BaseReader().prepare_reader(None)

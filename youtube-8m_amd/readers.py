@@ -1,0 +1,148 @@
+"""Input readers with the reference's class names / constructor arguments (W/readers.py:66-259) on top of the native
+TFRecord + protobuf decoder in libyt8m_hip.so (csrc/tfrecord.hip).  Instead of TF queue runners, ``prepare_reader``
+returns a Python iterator of batches; frame features are delivered as RAW uint8 [B, max_frames, D] (pinned host
+memory -> device), the fused device transform (ops.dequant_l2norm) does Dequantize + padding + L2-normalise.
+"""
+import ctypes
+import glob
+
+import torch
+
+from . import _lib
+from .flags import DEFINE_integer
+
+DEFINE_integer("num_readers", 8, "How many threads to use for reading input files.")
+ID_STRIDE = 32
+
+
+class BaseReader(object):
+    """W/readers.py:58-63."""
+
+    def prepare_reader(self, unused_filename_queue):
+        raise NotImplementedError()
+
+
+def _files(pattern_or_list):
+    if isinstance(pattern_or_list, (list, tuple)):
+        files = list(pattern_or_list)
+    else:
+        files = sorted(glob.glob(pattern_or_list))
+    if not files:
+        raise IOError("Unable to find training files. data_pattern='%s'." % (pattern_or_list,))   # W/train.py:193-195
+    return files
+
+
+def _c_names(names, sizes):
+    arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    szs = (ctypes.c_int32 * len(sizes))(*sizes)
+    return arr, szs
+
+
+def _ids(buf, n):
+    raw = buf[:n].numpy().tobytes()
+    return [raw[i * ID_STRIDE:(i + 1) * ID_STRIDE].split(b"\0", 1)[0] for i in range(n)]
+
+
+class _Open(object):
+    def __init__(self, path, check_crc):
+        self.h = ctypes.c_void_p()
+        _lib.check(_lib.lib().yt8m_tfrecord_open(path.encode(), int(check_crc), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            _lib.lib().yt8m_tfrecord_close(self.h)
+            self.h = None
+
+
+class YT8MAggregatedFeatureReader(BaseReader):
+    """Video-level Examples: sparse int64 'labels', 'video_id', fixed-length float features (W/readers.py:66-125)."""
+
+    def __init__(self, num_classes=4716, feature_sizes=[1024], feature_names=["mean_inc3"]):
+        assert len(feature_names) == len(feature_sizes), \
+            "length of feature_names (={}) != length of feature_sizes (={})".format(len(feature_names), len(feature_sizes))
+        self.num_classes = num_classes
+        self.feature_sizes = list(feature_sizes)
+        self.feature_names = list(feature_names)
+
+    def prepare_reader(self, filenames, batch_size=1024, device=None, check_crc=True):
+        """Yields (video_ids, features float32 [n, D], labels bool [n, num_classes], ones [n]) with n <= batch_size
+        (the last batch of a file may be smaller: read_up_to semantics, W/readers.py:104)."""
+        assert len(self.feature_names) > 0, "self.feature_names is empty!"
+        names, sizes = _c_names(self.feature_names, self.feature_sizes)
+        D = sum(self.feature_sizes)
+        pin = torch.cuda.is_available()
+        x = torch.empty((batch_size, D), dtype=torch.float32, pin_memory=pin)
+        lab = torch.empty((batch_size, self.num_classes), dtype=torch.uint8, pin_memory=pin)
+        ids = torch.empty((batch_size, ID_STRIDE), dtype=torch.uint8)
+        n = ctypes.c_int64(0)
+        L = _lib.lib()
+        for path in _files(filenames):
+            rd = _Open(path, check_crc)
+            try:
+                while True:
+                    _lib.check(L.yt8m_tfrecord_read_video_batch(rd.h, names, sizes, len(self.feature_names), self.num_classes,
+                                                                batch_size, x.data_ptr(), lab.data_ptr(), ids.data_ptr(),
+                                                                ID_STRIDE, ctypes.byref(n)))
+                    if n.value == 0:
+                        break
+                    k = n.value
+                    xb, lb = x[:k], lab[:k].bool()
+                    if device is not None:
+                        xb, lb = xb.to(device, non_blocking=True), lb.to(device, non_blocking=True)
+                        if pin:
+                            torch.cuda.current_stream().synchronize()      # the staging buffers are re-used
+                    else:
+                        xb, lb = xb.clone(), lb.clone()
+                    yield _ids(ids, k), xb, lb, torch.ones(k, device=xb.device)
+                    if k < batch_size:
+                        break
+            finally:
+                rd.close()
+
+
+class YT8MFrameFeatureReader(BaseReader):
+    """Frame-level SequenceExamples: 'labels' / 'video_id' context, one uint8 bytes feature per frame and feature name
+    (W/readers.py:127-259)."""
+
+    def __init__(self, num_classes=4716, feature_sizes=[1024], feature_names=["inc3"], max_frames=300):
+        assert len(feature_names) == len(feature_sizes), \
+            "length of feature_names (={}) != length of feature_sizes (={})".format(len(feature_names), len(feature_sizes))
+        self.num_classes = num_classes
+        self.feature_sizes = list(feature_sizes)
+        self.feature_names = list(feature_names)
+        self.max_frames = max_frames
+
+    def prepare_reader(self, filenames, batch_size=128, device=None, check_crc=True):
+        """Yields (video_ids, q uint8 [n, max_frames, D], labels bool [n, num_classes], num_frames int32 [n])."""
+        assert len(self.feature_names) > 0, "No feature selected: feature_names is empty!"
+        names, sizes = _c_names(self.feature_names, self.feature_sizes)
+        D = sum(self.feature_sizes)
+        pin = torch.cuda.is_available()
+        q = torch.empty((batch_size, self.max_frames, D), dtype=torch.uint8, pin_memory=pin)
+        nf = torch.empty((batch_size,), dtype=torch.int32, pin_memory=pin)
+        lab = torch.empty((batch_size, self.num_classes), dtype=torch.uint8, pin_memory=pin)
+        ids = torch.empty((batch_size, ID_STRIDE), dtype=torch.uint8)
+        n = ctypes.c_int64(0)
+        L = _lib.lib()
+        for path in _files(filenames):
+            rd = _Open(path, check_crc)
+            try:
+                while True:
+                    _lib.check(L.yt8m_tfrecord_read_frame_batch(rd.h, names, sizes, len(self.feature_names), self.max_frames,
+                                                                self.num_classes, batch_size, q.data_ptr(), nf.data_ptr(),
+                                                                lab.data_ptr(), ids.data_ptr(), ID_STRIDE, ctypes.byref(n)))
+                    if n.value == 0:
+                        break
+                    k = n.value
+                    qb, nb, lb = q[:k], nf[:k], lab[:k].bool()
+                    if device is not None:
+                        qb, nb, lb = (t.to(device, non_blocking=True) for t in (qb, nb, lb))
+                        if pin:
+                            torch.cuda.current_stream().synchronize()
+                    else:
+                        qb, nb, lb = qb.clone(), nb.clone(), lb.clone()
+                    yield _ids(ids, k), qb, lb, nb
+                    if k < batch_size:
+                        break
+            finally:
+                rd.close()
