@@ -361,9 +361,11 @@ def test_tfrecord_to_training_step(dev, flags, tmp_path):
     import yt8m_amd.ops as ops
     rs = np.random.RandomState(21)
     names, sizes = ["rgb", "audio"], [24, 8]
-    vids = [dict(video_id=("v%d" % i).encode(), labels=[int(rs.randint(0, 50))],
-                 frames={n: rs.randint(0, 256, size=(int(rs.randint(1, 12)), s)).astype(np.uint8) for n, s in zip(names, sizes)})
-            for i in range(6)]
+    vids = []
+    for i in range(6):
+        k = int(rs.randint(1, 12))
+        vids.append(dict(video_id=("v%d" % i).encode(), labels=[int(rs.randint(0, 50))],
+                         frames={n: rs.randint(0, 256, size=(k, s)).astype(np.uint8) for n, s in zip(names, sizes)}))
     p = str(tmp_path / "train.tfrecord")
     tr.write_frame_shard(p, vids, names)
     rd = readers.YT8MFrameFeatureReader(num_classes=50, feature_sizes=sizes, feature_names=names, max_frames=10)

@@ -102,6 +102,12 @@ def test_reader_errors(tmp_path):
     open(str(tmp_path / "trunc.tfrecord"), "wb").write(open(p, "rb").read()[:-3])
     with pytest.raises(ValueError, match="truncated"):
         list(rd.prepare_reader(str(tmp_path / "trunc.tfrecord")))
+    # the two feature lists of one video must have the same number of frames (tf.assert_equal, W/readers.py:239)
+    two = [dict(video_id=b"x", labels=[1], frames={"rgb": rs.randint(0, 256, size=(4, 16)).astype(np.uint8),
+                                                   "audio": rs.randint(0, 256, size=(5, 4)).astype(np.uint8)})]
+    tr.write_frame_shard(str(tmp_path / "two.tfrecord"), two, ["rgb", "audio"])
+    with pytest.raises(ValueError, match="disagree"):
+        list(readers.YT8MFrameFeatureReader(4716, [16, 4], ["rgb", "audio"], 8).prepare_reader(str(tmp_path / "two.tfrecord")))
     with pytest.raises(AssertionError):
         readers.YT8MFrameFeatureReader(4716, [16, 4], ["rgb"], 8)
     with pytest.raises(NotImplementedError):
