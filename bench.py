@@ -29,6 +29,7 @@ import __graft_entry__  # noqa: E402
 
 D_IN, VOCAB, MIX = 1152, 4716, 2
 PEAK_F32_MATRIX_TFLOPS = 157.3
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by the --dtype bf16 variant line
 
 
 def parse():
@@ -41,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline).  bf16 = same step with bf16 MFMA operands for the head "
+                         "GEMMs (fp32 accumulate / master weights / Adam): a separate, labelled line, never the headline.")
     ap.add_argument("--force-reducer", action="store_true", help="exercise the RCCL reducer even at world size 1 (test aid)")
     return ap.parse_args()
 
@@ -115,6 +119,10 @@ def main():
     if os.environ.get("YT8M_FUSED_HEAD_LOSS") == "0":     # A/B aid
         from yt8m_amd.flags import FLAGS
         FLAGS.fused_head_loss = False
+    bf16 = a.dtype == "bf16"
+    if bf16:
+        from yt8m_amd.flags import FLAGS
+        FLAGS.compute_dtype = "bfloat16"
     g = reset_default_graph(device=dev, seed=0)
     reducer = parallel.GradReducer() if (world > 1 or a.force_reducer) else None
     tg = train.TrainGraph(vlm.MoeModel(), batch_size=B * world, graph=g, reducer=reducer)
@@ -163,8 +171,9 @@ def main():
         avg_ms = ms.value / max(n.value, 1)
         flops_launch = flops_step / max(launches_step, 1)
         ach = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach,
-                "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS,
+        peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
+        roof = {"bound": "mfma", "kernel": "gemm_grouped_kernel (%s)" % ("v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x2_f32"),
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": None, "launches_per_step": launches_step, "avg_launch_ms": avg_ms,
                 "algorithmic_flops_per_launch": flops_launch}
         fam = {}
@@ -176,7 +185,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
             ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_f32_grouped_kernel")]
-            if ks and B == 1024:
+            if ks and B == 1024 and not bf16:
                 roof["traffic"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / len(ks)
                 roof["traffic_unit"] = "bytes/launch (L2-miss side, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.md)"
                 roof["algorithmic_bytes_per_launch"] = 4.0 * (B * D_IN + D_IN * VOCAB * (2 * MIX + 1) + B * VOCAB * (2 * MIX + 1))
@@ -194,9 +203,11 @@ def main():
     if rank == 0:
         out = {"metric": "training videos/sec", "value": a.steps * B * world / el, "unit": "videos/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "BASELINE configs[1]: MoeModel (2 mixtures) on video-level features, D=1152, V=4716, "
-                                      "fp32 training step (fwd+bwd+clip+Adam%s)" % ("+RCCL all-reduce" if world > 1 else ""),
+                                      "%s training step (fwd+bwd+clip+Adam%s)"
+                                      % ("bf16-operand VARIANT (not the fp32 headline) of the" if bf16 else "fp32",
+                                         "+RCCL all-reduce" if world > 1 else ""),
                           "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                           "params": 27173592},
                "roofline": roof, "cpu_baseline": cpu}

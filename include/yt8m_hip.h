@@ -61,8 +61,8 @@ int yt8m_gemm_f32_batched(int transA, int transB, int64_t M, int64_t N, int64_t 
  * yt8m_gemm_workspace_bytes() enables the split (NULL: remainder tiles run whole). */
 typedef struct yt8m_gemm_problem {
   int64_t M, N, K;
-  const float* A; int64_t lda;
-  const float* B; int64_t ldb;
+  const void* A; int64_t lda;   /* float (f32 entry points) or bf16 (yt8m_gemm_bf16_nt_grouped); ld in elements */
+  const void* B; int64_t ldb;
   float* C; int64_t ldc;
   const float* bias;  /* may be NULL */
   float beta;         /* 0 or 1 */
@@ -70,6 +70,14 @@ typedef struct yt8m_gemm_problem {
 int64_t yt8m_gemm_workspace_bytes(void);
 int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
                           int64_t workspace_bytes, yt8m_stream_t stream);
+/* bf16 operands, fp32 accumulate / output, "NT": C[M,N] = A[M,K] . B[N,K]^T with BOTH operands K-contiguous bf16
+ * (v_mfma_f32_32x32x16_bf16; same persistent scheduler).  K, lda, ldb even; 16-byte aligned rows (lda % 8 == 0) take the
+ * LDS-DMA path.  Serves the bf16 configuration (BASELINE config 5): x / W^T / dZ^T are kept as bf16 copies. */
+int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
+                              yt8m_stream_t stream);
+/* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows]. */
+int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int transpose,
+                       yt8m_stream_t stream);
 
 /* ---- input transform ---------------------------------------------------------------------------
  * yt8m_l2norm_*: tf.nn.l2_normalize on the last axis (W/all_feature_transform/default_transformer.py:4-8,

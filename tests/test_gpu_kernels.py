@@ -348,3 +348,39 @@ def test_sqnorm_and_adam_multi(dev):
     ops._lib.check(ops._lib.lib().yt8m_sqnorm_multi(ops._p(g.params), ops._p(g.grads), ops._p(g.chunks), g.nchunks,
                                                       ops._p(g.l2), 0.5, ops._p(g.partial), ops._p(g.norms), 0, 4, None, 0, ops._stream()))
     assert torch.equal(a, g.norms)                               # fixed-order reduction: bitwise reproducible
+
+
+def _bf16_round(a):
+    """numpy restatement of round-to-nearest-even fp32 -> bf16 (returned as float32 values)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_cast_bf16_and_bf16_gemm(dev):
+    """bf16 path: the cast is bit-exact against the RNE restatement (also transposed, ragged shapes); the bf16 NT GEMM
+    equals the fp64 product of the ROUNDED operands to fp32-accumulation noise, across tile / split-K / K-tail cases."""
+    rs = np.random.RandomState(31)
+    for R, C in [(5, 7), (64, 64), (130, 257), (1024, 1152)]:
+        x = (rs.randn(R, C) * 3).astype(np.float32)
+        x.flat[0] = 1.00390625         # exact tie between two bf16 values -> even
+        xb = ops.cast_bf16(D(x, dev))
+        assert np.array_equal(xb.float().cpu().numpy(), _bf16_round(x))
+        xt = ops.cast_bf16(D(x, dev), transpose=True)
+        assert xt.shape == (C, R) and np.array_equal(xt.float().cpu().numpy(), _bf16_round(x).T)
+    for M, N, K in [(1, 1, 2), (5, 7, 6), (128, 128, 32), (130, 257, 66), (64, 300, 1152), (1024, 2358, 1152), (100, 1000, 4096)]:
+        A = rs.randn(M, K).astype(np.float32)
+        B = rs.randn(N, K).astype(np.float32)
+        bias = rs.randn(N).astype(np.float32)
+        ref = _bf16_round(A).astype(np.float64) @ _bf16_round(B).astype(np.float64).T
+        Ab, Bb = ops.cast_bf16(D(A, dev)), ops.cast_bf16(D(B, dev))
+        C1, = ops.gemm_bf16_nt_grouped([dict(A=Ab, B=Bb)])
+        scale = np.abs(A).max() * np.abs(B).max() * K
+        assert np.abs(H(C1) - ref).max() <= 2e-6 * scale, (M, N, K)
+        C2, = ops.gemm_bf16_nt_grouped([dict(A=Ab, B=Bb, bias=D(bias, dev))])
+        ops.gemm_bf16_nt_grouped([dict(A=Ab, B=Bb, out=C2, beta=1.0)])
+        assert np.abs(H(C2) - (2 * ref + bias)).max() <= 4e-6 * scale
+    with pytest.raises(TypeError):
+        ops.gemm_bf16_nt_grouped([dict(A=torch.zeros(4, 4, device=dev), B=torch.zeros(4, 4, device=dev))])
+    with pytest.raises(ValueError):
+        ops.gemm_bf16_nt_grouped([dict(A=torch.zeros(4, 3, device=dev, dtype=torch.bfloat16), B=torch.zeros(4, 3, device=dev, dtype=torch.bfloat16))])

@@ -352,6 +352,72 @@ def test_fused_head_loss_equals_unfused(dev, flags, label_kind):
     assert torch.isfinite(out["loss"])
 
 
+def _bf16_round(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_moe_head_bf16(dev, flags, fused):
+    """compute_dtype=bfloat16 (BASELINE config 5): the head's GEMMs take bf16 operands with fp32 accumulation.  Forward is
+    checked two ways: against the fp64 oracle evaluated on the bf16-rounded operands (tight: only accumulation order
+    differs) and against the unrounded oracle at north_star's 1e-3; gradients against fp64 autograd at bf16 resolution
+    (operands of dW = x^T dZ carry 2^-9 relative rounding each).  Master weights / loss / optimiser stay fp32."""
+    rs = np.random.RandomState(31)
+    B, Dm, V, M = 64, 96, 250, 2
+    x = rs.randn(B, Dm).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)                    # the path's inputs are L2-normalised
+    y = rs.rand(B, V) < 0.03
+    flags.fused_head_loss = fused
+    flags.compute_dtype = "bfloat16"
+    g, r, loss, P = run_model(vlm.MoeModel(), x, y, dev, rs=np.random.RandomState(5))
+    assert ("loss" in r) == fused
+    got_p, got_g = H(r["predictions"]), grads_of(g)
+    # (a) oracle on rounded operands
+    pr_r = torch_ref.moe(_bf16_round(x), _bf16_round(P["gates/weights"]), _bf16_round(P["experts/weights"]),
+                         T(P["experts/biases"]), M)
+    assert np.abs(got_p - pr_r.numpy()).max() < 2e-6
+    # (b) unrounded oracle, north_star tolerance; loss and gradients
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    pr = torch_ref.moe(T(x), tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], M)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(got_p - pr.detach().numpy()).max() < TOL_P
+    assert abs(float(loss) - lr.item()) < 2e-3 * abs(lr.item())
+    for k, t in tp.items():
+        ref = t.grad.numpy()
+        assert np.abs(got_g[k] - ref).max() <= 1e-2 * np.abs(ref).max(), (k, np.abs(got_g[k] - ref).max(), np.abs(ref).max())
+    # fp32 path on the same weights: the bf16 result is a perturbation of it, not a different function
+    flags.compute_dtype = "float32"
+    g2, r2, loss2, _ = run_model(vlm.MoeModel(), x, y, dev, P={k: v.astype(np.float32) for k, v in P.items()})
+    assert np.abs(H(r2["predictions"]) - pr.detach().numpy()).max() < 1e-5
+    assert 0 < np.abs(H(r2["predictions"]) - got_p).max() < TOL_P
+    # odd reduction lengths cannot be packed in bf16 pairs: the op falls back to the exact fp32 MFMA path, loudly documented
+    flags.compute_dtype = "bfloat16"
+    xo = rs.randn(7, 33).astype(np.float32)
+    yo = rs.rand(7, 11) < 0.2
+    g3, r3, _, P3 = run_model(vlm.MoeModel(), xo, yo, dev, rs=np.random.RandomState(6))
+    po = torch_ref.moe(T(xo), T(P3["gates/weights"]), T(P3["experts/weights"]), T(P3["experts/biases"]), M)
+    assert np.abs(H(r3["predictions"]) - po.numpy()).max() < 1e-5
+
+
+def test_bf16_training_tracks_fp32(dev, flags):
+    """Ten steps of the config-1 shape at reduced size: the bf16-operand path's loss curve stays within 1e-3 relative of
+    the fp32 path's (fp32 master weights + fp32 Adam, so rounding does not accumulate in the parameters)."""
+    rs = np.random.RandomState(41)
+    B, Dm, V = 128, 128, 400
+    xs = [rs.randn(B, Dm).astype(np.float32) for _ in range(10)]
+    ys = [rs.rand(B, V) < 0.02 for _ in range(10)]
+    curves = {}
+    for dt in ("float32", "bfloat16"):
+        flags.compute_dtype = dt
+        g = reset_default_graph(device=dev, seed=3)
+        tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g)
+        curves[dt] = [float(tg.step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))["loss"]) for x, y in zip(xs, ys)]
+    a, b = np.array(curves["float32"]), np.array(curves["bfloat16"])
+    assert a[-1] < a[0]
+    assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max(), (a, b)
+
+
 def test_tfrecord_to_training_step(dev, flags, tmp_path):
     """End to end through the widened path: fabricated frame-level TFRecord shard -> native reader -> pinned host ->
     device uint8 -> fused dequantise/normalise -> LstmModel step; the transform is checked against the oracle on the

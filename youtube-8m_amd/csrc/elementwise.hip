@@ -323,6 +323,39 @@ __global__ __launch_bounds__(256) void dequant_mean_l2norm_kernel(const uint8_t*
   for (int64_t c = threadIdx.x; c < D; c += 256) x[b * D + c] *= r;
 }
 
+// ---- fp32 -> bf16 casts (round to nearest even), optionally transposing through a 64x64 LDS tile -----------------
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
+                                                        unsigned short* __restrict__ dst) {
+  const int64_t n = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / cols, c = e - r * cols;
+    dst[e] = f2bf(src[r * ld + c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_transpose_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
+                                                                  int64_t ld, unsigned short* __restrict__ dst) {
+  __shared__ unsigned short tile[64][66];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? f2bf(src[r * ld + c]) : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;          // dst[c][r]
+    if (c < cols && r < rows) dst[c * rows + r] = tile[tx][i];
+  }
+}
+
 inline unsigned grid_for(int64_t n, int per_block, int64_t cap = 1 << 20) {
   int64_t g = (n + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -446,6 +479,24 @@ extern "C" int yt8m_act_bwd_f32(int act, const float* y, const float* dy, float*
   ProfScope prof(F_ELEMENTWISE, s);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, act, y, dy, dx, n);
   return launch_status("act_bwd_kernel");
+}
+
+extern "C" int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int transpose,
+                                  yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, YT8M_E_SHAPE, "bad shape");
+  if (rows * cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(src && dst, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  if (transpose) {
+    YT8M_REQUIRE((rows + 63) / 64 <= 65535, YT8M_E_SHAPE, "too many rows for the transposing cast");
+    hipLaunchKernelGGL(cast_bf16_transpose_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s,
+                       src, rows, cols, ld, static_cast<unsigned short*>(dst));
+  } else {
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols, 256, 16384)), dim3(256), 0, s, src, rows, cols, ld,
+                       static_cast<unsigned short*>(dst));
+  }
+  return launch_status("cast_bf16_kernel");
 }
 
 extern "C" int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta,

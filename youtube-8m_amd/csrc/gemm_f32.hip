@@ -165,6 +165,31 @@ __device__ __forceinline__ void mma_step(const Frag& fa, const Frag& fb, f32x16 
   }
 }
 
+// bf16 operands (K-contiguous on both sides, "NT"): a bf16 matrix [M,K] IS, byte for byte, a float matrix [M,K/2], so the
+// fill / swizzle / pipeline code above is reused unchanged with K and the leading dimensions counted in floats; only the
+// MMA differs: the 16-byte chunk c = 2h + lk that load_frag<KC> fetches holds the bf16 elements k = 16h + 8*lk .. +7 of
+// the 32-wide bf16 K-step, which is exactly the per-lane operand of v_mfma_f32_32x32x16_bf16 number h.  2 MFMAs per
+// sub-tile pair and K-step (8 per wave) instead of 32: this path is bound by operand delivery (LDS-DMA / LDS reads).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void mma_step_bf16(const Frag& fa, const Frag& fb, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 qa = {fa.v[t][h][0], fa.v[t][h][1], fa.v[t][h][2], fa.v[t][h][3]};
+      const float4 qb = {fb.v[t][h][0], fb.v[t][h][1], fb.v[t][h][2], fb.v[t][h][3]};
+      a[t] = __builtin_bit_cast(bf16x8, qa);
+      b[t] = __builtin_bit_cast(bf16x8, qb);
+    }
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[1][1], 0, 0, 0);
+  }
+}
+
 // One pass over K for a workgroup tile.
 //  DMA path    : 3 LDS stages.  K-step kt+2 is issued as LDS-DMA at the TOP of iteration kt (side-effecting => it stays
 //                there) and has two MFMA blocks (2 x 2048 matrix-pipe cycles) to land; the wait before the barrier is a
@@ -174,7 +199,7 @@ __device__ __forceinline__ void mma_step(const Frag& fa, const Frag& fb, f32x16 
 //  guarded path: register staging, 2 stages; used for unaligned operands / K % 16 != 0.
 // In both, every fragment of the K-step is fetched from LDS before the first MFMA (sched_barrier pins the order) so
 // the LDS latency is paid once per K-step and the MFMAs stream.
-template <bool A_KC, bool B_KC, bool DMA>
+template <bool A_KC, bool B_KC, bool DMA, bool BF16>
 __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restrict__ Ap, const float* __restrict__ Bp,
                                          float* __restrict__ As, float* __restrict__ Bs, int m0, int n0, int kb, int ke,
                                          int tid, int wm, int wn, int li, int lk, f32x16 (&acc)[2][2]) {
@@ -202,7 +227,8 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
       load_frag<A_KC>(As + cur * TILE_FLOATS, wm, li, lk, fa);
       load_frag<B_KC>(Bs + cur * TILE_FLOATS, wn, li, lk, fb);
       __builtin_amdgcn_sched_barrier(0);
-      mma_step(fa, fb, acc);
+      if (BF16) mma_step_bf16(fa, fb, acc);
+      else mma_step(fa, fb, acc);
       __builtin_amdgcn_sched_barrier(0);
       // K-step kt+1 must have landed; kt+2 may stay in flight -- unless kt+2 was the guarded K-tail store (then it is
       // not a DMA: nothing younger than kt+1 is in flight, drain everything incl. the ds_writes)
@@ -237,7 +263,8 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
     load_frag<A_KC>(As + cur * TILE_FLOATS, wm, li, lk, fa);
     load_frag<B_KC>(Bs + cur * TILE_FLOATS, wn, li, lk, fb);
     __builtin_amdgcn_sched_barrier(0);
-    mma_step(fa, fb, acc);
+    if (BF16) mma_step_bf16(fa, fb, acc);
+    else mma_step(fa, fb, acc);
     __builtin_amdgcn_sched_barrier(0);
     *reinterpret_cast<float4*>(&An[tid * 4]) = ra0;
     *reinterpret_cast<float4*>(&An[(tid + 256) * 4]) = ra1;
@@ -251,7 +278,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
 // ---- one workgroup tile: K-steps [kb, ke) -> accumulators -> epilogue --------------------------------------------
 // mode 0: full reduction, C = acc (+ bias) (+ C).  mode 1: split-K part, raw accumulators to the workspace slot `ws`
 // (tile-local [128][128] image); the fix-up kernel adds the parts in a fixed order.
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool BF16>
 __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __restrict__ Ap, const float* __restrict__ Bp,
                                              float* __restrict__ Cp, float* __restrict__ smem, int tm, int tn, int kb,
                                              int ke, float* __restrict__ ws) {
@@ -273,8 +300,8 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
 
   // 16-byte aligned operands take the LDS-DMA path (edge tiles and the K tail included: see fill_dma / fill_step)
   const bool dma = g.vecA && g.vecB;
-  if (dma) mainloop<A_KC, B_KC, true>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
-  else mainloop<A_KC, B_KC, false>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
+  if (dma) mainloop<A_KC, B_KC, true, BF16>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
+  else mainloop<A_KC, B_KC, false, BF16>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if (ws) {
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGES * TILE_FLOATS];
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;  // M-tiles fastest: neighbours share the B panel
-  process_tile<A_KC, B_KC>(g, g.A + (int64_t)blockIdx.y * g.strideA, g.B + (int64_t)blockIdx.y * g.strideB,
+  process_tile<A_KC, B_KC, false>(g, g.A + (int64_t)blockIdx.y * g.strideA, g.B + (int64_t)blockIdx.y * g.strideB,
                            g.C + (int64_t)blockIdx.y * g.strideC, smem, tm, tn, 0, (g.K + BK - 1) / BK, nullptr);
 }
 
@@ -352,8 +379,8 @@ __device__ __forceinline__ int find_problem(const GroupArgs& G, int tile) {
   return q;
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupArgs G) {
+template <bool A_KC, bool B_KC, bool BF16>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(const GroupArgs G) {
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGES * TILE_FLOATS];
   // One work item per workgroup; the grid is full_rounds*P whole tiles followed by rem*S split-K parts.  The hardware
   // dispatcher hands out workgroups in id order, 3 resident per CU, so the whole-tile rounds run K-synchronised and the
@@ -376,8 +403,8 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const GroupArgs G
   const int lt = tile - G.tile_base[q];
   const int nk = (g.K + BK - 1) / BK;
   const int kb = (int)((int64_t)nk * part / nparts), ke = (int)((int64_t)nk * (part + 1) / nparts);
-  process_tile<A_KC, B_KC>(g, g.A, g.B, g.C, smem, lt % g.tiles_m, lt / g.tiles_m, kb, ke,
-                           nparts > 1 ? G.ws + (int64_t)slot * (BM * BN) : nullptr);
+  process_tile<A_KC, B_KC, BF16>(g, g.A, g.B, g.C, smem, lt % g.tiles_m, lt / g.tiles_m, kb, ke,
+                                 nparts > 1 ? G.ws + (int64_t)slot * (BM * BN) : nullptr);
 }
 
 // sums the S split-K parts of each remainder tile (fixed order) and applies the normal epilogue
@@ -469,8 +496,8 @@ static int gemm_launch(int transA, int transB, int64_t M, int64_t N, int64_t K, 
 
 extern "C" int64_t yt8m_gemm_workspace_bytes(void) { return (int64_t)SLOTS * BM * BN * (int64_t)sizeof(float); }
 
-extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
-                                     int64_t workspace_bytes, yt8m_stream_t stream) {
+static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+                          int64_t workspace_bytes, yt8m_stream_t stream) {
   using namespace yt8m;
   YT8M_REQUIRE(nprob >= 1 && nprob <= MAX_GROUP && probs, YT8M_E_BADARG, "1..4 problems");
   GroupArgs G;
@@ -479,7 +506,16 @@ extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     GemmArgs g;
-    int rc = fill_problem(g, transA, transB, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.bias, q.beta);
+    int rc;
+    if (bf16) {
+      // a bf16 [rows, K] matrix is byte-identical to a float [rows, K/2] matrix: run the float machinery on it
+      YT8M_REQUIRE(q.K % 2 == 0 && q.lda % 2 == 0 && q.ldb % 2 == 0, YT8M_E_SHAPE, "bf16 GEMM needs even K / lda / ldb");
+      rc = fill_problem(g, 0, 1, q.M, q.N, q.K / 2, static_cast<const float*>(q.A), q.lda / 2, static_cast<const float*>(q.B),
+                        q.ldb / 2, q.C, q.ldc, q.bias, q.beta);
+    } else {
+      rc = fill_problem(g, transA, transB, q.M, q.N, q.K, static_cast<const float*>(q.A), q.lda, static_cast<const float*>(q.B),
+                        q.ldb, q.C, q.ldc, q.bias, q.beta);
+    }
     if (rc != YT8M_OK) return rc;
     if (q.M == 0 || q.N == 0) continue;
     G.p[G.nprob] = g;
@@ -518,11 +554,24 @@ extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);
   const int64_t grid = (int64_t)G.full_rounds * G.P + (int64_t)G.rem * G.S;
-  launch_by_layout<GroupArgs>(transA, transB, gemm_f32_grouped_kernel<true, false>, gemm_f32_grouped_kernel<false, false>,
-                              gemm_f32_grouped_kernel<true, true>, gemm_f32_grouped_kernel<false, true>,
-                              dim3((unsigned)grid), s, G);
+  if (bf16)
+    hipLaunchKernelGGL((gemm_grouped_kernel<true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, G);
+  else
+    launch_by_layout<GroupArgs>(transA, transB, gemm_grouped_kernel<true, false, false>, gemm_grouped_kernel<false, false, false>,
+                                gemm_grouped_kernel<true, true, false>, gemm_grouped_kernel<false, true, false>,
+                                dim3((unsigned)grid), s, G);
   if (G.S > 1) hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)G.rem * 4), dim3(256), 0, s, G);
-  return launch_status("gemm_f32_grouped_kernel");
+  return launch_status("gemm_grouped_kernel");
+}
+
+extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+                                     int64_t workspace_bytes, yt8m_stream_t stream) {
+  return grouped_launch(transA, transB, 0, nprob, probs, workspace, workspace_bytes, stream);
+}
+
+extern "C" int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
+                                         yt8m_stream_t stream) {
+  return grouped_launch(0, 1, 1, nprob, probs, workspace, workspace_bytes, stream);
 }
 
 extern "C" int yt8m_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,

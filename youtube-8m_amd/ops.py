@@ -121,6 +121,55 @@ def gemm_simple(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0)
     return out
 
 
+def cast_bf16(x, transpose=False):
+    """fp32 [R,C] (inner stride 1) -> bf16 [R,C] or, transposed, [C,R] (yt8m_cast_f32_bf16, round to nearest even)."""
+    _dev(x)
+    x, ld = _rowmajor2d(x)
+    R, C = x.shape
+    out = torch.empty((C, R) if transpose else (R, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().yt8m_cast_f32_bf16(_p(x), R, C, ld, _p(out), int(transpose), _stream()))
+    return out
+
+
+def gemm_bf16_nt_grouped(items):
+    """items: dicts(A=bf16 [M,K], B=bf16 [N,K], out=None fp32 [M,N], bias=None, beta=0.0) -> fp32 outputs.
+    C = A . B^T on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (yt8m_gemm_bf16_nt_grouped)."""
+    probs, outs, keep = [], [], []
+    for it in items:
+        A, B = it["A"], it["B"]
+        _dev(A, B, it.get("out"), it.get("bias"))
+        if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or A.dim() != 2 or B.dim() != 2:
+            raise TypeError("gemm_bf16_nt: operands must be 2-D bfloat16")
+        A = A if A.stride(1) == 1 else A.contiguous()
+        B = B if B.stride(1) == 1 else B.contiguous()
+        M, K = A.shape
+        N, K2 = B.shape
+        if K != K2:
+            raise ValueError("gemm_bf16_nt: inner dimensions differ (%d vs %d)" % (K, K2))
+        out = it.get("out")
+        beta = it.get("beta", 0.0)
+        if out is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 needs an output tensor")
+            out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or (out.stride(1) != 1 and N != 1):
+            raise ValueError("gemm_bf16_nt: bad output tensor")
+        bias = it.get("bias")
+        if bias is not None:
+            bias = _f32c(bias)
+        lda = A.stride(0) if M > 1 else max(K, 1)
+        ldb = B.stride(0) if N > 1 else max(K, 1)
+        ldc = out.stride(0) if M > 1 else max(N, 1)
+        probs.append(_lib.GemmProblem(M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc,
+                                      bias.data_ptr() if bias is not None else None, float(beta)))
+        outs.append(out)
+        keep.append((A, B, bias))
+    arr = (_lib.GemmProblem * len(probs))(*probs)
+    ws = _workspace(outs[0].device)
+    _lib.check(_lib.lib().yt8m_gemm_bf16_nt_grouped(len(probs), arr, _p(ws), ws.numel() * 4, _stream()))
+    return outs
+
+
 def gemm_batched(A, B, out=None, transA=False, transB=False, beta=0.0):
     """Batched over dim 0 of 3-D contiguous tensors.  yt8m_gemm_f32_batched."""
     _dev(A, B, out)
@@ -371,9 +420,10 @@ class _MoeHead(torch.autograd.Function):
     """MoE block of W/all_video_models/moe_model.py:40-64: two GEMMs + mixing kernel; backward per Appendix G."""
 
     @staticmethod
-    def forward(ctx, x, token, Wg, We, be, V, M):
+    def forward(ctx, x, token, Wg, We, be, V, M, bf16):
         x2 = _f32c(x)
-        Zg, Ze = gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)])
+        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16)
+        ctx.bf16 = bf16
         p = moe_mix_fwd(Zg, Ze, V, M)
         ctx.save_for_backward(x2)
         ctx.Z = (Zg, Ze)
@@ -390,7 +440,22 @@ class _MoeHead(torch.autograd.Function):
         ctx.Z = None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
         dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
+
+
+def _bf16_ok(x2):
+    """bf16 GEMMs need even reduction lengths: D for the forward, the batch for dW."""
+    return x2.shape[0] % 2 == 0 and x2.shape[1] % 2 == 0
+
+
+def _moe_logits(x2, Wg, We, be, bf16):
+    """Zg = x.Wg, Ze = x.We + be as ONE persistent launch; bf16: operands are bf16 copies (x, Wg^T, We^T: both sides
+    K-contiguous), accumulation and outputs stay fp32."""
+    if bf16 and _bf16_ok(x2):
+        xb = cast_bf16(x2)
+        return gemm_bf16_nt_grouped([dict(A=xb, B=cast_bf16(Wg.data, transpose=True)),
+                                     dict(A=xb, B=cast_bf16(We.data, transpose=True), bias=be.data)])
+    return gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)])
 
 
 class _MoeHeadXent(torch.autograd.Function):
@@ -398,9 +463,10 @@ class _MoeHeadXent(torch.autograd.Function):
     _MoeHead; mixing+loss and (dL/dp -> dL/dZ) are single fused passes (yt8m_moe_mix_xent_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, x, token, Wg, We, be, labels, V, M):
+    def forward(ctx, x, token, Wg, We, be, labels, V, M, bf16):
         x2 = _f32c(x)
-        Zg, Ze = gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)])
+        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16)
+        ctx.bf16 = bf16
         B = x2.shape[0]
         lab, ldt = _labels_arg(labels)
         if tuple(lab.shape) != (B, V):
@@ -428,15 +494,48 @@ class _MoeHeadXent(torch.autograd.Function):
         V, M = ctx.VM
         ctx.Z = None
         if dloss is None:
-            return (None,) * 8
+            return (None,) * 9
         _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
                                                     XENT_EPS, 1.0, _stream()))
         dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
+
+
+def _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be):
+    """Same gradients on bf16 MFMAs: every product is written as A.B^T with K-contiguous bf16 copies
+    (dW = x^T.dZ = (x^T) . (dZ^T)^T, dx = dZ . (W)^T with W [D,N] itself K-contiguous over N)."""
+    dx = None
+    if ctx.needs_input_grad[0]:
+        if Zg.shape[1] % 2 == 0 and Ze.shape[1] % 2 == 0:
+            dx, = gemm_bf16_nt_grouped([dict(A=cast_bf16(Zg), B=cast_bf16(Wg.data))])
+            gemm_bf16_nt_grouped([dict(A=cast_bf16(Ze), B=cast_bf16(We.data), out=dx, beta=1.0)])
+        else:                                      # odd V*(M+1): the reduction length cannot be packed in bf16 pairs
+            dx = gemm(Zg, Wg.data, transB=True)
+            gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
+    if Wg.grad is not None and We.grad is not None:
+        xT = cast_bf16(x, transpose=True)
+        overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
+        pg = dict(A=xT, B=cast_bf16(Zg, transpose=True), out=Wg.grad, beta=Wg.grad_beta())
+        pe = dict(A=xT, B=cast_bf16(Ze, transpose=True), out=We.grad, beta=We.grad_beta())
+        if overlap:
+            gemm_bf16_nt_grouped([pg])
+            Wg.grad_done()
+            gemm_bf16_nt_grouped([pe])
+            We.grad_done()
+        else:
+            gemm_bf16_nt_grouped([pg, pe])
+            Wg.grad_done()
+            We.grad_done()
+    if be.grad is not None:
+        colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
+        be.grad_done()
+    return dx
 
 
 def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
     """dW_g = x^T dZ_g, dW_e = x^T dZ_e, db_e = colsum(dZ_e), dx = dZ_g W_g^T + dZ_e W_e^T."""
+    if getattr(ctx, "bf16", False) and _bf16_ok(x):
+        return _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be)
     dx = None
     if ctx.needs_input_grad[0]:                    # before the weights' gradient slots are released to an optimiser
         dx = gemm(Zg, Wg.data, transB=True)
@@ -459,12 +558,12 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
     return dx
 
 
-def moe_head_xent(x, Wg, We, be, labels, vocab_size, num_mixtures):
-    return _MoeHeadXent.apply(x, _token(Wg._graph), Wg, We, be, labels, vocab_size, num_mixtures)
+def moe_head_xent(x, Wg, We, be, labels, vocab_size, num_mixtures, bf16=False):
+    return _MoeHeadXent.apply(x, _token(Wg._graph), Wg, We, be, labels, vocab_size, num_mixtures, bool(bf16))
 
 
-def moe_head(x, Wg, We, be, vocab_size, num_mixtures):
-    return _MoeHead.apply(x, _token(Wg._graph), Wg, We, be, vocab_size, num_mixtures)
+def moe_head(x, Wg, We, be, vocab_size, num_mixtures, bf16=False):
+    return _MoeHead.apply(x, _token(Wg._graph), Wg, We, be, vocab_size, num_mixtures, bool(bf16))
 
 
 class _Xent(torch.autograd.Function):

@@ -16,6 +16,9 @@ DEFINE_integer("deep_chain_layers", 3, "The number of layers used for DeepChainM
 DEFINE_integer("deep_chain_relu_cells", 200, "The number of relu cells used for DeepChainModel")
 DEFINE_string("deep_chain_relu_type", "relu", "The type of relu cells used for DeepChainModel (options are elu and relu)")
 DEFINE_bool("deep_chain_use_length", False, "unused by DeepCombineChainModel (kept for flag compatibility)")
+# new: compute dtype of the MoE head GEMMs (BASELINE config 5 is bf16; configs 1-4 are fp32)
+DEFINE_string("compute_dtype", "float32", "float32 (exact fp32 MFMA) or bfloat16 (bf16 MFMA operands, fp32 accumulate, fp32 "
+              "master weights / optimiser) for the MoE head GEMMs.")
 # new: MoeModel may return its own "loss" (W/train.py:384-385 honours it) computed by the fused mixing+cross-entropy pass
 DEFINE_bool("fused_head_loss", True, "MoeModel returns {'loss': CrossEntropyLoss(predictions, labels)} from a fused kernel "
             "when labels are given, --label_loss=CrossEntropyLoss, no label smoothing and no --multitask.")
@@ -40,7 +43,7 @@ def moe_block(model_input, vocab_size, num_mixtures, l2_penalty, gate_scope, exp
     We = g.get_variable(expert_scope + "/weights", (d_in, vocab_size * M), xavier_uniform, l2=l2_penalty)
     be = g.get_variable(expert_scope + "/biases", (vocab_size * M,), zeros)
     lead = model_input.shape[:-1]
-    p = ops.moe_head(model_input.reshape(-1, d_in), Wg, We, be, vocab_size, M)
+    p = ops.moe_head(model_input.reshape(-1, d_in), Wg, We, be, vocab_size, M, bf16=FLAGS.compute_dtype == "bfloat16")
     return p.view(-1, vocab_size) if len(lead) <= 1 else p.view(-1, vocab_size)
 
 
@@ -67,7 +70,7 @@ class MoeModel(models.BaseModel):
             Wg = g.get_variable("gates" + sub_scope + "/weights", (d_in, vocab_size * (M + 1)), xavier_uniform, l2=l2_penalty)
             We = g.get_variable("experts" + sub_scope + "/weights", (d_in, vocab_size * M), xavier_uniform, l2=l2_penalty)
             be = g.get_variable("experts" + sub_scope + "/biases", (vocab_size * M,), zeros)
-            p, loss = ops.moe_head_xent(model_input, Wg, We, be, labels, vocab_size, M)
+            p, loss = ops.moe_head_xent(model_input, Wg, We, be, labels, vocab_size, M, bf16=FLAGS.compute_dtype == "bfloat16")
             return {"predictions": p, "loss": loss}
         p = moe_block(model_input, vocab_size, num_mixtures, l2_penalty, "gates" + sub_scope, "experts" + sub_scope)
         return {"predictions": p}
