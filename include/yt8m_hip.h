@@ -121,9 +121,12 @@ enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8
 int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream);
 /* dx = dy * act'(.) expressed from the OUTPUT y (sigmoid/tanh/relu/relu6/elu all admit it) */
 int yt8m_act_bwd_f32(int act, const float* y, const float* dy, float* dx, int64_t n, yt8m_stream_t stream);
-/* out[n] (beta=0) or out[n] += (beta=1): sum over rows of X[rows, cols]; deterministic */
-int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta,
-                    yt8m_stream_t stream);
+/* out[n] (beta=0) or out[n] += (beta=1): sum over rows of X[rows, cols]; deterministic (fixed summation order).
+ * workspace (optional, may be NULL): >= yt8m_colsum_workspace_bytes() device bytes let tall-and-narrow inputs
+ * ([B*F, 8..64] attention / cluster logits) be split over rows so that the whole chip is used. */
+int64_t yt8m_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta, void* workspace,
+                    int64_t workspace_bytes, yt8m_stream_t stream);
 
 /* ---- loss: CrossEntropyLoss (W/losses.py:110-130), probability space, eps = 1e-5 ---------------
  * loss = mean_b sum_l -[y log(p+eps) + (1-y) log(1-p+eps)] * (w_b);  dp = dloss/dp * upstream.

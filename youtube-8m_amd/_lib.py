@@ -43,7 +43,8 @@ SIGNATURES = {
     "yt8m_moe_mix_xent_bwd": (c_int, [P, P, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P]),
     "yt8m_act_fwd_f32": (c_int, [c_int, P, P, c_int64, P]),
     "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),
-    "yt8m_colsum_f32": (c_int, [P, c_int64, c_int64, c_int64, P, c_float, P]),
+    "yt8m_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "yt8m_colsum_f32": (c_int, [P, c_int64, c_int64, c_int64, P, c_float, P, c_int64, P]),
     "yt8m_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_xent_fwd_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P, P]),
     "yt8m_xent_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P]),

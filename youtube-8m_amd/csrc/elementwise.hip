@@ -162,11 +162,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __re
 }
 
 // column sums (bias gradients): 1024 threads = 64 columns x 16 row groups; fixed-order LDS tree => deterministic
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int64_t rows, int64_t cols, int64_t ldx,
-                                                      float* __restrict__ out, int accumulate) {
+// gridDim.y > 1: tall-and-narrow inputs (attention / cluster logits: [B*F, 8..64]) -- block (x, y) sums the row range
+// [y*rows_per, (y+1)*rows_per) into partial[y][col]; colsum_finish_kernel adds the partials in fixed order.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, int64_t rows_total, int64_t cols, int64_t ldx,
+                                                      float* __restrict__ out, int accumulate, int64_t rows_per) {
   __shared__ float red[16][65];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  if (gridDim.y > 1) {
+    X += (int64_t)blockIdx.y * rows_per * ldx;
+    out += (int64_t)blockIdx.y * cols;
+  }
+  const int64_t rows = gridDim.y > 1 ? min(rows_per, rows_total - (int64_t)blockIdx.y * rows_per) : rows_total;
   float s = 0.f;
   if (col < cols) {
     int64_t r = rg;
@@ -184,6 +191,15 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     for (int k = 0; k < 16; ++k) t += red[k][c];
     out[col] = accumulate ? out[col] + t : t;
   }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nsplit, int64_t cols,
+                                                            float* __restrict__ out, int accumulate) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  float t = 0.f;
+  for (int k = 0; k < nsplit; ++k) t += partial[(int64_t)k * cols + col];
+  out[col] = accumulate ? out[col] + t : t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,6 +276,51 @@ __global__ __launch_bounds__(256) void l2norm_fwd_row_kernel(const float* __rest
   ss = block_sum_256(ss, red);
   const float r = rsqrtf(fmaxf(ss, eps));
   for (int64_t c = threadIdx.x; c < cols; c += 256) yr[c] = xr[c] * r;
+}
+
+// very long rows (the [B, 64*1152] VLAD descriptor): one 1024-thread workgroup per row, float4 traffic; BWD adds the
+// x.dy reduction and applies dx = r*(dy - x*k).  cols % 4 == 0 and 16-byte aligned rows (checked by the caller).
+__device__ __forceinline__ float block_sum_1024(float v, float* red /* >= 16 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k];
+  return t;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(1024) void l2norm_long_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ out, int64_t cols, float eps) {
+  __shared__ float red[16];
+  const int64_t n4 = cols >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)blockIdx.x * cols);
+  const float4* gr = BWD ? reinterpret_cast<const float4*>(dy + (int64_t)blockIdx.x * cols) : nullptr;
+  float4* yr = reinterpret_cast<float4*>(out + (int64_t)blockIdx.x * cols);
+  float ss = 0.f, xd = 0.f;
+  for (int64_t c = threadIdx.x; c < n4; c += 1024) {
+    const float4 v = xr[c];
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    if (BWD) { const float4 g = gr[c]; xd += (v.x * g.x + v.y * g.y) + (v.z * g.z + v.w * g.w); }
+  }
+  ss = block_sum_1024(ss, red);
+  const float r = rsqrtf(fmaxf(ss, eps));
+  if (!BWD) {
+    for (int64_t c = threadIdx.x; c < n4; c += 1024) {
+      const float4 v = xr[c];
+      yr[c] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
+    }
+  } else {
+    xd = block_sum_1024(xd, red);
+    const float k = ss > eps ? xd * r * r : 0.f;
+    for (int64_t c = threadIdx.x; c < n4; c += 1024) {
+      const float4 v = xr[c], g = gr[c];
+      yr[c] = make_float4(r * (g.x - v.x * k), r * (g.y - v.y * k), r * (g.z - v.z * k), r * (g.w - v.w * k));
+    }
+  }
 }
 
 // dx = r*(dy - y*(y.dy)) if ss > eps else r*dy      
@@ -499,16 +560,37 @@ extern "C" int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, 
   return launch_status("cast_bf16_kernel");
 }
 
-extern "C" int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta,
-                               yt8m_stream_t stream) {
+extern "C" int64_t yt8m_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  (void)rows;
+  return cols > 0 ? 256 * cols * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta, void* workspace,
+                               int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(rows >= 0 && cols >= 0 && ldx >= cols, YT8M_E_SHAPE, "bad shape");
   YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
   if (cols == 0) return YT8M_OK;
   YT8M_REQUIRE(out && (X || rows == 0), YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, s, X, rows, cols, ldx, out,
-                     beta != 0.f ? 1 : 0);
+  const int64_t colblocks = (cols + 63) / 64;
+  // row split when the column blocks alone cannot fill the chip and there is enough work per block
+  int64_t nsplit = 1;
+  if (workspace && colblocks < 512 && rows >= 4096) {
+    nsplit = std::min<int64_t>(std::min<int64_t>(256, (1024 + colblocks - 1) / colblocks), rows / 1024);
+    if (nsplit * cols * (int64_t)sizeof(float) > workspace_bytes) nsplit = 1;
+  }
+  if (nsplit <= 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)colblocks), dim3(1024), 0, s, X, rows, cols, ldx, out, beta != 0.f ? 1 : 0,
+                       rows);
+  } else {
+    const int64_t rows_per = (rows + nsplit - 1) / nsplit;
+    nsplit = (rows + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)colblocks, (unsigned)nsplit), dim3(1024), 0, s, X, rows, cols, ldx,
+                       static_cast<float*>(workspace), 0, rows_per);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), (int)nsplit, cols, out, beta != 0.f ? 1 : 0);
+  }
   return launch_status("colsum_kernel");
 }
 
@@ -565,7 +647,9 @@ extern "C" int yt8m_l2norm_fwd_f32(const float* x, float* y, int64_t rows, int64
   YT8M_REQUIRE(x && y, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  if (cols >= 512 && rows <= 16384)
+  if (cols >= 8192 && (cols & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && rows <= 65536)
+    hipLaunchKernelGGL(l2norm_long_kernel<false>, dim3((unsigned)rows), dim3(1024), 0, s, x, (const float*)nullptr, y, cols, eps);
+  else if (cols >= 512 && rows <= 16384)
     hipLaunchKernelGGL(l2norm_fwd_row_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, y, cols, eps);
   else
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, y, rows, cols, eps);
@@ -579,7 +663,10 @@ extern "C" int yt8m_l2norm_bwd_f32(const float* x, const float* dy, float* dx, i
   YT8M_REQUIRE(x && dy && dx, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, dy, dx, rows, cols, eps);
+  if (cols >= 8192 && (cols & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && rows <= 65536)
+    hipLaunchKernelGGL(l2norm_long_kernel<true>, dim3((unsigned)rows), dim3(1024), 0, s, x, dy, dx, cols, eps);
+  else
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, dy, dx, rows, cols, eps);
   return launch_status("l2norm_bwd_kernel");
 }
 

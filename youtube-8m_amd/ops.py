@@ -192,7 +192,9 @@ def gemm_batched(A, B, out=None, transA=False, transB=False, beta=0.0):
 def colsum(X, out, beta=0.0):
     _dev(X, out)
     X, ld = _rowmajor2d(X)
-    _lib.check(_lib.lib().yt8m_colsum_f32(_p(X), X.shape[0], X.shape[1], ld, _p(out), float(beta), _stream()))
+    ws = _workspace(X.device)       # stream-ordered scratch shared with the GEMM's split-K partials
+    _lib.check(_lib.lib().yt8m_colsum_f32(_p(X), X.shape[0], X.shape[1], ld, _p(out), float(beta), _p(ws),
+                                          min(ws.numel() * 4, 1 << 22), _stream()))
     return out
 
 
