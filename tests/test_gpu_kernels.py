@@ -318,6 +318,79 @@ def test_attention_and_assignment_softmax(dev):
     assert np.abs(H(sd.grad) - ts.grad.numpy()).max() < 1e-5
 
 
+def _netvlad_pool_ref(q, nf, Wc, bc, dagg=None, dn=None):
+    """fp64 restatement of the fused pooling (SURVEY.md Appendix B on the folded uint8 input, section 0.7)."""
+    x = np_ref.dequant_l2norm_folded(q, nf)                                  # [B,F,D], rows >= nf are 0
+    B, F, _ = x.shape
+    mask = (np.arange(F)[None, :] < nf[:, None]).astype(np.float64)
+    # the assignment sees the NORMALISED frame for every row (padding rows are masked afterwards)
+    xa = np_ref.dequant_l2norm_folded(q, None)
+    a = np_ref.softmax(xa @ Wc + bc, axis=2) * mask[:, :, None]
+    agg = np.einsum("bfk,bfd->bkd", a, x)
+    if dagg is None:
+        return a, agg
+    da = np.einsum("bfd,bkd->bfk", xa, dagg) + dn[:, None, :]
+    ds = a * (da - (a * da).sum(2, keepdims=True))
+    dWc = np.einsum("bfd,bfk->dk", xa, ds)
+    return a, agg, dWc, ds.sum((0, 1))
+
+
+@pytest.mark.parametrize("shape", [(5, 50, 128), (3, 300, 1152), (2, 37, 1024), (260, 9, 64)])
+@pytest.mark.parametrize("nsplit", [2, 1])
+def test_netvlad_fused_u8(dev, shape, nsplit):
+    """Fused uint8 NetVLAD pooling (rows + cols kernels, csrc/netvlad_fused.hip) against the fp64 oracle: assignment,
+    aggregation and the backward into W_c / b_c; ragged num_frames incl. 0, 1 and F; frame counts that are not multiples
+    of the 32-frame step; feature widths with a partial last 384-slice (1024) and a single block (64)."""
+    B, F, Dm = shape
+    K = 64
+    rs = np.random.RandomState(B * 1000 + F)
+    q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+    q[0, 0] = 0
+    q[0, F - 1] = 255
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0] = F
+    nf[1] = 1
+    if B > 2:
+        nf[2] = 0
+    Wc = (rs.randn(Dm, K) * 3.0 / np.sqrt(Dm)).astype(np.float32)
+    bc = (rs.randn(K) * 0.5).astype(np.float32)
+    dagg = (rs.randn(B, K, Dm) * 1e-3 * np.exp(rs.randn(B, 1, 1))).astype(np.float32)    # per-video gradient scales differ
+    dn = (rs.randn(B, K) * 1e-3).astype(np.float32)
+    aref, aggref, dWref, dbref = _netvlad_pool_ref(q, nf, Wc.astype(np.float64), bc.astype(np.float64),
+                                                   dagg.astype(np.float64), dn.astype(np.float64))
+    qd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev)
+    a, agg = seq_ops.netvlad_fwd_u8(qd, nfd, D(Wc, dev), D(bc, dev), nsplit=nsplit)
+    tol = 2e-6 if nsplit == 2 else 3e-3
+    assert np.abs(H(a) - aref).max() < tol
+    assert np.abs(H(agg) - aggref).max() < tol * max(1.0, np.abs(aggref).max())
+    assert (H(a)[1, 1:] == 0).all()                                           # masked frames are exactly 0
+    if B > 2:
+        assert (H(a)[2] == 0).all() and (H(agg)[2] == 0).all()
+    # backward (uses the kernel's own a, as the training step does)
+    dW = torch.full((Dm, K), 7.0, device=dev)
+    db = torch.full((K,), 7.0, device=dev)
+    seq_ops.netvlad_bwd_u8(qd, nfd, a, D(dagg, dev), D(dn, dev), dW, 0.0, db, 0.0, nsplit=nsplit)
+    gt = 2e-5 if nsplit == 2 else 5e-3
+    assert np.abs(H(dW) - dWref).max() < gt * np.abs(dWref).max()
+    assert np.abs(H(db) - dbref).max() < gt * max(np.abs(dbref).max(), 1e-6)
+    seq_ops.netvlad_bwd_u8(qd, nfd, a, D(dagg, dev), D(dn, dev), dW, 1.0, db, 1.0, nsplit=nsplit)   # beta = 1 accumulates
+    assert np.abs(H(dW) - 2 * dWref).max() < 2 * gt * np.abs(dWref).max()
+    # vanishing upstream gradients (saturated model: fp32 denormal range) stay finite -- no scale overflow
+    seq_ops.netvlad_bwd_u8(qd, nfd, a, D(dagg * 1e-35, dev), D(dn * 1e-35, dev), dW, 0.0, db, 0.0, nsplit=nsplit)
+    assert torch.isfinite(dW).all() and torch.isfinite(db).all() and float(dW.abs().max()) < 1e-30
+    # deterministic: same bits on a second run
+    a2, agg2 = seq_ops.netvlad_fwd_u8(qd, nfd, D(Wc, dev), D(bc, dev), nsplit=nsplit)
+    assert torch.equal(a, a2) and torch.equal(agg, agg2)
+
+
+def test_netvlad_fused_rejects_unsupported(dev):
+    q = torch.zeros((2, 4, 100), dtype=torch.uint8, device=dev)               # D % 64 != 0
+    assert not seq_ops.netvlad_fused_supported(q, 64)
+    assert not seq_ops.netvlad_fused_supported(torch.zeros((2, 4, 128), dtype=torch.uint8, device=dev), 32)
+    with pytest.raises(ValueError):                                            # YT8M_E_SHAPE, no silent fallback in the op
+        seq_ops.netvlad_fwd_u8(q, None, torch.zeros((100, 64), device=dev), torch.zeros(64, device=dev))
+
+
 def test_sqnorm_and_adam_multi(dev):
     """Per-tensor clip on (g*gscale + l2 w) + TF-Adam over the arena vs the oracle, incl. ragged tensor sizes that
     exercise chunk tails, and bitwise reproducibility of the reduction."""

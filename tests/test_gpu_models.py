@@ -352,6 +352,52 @@ def test_fused_head_loss_equals_unfused(dev, flags, label_kind):
     assert torch.isfinite(out["loss"])
 
 
+@pytest.mark.parametrize("gated", [False, True])
+def test_netvlad_u8_fused_equals_generic(dev, flags, gated):
+    """NetVLAD plugin fed the reader's raw uint8 frames: the fused path (dequantise + l2-normalise folded into the
+    pooling GEMMs) against (i) the generic fp32 path on the transformed input and (ii) the fp64 oracle -- predictions,
+    loss and every gradient.  K = 64 clusters as the fused kernels require."""
+    rs = np.random.RandomState(14)
+    B, F, Dm, K, Hf, V = 6, 40, 128, 64, 24, 31
+    flags.netvlad_cluster_size, flags.netvlad_hidden_size = K, Hf
+    q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+    nf = np.array([40, 1, 17, 40, 33, 8], dtype=np.int32)
+    y = rs.rand(B, V) < 0.15
+    model = flm.GatedNetVLADModel if gated else flm.NetVLADModel
+    out = {}
+    for fold in (True, False):
+        flags.fold_dequant = fold
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(model(), batch_size=B, graph=g)
+        qd, yd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+        tg.forward(qd, yd, nfd)
+        g.finalize()
+        if fold:
+            P = randomise(g, np.random.RandomState(3), scale=0.4)
+        inject(g, P, dev)
+        res = tg.forward(qd, yd, nfd)
+        loss = tg.loss(res, yd)
+        loss.backward()
+        out[fold] = (H(res["predictions"]), float(loss), grads_of(g))
+    assert np.abs(out[True][0] - out[False][0]).max() < 2e-5
+    assert out[True][1] == pytest.approx(out[False][1], rel=1e-5)
+    for k in out[True][2]:
+        ref = out[False][2][k]
+        assert np.abs(out[True][2][k] - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-7), k
+    x = np_ref.dequant_l2norm_folded(q, nf)
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    h = torch_ref.netvlad_hidden(T(x), torch.from_numpy(nf), tp["netvlad/cluster_weights"], tp["netvlad/cluster_biases"],
+                                 tp["netvlad/centres"], tp["netvlad/hidden/weights"], tp["netvlad/hidden/biases"],
+                                 tp["netvlad/gating/weights"] if gated else None, tp["netvlad/gating/biases"] if gated else None)
+    pr = torch_ref.moe(h, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(out[True][0] - pr.detach().numpy()).max() < 1e-4
+    for k, t in tp.items():
+        ref = t.grad.numpy()
+        assert np.abs(out[True][2][k] - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max()), k
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64)
 

@@ -213,8 +213,14 @@ class DbofModel(models.BaseModel):
 
 
 class NetVLADModel(models.BaseModel):
-    """soft-assignment + residual aggregation + intra-norm + L2 + hidden FC (+ context gating)."""
+    """soft-assignment + residual aggregation + intra-norm + L2 + hidden FC (+ context gating).
+
+    accepts_quantized_input: the trainer may hand over the reader's RAW uint8 frames [B,F,D] instead of running the
+    DefaultTransformer first; dequantise + l2-normalise are then folded into the pooling GEMMs (csrc/netvlad_fused.hip)
+    and the fp32 [B,F,D] tensor is never written.  float inputs (or shapes the fused kernels do not cover) take the
+    generic GEMM + softmax + batched-GEMM path; both give the same function."""
     gating = None
+    accepts_quantized_input = True
 
     def create_model(self, model_input, vocab_size, num_frames, cluster_size=None, hidden_size=None, gating=None,
                      **unused_params):
@@ -226,10 +232,16 @@ class NetVLADModel(models.BaseModel):
         Wc = g.get_variable("netvlad/cluster_weights", (D, K), random_normal(1 / math.sqrt(D)))
         bc = g.get_variable("netvlad/cluster_biases", (K,), zeros)
         centres = g.get_variable("netvlad/centres", (K, D), random_normal(1 / math.sqrt(D)))
-        s = ops.linear(model_input, Wc, bc)                               # [B,F,K] assignment logits
-        a = seq_ops.masked_softmax_rows(s, num_frames)                    # softmax_k * mask
-        agg = seq_ops.pool_tn(a, model_input)                             # [B,K,D] = a^T x per video
-        vlad = seq_ops.vlad_finish(agg, a, centres)                       # (agg - n*c), intra-normalised per cluster
+        if model_input.dtype == torch.uint8 and seq_ops.netvlad_fused_supported(model_input, K):
+            nsplit = 1 if FLAGS.compute_dtype == "bfloat16" else 2        # f16 operands vs f16 hi+lo (fp32-class)
+            vlad = seq_ops.netvlad_pool_u8(model_input, num_frames, Wc, bc, centres, nsplit)
+        else:
+            if model_input.dtype == torch.uint8:                          # shapes outside the fused kernels' cover
+                model_input = ops.dequant_l2norm(model_input, num_frames)
+            s = ops.linear(model_input, Wc, bc)                           # [B,F,K] assignment logits
+            a = seq_ops.masked_softmax_rows(s, num_frames)                # softmax_k * mask
+            agg = seq_ops.pool_tn(a, model_input)                         # [B,K,D] = a^T x per video
+            vlad = seq_ops.vlad_finish(agg, a, centres)                   # (agg - n*c), intra-normalised per cluster
         v = ops.l2_normalize(vlad.reshape(B, K * D))
         h = video_level_models.fully_connected(v, Hfc, "netvlad/hidden")
         if gating:

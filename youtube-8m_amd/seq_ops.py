@@ -195,3 +195,91 @@ class _VladFinish(torch.autograd.Function):
 
 def vlad_finish(agg, a, centres, eps=1e-12):
     return _VladFinish.apply(agg, a, _token(centres._graph), centres, eps)
+
+
+# ---- fused NetVLAD pooling on raw uint8 frames (csrc/netvlad_fused.hip) ---------------------------------------------
+_NV_WS = {}
+
+
+def _netvlad_workspace(B, F, D, K, device):
+    need = _lib.lib().yt8m_netvlad_workspace_bytes(B, F, D, K)
+    ws = _NV_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _NV_WS[device] = ws
+    return ws
+
+
+def netvlad_fused_supported(q, K):
+    return (q.dtype == torch.uint8 and q.dim() == 3 and q.is_cuda
+            and bool(_lib.lib().yt8m_netvlad_supported(q.shape[0], q.shape[1], q.shape[2], K)))
+
+
+def netvlad_fwd_u8(q, num_frames, Wc, bc, nsplit=2, eps=1e-12):
+    """(a [B,F,K], agg [B,K,D]) from raw uint8 frames (yt8m_netvlad_fwd_u8)."""
+    _dev(q, Wc, bc)
+    q = q.contiguous()
+    B, F, D = q.shape
+    K = Wc.shape[1]
+    nf = _nf(num_frames)
+    a = torch.empty((B, F, K), dtype=torch.float32, device=q.device)
+    agg = torch.empty((B, K, D), dtype=torch.float32, device=q.device)
+    ws = _netvlad_workspace(B, F, D, K, q.device)
+    _lib.check(_lib.lib().yt8m_netvlad_fwd_u8(_p(q), _p(nf), _p(_f32c(Wc)), _p(_f32c(bc)), B, F, D, K, int(nsplit), eps, _p(a),
+                                              _p(agg), _p(ws), ws.numel(), _stream()))
+    return a, agg
+
+
+def netvlad_bwd_u8(q, num_frames, a, dagg, dn, dWc, dWc_beta, dbc, dbc_beta, nsplit=2, eps=1e-12):
+    _dev(q, a, dagg, dn, dWc, dbc)
+    B, F, D = q.shape
+    K = a.shape[2]
+    nf = _nf(num_frames)
+    ws = _netvlad_workspace(B, F, D, K, q.device)
+    _lib.check(_lib.lib().yt8m_netvlad_bwd_u8(_p(q), _p(nf), _p(a), _p(_f32c(dagg)), _p(_f32c(dn)), B, F, D, K, int(nsplit), eps,
+                                              _p(dWc), float(dWc_beta), _p(dbc), float(dbc_beta), _p(ws), ws.numel(), _stream()))
+
+
+class _NetVladPoolU8(torch.autograd.Function):
+    """uint8 frames -> intra-normalised VLAD descriptor [B,K,D], the dequantise + l2-normalise of
+    the input pipeline folded into the two GEMMs; backward writes dW_c, db_c, dcentres into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, q, num_frames, token, Wc, bc, centres, nsplit, eps):
+        q = q.contiguous()
+        a, agg = netvlad_fwd_u8(q, num_frames, Wc.data, bc.data, nsplit)
+        B, K, D = agg.shape
+        vlad = torch.empty_like(agg)
+        n = torch.empty((B, K), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), _p(a), _p(centres.data), _p(vlad), _p(n), B, q.shape[1], K, D, eps,
+                                                   _stream()))
+        ctx.saved = (q, num_frames, a, agg, n)
+        ctx.vars = (Wc, bc, centres)
+        ctx.cfg = (nsplit, eps)
+        return vlad
+
+    @staticmethod
+    def backward(ctx, dvlad):
+        q, num_frames, a, agg, n = ctx.saved
+        Wc, bc, c = ctx.vars
+        nsplit, eps = ctx.cfg
+        ctx.saved = None
+        dvlad = _f32c(dvlad)
+        B, K, D = agg.shape
+        dagg = torch.empty_like(agg)
+        dn = torch.empty((B, K), dtype=torch.float32, device=agg.device)
+        dc = c.grad if c.grad is not None else None
+        beta = c.grad_beta() if dc is not None else 0.0
+        _lib.check(_lib.lib().yt8m_vlad_finish_bwd(_p(agg), _p(n), _p(c.data), _p(dvlad), _p(dagg), _p(dn), _p(dc), beta, B, K, D,
+                                                   eps, _stream()))
+        if dc is not None:
+            c.grad_done()
+        if Wc.grad is not None and bc.grad is not None:
+            netvlad_bwd_u8(q, num_frames, a, dagg, dn, Wc.grad, Wc.grad_beta(), bc.grad.view(-1), bc.grad_beta(), nsplit)
+            Wc.grad_done()
+            bc.grad_done()
+        return (None,) * 8
+
+
+def netvlad_pool_u8(q, num_frames, Wc, bc, centres, nsplit=2, eps=1e-12):
+    return _NetVladPoolU8.apply(q, num_frames, _token(Wc._graph), Wc, bc, centres, int(nsplit), eps)

@@ -11,6 +11,7 @@ import math
 import torch
 
 from . import feature_transform, losses, ops
+from .feature_transform import DefaultTransformer
 from .flags import FLAGS, DEFINE_integer, DEFINE_float, DEFINE_string, DEFINE_bool
 from .variables import Graph, get_default_graph, set_default_graph
 
@@ -27,6 +28,8 @@ DEFINE_float("clip_gradient_norm", 1.0, "Norm to clip gradients to.")
 DEFINE_bool("multitask", False, "Whether to consider support_predictions")
 DEFINE_string("feature_names", "mean_rgb", "Name of the feature to use for training.")
 DEFINE_string("feature_sizes", "1024", "Length of the feature vectors.")
+# new: raw uint8 frame blocks reach models that fold the input transform into their first GEMM (NetVLAD)
+DEFINE_bool("fold_dequant", True, "Hand raw uint8 frames to models that declare accepts_quantized_input.")
 DEFINE_bool("frame_features", False, "If set, then --train_data_pattern must be frame-level features.")
 
 
@@ -63,11 +66,20 @@ class TrainGraph(object):
         self.global_step = 0
         self.b1, self.b2, self.eps = beta1, beta2, epsilon
 
+    def _transform(self, model_input_raw, num_frames):
+        """W/train.py:352-353 feature transform.  Raw uint8 frame blocks go to the model untouched when the model folds
+        the DefaultTransformer (dequantise + zero padding + l2-normalise) into its first GEMM."""
+        if (model_input_raw.dtype == torch.uint8 and model_input_raw.dim() == 3 and FLAGS.fold_dequant
+                and isinstance(self.transformer, DefaultTransformer)
+                and getattr(self.model, "accepts_quantized_input", False)):
+            return model_input_raw, num_frames
+        return self.transformer.transform(model_input_raw, num_frames=num_frames)
+
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, model_input_raw, labels_batch=None, num_frames=None, is_training=True, fuse_loss=True):
         g = set_default_graph(self.graph)
         g.begin_step()
-        model_input, num_frames = self.transformer.transform(model_input_raw, num_frames=num_frames)
+        model_input, num_frames = self._transform(model_input_raw, num_frames)
         kw = {} if is_training else {"is_training": False}
         if not fuse_loss:
             kw["fuse_loss"] = False
@@ -121,7 +133,7 @@ class TrainGraph(object):
     def predict(self, model_input_raw, num_frames=None, vocab_size=None):
         g = set_default_graph(self.graph)
         g.begin_step()
-        model_input, num_frames = self.transformer.transform(model_input_raw, num_frames=num_frames)
+        model_input, num_frames = self._transform(model_input_raw, num_frames)
         result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=vocab_size or FLAGS.num_classes,
                                          is_training=False)
         return result["predictions"]
