@@ -57,18 +57,25 @@ __device__ __forceinline__ float pow2_scale(float m) {
   return ldexpf(1.f, SCALE_TARGET - e);
 }
 
-// ---- scale[b] = 2^(SCALE_TARGET - e), max|v[b]| = f * 2^e, f in [0.5, 1)  -> |v| * scale < 2^SCALE_TARGET -------------
-__global__ __launch_bounds__(256) void vlad_scale_kernel(const float* __restrict__ v, int64_t n, int64_t stride,
-                                                         float* __restrict__ scale) {
+// ---- per-video max |v| in MAXP partial maxima (grid (MAXP, B)); the pack kernel turns them into the power-of-two scale ----
+constexpr int MAXP = 16;
+__global__ __launch_bounds__(256) void vlad_absmax_part_kernel(const float* __restrict__ v, int64_t n, int64_t stride,
+                                                               float* __restrict__ part) {
   __shared__ float red[4];
-  const float* p = v + (int64_t)blockIdx.x * stride;
+  const float* p = v + (int64_t)blockIdx.y * stride;
+  const int64_t chunk = ((n + MAXP - 1) / MAXP + 3) & ~(int64_t)3;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(p[i]));
-  m = block_max_256(m, red);
-  if (threadIdx.x == 0) {
-    const float s = pow2_scale(m);
-    scale[blockIdx.x] = s;
+  if ((((uintptr_t)p) & 15) == 0 && (n & 3) == 0) {
+    for (int64_t i = lo + 4 * (int64_t)threadIdx.x; i < hi; i += 1024) {
+      const float4 x = *reinterpret_cast<const float4*>(p + i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(p[i]));
   }
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.y * MAXP + blockIdx.x] = m;
 }
 
 // ---- packed f16 weights in MFMA fragment order ----------------------------------------------------------------------
@@ -78,11 +85,15 @@ __global__ __launch_bounds__(256) void vlad_scale_kernel(const float* __restrict
 // cs_part[b][j][k] = sum over the block's 64 features of the ROUNDED weights (hi + lo) / scale.
 template <bool SRC_KD>   // false: src[b][d][k] (W_c, [D,64]);  true: src[b][k][d] (G = d agg, [64,D])
 __global__ __launch_bounds__(256) void vlad_pack_kernel(const float* __restrict__ src, int64_t bstride, int D,
-                                                        const float* __restrict__ scale, int nsplit,
-                                                        _Float16* __restrict__ Wp, float* __restrict__ cs_part) {
+                                                        const float* __restrict__ maxpart, float* __restrict__ scale,
+                                                        int nsplit, _Float16* __restrict__ Wp, float* __restrict__ cs_part) {
   __shared__ float tile[64][65];
   const int j = blockIdx.x, b = blockIdx.y, nblk = gridDim.x;
-  const float S = scale[b];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) mx = fmaxf(mx, maxpart[(int64_t)b * MAXP + i]);
+  const float S = pow2_scale(mx);                                     // every thread derives the same scale
+  if (j == 0 && threadIdx.x == 0) scale[b] = S;
   const float* sp = src + (int64_t)b * bstride;
   for (int e = threadIdx.x; e < 4096; e += 256) {
     int dl, k;
@@ -532,6 +543,21 @@ __global__ __launch_bounds__(256) void vlad_cols_kernel(ColsArgs g) {
     }
 }
 
+// first level of the dW reduction: out[r][k][d] = sum over groups g = r, r + RED2, ... of part[g][k][d]  (fixed order)
+constexpr int RED2 = 16;
+__global__ __launch_bounds__(256) void vlad_part_reduce_kernel(const float* __restrict__ part, int groups, int64_t n,
+                                                               float* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const int r = blockIdx.y;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int gI = r; gI < groups; gI += RED2) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)gI * n + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + (int64_t)r * n + i) = s;
+}
+
 // dW[d,k] (+)= sum_g part[g][k][d]   (transposing, fixed order);  one workgroup per 64 features
 __global__ __launch_bounds__(256) void vlad_dw_reduce_kernel(const float* __restrict__ part, int groups, int D,
                                                              float* __restrict__ dW, int accumulate) {
@@ -588,7 +614,7 @@ struct Layout {
   int64_t nblk, Fp, ranges, groups, vids;
   int nt;
   // byte offsets into the workspace
-  int64_t o_scale, o_wp, o_cs, o_cT, o_wgmax, o_escale, o_colpart, o_part, total;
+  int64_t o_scale, o_maxpart, o_wp, o_cs, o_cT, o_wgmax, o_escale, o_colpart, o_part, o_part2, total;
 };
 
 Layout make_layout(int64_t B, int64_t F, int64_t D) {
@@ -598,11 +624,12 @@ Layout make_layout(int64_t B, int64_t F, int64_t D) {
   L.nt = pick_nt(B, F);
   L.ranges = (F + 64 * L.nt - 1) / (64 * L.nt);
   const int64_t slices = (D + 383) / 384;
-  L.groups = std::min<int64_t>(B, std::max<int64_t>(1, 768 / slices));
+  L.groups = std::min<int64_t>(B, std::max<int64_t>(1, 384 / slices));
   L.vids = (B + L.groups - 1) / L.groups;
   L.groups = (B + L.vids - 1) / L.vids;
   int64_t o = 0;
   L.o_scale = o;   o += align_up((B + 1) * 4, 256);
+  L.o_maxpart = o; o += align_up(B * MAXP * 4, 256);
   L.o_wp = o;      o += align_up(B * L.nblk * 4096 * 2 * 2, 256);     // nsplit = 2, per-video weights (backward)
   L.o_cs = o;      o += align_up(B * L.nblk * NK * 4, 256);
   L.o_cT = o;      o += align_up(B * NK * L.Fp * 4, 256);
@@ -610,6 +637,7 @@ Layout make_layout(int64_t B, int64_t F, int64_t D) {
   L.o_escale = o;  o += 256;
   L.o_colpart = o; o += align_up(B * L.ranges * NK * 4, 256);
   L.o_part = o;    o += align_up(L.groups * NK * D * 4, 256);
+  L.o_part2 = o;   o += align_up(RED2 * NK * D * 4, 256);
   L.total = o;
   return L;
 }
@@ -656,9 +684,10 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   float* cs = reinterpret_cast<float*>(ws + L.o_cs);
   float* cT = reinterpret_cast<float*>(ws + L.o_cT);
   float* escale = reinterpret_cast<float*>(ws + L.o_escale);
-  hipLaunchKernelGGL(vlad_scale_kernel, dim3(1), dim3(256), 0, s, Wc, D * NK, (int64_t)0, scale);
-  hipLaunchKernelGGL(vlad_pack_kernel<false>, dim3((unsigned)L.nblk, 1), dim3(256), 0, s, Wc, (int64_t)0, (int)D, scale, nsplit, Wp,
-                     cs);
+  float* maxpart = reinterpret_cast<float*>(ws + L.o_maxpart);
+  hipLaunchKernelGGL(vlad_absmax_part_kernel, dim3(MAXP, 1), dim3(256), 0, s, Wc, D * NK, (int64_t)0, maxpart);
+  hipLaunchKernelGGL(vlad_pack_kernel<false>, dim3((unsigned)L.nblk, 1), dim3(256), 0, s, Wc, (int64_t)0, (int)D, maxpart, scale,
+                     nsplit, Wp, cs);
   float* wgmax = reinterpret_cast<float*>(ws + L.o_wgmax);
   RowsArgs ra;
   ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = 0; ra.cs_part = cs; ra.cs_bstride = 0; ra.wscale = scale;
@@ -699,9 +728,11 @@ extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, 
   float* colpart = reinterpret_cast<float*>(ws + L.o_colpart);
   float* part = reinterpret_cast<float*>(ws + L.o_part);
   // per-video weights G[b] = dagg[b] ([64, D]): scale, pack, row pass with the softmax backward in the epilogue
-  hipLaunchKernelGGL(vlad_scale_kernel, dim3((unsigned)B), dim3(256), 0, s, dagg, NK * D, NK * D, scale);
-  hipLaunchKernelGGL(vlad_pack_kernel<true>, dim3((unsigned)L.nblk, (unsigned)B), dim3(256), 0, s, dagg, NK * D, (int)D, scale,
-                     nsplit, Wp, cs);
+  float* maxpart = reinterpret_cast<float*>(ws + L.o_maxpart);
+  float* part2 = reinterpret_cast<float*>(ws + L.o_part2);
+  hipLaunchKernelGGL(vlad_absmax_part_kernel, dim3(MAXP, (unsigned)B), dim3(256), 0, s, dagg, NK * D, NK * D, maxpart);
+  hipLaunchKernelGGL(vlad_pack_kernel<true>, dim3((unsigned)L.nblk, (unsigned)B), dim3(256), 0, s, dagg, NK * D, (int)D, maxpart,
+                     scale, nsplit, Wp, cs);
   RowsArgs ra;
   ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = L.nblk * 4096 * nsplit; ra.cs_part = cs; ra.cs_bstride = L.nblk * NK;
   ra.wscale = scale; ra.wscale_bstride = 1; ra.bias = dn; ra.bias_bstride = NK; ra.a = const_cast<float*>(a); ra.outT = eT;
@@ -716,8 +747,16 @@ extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, 
   const dim3 cgrid((unsigned)((D + 383) / 384), (unsigned)L.groups);
   if (nsplit == 2) hipLaunchKernelGGL(vlad_cols_kernel<2>, cgrid, dim3(256), 0, s, ca);
   else hipLaunchKernelGGL(vlad_cols_kernel<1>, cgrid, dim3(256), 0, s, ca);
-  hipLaunchKernelGGL(vlad_dw_reduce_kernel, dim3((unsigned)L.nblk), dim3(256), 0, s, part, (int)L.groups, (int)D, dWc,
-                     dWc_beta != 0.f ? 1 : 0);
+  if (L.groups > RED2) {
+    const int64_t n = NK * D;
+    hipLaunchKernelGGL(vlad_part_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256), RED2), dim3(256), 0, s, part, (int)L.groups, n,
+                       part2);
+    hipLaunchKernelGGL(vlad_dw_reduce_kernel, dim3((unsigned)L.nblk), dim3(256), 0, s, part2, RED2, (int)D, dWc,
+                       dWc_beta != 0.f ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(vlad_dw_reduce_kernel, dim3((unsigned)L.nblk), dim3(256), 0, s, part, (int)L.groups, (int)D, dWc,
+                       dWc_beta != 0.f ? 1 : 0);
+  }
   const int st = launch_status("yt8m_netvlad_bwd_u8");
   if (st != YT8M_OK) return st;
   // db_c = sum of the per-workgroup partial sums of ds (fixed order)
