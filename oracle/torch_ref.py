@@ -100,11 +100,11 @@ def lstm_model_state(x, num_frames, layers):
     return torch.cat([t for pair in zip(c, h) for t in pair], 1)
 
 
-def attention_pool(x, outputs, num_frames, Wa, ba):
-    """W/all_frame_models/lstm_attention_max_pooling_model.py:34,51-63."""
+def attention_pool(x, outputs, num_frames, Wa, ba, order="input_first"):
+    """W/all_frame_models/lstm_attention_max_pooling_model.py:34,51-63.  order: which tensor comes first in the FC input."""
     F = x.shape[1]
     mask = (torch.arange(F)[None, :] < num_frames[:, None]).to(x.dtype)
-    act = torch.cat([x, outputs], 2) @ Wa + ba
+    act = torch.cat([x, outputs] if order == "input_first" else [outputs, x], 2) @ Wa + ba
     w = torch.softmax(act, dim=1) * mask[:, :, None]           # [B,F,A]
     w = w / w.sum(1, keepdim=True)
     return torch.einsum("bfh,bfa->bah", outputs, w)
@@ -132,6 +132,21 @@ def netvlad_hidden(x, num_frames, Wc, bc, centres, Wh, bh, Wgate=None, bgate=Non
     if Wgate is not None:
         h = h * torch.sigmoid(h @ Wgate + bgate)
     return h
+
+
+def gated_netvlad_attention_chain(x, num_frames, P, L, M, A):
+    """BASELINE configs[4] composite as SURVEY.md Appendix B fixes it (not a reference class): gated NetVLAD descriptor,
+    attention pooling of the frames themselves (lstm_attention_max_pooling_model.py:34,51-63 with outputs := x and the FC
+    input [x || mean_x]), DeepCombineChainModel on [h || att_a], max over the A attentions for predictions and support."""
+    B, F, D = x.shape
+    h = netvlad_hidden(x, num_frames, P["netvlad/cluster_weights"], P["netvlad/cluster_biases"], P["netvlad/centres"],
+                       P["netvlad/hidden/weights"], P["netvlad/hidden/biases"], P["netvlad/gating/weights"],
+                       P["netvlad/gating/biases"])
+    mean_x = (x.sum(1, keepdim=True) / num_frames.to(x.dtype).clamp(min=1).view(B, 1, 1)).expand(B, F, D)
+    att = attention_pool(mean_x, x, num_frames, P["attention-/weights"], P["attention-/biases"], order="outputs_first")
+    cin = torch.cat([h[:, None, :].expand(B, A, h.shape[1]), att], 2).reshape(B * A, -1)
+    main, sup = deep_combine_chain(cin, P, L, M)
+    return main.view(B, A, -1).max(1).values, sup.view(B, A, -1).max(1).values
 
 
 def dbof_hidden(xs, Wc, bc, Wh, bh, pooling="max"):

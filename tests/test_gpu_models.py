@@ -398,6 +398,50 @@ def test_netvlad_u8_fused_equals_generic(dev, flags, gated):
         assert np.abs(out[True][2][k] - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max()), k
 
 
+@pytest.mark.parametrize("quantized", [False, True])
+def test_config5_composite_model(dev, flags, quantized):
+    """GatedNetVLADAttentionChainModel (BASELINE configs[4] composite) under the multitask loss
+    against the oracle: predictions, support predictions, loss and every gradient; float input and raw uint8 input."""
+    rs = np.random.RandomState(17)
+    B, F, Dm, K, Hf, V, A, L = 4, 10, 64, 64, 16, 13, 3, 2
+    flags.netvlad_cluster_size, flags.netvlad_hidden_size, flags.lstm_attentions = K, Hf, A
+    flags.deep_chain_layers, flags.deep_chain_relu_cells = L, 8
+    flags.support_type = ",".join(["label"] * L)
+    flags.support_loss_percent = 0.1
+    nf = np.array([10, 1, 4, 7], dtype=np.int32)
+    y = rs.rand(B, V) < 0.2
+    if quantized:
+        q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+        x64 = np_ref.dequant_l2norm_folded(q, nf)
+        inp = q
+    else:
+        x64 = np_ref.l2_normalize(rs.randn(B, F, Dm)) * (np.arange(F)[None, :, None] < nf[:, None, None])
+        inp = x64.astype(np.float32)
+        x64 = inp.astype(np.float64)
+    g = reset_default_graph(device=dev, seed=0)
+    tcls = __import__("yt8m_amd.feature_transform", fromlist=["x"])
+    tg = train.TrainGraph(flm.GatedNetVLADAttentionChainModel(), batch_size=B, graph=g, multitask=True,
+                          label_loss_fn=losses.MultiTaskCrossEntropyLoss(),
+                          transformer_class=tcls.DefaultTransformer if quantized else tcls.IdenticalTransformer)
+    xd, yd, nfd = torch.from_numpy(inp).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+    tg.forward(xd, yd, nfd)
+    g.finalize()
+    P = randomise(g, rs, scale=0.4)
+    inject(g, P, dev)
+    res = tg.forward(xd, yd, nfd)
+    loss = tg.loss(res, yd)
+    loss.backward()
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    main, sup = torch_ref.gated_netvlad_attention_chain(T(x64), torch.from_numpy(nf), tp, L, 2, A)
+    assert np.abs(H(res["predictions"]) - main.detach().numpy()).max() < 1e-4
+    assert np.abs(H(res["support_predictions"]) - sup.detach().numpy()).max() < 1e-4
+    yt = T(y)
+    lr = 0.9 * torch_ref.cross_entropy(main, yt) + 0.1 * torch_ref.cross_entropy(sup, yt.repeat(1, L))
+    lr.backward()
+    assert abs(float(loss.detach()) - lr.item()) < 1e-4 * abs(lr.item())
+    check_grads(g, tp, tol=5e-4)
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64)
 

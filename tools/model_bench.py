@@ -30,6 +30,12 @@ CONFIGS = {
     "lstm_b512": dict(model=flm.LstmModel, B=512, frame=True),
     "lstm_attn": dict(model=flm.LstmAttentionMaxPoolingModel, B=128, frame=True),
     "netvlad": dict(model=flm.NetVLADModel, B=128, frame=True),
+    "config5": dict(model=flm.GatedNetVLADAttentionChainModel, B=128, frame=True, multitask=True,
+                    flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3))),
+    "config5_bf16": dict(model=flm.GatedNetVLADAttentionChainModel, B=128, frame=True, multitask=True,
+                         flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3),
+                                    compute_dtype="bfloat16")),
+    "netvlad_bf16": dict(model=flm.NetVLADModel, B=128, frame=True, flags=dict(compute_dtype="bfloat16")),
     "dbof": dict(model=flm.DbofModel, B=128, frame=True, flags=dict(dbof_add_batch_norm=False)),
 }
 
@@ -76,5 +82,5 @@ def run(name, steps=5):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or [c for c in CONFIGS if c != "lstm_b512"]):
+    for n in (sys.argv[1:] or [c for c in CONFIGS if c not in ("lstm_b512", "config5_bf16", "netvlad_bf16")]):
         run(n)

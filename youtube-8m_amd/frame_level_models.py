@@ -222,8 +222,8 @@ class NetVLADModel(models.BaseModel):
     gating = None
     accepts_quantized_input = True
 
-    def create_model(self, model_input, vocab_size, num_frames, cluster_size=None, hidden_size=None, gating=None,
-                     **unused_params):
+    def descriptor(self, model_input, num_frames, cluster_size=None, hidden_size=None, gating=None):
+        """[B,F,D] frames (uint8 raw or float transformed) -> hidden descriptor h [B, netvlad_hidden_size]."""
         K = cluster_size or FLAGS.netvlad_cluster_size
         Hfc = hidden_size or FLAGS.netvlad_hidden_size
         gating = (self.gating if self.gating is not None else FLAGS.netvlad_gating) if gating is None else gating
@@ -247,9 +247,45 @@ class NetVLADModel(models.BaseModel):
         if gating:
             gate = video_level_models.fully_connected(h, Hfc, "netvlad/gating", activation="sigmoid")
             h = h * gate
+        return h
+
+    def create_model(self, model_input, vocab_size, num_frames, cluster_size=None, hidden_size=None, gating=None,
+                     **unused_params):
+        h = self.descriptor(model_input, num_frames, cluster_size, hidden_size, gating)
         return _head()().create_model(model_input=h, original_input=model_input, vocab_size=vocab_size,
                                       **unused_params)
 
 
 class GatedNetVLADModel(NetVLADModel):
     gating = True
+
+
+class GatedNetVLADAttentionChainModel(GatedNetVLADModel):
+    """BASELINE configs[4] composite ("Gated-NetVLAD + attention pooling + chained MoE"), fixed in SURVEY.md Appendix B
+    from reference parts (NOT a reference class):
+      (i)   h[b]       = gated NetVLAD descriptor (GatedNetVLADModel.descriptor);
+      (ii)  att[b,a,:] = sum_f w[b,f,a] x[b,f,:],  w = renorm(mask * softmax_F([x || mean_x] W_a + b_a)) -- the attention
+            pooling of W/all_frame_models/lstm_attention_max_pooling_model.py:34,51-63 with the LSTM outputs replaced by
+            the frames themselves, A = --lstm_attentions;
+      (iii) [h[b] || att[b,a]] -> DeepCombineChainModel (W/all_video_models/deep_combine_chain_model.py:12-85) on the
+            [B*A] rows -> max over the A attentions (lstm_attention_max_pooling_model.py:64-66), for the predictions AND the
+            support predictions so that they line up with MultiTaskCrossEntropyLoss.get_support (W/losses.py:225-255)."""
+
+    def create_model(self, model_input, vocab_size, num_frames, l2_penalty=1e-8, **unused_params):
+        A = FLAGS.lstm_attentions
+        B, F, D = model_input.shape
+        h = self.descriptor(model_input, num_frames)                                       # [B,Hfc] (uint8 stays fused)
+        x = ops.dequant_l2norm(model_input, num_frames) if model_input.dtype == torch.uint8 else model_input
+        nf = num_frames.to(x.dtype).clamp(min=1).view(B, 1, 1) if num_frames is not None else float(F)
+        mean_x = (x.sum(dim=1, keepdim=True) / nf).expand(B, F, D)
+        act = video_level_models.fully_connected(torch.cat([x, mean_x], dim=2), A, "attention-", l2_penalty=l2_penalty)
+        w = seq_ops.attention_weights(act, num_frames)                                     # [B,F,A]
+        att = seq_ops.pool_tn(w, x)                                                        # [B,A,D]
+        chain_in = torch.cat([h.unsqueeze(1).expand(B, A, h.shape[1]), att], dim=2).reshape(B * A, -1)
+        unused_params.pop("original_input", None)
+        res = video_level_models.DeepCombineChainModel().create_model(chain_in, vocab_size, l2_penalty=l2_penalty,
+                                                                      original_input=model_input, **unused_params)
+        out = {"predictions": res["predictions"].view(B, A, vocab_size).max(dim=1).values}
+        sup = res["support_predictions"]
+        out["support_predictions"] = sup.view(B, A, sup.shape[1]).max(dim=1).values
+        return out
