@@ -430,6 +430,38 @@ def _bf16_round(a):
     return u.astype(np.uint32).view(np.float32)
 
 
+def test_linear_bf16_mode(dev, monkeypatch):
+    """ops.linear with bf16=True: forward equals the fp64 product of the bf16-ROUNDED operands; dW / dx / db against fp64
+    autograd of the unrounded op at bf16 resolution; small problems stay on the exact fp32 path."""
+    from yt8m_amd.variables import reset_default_graph, random_normal, zeros
+    monkeypatch.setattr(ops, "BF16_MIN_ROWS", 2)                             # production: 512 rows (cast amortisation)
+    rs = np.random.RandomState(33)
+    M, K, N = 256, 512, 1024                                                # M*N*K = 2^27: bf16 for all three GEMMs
+    g = reset_default_graph(device=dev, seed=1)
+    g.begin_step()
+    W = g.get_variable("fc/weights", (K, N), random_normal(0.05))
+    b = g.get_variable("fc/biases", (N,), zeros)
+    g.finalize()
+    x = rs.randn(M, K).astype(np.float32)
+    dy = rs.randn(M, N).astype(np.float32)
+    xd = D(x, dev).requires_grad_(True)
+    y = ops.linear(xd, W, b, bf16=True)
+    Wh = H(W.data)
+    ref = _bf16_round(x).astype(np.float64) @ _bf16_round(Wh.astype(np.float32)).astype(np.float64)
+    assert np.abs(H(y) - ref).max() < 1e-4
+    assert 1e-4 < np.abs(H(y) - x.astype(np.float64) @ Wh).max() < 5e-2       # it really is the bf16 path
+    y.backward(D(dy, dev))
+    dW, dx, db = x.astype(np.float64).T @ dy, dy.astype(np.float64) @ Wh.T, dy.astype(np.float64).sum(0)
+    assert np.abs(H(W.grad) - dW).max() < 1e-2 * np.abs(dW).max()
+    assert np.abs(H(xd.grad) - dx).max() < 1e-2 * np.abs(dx).max()
+    assert np.abs(H(b.grad) - db).max() < 1e-4 * np.abs(db).max()
+    # small problem: exact path even when bf16 is requested
+    g.begin_step()
+    xs = D(x[:8], dev)
+    ys = ops.linear(xs, W, b, bf16=True)
+    assert np.abs(H(ys) - x[:8].astype(np.float64) @ Wh).max() < 1e-5
+
+
 def test_cast_bf16_and_bf16_gemm(dev):
     """bf16 path: the cast is bit-exact against the RNE restatement (also transposed, ragged shapes); the bf16 NT GEMM
     equals the fp64 product of the ROUNDED operands to fp32-accumulation noise, across tile / split-K / K-tail cases."""

@@ -447,11 +447,13 @@ def _bf16_round(a):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_moe_head_bf16(dev, flags, fused):
+def test_moe_head_bf16(dev, flags, fused, monkeypatch):
     """compute_dtype=bfloat16 (BASELINE config 5): the head's GEMMs take bf16 operands with fp32 accumulation.  Forward is
     checked two ways: against the fp64 oracle evaluated on the bf16-rounded operands (tight: only accumulation order
     differs) and against the unrounded oracle at north_star's 1e-3; gradients against fp64 autograd at bf16 resolution
     (operands of dW = x^T dZ carry 2^-9 relative rounding each).  Master weights / loss / optimiser stay fp32."""
+    import yt8m_amd.ops as ops
+    monkeypatch.setattr(ops, "BF16_MIN_ROWS", 2)                     # the production threshold (512 rows) is a cost model
     rs = np.random.RandomState(31)
     B, Dm, V, M = 64, 96, 250, 2
     x = rs.randn(B, Dm).astype(np.float32)
@@ -490,9 +492,11 @@ def test_moe_head_bf16(dev, flags, fused):
     assert np.abs(H(r3["predictions"]) - po.numpy()).max() < 1e-5
 
 
-def test_bf16_training_tracks_fp32(dev, flags):
+def test_bf16_training_tracks_fp32(dev, flags, monkeypatch):
     """Ten steps of the config-1 shape at reduced size: the bf16-operand path's loss curve stays within 1e-3 relative of
     the fp32 path's (fp32 master weights + fp32 Adam, so rounding does not accumulate in the parameters)."""
+    import yt8m_amd.ops as ops
+    monkeypatch.setattr(ops, "BF16_MIN_ROWS", 2)
     rs = np.random.RandomState(41)
     B, Dm, V = 128, 128, 400
     xs = [rs.randn(B, Dm).astype(np.float32) for _ in range(10)]

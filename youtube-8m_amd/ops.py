@@ -13,7 +13,13 @@ import ctypes
 import torch
 
 from . import _lib
+from .flags import FLAGS, DEFINE_string
 from .variables import get_default_graph
+
+# new: compute dtype of the large GEMMs (BASELINE config 5 is bf16; configs 1-4 are fp32)
+DEFINE_string("compute_dtype", "float32", "float32 (exact fp32 MFMA) or bfloat16 (bf16 MFMA operands, fp32 accumulate, fp32 "
+              "master weights / gradients / optimiser) for the fully-connected and MoE-head GEMMs; the fused NetVLAD pooling "
+              "uses single-f16 operands instead of the f16 hi+lo split.")
 
 ACT = {"sigmoid": 0, "relu": 1, "relu6": 2, "tanh": 3, "elu": 4}
 XENT_EPS = 10e-6  # W/losses.py:115
@@ -350,15 +356,34 @@ def _token(graph=None):
     return g.token
 
 
+BF16_MIN_MACS = 1 << 27      # below this the cast passes cost more than the bf16 MFMAs save
+BF16_MIN_ROWS = 512          # a weight matrix is re-cast every step (6 B/element): that only pays when >= ~100 activation
+                             # rows share it; 512 keeps a margin (measured: B = 128 NetVLAD hidden FC loses, 1024-row chain wins)
+
+
+def _use_bf16(bf16, M, N, K, weight_operand=True):
+    """bf16 operands for C[M,N] = A[M,K].B[K,N]?  Needs an even reduction length (bf16 pairs), enough work, and -- when B
+    is a weight matrix that has to be cast for this one product -- enough rows to amortise the cast."""
+    return (bool(bf16) and K % 2 == 0 and M * N * K >= BF16_MIN_MACS and (not weight_operand or M >= BF16_MIN_ROWS))
+
+
 class _Linear(torch.autograd.Function):
-    """y = x.W (+ b) for a 2-D x.  slim.fully_connected without activation."""
+    """y = x.W (+ b) for a 2-D x.  slim.fully_connected without activation.
+    bf16 = True (compute_dtype=bfloat16): each of the three GEMMs takes bf16 copies of its operands (K-contiguous on both
+    sides, fp32 accumulation, fp32 master weights and gradients) when it is large enough to pay for the casts."""
 
     @staticmethod
-    def forward(ctx, x, token, W, b):
+    def forward(ctx, x, token, W, b, bf16):
         x2 = _f32c(x)
-        y = gemm(x2, W.data, bias=None if b is None else b.data)
+        M, K = x2.shape
+        N = W.data.shape[1]
+        if _use_bf16(bf16, M, N, K):
+            y, = gemm_bf16_nt_grouped([dict(A=cast_bf16(x2), B=cast_bf16(W.data, transpose=True),
+                                            bias=None if b is None else b.data)])
+        else:
+            y = gemm(x2, W.data, bias=None if b is None else b.data)
         ctx.save_for_backward(x2)
-        ctx.W, ctx.b = W, b
+        ctx.W, ctx.b, ctx.bf16 = W, b, bf16
         return y
 
     @staticmethod
@@ -366,18 +391,32 @@ class _Linear(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         W, b = ctx.W, ctx.b
         dy = _f32c(dy)
+        M, K = x.shape
+        N = dy.shape[1]
+        dyT = None
         if W.trainable and W.grad is not None:
-            gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta())
+            if _use_bf16(ctx.bf16, K, N, M, weight_operand=False):   # dW[K,N] = x^T dy: reduction over the M rows
+                gemm_bf16_nt_grouped([dict(A=cast_bf16(x, transpose=True), B=cast_bf16(dy, transpose=True), out=W.grad,
+                                           beta=W.grad_beta())])
+            else:
+                gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta())
         if b is not None and b.trainable and b.grad is not None:
             colsum(dy, b.grad.view(-1), beta=b.grad_beta())
-        dx = gemm(dy, W.data, transB=True) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _use_bf16(ctx.bf16, M, K, N):                     # dx[M,K] = dy W^T: reduction over N
+                dx, = gemm_bf16_nt_grouped([dict(A=cast_bf16(dy), B=cast_bf16(W.data))])
+            else:
+                dx = gemm(dy, W.data, transB=True)
+        return dx, None, None, None, None
 
 
-def linear(x, W, b=None):
+def linear(x, W, b=None, bf16=None):
     """Rank-N input is flattened on the leading dims like slim.fully_connected."""
     lead = x.shape[:-1]
-    y = _Linear.apply(x.reshape(-1, x.shape[-1]), _token(W._graph), W, b)
+    if bf16 is None:
+        bf16 = FLAGS.compute_dtype == "bfloat16"
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), _token(W._graph), W, b, bool(bf16))
     return y.view(*lead, y.shape[-1])
 
 
@@ -446,8 +485,9 @@ class _MoeHead(torch.autograd.Function):
 
 
 def _bf16_ok(x2):
-    """bf16 GEMMs need even reduction lengths: D for the forward, the batch for dW."""
-    return x2.shape[0] % 2 == 0 and x2.shape[1] % 2 == 0
+    """bf16 GEMMs need even reduction lengths (D for the forward, the batch for dW) and enough rows to amortise the
+    per-step cast of the weights (see BF16_MIN_ROWS)."""
+    return x2.shape[0] % 2 == 0 and x2.shape[1] % 2 == 0 and x2.shape[0] >= BF16_MIN_ROWS
 
 
 def _moe_logits(x2, Wg, We, be, bf16):

@@ -16,9 +16,6 @@ DEFINE_integer("deep_chain_layers", 3, "The number of layers used for DeepChainM
 DEFINE_integer("deep_chain_relu_cells", 200, "The number of relu cells used for DeepChainModel")
 DEFINE_string("deep_chain_relu_type", "relu", "The type of relu cells used for DeepChainModel (options are elu and relu)")
 DEFINE_bool("deep_chain_use_length", False, "unused by DeepCombineChainModel (kept for flag compatibility)")
-# new: compute dtype of the MoE head GEMMs (BASELINE config 5 is bf16; configs 1-4 are fp32)
-DEFINE_string("compute_dtype", "float32", "float32 (exact fp32 MFMA) or bfloat16 (bf16 MFMA operands, fp32 accumulate, fp32 "
-              "master weights / optimiser) for the MoE head GEMMs.")
 # new: MoeModel may return its own "loss" (W/train.py:384-385 honours it) computed by the fused mixing+cross-entropy pass
 DEFINE_bool("fused_head_loss", True, "MoeModel returns {'loss': CrossEntropyLoss(predictions, labels)} from a fused kernel "
             "when labels are given, --label_loss=CrossEntropyLoss, no label smoothing and no --multitask.")
