@@ -214,7 +214,8 @@ int yt8m_softmax_rows_bwd(const float* a, const float* da, const int32_t* num_fr
 
 /* ---- NetVLAD residual aggregation + intra-normalisation (not in the reference) -------------
  * agg [B,K,D] = a^T x per video (batched GEMM), a [B,F,K] masked assignment, centres [K,D]:
- * n = sum_f a;  vlad = l2norm_D(agg - n*c).  One pass over the rows.  n_out [B,K] is saved for the backward.
+ * n = sum_f a;  vlad = l2norm_D(agg - n*c).  One pass over the rows.  n_out [B,K] is saved for the backward
+ * (a == NULL: n_out already holds n on entry -- the fused uint8 pooling computes it).
  * bwd: dagg [B,K,D], dn [B,K] (to be broadcast over frames into da), dcentres [K,D] (beta 0/1; may be NULL). */
 int yt8m_vlad_finish_fwd(const float* agg, const float* a, const float* centres, float* vlad, float* n_out,
                          int64_t B, int64_t F, int64_t K, int64_t D, float eps, yt8m_stream_t stream);
@@ -226,18 +227,21 @@ int yt8m_vlad_finish_bwd(const float* agg, const float* n_in, const float* centr
  * Replaces, for the NetVLAD plugin, the chain  Dequantize (W/utils.py:23-38) -> zero padding (W/readers.py:178-187) ->
  * l2_normalize (W/all_feature_transform/default_transformer.py:7) -> assignment GEMM -> masked softmax -> aggregation GEMM.
  *   q [B,F,D] uint8 (16-byte aligned), num_frames [B] int32 or NULL, Wc [D,K], bc [K]
- *   a_out [B,F,K] = softmax_K(x.Wc + bc) * (f < num_frames)      x = l2_normalize(dequantise(q)), never written
- *   agg_out [B,K,D] = sum_f a[f,k] x[f,:]                        (feed yt8m_vlad_finish_fwd)
- * bwd: dagg [B,K,D], dn [B,K] (both from yt8m_vlad_finish_bwd) -> dWc [D,K], dbc [K] (beta 0/1).  q carries no gradient.
+ *   a [B,F,K] = softmax_K(x.Wc + bc) * (f < num_frames)          x = l2_normalize(dequantise(q)), never written
+ *   cT_out [B,K,Fp] = a[f,k] / ||dequantise(q[f])||, frames contiguous, Fp = F rounded up to 32 (zero padded): the tensor
+ *                     the backward needs (a = cT * ||.||); 16-byte aligned
+ *   n_out [B,K] = sum_f a[f,k];   agg_out [B,K,D] = sum_f a[f,k] x[f,:]     (feed yt8m_vlad_finish_fwd with a = NULL)
+ * bwd: cT (from the forward), dagg [B,K,D], dn [B,K] (both from yt8m_vlad_finish_bwd) -> dWc [D,K], dbc [K] (beta 0/1).
+ * q carries no gradient.
  * nsplit = 2: fp32 operands enter the f16 matrix cores as hi + lo halves (fp32-class, ~1e-6 relative);
  * nsplit = 1: single f16 operand (the reduced-precision variant, ~5e-4 relative on the weights).
  * Supported when yt8m_netvlad_supported() != 0 (K == 64, D % 64 == 0); workspace from yt8m_netvlad_workspace_bytes(). */
 int yt8m_netvlad_supported(int64_t B, int64_t F, int64_t D, int64_t K);
 int64_t yt8m_netvlad_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t K);
 int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, const float* Wc, const float* bc, int64_t B,
-                        int64_t F, int64_t D, int64_t K, int nsplit, float eps, float* a_out, float* agg_out,
-                        void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
-int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float* a, const float* dagg,
+                        int64_t F, int64_t D, int64_t K, int nsplit, float eps, float* cT_out, float* n_out,
+                        float* agg_out, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float* cT, const float* dagg,
                         const float* dn, int64_t B, int64_t F, int64_t D, int64_t K, int nsplit, float eps,
                         float* dWc, float dWc_beta, float* dbc, float dbc_beta, void* workspace,
                         int64_t workspace_bytes, yt8m_stream_t stream);

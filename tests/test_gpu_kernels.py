@@ -359,13 +359,21 @@ def test_netvlad_fused_u8(dev, shape, nsplit):
     aref, aggref, dWref, dbref = _netvlad_pool_ref(q, nf, Wc.astype(np.float64), bc.astype(np.float64),
                                                    dagg.astype(np.float64), dn.astype(np.float64))
     qd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev)
-    a, agg = seq_ops.netvlad_fwd_u8(qd, nfd, D(Wc, dev), D(bc, dev), nsplit=nsplit)
+    cT, nsum, agg = seq_ops.netvlad_fwd_u8(qd, nfd, D(Wc, dev), D(bc, dev), nsplit=nsplit)
     tol = 2e-6 if nsplit == 2 else 3e-3
-    assert np.abs(H(a) - aref).max() < tol
+    # cT[b,k,f] = a[b,f,k] / ||dequantised frame||, frames contiguous and zero padded to a multiple of 32
+    Fp = (F + 31) // 32 * 32
+    assert tuple(cT.shape) == (B, K, Fp)
+    norm = np.sqrt(((q.astype(np.float64) * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)) ** 2).sum(-1))       # [B,F]
+    a = H(cT)[:, :, :F].transpose(0, 2, 1) * norm[:, :, None]
+    assert np.abs(a - aref).max() < tol
+    assert (H(cT)[:, :, F:] == 0).all()
+    assert np.abs(H(nsum) - aref.sum(1)).max() < tol * F
     assert np.abs(H(agg) - aggref).max() < tol * max(1.0, np.abs(aggref).max())
-    assert (H(a)[1, 1:] == 0).all()                                           # masked frames are exactly 0
+    assert (a[1, 1:] == 0).all()                                              # masked frames are exactly 0
     if B > 2:
-        assert (H(a)[2] == 0).all() and (H(agg)[2] == 0).all()
+        assert (a[2] == 0).all() and (H(agg)[2] == 0).all()
+    a = cT
     # backward (uses the kernel's own a, as the training step does)
     dW = torch.full((Dm, K), 7.0, device=dev)
     db = torch.full((K,), 7.0, device=dev)
@@ -379,8 +387,8 @@ def test_netvlad_fused_u8(dev, shape, nsplit):
     seq_ops.netvlad_bwd_u8(qd, nfd, a, D(dagg * 1e-35, dev), D(dn * 1e-35, dev), dW, 0.0, db, 0.0, nsplit=nsplit)
     assert torch.isfinite(dW).all() and torch.isfinite(db).all() and float(dW.abs().max()) < 1e-30
     # deterministic: same bits on a second run
-    a2, agg2 = seq_ops.netvlad_fwd_u8(qd, nfd, D(Wc, dev), D(bc, dev), nsplit=nsplit)
-    assert torch.equal(a, a2) and torch.equal(agg, agg2)
+    c2, n2, agg2 = seq_ops.netvlad_fwd_u8(qd, nfd, D(Wc, dev), D(bc, dev), nsplit=nsplit)
+    assert torch.equal(cT, c2) and torch.equal(agg, agg2) and torch.equal(nsum, n2)
 
 
 def test_netvlad_fused_rejects_unsupported(dev):

@@ -39,7 +39,7 @@ def main():
         dn = torch.randn((B, K), device=dev, generator=gen) * 1e-3
         dW, db = torch.empty((D, K), device=dev), torch.empty(K, device=dev)
         for nsplit in (2, 1):
-            a, agg = seq_ops.netvlad_fwd_u8(q, nf, Wc, bc, nsplit=nsplit)
+            a, _, agg = seq_ops.netvlad_fwd_u8(q, nf, Wc, bc, nsplit=nsplit)
             tf = timeit(lambda: seq_ops.netvlad_fwd_u8(q, nf, Wc, bc, nsplit=nsplit))
             tb = timeit(lambda: seq_ops.netvlad_bwd_u8(q, nf, a, dagg, dn, dW, 0.0, db, 0.0, nsplit=nsplit))
             # algorithmic HBM bytes: fwd reads q once, writes a and agg; bwd reads q, a, dagg once

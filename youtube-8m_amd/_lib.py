@@ -60,7 +60,7 @@ SIGNATURES = {
     "yt8m_softmax_rows_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_netvlad_supported": (c_int, [c_int64, c_int64, c_int64, c_int64]),
     "yt8m_netvlad_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
-    "yt8m_netvlad_fwd_u8": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_float, P, P, P, c_int64, P]),
+    "yt8m_netvlad_fwd_u8": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_float, P, P, P, P, c_int64, P]),
     "yt8m_netvlad_bwd_u8": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_float, P, c_float, P, c_float,
                                     P, c_int64, P]),
     "yt8m_vlad_finish_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),

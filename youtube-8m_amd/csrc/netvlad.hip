@@ -18,9 +18,14 @@ __global__ __launch_bounds__(256) void vlad_finish_fwd_kernel(const float* __res
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b,k)
   if (row >= B * K) return;
   const int64_t b = row / K, k = row - b * K;
-  float n = 0.f;
-  for (int64_t f = lane; f < F; f += 64) n += a[(b * F + f) * K + k];
-  n = wave_sum(n);
+  float n;
+  if (a) {
+    n = 0.f;
+    for (int64_t f = lane; f < F; f += 64) n += a[(b * F + f) * K + k];
+    n = wave_sum(n);
+  } else {
+    n = n_out[row];                                                       // precomputed by the fused pooling kernels
+  }
   const float* ar = agg + row * D;
   const float* cr = c + k * D;
   float ss = 0.f;
@@ -29,7 +34,7 @@ __global__ __launch_bounds__(256) void vlad_finish_fwd_kernel(const float* __res
   const float r = rsqrtf(fmaxf(ss, eps));
   float* vr = vlad + row * D;
   for (int64_t d = lane; d < D; d += 64) vr[d] = (ar[d] - n * cr[d]) * r;
-  if (lane == 0) n_out[row] = n;
+  if (a && lane == 0) n_out[row] = n;
 }
 
 __global__ __launch_bounds__(256) void vlad_finish_bwd_kernel(const float* __restrict__ agg, const float* __restrict__ n_in,
@@ -82,7 +87,7 @@ extern "C" int yt8m_vlad_finish_fwd(const float* agg, const float* a, const floa
                                     int64_t F, int64_t K, int64_t D, float eps, yt8m_stream_t stream) {
   YT8M_REQUIRE(B >= 0 && F >= 0 && K >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
   if (B * K * D == 0) return YT8M_OK;
-  YT8M_REQUIRE(agg && centres && vlad && n_out && (a || F == 0), YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(agg && centres && vlad && n_out, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_NETVLAD, s);
   hipLaunchKernelGGL(vlad_finish_fwd_kernel, dim3((unsigned)((B * K + 3) / 4)), dim3(256), 0, s, agg, a, centres, vlad, n_out, B,

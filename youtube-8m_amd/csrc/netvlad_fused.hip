@@ -132,115 +132,95 @@ struct RowsArgs {
   const int32_t* nf;       // [B] or null
   const _Float16* Wp;      // packed weights
   int64_t wp_bstride;      // halves between videos (0: shared W_c)
-  const float* cs_part;    // [*, nblk, 64]
+  const float* cs;         // [*, 64] column sums of the (rounded, unscaled) packed weights
   int64_t cs_bstride;      // floats between videos (0: shared)
   const float* wscale;     // [1] or [B]
   int wscale_bstride;      // 0 / 1
   const float* bias;       // fwd: b_c [64];  bwd: dn [B,64]
   int bias_bstride;        // 0 / 64
-  float* a;                // fwd: out [B,F,64];  bwd: in
-  float* outT;             // [B,64,Fp]: fwd a*r, bwd ds*r
-  float* wgmax;            // bwd: [B*ranges] max |outT| of the workgroup
-  float* colpart;          // bwd: [B*ranges,64] sum over the workgroup's frames of ds
+  const float* cfw;        // bwd: the forward's c = a*r [B,64,Fp] (a is recovered as c / r);  fwd: unused
+  float* outT;             // [B,64,Fp]: fwd a*r, bwd ds*r  (frames contiguous: what the cols kernel consumes)
+  float* wgmax;            // [B*ranges] max |outT| of the workgroup
+  float* colpart;          // [B*ranges,64] sum over the workgroup's frames of a (fwd: n = sum_f a) or ds (bwd: db_c)
   int B, F, D, Fp;
   float eps;
 };
 
-template <int NSPLIT>
-__device__ __forceinline__ void rows_fill(const _Float16* src, _Float16* stage, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2 * NSPLIT; ++i) {
-    const int idx = tid + i * 256;                                  // 16-byte slot
-    const _Float16* s = src + idx * 8;
-    _Float16* d = stage + (idx & ~63) * 8;                          // wave-uniform base; hardware adds lane*16 B
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                     (__attribute__((address_space(3))) void*)d, 16, 0, 0);
-  }
-}
+// ---- LDS-DMA + inline-asm LDS reads ---------------------------------------------------------------------------------
+// Both kernels stream EVERY operand HBM/L2 -> LDS with LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) through a
+// 3-stage ring with counted s_waitcnt vmcnt(N): two blocks stay in flight while one is consumed.  The LDS reads are
+// inline asm on purpose: hipcc inserts s_waitcnt vmcnt(0) before any LDS load it can see while LDS-DMA is pending (and
+// before any VGPR load result is used), which would drain the blocks that were only just issued.
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
 
-// fragment reads + MFMAs of one 64-feature block.  The LDS reads are inline asm on purpose: hipcc waits for ALL pending
-// LDS-DMA (s_waitcnt vmcnt(0)) before any LDS load it can see -- that would drain the W block / q rows that were only just
-// issued for the NEXT block.  The stage being read here was completed by the explicit wait + barrier at the block's top.
-template <int OFF>
-__device__ __forceinline__ h8 lds_read_b128(uint32_t addr) {
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {      // + lane*16 bytes added by hardware
+  __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ h8 lds_read_h8(uint32_t addr) {
   h8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
-
-template <int NSPLIT, int NT>
-__device__ __forceinline__ void rows_mma(uint32_t st /* LDS byte address of the stage + lane*16 */, const h8 (&af)[NT][2],
-                                         f4 (&acc)[NT][4]) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    h8 bf[4][NSPLIT];
-    if (ks == 0) {
-      bf[0][0] = lds_read_b128<((0 * 4 + 0) * NSPLIT + 0) * 1024>(st);
-      bf[1][0] = lds_read_b128<((0 * 4 + 1) * NSPLIT + 0) * 1024>(st);
-      bf[2][0] = lds_read_b128<((0 * 4 + 2) * NSPLIT + 0) * 1024>(st);
-      bf[3][0] = lds_read_b128<((0 * 4 + 3) * NSPLIT + 0) * 1024>(st);
-      if (NSPLIT == 2) {
-        bf[0][NSPLIT - 1] = lds_read_b128<((0 * 4 + 0) * NSPLIT + NSPLIT - 1) * 1024>(st);
-        bf[1][NSPLIT - 1] = lds_read_b128<((0 * 4 + 1) * NSPLIT + NSPLIT - 1) * 1024>(st);
-        bf[2][NSPLIT - 1] = lds_read_b128<((0 * 4 + 2) * NSPLIT + NSPLIT - 1) * 1024>(st);
-        bf[3][NSPLIT - 1] = lds_read_b128<((0 * 4 + 3) * NSPLIT + NSPLIT - 1) * 1024>(st);
-      }
-    } else {
-      bf[0][0] = lds_read_b128<((1 * 4 + 0) * NSPLIT + 0) * 1024>(st);
-      bf[1][0] = lds_read_b128<((1 * 4 + 1) * NSPLIT + 0) * 1024>(st);
-      bf[2][0] = lds_read_b128<((1 * 4 + 2) * NSPLIT + 0) * 1024>(st);
-      bf[3][0] = lds_read_b128<((1 * 4 + 3) * NSPLIT + 0) * 1024>(st);
-      if (NSPLIT == 2) {
-        bf[0][NSPLIT - 1] = lds_read_b128<((1 * 4 + 0) * NSPLIT + NSPLIT - 1) * 1024>(st);
-        bf[1][NSPLIT - 1] = lds_read_b128<((1 * 4 + 1) * NSPLIT + NSPLIT - 1) * 1024>(st);
-        bf[2][NSPLIT - 1] = lds_read_b128<((1 * 4 + 2) * NSPLIT + NSPLIT - 1) * 1024>(st);
-        bf[3][NSPLIT - 1] = lds_read_b128<((1 * 4 + 3) * NSPLIT + NSPLIT - 1) * 1024>(st);
-      }
-    }
-    // the compiler does not track asm loads: wait here, and tie the fragments to the wait so the MFMAs stay below it
-    if (NSPLIT == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(bf[0][0]), "+v"(bf[1][0]), "+v"(bf[2][0]), "+v"(bf[3][0]), "+v"(bf[0][NSPLIT - 1]),
-                     "+v"(bf[1][NSPLIT - 1]), "+v"(bf[2][NSPLIT - 1]), "+v"(bf[3][NSPLIT - 1])
-                   :
-                   : "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0][0]), "+v"(bf[1][0]), "+v"(bf[2][0]), "+v"(bf[3][0]) : : "memory");
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int sp = 0; sp < NSPLIT; ++sp)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t][ks], bf[ct][sp], acc[t][ct], 0, 0, 0);
-  }
+__device__ __forceinline__ u4 lds_read_u4(uint32_t addr) {
+  u4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
 }
+__device__ __forceinline__ f4 lds_read_f4(uint32_t addr) {
+  f4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// reductions over the 16 lanes of a DPP row (the 16 clusters of one accumulator tile): quad xor-1, quad xor-2, half-row
+// mirror, row mirror -- four full-rate VALU DPP moves, no LDS traffic (ds_bpermute-based shuffles made the epilogue cost
+// more than the main loop).  Every lane ends up with the reduction over its row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float grp16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_mov<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov<0x141>(v));     // row_half_mirror
+  v = fmaxf(v, dpp_mov<0x140>(v));     // row_mirror
   return v;
 }
 __device__ __forceinline__ float grp16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
   return v;
 }
 
-// NT = row tiles per wave (rows per workgroup = 64 NT).  Everything that issues memory operations is free of run-time
-// branches (NT is a template parameter, the pipeline tail is peeled) so that the compiler's s_waitcnt counts are exact:
-// a conservative count would wait for the loads issued one block AHEAD and serialise the pipeline.
+// NT = row tiles per wave (rows per workgroup = 64 NT).
+// Per 64-feature block: the packed W block goes L2 -> LDS by LDS-DMA (2 stages), the workgroup's q bytes go HBM -> VGPR
+// (16 B per lane and tile) one block ahead.  hipcc drains vmcnt to 0 whenever a VGPR load is consumed while LDS-DMA is
+// pending (it treats the DMA as a possibly out-of-order flat access), so the block's q bytes are converted to f16
+// fragments FIRST -- that wait covers loads issued a whole block ago -- and only then W(j+1) / q(j+1) are issued; they fly
+// during the block's MFMAs.  (Loads through inline asm with counted waits were tried: the register allocator is free to
+// copy a not-yet-landed destination register, which it does.)
 template <int NSPLIT, bool BWD, int NT>
 __global__ __launch_bounds__(256) void vlad_rows_kernel(RowsArgs g) {
-  constexpr int BLK = 4096 * NSPLIT;                                 // halves per 64-feature block of packed weights
-  __shared__ __attribute__((aligned(16))) _Float16 Ws[2][BLK];
-  __shared__ float red[4][NK + 1];
+  constexpr int WB = 8192 * NSPLIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][WB] + reduction scratch
+  float (*red)[NK + 1] = reinterpret_cast<float (*)[NK + 1]>(smem + 2 * WB);
   const int b = blockIdx.y, range = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int m = lane & 15, kg = lane >> 4;
   const int f0 = range * 64 * NT;
   const int nblk = g.D >> 6;
 
+  const char* wsrc = reinterpret_cast<const char*>(g.Wp + (int64_t)b * g.wp_bstride) + tid * 16;
   const uint8_t* qrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -248,7 +228,13 @@ __global__ __launch_bounds__(256) void vlad_rows_kernel(RowsArgs g) {
     f = f < g.F ? f : g.F - 1;                                       // rows beyond the video only feed outputs never stored
     qrow[t] = g.q + ((int64_t)b * g.F + f) * g.D + 16 * kg;
   }
-  const _Float16* Wsrc = g.Wp + (int64_t)b * g.wp_bstride;
+  const int wave_off = (tid & ~63) * 16;
+  auto issue_w = [&](int j, int stage) {
+    char* st = smem + stage * WB + wave_off;
+#pragma unroll
+    for (int i = 0; i < 2 * NSPLIT; ++i) dma16(wsrc + (int64_t)j * WB + i * 4096, st + i * 4096);
+  };
+  const uint32_t wfrag = (uint32_t)(uintptr_t)((AS3 char*)smem) + (uint32_t)lane * 16u;
 
   f4 acc[NT][4];
 #pragma unroll
@@ -259,20 +245,17 @@ __global__ __launch_bounds__(256) void vlad_rows_kernel(RowsArgs g) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0u;
 
-  // Pipeline (2 LDS stages, ONE barrier per 64-feature block).  hipcc drains vmcnt to 0 whenever a VGPR load is consumed
-  // while LDS-DMA is pending (it treats the DMA as a possibly out-of-order flat access), so counted waits are not
-  // available here; instead the block's q bytes are converted to f16 fragments FIRST (that wait covers loads issued a
-  // whole block ago: q(j) and the DMA of W(j)), then W(j+1) / q(j+1) are issued and fly during the block's MFMAs.
   u4 qc[NT];
-  const uint32_t lds_base =
-      (uint32_t)(uintptr_t)((__attribute__((address_space(3))) _Float16*)&Ws[0][0]) + (uint32_t)lane * 16u;
-  rows_fill<NSPLIT>(Wsrc, Ws[0], tid);
+#ifdef NV_TIMING
+  const uint64_t tm0 = __builtin_amdgcn_s_memtime();
+#endif
+  issue_w(0, 0);
 #pragma unroll
   for (int t = 0; t < NT; ++t) qc[t] = *reinterpret_cast<const u4*>(qrow[t]);
 
-  auto block = [&](int j, auto prefetch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // W(j) landed for every wave; stage (j+1)&1 is free again
+  for (int j = 0; j < nblk; ++j) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                 // W(j) landed for every wave; the other stage is free again
     h8 af[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -292,115 +275,157 @@ __global__ __launch_bounds__(256) void vlad_rows_kernel(RowsArgs g) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (decltype(prefetch)::value) {
-      rows_fill<NSPLIT>(Wsrc + (int64_t)(j + 1) * BLK, Ws[(j + 1) & 1], tid);
+    if (j + 1 < nblk) {
+      issue_w(j + 1, (j + 1) & 1);
 #pragma unroll
       for (int t = 0; t < NT; ++t) qc[t] = *reinterpret_cast<const u4*>(qrow[t] + 64 * (j + 1));
     }
     __builtin_amdgcn_sched_barrier(0);
-    rows_mma<NSPLIT, NT>(lds_base + (uint32_t)(j & 1) * (uint32_t)(BLK * 2), af, acc);
+    const uint32_t so = (uint32_t)((j & 1) * WB);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h8 bf[4][NSPLIT];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp) bf[ct][sp] = lds_read_h8(wfrag + so + (uint32_t)(((ks * 4 + ct) * NSPLIT + sp) * 1024));
+      // the compiler does not track asm loads: wait, and tie the registers to the wait so their uses stay below it
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[ct][sp]) : : "memory");
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t][ks], bf[ct][sp], acc[t][ct], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-  };
-  {
-    int j = 0;
-    for (; j + 1 < nblk; ++j) block(j, std::true_type());
-    block(j, std::false_type());
   }
+  __syncthreads();                                                    // LDS is re-used as reduction scratch below
+#ifdef NV_TIMING
+  const uint64_t tm1 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef NV_SKIP_EPI   // (timing experiments only): keep the accumulators alive, skip the epilogue
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t += acc[tt][c][0] + acc[tt][c][1] + acc[tt][c][2] + acc[tt][c][3];
+    if (t == 123.456f) g.outT[tid] = t + (float)(s1[0] + s2[0]);
+    return;
+  }
+#endif
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
-  // 1/||dequantised frame|| from the integer row sums (lane (m, kg) holds a quarter of row m)
-  float rr[NT];
+  // ||dequantised frame||^2 from the integer row sums (lane (m, kg) holds a quarter of row m)
+  float ssq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     uint32_t a1 = s1[t], a2 = s2[t];
     a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
     a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
-    const float ss = (DQ_A * DQ_A) * (float)a2 + (2.0f * DQ_A * DQ_B) * (float)a1 + (float)g.D * (DQ_B * DQ_B);
-    rr[t] = rsqrtf(fmaxf(ss, g.eps));
+    ssq[t] = fmaxf((DQ_A * DQ_A) * (float)a2 + (2.0f * DQ_A * DQ_B) * (float)a1 + (float)g.D * (DQ_B * DQ_B), g.eps);
   }
   const float S = g.wscale[b * g.wscale_bstride];
   const float A1 = DQ_A / S;
   const int n = m;                                                    // result column of this lane inside a cluster tile
   float cb[4], bs[4];
   {
-    const float* cp = g.cs_part + (int64_t)b * g.cs_bstride;
+    const float* cp = g.cs + (int64_t)b * g.cs_bstride;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      float t = 0.f;
-      for (int j = 0; j < nblk; ++j) t += cp[j * NK + 16 * ct + n];
-      cb[ct] = DQ_C * t;
+      cb[ct] = DQ_C * cp[16 * ct + n];
       bs[ct] = g.bias[b * g.bias_bstride + 16 * ct + n];
     }
   }
   const int nfb = g.nf ? min(max(g.nf[b], 0), g.F) : g.F;
   float vmax = 0.f;
-  float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  // results leave as float4 runs of 4 consecutive frames per (cluster, lane): 4 stores per tile (the store path is
+  // issue-bound: one dword store per element made the epilogue cost more than the main loop)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    {
-      const int fb = f0 + 16 * (w + 4 * t) + 4 * kg;                  // first of this lane's 4 result frames
-      f4 ov[4];
+    const int fb = f0 + 16 * (w + 4 * t) + 4 * kg;                    // first of this lane's 4 result frames
+    f4 cin[4];
+    if (BWD) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int f = fb + i;
-        const float r = __shfl(rr[t], 4 * kg + i, 64);
-        float v[4];
+      for (int ct = 0; ct < 4; ++ct)
+        cin[ct] = fb < g.Fp ? *reinterpret_cast<const f4*>(g.cfw + ((int64_t)b * NK + 16 * ct + n) * g.Fp + fb)
+                            : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    f4 ov[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) v[ct] = r * (A1 * acc[t][ct][i] + cb[ct]) + bs[ct];
-        if (!BWD) {
-          const float mx = grp16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-          float e[4], sum = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int f = fb + i;
+      const float ss = __shfl(ssq[t], 4 * kg + i, 64);
+      const float r = rsqrtf(ss);
+      float v[4];
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) { e[ct] = __expf(v[ct] - mx); sum += e[ct]; }
-          sum = grp16_sum(sum);
-          const float inv = f < nfb ? 1.0f / sum : 0.f;
+      for (int ct = 0; ct < 4; ++ct) v[ct] = r * (A1 * acc[t][ct][i] + cb[ct]) + bs[ct];
+      if (!BWD) {
+        const float mx = grp16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float e[4], sum = 0.f;
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            const float av = e[ct] * inv;
-            if (f < g.F) g.a[((int64_t)b * g.F + f) * NK + 16 * ct + n] = av;
-            ov[ct][i] = av * r;
-            vmax = fmaxf(vmax, av * r);
-          }
-        } else {
-          float av[4], dot = 0.f;
+        for (int ct = 0; ct < 4; ++ct) { e[ct] = __expf(v[ct] - mx); sum += e[ct]; }
+        sum = grp16_sum(sum);
+        const float inv = f < nfb ? 1.0f / sum : 0.f;
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            av[ct] = f < g.F ? g.a[((int64_t)b * g.F + f) * NK + 16 * ct + n] : 0.f;
-            dot += av[ct] * v[ct];
-          }
-          dot = grp16_sum(dot);
+        for (int ct = 0; ct < 4; ++ct) {
+          const float av = e[ct] * inv;
+          csum[ct] += av;
+          ov[ct][i] = av * r;
+          vmax = fmaxf(vmax, av * r);
+        }
+      } else {
+        const float rinv = sqrtf(ss);                                 // a = c / r
+        float av[4], dot = 0.f;
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            const float ds = av[ct] * (v[ct] - dot);
-            dsum[ct] += ds;
-            const float e = ds * r;
-            vmax = fmaxf(vmax, fabsf(e));
-            ov[ct][i] = e;
-          }
+        for (int ct = 0; ct < 4; ++ct) {
+          av[ct] = cin[ct][i] * rinv;
+          dot += av[ct] * v[ct];
+        }
+        dot = grp16_sum(dot);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const float ds = av[ct] * (v[ct] - dot);
+          csum[ct] += ds;
+          const float e = ds * r;
+          vmax = fmaxf(vmax, fabsf(e));
+          ov[ct][i] = e;
         }
       }
-      if (fb < g.Fp) {
+    }
+    if (fb < g.Fp) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          *reinterpret_cast<f4*>(g.outT + ((int64_t)b * NK + 16 * ct + n) * g.Fp + fb) = ov[ct];
-      }
+      for (int ct = 0; ct < 4; ++ct)
+        *reinterpret_cast<f4*>(g.outT + ((int64_t)b * NK + 16 * ct + n) * g.Fp + fb) = ov[ct];
     }
   }
   const int slot = b * gridDim.x + range;
-  if (BWD) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      float t = dsum[ct];
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      if (kg == 0) red[w][16 * ct + n] = t;
-    }
+  for (int ct = 0; ct < 4; ++ct) {
+    float t = csum[ct];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (kg == 0) red[w][16 * ct + n] = t;
   }
   vmax = wave_max(vmax);
   if (lane == 0) red[w][NK] = vmax;
   __syncthreads();
-  if (BWD && tid < NK) g.colpart[(int64_t)slot * NK + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid < NK) g.colpart[(int64_t)slot * NK + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   if (tid == 0) g.wgmax[slot] = fmaxf(fmaxf(red[0][NK], red[1][NK]), fmaxf(red[2][NK], red[3][NK]));
+#ifdef NV_TIMING   // (timing experiments only) cycles of the main loop / the epilogue land in n_out[b, 0..1]
+  __syncthreads();
+  if (tid == 0) {
+    const uint64_t tm2 = __builtin_amdgcn_s_memtime();
+    g.colpart[(int64_t)slot * NK + 0] = (float)(tm1 - tm0);
+    g.colpart[(int64_t)slot * NK + 1] = (float)(tm2 - tm1);
+  }
+#endif
 }
 
 // ---- cols kernel ----------------------------------------------------------------------------------------------------
@@ -412,20 +437,70 @@ struct ColsArgs {
   int B, F, D, Fp, vids;   // vids = videos per workgroup (consecutive)
 };
 
+// LDS stage = [q: 32 frames x 384 B of the slice, 16-byte chunks rotated by 4*(row>>3) positions (kg groups of the
+// ds_read_b32 fetch land on different banks)][c: 64 cluster rows x 32 frames fp32, chunks XOR-swizzled by row & 7].
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void vlad_cols_kernel(ColsArgs g) {
+  constexpr int QB = 32 * 384, CBYTES = NK * 128, SB = QB + CBYTES;
+  constexpr int PER = 5;                                             // DMA instructions per thread and step (3 q + 2 c)
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [3][SB]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, kg = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
-  const int dbase = blockIdx.x * 384 + wn * 192;
+  const int d0 = blockIdx.x * 384;
+  const int dbase = d0 + wn * 192;
   const int grp = blockIdx.y;
-  // 64-feature groups past the end of D (last slice of e.g. D = 1024) are computed on clamped, in-bounds addresses and
-  // not stored: the load / MFMA stream stays free of run-time branches (exact s_waitcnt counts, see the rows kernel)
-  int goff[3];
-#pragma unroll
-  for (int gq = 0; gq < 3; ++gq) goff[gq] = min(dbase + 64 * gq, g.D - 64) - dbase;
   const float S = g.scale[0];
   const int steps = g.Fp >> 5;
+
+  // DMA slots of this thread
+  int qrow[3], qd[3], crow[2], cc[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i, row = idx / 24, cpos = idx - row * 24;
+    int c = cpos - 4 * ((row >> 3) & 3);
+    c = c < 0 ? c + 24 : c;
+    qrow[i] = row;
+    qd[i] = min(d0 + 16 * c, g.D - 16);                               // chunks past the end of D (last slice) stay in bounds
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    crow[i] = idx >> 3;
+    cc[i] = (idx & 7) ^ (crow[i] & 7);
+  }
+  const int wave_off = (tid & ~63) * 16;
+  const int v0 = grp * g.vids;
+  const int v1 = min(v0 + g.vids, g.B);
+  const int total = (v1 - v0) * steps;                                // flattened (video, frame step) iterations
+  auto issue = [&](int it, int stage) {
+    const int vq = it / steps;
+    const int v = v0 + vq, s = it - vq * steps;
+    char* st = smem + stage * SB + wave_off;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int f = 32 * s + qrow[i];
+      f = f < g.F ? f : g.F - 1;                                      // padded frames carry c = 0
+      dma16(g.q + ((int64_t)v * g.F + f) * g.D + qd[i], st + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      dma16(g.cT + ((int64_t)v * NK + crow[i]) * g.Fp + 32 * s + 4 * cc[i], st + QB + i * 4096);
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((AS3 char*)smem);
+  uint32_t cfrag[2][2], qfrag[3];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      cfrag[mt][h] = lds0 + (uint32_t)(QB + (32 * wm + 16 * mt + n) * 128 + (((2 * kg + h) ^ (n & 7)) << 4));
+#pragma unroll
+  for (int gq = 0; gq < 3; ++gq) {
+    int pos = 12 * wn + 4 * gq + (n >> 2) + 4 * kg;
+    pos = pos >= 24 ? pos - 24 : pos;
+    qfrag[gq] = lds0 + (uint32_t)(8 * kg * 384 + pos * 16 + (n & 3) * 4);
+  }
 
   f4 acc[2][3][4], acc1[2];
 #pragma unroll
@@ -439,33 +514,26 @@ __global__ __launch_bounds__(256) void vlad_cols_kernel(ColsArgs g) {
   u4 onesv = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
   const h8 ones = __builtin_bit_cast(h8, onesv);
 
-  const int v0 = grp * g.vids;
-  const int v1 = min(v0 + g.vids, g.B);
-  const int total = (v1 - v0) * steps;                                // flattened (video, frame step) iterations
-
-  // operand registers of one step: c rows (2 cluster tiles x 8 frames) and q (3 groups x 8 frames x 4 features)
-  f4 cA[2][2], cN[2][2];
-  uint32_t qA[3][8], qN[3][8];
-  auto load_step = [&](int it, f4 (&cr)[2][2], uint32_t (&qr)[3][8]) {
-    const int v = v0 + it / steps, s = it - (it / steps) * steps;
-    const float* cp = g.cT + ((int64_t)v * NK + 32 * wm + n) * g.Fp + 32 * s + 8 * kg;
+  auto compute = [&](int stage) {
+    const uint32_t so = (uint32_t)(stage * SB);
+    f4 cr[2][2];
+    uint32_t qr[3][8];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      cr[mt][0] = *reinterpret_cast<const f4*>(cp + (int64_t)16 * mt * g.Fp);
-      cr[mt][1] = *reinterpret_cast<const f4*>(cp + (int64_t)16 * mt * g.Fp + 4);
-    }
-    const uint8_t* qv = g.q + (int64_t)v * g.F * g.D + dbase + 4 * n;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int f = 32 * s + 8 * kg + i;
-      f = f < g.F ? f : g.F - 1;                                      // padded frames carry c = 0
-      const uint8_t* qp = qv + (int64_t)f * g.D;
+      for (int h = 0; h < 2; ++h) cr[mt][h] = lds_read_f4(cfrag[mt][h] + so);
 #pragma unroll
-      for (int gq = 0; gq < 3; ++gq) qr[gq][i] = *reinterpret_cast<const uint32_t*>(qp + goff[gq]);
-    }
-  };
-
-  auto compute = [&]() {
+    for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qr[gq][i] = lds_read_u32(qfrag[gq] + so + (uint32_t)(i * 384));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cr[mt][h]) : : "memory");
+#pragma unroll
+    for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(qr[gq][i]) : : "memory");
     // split the fp32 operand into scaled f16 hi (+ lo)
     h8 af[2][NSPLIT];
 #pragma unroll
@@ -473,7 +541,7 @@ __global__ __launch_bounds__(256) void vlad_cols_kernel(ColsArgs g) {
       h8 hi, lo;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float x = cA[mt][i >> 2][i & 3] * S;
+        const float x = cr[mt][i >> 2][i & 3] * S;
         hi[i] = (_Float16)x;
         lo[i] = (_Float16)(x - (float)hi[i]);
       }
@@ -487,40 +555,36 @@ __global__ __launch_bounds__(256) void vlad_cols_kernel(ColsArgs g) {
         acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][sp], ones, acc1[mt], 0, 0, 0);
 #pragma unroll
     for (int gq = 0; gq < 3; ++gq) {
-      {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          // byte t of 8 frame rows -> 8 halves (1024 + q), frame pairs packed per register
-          const uint32_t sel = 0x0c040c00u + (uint32_t)t * 0x00010001u;   // [0, S0.byte t, 0, S1.byte t]
-          u4 bv;
+      for (int t = 0; t < 4; ++t) {
+        // byte t of 8 frame rows -> 8 halves (1024 + q) - 1152 = q - 128, frame pairs packed per register
+        const uint32_t sel = 0x0c040c00u + (uint32_t)t * 0x00010001u;   // [0, S0.byte t, 0, S1.byte t]
+        u4 bv;
 #pragma unroll
-          for (int p = 0; p < 4; ++p) bv[p] = __builtin_amdgcn_perm(qA[gq][2 * p + 1], qA[gq][2 * p], sel) | BIAS2;
-          const h8 bq = __builtin_bit_cast(h8, bv) - (_Float16)1152.0f;   // q - 128
+        for (int p = 0; p < 4; ++p) bv[p] = __builtin_amdgcn_perm(qr[gq][2 * p + 1], qr[gq][2 * p], sel) | BIAS2;
+        const h8 bq = __builtin_bit_cast(h8, bv) - (_Float16)1152.0f;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int sp = 0; sp < NSPLIT; ++sp)
-              acc[mt][gq][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][sp], bq, acc[mt][gq][t], 0, 0, 0);
-        }
+          for (int sp = 0; sp < NSPLIT; ++sp)
+            acc[mt][gq][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][sp], bq, acc[mt][gq][t], 0, 0, 0);
       }
     }
   };
 
   if (total > 0) {
-    load_step(0, cA, qA);
-    for (int it = 0; it + 1 < total; ++it) {
-      load_step(it + 1, cN, qN);
+    issue(0, 0);
+    if (total > 1) issue(1, 1);
+    for (int it = 0, st = 0; it < total; ++it) {
+      if (it + 1 < total) wait_vmcnt<PER>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (it + 2 < total) issue(it + 2, st >= 1 ? st - 1 : 2);
       __builtin_amdgcn_sched_barrier(0);
-      compute();
+      compute(st);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) { cA[mt][0] = cN[mt][0]; cA[mt][1] = cN[mt][1]; }
-#pragma unroll
-      for (int gq = 0; gq < 3; ++gq)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qA[gq][i] = qN[gq][i];
+      st = st == 2 ? 0 : st + 1;
     }
-    compute();
   }
 
   // out[k, d] = sum_f c x = (alpha/S) acc + ((beta + 128 alpha)/S) m1,  m1 = sum_f (scaled, rounded) c
@@ -593,6 +657,28 @@ __global__ __launch_bounds__(256) void vlad_max_to_scale_kernel(const float* __r
   }
 }
 
+// cs[b,k] = sum_j cs_part[b,j,k]  (the rows kernel used to do this sum itself: 18 dependent L2 round trips per cluster
+// tile in its epilogue, ~35k cycles per workgroup)
+__global__ __launch_bounds__(256) void vlad_cs_sum_kernel(const float* __restrict__ part, int nblk, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (b, k)
+  if (i >= n) return;
+  const int64_t b = i / NK, k = i - b * NK;
+  float t = 0.f;
+  for (int j = 0; j < nblk; ++j) t += part[(b * nblk + j) * NK + k];
+  out[i] = t;
+}
+
+// n[b,k] = sum over the row ranges of a video of the per-workgroup partial sums (fixed order)
+__global__ __launch_bounds__(256) void vlad_sum_parts_kernel(const float* __restrict__ part, int ranges, int64_t n,
+                                                             float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;         // (b, k)
+  if (i >= n) return;
+  const int64_t b = i / NK, k = i - b * NK;
+  float t = 0.f;
+  for (int r = 0; r < ranges; ++r) t += part[(b * ranges + r) * NK + k];
+  out[i] = t;
+}
+
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // rows per workgroup = 64 nt: the tile count that wastes the fewest padded frames while giving the chip >= 2 workgroups
@@ -614,7 +700,7 @@ struct Layout {
   int64_t nblk, Fp, ranges, groups, vids;
   int nt;
   // byte offsets into the workspace
-  int64_t o_scale, o_maxpart, o_wp, o_cs, o_cT, o_wgmax, o_escale, o_colpart, o_part, o_part2, total;
+  int64_t o_scale, o_maxpart, o_wp, o_cs, o_cssum, o_cT, o_wgmax, o_escale, o_colpart, o_part, o_part2, total;
 };
 
 Layout make_layout(int64_t B, int64_t F, int64_t D) {
@@ -632,6 +718,7 @@ Layout make_layout(int64_t B, int64_t F, int64_t D) {
   L.o_maxpart = o; o += align_up(B * MAXP * 4, 256);
   L.o_wp = o;      o += align_up(B * L.nblk * 4096 * 2 * 2, 256);     // nsplit = 2, per-video weights (backward)
   L.o_cs = o;      o += align_up(B * L.nblk * NK * 4, 256);
+  L.o_cssum = o;   o += align_up(B * NK * 4, 256);
   L.o_cT = o;      o += align_up(B * NK * L.Fp * 4, 256);
   L.o_wgmax = o;   o += align_up(B * L.ranges * 4, 256);
   L.o_escale = o;  o += 256;
@@ -642,16 +729,31 @@ Layout make_layout(int64_t B, int64_t F, int64_t D) {
   return L;
 }
 
+// dynamic LDS above 64 KiB has to be allowed per kernel
+template <typename K, typename A>
+void launch_lds(K kernel, dim3 grid, int lds_bytes, hipStream_t s, const A& args) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, s, args);
+}
+
 template <int NSPLIT, bool BWD>
 void launch_rows(const RowsArgs& a, int nt, int64_t ranges, hipStream_t s) {
-  const dim3 grid((unsigned)ranges, (unsigned)a.B), block(256);
+  const dim3 grid((unsigned)ranges, (unsigned)a.B);
+  const int lds = 2 * 8192 * NSPLIT + 4 * (NK + 1) * (int)sizeof(float);
+  (void)nt;
   switch (nt) {
-    case 1: hipLaunchKernelGGL((vlad_rows_kernel<NSPLIT, BWD, 1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((vlad_rows_kernel<NSPLIT, BWD, 2>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((vlad_rows_kernel<NSPLIT, BWD, 3>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((vlad_rows_kernel<NSPLIT, BWD, 4>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((vlad_rows_kernel<NSPLIT, BWD, 5>), grid, block, 0, s, a); break;
+    case 1: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 1>, grid, lds, s, a); break;
+    case 2: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 2>, grid, lds, s, a); break;
+    case 3: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 3>, grid, lds, s, a); break;
+    case 4: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 4>, grid, lds, s, a); break;
+    default: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 5>, grid, lds, s, a); break;
   }
+}
+
+void launch_cols(const ColsArgs& a, int nsplit, dim3 grid, hipStream_t s) {
+  const int lds = 3 * (32 * 384 + NK * 128);
+  if (nsplit == 2) launch_lds(vlad_cols_kernel<2>, grid, lds, s, a);
+  else launch_lds(vlad_cols_kernel<1>, grid, lds, s, a);
 }
 
 }  // namespace
@@ -668,12 +770,13 @@ extern "C" int64_t yt8m_netvlad_workspace_bytes(int64_t B, int64_t F, int64_t D,
 }
 
 extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, const float* Wc, const float* bc, int64_t B,
-                                   int64_t F, int64_t D, int64_t K, int nsplit, float eps, float* a_out, float* agg_out,
-                                   void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+                                   int64_t F, int64_t D, int64_t K, int nsplit, float eps, float* cT_out, float* n_out,
+                                   float* agg_out, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(yt8m_netvlad_supported(B, F, D, K), YT8M_E_SHAPE, "fused NetVLAD needs K == 64, D % 64 == 0");
   YT8M_REQUIRE(nsplit == 1 || nsplit == 2, YT8M_E_BADARG, "nsplit must be 1 or 2");
-  YT8M_REQUIRE(q && Wc && bc && a_out && agg_out && workspace, YT8M_E_BADARG, "null operand");
-  YT8M_REQUIRE((((uintptr_t)q | (uintptr_t)agg_out | (uintptr_t)workspace) & 15) == 0, YT8M_E_BADARG, "operands must be 16-byte aligned");
+  YT8M_REQUIRE(q && Wc && bc && cT_out && n_out && agg_out && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE((((uintptr_t)q | (uintptr_t)agg_out | (uintptr_t)cT_out | (uintptr_t)workspace) & 15) == 0, YT8M_E_BADARG,
+               "operands must be 16-byte aligned");
   const Layout L = make_layout(B, F, D);
   YT8M_REQUIRE(workspace_bytes >= L.total, YT8M_E_BADARG, "workspace too small");
   hipStream_t s = as_stream(stream);
@@ -682,38 +785,43 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   float* scale = reinterpret_cast<float*>(ws + L.o_scale);
   _Float16* Wp = reinterpret_cast<_Float16*>(ws + L.o_wp);
   float* cs = reinterpret_cast<float*>(ws + L.o_cs);
-  float* cT = reinterpret_cast<float*>(ws + L.o_cT);
+  float* cT = cT_out;
   float* escale = reinterpret_cast<float*>(ws + L.o_escale);
   float* maxpart = reinterpret_cast<float*>(ws + L.o_maxpart);
+  float* colpart = reinterpret_cast<float*>(ws + L.o_colpart);
   hipLaunchKernelGGL(vlad_absmax_part_kernel, dim3(MAXP, 1), dim3(256), 0, s, Wc, D * NK, (int64_t)0, maxpart);
   hipLaunchKernelGGL(vlad_pack_kernel<false>, dim3((unsigned)L.nblk, 1), dim3(256), 0, s, Wc, (int64_t)0, (int)D, maxpart, scale,
                      nsplit, Wp, cs);
   float* wgmax = reinterpret_cast<float*>(ws + L.o_wgmax);
+  float* cssum = reinterpret_cast<float*>(ws + L.o_cssum);
+  hipLaunchKernelGGL(vlad_cs_sum_kernel, dim3(1), dim3(256), 0, s, cs, (int)L.nblk, (int64_t)NK, cssum);
   RowsArgs ra;
-  ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = 0; ra.cs_part = cs; ra.cs_bstride = 0; ra.wscale = scale;
-  ra.wscale_bstride = 0; ra.bias = bc; ra.bias_bstride = 0; ra.a = a_out; ra.outT = cT; ra.wgmax = wgmax; ra.colpart = nullptr;
+  ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = 0; ra.cs = cssum; ra.cs_bstride = 0; ra.wscale = scale;
+  ra.wscale_bstride = 0; ra.bias = bc; ra.bias_bstride = 0; ra.cfw = nullptr; ra.outT = cT; ra.wgmax = wgmax; ra.colpart = colpart;
   ra.B = (int)B; ra.F = (int)F; ra.D = (int)D; ra.Fp = (int)L.Fp; ra.eps = eps;
   if (nsplit == 2) launch_rows<2, false>(ra, L.nt, L.ranges, s);
   else launch_rows<1, false>(ra, L.nt, L.ranges, s);
   hipLaunchKernelGGL(vlad_max_to_scale_kernel, dim3(1), dim3(256), 0, s, wgmax, B * L.ranges, escale);
+  hipLaunchKernelGGL(vlad_sum_parts_kernel, dim3((unsigned)((B * NK + 255) / 256)), dim3(256), 0, s, colpart, (int)L.ranges, B * NK,
+                     n_out);
   ColsArgs ca;
   ca.q = q; ca.cT = cT; ca.scale = escale; ca.out = agg_out; ca.B = (int)B; ca.F = (int)F; ca.D = (int)D; ca.Fp = (int)L.Fp;
   ca.vids = 1;
   const dim3 cgrid((unsigned)((D + 383) / 384), (unsigned)B);
-  if (nsplit == 2) hipLaunchKernelGGL(vlad_cols_kernel<2>, cgrid, dim3(256), 0, s, ca);
-  else hipLaunchKernelGGL(vlad_cols_kernel<1>, cgrid, dim3(256), 0, s, ca);
+  launch_cols(ca, nsplit, cgrid, s);
   return launch_status("yt8m_netvlad_fwd_u8");
 }
 
-extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float* a, const float* dagg,
+extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float* cT, const float* dagg,
                                    const float* dn, int64_t B, int64_t F, int64_t D, int64_t K, int nsplit, float eps,
                                    float* dWc, float dWc_beta, float* dbc, float dbc_beta, void* workspace,
                                    int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(yt8m_netvlad_supported(B, F, D, K), YT8M_E_SHAPE, "fused NetVLAD needs K == 64, D % 64 == 0");
   YT8M_REQUIRE(nsplit == 1 || nsplit == 2, YT8M_E_BADARG, "nsplit must be 1 or 2");
-  YT8M_REQUIRE(q && a && dagg && dn && dWc && dbc && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(q && cT && dagg && dn && dWc && dbc && workspace, YT8M_E_BADARG, "null operand");
   YT8M_REQUIRE((dWc_beta == 0.f || dWc_beta == 1.f) && (dbc_beta == 0.f || dbc_beta == 1.f), YT8M_E_BADARG, "beta must be 0 or 1");
-  YT8M_REQUIRE((((uintptr_t)q | (uintptr_t)workspace) & 15) == 0, YT8M_E_BADARG, "operands must be 16-byte aligned");
+  YT8M_REQUIRE((((uintptr_t)q | (uintptr_t)cT | (uintptr_t)workspace) & 15) == 0, YT8M_E_BADARG,
+               "operands must be 16-byte aligned");
   const Layout L = make_layout(B, F, D);
   YT8M_REQUIRE(workspace_bytes >= L.total, YT8M_E_BADARG, "workspace too small");
   hipStream_t s = as_stream(stream);
@@ -733,9 +841,11 @@ extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, 
   hipLaunchKernelGGL(vlad_absmax_part_kernel, dim3(MAXP, (unsigned)B), dim3(256), 0, s, dagg, NK * D, NK * D, maxpart);
   hipLaunchKernelGGL(vlad_pack_kernel<true>, dim3((unsigned)L.nblk, (unsigned)B), dim3(256), 0, s, dagg, NK * D, (int)D, maxpart,
                      scale, nsplit, Wp, cs);
+  float* cssum = reinterpret_cast<float*>(ws + L.o_cssum);
+  hipLaunchKernelGGL(vlad_cs_sum_kernel, dim3((unsigned)((B * NK + 255) / 256)), dim3(256), 0, s, cs, (int)L.nblk, B * NK, cssum);
   RowsArgs ra;
-  ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = L.nblk * 4096 * nsplit; ra.cs_part = cs; ra.cs_bstride = L.nblk * NK;
-  ra.wscale = scale; ra.wscale_bstride = 1; ra.bias = dn; ra.bias_bstride = NK; ra.a = const_cast<float*>(a); ra.outT = eT;
+  ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = L.nblk * 4096 * nsplit; ra.cs = cssum; ra.cs_bstride = NK;
+  ra.wscale = scale; ra.wscale_bstride = 1; ra.bias = dn; ra.bias_bstride = NK; ra.cfw = cT; ra.outT = eT;
   ra.wgmax = wgmax; ra.colpart = colpart;
   ra.B = (int)B; ra.F = (int)F; ra.D = (int)D; ra.Fp = (int)L.Fp; ra.eps = eps;
   if (nsplit == 2) launch_rows<2, true>(ra, L.nt, L.ranges, s);
@@ -745,8 +855,7 @@ extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, 
   ca.q = q; ca.cT = eT; ca.scale = escale; ca.out = part; ca.B = (int)B; ca.F = (int)F; ca.D = (int)D; ca.Fp = (int)L.Fp;
   ca.vids = (int)L.vids;
   const dim3 cgrid((unsigned)((D + 383) / 384), (unsigned)L.groups);
-  if (nsplit == 2) hipLaunchKernelGGL(vlad_cols_kernel<2>, cgrid, dim3(256), 0, s, ca);
-  else hipLaunchKernelGGL(vlad_cols_kernel<1>, cgrid, dim3(256), 0, s, ca);
+  launch_cols(ca, nsplit, cgrid, s);
   if (L.groups > RED2) {
     const int64_t n = NK * D;
     hipLaunchKernelGGL(vlad_part_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256), RED2), dim3(256), 0, s, part, (int)L.groups, n,

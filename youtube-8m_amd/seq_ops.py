@@ -216,27 +216,30 @@ def netvlad_fused_supported(q, K):
 
 
 def netvlad_fwd_u8(q, num_frames, Wc, bc, nsplit=2, eps=1e-12):
-    """(a [B,F,K], agg [B,K,D]) from raw uint8 frames (yt8m_netvlad_fwd_u8)."""
+    """(cT [B,K,Fp], n [B,K], agg [B,K,D]) from raw uint8 frames (yt8m_netvlad_fwd_u8).  cT[b,k,f] = a[b,f,k] / ||deq(q[b,f])||
+    with the frames contiguous and zero padded to Fp = 32*ceil(F/32): what the aggregation and the backward consume."""
     _dev(q, Wc, bc)
     q = q.contiguous()
     B, F, D = q.shape
     K = Wc.shape[1]
     nf = _nf(num_frames)
-    a = torch.empty((B, F, K), dtype=torch.float32, device=q.device)
+    Fp = (F + 31) // 32 * 32
+    cT = torch.empty((B, K, Fp), dtype=torch.float32, device=q.device)
+    n = torch.empty((B, K), dtype=torch.float32, device=q.device)
     agg = torch.empty((B, K, D), dtype=torch.float32, device=q.device)
     ws = _netvlad_workspace(B, F, D, K, q.device)
-    _lib.check(_lib.lib().yt8m_netvlad_fwd_u8(_p(q), _p(nf), _p(_f32c(Wc)), _p(_f32c(bc)), B, F, D, K, int(nsplit), eps, _p(a),
-                                              _p(agg), _p(ws), ws.numel(), _stream()))
-    return a, agg
+    _lib.check(_lib.lib().yt8m_netvlad_fwd_u8(_p(q), _p(nf), _p(_f32c(Wc)), _p(_f32c(bc)), B, F, D, K, int(nsplit), eps, _p(cT),
+                                              _p(n), _p(agg), _p(ws), ws.numel(), _stream()))
+    return cT, n, agg
 
 
-def netvlad_bwd_u8(q, num_frames, a, dagg, dn, dWc, dWc_beta, dbc, dbc_beta, nsplit=2, eps=1e-12):
-    _dev(q, a, dagg, dn, dWc, dbc)
+def netvlad_bwd_u8(q, num_frames, cT, dagg, dn, dWc, dWc_beta, dbc, dbc_beta, nsplit=2, eps=1e-12):
+    _dev(q, cT, dagg, dn, dWc, dbc)
     B, F, D = q.shape
-    K = a.shape[2]
+    K = cT.shape[1]
     nf = _nf(num_frames)
     ws = _netvlad_workspace(B, F, D, K, q.device)
-    _lib.check(_lib.lib().yt8m_netvlad_bwd_u8(_p(q), _p(nf), _p(a), _p(_f32c(dagg)), _p(_f32c(dn)), B, F, D, K, int(nsplit), eps,
+    _lib.check(_lib.lib().yt8m_netvlad_bwd_u8(_p(q), _p(nf), _p(cT), _p(_f32c(dagg)), _p(_f32c(dn)), B, F, D, K, int(nsplit), eps,
                                               _p(dWc), float(dWc_beta), _p(dbc), float(dbc_beta), _p(ws), ws.numel(), _stream()))
 
 
@@ -247,20 +250,19 @@ class _NetVladPoolU8(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, num_frames, token, Wc, bc, centres, nsplit, eps):
         q = q.contiguous()
-        a, agg = netvlad_fwd_u8(q, num_frames, Wc.data, bc.data, nsplit)
+        cT, n, agg = netvlad_fwd_u8(q, num_frames, Wc.data, bc.data, nsplit)
         B, K, D = agg.shape
         vlad = torch.empty_like(agg)
-        n = torch.empty((B, K), dtype=torch.float32, device=q.device)
-        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), _p(a), _p(centres.data), _p(vlad), _p(n), B, q.shape[1], K, D, eps,
+        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), None, _p(centres.data), _p(vlad), _p(n), B, q.shape[1], K, D, eps,
                                                    _stream()))
-        ctx.saved = (q, num_frames, a, agg, n)
+        ctx.saved = (q, num_frames, cT, agg, n)
         ctx.vars = (Wc, bc, centres)
         ctx.cfg = (nsplit, eps)
         return vlad
 
     @staticmethod
     def backward(ctx, dvlad):
-        q, num_frames, a, agg, n = ctx.saved
+        q, num_frames, cT, agg, n = ctx.saved
         Wc, bc, c = ctx.vars
         nsplit, eps = ctx.cfg
         ctx.saved = None
@@ -275,7 +277,7 @@ class _NetVladPoolU8(torch.autograd.Function):
         if dc is not None:
             c.grad_done()
         if Wc.grad is not None and bc.grad is not None:
-            netvlad_bwd_u8(q, num_frames, a, dagg, dn, Wc.grad, Wc.grad_beta(), bc.grad.view(-1), bc.grad_beta(), nsplit)
+            netvlad_bwd_u8(q, num_frames, cT, dagg, dn, Wc.grad, Wc.grad_beta(), bc.grad.view(-1), bc.grad_beta(), nsplit)
             Wc.grad_done()
             bc.grad_done()
         return (None,) * 8
