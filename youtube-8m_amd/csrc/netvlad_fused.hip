@@ -210,7 +210,7 @@ __device__ __forceinline__ float grp16_sum(float v) {
 // during the block's MFMAs.  (Loads through inline asm with counted waits were tried: the register allocator is free to
 // copy a not-yet-landed destination register, which it does.)
 template <int NSPLIT, bool BWD, int NT>
-__global__ __launch_bounds__(256) void vlad_rows_kernel(RowsArgs g) {
+__global__ __launch_bounds__(256, 2) void vlad_rows_kernel(RowsArgs g) {
   constexpr int WB = 8192 * NSPLIT;
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][WB] + reduction scratch
   float (*red)[NK + 1] = reinterpret_cast<float (*)[NK + 1]>(smem + 2 * WB);
