@@ -198,6 +198,22 @@ int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const 
                         const int32_t* num_frames, int64_t F, int64_t B, int64_t H,
                         void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream);
 
+/* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the
+ * re-packed recurrent weights owned by the caller (yt8m_lstm_pack; yt8m_lstm_packed_floats() floats each for the forward
+ * image Wp and the backward image Wq; 0 = shape not covered, pass NULL and the generic per-step GEMM path runs).
+ * z / cs / hs / out / gates / dz / dout are the WHOLE-layer base pointers.  They let a multi-layer stack (MultiRNNCell,
+ * lstm_model.py:34-40) be pipelined over time chunks on separate streams.  bwd: work [4,B,H] holds the running (dh, dc)
+ * in work[0..1] (phase 0) or work[2..3] (phase 1); each step flips the phase, the caller carries (phase + T) % 2. */
+int64_t yt8m_lstm_packed_floats(int64_t B, int64_t H);
+int yt8m_lstm_pack(const float* Wh, int64_t ldw, int64_t H, float* Wp, float* Wq, yt8m_stream_t stream);
+int yt8m_lstm_steps_fwd(float* z, const float* Wh, int64_t ldw, const float* Wp, float* cs, float* hs, float* out,
+                        const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                        void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream);
+int yt8m_lstm_steps_bwd(const float* gates, const float* Wh, int64_t ldw, const float* Wq, const float* cs,
+                        const float* dout, float* dz, float* work, int phase, const int32_t* num_frames, int64_t t0,
+                        int64_t T, int64_t B, int64_t H, void* gemm_workspace, int64_t gemm_workspace_bytes,
+                        yt8m_stream_t stream);
+
 /* ---- masked softmax over frames + renormalise (lstm_attention_max_pooling_model.py:59-60) -------
  * act [B,F,A] -> w [B,F,A]: w = mask * softmax_F(act) / sum_F(mask * softmax_F(act)).  bwd: dact from dw. */
 int yt8m_attn_softmax_fwd(const float* act, const int32_t* num_frames, float* w, int64_t B, int64_t F,

@@ -135,11 +135,13 @@ def _lstm_ref_layers(tp, L):
             for l in range(L)]
 
 
+@pytest.mark.parametrize("chunks", [1, 4, 10])
 @pytest.mark.parametrize("cls", ["LstmModel", "LstmMemoryModel"])
-def test_lstm_models(dev, flags, cls):
+def test_lstm_models(dev, flags, cls, chunks):
     rs = np.random.RandomState(2)
     B, F, Dm, Hh, V = 6, 10, 12, 8, 17
     flags.lstm_cells, flags.lstm_layers = str(Hh), 2
+    flags.lstm_pipeline_chunks = chunks                               # layer pipeline over time chunks (1 = sequential)
     x = rs.randn(B, F, Dm).astype(np.float32)
     nf = np.array([10, 1, 5, 10, 3, 7], dtype=np.int32)
     x *= (np.arange(F)[None, :, None] < nf[:, None, None])
@@ -158,6 +160,44 @@ def test_lstm_models(dev, flags, cls):
     lr.backward()
     assert np.abs(H(res["predictions"]) - pr.detach().numpy()).max() < 1e-4
     check_grads(g, tp, tol=5e-4)
+
+
+def test_lstm_stack_pipelined_equals_sequential(dev, flags):
+    """The layer-pipelined stack (time chunks on separate streams, fused step kernels: H % 128 == 0) against the same op
+    with one chunk: forward results are bit-identical (same kernels, same per-step arithmetic); weight gradients differ only
+    by the chunk-wise accumulation order of the hoisted dW GEMMs.  Repeated to catch stream races."""
+    import yt8m_amd.seq_ops as seq_ops
+    from yt8m_amd.variables import xavier_uniform, zeros
+    rs = np.random.RandomState(23)
+    F, B, Dm, Hh = 37, 48, 64, 128
+    x = torch.from_numpy(rs.randn(F, B, Dm).astype(np.float32)).to(dev)
+    nf = torch.from_numpy(rs.randint(1, F + 1, size=B).astype(np.int32)).to(dev)
+    dout = torch.from_numpy(rs.randn(F, B, Hh).astype(np.float32)).to(dev)
+    res = {}
+    for chunks in (1, 5, 5, 3):
+        g = reset_default_graph(device=dev, seed=4)
+        g.begin_step()
+        wb = []
+        for l, din in enumerate((Dm, Hh, Hh)):
+            wb.append((g.get_variable("l%d/weights" % l, (din + Hh, 4 * Hh), xavier_uniform),
+                       g.get_variable("l%d/biases" % l, (4 * Hh,), zeros)))
+        g.finalize()
+        xin = x.clone().requires_grad_(True)
+        out, fin = seq_ops.lstm_stack(xin, nf, wb, chunks=chunks)
+        loss = (out * dout).sum() + sum((c * 0.3).sum() + (h * 0.7).sum() for c, h in fin)
+        loss.backward()
+        torch.cuda.synchronize()
+        cur = (out.detach().clone(), [t.detach().clone() for ch in fin for t in ch], xin.grad.clone(),
+               {k: v.grad.clone() for k, v in g.vars.items()})
+        if chunks == 1:
+            res = cur
+            continue
+        assert torch.equal(cur[0], res[0])
+        for a, b in zip(cur[1], res[1]):
+            assert torch.equal(a, b)
+        assert float((cur[2] - res[2]).abs().max()) <= 1e-6 * float(res[2].abs().max())
+        for k in res[3]:
+            assert float((cur[3][k] - res[3][k]).abs().max()) <= 2e-6 * max(float(res[3][k].abs().max()), 1e-6), k
 
 
 def test_lstm_attention_max_pooling_model(dev, flags):

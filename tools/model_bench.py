@@ -45,6 +45,10 @@ def run(name, steps=5):
     FLAGS.reset()
     for k, v in cfg.get("flags", {}).items():
         setattr(FLAGS, k, v)
+    for kv in os.environ.get("YT8M_SET", "").split(","):           # e.g. YT8M_SET=lstm_pipeline_chunks=8
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            setattr(FLAGS, k, type(getattr(FLAGS, k))(v) if not isinstance(getattr(FLAGS, k), bool) else v == "1")
     B = cfg["B"]
     g = reset_default_graph(device=dev, seed=0)
     mt = cfg.get("multitask", False)

@@ -53,6 +53,10 @@ SIGNATURES = {
     "yt8m_lstm_gates_fwd": (c_int, [P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, c_float, P]),
     "yt8m_lstm_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, P]),
     "yt8m_lstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_lstm_packed_floats": (c_int64, [c_int64, c_int64]),
+    "yt8m_lstm_pack": (c_int, [P, c_int64, c_int64, P, P, P]),
+    "yt8m_lstm_steps_fwd": (c_int, [P, P, c_int64, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_lstm_steps_bwd": (c_int, [P, P, c_int64, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lstm_layer_bwd": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_attn_softmax_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_attn_softmax_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),

@@ -296,6 +296,85 @@ extern "C" int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t 
   return YT8M_OK;
 }
 
+// ---- time-range forms: the same step kernels over steps [t0, t0 + T) of a layer, with the packed recurrent weights owned
+// by the caller.  They let the host pipeline the layers of a stack over time chunks on separate streams (layer l+1's
+// input projection and recurrence for chunk c run while layer l is in chunk c+1), seq_ops._LstmStack.
+extern "C" int64_t yt8m_lstm_packed_floats(int64_t B, int64_t H) {
+  return lstm_fused_supported(B, H, (int64_t)sizeof(float) * H * 4 * H) ? H * 4 * H : 0;
+}
+
+extern "C" int yt8m_lstm_pack(const float* Wh, int64_t ldw, int64_t H, float* Wp, float* Wq, yt8m_stream_t stream) {
+  YT8M_REQUIRE(Wh && H > 0 && ldw >= 4 * H && (Wp || Wq), YT8M_E_BADARG, "bad operand");
+  YT8M_REQUIRE(lstm_fused_supported(1, H, (int64_t)sizeof(float) * H * 4 * H), YT8M_E_SHAPE, "H must be a multiple of 128");
+  ProfScope prof(F_LSTM, as_stream(stream));
+  return lstm_pack(Wh, ldw, Wp, Wq, H, as_stream(stream));
+}
+
+extern "C" int yt8m_lstm_steps_fwd(float* z, const float* Wh, int64_t ldw, const float* Wp, float* cs, float* hs, float* out,
+                                   const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                                   void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (T * B * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(z && Wh && cs && hs, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldw >= 4 * H, YT8M_E_SHAPE, "ldw < 4H");
+  const int64_t BH = B * H;
+  if (Wp) {
+    YT8M_REQUIRE(lstm_fused_supported(B, H, (int64_t)sizeof(float) * H * 4 * H), YT8M_E_SHAPE, "packed path needs H % 128 == 0");
+    ProfScope prof(F_LSTM, as_stream(stream));
+    int rc = YT8M_OK;
+    for (int64_t t = t0; t < t0 + T && rc == YT8M_OK; ++t)
+      rc = lstm_step_fwd(z + t * B * 4 * H, Wp, cs + t * BH, hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH,
+                         out ? out + t * BH : nullptr, num_frames, (int)t, B, H, forget_bias, as_stream(stream));
+    return rc;
+  }
+  for (int64_t t = t0; t < t0 + T; ++t) {
+    float* zt = z + t * B * 4 * H;
+    yt8m_gemm_problem pr = {B, 4 * H, H, hs + t * BH, H, Wh, ldw, zt, 4 * H, nullptr, 1.0f};
+    int rc = yt8m_gemm_f32_grouped(0, 0, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
+    if (rc != YT8M_OK) return rc;
+    rc = yt8m_lstm_gates_fwd(zt, cs + t * BH, hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH,
+                             out ? out + t * BH : nullptr, num_frames, (int32_t)t, B, H, forget_bias, stream);
+    if (rc != YT8M_OK) return rc;
+  }
+  return YT8M_OK;
+}
+
+// steps t0 + T - 1 down to t0.  work [4,B,H]: the running (dh, dc) live in work[0], work[1] when `phase` is 0 and in
+// work[2], work[3] when it is 1; every step flips it -- the caller carries phase' = (phase + T) % 2 to the next chunk.
+extern "C" int yt8m_lstm_steps_bwd(const float* gates, const float* Wh, int64_t ldw, const float* Wq, const float* cs,
+                                   const float* dout, float* dz, float* work, int phase, const int32_t* num_frames, int64_t t0,
+                                   int64_t T, int64_t B, int64_t H, void* gemm_workspace, int64_t gemm_workspace_bytes,
+                                   yt8m_stream_t stream) {
+  YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
+  if (T * B * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(gates && Wh && cs && dz && work, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldw >= 4 * H, YT8M_E_SHAPE, "ldw < 4H");
+  if (Wq) YT8M_REQUIRE(lstm_fused_supported(B, H, (int64_t)sizeof(float) * H * 4 * H), YT8M_E_SHAPE, "packed path needs H % 128 == 0");
+  hipStream_t s = as_stream(stream);
+  const int64_t BH = B * H;
+  float* dh_cur = work + (phase ? 2 : 0) * BH;
+  float* dc_cur = dh_cur + BH;
+  float* dh_prev = work + (phase ? 0 : 2) * BH;
+  float* dc_prev = dh_prev + BH;
+  for (int64_t t = t0 + T - 1; t >= t0; --t) {
+    float* dzt = dz + t * B * 4 * H;
+    int rc = yt8m_lstm_gates_bwd(gates + t * B * 4 * H, cs + t * BH, cs + (t + 1) * BH, dh_cur, dc_cur,
+                                 dout ? dout + t * BH : nullptr, dzt, dc_prev, dh_prev, num_frames, (int32_t)t, B, H, stream);
+    if (rc != YT8M_OK) return rc;
+    if (Wq) {
+      rc = lstm_step_bwd(dzt, Wq, dh_prev, B, H, s);
+    } else {
+      yt8m_gemm_problem pr = {B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f};
+      rc = yt8m_gemm_f32_grouped(0, 1, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
+    }
+    if (rc != YT8M_OK) return rc;
+    float* tmp = dh_cur; dh_cur = dh_prev; dh_prev = tmp;
+    tmp = dc_cur; dc_cur = dc_prev; dc_prev = tmp;
+  }
+  return YT8M_OK;
+}
+
 extern "C" int yt8m_attn_softmax_fwd(const float* act, const int32_t* num_frames, float* w, int64_t B, int64_t F,
                                      int64_t A, yt8m_stream_t stream) {
   YT8M_REQUIRE(B >= 0 && F >= 0 && A >= 0, YT8M_E_SHAPE, "negative dimension");

@@ -23,6 +23,8 @@ DEFINE_string("video_level_classifier_model", "MoeModel", "Some Frame-Level mode
 DEFINE_bool("rnn_swap_memory", False, "If true, swap_memory = True.  (No numerical effect; ignored: 288 GB HBM.)")
 DEFINE_string("lstm_cells", "1024", "Number of LSTM cells.")
 DEFINE_integer("lstm_layers", 2, "Number of LSTM layers.")
+# new: time chunks of the layer-pipelined LSTM stack (1 = one layer after the other)
+DEFINE_integer("lstm_pipeline_chunks", 4, "Time chunks over which the layers of the LSTM stack are pipelined on separate streams.")
 DEFINE_integer("lstm_attentions", 8, "Attention size in lstm_attention_max_pooling_model.")
 DEFINE_bool("is_training", False, "used in batch normalization.")
 # new (Appendix B)
@@ -43,17 +45,17 @@ def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers):
     and the per-layer final (c, h)."""
     g = get_default_graph()
     x_tm = model_input.transpose(0, 1).contiguous()          # [F,B,D]   (layout glue)
-    finals = []
-    inp = x_tm
+    wb = []
+    d_in = x_tm.shape[2]
     with g.variable_scope("RNN"):
         for l in range(number_of_layers):
-            d_in = inp.shape[2]
             scope = "multi_rnn_cell/cell_%d/basic_lstm_cell" % l
             W = g.get_variable(scope + "/weights", (d_in + lstm_size, 4 * lstm_size), xavier_uniform)
             b = g.get_variable(scope + "/biases", (4 * lstm_size,), zeros)
-            inp, c, h = seq_ops.lstm_layer(inp, W, b, num_frames, forget_bias=1.0)
-            finals.append((c, h))
-    return inp, finals
+            wb.append((W, b))
+            d_in = lstm_size
+    # all layers in one op: layer l+1 works on time chunk c while layer l is already in chunk c+1 (seq_ops._LstmStack)
+    return seq_ops.lstm_stack(x_tm, num_frames, wb, forget_bias=1.0, chunks=FLAGS.lstm_pipeline_chunks)
 
 
 class FrameLevelLogisticModel(models.BaseModel):

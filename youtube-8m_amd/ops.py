@@ -66,11 +66,13 @@ _WS = {}
 
 
 def _workspace(device):
-    """Split-K workspace of the persistent GEMM (one per device; ~48 MiB of the 288 GB)."""
-    ws = _WS.get(device)
+    """Split-K workspace of the persistent GEMM: one per (device, stream) -- ~48 MiB each of the 288 GB -- so that GEMMs
+    running concurrently on different streams (the pipelined LSTM stack) never share scratch."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(_lib.lib().yt8m_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 

@@ -77,6 +77,209 @@ def lstm_layer(x_tm, W, b, num_frames, forget_bias=1.0):
     return _LstmLayer.apply(x_tm, _token(W._graph), W, b, num_frames, forget_bias)
 
 
+# ---- MultiRNNCell stack, pipelined over time chunks ----------------------------------------------------------------
+_SIDE = {}
+
+
+def _side_streams(device, L):
+    """Per device: one stream per layer (its projection / dx GEMMs and its recurrence run in order on it) and one for the
+    weight-gradient GEMMs.  Measured on the 2-layer BASELINE configs[3] stack (B = 128): a separate GEMM stream per layer is
+    no better (51.7 vs 49.0 ms/step) and HIGH-priority recurrence streams are far worse (96 ms: the priority queues throttle
+    the step kernels), so neither is used."""
+    pool = _SIDE.setdefault(device, dict(r=[], w=None))
+    while len(pool["r"]) < L:
+        pool["r"].append(torch.cuda.Stream(device=device))
+    if pool["w"] is None:
+        pool["w"] = torch.cuda.Stream(device=device)
+    return pool["r"][:L], pool["r"][:L], pool["w"]
+
+
+def _chunks(F, n):
+    n = max(1, min(int(n), F))
+    step = (F + n - 1) // n
+    return [(t0, min(step, F - t0)) for t0 in range(0, F, step)]
+
+
+class _LstmStack(torch.autograd.Function):
+    """MultiRNNCell([BasicLSTMCell] * L) under tf.nn.dynamic_rnn (W/all_frame_models/lstm_model.py:34-47), time-major, as ONE
+    op so that the layers can be pipelined: the sequence is cut into time chunks; layer l's hoisted input projection of
+    chunk c (a GEMM stream) starts as soon as layer l-1 has finished the recurrence of chunk c, and its own recurrence of
+    chunk c (a high-priority stream per layer) follows -- while layer l-1 is already in chunk c+1.  The MFMA-bound GEMMs then
+    overlap the latency-bound recurrence steps.  Backward runs the same wavefront in reverse time order (top layer first;
+    the dx GEMM of a chunk releases the layer below) and every weight-gradient GEMM goes to a further stream, accumulating
+    chunk by chunk.  Same kernels and the same per-step arithmetic as the unpipelined op; chunks = 1 is the sequential form.
+
+    apply(x_tm [F,B,D], token, num_frames, forget_bias, chunks, W_0, b_0, ..., W_{L-1}, b_{L-1})
+      -> (out_top [F,B,H], c_0, h_0, ..., c_{L-1}, h_{L-1})"""
+
+    @staticmethod
+    def forward(ctx, x_tm, token, num_frames, forget_bias, chunks, *wb):
+        x_tm = _f32c(x_tm)
+        _dev(x_tm)
+        L = len(wb) // 2
+        Ws, bs = wb[0::2], wb[1::2]
+        F, B, _ = x_tm.shape
+        dev = x_tm.device
+        lib = _lib.lib()
+        nf = _nf(num_frames)
+        main = torch.cuda.current_stream(dev)
+        rs, gs, _ = _side_streams(dev, L)
+        parts = _chunks(F, chunks)
+        layers, inp = [], x_tm
+        for l in range(L):                                          # every buffer comes from the main stream's pool
+            Din = inp.shape[2]
+            H = Ws[l].data.shape[1] // 4
+            assert Ws[l].data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
+            st = dict(x=inp, Din=Din, H=H, W=Ws[l], b=bs[l],
+                      z=torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev),
+                      cs=torch.empty((F + 1, B, H), dtype=torch.float32, device=dev),
+                      hs=torch.empty((F + 1, B, H), dtype=torch.float32, device=dev),
+                      out=torch.empty((F, B, H), dtype=torch.float32, device=dev))
+            npk = lib.yt8m_lstm_packed_floats(B, H)
+            st["Wp"] = torch.empty(npk, dtype=torch.float32, device=dev) if npk else None
+            layers.append(st)
+            inp = st["out"]
+        start = torch.cuda.Event()
+        start.record(main)
+        for l, st in enumerate(layers):
+            gs[l].wait_event(start)
+            with torch.cuda.stream(rs[l]):
+                rs[l].wait_event(start)
+                st["cs"][0].zero_()
+                st["hs"][0].zero_()
+                if st["Wp"] is not None:
+                    _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
+        r_done = [[torch.cuda.Event() for _ in parts] for _ in range(L)]
+        for c, (t0, T) in enumerate(parts):
+            for l, st in enumerate(layers):
+                Din, H = st["Din"], st["H"]
+                with torch.cuda.stream(gs[l]):                      # hoisted input projection of the chunk
+                    if l > 0:
+                        gs[l].wait_event(r_done[l - 1][c])
+                    ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
+                             bias=st["b"].data)
+                    g_ev = torch.cuda.Event()
+                    g_ev.record(gs[l])
+                with torch.cuda.stream(rs[l]):                      # recurrence steps of the chunk
+                    rs[l].wait_event(g_ev)
+                    ws = ops._workspace(dev)
+                    _lib.check(lib.yt8m_lstm_steps_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["Wp"]), _p(st["cs"]),
+                                                       _p(st["hs"]), _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias),
+                                                       _p(ws), ws.numel() * 4, _stream()))
+                    r_done[l][c].record(rs[l])
+        for l in range(L):
+            main.wait_event(r_done[l][-1])
+        ctx.layers, ctx.nf, ctx.parts = layers, nf, parts
+        ctx.set_materialize_grads(False)
+        outs = [layers[-1]["out"]]
+        for st in layers:
+            outs += [st["cs"][F], st["hs"][F]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dout_top, *dfinal):
+        layers, nf, parts = ctx.layers, ctx.nf, ctx.parts
+        ctx.layers = None
+        L = len(layers)
+        F, B, _ = layers[0]["x"].shape
+        dev = layers[0]["x"].device
+        lib = _lib.lib()
+        main = torch.cuda.current_stream(dev)
+        rs, gs, sw = _side_streams(dev, L)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(layers[0]["x"]) if need_dx else None
+        for l, st in enumerate(layers):                            # buffers come from the main stream's pool
+            H = st["H"]
+            st["dz"] = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
+            st["work"] = torch.empty((4, B, H), dtype=torch.float32, device=dev)
+            st["dout"] = (None if dout_top is None else _f32c(dout_top)) if l == L - 1 else \
+                torch.empty((F, B, H), dtype=torch.float32, device=dev)
+            npk = lib.yt8m_lstm_packed_floats(B, H)
+            st["Wq"] = torch.empty(npk, dtype=torch.float32, device=dev) if npk else None
+        start = torch.cuda.Event()
+        start.record(main)
+        sw.wait_event(start)
+        for l, st in enumerate(layers):
+            H = st["H"]
+            gs[l].wait_event(start)
+            with torch.cuda.stream(rs[l]):
+                rs[l].wait_event(start)
+                dc, dh = dfinal[2 * l], dfinal[2 * l + 1]
+                if dh is None:
+                    st["work"][0].zero_()
+                else:
+                    st["work"][0].copy_(dh)
+                if dc is None:
+                    st["work"][1].zero_()
+                else:
+                    st["work"][1].copy_(dc)
+                st["phase"] = 0
+                if st["Wq"] is not None:
+                    _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * H, H, None, _p(st["Wq"]), _stream()))
+        wbeta = {}
+        last = []
+        for c in range(len(parts) - 1, -1, -1):
+            t0, T = parts[c]
+            dx_ev = None                                            # dx GEMM of the layer above for this chunk
+            for l in range(L - 1, -1, -1):
+                st = layers[l]
+                Din, H, W, b = st["Din"], st["H"], st["W"], st["b"]
+                dzc = st["dz"][t0:t0 + T].view(T * B, 4 * H)
+                with torch.cuda.stream(rs[l]):
+                    if dx_ev is not None:
+                        rs[l].wait_event(dx_ev)
+                    ws = ops._workspace(dev)
+                    _lib.check(lib.yt8m_lstm_steps_bwd(_p(st["z"]), _p(W.data[Din:]), 4 * H, _p(st["Wq"]), _p(st["cs"]), _p(st["dout"]),
+                                                       _p(st["dz"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H, _p(ws),
+                                                       ws.numel() * 4, _stream()))
+                    st["phase"] = (st["phase"] + T) % 2
+                    rb = torch.cuda.Event()
+                    rb.record(rs[l])
+                dx_ev = None
+                if l > 0 or need_dx:
+                    with torch.cuda.stream(gs[l]):
+                        gs[l].wait_event(rb)
+                        dst = layers[l - 1]["dout"] if l > 0 else dx
+                        ops.gemm(dzc, W.data[:Din], out=dst[t0:t0 + T].view(T * B, Din), transB=True)
+                        dx_ev = torch.cuda.Event()
+                        dx_ev.record(gs[l])
+                        if c == 0:
+                            last.append(dx_ev)
+                with torch.cuda.stream(sw):
+                    sw.wait_event(rb)
+                    if W.grad is not None:
+                        beta = wbeta.get(id(W))
+                        if beta is None:
+                            beta = W.grad_beta()
+                            wbeta[id(W)] = 1.0
+                        ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta)
+                        ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta)
+                    if b.grad is not None:
+                        beta = wbeta.get(id(b))
+                        if beta is None:
+                            beta = b.grad_beta()
+                            wbeta[id(b)] = 1.0
+                        ops.colsum(dzc, b.grad.view(-1), beta=beta)
+        fin = torch.cuda.Event()
+        fin.record(sw)                                              # sw waited for every recurrence chunk
+        main.wait_event(fin)
+        for e in last:
+            main.wait_event(e)
+        for st in layers:
+            if st["W"].grad is not None:
+                st["W"].grad_done()
+            if st["b"].grad is not None:
+                st["b"].grad_done()
+        return (dx, None, None, None, None) + (None,) * (2 * L)
+
+
+def lstm_stack(x_tm, num_frames, weights_biases, forget_bias=1.0, chunks=4):
+    """weights_biases: [(W_0, b_0), ...] Variables.  Returns (out_top, [(c_l, h_l), ...])."""
+    flat = [v for wb in weights_biases for v in wb]
+    res = _LstmStack.apply(x_tm, _token(flat[0]._graph), num_frames, forget_bias, int(chunks), *flat)
+    return res[0], [(res[1 + 2 * l], res[2 + 2 * l]) for l in range(len(weights_biases))]
+
+
 class _AttnSoftmax(torch.autograd.Function):
     """mask * softmax over frames, renormalised (lstm_attention_max_pooling_model.py:59-60).  act, w: [B,F,A]."""
 
