@@ -117,6 +117,55 @@ def lstm_attention_max_pooling(x, num_frames, layers, Wa, ba, Wg, We, be, M):
     return moe(pooled.reshape(B * A, H), Wg, We, be, M).view(B, A, -1).max(1).values
 
 
+def lstm_parallel_finaloutput(x, num_frames, layer_sets, feature_sizes):
+    """W/all_frame_models/lstm_parallel_finaloutput_model.py:34-64: split by feature, l2-normalise each part, one LSTM
+    stack per part, concat of every layer's final h (state_is_tuple=True -> x.h)."""
+    states, off = [], 0
+    for fs, layers in zip(feature_sizes, layer_sets):
+        sub = l2_normalize(x[:, :, off:off + fs], 2)
+        off += fs
+        _, _, h = lstm_stack(sub, num_frames, layers)
+        states.extend(h)
+    return torch.cat(states, 1)
+
+
+def lstm_positional_attention_max_pooling(x, num_frames, layers, emb, Wa, ba, Wg, We, be, M):
+    """W/all_frame_models/lstm_positional_attention_max_pooling_model.py:30-66,68-85."""
+    B, F, D = x.shape
+    outputs, _, _ = lstm_stack(x, num_frames, layers)
+    mask = (torch.arange(F)[None, :] < num_frames[:, None]).to(x.dtype)
+    mean_input = torch.einsum("ijk,ij->ik", x, mask) / num_frames.to(x.dtype)[:, None]
+    act = torch.cat([x, emb.expand(B, F, emb.shape[2]), mean_input[:, None, :].expand(B, F, D), outputs], 2) @ Wa + ba
+    w = torch.softmax(act, dim=1) * mask[:, :, None]
+    w = w / w.sum(1, keepdim=True)
+    pooled = torch.einsum("bfh,bfa->bah", outputs, w)
+    A, H = pooled.shape[1], pooled.shape[2]
+    return moe(pooled.reshape(B * A, H), Wg, We, be, M).view(B, A, -1).max(1).values
+
+
+def cnn_deep_combine_chain(x, num_frames, P, L, M, relu_cells):
+    """W/all_frame_models/cnn_deep_combine_chain_model.py:13-88 (cnn: :13-39)."""
+    B, F, D = x.shape
+    mask = (torch.arange(F)[None, :] < num_frames[:, None]).to(x.dtype)
+    mean_input = torch.einsum("ijk,ij->ik", x, mask) / num_frames.to(x.dtype)[:, None]
+
+    def cnn(scope):
+        shifts = [x] + [torch.cat([x.new_zeros(B, i, D), x[:, :F - i]], 1) for i in (1, 2)]
+        outs = [torch.cat(shifts[:fs], 2) @ P["%scnn-filter-len%d" % (scope, fs)] for fs in (1, 2, 3)]
+        return l2_normalize(torch.cat(outs, 2).max(1).values, 1)
+
+    relu_layers = [l2_normalize(torch.relu(mean_input @ P["mean-relu/weights"] + P["mean-relu/biases"]), 1)]
+    nxt, sup = cnn("cnn0"), []
+    for layer in range(L):
+        s = "prediction-%d" % layer
+        sp = moe(nxt, P["gates-%s/weights" % s], P["experts-%s/weights" % s], P["experts-%s/biases" % s], M)
+        sup.append(sp)
+        relu_layers.append(l2_normalize(torch.relu(sp @ P["relu-%d/weights" % layer] + P["relu-%d/biases" % layer]), 1))
+        nxt = torch.cat([mean_input, cnn("cnn%d" % (layer + 1))] + relu_layers, 1)
+    main = moe(nxt, P["gates--main/weights"], P["experts--main/weights"], P["experts--main/biases"], M)
+    return main, torch.cat(sup, 1)
+
+
 def netvlad(x, num_frames, Wc, bc, centres, eps=1e-12):
     """SURVEY.md Appendix B (not in the reference)."""
     B, F, D = x.shape

@@ -96,7 +96,8 @@ def test_plugin_surface(flags):
         assert issubclass(getattr(vlm, name), models.BaseModel)
     for name in ["LstmModel", "LstmMemoryModel", "LstmAttentionMaxPoolingModel", "DbofModel", "FrameLevelLogisticModel",
                  "NetVLADModel", "GatedNetVLADModel",
-                 "GatedNetVLADAttentionChainModel"]:
+                 "GatedNetVLADAttentionChainModel", "LstmParallelFinaloutputModel", "LstmPositionalAttentionMaxPoolingModel",
+                 "CnnDeepCombineChainModel"]:
         assert issubclass(getattr(flm, name), models.BaseModel), name
     # reference flag names / defaults
     assert flags.moe_num_mixtures == 2 and flags.deep_chain_layers == 3 and flags.deep_chain_relu_cells == 200

@@ -200,6 +200,75 @@ def test_lstm_stack_pipelined_equals_sequential(dev, flags):
             assert float((cur[3][k] - res[3][k]).abs().max()) <= 2e-6 * max(float(res[3][k].abs().max()), 1e-6), k
 
 
+def test_lstm_parallel_finaloutput_model(dev, flags):
+    """parallel rgb / audio LSTM stacks (W/all_frame_models/lstm_parallel_finaloutput_model.py)."""
+    rs = np.random.RandomState(6)
+    B, F, V = 5, 9, 13
+    fsz, hsz = [10, 6], [8, 4]
+    flags.feature_sizes, flags.lstm_cells, flags.lstm_layers = "10,6", "8,4", 2
+    nf = np.array([9, 1, 4, 9, 6], dtype=np.int32)
+    x = rs.randn(B, F, sum(fsz)).astype(np.float32) * (np.arange(F)[None, :, None] < nf[:, None, None])
+    y = rs.rand(B, V) < 0.2
+    g, res, loss, P = run_model(flm.LstmParallelFinaloutputModel(), x, y, dev, nf=nf, rs=rs)
+    assert "RNN1/multi_rnn_cell/cell_1/basic_lstm_cell/weights" in g.vars
+    assert g.vars["gates/weights"].shape[0] == 2 * (8 + 4)                                  # h of 2 layers x 2 stacks
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    sets = [[(tp["RNN%d/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % (i, l)],
+              tp["RNN%d/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % (i, l)]) for l in range(2)] for i in range(2)]
+    st = torch_ref.lstm_parallel_finaloutput(T(x), torch.from_numpy(nf), sets, fsz)
+    pr = torch_ref.moe(st, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(H(res["predictions"]) - pr.detach().numpy()).max() < 1e-4
+    check_grads(g, tp, tol=5e-4)
+    flags.lstm_cells = "8"
+    with pytest.raises(AssertionError):                                                       # reference assert (:39-41)
+        run_model(flm.LstmParallelFinaloutputModel(), x, y, dev, nf=nf, rs=rs)
+
+
+def test_lstm_positional_attention_max_pooling_model(dev, flags):
+    """positional attention (W/all_frame_models/lstm_positional_attention_max_pooling_model.py)."""
+    rs = np.random.RandomState(7)
+    B, F, Dm, Hh, V, A, E = 4, 7, 10, 8, 11, 3, 5
+    flags.lstm_cells, flags.lstm_layers, flags.lstm_attentions, flags.positional_embedding_size = str(Hh), 2, A, E
+    nf = np.array([7, 2, 5, 7], dtype=np.int32)
+    x = rs.randn(B, F, Dm).astype(np.float32) * (np.arange(F)[None, :, None] < nf[:, None, None])
+    y = rs.rand(B, V) < 0.2
+    g, res, loss, P = run_model(flm.LstmPositionalAttentionMaxPoolingModel(), x, y, dev, nf=nf, rs=rs)
+    assert g.vars["positional_embedding"].shape == (1, F, E) and g.vars["positional_embedding"].l2 == 1e-8
+    assert g.vars["attention-/weights"].shape == (Dm + E + Dm + Hh, A)
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    pr = torch_ref.lstm_positional_attention_max_pooling(
+        T(x), torch.from_numpy(nf), _lstm_ref_layers(tp, 2), tp["positional_embedding"], tp["attention-/weights"],
+        tp["attention-/biases"], tp["gates-sub-moe/weights"], tp["experts-sub-moe/weights"], tp["experts-sub-moe/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(H(res["predictions"]) - pr.detach().numpy()).max() < 1e-4
+    check_grads(g, tp, tol=5e-4)
+
+
+def test_cnn_deep_combine_chain_model(dev, flags):
+    """einsum-CNN chain (W/all_frame_models/cnn_deep_combine_chain_model.py) under the multitask loss."""
+    rs = np.random.RandomState(8)
+    B, F, Dm, V, L, cells = 4, 6, 9, 12, 2, 5
+    flags.deep_chain_layers, flags.deep_chain_relu_cells = L, cells
+    flags.support_type = ",".join(["label"] * L)
+    nf = np.array([6, 1, 4, 3], dtype=np.int32)
+    x = rs.randn(B, F, Dm).astype(np.float32) * (np.arange(F)[None, :, None] < nf[:, None, None])
+    y = rs.rand(B, V) < 0.2
+    g, res, loss, P = run_model(flm.CnnDeepCombineChainModel(), x, y, dev, nf=nf, rs=rs, multitask=True)
+    assert g.vars["cnn1cnn-filter-len3"].shape == (3 * Dm, 2 * cells) and g.vars["cnn0cnn-filter-len2"].l2 == 1e-8
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    main, sup = torch_ref.cnn_deep_combine_chain(T(x), torch.from_numpy(nf), tp, L, 2, cells)
+    assert np.abs(H(res["predictions"]) - main.detach().numpy()).max() < 1e-4
+    assert np.abs(H(res["support_predictions"]) - sup.detach().numpy()).max() < 1e-4
+    s = flags.support_loss_percent
+    lr = (1 - s) * torch_ref.cross_entropy(main, T(y)) + s * torch_ref.cross_entropy(sup, T(y).repeat(1, L))
+    lr.backward()
+    assert abs(float(loss.detach()) - lr.item()) < 1e-4 * abs(lr.item())
+    check_grads(g, tp, tol=5e-4)
+
+
 def test_lstm_attention_max_pooling_model(dev, flags):
     rs = np.random.RandomState(3)
     B, F, Dm, Hh, V, A = 5, 9, 10, 6, 13, 3

@@ -25,6 +25,8 @@ DEFINE_string("lstm_cells", "1024", "Number of LSTM cells.")
 DEFINE_integer("lstm_layers", 2, "Number of LSTM layers.")
 # new: time chunks of the layer-pipelined LSTM stack (1 = one layer after the other)
 DEFINE_integer("lstm_pipeline_chunks", 4, "Time chunks over which the layers of the LSTM stack are pipelined on separate streams.")
+DEFINE_string("feature_sizes", "1024", "Length of the feature vectors.")     # W/train.py:58 (read by the parallel LSTM model)
+DEFINE_integer("positional_embedding_size", 32, "Positional embedding dimension use in lstm_positional_attention_max_pooling_model.")
 DEFINE_integer("lstm_attentions", 8, "Attention size in lstm_attention_max_pooling_model.")
 DEFINE_bool("is_training", False, "used in batch normalization.")
 # new (Appendix B)
@@ -38,7 +40,7 @@ def _head(name=None):
     return getattr(video_level_models, name or FLAGS.video_level_classifier_model)
 
 
-def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers):
+def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN"):
     """MultiRNNCell([BasicLSTMCell(H, forget_bias=1.0)] * L) under tf.nn.dynamic_rnn inside variable_scope("RNN")
     (W/all_frame_models/lstm_model.py:34-47).  TF-1.0 variable names:
     RNN/multi_rnn_cell/cell_<l>/basic_lstm_cell/{weights,biases}.  Returns time-major outputs of the top layer
@@ -47,7 +49,7 @@ def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers):
     x_tm = model_input.transpose(0, 1).contiguous()          # [F,B,D]   (layout glue)
     wb = []
     d_in = x_tm.shape[2]
-    with g.variable_scope("RNN"):
+    with g.variable_scope(scope):
         for l in range(number_of_layers):
             scope = "multi_rnn_cell/cell_%d/basic_lstm_cell" % l
             W = g.get_variable(scope + "/weights", (d_in + lstm_size, 4 * lstm_size), xavier_uniform)
@@ -120,6 +122,108 @@ class LstmAttentionMaxPoolingModel(models.BaseModel):
         return {"predictions": max_predictions}
 
     def sub_moe(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", **unused_params):
+        num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
+        return video_level_models.moe_block(model_input, vocab_size, num_mixtures, l2_penalty,
+                                            "gates-" + sub_scope, "experts-" + sub_scope)
+
+
+class LstmParallelFinaloutputModel(models.BaseModel):
+    """W/all_frame_models/lstm_parallel_finaloutput_model.py:13-73: one LSTM stack per input feature (rgb / audio: the
+    input is split by --feature_sizes, each part re-normalised), head input = concat of every layer's final h."""
+
+    def create_model(self, model_input, vocab_size, num_frames, **unused_params):
+        number_of_layers = FLAGS.lstm_layers
+        lstm_sizes = [int(v) for v in str(FLAGS.lstm_cells).split(",")]
+        feature_sizes = [int(v) for v in str(FLAGS.feature_sizes).split(",")]
+        assert len(lstm_sizes) == len(feature_sizes), \
+            "length of lstm_sizes (={}) != length of feature_sizes (={})".format(len(lstm_sizes), len(feature_sizes))
+        assert sum(feature_sizes) == model_input.shape[2], "feature_sizes do not add up to the input width"
+        states, off = [], 0
+        for i, (fs, hs) in enumerate(zip(feature_sizes, lstm_sizes)):
+            sub_input = ops.l2_normalize(model_input[:, :, off:off + fs].contiguous())
+            off += fs
+            _, finals = _lstm_stack(sub_input, num_frames, hs, number_of_layers, scope="RNN%d" % i)
+            states.extend(h for _, h in finals)
+        final_state = torch.cat(states, dim=1)
+        return _head()().create_model(model_input=final_state, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
+
+
+class LstmPositionalAttentionMaxPoolingModel(LstmAttentionMaxPoolingModel):
+    """W/all_frame_models/lstm_positional_attention_max_pooling_model.py:10-87: as LstmAttentionMaxPoolingModel, the
+    attention FC additionally sees a learned positional embedding [1,F,E] and the masked mean of the input."""
+
+    def create_model(self, model_input, vocab_size, num_frames, num_mixtures=None, l2_penalty=1e-8, sub_scope="",
+                     original_input=None, **unused_params):
+        lstm_size = int(FLAGS.lstm_cells)
+        num_attentions = FLAGS.lstm_attentions
+        B, F, D = model_input.shape
+        out_tm, _ = _lstm_stack(model_input, num_frames, lstm_size, FLAGS.lstm_layers)
+        outputs = out_tm.transpose(0, 1).contiguous()                               # [B,F,H]
+        g = get_default_graph()
+        emb = g.get_variable("positional_embedding", (1, F, FLAGS.positional_embedding_size), xavier_uniform, l2=l2_penalty)
+        positional_embedding = ops.as_tensor(emb).expand(B, F, FLAGS.positional_embedding_size)
+        mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
+        mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
+        attention_activations = video_level_models.fully_connected(
+            torch.cat([model_input, positional_embedding, mean_input[:, None, :].expand(B, F, D), outputs], dim=2),
+            num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
+        attention_weights = seq_ops.attention_weights(attention_activations, num_frames)   # [B,F,A]
+        attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
+        moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")
+        predictions = moe_predictions.view(-1, num_attentions, vocab_size)
+        return {"predictions": predictions.max(dim=1).values}
+
+
+class CnnDeepCombineChainModel(models.BaseModel):
+    """W/all_frame_models/cnn_deep_combine_chain_model.py:10-140: chain of MoE sub-predictions whose inputs are max-pooled
+    "einsum CNNs" over the frames (filter lengths 1,2,3 = GEMMs on the input concatenated with its 1- and 2-frame shifts),
+    the masked mean input and the l2-normalised relu projections of the previous predictions."""
+
+    def cnn(self, model_input, l2_penalty=1e-8, num_filters=(1024, 1024, 1024), filter_sizes=(1, 2, 3), sub_scope="",
+            **unused_params):
+        g = get_default_graph()
+        B, F, D = model_input.shape
+        shift_inputs = [model_input]
+        for i in range(1, max(filter_sizes)):                         # tf.pad(..., [[0,0],[i,0],[0,0]])[:, :F]
+            shift_inputs.append(torch.cat([model_input.new_zeros(B, i, D), model_input[:, :F - i]], dim=1))
+        cnn_outputs = []
+        for nf, fs in zip(num_filters, filter_sizes):
+            sub_input = torch.cat(shift_inputs[:fs], dim=2) if fs > 1 else shift_inputs[0]
+            sub_filter = g.get_variable(sub_scope + "cnn-filter-len%d" % fs, (D * fs, nf), random_normal(0.1), l2=l2_penalty)
+            cnn_outputs.append(ops.linear(sub_input, sub_filter))
+        return torch.cat(cnn_outputs, dim=2)
+
+    def create_model(self, model_input, vocab_size, num_frames, num_mixtures=None, l2_penalty=1e-8, sub_scope="",
+                     original_input=None, **unused_params):
+        num_layers = FLAGS.deep_chain_layers
+        relu_cells = FLAGS.deep_chain_relu_cells
+        B, F, D = model_input.shape
+        mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
+        mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
+        mean_relu = video_level_models.fully_connected(mean_input, relu_cells, sub_scope + "mean-relu", activation="relu",
+                                                       l2_penalty=l2_penalty)
+        relu_layers = [ops.l2_normalize(mean_relu)]
+        filters = dict(num_filters=[relu_cells, relu_cells, relu_cells * 2], filter_sizes=[1, 2, 3])
+
+        def pooled_cnn(scope):
+            cnn_output = self.cnn(model_input, sub_scope=scope, l2_penalty=l2_penalty, **filters)
+            return ops.l2_normalize(cnn_output.max(dim=1).values)      # reduce_max over ALL max_frames rows, as the reference
+
+        next_input = pooled_cnn(sub_scope + "cnn0")
+        support_predictions = []
+        for layer in range(num_layers):
+            sub_prediction = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "prediction-%d" % layer)
+            support_predictions.append(sub_prediction)
+            sub_relu = video_level_models.fully_connected(sub_prediction, relu_cells, sub_scope + "relu-%d" % layer,
+                                                          activation="relu", l2_penalty=l2_penalty)
+            relu_layers.append(ops.l2_normalize(sub_relu))
+            normalized_cnn_output = pooled_cnn(sub_scope + "cnn%d" % (layer + 1))
+            next_input = torch.cat([mean_input, normalized_cnn_output] + relu_layers, dim=1)
+        main_predictions = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "-main")
+        return {"predictions": main_predictions, "support_predictions": torch.cat(support_predictions, dim=1)}
+
+    def sub_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", **unused_params):
         num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
         return video_level_models.moe_block(model_input, vocab_size, num_mixtures, l2_penalty,
                                             "gates-" + sub_scope, "experts-" + sub_scope)

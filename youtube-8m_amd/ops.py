@@ -422,6 +422,32 @@ def linear(x, W, b=None, bf16=None):
     return y.view(*lead, y.shape[-1])
 
 
+class _VarTensor(torch.autograd.Function):
+    """A Variable used as a plain tensor in layout glue (tile / concat), e.g. the positional embedding of
+    W/all_frame_models/lstm_positional_attention_max_pooling_model.py:68-76: forward hands out the parameter, backward
+    lands the gradient in the arena slice (beta 0/1 like every other op)."""
+
+    @staticmethod
+    def forward(ctx, token, var):
+        ctx.var = var
+        return var.data.view_as(var.data)
+
+    @staticmethod
+    def backward(ctx, g):
+        var = ctx.var
+        if var.grad is not None and g is not None:
+            if var.grad_beta() == 0.0:
+                var.grad.copy_(g.view_as(var.grad))
+            else:
+                var.grad.add_(g.view_as(var.grad))
+            var.grad_done()
+        return None, None
+
+
+def as_tensor(var):
+    return _VarTensor.apply(_token(var._graph), var)
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind):
