@@ -285,6 +285,13 @@ int yt8m_tfrecord_read_video_batch(void* reader, const char* const* feature_name
                                    int64_t num_classes, int64_t max_records, float* x, uint8_t* labels, char* video_ids,
                                    int64_t id_stride, int64_t* n_read);
 
+/* prediction dump for the ensemble stage (W/inference-pre-ensemble.py:291-308): one tf.train.Example per video with
+ * {"video_id", "labels" = nonzero(labels row), feature_name = predictions row (float list)}, TFRecord framed.  HOST buffers:
+ * video_ids [n, id_stride] NUL-padded, labels [n, num_classes] uint8 multi-hot, predictions [n, num_classes] float32. */
+int yt8m_tfrecord_write_predictions(const char* path, int64_t n, const char* video_ids, int64_t id_stride,
+                                    const uint8_t* labels, const float* predictions, int64_t num_classes,
+                                    const char* feature_name);
+
 #ifdef __cplusplus
 }
 #endif

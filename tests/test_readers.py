@@ -112,3 +112,30 @@ def test_reader_errors(tmp_path):
         readers.YT8MFrameFeatureReader(4716, [16, 4], ["rgb"], 8)
     with pytest.raises(NotImplementedError):
         readers.BaseReader().prepare_reader(None)
+
+
+def test_prediction_dump_bit_exact_and_round_trip(tmp_path):
+    """the ensemble-stage prediction dump (W/inference-pre-ensemble.py:291-308).  The native writer's
+    file equals the oracle's pure-Python encoding byte for byte, and the native reader reads it back exactly."""
+    import yt8m_amd.inference as inference
+    rs = np.random.RandomState(5)
+    n, V = 7, 4716
+    pred = rs.rand(n, V).astype(np.float32)
+    lab = rs.rand(n, V) < 0.001
+    lab[3] = False                                                             # a video without labels
+    ids = [("vid%03d" % i).encode() for i in range(n)]
+    ids[2] = b"x"
+    p = str(tmp_path / "predictions-0000.tfrecord")
+    inference.write_to_record(p, ids, lab, pred)
+    videos = [dict(video_id=ids[i], labels=list(np.nonzero(lab[i])[0]), features={"predictions": pred[i]}) for i in range(n)]
+    q = str(tmp_path / "oracle.tfrecord")
+    tr.write_video_shard(q, videos, ["predictions"])
+    assert open(p, "rb").read() == open(q, "rb").read()
+    rd = readers.YT8MAggregatedFeatureReader(num_classes=V, feature_sizes=[V], feature_names=["predictions"])
+    got = list(rd.prepare_reader(p, batch_size=4))
+    vids = [v for b in got for v in b[0]]
+    x = np.concatenate([b[1].numpy() for b in got])
+    y = np.concatenate([b[2].numpy() for b in got])
+    assert vids == ids and np.array_equal(x, pred) and np.array_equal(y != 0, lab)
+    with pytest.raises(ValueError):
+        inference.write_to_record(str(tmp_path / "no_such_dir" / "f.tfrecord"), ids, lab, pred)

@@ -342,3 +342,72 @@ extern "C" int yt8m_tfrecord_read_video_batch(void* reader, const char* const* f
   }
   return YT8M_OK;
 }
+
+// ---- prediction dump for the ensemble stage (W/inference-pre-ensemble.py:291-308 write_to_record / get_output_feature) ----
+// One tf.train.Example per video: {"video_id": bytes, "labels": int64 list = nonzero(label row), <feature_name>: float list =
+// the prediction row}, framed as TFRecord.  Repeated scalars are written packed (what TF's proto3 Example encoders emit);
+// map entries in the order video_id, labels, feature (readers are order-agnostic).
+namespace {
+
+void put_varint(std::string& o, uint64_t v) {
+  while (v >= 0x80) { o.push_back((char)((v & 0x7f) | 0x80)); v >>= 7; }
+  o.push_back((char)v);
+}
+void put_ld(std::string& o, int field, const std::string& payload) {
+  put_varint(o, ((uint64_t)field << 3) | 2);
+  put_varint(o, payload.size());
+  o += payload;
+}
+std::string map_entry(const char* key, const std::string& feature) {
+  std::string e;
+  put_ld(e, 1, std::string(key));
+  put_ld(e, 2, feature);
+  return e;
+}
+
+}  // namespace
+
+extern "C" int yt8m_tfrecord_write_predictions(const char* path, int64_t n, const char* video_ids, int64_t id_stride,
+                                               const uint8_t* labels, const float* predictions, int64_t num_classes,
+                                               const char* feature_name) {
+  YT8M_REQUIRE(path && feature_name && n >= 0 && num_classes >= 0 && id_stride > 0, YT8M_E_BADARG, "bad argument");
+  YT8M_REQUIRE(n == 0 || (video_ids && labels && predictions), YT8M_E_BADARG, "null operand");
+  FILE* fh = fopen(path, "wb");
+  if (!fh) return yt8m::fail(YT8M_E_BADARG, "yt8m_tfrecord_write_predictions: cannot open %s", path);
+  int rc = YT8M_OK;
+  for (int64_t r = 0; r < n && rc == YT8M_OK; ++r) {
+    const char* id = video_ids + r * id_stride;
+    std::string bl;                                                   // BytesList { value = id }
+    put_ld(bl, 1, std::string(id, strnlen(id, (size_t)id_stride)));
+    std::string f_id;
+    put_ld(f_id, 1, bl);                                              // Feature.bytes_list = 1
+    std::string ints;
+    for (int64_t c = 0; c < num_classes; ++c)
+      if (labels[r * num_classes + c]) put_varint(ints, (uint64_t)c);
+    std::string il;
+    put_ld(il, 1, ints);                                              // Int64List { packed value }
+    std::string f_lab;
+    put_ld(f_lab, 3, il);                                             // Feature.int64_list = 3
+    std::string fl;
+    put_ld(fl, 1, std::string(reinterpret_cast<const char*>(predictions + r * num_classes), (size_t)num_classes * 4));
+    std::string f_pred;
+    put_ld(f_pred, 2, fl);                                            // Feature.float_list = 2 (little-endian host)
+    std::string feats;                                                // Features { map<string, Feature> feature = 1 }
+    put_ld(feats, 1, map_entry("video_id", f_id));
+    put_ld(feats, 1, map_entry("labels", f_lab));
+    put_ld(feats, 1, map_entry(feature_name, f_pred));
+    std::string ex;
+    put_ld(ex, 1, feats);                                             // Example { features = 1 }
+    const uint64_t len = ex.size();
+    uint8_t hdr[12];
+    memcpy(hdr, &len, 8);
+    const uint32_t hc = mask_crc(crc32c(hdr, 8));
+    memcpy(hdr + 8, &hc, 4);
+    const uint32_t pc = mask_crc(crc32c(reinterpret_cast<const uint8_t*>(ex.data()), ex.size()));
+    if (fwrite(hdr, 1, 12, fh) != 12 || fwrite(ex.data(), 1, ex.size(), fh) != ex.size() || fwrite(&pc, 1, 4, fh) != 4) {
+      rc = yt8m::fail(YT8M_E_BADARG, "yt8m_tfrecord_write_predictions: short write to %s", path);
+    }
+  }
+  if (fclose(fh) != 0 && rc == YT8M_OK) rc = yt8m::fail(YT8M_E_BADARG, "yt8m_tfrecord_write_predictions: close failed for %s", path);
+  return rc;
+}
