@@ -214,6 +214,12 @@ int yt8m_lstm_steps_bwd(const float* gates, const float* Wh, int64_t ldw, const 
                         int64_t T, int64_t B, int64_t H, void* gemm_workspace, int64_t gemm_workspace_bytes,
                         yt8m_stream_t stream);
 
+/* The packed-weight step chains above are launch-bound (75-300 steps x 1-2 kernels of ~20 us): each distinct argument tuple is
+ * captured once on the caller's stream and replayed as ONE hipGraph launch afterwards (LRU cache inside the library; off
+ * while yt8m_prof_enable(1) is active or with YT8M_NO_GRAPH set in the environment). */
+int yt8m_graph_cache_stats(int64_t* hits, int64_t* captures, int64_t* fallbacks, int64_t* entries);
+int yt8m_graph_cache_clear(void);
+
 /* ---- masked softmax over frames + renormalise (lstm_attention_max_pooling_model.py:59-60) -------
  * act [B,F,A] -> w [B,F,A]: w = mask * softmax_F(act) / sum_F(mask * softmax_F(act)).  bwd: dact from dw. */
 int yt8m_attn_softmax_fwd(const float* act, const int32_t* num_frames, float* w, int64_t B, int64_t F,

@@ -198,6 +198,15 @@ def test_lstm_stack_pipelined_equals_sequential(dev, flags):
         assert float((cur[2] - res[2]).abs().max()) <= 1e-6 * float(res[2].abs().max())
         for k in res[3]:
             assert float((cur[3][k] - res[3][k]).abs().max()) <= 2e-6 * max(float(res[3][k].abs().max()), 1e-6), k
+    # the step chains went through the hipGraph replay cache (capture on first use, replay when the arguments repeat)
+    import ctypes
+    import yt8m_amd._lib as L
+    h, c, f, e = (ctypes.c_int64(0) for _ in range(4))
+    L.check(L.lib().yt8m_graph_cache_stats(ctypes.byref(h), ctypes.byref(c), ctypes.byref(f), ctypes.byref(e)))
+    assert c.value > 0 and f.value == 0 and e.value <= 96
+    L.check(L.lib().yt8m_graph_cache_clear())
+    L.check(L.lib().yt8m_graph_cache_stats(None, None, None, ctypes.byref(e)))
+    assert e.value == 0
 
 
 def test_lstm_parallel_finaloutput_model(dev, flags):

@@ -67,7 +67,8 @@ def run(name, steps=5):
         tg.step(x, y, nf)
     torch.cuda.synchronize()
     lib.yt8m_prof_reset()
-    lib.yt8m_prof_enable(1)
+    prof = os.environ.get("YT8M_NO_PROF") is None      # the per-family hipEvent profiler turns hipGraph replay off
+    lib.yt8m_prof_enable(1 if prof else 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = tg.step(x, y, nf)

@@ -53,6 +53,9 @@ SIGNATURES = {
     "yt8m_lstm_gates_fwd": (c_int, [P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, c_float, P]),
     "yt8m_lstm_gates_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, ctypes.c_int32, c_int64, c_int64, P]),
     "yt8m_lstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_graph_cache_stats": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
+                                       ctypes.POINTER(c_int64)]),
+    "yt8m_graph_cache_clear": (c_int, []),
     "yt8m_lstm_packed_floats": (c_int64, [c_int64, c_int64]),
     "yt8m_lstm_pack": (c_int, [P, c_int64, c_int64, P, P, P]),
     "yt8m_lstm_steps_fwd": (c_int, [P, P, c_int64, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),

@@ -45,6 +45,20 @@ struct ProfScope {
   ~ProfScope();
 };
 
+bool prof_enabled();
+
+// hipGraph replay of a launch-bound kernel chain (runtime.hip).  The key must identify every argument the chain depends on.
+struct GraphKey {
+  int kind;
+  int pad;
+  const void* p[10];
+  int64_t v[8];
+};
+}  // namespace yt8m
+#include <functional>
+namespace yt8m {
+int run_chain(const GraphKey& key, hipStream_t s, const std::function<int()>& launch_all);
+
 inline hipStream_t as_stream(yt8m_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int launch_status(const char* what) {

@@ -1,4 +1,6 @@
 // runtime.hip -- error reporting, ABI version and the per-family hipEvent profiler.
+#include <stdlib.h>
+#include <functional>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -25,6 +27,86 @@ ProfScope::~ProfScope() {
   g_pending.push_back({fam, e0, e1});
 }
 
+bool prof_enabled() { return g_prof_on; }
+
+// ---- hipGraph replay of launch-bound kernel chains (the LSTM recurrence: 75-300 steps x 1-2 tiny kernels) ------------
+// A chain is captured once per distinct argument tuple (pointers + shapes) on the caller's stream, instantiated and kept in a
+// small LRU cache; later calls with the same arguments replay it with ONE hipGraphLaunch.  PyTorch's caching allocator
+// hands the same addresses to the same allocation sequence every training step, so steady-state steps hit the cache.
+// Off while the hipEvent profiler is on (its event records would be captured) or when YT8M_NO_GRAPH is set.
+struct GraphEntry {
+  GraphKey key;
+  hipGraphExec_t exec;
+  uint64_t last;
+};
+static std::mutex g_graph_mu;
+static std::vector<GraphEntry> g_graphs;
+static uint64_t g_graph_tick = 0;
+static int64_t g_graph_hits = 0, g_graph_captures = 0, g_graph_fallbacks = 0;
+static const size_t GRAPH_CACHE = 96;
+
+static bool graphs_disabled() {
+  static const bool off = getenv("YT8M_NO_GRAPH") != nullptr;
+  return off;
+}
+
+int run_chain(const GraphKey& key, hipStream_t s, const std::function<int()>& launch_all) {
+  if (graphs_disabled() || g_prof_on) return launch_all();
+  {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& e : g_graphs) {
+      if (memcmp(&e.key, &key, sizeof(GraphKey)) == 0) {
+        e.last = ++g_graph_tick;
+        ++g_graph_hits;
+        if (hipGraphLaunch(e.exec, s) == hipSuccess) return YT8M_OK;
+        (void)hipGetLastError();
+        break;                                                       // stale exec: fall through to a direct launch
+      }
+    }
+  }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    ++g_graph_fallbacks;
+    return launch_all();
+  }
+  const int rc = launch_all();
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(s, &graph);
+  if (rc != YT8M_OK || ec != hipSuccess || !graph) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    ++g_graph_fallbacks;
+    return rc != YT8M_OK ? rc : launch_all();                        // nothing ran during the failed capture
+  }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(graph);
+    ++g_graph_fallbacks;
+    return launch_all();
+  }
+  (void)hipGraphDestroy(graph);
+  if (hipGraphLaunch(exec, s) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphExecDestroy(exec);
+    ++g_graph_fallbacks;
+    return launch_all();
+  }
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  ++g_graph_captures;
+  if (g_graphs.size() >= GRAPH_CACHE) {                              // evict the least recently used entry
+    size_t victim = 0;
+    for (size_t i = 1; i < g_graphs.size(); ++i)
+      if (g_graphs[i].last < g_graphs[victim].last) victim = i;
+    // an evicted executable may still be running: synchronise its stream's work before destroying it
+    (void)hipDeviceSynchronize();
+    (void)hipGraphExecDestroy(g_graphs[victim].exec);
+    g_graphs.erase(g_graphs.begin() + victim);
+  }
+  g_graphs.push_back({key, exec, ++g_graph_tick});
+  return YT8M_OK;
+}
+
 static void drain() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& p : g_pending) {
@@ -46,6 +128,21 @@ extern "C" const char* yt8m_built_arch(void) { return "gfx950"; }
 
 extern "C" int yt8m_prof_enable(int on) {
   yt8m::g_prof_on = on != 0;
+  return YT8M_OK;
+}
+extern "C" int yt8m_graph_cache_stats(int64_t* hits, int64_t* captures, int64_t* fallbacks, int64_t* entries) {
+  std::lock_guard<std::mutex> lk(yt8m::g_graph_mu);
+  if (hits) *hits = yt8m::g_graph_hits;
+  if (captures) *captures = yt8m::g_graph_captures;
+  if (fallbacks) *fallbacks = yt8m::g_graph_fallbacks;
+  if (entries) *entries = (int64_t)yt8m::g_graphs.size();
+  return YT8M_OK;
+}
+extern "C" int yt8m_graph_cache_clear(void) {
+  std::lock_guard<std::mutex> lk(yt8m::g_graph_mu);
+  (void)hipDeviceSynchronize();
+  for (auto& e : yt8m::g_graphs) (void)hipGraphExecDestroy(e.exec);
+  yt8m::g_graphs.clear();
   return YT8M_OK;
 }
 extern "C" int yt8m_prof_reset(void) {

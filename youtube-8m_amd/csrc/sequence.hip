@@ -321,11 +321,21 @@ extern "C" int yt8m_lstm_steps_fwd(float* z, const float* Wh, int64_t ldw, const
   if (Wp) {
     YT8M_REQUIRE(lstm_fused_supported(B, H, (int64_t)sizeof(float) * H * 4 * H), YT8M_E_SHAPE, "packed path needs H % 128 == 0");
     ProfScope prof(F_LSTM, as_stream(stream));
-    int rc = YT8M_OK;
-    for (int64_t t = t0; t < t0 + T && rc == YT8M_OK; ++t)
-      rc = lstm_step_fwd(z + t * B * 4 * H, Wp, cs + t * BH, hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH,
-                         out ? out + t * BH : nullptr, num_frames, (int)t, B, H, forget_bias, as_stream(stream));
-    return rc;
+    hipStream_t s = as_stream(stream);
+    // T tiny kernels back to back: launch-bound -> captured once per argument tuple, replayed as one hipGraph afterwards
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = 1;
+    key.p[0] = z; key.p[1] = Wp; key.p[2] = cs; key.p[3] = hs; key.p[4] = out; key.p[5] = num_frames;
+    key.v[0] = t0; key.v[1] = T; key.v[2] = B; key.v[3] = H;
+    memcpy(&key.v[4], &forget_bias, sizeof(float));
+    return run_chain(key, s, [&]() {
+      int rc = YT8M_OK;
+      for (int64_t t = t0; t < t0 + T && rc == YT8M_OK; ++t)
+        rc = lstm_step_fwd(z + t * B * 4 * H, Wp, cs + t * BH, hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH,
+                           out ? out + t * BH : nullptr, num_frames, (int)t, B, H, forget_bias, s);
+      return rc;
+    });
   }
   for (int64_t t = t0; t < t0 + T; ++t) {
     float* zt = z + t * B * 4 * H;
@@ -353,26 +363,35 @@ extern "C" int yt8m_lstm_steps_bwd(const float* gates, const float* Wh, int64_t 
   if (Wq) YT8M_REQUIRE(lstm_fused_supported(B, H, (int64_t)sizeof(float) * H * 4 * H), YT8M_E_SHAPE, "packed path needs H % 128 == 0");
   hipStream_t s = as_stream(stream);
   const int64_t BH = B * H;
-  float* dh_cur = work + (phase ? 2 : 0) * BH;
-  float* dc_cur = dh_cur + BH;
-  float* dh_prev = work + (phase ? 0 : 2) * BH;
-  float* dc_prev = dh_prev + BH;
-  for (int64_t t = t0 + T - 1; t >= t0; --t) {
-    float* dzt = dz + t * B * 4 * H;
-    int rc = yt8m_lstm_gates_bwd(gates + t * B * 4 * H, cs + t * BH, cs + (t + 1) * BH, dh_cur, dc_cur,
-                                 dout ? dout + t * BH : nullptr, dzt, dc_prev, dh_prev, num_frames, (int32_t)t, B, H, stream);
-    if (rc != YT8M_OK) return rc;
-    if (Wq) {
-      rc = lstm_step_bwd(dzt, Wq, dh_prev, B, H, s);
-    } else {
-      yt8m_gemm_problem pr = {B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f};
-      rc = yt8m_gemm_f32_grouped(0, 1, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
+  auto chain = [&]() {
+    float* dh_cur = work + (phase ? 2 : 0) * BH;
+    float* dc_cur = dh_cur + BH;
+    float* dh_prev = work + (phase ? 0 : 2) * BH;
+    float* dc_prev = dh_prev + BH;
+    for (int64_t t = t0 + T - 1; t >= t0; --t) {
+      float* dzt = dz + t * B * 4 * H;
+      int rc = yt8m_lstm_gates_bwd(gates + t * B * 4 * H, cs + t * BH, cs + (t + 1) * BH, dh_cur, dc_cur,
+                                   dout ? dout + t * BH : nullptr, dzt, dc_prev, dh_prev, num_frames, (int32_t)t, B, H, stream);
+      if (rc != YT8M_OK) return rc;
+      if (Wq) {
+        rc = lstm_step_bwd(dzt, Wq, dh_prev, B, H, s);
+      } else {
+        yt8m_gemm_problem pr = {B, H, 4 * H, dzt, 4 * H, Wh, ldw, dh_prev, H, nullptr, 1.0f};
+        rc = yt8m_gemm_f32_grouped(0, 1, 1, &pr, gemm_workspace, gemm_workspace_bytes, stream);
+      }
+      if (rc != YT8M_OK) return rc;
+      float* tmp = dh_cur; dh_cur = dh_prev; dh_prev = tmp;
+      tmp = dc_cur; dc_cur = dc_prev; dc_prev = tmp;
     }
-    if (rc != YT8M_OK) return rc;
-    float* tmp = dh_cur; dh_cur = dh_prev; dh_prev = tmp;
-    tmp = dc_cur; dc_cur = dc_prev; dc_prev = tmp;
-  }
-  return YT8M_OK;
+    return (int)YT8M_OK;
+  };
+  if (!Wq) return chain();                        // generic path: host-side split-K decisions, not captured
+  GraphKey key;
+  memset(&key, 0, sizeof(key));
+  key.kind = 2;
+  key.p[0] = gates; key.p[1] = Wq; key.p[2] = cs; key.p[3] = dout; key.p[4] = dz; key.p[5] = work; key.p[6] = num_frames;
+  key.v[0] = t0; key.v[1] = T; key.v[2] = B; key.v[3] = H; key.v[4] = phase;
+  return run_chain(key, s, chain);
 }
 
 extern "C" int yt8m_attn_softmax_fwd(const float* act, const int32_t* num_frames, float* w, int64_t B, int64_t F,
