@@ -36,6 +36,11 @@ CONFIGS = {
                          flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3),
                                     compute_dtype="bfloat16")),
     "netvlad_bf16": dict(model=flm.NetVLADModel, B=128, frame=True, flags=dict(compute_dtype="bfloat16")),
+    "lstm_parallel": dict(model=flm.LstmParallelFinaloutputModel, B=128, frame=True,
+                          flags=dict(feature_sizes="1024,128", lstm_cells="1024,128")),
+    "lstm_posattn": dict(model=flm.LstmPositionalAttentionMaxPoolingModel, B=128, frame=True),
+    "cnn_chain": dict(model=flm.CnnDeepCombineChainModel, B=128, frame=True, multitask=True,
+                      flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3))),
     "dbof": dict(model=flm.DbofModel, B=128, frame=True, flags=dict(dbof_add_batch_norm=False)),
 }
 
