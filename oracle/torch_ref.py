@@ -166,6 +166,20 @@ def cnn_deep_combine_chain(x, num_frames, P, L, M, relu_cells):
     return main, torch.cat(sup, 1)
 
 
+def reform_distill_labels(y, distill, p):
+    """W/train.py:320-327."""
+    sy = y.sum(1, keepdim=True)
+    sd = distill.sum(1, keepdim=True) + 1e-6
+    return torch.clamp(y + distill * (sy / sd * p), 0.0, 1.0)
+
+
+def weights_by_predictions(y, predictions):
+    """W/train.py:250-260."""
+    eps = 1e-6
+    ce = -(y * torch.log(predictions + eps) + (1 - y) * torch.log(1 - predictions + eps)).sum(1)
+    return torch.where(ce > (ce + eps).mean(), torch.full_like(ce, 3.0), torch.full_like(ce, 0.5))
+
+
 def netvlad(x, num_frames, Wc, bc, centres, eps=1e-12):
     """SURVEY.md Appendix B (not in the reference)."""
     B, F, D = x.shape

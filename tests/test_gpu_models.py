@@ -560,6 +560,69 @@ def test_config5_composite_model(dev, flags, quantized):
     check_grads(g, tp, tol=5e-4)
 
 
+@pytest.mark.parametrize("mode", ["type1", "type2", "boosting", "type1_multitask"])
+def test_distillation_losses(dev, flags, mode):
+    """SURVEY.md 8f item 3, W/train.py:312-327,384-430: distillation labels blended into / replacing the label loss, re-formed
+    labels (type 2) and boosting weights from the teacher's cross entropy -- loss and gradients against the oracle."""
+    rs = np.random.RandomState(19)
+    B, Dm, V = 9, 14, 23
+    x = rs.randn(B, Dm).astype(np.float32)
+    y = rs.rand(B, V) < 0.15
+    teacher = rs.rand(B, V).astype(np.float32) * 0.9 + 0.05
+    flags.distillation_features = True
+    flags.distillation_percent = 0.3
+    multitask = mode == "type1_multitask"
+    if mode.startswith("type1"):
+        flags.distillation_type = 1
+    elif mode == "type2":
+        flags.distillation_type = 2
+    else:
+        flags.distillation_type = 0
+        flags.distillation_as_boosting = True
+    if multitask:
+        flags.deep_chain_layers, flags.deep_chain_relu_cells, flags.support_type = 2, 4, "label,label"
+    model = vlm.DeepCombineChainModel() if multitask else vlm.MoeModel()
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(model, batch_size=B, graph=g, multitask=multitask,
+                          label_loss_fn=losses.MultiTaskCrossEntropyLoss() if multitask else None,
+                          transformer_class=__import__("yt8m_amd.feature_transform", fromlist=["x"]).IdenticalTransformer)
+    xd, yd, td = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(teacher).to(dev)
+    tg.forward(xd, yd)
+    g.finalize()
+    P = randomise(g, rs)
+    inject(g, P, dev)
+    before = {k: v.data.clone() for k, v in g.vars.items()}
+    out = tg.step(xd, yd, distill_labels_batch=td)
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    yt, tt = T(y), T(teacher)
+    if multitask:
+        main, sup = torch_ref.deep_combine_chain(T(x), tp, 2, 2)
+
+        def L(lab, w=None):
+            s = flags.support_loss_percent
+            return (1 - s) * torch_ref.cross_entropy(main, lab, w) + s * torch_ref.cross_entropy(sup, lab.repeat(1, 2), w)
+    else:
+        pr = torch_ref.moe(T(x), tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+
+        def L(lab, w=None):
+            return torch_ref.cross_entropy(pr, lab, w)
+    if mode.startswith("type1"):
+        lr = 0.7 * L(yt) + 0.3 * L(tt)
+    elif mode == "type2":
+        lr = L(torch_ref.reform_distill_labels(yt, tt, 0.3))
+    else:
+        lr = L(yt, torch_ref.weights_by_predictions(yt, tt))
+    lr.backward()
+    assert abs(float(out["loss"]) - lr.item()) < 1e-4 * abs(lr.item())
+    # one Adam step from the same start: compare the parameter update direction through the gradient the step used
+    got = grads_of(g)
+    for k, t in tp.items():
+        if t.grad is not None:
+            ref = t.grad.numpy()
+            assert np.abs(got[k] - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max()), k
+    assert any(float((g.vars[k].data - before[k]).abs().max()) > 0 for k in before)
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64)
 

@@ -30,6 +30,13 @@ DEFINE_string("feature_names", "mean_rgb", "Name of the feature to use for train
 DEFINE_string("feature_sizes", "1024", "Length of the feature vectors.")
 # new: raw uint8 frame blocks reach models that fold the input transform into their first GEMM (NetVLAD)
 DEFINE_bool("fold_dequant", True, "Hand raw uint8 frames to models that declare accepts_quantized_input.")
+# W/train.py:53-64 distillation inputs: a second model's predictions arrive with the batch
+DEFINE_bool("distillation_features", False, "If set, *DistillationFeatureReader will be used, the feature must contains the "
+            "added distillation_predictions features.")
+DEFINE_integer("distillation_type", 0, "Type of distillation, options are 1 and 2.")
+DEFINE_bool("distillation_as_input", False, "If set true, distillation_predictions will be given to model.")
+DEFINE_bool("distillation_as_boosting", False, "If set true, distillation_predictions will be used in computation of weighted loss.")
+DEFINE_float("distillation_percent", 0.0, "If larger than 0, final_loss = distillation_loss * percent + normal_loss * (1.0 - percent).")
 DEFINE_bool("frame_features", False, "If set, then --train_data_pattern must be frame-level features.")
 
 
@@ -42,6 +49,25 @@ def find_class_by_name(name, modules):
 def exponential_decay(base_lr, global_step, batch_size, decay_examples, decay):
     """tf.train.exponential_decay(staircase=True) as called at W/train.py:303-308."""
     return base_lr * decay ** math.floor(global_step * batch_size / float(decay_examples))
+
+
+def reform_distill_labels(labels_batch, distill_labels_batch, p):
+    """W/train.py:320-327 (distillation_type == 2): labels + distill * (sum(labels) / (sum(distill) + 1e-6) * p), clipped to
+    [0, 1].  Label preparation (not differentiated)."""
+    float_labels = labels_batch.to(torch.float32)
+    sum_float_labels = float_labels.sum(dim=1, keepdim=True)
+    sum_distill_labels = distill_labels_batch.sum(dim=1, keepdim=True) + 1e-6
+    return (float_labels + distill_labels_batch * (sum_float_labels / sum_distill_labels * p)).clamp_(0.0, 1.0)
+
+
+def get_weights_by_predictions(labels_batch, predictions):
+    """W/train.py:250-260 (distillation_as_boosting): per-video weight 3.0 where the teacher's cross entropy is above the
+    batch mean, else 0.5 (epsilon 1e-6 here, unlike the loss's 1e-5)."""
+    epsilon = 1e-6
+    float_labels = labels_batch.to(torch.float32)
+    ce = -(float_labels * torch.log(predictions + epsilon) + (1 - float_labels) * torch.log(1 - predictions + epsilon)).sum(dim=1)
+    mean_ce = (ce + epsilon).mean()
+    return torch.where(ce > mean_ce, torch.full_like(ce, 3.0), torch.full_like(ce, 0.5))
 
 
 class TrainGraph(object):
@@ -76,7 +102,8 @@ class TrainGraph(object):
         return self.transformer.transform(model_input_raw, num_frames=num_frames)
 
     # ---- forward -----------------------------------------------------------------------------------
-    def forward(self, model_input_raw, labels_batch=None, num_frames=None, is_training=True, fuse_loss=True):
+    def forward(self, model_input_raw, labels_batch=None, num_frames=None, is_training=True, fuse_loss=True,
+                distillation_predictions=None):
         g = set_default_graph(self.graph)
         g.begin_step()
         model_input, num_frames = self._transform(model_input_raw, num_frames)
@@ -85,22 +112,45 @@ class TrainGraph(object):
             kw["fuse_loss"] = False
         result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=FLAGS.num_classes
                                          if labels_batch is None else labels_batch.shape[1],
-                                         labels=labels_batch, distillation_predictions=None, noise_level=None, **kw)
+                                         labels=labels_batch, distillation_predictions=distillation_predictions,
+                                         noise_level=None, **kw)
         return result
 
-    def loss(self, result, labels_batch, weights=None):
-        predictions = result["predictions"]
+    def _label_loss(self, result, labels, weights):
+        if self.multitask:                                        # W/train.py:394-413
+            return self.label_loss_fn.calculate_loss(result["predictions"], result["support_predictions"], labels, weights=weights)
+        return self.label_loss_fn.calculate_loss(result["predictions"], labels, weights=weights)
+
+    def loss(self, result, labels_batch, weights=None, distill_labels_batch=None):
+        """W/train.py:384-430: a model-provided "loss" wins; otherwise the label loss, optionally blended with / replaced by
+        the loss against the distillation labels and weighted by the boosting weights."""
         if "loss" in result:                                      # W/train.py:384-385
             return result["loss"]
-        if self.multitask:                                        # W/train.py:394-413
-            return self.label_loss_fn.calculate_loss(predictions, result["support_predictions"], labels_batch, weights=weights)
-        return self.label_loss_fn.calculate_loss(predictions, labels_batch, weights=weights)
+        if FLAGS.distillation_as_boosting and distill_labels_batch is not None:            # :391-392
+            weights = get_weights_by_predictions(labels_batch, distill_labels_batch)
+        if FLAGS.distillation_features and distill_labels_batch is not None:
+            if FLAGS.distillation_type == 1:                      # :398-407 / :415-424
+                p = FLAGS.distillation_percent
+                if p <= 0:
+                    return self._label_loss(result, labels_batch, weights)
+                if p >= 1:
+                    return self._label_loss(result, distill_labels_batch, weights)
+                return self._label_loss(result, labels_batch, weights) * (1.0 - p) + \
+                    self._label_loss(result, distill_labels_batch, weights) * p
+            if FLAGS.distillation_type == 2:                      # :408-410 / :425-427 "pure distillation loss"
+                return self._label_loss(result, distill_labels_batch, weights)
+        return self._label_loss(result, labels_batch, weights)
 
     # ---- one optimisation step -----------------------------------------------------------------------
-    def step(self, model_input_raw, labels_batch, num_frames=None, weights=None):
+    def step(self, model_input_raw, labels_batch, num_frames=None, weights=None, distill_labels_batch=None):
         g = self.graph
-        result = self.forward(model_input_raw, labels_batch, num_frames, fuse_loss=weights is None)
-        label_loss = self.loss(result, labels_batch, weights)
+        distill = distill_labels_batch if FLAGS.distillation_features else None
+        if distill is not None and FLAGS.distillation_type == 2:  # W/train.py:320-327: labels are re-formed up front
+            distill = reform_distill_labels(labels_batch, distill, FLAGS.distillation_percent)
+        # (the fused mixing + loss of MoeModel is this build's addition: it must not pre-empt weights / distillation)
+        result = self.forward(model_input_raw, labels_batch, num_frames, fuse_loss=weights is None and distill is None,
+                              distillation_predictions=distill if FLAGS.distillation_as_input else None)
+        label_loss = self.loss(result, labels_batch, weights, distill)
         if not g.finalized:
             g.finalize()
             if self.reg_penalty != 1:
