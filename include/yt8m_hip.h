@@ -116,6 +116,26 @@ int yt8m_moe_mix_xent_fwd(const float* Zg, const float* Ze, const void* labels, 
 int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev,
                           int64_t B, int64_t V, int M, float eps, float upstream, yt8m_stream_t stream);
 
+/* ---- whole-head entry points (yt8m_moe_fwd / yt8m_moe_bwd / yt8m_logistic_fwd_bwd) ---------------
+ * MoeModel.create_model (moe_model.py:12-65) + CrossEntropyLoss (losses.py:110-130) in two calls for a non-Python host:
+ *   fwd: Zg = x.Wg, Ze = x.We + be (ONE persistent grouped GEMM launch) -> p [B,V] (+ loss when labels != NULL).
+ *        Zg [B,V(M+1)] / Ze [B,VM] are caller-owned and must be handed to the backward unchanged.
+ *   bwd: Zg/Ze <- dL/dZ in place, dWg = x^T dZg, dWe = x^T dZe (one grouped launch), dbe = colsum(dZe), dx optional;
+ *        beta 0 overwrites / 1 accumulates the three gradients; upstream scales dL (e.g. 1 - support_loss_percent).
+ * x [B,D], Wg [D,V(M+1)], We [D,VM], be [VM] row-major fp32; labels uint8 / float32 [B,V]; loss_out device float[1].
+ * workspace >= yt8m_moe_workspace_bytes(B, V).  LogisticModel (logistic_model.py:12-26): p = sigmoid(x W + b), same
+ * loss; Z [B,V] is scratch (dL/dz); labels == NULL -> forward only; workspace >= yt8m_moe_workspace_bytes(B, V). */
+int64_t yt8m_moe_workspace_bytes(int64_t B, int64_t V);
+int yt8m_moe_fwd(const float* x, const float* Wg, const float* We, const float* be, const void* labels, int label_dtype,
+                 int64_t B, int64_t D, int64_t V, int M, float eps, float* Zg, float* Ze, float* p, float* loss_out,
+                 void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_moe_bwd(const float* x, const float* Wg, const float* We, float* Zg, float* Ze, const void* labels, int label_dtype,
+                 int64_t B, int64_t D, int64_t V, int M, float eps, float upstream, float* dWg, float* dWe, float* dbe,
+                 float beta, float* dx, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_logistic_fwd_bwd(const float* x, const float* W, const float* b, const void* labels, int label_dtype, int64_t B,
+                          int64_t D, int64_t V, float eps, float* p, float* loss_out, float* Z, float* dW, float* db,
+                          float beta, float* dx, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+
 /* ---- elementwise activations + column sums (bias gradients) ------------------------------------ */
 enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8M_ACT_TANH = 3, YT8M_ACT_ELU = 4 };
 int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream);

@@ -399,6 +399,69 @@ def test_netvlad_fused_rejects_unsupported(dev):
         seq_ops.netvlad_fwd_u8(q, None, torch.zeros((100, 64), device=dev), torch.zeros(64, device=dev))
 
 
+def test_whole_head_entry_points(dev):
+    """yt8m_moe_fwd / yt8m_moe_bwd / yt8m_logistic_fwd_bwd: the complete MoeModel / LogisticModel head +
+    CrossEntropyLoss in two (one) C calls, against fp64 autograd of the oracle; beta accumulation; inference form."""
+    import ctypes
+    from oracle import torch_ref
+    lib = L.lib()
+    rs = np.random.RandomState(44)
+    B, Dm, V, M = 37, 70, 131, 2
+    x = rs.randn(B, Dm).astype(np.float32)
+    Wg = (rs.randn(Dm, V * (M + 1)) * 0.3).astype(np.float32)
+    We = (rs.randn(Dm, V * M) * 0.3).astype(np.float32)
+    be = (rs.randn(V * M) * 0.3).astype(np.float32)
+    y = (rs.rand(B, V) < 0.05).astype(np.uint8)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    xd, Wgd, Wed, bed, yd = D(x, dev), D(Wg, dev), D(We, dev), D(be, dev), torch.from_numpy(y).to(dev)
+    Zg = torch.empty((B, V * (M + 1)), device=dev)
+    Ze = torch.empty((B, V * M), device=dev)
+    p = torch.empty((B, V), device=dev)
+    loss = torch.zeros((), device=dev)
+    ws = torch.empty(lib.yt8m_moe_workspace_bytes(B, V), dtype=torch.uint8, device=dev)
+    L.check(lib.yt8m_moe_fwd(P(xd), P(Wgd), P(Wed), P(bed), P(yd), 0, B, Dm, V, M, 1e-5, P(Zg), P(Ze), P(p), P(loss), P(ws),
+                             ws.numel(), st))
+    t = {k: torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for k, v in dict(x=x, Wg=Wg, We=We, be=be).items()}
+    pr = torch_ref.moe(t["x"], t["Wg"], t["We"], t["be"], M)
+    lr = torch_ref.cross_entropy(pr, torch.from_numpy(y.astype(np.float64)))
+    (0.9 * lr).backward()
+    assert np.abs(H(p) - pr.detach().numpy()).max() < 1e-5
+    assert abs(float(loss) - lr.item()) < 1e-5 * abs(lr.item())
+    dWg, dWe, dbe = torch.full_like(Wgd, 3.0), torch.full_like(Wed, 3.0), torch.full_like(bed, 3.0)
+    dx = torch.empty_like(xd)
+    L.check(lib.yt8m_moe_bwd(P(xd), P(Wgd), P(Wed), P(Zg), P(Ze), P(yd), 0, B, Dm, V, M, 1e-5, 0.9, P(dWg), P(dWe), P(dbe), 1.0,
+                             P(dx), P(ws), ws.numel(), st))
+    for got, ref, off in ((dWg, t["Wg"].grad, 3.0), (dWe, t["We"].grad, 3.0), (dbe, t["be"].grad, 3.0), (dx, t["x"].grad, 0.0)):
+        r = ref.numpy()
+        assert np.abs(H(got) - off - r).max() <= 2e-4 * max(1.0, np.abs(r).max())
+    # inference form: no labels, no loss
+    p2 = torch.empty_like(p)
+    L.check(lib.yt8m_moe_fwd(P(xd), P(Wgd), P(Wed), P(bed), None, 0, B, Dm, V, M, 1e-5, P(Zg), P(Ze), P(p2), None, P(ws),
+                             ws.numel(), st))
+    assert torch.equal(p, p2)
+    assert lib.yt8m_moe_fwd(P(xd), P(Wgd), P(Wed), P(bed), P(yd), 0, B, Dm, V, M, 1e-5, P(Zg), P(Ze), P(p2), None, P(ws),
+                            ws.numel(), st) == -1                                      # labels without loss_out
+    assert lib.yt8m_moe_fwd(P(xd), P(Wgd), P(Wed), P(bed), None, 0, B, Dm, V, M, 1e-5, P(Zg), P(Ze), P(p2), None, P(ws), 16,
+                            st) == -1                                                  # workspace too small
+    # LogisticModel
+    W = (rs.randn(Dm, V) * 0.3).astype(np.float32)
+    b = (rs.randn(V) * 0.3).astype(np.float32)
+    Wd, bd = D(W, dev), D(b, dev)
+    Z = torch.empty((B, V), device=dev)
+    dW, db = torch.empty_like(Wd), torch.empty_like(bd)
+    L.check(lib.yt8m_logistic_fwd_bwd(P(xd), P(Wd), P(bd), P(yd), 0, B, Dm, V, 1e-5, P(p), P(loss), P(Z), P(dW), P(db), 0.0,
+                                      P(dx), P(ws), ws.numel(), st))
+    tl = {k: torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for k, v in dict(x=x, W=W, b=b).items()}
+    pl = torch_ref.logistic(tl["x"], tl["W"], tl["b"])
+    ll = torch_ref.cross_entropy(pl, torch.from_numpy(y.astype(np.float64)))
+    ll.backward()
+    assert np.abs(H(p) - pl.detach().numpy()).max() < 1e-5 and abs(float(loss) - ll.item()) < 1e-5 * abs(ll.item())
+    for got, ref in ((dW, tl["W"].grad), (db, tl["b"].grad), (dx, tl["x"].grad)):
+        r = ref.numpy()
+        assert np.abs(H(got) - r).max() <= 2e-4 * max(1.0, np.abs(r).max())
+
+
 def test_sqnorm_and_adam_multi(dev):
     """Per-tensor clip on (g*gscale + l2 w) + TF-Adam over the arena vs the oracle, incl. ragged tensor sizes that
     exercise chunk tails, and bitwise reproducibility of the reduction."""

@@ -36,6 +36,12 @@ SIGNATURES = {
     "yt8m_l2norm_bwd_f32": (c_int, [P, P, P, c_int64, c_int64, c_float, P]),
     "yt8m_dequant_l2norm_u8": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_dequant_mean_l2norm_u8": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_moe_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "yt8m_moe_fwd": (c_int, [P, P, P, P, P, c_int, c_int64, c_int64, c_int64, c_int, c_float, P, P, P, P, P, c_int64, P]),
+    "yt8m_moe_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int64, c_int64, c_int64, c_int, c_float, c_float, P, P, P, c_float, P, P,
+                             c_int64, P]),
+    "yt8m_logistic_fwd_bwd": (c_int, [P, P, P, P, c_int, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, c_float, P, P,
+                                      c_int64, P]),
     "yt8m_moe_mix_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int, P]),
     "yt8m_moe_mix_bwd": (c_int, [P, P, P, c_int64, c_int64, c_int, P]),
     "yt8m_moe_mix_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),

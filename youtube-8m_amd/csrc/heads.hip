@@ -1,0 +1,93 @@
+// heads.hip -- whole-head entry points over the kernels of this library, the shape SURVEY.md section 8b proposes for the C ABI
+// (yt8m_moe_fwd / yt8m_moe_bwd / yt8m_logistic_fwd_bwd): a non-Python host drives a full classifier head with two calls.
+//   MoeModel.create_model       W/all_video_models/moe_model.py:12-65   (+ CrossEntropyLoss W/losses.py:110-130)
+//   LogisticModel.create_model  W/all_video_models/logistic_model.py:12-26
+// They only sequence existing launches (persistent grouped GEMM, fused mixing + loss, column sums) on the caller's stream.
+#include "common.h"
+
+using namespace yt8m;
+
+// scratch: [ mix+xent partial sums ][ GEMM split-K workspace ]
+extern "C" int64_t yt8m_moe_workspace_bytes(int64_t B, int64_t V) {
+  return ((yt8m_moe_mix_xent_workspace_bytes(B, V) + 255) / 256) * 256 + yt8m_gemm_workspace_bytes();
+}
+
+// Zg [B, V(M+1)], Ze [B, VM]: logits out (kept by the caller for yt8m_moe_bwd).  labels NULL: p only (inference).
+extern "C" int yt8m_moe_fwd(const float* x, const float* Wg, const float* We, const float* be, const void* labels,
+                            int label_dtype, int64_t B, int64_t D, int64_t V, int M, float eps, float* Zg, float* Ze, float* p,
+                            float* loss_out, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && D >= 0 && V >= 0 && M >= 1, YT8M_E_SHAPE, "bad shape");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(x && Wg && We && be && Zg && Ze && p && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(!labels || loss_out, YT8M_E_BADARG, "labels given but loss_out is NULL");
+  YT8M_REQUIRE(workspace_bytes >= yt8m_moe_workspace_bytes(B, V), YT8M_E_BADARG, "workspace too small");
+  const int64_t Ng = V * (M + 1), Ne = V * M;
+  const int64_t off = ((yt8m_moe_mix_xent_workspace_bytes(B, V) + 255) / 256) * 256;
+  char* ws = static_cast<char*>(workspace);
+  yt8m_gemm_problem pr[2] = {{B, Ng, D, x, D, Wg, Ng, Zg, Ng, nullptr, 0.0f}, {B, Ne, D, x, D, We, Ne, Ze, Ne, be, 0.0f}};
+  int rc = yt8m_gemm_f32_grouped(0, 0, 2, pr, ws + off, workspace_bytes - off, stream);
+  if (rc != YT8M_OK) return rc;
+  if (labels) return yt8m_moe_mix_xent_fwd(Zg, Ze, labels, label_dtype, p, loss_out, B, V, M, eps, ws, stream);
+  return yt8m_moe_mix_fwd(Zg, Ze, p, B, V, M, stream);
+}
+
+// Zg / Ze hold the forward logits on entry and dL/dZ on exit.  dWg, dWe, dbe: beta 0 (overwrite) or 1 (accumulate).
+// dx [B,D] may be NULL (the head sits on input data).  upstream scales the loss gradient (e.g. 1 - support_loss_percent).
+extern "C" int yt8m_moe_bwd(const float* x, const float* Wg, const float* We, float* Zg, float* Ze, const void* labels,
+                            int label_dtype, int64_t B, int64_t D, int64_t V, int M, float eps, float upstream, float* dWg,
+                            float* dWe, float* dbe, float beta, float* dx, void* workspace, int64_t workspace_bytes,
+                            yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && D >= 0 && V >= 0 && M >= 1, YT8M_E_SHAPE, "bad shape");
+  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(x && Wg && We && Zg && Ze && labels && dWg && dWe && dbe && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(workspace_bytes >= yt8m_moe_workspace_bytes(B, V), YT8M_E_BADARG, "workspace too small");
+  const int64_t Ng = V * (M + 1), Ne = V * M;
+  const int64_t off = ((yt8m_moe_mix_xent_workspace_bytes(B, V) + 255) / 256) * 256;
+  char* ws = static_cast<char*>(workspace);
+  int rc = yt8m_moe_mix_xent_bwd(Zg, Ze, labels, label_dtype, nullptr, B, V, M, eps, upstream, stream);
+  if (rc != YT8M_OK) return rc;
+  if (dx) {                                               // dx = dZg Wg^T + dZe We^T
+    yt8m_gemm_problem px = {B, D, Ng, Zg, Ng, Wg, Ng, dx, D, nullptr, 0.0f};
+    rc = yt8m_gemm_f32_grouped(0, 1, 1, &px, ws + off, workspace_bytes - off, stream);
+    if (rc != YT8M_OK) return rc;
+    yt8m_gemm_problem py = {B, D, Ne, Ze, Ne, We, Ne, dx, D, nullptr, 1.0f};
+    rc = yt8m_gemm_f32_grouped(0, 1, 1, &py, ws + off, workspace_bytes - off, stream);
+    if (rc != YT8M_OK) return rc;
+  }
+  yt8m_gemm_problem pw[2] = {{D, Ng, B, x, D, Zg, Ng, dWg, Ng, nullptr, beta}, {D, Ne, B, x, D, Ze, Ne, dWe, Ne, nullptr, beta}};
+  rc = yt8m_gemm_f32_grouped(1, 0, 2, pw, ws + off, workspace_bytes - off, stream);
+  if (rc != YT8M_OK) return rc;
+  return yt8m_colsum_f32(Ze, B, Ne, Ne, dbe, beta, ws, off, stream);
+}
+
+// p = sigmoid(x W + b), loss = CrossEntropyLoss(p, labels), dW / db (beta 0/1), dx optional.  Z [B,V] scratch (holds dL/dz).
+extern "C" int yt8m_logistic_fwd_bwd(const float* x, const float* W, const float* b, const void* labels, int label_dtype,
+                                     int64_t B, int64_t D, int64_t V, float eps, float* p, float* loss_out, float* Z, float* dW,
+                                     float* db, float beta, float* dx, void* workspace, int64_t workspace_bytes,
+                                     yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && D >= 0 && V >= 0, YT8M_E_SHAPE, "bad shape");
+  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(x && W && b && p && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(!labels || (loss_out && Z && dW && db), YT8M_E_BADARG, "training call needs loss_out, Z, dW, db");
+  const int64_t off = ((yt8m_xent_workspace_bytes(B, V) + 255) / 256) * 256;
+  YT8M_REQUIRE(workspace_bytes >= off + yt8m_gemm_workspace_bytes(), YT8M_E_BADARG, "workspace too small");
+  char* ws = static_cast<char*>(workspace);
+  yt8m_gemm_problem pf = {B, V, D, x, D, W, V, p, V, b, 0.0f};
+  int rc = yt8m_gemm_f32_grouped(0, 0, 1, &pf, ws + off, workspace_bytes - off, stream);
+  if (rc != YT8M_OK) return rc;
+  rc = yt8m_act_fwd_f32(YT8M_ACT_SIGMOID, p, p, B * V, stream);
+  if (rc != YT8M_OK || !labels) return rc;
+  rc = yt8m_xent_fwd_bwd(p, labels, label_dtype, nullptr, loss_out, Z, B, V, eps, 1.0f, ws, stream);      // Z <- dL/dp
+  if (rc != YT8M_OK) return rc;
+  rc = yt8m_act_bwd_f32(YT8M_ACT_SIGMOID, p, Z, Z, B * V, stream);                                         // Z <- dL/dz
+  if (rc != YT8M_OK) return rc;
+  yt8m_gemm_problem pw = {D, V, B, x, D, Z, V, dW, V, nullptr, beta};
+  rc = yt8m_gemm_f32_grouped(1, 0, 1, &pw, ws + off, workspace_bytes - off, stream);
+  if (rc != YT8M_OK) return rc;
+  rc = yt8m_colsum_f32(Z, B, V, V, db, beta, ws, off, stream);
+  if (rc != YT8M_OK || !dx) return rc;
+  yt8m_gemm_problem px = {B, D, V, Z, V, W, V, dx, D, nullptr, 0.0f};
+  return yt8m_gemm_f32_grouped(0, 1, 1, &px, ws + off, workspace_bytes - off, stream);
+}
