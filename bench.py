@@ -184,7 +184,7 @@ def main():
         # separate FETCH_SIZE / WRITE_SIZE passes, calibrated on the copy probe); rocprofv3 cannot run inside bench.py.
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_f32_grouped_kernel")]
+            ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_grouped_kernel")]
             if ks and B == 1024 and not bf16:
                 roof["traffic"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / len(ks)
                 roof["traffic_unit"] = "bytes/launch (L2-miss side, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.md)"
