@@ -311,6 +311,19 @@ int yt8m_tfrecord_read_video_batch(void* reader, const char* const* feature_name
                                    int64_t num_classes, int64_t max_records, float* x, uint8_t* labels, char* video_ids,
                                    int64_t id_stride, int64_t* n_read);
 
+/* multi-threaded shard prefetcher (the reference's num_readers queue-runner threads + batch_join, W/train.py:199-209):
+ * nthreads workers decode whole batches of `batch` records (short at shard ends, never spanning shards) into slots of pinned
+ * host memory; acquire() lends the next ready batch (pointers valid until the next acquire / close; *n == 0: all shards
+ * done).  One thread reproduces the sequential reader's batch sequence; more threads deliver every record exactly once in a
+ * scheduling-dependent batch order (the reference shuffles).  frame_level: q uint8 [n,max_frames,D] + num_frames; else x
+ * float [n,D].  A decode error in any worker surfaces from acquire() with that worker's message. */
+int yt8m_prefetch_open(const char* const* paths, int npaths, int frame_level, const char* const* feature_names,
+                       const int32_t* feature_sizes, int nfeat, int64_t max_frames, int64_t num_classes, int64_t batch,
+                       int nthreads, int queue_depth, int check_crc, void** prefetcher_out);
+int yt8m_prefetch_acquire(void* prefetcher, void** q_or_x, int32_t** num_frames, uint8_t** labels, char** video_ids,
+                          int64_t* id_stride, int64_t* n, int* pinned);
+int yt8m_prefetch_close(void* prefetcher);
+
 /* prediction dump for the ensemble stage (W/inference-pre-ensemble.py:291-308): one tf.train.Example per video with
  * {"video_id", "labels" = nonzero(labels row), feature_name = predictions row (float list)}, TFRecord framed.  HOST buffers:
  * video_ids [n, id_stride] NUL-padded, labels [n, num_classes] uint8 multi-hot, predictions [n, num_classes] float32. */

@@ -723,3 +723,10 @@ def test_tfrecord_to_training_step(dev, flags, tmp_path):
         assert torch.isfinite(out["loss"]) and out["predictions"].shape == (6, 50)
         n += len(ids)
     assert n == 6
+    # the multi-threaded prefetcher (pinned slots lent zero-copy, async H2D) delivers the same bytes
+    got = list(rd.prepare_reader([p], batch_size=4, device=dev, num_threads=2))
+    eq, enf, elab = tr.expected_frame_batch(vids, names, sizes, 10, 50)
+    assert [len(b[0]) for b in got] == [4, 2]
+    assert np.array_equal(torch.cat([b[1] for b in got]).cpu().numpy(), eq)
+    assert np.array_equal(torch.cat([b[3] for b in got]).cpu().numpy(), enf)
+    assert np.array_equal(torch.cat([b[2] for b in got]).cpu().numpy(), elab.astype(bool))

@@ -80,6 +80,13 @@ SIGNATURES = {
     "yt8m_vlad_finish_bwd": (c_int, [P, P, P, P, P, P, P, c_float, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_crc32c": (ctypes.c_uint32, [P, c_int64]),
     "yt8m_crc32c_masked": (ctypes.c_uint32, [P, c_int64]),
+    "yt8m_prefetch_open": (c_int, [ctypes.POINTER(ctypes.c_char_p), c_int, c_int, ctypes.POINTER(ctypes.c_char_p),
+                                   ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                   ctypes.POINTER(c_void_p)]),
+    "yt8m_prefetch_acquire": (c_int, [P, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                      ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
+                                      ctypes.POINTER(c_int)]),
+    "yt8m_prefetch_close": (c_int, [P]),
     "yt8m_tfrecord_write_predictions": (c_int, [ctypes.c_char_p, c_int64, P, c_int64, P, P, c_int64, ctypes.c_char_p]),
     "yt8m_tfrecord_open": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_void_p)]),
     "yt8m_tfrecord_close": (c_int, [P]),

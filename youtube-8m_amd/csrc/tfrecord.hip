@@ -411,3 +411,200 @@ extern "C" int yt8m_tfrecord_write_predictions(const char* path, int64_t n, cons
   if (fclose(fh) != 0 && rc == YT8M_OK) rc = yt8m::fail(YT8M_E_BADARG, "yt8m_tfrecord_write_predictions: close failed for %s", path);
   return rc;
 }
+
+// ---- multi-threaded shard prefetcher (the role of the reference's num_readers queue-runner threads + batch_join,
+// W/train.py:199-209 / W/readers.py prepare_reader) ---------------------------------------------------------------------------
+// nthreads workers pull shard indices from a shared counter, decode whole batches straight into slots of PINNED host memory
+// (hipHostMalloc; plain malloc when no HIP device is present) and hand them to the consumer through a bounded ready queue.
+// A batch never spans two shards (like the reference's read_up_to: short batches at shard ends).  With one thread the batch
+// sequence equals the sequential reader's; with more, the order of batches across shards is scheduling-dependent (the
+// reference shuffles anyway) but every record is delivered exactly once.
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct Slot {
+  uint8_t* q = nullptr;      // frame level: [batch, max_frames, D] uint8
+  float* x = nullptr;        // video level: [batch, D] float
+  int32_t* nf = nullptr;     // [batch]
+  uint8_t* labels = nullptr; // [batch, num_classes]
+  char* ids = nullptr;       // [batch, id_stride]
+  int64_t n = 0;
+};
+
+struct Prefetcher {
+  std::vector<std::string> paths;
+  std::vector<std::string> names;
+  std::vector<const char*> cnames;
+  std::vector<int32_t> sizes;
+  bool frame_level = true, check_crc = true, pinned = false;
+  int64_t max_frames = 0, num_classes = 0, batch = 0, id_stride = 32, D = 0;
+  std::vector<Slot> slots;
+  std::deque<int> free_slots, ready;
+  std::mutex mu;
+  std::condition_variable cv_free, cv_ready;
+  std::atomic<size_t> next_shard{0};
+  int active_workers = 0;
+  bool stop = false;
+  int error = 0;
+  std::string error_msg;
+  int held = -1;              // slot currently lent to the consumer
+  std::vector<std::thread> threads;
+};
+
+void* host_alloc(size_t bytes, bool* pinned) {
+  void* p = nullptr;
+  if (*pinned && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) return p;
+  (void)hipGetLastError();
+  *pinned = false;
+  return malloc(bytes);
+}
+
+void prefetch_worker(Prefetcher* P) {
+  for (;;) {
+    const size_t si = P->next_shard.fetch_add(1);
+    if (si >= P->paths.size()) break;
+    void* rd = nullptr;
+    int rc = yt8m_tfrecord_open(P->paths[si].c_str(), P->check_crc ? 1 : 0, &rd);
+    while (rc == YT8M_OK) {
+      int s;
+      {
+        std::unique_lock<std::mutex> lk(P->mu);
+        P->cv_free.wait(lk, [&] { return P->stop || !P->free_slots.empty(); });
+        if (P->stop) break;
+        s = P->free_slots.front();
+        P->free_slots.pop_front();
+      }
+      Slot& sl = P->slots[s];
+      int64_t n = 0;
+      if (P->frame_level)
+        rc = yt8m_tfrecord_read_frame_batch(rd, P->cnames.data(), P->sizes.data(), (int)P->sizes.size(), P->max_frames,
+                                            P->num_classes, P->batch, sl.q, sl.nf, sl.labels, sl.ids, P->id_stride, &n);
+      else
+        rc = yt8m_tfrecord_read_video_batch(rd, P->cnames.data(), P->sizes.data(), (int)P->sizes.size(), P->num_classes, P->batch,
+                                            sl.x, sl.labels, sl.ids, P->id_stride, &n);
+      std::unique_lock<std::mutex> lk(P->mu);
+      if (rc != YT8M_OK || n == 0) {                        // error or end of shard: the slot goes back unused
+        P->free_slots.push_back(s);
+        P->cv_free.notify_one();
+        break;
+      }
+      sl.n = n;
+      P->ready.push_back(s);
+      P->cv_ready.notify_one();
+      if (n < P->batch) break;                              // short batch = end of this shard
+    }
+    if (rd) yt8m_tfrecord_close(rd);
+    if (rc != YT8M_OK) {
+      std::unique_lock<std::mutex> lk(P->mu);
+      if (!P->error) {
+        P->error = rc;
+        P->error_msg = yt8m_last_error();                   // thread-local message of THIS worker
+      }
+      P->stop = true;
+      P->cv_free.notify_all();
+      P->cv_ready.notify_all();
+      break;
+    }
+    {
+      std::unique_lock<std::mutex> lk(P->mu);
+      if (P->stop) break;
+    }
+  }
+  std::unique_lock<std::mutex> lk(P->mu);
+  P->active_workers--;
+  P->cv_ready.notify_all();
+}
+
+}  // namespace
+
+extern "C" int yt8m_prefetch_open(const char* const* paths, int npaths, int frame_level, const char* const* feature_names,
+                                  const int32_t* feature_sizes, int nfeat, int64_t max_frames, int64_t num_classes,
+                                  int64_t batch, int nthreads, int queue_depth, int check_crc, void** out) {
+  using namespace yt8m;
+  YT8M_REQUIRE(paths && feature_names && feature_sizes && out, YT8M_E_BADARG, "null argument");
+  YT8M_REQUIRE(npaths >= 1 && nfeat >= 1 && num_classes >= 1 && batch >= 1 && nthreads >= 1 && queue_depth >= 1 &&
+                   (!frame_level || max_frames >= 1), YT8M_E_SHAPE, "bad sizes");
+  Prefetcher* P = new Prefetcher();
+  for (int i = 0; i < npaths; ++i) P->paths.push_back(paths[i]);
+  for (int i = 0; i < nfeat; ++i) { P->names.push_back(feature_names[i]); P->sizes.push_back(feature_sizes[i]); P->D += feature_sizes[i]; }
+  for (auto& s : P->names) P->cnames.push_back(s.c_str());
+  P->frame_level = frame_level != 0;
+  P->check_crc = check_crc != 0;
+  P->max_frames = max_frames; P->num_classes = num_classes; P->batch = batch;
+  nthreads = std::min(nthreads, npaths);
+  const int nslots = queue_depth + nthreads + 1;            // ready queue + one in flight per worker + the one lent out
+  P->pinned = true;
+  P->slots.resize(nslots);
+  for (int s = 0; s < nslots; ++s) {
+    Slot& sl = P->slots[s];
+    if (P->frame_level) {
+      sl.q = static_cast<uint8_t*>(host_alloc((size_t)(batch * max_frames * P->D), &P->pinned));
+      sl.nf = static_cast<int32_t*>(host_alloc((size_t)batch * 4, &P->pinned));
+    } else {
+      sl.x = static_cast<float*>(host_alloc((size_t)(batch * P->D) * 4, &P->pinned));
+    }
+    sl.labels = static_cast<uint8_t*>(host_alloc((size_t)(batch * num_classes), &P->pinned));
+    sl.ids = static_cast<char*>(host_alloc((size_t)(batch * P->id_stride), &P->pinned));
+    P->free_slots.push_back(s);
+  }
+  P->active_workers = nthreads;
+  for (int t = 0; t < nthreads; ++t) P->threads.emplace_back(prefetch_worker, P);
+  *out = P;
+  return YT8M_OK;
+}
+
+// Lends the next ready batch (host pointers valid until the next acquire / close).  *n = 0: every shard is exhausted.
+extern "C" int yt8m_prefetch_acquire(void* handle, void** q_or_x, int32_t** num_frames, uint8_t** labels, char** video_ids,
+                                     int64_t* id_stride, int64_t* n, int* pinned) {
+  using namespace yt8m;
+  YT8M_REQUIRE(handle && q_or_x && labels && n, YT8M_E_BADARG, "null argument");
+  Prefetcher* P = static_cast<Prefetcher*>(handle);
+  std::unique_lock<std::mutex> lk(P->mu);
+  if (P->held >= 0) {                                       // give the previous batch's slot back to the workers
+    P->free_slots.push_back(P->held);
+    P->held = -1;
+    P->cv_free.notify_one();
+  }
+  P->cv_ready.wait(lk, [&] { return !P->ready.empty() || P->active_workers == 0 || P->error; });
+  if (P->error) return fail(P->error, "prefetch: %s", P->error_msg.c_str());
+  if (P->ready.empty()) { *n = 0; return YT8M_OK; }
+  const int s = P->ready.front();
+  P->ready.pop_front();
+  P->held = s;
+  Slot& sl = P->slots[s];
+  *q_or_x = P->frame_level ? static_cast<void*>(sl.q) : static_cast<void*>(sl.x);
+  if (num_frames) *num_frames = sl.nf;
+  *labels = sl.labels;
+  if (video_ids) *video_ids = sl.ids;
+  if (id_stride) *id_stride = P->id_stride;
+  if (pinned) *pinned = P->pinned ? 1 : 0;
+  *n = sl.n;
+  return YT8M_OK;
+}
+
+extern "C" int yt8m_prefetch_close(void* handle) {
+  Prefetcher* P = static_cast<Prefetcher*>(handle);
+  if (!P) return YT8M_OK;
+  {
+    std::unique_lock<std::mutex> lk(P->mu);
+    P->stop = true;
+    P->cv_free.notify_all();
+    P->cv_ready.notify_all();
+  }
+  for (auto& t : P->threads) t.join();
+  for (auto& sl : P->slots) {
+    void* ptrs[5] = {sl.q, sl.x, sl.nf, sl.labels, sl.ids};
+    for (void* p : ptrs) {
+      if (!p) continue;
+      if (P->pinned) (void)hipHostFree(p);
+      else free(p);
+    }
+  }
+  delete P;
+  return YT8M_OK;
+}

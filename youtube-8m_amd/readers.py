@@ -54,6 +54,62 @@ class _Open(object):
             self.h = None
 
 
+def _view(ptr, shape, dtype):
+    """Zero-copy torch view of a host buffer lent by the native prefetcher (valid until the next acquire)."""
+    import numpy
+    n = 1
+    for d in shape:
+        n *= d
+    if n == 0:
+        return torch.empty(shape, dtype=dtype)
+    ct = {torch.uint8: ctypes.c_uint8, torch.int32: ctypes.c_int32, torch.float32: ctypes.c_float}[dtype]
+    arr = numpy.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(n,))
+    return torch.from_numpy(arr).view(*shape)
+
+
+def _prefetched(reader, filenames, batch_size, device, check_crc, num_threads, queue_depth, frame_level):
+    """Batches from the native multi-threaded shard prefetcher (yt8m_prefetch_*): the reference's num_readers reader threads
+    (W/train.py:199-209).  Same tuples as the sequential path; batches never span shards."""
+    files = _files(filenames)
+    names, sizes = _c_names(reader.feature_names, reader.feature_sizes)
+    paths = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
+    D = sum(reader.feature_sizes)
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    _lib.check(L.yt8m_prefetch_open(paths, len(files), int(frame_level), names, sizes, len(reader.feature_names),
+                                    getattr(reader, "max_frames", 1), reader.num_classes, batch_size, int(num_threads),
+                                    int(queue_depth), int(check_crc), ctypes.byref(h)))
+    try:
+        data, nfp, labp, idp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        stride, n, pinned = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+        while True:
+            _lib.check(L.yt8m_prefetch_acquire(h, ctypes.byref(data), ctypes.byref(nfp), ctypes.byref(labp), ctypes.byref(idp),
+                                               ctypes.byref(stride), ctypes.byref(n), ctypes.byref(pinned)))
+            k = n.value
+            if k == 0:
+                break
+            ids = _view(idp.value, (k, stride.value), torch.uint8)
+            raw = ids.numpy().tobytes()
+            vids = [raw[i * stride.value:(i + 1) * stride.value].split(b"\0", 1)[0] for i in range(k)]
+            lab = _view(labp.value, (k, reader.num_classes), torch.uint8)
+            if frame_level:
+                feat = _view(data.value, (k, reader.max_frames, D), torch.uint8)
+                extra = _view(nfp.value, (k,), torch.int32)
+            else:
+                feat = _view(data.value, (k, D), torch.float32)
+                extra = None
+            if device is not None:                       # the slot is lent: the copies must finish before the next acquire
+                feat, lab = feat.to(device, non_blocking=True), lab.to(device, non_blocking=True).bool()
+                extra = extra.to(device, non_blocking=True) if extra is not None else torch.ones(k, device=device)
+                torch.cuda.current_stream().synchronize()
+            else:
+                feat, lab = feat.clone(), lab.bool()
+                extra = extra.clone() if extra is not None else torch.ones(k)
+            yield vids, feat, lab, extra
+    finally:
+        L.yt8m_prefetch_close(h)
+
+
 class YT8MAggregatedFeatureReader(BaseReader):
     """Video-level Examples: sparse int64 'labels', 'video_id', fixed-length float features (W/readers.py:66-125)."""
 
@@ -64,10 +120,14 @@ class YT8MAggregatedFeatureReader(BaseReader):
         self.feature_sizes = list(feature_sizes)
         self.feature_names = list(feature_names)
 
-    def prepare_reader(self, filenames, batch_size=1024, device=None, check_crc=True):
+    def prepare_reader(self, filenames, batch_size=1024, device=None, check_crc=True, num_threads=0, queue_depth=4):
         """Yields (video_ids, features float32 [n, D], labels bool [n, num_classes], ones [n]) with n <= batch_size
-        (the last batch of a file may be smaller: read_up_to semantics, W/readers.py:104)."""
+        (the last batch of a file may be smaller: read_up_to semantics, W/readers.py:104).  num_threads > 0: the native
+        multi-threaded shard prefetcher (--num_readers) instead of the sequential loop."""
         assert len(self.feature_names) > 0, "self.feature_names is empty!"
+        if num_threads > 0:
+            yield from _prefetched(self, filenames, batch_size, device, check_crc, num_threads, queue_depth, False)
+            return
         names, sizes = _c_names(self.feature_names, self.feature_sizes)
         D = sum(self.feature_sizes)
         pin = torch.cuda.is_available()
@@ -112,9 +172,13 @@ class YT8MFrameFeatureReader(BaseReader):
         self.feature_names = list(feature_names)
         self.max_frames = max_frames
 
-    def prepare_reader(self, filenames, batch_size=128, device=None, check_crc=True):
-        """Yields (video_ids, q uint8 [n, max_frames, D], labels bool [n, num_classes], num_frames int32 [n])."""
+    def prepare_reader(self, filenames, batch_size=128, device=None, check_crc=True, num_threads=0, queue_depth=4):
+        """Yields (video_ids, q uint8 [n, max_frames, D], labels bool [n, num_classes], num_frames int32 [n]).
+        num_threads > 0: the native multi-threaded shard prefetcher (--num_readers)."""
         assert len(self.feature_names) > 0, "No feature selected: feature_names is empty!"
+        if num_threads > 0:
+            yield from _prefetched(self, filenames, batch_size, device, check_crc, num_threads, queue_depth, True)
+            return
         names, sizes = _c_names(self.feature_names, self.feature_sizes)
         D = sum(self.feature_sizes)
         pin = torch.cuda.is_available()
