@@ -298,11 +298,24 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef YT8M_GEMM_TIMING
+  const uint64_t tm0 = __builtin_amdgcn_s_memtime();
+#endif
   // 16-byte aligned operands take the LDS-DMA path (edge tiles and the K tail included: see fill_dma / fill_step)
   const bool dma = g.vecA && g.vecB;
   if (dma) mainloop<A_KC, B_KC, true, BF16>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
   else mainloop<A_KC, B_KC, false, BF16>(g, Ap, Bp, As, Bs, m0, n0, kb, ke, tid, wm, wn, li, lk, acc);
 
+#ifdef YT8M_GEMM_TIMING   // (timing experiments only) cycles of the main loop / epilogue overwrite C[m0, n0..n0+1]
+  const uint64_t tm1 = __builtin_amdgcn_s_memtime();
+  struct TimingGuard {
+    uint64_t a, b; float* c; int t;
+    __device__ ~TimingGuard() {
+      __syncthreads();
+      if (t == 0 && c) { const uint64_t e = __builtin_amdgcn_s_memtime(); c[0] = (float)(b - a); c[1] = (float)(e - b); }
+    }
+  } tguard{tm0, tm1, ws ? nullptr : Cp + (int64_t)m0 * g.ldc + n0, tid};
+#endif
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if (ws) {
 #pragma unroll
@@ -314,6 +327,10 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
           ws[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + wn + j * 32 + li] = acc[i][j][r];
     return;
   }
+  // Output path: one dword store per accumulator register (64 per wave and tile).  A float4 path staged through LDS was
+  // measured (tools/gemm_timing.py): it cuts the per-tile epilogue from 74k to 29k cycles, but the epilogue of one workgroup
+  // already hides under the main loops of the two others on the CU, while its LDS traffic slows those loops by ~2 %
+  // (cfg[1] dW shape +7 %, forward +0 %, K >= 4096 shapes -3..5 %) -- not kept.
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn + j * 32 + li;
