@@ -14,7 +14,9 @@ Pinning status
   or run here (no python2, no TF wheel, no network) and the reference ships no tests or golden
   vectors.  The arithmetic is restated from the cited reference lines plus TF-1.0 documented
   semantics; the two restatements (numpy fp64, torch autograd) are written
-  independently and must agree with each other.
+  independently and must agree with each other.  ``tests/test_oracle_thirdparty.py`` additionally checks them against
+  PyTorch's own implementations of the same published algorithms (torch.nn.LSTM on packed sequences, torch.optim.Adam as
+  eps -> 0, torch.nn.functional): that pins "standard algorithm", it does NOT pin TensorFlow's behaviour.
 * NetVLAD is not in the reference at all; its oracle is this
   package's own definition.
 """
