@@ -76,6 +76,26 @@ def _worker(rank, world, port, overlap, q):
         assert torch.allclose(gl, grads(x, y), atol=1e-12)
         with pytest.raises(ValueError):
             parallel.shard_batch(7, rank, world)
+        # 4. distributed evaluation: each rank contributes the top-k pairs of ITS shard (uneven shards on
+        #    purpose); every rank ends up with the GAP / Hit@1 / loss of the global batch
+        import numpy as np
+        import yt8m_amd.eval_util as eval_util
+        rs = np.random.RandomState(5)
+        Bg, Vg, k = 11, 30, 5
+        pg = rs.rand(Bg, Vg).astype(np.float32)
+        yg = rs.rand(Bg, Vg) < 0.2
+        cut = 4
+        sl = slice(0, cut) if rank == 0 else slice(cut, Bg)
+        pt, yt = torch.from_numpy(pg[sl]), torch.from_numpy(yg[sl]).float()
+        vals, idx = torch.topk(pt, k, dim=1)                      # (test-side top-k: the product's runs on the device)
+        em = eval_util.EvaluationMetrics(Vg, k)
+        out = em.accumulate_topk(vals, torch.gather(yt, 1, idx), yt.sum(), loss=float(rank + 1))
+        ref = eval_util.EvaluationMetrics(Vg, k)
+        ref.accumulate(pg, yg, np.array([(1.0 * cut + 2.0 * (Bg - cut)) / Bg]))
+        got, exp = em.get(), ref.get()
+        assert abs(got["gap"] - exp["gap"]) < 1e-12 and abs(got["avg_hit_at_one"] - exp["avg_hit_at_one"]) < 1e-12
+        assert abs(got["avg_loss"] - exp["avg_loss"]) < 1e-12 and em.num_examples == Bg
+        assert abs(out["hit_at_one"] - exp["avg_hit_at_one"]) < 1e-12
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

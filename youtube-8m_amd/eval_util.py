@@ -108,21 +108,45 @@ class EvaluationMetrics(object):
         self.sum_loss += mean_loss * batch_size
         return {"hit_at_one": mean_hit_at_one, "perr": mean_perr, "loss": mean_loss}
 
-    def accumulate_device(self, predictions, labels, loss):
-        """GPU path for GAP / Hit@1: predictions, labels are device tensors [B, V]."""
+    def accumulate_device(self, predictions, labels, loss, group=None):
+        """GPU path for GAP / Hit@1: predictions, labels are device tensors [B, V] (this rank's shard under data parallelism).
+        Per-video top-k runs on the device (yt8m_topk_rows); only B*k (score, label) pairs leave it."""
         import torch
         from . import ops
         vals, idx = ops.topk_rows(predictions, self.top_k)
         lab = labels.to(torch.float32)
         picked = torch.gather(lab, 1, idx.long())
-        npos = float(lab.sum().item())
-        hit = float(picked[:, 0].mean().item())
+        return self.accumulate_topk(vals, picked, lab.sum(), float(loss), group=group)
+
+    def accumulate_topk(self, vals, picked, num_positives, loss, group=None):
+        """vals / picked [B, k]: per-video top-k scores (descending) and their labels; num_positives: scalar tensor = number of
+        positive labels in the shard (ALL labels, not only the top-k ones: W/average_precision_calculator.py total_positives).
+        Under torch.distributed every rank's pairs are all-gathered (B*k*8 bytes per rank) and the positives /
+        loss sums all-reduced, so every rank accumulates the metrics of the GLOBAL batch."""
+        import torch
+        import torch.distributed as dist
+        bs = vals.shape[0]
+        stats = torch.stack([num_positives.to(torch.float64).reshape(()), picked[:, 0].to(torch.float64).sum(),
+                             torch.tensor(float(loss) * bs, dtype=torch.float64, device=vals.device),
+                             torch.tensor(float(bs), dtype=torch.float64, device=vals.device)])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            world = dist.get_world_size(group)
+            counts = [torch.zeros(1, dtype=torch.int64, device=vals.device) for _ in range(world)]
+            dist.all_gather(counts, torch.tensor([bs], dtype=torch.int64, device=vals.device), group=group)
+            cap = int(max(int(c.item()) for c in counts))
+            pad = torch.zeros((cap, 2, vals.shape[1]), dtype=torch.float32, device=vals.device)
+            pad[:bs, 0], pad[:bs, 1] = vals, picked
+            gathered = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(gathered, pad, group=group)
+            vals = torch.cat([g[:int(c.item()), 0] for g, c in zip(gathered, counts)])
+            picked = torch.cat([g[:int(c.item()), 1] for g, c in zip(gathered, counts)])
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        npos, hits, loss_sum, n = (float(v) for v in stats.cpu())
         self.global_ap_calculator.accumulate(vals.reshape(-1).cpu().numpy(), picked.reshape(-1).cpu().numpy(), npos)
-        bs = predictions.shape[0]
-        self.num_examples += bs
-        self.sum_hit_at_one += hit * bs
-        self.sum_loss += float(loss) * bs
-        return {"hit_at_one": hit, "loss": float(loss)}
+        self.num_examples += int(n)
+        self.sum_hit_at_one += hits
+        self.sum_loss += loss_sum
+        return {"hit_at_one": hits / n, "loss": loss_sum / n}
 
     def get(self):
         if self.num_examples <= 0:
