@@ -623,6 +623,50 @@ def test_distillation_losses(dev, flags, mode):
     assert any(float((g.vars[k].data - before[k]).abs().max()) > 0 for k in before)
 
 
+def test_gap_on_heldout_shard_matches_cpu_training(dev, flags):
+    """North-star acceptance check, at a size the CPU oracle trains in seconds: MoeModel trained on a synthetic
+    teacher shard by the HIP path and by the torch-CPU restatement from the SAME initial weights on the SAME batches; GAP@20 on
+    a disjoint held-out shard must agree within 0.001 (and be far above the untrained model's)."""
+    import yt8m_amd.eval_util as eu
+    D_, V_, M_, B_, steps, held = 64, 300, 2, 256, 60, 2048
+    gen = torch.Generator().manual_seed(7)
+    Wt = torch.randn(D_, V_, generator=gen) / D_ ** 0.5
+
+    def shard(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(n, D_, generator=g) * 4.0 - 2.0
+        logit = x @ Wt * 3.0 - 3.0 + 0.5 * torch.randn(n, V_, generator=g)
+        tau = torch.quantile(logit.flatten()[:200000], 1.0 - 3.4 / V_)        # ~3.4 positives per video
+        return x, logit > tau
+    xtr, ytr = shard(B_ * steps, 11)
+    xho, yho = shard(held, 12)                                               # disjoint seed = held-out shard
+    assert 2.0 < float(yho.float().sum(1).mean()) < 5.0
+    cpu = torch_ref.MoeTrainStepCPU(D=D_, V=V_, M=M_, batch_size=B_, dtype=torch.float32, seed=3)
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(vlm.MoeModel(), batch_size=B_, graph=g)
+    tg.forward(xtr[:B_].to(dev), ytr[:B_].to(dev))
+    g.finalize()
+    inject(g, {k: v.detach().numpy() for k, v in cpu.P.items()}, dev)
+    p0 = tg.predict(xho.to(dev), vocab_size=V_)
+    gap0 = eu.calculate_gap(p0.cpu().numpy(), yho.numpy().astype(np.float32), 20)
+    for i in range(steps):
+        xb, yb = xtr[i * B_:(i + 1) * B_], ytr[i * B_:(i + 1) * B_]
+        lh = tg.step(xb.to(dev), yb.to(dev))["loss"]
+        lc, _ = cpu.step(xb, yb)
+        assert abs(float(lh) - float(lc)) < 2e-3 * abs(float(lc)), (i, float(lh), float(lc))
+    ph = tg.predict(xho.to(dev), vocab_size=V_).cpu()
+    with torch.no_grad():
+        pc = torch_ref.moe(torch_ref.l2_normalize(xho, 1), cpu.P["gates/weights"], cpu.P["experts/weights"], cpu.P["experts/biases"], M_)
+    gh = eu.calculate_gap(ph.numpy(), yho.numpy().astype(np.float32), 20)
+    gc = eu.calculate_gap(pc.numpy(), yho.numpy().astype(np.float32), 20)
+    assert abs(gh - gc) < 1e-3, (gh, gc)
+    assert gh > gap0 + 0.05 and gh > 0.2, (gap0, gh)
+    # the device metric path agrees with the host one on the same predictions
+    em = eu.EvaluationMetrics(V_, 20)
+    em.accumulate_device(ph.to(dev), yho.to(dev), 0.0)
+    assert abs(em.get()["gap"] - gh) < 1e-3
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64)
 
