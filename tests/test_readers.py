@@ -157,6 +157,9 @@ def test_prefetcher_delivers_every_record_once(tmp_path, threads):
         tr.write_frame_shard(p, vids, names)
         shards.append(p)
         allv += vids
+    empty = str(tmp_path / "empty.tfrecord")                                   # a shard with no records is skipped cleanly
+    open(empty, "wb").close()
+    shards.insert(2, empty)
     rd = readers.YT8MFrameFeatureReader(num_classes=50, feature_sizes=sizes, feature_names=names, max_frames=6)
     seq = list(rd.prepare_reader(shards, batch_size=4))
     got = list(rd.prepare_reader(shards, batch_size=4, num_threads=threads, queue_depth=2))
