@@ -18,6 +18,13 @@
 //   that each XCD walks a contiguous strip of tiles and re-uses its B panel from its own 4 MiB L2 across M-tiles.
 #include "common.h"
 
+#ifdef YT8M_GEMM_TIMING
+__device__ unsigned long long yt8m_gemm_phase[8];
+extern "C" int yt8m_debug_gemm_phase(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(yt8m_gemm_phase), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
@@ -217,26 +224,49 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cur = 0;
+#ifdef YT8M_GEMM_TIMING   // (timing experiments only) per-phase cycle sums of one wave: DMA issue, LDS fragment reads, MFMA
+    uint64_t ph[5] = {0, 0, 0, 0, 0};   // block, vmcnt wait, barrier
+#define PH_T(x) const uint64_t x = __builtin_amdgcn_s_memtime()
+#else
+#define PH_T(x)
+#endif
     for (int kt = kb; kt < ke; ++kt) {
       const int nxt2 = cur >= 1 ? cur - 1 : 2;           // (cur + 2) % 3
+      PH_T(p0);
       if (kt + 2 < ke) {
         fill_step<A_KC>(Ap, g.lda, m0, kt + 2, g.M, g.K, As + nxt2 * TILE_FLOATS, tid);
         fill_step<B_KC>(Bp, g.ldb, n0, kt + 2, g.N, g.K, Bs + nxt2 * TILE_FLOATS, tid);
       }
+      PH_T(p1);
       Frag fa, fb;
       load_frag<A_KC>(As + cur * TILE_FLOATS, wm, li, lk, fa);
       load_frag<B_KC>(Bs + cur * TILE_FLOATS, wn, li, lk, fb);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef YT8M_GEMM_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      PH_T(p2);
       if (BF16) mma_step_bf16(fa, fb, acc);
       else mma_step(fa, fb, acc);
       __builtin_amdgcn_sched_barrier(0);
+      PH_T(p3);
       // K-step kt+1 must have landed; kt+2 may stay in flight -- unless kt+2 was the guarded K-tail store (then it is
       // not a DMA: nothing younger than kt+1 is in flight, drain everything incl. the ds_writes)
       if (kt + 2 < ke && (kt + 3) * BK <= g.K) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      PH_T(p4);
       __builtin_amdgcn_s_barrier();
+#ifdef YT8M_GEMM_TIMING
+      PH_T(p5);
+      ph[0] += p1 - p0; ph[1] += p2 - p1; ph[2] += p3 - p2; ph[3] += p4 - p3; ph[4] += p5 - p4;
+#endif
       cur = cur == 2 ? 0 : cur + 1;
     }
+#ifdef YT8M_GEMM_TIMING
+    if (tid == 0 && blockIdx.x == 300)
+      for (int i = 0; i < 5; ++i) yt8m_gemm_phase[i] = ph[i];
+    if (tid == 0 && blockIdx.x == 300) yt8m_gemm_phase[5] = (uint64_t)(ke - kb);
+#endif
     return;
   }
   float4 ra0, ra1, rb0, rb1;
@@ -278,7 +308,7 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, const float* __restr
 // ---- one workgroup tile: K-steps [kb, ke) -> accumulators -> epilogue --------------------------------------------
 // mode 0: full reduction, C = acc (+ bias) (+ C).  mode 1: split-K part, raw accumulators to the workspace slot `ws`
 // (tile-local [128][128] image); the fix-up kernel adds the parts in a fixed order.
-template <bool A_KC, bool B_KC, bool BF16>
+template <bool A_KC, bool B_KC, bool BF16, bool VEPI = false>
 __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __restrict__ Ap, const float* __restrict__ Bp,
                                              float* __restrict__ Cp, float* __restrict__ smem, int tm, int tn, int kb,
                                              int ke, float* __restrict__ ws) {
@@ -327,10 +357,53 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
           ws[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + wn + j * 32 + li] = acc[i][j][r];
     return;
   }
-  // Output path: one dword store per accumulator register (64 per wave and tile).  A float4 path staged through LDS was
-  // measured (tools/gemm_timing.py): it cuts the per-tile epilogue from 74k to 29k cycles, but the epilogue of one workgroup
-  // already hides under the main loops of the two others on the CU, while its LDS traffic slows those loops by ~2 %
-  // (cfg[1] dW shape +7 %, forward +0 %, K >= 4096 shapes -3..5 %) -- not kept.
+  // Output path.  Default: one dword store per accumulator register (64 per wave and tile).  VEPI: the accumulators are
+  // transposed through LDS (free after the main loop; each wave stages its own 32 x 64 half-tiles) and leave as 16-byte
+  // stores, 16 instead of 64 store instructions per wave -- the store pipe is issue-bound, this cuts the per-tile epilogue
+  // from 74k to 29k cycles (tools/gemm_timing.py).  It is a separate instantiation because it only pays where the epilogue
+  // is a large share of a tile: measured +7 % on the cfg[1] dW shape (K = 1024, transA), +-0 on the forward shape and
+  // -3..5 % at K >= 4096 (the epilogue of one workgroup already hides under the main loops of the two others on the CU).
+  if (VEPI && (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cp) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0) {
+    constexpr int P = 68;                                   // padded row pitch (floats) of the staging image
+    float* st = smem + (tid >> 6) * (32 * P);
+    const int lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = lane + 64 * k;
+        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        const int row = m0 + wm + i * 32 + rr, col = n0 + wn + c4;
+        float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+        if (row < g.M && col < g.N) {
+          float* c = Cp + (int64_t)row * g.ldc + col;
+          if (col + 3 < g.N) {
+            if (g.bias) {
+              const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (g.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(c);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(c) = v;
+          } else {                                          // last, partial group of columns of the matrix
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int e = 0; e < 4 && col + e < g.N; ++e) {
+              float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
+              if (g.accumulate) t += c[e];
+              c[e] = t;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn + j * 32 + li;
@@ -396,7 +469,7 @@ __device__ __forceinline__ int find_problem(const GroupArgs& G, int tile) {
   return q;
 }
 
-template <bool A_KC, bool B_KC, bool BF16>
+template <bool A_KC, bool B_KC, bool BF16, bool VEPI = false>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GroupArgs G) {
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGES * TILE_FLOATS];
   // One work item per workgroup; the grid is full_rounds*P whole tiles followed by rem*S split-K parts.  The hardware
@@ -420,7 +493,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GroupArgs G) {
   const int lt = tile - G.tile_base[q];
   const int nk = (g.K + BK - 1) / BK;
   const int kb = (int)((int64_t)nk * part / nparts), ke = (int)((int64_t)nk * (part + 1) / nparts);
-  process_tile<A_KC, B_KC, BF16>(g, g.A, g.B, g.C, smem, lt % g.tiles_m, lt / g.tiles_m, kb, ke,
+  process_tile<A_KC, B_KC, BF16, VEPI>(g, g.A, g.B, g.C, smem, lt % g.tiles_m, lt / g.tiles_m, kb, ke,
                                  nparts > 1 ? G.ws + (int64_t)slot * (BM * BN) : nullptr);
 }
 
@@ -571,8 +644,12 @@ static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);
   const int64_t grid = (int64_t)G.full_rounds * G.P + (int64_t)G.rem * G.S;
+  int kmax = 0;
+  for (int i = 0; i < G.nprob; ++i) kmax = std::max(kmax, G.p[i].K);
   if (bf16)
     hipLaunchKernelGGL((gemm_grouped_kernel<true, true, true>), dim3((unsigned)grid), dim3(256), 0, s, G);
+  else if (transA && !transB && kmax <= 2048)     // weight-gradient shapes with a short reduction: float4 epilogue variant
+    hipLaunchKernelGGL((gemm_grouped_kernel<false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, G);
   else
     launch_by_layout<GroupArgs>(transA, transB, gemm_grouped_kernel<true, false, false>, gemm_grouped_kernel<false, false, false>,
                                 gemm_grouped_kernel<true, true, false>, gemm_grouped_kernel<false, true, false>,
