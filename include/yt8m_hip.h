@@ -136,6 +136,17 @@ int yt8m_logistic_fwd_bwd(const float* x, const float* W, const float* b, const 
                           int64_t D, int64_t V, float eps, float* p, float* loss_out, float* Z, float* dW, float* db,
                           float beta, float* dx, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- counter-based random elementwise ops (csrc/random.hip) -------------------------------------
+ * Philox4x32-10: element e of the logical tensor uses word (e & 3) of the block with counter (e >> 2), key = seed;
+ * `offset` = logical index of x[0], so a chunk of a tensor draws the same numbers as a call over the whole tensor and the
+ * backward pass regenerates the mask from (seed, offset) instead of storing it.
+ * yt8m_dropout_f32: tf.nn.dropout (W/all_video_models/deep_combine_chain_model.py:57-58; DropoutWrapper input_keep_prob,
+ *   W/all_frame_models/lstm_memory_model.py:36-45): y = floor(keep_prob + u) ? x / keep_prob : 0, u = (word >> 8) * 2^-24.
+ *   In place (y == x) allowed; its own backward is the same call on the upstream gradient.
+ * yt8m_add_noise_f32: y = x + stddev * N(0,1) (W/all_frame_models/lstm_memory_model.py:62-63), Box-Muller on word pairs. */
+int yt8m_dropout_f32(const float* x, float* y, int64_t n, float keep_prob, uint64_t seed, int64_t offset, yt8m_stream_t stream);
+int yt8m_add_noise_f32(const float* x, float* y, int64_t n, float stddev, uint64_t seed, int64_t offset, yt8m_stream_t stream);
+
 /* ---- elementwise activations + column sums (bias gradients) ------------------------------------ */
 enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8M_ACT_TANH = 3, YT8M_ACT_ELU = 4 };
 int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream);

@@ -58,12 +58,20 @@ def logistic(x, W, b):
     return torch.sigmoid(x @ W + b)
 
 
-def deep_combine_chain(x, P, L, M, relu_type="relu"):
-    """W/all_video_models/deep_combine_chain_model.py:12-85."""
+def dropout(x, keep_prob, seed, offset=0):
+    """tf.nn.dropout with the build's Philox convention (oracle/philox.py): element index = row-major position."""
+    from . import philox
+    m = torch.from_numpy(philox.dropout_mask(x.numel(), keep_prob, seed, offset)).view(x.shape)
+    return torch.where(m, x / torch.tensor(keep_prob, dtype=x.dtype), torch.zeros_like(x))
+
+
+def deep_combine_chain(x, P, L, M, relu_type="relu", dropout_spec=None):
+    """W/all_video_models/deep_combine_chain_model.py:12-85.  dropout_spec = (keep_prob, [seed per sub-model]): :57-58."""
     cur, sup = x, []
     for i in range(L):
         s = "prediction-%d" % i
-        sp = moe(cur, P["gates-%s/weights" % s], P["experts-%s/weights" % s], P["experts-%s/biases" % s], M)
+        inp = cur if dropout_spec is None else dropout(cur, dropout_spec[0], dropout_spec[1][i])
+        sp = moe(inp, P["gates-%s/weights" % s], P["experts-%s/weights" % s], P["experts-%s/biases" % s], M)
         a = sp @ P["relu-%d/weights" % i] + P["relu-%d/biases" % i]
         r = torch.nn.functional.elu(a) if relu_type == "elu" else torch.relu(a)
         cur = torch.cat([cur, l2_normalize(r, 1)], 1)
@@ -72,8 +80,11 @@ def deep_combine_chain(x, P, L, M, relu_type="relu"):
     return main, torch.cat(sup, 1)
 
 
-def lstm_stack(x, num_frames, layers, forget_bias=1.0):
-    """A.3-A.5 (BasicLSTMCell / MultiRNNCell / dynamic_rnn with copy-through; Z/rnn_residual.py:61-188)."""
+def lstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None):
+    """A.3-A.5 (BasicLSTMCell / MultiRNNCell / dynamic_rnn with copy-through; Z/rnn_residual.py:61-188).
+    dropout_spec = (input_keep_prob, [seed per layer]): DropoutWrapper(cell, input_keep_prob)
+    (W/all_frame_models/lstm_memory_model.py:36-45) -- the layer input of step t is element block t of a time-major
+    [F,B,in] mask tensor."""
     B, F, _ = x.shape
     H = layers[0][1].numel() // 4
     c = [x.new_zeros(B, H) for _ in layers]
@@ -83,6 +94,8 @@ def lstm_stack(x, num_frames, layers, forget_bias=1.0):
         live = (t < num_frames).unsqueeze(1)
         inp = x[:, t]
         for l, (W, b) in enumerate(layers):
+            if dropout_spec is not None:
+                inp = dropout(inp, dropout_spec[0], dropout_spec[1][l], offset=t * inp.numel())
             z = torch.cat([inp, h[l]], 1) @ W + b
             i, j, f, o = z.chunk(4, 1)
             cn = c[l] * torch.sigmoid(f + forget_bias) + torch.sigmoid(i) * torch.tanh(j)

@@ -560,3 +560,48 @@ def test_cast_bf16_and_bf16_gemm(dev):
         ops.gemm_bf16_nt_grouped([dict(A=torch.zeros(4, 4, device=dev), B=torch.zeros(4, 4, device=dev))])
     with pytest.raises(ValueError):
         ops.gemm_bf16_nt_grouped([dict(A=torch.zeros(4, 3, device=dev, dtype=torch.bfloat16), B=torch.zeros(4, 3, device=dev, dtype=torch.bfloat16))])
+
+
+@pytest.mark.parametrize("n,offset", [(1, 0), (7, 0), (1024, 0), (1027, 5), (4099, 4096), (3, 2), (100001, 123457)])
+def test_dropout_bit_exact_with_philox_oracle(dev, n, offset):
+    """yt8m_dropout_f32 == oracle.philox.dropout bit for bit (mask AND the x / keep_prob quotient), for aligned and unaligned
+    offsets / sizes; in place; and the autograd backward replays the same mask."""
+    from oracle import philox
+    rs = np.random.RandomState(n)
+    x = rs.randn(n).astype(np.float32)
+    seed = 0x9E3779B97F4A7C15 ^ n
+    for keep in (0.5, 0.7, 1.0):
+        ref = philox.dropout(x, keep, seed, offset)
+        xd = D(x, dev).requires_grad_(True)
+        y = ops._Dropout.apply(xd, keep, seed, offset)
+        assert np.array_equal(y.detach().cpu().numpy(), ref), (n, offset, keep)
+        dy = rs.randn(n).astype(np.float32)
+        y.backward(D(dy, dev))
+        assert np.array_equal(xd.grad.cpu().numpy(), philox.dropout(dy, keep, seed, offset))
+        z = D(x, dev)
+        ops.dropout_(z, keep, seed, offset)
+        assert np.array_equal(z.cpu().numpy(), ref)
+    if n > 8:                                      # a chunk draws what the whole tensor draws at that position
+        h = n // 3
+        whole = ops._Dropout.apply(D(x, dev), 0.7, seed, offset).cpu().numpy()
+        part = ops._Dropout.apply(D(x[h:], dev), 0.7, seed, offset + h).cpu().numpy()
+        assert np.array_equal(whole[h:], part)
+
+
+def test_dropout_and_noise_statistics_and_errors(dev):
+    from oracle import philox
+    n = 1 << 20
+    x = torch.ones(n, device=dev)
+    y = ops.dropout(x, 0.8, seed=42).cpu().numpy()
+    assert abs((y != 0).mean() - 0.8) < 2e-3 and np.allclose(y[y != 0], np.float32(1.0) / np.float32(0.8))
+    z = ops.add_noise(torch.zeros(n + 3, device=dev), 0.5, seed=43, offset=1).cpu().numpy().astype(np.float64)
+    ref = philox.add_noise(np.zeros(n + 3), 0.5, 43, offset=1)
+    assert np.abs(z - ref).max() < 5e-6                       # device logf / cosf vs float64 Box-Muller
+    assert abs(z.mean()) < 2e-3 and abs(z.std() - 0.5) < 2e-3
+    zz = z / 0.5
+    assert abs((zz ** 3).mean()) < 2e-2 and abs((zz ** 4).mean() - 3.0) < 5e-2
+    with pytest.raises(ValueError):
+        ops.dropout(x, 0.0, seed=1)
+    with pytest.raises(ValueError):
+        ops.dropout(x, 1.5, seed=1)
+    assert ops.dropout(torch.empty(0, device=dev), 0.5, seed=1).numel() == 0

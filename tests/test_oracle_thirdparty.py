@@ -105,3 +105,33 @@ def test_elementwise_restatements_vs_torch_functional():
     bce = torch.nn.functional.binary_cross_entropy(torch.from_numpy(p), torch.from_numpy(y), reduction="none").sum(1).mean().item()
     assert abs(np_ref.cross_entropy_loss(p, y) - bce) < 1e-3 * bce
     assert abs(np_ref.cross_entropy_loss(p, y, eps=0.0) - bce) < 1e-12 * bce
+
+
+def test_philox_known_answers_and_streams():
+    """oracle/philox.py against the Random123 known-answer vectors for philox4x32-10, then the conventions built on it."""
+    from oracle import philox
+    from yt8m_amd.variables import random_seed
+
+    def kat(ctr, key):
+        r = philox.philox4x32_10(*[np.array([v], dtype=np.uint64) for v in ctr], key[0], key[1])
+        return [int(v[0]) for v in r]
+
+    assert kat((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert kat((0xffffffff,) * 4, (0xffffffff,) * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert kat((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    w = philox.words(64, 7)
+    assert np.array_equal(w[5:41], philox.words(36, 7, offset=5))               # offset = position in the logical tensor
+    blk = philox.philox4x32_10(np.array([3], dtype=np.uint64), np.array([0], dtype=np.uint64), np.array([0], dtype=np.uint64),
+                               np.array([0], dtype=np.uint64), 7, 0)
+    assert [int(w[12 + k]) for k in range(4)] == [int(b[0]) for b in blk]       # element e -> word e & 3 of block e >> 2
+    m = philox.dropout_mask(1 << 18, 0.7, 99)
+    assert abs(m.mean() - 0.7) < 4e-3 and philox.dropout_mask(1000, 1.0, 5).all()
+    x = np.arange(1, 9, dtype=np.float32)
+    d = philox.dropout(x, 0.5, 3)
+    assert set(np.unique(d / x)) <= {0.0, 2.0}
+    z = philox.normal(1 << 18, 11)
+    assert abs(z.mean()) < 6e-3 and abs(z.std() - 1) < 6e-3
+    seeds = {random_seed(0, r, s, c) for r in range(2) for s in range(50) for c in range(8)}
+    assert len(seeds) == 800 and all(0 <= v < 1 << 64 for v in seeds)
+    assert random_seed(3, 1, 2, 0) == random_seed(3, 1, 2, 0) != random_seed(4, 1, 2, 0)

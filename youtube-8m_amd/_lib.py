@@ -47,6 +47,8 @@ SIGNATURES = {
     "yt8m_moe_mix_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_moe_mix_xent_fwd": (c_int, [P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_float, P, P]),
     "yt8m_moe_mix_xent_bwd": (c_int, [P, P, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P]),
+    "yt8m_dropout_f32": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, c_int64, P]),
+    "yt8m_add_noise_f32": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, c_int64, P]),
     "yt8m_act_fwd_f32": (c_int, [c_int, P, P, c_int64, P]),
     "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),
     "yt8m_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),

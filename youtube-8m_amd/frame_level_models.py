@@ -40,7 +40,7 @@ def _head(name=None):
     return getattr(video_level_models, name or FLAGS.video_level_classifier_model)
 
 
-def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN"):
+def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN", input_keep_prob=None):
     """MultiRNNCell([BasicLSTMCell(H, forget_bias=1.0)] * L) under tf.nn.dynamic_rnn inside variable_scope("RNN")
     (W/all_frame_models/lstm_model.py:34-47).  TF-1.0 variable names:
     RNN/multi_rnn_cell/cell_<l>/basic_lstm_cell/{weights,biases}.  Returns time-major outputs of the top layer
@@ -57,7 +57,8 @@ def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN
             wb.append((W, b))
             d_in = lstm_size
     # all layers in one op: layer l+1 works on time chunk c while layer l is already in chunk c+1 (seq_ops._LstmStack)
-    return seq_ops.lstm_stack(x_tm, num_frames, wb, forget_bias=1.0, chunks=FLAGS.lstm_pipeline_chunks)
+    return seq_ops.lstm_stack(x_tm, num_frames, wb, forget_bias=1.0, chunks=FLAGS.lstm_pipeline_chunks,
+                              input_keep_prob=input_keep_prob)
 
 
 class FrameLevelLogisticModel(models.BaseModel):
@@ -89,14 +90,14 @@ class LstmMemoryModel(models.BaseModel):
 
     def create_model(self, model_input, vocab_size, num_frames, dropout=False, keep_prob=None, noise_level=None,
                      **unused_params):
-        if dropout:
-            raise NotImplementedError("DropoutWrapper is out of scope this round (SURVEY.md 8f item 3)")
         lstm_size = int(FLAGS.lstm_cells)
         number_of_layers = FLAGS.lstm_layers
-        _, finals = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers)
+        # :36-45 DropoutWrapper(BasicLSTMCell, input_keep_prob=keep_prob) around every layer when --dropout
+        _, finals = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers,
+                                input_keep_prob=keep_prob if dropout else None)
         final_state = torch.cat([c for c, _ in finals], dim=1)
         if noise_level is not None:
-            final_state = final_state + torch.randn_like(final_state) * noise_level
+            final_state = ops.add_noise(final_state, noise_level)
         return _head()().create_model(model_input=final_state, original_input=model_input, vocab_size=vocab_size,
                                       num_frames=num_frames, **unused_params)
 

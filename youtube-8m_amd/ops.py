@@ -358,6 +358,64 @@ def _token(graph=None):
     return g.token
 
 
+class _Dropout(torch.autograd.Function):
+    """tf.nn.dropout(x, keep_prob) (W/all_video_models/deep_combine_chain_model.py:57-58): x / keep_prob where the Philox
+    stream of (seed, offset + element) keeps the element, else 0.  The mask is never stored: backward replays it."""
+
+    @staticmethod
+    def forward(ctx, x, keep_prob, seed, offset):
+        x = _f32c(x)
+        _dev(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().yt8m_dropout_f32(_p(x), _p(y), x.numel(), float(keep_prob), int(seed), int(offset), _stream()))
+        ctx.args = (float(keep_prob), int(seed), int(offset))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        keep_prob, seed, offset = ctx.args
+        _lib.check(_lib.lib().yt8m_dropout_f32(_p(dy), _p(dx), dy.numel(), keep_prob, seed, offset, _stream()))
+        return dx, None, None, None
+
+
+def dropout(x, keep_prob, seed=None, offset=0, graph=None):
+    """seed None: the next key of the graph's random stream (variables.random_seed)."""
+    if seed is None:
+        seed = (graph or get_default_graph()).next_random_seed()
+    return _Dropout.apply(x, keep_prob, seed, offset)
+
+
+def dropout_(x, keep_prob, seed, offset=0):
+    """In place, no autograd (used inside the fused recurrent-stack op)."""
+    _dev(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    _lib.check(_lib.lib().yt8m_dropout_f32(_p(x), _p(x), x.numel(), float(keep_prob), int(seed), int(offset), _stream()))
+    return x
+
+
+class _AddNoise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stddev, seed, offset):
+        x = _f32c(x)
+        _dev(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().yt8m_add_noise_f32(_p(x), _p(y), x.numel(), float(stddev), int(seed), int(offset), _stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None
+
+
+def add_noise(x, stddev, seed=None, offset=0, graph=None):
+    """x + N(0, stddev^2) (W/all_frame_models/lstm_memory_model.py:62-63); the gradient passes through unchanged."""
+    if seed is None:
+        seed = (graph or get_default_graph()).next_random_seed()
+    return _AddNoise.apply(x, stddev, seed, offset)
+
+
 BF16_MIN_MACS = 1 << 27      # below this the cast passes cost more than the bf16 MFMAs save
 BF16_MIN_ROWS = 512          # a weight matrix is re-cast every step (6 B/element): that only pays when >= ~100 activation
                              # rows share it; 512 keeps a margin (measured: B = 128 NetVLAD hidden FC loses, 1024-row chain wins)

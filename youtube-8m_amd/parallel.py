@@ -60,6 +60,7 @@ class GradReducer(object):
         """Hooks the graph and makes every rank start from rank 0's parameters."""
         self.graph = graph
         self.active = dist.is_initialized()
+        graph.rank = dist.get_rank(self.group) if self.active else 0     # ranks draw different dropout / noise streams
         graph.grad_ready_hook = self._on_ready if (self.overlap and self.active) else None
         if self.active:
             dist.broadcast(graph.params, src=0, group=self.group)

@@ -109,11 +109,18 @@ class _LstmStack(torch.autograd.Function):
     the dx GEMM of a chunk releases the layer below) and every weight-gradient GEMM goes to a further stream, accumulating
     chunk by chunk.  Same kernels and the same per-step arithmetic as the unpipelined op; chunks = 1 is the sequential form.
 
-    apply(x_tm [F,B,D], token, num_frames, forget_bias, chunks, W_0, b_0, ..., W_{L-1}, b_{L-1})
+    input_keep_prob < 1 is tf.contrib.rnn.DropoutWrapper(cell, input_keep_prob) around every layer
+    (W/all_frame_models/lstm_memory_model.py:36-45): the INPUT of each layer (frames for layer 0, the outputs of the layer
+    below otherwise -- never the recurrent state) goes through tf.nn.dropout with a fresh mask per time step.  Here: one
+    Philox key per layer (seeds), element index = position in the [F,B,in] tensor, applied chunk by chunk on the layer's
+    stream right before the projection GEMM (in place on the lower layer's output buffer, which nothing else reads) and
+    replayed on the dx chunk in backward.
+
+    apply(x_tm [F,B,D], token, num_frames, forget_bias, chunks, input_keep_prob, seeds, W_0, b_0, ..., W_{L-1}, b_{L-1})
       -> (out_top [F,B,H], c_0, h_0, ..., c_{L-1}, h_{L-1})"""
 
     @staticmethod
-    def forward(ctx, x_tm, token, num_frames, forget_bias, chunks, *wb):
+    def forward(ctx, x_tm, token, num_frames, forget_bias, chunks, input_keep_prob, seeds, *wb):
         x_tm = _f32c(x_tm)
         _dev(x_tm)
         L = len(wb) // 2
@@ -125,8 +132,11 @@ class _LstmStack(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         rs, gs, _ = _side_streams(dev, L)
         parts = _chunks(F, chunks)
+        drop = input_keep_prob is not None and float(input_keep_prob) < 1.0
         layers, inp = [], x_tm
         for l in range(L):                                          # every buffer comes from the main stream's pool
+            if drop and l == 0:
+                inp = torch.empty_like(x_tm)                        # dropped copy of the frames (the input itself is data)
             Din = inp.shape[2]
             H = Ws[l].data.shape[1] // 4
             assert Ws[l].data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
@@ -156,6 +166,11 @@ class _LstmStack(torch.autograd.Function):
                 with torch.cuda.stream(gs[l]):                      # hoisted input projection of the chunk
                     if l > 0:
                         gs[l].wait_event(r_done[l - 1][c])
+                    if drop:
+                        xc = st["x"][t0:t0 + T]
+                        src = x_tm[t0:t0 + T] if l == 0 else xc
+                        _lib.check(lib.yt8m_dropout_f32(_p(src), _p(xc), xc.numel(), float(input_keep_prob), int(seeds[l]),
+                                                        t0 * B * Din, _stream()))
                     ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
                              bias=st["b"].data)
                     g_ev = torch.cuda.Event()
@@ -170,6 +185,7 @@ class _LstmStack(torch.autograd.Function):
         for l in range(L):
             main.wait_event(r_done[l][-1])
         ctx.layers, ctx.nf, ctx.parts = layers, nf, parts
+        ctx.drop = (float(input_keep_prob), tuple(int(v) for v in seeds)) if drop else None
         ctx.set_materialize_grads(False)
         outs = [layers[-1]["out"]]
         for st in layers:
@@ -241,6 +257,8 @@ class _LstmStack(torch.autograd.Function):
                         gs[l].wait_event(rb)
                         dst = layers[l - 1]["dout"] if l > 0 else dx
                         ops.gemm(dzc, W.data[:Din], out=dst[t0:t0 + T].view(T * B, Din), transB=True)
+                        if ctx.drop is not None:
+                            ops.dropout_(dst[t0:t0 + T], ctx.drop[0], ctx.drop[1][l], t0 * B * Din)
                         dx_ev = torch.cuda.Event()
                         dx_ev.record(gs[l])
                         if c == 0:
@@ -270,13 +288,18 @@ class _LstmStack(torch.autograd.Function):
                 st["W"].grad_done()
             if st["b"].grad is not None:
                 st["b"].grad_done()
-        return (dx, None, None, None, None) + (None,) * (2 * L)
+        return (dx, None, None, None, None, None, None) + (None,) * (2 * L)
 
 
-def lstm_stack(x_tm, num_frames, weights_biases, forget_bias=1.0, chunks=4):
-    """weights_biases: [(W_0, b_0), ...] Variables.  Returns (out_top, [(c_l, h_l), ...])."""
+def lstm_stack(x_tm, num_frames, weights_biases, forget_bias=1.0, chunks=4, input_keep_prob=None, seeds=None):
+    """weights_biases: [(W_0, b_0), ...] Variables.  Returns (out_top, [(c_l, h_l), ...]).
+    input_keep_prob < 1: DropoutWrapper(input_keep_prob) on every layer; seeds = one Philox key per layer (default: the
+    graph's random stream)."""
     flat = [v for wb in weights_biases for v in wb]
-    res = _LstmStack.apply(x_tm, _token(flat[0]._graph), num_frames, forget_bias, int(chunks), *flat)
+    if input_keep_prob is not None and float(input_keep_prob) < 1.0 and seeds is None:
+        seeds = [flat[0]._graph.next_random_seed() for _ in weights_biases]
+    res = _LstmStack.apply(x_tm, _token(flat[0]._graph), num_frames, forget_bias, int(chunks), input_keep_prob,
+                           tuple(seeds) if seeds is not None else None, *flat)
     return res[0], [(res[1 + 2 * l], res[2 + 2 * l]) for l in range(len(weights_biases))]
 
 

@@ -37,6 +37,9 @@ DEFINE_integer("distillation_type", 0, "Type of distillation, options are 1 and 
 DEFINE_bool("distillation_as_input", False, "If set true, distillation_predictions will be given to model.")
 DEFINE_bool("distillation_as_boosting", False, "If set true, distillation_predictions will be used in computation of weighted loss.")
 DEFINE_float("distillation_percent", 0.0, "If larger than 0, final_loss = distillation_loss * percent + normal_loss * (1.0 - percent).")
+DEFINE_bool("dropout", False, "Whether to consider dropout")
+DEFINE_float("keep_prob", 1.0, "probability to keep output (used in dropout, keep it unchanged in validationg and test)")
+DEFINE_float("noise_level", 0.0, "standard deviation of noise (added to hidden nodes)")
 DEFINE_bool("frame_features", False, "If set, then --train_data_pattern must be frame-level features.")
 
 
@@ -110,10 +113,14 @@ class TrainGraph(object):
         kw = {} if is_training else {"is_training": False}
         if not fuse_loss:
             kw["fuse_loss"] = False
+        if FLAGS.dropout:                                         # W/train.py:359-369; the keep_prob placeholder defaults to
+            kw["dropout"] = True                                  # 1.0 and is fed FLAGS.keep_prob by the training loop (:569)
+            kw["keep_prob"] = float(FLAGS.keep_prob) if is_training else 1.0
+        noise_level = float(FLAGS.noise_level) if (FLAGS.noise_level > 0 and is_training) else None      # :349-352, :571
         result = self.model.create_model(model_input, num_frames=num_frames, vocab_size=FLAGS.num_classes
                                          if labels_batch is None else labels_batch.shape[1],
                                          labels=labels_batch, distillation_predictions=distillation_predictions,
-                                         noise_level=None, **kw)
+                                         noise_level=noise_level, **kw)
         return result
 
     def _label_loss(self, result, labels, weights):

@@ -73,6 +73,16 @@ def random_normal(stddev):
     return init
 
 
+def random_seed(graph_seed, rank, step, call):
+    """Key of random op number `call` of forward pass `step` on `rank`: splitmix64 finaliser over the packed tuple, so that
+    tests (and a restarted job) can reproduce every mask from four integers."""
+    m = (1 << 64) - 1
+    z = (int(graph_seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xBF58476D1CE4E5B9 + int(step) * 0x94D049BB133111EB + int(call) + 1) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
 class Graph(object):
     def __init__(self, device=None, seed=0):
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -84,6 +94,9 @@ class Graph(object):
         self._gen = None
         self.grad_ready_hook = None
         self.token = None              # dummy requires-grad tensor threaded through ops (see ops.py)
+        self.rank = 0                  # data-parallel rank: part of every random-op seed (parallel.GradReducer.attach)
+        self._rng_step = -1            # forward passes begun so far - 1
+        self._rng_calls = 0            # random ops issued in the current forward pass
         # arenas
         self.params = self.grads = self.adam_m = self.adam_v = None
         self.chunks = self.l2 = self.norms = self.partial = None
@@ -105,10 +118,18 @@ class Graph(object):
     def begin_step(self):
         """Resets per-forward state: anonymous tf.Variable() numbering and the grad-written flags."""
         self._anon_counter = 0
+        self._rng_step += 1
+        self._rng_calls = 0
         for v in self.vars.values():
             v.grad_written = False
         if self.token is None:
             self.token = torch.zeros((), dtype=torch.float32, device=self.device, requires_grad=True)
+
+    def next_random_seed(self):
+        """64-bit Philox key of the next random op (dropout / noise) of this forward pass."""
+        s = random_seed(self.seed, self.rank, self._rng_step, self._rng_calls)
+        self._rng_calls += 1
+        return s
 
     def _generator(self):
         if self._gen is None:

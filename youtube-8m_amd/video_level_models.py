@@ -91,7 +91,7 @@ class DeepCombineChainModel(models.BaseModel):
             sub_activation = fully_connected(sub_prediction, relu_cells, sub_scope + "relu-%d" % layer, l2_penalty=l2_penalty)
             sub_relu = ops.activation(sub_activation, "elu" if relu_type == "elu" else "relu")
             if noise_level is not None:
-                sub_relu = sub_relu + torch.randn_like(sub_relu) * noise_level
+                sub_relu = ops.add_noise(sub_relu, noise_level)
             relu_norm = ops.l2_normalize(sub_relu)
             next_input = torch.cat([next_input, relu_norm], dim=1)
             support_predictions.append(sub_prediction)
@@ -101,6 +101,6 @@ class DeepCombineChainModel(models.BaseModel):
     def sub_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", dropout=False,
                   keep_prob=None, noise_level=None, **unused_params):
         num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
-        if dropout:
-            raise NotImplementedError("dropout inputs are out of scope (SURVEY.md 8f item 3)")
+        if dropout:                                                 # :57-58 tf.nn.dropout on the (grown) chain input
+            model_input = ops.dropout(model_input, 1.0 if keep_prob is None else keep_prob)
         return moe_block(model_input, vocab_size, num_mixtures, l2_penalty, "gates-" + sub_scope, "experts-" + sub_scope)
