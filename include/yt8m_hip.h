@@ -136,6 +136,37 @@ int yt8m_logistic_fwd_bwd(const float* x, const float* W, const float* b, const 
                           int64_t D, int64_t V, float eps, float* p, float* loss_out, float* Z, float* dW, float* db,
                           float beta, float* dx, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- GRUCell / LayerNormBasicLSTMCell layers (csrc/cells.hip), time-major, generic per-step form --------------------
+ * tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn (W/all_frame_models/gru_pooling_model.py:34-47):
+ *   zg [F,B,2H]: in = x.Wg[:in] + b_gates (hoisted by the caller), out = the gates r | u;
+ *   zc [F,B,H] : in = x.Wc[:in] + b_cand, out = the candidate c;   Wg_h = Wg[in:] [H,2H], Wc_h = Wc[in:] [H,H];
+ *   hs [F+1,B,H] with hs[0] = initial state (caller), rh [F,B,H] receives r*h (saved for the weight gradient), out [F,B,H]
+ *   (optional) the dynamic_rnn outputs (zero past num_frames; state copied through).
+ * Backward: dout [F,B,H] (optional), dh_final [B,H] (optional) -> dzg [F,B,2H], dzc [F,B,H]; work >= 3*B*H floats; the final
+ * dh of step 0 is left in work[(F % 2) * B*H].  Weight / input gradients are hoisted GEMMs over dzg / dzc (caller). */
+int yt8m_gru_layer_fwd(float* zg, float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc, float* hs, float* rh,
+                       float* out, const int32_t* num_frames, int64_t F, int64_t B, int64_t H, void* gemm_workspace,
+                       int64_t gemm_workspace_bytes, yt8m_stream_t stream);
+int yt8m_gru_layer_bwd(const float* zg, const float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc,
+                       const float* hs, const float* dout, const float* dh_final, float* dzg, float* dzc, float* work,
+                       const int32_t* num_frames, int64_t F, int64_t B, int64_t H, void* gemm_workspace,
+                       int64_t gemm_workspace_bytes, yt8m_stream_t stream);
+/* tf.contrib.rnn.LayerNormBasicLSTMCell(H, forget_bias, dropout_keep_prob) (W/all_frame_models/layernorm_lstm_memory_model.py:37-50):
+ *   z [F,B,4H]: in = x.W[:in] (no bias), stays RAW (+ h.Wh) for the backward pass; gamma / beta [5,H] in the order
+ *   input, transform, forget, output, state; stats [F,B,10] receives (mean, rstd) of the five normalisations; cs / hs
+ *   [F+1,B,H] with row 0 = initial state; keep_prob < 1 drops the candidate g (Philox element (t*B+b)*H+h under `seed`).
+ * Backward writes dz [F,B,4H] (w.r.t. the raw pre-activations), dyb / dyg [F,B,5H] (column sums = dbeta / dgamma);
+ * work >= 4*B*H floats.  H <= 2048. */
+int yt8m_lnlstm_layer_fwd(float* z, const float* Wh, int64_t ldw, const float* gamma, const float* beta, float* stats, float* cs,
+                          float* hs, float* out, const int32_t* num_frames, int64_t F, int64_t B, int64_t H, float forget_bias,
+                          float keep_prob, uint64_t seed, void* gemm_workspace, int64_t gemm_workspace_bytes,
+                          yt8m_stream_t stream);
+int yt8m_lnlstm_layer_bwd(const float* z, const float* Wh, int64_t ldw, const float* gamma, const float* beta, const float* stats,
+                          const float* cs, const float* dout, const float* dc_final, const float* dh_final, float* dz, float* dyb,
+                          float* dyg, float* work, const int32_t* num_frames, int64_t F, int64_t B, int64_t H, float forget_bias,
+                          float keep_prob, uint64_t seed, void* gemm_workspace, int64_t gemm_workspace_bytes,
+                          yt8m_stream_t stream);
+
 /* ---- counter-based random elementwise ops (csrc/random.hip) -------------------------------------
  * Philox4x32-10: element e of the logical tensor uses word (e & 3) of the block with counter (e >> 2), key = seed;
  * `offset` = logical index of x[0], so a chunk of a tensor draws the same numbers as a call over the whole tensor and the

@@ -107,6 +107,63 @@ def lstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None):
     return torch.stack(outs, 1), c, h
 
 
+def gru_stack(x, num_frames, layers):
+    """tf.contrib.rnn.GRUCell (TF 1.0: gates = sigmoid([x|h].Wg + bg) split r | u; c = tanh([x | r*h].Wc + bc);
+    h' = u*h + (1-u)*c) stacked by MultiRNNCell under dynamic_rnn (W/all_frame_models/gru_pooling_model.py:34-47).
+    layers: [(Wg, bg, Wc, bc)].  Returns (top outputs [B,F,H], [h_l final])."""
+    B, F, _ = x.shape
+    H = layers[0][3].numel()
+    h = [x.new_zeros(B, H) for _ in layers]
+    outs = []
+    for t in range(F):
+        live = (t < num_frames).unsqueeze(1)
+        inp = x[:, t]
+        for l, (Wg, bg, Wc, bc) in enumerate(layers):
+            r, u = torch.sigmoid(torch.cat([inp, h[l]], 1) @ Wg + bg).chunk(2, 1)
+            c = torch.tanh(torch.cat([inp, r * h[l]], 1) @ Wc + bc)
+            hn = u * h[l] + (1 - u) * c
+            h[l] = torch.where(live, hn, h[l])
+            inp = hn
+        outs.append(torch.where(live, inp, torch.zeros_like(inp)))
+    return torch.stack(outs, 1), h
+
+
+def layer_norm(x, gamma, beta, eps=1e-12):
+    """tf.contrib.layers.layer_norm on a 2-D input (TF 1.0): moments over axis 1, batch_normalization with epsilon 1e-12."""
+    mean = x.mean(1, keepdim=True)
+    var = ((x - mean) ** 2).mean(1, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def lnlstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None):
+    """tf.contrib.rnn.LayerNormBasicLSTMCell (TF 1.0: concat = [x|h].W without bias; i, j, f, o each layer-normalised;
+    g = tanh(j) [dropout(g, keep_prob)]; c' = LN_state(c*sigmoid(f + forget_bias) + sigmoid(i)*g); h' = tanh(c')*sigmoid(o))
+    stacked under dynamic_rnn (W/all_frame_models/layernorm_lstm_memory_model.py:37-58).
+    layers: [(W, [gamma]*5, [beta]*5)] in the order input, transform, forget, output, state.
+    dropout_spec = (keep_prob, [seed per layer]): the candidate of step t is element block t of a [F,B,H] mask tensor."""
+    B, F, _ = x.shape
+    H = layers[0][1][0].numel()
+    c = [x.new_zeros(B, H) for _ in layers]
+    h = [x.new_zeros(B, H) for _ in layers]
+    outs = []
+    for t in range(F):
+        live = (t < num_frames).unsqueeze(1)
+        inp = x[:, t]
+        for l, (W, ga, be) in enumerate(layers):
+            i, j, f, o = (torch.cat([inp, h[l]], 1) @ W).chunk(4, 1)
+            i, j, f, o = [layer_norm(v, ga[k], be[k]) for k, v in enumerate((i, j, f, o))]
+            gg = torch.tanh(j)
+            if dropout_spec is not None:
+                gg = dropout(gg, dropout_spec[0], dropout_spec[1][l], offset=t * B * H)
+            cn = layer_norm(c[l] * torch.sigmoid(f + forget_bias) + torch.sigmoid(i) * gg, ga[4], be[4])
+            hn = torch.tanh(cn) * torch.sigmoid(o)
+            c[l] = torch.where(live, cn, c[l])
+            h[l] = torch.where(live, hn, h[l])
+            inp = hn
+        outs.append(torch.where(live, inp, torch.zeros_like(inp)))
+    return torch.stack(outs, 1), c, h
+
+
 def lstm_model_state(x, num_frames, layers):
     """W/all_frame_models/lstm_model.py:34-52: [c0||h0||c1||h1]."""
     _, c, h = lstm_stack(x, num_frames, layers)

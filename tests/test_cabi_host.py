@@ -97,11 +97,13 @@ def test_plugin_surface(flags):
     for name in ["LstmModel", "LstmMemoryModel", "LstmAttentionMaxPoolingModel", "DbofModel", "FrameLevelLogisticModel",
                  "NetVLADModel", "GatedNetVLADModel",
                  "GatedNetVLADAttentionChainModel", "LstmParallelFinaloutputModel", "LstmPositionalAttentionMaxPoolingModel",
-                 "CnnDeepCombineChainModel"]:
+                 "CnnDeepCombineChainModel", "GruPoolingModel", "GruWithPoolingModel", "LayerNormLstmMemoryModel"]:
         assert issubclass(getattr(flm, name), models.BaseModel), name
     # reference flag names / defaults
     assert flags.moe_num_mixtures == 2 and flags.deep_chain_layers == 3 and flags.deep_chain_relu_cells == 200
     assert flags.lstm_cells == "1024" and flags.lstm_layers == 2 and flags.lstm_attentions == 8
+    assert flags.gru_cells == 1024 and flags.gru_layers == 2 and flags.dropout is False and flags.keep_prob == 1.0
+    assert flags.noise_level == 0.0
     assert flags.video_level_classifier_model == "MoeModel" and flags.dbof_cluster_size == 8192
     assert flags.batch_size == 1024 and flags.base_learning_rate == 0.01 and flags.clip_gradient_norm == 1.0
     assert flags.learning_rate_decay == 0.95 and flags.learning_rate_decay_examples == 4000000

@@ -605,3 +605,73 @@ def test_dropout_and_noise_statistics_and_errors(dev):
     with pytest.raises(ValueError):
         ops.dropout(x, 1.5, seed=1)
     assert ops.dropout(torch.empty(0, device=dev), 0.5, seed=1).numel() == 0
+
+
+def _mkvars(dev, arrays):
+    from yt8m_amd.variables import reset_default_graph, zeros
+    g = reset_default_graph(device=dev)
+    g.begin_step()
+    vs = [g.get_variable("v%d" % i, a.shape, zeros) for i, a in enumerate(arrays)]
+    g.finalize()
+    for v, a in zip(vs, arrays):
+        v.data.copy_(D(a, dev))
+    return vs
+
+
+@pytest.mark.parametrize("B,F,Din,Hh", [(5, 7, 6, 4), (37, 5, 20, 256), (70, 3, 16, 512)])
+def test_gru_layer_fwd_bwd(dev, B, F, Din, Hh):
+    """GRUCell layer vs the oracle (fp64 autograd): H = 4 takes the per-step grouped-GEMM form, H = 256 / 512 the packed MFMA
+    step kernels with fused epilogues (lstm_fused.hip EP_GRU_*), B not a multiple of the 32 / 16 row tiles, ragged num_frames."""
+    from oracle import torch_ref
+    rs = np.random.RandomState(31)
+    x = rs.randn(B, F, Din).astype(np.float32)
+    nf = rs.randint(0, F + 1, size=B).astype(np.int32)
+    nf[:5] = [F, 1, min(4, F), 0, F]
+    sc = 0.4 if Hh < 64 else 0.06
+    arrs = [(rs.randn(Din + Hh, 2 * Hh) * sc).astype(np.float32), (rs.randn(2 * Hh) * 0.1 + 1).astype(np.float32),
+            (rs.randn(Din + Hh, Hh) * sc).astype(np.float32), (rs.randn(Hh) * 0.1).astype(np.float32)]
+    Wg, bg, Wc, bc = _mkvars(dev, arrs)
+    xt = D(x, dev).transpose(0, 1).contiguous().requires_grad_(True)
+    out, h = seq_ops.gru_layer(xt, Wg, bg, Wc, bc, torch.from_numpy(nf).to(dev))
+    go, gh = rs.randn(F, B, Hh).astype(np.float32), rs.randn(B, Hh).astype(np.float32)
+    ((out * D(go, dev)).sum() + (h * D(gh, dev)).sum()).backward()
+    tx = torch.from_numpy(x.astype(np.float64)).requires_grad_(True)
+    tp = [torch.from_numpy(a.astype(np.float64)).requires_grad_(True) for a in arrs]
+    to, th = torch_ref.gru_stack(tx, torch.from_numpy(nf), [tuple(tp)])
+    ((to * torch.from_numpy(go.astype(np.float64)).transpose(0, 1)).sum() + (th[0] * torch.from_numpy(gh.astype(np.float64))).sum()).backward()
+    assert np.abs(H(out).transpose(1, 0, 2) - to.detach().numpy()).max() < 2e-5
+    assert np.abs(H(h) - th[0].detach().numpy()).max() < 2e-5
+    for v, t in zip((Wg, bg, Wc, bc), tp):
+        assert np.abs(H(v.grad) - t.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(t.grad.numpy()).max())
+    assert np.abs(H(xt.grad).transpose(1, 0, 2) - tx.grad.numpy()).max() < 2e-4
+
+
+@pytest.mark.parametrize("B,F,Din,Hh,keep", [(5, 7, 6, 12, 1.0), (37, 5, 20, 256, 1.0), (33, 4, 16, 512, 0.75), (3, 3, 8, 300, 0.5)])
+def test_lnlstm_layer_fwd_bwd(dev, B, F, Din, Hh, keep):
+    """LayerNormBasicLSTMCell layer vs the oracle: generic product (H = 12, 300) and the packed add-only step product
+    (H = 256, 512); recurrent dropout masks from the Philox oracle; gamma / beta gradients of all five normalisations."""
+    from oracle import torch_ref
+    rs = np.random.RandomState(32)
+    x = rs.randn(B, F, Din).astype(np.float32)
+    nf = rs.randint(0, F + 1, size=B).astype(np.int32)
+    nf[:3] = [F, 1, 0]
+    arrs = [(rs.randn(Din + Hh, 4 * Hh) * (0.4 if Hh < 64 else 0.08)).astype(np.float32)]
+    arrs += [(rs.rand(Hh) + 0.5).astype(np.float32) for _ in range(5)] + [(rs.randn(Hh) * 0.2).astype(np.float32) for _ in range(5)]
+    vs = _mkvars(dev, arrs)
+    xt = D(x, dev).transpose(0, 1).contiguous().requires_grad_(True)
+    seed = 0xC0FFEE1234
+    out, c, h = seq_ops.lnlstm_layer(xt, vs[0], vs[1:6], vs[6:11], torch.from_numpy(nf).to(dev), forget_bias=1.0, keep_prob=keep, seed=seed)
+    go, gc, gh = rs.randn(F, B, Hh).astype(np.float32), rs.randn(B, Hh).astype(np.float32), rs.randn(B, Hh).astype(np.float32)
+    ((out * D(go, dev)).sum() + (c * D(gc, dev)).sum() + (h * D(gh, dev)).sum()).backward()
+    tx = torch.from_numpy(x.astype(np.float64)).requires_grad_(True)
+    tp = [torch.from_numpy(a.astype(np.float64)).requires_grad_(True) for a in arrs]
+    to, tc, th = torch_ref.lnlstm_stack(tx, torch.from_numpy(nf), [(tp[0], tp[1:6], tp[6:11])],
+                                        dropout_spec=None if keep >= 1 else (keep, [seed]))
+    ((to * torch.from_numpy(go.astype(np.float64)).transpose(0, 1)).sum() + (tc[0] * torch.from_numpy(gc.astype(np.float64))).sum()
+     + (th[0] * torch.from_numpy(gh.astype(np.float64))).sum()).backward()
+    assert np.abs(H(out).transpose(1, 0, 2) - to.detach().numpy()).max() < 5e-5
+    assert np.abs(H(c) - tc[0].detach().numpy()).max() < 5e-5 and np.abs(H(h) - th[0].detach().numpy()).max() < 5e-5
+    for k, (v, t) in enumerate(zip(vs, tp)):
+        ref = t.grad.numpy()
+        assert np.abs(H(v.grad) - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), k
+    assert np.abs(H(xt.grad).transpose(1, 0, 2) - tx.grad.numpy()).max() < 5e-4 * max(1.0, np.abs(tx.grad.numpy()).max())

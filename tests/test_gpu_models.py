@@ -852,3 +852,73 @@ def test_noise_level_flag(dev, flags):
     lr.backward()
     assert np.abs(H(res["predictions"]) - pr.detach().numpy()).max() < 1e-4
     check_grads(g, tp, tol=5e-4)
+
+
+def _gru_ref_layers(tp, L):
+    s = "RNN/multi_rnn_cell/cell_%d/gru_cell/%s"
+    return [(tp[s % (l, "gates/weights")], tp[s % (l, "gates/biases")], tp[s % (l, "candidate/weights")],
+             tp[s % (l, "candidate/biases")]) for l in range(L)]
+
+
+@pytest.mark.parametrize("cls", ["GruPoolingModel", "GruWithPoolingModel"])
+def test_gru_models(dev, flags, cls):
+    """tf.contrib.rnn.GRUCell stack (W/all_frame_models/gru_pooling_model.py, gru_with_pooling_model.py): ragged num_frames
+    (copy-through + zero outputs), mean over the video's frames, [pooled || h_0 || h_1] for the WithPooling variant."""
+    rs = np.random.RandomState(21)
+    B, F, Dm, Hh, V = 6, 9, 12, 8, 17
+    flags.gru_cells, flags.gru_layers = Hh, 2
+    x = rs.randn(B, F, Dm).astype(np.float32)
+    nf = np.array([9, 1, 5, 9, 3, 7], dtype=np.int32)
+    x *= (np.arange(F)[None, :, None] < nf[:, None, None])
+    y = rs.rand(B, V) < 0.15
+    g, res, loss, P = run_model(getattr(flm, cls)(), x, y, dev, nf=nf, rs=rs)
+    assert g.vars["RNN/multi_rnn_cell/cell_1/gru_cell/gates/weights"].shape == (2 * Hh, 2 * Hh)
+    assert g.vars["gates/weights"].shape[0] == (Hh if cls == "GruPoolingModel" else 3 * Hh)
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    outs, hfin = torch_ref.gru_stack(T(x), torch.from_numpy(nf), _gru_ref_layers(tp, 2))
+    pooled = outs.sum(1) / T(np.maximum(nf, 1)).unsqueeze(1)
+    st = pooled if cls == "GruPoolingModel" else torch.cat([pooled] + hfin, 1)
+    pr = torch_ref.moe(st, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(H(res["predictions"]) - pr.detach().numpy()).max() < 1e-4
+    check_grads(g, tp, tol=5e-4)
+    # fresh variables: the gate bias starts at 1 (TF-1.0 GRUCell), everything else as slim / zeros
+    g2 = reset_default_graph(device=dev, seed=0)
+    g2.begin_step()
+    getattr(flm, cls)().create_model(torch.from_numpy(x).to(dev), vocab_size=V, num_frames=torch.from_numpy(nf).to(dev))
+    assert float(g2.vars["RNN/multi_rnn_cell/cell_0/gru_cell/gates/biases"].data.min()) == 1.0
+    assert float(g2.vars["RNN/multi_rnn_cell/cell_0/gru_cell/candidate/biases"].data.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("keep", [1.0, 0.7])
+def test_layernorm_lstm_memory_model(dev, flags, keep):
+    """tf.contrib.rnn.LayerNormBasicLSTMCell stack (W/all_frame_models/layernorm_lstm_memory_model.py): five layer norms per
+    step with their gamma / beta gradients, normalised cell state carried, recurrent dropout on the candidate with --dropout."""
+    rs = np.random.RandomState(22)
+    B, F, Dm, Hh, V = 6, 8, 12, 10, 17
+    flags.lstm_cells, flags.lstm_layers = str(Hh), 2
+    if keep < 1:
+        flags.dropout, flags.keep_prob = True, keep
+    x = rs.randn(B, F, Dm).astype(np.float32)
+    nf = np.array([8, 1, 5, 8, 3, 7], dtype=np.int32)
+    x *= (np.arange(F)[None, :, None] < nf[:, None, None])
+    y = rs.rand(B, V) < 0.15
+    g, res, loss, P = run_model(flm.LayerNormLstmMemoryModel(), x, y, dev, nf=nf, rs=rs)
+    s = "RNN/multi_rnn_cell/cell_%d/layer_norm_basic_lstm_cell/%s"
+    assert g.vars[s % (1, "weights")].shape == (2 * Hh, 4 * Hh) and (s % (0, "biases")) not in g.vars
+    assert g.vars["gates/weights"].shape[0] == 2 * Hh
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    layers = [(tp[s % (l, "weights")], [tp[s % (l, n + "/gamma")] for n in flm.LN_GATES],
+               [tp[s % (l, n + "/beta")] for n in flm.LN_GATES]) for l in range(2)]
+    _, c, _ = torch_ref.lnlstm_stack(T(x), torch.from_numpy(nf), layers,
+                                     dropout_spec=None if keep >= 1 else (keep, _step_seeds(2)))
+    pr = torch_ref.moe(torch.cat(c, 1), tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(H(res["predictions"]) - pr.detach().numpy()).max() < 1e-4
+    check_grads(g, tp, tol=5e-4)
+    g2 = reset_default_graph(device=dev, seed=0)
+    g2.begin_step()
+    flm.LayerNormLstmMemoryModel().create_model(torch.from_numpy(x).to(dev), vocab_size=V, num_frames=torch.from_numpy(nf).to(dev))
+    assert float(g2.vars[s % (0, "state/gamma")].data.min()) == 1.0 and float(g2.vars[s % (0, "input/beta")].data.abs().max()) == 0.0

@@ -41,6 +41,12 @@ CONFIGS = {
     "lstm_posattn": dict(model=flm.LstmPositionalAttentionMaxPoolingModel, B=128, frame=True),
     "cnn_chain": dict(model=flm.CnnDeepCombineChainModel, B=128, frame=True, multitask=True,
                       flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3))),
+    "gru_pool": dict(model=flm.GruPoolingModel, B=128, frame=True),
+    "ln_lstm": dict(model=flm.LayerNormLstmMemoryModel, B=128, frame=True),
+    "lstm_mem_dropout": dict(model=flm.LstmMemoryModel, B=128, frame=True, flags=dict(dropout=True, keep_prob=0.8)),
+    "chain_dropout": dict(model=vlm.DeepCombineChainModel, B=512, frame=False, multitask=True,
+                          flags=dict(deep_chain_layers=8, deep_chain_relu_cells=128, support_type=",".join(["label"] * 8),
+                                     dropout=True, keep_prob=0.8)),
     "dbof": dict(model=flm.DbofModel, B=128, frame=True, flags=dict(dbof_add_batch_norm=False)),
 }
 

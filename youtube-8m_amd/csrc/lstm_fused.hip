@@ -20,34 +20,46 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Wp[ug][k][c], c = gate*8 + u  <-  Wh[k][gate*H + ug*8 + u]        (H/8 groups, k < H)
-// Wq[ug][k][u]                  <-  Wh[ug*16 + u][k]                 (H/16 groups, k < 4H)
+// G gates of H units each (LSTM 4: i|j|f|o, GRU gate block 2: r|u, GRU candidate 1); U = 32 / G units per group.
+// Wp[ug][k][c], c = gate*U + u  <-  Wh[k][gate*H + ug*U + u]        (H/U groups, k < H)
+// Wq[ug][k][u]                  <-  Wh[ug*16 + u][k]                 (H/16 groups, k < G*H)
 __global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ Wh, int64_t ldw, float* __restrict__ Wp,
-                                                        float* __restrict__ Wq, int H) {
-  const int64_t n = (int64_t)H * 4 * H;
+                                                        float* __restrict__ Wq, int H, int G) {
+  const int64_t n = (int64_t)H * G * H;
+  const int U = 32 / G, K = G * H;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     if (Wp) {
       const int c = (int)(e & 31);
       const int64_t r = e >> 5;           // ug*H + k
       const int k = (int)(r % H), ug = (int)(r / H);
-      Wp[e] = Wh[(int64_t)k * ldw + (c >> 3) * H + ug * 8 + (c & 7)];
+      Wp[e] = Wh[(int64_t)k * ldw + (c / U) * H + ug * U + (c % U)];
     }
     if (Wq) {
       const int u = (int)(e & 15);
-      const int64_t r = e >> 4;           // ug*4H + k
-      const int k = (int)(r % (4 * H)), ug = (int)(r / (4 * H));
+      const int64_t r = e >> 4;           // ug*K + k
+      const int k = (int)(r % K), ug = (int)(r / K);
       Wq[e] = Wh[(int64_t)(ug * 16 + u) * ldw + k];
     }
   }
 }
 
+// epilogues of the forward step kernel
+enum { EP_LSTM = 0,        // G = 4: BasicLSTMCell gates + cell update + copy-through
+       EP_ADD = 1,         // any G: z += a . W only (LayerNormBasicLSTMCell: the normalisations need whole rows -> cells.hip)
+       EP_GRU_GATES = 2,   // G = 2: r|u = sigmoid(zg + h . Wg_h), stored over zg; rh = r * h
+       EP_GRU_CAND = 3 };  // G = 1: c = tanh(zc + rh . Wc_h) stored over zc; h' = u*h + (1-u)*c with copy-through
+
+// a_in [B,H]: the A operand of the recurrent product (h_{t-1}; r*h for the GRU candidate).  gates / rh: GRU only.
+template <int G, int EP>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ z, const float* __restrict__ Wp,
-                                                            const float* __restrict__ c_prev, const float* __restrict__ h_prev,
-                                                            float* __restrict__ c_new, float* __restrict__ h_new,
-                                                            float* __restrict__ out, const int32_t* __restrict__ nf, int t, int B,
-                                                            int H, float fb) {
+                                                            const float* __restrict__ a_in, const float* __restrict__ c_prev,
+                                                            const float* __restrict__ h_prev, float* __restrict__ c_new,
+                                                            float* __restrict__ h_new, float* __restrict__ out,
+                                                            const int32_t* __restrict__ nf, int t, int B, int H, float fb,
+                                                            const float* __restrict__ gates, float* __restrict__ rh) {
   __shared__ float red[4][32][33];
-  const int groups = H >> 3;
+  constexpr int U = 32 / G;
+  const int groups = H / U;
   const int ug = blockIdx.x % groups, rt = blockIdx.x / groups;
   const int m0 = rt * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -55,7 +67,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   const int kq = H >> 2;                                   // K-range of one wave
   int row = m0 + i;
   if (row >= B) row = B - 1;                               // clamped rows feed output rows >= B only (never stored)
-  const float* ap = h_prev + (int64_t)row * H + w * kq + 4 * kh;
+  const float* ap = a_in + (int64_t)row * H + w * kq + 4 * kh;
   const float* bp = Wp + ((int64_t)ug * H + w * kq + 4 * kh) * 32 + i;
   f32x16 acc;
 #pragma unroll
@@ -85,6 +97,32 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   const int r = tid >> 3, u = tid & 7;
   const int b = m0 + r;
   if (b >= B) return;
+  if (EP != EP_LSTM) {
+    const bool live = nf ? (t < nf[b]) : true;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int c = u + 8 * jj;                              // column of the 32-wide group
+      const float sum = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+      if (EP == EP_ADD) {
+        z[(int64_t)b * G * H + (c / U) * H + ug * U + (c % U)] += sum;
+      } else if (EP == EP_GRU_GATES) {                       // columns 0..15 = r of 16 units, 16..31 = u of the same units
+        const int unit = ug * 16 + (c & 15);
+        float* zp = z + (int64_t)b * 2 * H + (c >> 4) * H + unit;
+        const float gv = sigmoidf_(*zp + sum);
+        *zp = gv;
+        if (c < 16) rh[(int64_t)b * H + unit] = gv * h_prev[(int64_t)b * H + unit];
+      } else {                                               // EP_GRU_CAND
+        const int64_t idx = (int64_t)b * H + ug * 32 + c;
+        const float cand = tanhf(z[idx] + sum);
+        z[idx] = cand;
+        const float uu = gates[(int64_t)b * 2 * H + H + ug * 32 + c], hp = h_prev[idx];
+        const float hn = live ? uu * hp + (1.0f - uu) * cand : hp;
+        h_new[idx] = hn;
+        if (out) out[idx] = live ? hn : 0.f;
+      }
+    }
+    return;
+  }
   const int unit = ug * 8 + u;
   const int64_t idx = (int64_t)b * H + unit;
   const bool live = nf ? (t < nf[b]) : true;
@@ -111,22 +149,27 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   if (out) out[idx] = hn;
 }
 
-// dh_prev[B,H] += dz[B,4H] . Wh^T     (16 rows x 16 units per workgroup, v_mfma_f32_16x16x4_f32, K = 4H over 4 waves)
+// dh_prev[B,H] += dz[B,K] . Wh^T, K = G*H (16 rows x 16 units per workgroup, v_mfma_f32_16x16x4_f32, K over 4 waves)
+// BEP 0: accumulate (LSTM, LN-LSTM, GRU gate block).  BEP 1 (GRU candidate, K = H): the product is d(r*h):
+//        dzg_r = d * h * r * (1 - r) for live rows (0 otherwise), dh_prev += d * r.
+template <int BEP>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ Wq,
-                                                            float* __restrict__ dh_prev, int B, int H) {
+                                                            float* __restrict__ dh_prev, int B, int H, int K4,
+                                                            const float* __restrict__ gates, const float* __restrict__ h_prev,
+                                                            float* __restrict__ dzg, const int32_t* __restrict__ nf, int t) {
   __shared__ float red[4][16][17];
   const int groups = H >> 4;
   const int ug = blockIdx.x % groups, rt = blockIdx.x / groups;
   const int m0 = rt * 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int K4 = 4 * H;
+  const int KW = K4 >> 2;                                   // K-range of one wave
   int row = m0 + i;
   if (row >= B) row = B - 1;
-  const float* ap = dz + (int64_t)row * K4 + w * H + 4 * kq;
-  const float* bp = Wq + ((int64_t)ug * K4 + w * H + 4 * kq) * 16 + i;
+  const float* ap = dz + (int64_t)row * K4 + w * KW + 4 * kq;
+  const float* bp = Wq + ((int64_t)ug * K4 + w * KW + 4 * kq) * 16 + i;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: 16x16x4 has 40-cycle dependent latency
-  for (int g0 = 0; g0 < H; g0 += 64) {        // H % 64 == 0; 4 groups of 16 k in flight
+  for (int g0 = 0; g0 < KW; g0 += 64) {       // KW % 64 == 0; 4 groups of 16 k in flight
     float4 a[4];
     float bb[4][4];
 #pragma unroll
@@ -152,7 +195,16 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   const int b = m0 + r;
   if (b >= B) return;
   float* d = dh_prev + (int64_t)b * H + ug * 16 + u;
-  *d += (red[0][r][u] + red[1][r][u]) + (red[2][r][u] + red[3][r][u]);
+  const float sum = (red[0][r][u] + red[1][r][u]) + (red[2][r][u] + red[3][r][u]);
+  if (BEP == 0) {
+    *d += sum;
+  } else {
+    const bool live = nf ? (t < nf[b]) : true;
+    const int64_t gi = (int64_t)b * 2 * H + ug * 16 + u;
+    const float rr = gates[gi];
+    dzg[gi] = live ? sum * h_prev[(int64_t)b * H + ug * 16 + u] * rr * (1.0f - rr) : 0.f;
+    if (live) *d += sum * rr;
+  }
 }
 
 }  // namespace
@@ -164,22 +216,74 @@ bool lstm_fused_supported(int64_t B, int64_t H, int64_t workspace_bytes) {
 }
 
 int lstm_pack(const float* Wh, int64_t ldw, float* Wp, float* Wq, int64_t H, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_pack_kernel, dim3(2048), dim3(256), 0, s, Wh, ldw, Wp, Wq, (int)H);
+  hipLaunchKernelGGL(lstm_pack_kernel, dim3(2048), dim3(256), 0, s, Wh, ldw, Wp, Wq, (int)H, 4);
   return launch_status("lstm_pack_kernel");
 }
 
 int lstm_step_fwd(float* z, const float* Wp, const float* c_prev, const float* h_prev, float* c_new, float* h_new, float* out,
                   const int32_t* nf, int t, int64_t B, int64_t H, float fb, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 8));
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(grid), dim3(256), 0, s, z, Wp, c_prev, h_prev, c_new, h_new, out, nf, t, (int)B,
-                     (int)H, fb);
+  hipLaunchKernelGGL((lstm_step_fwd_kernel<4, EP_LSTM>), dim3(grid), dim3(256), 0, s, z, Wp, h_prev, c_prev, h_prev, c_new,
+                     h_new, out, nf, t, (int)B, (int)H, fb, (const float*)nullptr, (float*)nullptr);
   return launch_status("lstm_step_fwd_kernel");
 }
 
 int lstm_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
-  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H);
+  hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(4 * H),
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0);
   return launch_status("lstm_step_bwd_kernel");
+}
+
+// ---- the same packed-weight step products for the other cells (cells.hip) ----------------------------------------------
+// G gates: packed sizes are H * G*H floats for both Wp and Wq.  Needs H % 256 == 0 (the K = H backward split).
+bool cell_packed_supported(int64_t B, int64_t H) { return B >= 1 && H >= 256 && (H % 256) == 0; }
+
+int cell_pack(const float* Wh, int64_t ldw, float* Wp, float* Wq, int64_t H, int G, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pack_kernel, dim3(2048), dim3(256), 0, s, Wh, ldw, Wp, Wq, (int)H, G);
+  return launch_status("lstm_pack_kernel");
+}
+
+// z[B,4H] += h . Wh (packed, G = 4), nothing else
+int cell_step_add4(float* z, const float* Wp, const float* h_prev, int64_t B, int64_t H, hipStream_t s) {
+  const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 8));
+  hipLaunchKernelGGL((lstm_step_fwd_kernel<4, EP_ADD>), dim3(grid), dim3(256), 0, s, z, Wp, h_prev, (const float*)nullptr, h_prev,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0, (int)B, (int)H, 0.f,
+                     (const float*)nullptr, (float*)nullptr);
+  return launch_status("lstm_step_fwd_kernel<add>");
+}
+
+int gru_step_gates(float* zg, const float* Wp_g, const float* h_prev, float* rh, int64_t B, int64_t H, hipStream_t s) {
+  const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 16));
+  hipLaunchKernelGGL((lstm_step_fwd_kernel<2, EP_GRU_GATES>), dim3(grid), dim3(256), 0, s, zg, Wp_g, h_prev, (const float*)nullptr,
+                     h_prev, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0, (int)B, (int)H, 0.f,
+                     (const float*)nullptr, rh);
+  return launch_status("lstm_step_fwd_kernel<gru gates>");
+}
+
+int gru_step_cand(float* zc, const float* Wp_c, const float* rh, const float* zg, const float* h_prev, float* h_new, float* out,
+                  const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s) {
+  const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 32));
+  hipLaunchKernelGGL((lstm_step_fwd_kernel<1, EP_GRU_CAND>), dim3(grid), dim3(256), 0, s, zc, Wp_c, rh, (const float*)nullptr, h_prev,
+                     (float*)nullptr, h_new, out, nf, t, (int)B, (int)H, 0.f, zg, (float*)nullptr);
+  return launch_status("lstm_step_fwd_kernel<gru candidate>");
+}
+
+// dh_prev += dz[B,G*H] . Wh^T
+int cell_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, int G, hipStream_t s) {
+  const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
+  hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(G * H),
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0);
+  return launch_status("lstm_step_bwd_kernel");
+}
+
+// d(r*h) = dzc . Wc_h^T folded into dzg_r and dh_prev
+int gru_step_bwd_cand(const float* dzc, const float* Wq_c, float* dh_prev, const float* zg, const float* h_prev, float* dzg,
+                      const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s) {
+  const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
+  hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), dim3(grid), dim3(256), 0, s, dzc, Wq_c, dh_prev, (int)B, (int)H, (int)H, zg, h_prev,
+                     dzg, nf, t);
+  return launch_status("lstm_step_bwd_kernel<gru candidate>");
 }
 
 }  // namespace yt8m

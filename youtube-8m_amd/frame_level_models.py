@@ -24,6 +24,8 @@ DEFINE_bool("rnn_swap_memory", False, "If true, swap_memory = True.  (No numeric
 DEFINE_string("lstm_cells", "1024", "Number of LSTM cells.")
 DEFINE_integer("lstm_layers", 2, "Number of LSTM layers.")
 # new: time chunks of the layer-pipelined LSTM stack (1 = one layer after the other)
+DEFINE_integer("gru_cells", 1024, "Number of GRU cells.")
+DEFINE_integer("gru_layers", 2, "Number of GRU layers.")
 DEFINE_integer("lstm_pipeline_chunks", 4, "Time chunks over which the layers of the LSTM stack are pipelined on separate streams.")
 DEFINE_string("feature_sizes", "1024", "Length of the feature vectors.")     # W/train.py:58 (read by the parallel LSTM model)
 DEFINE_integer("positional_embedding_size", 32, "Positional embedding dimension use in lstm_positional_attention_max_pooling_model.")
@@ -100,6 +102,90 @@ class LstmMemoryModel(models.BaseModel):
             final_state = ops.add_noise(final_state, noise_level)
         return _head()().create_model(model_input=final_state, original_input=model_input, vocab_size=vocab_size,
                                       num_frames=num_frames, **unused_params)
+
+
+def _gru_stack(model_input, num_frames, gru_size, number_of_layers):
+    """MultiRNNCell([GRUCell(H)] * L, state_is_tuple=False) under tf.nn.dynamic_rnn in variable_scope("RNN")
+    (W/all_frame_models/gru_pooling_model.py:34-47).  TF-1.0 names: RNN/multi_rnn_cell/cell_<l>/gru_cell/{gates,candidate}/
+    {weights,biases}; the gate bias starts at 1.  Returns (top outputs time-major [F,B,H], [h_l final])."""
+    g = get_default_graph()
+    x_tm = model_input.transpose(0, 1).contiguous()
+    finals = []
+    d_in = x_tm.shape[2]
+    with g.variable_scope("RNN"):
+        for l in range(number_of_layers):
+            scope = "multi_rnn_cell/cell_%d/gru_cell" % l
+            Wg = g.get_variable(scope + "/gates/weights", (d_in + gru_size, 2 * gru_size), xavier_uniform)
+            bg = g.get_variable(scope + "/gates/biases", (2 * gru_size,), ones)
+            Wc = g.get_variable(scope + "/candidate/weights", (d_in + gru_size, gru_size), xavier_uniform)
+            bc = g.get_variable(scope + "/candidate/biases", (gru_size,), zeros)
+            x_tm, h = seq_ops.gru_layer(x_tm, Wg, bg, Wc, bc, num_frames)
+            finals.append(h)
+            d_in = gru_size
+    return x_tm, finals
+
+
+def _mean_over_frames(out_tm, num_frames):
+    """reduce_sum(outputs, axis=1) / max(num_frames, 1) (W/all_frame_models/gru_pooling_model.py:48-49): dynamic_rnn outputs
+    are zero past num_frames, so this is one [1,F] x [F,H] product per video with constant weights 1 / max(num_frames, 1)."""
+    F, B, H = out_tm.shape
+    w = (1.0 / num_frames.to(torch.float32).clamp(min=1.0)).view(B, 1, 1).expand(B, F, 1).contiguous()
+    return seq_ops.pool_tn(w, out_tm.transpose(0, 1).contiguous()).view(B, H)
+
+
+class GruPoolingModel(models.BaseModel):
+    """W/all_frame_models/gru_pooling_model.py:13-58: GRU stack, head input = outputs averaged over the video's frames.
+    (The reference file divides by tf.maximum(num_frames, tf.ones([batch_size, 1])) with `batch_size` undefined -- it raises
+    NameError at graph construction; built here with the evident meaning.)"""
+
+    def create_model(self, model_input, vocab_size, num_frames, **unused_params):
+        out_tm, _ = _gru_stack(model_input, num_frames, FLAGS.gru_cells, FLAGS.gru_layers)
+        pooling_output = _mean_over_frames(out_tm, num_frames)
+        return _head()().create_model(model_input=pooling_output, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
+
+
+class GruWithPoolingModel(models.BaseModel):
+    """W/all_frame_models/gru_with_pooling_model.py:13-60: head input = [mean-pooled outputs || final state of every layer]
+    (state_is_tuple=False: [h_0 || h_1 ...]).  Same `batch_size` NameError in the reference as GruPoolingModel."""
+
+    def create_model(self, model_input, vocab_size, num_frames, **unused_params):
+        out_tm, finals = _gru_stack(model_input, num_frames, FLAGS.gru_cells, FLAGS.gru_layers)
+        final_output = torch.cat([_mean_over_frames(out_tm, num_frames)] + finals, dim=1)
+        return _head()().create_model(model_input=final_output, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
+
+
+LN_GATES = ("input", "transform", "forget", "output", "state")
+
+
+class LayerNormLstmMemoryModel(models.BaseModel):
+    """W/all_frame_models/layernorm_lstm_memory_model.py:13-72: MultiRNNCell([LayerNormBasicLSTMCell(H)] * L); with --dropout the
+    cells get dropout_keep_prob=keep_prob (recurrent dropout on the candidate); head input = concat of the (normalised) c
+    states.  TF-1.0 names: RNN/multi_rnn_cell/cell_<l>/layer_norm_basic_lstm_cell/{weights, <gate>/gamma, <gate>/beta}."""
+
+    def create_model(self, model_input, vocab_size, num_frames, dropout=False, keep_prob=None, noise_level=None,
+                     **unused_params):
+        lstm_size = int(FLAGS.lstm_cells)
+        g = get_default_graph()
+        x_tm = model_input.transpose(0, 1).contiguous()
+        cs = []
+        d_in = x_tm.shape[2]
+        with g.variable_scope("RNN"):
+            for l in range(FLAGS.lstm_layers):
+                scope = "multi_rnn_cell/cell_%d/layer_norm_basic_lstm_cell" % l
+                W = g.get_variable(scope + "/weights", (d_in + lstm_size, 4 * lstm_size), xavier_uniform)
+                gammas = [g.get_variable("%s/%s/gamma" % (scope, n), (lstm_size,), ones) for n in LN_GATES]
+                betas = [g.get_variable("%s/%s/beta" % (scope, n), (lstm_size,), zeros) for n in LN_GATES]
+                x_tm, c, _ = seq_ops.lnlstm_layer(x_tm, W, gammas, betas, num_frames, forget_bias=1.0,
+                                                  keep_prob=keep_prob if (dropout and keep_prob is not None) else 1.0)
+                cs.append(c)
+                d_in = lstm_size
+        final_state = torch.cat(cs, dim=1)
+        if noise_level is not None:
+            final_state = ops.add_noise(final_state, noise_level)
+        return _head()().create_model(model_input=final_state, original_input=model_input, vocab_size=vocab_size,
+                                      **unused_params)
 
 
 class LstmAttentionMaxPoolingModel(models.BaseModel):

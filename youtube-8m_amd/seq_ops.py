@@ -77,6 +77,161 @@ def lstm_layer(x_tm, W, b, num_frames, forget_bias=1.0):
     return _LstmLayer.apply(x_tm, _token(W._graph), W, b, num_frames, forget_bias)
 
 
+class _GruLayer(torch.autograd.Function):
+    """One tf.contrib.rnn.GRUCell layer under tf.nn.dynamic_rnn (W/all_frame_models/gru_pooling_model.py:34-47), time-major.
+    x_tm [F,B,in]; Wg "gates/weights" [in+H, 2H] (r | u), bg "gates/biases" [2H]; Wc "candidate/weights" [in+H, H],
+    bc "candidate/biases" [H].  Returns (out_tm [F,B,H], h_final [B,H]).  The input halves of both projections are hoisted
+    GEMMs over all steps; yt8m_gru_layer_fwd / _bwd hold the time loop."""
+
+    @staticmethod
+    def forward(ctx, x_tm, token, Wg, bg, Wc, bc, num_frames):
+        x_tm = _f32c(x_tm)
+        _dev(x_tm)
+        F, B, Din = x_tm.shape
+        H = Wc.data.shape[1]
+        assert Wg.data.shape == (Din + H, 2 * H) and Wc.data.shape[0] == Din + H, "GRU weights must be [in + H, 2H] / [in + H, H]"
+        dev = x_tm.device
+        x2 = x_tm.view(F * B, Din)
+        zg = torch.empty((F, B, 2 * H), dtype=torch.float32, device=dev)
+        zc = torch.empty((F, B, H), dtype=torch.float32, device=dev)
+        ops.gemm_grouped([dict(A=x2, B=Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data),
+                          dict(A=x2, B=Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data)])
+        hs = torch.empty((F + 1, B, H), dtype=torch.float32, device=dev)
+        hs[0].zero_()
+        rh = torch.empty((F, B, H), dtype=torch.float32, device=dev)
+        out = torch.empty((F, B, H), dtype=torch.float32, device=dev)
+        nf = _nf(num_frames)
+        ws = ops._workspace(dev)
+        _lib.check(_lib.lib().yt8m_gru_layer_fwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(rh),
+                                                 _p(out), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _stream()))
+        ctx.save_for_backward(x_tm)
+        ctx.state = (zg, zc, hs, rh, nf, Wg, bg, Wc, bc)
+        ctx.set_materialize_grads(False)
+        return out, hs[F]
+
+    @staticmethod
+    def backward(ctx, dout, dh_final):
+        (x_tm,) = ctx.saved_tensors
+        zg, zc, hs, rh, nf, Wg, bg, Wc, bc = ctx.state
+        ctx.state = None
+        F, B, Din = x_tm.shape
+        H = Wc.data.shape[1]
+        dev = x_tm.device
+        dzg = torch.empty((F, B, 2 * H), dtype=torch.float32, device=dev)
+        dzc = torch.empty((F, B, H), dtype=torch.float32, device=dev)
+        work = torch.empty((3, B, H), dtype=torch.float32, device=dev)
+        dout = None if dout is None else _f32c(dout)
+        dh_final = None if dh_final is None else _f32c(dh_final)
+        ws = ops._workspace(dev)
+        _lib.check(_lib.lib().yt8m_gru_layer_bwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(dout),
+                                                 _p(dh_final), _p(dzg), _p(dzc), _p(work), _p(nf), F, B, H, _p(ws),
+                                                 ws.numel() * 4, _stream()))
+        x2, g2, c2 = x_tm.view(F * B, Din), dzg.view(F * B, 2 * H), dzc.view(F * B, H)
+        if Wg.grad is not None:
+            beta = Wg.grad_beta()
+            ops.gemm_grouped([dict(A=x2, B=g2, out=Wg.grad[:Din], beta=beta),
+                              dict(A=hs[:F].view(F * B, H), B=g2, out=Wg.grad[Din:], beta=beta)], transA=True)
+            Wg.grad_done()
+        if Wc.grad is not None:
+            beta = Wc.grad_beta()
+            ops.gemm_grouped([dict(A=x2, B=c2, out=Wc.grad[:Din], beta=beta),
+                              dict(A=rh.view(F * B, H), B=c2, out=Wc.grad[Din:], beta=beta)], transA=True)
+            Wc.grad_done()
+        if bg.grad is not None:
+            ops.colsum(g2, bg.grad.view(-1), beta=bg.grad_beta())
+            bg.grad_done()
+        if bc.grad is not None:
+            ops.colsum(c2, bc.grad.view(-1), beta=bc.grad_beta())
+            bc.grad_done()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(g2, Wg.data[:Din], transB=True)
+            ops.gemm(c2, Wc.data[:Din], out=dx, transB=True, beta=1.0)
+            dx = dx.view(F, B, Din)
+        return dx, None, None, None, None, None, None
+
+
+def gru_layer(x_tm, Wg, bg, Wc, bc, num_frames):
+    return _GruLayer.apply(x_tm, _token(Wg._graph), Wg, bg, Wc, bc, num_frames)
+
+
+class _LnLstmLayer(torch.autograd.Function):
+    """One tf.contrib.rnn.LayerNormBasicLSTMCell layer under tf.nn.dynamic_rnn
+    (W/all_frame_models/layernorm_lstm_memory_model.py:37-58), time-major.  W "weights" [in+H, 4H] (no bias); gammas / betas:
+    five Variables each, in the order input, transform, forget, output, state.  keep_prob < 1 = the cell's dropout_keep_prob
+    (tf.nn.dropout on the candidate g; mask = Philox stream of `seed`, replayed in backward).
+    Returns (out_tm, c_final, h_final) -- c is the layer-normalised cell state, as in the TF cell."""
+
+    @staticmethod
+    def forward(ctx, x_tm, token, W, gammas, betas, num_frames, forget_bias, keep_prob, seed):
+        x_tm = _f32c(x_tm)
+        _dev(x_tm)
+        F, B, Din = x_tm.shape
+        H = W.data.shape[1] // 4
+        assert W.data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
+        dev = x_tm.device
+        z = ops.gemm(x_tm.view(F * B, Din), W.data[:Din]).view(F, B, 4 * H)
+        gamma = torch.stack([v.data for v in gammas]).contiguous()
+        beta = torch.stack([v.data for v in betas]).contiguous()
+        stats = torch.zeros((F, B, 10), dtype=torch.float32, device=dev)
+        cs = torch.empty((F + 1, B, H), dtype=torch.float32, device=dev)
+        hs = torch.empty((F + 1, B, H), dtype=torch.float32, device=dev)
+        cs[0].zero_()
+        hs[0].zero_()
+        out = torch.empty((F, B, H), dtype=torch.float32, device=dev)
+        nf = _nf(num_frames)
+        ws = ops._workspace(dev)
+        _lib.check(_lib.lib().yt8m_lnlstm_layer_fwd(_p(z), _p(W.data[Din:]), 4 * H, _p(gamma), _p(beta), _p(stats), _p(cs), _p(hs),
+                                                    _p(out), _p(nf), F, B, H, float(forget_bias), float(keep_prob), int(seed),
+                                                    _p(ws), ws.numel() * 4, _stream()))
+        ctx.save_for_backward(x_tm)
+        ctx.state = (z, gamma, beta, stats, cs, hs, nf, W, gammas, betas, float(forget_bias), float(keep_prob), int(seed))
+        ctx.set_materialize_grads(False)
+        return out, cs[F], hs[F]
+
+    @staticmethod
+    def backward(ctx, dout, dc_final, dh_final):
+        (x_tm,) = ctx.saved_tensors
+        z, gamma, beta, stats, cs, hs, nf, W, gammas, betas, fb, keep, seed = ctx.state
+        ctx.state = None
+        F, B, Din = x_tm.shape
+        H = W.data.shape[1] // 4
+        dev = x_tm.device
+        dz = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
+        dyb = torch.empty((F, B, 5 * H), dtype=torch.float32, device=dev)
+        dyg = torch.empty((F, B, 5 * H), dtype=torch.float32, device=dev)
+        work = torch.empty((4, B, H), dtype=torch.float32, device=dev)
+        dout = None if dout is None else _f32c(dout)
+        dc_final = None if dc_final is None else _f32c(dc_final)
+        dh_final = None if dh_final is None else _f32c(dh_final)
+        ws = ops._workspace(dev)
+        _lib.check(_lib.lib().yt8m_lnlstm_layer_bwd(_p(z), _p(W.data[Din:]), 4 * H, _p(gamma), _p(beta), _p(stats), _p(cs), _p(dout),
+                                                    _p(dc_final), _p(dh_final), _p(dz), _p(dyb), _p(dyg), _p(work), _p(nf), F, B, H,
+                                                    fb, keep, seed, _p(ws), ws.numel() * 4, _stream()))
+        dz2 = dz.view(F * B, 4 * H)
+        if W.grad is not None:
+            b = W.grad_beta()
+            ops.gemm_grouped([dict(A=x_tm.view(F * B, Din), B=dz2, out=W.grad[:Din], beta=b),
+                              dict(A=hs[:F].view(F * B, H), B=dz2, out=W.grad[Din:], beta=b)], transA=True)
+            W.grad_done()
+        yb, yg = dyb.view(F * B, 5 * H), dyg.view(F * B, 5 * H)
+        for k in range(5):
+            for v, src in ((gammas[k], yg), (betas[k], yb)):
+                if v.grad is not None:
+                    ops.colsum(src[:, k * H:(k + 1) * H], v.grad.view(-1), beta=v.grad_beta())
+                    v.grad_done()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dz2, W.data[:Din], transB=True).view(F, B, Din)
+        return dx, None, None, None, None, None, None, None, None
+
+
+def lnlstm_layer(x_tm, W, gammas, betas, num_frames, forget_bias=1.0, keep_prob=1.0, seed=None):
+    if seed is None:
+        seed = W._graph.next_random_seed() if float(keep_prob) < 1.0 else 0
+    return _LnLstmLayer.apply(x_tm, _token(W._graph), W, tuple(gammas), tuple(betas), num_frames, forget_bias, keep_prob, seed)
+
+
 # ---- MultiRNNCell stack, pipelined over time chunks ----------------------------------------------------------------
 _SIDE = {}
 
