@@ -15,29 +15,36 @@
 // 16 rows x 16 units per workgroup (512 workgroups) over Wq[unit-group][k][16], K = 4H split over the four waves.
 #include "common.h"
 
+#ifndef STEP_KDIV
+#define STEP_KDIV 1     // timing experiments only (tools/build_variant.sh -DSTEP_KDIV=n): run 1/n of every K loop
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // G gates of H units each (LSTM 4: i|j|f|o, GRU gate block 2: r|u, GRU candidate 1); U = 32 / G units per group.
-// Wp[ug][k][c], c = gate*U + u  <-  Wh[k][gate*H + ug*U + u]        (H/U groups, k < H)
-// Wq[ug][k][u]                  <-  Wh[ug*16 + u][k]                 (H/16 groups, k < G*H)
+// Both packed forms keep FOUR consecutive k of one column adjacent, so a lane fetches its B fragments for four successive
+// MFMAs with one 16-byte load and a wave-wide load instruction reads 1 KB contiguous (8 full cache lines):
+// Wp[ug][k/4][c][k%4], c = gate*U + u  <-  Wh[k][gate*H + ug*U + u]      (H/U groups, k < H)
+// Wq[ug][k/4][u][k%4]                  <-  Wh[ug*16 + u][k]               (H/16 groups, k < G*H)
 __global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ Wh, int64_t ldw, float* __restrict__ Wp,
                                                         float* __restrict__ Wq, int H, int G) {
   const int64_t n = (int64_t)H * G * H;
   const int U = 32 / G, K = G * H;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int k4 = (int)(e & 3);
     if (Wp) {
-      const int c = (int)(e & 31);
-      const int64_t r = e >> 5;           // ug*H + k
-      const int k = (int)(r % H), ug = (int)(r / H);
+      const int c = (int)((e >> 2) & 31);
+      const int64_t r = e >> 7;           // ug*(H/4) + kb
+      const int k = (int)(r % (H >> 2)) * 4 + k4, ug = (int)(r / (H >> 2));
       Wp[e] = Wh[(int64_t)k * ldw + (c / U) * H + ug * U + (c % U)];
     }
     if (Wq) {
-      const int u = (int)(e & 15);
-      const int64_t r = e >> 4;           // ug*K + k
-      const int k = (int)(r % K), ug = (int)(r / K);
+      const int u = (int)((e >> 2) & 15);
+      const int64_t r = e >> 6;           // ug*(K/4) + kb
+      const int k = (int)(r % (K >> 2)) * 4 + k4, ug = (int)(r / (K >> 2));
       Wq[e] = Wh[(int64_t)(ug * 16 + u) * ldw + k];
     }
   }
@@ -50,7 +57,10 @@ enum { EP_LSTM = 0,        // G = 4: BasicLSTMCell gates + cell update + copy-th
        EP_GRU_CAND = 3 };  // G = 1: c = tanh(zc + rh . Wc_h) stored over zc; h' = u*h + (1-u)*c with copy-through
 
 // a_in [B,H]: the A operand of the recurrent product (h_{t-1}; r*h for the GRU candidate).  gates / rh: GRU only.
-template <int G, int EP>
+// MODE bit 0: software prefetch of the next 32-k block; bit 1: the A tile (32 rows x 32 k per wave and block) is fetched
+// with line-coalesced loads (a wave instruction = 8 rows x 128 B) and re-read in MFMA fragment order from a wave-private
+// padded LDS tile -- fetching fragments directly costs four partial touches of every 128-byte line.
+template <int G, int EP, int MODE>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ z, const float* __restrict__ Wp,
                                                             const float* __restrict__ a_in, const float* __restrict__ c_prev,
                                                             const float* __restrict__ h_prev, float* __restrict__ c_new,
@@ -65,30 +75,94 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 31, kh = lane >> 5;
   const int kq = H >> 2;                                   // K-range of one wave
-  int row = m0 + i;
-  if (row >= B) row = B - 1;                               // clamped rows feed output rows >= B only (never stored)
-  const float* ap = a_in + (int64_t)row * H + w * kq + 4 * kh;
-  const float* bp = Wp + ((int64_t)ug * H + w * kq + 4 * kh) * 32 + i;
+  constexpr bool PREF = (MODE & 1) != 0, STAGE = (MODE & 2) != 0;
+  __shared__ float stage[STAGE ? 4 : 1][STAGE ? 32 * 36 : 1];   // per wave: 32 rows x (32 k + 4 pad) floats
+  // A addressing.  direct: lane (i, kh) reads its fragment row i, k = 8q + 4kh.. ; staged: lane l reads row l/8 + 8j, the
+  // 16-byte chunk l%8 of the block's 128-byte row segment.
+  const int srow = lane >> 3, sch = lane & 7;
+  const float* apd;
+  const float* aps[4];
+  {
+    int row = m0 + i;
+    if (row >= B) row = B - 1;                             // clamped rows feed output rows >= B only (never stored)
+    apd = a_in + (int64_t)row * H + w * kq + 4 * kh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int r = m0 + srow + 8 * j;
+      if (r >= B) r = B - 1;
+      aps[j] = a_in + (int64_t)r * H + w * kq + 4 * sch;
+    }
+  }
+  const float4* bp4 = reinterpret_cast<const float4*>(Wp) + ((int64_t)ug * (H >> 2) + ((w * kq) >> 2) + kh) * 32 + i;
+  float* lw = &stage[STAGE ? w : 0][0];
+  // the epilogue's operands do not depend on the product: fetch them now, their latency hides under the K loop
+  float zpre[4] = {0.f, 0.f, 0.f, 0.f}, cpre = 0.f;
+  int nfpre = 0x7fffffff;
+  {
+    const int eb = m0 + (tid >> 3);
+    if (eb < B) {
+      if (nf) nfpre = nf[eb];
+      if (EP == EP_LSTM) {
+        const int eu = ug * 8 + (tid & 7);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) zpre[g4] = z[(int64_t)eb * 4 * H + g4 * H + eu];
+        cpre = c_prev[(int64_t)eb * H + eu];
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int c = (tid & 7) + 8 * jj;
+          zpre[jj] = z[(int64_t)eb * G * H + (c / U) * H + ug * U + (c % U)];
+        }
+      }
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int g0 = 0; g0 < kq; g0 += 32) {       // kq % 32 == 0 (H % 128 == 0); 4 groups of 8 k in flight
-    float4 a[4];
-    float bb[4][4];
+  float4 v[4], bq[4];
+  if (PREF) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int g = g0 + 8 * q;
-      a[q] = *reinterpret_cast<const float4*>(ap + g);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) bb[q][jj] = bp[(g + jj) * 32];
+      v[q] = *reinterpret_cast<const float4*>(STAGE ? aps[q] : apd + 8 * q);
+      bq[q] = bp4[(2 * q) * 32];
     }
+  }
+  for (int g0 = 0; g0 < kq / STEP_KDIV; g0 += 32) {       // kq % 32 == 0 (H % 128 == 0); one block = 32 k = 16 MFMAs
+    if (!PREF) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = *reinterpret_cast<const float4*>(STAGE ? aps[q] + g0 : apd + g0 + 8 * q);
+        bq[q] = bp4[((g0 >> 2) + 2 * q) * 32];
+      }
+    }
+    float4 a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bb[q][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bb[q][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bb[q][2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bb[q][3], acc, 0, 0, 0);
+      b[q] = bq[q];
+      if (STAGE) *reinterpret_cast<float4*>(lw + (srow + 8 * q) * 36 + 4 * sch) = v[q];
+      else a[q] = v[q];
     }
+    if (PREF) {                                // no branch around the loads: the last block re-fetches itself
+      const int gn = (g0 + 32 < kq) ? g0 + 32 : g0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = *reinterpret_cast<const float4*>(STAGE ? aps[q] + gn : apd + gn + 8 * q);
+        bq[q] = bp4[((gn >> 2) + 2 * q) * 32];
+      }
+    }
+    if (STAGE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const float4*>(lw + i * 36 + 8 * q + 4 * kh);
+    }
+    if (PREF) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMA block (the scheduler sinks loads)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+    }
+    if (PREF) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * kh][i] = acc[r];
@@ -98,22 +172,22 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   const int b = m0 + r;
   if (b >= B) return;
   if (EP != EP_LSTM) {
-    const bool live = nf ? (t < nf[b]) : true;
+    const bool live = t < nfpre;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int c = u + 8 * jj;                              // column of the 32-wide group
       const float sum = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
       if (EP == EP_ADD) {
-        z[(int64_t)b * G * H + (c / U) * H + ug * U + (c % U)] += sum;
+        z[(int64_t)b * G * H + (c / U) * H + ug * U + (c % U)] = zpre[jj] + sum;
       } else if (EP == EP_GRU_GATES) {                       // columns 0..15 = r of 16 units, 16..31 = u of the same units
         const int unit = ug * 16 + (c & 15);
         float* zp = z + (int64_t)b * 2 * H + (c >> 4) * H + unit;
-        const float gv = sigmoidf_(*zp + sum);
+        const float gv = sigmoidf_(zpre[jj] + sum);
         *zp = gv;
         if (c < 16) rh[(int64_t)b * H + unit] = gv * h_prev[(int64_t)b * H + unit];
       } else {                                               // EP_GRU_CAND
         const int64_t idx = (int64_t)b * H + ug * 32 + c;
-        const float cand = tanhf(z[idx] + sum);
+        const float cand = tanhf(zpre[jj] + sum);
         z[idx] = cand;
         const float uu = gates[(int64_t)b * 2 * H + H + ug * 32 + c], hp = h_prev[idx];
         const float hn = live ? uu * hp + (1.0f - uu) * cand : hp;
@@ -125,9 +199,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   }
   const int unit = ug * 8 + u;
   const int64_t idx = (int64_t)b * H + unit;
-  const bool live = nf ? (t < nf[b]) : true;
+  const bool live = t < nfpre;
   if (!live) {
-    c_new[idx] = c_prev[idx];
+    c_new[idx] = cpre;
     h_new[idx] = h_prev[idx];
     if (out) out[idx] = 0.f;
     return;
@@ -136,12 +210,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   float pre[4];
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4)
-    pre[g4] = zr[g4 * H] + ((red[0][r][g4 * 8 + u] + red[1][r][g4 * 8 + u]) + (red[2][r][g4 * 8 + u] + red[3][r][g4 * 8 + u]));
+    pre[g4] = zpre[g4] + ((red[0][r][g4 * 8 + u] + red[1][r][g4 * 8 + u]) + (red[2][r][g4 * 8 + u] + red[3][r][g4 * 8 + u]));
   const float gi = sigmoidf_(pre[0]);
   const float gj = tanhf(pre[1]);
   const float gf = sigmoidf_(pre[2] + fb);
   const float go = sigmoidf_(pre[3]);
-  const float c = c_prev[idx] * gf + gi * gj;
+  const float c = cpre * gf + gi * gj;
   const float hn = tanhf(c) * go;
   zr[0] = gi; zr[H] = gj; zr[2 * H] = gf; zr[3 * H] = go;
   c_new[idx] = c;
@@ -152,7 +226,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
 // dh_prev[B,H] += dz[B,K] . Wh^T, K = G*H (16 rows x 16 units per workgroup, v_mfma_f32_16x16x4_f32, K over 4 waves)
 // BEP 0: accumulate (LSTM, LN-LSTM, GRU gate block).  BEP 1 (GRU candidate, K = H): the product is d(r*h):
 //        dzg_r = d * h * r * (1 - r) for live rows (0 otherwise), dh_prev += d * r.
-template <int BEP>
+template <int BEP, int MODE>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ Wq,
                                                             float* __restrict__ dh_prev, int B, int H, int K4,
                                                             const float* __restrict__ gates, const float* __restrict__ h_prev,
@@ -164,28 +238,82 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int KW = K4 >> 2;                                   // K-range of one wave
-  int row = m0 + i;
-  if (row >= B) row = B - 1;
-  const float* ap = dz + (int64_t)row * K4 + w * KW + 4 * kq;
-  const float* bp = Wq + ((int64_t)ug * K4 + w * KW + 4 * kq) * 16 + i;
+  constexpr bool PREF = (MODE & 1) != 0, STAGE = (MODE & 2) != 0;
+  __shared__ float stage[STAGE ? 4 : 1][STAGE ? 16 * 68 : 1];   // per wave: 16 rows x (64 k + 4 pad) floats
+  const int srow = lane >> 4, sch = lane & 15;                // staged: lane l reads row l/16 + 4j, chunk l%16 of 256 bytes
+  const float* apd;
+  const float* aps[4];
+  {
+    int row = m0 + i;
+    if (row >= B) row = B - 1;
+    apd = dz + (int64_t)row * K4 + w * KW + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int r = m0 + srow + 4 * j;
+      if (r >= B) r = B - 1;
+      aps[j] = dz + (int64_t)r * K4 + w * KW + 4 * sch;
+    }
+  }
+  const float4* bp4 = reinterpret_cast<const float4*>(Wq) + ((int64_t)ug * (K4 >> 2) + ((w * KW) >> 2) + kq) * 16 + i;
+  float* lw = &stage[STAGE ? w : 0][0];
+  float dpre = 0.f, rpre = 0.f, hpre = 0.f;                 // epilogue operands, fetched ahead of the K loop
+  int nfpre = 0x7fffffff;
+  {
+    const int eb = m0 + (tid >> 4), eu = ug * 16 + (tid & 15);
+    if (eb < B) {
+      dpre = dh_prev[(int64_t)eb * H + eu];
+      if (BEP == 1) {
+        rpre = gates[(int64_t)eb * 2 * H + eu];
+        hpre = h_prev[(int64_t)eb * H + eu];
+        if (nf) nfpre = nf[eb];
+      }
+    }
+  }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: 16x16x4 has 40-cycle dependent latency
-  for (int g0 = 0; g0 < KW; g0 += 64) {       // KW % 64 == 0; 4 groups of 16 k in flight
-    float4 a[4];
-    float bb[4][4];
+  float4 v[4], bq[4];
+  if (PREF) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int g = g0 + 16 * q;
-      a[q] = *reinterpret_cast<const float4*>(ap + g);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) bb[q][jj] = bp[(g + jj) * 16];
+      v[q] = *reinterpret_cast<const float4*>(STAGE ? aps[q] : apd + 16 * q);
+      bq[q] = bp4[(4 * q) * 16];
     }
+  }
+  for (int g0 = 0; g0 < KW / STEP_KDIV; g0 += 64) {       // KW % 64 == 0; one block = 64 k = 16 MFMAs
+    if (!PREF) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = *reinterpret_cast<const float4*>(STAGE ? aps[q] + g0 : apd + g0 + 16 * q);
+        bq[q] = bp4[((g0 >> 2) + 4 * q) * 16];
+      }
+    }
+    float4 a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, bb[q][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, bb[q][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, bb[q][2], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, bb[q][3], acc1, 0, 0, 0);
+      b[q] = bq[q];
+      if (STAGE) *reinterpret_cast<float4*>(lw + (srow + 4 * q) * 68 + 4 * sch) = v[q];
+      else a[q] = v[q];
     }
+    if (PREF) {
+      const int gn = (g0 + 64 < KW) ? g0 + 64 : g0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = *reinterpret_cast<const float4*>(STAGE ? aps[q] + gn : apd + gn + 16 * q);
+        bq[q] = bp4[((gn >> 2) + 4 * q) * 16];
+      }
+    }
+    if (STAGE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const float4*>(lw + i * 68 + 16 * q + 4 * kq);
+    }
+    if (PREF) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acc1, 0, 0, 0);
+    }
+    if (PREF) __builtin_amdgcn_sched_barrier(0);
   }
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
@@ -197,19 +325,48 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   float* d = dh_prev + (int64_t)b * H + ug * 16 + u;
   const float sum = (red[0][r][u] + red[1][r][u]) + (red[2][r][u] + red[3][r][u]);
   if (BEP == 0) {
-    *d += sum;
+    *d = dpre + sum;
   } else {
-    const bool live = nf ? (t < nf[b]) : true;
+    const bool live = t < nfpre;
     const int64_t gi = (int64_t)b * 2 * H + ug * 16 + u;
-    const float rr = gates[gi];
-    dzg[gi] = live ? sum * h_prev[(int64_t)b * H + ug * 16 + u] * rr * (1.0f - rr) : 0.f;
-    if (live) *d += sum * rr;
+    dzg[gi] = live ? sum * hpre * rpre * (1.0f - rpre) : 0.f;
+    if (live) *d = dpre + sum * rpre;
   }
 }
 
 }  // namespace
 
 namespace yt8m {
+
+// loop form per kernel class (MODE of the templates): YT8M_STEP_MODE = four decimal digits "abcd" -> fwd G=4, fwd G<4,
+// bwd K=4H, bwd K<4H; each digit 0..3 (bit 0 prefetch, bit 1 LDS-staged A).  Defaults chosen on the B=128, 2x1024 stack.
+static int step_mode(int cls) {
+  static int m[4] = {-1, -1, -1, -1};
+  if (m[0] < 0) {
+    const char* e = getenv("YT8M_STEP_MODE");
+    const char* d = (e && strlen(e) == 4) ? e : "2122";
+    for (int c = 0; c < 4; ++c) m[c] = (d[c] - '0') & 3;
+  }
+  return m[cls];
+}
+#define FWD_LAUNCH(G, EP, CLS, ...)                                                                                    \
+  do {                                                                                                                 \
+    switch (step_mode(CLS)) {                                                                                          \
+      case 0: hipLaunchKernelGGL((lstm_step_fwd_kernel<G, EP, 0>), __VA_ARGS__); break;                                \
+      case 1: hipLaunchKernelGGL((lstm_step_fwd_kernel<G, EP, 1>), __VA_ARGS__); break;                                \
+      case 2: hipLaunchKernelGGL((lstm_step_fwd_kernel<G, EP, 2>), __VA_ARGS__); break;                                \
+      default: hipLaunchKernelGGL((lstm_step_fwd_kernel<G, EP, 3>), __VA_ARGS__); break;                               \
+    }                                                                                                                  \
+  } while (0)
+#define BWD_LAUNCH(BEP, CLS, ...)                                                                                      \
+  do {                                                                                                                 \
+    switch (step_mode(CLS)) {                                                                                          \
+      case 0: hipLaunchKernelGGL((lstm_step_bwd_kernel<BEP, 0>), __VA_ARGS__); break;                                  \
+      case 1: hipLaunchKernelGGL((lstm_step_bwd_kernel<BEP, 1>), __VA_ARGS__); break;                                  \
+      case 2: hipLaunchKernelGGL((lstm_step_bwd_kernel<BEP, 2>), __VA_ARGS__); break;                                  \
+      default: hipLaunchKernelGGL((lstm_step_bwd_kernel<BEP, 3>), __VA_ARGS__); break;                                 \
+    }                                                                                                                  \
+  } while (0)
 
 bool lstm_fused_supported(int64_t B, int64_t H, int64_t workspace_bytes) {
   return H >= 128 && (H % 128) == 0 && B >= 1 && workspace_bytes >= (int64_t)sizeof(float) * H * 4 * H;
@@ -223,14 +380,14 @@ int lstm_pack(const float* Wh, int64_t ldw, float* Wp, float* Wq, int64_t H, hip
 int lstm_step_fwd(float* z, const float* Wp, const float* c_prev, const float* h_prev, float* c_new, float* h_new, float* out,
                   const int32_t* nf, int t, int64_t B, int64_t H, float fb, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 8));
-  hipLaunchKernelGGL((lstm_step_fwd_kernel<4, EP_LSTM>), dim3(grid), dim3(256), 0, s, z, Wp, h_prev, c_prev, h_prev, c_new,
+  FWD_LAUNCH(4, EP_LSTM, 0, dim3(grid), dim3(256), 0, s, z, Wp, h_prev, c_prev, h_prev, c_new,
                      h_new, out, nf, t, (int)B, (int)H, fb, (const float*)nullptr, (float*)nullptr);
   return launch_status("lstm_step_fwd_kernel");
 }
 
 int lstm_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
-  hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(4 * H),
+  BWD_LAUNCH(0, 2, dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(4 * H),
                      (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0);
   return launch_status("lstm_step_bwd_kernel");
 }
@@ -247,7 +404,7 @@ int cell_pack(const float* Wh, int64_t ldw, float* Wp, float* Wq, int64_t H, int
 // z[B,4H] += h . Wh (packed, G = 4), nothing else
 int cell_step_add4(float* z, const float* Wp, const float* h_prev, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 8));
-  hipLaunchKernelGGL((lstm_step_fwd_kernel<4, EP_ADD>), dim3(grid), dim3(256), 0, s, z, Wp, h_prev, (const float*)nullptr, h_prev,
+  FWD_LAUNCH(4, EP_ADD, 0, dim3(grid), dim3(256), 0, s, z, Wp, h_prev, (const float*)nullptr, h_prev,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0, (int)B, (int)H, 0.f,
                      (const float*)nullptr, (float*)nullptr);
   return launch_status("lstm_step_fwd_kernel<add>");
@@ -255,7 +412,7 @@ int cell_step_add4(float* z, const float* Wp, const float* h_prev, int64_t B, in
 
 int gru_step_gates(float* zg, const float* Wp_g, const float* h_prev, float* rh, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 16));
-  hipLaunchKernelGGL((lstm_step_fwd_kernel<2, EP_GRU_GATES>), dim3(grid), dim3(256), 0, s, zg, Wp_g, h_prev, (const float*)nullptr,
+  FWD_LAUNCH(2, EP_GRU_GATES, 1, dim3(grid), dim3(256), 0, s, zg, Wp_g, h_prev, (const float*)nullptr,
                      h_prev, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0, (int)B, (int)H, 0.f,
                      (const float*)nullptr, rh);
   return launch_status("lstm_step_fwd_kernel<gru gates>");
@@ -264,7 +421,7 @@ int gru_step_gates(float* zg, const float* Wp_g, const float* h_prev, float* rh,
 int gru_step_cand(float* zc, const float* Wp_c, const float* rh, const float* zg, const float* h_prev, float* h_new, float* out,
                   const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 31) / 32) * (H / 32));
-  hipLaunchKernelGGL((lstm_step_fwd_kernel<1, EP_GRU_CAND>), dim3(grid), dim3(256), 0, s, zc, Wp_c, rh, (const float*)nullptr, h_prev,
+  FWD_LAUNCH(1, EP_GRU_CAND, 1, dim3(grid), dim3(256), 0, s, zc, Wp_c, rh, (const float*)nullptr, h_prev,
                      (float*)nullptr, h_new, out, nf, t, (int)B, (int)H, 0.f, zg, (float*)nullptr);
   return launch_status("lstm_step_fwd_kernel<gru candidate>");
 }
@@ -272,7 +429,7 @@ int gru_step_cand(float* zc, const float* Wp_c, const float* rh, const float* zg
 // dh_prev += dz[B,G*H] . Wh^T
 int cell_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, int G, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
-  hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(G * H),
+  BWD_LAUNCH(0, (G == 4 ? 2 : 3), dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(G * H),
                      (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0);
   return launch_status("lstm_step_bwd_kernel");
 }
@@ -281,7 +438,7 @@ int cell_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, i
 int gru_step_bwd_cand(const float* dzc, const float* Wq_c, float* dh_prev, const float* zg, const float* h_prev, float* dzg,
                       const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
-  hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), dim3(grid), dim3(256), 0, s, dzc, Wq_c, dh_prev, (int)B, (int)H, (int)H, zg, h_prev,
+  BWD_LAUNCH(1, 3, dim3(grid), dim3(256), 0, s, dzc, Wq_c, dh_prev, (int)B, (int)H, (int)H, zg, h_prev,
                      dzg, nf, t);
   return launch_status("lstm_step_bwd_kernel<gru candidate>");
 }
