@@ -223,14 +223,29 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float* __restrict__ 
   if (out) out[idx] = hn;
 }
 
+// operands of the BasicLSTM gate backward of step t-1, run as the epilogue of step t's product (BEP 2)
+struct GateBwd {
+  const float* gates1;   // [B,4H] saved gates i|j|f|o of step t-1
+  const float* c_prev1;  // [B,H] c_{t-2}
+  const float* c_new1;   // [B,H] c_{t-1}
+  const float* dc_in;    // [B,H] dL/dc_{t-1} carried from step t
+  const float* dout1;    // [B,H] dL/d(output_{t-1}) or NULL
+  float* dz1;            // [B,4H] out: dL/dz_{t-1}
+  float* dc_out;         // [B,H]  out: dL/dc_{t-2}
+  float* dh_out;         // [B,H]  out: the part of dL/dh_{t-2} that does not come from the product (0, or the copy-through)
+};
+
 // dh_prev[B,H] += dz[B,K] . Wh^T, K = G*H (16 rows x 16 units per workgroup, v_mfma_f32_16x16x4_f32, K over 4 waves)
 // BEP 0: accumulate (LSTM, LN-LSTM, GRU gate block).  BEP 1 (GRU candidate, K = H): the product is d(r*h):
 //        dzg_r = d * h * r * (1 - r) for live rows (0 otherwise), dh_prev += d * r.
+// BEP 2 (LSTM): dL/dh_{t-1} = dh_prev + product stays in a register and feeds the gate backward of step t-1 at once (one
+//        (row, unit) per thread = exactly the pointwise kernel's work item): one launch per backward step instead of two.
 template <int BEP, int MODE>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ Wq,
                                                             float* __restrict__ dh_prev, int B, int H, int K4,
                                                             const float* __restrict__ gates, const float* __restrict__ h_prev,
-                                                            float* __restrict__ dzg, const int32_t* __restrict__ nf, int t) {
+                                                            float* __restrict__ dzg, const int32_t* __restrict__ nf, int t,
+                                                            GateBwd gb) {
   __shared__ float red[4][16][17];
   const int groups = H >> 4;
   const int ug = blockIdx.x % groups, rt = blockIdx.x / groups;
@@ -257,6 +272,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   const float4* bp4 = reinterpret_cast<const float4*>(Wq) + ((int64_t)ug * (K4 >> 2) + ((w * KW) >> 2) + kq) * 16 + i;
   float* lw = &stage[STAGE ? w : 0][0];
   float dpre = 0.f, rpre = 0.f, hpre = 0.f;                 // epilogue operands, fetched ahead of the K loop
+  float gpre[4] = {0.f, 0.f, 0.f, 0.f}, cp1 = 0.f, cn1 = 0.f, dc1 = 0.f, do1 = 0.f;
   int nfpre = 0x7fffffff;
   {
     const int eb = m0 + (tid >> 4), eu = ug * 16 + (tid & 15);
@@ -266,6 +282,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
         rpre = gates[(int64_t)eb * 2 * H + eu];
         hpre = h_prev[(int64_t)eb * H + eu];
         if (nf) nfpre = nf[eb];
+      }
+      if (BEP == 2) {
+        if (nf) nfpre = nf[eb];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) gpre[g4] = gb.gates1[(int64_t)eb * 4 * H + g4 * H + eu];
+        cp1 = gb.c_prev1[(int64_t)eb * H + eu];
+        cn1 = gb.c_new1[(int64_t)eb * H + eu];
+        dc1 = gb.dc_in[(int64_t)eb * H + eu];
+        do1 = gb.dout1 ? gb.dout1[(int64_t)eb * H + eu] : 0.f;
       }
     }
   }
@@ -326,6 +351,26 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   const float sum = (red[0][r][u] + red[1][r][u]) + (red[2][r][u] + red[3][r][u]);
   if (BEP == 0) {
     *d = dpre + sum;
+  } else if (BEP == 2) {                                     // sequence.hip lstm_gates_bwd_kernel for step t-1, fed from registers
+    const int64_t idx = (int64_t)b * H + ug * 16 + u;
+    float* dzr = gb.dz1 + (int64_t)b * 4 * H + ug * 16 + u;
+    const float dh_in = dpre + sum;
+    if (!((t - 1) < nfpre)) {
+      dzr[0] = 0.f; dzr[H] = 0.f; dzr[2 * H] = 0.f; dzr[3 * H] = 0.f;
+      gb.dc_out[idx] = dc1;
+      gb.dh_out[idx] = dh_in;
+    } else {
+      const float gi = gpre[0], gj = gpre[1], gf = gpre[2], go = gpre[3];
+      const float tc = tanhf(cn1);
+      const float dht = dh_in + do1;
+      const float dct = dc1 + dht * go * (1.0f - tc * tc);
+      dzr[0] = dct * gj * gi * (1.0f - gi);
+      dzr[H] = dct * gi * (1.0f - gj * gj);
+      dzr[2 * H] = dct * cp1 * gf * (1.0f - gf);
+      dzr[3 * H] = dht * tc * go * (1.0f - go);
+      gb.dc_out[idx] = dct * gf;
+      gb.dh_out[idx] = 0.f;
+    }
   } else {
     const bool live = t < nfpre;
     const int64_t gi = (int64_t)b * 2 * H + ug * 16 + u;
@@ -388,8 +433,19 @@ int lstm_step_fwd(float* z, const float* Wp, const float* c_prev, const float* h
 int lstm_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
   BWD_LAUNCH(0, 2, dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(4 * H),
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0);
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0, GateBwd{});
   return launch_status("lstm_step_bwd_kernel");
+}
+
+// product of step t (dz_t . Wh^T added to dh_prev) + gate backward of step t1 = t - 1 in one launch
+int lstm_step_bwd_fused(const float* dz_t, const float* Wq, const float* dh_prev, const float* gates1, const float* c_prev1,
+                        const float* c_new1, const float* dc_in, const float* dout1, float* dz1, float* dc_out, float* dh_out,
+                        const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s) {
+  const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
+  GateBwd gb = {gates1, c_prev1, c_new1, dc_in, dout1, dz1, dc_out, dh_out};
+  BWD_LAUNCH(2, 2, dim3(grid), dim3(256), 0, s, dz_t, Wq, const_cast<float*>(dh_prev), (int)B, (int)H, (int)(4 * H),
+             (const float*)nullptr, (const float*)nullptr, (float*)nullptr, nf, t, gb);
+  return launch_status("lstm_step_bwd_kernel<fused gates>");
 }
 
 // ---- the same packed-weight step products for the other cells (cells.hip) ----------------------------------------------
@@ -430,7 +486,7 @@ int gru_step_cand(float* zc, const float* Wp_c, const float* rh, const float* zg
 int cell_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, int G, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
   BWD_LAUNCH(0, (G == 4 ? 2 : 3), dim3(grid), dim3(256), 0, s, dz, Wq, dh_prev, (int)B, (int)H, (int)(G * H),
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0);
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, 0, GateBwd{});
   return launch_status("lstm_step_bwd_kernel");
 }
 
@@ -439,7 +495,7 @@ int gru_step_bwd_cand(const float* dzc, const float* Wq_c, float* dh_prev, const
                       const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s) {
   const unsigned grid = (unsigned)(((B + 15) / 16) * (H / 16));
   BWD_LAUNCH(1, 3, dim3(grid), dim3(256), 0, s, dzc, Wq_c, dh_prev, (int)B, (int)H, (int)H, zg, h_prev,
-                     dzg, nf, t);
+                     dzg, nf, t, GateBwd{});
   return launch_status("lstm_step_bwd_kernel<gru candidate>");
 }
 

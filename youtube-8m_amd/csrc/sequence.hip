@@ -193,7 +193,36 @@ int lstm_pack(const float* Wh, int64_t ldw, float* Wp, float* Wq, int64_t H, hip
 int lstm_step_fwd(float* z, const float* Wp, const float* c_prev, const float* h_prev, float* c_new, float* h_new, float* out,
                   const int32_t* nf, int t, int64_t B, int64_t H, float fb, hipStream_t s);
 int lstm_step_bwd(const float* dz, const float* Wq, float* dh_prev, int64_t B, int64_t H, hipStream_t s);
+int lstm_step_bwd_fused(const float* dz_t, const float* Wq, const float* dh_prev, const float* gates1, const float* c_prev1,
+                        const float* c_new1, const float* dc_in, const float* dout1, float* dz1, float* dc_out, float* dh_out,
+                        const int32_t* nf, int t, int64_t B, int64_t H, hipStream_t s);
 }  // namespace yt8m
+
+// Packed-weight backward over steps t_hi .. t_lo: ONE launch per step -- the pointwise gate backward runs once for t_hi,
+// afterwards the product kernel of step t carries the gate backward of step t-1 as its epilogue; a plain product closes
+// the range.  (dh, dc) ping-pong between the two halves of `work` exactly as in the two-launch form.
+static int lstm_bwd_range_packed(const float* gates, const float* Wq, const float* cs, const float* dout, float* dz,
+                                 float*& dh_cur, float*& dc_cur, float*& dh_prev, float*& dc_prev, const int32_t* num_frames,
+                                 int64_t t_lo, int64_t t_hi, int64_t B, int64_t H, yt8m_stream_t stream) {
+  hipStream_t s = as_stream(stream);
+  const int64_t BH = B * H, Z = B * 4 * H;
+  int rc = yt8m_lstm_gates_bwd(gates + t_hi * Z, cs + t_hi * BH, cs + (t_hi + 1) * BH, dh_cur, dc_cur,
+                               dout ? dout + t_hi * BH : nullptr, dz + t_hi * Z, dc_prev, dh_prev, num_frames, (int32_t)t_hi, B, H,
+                               stream);
+  ProfScope prof(F_LSTM, s);
+  for (int64_t t = t_hi; t >= t_lo && rc == YT8M_OK; --t) {
+    if (t > t_lo) {
+      const int64_t t1 = t - 1;
+      rc = lstm_step_bwd_fused(dz + t * Z, Wq, dh_prev, gates + t1 * Z, cs + t1 * BH, cs + (t1 + 1) * BH, dc_prev,
+                               dout ? dout + t1 * BH : nullptr, dz + t1 * Z, dc_cur, dh_cur, num_frames, (int)t, B, H, s);
+    } else {
+      rc = lstm_step_bwd(dz + t * Z, Wq, dh_prev, B, H, s);
+    }
+    float* tmp = dh_cur; dh_cur = dh_prev; dh_prev = tmp;
+    tmp = dc_cur; dc_cur = dc_prev; dc_prev = tmp;
+  }
+  return rc;
+}
 
 extern "C" int yt8m_lstm_gates_fwd(float* z, const float* c_prev, const float* h_prev, float* c_new, float* h_new,
                                    float* out, const int32_t* num_frames, int32_t t, int64_t B, int64_t H,
@@ -276,6 +305,7 @@ extern "C" int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t 
   if (fused) {
     int rc = lstm_pack(Wh, ldw, nullptr, Wq, H, s);
     if (rc != YT8M_OK) return rc;
+    return lstm_bwd_range_packed(gates, Wq, cs, dout, dz, dh_cur, dc_cur, dh_prev, dc_prev, num_frames, 0, F - 1, B, H, stream);
   }
   for (int64_t t = F - 1; t >= 0; --t) {
     float* dzt = dz + t * B * 4 * H;
@@ -368,6 +398,7 @@ extern "C" int yt8m_lstm_steps_bwd(const float* gates, const float* Wh, int64_t 
     float* dc_cur = dh_cur + BH;
     float* dh_prev = work + (phase ? 0 : 2) * BH;
     float* dc_prev = dh_prev + BH;
+    if (Wq) return lstm_bwd_range_packed(gates, Wq, cs, dout, dz, dh_cur, dc_cur, dh_prev, dc_prev, num_frames, t0, t0 + T - 1, B, H, stream);
     for (int64_t t = t0 + T - 1; t >= t0; --t) {
       float* dzt = dz + t * B * 4 * H;
       int rc = yt8m_lstm_gates_bwd(gates + t * B * 4 * H, cs + t * BH, cs + (t + 1) * BH, dh_cur, dc_cur,
