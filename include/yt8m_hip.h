@@ -136,6 +136,22 @@ int yt8m_logistic_fwd_bwd(const float* x, const float* W, const float* b, const 
                           int64_t D, int64_t V, float eps, float* p, float* loss_out, float* Z, float* dW, float* db,
                           float beta, float* dx, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- fully-connected layers with N <= 16 outputs over very many rows (csrc/gemm_skinny.hip) ------------------------
+ * The attention logits of W/all_frame_models/lstm_attention_max_pooling_model.py:51-56 (slim.fully_connected on
+ * [B*300, 1152+1024] -> 8).  Vector-ALU streaming kernels at the HBM rate instead of 94 %-padded MFMA tiles.  Row-major
+ * fp32, K % 4 == 0, x / dx 16-byte aligned with ld % 4 == 0, beta in {0, 1}.
+ *   fwd: y[M,N] (+)= x[M,K] . W[K,N] (+ bias)           (needs yt8m_skinny_supported(M,K,N): weights resident in LDS)
+ *   dw : dW[K,N] (+)= x^T . dy   (workspace >= yt8m_skinny_workspace_bytes(); deterministic two-stage reduction)
+ *   dx : dx[M,K] (+)= dy . W^T */
+int yt8m_skinny_supported(int64_t M, int64_t K, int64_t N);
+int64_t yt8m_skinny_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int yt8m_skinny_fwd_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* y, int64_t ldy,
+                        int64_t M, int64_t K, int64_t N, float beta, yt8m_stream_t stream);
+int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, float* dW, int64_t lddw, int64_t M, int64_t K,
+                       int64_t N, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, int64_t ldw, float* dx, int64_t lddx, int64_t M, int64_t K,
+                       int64_t N, float beta, yt8m_stream_t stream);
+
 /* ---- GRUCell / LayerNormBasicLSTMCell layers (csrc/cells.hip), time-major, generic per-step form --------------------
  * tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn (W/all_frame_models/gru_pooling_model.py:34-47):
  *   zg [F,B,2H]: in = x.Wg[:in] + b_gates (hoisted by the caller), out = the gates r | u;

@@ -675,3 +675,71 @@ def test_lnlstm_layer_fwd_bwd(dev, B, F, Din, Hh, keep):
         ref = t.grad.numpy()
         assert np.abs(H(v.grad) - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), k
     assert np.abs(H(xt.grad).transpose(1, 0, 2) - tx.grad.numpy()).max() < 5e-4 * max(1.0, np.abs(tx.grad.numpy()).max())
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 4, 1), (37, 256, 8), (5000, 2304, 8), (4099, 1000, 9), (2500, 2048, 16), (70, 516, 3)])
+def test_skinny_gemm_kernels(dev, M, K, N):
+    """csrc/gemm_skinny.hip (<= 16 outputs over many rows) vs fp64 numpy: forward with bias / accumulate, dW through the
+    chunked deterministic reduction, dx with accumulate; W given as a row slice of a wider matrix (ld = N)."""
+    rs = np.random.RandomState(M + K + N)
+    x = rs.randn(M, K).astype(np.float32)
+    Wfull = rs.randn(K + 8, N).astype(np.float32)
+    b = rs.randn(N).astype(np.float32)
+    dy = rs.randn(M, N).astype(np.float32)
+    y0 = rs.randn(M, N).astype(np.float32)
+    xd, Wd, bd, dyd = D(x, dev), D(Wfull, dev)[4:4 + K], D(b, dev), D(dy, dev)
+    W = Wfull[4:4 + K].astype(np.float64)
+    assert L.lib().yt8m_skinny_supported(M, K, N) == 1
+    y = ops.skinny_fwd(xd, Wd, bd, torch.empty(M, N, device=dev))
+    ref = x.astype(np.float64) @ W + b
+    assert np.abs(H(y) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    y2 = ops.skinny_fwd(xd, Wd, None, D(y0, dev), beta=1.0)
+    assert np.abs(H(y2) - (x.astype(np.float64) @ W + y0)).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    refdw = x.astype(np.float64).T @ dy
+    dW = ops.skinny_dw(xd, dyd, torch.empty(K, N, device=dev))
+    assert np.abs(H(dW) - refdw).max() < 2e-5 * max(1.0, np.abs(refdw).max())
+    dW1 = ops.skinny_dw(xd, dyd, dW.clone(), beta=1.0)
+    assert np.abs(H(dW1) - 2 * refdw).max() < 4e-5 * max(1.0, np.abs(refdw).max())
+    assert torch.equal(ops.skinny_dw(xd, dyd, torch.empty(K, N, device=dev)), dW)          # deterministic
+    refdx = dy.astype(np.float64) @ W.T
+    dx = ops.skinny_dx(dyd, Wd)
+    assert np.abs(H(dx) - refdx).max() < 2e-5 * max(1.0, np.abs(refdx).max())
+    dx1 = ops.skinny_dx(dyd, Wd, dx=dx.clone(), beta=1.0)
+    assert np.abs(H(dx1) - 2 * refdx).max() < 4e-5 * max(1.0, np.abs(refdx).max())
+
+
+def test_skinny_rejects_and_linear_cat(dev, monkeypatch):
+    """N > 16 / K % 4 != 0 are shape errors; ops.linear_cat (FC over a logical concatenation, with a per-group tiled part) ==
+    torch on the materialised concatenation, through both the streaming kernels and the MFMA path."""
+    from yt8m_amd.variables import reset_default_graph, zeros
+    x = torch.zeros(64, 8, device=dev)
+    with pytest.raises(ValueError):
+        ops.skinny_fwd(x, torch.zeros(8, 17, device=dev), None, torch.zeros(64, 17, device=dev))
+    with pytest.raises(ValueError):
+        ops.skinny_fwd(torch.zeros(64, 6, device=dev), torch.zeros(6, 4, device=dev), None, torch.zeros(64, 4, device=dev))
+    assert L.lib().yt8m_skinny_supported(100, 8192, 8) == 0 and L.lib().yt8m_skinny_supported(100, 4096, 8) == 1
+    rs = np.random.RandomState(5)
+    Bv, F, K1, K2, K3, N = 6, 50, 24, 12, 16, 8
+    a = rs.randn(Bv, F, K1).astype(np.float32)
+    c = rs.randn(Bv, F, K2).astype(np.float32)
+    m = rs.randn(Bv, K3).astype(np.float32)
+    Wn = (rs.randn(K1 + K2 + K3, N) * 0.3).astype(np.float32)
+    bn = rs.randn(N).astype(np.float32)
+    gy = rs.randn(Bv, F, N).astype(np.float32)
+    ta, tc, tm, tW, tb = [torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for v in (a, c, m, Wn, bn)]
+    ty = torch.cat([ta, tc, tm[:, None, :].expand(Bv, F, K3)], 2) @ tW + tb
+    (ty * torch.from_numpy(gy.astype(np.float64))).sum().backward()
+    for min_rows in (1, 1 << 30):                  # streaming kernels / padded MFMA tiles
+        monkeypatch.setattr(ops, "SKINNY_MIN_ROWS", min_rows)
+        g = reset_default_graph(device=dev)
+        g.begin_step()
+        W = g.get_variable("w", Wn.shape, zeros)
+        b = g.get_variable("b", bn.shape, zeros)
+        g.finalize()
+        W.data.copy_(D(Wn, dev)); b.data.copy_(D(bn, dev))
+        da, dc, dm = [D(v, dev).requires_grad_(True) for v in (a, c, m)]
+        y = ops.linear_cat([da, dc], W, b, group_parts=(dm,))
+        assert y.shape == (Bv, F, N) and np.abs(H(y) - ty.detach().numpy()).max() < 2e-5
+        (y * D(gy, dev)).sum().backward()
+        for got, ref in ((W.grad, tW.grad), (b.grad, tb.grad), (da.grad, ta.grad), (dc.grad, tc.grad), (dm.grad, tm.grad)):
+            assert np.abs(H(got) - ref.numpy()).max() < 5e-5 * max(1.0, np.abs(ref.numpy()).max())

@@ -1,0 +1,40 @@
+"""TFLOP/s of the fp32 grouped GEMM on a list of shapes: python tools/gemm_shapes.py  (GPU box)"""
+import sys
+import torch
+sys.path.insert(0, ".")
+import __graft_entry__
+__graft_entry__.load_package()
+import yt8m_amd.ops as ops
+
+dev = torch.device("cuda:0")
+SHAPES = [  # (label, transA, transB, [(M, N, K), ...])
+    ("cfg1 fwd  M=1024", False, False, [(1024, 14148, 1152), (1024, 9432, 1152)]),
+    ("head fwd  M=8192", False, False, [(8192, 14148, 1152), (8192, 9432, 1152)]),
+    ("head fwd  M=8192 one", False, False, [(8192, 23580, 1152)]),
+    ("head fwd  M=8192 N=23552", False, False, [(8192, 23552, 1152)]),
+    ("head fwd  M=4096", False, False, [(4096, 14148, 1152), (4096, 9432, 1152)]),
+    ("head fwd  M=2048", False, False, [(2048, 14148, 1152), (2048, 9432, 1152)]),
+    ("lstm proj M=38400", False, False, [(38400, 4096, 1152)]),
+    ("square 4096", False, False, [(4096, 4096, 4096)]),
+    ("head dW   K=8192", True, False, [(1152, 14148, 8192), (1152, 9432, 8192)]),
+    ("head dx   K=23580", False, True, [(8192, 1152, 14148), (8192, 1152, 9432)]),
+]
+for label, tA, tB, probs in SHAPES:
+    items, fl = [], 0.0
+    for (M, N, K) in probs:
+        A = torch.randn((K, M) if tA else (M, K), device=dev)
+        B = torch.randn((N, K) if tB else (K, N), device=dev)
+        items.append(dict(A=A, B=B, out=torch.empty((M, N), device=dev)))
+        fl += 2.0 * M * N * K
+    for _ in range(3):
+        ops.gemm_grouped(items, transA=tA, transB=tB)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 10
+    for _ in range(n):
+        ops.gemm_grouped(items, transA=tA, transB=tB)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print("%-26s %8.3f ms  %6.1f TFLOP/s" % (label, ms, fl / ms / 1e9))
+    del items

@@ -36,6 +36,11 @@ CONFIGS = {
                          flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3),
                                     compute_dtype="bfloat16")),
     "netvlad_bf16": dict(model=flm.NetVLADModel, B=128, frame=True, flags=dict(compute_dtype="bfloat16")),
+    "config5_b1024": dict(model=flm.GatedNetVLADAttentionChainModel, B=1024, frame=True, multitask=True,
+                          flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3))),
+    "config5_bf16_b1024": dict(model=flm.GatedNetVLADAttentionChainModel, B=1024, frame=True, multitask=True,
+                               flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3),
+                                          compute_dtype="bfloat16")),
     "lstm_parallel": dict(model=flm.LstmParallelFinaloutputModel, B=128, frame=True,
                           flags=dict(feature_sizes="1024,128", lstm_cells="1024,128")),
     "lstm_posattn": dict(model=flm.LstmPositionalAttentionMaxPoolingModel, B=128, frame=True),
@@ -98,5 +103,5 @@ def run(name, steps=5):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or [c for c in CONFIGS if c not in ("lstm_b512", "config5_bf16", "netvlad_bf16")]):
+    for n in (sys.argv[1:] or [c for c in CONFIGS if c not in ("lstm_b512", "config5_bf16", "netvlad_bf16", "config5_b1024", "config5_bf16_b1024")]):
         run(n)

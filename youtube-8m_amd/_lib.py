@@ -47,6 +47,11 @@ SIGNATURES = {
     "yt8m_moe_mix_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_moe_mix_xent_fwd": (c_int, [P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_float, P, P]),
     "yt8m_moe_mix_xent_bwd": (c_int, [P, P, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P]),
+    "yt8m_skinny_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "yt8m_skinny_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "yt8m_skinny_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_skinny_dw_f32": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_skinny_dx_f32": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_gru_layer_fwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_gru_layer_bwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lnlstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_float,

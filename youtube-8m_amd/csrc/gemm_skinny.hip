@@ -1,0 +1,296 @@
+// gemm_skinny.hip -- fully-connected layers with a handful of outputs over very many rows (gfx950, wave64).
+// The attention logits of W/all_frame_models/lstm_attention_max_pooling_model.py:51-56 are slim.fully_connected on
+// [B*300, 1152 + 1024] -> 8: M = 38 400 ... 307 200 rows, N = 8.  On 128 x 128 MFMA tiles 94 % of the matrix work is padding
+// (measured 5.5-7.2 TFLOP/s "useful"); the layer is a pure stream over x, so it is done on the vector ALU at the HBM rate:
+//   forward   y[M,N]  (+)= x[M,K] . W[K,N] (+ bias)       8 B of FLOP per byte of x -> HBM-bound
+//   dW        dW[K,N] (+)= x[M,K]^T . dy[M,N]             x read once; row chunks -> partials -> fixed-order reduction
+//   dx        dx[M,K] (+)= dy[M,N] . W[K,N]^T             output-write-bound
+// N <= 16 (padded to NT = 8 or 16 in registers), K % 4 == 0, fp32.  Algorithmic bytes: 4*M*K (+ 4*M*N) per pass.
+#include "common.h"
+
+namespace {
+
+// ---- forward: a wave owns 4 rows at a time; lane l covers k = 256 j + 4 l + e; W lives in LDS as [j][q = 2e+h][lane][4]
+//      (n = 4h..4h+3 for NT = 8; q = 4e + h for NT = 16) so that the per-lane b128 reads are conflict-free -------------------
+template <int NT>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W,
+                                                         int64_t ldw, const float* __restrict__ bias, float* __restrict__ y,
+                                                         int64_t ldy, int64_t M, int K, int N, float beta, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];           // J * (NT) * 64 * 4 floats
+  constexpr int QN = NT / 4;                                           // float4 groups per k
+  constexpr int R = 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int J = (K + 255) >> 8;
+  for (int e = tid; e < J * 4 * QN * 64; e += 256) {                   // e -> (j, q, l); element group of 4 n
+    const int l = e & 63, q = (e >> 6) % (4 * QN), j = e / (64 * 4 * QN);
+    const int k = 256 * j + 4 * l + q / QN, n0 = 4 * (q % QN);
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {
+      if (n0 + 0 < N) v.x = W[(int64_t)k * ldw + n0 + 0];
+      if (n0 + 1 < N) v.y = W[(int64_t)k * ldw + n0 + 1];
+      if (n0 + 2 < N) v.z = W[(int64_t)k * ldw + n0 + 2];
+      if (n0 + 3 < N) v.w = W[(int64_t)k * ldw + n0 + 3];
+    }
+    *reinterpret_cast<float4*>(wl + (int64_t)e * 4) = v;
+  }
+  __syncthreads();
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r_end = r_begin + rows_per_wg < M ? r_begin + rows_per_wg : M;
+  for (int64_t r0 = r_begin + w * R; r0 < r_end; r0 += 4 * R) {
+    float acc[R * NT];
+#pragma unroll
+    for (int i = 0; i < R * NT; ++i) acc[i] = 0.f;
+    const float* xr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) xr[r] = x + (r0 + r < M ? r0 + r : M - 1) * ldx + 4 * lane;
+    for (int j = 0; j < J; ++j) {
+      float4 xv[R];
+      const bool in = 256 * j + 4 * lane < K;                          // K % 4 == 0: a float4 is inside or outside
+#pragma unroll
+      for (int r = 0; r < R; ++r) xv[r] = in ? *reinterpret_cast<const float4*>(xr[r] + 256 * j) : float4{0.f, 0.f, 0.f, 0.f};
+      const float* wj = wl + ((int64_t)j * 4 * QN * 64 + lane) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int h = 0; h < QN; ++h) {
+          const float4 wv = *reinterpret_cast<const float4*>(wj + (e * QN + h) * 256);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float xk = e == 0 ? xv[r].x : e == 1 ? xv[r].y : e == 2 ? xv[r].z : xv[r].w;
+            acc[r * NT + 4 * h + 0] = fmaf(xk, wv.x, acc[r * NT + 4 * h + 0]);
+            acc[r * NT + 4 * h + 1] = fmaf(xk, wv.y, acc[r * NT + 4 * h + 1]);
+            acc[r * NT + 4 * h + 2] = fmaf(xk, wv.z, acc[r * NT + 4 * h + 2]);
+            acc[r * NT + 4 * h + 3] = fmaf(xk, wv.w, acc[r * NT + 4 * h + 3]);
+          }
+        }
+      }
+    }
+    // transposing butterfly: R*NT values x 64 lanes -> every value summed over the wave with R*NT (+ tail) shuffles instead
+    // of 6 per value.  After the masks 32..(64/(R*NT)) lane L holds value index L / (64 / (R*NT)).
+    constexpr int NV = R * NT;                                         // 32 or 64
+    int n = NV;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      if (n > 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i) {
+          if (i < n / 2) {
+            const float a = acc[i], b = acc[i + n / 2];
+            const float recv = __shfl_xor(up ? a : b, m, 64);
+            acc[i] = (up ? b : a) + recv;
+          }
+        }
+        n >>= 1;
+      } else {
+        acc[0] += __shfl_xor(acc[0], m, 64);
+      }
+    }
+    constexpr int LPV = 64 / NV;                                       // lanes per value (2 for NV = 32, 1 for 64)
+    const int vi = lane / LPV;
+    if ((lane % LPV) == 0) {
+      const int r = vi / NT, nn = vi % NT;
+      if (r0 + r < r_end && nn < N) {
+        float* yp = y + (r0 + r) * ldy + nn;
+        float v = acc[0] + (bias ? bias[nn] : 0.f);
+        if (beta != 0.f) v += *yp;
+        *yp = v;
+      }
+    }
+  }
+}
+
+// ---- dW / dx: a thread owns 4 consecutive k of a 1024-wide k slice; the dy rows of the chunk sit in LDS (broadcast reads) ----
+template <int NT, bool DX>
+__global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                         int64_t ldy, const float* __restrict__ W, int64_t ldw,
+                                                         float* __restrict__ out, int64_t ldo, int64_t M, int K, int N,
+                                                         float beta, int rows_per_chunk) {
+  constexpr int RC = 64;                                               // dy rows staged per pass
+  __shared__ __attribute__((aligned(16))) float dyl[RC * NT];
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * 1024 + 4 * tid;
+  const bool kin = k0 < K;
+  const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r_end = r_begin + rows_per_chunk < M ? r_begin + rows_per_chunk : M;
+  float acc[4 * NT];                                                   // dW: partial sums; dx: the W[k0..k0+3][0..NT) block
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) acc[i] = 0.f;
+  if (DX && kin) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[e * NT + n] = n < N ? W[(int64_t)(k0 + e) * ldw + n] : 0.f;
+  }
+  for (int64_t rb = r_begin; rb < r_end; rb += RC) {
+    __syncthreads();
+    for (int e = tid; e < RC * NT; e += 256) {
+      const int64_t r = rb + e / NT;
+      const int n = e % NT;
+      dyl[e] = (r < r_end && n < N) ? dy[r * ldy + n] : 0.f;
+    }
+    __syncthreads();
+    if (!kin) continue;
+    const int nr = (int)(r_end - rb < RC ? r_end - rb : RC);
+    for (int r = 0; r < nr; ++r) {
+      float dv[NT];
+#pragma unroll
+      for (int q = 0; q < NT / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(dyl + r * NT + 4 * q);
+        dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+      }
+      if (DX) {
+        float4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          o.x = fmaf(dv[n], acc[0 * NT + n], o.x);
+          o.y = fmaf(dv[n], acc[1 * NT + n], o.y);
+          o.z = fmaf(dv[n], acc[2 * NT + n], o.z);
+          o.w = fmaf(dv[n], acc[3 * NT + n], o.w);
+        }
+        float4* op = reinterpret_cast<float4*>(out + (rb + r) * ldo + k0);
+        if (beta != 0.f) { const float4 p = *op; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        *op = o;
+      } else {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (rb + r) * ldx + k0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[0 * NT + n] = fmaf(xv.x, dv[n], acc[0 * NT + n]);
+          acc[1 * NT + n] = fmaf(xv.y, dv[n], acc[1 * NT + n]);
+          acc[2 * NT + n] = fmaf(xv.z, dv[n], acc[2 * NT + n]);
+          acc[3 * NT + n] = fmaf(xv.w, dv[n], acc[3 * NT + n]);
+        }
+      }
+    }
+  }
+  if (!DX && kin) {                                                    // partial of this row chunk: out = ws[chunk][K][NT]
+    float* p = out + ((int64_t)blockIdx.y * K + k0) * NT;
+#pragma unroll
+    for (int i = 0; i < 4 * NT; i += 4) *reinterpret_cast<float4*>(p + i) = float4{acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void skinny_dw_reduce_kernel(const float* __restrict__ ws, int chunks, float* __restrict__ dW,
+                                                               int64_t lddw, int K, int N, float beta) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                        // (k, n) of the padded [K][NT] image
+  if (e >= K * NT) return;
+  const int k = e / NT, n = e % NT;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += ws[(int64_t)c * K * NT + e];   // fixed order: deterministic
+  float* d = dW + (int64_t)k * lddw + n;
+  *d = beta != 0.f ? *d + s : s;
+}
+
+int chunk_rows(int64_t M, int chunks) {
+  int64_t r = (M + chunks - 1) / chunks;
+  r = (r + 63) / 64 * 64;
+  return (int)(r < 64 ? 64 : r);
+}
+
+}  // namespace
+
+using namespace yt8m;
+
+static int skinny_check(int64_t M, int64_t K, int64_t N, float beta) {
+  YT8M_REQUIRE(M >= 0 && K >= 0 && N >= 0, YT8M_E_SHAPE, "negative dimension");
+  YT8M_REQUIRE(N <= 16, YT8M_E_SHAPE, "skinny GEMM needs N <= 16");
+  YT8M_REQUIRE(K % 4 == 0 && K < (1 << 24), YT8M_E_SHAPE, "skinny GEMM needs K % 4 == 0");
+  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  return YT8M_OK;
+}
+
+extern "C" int yt8m_skinny_supported(int64_t M, int64_t K, int64_t N) {
+  const int NT = N <= 8 ? 8 : 16;
+  return N >= 1 && N <= 16 && K >= 4 && K % 4 == 0 && M >= 1 && ((K + 255) / 256) * 256 * NT * 4 <= 144 * 1024;
+}
+
+extern "C" int64_t yt8m_skinny_workspace_bytes(int64_t M, int64_t K, int64_t N) {
+  const int NT = N <= 8 ? 8 : 16;
+  const int chunks = 256;
+  const int rows = chunk_rows(M, chunks);
+  return ((M + rows - 1) / rows) * K * NT * (int64_t)sizeof(float);
+}
+
+extern "C" int yt8m_skinny_fwd_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* y,
+                                   int64_t ldy, int64_t M, int64_t K, int64_t N, float beta, yt8m_stream_t stream) {
+  int rc = skinny_check(M, K, N, beta);
+  if (rc != YT8M_OK) return rc;
+  if (M == 0 || N == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_skinny_supported(M, K, N), YT8M_E_SHAPE, "K too large for the LDS-resident weight image");
+  YT8M_REQUIRE(x && W && y, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldx >= K && ldx % 4 == 0 && ldw >= N && ldy >= N && ((uintptr_t)x & 15) == 0, YT8M_E_SHAPE, "bad leading dimension / alignment");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int J = (int)((K + 255) / 256);
+  int rows_per_wg = (int)((M + 1023) / 1024);                          // ~1024 workgroups
+  rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+  const unsigned grid = (unsigned)((M + rows_per_wg - 1) / rows_per_wg);
+  if (N <= 8) {
+    const size_t lds = (size_t)J * 8 * 64 * 4 * sizeof(float);
+    static bool once8 = false;
+    if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once8 = true; }
+    hipLaunchKernelGGL(skinny_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, bias, y, ldy, M, (int)K, (int)N, beta,
+                       rows_per_wg);
+  } else {
+    const size_t lds = (size_t)J * 16 * 64 * 4 * sizeof(float);
+    static bool once16 = false;
+    if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once16 = true; }
+    hipLaunchKernelGGL(skinny_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, bias, y, ldy, M, (int)K, (int)N, beta,
+                       rows_per_wg);
+  }
+  return launch_status("skinny_fwd_kernel");
+}
+
+extern "C" int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy, float* dW, int64_t lddw, int64_t M,
+                                  int64_t K, int64_t N, float beta, void* workspace, int64_t workspace_bytes,
+                                  yt8m_stream_t stream) {
+  int rc = skinny_check(M, K, N, beta);
+  if (rc != YT8M_OK) return rc;
+  if (K == 0 || N == 0) return YT8M_OK;
+  YT8M_REQUIRE(dW && (M == 0 || (x && dy)), YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldx >= K && ldx % 4 == 0 && ldy >= N && lddw >= N && ((uintptr_t)x & 15) == 0, YT8M_E_SHAPE, "bad leading dimension / alignment");
+  YT8M_REQUIRE(workspace && workspace_bytes >= yt8m_skinny_workspace_bytes(M, K, N), YT8M_E_BADARG, "workspace too small");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int rows = chunk_rows(M, 256);
+  const int chunks = (int)((M + rows - 1) / rows);
+  float* ws = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)(chunks > 0 ? chunks : 1));
+  if (N <= 8) {
+    if (chunks > 0)
+      hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0, ws,
+                         (int64_t)0, M, (int)K, (int)N, 0.f, rows);
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw, (int)K,
+                       (int)N, beta);
+  } else {
+    if (chunks > 0)
+      hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0, ws,
+                         (int64_t)0, M, (int)K, (int)N, 0.f, rows);
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw,
+                       (int)K, (int)N, beta);
+  }
+  return launch_status("skinny_bwd_kernel<dW>");
+}
+
+extern "C" int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, int64_t ldw, float* dx, int64_t lddx, int64_t M,
+                                  int64_t K, int64_t N, float beta, yt8m_stream_t stream) {
+  int rc = skinny_check(M, K, N, beta);
+  if (rc != YT8M_OK) return rc;
+  if (M == 0 || K == 0) return YT8M_OK;
+  YT8M_REQUIRE(dy && W && dx, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(lddx >= K && lddx % 4 == 0 && ldy >= N && ldw >= N && ((uintptr_t)dx & 15) == 0, YT8M_E_SHAPE, "bad leading dimension / alignment");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int rows = chunk_rows(M, 256);
+  const int chunks = (int)((M + rows - 1) / rows);
+  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)chunks);
+  if (N <= 8)
+    hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw, dx, lddx,
+                       M, (int)K, (int)N, beta, rows);
+  else
+    hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw, dx,
+                       lddx, M, (int)K, (int)N, beta, rows);
+  return launch_status("skinny_bwd_kernel<dx>");
+}

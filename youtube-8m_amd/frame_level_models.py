@@ -199,8 +199,8 @@ class LstmAttentionMaxPoolingModel(models.BaseModel):
         num_attentions = FLAGS.lstm_attentions
         out_tm, _ = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers)
         outputs = out_tm.transpose(0, 1).contiguous()                               # [B,F,H]
-        attention_activations = video_level_models.fully_connected(
-            torch.cat([model_input, outputs], dim=2), num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
+        attention_activations = video_level_models.fully_connected_cat(               # :51-56 FC on concat([input, outputs])
+            [model_input, outputs], num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
         attention_weights = seq_ops.attention_weights(attention_activations, num_frames)   # [B,F,A]
         attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
         moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")
@@ -252,8 +252,8 @@ class LstmPositionalAttentionMaxPoolingModel(LstmAttentionMaxPoolingModel):
         positional_embedding = ops.as_tensor(emb).expand(B, F, FLAGS.positional_embedding_size)
         mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
         mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
-        attention_activations = video_level_models.fully_connected(
-            torch.cat([model_input, positional_embedding, mean_input[:, None, :].expand(B, F, D), outputs], dim=2),
+        attention_activations = video_level_models.fully_connected_cat(
+            [model_input, positional_embedding, mean_input[:, None, :].expand(B, F, D), outputs],
             num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
         attention_weights = seq_ops.attention_weights(attention_activations, num_frames)   # [B,F,A]
         attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
@@ -470,8 +470,8 @@ class GatedNetVLADAttentionChainModel(GatedNetVLADModel):
         h = self.descriptor(model_input, num_frames)                                       # [B,Hfc] (uint8 stays fused)
         x = ops.dequant_l2norm(model_input, num_frames) if model_input.dtype == torch.uint8 else model_input
         nf = num_frames.to(x.dtype).clamp(min=1).view(B, 1, 1) if num_frames is not None else float(F)
-        mean_x = (x.sum(dim=1, keepdim=True) / nf).expand(B, F, D)
-        act = video_level_models.fully_connected(torch.cat([x, mean_x], dim=2), A, "attention-", l2_penalty=l2_penalty)
+        mean_x = (x.sum(dim=1, keepdim=True) / nf).view(B, D)                              # tiled over the frames by the FC
+        act = video_level_models.fully_connected_cat([x], A, "attention-", l2_penalty=l2_penalty, group_parts=[mean_x])
         w = seq_ops.attention_weights(act, num_frames)                                     # [B,F,A]
         att = seq_ops.pool_tn(w, x)                                                        # [B,A,D]
         chain_in = torch.cat([h.unsqueeze(1).expand(B, A, h.shape[1]), att], dim=2).reshape(B * A, -1)

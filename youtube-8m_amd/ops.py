@@ -471,8 +471,130 @@ class _Linear(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+SKINNY_MIN_ROWS = 2048       # below this the padded MFMA tiles are cheap enough
+
+
+def skinny_ok(M, K, N, *tensors):
+    """Layers with <= 16 outputs over many rows (attention logits): vector-ALU streaming kernels (csrc/gemm_skinny.hip)."""
+    if not (N <= 16 and M >= SKINNY_MIN_ROWS and K % 4 == 0 and _lib.lib().yt8m_skinny_supported(M, K, N)):
+        return False
+    return all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def skinny_fwd(x, W, bias, y, beta=0.0):
+    """y[M,N] (+)= x[M,K] . W[K,N] (+ bias); W may be a row slice of a wider-K weight (ld = N)."""
+    M, K = x.shape
+    N = W.shape[1]
+    _lib.check(_lib.lib().yt8m_skinny_fwd_f32(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), _p(y), y.stride(0), M, K, N,
+                                              float(beta), _stream()))
+    return y
+
+
+def skinny_dw(x, dy, dW, beta=0.0):
+    M, K = x.shape
+    N = dy.shape[1]
+    ws = _workspace(x.device)
+    _lib.check(_lib.lib().yt8m_skinny_dw_f32(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dW), dW.stride(0), M, K, N, float(beta),
+                                             _p(ws), ws.numel() * 4, _stream()))
+    return dW
+
+
+def skinny_dx(dy, W, dx=None, beta=0.0):
+    M, N = dy.shape
+    K = W.shape[0]
+    if dx is None:
+        dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().yt8m_skinny_dx_f32(_p(dy), dy.stride(0), _p(W), W.stride(0), _p(dx), dx.stride(0), M, K, N, float(beta),
+                                             _stream()))
+    return dx
+
+
+class _LinearCat(torch.autograd.Function):
+    """slim.fully_connected on tf.concat(parts, axis=-1) without materialising the concatenation
+    (W/all_frame_models/lstm_attention_max_pooling_model.py:51-56): y = sum_i parts_i . W[rows_i] + b.  W rows are taken in
+    part order.  The first `nfull` parts are [M, K_i]; the others are PER-GROUP parts [M / rep, K_i] whose rows stand for
+    `rep` consecutive rows of the concatenation each (a per-video vector tiled over the frames, e.g. the mean frame of
+    lstm_positional_attention_max_pooling_model.py:77-84): their product is computed once per group and broadcast.
+    Narrow outputs (<= 16) over many rows take the streaming kernels (csrc/gemm_skinny.hip)."""
+
+    @staticmethod
+    def forward(ctx, token, W, b, rep, nfull, *parts):
+        parts = [_f32c(p) for p in parts]
+        _dev(*parts)
+        M = parts[0].shape[0]
+        N = W.data.shape[1]
+        assert nfull >= 1 and sum(p.shape[1] for p in parts) == W.data.shape[0], "parts do not add up to the weight's input width"
+        y = torch.empty((M, N), dtype=torch.float32, device=parts[0].device)
+        k0 = 0
+        for i, p in enumerate(parts):
+            K = p.shape[1]
+            Wi = W.data[k0:k0 + K]
+            if i >= nfull:
+                assert p.shape[0] * rep == M
+                t = gemm(p, Wi)                                       # [M / rep, N]: tiny
+                y.view(-1, rep, N).add_(t.view(-1, 1, N))             # broadcast over the group (layout glue on [M, N])
+            elif skinny_ok(M, K, N, p):
+                skinny_fwd(p, Wi, b.data if (b is not None and i == 0) else None, y, beta=0.0 if i == 0 else 1.0)
+            else:
+                gemm(p, Wi, out=y, bias=b.data if (b is not None and i == 0) else None, beta=0.0 if i == 0 else 1.0)
+            k0 += K
+        ctx.save_for_backward(*parts)
+        ctx.W, ctx.b, ctx.rep, ctx.nfull = W, b, rep, nfull
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        parts = ctx.saved_tensors
+        W, b, rep, nfull = ctx.W, ctx.b, ctx.rep, ctx.nfull
+        dy = _f32c(dy)
+        M, N = dy.shape
+        dxs = []
+        wbeta = W.grad_beta() if (W.trainable and W.grad is not None) else None
+        dyg = None
+        k0 = 0
+        for i, p in enumerate(parts):
+            K = p.shape[1]
+            Wi = W.data[k0:k0 + K]
+            need_dx = ctx.needs_input_grad[5 + i]
+            if i >= nfull:
+                if dyg is None:
+                    dyg = dy.view(-1, rep, N).sum(dim=1)              # [M / rep, N]
+                if wbeta is not None:
+                    gemm(p, dyg, out=W.grad[k0:k0 + K], transA=True, beta=wbeta)
+                dxs.append(gemm(dyg, Wi, transB=True) if need_dx else None)
+            else:
+                sk = skinny_ok(M, K, N, p, dy)
+                if wbeta is not None:
+                    if sk:
+                        skinny_dw(p, dy, W.grad[k0:k0 + K], beta=wbeta)
+                    else:
+                        gemm(p, dy, out=W.grad[k0:k0 + K], transA=True, beta=wbeta)
+                dxs.append((skinny_dx(dy, Wi) if sk else gemm(dy, Wi, transB=True)) if need_dx else None)
+            k0 += K
+        if wbeta is not None:
+            W.grad_done()
+        if b is not None and b.trainable and b.grad is not None:
+            colsum(dy, b.grad.view(-1), beta=b.grad_beta())
+            b.grad_done()
+        return (None, None, None, None, None) + tuple(dxs)
+
+
+def linear_cat(parts, W, b=None, group_parts=()):
+    """parts: tensors [..., K_i] with equal leading dims; group_parts: tensors [G, K_j] with G * rep = number of rows, each row
+    standing for `rep` consecutive rows (appended after `parts` in the concatenation order)."""
+    lead = parts[0].shape[:-1]
+    flat = [p.reshape(-1, p.shape[-1]) for p in parts]
+    rep = 1
+    if group_parts:
+        rep = flat[0].shape[0] // group_parts[0].shape[0]
+    y = _LinearCat.apply(_token(W._graph), W, b, rep, len(flat), *flat, *group_parts)
+    return y.view(*lead, y.shape[-1])
+
+
 def linear(x, W, b=None, bf16=None):
     """Rank-N input is flattened on the leading dims like slim.fully_connected."""
+    if W.data.shape[1] <= 16 and x.numel() // x.shape[-1] >= SKINNY_MIN_ROWS:
+        return linear_cat([x], W, b)
     lead = x.shape[:-1]
     if bf16 is None:
         bf16 = FLAGS.compute_dtype == "bfloat16"

@@ -30,6 +30,17 @@ def fully_connected(x, num_outputs, scope, activation=None, use_bias=True, l2_pe
     return ops.activation(y, activation) if activation else y
 
 
+def fully_connected_cat(parts, num_outputs, scope, activation=None, use_bias=True, l2_penalty=0.0, group_parts=()):
+    """slim.fully_connected(tf.concat(parts + tiled group_parts, axis=-1), ...) without materialising the concatenation
+    (same variables): group_parts are per-video vectors [B, K] that the reference tiles over the frame axis."""
+    g = get_default_graph()
+    width = sum(p.shape[-1] for p in parts) + sum(p.shape[-1] for p in group_parts)
+    W = g.get_variable(scope + "/weights", (width, num_outputs), xavier_uniform, l2=l2_penalty)
+    b = g.get_variable(scope + "/biases", (num_outputs,), zeros) if use_bias else None
+    y = ops.linear_cat(list(parts), W, b, group_parts=tuple(group_parts))
+    return ops.activation(y, activation) if activation else y
+
+
 def moe_block(model_input, vocab_size, num_mixtures, l2_penalty, gate_scope, expert_scope):
     """The MoE block shared by MoeModel, the chain models' sub_model and the attention model's sub_moe
     (W/all_video_models/moe_model.py:40-64).  Gate FC has no bias; column l*(M+1)+m = gate m of label l."""
