@@ -105,12 +105,12 @@ template <int NT, bool DX>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                          int64_t ldy, const float* __restrict__ W, int64_t ldw,
                                                          float* __restrict__ out, int64_t ldo, int64_t M, int K, int N,
-                                                         float beta, int rows_per_chunk) {
+                                                         float beta, int rows_per_chunk, int kslice) {
   constexpr int RC = 64;                                               // dy rows staged per pass
   __shared__ __attribute__((aligned(16))) float dyl[RC * NT];
   const int tid = threadIdx.x;
-  const int k0 = blockIdx.x * 1024 + 4 * tid;
-  const bool kin = k0 < K;
+  const int k0 = blockIdx.x * kslice + 4 * tid;                        // kslice <= 1024, % 4 == 0: balanced k slices
+  const bool kin = 4 * tid < kslice && k0 < K;
   const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
   const int64_t r_end = r_begin + rows_per_chunk < M ? r_begin + rows_per_chunk : M;
   float acc[4 * NT];                                                   // dW: partial sums; dx: the W[k0..k0+3][0..NT) block
@@ -189,6 +189,20 @@ int chunk_rows(int64_t M, int chunks) {
   return (int)(r < 64 ? 64 : r);
 }
 
+// k slices of equal width (<= 1024 = 256 threads x float4) and enough row chunks for >= ~1536 workgroups
+struct BwdPlan { int nslices, kslice, chunks, rows; };
+BwdPlan bwd_plan(int64_t M, int64_t K) {
+  BwdPlan p;
+  p.nslices = (int)((K + 1023) / 1024);
+  p.kslice = (int)(((K + p.nslices - 1) / p.nslices + 3) / 4 * 4);
+  int want = (1536 + p.nslices - 1) / p.nslices;
+  if (want > 512) want = 512;
+  if (want < 64) want = 64;
+  p.rows = chunk_rows(M, want);
+  p.chunks = (int)((M + p.rows - 1) / p.rows);
+  return p;
+}
+
 }  // namespace
 
 using namespace yt8m;
@@ -208,9 +222,8 @@ extern "C" int yt8m_skinny_supported(int64_t M, int64_t K, int64_t N) {
 
 extern "C" int64_t yt8m_skinny_workspace_bytes(int64_t M, int64_t K, int64_t N) {
   const int NT = N <= 8 ? 8 : 16;
-  const int chunks = 256;
-  const int rows = chunk_rows(M, chunks);
-  return ((M + rows - 1) / rows) * K * NT * (int64_t)sizeof(float);
+  const BwdPlan p = bwd_plan(M, K);
+  return (int64_t)(p.chunks > 0 ? p.chunks : 1) * K * NT * (int64_t)sizeof(float);
 }
 
 extern "C" int yt8m_skinny_fwd_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* y,
@@ -254,20 +267,20 @@ extern "C" int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, 
   YT8M_REQUIRE(workspace && workspace_bytes >= yt8m_skinny_workspace_bytes(M, K, N), YT8M_E_BADARG, "workspace too small");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);
-  const int rows = chunk_rows(M, 256);
-  const int chunks = (int)((M + rows - 1) / rows);
+  const BwdPlan pl = bwd_plan(M, K);
+  const int rows = pl.rows, chunks = pl.chunks, kslice = pl.kslice;
   float* ws = static_cast<float*>(workspace);
-  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)(chunks > 0 ? chunks : 1));
+  const dim3 grid((unsigned)pl.nslices, (unsigned)(chunks > 0 ? chunks : 1));
   if (N <= 8) {
     if (chunks > 0)
       hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0, ws,
-                         (int64_t)0, M, (int)K, (int)N, 0.f, rows);
+                         (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice);
     hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw, (int)K,
                        (int)N, beta);
   } else {
     if (chunks > 0)
       hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0, ws,
-                         (int64_t)0, M, (int)K, (int)N, 0.f, rows);
+                         (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice);
     hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw,
                        (int)K, (int)N, beta);
   }
@@ -283,14 +296,14 @@ extern "C" int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, 
   YT8M_REQUIRE(lddx >= K && lddx % 4 == 0 && ldy >= N && ldw >= N && ((uintptr_t)dx & 15) == 0, YT8M_E_SHAPE, "bad leading dimension / alignment");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);
-  const int rows = chunk_rows(M, 256);
-  const int chunks = (int)((M + rows - 1) / rows);
-  const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)chunks);
+  const BwdPlan pl = bwd_plan(M, K);
+  const int rows = pl.rows, kslice = pl.kslice;
+  const dim3 grid((unsigned)pl.nslices, (unsigned)pl.chunks);
   if (N <= 8)
     hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw, dx, lddx,
-                       M, (int)K, (int)N, beta, rows);
+                       M, (int)K, (int)N, beta, rows, kslice);
   else
     hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw, dx,
-                       lddx, M, (int)K, (int)N, beta, rows);
+                       lddx, M, (int)K, (int)N, beta, rows, kslice);
   return launch_status("skinny_bwd_kernel<dx>");
 }
