@@ -78,6 +78,11 @@ int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* w
 /* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows]. */
 int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int transpose,
                        yt8m_stream_t stream);
+/* both layouts from ONE pass over the fp32 source: dst_plain [rows, cols] and dst_trans [cols, rows] (8 B/element of HBM
+ * traffic instead of 12).  Operands that are needed K-contiguous in one product and N-contiguous in another (dZ for dx and
+ * dW; W for the forward and dx; x for the forward and dW) are cast once. */
+int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_plain, void* dst_trans,
+                            yt8m_stream_t stream);
 
 /* ---- input transform ---------------------------------------------------------------------------
  * yt8m_l2norm_*: tf.nn.l2_normalize on the last axis (W/all_feature_transform/default_transformer.py:4-8,

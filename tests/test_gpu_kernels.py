@@ -537,13 +537,21 @@ def test_cast_bf16_and_bf16_gemm(dev):
     """bf16 path: the cast is bit-exact against the RNE restatement (also transposed, ragged shapes); the bf16 NT GEMM
     equals the fp64 product of the ROUNDED operands to fp32-accumulation noise, across tile / split-K / K-tail cases."""
     rs = np.random.RandomState(31)
-    for R, C in [(5, 7), (64, 64), (130, 257), (1024, 1152)]:
+    # (5,7) / (130,257): scalar kernels; (64,64), (1024,1152), (132,260), (8,4716): vector / tiled kernels incl. ragged tiles
+    for R, C in [(5, 7), (64, 64), (130, 257), (1024, 1152), (132, 260), (8, 4716), (6, 8)]:
         x = (rs.randn(R, C) * 3).astype(np.float32)
         x.flat[0] = 1.00390625         # exact tie between two bf16 values -> even
+        x.flat[-1] = np.nan
+        want = _bf16_round(x)
         xb = ops.cast_bf16(D(x, dev))
-        assert np.array_equal(xb.float().cpu().numpy(), _bf16_round(x))
+        assert np.array_equal(xb.float().cpu().numpy(), want, equal_nan=True)
         xt = ops.cast_bf16(D(x, dev), transpose=True)
-        assert xt.shape == (C, R) and np.array_equal(xt.float().cpu().numpy(), _bf16_round(x).T)
+        assert xt.shape == (C, R) and np.array_equal(xt.float().cpu().numpy(), want.T, equal_nan=True)
+        pb, pt = ops.cast_bf16_both(D(x, dev))                       # both layouts from one pass
+        assert torch.equal(pb.view(torch.int16), xb.view(torch.int16)) and torch.equal(pt.view(torch.int16), xt.view(torch.int16))
+        wide = D(np.concatenate([x, x], axis=1), dev)[:, :C]          # a row-strided view (ld = 2C)
+        assert torch.equal(ops.cast_bf16(wide).view(torch.int16), xb.view(torch.int16))
+        assert torch.equal(ops.cast_bf16_both(wide)[1].view(torch.int16), xt.view(torch.int16))
     for M, N, K in [(1, 1, 2), (5, 7, 6), (128, 128, 32), (130, 257, 66), (64, 300, 1152), (1024, 2358, 1152), (100, 1000, 4096)]:
         A = rs.randn(M, K).astype(np.float32)
         B = rs.randn(N, K).astype(np.float32)

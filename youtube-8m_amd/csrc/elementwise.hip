@@ -417,6 +417,60 @@ __global__ __launch_bounds__(256) void cast_bf16_transpose_kernel(const float* _
   }
 }
 
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) { return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16); }
+
+// Vector forms for 16-byte aligned sources with cols % 4 == 0 (every tensor of the bf16 training path):
+// plain: 8 elements per thread (two float4 in, one 16-byte store).
+__global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
+                                                            unsigned short* __restrict__ dst) {
+  const int64_t cg = cols >> 2;                                        // float4 groups per row
+  const int64_t n = rows * cg;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / cg, c = (e - r * cg) << 2;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
+    *reinterpret_cast<uint2*>(dst + r * cols + c) = uint2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+  }
+}
+
+// 64 x 64 tile: float4 loads (a row of the tile = 16 lanes), optional plain bf16 store (8 bytes per lane, 128 B per row),
+// transposed store through an LDS tile of bf16 PAIRS [64 rows][32 column pairs + 1]: a lane gathers rows 4q..4q+3 of one
+// column pair (4 ds_read_b32, 2-way conflicts at most) and writes 8 bytes to each of the two transposed rows, so a 16-lane
+// group writes 128 contiguous bytes of dst[c][r0..r0+63].  PLAIN && TRANS: both layouts from ONE read of the fp32 source.
+template <bool PLAIN, bool TRANS>
+__global__ __launch_bounds__(256) void cast_bf16_tile_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
+                                                             unsigned short* __restrict__ dplain, unsigned short* __restrict__ dtrans) {
+  __shared__ unsigned int tile[64][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  {
+    const int lr = tid >> 4, lc = (tid & 15) << 2;                     // 16 rows per pass
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int64_t r = r0 + lr + 16 * ps, c = c0 + lc;
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && c < cols) v = *reinterpret_cast<const float4*>(src + r * ld + c);   // cols % 4 == 0: all or nothing
+      const unsigned int p0 = pack_bf2(v.x, v.y), p1 = pack_bf2(v.z, v.w);
+      if (PLAIN && r < rows && c < cols) *reinterpret_cast<uint2*>(dplain + r * cols + c) = uint2{p0, p1};
+      if (TRANS) { tile[lr + 16 * ps][lc >> 1] = p0; tile[lr + 16 * ps][(lc >> 1) + 1] = p1; }
+    }
+  }
+  if (!TRANS) return;
+  __syncthreads();
+  const int rq = tid & 15;                                              // rows 4rq .. 4rq+3 of the tile
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int cp = (tid >> 4) + 16 * ps;                                // column pair
+    const unsigned int a = tile[4 * rq + 0][cp], b = tile[4 * rq + 1][cp], c = tile[4 * rq + 2][cp], d = tile[4 * rq + 3][cp];
+    const int64_t cc = c0 + 2 * cp, rr = r0 + 4 * rq;
+    if (rr + 3 < rows) {                                                // rows % 4 == 0 on this path
+      if (cc < cols)
+        *reinterpret_cast<uint2*>(dtrans + cc * rows + rr) = uint2{(a & 0xffffu) | (b << 16), (c & 0xffffu) | (d << 16)};
+      if (cc + 1 < cols)
+        *reinterpret_cast<uint2*>(dtrans + (cc + 1) * rows + rr) = uint2{(a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u)};
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t n, int per_block, int64_t cap = 1 << 20) {
   int64_t g = (n + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -542,6 +596,10 @@ extern "C" int yt8m_act_bwd_f32(int act, const float* y, const float* dy, float*
   return launch_status("act_bwd_kernel");
 }
 
+static bool cast_vec_ok(const float* src, int64_t rows, int64_t cols, int64_t ld, bool transposed) {
+  return cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src & 15) == 0 && (!transposed || rows % 4 == 0);
+}
+
 extern "C" int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int transpose,
                                   yt8m_stream_t stream) {
   YT8M_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, YT8M_E_SHAPE, "bad shape");
@@ -549,15 +607,37 @@ extern "C" int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, 
   YT8M_REQUIRE(src && dst, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
+  unsigned short* d = static_cast<unsigned short*>(dst);
   if (transpose) {
     YT8M_REQUIRE((rows + 63) / 64 <= 65535, YT8M_E_SHAPE, "too many rows for the transposing cast");
-    hipLaunchKernelGGL(cast_bf16_transpose_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s,
-                       src, rows, cols, ld, static_cast<unsigned short*>(dst));
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    if (cast_vec_ok(src, rows, cols, ld, true) && ((uintptr_t)dst & 7) == 0)
+      hipLaunchKernelGGL((cast_bf16_tile_kernel<false, true>), grid, dim3(256), 0, s, src, rows, cols, ld, (unsigned short*)nullptr, d);
+    else
+      hipLaunchKernelGGL(cast_bf16_transpose_kernel, grid, dim3(256), 0, s, src, rows, cols, ld, d);
+  } else if (cast_vec_ok(src, rows, cols, ld, false) && ((uintptr_t)dst & 7) == 0) {
+    hipLaunchKernelGGL(cast_bf16_vec_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, s, src, rows, cols, ld, d);
   } else {
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols, 256, 16384)), dim3(256), 0, s, src, rows, cols, ld,
-                       static_cast<unsigned short*>(dst));
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols, 256, 16384)), dim3(256), 0, s, src, rows, cols, ld, d);
   }
   return launch_status("cast_bf16_kernel");
+}
+
+extern "C" int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_plain, void* dst_trans,
+                                       yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, YT8M_E_SHAPE, "bad shape");
+  if (rows * cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(src && dst_plain && dst_trans, YT8M_E_BADARG, "null operand");
+  if (!(cast_vec_ok(src, rows, cols, ld, true) && (((uintptr_t)dst_plain | (uintptr_t)dst_trans) & 7) == 0)) {
+    int rc = yt8m_cast_f32_bf16(src, rows, cols, ld, dst_plain, 0, stream);       // unaligned / odd shapes: two passes
+    return rc != YT8M_OK ? rc : yt8m_cast_f32_bf16(src, rows, cols, ld, dst_trans, 1, stream);
+  }
+  YT8M_REQUIRE((rows + 63) / 64 <= 65535, YT8M_E_SHAPE, "too many rows for the transposing cast");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL((cast_bf16_tile_kernel<true, true>), dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0,
+                     s, src, rows, cols, ld, static_cast<unsigned short*>(dst_plain), static_cast<unsigned short*>(dst_trans));
+  return launch_status("cast_bf16_tile_kernel");
 }
 
 extern "C" int64_t yt8m_colsum_workspace_bytes(int64_t rows, int64_t cols) {

@@ -139,6 +139,17 @@ def cast_bf16(x, transpose=False):
     return out
 
 
+def cast_bf16_both(x):
+    """fp32 [R,C] -> (bf16 [R,C], bf16 [C,R]) from one pass over the source (yt8m_cast_f32_bf16_dual)."""
+    _dev(x)
+    x, ld = _rowmajor2d(x)
+    R, C = x.shape
+    plain = torch.empty((R, C), dtype=torch.bfloat16, device=x.device)
+    trans = torch.empty((C, R), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().yt8m_cast_f32_bf16_dual(_p(x), R, C, ld, _p(plain), _p(trans), _stream()))
+    return plain, trans
+
+
 def gemm_bf16_nt_grouped(items):
     """items: dicts(A=bf16 [M,K], B=bf16 [N,K], out=None fp32 [M,N], bias=None, beta=0.0) -> fp32 outputs.
     C = A . B^T on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (yt8m_gemm_bf16_nt_grouped)."""
@@ -453,11 +464,15 @@ class _Linear(torch.autograd.Function):
         dy = _f32c(dy)
         M, K = x.shape
         N = dy.shape[1]
-        dyT = None
+        dyb = None
         if W.trainable and W.grad is not None:
             if _use_bf16(ctx.bf16, K, N, M, weight_operand=False):   # dW[K,N] = x^T dy: reduction over the M rows
-                gemm_bf16_nt_grouped([dict(A=cast_bf16(x, transpose=True), B=cast_bf16(dy, transpose=True), out=W.grad,
-                                           beta=W.grad_beta())])
+                if ctx.needs_input_grad[0] and _use_bf16(ctx.bf16, M, K, N):
+                    dyb, dyT = cast_bf16_both(dy)                   # dy feeds dW (transposed) and dx (plain): one pass
+                else:
+                    dyT = cast_bf16(dy, transpose=True)
+                gemm_bf16_nt_grouped([dict(A=cast_bf16(x, transpose=True), B=dyT, out=W.grad, beta=W.grad_beta())])
+                del dyT
             else:
                 gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta())
         if b is not None and b.trainable and b.grad is not None:
@@ -465,7 +480,7 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if _use_bf16(ctx.bf16, M, K, N):                     # dx[M,K] = dy W^T: reduction over N
-                dx, = gemm_bf16_nt_grouped([dict(A=cast_bf16(dy), B=cast_bf16(W.data))])
+                dx, = gemm_bf16_nt_grouped([dict(A=dyb if dyb is not None else cast_bf16(dy), B=cast_bf16(W.data))])
             else:
                 dx = gemm(dy, W.data, transB=True)
         return dx, None, None, None, None
@@ -755,18 +770,25 @@ def _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be):
     """Same gradients on bf16 MFMAs: every product is written as A.B^T with K-contiguous bf16 copies
     (dW = x^T.dZ = (x^T) . (dZ^T)^T, dx = dZ . (W)^T with W [D,N] itself K-contiguous over N)."""
     dx = None
+    need_dw = Wg.grad is not None and We.grad is not None
+    dx_bf16 = ctx.needs_input_grad[0] and Zg.shape[1] % 2 == 0 and Ze.shape[1] % 2 == 0
+    ZgT = ZeT = None
     if ctx.needs_input_grad[0]:
-        if Zg.shape[1] % 2 == 0 and Ze.shape[1] % 2 == 0:
-            dx, = gemm_bf16_nt_grouped([dict(A=cast_bf16(Zg), B=cast_bf16(Wg.data))])
-            gemm_bf16_nt_grouped([dict(A=cast_bf16(Ze), B=cast_bf16(We.data), out=dx, beta=1.0)])
+        if dx_bf16:
+            # dZ is needed K-contiguous for dx and row-transposed for dW: both layouts from one pass over the fp32 logits
+            Zgb, ZgT = cast_bf16_both(Zg) if need_dw else (cast_bf16(Zg), None)
+            Zeb, ZeT = cast_bf16_both(Ze) if need_dw else (cast_bf16(Ze), None)
+            dx, = gemm_bf16_nt_grouped([dict(A=Zgb, B=cast_bf16(Wg.data))])
+            gemm_bf16_nt_grouped([dict(A=Zeb, B=cast_bf16(We.data), out=dx, beta=1.0)])
+            del Zgb, Zeb
         else:                                      # odd V*(M+1): the reduction length cannot be packed in bf16 pairs
             dx = gemm(Zg, Wg.data, transB=True)
             gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
-    if Wg.grad is not None and We.grad is not None:
+    if need_dw:
         xT = cast_bf16(x, transpose=True)
         overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
-        pg = dict(A=xT, B=cast_bf16(Zg, transpose=True), out=Wg.grad, beta=Wg.grad_beta())
-        pe = dict(A=xT, B=cast_bf16(Ze, transpose=True), out=We.grad, beta=We.grad_beta())
+        pg = dict(A=xT, B=ZgT if ZgT is not None else cast_bf16(Zg, transpose=True), out=Wg.grad, beta=Wg.grad_beta())
+        pe = dict(A=xT, B=ZeT if ZeT is not None else cast_bf16(Ze, transpose=True), out=We.grad, beta=We.grad_beta())
         if overlap:
             gemm_bf16_nt_grouped([pg])
             Wg.grad_done()
