@@ -3,7 +3,8 @@ YT8M_NO_PACKED_CELLS=1) -- prints checksums of outputs and gradients."""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__
 __graft_entry__.load_package()
 import yt8m_amd.seq_ops as seq_ops

@@ -1,7 +1,8 @@
 """Per-step losses and per-variable gradient checksums of the GRU pooling model (A/B with YT8M_NO_PACKED_CELLS=1)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__
 __graft_entry__.load_package()
 import yt8m_amd.frame_level_models as flm

@@ -2,8 +2,9 @@
 step itself is slower): python tools/gemm_calls.py config5_b1024"""
 import sys
 import torch
-sys.path.insert(0, ".")
-sys.path.insert(0, "tools")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import __graft_entry__
 __graft_entry__.load_package()
 import yt8m_amd.ops as ops

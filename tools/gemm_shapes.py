@@ -1,7 +1,8 @@
 """TFLOP/s of the fp32 grouped GEMM on a list of shapes: python tools/gemm_shapes.py  (GPU box)"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__
 __graft_entry__.load_package()
 import yt8m_amd.ops as ops
@@ -19,6 +20,10 @@ SHAPES = [  # (label, transA, transB, [(M, N, K), ...])
     ("head dW   K=8192", True, False, [(1152, 14148, 8192), (1152, 9432, 8192)]),
     ("head dx   K=23580", False, True, [(8192, 1152, 14148), (8192, 1152, 9432)]),
 ]
+_w = torch.randn(4096, 4096, device=dev)
+for _ in range(60):                      # ~70 ms of load first: the clocks of an idle box take a while to ramp
+    ops.gemm(_w, _w)
+torch.cuda.synchronize()
 for label, tA, tB, probs in SHAPES:
     items, fl = [], 0.0
     for (M, N, K) in probs:

@@ -1,7 +1,8 @@
 """Sustained-load check: TFLOP/s of one fp32 GEMM shape over successive windows (power / clock behaviour of the box)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__
 __graft_entry__.load_package()
 import yt8m_amd.ops as ops

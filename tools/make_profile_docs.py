@@ -54,21 +54,28 @@ def main():
         "```\nrocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_r1/lstm -o lstm -- python tools/model_bench.py lstm\n"
         "python tools/trace_gaps.py gpurun_out/prof_r1/lstm/lstm_kernel_trace.csv 0.6        # last 40 %% of the trace = ~3 steps\n```\n"
         "Step (profiled run, layer-pipelined stack with 4 time chunks): `%s`\n\n```\n%s```\n"
-        "Reading: per training step ~20 ms of hoisted projection / dW / dx GEMMs at the fp32 MFMA roofline (~120 TFLOP/s) and ~27 ms\n"
-        "of recurrence kernels (600 forward steps x 19.4 us, 600 backward steps x (22.2 + 4.0) us).  The layers of the stack run as a\n"
-        "wavefront over time chunks on separate streams (seq_ops._LstmStack), so the two classes overlap: the step takes 47-50 ms\n"
-        "instead of the 54.7 ms of the sequential form (busy fraction above counts overlapped kernels once).  The recurrence step\n"
-        "kernels run at 2.5-3x their MFMA bound (7 us): L2-bound re-streaming of h / dz / W_h (DESIGN.md section 7).  hipGraph replay\n"
-        "of the step chains is in place and hits its cache, but does not shorten the GPU-side gaps on this stack.\n" % (lstep, gaps))
+        "Reading: per training step ~20 ms of hoisted projection / dW / dx GEMMs at the fp32 MFMA roofline (~120 TFLOP/s) and the\n"
+        "recurrence: 600 forward step launches (`lstm_step_fwd_kernel<4, 0, 2>`: recurrent product + gates + copy-through) and 600\n"
+        "backward step launches (`lstm_step_bwd_kernel<2, 2>`: product of step t + gate backward of step t-1; the pointwise\n"
+        "`lstm_gates_bwd_kernel` only opens each time chunk).  The layers of the stack run as a wavefront over time chunks on\n"
+        "separate streams (seq_ops._LstmStack), so GEMMs and recurrence overlap (busy fraction above counts overlapped kernels\n"
+        "once).  Round history of this step: 54.7 ms (sequential layers) -> 49.5 (layer pipeline) -> 45.5 (float4-of-k packed\n"
+        "weights, line-coalesced A tile through LDS, prefetched epilogue operands) -> 42.2-42.6 (one launch per backward step).\n"
+        "What bounds the step kernels now (DESIGN.md section 4, 'Recurrence step kernels'): an L2-bandwidth-bound K loop (128 MB of\n"
+        "h / W_h per step) plus 6-7 us of fixed cost per launch, against a 6.8 us MFMA bound.\n" % (lstep, gaps))
     mb = "\n".join(l for l in open(O + "model_bench.txt").read().splitlines() if "B=" in l)
     open(R + "profiles/r1_plugin_step_times.md", "w").write(
         "# Round 1 -- training-step time of every plugin configuration (1 x MI355X, synthetic inputs, un-profiled by rocprofv3)\n\n"
         "`python tools/model_bench.py` (+ `config5_bf16 netvlad_bf16`): 5 timed steps after 2 warm-up steps; frame-level models get raw\n"
         "uint8 [B,300,1152] input, video-level models fp32 [B,1152]; V = 4716; families are hipEvent sums inside the library (they\n"
         "overlap for the layer-pipelined LSTM stacks, so their sum exceeds the step time there; the library profiler also turns the\n"
-        "hipGraph replay off and costs ~2 ms on the LSTM rows: 47.1 ms/step with `YT8M_NO_PROF=1`).\n\n```\n%s\n```\n"
-        "Default `python bench.py` line of the same build: %.1f k videos/s, %.3f ms/step, roofline.frac %.3f.\n"
-        % (mb, bench["value"] / 1e3, bench["ms_per_step"], r["frac"]))
+        "hipGraph replay off: see the `lstm(no library profiler ...)` row).\n\n```\n%s\n```\n"
+        "Default `python bench.py` line of the same build: %.1f k videos/s, %.3f ms/step, roofline.frac %.3f.\n\n"
+        "fp32 grouped GEMM on the shapes of these models (`tools/gemm_shapes.py`):\n\n```\n%s\n```\n"
+        "Streaming kernels of the attention-logit layer (`tools/skinny_bench.py`; TB/s = 4*M*K bytes / time):\n\n```\n%s\n```\n"
+        % (mb, bench["value"] / 1e3, bench["ms_per_step"], r["frac"],
+           "\n".join(l for l in open(O + "gemm_shapes.txt").read().splitlines() if "TFLOP" in l),
+           "\n".join(l for l in open(O + "skinny_bench.txt").read().splitlines() if "M=" in l)))
     print("profiles/ refreshed")
 
 

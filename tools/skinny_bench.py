@@ -1,7 +1,8 @@
 """GB/s of the skinny fully-connected kernels on the attention-logit shapes: python tools/skinny_bench.py (GPU box)"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__
 __graft_entry__.load_package()
 import yt8m_amd.ops as ops
