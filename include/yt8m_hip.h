@@ -75,14 +75,16 @@ int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_pro
  * LDS-DMA path.  Serves the bf16 configuration (BASELINE config 5): x / W^T / dZ^T are kept as bf16 copies. */
 int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                               yt8m_stream_t stream);
-/* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows]. */
-int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int transpose,
+/* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows].
+ * dst_ld: row stride of dst in bf16 elements (0 = dense).  The training path pads it to a multiple of 8 so that every bf16
+ * row starts 16-byte aligned and the GEMMs stay on their LDS-DMA path (V*(M+1) = 14148 is not a multiple of 8). */
+int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t dst_ld, int transpose,
                        yt8m_stream_t stream);
 /* both layouts from ONE pass over the fp32 source: dst_plain [rows, cols] and dst_trans [cols, rows] (8 B/element of HBM
  * traffic instead of 12).  Operands that are needed K-contiguous in one product and N-contiguous in another (dZ for dx and
  * dW; W for the forward and dx; x for the forward and dW) are cast once. */
-int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_plain, void* dst_trans,
-                            yt8m_stream_t stream);
+int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_plain, int64_t plain_ld,
+                            void* dst_trans, int64_t trans_ld, yt8m_stream_t stream);
 
 /* ---- input transform ---------------------------------------------------------------------------
  * yt8m_l2norm_*: tf.nn.l2_normalize on the last axis (W/all_feature_transform/default_transformer.py:4-8,

@@ -29,8 +29,8 @@ SIGNATURES = {
     "yt8m_gemm_workspace_bytes": (c_int64, []),
     "yt8m_gemm_f32_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_gemm_bf16_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
-    "yt8m_cast_f32_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, c_int, P]),
-    "yt8m_cast_f32_bf16_dual": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
+    "yt8m_cast_f32_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int, P]),
+    "yt8m_cast_f32_bf16_dual": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P]),
     "yt8m_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64,
                                       P, c_int64, c_int64, c_float, c_int64, P]),
     "yt8m_l2norm_fwd_f32": (c_int, [P, P, c_int64, c_int64, c_float, P]),

@@ -393,16 +393,16 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
-                                                        unsigned short* __restrict__ dst) {
+                                                        unsigned short* __restrict__ dst, int64_t dld) {
   const int64_t n = rows * cols;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / cols, c = e - r * cols;
-    dst[e] = f2bf(src[r * ld + c]);
+    dst[r * dld + c] = f2bf(src[r * ld + c]);
   }
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_transpose_kernel(const float* __restrict__ src, int64_t rows, int64_t cols,
-                                                                  int64_t ld, unsigned short* __restrict__ dst) {
+                                                                  int64_t ld, unsigned short* __restrict__ dst, int64_t dld) {
   __shared__ unsigned short tile[64][66];
   const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void cast_bf16_transpose_kernel(const float* _
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int64_t c = c0 + i, r = r0 + tx;          // dst[c][r]
-    if (c < cols && r < rows) dst[c * rows + r] = tile[tx][i];
+    if (c < cols && r < rows) dst[c * dld + r] = tile[tx][i];
   }
 }
 
@@ -422,13 +422,13 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) { return (u
 // Vector forms for 16-byte aligned sources with cols % 4 == 0 (every tensor of the bf16 training path):
 // plain: 8 elements per thread (two float4 in, one 16-byte store).
 __global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
-                                                            unsigned short* __restrict__ dst) {
+                                                            unsigned short* __restrict__ dst, int64_t dld) {
   const int64_t cg = cols >> 2;                                        // float4 groups per row
   const int64_t n = rows * cg;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / cg, c = (e - r * cg) << 2;
     const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
-    *reinterpret_cast<uint2*>(dst + r * cols + c) = uint2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+    *reinterpret_cast<uint2*>(dst + r * dld + c) = uint2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
   }
 }
 
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float* __restr
 // group writes 128 contiguous bytes of dst[c][r0..r0+63].  PLAIN && TRANS: both layouts from ONE read of the fp32 source.
 template <bool PLAIN, bool TRANS>
 __global__ __launch_bounds__(256) void cast_bf16_tile_kernel(const float* __restrict__ src, int64_t rows, int64_t cols, int64_t ld,
-                                                             unsigned short* __restrict__ dplain, unsigned short* __restrict__ dtrans) {
+                                                             unsigned short* __restrict__ dplain, int64_t pld,
+                                                             unsigned short* __restrict__ dtrans, int64_t tld) {
   __shared__ unsigned int tile[64][33];
   const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void cast_bf16_tile_kernel(const float* __rest
       float4 v = {0.f, 0.f, 0.f, 0.f};
       if (r < rows && c < cols) v = *reinterpret_cast<const float4*>(src + r * ld + c);   // cols % 4 == 0: all or nothing
       const unsigned int p0 = pack_bf2(v.x, v.y), p1 = pack_bf2(v.z, v.w);
-      if (PLAIN && r < rows && c < cols) *reinterpret_cast<uint2*>(dplain + r * cols + c) = uint2{p0, p1};
+      if (PLAIN && r < rows && c < cols) *reinterpret_cast<uint2*>(dplain + r * pld + c) = uint2{p0, p1};
       if (TRANS) { tile[lr + 16 * ps][lc >> 1] = p0; tile[lr + 16 * ps][(lc >> 1) + 1] = p1; }
     }
   }
@@ -464,9 +465,9 @@ __global__ __launch_bounds__(256) void cast_bf16_tile_kernel(const float* __rest
     const int64_t cc = c0 + 2 * cp, rr = r0 + 4 * rq;
     if (rr + 3 < rows) {                                                // rows % 4 == 0 on this path
       if (cc < cols)
-        *reinterpret_cast<uint2*>(dtrans + cc * rows + rr) = uint2{(a & 0xffffu) | (b << 16), (c & 0xffffu) | (d << 16)};
+        *reinterpret_cast<uint2*>(dtrans + cc * tld + rr) = uint2{(a & 0xffffu) | (b << 16), (c & 0xffffu) | (d << 16)};
       if (cc + 1 < cols)
-        *reinterpret_cast<uint2*>(dtrans + (cc + 1) * rows + rr) = uint2{(a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u)};
+        *reinterpret_cast<uint2*>(dtrans + (cc + 1) * tld + rr) = uint2{(a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u)};
     }
   }
 }
@@ -600,43 +601,53 @@ static bool cast_vec_ok(const float* src, int64_t rows, int64_t cols, int64_t ld
   return cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src & 15) == 0 && (!transposed || rows % 4 == 0);
 }
 
-extern "C" int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int transpose,
-                                  yt8m_stream_t stream) {
+extern "C" int yt8m_cast_f32_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst, int64_t dst_ld,
+                                  int transpose, yt8m_stream_t stream) {
   YT8M_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, YT8M_E_SHAPE, "bad shape");
+  if (dst_ld == 0) dst_ld = transpose ? rows : cols;
+  YT8M_REQUIRE(dst_ld >= (transpose ? rows : cols), YT8M_E_SHAPE, "dst_ld too small");
   if (rows * cols == 0) return YT8M_OK;
   YT8M_REQUIRE(src && dst, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
   unsigned short* d = static_cast<unsigned short*>(dst);
+  const bool dal = ((uintptr_t)dst & 7) == 0 && dst_ld % 4 == 0;
   if (transpose) {
     YT8M_REQUIRE((rows + 63) / 64 <= 65535, YT8M_E_SHAPE, "too many rows for the transposing cast");
     const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-    if (cast_vec_ok(src, rows, cols, ld, true) && ((uintptr_t)dst & 7) == 0)
-      hipLaunchKernelGGL((cast_bf16_tile_kernel<false, true>), grid, dim3(256), 0, s, src, rows, cols, ld, (unsigned short*)nullptr, d);
+    if (cast_vec_ok(src, rows, cols, ld, true) && dal)
+      hipLaunchKernelGGL((cast_bf16_tile_kernel<false, true>), grid, dim3(256), 0, s, src, rows, cols, ld, (unsigned short*)nullptr,
+                         (int64_t)0, d, dst_ld);
     else
-      hipLaunchKernelGGL(cast_bf16_transpose_kernel, grid, dim3(256), 0, s, src, rows, cols, ld, d);
-  } else if (cast_vec_ok(src, rows, cols, ld, false) && ((uintptr_t)dst & 7) == 0) {
-    hipLaunchKernelGGL(cast_bf16_vec_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, s, src, rows, cols, ld, d);
+      hipLaunchKernelGGL(cast_bf16_transpose_kernel, grid, dim3(256), 0, s, src, rows, cols, ld, d, dst_ld);
+  } else if (cast_vec_ok(src, rows, cols, ld, false) && dal) {
+    hipLaunchKernelGGL(cast_bf16_vec_kernel, dim3(grid_for(rows * (cols / 4), 256, 16384)), dim3(256), 0, s, src, rows, cols, ld, d,
+                       dst_ld);
   } else {
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols, 256, 16384)), dim3(256), 0, s, src, rows, cols, ld, d);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols, 256, 16384)), dim3(256), 0, s, src, rows, cols, ld, d, dst_ld);
   }
   return launch_status("cast_bf16_kernel");
 }
 
-extern "C" int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_plain, void* dst_trans,
-                                       yt8m_stream_t stream) {
+extern "C" int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst_plain,
+                                       int64_t plain_ld, void* dst_trans, int64_t trans_ld, yt8m_stream_t stream) {
   YT8M_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, YT8M_E_SHAPE, "bad shape");
+  if (plain_ld == 0) plain_ld = cols;
+  if (trans_ld == 0) trans_ld = rows;
+  YT8M_REQUIRE(plain_ld >= cols && trans_ld >= rows, YT8M_E_SHAPE, "destination leading dimension too small");
   if (rows * cols == 0) return YT8M_OK;
   YT8M_REQUIRE(src && dst_plain && dst_trans, YT8M_E_BADARG, "null operand");
-  if (!(cast_vec_ok(src, rows, cols, ld, true) && (((uintptr_t)dst_plain | (uintptr_t)dst_trans) & 7) == 0)) {
-    int rc = yt8m_cast_f32_bf16(src, rows, cols, ld, dst_plain, 0, stream);       // unaligned / odd shapes: two passes
-    return rc != YT8M_OK ? rc : yt8m_cast_f32_bf16(src, rows, cols, ld, dst_trans, 1, stream);
+  if (!(cast_vec_ok(src, rows, cols, ld, true) && (((uintptr_t)dst_plain | (uintptr_t)dst_trans) & 7) == 0 && plain_ld % 4 == 0 &&
+        trans_ld % 4 == 0)) {
+    int rc = yt8m_cast_f32_bf16(src, rows, cols, ld, dst_plain, plain_ld, 0, stream);    // unaligned / odd shapes: two passes
+    return rc != YT8M_OK ? rc : yt8m_cast_f32_bf16(src, rows, cols, ld, dst_trans, trans_ld, 1, stream);
   }
   YT8M_REQUIRE((rows + 63) / 64 <= 65535, YT8M_E_SHAPE, "too many rows for the transposing cast");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
   hipLaunchKernelGGL((cast_bf16_tile_kernel<true, true>), dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0,
-                     s, src, rows, cols, ld, static_cast<unsigned short*>(dst_plain), static_cast<unsigned short*>(dst_trans));
+                     s, src, rows, cols, ld, static_cast<unsigned short*>(dst_plain), plain_ld, static_cast<unsigned short*>(dst_trans),
+                     trans_ld);
   return launch_status("cast_bf16_tile_kernel");
 }
 

@@ -1,0 +1,270 @@
+// gemm_bf16.hip -- large-tile bf16 "NT" GEMM for the bf16 configuration (BASELINE configs[4]); gfx950, wave64.
+//
+// C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias), A / B bf16 with K contiguous, fp32 accumulate / output (v_mfma_f32_32x32x16_bf16).
+//
+// Why a second kernel: on the 128 x 128 tiles of gemm_f32.hip a bf16 K-step carries 8x less matrix time than an fp32 one for
+// the same operand bytes, and the kernel runs at the rate the L2 delivers operands: 64 FLOP per byte of L2 -> LDS traffic x
+// ~8.5 TB/s = 0.55 PFLOP/s measured on the [8192, 2304] x [23580, 2304] MoE heads (22 % of the 2.5 PFLOP/s peak).  Here a
+// workgroup owns a 256 x 256 tile (128 FLOP per operand byte): 8 waves as 2 (M) x 4 (N), each 128 x 64 = 4 x 2 MFMA tiles
+// (128 accumulator registers), operands HBM/L2 -> LDS by LDS-DMA into a 4-stage ring (K-step = 32 bf16 = 64 bytes per row,
+// 32 KiB per stage, three steps on the wire), the same XOR-swizzled lane-linear image and conflict-free ds_read_b128 fragment
+// fetch as gemm_f32.hip, float4 epilogue through LDS.  One tile per workgroup, banded + XCD-aware tile order, up to four
+// problems per launch.  K tails (K % 32 != 0) take a guarded zero-padded store for the last step.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, BKF = 16;          // BKF: floats per row and K-step (= 32 bf16)
+constexpr int TILE_F = BKF * 256;                     // floats of one operand tile (16 KiB)
+constexpr int NST = 4;                                // LDS-DMA ring depth
+constexpr int STAGE_F = 2 * TILE_F;                   // A tile + B tile
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct BArgs {
+  const float* A;       // bf16 [M, K] viewed as float [M, K/2]
+  const float* B;       // bf16 [N, K] viewed as float [N, K/2]
+  float* C;
+  const float* bias;
+  int64_t lda, ldb, ldc;   // lda / ldb in floats
+  int M, N, K;             // K in floats
+  int tiles_m, tiles_n;
+  int accumulate;
+};
+struct BGroup {
+  BArgs p[4];
+  int tile_base[5];
+  int nprob;
+};
+
+__device__ __forceinline__ int xcd_remap(int wg, int n) {
+  const int xcd = wg & 7, slot = wg >> 3;
+  const int q = n >> 3, rem = n & 7;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+}
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int lt, int& tm, int& tn) {
+  constexpr int GM = 4;                                // 4 x 8 tile blocks per XCD share of a 256-workgroup round
+  const int band_tiles = GM * tiles_n;
+  const int band = lt / band_tiles;
+  const int first = band * GM;
+  const int rows = min(GM, tiles_m - first);
+  const int in = lt - band * band_tiles;
+  tn = in / rows;
+  tm = first + (in - tn * rows);
+}
+
+// slot idx in [0, 1024): row x = idx >> 2 of the tile, 16-byte chunk slot idx & 3 holding chunk (idx & 3) ^ ((x >> 2) & 3)
+__device__ __forceinline__ void fill_dma(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, float* S, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 512;
+    const int x = idx >> 2;
+    int gx = x0 + x;
+    if (gx >= X) gx = X - 1;                           // rows beyond the matrix only feed outputs that are never stored
+    const float* src = P + (int64_t)gx * ld + k0 + 4 * ((idx & 3) ^ ((x >> 2) & 3));
+    float* dst = S + (idx & ~63) * 4;                  // wave-uniform base; the hardware adds lane * 16 bytes
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void fill_guarded(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, int K, float* S, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 512;
+    const int x = idx >> 2;
+    const int gx = x0 + x, gk = k0 + 4 * ((idx & 3) ^ ((x >> 2) & 3));
+    float4 r = {0.f, 0.f, 0.f, 0.f};
+    if (gx < X) {
+      const float* p = P + (int64_t)gx * ld + gk;
+      if (gk + 3 < K) r = *reinterpret_cast<const float4*>(p);
+      else {
+        if (gk + 0 < K) r.x = p[0];
+        if (gk + 1 < K) r.y = p[1];
+        if (gk + 2 < K) r.z = p[2];
+      }
+    }
+    *reinterpret_cast<float4*>(&S[idx * 4]) = r;
+  }
+}
+__device__ __forceinline__ void fill_step(const BArgs& g, int m0, int n0, int kt, float* stage, int tid) {
+  if ((kt + 1) * BKF <= g.K) {
+    fill_dma(g.A, g.lda, m0, kt * BKF, g.M, stage, tid);
+    fill_dma(g.B, g.ldb, n0, kt * BKF, g.N, stage + TILE_F, tid);
+  } else {
+    fill_guarded(g.A, g.lda, m0, kt * BKF, g.M, g.K, stage, tid);
+    fill_guarded(g.B, g.ldb, n0, kt * BKF, g.N, g.K, stage + TILE_F, tid);
+  }
+}
+
+__device__ __forceinline__ bf16x8 frag(const float* __restrict__ S, int row, int h, int lk) {
+  const float4 q = *reinterpret_cast<const float4*>(&S[row * 16 + 4 * ((2 * h + lk) ^ ((row >> 2) & 3))]);
+  return __builtin_bit_cast(bf16x8, q);
+}
+
+__device__ __forceinline__ void wait_dma(int younger_steps) {      // 4 DMA instructions per thread and K-step
+  if (younger_steps >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (younger_steps == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 128 KiB
+  const int tile = xcd_remap(blockIdx.x, G.tile_base[G.nprob]);
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  const BArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int nk = (g.K + BKF - 1) / BKF;
+  const bool tail = nk * BKF != g.K;                               // the last step is a guarded (non-DMA) fill
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: steps 0, 1, 2 on the wire; wait for step 0 only
+  const int pro = nk < 3 ? nk : 3;
+  for (int s = 0; s < pro; ++s) fill_step(g, m0, n0, s, smem + s * STAGE_F, tid);
+  // DMA steps younger than step 0 that are still allowed in flight; once the guarded tail has been stored (its register
+  // loads completed in order behind every DMA) everything has landed and a full drain is exact
+  {
+    const bool tail_issued = tail && pro == nk;
+    wait_dma(tail_issued ? 0 : pro - 1);
+  }
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 3 < nk) fill_step(g, m0, n0, kt + 3, smem + ((cur + 3) & 3) * STAGE_F, tid);
+    const float* As = smem + cur * STAGE_F;
+    const float* Bs = As + TILE_F;
+    bf16x8 a[2][4], b[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[h][t] = frag(As, wm + t * 32 + li, h, lk);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[h][t] = frag(Bs, wn + t * 32 + li, h, lk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // step kt+1 must have landed; kt+2 and kt+3 may stay on the wire
+    {
+      const int last_issued = kt + 3 < nk ? kt + 3 : nk - 1;
+      const bool tail_issued = tail && last_issued == nk - 1;
+      int younger = last_issued - (kt + 1);
+      if (younger < 0) younger = 0;
+      wait_dma(tail_issued ? 0 : younger);
+    }
+    __builtin_amdgcn_s_barrier();
+    cur = (cur + 1) & 3;
+  }
+
+  // epilogue: accumulators -> wave-private LDS image [32][68] -> 16-byte stores (the store pipe is issue-bound)
+  constexpr int P = 68;
+  float* st = smem + wave * (32 * P);
+  const bool vec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = lane + 64 * k;
+      const int rr = idx >> 4, c4 = (idx & 15) * 4;
+      const int row = m0 + wm + i * 32 + rr, col = n0 + wn + c4;
+      float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+      if (row < g.M && col < g.N) {
+        float* c = g.C + (int64_t)row * g.ldc + col;
+        if (vec && col + 3 < g.N) {
+          if (g.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (g.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(c) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && col + e < g.N; ++e) {
+            float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
+            if (g.accumulate) t += c[e];
+            c[e] = t;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace yt8m {
+
+// true when the large-tile kernel can take the whole group (16-byte aligned K-contiguous rows) and there are enough tiles
+bool gemm_bf16_big_ok(int nprob, const yt8m_gemm_problem* probs) {
+  const char* e = getenv("YT8M_BF16_BIG_MIN");            // A/B switch (tools/, tests): minimum number of 256 x 256 tiles
+  const int64_t min_tiles = e ? atoll(e) : 512;
+  int64_t T = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    if (q.M == 0 || q.N == 0) continue;
+    if (q.K < 32 || q.K % 2 || q.lda % 8 || q.ldb % 8) return false;
+    if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return false;
+    T += ((q.M + TM - 1) / TM) * ((q.N + TN - 1) / TN);
+  }
+  return T >= min_tiles;
+}
+
+int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, hipStream_t s) {
+  BGroup G;
+  G.nprob = 0;
+  int64_t T = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    if (q.M == 0 || q.N == 0) continue;
+    BArgs g;
+    g.A = static_cast<const float*>(q.A); g.B = static_cast<const float*>(q.B); g.C = q.C; g.bias = q.bias;
+    g.lda = q.lda / 2; g.ldb = q.ldb / 2; g.ldc = q.ldc;
+    g.M = (int)q.M; g.N = (int)q.N; g.K = (int)(q.K / 2);
+    g.tiles_m = (int)((q.M + TM - 1) / TM); g.tiles_n = (int)((q.N + TN - 1) / TN);
+    g.accumulate = q.beta != 0.f;
+    G.p[G.nprob] = g;
+    G.tile_base[G.nprob] = (int)T;
+    T += (int64_t)g.tiles_m * g.tiles_n;
+    ++G.nprob;
+  }
+  if (G.nprob == 0) return YT8M_OK;
+  for (int i = G.nprob; i <= 4; ++i) G.tile_base[i] = (int)T;
+  for (int i = G.nprob; i < 4; ++i) G.p[i] = G.p[0];
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NST * STAGE_F * (int)sizeof(float));
+    once = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3((unsigned)T), dim3(512), NST * STAGE_F * sizeof(float), s, G);
+  return launch_status("gemm_bf16_big_kernel");
+}
+
+}  // namespace yt8m

@@ -684,8 +684,25 @@ extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt
   return grouped_launch(transA, transB, 0, nprob, probs, workspace, workspace_bytes, stream);
 }
 
+namespace yt8m {  // gemm_bf16.hip: 256 x 256 tiles for problems large enough to fill the chip with them
+bool gemm_bf16_big_ok(int nprob, const yt8m_gemm_problem* probs);
+int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, hipStream_t s);
+}  // namespace yt8m
+
 extern "C" int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                                          yt8m_stream_t stream) {
+  using namespace yt8m;
+  YT8M_REQUIRE(nprob >= 1 && nprob <= MAX_GROUP && probs, YT8M_E_BADARG, "1..4 problems");
+  bool simple = true;                              // the large-tile kernel takes validated, aligned problems only
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    simple = simple && q.M >= 0 && q.N >= 0 && q.K >= 0 && q.A && q.B && q.C && q.lda >= q.K && q.ldb >= q.K && q.ldc >= q.N &&
+             (q.beta == 0.f || q.beta == 1.f);
+  }
+  if (simple && gemm_bf16_big_ok(nprob, probs)) {
+    ProfScope prof(F_GEMM, as_stream(stream));
+    return gemm_bf16_big_launch(nprob, probs, as_stream(stream));
+  }
   return grouped_launch(0, 1, 1, nprob, probs, workspace, workspace_bytes, stream);
 }
 

@@ -129,13 +129,21 @@ def gemm_simple(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0)
     return out
 
 
+def _bf16_empty(rows, cols, device):
+    """bf16 [rows, cols] whose rows start 16-byte aligned (row pitch padded to a multiple of 8 elements): the bf16 GEMMs then
+    stay on their LDS-DMA path for any reduction length (V*(M+1) = 14148 is not a multiple of 8)."""
+    pitch = (cols + 7) // 8 * 8
+    return torch.empty((rows, pitch), dtype=torch.bfloat16, device=device)[:, :cols]
+
+
 def cast_bf16(x, transpose=False):
-    """fp32 [R,C] (inner stride 1) -> bf16 [R,C] or, transposed, [C,R] (yt8m_cast_f32_bf16, round to nearest even)."""
+    """fp32 [R,C] (inner stride 1) -> bf16 [R,C] or, transposed, [C,R] (yt8m_cast_f32_bf16, round to nearest even); the result
+    is a view with a 16-byte aligned row pitch."""
     _dev(x)
     x, ld = _rowmajor2d(x)
     R, C = x.shape
-    out = torch.empty((C, R) if transpose else (R, C), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().yt8m_cast_f32_bf16(_p(x), R, C, ld, _p(out), int(transpose), _stream()))
+    out = _bf16_empty(C, R, x.device) if transpose else _bf16_empty(R, C, x.device)
+    _lib.check(_lib.lib().yt8m_cast_f32_bf16(_p(x), R, C, ld, _p(out), out.stride(0), int(transpose), _stream()))
     return out
 
 
@@ -144,9 +152,9 @@ def cast_bf16_both(x):
     _dev(x)
     x, ld = _rowmajor2d(x)
     R, C = x.shape
-    plain = torch.empty((R, C), dtype=torch.bfloat16, device=x.device)
-    trans = torch.empty((C, R), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().yt8m_cast_f32_bf16_dual(_p(x), R, C, ld, _p(plain), _p(trans), _stream()))
+    plain = _bf16_empty(R, C, x.device)
+    trans = _bf16_empty(C, R, x.device)
+    _lib.check(_lib.lib().yt8m_cast_f32_bf16_dual(_p(x), R, C, ld, _p(plain), plain.stride(0), _p(trans), trans.stride(0), _stream()))
     return plain, trans
 
 
