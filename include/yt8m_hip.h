@@ -159,6 +159,14 @@ int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy
 int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, int64_t ldw, float* dx, int64_t lddx, int64_t M, int64_t K,
                        int64_t N, float beta, yt8m_stream_t stream);
 
+/* attention pooling over the frame axis (lstm_attention_max_pooling_model.py:63, einsum "ijk,ijl->ikl") on the same streaming
+ * kernels: w [B,F,A] (A <= 16), x [B,F,H] (H % 4 == 0), C [B,A,H] = w^T . x per video; dense row-major fp32.
+ * bwd: dw [B,F,A] = x . dC^T and / or dx [B,F,H] = w . dC (either may be NULL). */
+int yt8m_attn_pool_supported(int64_t B, int64_t F, int64_t A, int64_t H);
+int yt8m_attn_pool_fwd(const float* w, const float* x, float* C, int64_t B, int64_t F, int64_t A, int64_t H, yt8m_stream_t stream);
+int yt8m_attn_pool_bwd(const float* w, const float* x, const float* dC, float* dw, float* dx, int64_t B, int64_t F, int64_t A,
+                       int64_t H, yt8m_stream_t stream);
+
 /* ---- GRUCell / LayerNormBasicLSTMCell layers (csrc/cells.hip), time-major, generic per-step form --------------------
  * tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn (W/all_frame_models/gru_pooling_model.py:34-47):
  *   zg [F,B,2H]: in = x.Wg[:in] + b_gates (hoisted by the caller), out = the gates r | u;

@@ -751,3 +751,25 @@ def test_skinny_rejects_and_linear_cat(dev, monkeypatch):
         (y * D(gy, dev)).sum().backward()
         for got, ref in ((W.grad, tW.grad), (b.grad, tb.grad), (da.grad, ta.grad), (dc.grad, tc.grad), (dm.grad, tm.grad)):
             assert np.abs(H(got) - ref.numpy()).max() < 5e-5 * max(1.0, np.abs(ref.numpy()).max())
+
+
+@pytest.mark.parametrize("B,F,A,Hh", [(3, 7, 3, 8), (5, 300, 8, 1152), (2, 129, 16, 260), (4, 64, 1, 1024)])
+def test_attention_pooling_streaming_kernels(dev, B, F, A, Hh, monkeypatch):
+    """yt8m_attn_pool_fwd / _bwd (einsum "ijk,ijl->ikl" and its two gradients) vs fp64 numpy, and seq_ops.pool_tn through both
+    the streaming kernels and the batched GEMM."""
+    rs = np.random.RandomState(B * F + A)
+    w = rs.randn(B, F, A).astype(np.float32)
+    x = rs.randn(B, F, Hh).astype(np.float32)
+    g = rs.randn(B, A, Hh).astype(np.float32)
+    refC = np.einsum("bfa,bfh->bah", w.astype(np.float64), x.astype(np.float64))
+    refdw = np.einsum("bfh,bah->bfa", x.astype(np.float64), g.astype(np.float64))
+    refdx = np.einsum("bfa,bah->bfh", w.astype(np.float64), g.astype(np.float64))
+    for min_elems in (1, 1 << 40):
+        monkeypatch.setattr(seq_ops, "POOL_STREAM_MIN", min_elems)
+        wd, xd = D(w, dev).requires_grad_(True), D(x, dev).requires_grad_(True)
+        C = seq_ops.pool_tn(wd, xd)
+        assert np.abs(H(C) - refC).max() < 2e-5 * max(1.0, np.abs(refC).max())
+        (C * D(g, dev)).sum().backward()
+        assert np.abs(H(wd.grad) - refdw).max() < 2e-5 * max(1.0, np.abs(refdw).max())
+        assert np.abs(H(xd.grad) - refdx).max() < 2e-5 * max(1.0, np.abs(refdx).max())
+    assert L.lib().yt8m_attn_pool_supported(4, 10, 17, 64) == 0 and L.lib().yt8m_attn_pool_supported(4, 10, 8, 66) == 0

@@ -53,6 +53,9 @@ SIGNATURES = {
     "yt8m_skinny_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_skinny_dw_f32": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_skinny_dx_f32": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_attn_pool_supported": (c_int, [c_int64, c_int64, c_int64, c_int64]),
+    "yt8m_attn_pool_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "yt8m_attn_pool_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "yt8m_gru_layer_fwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_gru_layer_bwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lnlstm_layer_fwd": (c_int, [P, P, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_float,

@@ -12,11 +12,17 @@ namespace {
 
 // ---- forward: a wave owns 4 rows at a time; lane l covers k = 256 j + 4 l + e; W lives in LDS as [j][q = 2e+h][lane][4]
 //      (n = 4h..4h+3 for NT = 8; q = 4e + h for NT = 16) so that the per-lane b128 reads are conflict-free -------------------
+// Batched form (blockIdx.y = batch, element strides bx / bw / by): the attention pooling backward dw[b] = x[b] . dC[b]^T of
+// lstm_attention_max_pooling_model.py:63, with W[k][n] = dC[b][n][k] addressed through (wsk, wsn).
 template <int NT>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W,
-                                                         int64_t ldw, const float* __restrict__ bias, float* __restrict__ y,
-                                                         int64_t ldy, int64_t M, int K, int N, float beta, int rows_per_wg) {
+                                                         int64_t wsk, int64_t wsn, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int64_t ldy, int64_t M, int K, int N, float beta,
+                                                         int rows_per_wg, int64_t bx, int64_t bw, int64_t by) {
   extern __shared__ __attribute__((aligned(16))) float wl[];           // J * (NT) * 64 * 4 floats
+  x += (int64_t)blockIdx.y * bx;
+  W += (int64_t)blockIdx.y * bw;
+  y += (int64_t)blockIdx.y * by;
   constexpr int QN = NT / 4;                                           // float4 groups per k
   constexpr int R = 4;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -26,10 +32,10 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     const int k = 256 * j + 4 * l + q / QN, n0 = 4 * (q % QN);
     float4 v = {0.f, 0.f, 0.f, 0.f};
     if (k < K) {
-      if (n0 + 0 < N) v.x = W[(int64_t)k * ldw + n0 + 0];
-      if (n0 + 1 < N) v.y = W[(int64_t)k * ldw + n0 + 1];
-      if (n0 + 2 < N) v.z = W[(int64_t)k * ldw + n0 + 2];
-      if (n0 + 3 < N) v.w = W[(int64_t)k * ldw + n0 + 3];
+      if (n0 + 0 < N) v.x = W[(int64_t)k * wsk + (n0 + 0) * wsn];
+      if (n0 + 1 < N) v.y = W[(int64_t)k * wsk + (n0 + 1) * wsn];
+      if (n0 + 2 < N) v.z = W[(int64_t)k * wsk + (n0 + 2) * wsn];
+      if (n0 + 3 < N) v.w = W[(int64_t)k * wsk + (n0 + 3) * wsn];
     }
     *reinterpret_cast<float4*>(wl + (int64_t)e * 4) = v;
   }
@@ -101,14 +107,21 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 }
 
 // ---- dW / dx: a thread owns 4 consecutive k of a 1024-wide k slice; the dy rows of the chunk sit in LDS (broadcast reads) ----
+// Batched form (blockIdx.z = batch): `direct` (dW only, one row chunk) writes out[b][n * ldo + k] itself -- the attention
+// pooling C[b] = w[b]^T . x[b] of lstm_attention_max_pooling_model.py:63 ([A, H] per video, k contiguous).
 template <int NT, bool DX>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
-                                                         int64_t ldy, const float* __restrict__ W, int64_t ldw,
+                                                         int64_t ldy, const float* __restrict__ W, int64_t wsk, int64_t wsn,
                                                          float* __restrict__ out, int64_t ldo, int64_t M, int K, int N,
-                                                         float beta, int rows_per_chunk, int kslice) {
+                                                         float beta, int rows_per_chunk, int kslice, int direct, int64_t bx,
+                                                         int64_t bdy, int64_t bw, int64_t bo) {
   constexpr int RC = 64;                                               // dy rows staged per pass
   __shared__ __attribute__((aligned(16))) float dyl[RC * NT];
   const int tid = threadIdx.x;
+  if (x) x += (int64_t)blockIdx.z * bx;
+  dy += (int64_t)blockIdx.z * bdy;
+  if (W) W += (int64_t)blockIdx.z * bw;
+  out += (int64_t)blockIdx.z * bo;
   const int k0 = blockIdx.x * kslice + 4 * tid;                        // kslice <= 1024, % 4 == 0: balanced k slices
   const bool kin = 4 * tid < kslice && k0 < K;
   const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[e * NT + n] = n < N ? W[(int64_t)(k0 + e) * ldw + n] : 0.f;
+      for (int n = 0; n < NT; ++n) acc[e * NT + n] = n < N ? W[(int64_t)(k0 + e) * wsk + n * wsn] : 0.f;
   }
   for (int64_t rb = r_begin; rb < r_end; rb += RC) {
     __syncthreads();
@@ -163,7 +176,14 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
       }
     }
   }
-  if (!DX && kin) {                                                    // partial of this row chunk: out = ws[chunk][K][NT]
+  if (!DX && kin && direct) {                                          // single row chunk: out[n][k0..k0+3] (+)= acc
+    for (int n = 0; n < N; ++n) {
+      float4* op = reinterpret_cast<float4*>(out + (int64_t)n * ldo + k0);
+      float4 o = {acc[0 * NT + n], acc[1 * NT + n], acc[2 * NT + n], acc[3 * NT + n]};
+      if (beta != 0.f) { const float4 pv = *op; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
+      *op = o;
+    }
+  } else if (!DX && kin) {                                             // partial of this row chunk: out = ws[chunk][K][NT]
     float* p = out + ((int64_t)blockIdx.y * K + k0) * NT;
 #pragma unroll
     for (int i = 0; i < 4 * NT; i += 4) *reinterpret_cast<float4*>(p + i) = float4{acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
@@ -244,14 +264,14 @@ extern "C" int yt8m_skinny_fwd_f32(const float* x, int64_t ldx, const float* W, 
     const size_t lds = (size_t)J * 8 * 64 * 4 * sizeof(float);
     static bool once8 = false;
     if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once8 = true; }
-    hipLaunchKernelGGL(skinny_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, bias, y, ldy, M, (int)K, (int)N, beta,
-                       rows_per_wg);
+    hipLaunchKernelGGL(skinny_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, (int64_t)1, bias, y, ldy, M, (int)K, (int)N,
+                       beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0);
   } else {
     const size_t lds = (size_t)J * 16 * 64 * 4 * sizeof(float);
     static bool once16 = false;
     if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once16 = true; }
-    hipLaunchKernelGGL(skinny_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, bias, y, ldy, M, (int)K, (int)N, beta,
-                       rows_per_wg);
+    hipLaunchKernelGGL(skinny_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, (int64_t)1, bias, y, ldy, M, (int)K, (int)N,
+                       beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0);
   }
   return launch_status("skinny_fwd_kernel");
 }
@@ -273,14 +293,16 @@ extern "C" int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, 
   const dim3 grid((unsigned)pl.nslices, (unsigned)(chunks > 0 ? chunks : 1));
   if (N <= 8) {
     if (chunks > 0)
-      hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0, ws,
-                         (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice);
+      hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
+                         (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0,
+                         (int64_t)0);
     hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw, (int)K,
                        (int)N, beta);
   } else {
     if (chunks > 0)
-      hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0, ws,
-                         (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice);
+      hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
+                         (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0,
+                         (int64_t)0);
     hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw,
                        (int)K, (int)N, beta);
   }
@@ -300,10 +322,81 @@ extern "C" int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, 
   const int rows = pl.rows, kslice = pl.kslice;
   const dim3 grid((unsigned)pl.nslices, (unsigned)pl.chunks);
   if (N <= 8)
-    hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw, dx, lddx,
-                       M, (int)K, (int)N, beta, rows, kslice);
+    hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw,
+                       (int64_t)1, dx, lddx, M, (int)K, (int)N, beta, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
   else
-    hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw, dx,
-                       lddx, M, (int)K, (int)N, beta, rows, kslice);
+    hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw,
+                       (int64_t)1, dx, lddx, M, (int)K, (int)N, beta, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
   return launch_status("skinny_bwd_kernel<dx>");
+}
+
+// ---- attention pooling over frames (W/all_frame_models/lstm_attention_max_pooling_model.py:63: einsum("ijk,ijl->ikl")) ---------
+// w [B,F,A] (A <= 16), x [B,F,H] (H % 4 == 0), C [B,A,H], all dense row-major fp32.
+//   fwd : C[b]  = w[b]^T . x[b]                 x streamed once
+//   bwd : dw[b] = x[b] . dC[b]^T   (optional),  dx[b] = w[b] . dC[b]   (optional)
+extern "C" int yt8m_attn_pool_supported(int64_t B, int64_t F, int64_t A, int64_t H) {
+  const int NT = A <= 8 ? 8 : 16;
+  return B >= 1 && B <= 65535 && F >= 1 && A >= 1 && A <= 16 && H >= 4 && H % 4 == 0 && ((H + 255) / 256) * 256 * NT * 4 <= 144 * 1024;
+}
+
+extern "C" int yt8m_attn_pool_fwd(const float* w, const float* x, float* C, int64_t B, int64_t F, int64_t A, int64_t H,
+                                  yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && A >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * A * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_attn_pool_supported(B, F, A, H), YT8M_E_SHAPE, "attention pooling needs A <= 16, H % 4 == 0");
+  YT8M_REQUIRE(w && x && C && (((uintptr_t)x | (uintptr_t)C) & 15) == 0, YT8M_E_BADARG, "null / unaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int nsl = (int)((H + 1023) / 1024);
+  const int kslice = (int)(((H + nsl - 1) / nsl + 3) / 4 * 4);
+  const dim3 grid((unsigned)nsl, 1, (unsigned)B);
+  const int rows = (int)((F + 63) / 64 * 64);
+  if (A <= 8)
+    hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, H, w, A, (const float*)nullptr, (int64_t)0, (int64_t)0, C,
+                       H, F, (int)H, (int)A, 0.f, rows, kslice, 1, F * H, F * A, (int64_t)0, A * H);
+  else
+    hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, H, w, A, (const float*)nullptr, (int64_t)0, (int64_t)0, C,
+                       H, F, (int)H, (int)A, 0.f, rows, kslice, 1, F * H, F * A, (int64_t)0, A * H);
+  return launch_status("skinny_bwd_kernel<pool>");
+}
+
+extern "C" int yt8m_attn_pool_bwd(const float* w, const float* x, const float* dC, float* dw, float* dx, int64_t B, int64_t F,
+                                  int64_t A, int64_t H, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && A >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * A * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_attn_pool_supported(B, F, A, H), YT8M_E_SHAPE, "attention pooling needs A <= 16, H % 4 == 0");
+  YT8M_REQUIRE(dC && (!dw || x) && (!dx || w), YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE((((uintptr_t)x | (uintptr_t)dx) & 15) == 0, YT8M_E_BADARG, "unaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  if (dw) {                                            // dw[b][f][a] = sum_h x[b][f][h] * dC[b][a][h]: W[k][n] = dC[b][n][k]
+    const int J = (int)((H + 255) / 256);
+    int rows_per_wg = (int)((F + 3) / 4);              // ~4 workgroups per video
+    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+    const dim3 grid((unsigned)((F + rows_per_wg - 1) / rows_per_wg), (unsigned)B);
+    if (A <= 8) {
+      static bool once = false;
+      if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once = true; }
+      hipLaunchKernelGGL(skinny_fwd_kernel<8>, grid, dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, x, H, dC, (int64_t)1, H,
+                         (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A);
+    } else {
+      static bool once = false;
+      if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once = true; }
+      hipLaunchKernelGGL(skinny_fwd_kernel<16>, grid, dim3(256), (size_t)J * 16 * 64 * 4 * sizeof(float), s, x, H, dC, (int64_t)1, H,
+                         (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A);
+    }
+  }
+  if (dx) {                                            // dx[b][f][h] = sum_a w[b][f][a] * dC[b][a][h]
+    const int nsl = (int)((H + 1023) / 1024);
+    const int kslice = (int)(((H + nsl - 1) / nsl + 3) / 4 * 4);
+    const dim3 grid((unsigned)nsl, 1, (unsigned)B);
+    const int rows = (int)((F + 63) / 64 * 64);
+    if (A <= 8)
+      hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, w, A, dC, (int64_t)1, H,
+                         dx, H, F, (int)H, (int)A, 0.f, rows, kslice, 0, (int64_t)0, F * A, A * H, F * H);
+    else
+      hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, w, A, dC, (int64_t)1, H,
+                         dx, H, F, (int)H, (int)A, 0.f, rows, kslice, 0, (int64_t)0, F * A, A * H, F * H);
+  }
+  return launch_status("attention pooling backward");
 }

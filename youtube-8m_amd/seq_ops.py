@@ -516,20 +516,45 @@ def masked_softmax_rows(s, num_frames):
     return _SoftmaxRows.apply(s, num_frames)
 
 
+POOL_STREAM_MIN = 1 << 22      # elements of x from which the streaming pooling kernels replace the padded batched GEMM
+
+
+def _pool_stream_ok(w, x):
+    B, F, A = w.shape
+    H = x.shape[2]
+    return (A <= 16 and x.numel() >= POOL_STREAM_MIN and x.data_ptr() % 16 == 0
+            and _lib.lib().yt8m_attn_pool_supported(B, F, A, H) == 1)
+
+
 class _PoolTN(torch.autograd.Function):
     """C[b] = w[b]^T . x[b]   (w [B,F,A], x [B,F,H] -> [B,A,H]): attention pooling
-    (lstm_attention_max_pooling_model.py:63) and NetVLAD aggregation (Appendix B) as one batched GEMM."""
+    (lstm_attention_max_pooling_model.py:63) and NetVLAD aggregation (Appendix B).  A handful of attentions over a large
+    frame block takes the streaming kernels (yt8m_attn_pool_*: x crosses HBM once per pass); otherwise one batched GEMM."""
 
     @staticmethod
     def forward(ctx, w, x):
         w, x = _f32c(w), _f32c(x)
         ctx.save_for_backward(w, x)
+        if _pool_stream_ok(w, x):
+            B, F, A = w.shape
+            H = x.shape[2]
+            C = torch.empty((B, A, H), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().yt8m_attn_pool_fwd(_p(w), _p(x), _p(C), B, F, A, H, _stream()))
+            return C
         return ops.gemm_batched(w, x, transA=True)
 
     @staticmethod
     def backward(ctx, dC):
         w, x = ctx.saved_tensors
         dC = _f32c(dC)
+        if _pool_stream_ok(w, x):
+            B, F, A = w.shape
+            H = x.shape[2]
+            dw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+            dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+            if dw is not None or dx is not None:
+                _lib.check(_lib.lib().yt8m_attn_pool_bwd(_p(w), _p(x), _p(dC), _p(dw), _p(dx), B, F, A, H, _stream()))
+            return dw, dx
         dw = ops.gemm_batched(x, dC, transB=True) if ctx.needs_input_grad[0] else None   # [F,H].[H,A]
         dx = ops.gemm_batched(w, dC) if ctx.needs_input_grad[1] else None                # [F,A].[A,H]
         return dw, dx
