@@ -773,3 +773,27 @@ def test_attention_pooling_streaming_kernels(dev, B, F, A, Hh, monkeypatch):
         assert np.abs(H(wd.grad) - refdw).max() < 2e-5 * max(1.0, np.abs(refdw).max())
         assert np.abs(H(xd.grad) - refdx).max() < 2e-5 * max(1.0, np.abs(refdx).max())
     assert L.lib().yt8m_attn_pool_supported(4, 10, 17, 64) == 0 and L.lib().yt8m_attn_pool_supported(4, 10, 8, 66) == 0
+
+
+def test_bf16_large_tile_gemm(dev, monkeypatch):
+    """gemm_bf16.hip (256 x 256 tiles, 4-stage LDS-DMA ring) forced on for small problems: ragged edges in M and N, K tails
+    (K % 32 != 0), padded row pitches, bias, accumulate, two problems in one launch -- against the fp64 product of the rounded
+    operands, and bit-for-bit what the small-tile kernel returns is NOT required (different summation order)."""
+    monkeypatch.setenv("YT8M_BF16_BIG_MIN", "1")
+    rs = np.random.RandomState(41)
+    for shapes in [[(300, 520, 72)], [(1000, 777, 1000), (300, 5000, 72)], [(257, 255, 2304)], [(512, 512, 14148)], [(64, 64, 32)]]:
+        items, refs = [], []
+        for (M, N, K) in shapes:
+            A = rs.randn(M, K).astype(np.float32)
+            B = rs.randn(N, K).astype(np.float32)
+            bias = rs.randn(N).astype(np.float32)
+            refs.append((_bf16_round(A).astype(np.float64) @ _bf16_round(B).astype(np.float64).T, bias,
+                         np.abs(A).max() * np.abs(B).max() * K))
+            items.append(dict(A=ops.cast_bf16(D(A, dev)), B=ops.cast_bf16(D(B, dev)), bias=D(bias, dev)))
+        outs = ops.gemm_bf16_nt_grouped(items)
+        for o, (ref, bias, scale) in zip(outs, refs):
+            assert np.abs(H(o) - (ref + bias)).max() <= 2e-6 * scale
+        items2 = [dict(A=it["A"], B=it["B"], out=o, beta=1.0) for it, o in zip(items, outs)]
+        ops.gemm_bf16_nt_grouped(items2)
+        for o, (ref, bias, scale) in zip(outs, refs):
+            assert np.abs(H(o) - (2 * ref + bias)).max() <= 4e-6 * scale
