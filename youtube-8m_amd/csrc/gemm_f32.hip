@@ -25,8 +25,18 @@ extern "C" int yt8m_debug_gemm_phase(unsigned long long* out) {
 }
 #endif
 
+// Experiment switch (tools/build_variant.sh -DYT8M_GEMM_TEPI=1): accumulate C^T sub-tiles (operands swapped in the MFMA) so that
+// a lane owns 4 CONSECUTIVE columns of one C row per register quad and stores 16 bytes straight from the accumulators (16
+// instead of 64 store instructions per wave, no LDS pass).  Bit-identical results; measured SLOWER: cfg[1] step 1.240 -> 1.266
+// ms, M = 8192 heads 123 -> 119 TFLOP/s -- a wave store then touches 32 rows x 32 bytes instead of 2 rows x 128 bytes, and the
+// write path prefers whole 128-byte segments over fewer instructions.  Off.
+#ifndef YT8M_GEMM_TEPI
+#define YT8M_GEMM_TEPI 0
+#endif
+
 namespace {
 
+constexpr bool TEPI = YT8M_GEMM_TEPI != 0;
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int TILE_FLOATS = BK * 128;  // one operand tile in LDS (8 KiB), no padding
 constexpr int STAGES = 3;               // LDS-DMA pipeline depth (3 x 16 KiB per workgroup, 3 workgroups per CU = 144 KiB)
@@ -164,10 +174,17 @@ __device__ __forceinline__ void mma_step(const Frag& fa, const Frag& fb, f32x16 
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[0][h][j], fb.v[0][h][j], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[0][h][j], fb.v[1][h][j], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[1][h][j], fb.v[0][h][j], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[1][h][j], fb.v[1][h][j], acc[1][1], 0, 0, 0);
+      if (TEPI) {   // D = B^T-operand x A-operand: the same products in the same order, the tile lands transposed
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb.v[0][h][j], fa.v[0][h][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb.v[1][h][j], fa.v[0][h][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb.v[0][h][j], fa.v[1][h][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb.v[1][h][j], fa.v[1][h][j], acc[1][1], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[0][h][j], fb.v[0][h][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[0][h][j], fb.v[1][h][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[1][h][j], fb.v[0][h][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[1][h][j], fb.v[1][h][j], acc[1][1], 0, 0, 0);
+      }
     }
   }
 }
@@ -190,10 +207,17 @@ __device__ __forceinline__ void mma_step_bf16(const Frag& fa, const Frag& fb, f3
       a[t] = __builtin_bit_cast(bf16x8, qa);
       b[t] = __builtin_bit_cast(bf16x8, qb);
     }
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[1][1], 0, 0, 0);
+    if (TEPI) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[1], acc[1][1], 0, 0, 0);
+    } else {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[1][1], 0, 0, 0);
+    }
   }
 }
 
@@ -347,14 +371,61 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
   } tguard{tm0, tm1, ws ? nullptr : Cp + (int64_t)m0 * g.ldc + n0, tid};
 #endif
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // TEPI: acc[i][j][r] = C[m0 + wm + 32i + li][n0 + wn + 32j + (r & 3) + 8 (r >> 2) + 4 lk]: registers 4q..4q+3 of a lane are four
+  // consecutive columns of one row
   if (ws) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        if (TEPI) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ws[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + wn + j * 32 + li] = acc[i][j][r];
+          for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(&ws[(wm + i * 32 + li) * BN + wn + j * 32 + 8 * qd + 4 * lk]) =
+                float4{acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            ws[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * BN + wn + j * 32 + li] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  if (TEPI) {
+    const bool vec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cp) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + wm + i * 32 + li;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int col = n0 + wn + j * 32 + 8 * qd + 4 * lk;
+          if (col >= g.N) continue;
+          float4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+          float* c = Cp + (int64_t)row * g.ldc + col;
+          if (vec && col + 3 < g.N) {
+            if (g.bias) {
+              const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (g.accumulate) {
+              const float4 o = *reinterpret_cast<const float4*>(c);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(c) = v;
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int e = 0; e < 4 && col + e < g.N; ++e) {
+              float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
+              if (g.accumulate) t += c[e];
+              c[e] = t;
+            }
+          }
+        }
+      }
+    }
     return;
   }
   // Output path.  Default: one dword store per accumulator register (64 per wave and tile).  VEPI: the accumulators are
