@@ -475,6 +475,45 @@ __device__ __forceinline__ void process_tile(const GemmArgs& g, const float* __r
     }
     return;
   }
+#ifndef YT8M_GEMM_PAIR_EPI
+#define YT8M_GEMM_PAIR_EPI 0      // experiment (-DYT8M_GEMM_PAIR_EPI=1): +1 % on M >= 8192 shapes, -1 % on cfg[1], -3.6 % on the dx shape: off
+#endif
+  // Pair epilogue: neighbouring lanes (columns c, c+1) swap one register of each accumulator pair (rows R, R+1) with a DPP quad
+  // permute, after which the even lane holds (c, c+1) of row R and the odd lane (c-1, c) of row R+1: 8-byte stores, 4 rows x
+  // 128 contiguous bytes per wave instruction, half the store instructions of the dword form and no LDS pass.
+  if (YT8M_GEMM_PAIR_EPI && (g.ldc & 1) == 0 && ((reinterpret_cast<uintptr_t>(Cp) | reinterpret_cast<uintptr_t>(g.bias)) & 7) == 0) {
+    const bool odd = (li & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + j * 32 + (li & ~1);
+      float2 bv = {0.f, 0.f};
+      if (g.bias && col + 1 < g.N) bv = *reinterpret_cast<const float2*>(g.bias + col);
+      else if (g.bias && col < g.N) bv.x = g.bias[col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const float a0 = acc[i][j][2 * rp], a1 = acc[i][j][2 * rp + 1];
+          const float send = odd ? a0 : a1;
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
+          const int r = 2 * rp + (odd ? 1 : 0);
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          float2 v = {(odd ? recv : a0) + bv.x, (odd ? a1 : recv) + bv.y};
+          if (row < g.M && col < g.N) {
+            float* c = Cp + (int64_t)row * g.ldc + col;
+            if (col + 1 < g.N) {
+              if (g.accumulate) { const float2 o = *reinterpret_cast<const float2*>(c); v.x += o.x; v.y += o.y; }
+              *reinterpret_cast<float2*>(c) = v;
+            } else {
+              if (g.accumulate) v.x += c[0];
+              c[0] = v.x;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn + j * 32 + li;
