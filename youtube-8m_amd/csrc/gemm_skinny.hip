@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // ---- dW / dx: a thread owns 4 consecutive k of a 1024-wide k slice; the dy rows of the chunk sit in LDS (broadcast reads) ----
 // Batched form (blockIdx.z = batch): `direct` (dW only, one row chunk) writes out[b][n * ldo + k] itself -- the attention
 // pooling C[b] = w[b]^T . x[b] of lstm_attention_max_pooling_model.py:63 ([A, H] per video, k contiguous).
-template <int NT, bool DX>
+template <int NT, bool DX, bool BATCH>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                          int64_t ldy, const float* __restrict__ W, int64_t wsk, int64_t wsn,
                                                          float* __restrict__ out, int64_t ldo, int64_t M, int K, int N,
@@ -118,10 +118,12 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
   constexpr int RC = 64;                                               // dy rows staged per pass
   __shared__ __attribute__((aligned(16))) float dyl[RC * NT];
   const int tid = threadIdx.x;
-  if (x) x += (int64_t)blockIdx.z * bx;
-  dy += (int64_t)blockIdx.z * bdy;
-  if (W) W += (int64_t)blockIdx.z * bw;
-  out += (int64_t)blockIdx.z * bo;
+  if (BATCH) {                      // a separate instantiation: the un-batched kernels keep their (faster) code
+    if (!DX) x += (int64_t)blockIdx.z * bx;
+    dy += (int64_t)blockIdx.z * bdy;
+    if (DX) W += (int64_t)blockIdx.z * bw;
+    out += (int64_t)blockIdx.z * bo;
+  }
   const int k0 = blockIdx.x * kslice + 4 * tid;                        // kslice <= 1024, % 4 == 0: balanced k slices
   const bool kin = 4 * tid < kslice && k0 < K;
   const int64_t r_begin = (int64_t)blockIdx.y * rows_per_chunk;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
       }
     }
   }
-  if (!DX && kin && direct) {                                          // single row chunk: out[n][k0..k0+3] (+)= acc
+  if (BATCH && !DX && kin && direct) {                                          // single row chunk: out[n][k0..k0+3] (+)= acc
     for (int n = 0; n < N; ++n) {
       float4* op = reinterpret_cast<float4*>(out + (int64_t)n * ldo + k0);
       float4 o = {acc[0 * NT + n], acc[1 * NT + n], acc[2 * NT + n], acc[3 * NT + n]};
@@ -293,14 +295,14 @@ extern "C" int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, 
   const dim3 grid((unsigned)pl.nslices, (unsigned)(chunks > 0 ? chunks : 1));
   if (N <= 8) {
     if (chunks > 0)
-      hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
+      hipLaunchKernelGGL((skinny_bwd_kernel<8, false, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
                          (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0,
                          (int64_t)0);
     hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw, (int)K,
                        (int)N, beta);
   } else {
     if (chunks > 0)
-      hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
+      hipLaunchKernelGGL((skinny_bwd_kernel<16, false, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
                          (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0,
                          (int64_t)0);
     hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw,
@@ -322,10 +324,10 @@ extern "C" int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, 
   const int rows = pl.rows, kslice = pl.kslice;
   const dim3 grid((unsigned)pl.nslices, (unsigned)pl.chunks);
   if (N <= 8)
-    hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw,
+    hipLaunchKernelGGL((skinny_bwd_kernel<8, true, false>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw,
                        (int64_t)1, dx, lddx, M, (int)K, (int)N, beta, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
   else
-    hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw,
+    hipLaunchKernelGGL((skinny_bwd_kernel<16, true, false>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, dy, ldy, W, ldw,
                        (int64_t)1, dx, lddx, M, (int)K, (int)N, beta, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
   return launch_status("skinny_bwd_kernel<dx>");
 }
@@ -352,10 +354,10 @@ extern "C" int yt8m_attn_pool_fwd(const float* w, const float* x, float* C, int6
   const dim3 grid((unsigned)nsl, 1, (unsigned)B);
   const int rows = (int)((F + 63) / 64 * 64);
   if (A <= 8)
-    hipLaunchKernelGGL((skinny_bwd_kernel<8, false>), grid, dim3(256), 0, s, x, H, w, A, (const float*)nullptr, (int64_t)0, (int64_t)0, C,
+    hipLaunchKernelGGL((skinny_bwd_kernel<8, false, true>), grid, dim3(256), 0, s, x, H, w, A, (const float*)nullptr, (int64_t)0, (int64_t)0, C,
                        H, F, (int)H, (int)A, 0.f, rows, kslice, 1, F * H, F * A, (int64_t)0, A * H);
   else
-    hipLaunchKernelGGL((skinny_bwd_kernel<16, false>), grid, dim3(256), 0, s, x, H, w, A, (const float*)nullptr, (int64_t)0, (int64_t)0, C,
+    hipLaunchKernelGGL((skinny_bwd_kernel<16, false, true>), grid, dim3(256), 0, s, x, H, w, A, (const float*)nullptr, (int64_t)0, (int64_t)0, C,
                        H, F, (int)H, (int)A, 0.f, rows, kslice, 1, F * H, F * A, (int64_t)0, A * H);
   return launch_status("skinny_bwd_kernel<pool>");
 }
@@ -392,10 +394,10 @@ extern "C" int yt8m_attn_pool_bwd(const float* w, const float* x, const float* d
     const dim3 grid((unsigned)nsl, 1, (unsigned)B);
     const int rows = (int)((F + 63) / 64 * 64);
     if (A <= 8)
-      hipLaunchKernelGGL((skinny_bwd_kernel<8, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, w, A, dC, (int64_t)1, H,
+      hipLaunchKernelGGL((skinny_bwd_kernel<8, true, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, w, A, dC, (int64_t)1, H,
                          dx, H, F, (int)H, (int)A, 0.f, rows, kslice, 0, (int64_t)0, F * A, A * H, F * H);
     else
-      hipLaunchKernelGGL((skinny_bwd_kernel<16, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, w, A, dC, (int64_t)1, H,
+      hipLaunchKernelGGL((skinny_bwd_kernel<16, true, true>), grid, dim3(256), 0, s, (const float*)nullptr, (int64_t)0, w, A, dC, (int64_t)1, H,
                          dx, H, F, (int)H, (int)A, 0.f, rows, kslice, 0, (int64_t)0, F * A, A * H, F * H);
   }
   return launch_status("attention pooling backward");
