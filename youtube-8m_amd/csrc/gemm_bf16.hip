@@ -11,6 +11,7 @@
 // fetch as gemm_f32.hip, float4 epilogue through LDS.  One tile per workgroup, banded + XCD-aware tile order, up to four
 // problems per launch.  K tails (K % 32 != 0) take a guarded zero-padded store for the last step.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -32,10 +33,16 @@ struct BArgs {
   int tiles_m, tiles_n;
   int accumulate;
 };
+// Tile space of a launch: `full` tiles (a multiple of the 256 resident workgroups) run whole; the `rem` tiles of the last, partial
+// round are split along K into S parts each (rem * S <= 256 workgroups), parked as raw accumulators in ws[part slot][256][256] and
+// summed in a fixed order by bf16_fixup_kernel -- the wave-quantisation tail of e.g. 288 tiles (dx of the MoE heads) costs a
+// quarter of a round instead of a whole one.
 struct BGroup {
   BArgs p[4];
   int tile_base[5];
   int nprob;
+  int full, rem, S;
+  float* ws;
 };
 
 __device__ __forceinline__ int xcd_remap(int wg, int n) {
@@ -110,7 +117,16 @@ __device__ __forceinline__ void wait_dma(int younger_steps) {      // 4 DMA inst
 
 __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
   extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 128 KiB
-  const int tile = xcd_remap(blockIdx.x, G.tile_base[G.nprob]);
+  int tile, part = 0, nparts = 1, slot = 0;
+  if ((int)blockIdx.x < G.full) {
+    tile = xcd_remap(blockIdx.x, G.full);
+  } else {
+    slot = blockIdx.x - G.full;
+    const int rt = slot / G.S;
+    part = slot - rt * G.S;
+    nparts = G.S;
+    tile = G.full + rt;
+  }
   int q = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i)
@@ -122,8 +138,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
   const int li = lane & 31, lk = lane >> 5;
-  const int nk = (g.K + BKF - 1) / BKF;
-  const bool tail = nk * BKF != g.K;                               // the last step is a guarded (non-DMA) fill
+  const int nk_all = (g.K + BKF - 1) / BKF;
+  const int kb = (int)((int64_t)nk_all * part / nparts), ke = (int)((int64_t)nk_all * (part + 1) / nparts);
+  const int nk = ke - kb;                                          // K-steps kb .. ke-1 of this tile (local index 0 .. nk-1)
+  const bool tail = ke == nk_all && nk_all * BKF != g.K;           // the last step is a guarded (non-DMA) fill
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
 
   // prologue: steps 0, 1, 2 on the wire; wait for step 0 only
   const int pro = nk < 3 ? nk : 3;
-  for (int s = 0; s < pro; ++s) fill_step(g, m0, n0, s, smem + s * STAGE_F, tid);
+  for (int s = 0; s < pro; ++s) fill_step(g, m0, n0, kb + s, smem + s * STAGE_F, tid);
   // DMA steps younger than step 0 that are still allowed in flight; once the guarded tail has been stored (its register
   // loads completed in order behind every DMA) everything has landed and a full drain is exact
   {
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
   __builtin_amdgcn_s_barrier();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 3 < nk) fill_step(g, m0, n0, kt + 3, smem + ((cur + 3) & 3) * STAGE_F, tid);
+    if (kt + 3 < nk) fill_step(g, m0, n0, kb + kt + 3, smem + ((cur + 3) & 3) * STAGE_F, tid);
     const float* As = smem + cur * STAGE_F;
     const float* Bs = As + TILE_F;
     bf16x8 a[2][4], b[2][2];
@@ -179,6 +197,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
   // epilogue: accumulators -> wave-private LDS image [32][68] -> 16-byte stores (the store pipe is issue-bound)
   constexpr int P = 68;
   float* st = smem + wave * (32 * P);
+  if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace image
+    float* wsl = G.ws + (int64_t)slot * (TM * TN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = lane + 64 * k;
+        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        *reinterpret_cast<float4*>(&wsl[(wm + i * 32 + rr) * TN + wn + c4]) = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+      }
+    }
+    return;
+  }
   const bool vec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -217,6 +252,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
   }
 }
 
+// sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
+__global__ __launch_bounds__(256) void bf16_fixup_kernel(const BGroup G) {
+  const int rt = blockIdx.x >> 4, sixteenth = blockIdx.x & 15;      // 16 workgroups per tile, 16 rows each
+  const int tile = G.full + rt;
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  const BArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const float* base = G.ws + (int64_t)rt * G.S * (TM * TN);
+  for (int e = sixteenth * (TM * TN / 16) + threadIdx.x * 4; e < (sixteenth + 1) * (TM * TN / 16); e += 256 * 4) {
+    float4 v = *reinterpret_cast<const float4*>(base + e);
+    for (int s = 1; s < G.S; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * (TM * TN) + e);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int row = m0 + e / TN, col = n0 + (e % TN);
+    if (row >= g.M) continue;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float* c = g.C + (int64_t)row * g.ldc + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (col + k < g.N) {
+        float o = vv[k] + (g.bias ? g.bias[col + k] : 0.f);
+        if (g.accumulate) o += c[k];
+        c[k] = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace yt8m {
@@ -224,7 +293,7 @@ namespace yt8m {
 // true when the large-tile kernel can take the whole group (16-byte aligned K-contiguous rows) and there are enough tiles
 bool gemm_bf16_big_ok(int nprob, const yt8m_gemm_problem* probs) {
   const char* e = getenv("YT8M_BF16_BIG_MIN");            // A/B switch (tools/, tests): minimum number of 256 x 256 tiles
-  const int64_t min_tiles = e ? atoll(e) : 512;
+  const int64_t min_tiles = e ? atoll(e) : 256;                  // at least one full round of 256 x 256 tiles
   int64_t T = 0;
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
@@ -236,7 +305,7 @@ bool gemm_bf16_big_ok(int nprob, const yt8m_gemm_problem* probs) {
   return T >= min_tiles;
 }
 
-int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, hipStream_t s) {
+int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes, hipStream_t s) {
   BGroup G;
   G.nprob = 0;
   int64_t T = 0;
@@ -257,13 +326,32 @@ int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, hipStream_t 
   if (G.nprob == 0) return YT8M_OK;
   for (int i = G.nprob; i <= 4; ++i) G.tile_base[i] = (int)T;
   for (int i = G.nprob; i < 4; ++i) G.p[i] = G.p[0];
+  constexpr int SLOTS = 256;                                       // one 128 KiB workgroup per CU
+  G.full = (int)(T / SLOTS) * SLOTS;
+  G.rem = (int)(T - G.full);
+  G.S = 1;
+  G.ws = static_cast<float*>(workspace);
+  if (G.rem > 0) {
+    int S = SLOTS / G.rem;
+    int min_nk = 1 << 30;
+    for (int i = 0; i < G.nprob; ++i) min_nk = std::min(min_nk, (G.p[i].K + BKF - 1) / BKF);
+    if (S > min_nk / 16) S = min_nk / 16;                          // >= 16 K-steps per part
+    if (S > 8) S = 8;
+    const int64_t per_part = (int64_t)TM * TN * sizeof(float);
+    if (!workspace) S = 1;
+    else if ((int64_t)G.rem * S * per_part > workspace_bytes) S = (int)(workspace_bytes / (G.rem * per_part));
+    if (S < 1) S = 1;
+    G.S = S;
+  }
+  const int64_t grid = (int64_t)G.full + (int64_t)G.rem * G.S;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               NST * STAGE_F * (int)sizeof(float));
     once = true;
   }
-  hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3((unsigned)T), dim3(512), NST * STAGE_F * sizeof(float), s, G);
+  hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3((unsigned)grid), dim3(512), NST * STAGE_F * sizeof(float), s, G);
+  if (G.S > 1) hipLaunchKernelGGL(bf16_fixup_kernel, dim3((unsigned)G.rem * 16), dim3(256), 0, s, G);
   return launch_status("gemm_bf16_big_kernel");
 }
 

@@ -796,7 +796,7 @@ extern "C" int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt
 
 namespace yt8m {  // gemm_bf16.hip: 256 x 256 tiles for problems large enough to fill the chip with them
 bool gemm_bf16_big_ok(int nprob, const yt8m_gemm_problem* probs);
-int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, hipStream_t s);
+int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes, hipStream_t s);
 }  // namespace yt8m
 
 extern "C" int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
@@ -811,7 +811,7 @@ extern "C" int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* pro
   }
   if (simple && gemm_bf16_big_ok(nprob, probs)) {
     ProfScope prof(F_GEMM, as_stream(stream));
-    return gemm_bf16_big_launch(nprob, probs, as_stream(stream));
+    return gemm_bf16_big_launch(nprob, probs, workspace, workspace_bytes, as_stream(stream));
   }
   return grouped_launch(0, 1, 1, nprob, probs, workspace, workspace_bytes, stream);
 }
