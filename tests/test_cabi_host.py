@@ -51,6 +51,28 @@ def test_argument_validation_without_device():
     assert lib.yt8m_topk_rows(one, 2, 10, 11, one, one, None) == -1
     assert lib.yt8m_act_fwd_f32(9, one, one, 4, None) == -1
     assert lib.yt8m_xent_workspace_bytes(1024, 4716) == 4 * (1024 * 5 + 1)
+    # entry points added for the recurrent cells, the random ops, the streaming FC / pooling kernels and the bf16 casts
+    assert lib.yt8m_dropout_f32(one, one, 8, 0.0, 1, 0, None) == -1                             # keep_prob out of (0, 1]
+    assert lib.yt8m_dropout_f32(one, one, 8, 1.5, 1, 0, None) == -1
+    assert lib.yt8m_dropout_f32(one, one, -1, 0.5, 1, 0, None) == -2
+    assert lib.yt8m_dropout_f32(None, None, 0, 0.5, 1, 0, None) == 0
+    assert lib.yt8m_add_noise_f32(one, one, 8, -1.0, 1, 0, None) == -1
+    assert lib.yt8m_skinny_supported(100, 1152, 8) == 1 and lib.yt8m_skinny_supported(100, 1152, 17) == 0
+    assert lib.yt8m_skinny_supported(100, 1150, 8) == 0 and lib.yt8m_skinny_supported(100, 8192, 8) == 0
+    assert lib.yt8m_skinny_fwd_f32(one, 8, one, 17, None, one, 17, 4, 8, 17, 0.0, None) == -2   # N > 16
+    assert lib.yt8m_skinny_fwd_f32(one, 6, one, 4, None, one, 4, 4, 6, 4, 0.0, None) == -2      # K % 4 != 0
+    assert lib.yt8m_skinny_fwd_f32(one, 8, one, 4, None, one, 4, 4, 8, 4, 0.5, None) == -1      # beta
+    assert lib.yt8m_skinny_dw_f32(one, 8, one, 4, one, 4, 4, 8, 4, 0.0, None, 0, None) == -1    # no workspace
+    assert lib.yt8m_skinny_workspace_bytes(307200, 1152, 8) >= 64 * 1152 * 8 * 4
+    assert lib.yt8m_attn_pool_supported(128, 300, 8, 1152) == 1 and lib.yt8m_attn_pool_supported(128, 300, 17, 1152) == 0
+    assert lib.yt8m_attn_pool_fwd(one, one, one, 2, 10, 17, 64, None) == -2
+    assert lib.yt8m_attn_pool_fwd(None, None, None, 0, 10, 8, 64, None) == 0
+    assert lib.yt8m_cast_f32_bf16(one, 4, 8, 8, one, 4, 0, None) == -2                          # dst_ld < cols
+    assert lib.yt8m_cast_f32_bf16_dual(one, 4, 8, 8, one, 8, one, 2, None) == -2                # trans_ld < rows
+    assert lib.yt8m_gru_layer_fwd(None, one, one, 8, one, 4, one, one, None, None, 2, 2, 4, None, 0, None) == -1
+    assert lib.yt8m_gru_layer_fwd(one, one, one, 4, one, 4, one, one, None, None, 2, 2, 4, None, 0, None) == -2   # ldg < 2H
+    assert lib.yt8m_lnlstm_layer_fwd(one, one, 16, one, one, one, one, one, None, None, 2, 2, 4096, 1.0, 1.0, 0, None, 0, None) == -2
+    assert lib.yt8m_lnlstm_layer_fwd(one, one, 16, one, one, one, one, one, None, None, 2, 2, 4, 1.0, 0.0, 0, None, 0, None) == -1
     with pytest.raises(ValueError):
         L.check(-2)
     with pytest.raises(L.Yt8mHipError):
