@@ -17,7 +17,7 @@ timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/lstm -o lstm -- python $R/tools/model_bench.py lstm < /dev/null > $O/lstm_step.txt 2>&1
 # 5. all plugin configs, un-profiled
 timeout 400 python $R/tools/model_bench.py < /dev/null > $O/model_bench.txt 2>&1
-timeout 200 python $R/tools/model_bench.py config5_bf16 netvlad_bf16 config5_b1024 config5_bf16_b1024 < /dev/null >> $O/model_bench.txt 2>&1
+timeout 200 python $R/tools/model_bench.py config5_bf16 netvlad_bf16 lstm_bf16 config5_b1024 config5_bf16_b1024 < /dev/null >> $O/model_bench.txt 2>&1
 YT8M_NO_PROF=1 timeout 100 python $R/tools/model_bench.py lstm < /dev/null 2>&1 | grep "B=" | sed 's/^lstm /lstm(no library profiler, hipGraph replay on) /' >> $O/model_bench.txt
 timeout 100 python $R/tools/gemm_shapes.py < /dev/null > $O/gemm_shapes.txt 2>&1
 timeout 100 python $R/tools/skinny_bench.py < /dev/null > $O/skinny_bench.txt 2>&1

@@ -28,6 +28,7 @@ CONFIGS = {
                   flags=dict(deep_chain_layers=8, deep_chain_relu_cells=128, support_type=",".join(["label"] * 8))),
     "lstm": dict(model=flm.LstmModel, B=128, frame=True),
     "lstm_b512": dict(model=flm.LstmModel, B=512, frame=True),
+    "lstm_bf16": dict(model=flm.LstmModel, B=128, frame=True, flags=dict(compute_dtype="bfloat16")),
     "lstm_attn": dict(model=flm.LstmAttentionMaxPoolingModel, B=128, frame=True),
     "netvlad": dict(model=flm.NetVLADModel, B=128, frame=True),
     "config5": dict(model=flm.GatedNetVLADAttentionChainModel, B=128, frame=True, multitask=True,
@@ -103,5 +104,5 @@ def run(name, steps=5):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or [c for c in CONFIGS if c not in ("lstm_b512", "config5_bf16", "netvlad_bf16", "config5_b1024", "config5_bf16_b1024")]):
+    for n in (sys.argv[1:] or [c for c in CONFIGS if c not in ("lstm_b512", "lstm_bf16", "config5_bf16", "netvlad_bf16", "config5_b1024", "config5_bf16_b1024")]):
         run(n)

@@ -60,7 +60,7 @@ def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN
             d_in = lstm_size
     # all layers in one op: layer l+1 works on time chunk c while layer l is already in chunk c+1 (seq_ops._LstmStack)
     return seq_ops.lstm_stack(x_tm, num_frames, wb, forget_bias=1.0, chunks=FLAGS.lstm_pipeline_chunks,
-                              input_keep_prob=input_keep_prob)
+                              input_keep_prob=input_keep_prob, bf16=FLAGS.compute_dtype == "bfloat16")
 
 
 class FrameLevelLogisticModel(models.BaseModel):

@@ -271,11 +271,15 @@ class _LstmStack(torch.autograd.Function):
     stream right before the projection GEMM (in place on the lower layer's output buffer, which nothing else reads) and
     replayed on the dx chunk in backward.
 
-    apply(x_tm [F,B,D], token, num_frames, forget_bias, chunks, input_keep_prob, seeds, W_0, b_0, ..., W_{L-1}, b_{L-1})
+    bf16 (compute_dtype=bfloat16): the hoisted products (input projection, its weight gradients and dx) take bf16 copies of
+    their operands on the bf16 MFMA path (fp32 accumulate, fp32 master weights and gradients); the recurrence -- state, gates,
+    recurrent product -- stays fp32.
+
+    apply(x_tm [F,B,D], token, num_frames, forget_bias, chunks, input_keep_prob, seeds, bf16, W_0, b_0, ..., W_{L-1}, b_{L-1})
       -> (out_top [F,B,H], c_0, h_0, ..., c_{L-1}, h_{L-1})"""
 
     @staticmethod
-    def forward(ctx, x_tm, token, num_frames, forget_bias, chunks, input_keep_prob, seeds, *wb):
+    def forward(ctx, x_tm, token, num_frames, forget_bias, chunks, input_keep_prob, seeds, bf16, *wb):
         x_tm = _f32c(x_tm)
         _dev(x_tm)
         L = len(wb) // 2
@@ -287,6 +291,7 @@ class _LstmStack(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         rs, gs, _ = _side_streams(dev, L)
         parts = _chunks(F, chunks)
+        bf16 = bool(bf16) and B % 2 == 0 and min(T for _, T in parts) * B >= ops.BF16_MIN_ROWS
         drop = input_keep_prob is not None and float(input_keep_prob) < 1.0
         layers, inp = [], x_tm
         for l in range(L):                                          # every buffer comes from the main stream's pool
@@ -314,6 +319,9 @@ class _LstmStack(torch.autograd.Function):
                 st["hs"][0].zero_()
                 if st["Wp"] is not None:
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
+                st["bf16"] = bf16 and st["Din"] % 2 == 0
+                if st["bf16"]:                                      # W_x^T once per step, K-contiguous for the NT product
+                    st["WxT"] = ops.cast_bf16(st["W"].data[:st["Din"]], transpose=True)
         r_done = [[torch.cuda.Event() for _ in parts] for _ in range(L)]
         for c, (t0, T) in enumerate(parts):
             for l, st in enumerate(layers):
@@ -326,8 +334,12 @@ class _LstmStack(torch.autograd.Function):
                         src = x_tm[t0:t0 + T] if l == 0 else xc
                         _lib.check(lib.yt8m_dropout_f32(_p(src), _p(xc), xc.numel(), float(input_keep_prob), int(seeds[l]),
                                                         t0 * B * Din, _stream()))
-                    ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
-                             bias=st["b"].data)
+                    if st["bf16"]:
+                        ops.gemm_bf16_nt_grouped([dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din)), B=st["WxT"],
+                                                       out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
+                    else:
+                        ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
+                                 bias=st["b"].data)
                     g_ev = torch.cuda.Event()
                     g_ev.record(gs[l])
                 with torch.cuda.stream(rs[l]):                      # recurrence steps of the chunk
@@ -359,6 +371,8 @@ class _LstmStack(torch.autograd.Function):
         rs, gs, sw = _side_streams(dev, L)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(layers[0]["x"]) if need_dx else None
+        for st in layers:
+            st.pop("WxT", None)
         for l, st in enumerate(layers):                            # buffers come from the main stream's pool
             H = st["H"]
             st["dz"] = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
@@ -407,11 +421,23 @@ class _LstmStack(torch.autograd.Function):
                     rb = torch.cuda.Event()
                     rb.record(rs[l])
                 dx_ev = None
+                dzb = dzT = None
+                if st["bf16"]:                                      # dz feeds dx (plain) and both dW products (transposed)
+                    with torch.cuda.stream(gs[l]):
+                        gs[l].wait_event(rb)
+                        dzb, dzT = ops.cast_bf16_both(dzc)
+                        if "Wxb" not in st:
+                            st["Wxb"] = ops.cast_bf16(W.data[:Din])
+                        cast_ev = torch.cuda.Event()
+                        cast_ev.record(gs[l])
                 if l > 0 or need_dx:
                     with torch.cuda.stream(gs[l]):
                         gs[l].wait_event(rb)
                         dst = layers[l - 1]["dout"] if l > 0 else dx
-                        ops.gemm(dzc, W.data[:Din], out=dst[t0:t0 + T].view(T * B, Din), transB=True)
+                        if st["bf16"]:
+                            ops.gemm_bf16_nt_grouped([dict(A=dzb, B=st["Wxb"], out=dst[t0:t0 + T].view(T * B, Din))])
+                        else:
+                            ops.gemm(dzc, W.data[:Din], out=dst[t0:t0 + T].view(T * B, Din), transB=True)
                         if ctx.drop is not None:
                             ops.dropout_(dst[t0:t0 + T], ctx.drop[0], ctx.drop[1][l], t0 * B * Din)
                         dx_ev = torch.cuda.Event()
@@ -425,8 +451,15 @@ class _LstmStack(torch.autograd.Function):
                         if beta is None:
                             beta = W.grad_beta()
                             wbeta[id(W)] = 1.0
-                        ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta)
-                        ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta)
+                        if st["bf16"]:
+                            sw.wait_event(cast_ev)
+                            dzT.record_stream(sw)
+                            ops.gemm_bf16_nt_grouped([
+                                dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din), transpose=True), B=dzT, out=W.grad[:Din], beta=beta),
+                                dict(A=ops.cast_bf16(st["hs"][t0:t0 + T].view(T * B, H), transpose=True), B=dzT, out=W.grad[Din:], beta=beta)])
+                        else:
+                            ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta)
+                            ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta)
                     if b.grad is not None:
                         beta = wbeta.get(id(b))
                         if beta is None:
@@ -443,10 +476,10 @@ class _LstmStack(torch.autograd.Function):
                 st["W"].grad_done()
             if st["b"].grad is not None:
                 st["b"].grad_done()
-        return (dx, None, None, None, None, None, None) + (None,) * (2 * L)
+        return (dx, None, None, None, None, None, None, None) + (None,) * (2 * L)
 
 
-def lstm_stack(x_tm, num_frames, weights_biases, forget_bias=1.0, chunks=4, input_keep_prob=None, seeds=None):
+def lstm_stack(x_tm, num_frames, weights_biases, forget_bias=1.0, chunks=4, input_keep_prob=None, seeds=None, bf16=False):
     """weights_biases: [(W_0, b_0), ...] Variables.  Returns (out_top, [(c_l, h_l), ...]).
     input_keep_prob < 1: DropoutWrapper(input_keep_prob) on every layer; seeds = one Philox key per layer (default: the
     graph's random stream)."""
@@ -454,7 +487,7 @@ def lstm_stack(x_tm, num_frames, weights_biases, forget_bias=1.0, chunks=4, inpu
     if input_keep_prob is not None and float(input_keep_prob) < 1.0 and seeds is None:
         seeds = [flat[0]._graph.next_random_seed() for _ in weights_biases]
     res = _LstmStack.apply(x_tm, _token(flat[0]._graph), num_frames, forget_bias, int(chunks), input_keep_prob,
-                           tuple(seeds) if seeds is not None else None, *flat)
+                           tuple(seeds) if seeds is not None else None, bool(bf16), *flat)
     return res[0], [(res[1 + 2 * l], res[2 + 2 * l]) for l in range(len(weights_biases))]
 
 
