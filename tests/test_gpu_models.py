@@ -771,6 +771,31 @@ def test_lstm_model_bf16_projections(dev, flags, chunks, monkeypatch):
         assert np.abs(got[k] - ref).max() <= 6e-2 * max(np.abs(ref).max(), 1e-3), k
 
 
+@pytest.mark.parametrize("cls", ["GruPoolingModel", "LayerNormLstmMemoryModel"])
+def test_gru_and_layernorm_models_bf16_hoisted_products(dev, flags, cls, monkeypatch):
+    """--compute_dtype=bfloat16 for the other recurrent cells: hoisted products on bf16 operands (ops.gemm_any), recurrence
+    fp32; the bf16 step tracks the fp32 step of the same weights (loss within 1 %, every gradient within 6 % of its scale)."""
+    import yt8m_amd.ops as ops
+    monkeypatch.setattr(ops, "BF16_MIN_ROWS", 2)
+    monkeypatch.setattr(ops, "BF16_MIN_MACS", 1)
+    rs = np.random.RandomState(52)
+    B, F, Dm, Hh, V = 8, 12, 32, 64, 17
+    flags.gru_cells, flags.gru_layers, flags.lstm_cells, flags.lstm_layers = Hh, 2, str(Hh), 2
+    x = rs.randn(B, F, Dm).astype(np.float32)
+    nf = np.array([12, 1, 5, 12, 3, 7, 12, 9], dtype=np.int32)
+    x *= (np.arange(F)[None, :, None] < nf[:, None, None])
+    y = rs.rand(B, V) < 0.15
+    g32, res32, loss32, P = run_model(getattr(flm, cls)(), x, y, dev, nf=nf, rs=rs)
+    ref = grads_of(g32)
+    flags.compute_dtype = "bfloat16"
+    g16, res16, loss16, _ = run_model(getattr(flm, cls)(), x, y, dev, nf=nf, P={k: v.astype(np.float32) for k, v in P.items()})
+    assert abs(float(loss16) - float(loss32)) < 1e-2 * abs(float(loss32))
+    assert np.abs(H(res16["predictions"]) - H(res32["predictions"])).max() < 3e-2
+    got = grads_of(g16)
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() <= 6e-2 * max(np.abs(r).max(), 1e-3), k
+
+
 def test_tfrecord_to_training_step(dev, flags, tmp_path):
     """End to end through the widened path: fabricated frame-level TFRecord shard -> native reader -> pinned host ->
     device uint8 -> fused dequantise/normalise -> LstmModel step; the transform is checked against the oracle on the

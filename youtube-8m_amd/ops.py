@@ -147,6 +147,18 @@ def cast_bf16(x, transpose=False):
     return out
 
 
+def gemm_any(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0, bf16=False):
+    """C = op(A) . op(B) (+ bias) (+ C); bf16=True takes bf16 copies of both operands (each cast into the K-contiguous layout the
+    NT kernel wants) when the product is large enough to pay for the two cast passes, fp32 accumulate / output either way."""
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N = B.shape[0] if transB else B.shape[1]
+    if not (bf16 and _use_bf16(True, M, N, K, weight_operand=False) and K >= 32):
+        return gemm(A, B, out=out, transA=transA, transB=transB, bias=bias, beta=beta)
+    Ab = cast_bf16(A, transpose=transA)                # op(A)   [M, K]
+    Bb = cast_bf16(B, transpose=not transB)            # op(B)^T [N, K]
+    return gemm_bf16_nt_grouped([dict(A=Ab, B=Bb, out=out, bias=bias, beta=beta)])[0]
+
+
 def cast_bf16_both(x):
     """fp32 [R,C] -> (bf16 [R,C], bf16 [C,R]) from one pass over the source (yt8m_cast_f32_bf16_dual)."""
     _dev(x)

@@ -94,8 +94,9 @@ class _GruLayer(torch.autograd.Function):
         x2 = x_tm.view(F * B, Din)
         zg = torch.empty((F, B, 2 * H), dtype=torch.float32, device=dev)
         zc = torch.empty((F, B, H), dtype=torch.float32, device=dev)
-        ops.gemm_grouped([dict(A=x2, B=Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data),
-                          dict(A=x2, B=Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data)])
+        bf = ops.FLAGS.compute_dtype == "bfloat16"
+        ops.gemm_any(x2, Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data, bf16=bf)
+        ops.gemm_any(x2, Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data, bf16=bf)
         hs = torch.empty((F + 1, B, H), dtype=torch.float32, device=dev)
         hs[0].zero_()
         rh = torch.empty((F, B, H), dtype=torch.float32, device=dev)
@@ -106,6 +107,7 @@ class _GruLayer(torch.autograd.Function):
                                                  _p(out), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _stream()))
         ctx.save_for_backward(x_tm)
         ctx.state = (zg, zc, hs, rh, nf, Wg, bg, Wc, bc)
+        ctx.bf16 = bf
         ctx.set_materialize_grads(False)
         return out, hs[F]
 
@@ -127,15 +129,16 @@ class _GruLayer(torch.autograd.Function):
                                                  _p(dh_final), _p(dzg), _p(dzc), _p(work), _p(nf), F, B, H, _p(ws),
                                                  ws.numel() * 4, _stream()))
         x2, g2, c2 = x_tm.view(F * B, Din), dzg.view(F * B, 2 * H), dzc.view(F * B, H)
+        bf = ctx.bf16
         if Wg.grad is not None:
             beta = Wg.grad_beta()
-            ops.gemm_grouped([dict(A=x2, B=g2, out=Wg.grad[:Din], beta=beta),
-                              dict(A=hs[:F].view(F * B, H), B=g2, out=Wg.grad[Din:], beta=beta)], transA=True)
+            ops.gemm_any(x2, g2, out=Wg.grad[:Din], transA=True, beta=beta, bf16=bf)
+            ops.gemm_any(hs[:F].view(F * B, H), g2, out=Wg.grad[Din:], transA=True, beta=beta, bf16=bf)
             Wg.grad_done()
         if Wc.grad is not None:
             beta = Wc.grad_beta()
-            ops.gemm_grouped([dict(A=x2, B=c2, out=Wc.grad[:Din], beta=beta),
-                              dict(A=rh.view(F * B, H), B=c2, out=Wc.grad[Din:], beta=beta)], transA=True)
+            ops.gemm_any(x2, c2, out=Wc.grad[:Din], transA=True, beta=beta, bf16=bf)
+            ops.gemm_any(rh.view(F * B, H), c2, out=Wc.grad[Din:], transA=True, beta=beta, bf16=bf)
             Wc.grad_done()
         if bg.grad is not None:
             ops.colsum(g2, bg.grad.view(-1), beta=bg.grad_beta())
@@ -145,8 +148,8 @@ class _GruLayer(torch.autograd.Function):
             bc.grad_done()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(g2, Wg.data[:Din], transB=True)
-            ops.gemm(c2, Wc.data[:Din], out=dx, transB=True, beta=1.0)
+            dx = ops.gemm_any(g2, Wg.data[:Din], transB=True, bf16=bf)
+            ops.gemm_any(c2, Wc.data[:Din], out=dx, transB=True, beta=1.0, bf16=bf)
             dx = dx.view(F, B, Din)
         return dx, None, None, None, None, None, None
 
@@ -170,7 +173,8 @@ class _LnLstmLayer(torch.autograd.Function):
         H = W.data.shape[1] // 4
         assert W.data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
         dev = x_tm.device
-        z = ops.gemm(x_tm.view(F * B, Din), W.data[:Din]).view(F, B, 4 * H)
+        bf = ops.FLAGS.compute_dtype == "bfloat16"
+        z = ops.gemm_any(x_tm.view(F * B, Din), W.data[:Din], bf16=bf).view(F, B, 4 * H)
         gamma = torch.stack([v.data for v in gammas]).contiguous()
         beta = torch.stack([v.data for v in betas]).contiguous()
         stats = torch.zeros((F, B, 10), dtype=torch.float32, device=dev)
@@ -186,6 +190,7 @@ class _LnLstmLayer(torch.autograd.Function):
                                                     _p(ws), ws.numel() * 4, _stream()))
         ctx.save_for_backward(x_tm)
         ctx.state = (z, gamma, beta, stats, cs, hs, nf, W, gammas, betas, float(forget_bias), float(keep_prob), int(seed))
+        ctx.bf16 = bf
         ctx.set_materialize_grads(False)
         return out, cs[F], hs[F]
 
@@ -211,8 +216,8 @@ class _LnLstmLayer(torch.autograd.Function):
         dz2 = dz.view(F * B, 4 * H)
         if W.grad is not None:
             b = W.grad_beta()
-            ops.gemm_grouped([dict(A=x_tm.view(F * B, Din), B=dz2, out=W.grad[:Din], beta=b),
-                              dict(A=hs[:F].view(F * B, H), B=dz2, out=W.grad[Din:], beta=b)], transA=True)
+            ops.gemm_any(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=b, bf16=ctx.bf16)
+            ops.gemm_any(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=b, bf16=ctx.bf16)
             W.grad_done()
         yb, yg = dyb.view(F * B, 5 * H), dyg.view(F * B, 5 * H)
         for k in range(5):
@@ -222,7 +227,7 @@ class _LnLstmLayer(torch.autograd.Function):
                     v.grad_done()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dz2, W.data[:Din], transB=True).view(F, B, Din)
+            dx = ops.gemm_any(dz2, W.data[:Din], transB=True, bf16=ctx.bf16).view(F, B, Din)
         return dx, None, None, None, None, None, None, None, None
 
 
