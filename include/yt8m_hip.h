@@ -159,6 +159,19 @@ int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, int64_t ldy
 int yt8m_skinny_dx_f32(const float* dy, int64_t ldy, const float* W, int64_t ldw, float* dx, int64_t lddx, int64_t M, int64_t K,
                        int64_t N, float beta, yt8m_stream_t stream);
 
+/* BasicLSTM recurrence with bf16 operands for the recurrent product (csrc/lstm_bf16.hip; --compute_dtype=bfloat16): h_{t-1} /
+ * dz_t and the packed W_h enter the matrix cores as bf16, accumulation, state, gates and gradients stay fp32.  H % 256 == 0
+ * (yt8m_lstm_packed16_elems() > 0).  hs16 [F+1,B,H] bf16 mirrors hs (row t0 must hold the bf16 copy of hs[t0]: zeros at t0 = 0,
+ * afterwards written by the previous chunk); dz16 [F,B,4H] bf16 is scratch that receives the bf16 copy of dz.  Other arguments
+ * as yt8m_lstm_steps_fwd / _bwd. */
+int64_t yt8m_lstm_packed16_elems(int64_t B, int64_t H);
+int yt8m_lstm_pack_bf16(const float* Wh, int64_t ldw, int64_t H, void* Wp16, void* Wq16, yt8m_stream_t stream);
+int yt8m_lstm_steps_fwd_bf16(float* z, const void* Wp16, float* cs, float* hs, void* hs16, float* out, const int32_t* num_frames,
+                             int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias, yt8m_stream_t stream);
+int yt8m_lstm_steps_bwd_bf16(const float* gates, const void* Wq16, const float* cs, const float* dout, float* dz, void* dz16,
+                             float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
+                             yt8m_stream_t stream);
+
 /* attention pooling over the frame axis (lstm_attention_max_pooling_model.py:63, einsum "ijk,ijl->ikl") on the same streaming
  * kernels: w [B,F,A] (A <= 16), x [B,F,H] (H % 4 == 0), C [B,A,H] = w^T . x per video; dense row-major fp32.
  * bwd: dw [B,F,A] = x . dC^T and / or dx [B,F,H] = w . dC (either may be NULL). */

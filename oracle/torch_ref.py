@@ -80,7 +80,12 @@ def deep_combine_chain(x, P, L, M, relu_type="relu", dropout_spec=None):
     return main, torch.cat(sup, 1)
 
 
-def lstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None):
+def bf16_round(t):
+    """round-to-nearest-even fp32 -> bf16 -> back (value emulation of the device casts), any float dtype in / same dtype out"""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def lstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None, bf16_operands=False):
     """A.3-A.5 (BasicLSTMCell / MultiRNNCell / dynamic_rnn with copy-through; Z/rnn_residual.py:61-188).
     dropout_spec = (input_keep_prob, [seed per layer]): DropoutWrapper(cell, input_keep_prob)
     (W/all_frame_models/lstm_memory_model.py:36-45) -- the layer input of step t is element block t of a time-major
@@ -96,7 +101,13 @@ def lstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None):
         for l, (W, b) in enumerate(layers):
             if dropout_spec is not None:
                 inp = dropout(inp, dropout_spec[0], dropout_spec[1][l], offset=t * inp.numel())
-            z = torch.cat([inp, h[l]], 1) @ W + b
+            if bf16_operands == "input":   # --compute_dtype=bfloat16, hoisted input projection only (H % 256 != 0)
+                d = inp.shape[1]
+                z = bf16_round(inp) @ bf16_round(W[:d]) + h[l] @ W[d:] + b
+            elif bf16_operands:   # both products take bf16-rounded operands, fp32+ accumulation
+                z = bf16_round(torch.cat([inp, h[l]], 1)) @ bf16_round(W) + b
+            else:
+                z = torch.cat([inp, h[l]], 1) @ W + b
             i, j, f, o = z.chunk(4, 1)
             cn = c[l] * torch.sigmoid(f + forget_bias) + torch.sigmoid(i) * torch.tanh(j)
             hn = torch.tanh(cn) * torch.sigmoid(o)
@@ -164,9 +175,9 @@ def lnlstm_stack(x, num_frames, layers, forget_bias=1.0, dropout_spec=None):
     return torch.stack(outs, 1), c, h
 
 
-def lstm_model_state(x, num_frames, layers):
+def lstm_model_state(x, num_frames, layers, bf16_operands=False):
     """W/all_frame_models/lstm_model.py:34-52: [c0||h0||c1||h1]."""
-    _, c, h = lstm_stack(x, num_frames, layers)
+    _, c, h = lstm_stack(x, num_frames, layers, bf16_operands=bf16_operands)
     return torch.cat([t for pair in zip(c, h) for t in pair], 1)
 
 

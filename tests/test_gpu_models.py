@@ -742,24 +742,46 @@ def test_bf16_training_tracks_fp32(dev, flags, monkeypatch):
     assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max(), (a, b)
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_lstm_model_bf16_projections(dev, flags, chunks, monkeypatch):
+def _small_lstm_params(rs, Dm, Hh, V):
+    """xavier-scale weights (the randomise() default of 0.3 saturates a 256-wide cell and amplifies operand rounding)"""
+    P = {}
+    d_in = Dm
+    for l in range(2):
+        P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l] = (rs.randn(d_in + Hh, 4 * Hh) / np.sqrt(d_in + Hh)).astype(np.float32)
+        P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l] = (rs.randn(4 * Hh) * 0.1).astype(np.float32)
+        d_in = Hh
+    P["gates/weights"] = (rs.randn(4 * Hh, V * 3) * 0.05).astype(np.float32)
+    P["experts/weights"] = (rs.randn(4 * Hh, V * 2) * 0.05).astype(np.float32)
+    P["experts/biases"] = (rs.randn(V * 2) * 0.1).astype(np.float32)
+    return P
+
+
+@pytest.mark.parametrize("chunks,Hh", [(1, 128), (3, 128), (1, 256), (3, 256)])
+def test_lstm_model_bf16_projections(dev, flags, chunks, Hh, monkeypatch):
     """--compute_dtype=bfloat16 on LstmModel: the hoisted products of the stack (input projection, dW, dx) take bf16 operands,
-    the recurrence stays fp32.  Predictions stay within bf16 operand noise of the fp32 oracle and every gradient within 6 % of
-    its scale (8-bit mantissas through two layers and twelve steps of back-propagation; measured 3 %)."""
+    and -- for H % 256 == 0 -- the recurrent product too (csrc/lstm_bf16.hip: bf16 h / dz / W_h operands, fp32 state and
+    accumulation).  Predictions stay within bf16 operand noise of the fp32 oracle and every gradient within 6 % of its scale
+    (8-bit mantissas through two layers and twelve steps of back-propagation; measured 3 %)."""
     import yt8m_amd.ops as ops
     monkeypatch.setattr(ops, "BF16_MIN_ROWS", 2)
     monkeypatch.setattr(ops, "BF16_MIN_MACS", 1)
     rs = np.random.RandomState(51)
-    B, F, Dm, Hh, V = 8, 12, 16, 128, 17
+    B, F, Dm, V = 8, 12, 16, 17
     flags.lstm_cells, flags.lstm_layers, flags.lstm_pipeline_chunks = str(Hh), 2, chunks
     flags.compute_dtype = "bfloat16"
     x = rs.randn(B, F, Dm).astype(np.float32)
     nf = np.array([12, 1, 5, 12, 3, 7, 12, 9], dtype=np.int32)
     x *= (np.arange(F)[None, :, None] < nf[:, None, None])
     y = rs.rand(B, V) < 0.15
-    g, res, loss, P = run_model(flm.LstmModel(), x, y, dev, nf=nf, rs=rs)
+    g, res, loss, P = run_model(flm.LstmModel(), x, y, dev, nf=nf, rs=np.random.RandomState(53) if Hh < 256 else None,
+                                P=None if Hh < 256 else _small_lstm_params(rs, Dm, Hh, V))
     tp = {k: T(v * 1.0).requires_grad_(True) for k, v in P.items()}
+    with torch.no_grad():   # value emulation: both LSTM products on bf16-rounded operands (exactly what the device computes)
+        ste = torch_ref.lstm_model_state(T(x), torch.from_numpy(nf), _lstm_ref_layers(tp, 2),
+                                         bf16_operands=True if Hh % 256 == 0 else "input")
+        pre = torch_ref.moe(torch_ref.bf16_round(ste), torch_ref.bf16_round(tp["gates/weights"]),
+                            torch_ref.bf16_round(tp["experts/weights"]), tp["experts/biases"], 2)
+    assert np.abs(H(res["predictions"]) - pre.numpy()).max() < 2e-3
     st = torch_ref.lstm_model_state(T(x), torch.from_numpy(nf), _lstm_ref_layers(tp, 2))
     pr = torch_ref.moe(st, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
     lr = torch_ref.cross_entropy(pr, T(y))

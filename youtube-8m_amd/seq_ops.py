@@ -260,6 +260,10 @@ def _chunks(F, n):
     return [(t0, min(step, F - t0)) for t0 in range(0, F, step)]
 
 
+REC_BF16 = True       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
+                      # products only
+
+
 class _LstmStack(torch.autograd.Function):
     """MultiRNNCell([BasicLSTMCell] * L) under tf.nn.dynamic_rnn (W/all_frame_models/lstm_model.py:34-47), time-major, as ONE
     op so that the layers can be pipelined: the sequence is cut into time chunks; layer l's hoisted input projection of
@@ -325,8 +329,15 @@ class _LstmStack(torch.autograd.Function):
                 if st["Wp"] is not None:
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
                 st["bf16"] = bf16 and st["Din"] % 2 == 0
+                st["rec16"] = st["bf16"] and REC_BF16 and lib.yt8m_lstm_packed16_elems(B, st["H"]) > 0
                 if st["bf16"]:                                      # W_x^T once per step, K-contiguous for the NT product
                     st["WxT"] = ops.cast_bf16(st["W"].data[:st["Din"]], transpose=True)
+                if st["rec16"]:                                     # bf16 operands for the recurrent product too
+                    H_ = st["H"]
+                    st["hs16"] = torch.empty((F + 1, B, H_), dtype=torch.bfloat16, device=dev)
+                    st["hs16"][0].zero_()
+                    st["Wp16"] = torch.empty(H_ * 4 * H_, dtype=torch.bfloat16, device=dev)
+                    _lib.check(lib.yt8m_lstm_pack_bf16(_p(st["W"].data[st["Din"]:]), 4 * H_, H_, _p(st["Wp16"]), None, _stream()))
         r_done = [[torch.cuda.Event() for _ in parts] for _ in range(L)]
         for c, (t0, T) in enumerate(parts):
             for l, st in enumerate(layers):
@@ -350,9 +361,13 @@ class _LstmStack(torch.autograd.Function):
                 with torch.cuda.stream(rs[l]):                      # recurrence steps of the chunk
                     rs[l].wait_event(g_ev)
                     ws = ops._workspace(dev)
-                    _lib.check(lib.yt8m_lstm_steps_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["Wp"]), _p(st["cs"]),
-                                                       _p(st["hs"]), _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias),
-                                                       _p(ws), ws.numel() * 4, _stream()))
+                    if st["rec16"]:
+                        _lib.check(lib.yt8m_lstm_steps_fwd_bf16(_p(st["z"]), _p(st["Wp16"]), _p(st["cs"]), _p(st["hs"]), _p(st["hs16"]),
+                                                                _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _stream()))
+                    else:
+                        _lib.check(lib.yt8m_lstm_steps_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["Wp"]), _p(st["cs"]),
+                                                           _p(st["hs"]), _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias),
+                                                           _p(ws), ws.numel() * 4, _stream()))
                     r_done[l][c].record(rs[l])
         for l in range(L):
             main.wait_event(r_done[l][-1])
@@ -378,6 +393,8 @@ class _LstmStack(torch.autograd.Function):
         dx = torch.empty_like(layers[0]["x"]) if need_dx else None
         for st in layers:
             st.pop("WxT", None)
+            st.pop("Wp16", None)
+            st.pop("hs16", None)
         for l, st in enumerate(layers):                            # buffers come from the main stream's pool
             H = st["H"]
             st["dz"] = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
@@ -404,7 +421,11 @@ class _LstmStack(torch.autograd.Function):
                 else:
                     st["work"][1].copy_(dc)
                 st["phase"] = 0
-                if st["Wq"] is not None:
+                if st["rec16"]:
+                    st["dz16"] = torch.empty((F, B, 4 * H), dtype=torch.bfloat16, device=dev)
+                    st["Wq16"] = torch.empty(H * 4 * H, dtype=torch.bfloat16, device=dev)
+                    _lib.check(lib.yt8m_lstm_pack_bf16(_p(st["W"].data[st["Din"]:]), 4 * H, H, None, _p(st["Wq16"]), _stream()))
+                elif st["Wq"] is not None:
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * H, H, None, _p(st["Wq"]), _stream()))
         wbeta = {}
         last = []
@@ -419,9 +440,14 @@ class _LstmStack(torch.autograd.Function):
                     if dx_ev is not None:
                         rs[l].wait_event(dx_ev)
                     ws = ops._workspace(dev)
-                    _lib.check(lib.yt8m_lstm_steps_bwd(_p(st["z"]), _p(W.data[Din:]), 4 * H, _p(st["Wq"]), _p(st["cs"]), _p(st["dout"]),
-                                                       _p(st["dz"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H, _p(ws),
-                                                       ws.numel() * 4, _stream()))
+                    if st["rec16"]:
+                        _lib.check(lib.yt8m_lstm_steps_bwd_bf16(_p(st["z"]), _p(st["Wq16"]), _p(st["cs"]), _p(st["dout"]), _p(st["dz"]),
+                                                                _p(st["dz16"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H,
+                                                                _stream()))
+                    else:
+                        _lib.check(lib.yt8m_lstm_steps_bwd(_p(st["z"]), _p(W.data[Din:]), 4 * H, _p(st["Wq"]), _p(st["cs"]), _p(st["dout"]),
+                                                           _p(st["dz"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H, _p(ws),
+                                                           ws.numel() * 4, _stream()))
                     st["phase"] = (st["phase"] + T) % 2
                     rb = torch.cuda.Event()
                     rb.record(rs[l])
@@ -430,7 +456,10 @@ class _LstmStack(torch.autograd.Function):
                 if st["bf16"]:                                      # dz feeds dx (plain) and both dW products (transposed)
                     with torch.cuda.stream(gs[l]):
                         gs[l].wait_event(rb)
-                        dzb, dzT = ops.cast_bf16_both(dzc)
+                        if st["rec16"]:                         # the step kernels already wrote the plain bf16 copy
+                            dzb, dzT = st["dz16"][t0:t0 + T].view(T * B, 4 * H), ops.cast_bf16(dzc, transpose=True)
+                        else:
+                            dzb, dzT = ops.cast_bf16_both(dzc)
                         if "Wxb" not in st:
                             st["Wxb"] = ops.cast_bf16(W.data[:Din])
                         cast_ev = torch.cuda.Event()
