@@ -222,6 +222,17 @@ int yt8m_lnlstm_layer_bwd(const float* z, const float* Wh, int64_t ldw, const fl
 int yt8m_dropout_f32(const float* x, float* y, int64_t n, float keep_prob, uint64_t seed, int64_t offset, yt8m_stream_t stream);
 int yt8m_add_noise_f32(const float* x, float* y, int64_t n, float stddev, uint64_t seed, int64_t offset, yt8m_stream_t stream);
 
+/* MoE mixing backward straight into bf16 GEMM operands (csrc/moe_bf16.hip; --compute_dtype=bfloat16, num_mixtures == 2): one pass
+ * over the fp32 logits Zg [B, 3V] / Ze [B, 2V] (dense) and either dL/dp [B,V] (dp) or the labels (CrossEntropyLoss fused, as
+ * yt8m_moe_mix_xent_bwd: eps, dscale * upstream_dev[0]) writes dL/dZ as bf16 in both layouts -- dZg_b [B, 3V] (pitch gb_ld),
+ * dZg_t [3V, B] (gt_ld), dZe_b [B, 2V] (eb_ld), dZe_t [2V, B] (et_ld) -- and be_part [yt8m_moe_mix_bwd_bf16_partial_rows(B), 2V]:
+ * column sums of dZe per 64-row block (their column sum is the expert-bias gradient).  The fp32 logits are left untouched. */
+int64_t yt8m_moe_mix_bwd_bf16_partial_rows(int64_t B);
+int yt8m_moe_mix_bwd_bf16(const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype, int64_t B, int64_t V,
+                          int M, float eps, float dscale, const float* upstream_dev, void* dZg_b, int64_t gb_ld, void* dZg_t,
+                          int64_t gt_ld, void* dZe_b, int64_t eb_ld, void* dZe_t, int64_t et_ld, float* be_part,
+                          yt8m_stream_t stream);
+
 /* ---- elementwise activations + column sums (bias gradients) ------------------------------------ */
 enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8M_ACT_TANH = 3, YT8M_ACT_ELU = 4 };
 int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream);

@@ -797,3 +797,51 @@ def test_bf16_large_tile_gemm(dev, monkeypatch):
         ops.gemm_bf16_nt_grouped(items2)
         for o, (ref, bias, scale) in zip(outs, refs):
             assert np.abs(H(o) - (2 * ref + bias)).max() <= 4e-6 * scale
+
+
+@pytest.mark.parametrize("B,V", [(64, 64), (100, 70), (256, 4716), (37, 129)])
+def test_moe_mix_bwd_bf16_fused(dev, B, V):
+    """csrc/moe_bf16.hip: dL/dZ of the MoE mixing written straight as bf16 in both layouts + per-block bias partial sums ==
+    the fp32 mixing backward followed by the casts / column sum (to one bf16 ulp: the two kernels may contract differently),
+    for dL/dp given and for the CrossEntropyLoss-fused form; ragged row / label tiles and padded pitches."""
+    rs = np.random.RandomState(B + V)
+    M = 2
+    Zg = (rs.randn(B, V * 3) * 2).astype(np.float32)
+    Ze = (rs.randn(B, V * 2) * 2).astype(np.float32)
+    dp = rs.randn(B, V).astype(np.float32)
+    y = (rs.rand(B, V) < 0.1)
+    lib = L.lib()
+
+    def fused(dp_t, lab_t, dscale, up):
+        gb, gt = ops._bf16_empty(B, 3 * V, dev), ops._bf16_empty(3 * V, B, dev)
+        eb, et = ops._bf16_empty(B, 2 * V, dev), ops._bf16_empty(2 * V, B, dev)
+        part = torch.empty((lib.yt8m_moe_mix_bwd_bf16_partial_rows(B), 2 * V), device=dev)
+        zg_in, ze_in = D(Zg, dev), D(Ze, dev)                  # named: a temporary would be freed before the launch reads it
+        L.check(lib.yt8m_moe_mix_bwd_bf16(ops._p(zg_in), ops._p(ze_in), ops._p(dp_t), ops._p(lab_t), 0, B, V, M, 1e-5,
+                                          dscale, ops._p(up), ops._p(gb), gb.stride(0), ops._p(gt), gt.stride(0), ops._p(eb),
+                                          eb.stride(0), ops._p(et), et.stride(0), ops._p(part), ops._stream()))
+        return gb.float().cpu().numpy(), gt.float().cpu().numpy(), eb.float().cpu().numpy(), et.float().cpu().numpy(), H(part)
+
+    def close(a, ref):     # two bf16 ulps of slack (the kernels contract / order their fp32 maths differently) + an absolute
+        # term for the cancellation in s * (e - p) near zero
+        return np.all(np.abs(a - ref) <= np.maximum(np.abs(ref), np.abs(a)) * 2.0 ** -6 + 2e-6 * np.abs(ref).max())
+
+    # mode 0: dL/dp given
+    zg, ze = D(Zg, dev), D(Ze, dev)
+    ops.moe_mix_bwd_(zg, ze, D(dp, dev), V, M)
+    rg, re = _bf16_round(H(zg).astype(np.float32)), _bf16_round(H(ze).astype(np.float32))
+    gb, gt, eb, et, part = fused(D(dp, dev), None, 1.0, None)
+    assert close(gb, rg)
+    assert close(eb, re)
+    assert np.array_equal(gt, gb.T) and np.array_equal(et, eb.T)
+    assert np.abs(part.sum(0) - eb.astype(np.float64).sum(0)).max() < 1e-3 * max(1.0, np.abs(eb).sum(0).max())
+    # mode 1: labels, fused cross-entropy gradient with a device-side upstream scale
+    zg, ze = D(Zg, dev), D(Ze, dev)
+    up = torch.tensor([0.37], device=dev)
+    lab = torch.from_numpy(y.view(np.uint8)).to(dev)
+    L.check(lib.yt8m_moe_mix_xent_bwd(ops._p(zg), ops._p(ze), ops._p(lab), 0, ops._p(up), B, V, M, 1e-5, 1.0, ops._stream()))
+    rg, re = _bf16_round(H(zg).astype(np.float32)), _bf16_round(H(ze).astype(np.float32))
+    gb, gt, eb, et, part = fused(None, lab, 1.0 / B, up)
+    assert close(gb, rg)
+    assert close(eb, re)
+    assert np.array_equal(gt, gb.T) and np.array_equal(et, eb.T)

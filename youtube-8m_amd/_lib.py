@@ -68,6 +68,9 @@ SIGNATURES = {
                                       c_float, ctypes.c_uint64, P, c_int64, P]),
     "yt8m_dropout_f32": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, c_int64, P]),
     "yt8m_add_noise_f32": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, c_int64, P]),
+    "yt8m_moe_mix_bwd_bf16_partial_rows": (c_int64, [c_int64]),
+    "yt8m_moe_mix_bwd_bf16": (c_int, [P, P, P, P, c_int, c_int64, c_int64, c_int, c_float, c_float, P, P, c_int64, P, c_int64,
+                                      P, c_int64, P, c_int64, P, P]),
     "yt8m_act_fwd_f32": (c_int, [c_int, P, P, c_int64, P]),
     "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),
     "yt8m_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),

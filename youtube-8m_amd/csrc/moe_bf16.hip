@@ -1,0 +1,193 @@
+// moe_bf16.hip -- MoE mixing backward that leaves the logits' gradients directly as bf16 GEMM operands (--compute_dtype=bfloat16).
+//
+// In the bf16 configuration dL/dZ is consumed three times: K-contiguous by dx = dZ . W^T, row-transposed by dW = x^T . dZ, and
+// column-summed for the expert-bias gradient.  The fp32 path writes dZ in place (4 B/element), a dual cast re-reads it and
+// writes both bf16 layouts (4 + 2 + 2), colsum re-reads dZ_e: 15.6 B per logit element.  Here one pass reads Z (and dL/dp or the
+// labels), forms dL/dZ in registers (as moe_mix_bwd_kernel / moe_mix_xent_bwd_kernel) and writes
+//   dZg_b [B, V(M+1)]  dZg_t [V(M+1), B]   dZe_b [B, VM]   dZe_t [VM, B]      bf16, row pitches given by the caller
+//   be_part [B/64, VM]                     fp32 column sums of dZ_e over each 64-row block (fixed order -> deterministic)
+// = 4 + 2 + 2 B per element.  M = 2 (the reference's default and every BASELINE configuration); other M keep the fp32 path.
+// Workgroup = 64 rows x 64 labels; a thread owns (row, 16 consecutive labels): 48 + 32 contiguous logits in, 96 + 64 contiguous
+// bytes out; the transposed copies go through an LDS tile [column][64 rows] and leave as 128-byte rows.
+#include "common.h"
+
+namespace {
+
+constexpr int M2 = 2;
+constexpr int TR = 64, TL = 64;                    // rows x labels per workgroup
+constexpr int GC = TL * (M2 + 1), EC = TL * M2;    // 192 gate columns, 128 expert columns per tile
+constexpr int PITCH = TR + 8;                      // bf16 elements per LDS column (+8: 16-byte aligned rows, spreads banks)
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// MODE 0: d = dp[b, l].  MODE 1: d from the labels (uint8 / float), CrossEntropyLoss fused (eps, dscale * up_dev[0]).
+template <int MODE, typename LT>
+__global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __restrict__ Zg, const float* __restrict__ Ze,
+                                                               const float* __restrict__ dp, const LT* __restrict__ y,
+                                                               int64_t B, int64_t V, float eps, float dscale,
+                                                               const float* __restrict__ up_dev,
+                                                               unsigned short* __restrict__ gb, int64_t gb_ld,
+                                                               unsigned short* __restrict__ gt, int64_t gt_ld,
+                                                               unsigned short* __restrict__ eb, int64_t eb_ld,
+                                                               unsigned short* __restrict__ et, int64_t et_ld,
+                                                               float* __restrict__ be_part) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[(GC + EC) * PITCH];   // 320 x 72 x 2 B = 45 KiB
+  const int tid = threadIdx.x;
+  const int r = tid >> 2, lq = tid & 3;
+  const int64_t b = (int64_t)blockIdx.y * TR + r;
+  const int64_t l0 = (int64_t)blockIdx.x * TL + lq * 16;
+  if (MODE == 1 && up_dev) dscale *= up_dev[0];
+  unsigned short og[48], oe[32];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) og[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) oe[k] = 0;
+  if (b < B) {
+    const float* zg = Zg + b * V * 3 + l0 * 3;
+    const float* ze = Ze + b * V * 2 + l0 * 2;
+    const bool full = l0 + 16 <= V && ((reinterpret_cast<uintptr_t>(zg) | reinterpret_cast<uintptr_t>(ze)) & 15) == 0;
+    float g[48], e[32];
+    if (full) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(zg + 4 * k);
+        g[4 * k] = v.x; g[4 * k + 1] = v.y; g[4 * k + 2] = v.z; g[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ze + 4 * k);
+        e[4 * k] = v.x; e[4 * k + 1] = v.y; e[4 * k + 2] = v.z; e[4 * k + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 48; ++k) g[k] = (l0 + k / 3 < V) ? zg[k] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) e[k] = (l0 + k / 2 < V) ? ze[k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (l0 + j < V) {
+        const float g0 = g[3 * j], g1 = g[3 * j + 1], g2 = g[3 * j + 2];
+        const float mx = fmaxf(g0, fmaxf(g1, g2));
+        const float x0 = expf(g0 - mx), x1 = expf(g1 - mx), x2 = expf(g2 - mx);
+        const float inv = 1.0f / (x0 + x1 + x2);
+        const float s0 = x0 * inv, s1 = x1 * inv, s2 = x2 * inv;
+        const float e0 = 1.0f / (1.0f + expf(-e[2 * j])), e1 = 1.0f / (1.0f + expf(-e[2 * j + 1]));
+        const float pv = s0 * e0 + s1 * e1;
+        float d;
+        if (MODE == 0) {
+          d = dp[b * V + l0 + j];
+        } else {
+          const float yv = (float)y[b * V + l0 + j];
+          d = -(yv / (pv + eps) - (1.0f - yv) / (1.0f - pv + eps)) * dscale;
+        }
+        og[3 * j] = f2bf(d * s0 * (e0 - pv));
+        og[3 * j + 1] = f2bf(d * s1 * (e1 - pv));
+        og[3 * j + 2] = f2bf(d * s2 * (0.f - pv));
+        oe[2 * j] = f2bf(d * s0 * e0 * (1.0f - e0));
+        oe[2 * j + 1] = f2bf(d * s1 * e1 * (1.0f - e1));
+      }
+    }
+    // plain bf16 rows
+    unsigned short* pg = gb + b * gb_ld + l0 * 3;
+    unsigned short* pe = eb + b * eb_ld + l0 * 2;
+    if (l0 + 16 <= V && ((reinterpret_cast<uintptr_t>(pg) | reinterpret_cast<uintptr_t>(pe)) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        uint4 v;
+        v.x = og[8 * k] | ((unsigned)og[8 * k + 1] << 16); v.y = og[8 * k + 2] | ((unsigned)og[8 * k + 3] << 16);
+        v.z = og[8 * k + 4] | ((unsigned)og[8 * k + 5] << 16); v.w = og[8 * k + 6] | ((unsigned)og[8 * k + 7] << 16);
+        *reinterpret_cast<uint4*>(pg + 8 * k) = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint4 v;
+        v.x = oe[8 * k] | ((unsigned)oe[8 * k + 1] << 16); v.y = oe[8 * k + 2] | ((unsigned)oe[8 * k + 3] << 16);
+        v.z = oe[8 * k + 4] | ((unsigned)oe[8 * k + 5] << 16); v.w = oe[8 * k + 6] | ((unsigned)oe[8 * k + 7] << 16);
+        *reinterpret_cast<uint4*>(pe + 8 * k) = v;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 48; ++k) if (l0 + k / 3 < V) pg[k] = og[k];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) if (l0 + k / 2 < V) pe[k] = oe[k];
+    }
+  }
+  // transposed image: tile[column][row]; rows beyond B / labels beyond V hold zeros
+#pragma unroll
+  for (int k = 0; k < 48; ++k) tile[(lq * 48 + k) * PITCH + r] = og[k];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) tile[(GC + lq * 32 + k) * PITCH + r] = oe[k];
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.y * TR;
+  const bool rows_full = r0 + TR <= B;
+  for (int idx = tid; idx < (GC + EC) * 8; idx += 256) {      // 16-byte pieces: 8 per column
+    const int col = idx >> 3, piece = idx & 7;
+    const bool gate = col < GC;
+    const int64_t gcol = gate ? (int64_t)blockIdx.x * GC + col : (int64_t)blockIdx.x * EC + (col - GC);
+    if (gcol >= (gate ? V * 3 : V * 2)) continue;
+    unsigned short* dst = (gate ? gt + gcol * gt_ld : et + gcol * et_ld) + r0 + piece * 8;
+    const unsigned short* src = tile + col * PITCH + piece * 8;
+    if (rows_full && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int k = 0; k < 8; ++k)
+        if (r0 + piece * 8 + k < B) dst[k] = src[k];
+    }
+  }
+  // expert-bias partials: column sums of the (bf16-rounded) dZ_e over this 64-row block, fixed order
+  if (be_part && tid < EC) {
+    const int64_t gcol = (int64_t)blockIdx.x * EC + tid;
+    if (gcol < V * 2) {
+      float s = 0.f;
+      const unsigned short* src = tile + (GC + tid) * PITCH;
+#pragma unroll 8
+      for (int k = 0; k < TR; ++k) s += bf2f(src[k]);
+      be_part[(int64_t)blockIdx.y * V * 2 + gcol] = s;
+    }
+  }
+}
+
+}  // namespace
+
+using namespace yt8m;
+
+extern "C" int64_t yt8m_moe_mix_bwd_bf16_partial_rows(int64_t B) { return (B + TR - 1) / TR; }
+
+extern "C" int yt8m_moe_mix_bwd_bf16(const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype,
+                                     int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev, void* dZg_b,
+                                     int64_t gb_ld, void* dZg_t, int64_t gt_ld, void* dZe_b, int64_t eb_ld, void* dZe_t,
+                                     int64_t et_ld, float* be_part, yt8m_stream_t stream) {
+  YT8M_REQUIRE(M == 2, YT8M_E_BADARG, "the bf16 mixing backward is built for num_mixtures == 2");
+  YT8M_REQUIRE(B >= 0 && V >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(Zg && Ze && (dp || labels) && dZg_b && dZg_t && dZe_b && dZe_t, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(!(dp && labels), YT8M_E_BADARG, "give either dp or labels");
+  YT8M_REQUIRE(gb_ld >= V * 3 && eb_ld >= V * 2 && gt_ld >= B && et_ld >= B, YT8M_E_SHAPE, "leading dimension too small");
+  YT8M_REQUIRE((B + TR - 1) / TR <= 65535, YT8M_E_SHAPE, "too many rows");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const dim3 grid((unsigned)((V + TL - 1) / TL), (unsigned)((B + TR - 1) / TR));
+  unsigned short *gb = static_cast<unsigned short*>(dZg_b), *gt = static_cast<unsigned short*>(dZg_t);
+  unsigned short *eb = static_cast<unsigned short*>(dZe_b), *et = static_cast<unsigned short*>(dZe_t);
+  if (dp) {
+    hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<0, uint8_t>), grid, dim3(256), 0, s, Zg, Ze, dp, (const uint8_t*)nullptr, B, V, eps, dscale,
+                       upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld, be_part);
+  } else if (label_dtype == 0) {
+    hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<1, uint8_t>), grid, dim3(256), 0, s, Zg, Ze, (const float*)nullptr,
+                       static_cast<const uint8_t*>(labels), B, V, eps, dscale, upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld,
+                       be_part);
+  } else {
+    YT8M_REQUIRE(label_dtype == 1, YT8M_E_BADARG, "label_dtype must be 0 (uint8) or 1 (float32)");
+    hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<1, float>), grid, dim3(256), 0, s, Zg, Ze, (const float*)nullptr,
+                       static_cast<const float*>(labels), B, V, eps, dscale, upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld,
+                       be_part);
+  }
+  return launch_status("moe_mix_bwd_bf16_kernel");
+}

@@ -722,9 +722,58 @@ class _MoeHead(torch.autograd.Function):
         Wg, We, be = ctx.vars
         V, M = ctx.VM
         ctx.Z = None
+        if _fused_mix_bf16_ok(ctx, x, Zg, Ze, M):
+            dx = _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, dp=_f32c(dp))
+            return dx, None, None, None, None, None, None, None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
         dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
         return dx, None, None, None, None, None, None, None
+
+
+FUSED_MIX_BF16 = True     # compute_dtype=bfloat16, M == 2: mixing backward writes the bf16 GEMM operands itself (csrc/moe_bf16.hip)
+
+
+def _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, dp=None, labels=None, ldt=0, dscale=1.0, up=None):
+    """bf16 configuration: ONE pass over the fp32 logits produces dL/dZ as bf16 in both layouts + the bias partial sums, then
+    the same three bf16 products as _moe_head_param_grads_bf16 (no fp32 dZ, no cast passes, no colsum over dZ_e)."""
+    L = _lib.lib()
+    B = Zg.shape[0]
+    dev = Zg.device
+    Zgb, ZgT = _bf16_empty(B, Zg.shape[1], dev), _bf16_empty(Zg.shape[1], B, dev)
+    Zeb, ZeT = _bf16_empty(B, Ze.shape[1], dev), _bf16_empty(Ze.shape[1], B, dev)
+    part = torch.empty((L.yt8m_moe_mix_bwd_bf16_partial_rows(B), Ze.shape[1]), dtype=torch.float32, device=dev) \
+        if be.grad is not None else None
+    _lib.check(L.yt8m_moe_mix_bwd_bf16(_p(Zg), _p(Ze), _p(dp), _p(labels), ldt, B, V, M, XENT_EPS, float(dscale), _p(up),
+                                       _p(Zgb), Zgb.stride(0), _p(ZgT), ZgT.stride(0), _p(Zeb), Zeb.stride(0), _p(ZeT),
+                                       ZeT.stride(0), _p(part), _stream()))
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dx, = gemm_bf16_nt_grouped([dict(A=Zgb, B=cast_bf16(Wg.data))])
+        gemm_bf16_nt_grouped([dict(A=Zeb, B=cast_bf16(We.data), out=dx, beta=1.0)])
+    del Zgb, Zeb
+    if Wg.grad is not None and We.grad is not None:
+        xT = cast_bf16(x, transpose=True)
+        overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
+        pg = dict(A=xT, B=ZgT, out=Wg.grad, beta=Wg.grad_beta())
+        pe = dict(A=xT, B=ZeT, out=We.grad, beta=We.grad_beta())
+        if overlap:
+            gemm_bf16_nt_grouped([pg])
+            Wg.grad_done()
+            gemm_bf16_nt_grouped([pe])
+            We.grad_done()
+        else:
+            gemm_bf16_nt_grouped([pg, pe])
+            Wg.grad_done()
+            We.grad_done()
+    if be.grad is not None:
+        colsum(part, be.grad.view(-1), beta=be.grad_beta())
+        be.grad_done()
+    return dx
+
+
+def _fused_mix_bf16_ok(ctx, x, Zg, Ze, M):
+    return (FUSED_MIX_BF16 and getattr(ctx, "bf16", False) and M == 2 and _bf16_ok(x) and Zg.shape[1] % 2 == 0
+            and Ze.shape[1] % 2 == 0 and Zg.is_contiguous() and Ze.is_contiguous())
 
 
 def _bf16_ok(x2):
@@ -780,6 +829,10 @@ class _MoeHeadXent(torch.autograd.Function):
         ctx.Z = None
         if dloss is None:
             return (None,) * 9
+        if _fused_mix_bf16_ok(ctx, x, Zg, Ze, M):
+            dx = _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, labels=lab, ldt=ldt, dscale=1.0 / x.shape[0],
+                                          up=_f32c(dloss.reshape(1)))
+            return dx, None, None, None, None, None, None, None, None
         _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
                                                     XENT_EPS, 1.0, _stream()))
         dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
