@@ -69,6 +69,14 @@ def test_argument_validation_without_device():
     assert lib.yt8m_attn_pool_fwd(None, None, None, 0, 10, 8, 64, None) == 0
     assert lib.yt8m_cast_f32_bf16(one, 4, 8, 8, one, 4, 0, None) == -2                          # dst_ld < cols
     assert lib.yt8m_cast_f32_bf16_dual(one, 4, 8, 8, one, 8, one, 2, None) == -2                # trans_ld < rows
+    assert lib.yt8m_moe_mix_bwd_bf16(one, one, one, None, 0, 4, 8, 3, 1e-5, 1.0, None, one, 24, one, 8, one, 16, one, 8, None, None) == -1   # M != 2
+    assert lib.yt8m_moe_mix_bwd_bf16(one, one, one, one, 0, 4, 8, 2, 1e-5, 1.0, None, one, 24, one, 8, one, 16, one, 8, None, None) == -1   # dp AND labels
+    assert lib.yt8m_moe_mix_bwd_bf16(one, one, one, None, 0, 4, 8, 2, 1e-5, 1.0, None, one, 20, one, 8, one, 16, one, 8, None, None) == -2   # pitch < 3V
+    assert lib.yt8m_moe_mix_bwd_bf16_partial_rows(1024) == 16 and lib.yt8m_moe_mix_bwd_bf16_partial_rows(65) == 2
+    assert lib.yt8m_lstm_packed16_elems(128, 1024) == 1024 * 4096 and lib.yt8m_lstm_packed16_elems(128, 384) == 0
+    assert lib.yt8m_lstm_pack_bf16(one, 4 * 384, 384, one, None, None) == -2                    # H % 256 != 0
+    assert lib.yt8m_lstm_steps_fwd_bf16(one, one, one, one, None, None, None, 0, 2, 2, 256, 1.0, None) == -1   # hs16 missing
+    assert lib.yt8m_lstm_steps_bwd_bf16(one, one, one, None, one, one, one, 2, None, 0, 2, 2, 256, None) == -1  # phase
     assert lib.yt8m_gru_layer_fwd(None, one, one, 8, one, 4, one, one, None, None, 2, 2, 4, None, 0, None) == -1
     assert lib.yt8m_gru_layer_fwd(one, one, one, 4, one, 4, one, one, None, None, 2, 2, 4, None, 0, None) == -2   # ldg < 2H
     assert lib.yt8m_lnlstm_layer_fwd(one, one, 16, one, one, one, one, one, None, None, 2, 2, 4096, 1.0, 1.0, 0, None, 0, None) == -2
