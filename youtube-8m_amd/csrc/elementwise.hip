@@ -357,6 +357,35 @@ __global__ __launch_bounds__(256) void dequant_l2norm_kernel(const uint8_t* __re
   const uint8_t* qr = q + row * D;
   const float s = 4.0f / 255.0f, bias = 4.0f / 512.0f - 2.0f;
   float ss = 0.f;
+  if ((D & 3) == 0 && D <= 2048 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
+    // 4 bytes per lane and load, the row held in registers between the two passes, 16-byte stores (1 KiB per wave instruction)
+    const int nd = (int)(D >> 2);
+    uint32_t w[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c4 = lane + 64 * it;
+      w[it] = c4 < nd ? reinterpret_cast<const uint32_t*>(qr)[c4] : 0u;
+      if (c4 < nd) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float v = fmaf((float)((w[it] >> (8 * k)) & 255u), s, bias); ss += v * v; }
+      }
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(fmaxf(ss, eps));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c4 = lane + 64 * it;
+      if (c4 < nd) {
+        float4 o;
+        o.x = fmaf((float)(w[it] & 255u), s, bias) * r;
+        o.y = fmaf((float)((w[it] >> 8) & 255u), s, bias) * r;
+        o.z = fmaf((float)((w[it] >> 16) & 255u), s, bias) * r;
+        o.w = fmaf((float)(w[it] >> 24), s, bias) * r;
+        reinterpret_cast<float4*>(xr)[c4] = o;
+      }
+    }
+    return;
+  }
   for (int64_t c = lane; c < D; c += 64) { const float v = fmaf((float)qr[c], s, bias); ss += v * v; }
   ss = wave_sum(ss);
   const float r = rsqrtf(fmaxf(ss, eps));
