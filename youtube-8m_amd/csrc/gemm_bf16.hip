@@ -17,7 +17,13 @@ namespace {
 
 constexpr int TM = 256, TN = 256, BKF = 16;          // BKF: floats per row and K-step (= 32 bf16)
 constexpr int TILE_F = BKF * 256;                     // floats of one operand tile (16 KiB)
-constexpr int NST = 4;                                // LDS-DMA ring depth
+#ifndef YT8M_BF16_NST
+#define YT8M_BF16_NST 4
+#endif
+#ifndef YT8M_BF16_GM
+#define YT8M_BF16_GM 4
+#endif
+constexpr int NST = YT8M_BF16_NST;                    // LDS-DMA ring depth (tools/build_variant.sh -DYT8M_BF16_NST=3 for A/B)
 constexpr int STAGE_F = 2 * TILE_F;                   // A tile + B tile
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -51,7 +57,7 @@ __device__ __forceinline__ int xcd_remap(int wg, int n) {
   return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
 }
 __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int lt, int& tm, int& tn) {
-  constexpr int GM = 4;                                // 4 x 8 tile blocks per XCD share of a 256-workgroup round
+  constexpr int GM = YT8M_BF16_GM;                     // 4 x 8 tile blocks per XCD share of a 256-workgroup round
   const int band_tiles = GM * tiles_n;
   const int band = lt / band_tiles;
   const int first = band * GM;
