@@ -37,6 +37,16 @@ def _worker(rank, world, port, overlap, q):
         g.finalize()
         red = parallel.GradReducer(bucket_bytes=4 * 2000, overlap=overlap)
         red.attach(g)
+        # 0. the random-op stream (dropout / noise keys) is rank-dependent and reproducible from (seed, rank, pass, call)
+        from yt8m_amd.variables import random_seed
+        assert g.rank == rank
+        g.begin_step()
+        k0, k1 = g.next_random_seed(), g.next_random_seed()
+        assert k0 == random_seed(100 + rank, rank, g._rng_step, 0) and k1 == random_seed(100 + rank, rank, g._rng_step, 1) and k0 != k1
+        keys = [None] * world
+        import torch.distributed as dist
+        dist.all_gather_object(keys, random_seed(7, rank, 3, 0))
+        assert len(set(keys)) == world                      # same graph seed, same pass, same call: ranks draw different masks
         # 1. broadcast: every rank now holds rank 0's parameters
         ref = Graph(device="cpu", seed=100)
         ref.begin_step()
