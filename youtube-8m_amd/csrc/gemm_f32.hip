@@ -543,12 +543,13 @@ __device__ __forceinline__ int xcd_remap(int wg, int n) {
   return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
 }
 
-// Logical tile id -> (tm, tn): bands of GM = 8 M-tiles, inside a band the M index runs fastest.  An XCD's share of a round
-// (96 consecutive logical tiles) is then an 8 x 12 block that needs 8 A panels + 12 B panels instead of the 64 + 1.5 of the
-// plain M-fastest order when tiles_m >> 8.  For tiles_m <= 8 (BASELINE cfg[1]) the order is unchanged.  Measured effect on
+// Logical tile id -> (tm, tn): bands of GM = 16 M-tiles, inside a band the M index runs fastest.  An XCD's share of a round
+// (96 consecutive logical tiles) is then a 16 x 6 block that needs 16 A panels + 6 B panels instead of the 64 + 1.5 of the
+// plain M-fastest order when tiles_m >> 16.  For tiles_m <= 16 (BASELINE cfg[1]: 8 and 9 tile rows) the order is the plain
+// one it was tuned with (bands of 8 cost cfg[1]'s dW launch 1 %).  Measured effect on
 // the tall problems (M = 8192 MoE heads, M = 38400 LSTM projections) is small (+0.6 %): they already ran at 0.76-0.79 of the
 // MFMA peak out of the 256 MB Infinity Cache; kept because it cuts the beyond-L2 operand traffic per tile ~10x.
-constexpr int RASTER_GM = 8;
+constexpr int RASTER_GM = 16;   // >= 9: BASELINE cfg[1] (8 / 9 tile rows) keeps the plain M-fastest order it was tuned with
 __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int lt, int& tm, int& tn) {
   const int band_tiles = RASTER_GM * tiles_n;
   const int band = lt / band_tiles;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GroupArgs G) {
 
 // sums the S split-K parts of each remainder tile (fixed order) and applies the normal epilogue
 __global__ __launch_bounds__(256) void splitk_fixup_kernel(const GroupArgs G) {
-  const int rt = blockIdx.x >> 2, quarter = blockIdx.x & 3;   // 4 workgroups per remainder tile (32 rows each)
+  const int rt = blockIdx.x >> 4, quarter = blockIdx.x & 15;  // 16 workgroups per remainder tile (8 rows each)
   const int tile = G.full_rounds * G.P + rt;
   const int q = find_problem(G, tile);
   const GemmArgs& g = G.p[q];
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const GroupArgs G) {
   tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const float* base = G.ws + (int64_t)rt * G.S * (BM * BN);
-  for (int e = quarter * (BM * BN / 4) + threadIdx.x * 4; e < (quarter + 1) * (BM * BN / 4); e += 256 * 4) {
+  for (int e = quarter * (BM * BN / 16) + threadIdx.x * 4; e < (quarter + 1) * (BM * BN / 16); e += 256 * 4) {
     float4 v = *reinterpret_cast<const float4*>(base + e);
     for (int s = 1; s < G.S; ++s) {
       const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * (BM * BN) + e);
@@ -767,7 +768,8 @@ static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8
       if (nk < min_nk) min_nk = nk;
     }
     if (S > min_nk / 8) S = min_nk / 8;     // keep >= 8 K-steps per part (pipeline fill + epilogue amortisation)
-    if (S > 32) S = 32;
+    if (S > 32 && G.rem > 16) S = 32;        // many parts per tile only for few-tile problems with a very long K (NetVLAD FC at
+    if (S > 96) S = 96;                       // B = 128: 8 tiles, K = 73728): their weight stream needs the whole chip
     if (S < 1) S = 1;
     if (S > 1 && (!workspace || workspace_bytes < (int64_t)G.rem * S * BM * BN * (int64_t)sizeof(float))) S = 1;
     G.S = S;
@@ -785,7 +787,7 @@ static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8
     launch_by_layout<GroupArgs>(transA, transB, gemm_grouped_kernel<true, false, false>, gemm_grouped_kernel<false, false, false>,
                                 gemm_grouped_kernel<true, true, false>, gemm_grouped_kernel<false, true, false>,
                                 dim3((unsigned)grid), s, G);
-  if (G.S > 1) hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)G.rem * 4), dim3(256), 0, s, G);
+  if (G.S > 1) hipLaunchKernelGGL(splitk_fixup_kernel, dim3((unsigned)G.rem * 16), dim3(256), 0, s, G);
   return launch_status("gemm_grouped_kernel");
 }
 
