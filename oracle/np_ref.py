@@ -210,6 +210,71 @@ def dynamic_rnn_lstm(x, num_frames, layers, forget_bias=1.0):
     return outputs, list(zip(cs, hs))
 
 
+def gru_step(x_t, h, Wg, bg, Wc, bc):
+    """tf.contrib.rnn.GRUCell (TF 1.0; not in /root/reference -- call sites W/all_frame_models/gru_pooling_model.py:34-38):
+    [r | u] = sigmoid([x_t || h].Wg + bg) (bias initialised to 1), c = tanh([x_t || r*h].Wc + bc), h' = u*h + (1-u)*c."""
+    ru = sigmoid(np.concatenate([x_t, h], axis=1) @ Wg + bg)
+    r, u = np.split(ru, 2, axis=1)
+    c = np.tanh(np.concatenate([x_t, r * h], axis=1) @ Wc + bc)
+    return u * h + (1.0 - u) * c
+
+
+def dynamic_rnn_gru(x, num_frames, layers):
+    """MultiRNNCell([GRUCell]) under tf.nn.dynamic_rnn with the copy-through rule of dynamic_rnn_lstm.
+    layers = [(Wg [in+H, 2H], bg [2H], Wc [in+H, H], bc [H])].  Returns outputs [B,F,H] (top layer), [h_l final]."""
+    B, F, _ = x.shape
+    H = layers[0][3].shape[0]
+    hs = [np.zeros((B, H), dtype=x.dtype) for _ in layers]
+    outputs = np.zeros((B, F, H), dtype=x.dtype)
+    nf = np.asarray(num_frames)
+    for t in range(F):
+        live = (t < nf)[:, None]
+        inp = x[:, t, :]
+        for l, (Wg, bg, Wc, bc) in enumerate(layers):
+            h_new = gru_step(inp, hs[l], Wg, bg, Wc, bc)
+            hs[l] = np.where(live, h_new, hs[l])
+            inp = h_new
+        outputs[:, t, :] = np.where(live, inp, 0.0)
+    return outputs, hs
+
+
+def layer_norm(x, gamma, beta, eps=1e-12):
+    """tf.contrib.layers.layer_norm on [B, H] (TF 1.0): moments over the last axis, variance_epsilon 1e-12."""
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    return (x - mean) / np.sqrt(var + eps) * gamma + beta
+
+
+def layer_norm_lstm_step(x_t, c, h, W, gammas, betas, forget_bias=1.0):
+    """tf.contrib.rnn.LayerNormBasicLSTMCell (TF 1.0; call site W/all_frame_models/layernorm_lstm_memory_model.py:37-50), no
+    dropout: [i|j|f|o] = [x_t || h].W (no bias), each normalised; c' = LN(c*sigmoid(f + fb) + sigmoid(i)*tanh(j)); h' =
+    tanh(c')*sigmoid(o).  gammas / betas: input, transform, forget, output, state."""
+    i, j, f, o = np.split(np.concatenate([x_t, h], axis=1) @ W, 4, axis=1)
+    i, j, f, o = [layer_norm(v, gammas[k], betas[k]) for k, v in enumerate((i, j, f, o))]
+    c_new = layer_norm(c * sigmoid(f + forget_bias) + sigmoid(i) * np.tanh(j), gammas[4], betas[4])
+    return c_new, np.tanh(c_new) * sigmoid(o)
+
+
+def dynamic_rnn_layer_norm_lstm(x, num_frames, layers, forget_bias=1.0):
+    """layers = [(W [in+H, 4H], [gamma]*5, [beta]*5)].  Returns outputs [B,F,H] (top layer), [(c_l, h_l) final]."""
+    B, F, _ = x.shape
+    H = layers[0][1][0].shape[0]
+    cs = [np.zeros((B, H), dtype=x.dtype) for _ in layers]
+    hs = [np.zeros((B, H), dtype=x.dtype) for _ in layers]
+    outputs = np.zeros((B, F, H), dtype=x.dtype)
+    nf = np.asarray(num_frames)
+    for t in range(F):
+        live = (t < nf)[:, None]
+        inp = x[:, t, :]
+        for l, (W, ga, be) in enumerate(layers):
+            c_new, h_new = layer_norm_lstm_step(inp, cs[l], hs[l], W, ga, be, forget_bias)
+            cs[l] = np.where(live, c_new, cs[l])
+            hs[l] = np.where(live, h_new, hs[l])
+            inp = h_new
+        outputs[:, t, :] = np.where(live, inp, 0.0)
+    return outputs, list(zip(cs, hs))
+
+
 def lstm_model_state(x, num_frames, layers):
     """W/all_frame_models/lstm_model.py:34-52: state_is_tuple=False => the head input is the
     whole state [c0 || h0 || c1 || h1] (4H for two layers)."""

@@ -138,6 +138,39 @@ def test_lstm_dynamic_rnn_semantics():
     assert np.allclose(c, 1 / (1 + np.exp(-1.0)))
 
 
+def test_gru_and_layer_norm_lstm_restatements_agree():
+    """The numpy (loop) and torch (autograd) restatements of tf.contrib.rnn.GRUCell / LayerNormBasicLSTMCell under dynamic_rnn
+    are written independently and must agree, incl. copy-through for ragged num_frames and the layer-norm epsilon placement."""
+    rs = np.random.RandomState(14)
+    B, F, D, H = 4, 6, 5, 3
+    x = rs.randn(B, F, D)
+    nf = np.array([6, 1, 4, 0])
+    gl, d_in = [], D
+    for _ in range(2):
+        gl.append((rs.randn(d_in + H, 2 * H) * 0.5, rs.randn(2 * H) * 0.1 + 1, rs.randn(d_in + H, H) * 0.5, rs.randn(H) * 0.1))
+        d_in = H
+    out, hs = np_ref.dynamic_rnn_gru(x, nf, gl)
+    tout, th = torch_ref.gru_stack(T(x), T(nf), [tuple(T(a) for a in lay) for lay in gl])
+    assert np.abs(out - tout.numpy()).max() < 1e-13 and all(np.abs(h - t.numpy()).max() < 1e-13 for h, t in zip(hs, th))
+    assert (out[1, 1:] == 0).all() and (out[3] == 0).all() and (hs[1][3] == 0).all()
+    # u -> 1 keeps the state, u -> 0 with r = 1 makes it a plain tanh RNN step
+    h0 = rs.randn(2, H)
+    keep = np_ref.gru_step(rs.randn(2, D), h0, np.zeros((D + H, 2 * H)), np.full(2 * H, 50.0), rs.randn(D + H, H), np.zeros(H))
+    assert np.abs(keep - h0).max() < 1e-12
+    ll, d_in = [], D
+    for _ in range(2):
+        ll.append((rs.randn(d_in + H, 4 * H) * 0.5, [rs.rand(H) + 0.5 for _ in range(5)], [rs.randn(H) * 0.2 for _ in range(5)]))
+        d_in = H
+    out, fin = np_ref.dynamic_rnn_layer_norm_lstm(x, nf, ll)
+    tout, tc, th = torch_ref.lnlstm_stack(T(x), T(nf), [(T(W), [T(g) for g in ga], [T(b) for b in be]) for W, ga, be in ll])
+    assert np.abs(out - tout.numpy()).max() < 1e-12
+    for l in range(2):
+        assert np.abs(fin[l][0] - tc[l].numpy()).max() < 1e-12 and np.abs(fin[l][1] - th[l].numpy()).max() < 1e-12
+    # the carried cell state is the NORMALISED one: unit gamma / zero beta => zero mean, unit variance over the units
+    c1, _ = np_ref.layer_norm_lstm_step(rs.randn(3, D), rs.randn(3, 8), rs.randn(3, 8), rs.randn(D + 8, 32), [np.ones(8)] * 5, [np.zeros(8)] * 5)
+    assert np.abs(c1.mean(1)).max() < 1e-12 and np.abs(c1.var(1) - 1).max() < 1e-9
+
+
 def test_attention_pooling_and_model():
     rs = np.random.RandomState(5)
     B, F, D, H, A, V, M = 3, 6, 4, 3, 2, 5, 2
