@@ -119,6 +119,33 @@ def test_hip_path_reproduces_fixture(dev):
         cs.append(cfin)
     assert np.abs(Hn(x_tm).transpose(1, 0, 2) - expected("lnlstm", "outputs")).max() < 2e-5
     assert np.abs(Hn(cs[0]) - expected("lnlstm", "c0")).max() < 2e-5 and np.abs(Hn(cs[1]) - expected("lnlstm", "c1")).max() < 2e-5
+    c = model_cases.case_inputs("netvlad")                        # generic float path: FC -> masked softmax -> pooling -> finish
+    Wc, bc, cen = _vars(dev, [c["Wc"], c["bc"], c["centres"]])
+    xn = D(c["x"])
+    nfv = torch.from_numpy(c["nf"].astype(np.int32)).to(dev)
+    a = seq_ops.masked_softmax_rows(ops.linear(xn, Wc, bc), nfv)
+    assert np.abs(Hn(a) - expected("netvlad", "assignment")).max() < 1e-5
+    vlad = seq_ops.vlad_finish(seq_ops.pool_tn(a, xn), a, cen)
+    v = ops.l2_normalize(vlad.reshape(xn.shape[0], -1))
+    assert np.abs(Hn(v) - expected("netvlad", "vlad")).max() < 1e-5
+    c = model_cases.case_inputs("chain")                          # DeepCombineChainModel through the plugin surface
+    import yt8m_amd.video_level_models as vlm
+    from yt8m_amd.flags import FLAGS
+    from yt8m_amd.variables import reset_default_graph
+    FLAGS.reset()
+    FLAGS.deep_chain_layers, FLAGS.deep_chain_relu_cells, FLAGS.moe_num_mixtures = c["L"], 5, c["M"]
+    g = reset_default_graph(device=dev)
+    g.begin_step()
+    model = vlm.DeepCombineChainModel()
+    model.create_model(D(c["x"]), vocab_size=11)
+    g.finalize()
+    for k, v_ in c["P"].items():
+        g.vars[k].data.copy_(D(v_).view(g.vars[k].data.shape))
+    g.begin_step()
+    res = model.create_model(D(c["x"]), vocab_size=11)
+    FLAGS.reset()
+    assert np.abs(Hn(res["predictions"]) - expected("chain", "predictions")).max() < 1e-5
+    assert np.abs(Hn(res["support_predictions"]) - expected("chain", "support_predictions")).max() < 1e-5
     c = model_cases.case_inputs("xent")
     loss, _ = ops.xent_fwd(D(c["p"]), D(c["y"]), None, want_dp=False, upstream=1.0)
     assert abs(float(loss) - float(expected("xent", "loss"))) < 1e-4 * abs(float(expected("xent", "loss")))
