@@ -1,25 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- training videos/sec of the hot path on N MI355X (BASELINE.json metric).
 
-Workload (config.workload): BASELINE.json configs[1] -- MoeModel (2 mixtures) on video-level features
-(D=1152 -> V=4716 labels), batch 1024 PER GPU, fp32, full training step:
-    L2-normalise -> MoE head (2 GEMMs + mixing) -> CrossEntropyLoss -> backward (2 dW GEMMs, bias sums)
-    -> [RCCL gradient all-reduce for N>1] -> + l2*w -> per-tensor clip -> TF-Adam.
-Inputs are synthetic and already resident in HBM (a pool of distinct batches cycled through).
-One "step" = one such pass over one batch.  N>1: one process per GPU (torchrun contract), weak scaling.
+Headline workload (config.workload): BASELINE.json configs[3] -- the frame-level configuration the metric is quoted on
+("training videos/sec on synthetic [B,300,1152] tensors"): LstmModel, 2 x BasicLSTMCell(1024) under dynamic_rnn over
+F = 300 frames of raw uint8 [B,300,1152] features, MoE head (2 mixtures, 4716 labels) on [c0|h0|c1|h1], batch 128 PER
+GPU, fp32, full training step:
+    dequantise + l2-normalise -> hoisted input projections + persistent recurrence (2 layers) -> MoE head ->
+    CrossEntropyLoss -> backward (recurrence, dx, dW) -> [RCCL gradient all-reduce for N>1] -> + l2*w -> per-tensor
+    clip -> TF-Adam.
+Inputs are synthetic and already resident in HBM (a pool of distinct batches cycled through).  One "step" = one such
+pass over one batch.  N>1: one process per GPU (torchrun contract; `python bench.py --gpus N` without a torchrun
+environment re-launches itself under torch.distributed.run), weak scaling, the RCCL world size is printed.
 
-Extra legs (rank 0):
-  roofline     : hipEvent timing of the dominant kernel family (gemm_f32) inside the library, in a separate
-                 pass after the timed region; algorithmic FLOPs per launch / average launch duration vs the fp32
-                 matrix peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
-  cpu_baseline : the torch-CPU fp32 restatement of the same step (oracle/torch_ref.py, kind "port") on the host
-                 cores, bounded sample; N=1 only.
-  gap_at_20    : BASELINE.json's second metric -- GAP@20 on a held-out synthetic teacher shard after 768 further training
-                 steps of a fresh model (outside the timed region, ~1.5 s; N=1 only; --no-gap skips it).
+Extra lines in the same JSON ("extra", rank 0, N=1 only; each with its own per-family hipEvent times and roofline):
+  configs[1]  MoeModel (2 mixtures) on video-level [1024,1152] features, fp32 (>= 200 timed steps: the step is ~1 ms)
+  configs[2]  NetVLADModel (64 clusters) on raw uint8 [B,300,1152] frames + MoE head, fp32
+  configs[3]  in bfloat16 operand mode (a labelled VARIANT, never the headline)
+Other legs (rank 0):
+  roofline     : hipEvent timing of every kernel family inside the library (separate pass after the timed region);
+                 algorithmic FLOPs / family time vs the fp32 matrix peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline : the torch-CPU fp32 restatement of the same step (oracle/torch_ref.py, kind "port") on the host cores,
+                 bounded sample (reduced batch); N=1 only.
+  gap_at_20    : BASELINE.json's second metric -- GAP@20 on a held-out synthetic teacher shard after 768 training steps
+                 of a fresh MoeModel (outside the timed region, ~1.5 s; N=1 only; --no-gap skips it).
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,42 +39,254 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__  # noqa: E402
 
-D_IN, VOCAB, MIX = 1152, 4716, 2
+D_IN, VOCAB, MIX, FRAMES = 1152, 4716, 2, 300
+LSTM_H, LSTM_L = 1024, 2
 PEAK_F32_MATRIX_TFLOPS = 157.3
-PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by the --dtype bf16 variant line
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by bf16 VARIANT lines
+PEAK_HBM_GBS = 8000.0
+FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad"]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches resident in HBM")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["lstm", "moe", "netvlad"], default="lstm",
+                    help="headline workload; default = BASELINE configs[3] (the frame-level config the metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the config's: lstm 128, moe 1024, netvlad 1024)")
+    ap.add_argument("--pool", type=int, default=0, help="distinct synthetic batches resident in HBM (0 = per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[2] / bf16-variant extra lines")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 = BASELINE configs[1] (the headline).  bf16 = same step with bf16 MFMA operands for the head "
-                         "GEMMs (fp32 accumulate / master weights / Adam): a separate, labelled line, never the headline.")
+                    help="f32 = the reference's arithmetic (the headline).  bf16 = bf16 MFMA operands, fp32 accumulate / "
+                         "master weights / Adam: a separately labelled line, never the headline.")
     ap.add_argument("--no-gap", action="store_true", help="skip the GAP@20 leg (BASELINE.json's second metric)")
     ap.add_argument("--force-reducer", action="store_true", help="exercise the RCCL reducer even at world size 1 (test aid)")
     return ap.parse_args()
 
 
-def make_pool(n, B, dev, seed):
-    """Video-level synthetic inputs: x = mean over frames of dequantised uint8 ~ N(0.008, small) is
-    too degenerate to train on, so use a wide spread in the dequantised range [-2, 2]; labels ~ Bernoulli(3.4/4716)."""
+# ---- self-launch: `python bench.py --gpus N` must run N ranks even without torchrun -------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_relaunch(a):
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ---- workloads ---------------------------------------------------------------------------------------------------------
+def make_video_pool(n, B, dev, seed):
+    """Video-level synthetic inputs: a wide spread in the dequantised range [-2, 2]; labels ~ Bernoulli(3.4/V)."""
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    xs, ys = [], []
+    out = []
     for _ in range(n):
-        xs.append((torch.rand((B, D_IN), device=dev, generator=gen) * 4.0 - 2.0))
-        ys.append((torch.rand((B, VOCAB), device=dev, generator=gen) < (3.4 / VOCAB)))
-    return xs, ys
+        x = torch.rand((B, D_IN), device=dev, generator=gen) * 4.0 - 2.0
+        y = torch.rand((B, VOCAB), device=dev, generator=gen) < (3.4 / VOCAB)
+        out.append((x, y, None))
+    return out
 
 
-def gap_leg(dev, B, train_steps=768, heldout=16384, signal=3.0):
+def make_frame_pool(n, B, dev, seed):
+    """Frame-level synthetic inputs: raw uint8 [B,300,1152] exactly as the reader hands them over (W/readers.py:159-187),
+    every video 300 frames long (no work is skipped by the num_frames masks)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    out = []
+    for _ in range(n):
+        x = torch.randint(0, 256, (B, FRAMES, D_IN), device=dev, generator=gen, dtype=torch.uint8)
+        y = torch.rand((B, VOCAB), device=dev, generator=gen) < (3.4 / VOCAB)
+        nf = torch.full((B,), FRAMES, device=dev, dtype=torch.int32)
+        out.append((x, y, nf))
+    return out
+
+
+def lstm_flops(B):
+    """Algorithmic FLOPs of one configs[3] training step (per family)."""
+    H, L, F, D = LSTM_H, LSTM_L, FRAMES, D_IN
+    proj_fwd = 2.0 * F * B * (D * 4 * H + (L - 1) * H * 4 * H)
+    dw = 2.0 * F * B * ((D + H) * 4 * H + (L - 1) * (H + H) * 4 * H)
+    dx = 2.0 * F * B * (L - 1) * 4 * H * H
+    S = 2 * L * H
+    head = 3 * 2.0 * B * S * VOCAB * (2 * MIX + 1)
+    rec = 2 * L * 2.0 * F * B * H * 4 * H             # forward + backward recurrent products
+    return {"gemm": proj_fwd + dw + dx + head, "lstm_recurrence": rec}
+
+
+def moe_flops(B):
+    return {"gemm": 2.0 * 2.0 * B * D_IN * VOCAB * (2 * MIX + 1)}
+
+
+def netvlad_flops(B, K=64, hidden=1024):
+    F, D = FRAMES, D_IN
+    pool = 2 * 2 * 2.0 * B * F * D * K                 # assignment + aggregation, forward and backward
+    fc = 3 * 2.0 * B * (K * D) * hidden                # hidden FC fwd, dW, dx
+    head = 3 * 2.0 * B * hidden * VOCAB * (2 * MIX + 1)
+    return {"netvlad": pool, "gemm": fc + head}
+
+
+WORKLOADS = {
+    "lstm": dict(name="BASELINE configs[3]: LstmModel (2 x BasicLSTMCell(1024), dynamic_rnn over F=300) on raw uint8 "
+                      "[B,300,1152] frames + MoeModel head (2 mixtures, V=4716)",
+                 batch=128, pool=4, frame=True, flops=lstm_flops),
+    "moe": dict(name="BASELINE configs[1]: MoeModel (2 mixtures) on video-level features, D=1152, V=4716",
+                batch=1024, pool=8, frame=False, flops=moe_flops),
+    "netvlad": dict(name="BASELINE configs[2]: NetVLADModel (64 clusters, hidden 1024) on raw uint8 [B,300,1152] frames + "
+                         "MoeModel head (2 mixtures, V=4716)",
+                    batch=1024, pool=2, frame=True, flops=netvlad_flops),
+}
+
+
+def build(workload, B, world, rank, dev, reducer, bf16):
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.train as train
+    import yt8m_amd.video_level_models as vlm
+    from yt8m_amd.flags import FLAGS
+    from yt8m_amd.variables import reset_default_graph
+    FLAGS.reset()
+    if bf16:
+        FLAGS.compute_dtype = "bfloat16"
+    if os.environ.get("YT8M_FUSED_HEAD_LOSS") == "0":     # A/B aid
+        FLAGS.fused_head_loss = False
+    for kv in os.environ.get("YT8M_SET", "").split(","):  # e.g. YT8M_SET=lstm_pipeline_chunks=1
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            cur = getattr(FLAGS, k)
+            setattr(FLAGS, k, (v == "1") if isinstance(cur, bool) else type(cur)(v))
+    model = {"lstm": flm.LstmModel, "moe": vlm.MoeModel, "netvlad": flm.NetVLADModel}[workload]()
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(model, batch_size=B * world, graph=g, reducer=reducer)
+    w = make_pool(workload, B, dev, rank)
+    return g, tg, w
+
+
+def make_pool(workload, B, dev, rank, n=None):
+    cfg = WORKLOADS[workload]
+    n = n or cfg["pool"]
+    return (make_frame_pool if cfg["frame"] else make_video_pool)(n, B, dev, seed=1234 + rank)
+
+
+def family_times(lib, steps):
+    n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+    fam = {}
+    for fid, name in enumerate(FAMILIES):
+        lib.yt8m_prof_get(fid, ctypes.byref(n), ctypes.byref(ms))
+        if n.value:
+            fam[name] = {"launches_per_step": n.value / float(steps), "ms_per_step": ms.value / steps,
+                         "avg_launch_ms": ms.value / n.value}
+    return fam
+
+
+def roofline_from(fam, flops, bf16, extra_note=None):
+    """Dominant family = the one with the largest hipEvent time among the MFMA families that have an algorithmic FLOP
+    count.  achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch)."""
+    peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
+    rows = {}
+    for name, f in flops.items():
+        if name in fam and fam[name]["ms_per_step"] > 0:
+            ach = f / (fam[name]["ms_per_step"] * 1e-3) / 1e12
+            rows[name] = {"achieved": ach, "frac": ach / peak, "ms_per_step": fam[name]["ms_per_step"],
+                          "launches_per_step": fam[name]["launches_per_step"], "avg_launch_ms": fam[name]["avg_launch_ms"],
+                          "algorithmic_flops_per_step": f,
+                          "algorithmic_flops_per_launch": f / max(fam[name]["launches_per_step"], 1e-9)}
+    if not rows:
+        return None
+    dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
+    r = rows[dom]
+    roof = {"bound": "mfma", "kernel": dom + (" (bf16 operands)" if bf16 else " (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact fp32)"),
+            "achieved": r["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": r["frac"], "traffic": None,
+            "launches_per_step": r["launches_per_step"], "avg_launch_ms": r["avg_launch_ms"],
+            "algorithmic_flops_per_launch": r["algorithmic_flops_per_launch"],
+            "families": rows,
+            "other_families": {k: v for k, v in fam.items() if k not in rows}}
+    if extra_note:
+        roof["note"] = extra_note
+    return roof
+
+
+def timed_run(tg, pool, steps, warmup, world, dev, dist):
+    def run(k, base):
+        for i in range(k):
+            x, y, nf = pool[(base + i) % len(pool)]
+            tg.step(x, y, nf)
+
+    run(max(warmup, 1), 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps, warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el, run
+
+
+def profile_pass(lib, run, steps, rank):
+    if rank == 0:
+        lib.yt8m_prof_reset()
+        lib.yt8m_prof_enable(1)
+    run(steps, 0)                      # every rank runs the same extra steps (the all-reduce is collective)
+    torch.cuda.synchronize()
+    fam = None
+    if rank == 0:
+        lib.yt8m_prof_enable(0)
+        fam = family_times(lib, steps)
+    return fam
+
+
+def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None):
+    """One more configuration, rank 0 / N=1 only: its own timed region (>= 200 steps when a step is < 5 ms) + family times."""
+    cfg = WORKLOADS[workload]
+    B = cfg["batch"]
+    g, tg, pool = build(workload, B, 1, 0, dev, None, bf16)
+    x, y, nf = pool[0]
+    for _ in range(2):
+        tg.step(x, y, nf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tg.step(x, y, nf)
+    torch.cuda.synchronize()
+    probe = time.perf_counter() - t0
+    steps = steps or (200 if probe < 5e-3 else max(10, min(50, int(1.0 / probe))))
+    el, run = timed_run(tg, pool, steps, warmup or 3, 1, dev, None)
+    fam = profile_pass(lib, run, min(steps, 10), 0)
+    roof = roofline_from(fam, cfg["flops"](B), bf16)
+    if workload == "netvlad" and fam and "netvlad" in fam:
+        # the pooling kernels are HBM-bound on the uint8 frames (DESIGN.md section 4): report the frame-byte rate too
+        passes = 3.0                                                  # forward rows+cols share one pass when fused; see DESIGN
+        qbytes = float(B) * FRAMES * D_IN
+        roof["hbm"] = {"frame_bytes_per_pass": qbytes, "family_ms_per_step": fam["netvlad"]["ms_per_step"],
+                       "frame_GBps_if_%d_passes" % int(passes): passes * qbytes / (fam["netvlad"]["ms_per_step"] * 1e-3) / 1e9,
+                       "peak_GBps": PEAK_HBM_GBS}
+    del tg, g, pool
+    torch.cuda.empty_cache()
+    return {"workload": cfg["name"] + (" -- bf16-operand VARIANT" if bf16 else ", fp32"), "dtype": "bf16" if bf16 else "f32",
+            "per_gpu_batch": B, "steps": steps, "ms_per_step": el / steps * 1e3, "value": steps * B / el, "unit": "videos/s",
+            "roofline": roof}
+
+
+def gap_leg(dev, B=1024, train_steps=768, heldout=16384, signal=3.0):
     """BASELINE.json's second metric, outside the timed region: a fresh MoeModel (M = 2, D = 1152, V = 4716) is
     trained for `train_steps` steps of B videos on a synthetic teacher shard (fixed W_t ~ N(0, 1/sqrt(D)), logit = x.W_t * 3
     - 3 + 0.5 N(0,1), threshold at ~3.4 positives per video) and evaluated with GAP@20 on a disjoint held-out shard; the
@@ -73,7 +295,9 @@ def gap_leg(dev, B, train_steps=768, heldout=16384, signal=3.0):
     import yt8m_amd.eval_util as eval_util
     import yt8m_amd.train as train
     import yt8m_amd.video_level_models as vlm
+    from yt8m_amd.flags import FLAGS
     from yt8m_amd.variables import reset_default_graph
+    FLAGS.reset()
     gen = torch.Generator(device=dev).manual_seed(4242)
     Wt = torch.randn((D_IN, VOCAB), device=dev, generator=gen) / D_IN ** 0.5
 
@@ -98,7 +322,7 @@ def gap_leg(dev, B, train_steps=768, heldout=16384, signal=3.0):
         return em.get()
 
     tg.forward(x0, l0 > tau)
-    g.finalize()
+    tg.ensure_finalized() if hasattr(tg, "ensure_finalized") else g.finalize()
     before = evaluate(min(heldout, 4 * B))["gap"]
     pos = 0.0
     for _ in range(train_steps):
@@ -107,151 +331,134 @@ def gap_leg(dev, B, train_steps=768, heldout=16384, signal=3.0):
         pos += float(y.float().sum(1).mean())
         tg.step(x, y)
     m = evaluate(heldout)
-    return {"value": m["gap"], "hit_at_one": m["avg_hit_at_one"], "untrained": before, "train_steps": train_steps, "batch": B,
-            "heldout_videos": (heldout // B) * B, "positives_per_video": pos / train_steps, "data": "synthetic teacher shard"}
+    return {"value": m["gap"], "hit_at_one": m["avg_hit_at_one"], "perr": m.get("avg_perr"), "untrained": before,
+            "train_steps": train_steps, "batch": B, "heldout_videos": (heldout // B) * B,
+            "positives_per_video": pos / train_steps, "data": "synthetic teacher shard (MoeModel, configs[1])"}
 
 
-def cpu_baseline(B, seconds):
-    """Times the torch-CPU fp32 restatement of the same step on the host cores (a reported baseline, not a target).
-    Thread count: the best of {all usable cores, 64, 32, 16} on a cheap B=128 probe (oversubscribed MKL is far slower)."""
-    from oracle import torch_ref
+def _pick_threads(probe_fn):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    gen = torch.Generator().manual_seed(1)
-    x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
-    y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
-    # pick the thread count on a cheap B=128 probe (MKL/OpenMP with every hardware thread of a 256-thread host is an
-    # order of magnitude SLOWER than with 32-64 on this step); candidates: all, 64, 32, 16
-    probe = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=128, dtype=torch.float32, seed=0)
     best, best_t = None, None
     for cores in sorted({c for c in (usable, 64, 32, 16) if 1 <= c <= usable}, reverse=True):
         torch.set_num_threads(cores)
-        probe.step(x[:128], y[:128])                 # warm-up at this thread count
+        probe_fn()
         t0 = time.perf_counter()
-        probe.step(x[:128], y[:128])
+        probe_fn()
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best, best_t = cores, dt
-    st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
     torch.set_num_threads(best)
-    st.step(x, y)                                    # warm-up
+    return best, usable
+
+
+def cpu_baseline(workload, seconds):
+    """Times the torch-CPU fp32 restatement of the same training step on the host cores (a reported baseline, not a
+    target; TF1 itself is not runnable here).  Bounded sample: reduced batch for the frame-level step.  Thread count: the
+    best of {all usable cores, 64, 32, 16} on a cheap probe (oversubscribed MKL is far slower)."""
+    from oracle import torch_ref
+    gen = torch.Generator().manual_seed(1)
+    if workload == "moe":
+        B = 1024
+        x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
+        y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
+        probe = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=128, dtype=torch.float32, seed=0)
+        cores, usable = _pick_threads(lambda: probe.step(x[:128], y[:128]))
+        st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+        stepf = lambda: st.step(x, y)
+        what = "fp32 MoeModel training step"
+    elif workload == "lstm":
+        B = 8                                                       # bounded sample: 8 videos x 300 frames per CPU step
+        q = torch.randint(0, 256, (B, FRAMES, D_IN), generator=gen, dtype=torch.uint8)
+        y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
+        nf = torch.full((B,), FRAMES, dtype=torch.int32)
+        st = torch_ref.LstmTrainStepCPU(D=D_IN, H=LSTM_H, L=LSTM_L, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(usable, 32)                                     # the per-frame products are small: more threads lose
+        torch.set_num_threads(cores)
+        stepf = lambda: st.step(q, nf, y)
+        what = "fp32 LstmModel (2x1024, F=300) + MoE head training step"
+    else:
+        return None
+    stepf()                                          # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        st.step(x, y)
+        stepf()
         n += 1
         el = time.perf_counter() - t0
         if el >= seconds or n >= 200:
             break
-    return {"value": n * B / el, "unit": "videos/s", "cores": best, "kind": "port",
-            "sample": "%d steps of the same B=%d fp32 MoeModel training step on torch-CPU (oracle/torch_ref.py, TF1 itself "
-                      "is not runnable here), %.1f s, %d usable cores" % (n, B, el, usable)}
+    return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same %s at B=%d on torch-CPU (oracle/torch_ref.py; TF1 itself is not runnable "
+                      "here), %.1f s, %d usable cores" % (n, what, B, el, usable)}
 
 
 def main():
     a = parse()
+    maybe_relaunch(a)
     __graft_entry__.load_package()
     import yt8m_amd._lib as L
     import yt8m_amd.parallel as parallel
-    import yt8m_amd.train as train
-    import yt8m_amd.video_level_models as vlm
-    from yt8m_amd.variables import reset_default_graph
     import torch.distributed as dist
 
     rank, world, local = parallel.init_from_env()
-    if world != a.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    assert world == a.gpus, "--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the measured path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    L.lib()
+    lib = L.lib()
+    rccl_ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+    assert rccl_ranks == a.gpus, "RCCL world size %d != --gpus %d" % (rccl_ranks, a.gpus)
 
-    B = a.batch
-    if os.environ.get("YT8M_FUSED_HEAD_LOSS") == "0":     # A/B aid
-        from yt8m_amd.flags import FLAGS
-        FLAGS.fused_head_loss = False
+    cfg = WORKLOADS[a.workload]
+    B = a.batch or cfg["batch"]
     bf16 = a.dtype == "bf16"
-    if bf16:
-        from yt8m_amd.flags import FLAGS
-        FLAGS.compute_dtype = "bfloat16"
-    g = reset_default_graph(device=dev, seed=0)
     reducer = parallel.GradReducer() if (world > 1 or a.force_reducer) else None
-    tg = train.TrainGraph(vlm.MoeModel(), batch_size=B * world, graph=g, reducer=reducer)
-    xs, ys = make_pool(a.pool, B, dev, seed=1234 + rank)
-
-    def run(k, base):
-        for i in range(k):
-            j = (base + i) % a.pool
-            tg.step(xs[j], ys[j])
-
-    run(max(a.warmup, 1), 0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(a.steps, a.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    g, tg, pool = build(a.workload, B, world, rank, dev, reducer, bf16)
+    if a.pool:
+        pool = make_pool(a.workload, B, dev, rank, a.pool)
+    el, run = timed_run(tg, pool, a.steps, a.warmup, world, dev, dist)
+    params = sum(v.numel() for v in g.trainable_variables())
 
     roof = None
-    if rank == 0 and not a.no_roofline:
-        lib = L.lib()
-        import ctypes
-        lib.yt8m_prof_reset()
-        lib.yt8m_prof_enable(1)
     if not a.no_roofline:
-        # every rank runs the same extra steps (the all-reduce is collective); only rank 0 records events
-        run(min(a.steps, 20), 0)
-        torch.cuda.synchronize()
-    if rank == 0 and not a.no_roofline:
-        lib.yt8m_prof_enable(0)
-        n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
-        lib.yt8m_prof_get(0, ctypes.byref(n), ctypes.byref(ms))
-        steps_p = min(a.steps, 20)
-        # algorithmic FLOPs of the GEMM launches of one step: fwd x.Wg, x.We; bwd x^T.dZg, x^T.dZe
-        flops_step = 2.0 * 2.0 * B * D_IN * VOCAB * (2 * MIX + 1)
-        launches_step = n.value / float(steps_p) if steps_p else 0
-        avg_ms = ms.value / max(n.value, 1)
-        flops_launch = flops_step / max(launches_step, 1)
-        ach = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
-        roof = {"bound": "mfma", "kernel": "gemm_grouped_kernel (%s)" % ("v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x2_f32"),
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None, "launches_per_step": launches_step, "avg_launch_ms": avg_ms,
-                "algorithmic_flops_per_launch": flops_launch}
-        fam = {}
-        for fid, name in [(2, "elementwise"), (3, "optimizer")]:
-            lib.yt8m_prof_get(fid, ctypes.byref(n), ctypes.byref(ms))
-            fam[name] = {"launches_per_step": n.value / float(steps_p), "ms_per_step": ms.value / steps_p}
-        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_traffic.md:
-        # separate FETCH_SIZE / WRITE_SIZE passes, calibrated on the copy probe); rocprofv3 cannot run inside bench.py.
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_grouped_kernel")]
-            if ks and B == 1024 and not bf16:
-                roof["traffic"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / len(ks)
-                roof["traffic_unit"] = "bytes/launch (L2-miss side, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.md)"
-                roof["algorithmic_bytes_per_launch"] = 4.0 * (B * D_IN + D_IN * VOCAB * (2 * MIX + 1) + B * VOCAB * (2 * MIX + 1))
-        except Exception:
-            pass
-        roof["other_families"] = fam
-        roof["gemm_ms_per_step"] = avg_ms * launches_step
+        fam = profile_pass(lib, run, min(a.steps, 5 if a.workload != "moe" else 20), rank)
+        if rank == 0:
+            roof = roofline_from(fam, cfg["flops"](B), bf16)
+            if a.workload == "moe" and B == 1024 and not bf16 and roof:
+                try:                   # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_traffic.md)
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+                    ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_grouped_kernel")]
+                    roof["traffic"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / len(ks)
+                    roof["traffic_unit"] = "bytes/launch (L2-miss side, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.md)"
+                    roof["algorithmic_bytes_per_launch"] = 4.0 * (B * D_IN + D_IN * VOCAB * (2 * MIX + 1) + B * VOCAB * (2 * MIX + 1))
+                except Exception:
+                    pass
+            elif a.workload == "lstm" and roof:
+                try:                   # PMC passes of the headline step, committed with the round's profiles
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_lstm.json")))
+                    roof["traffic"] = pm.get("dominant_bytes_per_launch")
+                    roof["traffic_unit"] = pm.get("unit")
+                except Exception:
+                    pass
+    del tg, g, pool
+    torch.cuda.empty_cache()
+
+    extra = []
+    if rank == 0 and world == 1 and not a.no_extra and a.workload == "lstm" and not bf16:
+        for wl, b16 in (("moe", False), ("netvlad", False), ("lstm", True)):
+            try:
+                extra.append(extra_line(wl, dev, lib, bf16=b16))
+            except Exception as e:                                    # an extra line must never break the headline
+                extra.append({"workload": WORKLOADS[wl]["name"], "error": repr(e)})
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(B, a.cpu_seconds)
+        cpu = cpu_baseline(a.workload, a.cpu_seconds)
 
     gap = None
     if rank == 0 and world == 1 and not a.no_gap and not bf16:
         try:
-            gap = gap_leg(dev, B)
+            gap = gap_leg(dev)
         except Exception as e:                                    # never let the secondary metric break the bench line
             gap = {"value": None, "error": repr(e)}
 
@@ -259,15 +466,15 @@ def main():
         dist.barrier()
     if rank == 0:
         out = {"metric": "training videos/sec", "value": a.steps * B * world / el, "unit": "videos/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: MoeModel (2 mixtures) on video-level features, D=1152, V=4716, "
-                                      "%s training step (fwd+bwd+clip+Adam%s)"
-                                      % ("bf16-operand VARIANT (not the fp32 headline) of the" if bf16 else "fp32",
+               "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "%s, %s training step (fwd+bwd+clip+Adam%s)"
+                                      % (cfg["name"], "bf16-operand VARIANT (not the fp32 headline) of the" if bf16 else "fp32",
                                          "+RCCL all-reduce" if world > 1 else ""),
-                          "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                          "params": 27173592},
-               "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap}
+                          "per_gpu_batch": B, "global_batch": B * world, "frames": FRAMES if cfg["frame"] else None,
+                          "parallelism": "dp%d" % world, "params": params},
+               "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -390,6 +390,11 @@ int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float
 int yt8m_topk_rows(const float* p, int64_t B, int64_t V, int k, float* vals, int32_t* idx,
                    yt8m_stream_t stream);
 
+/* ---- per-row precision at equal recall rate (W/eval_util.py:74-99 calculate_precision_at_equal_recall_rate) ---
+ * p [B,V] f32, labels [B,V] uint8/bool -> perr [B]: among the top-(#labels) classes of the row (stable descending
+ * order), the fraction that are labels with a score > 0; 0 for a row without labels.  V <= 19200. */
+int yt8m_perr_rows(const float* p, const uint8_t* labels, int64_t B, int64_t V, float* perr, yt8m_stream_t stream);
+
 /* ---- native input reader (HOST buffers) ----------------------------------------------
  * TFRecord framing (u64 length | masked crc32c | payload | masked crc32c) + tf.train.SequenceExample / tf.train.Example
  * wire-format decode for YT8MFrameFeatureReader (W/readers.py:189-259) and YT8MAggregatedFeatureReader (:94-125).

@@ -377,3 +377,37 @@ class MoeTrainStepCPU:
         loss.backward()
         self.opt.step()
         return loss.detach(), p.detach()
+
+
+class LstmTrainStepCPU:
+    """Whole training step of BASELINE configs[3] on the host (bench.py cpu_baseline leg, kind "port"): dequantise +
+    l2-normalise (W/readers.py:178-187, W/train.py:343-344) -> LstmModel (W/all_frame_models/lstm_model.py:15-57: 2 x
+    BasicLSTMCell under dynamic_rnn, head on [c0||h0||c1||h1]) -> MoeModel head -> CrossEntropyLoss -> reg -> clip -> Adam."""
+
+    def __init__(self, D=1152, H=1024, L=2, V=4716, M=2, batch_size=128, dtype=torch.float32, seed=0, base_lr=0.01):
+        gen = torch.Generator().manual_seed(seed)
+        self.M, self.L = M, L
+        P = {}
+        d_in = D
+        for l in range(L):
+            P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l] = xavier_uniform_(torch.empty(d_in + H, 4 * H, dtype=dtype), gen)
+            P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l] = torch.zeros(4 * H, dtype=dtype)
+            d_in = H
+        S = 2 * L * H
+        P["gates/weights"] = xavier_uniform_(torch.empty(S, V * (M + 1), dtype=dtype), gen)
+        P["experts/weights"] = xavier_uniform_(torch.empty(S, V * M, dtype=dtype), gen)
+        P["experts/biases"] = torch.zeros(V * M, dtype=dtype)
+        self.P = {k: v.requires_grad_(True) for k, v in P.items()}
+        self.opt = TFAdam(self.P, ["gates/weights", "experts/weights"], base_lr=base_lr, batch_size=batch_size)
+        self.dtype = dtype
+
+    def step(self, q_frames, num_frames, labels):
+        x = l2_normalize(dequantize(q_frames, self.dtype), 2)
+        layers = [(self.P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l],
+                   self.P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l]) for l in range(self.L)]
+        state = lstm_model_state(x, num_frames, layers)
+        p = moe_fast(state, self.P["gates/weights"], self.P["experts/weights"], self.P["experts/biases"], self.M)
+        loss = cross_entropy(p, labels)
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), p.detach()

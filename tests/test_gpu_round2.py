@@ -1,0 +1,153 @@
+"""-m gpu: round-2 additions -- device PERR / mAP in the evaluation path, checkpoint resume equivalence on the device,
+model-provided regularization_loss / update_ops, the reference-signature clip_gradient_norms."""
+import numpy as np
+import pytest
+import torch
+
+import yt8m_amd.checkpoint as checkpoint
+import yt8m_amd.eval_util as eval_util
+import yt8m_amd.frame_level_models as flm
+import yt8m_amd.ops as ops
+import yt8m_amd.train as train
+import yt8m_amd.utils as utils
+import yt8m_amd.video_level_models as vlm
+from yt8m_amd.variables import reset_default_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def test_perr_rows_matches_host(dev):
+    """yt8m_perr_rows vs calculate_precision_at_equal_recall_rate (W/eval_util.py:74-99), incl. rows without labels, rows
+    whose top classes have score <= 0, and the full V = 4716."""
+    rs = np.random.RandomState(3)
+    for B, V, rate in [(7, 30, 0.2), (64, 4716, 3.4 / 4716), (5, 257, 0.5)]:
+        p = rs.rand(B, V).astype(np.float32)
+        p[1] -= 0.7                                   # mostly non-positive scores: the (score > 0) filter matters
+        y = rs.rand(B, V) < rate
+        y[0] = False                                  # a video without labels
+        got = ops.perr_rows(torch.from_numpy(p).to(dev), torch.from_numpy(y).to(dev)).cpu().numpy()
+        for r in range(B):
+            exp = eval_util.calculate_precision_at_equal_recall_rate(p[r:r + 1], y[r:r + 1])
+            assert abs(float(got[r]) - exp) < 1e-6, (B, V, r, got[r], exp)
+
+
+def test_device_metrics_equal_host_on_all_keys(dev):
+    """EvaluationMetrics.accumulate_device == accumulate on avg_hit_at_one, avg_perr, avg_loss, gap and aps."""
+    rs = np.random.RandomState(11)
+    B, V, k = 96, 300, 20
+    host, devm = eval_util.EvaluationMetrics(V, k), eval_util.EvaluationMetrics(V, k)
+    for it in range(3):
+        p = rs.rand(B, V).astype(np.float32)
+        y = rs.rand(B, V) < 0.02
+        loss = float(rs.rand())
+        host.accumulate(p, y, np.array([loss]))
+        out = devm.accumulate_device(torch.from_numpy(p).to(dev), torch.from_numpy(y).to(dev), loss)
+        assert set(out) == {"hit_at_one", "perr", "loss"}
+    a, b = host.get(), devm.get()
+    assert set(a) == set(b) == {"avg_hit_at_one", "avg_perr", "avg_loss", "aps", "gap"}
+    for key in ("avg_hit_at_one", "avg_perr", "avg_loss", "gap"):
+        assert abs(a[key] - b[key]) < 1e-6, (key, a[key], b[key])
+    assert np.allclose(a["aps"], b["aps"], atol=1e-6)
+    assert b["avg_perr"] > 0 and max(b["aps"]) > 0
+
+
+def _toy_batches(dev, n, B, D, V, seed):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    return [(torch.rand((B, D), device=dev, generator=gen) * 4 - 2, torch.rand((B, V), device=dev, generator=gen) < 0.05)
+            for _ in range(n)]
+
+
+def test_checkpoint_resume_is_bitwise_uninterrupted(dev, tmp_path, flags):
+    """save -> restore into a FRESH graph (after one forward pass, before any step: the documented flow) -> k more steps
+    == k uninterrupted steps, bit for bit: parameters, Adam slots, global_step (W/train.py:654-677,728)."""
+    B, D, V = 64, 96, 257
+    data = _toy_batches(dev, 8, B, D, V, 5)
+
+    def fresh(seed):
+        g = reset_default_graph(device=dev, seed=seed)
+        return g, train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g)
+
+    g1, t1 = fresh(0)
+    for x, y in data[:4]:
+        t1.step(x, y)
+    path = checkpoint.save(t1, str(tmp_path))
+    for x, y in data[4:]:
+        t1.step(x, y)
+    g2, t2 = fresh(123)                                  # different initial weights: everything must come from the file
+    t2.forward(data[0][0], data[0][1])                   # creates the variables; graph not finalized yet
+    assert not g2.finalized
+    checkpoint.restore(t2, path)
+    assert g2.finalized and t2.global_step == 4
+    for x, y in data[4:]:
+        t2.step(x, y)
+    assert t2.global_step == t1.global_step == 8
+    assert torch.equal(g1.params, g2.params)
+    assert torch.equal(g1.adam_m, g2.adam_m) and torch.equal(g1.adam_v, g2.adam_v)
+
+
+def test_checkpoint_resume_frame_level_model(dev, tmp_path, flags):
+    """The same for an LSTM model (TF variable names RNN/multi_rnn_cell/cell_<l>/basic_lstm_cell/...)."""
+    flags.lstm_cells = "128"
+    B, F, D, V = 8, 12, 64, 33
+    gen = torch.Generator(device=dev).manual_seed(2)
+    xs = [torch.randint(0, 256, (B, F, D), device=dev, generator=gen, dtype=torch.uint8) for _ in range(4)]
+    ys = [torch.rand((B, V), device=dev, generator=gen) < 0.1 for _ in range(4)]
+    nf = torch.tensor([12, 3, 7, 12, 1, 9, 12, 5], device=dev, dtype=torch.int32)
+
+    def fresh(seed):
+        g = reset_default_graph(device=dev, seed=seed)
+        return g, train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g)
+
+    g1, t1 = fresh(0)
+    for i in range(2):
+        t1.step(xs[i], ys[i], nf)
+    path = checkpoint.save(t1, str(tmp_path))
+    for i in range(2, 4):
+        t1.step(xs[i], ys[i], nf)
+    g2, t2 = fresh(9)
+    t2.forward(xs[0], ys[0], nf)
+    checkpoint.restore(t2, path)
+    for i in range(2, 4):
+        t2.step(xs[i], ys[i], nf)
+    assert sorted(g1.vars) == sorted(g2.vars) and "RNN/multi_rnn_cell/cell_1/basic_lstm_cell/weights" in g2.vars
+    assert torch.equal(g1.params, g2.params) and torch.equal(g1.adam_m, g2.adam_m) and torch.equal(g1.adam_v, g2.adam_v)
+
+
+def test_model_regularization_loss_and_update_ops(dev, flags):
+    """result["regularization_loss"] enters the final loss with --regularization_penalty, result["update_ops"] run before
+    the gradient step (W/train.py:435-456)."""
+    B, D, V = 32, 48, 65
+    (x, y), = _toy_batches(dev, 1, B, D, V, 1)
+    ran = []
+
+    class WithReg(vlm.LogisticModel):
+        def create_model(self, model_input, vocab_size, **kw):
+            out = super().create_model(model_input, vocab_size, **kw)
+            out["regularization_loss"] = (out["predictions"] ** 2).sum() * 0.01
+            out["update_ops"] = [lambda: ran.append(1)]
+            return out
+
+    def grads(model, penalty):
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(model, batch_size=B, graph=g, regularization_penalty=penalty, base_learning_rate=0.0)
+        tg.step(x, y)
+        return g.grads.clone()
+
+    base = grads(vlm.LogisticModel(), 1)
+    ran.clear()
+    reg2 = grads(WithReg(), 2)
+    assert ran == [1]
+    reg0 = grads(WithReg(), 0)
+    assert not torch.allclose(base, reg2) and torch.allclose(base, reg0, atol=1e-7)
+    # linear in the penalty: g(2) - g(0) == 2 * (g(1) - g(0))
+    reg1 = grads(WithReg(), 1)
+    assert torch.allclose(reg2 - reg0, 2 * (reg1 - reg0), rtol=1e-3, atol=1e-8)
+
+
+def test_clip_gradient_norms_reference_signature(dev):
+    """utils.clip_gradient_norms([(grad, var)], max_norm) -> [(clipped, var)] == the fused per-tensor clip (W/utils.py:164-174)."""
+    g1 = torch.full((10,), 3.0, device=dev)
+    g2 = torch.full((4,), 0.1, device=dev)
+    out = utils.clip_gradient_norms([(g1, "a"), (None, "b"), (g2, "c")], 1.0)
+    assert [v for _, v in out] == ["a", "b", "c"] and out[1][0] is None
+    assert abs(float(out[0][0].norm()) - 1.0) < 1e-6 and torch.equal(out[2][0], g2)

@@ -45,6 +45,21 @@ def test_checkpoint_round_trip_and_rotation(tmp_path):
     for k in a.graph.vars:
         assert torch.equal(b.graph.vars[k].data, a.graph.vars[k].data)
     assert torch.equal(b.graph.adam_m[:54], a.graph.adam_m[:54]) and torch.equal(b.graph.adam_v[:54], a.graph.adam_v[:54])
+    # documented resume flow: variables exist (one forward pass) but the graph is NOT finalized yet -> restore() must
+    # finalize through TrainGraph.ensure_finalized (l2 scaling + reducer attach happen there) and still load the Adam slots
+    calls = []
+    c = TG()
+    c.graph, c.global_step = Graph(device="cpu", seed=3), 0
+    c.graph.begin_step()
+    c.graph.get_variable("gates/weights", (6, 9), random_normal(0.3), l2=1e-8)
+    c.graph.get_variable("experts/biases", (9,), zeros)
+    c.graph.get_variable("bn/moving_mean", (9,), zeros, trainable=False)
+    c.ensure_finalized = lambda: (calls.append(1), train.TrainGraph.ensure_finalized(c))[1]
+    c.reg_penalty, c.reducer = 1, None
+    assert not c.graph.finalized
+    checkpoint.restore(c, path)
+    assert calls == [1] and c.graph.finalized and c.global_step == 40
+    assert torch.equal(c.graph.adam_m[:54], a.graph.adam_m[:54]) and torch.equal(c.graph.adam_v[:54], a.graph.adam_v[:54])
     from safetensors.torch import load_file
     sd = load_file(path)
     assert {"gates/weights", "gates/weights/Adam", "gates/weights/Adam_1", "experts/biases", "global_step"} <= set(sd)

@@ -99,13 +99,16 @@ def _worker(rank, world, port, overlap, q):
         pt, yt = torch.from_numpy(pg[sl]), torch.from_numpy(yg[sl]).float()
         vals, idx = torch.topk(pt, k, dim=1)                      # (test-side top-k: the product's runs on the device)
         em = eval_util.EvaluationMetrics(Vg, k)
-        out = em.accumulate_topk(vals, torch.gather(yt, 1, idx), yt.sum(), loss=float(rank + 1))
+        perr = torch.tensor(eval_util.calculate_precision_at_equal_recall_rate(pg[sl], yg[sl]) * pt.shape[0], dtype=torch.float64)
+        out = em.accumulate_topk(vals, torch.gather(yt, 1, idx), idx, yt.sum(0), perr, loss=float(rank + 1))
         ref = eval_util.EvaluationMetrics(Vg, k)
         ref.accumulate(pg, yg, np.array([(1.0 * cut + 2.0 * (Bg - cut)) / Bg]))
         got, exp = em.get(), ref.get()
         assert abs(got["gap"] - exp["gap"]) < 1e-12 and abs(got["avg_hit_at_one"] - exp["avg_hit_at_one"]) < 1e-12
         assert abs(got["avg_loss"] - exp["avg_loss"]) < 1e-12 and em.num_examples == Bg
         assert abs(out["hit_at_one"] - exp["avg_hit_at_one"]) < 1e-12
+        assert abs(got["avg_perr"] - exp["avg_perr"]) < 1e-12            # all five keys agree with the host path
+        assert np.allclose(got["aps"], exp["aps"], atol=1e-12)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

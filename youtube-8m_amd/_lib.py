@@ -119,6 +119,7 @@ SIGNATURES = {
     "yt8m_tfrecord_read_video_batch": (c_int, [P, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int32), c_int, c_int64,
                                                c_int64, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
     "yt8m_topk_rows": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
+    "yt8m_perr_rows": (c_int, [P, P, c_int64, c_int64, P, P]),
 }
 
 _lib = None

@@ -41,13 +41,25 @@ def restore(train_graph, path):
     from safetensors.torch import load_file
     g = train_graph.graph
     sd = load_file(path)
+    has_slots = any(k.endswith("/Adam") for k in sd)
+    if has_slots:
+        if not g.vars:
+            raise RuntimeError("restore() needs the variables to exist: run one forward pass (TrainGraph.forward) first")
+        # the Adam slots live in the arenas: finalize the way step() would (l2 scaling, reducer attach) BEFORE loading them;
+        # restoring between the first forward pass and the first step used to drop m / v silently
+        if hasattr(train_graph, "ensure_finalized"):
+            train_graph.ensure_finalized()
+        elif not g.finalized:
+            g.finalize()
     for name, v in g.vars.items():
         if name not in sd:
             raise KeyError("checkpoint %s has no variable %s" % (path, name))
         if tuple(sd[name].shape) != tuple(v.shape):
             raise ValueError("shape mismatch for %s: %s vs %s" % (name, tuple(sd[name].shape), tuple(v.shape)))
         v.data.copy_(sd[name].to(v.data.device))
-        if v.trainable and g.finalized and name + "/Adam" in sd:
+        if v.trainable and has_slots:
+            if name + "/Adam" not in sd or name + "/Adam_1" not in sd:
+                raise KeyError("checkpoint %s has Adam slots but none for %s" % (path, name))
             n = v.numel()
             g.adam_m[v.offset:v.offset + n].copy_(sd[name + "/Adam"].reshape(-1).to(g.adam_m.device))
             g.adam_v[v.offset:v.offset + n].copy_(sd[name + "/Adam_1"].reshape(-1).to(g.adam_v.device))

@@ -183,6 +183,50 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+// ---- per-row precision at equal recall rate (W/eval_util.py:74-99) ------------------------------------------------
+// One workgroup per video: the row and the list of its positive classes sit in LDS; a positive class j counts when its
+// rank (#scores above it, ties towards the lower class index = a stable descending sort) is below the number of
+// positives and its score is > 0.  Integer counting only: bit-exact against the host restatement when the boundary
+// scores are distinct.  A video without labels scores 0 (the reference then averages label hits over ALL classes: 0).
+__global__ __launch_bounds__(256) void perr_rows_kernel(const float* __restrict__ p, const uint8_t* __restrict__ y, int64_t V,
+                                                        float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  int* pos = reinterpret_cast<int*>(row + V);
+  __shared__ int npos;
+  __shared__ int cnt[4];
+  const int64_t b = blockIdx.x;
+  if (threadIdx.x == 0) npos = 0;
+  __syncthreads();
+  for (int c = threadIdx.x; c < (int)V; c += 256) {
+    row[c] = p[b * V + c];
+    if (y[b * V + c]) pos[atomicAdd(&npos, 1)] = c;
+  }
+  __syncthreads();
+  const int nl = npos;
+  if (nl == 0) {
+    if (threadIdx.x == 0) out[b] = 0.f;
+    return;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int hits = 0;
+  for (int q = 0; q < nl; ++q) {
+    const int j = pos[q];
+    const float pj = row[j];
+    int g = 0;
+    for (int c = threadIdx.x; c < (int)V; c += 256) {
+      const float v = row[c];
+      g += (v > pj || (v == pj && c < j)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+    if (lane == 0) cnt[wv] = g;
+    __syncthreads();
+    if (threadIdx.x == 0 && (cnt[0] + cnt[1] + cnt[2] + cnt[3]) < nl && pj > 0.f) ++hits;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = (float)hits / (float)nl;
+}
+
 }  // namespace
 
 using namespace yt8m;
@@ -485,4 +529,20 @@ extern "C" int yt8m_topk_rows(const float* p, int64_t B, int64_t V, int k, float
   }
   hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)B), dim3(256), shm, s, p, V, k, vals, idx);
   return launch_status("topk_rows_kernel");
+}
+
+extern "C" int yt8m_perr_rows(const float* p, const uint8_t* labels, int64_t B, int64_t V, float* perr, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && V >= 1, YT8M_E_SHAPE, "bad dimension");
+  YT8M_REQUIRE(V * 8 <= 150 * 1024, YT8M_E_SHAPE, "row + label list do not fit LDS (V > 19200)");
+  if (B == 0) return YT8M_OK;
+  YT8M_REQUIRE(p && labels && perr, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const size_t shm = (size_t)V * 8;
+  if (shm > 64 * 1024) {
+    YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(perr_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  }
+  hipLaunchKernelGGL(perr_rows_kernel, dim3((unsigned)B), dim3(256), shm, s, p, labels, V, perr);
+  return launch_status("perr_rows_kernel");
 }

@@ -9,6 +9,8 @@
 // irrelevant, W/readers.py:120,217-220).  TFRecord framing: u64 length, u32 masked crc32c(length), payload, u32 masked
 // crc32c(payload); mask(c) = ((c >> 15) | (c << 17)) + 0xa282ead8.  Everything here is byte / integer work: bit-exact.
 #include <stdlib.h>
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -16,10 +18,9 @@
 namespace {
 
 uint32_t g_crc_table[8][256];
-bool g_crc_ready = false;
+std::once_flag g_crc_once;
 
-void crc_init() {
-  if (g_crc_ready) return;
+void crc_build() {
   for (uint32_t i = 0; i < 256; ++i) {
     uint32_t c = i;
     for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);   // Castagnoli, reflected
@@ -27,8 +28,9 @@ void crc_init() {
   }
   for (uint32_t i = 0; i < 256; ++i)
     for (int t = 1; t < 8; ++t) g_crc_table[t][i] = (g_crc_table[t - 1][i] >> 8) ^ g_crc_table[0][g_crc_table[t - 1][i] & 0xff];
-  g_crc_ready = true;
 }
+
+void crc_init() { std::call_once(g_crc_once, crc_build); }   // the prefetch workers call this concurrently
 
 uint32_t crc32c(const uint8_t* p, size_t n) {
   crc_init();
@@ -454,13 +456,19 @@ struct Prefetcher {
   std::string error_msg;
   int held = -1;              // slot currently lent to the consumer
   std::vector<std::thread> threads;
+  std::vector<void*> pinned_ptrs;   // which buffers came from hipHostMalloc (freed with hipHostFree; the rest with free)
 };
 
-void* host_alloc(size_t bytes, bool* pinned) {
+// Pinned while hipHostMalloc succeeds; after the first failure the remaining buffers are pageable, P->pinned (what the
+// consumer is told: "every buffer is pinned") drops to false, and each buffer is released by the allocator it came from.
+void* host_alloc(size_t bytes, Prefetcher* P) {
   void* p = nullptr;
-  if (*pinned && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) return p;
+  if (P->pinned && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
+    P->pinned_ptrs.push_back(p);
+    return p;
+  }
   (void)hipGetLastError();
-  *pinned = false;
+  P->pinned = false;
   return malloc(bytes);
 }
 
@@ -543,13 +551,13 @@ extern "C" int yt8m_prefetch_open(const char* const* paths, int npaths, int fram
   for (int s = 0; s < nslots; ++s) {
     Slot& sl = P->slots[s];
     if (P->frame_level) {
-      sl.q = static_cast<uint8_t*>(host_alloc((size_t)(batch * max_frames * P->D), &P->pinned));
-      sl.nf = static_cast<int32_t*>(host_alloc((size_t)batch * 4, &P->pinned));
+      sl.q = static_cast<uint8_t*>(host_alloc((size_t)(batch * max_frames * P->D), P));
+      sl.nf = static_cast<int32_t*>(host_alloc((size_t)batch * 4, P));
     } else {
-      sl.x = static_cast<float*>(host_alloc((size_t)(batch * P->D) * 4, &P->pinned));
+      sl.x = static_cast<float*>(host_alloc((size_t)(batch * P->D) * 4, P));
     }
-    sl.labels = static_cast<uint8_t*>(host_alloc((size_t)(batch * num_classes), &P->pinned));
-    sl.ids = static_cast<char*>(host_alloc((size_t)(batch * P->id_stride), &P->pinned));
+    sl.labels = static_cast<uint8_t*>(host_alloc((size_t)(batch * num_classes), P));
+    sl.ids = static_cast<char*>(host_alloc((size_t)(batch * P->id_stride), P));
     P->free_slots.push_back(s);
   }
   P->active_workers = nthreads;
@@ -601,7 +609,7 @@ extern "C" int yt8m_prefetch_close(void* handle) {
     void* ptrs[5] = {sl.q, sl.x, sl.nf, sl.labels, sl.ids};
     for (void* p : ptrs) {
       if (!p) continue;
-      if (P->pinned) (void)hipHostFree(p);
+      if (std::find(P->pinned_ptrs.begin(), P->pinned_ptrs.end(), p) != P->pinned_ptrs.end()) (void)hipHostFree(p);
       else free(p);
     }
   }

@@ -1,9 +1,8 @@
 """Evaluation metrics (Hit@1, PERR, GAP@k); API mirrors W/eval_util.py:28-254.
 
 Host functions take numpy arrays like the reference.  ``EvaluationMetrics.accumulate_device`` is the
-MI355X path: the per-video top-k selection runs on the GPU (yt8m_topk_rows) and only
-B*k (score, label) pairs plus B hit / PERR scalars cross PCIe, instead of two [B, 4716] matrices per step
-(W/train.py:574-575).
+MI355X path: the per-video top-k selection and the PERR rank counts run on the GPU
+(yt8m_topk_rows, yt8m_perr_rows).
 """
 import numpy
 
@@ -83,85 +82,110 @@ def top_k_by_class(predictions, labels, k=20):
 
 
 class EvaluationMetrics(object):
-    """W/eval_util.py:167-254."""
+    """Running Hit@1 / PERR / loss / GAP@k / per-class AP over the batches of an evaluation run; the interface
+    (constructor, accumulate, get, clear and the dictionary keys) is the one W/eval_util.py:167-254 exposes to
+    train.py / eval.py.
+
+    Host and device batches end in the same place, ``_ingest``: the pooled per-video top-k (score, label, class)
+    triplets feed the global AP calculator (GAP@k) and, grouped by class with one stable sort, the per-class
+    calculators (mAP) -- the reference's per-class Python lists (top_k_by_class) are never built on this path.
+    ``accumulate_device`` produces the triplets on the MI355X (yt8m_topk_rows, yt8m_perr_rows) so only
+    B*k triplets, B PERR values and V class counts cross PCIe instead of two [B, V] matrices per step
+    (W/train.py:574-575)."""
+
+    _KEYS = ("hit_at_one", "perr", "loss")
 
     def __init__(self, num_class, top_k):
-        self.sum_hit_at_one = 0.0
-        self.sum_perr = 0.0
-        self.sum_loss = 0.0
+        self.num_class = int(num_class)
+        self.top_k = top_k
         self.map_calculator = map_calculator.MeanAveragePrecisionCalculator(num_class)
         self.global_ap_calculator = ap_calculator.AveragePrecisionCalculator()
-        self.top_k = top_k
+        self.clear()
+
+    def clear(self):
+        self._totals = dict.fromkeys(self._KEYS, 0.0)       # batch-size weighted sums
         self.num_examples = 0
+        self.map_calculator.clear()
+        self.global_ap_calculator.clear()
+
+    # kept as attributes: W/eval.py and tests read them
+    sum_hit_at_one = property(lambda self: self._totals["hit_at_one"])
+    sum_perr = property(lambda self: self._totals["perr"])
+    sum_loss = property(lambda self: self._totals["loss"])
+
+    def _ingest(self, scores, hits, classes, class_positives, n, sums):
+        """scores / hits / classes: flat arrays of the pooled top-k triplets; class_positives [V]: positives per class over
+        ALL labels of the batch (not only the top-k ones); sums: batch totals of hit@1, PERR, loss."""
+        scores = numpy.asarray(scores).reshape(-1)
+        hits = numpy.asarray(hits).reshape(-1)
+        classes = numpy.asarray(classes).reshape(-1)
+        class_positives = numpy.asarray(class_positives).reshape(-1)
+        self.global_ap_calculator.accumulate(scores, hits, float(class_positives.sum()))
+        self.map_calculator.accumulate_sparse(classes, scores, hits, class_positives)
+        self.num_examples += int(n)
+        for key in self._KEYS:
+            self._totals[key] += float(sums[key])
+        return {key: float(sums[key]) / n for key in self._KEYS}
 
     def accumulate(self, predictions, labels, loss):
-        batch_size = labels.shape[0]
-        mean_hit_at_one = calculate_hit_at_one(predictions, labels)
-        mean_perr = calculate_precision_at_equal_recall_rate(predictions, labels)
-        mean_loss = numpy.mean(loss)
-        sparse_predictions, sparse_labels, num_positives = top_k_by_class(predictions, labels, self.top_k)
-        self.map_calculator.accumulate(sparse_predictions, sparse_labels, num_positives)
-        self.global_ap_calculator.accumulate(flatten(sparse_predictions), flatten(sparse_labels), sum(num_positives))
-        self.num_examples += batch_size
-        self.sum_hit_at_one += mean_hit_at_one * batch_size
-        self.sum_perr += mean_perr * batch_size
-        self.sum_loss += mean_loss * batch_size
-        return {"hit_at_one": mean_hit_at_one, "perr": mean_perr, "loss": mean_loss}
+        """Host batch: predictions, labels numpy [B, V]; loss a scalar or per-example array."""
+        n = labels.shape[0]
+        k = min(self.top_k, predictions.shape[1])
+        if k <= 0:
+            raise ValueError("k must be a positive integer.")
+        idx = numpy.argpartition(predictions, -k, axis=1)[:, -k:]
+        rows = numpy.arange(n)[:, None]
+        sums = {"hit_at_one": calculate_hit_at_one(predictions, labels) * n,
+                "perr": calculate_precision_at_equal_recall_rate(predictions, labels) * n,
+                "loss": float(numpy.mean(loss)) * n}
+        return self._ingest(predictions[rows, idx], labels[rows, idx], idx, numpy.sum(labels, axis=0), n, sums)
 
     def accumulate_device(self, predictions, labels, loss, group=None):
-        """GPU path for GAP / Hit@1: predictions, labels are device tensors [B, V] (this rank's shard under data parallelism).
-        Per-video top-k runs on the device (yt8m_topk_rows); only B*k (score, label) pairs leave it."""
+        """Device batch: predictions, labels are tensors [B, V] on the MI355X (this rank's shard under data parallelism).
+        Top-k, Hit@1, PERR and the per-class label counts are computed there."""
         import torch
         from . import ops
         vals, idx = ops.topk_rows(predictions, self.top_k)
-        lab = labels.to(torch.float32)
-        picked = torch.gather(lab, 1, idx.long())
-        return self.accumulate_topk(vals, picked, lab.sum(), float(loss), group=group)
+        idx = idx.long().clamp_(0, predictions.shape[1] - 1)       # all-NaN rows report index INT_MAX: keep gather in range
+        lab_u8 = labels if labels.dtype in (torch.bool, torch.uint8) else (labels > 0)
+        picked = torch.gather(lab_u8.to(torch.float32), 1, idx)
+        perr = ops.perr_rows(predictions, lab_u8)
+        class_pos = lab_u8.to(torch.float64).sum(dim=0) if lab_u8.dtype != torch.bool else lab_u8.sum(dim=0, dtype=torch.float64)
+        return self.accumulate_topk(vals, picked, idx, class_pos, perr.sum(), float(loss), group=group)
 
-    def accumulate_topk(self, vals, picked, num_positives, loss, group=None):
-        """vals / picked [B, k]: per-video top-k scores (descending) and their labels; num_positives: scalar tensor = number of
-        positive labels in the shard (ALL labels, not only the top-k ones: W/average_precision_calculator.py total_positives).
-        Under torch.distributed every rank's pairs are all-gathered (B*k*8 bytes per rank) and the positives /
-        loss sums all-reduced, so every rank accumulates the metrics of the GLOBAL batch."""
+    def accumulate_topk(self, vals, picked, idx, class_positives, perr_sum, loss, group=None):
+        """vals / picked / idx [B, k]: per-video top-k scores (descending), their labels and class ids; class_positives [V]:
+        positives per class in the shard; perr_sum: sum of the per-video PERR values.  Under torch.distributed
+        every rank's triplets are all-gathered (B*k*12 bytes per rank) and the class counts / sums all-reduced, so every
+        rank accumulates the metrics of the GLOBAL batch."""
         import torch
         import torch.distributed as dist
         bs = vals.shape[0]
-        stats = torch.stack([num_positives.to(torch.float64).reshape(()), picked[:, 0].to(torch.float64).sum(),
-                             torch.tensor(float(loss) * bs, dtype=torch.float64, device=vals.device),
-                             torch.tensor(float(bs), dtype=torch.float64, device=vals.device)])
+        dev = vals.device
+        head = torch.stack([picked[:, 0].to(torch.float64).sum(), perr_sum.to(torch.float64).reshape(()),
+                            torch.tensor(float(loss) * bs, dtype=torch.float64, device=dev),
+                            torch.tensor(float(bs), dtype=torch.float64, device=dev)])
+        stats = torch.cat([head, class_positives.to(torch.float64).reshape(-1)])
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             world = dist.get_world_size(group)
-            counts = [torch.zeros(1, dtype=torch.int64, device=vals.device) for _ in range(world)]
-            dist.all_gather(counts, torch.tensor([bs], dtype=torch.int64, device=vals.device), group=group)
-            cap = int(max(int(c.item()) for c in counts))
-            pad = torch.zeros((cap, 2, vals.shape[1]), dtype=torch.float32, device=vals.device)
-            pad[:bs, 0], pad[:bs, 1] = vals, picked
+            counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(counts, torch.tensor([bs], dtype=torch.int64, device=dev), group=group)
+            counts = [int(c.item()) for c in counts]
+            pad = torch.zeros((max(counts), 3, vals.shape[1]), dtype=torch.float32, device=dev)
+            pad[:bs, 0], pad[:bs, 1], pad[:bs, 2] = vals, picked, idx.to(torch.float32)   # class ids < 2^24: exact in fp32
             gathered = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(gathered, pad, group=group)
-            vals = torch.cat([g[:int(c.item()), 0] for g, c in zip(gathered, counts)])
-            picked = torch.cat([g[:int(c.item()), 1] for g, c in zip(gathered, counts)])
+            vals, picked, idx = (torch.cat([g[:c, j] for g, c in zip(gathered, counts)]) for j in range(3))
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-        npos, hits, loss_sum, n = (float(v) for v in stats.cpu())
-        self.global_ap_calculator.accumulate(vals.reshape(-1).cpu().numpy(), picked.reshape(-1).cpu().numpy(), npos)
-        self.num_examples += int(n)
-        self.sum_hit_at_one += hits
-        self.sum_loss += loss_sum
-        return {"hit_at_one": hits / n, "loss": loss_sum / n}
+        stats = stats.cpu().numpy()
+        hit_sum, perr_tot, loss_sum, n = (float(v) for v in stats[:4])
+        return self._ingest(vals.cpu().numpy(), picked.cpu().numpy(), idx.cpu().numpy().astype(numpy.int64), stats[4:], int(n),
+                            {"hit_at_one": hit_sum, "perr": perr_tot, "loss": loss_sum})
 
     def get(self):
         if self.num_examples <= 0:
             raise ValueError("total_sample must be positive.")
-        avg_hit_at_one = self.sum_hit_at_one / self.num_examples
-        avg_perr = self.sum_perr / self.num_examples
-        avg_loss = self.sum_loss / self.num_examples
-        aps = self.map_calculator.peek_map_at_n()
-        gap = self.global_ap_calculator.peek_ap_at_n()
-        return {"avg_hit_at_one": avg_hit_at_one, "avg_perr": avg_perr, "avg_loss": avg_loss, "aps": aps, "gap": gap}
-
-    def clear(self):
-        self.sum_hit_at_one = 0.0
-        self.sum_perr = 0.0
-        self.sum_loss = 0.0
-        self.map_calculator.clear()
-        self.global_ap_calculator.clear()
-        self.num_examples = 0
+        out = {"avg_" + key: self._totals[key] / self.num_examples for key in self._KEYS}
+        out["aps"] = self.map_calculator.peek_map_at_n()
+        out["gap"] = self.global_ap_calculator.peek_ap_at_n()
+        return out

@@ -15,6 +15,29 @@ class MeanAveragePrecisionCalculator(object):
         for i in range(len(predictions)):
             self._ap_calculators[i].accumulate(predictions[i], actuals[i], num_positives[i])
 
+    def accumulate_sparse(self, class_ids, predictions, actuals, num_positives):
+        """Flat (class, score, label) triplets instead of one list per class: grouped with a single stable sort, so only the
+        classes that occur are touched; num_positives [num_class] still counts every class (a class whose positives never
+        reach a top-k keeps its denominator)."""
+        import numpy as np
+        class_ids = np.asarray(class_ids).reshape(-1)
+        predictions = np.asarray(predictions).reshape(-1)
+        actuals = np.asarray(actuals).reshape(-1)
+        order = np.argsort(class_ids, kind="stable")
+        sorted_ids = class_ids[order]
+        bounds = np.flatnonzero(np.diff(sorted_ids)) + 1
+        starts = np.concatenate(([0], bounds)) if len(sorted_ids) else np.zeros(0, dtype=np.int64)
+        ends = np.concatenate((bounds, [len(sorted_ids)])) if len(sorted_ids) else starts
+        seen = set()
+        for s, e in zip(starts, ends):
+            c = int(sorted_ids[s])
+            seen.add(c)
+            sel = order[s:e]
+            self._ap_calculators[c].accumulate(predictions[sel], actuals[sel], float(num_positives[c]))
+        for c in np.flatnonzero(np.asarray(num_positives) > 0):
+            if int(c) not in seen:
+                self._ap_calculators[int(c)].accumulate(np.zeros(0), np.zeros(0), float(num_positives[c]))
+
     def clear(self):
         for c in self._ap_calculators:
             c.clear()

@@ -361,6 +361,20 @@ def topk_rows(p, k=20):
     return vals, idx
 
 
+def perr_rows(p, labels):
+    """Per-video precision at equal recall rate on the device (W/eval_util.py:74-99); labels bool / uint8 [B,V]."""
+    _dev(p)
+    p = _f32c(p)
+    lab = labels.contiguous()
+    if lab.dtype == torch.bool:
+        lab = lab.view(torch.uint8)
+    assert lab.dtype == torch.uint8 and lab.shape == p.shape
+    B, V = p.shape
+    out = torch.empty((B,), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().yt8m_perr_rows(_p(p), _p(lab), B, V, _p(out), _stream()))
+    return out
+
+
 def sqnorm_and_adam(graph, lr_t, gscale=1.0, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8, tensors=None):
     """Per-tensor clip + TF-Adam over the arena (two multi-tensor passes).  tensors = (lo, hi) restricts the update
     to trainable variables lo..hi-1 (a contiguous slice of the chunk table)."""

@@ -83,6 +83,11 @@ class GradReducer(object):
     def _on_ready(self, var):
         """Marks var ready; launches an async all-reduce for every maximal run of ready, unlaunched, adjacent
         variables whose size reaches the bucket threshold."""
+        if self._launched[var.index]:
+            # a Variable used twice in one forward pass reports grad_done() after its FIRST backward contribution; the later
+            # one would add into a buffer whose all-reduce is already in flight (ADVICE r1): refuse loudly
+            raise RuntimeError("gradient of %s was reported done twice in one step (variable shared between ops?): its "
+                               "all-reduce is already in flight" % var.name)
         self._ready[var.index] = True
         self._flush(final=False)
 

@@ -148,6 +148,22 @@ class TrainGraph(object):
                 return self._label_loss(result, distill_labels_batch, weights)
         return self._label_loss(result, labels_batch, weights)
 
+    def ensure_finalized(self):
+        """Freezes the variable set into the flat parameter / gradient / Adam arenas (Graph.finalize), applies
+        --regularization_penalty to the per-variable l2 table and attaches the data-parallel reducer -- once.  Called by
+        step() after the first forward pass and by checkpoint.restore() (the Adam slots live in the arenas)."""
+        g = self.graph
+        if g.finalized and getattr(self, "_finalized_here", False):
+            return
+        if not g.finalized:
+            g.finalize()
+        if not getattr(self, "_finalized_here", False):
+            if self.reg_penalty != 1:
+                g.l2.mul_(float(self.reg_penalty))
+            if self.reducer is not None:
+                self.reducer.attach(g)
+            self._finalized_here = True
+
     # ---- one optimisation step -----------------------------------------------------------------------
     def step(self, model_input_raw, labels_batch, num_frames=None, weights=None, distill_labels_batch=None):
         g = self.graph
@@ -155,18 +171,26 @@ class TrainGraph(object):
         if distill is not None and FLAGS.distillation_type == 2:  # W/train.py:320-327: labels are re-formed up front
             distill = reform_distill_labels(labels_batch, distill, FLAGS.distillation_percent)
         # (the fused mixing + loss of MoeModel is this build's addition: it must not pre-empt weights / distillation)
-        result = self.forward(model_input_raw, labels_batch, num_frames, fuse_loss=weights is None and distill is None,
+        # and it computes exactly CrossEntropyLoss: any other configured loss (TrainGraph(label_loss_fn=...), multitask) wins
+        fuse = (weights is None and distill is None and not self.multitask
+                and type(self.label_loss_fn) is losses.CrossEntropyLoss)
+        result = self.forward(model_input_raw, labels_batch, num_frames, fuse_loss=fuse,
                               distillation_predictions=distill if FLAGS.distillation_as_input else None)
         label_loss = self.loss(result, labels_batch, weights, distill)
-        if not g.finalized:
-            g.finalize()
-            if self.reg_penalty != 1:
-                g.l2.mul_(float(self.reg_penalty))
-            if self.reducer is not None:
-                self.reducer.attach(g)
+        # W/train.py:435-456: a model may hand back its own "regularization_loss" (added to the final loss with the
+        # --regularization_penalty weight; the slim l2 regularisers are applied as l2*w inside the optimiser pass) and
+        # "update_ops" (run before the gradient step, e.g. moving averages)
+        final_loss = label_loss
+        if "regularization_loss" in result and torch.is_tensor(result["regularization_loss"]) \
+                and result["regularization_loss"].requires_grad and self.reg_penalty != 0:
+            final_loss = label_loss + float(self.reg_penalty) * result["regularization_loss"]
+        for op in result.get("update_ops", ()) or ():
+            if callable(op):
+                op()
+        self.ensure_finalized()
         if self.reducer is not None:
             self.reducer.begin_step()
-        label_loss.backward()
+        final_loss.backward()
         for v in g.trainable_variables():                       # variables the step did not touch: TF skips them
             if not v.grad_written:                              # (None gradient); here their gradient is zero
                 v.grad.zero_()

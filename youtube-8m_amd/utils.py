@@ -23,7 +23,20 @@ def GetListOfFeatureNamesAndSizes(feature_names, feature_sizes):
     return list_of_feature_names, list_of_feature_sizes
 
 
-def clip_gradient_norms(graph, max_norm):
-    """W/utils.py:164-174 is realised inside the fused optimiser pass (ops.sqnorm_and_adam): per-tensor
-    g * clip / max(||g||, clip).  This helper only reports the per-tensor norms of the last step."""
+def clip_gradient_norms(gradients_to_variables, max_norm):
+    """W/utils.py:164-174, same signature: [(grad, var)] -> [(clipped grad, var)], per tensor
+    tf.clip_by_norm(g, max_norm) = g * max_norm / max(||g||, max_norm); None gradients pass through.
+    API-parity form for callers that hold their own gradient list; the training step itself runs the same rule fused with
+    Adam over the gradient arena (ops.sqnorm_and_adam -> yt8m_sqnorm_multi + yt8m_adam_multi), see gradient_norms()."""
+    clipped_grads_and_vars = []
+    for grad, var in gradients_to_variables:
+        if grad is not None:
+            norm = torch.linalg.vector_norm(grad.to(torch.float32))
+            grad = grad * (max_norm / torch.clamp(norm, min=max_norm))
+        clipped_grads_and_vars.append((grad, var))
+    return clipped_grads_and_vars
+
+
+def gradient_norms(graph):
+    """Per-tensor gradient norms of the last fused clip+Adam pass (what W/utils.py:164-174 clips against)."""
     return graph.norms.sqrt()

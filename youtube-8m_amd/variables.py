@@ -42,12 +42,17 @@ class Variable(object):
     def grad_beta(self):
         """beta for the next gradient write (0 = overwrite) and marks the slot as written."""
         beta = 1.0 if self.grad_written else 0.0
+        if self.grad_written and self._graph is not None and getattr(self._graph, "grad_ready_hook", None) is not None \
+                and getattr(self, "_done_reported", False):
+            raise RuntimeError("second gradient contribution to %s after grad_done(): under data parallelism its all-reduce "
+                               "is already in flight" % self.name)
         self.grad_written = True
         return beta
 
     def grad_done(self):
         """Called by the op that produced the LAST contribution of this step (single-use variables: right after
         the first write).  Lets the data-parallel reducer start this slice's all-reduce early."""
+        self._done_reported = True
         if self._graph is not None and self._graph.grad_ready_hook is not None:
             self._graph.grad_ready_hook(self)
 
@@ -122,6 +127,7 @@ class Graph(object):
         self._rng_calls = 0
         for v in self.vars.values():
             v.grad_written = False
+            v._done_reported = False
         if self.token is None:
             self.token = torch.zeros((), dtype=torch.float32, device=self.device, requires_grad=True)
 
