@@ -315,6 +315,21 @@ int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const 
                         const int32_t* num_frames, int64_t F, int64_t B, int64_t H,
                         void* gemm_workspace, int64_t gemm_workspace_bytes, yt8m_stream_t stream);
 
+/* ---- persistent recurrence (csrc/lstm_persist.hip): ONE launch runs steps [t0, t0+T) of a BasicLSTM layer --------
+ * Replaces the per-step launches of yt8m_lstm_steps_fwd / _bwd (tf.nn.dynamic_rnn's while_loop body,
+ * W/all_frame_models/lstm_model.py:44-47) when yt8m_lstm_persist_supported(B, H): W_h stays in registers for all T
+ * steps, h_t / dz_t are exchanged between workgroups through `workspace` (MFMA-fragment order, write-through stores,
+ * per-tile arrival counters; no grid barrier).  Same arguments and semantics as the time-range forms; `workspace`
+ * (yt8m_lstm_persist_workspace_bytes) is scratch owned by the caller for the duration of the call chain of one layer.
+ * Launches of one device are chained behind each other inside the library (whole-chip residency).
+ * yt8m_lstm_persist_status: synchronises `stream` and returns YT8M_E_HIP if a launch on `workspace` gave up waiting. */
+int yt8m_lstm_persist_supported(int64_t B, int64_t H);
+int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H);
+int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream);
+int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
+                          const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                          void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+
 /* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the
  * re-packed recurrent weights owned by the caller (yt8m_lstm_pack; yt8m_lstm_packed_floats() floats each for the forward
  * image Wp and the backward image Wq; 0 = shape not covered, pass NULL and the generic per-step GEMM path runs).

@@ -1,0 +1,384 @@
+// lstm_persist.hip -- persistent BasicLSTM recurrence for gfx950: ONE launch runs T time steps of a layer
+// (tf.contrib.rnn.BasicLSTMCell under tf.nn.dynamic_rnn; W/all_frame_models/lstm_model.py:34-47).
+//
+// The per-step kernels (lstm_fused.hip) re-stream W_h from L2 for every step (128 MB / step at B = 128, H = 1024) and pay a
+// launch boundary per step: 19-22 us against a 6.8 us MFMA bound.  Here the recurrent weights never move:
+//   * forward: workgroup (unit group ug = 8 hidden units = their 32 gate columns, row group g) keeps its [H x 32] slice of
+//     W_h in REGISTERS, K split over the 8 waves of a 512-thread workgroup (wave w owns k in [w H/8, (w+1) H/8): NQ = H/128
+//     q-groups of 16 k = 8 NQ float4 B-fragments per lane); no LDS or L2 traffic for weights in the step loop.
+//   * the only per-step traffic is the state itself: h_t (512 KB) is exchanged through an "hx" buffer laid out in MFMA
+//     A-fragment order ([16-row tile][q-group][16 rows][16 k] = 1 KB blocks): a producer workgroup writes the 32 bytes per row
+//     it owns with write-through 16-byte stores (sc0 sc1), a consumer wave fetches one fully coalesced 1 KB block per 4
+//     MFMAs with sc0 sc1 loads (coherent across the 8 XCD-private L2s; no acquire fence, no L1 involvement).
+//   * no grid barrier: work is cut into ITEMS = (time step, 16-row tile).  Item (s, T) needs h_{s-1} of tile T only, so
+//     completion is tracked per tile with monotonic arrival counters (8 shards per tile, one 128-byte line each); a
+//     workgroup with >= 3 tiles prefetches the A fragments of item k+2 while the MFMAs of item k run, so the exchange
+//     latency (write-through drain + flag + fetch ~ 3 us) hides behind two items of matrix work.
+//   * per item a wave issues NQ x 4 x 2 v_mfma_f32_16x16x4_f32 (two independent accumulators = the two 16-column halves of
+//     the unit group), partial tiles of the 8 waves meet in LDS (double-buffered by item parity, ONE workgroup barrier per
+//     item), waves 0-1 run the gate epilogue (sigmoid / tanh, cell update, dynamic_rnn copy-through) for the 128 (row, unit)
+//     pairs while the other waves already issue the next item's MFMAs.
+// Exact fp32 (v_mfma_f32_16x16x4_f32 is an fmaf chain); the summation order over K is fixed, so results are bitwise
+// reproducible run to run.  Every spin is bounded (wall clock); on a timeout the control block's error word is set, all
+// waits fall through and the launch ends (the host reports YT8M_E_HIP on the next status query).
+//
+// Deadlock note: a persistent launch needs its whole grid resident (<= 1 workgroup per CU: 512 threads x <=256 VGPRs).  Two
+// such launches on different streams could each hold part of the chip and wait for the rest forever, so the host side
+// chains every persistent launch of a device behind the previous one with an event (PersistGate), whatever stream the
+// caller passes.
+#include <mutex>
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AUX_SYS = 17;                    // sc0 sc1: write-through store / coherent load (MI355X_MICROARCH.md, visibility)
+constexpr long long SPIN_TIMEOUT = 300000000;  // wall_clock64 ticks (100 MHz): 3 s
+constexpr int CTL_HDR = 32;                    // control block: [0] error word, counters from word 32
+
+struct PersistFwdArgs {
+  float* z;             // [F,B,4H] hoisted input projection + bias on entry, gate activations on exit
+  const float* Wh;      // [H, ldw]
+  long long ldw;
+  float* cs;            // [F+1,B,H]
+  float* hs;            // [F+1,B,H]
+  float* out;           // [F,B,H] or null
+  const int32_t* nf;    // [B] or null
+  float* hx;            // exchange buffer [2][NT16][H/16][256]
+  unsigned* ctl;        // control block (zeroed before the launch)
+  int t0, T, B, H;
+  float fb;
+  int NU, RB, NT16, per, pf;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float4 as_f4(u32x4 v) {
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// Waits until the 8 shard counters of `tile` sum to >= target.  Lanes 0-7 poll one shard each with relaxed agent-scope
+// loads; bounded: after SPIN_TIMEOUT the error word is set and every later wait falls through at once.
+__device__ __forceinline__ void wait_tile(unsigned* ctl, int tile, unsigned target, int lane) {
+  unsigned* c = ctl + CTL_HDR + (tile * 8 + (lane & 7)) * 32;
+  long long t_start = 0;
+  for (unsigned spins = 0;; ++spins) {
+    unsigned v = 0;
+    if (lane < 8) v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned tot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)v, i);
+    if (tot >= target) return;
+    if (spins >= 16) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 255) == 16) {
+        if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        const long long now = wall_clock64();
+        if (t_start == 0) t_start = now;
+        else if (now - t_start > SPIN_TIMEOUT) {
+          if (lane == 0) __hip_atomic_store(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+    }
+  }
+}
+
+// hx parity 0 <- h_{t0-1} (standard layout hs[t0], written by the previous launch / the caller), so that step 0 of a launch
+// reads its state exactly like every later step (one uniform, branch-free load path in the step loop).
+__global__ __launch_bounds__(256) void hx_pack_kernel(const float* __restrict__ h, float* __restrict__ hx, int B, int H, int NT16) {
+  const long long n = (long long)NT16 * 16 * H;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e & 15), i = (int)((e >> 4) & 15);
+    const long long blk = e >> 8;                      // T * (H/16) + q-group
+    const int qg = (int)(blk % (H >> 4)), T = (int)(blk / (H >> 4));
+    const int row = T * 16 + i;
+    hx[e] = row < B ? h[(long long)row * H + qg * 16 + j] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void lds_barrier() {        // LDS traffic only: global loads stay in flight across it
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// PF: every workgroup owns >= 3 tiles -> the A fragments of item k + 2 are requested at the start of item k (three
+// register buffers in rotation); otherwise each item waits for and fetches its own operands (small batches).
+template <int NQ, bool PF>
+__global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(PersistFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[2][8][2][4][64];       // [item parity][wave][col half][acc reg][lane]: 32 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int ug, g;
+  {
+    const int b = blockIdx.x;
+    if (a.per > 0) { const int x = b & 7; g = x / a.per; ug = (b >> 3) * a.per + (x % a.per); }   // row group <-> XCD set (speed only)
+    else { g = b / a.NU; ug = b % a.NU; }
+  }
+  const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
+  const int n_it = (NT16 - g + RB - 1) / RB;            // tiles g, g + RB, ... of this workgroup
+  const int total = n_it * a.T;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t hxr = make_rsrc(a.hx, (unsigned)(2u * NT16 * (unsigned)H * 16u * 4u));
+  const int QH = H >> 4;                                // q-groups per row
+
+  // ---- recurrent weights of this (wave, unit group) -> registers -----------------------------------------------------
+  // B fragment of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kq = lane >> 4) supplies B[k = kq][n]; a float4 covers the four
+  // successive MFMAs e = 0..3 of a q-group (k = 16 q + 4 kq + e).  Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4),
+  // so the four gates of a unit are four neighbouring lanes of the result (a float4 of the LDS partial tile).
+  float4 Wr[NQ][2];
+#pragma unroll
+  for (int qg = 0; qg < NQ; ++qg) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const long long k = (long long)(w * NQ + qg) * 16 + kq * 4;
+      const long long col = (long long)(i16 & 3) * H + ug * 8 + ct * 4 + (i16 >> 2);
+      const float* p = a.Wh + k * a.ldw + col;
+      Wr[qg][ct] = make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
+    }
+  }
+
+  // A fragments of item (s, T), this wave's K range: exchange buffer parity s & 1, one coherent 1 KB block load per q-group
+  const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQ) * 1024u;
+  auto load_item = [&](float4 (&A)[NQ], int s, int T) {
+    const unsigned base = (unsigned)(((s & 1) * NT16 + T) * QH) * 1024u + lane_off;
+#pragma unroll
+    for (int qg = 0; qg < NQ; ++qg)
+      A[qg] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)qg * 1024u), 0, AUX_SYS));
+  };
+
+  float4 A0[NQ], A1[NQ], A2[NQ];
+  if (PF) {                                             // items 0 and 1 both belong to step 0 (n_it >= 3): no wait
+    load_item(A0, 0, g);
+    load_item(A1, 0, g + RB);
+  }
+
+  int s_cur = 0, it_cur = 0;                            // item k = (s_cur, it_cur)
+  const unsigned arrivals = (unsigned)a.NU * 2u;        // per (tile, step): 2 epilogue waves per workgroup
+
+  auto item = [&](float4 (&A)[NQ], float4 (&Anext)[NQ], int k) {
+    const int s = s_cur, T = g + it_cur * RB;
+    const int erow = tid >> 3, eunit = tid & 7;         // (row in tile, unit in group) for tid < 128
+    const int brow = T * 16 + erow;
+    const bool evalid = (w < 2) && (brow < B);
+    const int t = a.t0 + s;
+    if (PF) {                                           // request item k + 2 (the last two items re-request themselves: no branch
+      int s2 = s, it2 = it_cur + 2;                     // around the loads, the data is long published)
+      while (it2 >= n_it) { it2 -= n_it; ++s2; }
+      const bool have2 = k + 2 < total;
+      const int T2 = have2 ? g + it2 * RB : T;
+      s2 = have2 ? s2 : s;
+      wait_tile(a.ctl, T2, (unsigned)s2 * arrivals, lane);
+      load_item(Anext, s2, T2);
+    } else {
+      wait_tile(a.ctl, T, (unsigned)s * arrivals, lane);
+      load_item(A, s, T);
+    }
+    // epilogue operands (waves 0-1) do not depend on the product: requested now, AFTER the poll (whose own wait drains every
+    // older load) so that they travel under the MFMA block
+    float zpre[4] = {0.f, 0.f, 0.f, 0.f}, cpre = 0.f, hpre = 0.f;
+    int nfpre = 0x7fffffff;
+    if (evalid) {
+      const float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) zpre[g4] = zr[g4 * H];
+      const long long idx = ((long long)t * B + brow) * H + ug * 8 + eunit;
+      cpre = a.cs[idx];
+      hpre = a.hs[idx];
+      if (a.nf) nfpre = a.nf[brow];
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qg = 0; qg < NQ; ++qg) {
+      const float4 av = A[qg];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][0].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][1].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][0].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][1].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][0].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][1].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][0].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][1].w, acc1, 0, 0, 0);
+    }
+    float* rw = &red[k & 1][w][0][0][lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rw[r * 64] = acc0[r]; rw[256 + r * 64] = acc1[r]; }
+    lds_barrier();
+    if (w < 2) {
+      // C layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + r.  (row, unit): the four gate columns of the
+      // unit are lanes 16 (row / 4) + 4 (unit % 4) + {0..3} of register r = row % 4 in half ct = unit / 4 -> one float4.
+      const int ct = eunit >> 2, r = erow & 3, l0 = (erow >> 2) * 16 + (eunit & 3) * 4;
+      float4 sum = *reinterpret_cast<const float4*>(&red[k & 1][0][ct][r][l0]);
+#pragma unroll
+      for (int wv = 1; wv < 8; ++wv) {
+        const float4 p = *reinterpret_cast<const float4*>(&red[k & 1][wv][ct][r][l0]);
+        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+      }
+      float hn = 0.f;                                   // rows >= B publish zeros
+      if (evalid) {
+        const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
+        const bool live = t < nfpre;
+        float cn;
+        if (live) {
+          const float gi = sigmoidf_(zpre[0] + sum.x);
+          const float gj = tanhf(zpre[1] + sum.y);
+          const float gf = sigmoidf_(zpre[2] + sum.z + a.fb);
+          const float go = sigmoidf_(zpre[3] + sum.w);
+          cn = cpre * gf + gi * gj;
+          hn = tanhf(cn) * go;
+          float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
+          zr[0] = gi; zr[H] = gj; zr[2 * H] = gf; zr[3 * H] = go;
+        } else {                                        // dynamic_rnn copy-through: state passes, output is zero
+          cn = cpre;
+          hn = hpre;
+        }
+        a.cs[idx1] = cn;
+        a.hs[idx1] = hn;
+        if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live ? hn : 0.f;
+      }
+      if (s + 1 < a.T) {                                // publish h_t of this tile for the next step
+        const float h1 = __shfl_down(hn, 1, 64), h2 = __shfl_down(hn, 2, 64), h3 = __shfl_down(hn, 3, 64);
+        if ((eunit & 3) == 0) {
+          u32x4 v;
+          v.x = __float_as_uint(hn); v.y = __float_as_uint(h1); v.z = __float_as_uint(h2); v.w = __float_as_uint(h3);
+          const unsigned off = ((unsigned)((((s + 1) & 1) * NT16 + T) * QH + (ug >> 1)) * 256u +
+                                (unsigned)(erow * 16 + (ug & 1) * 8 + eunit)) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b128(v, hxr, (int)off, 0, AUX_SYS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+        if (lane == 0)
+          __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * 8 + (blockIdx.x & 7)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+  };
+
+  for (int k = 0; k < total; k += 3) {
+    item(A0, A2, k);
+    if (k + 1 < total) item(A1, A0, k + 1);
+    if (k + 2 < total) item(A2, A1, k + 2);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+struct PersistGate {            // chains persistent launches of one device (see the deadlock note above)
+  std::mutex mu;
+  hipEvent_t ev[16];
+  bool has[16];
+  PersistGate() { memset(has, 0, sizeof(has)); }
+};
+PersistGate g_gate;
+
+int device_cus(int* dev_out) {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  if (dev_out) *dev_out = dev;
+  return cus[dev];
+}
+
+struct Geometry { int NQ, NU, RB, NT16, per, pf; };
+
+bool persist_geometry(int64_t B, int64_t H, Geometry* geo) {
+  static const bool off = getenv("YT8M_NO_PERSIST") != nullptr;
+  if (off || B < 1 || H < 256 || (H % 128) != 0 || H > 1024) return false;
+  const int NQ = (int)(H / 128);
+  if (!(NQ == 2 || NQ == 4 || NQ == 6 || NQ == 8)) return false;
+  int dev = 0;
+  const int cus = device_cus(&dev);
+  const int NU = (int)(H / 8);
+  if (cus < NU) return false;
+  const int NT16 = (int)((B + 15) / 16);
+  int RB = cus / NU;
+  if (RB > NT16) RB = NT16;
+  if (NT16 >= 3 && RB > NT16 / 3) RB = NT16 / 3;         // keep >= 3 tiles per workgroup when the batch allows (prefetch mode)
+  if (RB < 1) RB = 1;
+  const int nit_min = NT16 / RB;                          // the last row group has floor(NT16 / RB) or one more
+  int per = 0;
+  if (RB <= 8 && (8 % RB) == 0 && (NU % (8 / RB)) == 0) per = 8 / RB;
+  if (geo) *geo = {NQ, NU, RB, NT16, per, nit_min >= 3 ? 1 : 0};
+  return true;
+}
+
+template <int NQ>
+int launch_fwd(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
+  if (a.pf) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, true>), dim3(grid), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, false>), dim3(grid), dim3(512), 0, s, a);
+  return yt8m::launch_status("lstm_persist_fwd_kernel");
+}
+
+int64_t ctl_bytes(int NT16) { return (int64_t)(CTL_HDR + NT16 * 8 * 32) * 4; }
+
+}  // namespace
+
+using namespace yt8m;
+
+extern "C" int yt8m_lstm_persist_supported(int64_t B, int64_t H) { return persist_geometry(B, H, nullptr) ? 1 : 0; }
+
+extern "C" int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H) {
+  Geometry geo;
+  if (!persist_geometry(B, H, &geo)) return 0;
+  // control block + exchange buffer sized for the BACKWARD pass (dz is 4H wide): [2][NT16][4H/16][256] floats
+  return ((ctl_bytes(geo.NT16) + 255) / 256) * 256 + (int64_t)2 * geo.NT16 * 16 * 4 * H * 4;
+}
+
+extern "C" int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream) {
+  YT8M_REQUIRE(workspace, YT8M_E_BADARG, "null workspace");
+  unsigned err = 0;
+  YT8M_HIP_CHECK(hipMemcpyAsync(&err, workspace, 4, hipMemcpyDeviceToHost, as_stream(stream)));
+  YT8M_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  if (err != 0) return fail(YT8M_E_HIP, "persistent LSTM launch timed out waiting for a tile%s", "");
+  return YT8M_OK;
+}
+
+extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
+                                     const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                                     void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (T * B * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(z && Wh && cs && hs && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldw >= 4 * H, YT8M_E_SHAPE, "ldw < 4H");
+  Geometry geo;
+  YT8M_REQUIRE(persist_geometry(B, H, &geo), YT8M_E_SHAPE, "shape not supported by the persistent recurrence (see yt8m_lstm_persist_supported)");
+  YT8M_REQUIRE(workspace_bytes >= yt8m_lstm_persist_workspace_bytes(B, H), YT8M_E_SHAPE, "workspace too small");
+  YT8M_REQUIRE(T < (1 << 20), YT8M_E_SHAPE, "T too large");
+  hipStream_t s = as_stream(stream);
+  const int64_t cb = ((ctl_bytes(geo.NT16) + 255) / 256) * 256;
+  PersistFwdArgs a;
+  a.z = z; a.Wh = Wh; a.ldw = ldw; a.cs = cs; a.hs = hs; a.out = out; a.nf = num_frames;
+  a.ctl = static_cast<unsigned*>(workspace);
+  a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
+  a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.fb = forget_bias;
+  a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
+  const unsigned grid = (unsigned)(geo.NU * geo.RB);
+  int dev = 0;
+  device_cus(&dev);
+  ProfScope prof(F_LSTM, s);
+  std::lock_guard<std::mutex> lk(g_gate.mu);
+  if (g_gate.has[dev]) YT8M_HIP_CHECK(hipStreamWaitEvent(s, g_gate.ev[dev], 0));
+  YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
+  hipLaunchKernelGGL(hx_pack_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, a.hx, (int)B, (int)H, geo.NT16);
+  int rc = launch_status("hx_pack_kernel");
+  if (rc != YT8M_OK) return rc;
+  switch (geo.NQ) {
+    case 2: rc = launch_fwd<2>(a, grid, s); break;
+    case 4: rc = launch_fwd<4>(a, grid, s); break;
+    case 6: rc = launch_fwd<6>(a, grid, s); break;
+    default: rc = launch_fwd<8>(a, grid, s); break;
+  }
+  if (rc != YT8M_OK) return rc;
+  if (!g_gate.has[dev]) {
+    YT8M_HIP_CHECK(hipEventCreateWithFlags(&g_gate.ev[dev], hipEventDisableTiming));
+    g_gate.has[dev] = true;
+  }
+  YT8M_HIP_CHECK(hipEventRecord(g_gate.ev[dev], s));
+  return YT8M_OK;
+}

@@ -260,6 +260,9 @@ def _chunks(F, n):
     return [(t0, min(step, F - t0)) for t0 in range(0, F, step)]
 
 
+import os as _os
+PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent recurrence kernels (csrc/lstm_persist.hip)
+PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 REC_BF16 = True       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
                       # products only
 
@@ -316,6 +319,9 @@ class _LstmStack(torch.autograd.Function):
                       out=torch.empty((F, B, H), dtype=torch.float32, device=dev))
             npk = lib.yt8m_lstm_packed_floats(B, H)
             st["Wp"] = torch.empty(npk, dtype=torch.float32, device=dev) if npk else None
+            # persistent recurrence (csrc/lstm_persist.hip): one launch per (layer, chunk), W_h resident in registers
+            pws = lib.yt8m_lstm_persist_workspace_bytes(B, H) if PERSIST else 0
+            st["pws"] = torch.empty(pws, dtype=torch.uint8, device=dev) if pws else None
             layers.append(st)
             inp = st["out"]
         start = torch.cuda.Event()
@@ -330,6 +336,8 @@ class _LstmStack(torch.autograd.Function):
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
                 st["bf16"] = bf16 and st["Din"] % 2 == 0
                 st["rec16"] = st["bf16"] and REC_BF16 and lib.yt8m_lstm_packed16_elems(B, st["H"]) > 0
+                if st["rec16"]:
+                    st["pws"] = None
                 if st["bf16"]:                                      # W_x^T once per step, K-contiguous for the NT product
                     st["WxT"] = ops.cast_bf16(st["W"].data[:st["Din"]], transpose=True)
                 if st["rec16"]:                                     # bf16 operands for the recurrent product too
@@ -364,6 +372,12 @@ class _LstmStack(torch.autograd.Function):
                     if st["rec16"]:
                         _lib.check(lib.yt8m_lstm_steps_fwd_bf16(_p(st["z"]), _p(st["Wp16"]), _p(st["cs"]), _p(st["hs"]), _p(st["hs16"]),
                                                                 _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _stream()))
+                    elif st["pws"] is not None:
+                        _lib.check(lib.yt8m_lstm_persist_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["cs"]), _p(st["hs"]),
+                                                             _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _p(st["pws"]),
+                                                             st["pws"].numel(), _stream()))
+                        if PERSIST_CHECK:
+                            _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
                     else:
                         _lib.check(lib.yt8m_lstm_steps_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["Wp"]), _p(st["cs"]),
                                                            _p(st["hs"]), _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias),
