@@ -34,7 +34,13 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int AUX_SYS = 17;                    // sc0 sc1: write-through store / coherent load (MI355X_MICROARCH.md, visibility)
+#ifndef YT8M_AUX_ST
+#define YT8M_AUX_ST 17
+#endif
+#ifndef YT8M_AUX_LD
+#define YT8M_AUX_LD 17
+#endif
+// aux 17 = sc0 sc1: write-through store / coherent load (MI355X_MICROARCH.md, inter-workgroup visibility)
 constexpr long long SPIN_TIMEOUT = 300000000;  // wall_clock64 ticks (100 MHz): 3 s
 constexpr int CTL_HDR = 32;                    // control block: [0] error word, counters from word 32
 
@@ -51,7 +57,18 @@ struct PersistFwdArgs {
   int t0, T, B, H;
   float fb;
   int NU, RB, NT16, per, pf;
+  unsigned long long* dbg;   // timing variant (-DYT8M_PERSIST_TIMING): s_memtime stamps of workgroup 0
 };
+
+#ifdef YT8M_PERSIST_TIMING
+#define STAMP(slot)                                                                                            \
+  do {                                                                                                         \
+    if (blockIdx.x == 0 && (w == 0 || w == 8) && lane == 0 && k < 256)                                          \
+      a.dbg[((w >> 3) * 256 + k) * 8 + (slot)] = __builtin_readcyclecounter();                                 \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -101,17 +118,48 @@ __global__ __launch_bounds__(256) void hx_pack_kernel(const float* __restrict__ 
   }
 }
 
-__device__ __forceinline__ void lds_barrier() {        // LDS traffic only: global loads stay in flight across it
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+// Gate non-linearities of the persistent kernels: v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the libm-exact expf / tanhf of
+// the per-step kernels -- the epilogue is a single wave's dependent chain on the critical path of the state exchange, and the
+// exact forms cost ~10x the instructions.  Absolute error <= ~1.5e-7 per value (checked against the exact kernels and the fp64
+// oracle by the parity tests; north_star tolerance 1e-3).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-// PF: every workgroup owns >= 3 tiles -> the A fragments of item k + 2 are requested at the start of item k (three
-// register buffers in rotation); otherwise each item waits for and fetches its own operands (small batches).
+__device__ __forceinline__ unsigned lds_load(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// bounded spin on an LDS word (intra-workgroup hand-offs between the MFMA waves and the epilogue waves)
+__device__ __forceinline__ void lds_wait_ge(const unsigned* p, unsigned target, unsigned* ctl) {
+  for (unsigned spins = 0; lds_load(p) < target; ++spins) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 4095) == 4095 && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  }
+}
+
+constexpr int NSLOT = 4;     // partial-tile slots in LDS (items k, k+4, ... share slot k & 3)
+constexpr int NEPI = 4;      // epilogue waves (item k is finished by epilogue wave k & 3)
+
+// Workgroup = 12 waves in two roles, coupled only through LDS counters (no s_barrier in the step loop):
+//   waves 0-7  "matrix" waves: K split 8-way, W_h slice in registers; per item: poll + request the A fragments of the NEXT item,
+//              64 MFMAs on the current one, partial 16x32 tile -> LDS slot, ds_add on the slot's arrival counter.
+//   waves 8-11 "epilogue" waves: wave 8 + (k & 3) finishes item k: waits for the 8 partial tiles, reduces them in a fixed order,
+//              gate math + cell update + copy-through for the 128 (row, unit) pairs (2 per lane), stores, publishes h_t of the
+//              tile (write-through stores -> drain -> arrival counter).  Four of them in rotation: an epilogue (~2 us with
+//              its store drain) has four item times, so the matrix pipe never waits for it.
+// PF: every workgroup owns >= 2 tiles -> the A fragments of item k + 1 are requested at the start of item k; otherwise each
+// item waits for and fetches its own operands (tiny batches).
 template <int NQ, bool PF>
-__global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(PersistFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[2][8][2][4][64];       // [item parity][wave][col half][acc reg][lane]: 32 KB
+__global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[NSLOT][8][2][4][64];   // [slot][wave][col half][acc reg][lane]: 64 KB
+  __shared__ unsigned lds_cnt[NSLOT], lds_free[NSLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < NSLOT) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
+  __syncthreads();
   int ug, g;
   {
     const int b = blockIdx.x;
@@ -121,145 +169,195 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
   const int n_it = (NT16 - g + RB - 1) / RB;            // tiles g, g + RB, ... of this workgroup
   const int total = n_it * a.T;
-  const int i16 = lane & 15, kq = lane >> 4;
   const __amdgpu_buffer_rsrc_t hxr = make_rsrc(a.hx, (unsigned)(2u * NT16 * (unsigned)H * 16u * 4u));
   const int QH = H >> 4;                                // q-groups per row
+  const unsigned arrivals = (unsigned)a.NU;             // per (tile, step): one epilogue wave per workgroup
 
-  // ---- recurrent weights of this (wave, unit group) -> registers -----------------------------------------------------
-  // B fragment of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kq = lane >> 4) supplies B[k = kq][n]; a float4 covers the four
-  // successive MFMAs e = 0..3 of a q-group (k = 16 q + 4 kq + e).  Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4),
-  // so the four gates of a unit are four neighbouring lanes of the result (a float4 of the LDS partial tile).
-  float4 Wr[NQ][2];
-#pragma unroll
-  for (int qg = 0; qg < NQ; ++qg) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const long long k = (long long)(w * NQ + qg) * 16 + kq * 4;
-      const long long col = (long long)(i16 & 3) * H + ug * 8 + ct * 4 + (i16 >> 2);
-      const float* p = a.Wh + k * a.ldw + col;
-      Wr[qg][ct] = make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
-    }
-  }
-
-  // A fragments of item (s, T), this wave's K range: exchange buffer parity s & 1, one coherent 1 KB block load per q-group
-  const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQ) * 1024u;
-  auto load_item = [&](float4 (&A)[NQ], int s, int T) {
-    const unsigned base = (unsigned)(((s & 1) * NT16 + T) * QH) * 1024u + lane_off;
-#pragma unroll
-    for (int qg = 0; qg < NQ; ++qg)
-      A[qg] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)qg * 1024u), 0, AUX_SYS));
-  };
-
-  float4 A0[NQ], A1[NQ], A2[NQ];
-  if (PF) {                                             // items 0 and 1 both belong to step 0 (n_it >= 3): no wait
-    load_item(A0, 0, g);
-    load_item(A1, 0, g + RB);
-  }
-
-  int s_cur = 0, it_cur = 0;                            // item k = (s_cur, it_cur)
-  const unsigned arrivals = (unsigned)a.NU * 2u;        // per (tile, step): 2 epilogue waves per workgroup
-
-  auto item = [&](float4 (&A)[NQ], float4 (&Anext)[NQ], int k) {
-    const int s = s_cur, T = g + it_cur * RB;
-    const int erow = tid >> 3, eunit = tid & 7;         // (row in tile, unit in group) for tid < 128
-    const int brow = T * 16 + erow;
-    const bool evalid = (w < 2) && (brow < B);
-    const int t = a.t0 + s;
-    if (PF) {                                           // request item k + 2 (the last two items re-request themselves: no branch
-      int s2 = s, it2 = it_cur + 2;                     // around the loads, the data is long published)
-      while (it2 >= n_it) { it2 -= n_it; ++s2; }
-      const bool have2 = k + 2 < total;
-      const int T2 = have2 ? g + it2 * RB : T;
-      s2 = have2 ? s2 : s;
-      wait_tile(a.ctl, T2, (unsigned)s2 * arrivals, lane);
-      load_item(Anext, s2, T2);
-    } else {
-      wait_tile(a.ctl, T, (unsigned)s * arrivals, lane);
-      load_item(A, s, T);
-    }
-    // epilogue operands (waves 0-1) do not depend on the product: requested now, AFTER the poll (whose own wait drains every
-    // older load) so that they travel under the MFMA block
-    float zpre[4] = {0.f, 0.f, 0.f, 0.f}, cpre = 0.f, hpre = 0.f;
-    int nfpre = 0x7fffffff;
-    if (evalid) {
-      const float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) zpre[g4] = zr[g4 * H];
-      const long long idx = ((long long)t * B + brow) * H + ug * 8 + eunit;
-      cpre = a.cs[idx];
-      hpre = a.hs[idx];
-      if (a.nf) nfpre = a.nf[brow];
-    }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if (w < 8) {
+    // =============================== matrix waves ===============================
+    const int i16 = lane & 15, kq = lane >> 4;
+    // B fragment of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kq = lane >> 4) supplies B[k = kq][n]; a float4 covers the
+    // four successive MFMAs e = 0..3 of a q-group (k = 16 q + 4 kq + e).  Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4),
+    // so the four gates of a unit are four neighbouring lanes of the result (a float4 of the LDS partial tile).
+    float4 Wr[NQ][2];
 #pragma unroll
     for (int qg = 0; qg < NQ; ++qg) {
-      const float4 av = A[qg];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][0].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][1].x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][0].y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][1].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][0].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][1].z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][0].w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][1].w, acc1, 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const long long k = (long long)(w * NQ + qg) * 16 + kq * 4;
+        const long long col = (long long)(i16 & 3) * H + ug * 8 + ct * 4 + (i16 >> 2);
+        const float* p = a.Wh + k * a.ldw + col;
+        Wr[qg][ct] = make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
+      }
     }
-    float* rw = &red[k & 1][w][0][0][lane];
+    // A fragments of item (s, T), this wave's K range: exchange buffer parity s & 1, one coherent 1 KB block load per q-group
+    const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQ) * 1024u;
+    auto load_item = [&](float4 (&A)[NQ], int s, int T) {
+      const unsigned base = (unsigned)(((s & 1) * NT16 + T) * QH) * 1024u + lane_off;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { rw[r * 64] = acc0[r]; rw[256 + r * 64] = acc1[r]; }
-    lds_barrier();
-    if (w < 2) {
-      // C layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + r.  (row, unit): the four gate columns of the
-      // unit are lanes 16 (row / 4) + 4 (unit % 4) + {0..3} of register r = row % 4 in half ct = unit / 4 -> one float4.
-      const int ct = eunit >> 2, r = erow & 3, l0 = (erow >> 2) * 16 + (eunit & 3) * 4;
-      float4 sum = *reinterpret_cast<const float4*>(&red[k & 1][0][ct][r][l0]);
+      for (int qg = 0; qg < NQ; ++qg)
+        A[qg] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)qg * 1024u), 0, YT8M_AUX_LD));
+    };
+    float4 A0[NQ], A1[NQ];
+    if (PF) load_item(A0, 0, g);                        // item 0 reads the packed initial state: nothing to wait for
+    int s_cur = 0, it_cur = 0;                          // item k = (s_cur, it_cur)
+    auto item = [&](float4 (&A)[NQ], float4 (&Anext)[NQ], int k) {
+      const int s = s_cur, T = g + it_cur * RB;
+      STAMP(0);
+      int s1 = s, T1 = T;
+      unsigned pv = 0;
+      if (PF) {                                         // item k + 1 (the last item re-requests itself: no branch around the
+        int it1 = it_cur + 1;                           // loads, that data is long published)
+        if (it1 == n_it) { it1 = 0; ++s1; }
+        const bool have1 = k + 1 < total;
+        T1 = have1 ? g + it1 * RB : T;
+        s1 = have1 ? s1 : s;
+        // speculative poll: the counter read travels under the first half of the MFMA block
+        if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        wait_tile(a.ctl, T, (unsigned)s * arrivals, lane);
+        load_item(A, s, T);
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int wv = 1; wv < 8; ++wv) {
-        const float4 p = *reinterpret_cast<const float4*>(&red[k & 1][wv][ct][r][l0]);
-        sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
-      }
-      float hn = 0.f;                                   // rows >= B publish zeros
-      if (evalid) {
-        const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
-        const bool live = t < nfpre;
-        float cn;
-        if (live) {
-          const float gi = sigmoidf_(zpre[0] + sum.x);
-          const float gj = tanhf(zpre[1] + sum.y);
-          const float gf = sigmoidf_(zpre[2] + sum.z + a.fb);
-          const float go = sigmoidf_(zpre[3] + sum.w);
-          cn = cpre * gf + gi * gj;
-          hn = tanhf(cn) * go;
-          float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
-          zr[0] = gi; zr[H] = gj; zr[2 * H] = gf; zr[3 * H] = go;
-        } else {                                        // dynamic_rnn copy-through: state passes, output is zero
-          cn = cpre;
-          hn = hpre;
+      for (int qg = 0; qg < NQ; ++qg) {
+        if (PF && qg == NQ / 2) {                       // mid-item: the next item's state must be complete now; request it
+          unsigned tot = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)pv, i);
+          if (tot < (unsigned)s1 * arrivals) wait_tile(a.ctl, T1, (unsigned)s1 * arrivals, lane);
+          load_item(Anext, s1, T1);
+          STAMP(1);
         }
-        a.cs[idx1] = cn;
-        a.hs[idx1] = hn;
-        if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live ? hn : 0.f;
+        const float4 av = A[qg];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][0].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][1].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][0].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][1].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][0].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][1].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][0].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][1].w, acc1, 0, 0, 0);
       }
-      if (s + 1 < a.T) {                                // publish h_t of this tile for the next step
-        const float h1 = __shfl_down(hn, 1, 64), h2 = __shfl_down(hn, 2, 64), h3 = __shfl_down(hn, 3, 64);
-        if ((eunit & 3) == 0) {
-          u32x4 v;
-          v.x = __float_as_uint(hn); v.y = __float_as_uint(h1); v.z = __float_as_uint(h2); v.w = __float_as_uint(h3);
-          const unsigned off = ((unsigned)((((s + 1) & 1) * NT16 + T) * QH + (ug >> 1)) * 256u +
-                                (unsigned)(erow * 16 + (ug & 1) * 8 + eunit)) * 4u;
-          __builtin_amdgcn_raw_buffer_store_b128(v, hxr, (int)off, 0, AUX_SYS);
+      STAMP(2);
+      const int slot = k & (NSLOT - 1);
+      if (k >= NSLOT) lds_wait_ge(&lds_free[slot], (unsigned)(k / NSLOT), a.ctl);   // the epilogue of item k - 4 has read its tiles
+      float* rw = &red[slot][w][0][0][lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { rw[r * 64] = acc0[r]; rw[256 + r * 64] = acc1[r]; }
+      // LDS executes a wave's operations in order: the arrival count lands behind the tile, no wait needed in between
+      if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      STAMP(3);
+      if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+    };
+    for (int k = 0; k < total; k += 2) {
+      item(A0, A1, k);
+      if (k + 1 < total) item(A1, A0, k + 1);
+    }
+    return;
+  }
+
+  // =============================== epilogue waves ===============================
+  // Epilogue wave ew owns the tiles it = ew, ew + 4, ... of this workgroup for ALL steps: the c / h it reloads at step s + 1
+  // are its own stores of step s (same wave: program order), never another wave's.
+  const int ew = w - 8;
+  const int eunit = lane & 7;
+#ifndef YT8M_EPI_PRIO
+#define YT8M_EPI_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);             // the epilogue is the latency-critical chain: win VALU issue arbitration
+  for (int s = 0; s < a.T; ++s) {
+    const int t = a.t0 + s;
+    for (int it = ew; it < n_it; it += NEPI) {
+      const int k = s * n_it + it;
+      const int T = g + it * RB;
+      STAMP(0);
+      // pairs j = 0, 1: (row in tile = 8 j + lane / 8, unit in group = lane % 8).  Operands that do not depend on the product
+      // are requested before the wait; rows >= B are clamped (never stored) so that the loads stay branch-free.
+      float zpre[2][4], cpre[2], hpre[2];
+      bool live[2], evalid[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int brow = T * 16 + 8 * j + (lane >> 3);
+        evalid[j] = brow < B;
+        const int br = evalid[j] ? brow : B - 1;
+        const float* zr = a.z + ((long long)t * B + br) * 4 * H + ug * 8 + eunit;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) zpre[j][g4] = zr[g4 * H];
+        const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
+        cpre[j] = a.cs[idx];
+        hpre[j] = a.hs[idx];
+        live[j] = a.nf ? (t < a.nf[br]) : true;
+      }
+      const int slot = k & (NSLOT - 1);
+      lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(k / NSLOT + 1), a.ctl);
+      STAMP(1);
+      // C layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + r.  (row, unit): the four gate columns of the unit
+      // are lanes 16 (row / 4) + 4 (unit % 4) + {0..3} of register r = row % 4 in half ct = unit / 4 -> one float4 per matrix wave.
+      float4 sum[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int erow = 8 * j + (lane >> 3);
+        const int ct = eunit >> 2, r = erow & 3, l0 = (erow >> 2) * 16 + (eunit & 3) * 4;
+        sum[j] = *reinterpret_cast<const float4*>(&red[slot][0][ct][r][l0]);
+#pragma unroll
+        for (int wv = 1; wv < 8; ++wv) {
+          const float4 p = *reinterpret_cast<const float4*>(&red[slot][wv][ct][r][l0]);
+          sum[j].x += p.x; sum[j].y += p.y; sum[j].z += p.z; sum[j].w += p.w;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+      }
+      // (in-order LDS: the release of the slot is queued behind the reads above)
+      if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      STAMP(2);
+      // gate block (BasicLSTMCell: i | j | f | o, forget_bias on f), branch-free; sigmoid / tanh on v_exp_f32 + v_rcp_f32
+      float gi[2], gj[2], gf[2], go[2], cn[2], hn[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        gi[j] = fast_sigmoid(zpre[j][0] + sum[j].x);
+        gj[j] = fast_tanh(zpre[j][1] + sum[j].y);
+        gf[j] = fast_sigmoid(zpre[j][2] + sum[j].z + a.fb);
+        go[j] = fast_sigmoid(zpre[j][3] + sum[j].w);
+        const float c1 = cpre[j] * gf[j] + gi[j] * gj[j];
+        const float h1 = fast_tanh(c1) * go[j];
+        cn[j] = live[j] ? c1 : cpre[j];                  // dynamic_rnn copy-through: the state passes, the output is zero
+        hn[j] = live[j] ? h1 : hpre[j];
+        if (!evalid[j]) hn[j] = 0.f;                     // rows >= B publish zeros
+      }
+      if (s + 1 < a.T) {                                 // publish h_t of this tile first: it is what the other workgroups wait for
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float h1 = __shfl_down(hn[j], 1, 64), h2 = __shfl_down(hn[j], 2, 64), h3 = __shfl_down(hn[j], 3, 64);
+          if ((eunit & 3) == 0) {
+            u32x4 v;
+            v.x = __float_as_uint(hn[j]); v.y = __float_as_uint(h1); v.z = __float_as_uint(h2); v.w = __float_as_uint(h3);
+            const int erow = 8 * j + (lane >> 3);
+            const unsigned off = ((unsigned)((((s + 1) & 1) * NT16 + T) * QH + (ug >> 1)) * 256u +
+                                  (unsigned)(erow * 16 + (ug & 1) * 8 + eunit)) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, hxr, (int)off, 0, YT8M_AUX_ST);
+          }
+        }
+        STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the write-through stores, then count the arrival
         if (lane == 0)
           __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * 8 + (blockIdx.x & 7)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        STAMP(4);
+      }
+      // everything the backward pass / the caller needs, in the standard layouts (nobody inside this launch waits for these)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (evalid[j]) {
+          const int brow = T * 16 + 8 * j + (lane >> 3);
+          const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
+          if (live[j]) {
+            float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
+            zr[0] = gi[j]; zr[H] = gj[j]; zr[2 * H] = gf[j]; zr[3 * H] = go[j];
+          }
+          a.cs[idx1] = cn[j];
+          a.hs[idx1] = hn[j];
+          if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live[j] ? hn[j] : 0.f;
+        }
       }
     }
-    if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
-  };
-
-  for (int k = 0; k < total; k += 3) {
-    item(A0, A2, k);
-    if (k + 1 < total) item(A1, A0, k + 1);
-    if (k + 2 < total) item(A2, A1, k + 2);
   }
 }
 
@@ -299,22 +397,23 @@ bool persist_geometry(int64_t B, int64_t H, Geometry* geo) {
   const int NT16 = (int)((B + 15) / 16);
   int RB = cus / NU;
   if (RB > NT16) RB = NT16;
-  if (NT16 >= 3 && RB > NT16 / 3) RB = NT16 / 3;         // keep >= 3 tiles per workgroup when the batch allows (prefetch mode)
-  if (RB < 1) RB = 1;
+  if (RB > NT16 / 4) RB = NT16 / 4;                      // >= 4 tiles per workgroup when the batch allows: four independent chains
+  if (RB < 1) RB = 1;                                    // hide the exchange latency (publish -> visible -> fetched ~ 2 item times)
   const int nit_min = NT16 / RB;                          // the last row group has floor(NT16 / RB) or one more
   int per = 0;
   if (RB <= 8 && (8 % RB) == 0 && (NU % (8 / RB)) == 0) per = 8 / RB;
-  if (geo) *geo = {NQ, NU, RB, NT16, per, nit_min >= 3 ? 1 : 0};
+  if (geo) *geo = {NQ, NU, RB, NT16, per, nit_min >= 2 ? 1 : 0};
   return true;
 }
 
 template <int NQ>
 int launch_fwd(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
-  if (a.pf) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, true>), dim3(grid), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, false>), dim3(grid), dim3(512), 0, s, a);
+  if (a.pf) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, true>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, false>), dim3(grid), dim3(768), 0, s, a);
   return yt8m::launch_status("lstm_persist_fwd_kernel");
 }
 
+constexpr int64_t DBG_BYTES = 65536;     // tail of the workspace: s_memtime stamps of the timing variant
 int64_t ctl_bytes(int NT16) { return (int64_t)(CTL_HDR + NT16 * 8 * 32) * 4; }
 
 }  // namespace
@@ -327,7 +426,7 @@ extern "C" int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H) {
   Geometry geo;
   if (!persist_geometry(B, H, &geo)) return 0;
   // control block + exchange buffer sized for the BACKWARD pass (dz is 4H wide): [2][NT16][4H/16][256] floats
-  return ((ctl_bytes(geo.NT16) + 255) / 256) * 256 + (int64_t)2 * geo.NT16 * 16 * 4 * H * 4;
+  return ((ctl_bytes(geo.NT16) + 255) / 256) * 256 + (int64_t)2 * geo.NT16 * 16 * 4 * H * 4 + DBG_BYTES;
 }
 
 extern "C" int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream) {
@@ -358,6 +457,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.fb = forget_bias;
   a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
+  a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + yt8m_lstm_persist_workspace_bytes(B, H) - DBG_BYTES);
   const unsigned grid = (unsigned)(geo.NU * geo.RB);
   int dev = 0;
   device_cus(&dev);
