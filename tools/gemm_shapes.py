@@ -20,6 +20,21 @@ SHAPES = [  # (label, transA, transB, [(M, N, K), ...])
     ("head dW   K=8192", True, False, [(1152, 14148, 8192), (1152, 9432, 8192)]),
     ("head dx   K=23580", False, True, [(8192, 1152, 14148), (8192, 1152, 9432)]),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "lstm":       # the hoisted products of BASELINE configs[3] (B = 128, F = 300)
+    SHAPES = [
+        ("L0 proj  [38400,1152]x[1152,4096]", False, False, [(38400, 4096, 1152)]),
+        ("L1 proj  [38400,1024]x[1024,4096]", False, False, [(38400, 4096, 1024)]),
+        ("L1 dx    [38400,4096]x[1024,4096]^T", False, True, [(38400, 1024, 4096)]),
+        ("L0 dWx   [38400,1152]^T x dz", True, False, [(1152, 4096, 38400)]),
+        ("L dWh    [38400,1024]^T x dz", True, False, [(1024, 4096, 38400)]),
+        ("L0 dWx+dWh grouped", True, False, [(1152, 4096, 38400), (1024, 4096, 38400)]),
+        ("chunk dWx+dWh K=9600 grouped", True, False, [(1152, 4096, 9600), (1024, 4096, 9600)]),
+        ("chunk proj M=9600", False, False, [(9600, 4096, 1152)]),
+        ("chunk dx M=9600", False, True, [(9600, 1024, 4096)]),
+        ("head fwd [128,4096]x[4096,23580]", False, False, [(128, 14148, 4096), (128, 9432, 4096)]),
+        ("head dW  [128,4096]^T x dZ", True, False, [(4096, 14148, 128), (4096, 9432, 128)]),
+        ("head dx", False, True, [(128, 4096, 14148), (128, 4096, 9432)]),
+    ]
 _w = torch.randn(4096, 4096, device=dev)
 for _ in range(60):                      # ~70 ms of load first: the clocks of an idle box take a while to ramp
     ops.gemm(_w, _w)

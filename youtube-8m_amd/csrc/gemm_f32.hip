@@ -716,7 +716,8 @@ static int gemm_launch(int transA, int transB, int64_t M, int64_t N, int64_t K, 
   return launch_status("gemm_f32_kernel");
 }
 
-extern "C" int64_t yt8m_gemm_workspace_bytes(void) { return (int64_t)SLOTS * BM * BN * (int64_t)sizeof(float); }
+// room for 4096 split-K parts of 128 x 128 accumulators (256 MiB): several rounds of parts for long-K, few-tile problems
+extern "C" int64_t yt8m_gemm_workspace_bytes(void) { return (int64_t)4096 * BM * BN * (int64_t)sizeof(float); }
 
 static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8m_gemm_problem* probs, void* workspace,
                           int64_t workspace_bytes, yt8m_stream_t stream) {
@@ -761,17 +762,27 @@ static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8
     G.rem = (int)T;
   }
   if (G.rem > 0) {
-    int S = G.P / G.rem;
-    int min_nk = 1 << 30;
+    // Split factor of the remainder tiles, by a cost model in K-steps: ceil(rem * S / P) rounds of parts, each nk / S steps long
+    // plus a fixed per-item cost (prologue, epilogue / workspace round trip ~ 8 K-steps).  Long-K, few-tile problems (the LSTM
+    // weight gradients: 288 + 256 tiles, K = 38400) used to run ONE round at 544 / 768 slot fill -- three co-resident tiles
+    // on some CUs, two on others, i.e. 71 % of the matrix pipe; S = 7 fills five rounds to 99 %.
+    int min_nk = 1 << 30, max_nk = 0;
     for (int i = 0; i < G.nprob; ++i) {
       const int nk = (G.p[i].K + BK - 1) / BK;
       if (nk < min_nk) min_nk = nk;
+      if (nk > max_nk) max_nk = nk;
     }
-    if (S > min_nk / 8) S = min_nk / 8;     // keep >= 8 K-steps per part (pipeline fill + epilogue amortisation)
-    if (S > 32 && G.rem > 16) S = 32;        // many parts per tile only for few-tile problems with a very long K (NetVLAD FC at
-    if (S > 96) S = 96;                       // B = 128: 8 tiles, K = 73728): their weight stream needs the whole chip
-    if (S < 1) S = 1;
-    if (S > 1 && (!workspace || workspace_bytes < (int64_t)G.rem * S * BM * BN * (int64_t)sizeof(float))) S = 1;
+    int Smax = min_nk / 8;                    // keep >= 8 K-steps per part (pipeline fill + epilogue amortisation)
+    if (Smax > 96) Smax = 96;
+    const int64_t ws_items = workspace ? workspace_bytes / ((int64_t)BM * BN * (int64_t)sizeof(float)) : 0;
+    if ((int64_t)G.rem * Smax > ws_items) Smax = (int)(ws_items / G.rem);
+    int S = 1;
+    double best = 1e30;
+    for (int c = 1; c <= Smax; ++c) {
+      const int64_t rounds = ((int64_t)G.rem * c + G.P - 1) / G.P;
+      const double cost = (double)rounds * ((double)max_nk / c + 8.0) + (c > 1 ? 2.0 : 0.0);
+      if (cost < best * 0.98) { best = cost; S = c; }     // a larger split must buy >= 2 %
+    }
     G.S = S;
   }
   hipStream_t s = as_stream(stream);

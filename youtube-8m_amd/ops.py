@@ -66,7 +66,7 @@ _WS = {}
 
 
 def _workspace(device):
-    """Split-K workspace of the persistent GEMM: one per (device, stream) -- ~48 MiB each of the 288 GB -- so that GEMMs
+    """Split-K workspace of the persistent GEMM: one per (device, stream) -- 256 MiB each of the 288 GB -- so that GEMMs
     running concurrently on different streams (the pipelined LSTM stack) never share scratch."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
