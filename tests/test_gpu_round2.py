@@ -151,3 +151,79 @@ def test_clip_gradient_norms_reference_signature(dev):
     out = utils.clip_gradient_norms([(g1, "a"), (None, "b"), (g2, "c")], 1.0)
     assert [v for _, v in out] == ["a", "b", "c"] and out[1][0] is None
     assert abs(float(out[0][0].norm()) - 1.0) < 1e-6 and torch.equal(out[2][0], g2)
+
+
+# ---- persistent LSTM recurrence (csrc/lstm_persist.hip) vs the per-step kernels and the oracle -------------------------------
+def _stack_run(dev, B, F, D, H, L_, chunks, nf, persist, seed=0):
+    import yt8m_amd.seq_ops as seq_ops
+    from yt8m_amd.variables import xavier_uniform, zeros
+    old = (seq_ops.PERSIST, seq_ops.PERSIST_BWD, seq_ops.PERSIST_CHECK)
+    seq_ops.PERSIST, seq_ops.PERSIST_BWD, seq_ops.PERSIST_CHECK = persist, persist, True
+    try:
+        g = reset_default_graph(device=dev, seed=seed)
+        g.begin_step()
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        x = (torch.rand((F, B, D), device=dev, generator=gen) - 0.5)
+        wb, d_in = [], D
+        for l in range(L_):
+            wb.append((g.get_variable("l%d/w" % l, (d_in + H, 4 * H), xavier_uniform), g.get_variable("l%d/b" % l, (4 * H,), zeros)))
+            d_in = H
+        g.finalize()
+        x.requires_grad_(True)
+        out, finals = seq_ops.lstm_stack(x, nf, wb, chunks=chunks)
+        res = [out] + [t for p in finals for t in p]
+        gen2 = torch.Generator(device=dev).manual_seed(7)
+        sum((r * torch.rand(r.shape, device=dev, generator=gen2)).sum() for r in res).backward()
+        torch.cuda.synchronize()
+        P = [(w.data.detach().cpu().double(), b.data.detach().cpu().double()) for w, b in wb]
+        return [r.detach().cpu() for r in res], [x.grad.detach().cpu(), g.grads.detach().cpu().clone()], x.detach().cpu().double(), P
+    finally:
+        seq_ops.PERSIST, seq_ops.PERSIST_BWD, seq_ops.PERSIST_CHECK = old
+
+
+@pytest.mark.parametrize("B,F,D,H,L_,chunks,ragged", [
+    (8, 9, 64, 256, 2, 1, True),          # one tile per workgroup: no prefetch ("cold" mode), H = 256
+    (50, 12, 96, 512, 2, 2, True),        # rows padded to a multiple of 16, two time chunks
+    (128, 16, 1152, 1024, 2, 1, False),   # BASELINE configs[3] shape (short sequence)
+    (128, 24, 1152, 1024, 2, 4, True),    # ragged num_frames incl. 0 and F, four chunks
+    (512, 6, 128, 1024, 1, 1, True),      # 32 tiles: several per workgroup
+])
+def test_persistent_lstm_matches_step_kernels(dev, B, F, D, H, L_, chunks, ragged):
+    """Forward outputs / final states and all gradients of the persistent recurrence agree with the per-step kernels (which are
+    checked against the oracle elsewhere) to fp32 rounding: the only arithmetic differences are the K summation order and the
+    v_exp_f32 / v_rcp_f32 gate non-linearities (<= 1.5e-7 absolute each)."""
+    import yt8m_amd._lib as L
+    if not L.lib().yt8m_lstm_persist_supported(B, H):
+        pytest.skip("persistent recurrence not available for this shape / device")
+    nf = None
+    if ragged:
+        nf = torch.randint(0, F + 1, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(3), dtype=torch.int32)
+        nf[0], nf[1] = F, 0
+    a, ga, _, _ = _stack_run(dev, B, F, D, H, L_, chunks, nf, True)
+    b, gb, _, _ = _stack_run(dev, B, F, D, H, L_, chunks, nf, False)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) < 5e-6
+    for u, v in zip(ga, gb):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-9
+
+
+def test_persistent_lstm_vs_fp64_oracle_full_width(dev):
+    """H = 1024 (the BASELINE width) forward AND backward against fp64 autograd of the oracle restatement on three videos'
+    worth of rows per tile pattern: B = 20 (two 16-row tiles, the second padded), F = 10, ragged lengths."""
+    from oracle import torch_ref
+    B, F, D, H = 20, 10, 96, 1024
+    nf = torch.tensor([10, 0, 3, 10, 7, 1, 9, 10, 2, 5, 10, 4, 6, 8, 10, 10, 3, 0, 10, 7], device=dev, dtype=torch.int32)
+    res, grads, x64, P = _stack_run(dev, B, F, D, H, 2, 1, nf, True)
+    xs = x64.transpose(0, 1).clone().requires_grad_(True)          # oracle takes [B,F,D]
+    layers = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in P]
+    out, c, h = torch_ref.lstm_stack(xs, nf.cpu(), layers)
+    ref = [out.transpose(0, 1)] + [t for pair in zip(c, h) for t in pair]
+    for u, v in zip(res, ref):
+        assert float((u.double() - v).abs().max()) < 2e-5
+    gen2 = torch.Generator(device=dev).manual_seed(7)
+    loss = sum((r * torch.rand(r.shape, device=dev, generator=gen2).cpu().double()).sum() for r in ref)
+    loss.backward()
+    dx_ref = xs.grad.transpose(0, 1)
+    assert float((grads[0].double() - dx_ref).abs().max()) <= 1e-4 * float(dx_ref.abs().max())
+    gW = torch.cat([t.grad.reshape(-1) for pair in layers for t in pair])
+    assert float((grads[1].double() - gW).abs().max()) <= 1e-4 * float(gW.abs().max())

@@ -16,10 +16,12 @@ from yt8m_amd.variables import reset_default_graph, xavier_uniform, zeros  # noq
 
 dev = torch.device("cuda:0")
 seq_ops.PERSIST_CHECK = True
+MODE = 1 if os.environ.get("PCHECK_FWD_ONLY") else 2      # 1: persistent forward only, 2: forward + backward
 
 
 def run(B, F, D, H, L_, chunks, nf, persist, seed=0, backward=True):
-    seq_ops.PERSIST = persist
+    seq_ops.PERSIST = bool(persist)
+    seq_ops.PERSIST_BWD = persist == 2 or persist is True
     g = reset_default_graph(device=dev, seed=seed)
     g.begin_step()
     gen = torch.Generator(device=dev).manual_seed(seed)
@@ -51,7 +53,7 @@ def compare(tag, B, F, D, H, L_, chunks, ragged):
         nf[0] = F
         if B > 1:
             nf[1] = 0
-    a, ga = run(B, F, D, H, L_, chunks, nf, True)
+    a, ga = run(B, F, D, H, L_, chunks, nf, MODE)
     b, gb = run(B, F, D, H, L_, chunks, nf, False)
     md = max(float((u - v).abs().max()) for u, v in zip(a, b))
     mg = max(float((u - v).abs().max() / (v.abs().max() + 1e-30)) for u, v in zip(ga, gb))
@@ -93,6 +95,29 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
               flush=True)
 
 
+def timing_bwd(B=128, F=300, H=1024):
+    lib = L.lib()
+    from yt8m_amd.ops import _p, _stream
+    gates = torch.rand((F, B, 4 * H), device=dev)
+    Wh = (torch.rand((H, 4 * H), device=dev) - 0.5) * 0.06
+    cs = torch.randn((F + 1, B, H), device=dev) * 0.5
+    dz = torch.empty((F, B, 4 * H), device=dev)
+    dout = torch.randn((F, B, H), device=dev) * 0.01
+    pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes(B, H), dtype=torch.uint8, device=dev)
+    for it in range(3):
+        work = torch.zeros((4, B, H), device=dev)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, 0, F, B, H, _p(pws),
+                                          pws.numel(), _stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        print("persistent bwd kernel: %.3f ms for %d steps = %.2f us/step" % (e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F),
+              flush=True)
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
     compare("small cold H=256", 8, 9, 64, 256, 2, 1, 1)
@@ -101,4 +126,5 @@ if __name__ == "__main__":
     compare("headline ragged chunks=4", 128, 24, 1152, 1024, 2, 4, 1)
     compare("big batch", 512, 6, 128, 1024, 1, 1, 1)
     if len(sys.argv) > 1:
+        timing_bwd()
         timing()

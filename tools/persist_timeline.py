@@ -24,7 +24,22 @@ hs = torch.zeros((F + 1, B, H), device=dev)
 out = torch.empty((F, B, H), device=dev)
 nb = lib.yt8m_lstm_persist_workspace_bytes(B, H)
 pws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
+gates = torch.rand((F, B, 4 * H), device=dev)
+csr = torch.randn((F + 1, B, H), device=dev) * 0.5
+dz = torch.empty((F, B, 4 * H), device=dev)
+dout = torch.randn((F, B, H), device=dev) * 0.01
 for it in range(2):
+    if BWD:
+        work = torch.zeros((4, B, H), device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(csr), _p(dout), _p(dz), _p(work), 0, None, 0, F, B, H, _p(pws), nb,
+                                          _stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        print("bwd kernel %.3f ms = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / F))
+        continue
     z = z0.clone()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -37,7 +52,7 @@ for wsel, wname, names in ((0, "matrix wave 0", ["start", "polled + next loads i
                            (1, "epilogue wave 8 (every 4th item)", ["start (operand loads issued)", "partials arrived", "reduced",
                                                                     "stores issued", "drained"])):
     d = dbg[wsel]
-    ks = np.arange(40, 104) if wsel == 0 else np.arange(40, 104, 4)
+    ks = np.arange(40, 104) if (wsel == 0 or BWD) else np.arange(40, 104, 4)
     print(wname, "-- cycles (mean / min / max)")
     period = np.diff(d[ks, 0])
     print("  %-34s %8.0f %8.0f %8.0f" % ("period", period.mean(), period.min(), period.max()))
@@ -45,7 +60,7 @@ for wsel, wname, names in ((0, "matrix wave 0", ["start", "polled + next loads i
         seg = d[ks, i + 1] - d[ks, i]
         print("  %-34s %8.0f %8.0f %8.0f" % (names[i] + " -> " + names[i + 1][:12], seg.mean(), seg.min(), seg.max()))
 m, e = dbg[0], dbg[1]
-ks = np.arange(40, 104, 4)
+ks = np.arange(40, 104) if BWD else np.arange(40, 104, 4)
 lag = e[ks, 4] - m[ks, 3]
 print("matrix wave 0 partials written -> epilogue drained (publish latency) %8.0f %8.0f %8.0f" % (lag.mean(), lag.min(), lag.max()))
 chain = m[43:104, 1] - m[40:101, 3]

@@ -34,6 +34,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef YT8M_FWD_POLLQ
+#define YT8M_FWD_POLLQ 2     // where in an item (quarters of its MFMA block) the state of the item PD ahead is requested
+#endif
 #ifndef YT8M_AUX_ST
 #define YT8M_AUX_ST 17
 #endif
@@ -129,6 +132,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// value of lane + N within a row of 16 lanes (DPP row_shl: one VALU op; __shfl_down is a ds_bpermute round trip through LDS)
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ unsigned lds_load(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -152,14 +161,17 @@ constexpr int NEPI = 4;      // epilogue waves (item k is finished by epilogue w
 //              its store drain) has four item times, so the matrix pipe never waits for it.
 // PF: every workgroup owns >= 2 tiles -> the A fragments of item k + 1 are requested at the start of item k; otherwise each
 // item waits for and fetches its own operands (tiny batches).
-template <int NQ, bool PF>
+// PD = how many items ahead the A fragments are requested: 2 when every workgroup owns >= 4 tiles (three register buffers in
+// rotation; the coherent loads take ~2 us under load, more than one item of matrix work), 1 for 2-3 tiles, 0 (each item waits
+// for and fetches its own operands) for a single tile.
+template <int NQ, int PD>
 __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a) {
+  constexpr int HQ = NQ / 2;                             // q-groups per wave whose weights sit in registers (the rest: LDS)
   __shared__ __attribute__((aligned(16))) float red[NSLOT][8][2][4][64];   // [slot][wave][col half][acc reg][lane]: 64 KB
+  __shared__ __attribute__((aligned(16))) float4 Wl[8][HQ][2][64];         // LDS-resident half of W_h's slice: 8 * HQ * 2 KB
   __shared__ unsigned lds_cnt[NSLOT], lds_free[NSLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid < NSLOT) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
-  __syncthreads();
   int ug, g;
   {
     const int b = blockIdx.x;
@@ -172,24 +184,32 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   const __amdgpu_buffer_rsrc_t hxr = make_rsrc(a.hx, (unsigned)(2u * NT16 * (unsigned)H * 16u * 4u));
   const int QH = H >> 4;                                // q-groups per row
   const unsigned arrivals = (unsigned)a.NU;             // per (tile, step): one epilogue wave per workgroup
+  // B fragment of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kq = lane >> 4) supplies B[k = kq][n]; a float4 covers the four
+  // successive MFMAs e = 0..3 of a q-group (k = 16 q + 4 kq + e).  Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4), so
+  // the four gates of a unit are four neighbouring lanes of the result (a float4 of the LDS partial tile).
+  auto w_frag = [&](int qg, int ct) -> float4 {
+    const int i16 = lane & 15, kq = lane >> 4;
+    const long long k = (long long)(w * NQ + qg) * 16 + kq * 4;
+    const long long col = (long long)(i16 & 3) * H + ug * 8 + ct * 4 + (i16 >> 2);
+    const float* p = a.Wh + k * a.ldw + col;
+    return make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
+  };
+  if (tid < NSLOT) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
+  if (w < 8) {
+#pragma unroll
+    for (int qq = 0; qq < HQ; ++qq) {
+      Wl[w][qq][0][lane] = w_frag(HQ + qq, 0);
+      Wl[w][qq][1][lane] = w_frag(HQ + qq, 1);
+    }
+  }
+  __syncthreads();
 
   if (w < 8) {
     // =============================== matrix waves ===============================
     const int i16 = lane & 15, kq = lane >> 4;
-    // B fragment of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kq = lane >> 4) supplies B[k = kq][n]; a float4 covers the
-    // four successive MFMAs e = 0..3 of a q-group (k = 16 q + 4 kq + e).  Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4),
-    // so the four gates of a unit are four neighbouring lanes of the result (a float4 of the LDS partial tile).
-    float4 Wr[NQ][2];
+    float4 Wr[HQ][2];
 #pragma unroll
-    for (int qg = 0; qg < NQ; ++qg) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const long long k = (long long)(w * NQ + qg) * 16 + kq * 4;
-        const long long col = (long long)(i16 & 3) * H + ug * 8 + ct * 4 + (i16 >> 2);
-        const float* p = a.Wh + k * a.ldw + col;
-        Wr[qg][ct] = make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
-      }
-    }
+    for (int qg = 0; qg < HQ; ++qg) { Wr[qg][0] = w_frag(qg, 0); Wr[qg][1] = w_frag(qg, 1); }
     // A fragments of item (s, T), this wave's K range: exchange buffer parity s & 1, one coherent 1 KB block load per q-group
     const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQ) * 1024u;
     auto load_item = [&](float4 (&A)[NQ], int s, int T) {
@@ -198,22 +218,24 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
       for (int qg = 0; qg < NQ; ++qg)
         A[qg] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)qg * 1024u), 0, YT8M_AUX_LD));
     };
-    float4 A0[NQ], A1[NQ];
-    if (PF) load_item(A0, 0, g);                        // item 0 reads the packed initial state: nothing to wait for
+    float4 A0[NQ], A1[NQ], A2[NQ];
+    if (PD >= 1) load_item(A0, 0, g);                   // items 0 (and 1) read the packed initial state: nothing to wait for
+    if (PD >= 2 && total > 1) load_item(A1, 0, g + RB);
     int s_cur = 0, it_cur = 0;                          // item k = (s_cur, it_cur)
-    auto item = [&](float4 (&A)[NQ], float4 (&Anext)[NQ], int k) {
+    // A = this item's fragments, Areq = the buffer the item PD ahead goes to
+    auto item = [&](float4 (&A)[NQ], float4 (&Areq)[NQ], int k) {
       const int s = s_cur, T = g + it_cur * RB;
       STAMP(0);
-      int s1 = s, T1 = T;
-      unsigned pv = 0;
-      if (PF) {                                         // item k + 1 (the last item re-requests itself: no branch around the
-        int it1 = it_cur + 1;                           // loads, that data is long published)
-        if (it1 == n_it) { it1 = 0; ++s1; }
-        const bool have1 = k + 1 < total;
-        T1 = have1 ? g + it1 * RB : T;
-        s1 = have1 ? s1 : s;
-        // speculative poll: the counter read travels under the first half of the MFMA block
-        if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int sr = s, Tr = T;                               // item k + PD (the last PD items re-request themselves: no branch
+      unsigned pv = 0;                                  // around the loads, that data is long published)
+      if (PD >= 1) {
+        int itr = it_cur + PD;
+        while (itr >= n_it) { itr -= n_it; ++sr; }
+        const bool have = k + PD < total;
+        Tr = have ? g + itr * RB : T;
+        sr = have ? sr : s;
+        // speculative poll: the counter read travels under the first MFMAs
+        if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (Tr * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         wait_tile(a.ctl, T, (unsigned)s * arrivals, lane);
         load_item(A, s, T);
@@ -221,23 +243,26 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int qg = 0; qg < NQ; ++qg) {
-        if (PF && qg == NQ / 2) {                       // mid-item: the next item's state must be complete now; request it
+        if (PD >= 1 && qg == (NQ * YT8M_FWD_POLLQ) / 4) {   // request point: the state of item k + PD must be complete now
           unsigned tot = 0;
 #pragma unroll
           for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)pv, i);
-          if (tot < (unsigned)s1 * arrivals) wait_tile(a.ctl, T1, (unsigned)s1 * arrivals, lane);
-          load_item(Anext, s1, T1);
+          if (tot < (unsigned)sr * arrivals) wait_tile(a.ctl, Tr, (unsigned)sr * arrivals, lane);
+          load_item(Areq, sr, Tr);
           STAMP(1);
         }
         const float4 av = A[qg];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][0].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wr[qg][1].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][0].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wr[qg][1].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][0].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wr[qg][1].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][0].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wr[qg][1].w, acc1, 0, 0, 0);
+        float4 b0, b1;
+        if (qg < HQ) { b0 = Wr[qg < HQ ? qg : 0][0]; b1 = Wr[qg < HQ ? qg : 0][1]; }
+        else { b0 = Wl[w][qg - HQ][0][lane]; b1 = Wl[w][qg - HQ][1][lane]; }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
       }
       STAMP(2);
       const int slot = k & (NSLOT - 1);
@@ -250,9 +275,17 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
       STAMP(3);
       if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
     };
-    for (int k = 0; k < total; k += 2) {
-      item(A0, A1, k);
-      if (k + 1 < total) item(A1, A0, k + 1);
+    if (PD == 2) {
+      for (int k = 0; k < total; k += 3) {
+        item(A0, A2, k);
+        if (k + 1 < total) item(A1, A0, k + 1);
+        if (k + 2 < total) item(A2, A1, k + 2);
+      }
+    } else {
+      for (int k = 0; k < total; k += 2) {
+        item(A0, A1, k);
+        if (k + 1 < total) item(A1, A0, k + 1);
+      }
     }
     return;
   }
@@ -326,7 +359,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
       if (s + 1 < a.T) {                                 // publish h_t of this tile first: it is what the other workgroups wait for
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float h1 = __shfl_down(hn[j], 1, 64), h2 = __shfl_down(hn[j], 2, 64), h3 = __shfl_down(hn[j], 3, 64);
+          const float h1 = row_shl<1>(hn[j]), h2 = row_shl<2>(hn[j]), h3 = row_shl<3>(hn[j]);
           if ((eunit & 3) == 0) {
             u32x4 v;
             v.x = __float_as_uint(hn[j]); v.y = __float_as_uint(h1); v.z = __float_as_uint(h2); v.w = __float_as_uint(h3);
@@ -361,6 +394,268 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   }
 }
 
+// =====================================================================================================================
+// Backward recurrence.  Step t (t_hi down to t_lo):  dL/dh_{t-1} = base_t + dz_t . W_h^T  ([B,4H] x [4H,H], K = 4H), then the
+// BasicLSTM gate backward of step t-1 turns (dL/dh_{t-1} + dout_{t-1}, dL/dc_{t-1}) into dz_{t-1} (sequence.hip
+// lstm_gates_bwd_kernel).  The output is only H wide but the reduction is 4H long, so a workgroup owns 16
+// hidden units (one 16-column MFMA tile) and its [16 x 4H] slice of W_h -- 256 KB: half of every wave's K range sits in
+// registers, the other half in LDS (128 KB).  dz_t (4H wide: 4x the forward's state) is what travels: "dzx" in A-fragment order,
+// same write-through / arrival-counter protocol as the forward pass, fetched through a 16-slot register ring that always runs
+// half an item ahead (mid-item poll of the next item, as in the forward kernel).
+//   matrix waves 0-7 : K = 4H split 8-way (NQB = H/32 q-groups of 16 k each); q-groups [0, NQB/2) multiply register-resident
+//                      weights, [NQB/2, NQB) LDS-resident ones (ds_read_b128, lane-linear = conflict-free); two accumulators.
+//   epilogue waves 8-11: ALL four finish EVERY item together (wave e: rows 4e..4e+3 of the 16-row tile x 16 units, one pair per
+//                      lane), so a pair's running (base, dc) state is always re-read by the lane that wrote it.
+struct PersistBwdArgs {
+  const float* gates;   // [F,B,4H] saved i|j|f|o
+  const float* Wh;      // [H, ldw]
+  long long ldw;
+  const float* cs;      // [F+1,B,H]
+  const float* dout;    // [F,B,H] or null
+  float* dz;            // [F,B,4H]
+  float* work;          // [4,B,H]: running (dh, dc) in halves 0 / 1
+  const int32_t* nf;
+  float* dzx;           // exchange buffer [2][NT16][4H/16][256]
+  unsigned* ctl;
+  int t0, T, B, H, phase;
+  int NUB, RB, NT16, per, pf;
+  unsigned long long* dbg;
+};
+
+constexpr int NSLOT_B = 3;
+
+template <int NQB, bool PF>
+__global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
+  constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
+  __shared__ __attribute__((aligned(16))) float4 Wl[8][HALF][64];          // LDS-resident half of the weights: 8 * HALF KB
+  __shared__ __attribute__((aligned(16))) float red[NSLOT_B][8][4][64];    // [slot][wave][acc reg][lane]: 24 KB
+  __shared__ unsigned lds_cnt[NSLOT_B], lds_free[NSLOT_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int ub, g;
+  {
+    const int b = blockIdx.x;
+    if (a.per > 0) { const int x = b & 7; g = x / a.per; ub = (b >> 3) * a.per + (x % a.per); }
+    else { g = b / a.NUB; ub = b % a.NUB; }
+  }
+  const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
+  const int n_it = (NT16 - g + RB - 1) / RB;
+  const int total = n_it * a.T;
+  const int QH4 = H >> 2;                                // q-groups per dz row (4H / 16)
+  const __amdgpu_buffer_rsrc_t dxr = make_rsrc(a.dzx, (unsigned)(2u * NT16 * (unsigned)H * 64u * 4u));
+  const unsigned arrivals = (unsigned)a.NUB * 4u;        // per (tile, publish): four epilogue waves per workgroup
+  const int i16 = lane & 15, kq = lane >> 4;
+  if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
+  if (w < 8) {
+    // B fragment: lane (n = unit, kq) supplies W_h[16 ub + n][k = 16 q + 4 kq + e], e = 0..3: a float4 of a W_h row
+    const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * NQB) * 16 + kq * 4;
+#pragma unroll
+    for (int qq = 0; qq < HALF; ++qq) Wl[w][qq][lane] = *reinterpret_cast<const float4*>(wrow + (HALF + qq) * 16);
+  }
+  __syncthreads();
+
+  if (w < 8) {
+    // =============================== matrix waves ===============================
+    const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * NQB) * 16 + kq * 4;
+    float4 Wr[HALF];
+#pragma unroll
+    for (int qg = 0; qg < HALF; ++qg) Wr[qg] = *reinterpret_cast<const float4*>(wrow + qg * 16);
+    const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQB) * 1024u;
+    auto blk = [&](int s, int T) -> unsigned { return (unsigned)(((s & 1) * NT16 + T) * QH4) * 1024u + lane_off; };
+    float4 ring[HALF];
+    int s_cur = 0, it_cur = 0, slot = 0, gen = 0;
+    if (PF) {                                            // first half of item 0: after every workgroup's prologue publish
+      wait_tile(a.ctl, g, arrivals, lane);
+      const unsigned b0 = blk(0, g);
+#pragma unroll
+      for (int q = 0; q < HALF; ++q)
+        ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(b0 + (unsigned)q * 1024u), 0, YT8M_AUX_LD));
+    }
+    for (int k = 0; k < total; ++k) {
+      const int s = s_cur, T = g + it_cur * RB;
+      STAMP(0);
+      int s1 = s, it1 = it_cur + 1;
+      if (it1 == n_it) { it1 = 0; ++s1; }
+      const bool have1 = k + 1 < total;
+      const int T1 = have1 ? g + it1 * RB : T;
+      s1 = have1 ? s1 : s;
+      unsigned pv = 0;
+      const unsigned bcur = blk(s, T);
+      if (PF) {
+        if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        wait_tile(a.ctl, T, (unsigned)(s + 1) * arrivals, lane);
+#pragma unroll
+        for (int q = 0; q < HALF; ++q)
+          ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)q * 1024u), 0, YT8M_AUX_LD));
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) {                   // first half: register-resident weights; refill with this item's 2nd half
+        const float4 av = ring[q], bv = Wr[q];
+        ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)(HALF + q) * 1024u), 0, YT8M_AUX_LD));
+        if (q & 1) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
+        }
+      }
+      unsigned bnext = bcur;
+      if (PF) {                                          // mid-item: dz of the next item must be complete before its fetch starts
+        unsigned tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)pv, i);
+        if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
+        bnext = blk(s1, T1);
+        STAMP(1);
+      }
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) {                   // second half: LDS-resident weights; refill with the next item's 1st half
+        const float4 av = ring[q];
+        const float4 bv = Wl[w][q][lane];
+        if (PF) ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bnext + (unsigned)q * 1024u), 0, YT8M_AUX_LD));
+        if (q & 1) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
+        }
+      }
+      STAMP(2);
+      if (gen > 0) lds_wait_ge(&lds_free[slot], 4u * (unsigned)gen, a.ctl);   // all four epilogue waves have read item k - 3
+      float* rw = &red[slot][w][0][lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rw[r * 64] = acc0[r] + acc1[r];
+      if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      STAMP(3);
+      if (++slot == NSLOT_B) { slot = 0; ++gen; }
+      if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+    }
+    return;
+  }
+
+  // =============================== epilogue waves ===============================
+  const int ew = w - 8;
+  __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);
+  const int er = lane >> 4, eunit = lane & 15;           // pair of this lane: (row 4 ew + er of the tile, unit eunit of the group)
+  const int erow = 4 * ew + er;
+  const int t_hi = a.t0 + a.T - 1;
+  const long long BH = (long long)B * H;
+  // gate backward of step t1 for this lane's pair of tile T: consumes (dh_in, dc) and produces dz (4 gates), dc', base'
+  auto publish = [&](int T, int pub, const float (&dzv)[4]) {
+    // dzx block of gate g4 = q-group g4 * (H/16) + ub: [16 rows][16 units]; four neighbouring lanes -> one 16-byte store
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float v0 = dzv[g4];
+      const float v1 = row_shl<1>(v0), v2 = row_shl<2>(v0), v3 = row_shl<3>(v0);
+      if ((eunit & 3) == 0) {
+        u32x4 v;
+        v.x = __float_as_uint(v0); v.y = __float_as_uint(v1); v.z = __float_as_uint(v2); v.w = __float_as_uint(v3);
+        const unsigned off = ((unsigned)(((pub & 1) * NT16 + T) * QH4 + g4 * (H >> 4) + ub) * 256u + (unsigned)(erow * 16 + eunit)) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(v, dxr, (int)off, 0, YT8M_AUX_ST);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * 8 + (blockIdx.x & 7)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  struct GateIn { float gi, gj, gf, go, cp, cn, dout; bool live; };
+  auto gate_load = [&](int t1, int br) -> GateIn {
+    GateIn q;
+    const float* gr = a.gates + ((long long)t1 * B + br) * 4 * H + ub * 16 + eunit;
+    q.gi = gr[0]; q.gj = gr[H]; q.gf = gr[2 * H]; q.go = gr[3 * H];
+    const long long idx = (long long)t1 * BH + (long long)br * H + ub * 16 + eunit;
+    q.cp = a.cs[idx];
+    q.cn = a.cs[idx + BH];
+    q.dout = a.dout ? a.dout[idx] : 0.f;
+    q.live = a.nf ? (t1 < a.nf[br]) : true;
+    return q;
+  };
+  auto gate_bwd = [&](const GateIn& q, float dh_in, float dc, float (&dzv)[4], float& dc_out, float& base_out) {
+    const float tc = fast_tanh(q.cn);
+    const float dht = dh_in + q.dout;
+    const float dct = dc + dht * q.go * (1.0f - tc * tc);
+    dzv[0] = q.live ? dct * q.gj * q.gi * (1.0f - q.gi) : 0.f;
+    dzv[1] = q.live ? dct * q.gi * (1.0f - q.gj * q.gj) : 0.f;
+    dzv[2] = q.live ? dct * q.cp * q.gf * (1.0f - q.gf) : 0.f;
+    dzv[3] = q.live ? dht * tc * q.go * (1.0f - q.go) : 0.f;
+    dc_out = q.live ? dct * q.gf : dc;
+    base_out = q.live ? 0.f : dh_in;
+  };
+  auto store_std = [&](int t1, int brow, const float (&dzv)[4], float dc_out, float base_out, int half) {
+    float* dzr = a.dz + ((long long)t1 * B + brow) * 4 * H + ub * 16 + eunit;
+    dzr[0] = dzv[0]; dzr[H] = dzv[1]; dzr[2 * H] = dzv[2]; dzr[3 * H] = dzv[3];
+    float* wk = a.work + (long long)(2 * half) * BH + (long long)brow * H + ub * 16 + eunit;
+    wk[0] = base_out;
+    wk[BH] = dc_out;
+  };
+  // ---- prologue: gate backward of step t_hi from the caller's running (dh, dc) in half `phase`; publish #1 of every tile
+  for (int it = 0; it < n_it; ++it) {
+    const int T = g + it * RB;
+    const int brow = T * 16 + erow;
+    const bool valid = brow < B;
+    const int br = valid ? brow : B - 1;
+    const float* wk = a.work + (long long)(2 * a.phase) * BH + (long long)br * H + ub * 16 + eunit;
+    const float dh0 = wk[0], dc0 = wk[BH];
+    const GateIn q = gate_load(t_hi, br);
+    float dzv[4], dc_out, base_out;
+    gate_bwd(q, dh0, dc0, dzv, dc_out, base_out);
+    if (!valid) { dzv[0] = dzv[1] = dzv[2] = dzv[3] = 0.f; }
+    publish(T, 0, dzv);
+    if (valid) store_std(t_hi, brow, dzv, dc_out, base_out, a.phase ^ 1);
+  }
+  int slot = 0, gen = 0;
+  for (int s = 0; s < a.T; ++s) {
+    const int t1 = t_hi - s - 1;                         // the step whose gate backward follows the product of step t_hi - s
+    const bool last = s + 1 == a.T;
+    const int half = (a.phase + s + 1) & 1;              // where this step's (base, dc) live
+    for (int it = 0; it < n_it; ++it) {
+      const int k = s * n_it + it;
+      const int T = g + it * RB;
+      const int brow = T * 16 + erow;
+      const bool valid = brow < B;
+      const int br = valid ? brow : B - 1;
+      STAMP(0);
+      float* wk = a.work + (long long)(2 * half) * BH + (long long)br * H + ub * 16 + eunit;
+      const float base = wk[0], dc = wk[BH];
+      GateIn q;
+      if (!last) q = gate_load(t1, br);
+      lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(gen + 1), a.ctl);
+      STAMP(1);
+      // C layout: column = lane & 15 (unit), row = 4 (lane >> 4) + r  ->  pair (row 4 ew + er, unit): register er, lane 16 ew + unit
+      float p = red[slot][0][er][ew * 16 + eunit];
+#pragma unroll
+      for (int wv = 1; wv < 8; ++wv) p += red[slot][wv][er][ew * 16 + eunit];
+      if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (++slot == NSLOT_B) { slot = 0; ++gen; }
+      STAMP(2);
+      const float dh_in = base + p;
+      if (last) {                                        // dL/dh_{t_lo - 1}: handed to the caller (next chunk / initial state)
+        if (valid) wk[0] = dh_in;
+        continue;
+      }
+      float dzv[4], dc_out, base_out;
+      gate_bwd(q, dh_in, dc, dzv, dc_out, base_out);
+      if (!valid) { dzv[0] = dzv[1] = dzv[2] = dzv[3] = 0.f; }
+      STAMP(3);
+      publish(T, s + 1, dzv);
+      STAMP(4);
+      if (valid) store_std(t1, brow, dzv, dc_out, base_out, half ^ 1);
+    }
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct PersistGate {            // chains persistent launches of one device (see the deadlock note above)
   std::mutex mu;
@@ -369,6 +664,15 @@ struct PersistGate {            // chains persistent launches of one device (see
   PersistGate() { memset(has, 0, sizeof(has)); }
 };
 PersistGate g_gate;
+
+// CUs a persistent launch may occupy: the whole chip, or YT8M_PERSIST_CUS of them (the rest stays free for kernels of other
+// streams -- the hoisted GEMMs of the layer pipeline -- to run beside the recurrence)
+int persist_cu_budget(int cus, bool bwd = false) {
+  static const int cap = getenv("YT8M_PERSIST_CUS") ? atoi(getenv("YT8M_PERSIST_CUS")) : 0;
+  static const int cap_b = getenv("YT8M_PERSIST_CUS_BWD") ? atoi(getenv("YT8M_PERSIST_CUS_BWD")) : 128;
+  const int c = bwd ? cap_b : cap;
+  return (c > 0 && c < cus) ? c : cus;
+}
 
 int device_cus(int* dev_out) {
   static int cus[16] = {0};
@@ -395,21 +699,23 @@ bool persist_geometry(int64_t B, int64_t H, Geometry* geo) {
   const int NU = (int)(H / 8);
   if (cus < NU) return false;
   const int NT16 = (int)((B + 15) / 16);
-  int RB = cus / NU;
+  int RB = persist_cu_budget(cus) / NU;
   if (RB > NT16) RB = NT16;
   if (RB > NT16 / 4) RB = NT16 / 4;                      // >= 4 tiles per workgroup when the batch allows: four independent chains
   if (RB < 1) RB = 1;                                    // hide the exchange latency (publish -> visible -> fetched ~ 2 item times)
   const int nit_min = NT16 / RB;                          // the last row group has floor(NT16 / RB) or one more
   int per = 0;
   if (RB <= 8 && (8 % RB) == 0 && (NU % (8 / RB)) == 0) per = 8 / RB;
-  if (geo) *geo = {NQ, NU, RB, NT16, per, nit_min >= 2 ? 1 : 0};
+  // two items ahead only with >= 8 chains: with 4 the producer of item k + 2 has barely published when it is requested
+  if (geo) *geo = {NQ, NU, RB, NT16, per, nit_min >= 8 ? 2 : (nit_min >= 2 ? 1 : 0)};
   return true;
 }
 
 template <int NQ>
 int launch_fwd(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
-  if (a.pf) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, true>), dim3(grid), dim3(768), 0, s, a);
-  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, false>), dim3(grid), dim3(768), 0, s, a);
+  if (a.pf >= 2) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 2>), dim3(grid), dim3(768), 0, s, a);
+  else if (a.pf == 1) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 1>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 0>), dim3(grid), dim3(768), 0, s, a);
   return yt8m::launch_status("lstm_persist_fwd_kernel");
 }
 
@@ -473,6 +779,91 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
     case 4: rc = launch_fwd<4>(a, grid, s); break;
     case 6: rc = launch_fwd<6>(a, grid, s); break;
     default: rc = launch_fwd<8>(a, grid, s); break;
+  }
+  if (rc != YT8M_OK) return rc;
+  if (!g_gate.has[dev]) {
+    YT8M_HIP_CHECK(hipEventCreateWithFlags(&g_gate.ev[dev], hipEventDisableTiming));
+    g_gate.has[dev] = true;
+  }
+  YT8M_HIP_CHECK(hipEventRecord(g_gate.ev[dev], s));
+  return YT8M_OK;
+}
+
+namespace {
+struct GeometryB { int NQB, NUB, RB, NT16, per, pf; };
+
+bool persist_geometry_bwd(int64_t B, int64_t H, GeometryB* geo) {
+  static const bool off = getenv("YT8M_NO_PERSIST") != nullptr || getenv("YT8M_NO_PERSIST_BWD") != nullptr;
+  if (off || B < 1 || H < 256 || (H % 256) != 0 || H > 1024) return false;
+  const int NQB = (int)(H / 32);
+  if (!(NQB == 8 || NQB == 16 || NQB == 24 || NQB == 32)) return false;
+  int dev = 0;
+  const int cus = device_cus(&dev);
+  const int NUB = (int)(H / 16);
+  if (cus < NUB) return false;
+  const int NT16 = (int)((B + 15) / 16);
+  // default: HALF the chip.  With 16 units per workgroup the whole chip leaves two 16-row tiles (= two independent chains) per
+  // workgroup at B = 128 and the exchange latency is exposed on every item (42 us / step measured); on 128 CUs a workgroup
+  // owns four tiles, runs 24 us / step -- the per-step kernels' speed on the whole chip -- and the other 128 CUs stay free for
+  // the weight-gradient GEMMs of the layer pipeline.
+  int RB = persist_cu_budget(cus, true) / NUB;
+  if (RB > NT16 / 2) RB = NT16 / 2;                      // >= 2 tiles per workgroup when the batch allows: one chain's exchange
+  if (RB < 1) RB = 1;                                    // latency hides behind the other chain's matrix work
+  const int nit_min = NT16 / RB;
+  int per = 0;
+  if (RB <= 8 && (8 % RB) == 0 && (NUB % (8 / RB)) == 0) per = 8 / RB;
+  if (geo) *geo = {NQB, NUB, RB, NT16, per, nit_min >= 2 ? 1 : 0};
+  return true;
+}
+
+template <int NQB>
+int launch_bwd(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
+  if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false>), dim3(grid), dim3(768), 0, s, a);
+  return yt8m::launch_status("lstm_persist_bwd_kernel");
+}
+}  // namespace
+
+extern "C" int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H) {
+  return (persist_geometry(B, H, nullptr) && persist_geometry_bwd(B, H, nullptr)) ? 1 : 0;
+}
+
+extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                                     float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
+                                     void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
+  if (T * B * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(gates && Wh && cs && dz && work && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldw >= 4 * H && (ldw % 4) == 0 && (reinterpret_cast<uintptr_t>(Wh) & 15) == 0, YT8M_E_SHAPE,
+               "W_h rows must be 16-byte aligned (ldw % 4 == 0)");
+  GeometryB geo;
+  YT8M_REQUIRE(persist_geometry(B, H, nullptr) && persist_geometry_bwd(B, H, &geo), YT8M_E_SHAPE,
+               "shape not supported by the persistent backward recurrence (see yt8m_lstm_persist_bwd_supported)");
+  YT8M_REQUIRE(workspace_bytes >= yt8m_lstm_persist_workspace_bytes(B, H), YT8M_E_SHAPE, "workspace too small");
+  YT8M_REQUIRE(T < (1 << 20), YT8M_E_SHAPE, "T too large");
+  hipStream_t s = as_stream(stream);
+  const int64_t cb = ((ctl_bytes(geo.NT16) + 255) / 256) * 256;
+  PersistBwdArgs a;
+  a.gates = gates; a.Wh = Wh; a.ldw = ldw; a.cs = cs; a.dout = dout; a.dz = dz; a.work = work; a.nf = num_frames;
+  a.ctl = static_cast<unsigned*>(workspace);
+  a.dzx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
+  a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.phase = phase;
+  a.NUB = geo.NUB; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
+  a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + yt8m_lstm_persist_workspace_bytes(B, H) - DBG_BYTES);
+  const unsigned grid = (unsigned)(geo.NUB * geo.RB);
+  int dev = 0;
+  device_cus(&dev);
+  ProfScope prof(F_LSTM, s);
+  std::lock_guard<std::mutex> lk(g_gate.mu);
+  if (g_gate.has[dev]) YT8M_HIP_CHECK(hipStreamWaitEvent(s, g_gate.ev[dev], 0));
+  YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
+  int rc;
+  switch (geo.NQB) {
+    case 8: rc = launch_bwd<8>(a, grid, s); break;
+    case 16: rc = launch_bwd<16>(a, grid, s); break;
+    case 24: rc = launch_bwd<24>(a, grid, s); break;
+    default: rc = launch_bwd<32>(a, grid, s); break;
   }
   if (rc != YT8M_OK) return rc;
   if (!g_gate.has[dev]) {

@@ -26,7 +26,7 @@ DEFINE_integer("lstm_layers", 2, "Number of LSTM layers.")
 # new: time chunks of the layer-pipelined LSTM stack (1 = one layer after the other)
 DEFINE_integer("gru_cells", 1024, "Number of GRU cells.")
 DEFINE_integer("gru_layers", 2, "Number of GRU layers.")
-DEFINE_integer("lstm_pipeline_chunks", 4, "Time chunks over which the layers of the LSTM stack are pipelined on separate streams.")
+DEFINE_integer("lstm_pipeline_chunks", 2, "Time chunks over which the layers of the LSTM stack are pipelined on separate streams.")
 DEFINE_string("feature_sizes", "1024", "Length of the feature vectors.")     # W/train.py:58 (read by the parallel LSTM model)
 DEFINE_integer("positional_embedding_size", 32, "Positional embedding dimension use in lstm_positional_attention_max_pooling_model.")
 DEFINE_integer("lstm_attentions", 8, "Attention size in lstm_attention_max_pooling_model.")

@@ -262,6 +262,7 @@ def _chunks(F, n):
 
 import os as _os
 PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent recurrence kernels (csrc/lstm_persist.hip)
+PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 REC_BF16 = True       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
                       # products only
@@ -458,6 +459,12 @@ class _LstmStack(torch.autograd.Function):
                         _lib.check(lib.yt8m_lstm_steps_bwd_bf16(_p(st["z"]), _p(st["Wq16"]), _p(st["cs"]), _p(st["dout"]), _p(st["dz"]),
                                                                 _p(st["dz16"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H,
                                                                 _stream()))
+                    elif st.get("pws") is not None and PERSIST_BWD and lib.yt8m_lstm_persist_bwd_supported(B, H):
+                        _lib.check(lib.yt8m_lstm_persist_bwd(_p(st["z"]), _p(W.data[Din:]), 4 * H, _p(st["cs"]), _p(st["dout"]),
+                                                             _p(st["dz"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H,
+                                                             _p(st["pws"]), st["pws"].numel(), _stream()))
+                        if PERSIST_CHECK:
+                            _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
                     else:
                         _lib.check(lib.yt8m_lstm_steps_bwd(_p(st["z"]), _p(W.data[Din:]), 4 * H, _p(st["Wq"]), _p(st["cs"]), _p(st["dout"]),
                                                            _p(st["dz"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H, _p(ws),
