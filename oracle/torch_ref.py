@@ -65,18 +65,24 @@ def dropout(x, keep_prob, seed, offset=0):
     return torch.where(m, x / torch.tensor(keep_prob, dtype=x.dtype), torch.zeros_like(x))
 
 
-def deep_combine_chain(x, P, L, M, relu_type="relu", dropout_spec=None):
-    """W/all_video_models/deep_combine_chain_model.py:12-85.  dropout_spec = (keep_prob, [seed per sub-model]): :57-58."""
+def deep_combine_chain(x, P, L, M, relu_type="relu", dropout_spec=None, bf16_heads=False):
+    """W/all_video_models/deep_combine_chain_model.py:12-85.  dropout_spec = (keep_prob, [seed per sub-model]): :57-58.
+    bf16_heads: VALUE emulation of --compute_dtype=bfloat16 on the MoE heads (both GEMM operands rounded to bf16, fp32+
+    accumulation), the products that take the bf16 MFMA path at >= 512 rows."""
+    if bf16_heads:
+        moe_ = lambda x_, Wg, We, be, M_: moe(bf16_round(x_), bf16_round(Wg), bf16_round(We), be, M_)
+    else:
+        moe_ = moe
     cur, sup = x, []
     for i in range(L):
         s = "prediction-%d" % i
         inp = cur if dropout_spec is None else dropout(cur, dropout_spec[0], dropout_spec[1][i])
-        sp = moe(inp, P["gates-%s/weights" % s], P["experts-%s/weights" % s], P["experts-%s/biases" % s], M)
+        sp = moe_(inp, P["gates-%s/weights" % s], P["experts-%s/weights" % s], P["experts-%s/biases" % s], M)
         a = sp @ P["relu-%d/weights" % i] + P["relu-%d/biases" % i]
         r = torch.nn.functional.elu(a) if relu_type == "elu" else torch.relu(a)
         cur = torch.cat([cur, l2_normalize(r, 1)], 1)
         sup.append(sp)
-    main = moe(cur, P["gates--main/weights"], P["experts--main/weights"], P["experts--main/biases"], M)
+    main = moe_(cur, P["gates--main/weights"], P["experts--main/weights"], P["experts--main/biases"], M)
     return main, torch.cat(sup, 1)
 
 
@@ -278,7 +284,7 @@ def netvlad_hidden(x, num_frames, Wc, bc, centres, Wh, bh, Wgate=None, bgate=Non
     return h
 
 
-def gated_netvlad_attention_chain(x, num_frames, P, L, M, A):
+def gated_netvlad_attention_chain(x, num_frames, P, L, M, A, bf16_heads=False):
     """BASELINE configs[4] composite as SURVEY.md Appendix B fixes it (not a reference class): gated NetVLAD descriptor,
     attention pooling of the frames themselves (lstm_attention_max_pooling_model.py:34,51-63 with outputs := x and the FC
     input [x || mean_x]), DeepCombineChainModel on [h || att_a], max over the A attentions for predictions and support."""
@@ -289,7 +295,7 @@ def gated_netvlad_attention_chain(x, num_frames, P, L, M, A):
     mean_x = (x.sum(1, keepdim=True) / num_frames.to(x.dtype).clamp(min=1).view(B, 1, 1)).expand(B, F, D)
     att = attention_pool(mean_x, x, num_frames, P["attention-/weights"], P["attention-/biases"], order="outputs_first")
     cin = torch.cat([h[:, None, :].expand(B, A, h.shape[1]), att], 2).reshape(B * A, -1)
-    main, sup = deep_combine_chain(cin, P, L, M)
+    main, sup = deep_combine_chain(cin, P, L, M, bf16_heads=bf16_heads)
     return main.view(B, A, -1).max(1).values, sup.view(B, A, -1).max(1).values
 
 

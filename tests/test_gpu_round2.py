@@ -227,3 +227,110 @@ def test_persistent_lstm_vs_fp64_oracle_full_width(dev):
     assert float((grads[0].double() - dx_ref).abs().max()) <= 1e-4 * float(dx_ref.abs().max())
     gW = torch.cat([t.grad.reshape(-1) for pair in layers for t in pair])
     assert float((grads[1].double() - gW).abs().max()) <= 1e-4 * float(gW.abs().max())
+
+
+# ---- BASELINE configs[4] in its own dtype: the bf16 composite end to end -------------------------------------
+def test_config5_composite_bf16_engaged(dev, flags, monkeypatch):
+    """GatedNetVLADAttentionChainModel with --compute_dtype=bfloat16 at B*A = 512 chain rows: the bf16 MFMA GEMMs, the fused
+    bf16 mixing backward and the single-f16-operand (nsplit = 1) NetVLAD pooling all switch on together.  Checked against the
+    oracle with the bf16 operand rounding of the MoE heads emulated in VALUE (oracle/torch_ref.py bf16_heads): predictions,
+    support predictions, loss; gradients against the fp32 oracle gradients by direction and scale (bf16 products: ~1e-2)."""
+    import yt8m_amd.losses as losses
+    import yt8m_amd.seq_ops as seq_ops
+    from oracle import np_ref, torch_ref
+    rs = np.random.RandomState(23)
+    B, F, Dm, K, Hf, V, A, L = 64, 32, 256, 64, 128, 600, 8, 2
+    flags.compute_dtype = "bfloat16"
+    flags.netvlad_cluster_size, flags.netvlad_hidden_size, flags.lstm_attentions = K, Hf, A
+    flags.deep_chain_layers, flags.deep_chain_relu_cells = L, 16
+    flags.support_type = ",".join(["label"] * L)
+    flags.support_loss_percent = 0.1
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 1
+    y = rs.rand(B, V) < 0.02
+    q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+    x64 = np_ref.dequant_l2norm_folded(q, nf)
+    calls = {"bf16_gemm": 0, "nsplit": set(), "fused_mix": 0}
+    real_gemm, real_nv, real_mix = ops.gemm_bf16_nt_grouped, seq_ops.netvlad_fwd_u8, ops._moe_head_bwd_bf16_fused
+
+    def spy_gemm(items):
+        calls["bf16_gemm"] += len(items)
+        return real_gemm(items)
+
+    def spy_nv(*a, **kw):
+        calls["nsplit"].add(kw.get("nsplit", a[4] if len(a) > 4 else 2))
+        return real_nv(*a, **kw)
+
+    def spy_mix(*a, **kw):
+        calls["fused_mix"] += 1
+        return real_mix(*a, **kw)
+
+    monkeypatch.setattr(ops, "gemm_bf16_nt_grouped", spy_gemm)
+    monkeypatch.setattr(seq_ops, "netvlad_fwd_u8", spy_nv)
+    monkeypatch.setattr(ops, "_moe_head_bwd_bf16_fused", spy_mix)
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(flm.GatedNetVLADAttentionChainModel(), batch_size=B, graph=g, multitask=True,
+                          label_loss_fn=losses.MultiTaskCrossEntropyLoss())
+    xd, yd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+    tg.forward(xd, yd, nfd)
+    g.finalize()
+    P = {}
+    for k, v in g.vars.items():
+        P[k] = (rs.randn(*v.shape) * (0.4 if "netvlad" in k or "attention" in k else 1.0 / np.sqrt(v.shape[0]))).astype(np.float32)
+        v.data.copy_(torch.from_numpy(P[k]).to(dev).view(v.data.shape))
+    calls["bf16_gemm"] = 0
+    res = tg.forward(xd, yd, nfd)
+    loss = tg.loss(res, yd)
+    loss.backward()
+    assert calls["bf16_gemm"] >= 3 * (L + 1) and calls["fused_mix"] >= L + 1 and 1 in calls["nsplit"], calls
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    main, sup = torch_ref.gated_netvlad_attention_chain(T(x64), torch.from_numpy(nf), tp, L, 2, A, bf16_heads=True)
+    pm, ps = res["predictions"].detach().cpu().double(), res["support_predictions"].detach().cpu().double()
+    assert float((pm - main.detach()).abs().max()) < 5e-3 and float((ps - sup.detach()).abs().max()) < 5e-3
+    yt = T(y)
+    lr = 0.9 * torch_ref.cross_entropy(main, yt) + 0.1 * torch_ref.cross_entropy(sup, yt.repeat(1, L))
+    assert abs(float(loss.detach()) - lr.item()) < 5e-3 * abs(lr.item())
+    # gradients vs the fp32 oracle (no emulation of the backward roundings): direction and scale
+    main32, sup32 = torch_ref.gated_netvlad_attention_chain(T(x64), torch.from_numpy(nf), tp, L, 2, A)
+    (0.9 * torch_ref.cross_entropy(main32, yt) + 0.1 * torch_ref.cross_entropy(sup32, yt.repeat(1, L))).backward()
+    for k, v in g.vars.items():
+        if not v.trainable or tp[k].grad is None:
+            continue
+        a, b = v.grad.detach().cpu().double().reshape(-1), tp[k].grad.reshape(-1)
+        nb = float(b.norm())
+        if nb < 1e-12:
+            continue
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+        assert cos > 0.99 and abs(float(a.norm()) / nb - 1.0) < 0.05, (k, cos, float(a.norm()) / nb)
+
+
+def test_config5_composite_bf16_full_batch_properties(dev, flags):
+    """configs[4] at its per-GPU batch (B = 1024 videos x 300 frames x 1152, V = 4716, bf16): one training step runs on the bf16
+    paths and keeps the size-independent properties -- probabilities in [0, 1], finite loss, predictions invariant under a
+    permutation of the videos (each video is pooled independently), padded frames beyond num_frames do not matter."""
+    import yt8m_amd.losses as losses
+    flags.compute_dtype = "bfloat16"
+    flags.deep_chain_layers, flags.deep_chain_relu_cells = 3, 128
+    flags.support_type = ",".join(["label"] * 3)
+    B, F, D, V = 1024, 300, 1152, 4716
+    gen = torch.Generator(device=dev).manual_seed(5)
+    q = torch.randint(0, 256, (B, F, D), device=dev, generator=gen, dtype=torch.uint8)
+    y = torch.rand((B, V), device=dev, generator=gen) < 3.4 / V
+    nf = torch.randint(1, F + 1, (B,), device=dev, generator=gen, dtype=torch.int32)
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(flm.GatedNetVLADAttentionChainModel(), batch_size=B, graph=g, multitask=True,
+                          label_loss_fn=losses.MultiTaskCrossEntropyLoss())
+    out = tg.step(q, y, nf)
+    p = out["predictions"]
+    assert torch.isfinite(out["loss"]) and float(p.min()) >= 0.0 and float(p.max()) <= 1.0
+    with torch.no_grad():
+        p0 = tg.predict(q[:64], nf[:64], vocab_size=V)
+        perm = torch.randperm(64, device=dev, generator=gen)
+        p1 = tg.predict(q[:64][perm], nf[:64][perm], vocab_size=V)
+        assert float((p0[perm] - p1).abs().max()) < 2e-3          # bf16 tile boundaries move with the row order
+        q2 = q[:64].clone()
+        mask = torch.arange(F, device=dev)[None, :] >= nf[:64, None]
+        q2[mask] = 255                                            # garbage in the padded frames
+        p2 = tg.predict(q2, nf[:64], vocab_size=V)
+        assert float((p0 - p2).abs().max()) < 2e-3
