@@ -406,6 +406,30 @@ int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float
                         float* dWc, float dWc_beta, float* dbc, float dbc_beta, void* workspace,
                         int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- DbofModel pieces (csrc/dbof.hip; W/all_frame_models/dbof_model.py:36-124, W/model_utils.py:23-95) -------
+ * yt8m_sample_frames_*: SampleRandomFrames (mode 0: index = int(u[b,s] * num_frames[b])) / SampleRandomSequence (mode 1:
+ *   start = int(u[b] * (max(num_frames - S, 0) + 1)), index = min(start + s, num_frames - 1)); u = Philox4x32-10 uniform
+ *   of element b*S+s (mode 0) or b (mode 1) under `seed`; x [B,F,D] -> out [B,S,D], idx_out [B,S] (may be NULL).
+ * yt8m_frame_pool_*: FramePooling over the S sampled frames, mode 0 max (gradient split equally between ties, as
+ *   tf.reduce_max) / 1 average; x [B,S,C] -> out [B,C].
+ * yt8m_batchnorm_*: slim.batch_norm(center=True, scale=True) over the rows of x [N,C]: training != 0 uses the batch
+ *   moments (biased variance) and updates moving_mean / moving_var with `decay`; save_mean / save_rstd [C] feed the
+ *   backward.  bwd: dx may be NULL (input is data); dgamma / dbeta written with beta_* = 0 or accumulated with 1. */
+int yt8m_sample_frames_f32(const float* x, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, int64_t S, int mode,
+                           uint64_t seed, float* out, int32_t* idx_out, yt8m_stream_t stream);
+int yt8m_sample_frames_u8(const uint8_t* x, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, int64_t S, int mode,
+                          uint64_t seed, uint8_t* out, int32_t* idx_out, yt8m_stream_t stream);
+int yt8m_frame_pool_fwd(const float* x, int64_t B, int64_t S, int64_t C, int mode, float* out, yt8m_stream_t stream);
+int yt8m_frame_pool_bwd(const float* x, const float* out, const float* dy, int64_t B, int64_t S, int64_t C, int mode,
+                        float* dx, yt8m_stream_t stream);
+int yt8m_batchnorm_fwd(const float* x, int64_t N, int64_t C, const float* gamma, const float* beta, float* moving_mean,
+                       float* moving_var, int training, float eps, float decay, float* y, float* save_mean,
+                       float* save_rstd, yt8m_stream_t stream);
+int64_t yt8m_batchnorm_workspace_bytes(int64_t C);
+int yt8m_batchnorm_bwd(const float* x, const float* dy, int64_t N, int64_t C, const float* gamma, const float* save_mean,
+                       const float* save_rstd, int training, float* dx, float* dgamma, float dgamma_beta, float* dbeta,
+                       float dbeta_beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+
 /* ---- per-row top-k for the GAP@20 eval path (W/eval_util.py:123-165 top_k_triplets) -------------
  * p [B,V] -> vals [B,k] (descending), idx [B,k] int32; ties broken towards the LOWER class index. k<=64 */
 int yt8m_topk_rows(const float* p, int64_t B, int64_t V, int k, float* vals, int32_t* idx,

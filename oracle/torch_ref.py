@@ -299,11 +299,32 @@ def gated_netvlad_attention_chain(x, num_frames, P, L, M, A, bf16_heads=False):
     return main.view(B, A, -1).max(1).values, sup.view(B, A, -1).max(1).values
 
 
+def batch_norm_train(x, gamma, beta, eps=1e-3):
+    """slim.batch_norm(center=True, scale=True, is_training=True): batch mean / BIASED variance over axis 0.
+    Returns (y, mean, var); the moving averages follow mm <- decay mm + (1 - decay) mean (decay 0.999), same for var."""
+    mu = x.mean(0)
+    var = ((x - mu) ** 2).mean(0)
+    return gamma * (x - mu) * torch.rsqrt(var + eps) + beta, mu, var
+
+
+def dbof_model_bn(xs, P, pooling="max", eps=1e-3):
+    """W/all_frame_models/dbof_model.py:57-116 with add_batch_norm=True on already sampled frames xs [B,S,D]: input_bn ->
+    cluster FC -> cluster_bn -> relu6 -> pool over frames (amax: the gradient is split between tied maxima, as tf.reduce_max's)
+    -> hidden FC -> hidden1_bn -> relu6.  P: "Variable" (cluster weights), "Variable_1" (hidden weights), "<bn>/gamma|beta"."""
+    B, S, D = xs.shape
+    r, _, _ = batch_norm_train(xs.reshape(-1, D), P["input_bn/gamma"], P["input_bn/beta"], eps)
+    a, _, _ = batch_norm_train(r @ P["Variable"], P["cluster_bn/gamma"], P["cluster_bn/beta"], eps)
+    a = torch.clamp(a, 0, 6).view(B, S, -1)
+    pooled = a.amax(1) if pooling == "max" else a.mean(1)
+    h, _, _ = batch_norm_train(pooled @ P["Variable_1"], P["hidden1_bn/gamma"], P["hidden1_bn/beta"], eps)
+    return torch.clamp(h, 0, 6)
+
+
 def dbof_hidden(xs, Wc, bc, Wh, bh, pooling="max"):
     """W/all_frame_models/dbof_model.py:57-116, add_batch_norm=False."""
     B, S, D = xs.shape
     act = torch.clamp(xs.reshape(-1, D) @ Wc + bc, 0, 6).view(B, S, -1)
-    pooled = act.max(1).values if pooling == "max" else act.mean(1)
+    pooled = act.amax(1) if pooling == "max" else act.mean(1)      # amax: tied maxima share the gradient (tf.reduce_max)
     return torch.clamp(pooled @ Wh + bh, 0, 6)
 
 

@@ -334,3 +334,136 @@ def test_config5_composite_bf16_full_batch_properties(dev, flags):
         q2[mask] = 255                                            # garbage in the padded frames
         p2 = tg.predict(q2, nf[:64], vocab_size=V)
         assert float((p0 - p2).abs().max()) < 2e-3
+
+
+# ---- DbofModel pieces on the device (csrc/dbof.hip) ---------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_sample_frames_bit_exact_vs_oracle(dev, dtype):
+    """SampleRandomFrames / SampleRandomSequence (W/model_utils.py:23-70): indices and gathered rows equal the oracle's on the
+    same Philox uniforms, bit for bit; ragged num_frames incl. 0, 1 and F; S larger than some videos."""
+    from oracle import np_ref, philox
+    rs = np.random.RandomState(31)
+    B, F, D, S = 9, 40, 24, 7
+    nf = np.array([40, 0, 1, 3, 7, 8, 25, 40, 2], dtype=np.int32)
+    x = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8) if dtype == "u8" else rs.randn(B, F, D).astype(np.float32)
+    xd, nfd = torch.from_numpy(x).to(dev), torch.from_numpy(nf).to(dev)
+    seed = 0x1234567890ABCDEF
+    out, idx = ops.sample_frames(xd, nfd, S, 0, seed, return_index=True)
+    u = philox.uniform01(B * S, seed).reshape(B, S)
+    ref, ridx = np_ref.sample_random_frames(x, nf, u)
+    ridx = np.clip(ridx, 0, F - 1)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(out.cpu().numpy(), np.take_along_axis(x, ridx[:, :, None].astype(np.int64), axis=1))
+    assert (ridx[nf > 0] < nf[nf > 0, None]).all()
+    out, idx = ops.sample_frames(xd, nfd, S, 1, seed, return_index=True)
+    ref, ridx = np_ref.sample_random_sequence(x, nf, philox.uniform01(B, seed), S)
+    ridx = np.clip(ridx, 0, F - 1)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(out.cpu().numpy(), np.take_along_axis(x, ridx[:, :, None].astype(np.int64), axis=1))
+
+
+@pytest.mark.parametrize("method", ["max", "average"])
+def test_frame_pool_with_ties(dev, method):
+    """FramePooling over relu6-clamped activations (ties at 0 and 6 everywhere): forward and the tie-splitting gradient vs torch."""
+    rs = np.random.RandomState(2)
+    x = np.clip(rs.randn(5, 6, 70) * 4 + 3, 0, 6).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    w = torch.from_numpy(rs.randn(5, 70).astype(np.float32))
+    out = ops.frame_pool(xd, method)
+    (out * w.to(dev)).sum().backward()
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    ref = xr.amax(1) if method == "max" else xr.mean(1)
+    (ref * w.double()).sum().backward()
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 1e-6
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_fwd_bwd_vs_oracle(dev, training):
+    """slim.batch_norm on [N, C] rows (C not a multiple of 64, N not a multiple of 4): output, moving averages, dx, dgamma, dbeta."""
+    from oracle import torch_ref
+    from yt8m_amd.variables import ones, zeros
+    rs = np.random.RandomState(4)
+    N, C, eps, decay = 203, 150, 1e-3, 0.999
+    x = (rs.randn(N, C) * rs.rand(C) * 3 + rs.randn(C)).astype(np.float32)
+    g = reset_default_graph(device=dev, seed=0)
+    g.begin_step()
+    gamma, beta = g.get_variable("bn/gamma", (C,), ones), g.get_variable("bn/beta", (C,), zeros)
+    mm, mv = g.get_variable("bn/moving_mean", (C,), zeros, trainable=False), g.get_variable("bn/moving_variance", (C,), ones, trainable=False)
+    g.finalize()
+    gam, bet = (rs.rand(C) + 0.5).astype(np.float32), rs.randn(C).astype(np.float32)
+    mm0, mv0 = rs.randn(C).astype(np.float32), (rs.rand(C) + 0.5).astype(np.float32)
+    for v, a in ((gamma, gam), (beta, bet), (mm, mm0), (mv, mv0)):
+        v.data.copy_(torch.from_numpy(a).to(dev))
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    w = rs.randn(N, C).astype(np.float32)
+    y = ops.batch_norm(xd, gamma, beta, mm, mv, training, eps, decay)
+    (y * torch.from_numpy(w).to(dev)).sum().backward()
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    gt, bt = torch.from_numpy(gam).double().requires_grad_(True), torch.from_numpy(bet).double().requires_grad_(True)
+    if training:
+        yr, mu, var = torch_ref.batch_norm_train(xt, gt, bt, eps)
+        assert np.abs(mm.data.cpu().numpy() - (decay * mm0 + (1 - decay) * mu.detach().numpy())).max() < 1e-6
+        assert np.abs(mv.data.cpu().numpy() - (decay * mv0 + (1 - decay) * var.detach().numpy())).max() < 1e-6
+    else:
+        yr = gt * (xt - torch.from_numpy(mm0).double()) * torch.rsqrt(torch.from_numpy(mv0).double() + eps) + bt
+        assert np.array_equal(mm.data.cpu().numpy(), mm0) and np.array_equal(mv.data.cpu().numpy(), mv0)
+    (yr * torch.from_numpy(w).double()).sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    for got, ref in ((xd.grad, xt.grad), (gamma.grad, gt.grad), (beta.grad, bt.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("quantized", [False, True])
+def test_dbof_model_with_batch_norm_vs_oracle(dev, flags, quantized):
+    """DbofModel with dbof_add_batch_norm on distinct frames (W/all_frame_models/dbof_model.py:36-124): the sampled frames are
+    reproduced in the oracle from the op's Philox key, then predictions, loss and EVERY gradient (incl. all gamma / beta) are
+    compared; raw uint8 input takes the sample-first path (only the sampled frames are dequantised)."""
+    import yt8m_amd.variables as variables
+    from oracle import np_ref, philox, torch_ref
+    rs = np.random.RandomState(8)
+    B, F, Dm, V, S = 12, 20, 18, 11, 6
+    flags.dbof_cluster_size, flags.dbof_hidden_size, flags.iterations, flags.dbof_add_batch_norm = 32, 16, S, True
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    y = rs.rand(B, V) < 0.2
+    if quantized:
+        q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+        x64 = np_ref.dequant_l2norm_folded(q, nf)
+        inp = q
+    else:
+        x64 = np_ref.l2_normalize(rs.randn(B, F, Dm)) * (np.arange(F)[None, :, None] < nf[:, None, None])
+        inp = x64.astype(np.float32)
+        x64 = inp.astype(np.float64)
+    g = reset_default_graph(device=dev, seed=3)
+    tcls = __import__("yt8m_amd.feature_transform", fromlist=["x"])
+    tg = train.TrainGraph(flm.DbofModel(), batch_size=B, graph=g,
+                          transformer_class=tcls.DefaultTransformer if quantized else tcls.IdenticalTransformer)
+    xd, yd, nfd = torch.from_numpy(inp).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+    tg.forward(xd, yd, nfd)
+    g.finalize()
+    P = {}
+    for k, v in g.vars.items():
+        if k.endswith("moving_variance") or k.endswith("gamma"):
+            P[k] = (rs.rand(*v.shape) + 0.5).astype(np.float32)
+        else:
+            P[k] = (rs.randn(*v.shape) * 0.4).astype(np.float32)
+        v.data.copy_(torch.from_numpy(P[k]).to(dev).view(v.data.shape))
+    res = tg.forward(xd, yd, nfd)
+    seed = variables.random_seed(g.seed, g.rank, g._rng_step, 0)          # key of the first random op of this forward pass
+    loss = tg.loss(res, yd)
+    loss.backward()
+    u = philox.uniform01(B * S, seed).reshape(B, S)
+    xs, _ = np_ref.sample_random_frames(x64, nf, u)
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items() if "moving" not in k}
+    h = torch_ref.dbof_model_bn(T(xs), tp)
+    pr = torch_ref.moe(h, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    assert float((res["predictions"].detach().cpu().double() - pr.detach()).abs().max()) < 1e-4
+    lr = torch_ref.cross_entropy(pr, T(y))
+    assert abs(float(loss.detach()) - lr.item()) < 1e-4 * abs(lr.item())
+    lr.backward()
+    for k, t in tp.items():
+        if t.grad is None:
+            continue
+        got = g.vars[k].grad.detach().cpu().double()
+        assert float((got - t.grad).abs().max()) <= 5e-4 * max(1.0, float(t.grad.abs().max())), k

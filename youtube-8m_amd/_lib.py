@@ -124,6 +124,13 @@ SIGNATURES = {
                                                c_int64, c_int64, P, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
     "yt8m_tfrecord_read_video_batch": (c_int, [P, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int32), c_int, c_int64,
                                                c_int64, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
+    "yt8m_sample_frames_f32": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, c_int, ctypes.c_uint64, P, P, P]),
+    "yt8m_sample_frames_u8": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, c_int, ctypes.c_uint64, P, P, P]),
+    "yt8m_frame_pool_fwd": (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
+    "yt8m_frame_pool_bwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_int, P, P]),
+    "yt8m_batchnorm_fwd": (c_int, [P, c_int64, c_int64, P, P, P, P, c_int, c_float, c_float, P, P, P, P]),
+    "yt8m_batchnorm_workspace_bytes": (c_int64, [c_int64]),
+    "yt8m_batchnorm_bwd": (c_int, [P, P, c_int64, c_int64, P, P, P, c_int, P, P, c_float, P, c_float, P, c_int64, P]),
     "yt8m_topk_rows": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
     "yt8m_perr_rows": (c_int, [P, P, c_int64, c_int64, P, P]),
 }

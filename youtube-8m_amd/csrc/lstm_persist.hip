@@ -622,6 +622,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
     const int half = (a.phase + s + 1) & 1;              // where this step's (base, dc) live
     for (int it = 0; it < n_it; ++it) {
       const int k = s * n_it + it;
+      (void)k;
       const int T = g + it * RB;
       const int brow = T * 16 + erow;
       const bool valid = brow < B;

@@ -205,7 +205,7 @@ class LstmAttentionMaxPoolingModel(models.BaseModel):
         attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
         moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")
         predictions = moe_predictions.view(-1, num_attentions, vocab_size)
-        max_predictions = predictions.max(dim=1).values
+        max_predictions = ops.frame_pool(predictions, "max")          # tf.reduce_max over the attentions
         return {"predictions": max_predictions}
 
     def sub_moe(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", **unused_params):
@@ -259,7 +259,7 @@ class LstmPositionalAttentionMaxPoolingModel(LstmAttentionMaxPoolingModel):
         attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
         moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")
         predictions = moe_predictions.view(-1, num_attentions, vocab_size)
-        return {"predictions": predictions.max(dim=1).values}
+        return {"predictions": ops.frame_pool(predictions, "max")}
 
 
 class CnnDeepCombineChainModel(models.BaseModel):
@@ -295,7 +295,7 @@ class CnnDeepCombineChainModel(models.BaseModel):
 
         def pooled_cnn(scope):
             cnn_output = self.cnn(model_input, sub_scope=scope, l2_penalty=l2_penalty, **filters)
-            return ops.l2_normalize(cnn_output.max(dim=1).values)      # reduce_max over ALL max_frames rows, as the reference
+            return ops.l2_normalize(ops.frame_pool(cnn_output, "max"))      # reduce_max over ALL max_frames rows, as the reference
 
         next_input = pooled_cnn(sub_scope + "cnn0")
         support_predictions = []
@@ -317,53 +317,24 @@ class CnnDeepCombineChainModel(models.BaseModel):
 
 
 def _batch_norm(x, scope, is_training, eps=1e-3, decay=0.999):
-    """slim.batch_norm(center=True, scale=True).  DBoF only -- not on any BASELINE config; the
-    statistics are plain torch reductions (couples the examples of the local batch, like the reference)."""
+    """slim.batch_norm(center=True, scale=True): batch moments, moving averages and the backward all in
+    csrc/dbof.hip (ops.batch_norm).  Couples the examples of the local batch, like the reference."""
     g = get_default_graph()
     n = x.shape[-1]
     gamma = g.get_variable(scope + "/gamma", (n,), ones)
     beta = g.get_variable(scope + "/beta", (n,), zeros)
     mm = g.get_variable(scope + "/moving_mean", (n,), zeros, trainable=False)
     mv = g.get_variable(scope + "/moving_variance", (n,), ones, trainable=False)
-    return _BatchNorm.apply(x, ops._token(g), gamma, beta, mm, mv, is_training, eps, decay)
-
-
-class _BatchNorm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, token, gamma, beta, mm, mv, is_training, eps, decay):
-        if is_training:
-            mu, var = x.mean(0), x.var(0, unbiased=False)
-            mm.data.mul_(decay).add_(mu, alpha=1 - decay)
-            mv.data.mul_(decay).add_(var, alpha=1 - decay)
-        else:
-            mu, var = mm.data, mv.data
-        rstd = torch.rsqrt(var + eps)
-        xhat = (x - mu) * rstd
-        ctx.save_for_backward(xhat, rstd)
-        ctx.vars = (gamma, beta, is_training)
-        return xhat * gamma.data + beta.data
-
-    @staticmethod
-    def backward(ctx, dy):
-        xhat, rstd = ctx.saved_tensors
-        gamma, beta, is_training = ctx.vars
-        if gamma.grad is not None:
-            gg = (dy * xhat).sum(0)
-            gamma.grad.copy_(gg) if gamma.grad_beta() == 0.0 else gamma.grad.add_(gg)
-        if beta.grad is not None:
-            gb = dy.sum(0)
-            beta.grad.copy_(gb) if beta.grad_beta() == 0.0 else beta.grad.add_(gb)
-        dxhat = dy * gamma.data
-        if is_training:
-            dx = rstd * (dxhat - dxhat.mean(0) - xhat * (dxhat * xhat).mean(0))
-        else:
-            dx = dxhat * rstd
-        return dx, None, None, None, None, None, None, None, None
+    return ops.batch_norm(x, gamma, beta, mm, mv, is_training, eps, decay)
 
 
 class DbofModel(models.BaseModel):
     """W/all_frame_models/dbof_model.py:13-124: sample frames -> cluster FC -> (BN) -> relu6 -> pool over frames ->
-    hidden FC -> (BN) -> relu6 -> head.  Weight variables are anonymous tf.Variable()s in the reference."""
+    hidden FC -> (BN) -> relu6 -> head.  Weight variables are anonymous tf.Variable()s in the reference.
+
+    accepts_quantized_input: raw uint8 frames are sampled FIRST (csrc/dbof.hip) and only the `iterations` sampled frames per
+    video are dequantised + l2-normalised -- 30 of 300 rows; the fp32 [B,300,1152] tensor is never written."""
+    accepts_quantized_input = True
 
     def create_model(self, model_input, vocab_size, num_frames, iterations=None, add_batch_norm=None,
                      sample_random_frames=None, cluster_size=None, hidden_size=None, is_training=True,
@@ -374,11 +345,13 @@ class DbofModel(models.BaseModel):
         cluster_size = cluster_size or FLAGS.dbof_cluster_size
         hidden1_size = hidden_size or FLAGS.dbof_hidden_size
         g = get_default_graph()
-        nf = num_frames.to(torch.float32).unsqueeze(1)
         if random_frames:
-            model_input = model_utils.SampleRandomFrames(model_input, nf, iterations)
+            model_input = model_utils.SampleRandomFrames(model_input, num_frames, iterations)
         else:
-            model_input = model_utils.SampleRandomSequence(model_input, nf, iterations)
+            model_input = model_utils.SampleRandomSequence(model_input, num_frames, iterations)
+        if model_input.dtype == torch.uint8:        # sampled frames are valid ones (all S, or none for a video without frames)
+            nf_s = None if num_frames is None else (num_frames.to(torch.int32) > 0).to(torch.int32) * iterations
+            model_input = ops.dequant_l2norm(model_input, nf_s)
         max_frames, feature_size = model_input.shape[1], model_input.shape[2]
         reshaped_input = model_input.reshape(-1, feature_size)
         if add_batch_norm:
@@ -478,7 +451,7 @@ class GatedNetVLADAttentionChainModel(GatedNetVLADModel):
         unused_params.pop("original_input", None)
         res = video_level_models.DeepCombineChainModel().create_model(chain_in, vocab_size, l2_penalty=l2_penalty,
                                                                       original_input=model_input, **unused_params)
-        out = {"predictions": res["predictions"].view(B, A, vocab_size).max(dim=1).values}
+        out = {"predictions": ops.frame_pool(res["predictions"].view(B, A, vocab_size), "max")}
         sup = res["support_predictions"]
-        out["support_predictions"] = sup.view(B, A, sup.shape[1]).max(dim=1).values
+        out["support_predictions"] = ops.frame_pool(sup.view(B, A, sup.shape[1]), "max")
         return out

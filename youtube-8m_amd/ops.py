@@ -361,6 +361,92 @@ def topk_rows(p, k=20):
     return vals, idx
 
 
+def sample_frames(x, num_frames, num_samples, mode, seed, return_index=False):
+    """SampleRandomFrames (mode 0) / SampleRandomSequence (mode 1) of W/model_utils.py:23-70 on the device: x [B,F,D] uint8 or
+    float32 -> [B,S,D] of the same dtype (the frames are data: no gradient)."""
+    _dev(x)
+    x = x.contiguous()
+    B, F, D = x.shape
+    nf = None if num_frames is None else num_frames.to(torch.int32).contiguous().view(-1)
+    out = torch.empty((B, num_samples, D), dtype=x.dtype, device=x.device)
+    idx = torch.empty((B, num_samples), dtype=torch.int32, device=x.device) if return_index else None
+    fn = {torch.uint8: "yt8m_sample_frames_u8", torch.float32: "yt8m_sample_frames_f32"}[x.dtype]
+    _lib.check(getattr(_lib.lib(), fn)(_p(x), _p(nf), B, F, D, int(num_samples), int(mode), int(seed), _p(out), _p(idx), _stream()))
+    return (out, idx) if return_index else out
+
+
+class _FramePool(torch.autograd.Function):
+    """FramePooling max / average over the sampled frames (W/model_utils.py:72-95); the max gradient is split equally between
+    tied maxima like tf.reduce_max's."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _f32c(x)
+        _dev(x)
+        B, S, C = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().yt8m_frame_pool_fwd(_p(x), B, S, C, mode, _p(out), _stream()))
+        ctx.save_for_backward(x, out)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, out = ctx.saved_tensors
+        B, S, C = x.shape
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().yt8m_frame_pool_bwd(_p(x), _p(out), _p(dy), B, S, C, ctx.mode, _p(dx), _stream()))
+        return dx, None
+
+
+def frame_pool(x, method):
+    return _FramePool.apply(x, {"max": 0, "average": 1}[method])
+
+
+class _BatchNorm(torch.autograd.Function):
+    """slim.batch_norm(center=True, scale=True) (W/all_frame_models/dbof_model.py:66-71,79-84,103-108) on the
+    rows of x [N,C]: yt8m_batchnorm_fwd / _bwd.  Couples the examples of the local batch, like the reference."""
+
+    @staticmethod
+    def forward(ctx, x, token, gamma, beta, mm, mv, is_training, eps, decay):
+        x = _f32c(x)
+        _dev(x)
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().yt8m_batchnorm_fwd(_p(x), N, C, _p(gamma.data), _p(beta.data), _p(mm.data), _p(mv.data),
+                                                 int(bool(is_training)), float(eps), float(decay), _p(y), _p(mean), _p(rstd), _stream()))
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.vars = (gamma, beta, bool(is_training))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta, is_training = ctx.vars
+        N, C = x.shape
+        dy = _f32c(dy)
+        L = _lib.lib()
+        ws = torch.empty(L.yt8m_batchnorm_workspace_bytes(C) // 4, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gg, gb = gamma.grad, beta.grad
+        bg = gamma.grad_beta() if gg is not None else 0.0
+        bb = beta.grad_beta() if gb is not None else 0.0
+        _lib.check(L.yt8m_batchnorm_bwd(_p(x), _p(dy), N, C, _p(gamma.data), _p(mean), _p(rstd), int(is_training), _p(dx), _p(gg),
+                                        float(bg), _p(gb), float(bb), _p(ws), ws.numel() * 4, _stream()))
+        if gg is not None:
+            gamma.grad_done()
+        if gb is not None:
+            beta.grad_done()
+        return dx, None, None, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, moving_mean, moving_variance, is_training, eps=1e-3, decay=0.999):
+    return _BatchNorm.apply(x, _token(gamma._graph), gamma, beta, moving_mean, moving_variance, is_training, eps, decay)
+
+
 def perr_rows(p, labels):
     """Per-video precision at equal recall rate on the device (W/eval_util.py:74-99); labels bool / uint8 [B,V]."""
     _dev(p)
