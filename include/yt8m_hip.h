@@ -406,6 +406,23 @@ int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float
                         float* dWc, float dWc_beta, float* dbc, float dbc_beta, void* workspace,
                         int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- uint8 operand path of the hoisted input projection (csrc/u8proj.hip) -----------------------------------------
+ * "readers.py uint8 -> float dequantise folded into the first GEMM" (W/readers.py:178-187, W/utils.py:23-38,
+ * default_transformer.py:4-8 -> lstm_model.py:34-47):  x.W = r (.) ((q - 128).(alpha W) + beta colsum(W)),  (q - 128) exact
+ * in bf16, alpha W split into three bf16 terms (exact to 2^-26), one bf16 NT product over the concatenated reduction.
+ *   yt8m_u8_frames_to_bf16_tm: q [B,F,D] uint8 -> Qb [F*B, ldq] bf16 (TIME-major rows f*B+b, `copies` copies of (q-128)
+ *     side by side), r_out [F*B] = 1/||dequantise(q_f)|| (0 for padding frames), optionally x_tm [F,B,D] fp32 = the
+ *     transformed frames themselves (bit-identical to yt8m_dequant_l2norm_u8, time-major) for the weight-gradient product.
+ *   yt8m_split3_bf16_t: W [K, ldw] fp32 -> out [N, ldo] bf16, out[n][j K + k] = term j of the split of scale * W[k][n].
+ *   yt8m_rowscale_bias_f32: z[m][n] = r[m] (z[m][n] + beta cs[n]) + bias[n] in place (the affine remainder). */
+int yt8m_u8_proj_supported(int64_t D);
+int yt8m_u8_frames_to_bf16_tm(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps,
+                              int copies, void* Qb, int64_t ldq, float* x_tm, float* r_out, yt8m_stream_t stream);
+int yt8m_split3_bf16_t(const float* W, int64_t ldw, int64_t K, int64_t N, float scale, void* out, int64_t ldo,
+                       yt8m_stream_t stream);
+int yt8m_rowscale_bias_f32(float* z, int64_t M, int64_t N, int64_t ldz, const float* r, const float* cs, float beta,
+                           const float* bias, yt8m_stream_t stream);
+
 /* ---- DbofModel pieces (csrc/dbof.hip; W/all_frame_models/dbof_model.py:36-124, W/model_utils.py:23-95) -------
  * yt8m_sample_frames_*: SampleRandomFrames (mode 0: index = int(u[b,s] * num_frames[b])) / SampleRandomSequence (mode 1:
  *   start = int(u[b] * (max(num_frames - S, 0) + 1)), index = min(start + s, num_frames - 1)); u = Philox4x32-10 uniform

@@ -467,3 +467,91 @@ def test_dbof_model_with_batch_norm_vs_oracle(dev, flags, quantized):
             continue
         got = g.vars[k].grad.detach().cpu().double()
         assert float((got - t.grad).abs().max()) <= 5e-4 * max(1.0, float(t.grad.abs().max())), k
+
+
+# ---- uint8 operand path of the hoisted LSTM input projection (csrc/u8proj.hip) -----------------------------
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_lstm_uint8_projection_matches_float_path_and_oracle(dev, flags, chunks):
+    """LstmModel on RAW uint8 frames: the layer-0 projection on exact bf16 operands ((q - 128) x 3-way split of (4/255) W) with
+    the row-norm / rank-1 epilogue equals (a) the float path (DefaultTransformer first, fp32 GEMM) on the same weights and (b) the
+    fp64 oracle on dequantise + l2-normalise, for predictions, loss and all gradients; ragged num_frames incl. 0 and F."""
+    from oracle import np_ref, torch_ref
+    flags.lstm_cells, flags.lstm_pipeline_chunks = "128", chunks
+    rs = np.random.RandomState(41)
+    B, F, D, V = 10, 9, 72, 17
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = np.array([9, 0, 1, 4, 9, 7, 2, 9, 5, 3], dtype=np.int32)
+    y = rs.rand(B, V) < 0.15
+    qd, yd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+    outs = {}
+    P = None
+    for fold in (True, False):
+        flags.fold_dequant = fold
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g)
+        tg.forward(qd, yd, nfd)
+        g.finalize()
+        if P is None:
+            P = {k: (rs.randn(*v.shape) * 0.3).astype(np.float32) for k, v in g.vars.items()}
+        for k, v in g.vars.items():
+            v.data.copy_(torch.from_numpy(P[k]).to(dev).view(v.data.shape))
+        res = tg.forward(qd, yd, nfd, fuse_loss=False)
+        loss = tg.loss(res, yd)
+        loss.backward()
+        outs[fold] = (res["predictions"].detach().cpu().double(), float(loss.detach()), g.grads.detach().cpu().double().clone(), dict(g.vars))
+    pa, la, ga, _ = outs[True]
+    pb, lb, gb, vars_b = outs[False]
+    assert float((pa - pb).abs().max()) < 1e-5 and abs(la - lb) < 1e-5 * abs(lb)
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    # fp64 oracle
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    x64 = np_ref.dequant_l2norm_folded(q, nf)
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    layers = [(tp["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l], tp["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l])
+              for l in range(2)]
+    state = torch_ref.lstm_model_state(T(x64), torch.from_numpy(nf), layers)
+    pr = torch_ref.moe(state, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    assert float((pa - pr.detach()).abs().max()) < 1e-5
+    torch_ref.cross_entropy(pr, T(y)).backward()
+    for k, t in tp.items():
+        v = vars_b[k]
+        got = ga[v.offset:v.offset + v.numel()].view(t.shape)
+        assert float((got - t.grad).abs().max()) <= 2e-4 * max(1.0, float(t.grad.abs().max())), k
+
+
+def test_u8_projection_kernels_exactness(dev):
+    """The pieces: (q - 128) as bf16 is exact, the 3-way split reproduces (4/255) W to <= 2^-24 relative, r / x_tm are
+    bit-identical to yt8m_dequant_l2norm_u8, and the assembled product equals the fp64 x.W to fp32 rounding at D = 1152."""
+    import yt8m_amd._lib as L
+    from yt8m_amd.ops import _p, _stream, _bf16_empty
+    from oracle import np_ref
+    rs = np.random.RandomState(6)
+    B, F, D, N = 5, 7, 1152, 256
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = np.array([7, 0, 3, 7, 1], dtype=np.int32)
+    W = (rs.randn(D, N) * 0.05).astype(np.float32)
+    qd, nfd, Wd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev), torch.from_numpy(W).to(dev)
+    lib = L.lib()
+    Qb = _bf16_empty(F * B, 3 * D, dev)
+    r = torch.empty((F * B,), dtype=torch.float32, device=dev)
+    xtm = torch.empty((F, B, D), dtype=torch.float32, device=dev)
+    L.check(lib.yt8m_u8_frames_to_bf16_tm(_p(qd), _p(nfd), B, F, D, 1e-12, 3, _p(Qb), Qb.stride(0), _p(xtm), _p(r), _stream()))
+    ref = ops.dequant_l2norm(qd, nfd)
+    assert torch.equal(xtm, ref.transpose(0, 1).contiguous())
+    Qf = Qb.float().cpu().numpy().reshape(F, B, 3, D)
+    exp = (q.astype(np.float32) - 128.0).transpose(1, 0, 2) * (np.arange(F)[:, None, None] < nf[None, :, None])
+    for j in range(3):
+        assert np.array_equal(Qf[:, :, j], exp)
+    W3 = _bf16_empty(N, 3 * D, dev)
+    L.check(lib.yt8m_split3_bf16_t(_p(Wd), N, D, N, 4.0 / 255.0, _p(W3), W3.stride(0), _stream()))
+    w3 = W3.float().cpu().numpy().astype(np.float64).reshape(N, 3, D).sum(1).T
+    aw = (W * np.float32(4.0 / 255.0)).astype(np.float64)
+    assert np.abs(w3 - aw).max() <= 2.0 ** -24 * np.abs(aw).max()
+    z, = ops.gemm_bf16_nt_grouped([dict(A=Qb, B=W3)])
+    cs = torch.empty((N,), dtype=torch.float32, device=dev)
+    ops.colsum(Wd, cs)
+    import yt8m_amd.seq_ops as seq_ops
+    L.check(lib.yt8m_rowscale_bias_f32(_p(z), F * B, N, N, _p(r), _p(cs), seq_ops.U8_BETA, None, _stream()))
+    x64 = np_ref.dequant_l2norm_folded(q, nf).transpose(1, 0, 2).reshape(F * B, D)
+    zr = x64 @ W.astype(np.float64)
+    assert np.abs(z.cpu().numpy() - zr).max() < 2e-6 * max(1.0, np.abs(zr).max())

@@ -124,6 +124,10 @@ SIGNATURES = {
                                                c_int64, c_int64, P, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
     "yt8m_tfrecord_read_video_batch": (c_int, [P, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int32), c_int, c_int64,
                                                c_int64, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
+    "yt8m_u8_proj_supported": (c_int, [c_int64]),
+    "yt8m_u8_frames_to_bf16_tm": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, c_int, P, c_int64, P, P, P]),
+    "yt8m_split3_bf16_t": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_rowscale_bias_f32": (c_int, [P, c_int64, c_int64, c_int64, P, P, c_float, P, P]),
     "yt8m_sample_frames_f32": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, c_int, ctypes.c_uint64, P, P, P]),
     "yt8m_sample_frames_u8": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, c_int, ctypes.c_uint64, P, P, P]),
     "yt8m_frame_pool_fwd": (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),

@@ -42,15 +42,29 @@ def _head(name=None):
     return getattr(video_level_models, name or FLAGS.video_level_classifier_model)
 
 
+def _lib_u8_ok(D):
+    from . import _lib
+    return bool(_lib.lib().yt8m_u8_proj_supported(int(D)))
+
+
 def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN", input_keep_prob=None):
     """MultiRNNCell([BasicLSTMCell(H, forget_bias=1.0)] * L) under tf.nn.dynamic_rnn inside variable_scope("RNN")
     (W/all_frame_models/lstm_model.py:34-47).  TF-1.0 variable names:
     RNN/multi_rnn_cell/cell_<l>/basic_lstm_cell/{weights,biases}.  Returns time-major outputs of the top layer
     and the per-layer final (c, h)."""
     g = get_default_graph()
-    x_tm = model_input.transpose(0, 1).contiguous()          # [F,B,D]   (layout glue)
+    if model_input.dtype == torch.uint8:
+        # raw reader bytes: the stack's layer-0 projection consumes them directly (csrc/u8proj.hip: exact bf16 operands, the
+        # dequantise / l2-normalise affine folded into the GEMM epilogue); no fp32 [B,F,D] tensor, no transpose copy
+        dropping = input_keep_prob is not None and float(input_keep_prob) < 1.0
+        if _lib_u8_ok(model_input.shape[2]) and not dropping:
+            x_tm = model_input                                   # [B,F,D] uint8, re-ordered time-major by the conversion pass
+        else:
+            x_tm = ops.dequant_l2norm(model_input, num_frames).transpose(0, 1).contiguous()
+    else:
+        x_tm = model_input.transpose(0, 1).contiguous()          # [F,B,D]   (layout glue)
     wb = []
-    d_in = x_tm.shape[2]
+    d_in = model_input.shape[2]
     with g.variable_scope(scope):
         for l in range(number_of_layers):
             scope = "multi_rnn_cell/cell_%d/basic_lstm_cell" % l
@@ -76,7 +90,8 @@ class FrameLevelLogisticModel(models.BaseModel):
 
 class LstmModel(models.BaseModel):
     """W/all_frame_models/lstm_model.py:13-57: the head reads the whole final state [c0||h0||c1||h1]
-    (state_is_tuple=False), 4H wide for two layers."""
+    (state_is_tuple=False), 4H wide for two layers.  accepts_quantized_input: see _lstm_stack."""
+    accepts_quantized_input = True
 
     def create_model(self, model_input, vocab_size, num_frames, **unused_params):
         lstm_size = int(FLAGS.lstm_cells)
@@ -89,6 +104,7 @@ class LstmModel(models.BaseModel):
 
 class LstmMemoryModel(models.BaseModel):
     """W/all_frame_models/lstm_memory_model.py:13-73: the head reads the concatenated c states (2H)."""
+    accepts_quantized_input = True
 
     def create_model(self, model_input, vocab_size, num_frames, dropout=False, keep_prob=None, noise_level=None,
                      **unused_params):

@@ -262,6 +262,7 @@ def _chunks(F, n):
 
 import os as _os
 PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent recurrence kernels (csrc/lstm_persist.hip)
+U8_BETA = 128.0 * 4.0 / 255.0 + (4.0 / 512.0 - 2.0)     # dequantise(q) = (4/255) (q - 128) + U8_BETA
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 REC_BF16 = True       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
@@ -293,14 +294,28 @@ class _LstmStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_tm, token, num_frames, forget_bias, chunks, input_keep_prob, seeds, bf16, *wb):
+        lib = _lib.lib()
+        nf = _nf(num_frames)
+        q_raw = None
+        if x_tm.dtype == torch.uint8:
+            # raw reader output [B,F,D] (batch-major): the layer-0 projection takes the bytes themselves (csrc/u8proj.hip) --
+            # one conversion pass writes (q - 128) as bf16 in time-major order (three copies side by side: the three bf16
+            # terms of alpha W share one concatenated reduction), the row norms, and the fp32 time-major frames that only
+            # the weight-gradient product still reads
+            _dev(x_tm)
+            q_raw = x_tm.contiguous()
+            Bq, Fq, Dq = q_raw.shape
+            Qb = ops._bf16_empty(Fq * Bq, 3 * Dq, q_raw.device)
+            rrow = torch.empty((Fq * Bq,), dtype=torch.float32, device=q_raw.device)
+            x_tm = torch.empty((Fq, Bq, Dq), dtype=torch.float32, device=q_raw.device)
+            _lib.check(lib.yt8m_u8_frames_to_bf16_tm(_p(q_raw), _p(nf), Bq, Fq, Dq, 1e-12, 3, _p(Qb), Qb.stride(0), _p(x_tm), _p(rrow),
+                                                     _stream()))
         x_tm = _f32c(x_tm)
         _dev(x_tm)
         L = len(wb) // 2
         Ws, bs = wb[0::2], wb[1::2]
         F, B, _ = x_tm.shape
         dev = x_tm.device
-        lib = _lib.lib()
-        nf = _nf(num_frames)
         main = torch.cuda.current_stream(dev)
         rs, gs, _ = _side_streams(dev, L)
         parts = _chunks(F, chunks)
@@ -336,6 +351,14 @@ class _LstmStack(torch.autograd.Function):
                 if st["Wp"] is not None:
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
                 st["bf16"] = bf16 and st["Din"] % 2 == 0
+                if l == 0 and q_raw is not None and not drop and not st["bf16"]:
+                    # 3-way bf16 split of (4/255) W_x, transposed ([4H, 3 D], K-contiguous) + the column sums of W_x
+                    Din_, H_ = st["Din"], st["H"]
+                    st["W3T"] = ops._bf16_empty(4 * H_, 3 * Din_, dev)
+                    _lib.check(lib.yt8m_split3_bf16_t(_p(st["W"].data[:Din_]), 4 * H_, Din_, 4 * H_, 4.0 / 255.0, _p(st["W3T"]),
+                                                      st["W3T"].stride(0), _stream()))
+                    st["Wcs"] = torch.empty((4 * H_,), dtype=torch.float32, device=dev)
+                    ops.colsum(st["W"].data[:Din_], st["Wcs"])
                 st["rec16"] = st["bf16"] and REC_BF16 and lib.yt8m_lstm_packed16_elems(B, st["H"]) > 0
                 if st["rec16"]:
                     st["pws"] = None
@@ -359,7 +382,12 @@ class _LstmStack(torch.autograd.Function):
                         src = x_tm[t0:t0 + T] if l == 0 else xc
                         _lib.check(lib.yt8m_dropout_f32(_p(src), _p(xc), xc.numel(), float(input_keep_prob), int(seeds[l]),
                                                         t0 * B * Din, _stream()))
-                    if st["bf16"]:
+                    if "W3T" in st:
+                        zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
+                        ops.gemm_bf16_nt_grouped([dict(A=Qb[t0 * B:(t0 + T) * B], B=st["W3T"], out=zc)])
+                        _lib.check(lib.yt8m_rowscale_bias_f32(_p(zc), T * B, 4 * H, 4 * H, _p(rrow[t0 * B:]), _p(st["Wcs"]),
+                                                              U8_BETA, _p(st["b"].data), _stream()))
+                    elif st["bf16"]:
                         ops.gemm_bf16_nt_grouped([dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din)), B=st["WxT"],
                                                        out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
                     else:
@@ -408,6 +436,8 @@ class _LstmStack(torch.autograd.Function):
         dx = torch.empty_like(layers[0]["x"]) if need_dx else None
         for st in layers:
             st.pop("WxT", None)
+            st.pop("W3T", None)
+            st.pop("Wcs", None)
             st.pop("Wp16", None)
             st.pop("hs16", None)
         for l, st in enumerate(layers):                            # buffers come from the main stream's pool
