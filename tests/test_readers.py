@@ -189,3 +189,71 @@ def test_prefetcher_delivers_every_record_once(tmp_path, threads):
     open(bad, "wb").write(bytes(raw))
     with pytest.raises(ValueError):
         list(rd.prepare_reader([shards[0], bad], batch_size=4, num_threads=threads))
+
+
+# ---- records encoded by the protobuf runtime (tests/golden/make_tfrecord_golden.py), not by this repository's writer --------
+def _golden(golden_dir):
+    import json
+    import os
+    meta = json.load(open(os.path.join(golden_dir, "tfrecord_golden.json")))
+    return meta, os.path.join(golden_dir, "tfrecord_frame.bin"), os.path.join(golden_dir, "tfrecord_video.bin")
+
+
+def test_protobuf_encoded_frame_records(golden_dir):
+    """tf.train.SequenceExample bytes from google.protobuf (deterministic serialisation, maps sorted by key -- a different field
+    order than the oracle writer emits) through the native reader: ids, labels (bit-exact multi-hot), num_frames, truncation to
+    max_frames = 10 and the uint8 frame bytes (checksums + edge rows) all as the generator recorded them."""
+    meta, frame_bin, _ = _golden(golden_dir)
+    rd = readers.YT8MFrameFeatureReader(num_classes=meta["num_classes"], feature_sizes=meta["sizes"], feature_names=meta["names"],
+                                        max_frames=meta["max_frames"])
+    got = list(rd.prepare_reader([frame_bin], batch_size=16))
+    assert len(got) == 1
+    ids, q, lab, nf = got[0]
+    q, lab, nf = q.numpy(), lab.numpy(), nf.numpy()
+    assert q.dtype == np.uint8 and q.shape == (4, 10, 1152)
+    for i, v in enumerate(meta["videos"]):
+        assert ids[i] == v["video_id"].encode()
+        assert sorted(np.nonzero(lab[i])[0].tolist()) == sorted(set(v["labels"]))
+        k = min(v["num_frames"], 10)
+        assert nf[i] == k and not q[i, k:].any()
+        off = 0
+        for n, s in zip(meta["names"], meta["sizes"]):
+            blk = q[i, :k, off:off + s]
+            assert blk[0, :8].tolist() == v["frame_first_row"][n] and blk[k - 1, -8:].tolist() == v["frame_last_row"][n]
+            if v["num_frames"] <= 10:
+                assert int(blk.astype(np.uint64).sum()) == v["frame_checksum"][n]
+            off += s
+
+
+def test_protobuf_encoded_video_records(golden_dir):
+    meta, _, video_bin = _golden(golden_dir)
+    names = ["mean_" + n for n in meta["names"]]
+    rd = readers.YT8MAggregatedFeatureReader(num_classes=meta["num_classes"], feature_sizes=meta["sizes"], feature_names=names)
+    got = list(rd.prepare_reader(video_bin, batch_size=16))
+    ids, x, lab, _ = got[0]
+    x, lab = x.numpy(), lab.numpy()
+    for i, v in enumerate(meta["videos"]):
+        assert ids[i] == v["video_id"].encode()
+        assert sorted(np.nonzero(lab[i])[0].tolist()) == sorted(set(v["labels"]))
+        off = 0
+        for n, s in zip(names, meta["sizes"]):
+            assert [float(t) for t in x[i, off:off + 6]] == v["features"][n]
+            assert abs(float(x[i, off:off + s].astype(np.float64).sum()) - v["feature_sum"][n]) < 1e-9
+            off += s
+
+
+def test_protobuf_golden_is_reproducible(golden_dir, tmp_path):
+    """The committed bytes are what the installed protobuf runtime produces today (skipped when protobuf is absent)."""
+    pytest.importorskip("google.protobuf")
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_tfrecord_golden", os.path.join(golden_dir, "make_tfrecord_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    Example, SequenceExample = mod.build_messages()
+    ex = SequenceExample()
+    ex.context.feature["labels"].int64_list.value.extend([1, 300])
+    ex.feature_lists.feature_list["rgb"].feature.add().bytes_list.value.append(b"\\x01\\x02")
+    # the oracle's encoder and protobuf agree byte for byte on a record whose maps have a single key each
+    ctx = {"labels": tr.int64_feature([1, 300])}
+    assert tr.sequence_example(ctx, {"rgb": [tr.bytes_feature([b"\\x01\\x02"])]}) == ex.SerializeToString(deterministic=True)
