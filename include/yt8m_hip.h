@@ -406,6 +406,21 @@ int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, const float
                         float* dWc, float dWc_beta, float* dbc, float dbc_beta, void* workspace,
                         int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- gradient all-reduce: RCCL over xGMI (csrc/comm.hip) ---------------------------------------
+ * Replaces the reference's asynchronous parameter-server traffic (tf.train.replica_device_setter + apply_gradients over
+ * gRPC, W/train.py:624-639,731-776) by the synchronous data-parallel mean of SURVEY.md 8e.  One communicator per process /
+ * GPU: rank 0 creates the 128-byte id (yt8m_comm_unique_id), the caller hands it to every rank, each rank calls
+ * yt8m_comm_init with its HIP device current.  All-reduce / broadcast are in place on fp32 device buffers and
+ * asynchronous on `stream`.  RCCL is bound with dlopen at first use; every failure here returns YT8M_E_RCCL. */
+#define YT8M_COMM_ID_BYTES 128
+int yt8m_comm_unique_id(void* id_out);
+int yt8m_comm_init(int rank, int world, const void* unique_id, void** comm_out);
+int yt8m_comm_size(void* comm, int* rank, int* world);
+int yt8m_comm_allreduce_f32(void* comm, float* buf, int64_t n, int mean, yt8m_stream_t stream);
+int yt8m_comm_allreduce_mean(void* comm, float* buf, int64_t n, yt8m_stream_t stream);
+int yt8m_comm_broadcast_f32(void* comm, float* buf, int64_t n, int root, yt8m_stream_t stream);
+int yt8m_comm_destroy(void* comm);
+
 /* ---- uint8 operand path of the hoisted input projection (csrc/u8proj.hip) -----------------------------------------
  * "readers.py uint8 -> float dequantise folded into the first GEMM" (W/readers.py:178-187, W/utils.py:23-38,
  * default_transformer.py:4-8 -> lstm_model.py:34-47):  x.W = r (.) ((q - 128).(alpha W) + beta colsum(W)),  (q - 128) exact

@@ -178,3 +178,21 @@ def test_lr_schedule_and_variable_store(flags):
     assert set(sd) == {"RNN/cell/weights", "experts/biases", "Variable", "Variable_1"}
     lim = (6.0 / (5000 + 3)) ** 0.5
     assert float(w.data.abs().max()) <= lim and float(w.data.abs().max()) > 0.9 * lim
+
+
+def test_comm_entry_points_fail_loudly_without_a_gpu():
+    """yt8m_comm_*: argument errors are YT8M_E_BADARG; anything RCCL refuses (no ROCm device on this box) is YT8M_E_RCCL with
+    the RCCL message in yt8m_last_error -- never a silent fallback."""
+    import ctypes
+    import yt8m_amd._lib as L
+    lib = L.lib()
+    buf = ctypes.create_string_buffer(128)
+    comm = ctypes.c_void_p()
+    assert lib.yt8m_comm_unique_id(None) == -1
+    assert lib.yt8m_comm_init(0, 0, buf, ctypes.byref(comm)) == -1 and lib.yt8m_comm_init(2, 2, buf, ctypes.byref(comm)) == -1
+    assert lib.yt8m_comm_allreduce_mean(None, None, 4, None) == -1
+    assert lib.yt8m_comm_destroy(None) == 0
+    rc = lib.yt8m_comm_unique_id(buf)
+    assert rc in (0, -4)
+    if rc == -4:
+        assert b"ncclGetUniqueId" in lib.yt8m_last_error() or b"RCCL" in lib.yt8m_last_error()

@@ -555,3 +555,96 @@ def test_u8_projection_kernels_exactness(dev):
     x64 = np_ref.dequant_l2norm_folded(q, nf).transpose(1, 0, 2).reshape(F * B, D)
     zr = x64 @ W.astype(np.float64)
     assert np.abs(z.cpu().numpy() - zr).max() < 2e-6 * max(1.0, np.abs(zr).max())
+
+
+# ---- RCCL in the C ABI (csrc/comm.hip) ------------------------------------------------------------------------------
+def test_cabi_comm_single_rank(dev):
+    """yt8m_comm_unique_id / init / size / allreduce (sum, mean) / broadcast / destroy on a 1-rank communicator, and the
+    GradReducer driving a training step through it: identical to the step without a reducer."""
+    import yt8m_amd.parallel as parallel
+    comm = parallel.CabiComm(0, 1)
+    assert comm.size() == (0, 1)
+    t = torch.arange(1000, dtype=torch.float32, device=dev)
+    ref = t.clone()
+    comm.all_reduce(t).wait()
+    comm.all_reduce(t, mean=True).wait()
+    comm.broadcast(t, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref)
+    B, D, V = 32, 40, 57
+    (x, y), = _toy_batches(dev, 1, B, D, V, 3)
+
+    def run(reducer):
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g, reducer=reducer)
+        for _ in range(2):
+            tg.step(x, y)
+        return g.params.clone()
+
+    a = run(None)
+    b = run(parallel.GradReducer(comm=comm))
+    assert torch.equal(a, b)
+    comm.close()
+
+
+def _two_rank_worker(rank, world, port, q):
+    try:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import __graft_entry__
+        __graft_entry__.load_package()
+        import torch.distributed as dist
+        import yt8m_amd.parallel as parallel
+        import yt8m_amd.train as train_
+        import yt8m_amd.video_level_models as vlm_
+        from yt8m_amd.variables import reset_default_graph as rdg
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        parallel.init_from_env("nccl")
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        Bg, D, V = 64, 48, 65
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        xs = [torch.rand((Bg, D), generator=gen) * 4 - 2 for _ in range(3)]
+        ys = [torch.rand((Bg, V), generator=gen) < 0.05 for _ in range(3)]
+        lo, hi = parallel.shard_batch(Bg, rank, world)
+        g = rdg(device=dev, seed=0)
+        tg = train_.TrainGraph(vlm_.MoeModel(), batch_size=Bg, graph=g, reducer=parallel.GradReducer())
+        for x, y in zip(xs, ys):
+            tg.step(x[lo:hi].to(dev), y[lo:hi].to(dev))
+        out = g.params.detach().cpu()
+        if rank == 0:
+            g1 = rdg(device=dev, seed=0)
+            t1 = train_.TrainGraph(vlm_.MoeModel(), batch_size=Bg, graph=g1)
+            for x, y in zip(xs, ys):
+                t1.step(x.to(dev), y.to(dev))
+            ref = g1.params.detach().cpu()
+            err = float((out - ref).abs().max() / ref.abs().max())
+            q.put((rank, "ok" if err < 1e-5 else "FAIL rel err %g" % err))
+        else:
+            q.put((rank, "ok"))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_two_rank_rccl_step_equals_one_rank_on_the_global_batch(dev):
+    """SURVEY.md 8e on real RCCL: two ranks on shards of a global batch (bucketed all-reduce, 1/world folded into Adam, global-
+    batch LR staircase) end at the 1-rank parameters on the concatenated batch.  Needs >= 2 GPUs (skipped on the 1-GPU box)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -124,6 +124,13 @@ SIGNATURES = {
                                                c_int64, c_int64, P, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
     "yt8m_tfrecord_read_video_batch": (c_int, [P, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int32), c_int, c_int64,
                                                c_int64, P, P, P, c_int64, ctypes.POINTER(c_int64)]),
+    "yt8m_comm_unique_id": (c_int, [P]),
+    "yt8m_comm_init": (c_int, [c_int, c_int, P, ctypes.POINTER(c_void_p)]),
+    "yt8m_comm_size": (c_int, [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "yt8m_comm_allreduce_f32": (c_int, [P, P, c_int64, c_int, P]),
+    "yt8m_comm_allreduce_mean": (c_int, [P, P, c_int64, P]),
+    "yt8m_comm_broadcast_f32": (c_int, [P, P, c_int64, c_int, P]),
+    "yt8m_comm_destroy": (c_int, [P]),
     "yt8m_u8_proj_supported": (c_int, [c_int64]),
     "yt8m_u8_frames_to_bf16_tm": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, c_int, P, c_int64, P, P, P]),
     "yt8m_split3_bf16_t": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),

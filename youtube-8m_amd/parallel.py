@@ -42,12 +42,89 @@ def shard_batch(n_global, rank, world):
     return rank * per, (rank + 1) * per
 
 
-class GradReducer(object):
-    """All-reduces the gradient arena of a variables.Graph; SUM over ranks, mean applied later via gscale."""
+class CabiComm(object):
+    """RCCL communicator owned by the C-ABI library (yt8m_comm_*, csrc/comm.hip) -- the form a non-PyTorch host binds
+    (INTEGRATION.md).  The 128-byte unique id of rank 0 travels through `exchange`: a callable rank-0-bytes -> bytes
+    (e.g. a torch.distributed.TCPStore round trip, a file, MPI); world == 1 needs none."""
 
-    def __init__(self, group=None, bucket_bytes=32 << 20, overlap=True):
+    def __init__(self, rank, world, exchange=None, device=None):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        L = _lib.lib()
+        if device is not None:
+            torch.cuda.set_device(device)
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.yt8m_comm_unique_id(buf))
+        if world > 1:
+            if exchange is None:
+                raise ValueError("world > 1 needs an `exchange` callable for the unique id")
+            buf = ctypes.create_string_buffer(exchange(buf.raw if rank == 0 else None), 128)
+        self.handle = ctypes.c_void_p()
+        _lib.check(L.yt8m_comm_init(int(rank), int(world), buf, ctypes.byref(self.handle)))
+        self.rank, self.world = int(rank), int(world)
+        self.stream = torch.cuda.Stream()                     # collectives run beside the backward kernels
+
+    def _p(self, t):
+        import ctypes
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        return ctypes.c_void_p(t.data_ptr())
+
+    def all_reduce(self, t, mean=False):
+        """In place SUM (or mean) of a contiguous fp32 device tensor; returns a handle whose wait() orders the CURRENT stream
+        behind the collective."""
+        import ctypes
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)
+        self._lib.check(self._lib.lib().yt8m_comm_allreduce_f32(self.handle, self._p(t), t.numel(), int(bool(mean)),
+                                                                ctypes.c_void_p(self.stream.cuda_stream)))
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        t.record_stream(self.stream)
+        return _CabiHandle(done)
+
+    def broadcast(self, t, root=0):
+        import ctypes
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)
+        self._lib.check(self._lib.lib().yt8m_comm_broadcast_f32(self.handle, self._p(t), t.numel(), int(root),
+                                                                ctypes.c_void_p(self.stream.cuda_stream)))
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        torch.cuda.current_stream().wait_event(done)
+
+    def size(self):
+        import ctypes
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._lib.check(self._lib.lib().yt8m_comm_size(self.handle, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            self._lib.check(self._lib.lib().yt8m_comm_destroy(self.handle))
+            self.handle = None
+
+
+class _CabiHandle(object):
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+class GradReducer(object):
+    """All-reduces the gradient arena of a variables.Graph; SUM over ranks, mean applied later via gscale.  Transport:
+    torch.distributed (backend "nccl" = RCCL) by default, or a CabiComm (the library's own RCCL binding) when `comm` is given."""
+
+    def __init__(self, group=None, bucket_bytes=32 << 20, overlap=True, comm=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm = comm
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
         self.graph = None
@@ -59,10 +136,15 @@ class GradReducer(object):
     def attach(self, graph):
         """Hooks the graph and makes every rank start from rank 0's parameters."""
         self.graph = graph
-        self.active = dist.is_initialized()
-        graph.rank = dist.get_rank(self.group) if self.active else 0     # ranks draw different dropout / noise streams
+        self.active = self.comm is not None or dist.is_initialized()
+        if self.comm is not None:
+            graph.rank = self.comm.rank
+        else:
+            graph.rank = dist.get_rank(self.group) if self.active else 0     # ranks draw different dropout / noise streams
         graph.grad_ready_hook = self._on_ready if (self.overlap and self.active) else None
-        if self.active:
+        if self.comm is not None:
+            self.comm.broadcast(graph.params, 0)
+        elif self.active:
             dist.broadcast(graph.params, src=0, group=self.group)
         nv = len(graph.trainable_variables())
         self._ready = [False] * nv
@@ -108,7 +190,10 @@ class GradReducer(object):
                 hs = []
                 while pos < hi:
                     end = min(hi, pos + 4 * self.bucket_elems)
-                    hs.append(dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if self.comm is not None:
+                        hs.append(self.comm.all_reduce(self.graph.grads[pos:end]))
+                    else:
+                        hs.append(dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     pos = end
                 self._handles.append((i, j + 1, hs))      # trainable variables [i, j+1) ride on these handles
                 for k in range(i, j + 1):
