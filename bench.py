@@ -436,10 +436,19 @@ def main():
             elif a.workload == "lstm" and roof:
                 try:                   # PMC passes of the headline step, committed with the round's profiles
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_lstm.json")))
-                    roof["traffic"] = pm.get("dominant_bytes_per_launch")
-                    roof["traffic_unit"] = pm.get("unit")
+                    key = "gemm" if roof["kernel"].startswith("gemm") else "lstm_recurrence"
+                    roof["traffic"] = pm["families"][key]["hbm_bytes_per_launch"]
+                    roof["traffic_unit"] = pm["unit"]
+                    roof["traffic_kernel"] = pm["families"][key]["kernel"]
+                    roof["algorithmic_bytes_per_launch"] = pm["families"][key].get("algorithmic_bytes_per_launch")
                 except Exception:
                     pass
+            if roof:
+                # whole-step view: every algorithmic FLOP of the step over the WALL time of the timed region (the families above
+                # are hipEvent durations of launches that share the chip across streams, so they overlap and add up to more)
+                tot = sum(cfg["flops"](B).values())
+                roof["step_level"] = {"algorithmic_flops_per_step": tot, "achieved": tot / (el / a.steps) / 1e12,
+                                      "frac": tot / (el / a.steps) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS)}
     del tg, g, pool
     torch.cuda.empty_cache()
 
