@@ -330,11 +330,13 @@ int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, flo
                           const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
                           void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* backward: steps t0+T-1 down to t0; (gates, cs, dout, dz, work, phase) exactly as yt8m_lstm_steps_bwd.  The backward of
- * dynamic_rnn's while_loop (tf.gradients through W/all_frame_models/lstm_model.py:44-47). */
+ * dynamic_rnn's while_loop (tf.gradients through W/all_frame_models/lstm_model.py:44-47).  dbias_rows (may be NULL):
+ * [B,4H] running sums of dz over the processed steps, accumulated IN PLACE (zero it before the first chunk); the bias
+ * gradient is its column sum -- saves the pass over the whole [F*B,4H] dz. */
 int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H);
 int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
-                          float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
-                          void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+                          float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                          int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
 /* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the
  * re-packed recurrent weights owned by the caller (yt8m_lstm_pack; yt8m_lstm_packed_floats() floats each for the forward

@@ -109,7 +109,7 @@ def timing_bwd(B=128, F=300, H=1024):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, 0, F, B, H, _p(pws),
+        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws),
                                           pws.numel(), _stream()))
         e1.record()
         torch.cuda.synchronize()

@@ -34,7 +34,7 @@ for it in range(2):
         work = torch.zeros((4, B, H), device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(csr), _p(dout), _p(dz), _p(work), 0, None, 0, F, B, H, _p(pws), nb,
+        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(csr), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), nb,
                                           _stream()))
         e1.record()
         torch.cuda.synchronize()

@@ -91,7 +91,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_status": (c_int, [P, P]),
     "yt8m_lstm_persist_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
-    "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
+    "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lstm_packed_floats": (c_int64, [c_int64, c_int64]),
     "yt8m_lstm_pack": (c_int, [P, c_int64, c_int64, P, P, P]),
     "yt8m_lstm_steps_fwd": (c_int, [P, P, c_int64, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),

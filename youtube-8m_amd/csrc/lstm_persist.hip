@@ -414,6 +414,7 @@ struct PersistBwdArgs {
   const float* dout;    // [F,B,H] or null
   float* dz;            // [F,B,4H]
   float* work;          // [4,B,H]: running (dh, dc) in halves 0 / 1
+  float* dbrows;        // [B,4H] or null: per-row running sum of dz over the steps (the bias gradient before its sum over rows)
   const int32_t* nf;
   float* dzx;           // exchange buffer [2][NT16][4H/16][256]
   unsigned* ctl;
@@ -596,6 +597,10 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   auto store_std = [&](int t1, int brow, const float (&dzv)[4], float dc_out, float base_out, int half) {
     float* dzr = a.dz + ((long long)t1 * B + brow) * 4 * H + ub * 16 + eunit;
     dzr[0] = dzv[0]; dzr[H] = dzv[1]; dzr[2 * H] = dzv[2]; dzr[3 * H] = dzv[3];
+    if (a.dbrows) {                                      // this lane owns (row, unit) for every step: a private running sum
+      float* db = a.dbrows + (long long)brow * 4 * H + ub * 16 + eunit;
+      db[0] += dzv[0]; db[H] += dzv[1]; db[2 * H] += dzv[2]; db[3 * H] += dzv[3];
+    }
     float* wk = a.work + (long long)(2 * half) * BH + (long long)brow * H + ub * 16 + eunit;
     wk[0] = base_out;
     wk[BH] = dc_out;
@@ -830,8 +835,8 @@ extern "C" int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H) {
 }
 
 extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
-                                     float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
-                                     void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+                                     float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                                     int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
   if (T * B * H == 0) return YT8M_OK;
@@ -847,6 +852,7 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   const int64_t cb = ((ctl_bytes(geo.NT16) + 255) / 256) * 256;
   PersistBwdArgs a;
   a.gates = gates; a.Wh = Wh; a.ldw = ldw; a.cs = cs; a.dout = dout; a.dz = dz; a.work = work; a.nf = num_frames;
+  a.dbrows = dbias_rows;
   a.ctl = static_cast<unsigned*>(workspace);
   a.dzx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.phase = phase;

@@ -263,6 +263,7 @@ def _chunks(F, n):
 import os as _os
 PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent recurrence kernels (csrc/lstm_persist.hip)
 U8_BETA = 128.0 * 4.0 / 255.0 + (4.0 / 512.0 - 2.0)     # dequantise(q) = (4/255) (q - 128) + U8_BETA
+PERSIST_DBROWS = False
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 REC_BF16 = True       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
@@ -490,9 +491,13 @@ class _LstmStack(torch.autograd.Function):
                                                                 _p(st["dz16"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H,
                                                                 _stream()))
                     elif st.get("pws") is not None and PERSIST_BWD and lib.yt8m_lstm_persist_bwd_supported(B, H):
+                        # bias gradient as per-row sums in the epilogue: measured SLOWER (37.1 -> 40.3 ms/step: four more scattered
+                        # read-modify-writes per lane and item sit in the CU's memory queue in front of the exchange loads); off
+                        if PERSIST_DBROWS and "dbrows" not in st and b.grad is not None:
+                            st["dbrows"] = torch.zeros((B, 4 * H), dtype=torch.float32, device=dev)
                         _lib.check(lib.yt8m_lstm_persist_bwd(_p(st["z"]), _p(W.data[Din:]), 4 * H, _p(st["cs"]), _p(st["dout"]),
-                                                             _p(st["dz"]), _p(st["work"]), st["phase"], _p(nf), t0, T, B, H,
-                                                             _p(st["pws"]), st["pws"].numel(), _stream()))
+                                                             _p(st["dz"]), _p(st["work"]), st["phase"], _p(st.get("dbrows")), _p(nf),
+                                                             t0, T, B, H, _p(st["pws"]), st["pws"].numel(), _stream()))
                         if PERSIST_CHECK:
                             _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
                     else:
@@ -545,12 +550,13 @@ class _LstmStack(torch.autograd.Function):
                         else:
                             ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta)
                             ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta)
-                    if b.grad is not None:
+                    if b.grad is not None and ("dbrows" not in st or c == 0):
                         beta = wbeta.get(id(b))
                         if beta is None:
                             beta = b.grad_beta()
                             wbeta[id(b)] = 1.0
-                        ops.colsum(dzc, b.grad.view(-1), beta=beta)
+                        # persistent backward: the per-row sums are complete after the last (earliest) chunk -> one [B,4H] column sum
+                        ops.colsum(st["dbrows"] if "dbrows" in st else dzc, b.grad.view(-1), beta=beta)
         fin = torch.cuda.Event()
         fin.record(sw)                                              # sw waited for every recurrence chunk
         main.wait_event(fin)
