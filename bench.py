@@ -418,6 +418,8 @@ def main():
         pool = make_pool(a.workload, B, dev, rank, a.pool)
     el, run = timed_run(tg, pool, a.steps, a.warmup, world, dev, dist)
     params = sum(v.numel() for v in g.trainable_variables())
+    import yt8m_amd.seq_ops as seq_ops
+    seq_ops.check_persist_errors()              # a persistent launch that timed out must fail the bench, not skew it
 
     roof = None
     if not a.no_roofline:

@@ -11,6 +11,8 @@ import torch
 
 def save(train_graph, directory, max_to_keep=3):
     from safetensors.torch import save_file
+    from . import seq_ops
+    seq_ops.check_persist_errors()              # never checkpoint weights produced by a timed-out recurrence launch
     g = train_graph.graph
     os.makedirs(directory, exist_ok=True)
     sd = {}

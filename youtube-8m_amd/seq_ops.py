@@ -263,7 +263,24 @@ def _chunks(F, n):
 import os as _os
 PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent recurrence kernels (csrc/lstm_persist.hip)
 U8_BETA = 128.0 * 4.0 / 255.0 + (4.0 / 512.0 - 2.0)     # dequantise(q) = (4/255) (q - 128) + U8_BETA
+BWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_BWD_CHUNKS", "0"))    # 0: same partition as the forward pass
 PERSIST_DBROWS = False
+_PERSIST_WS = {}      # data_ptr -> workspace tensor of recent persistent launches (for check_persist_errors)
+
+
+def _remember_ws(ws):
+    if len(_PERSIST_WS) > 64:
+        _PERSIST_WS.clear()
+    _PERSIST_WS[ws.data_ptr()] = ws
+
+
+def check_persist_errors():
+    """Synchronises and raises if any recent persistent-recurrence launch gave up waiting for a tile (bounded spins set an error
+    word instead of hanging the GPU).  The training loop calls this at its checkpoints; tests run with PERSIST_CHECK per launch."""
+    lib = _lib.lib()
+    for ws in list(_PERSIST_WS.values()):
+        _lib.check(lib.yt8m_lstm_persist_status(_p(ws), _stream()))
+    _PERSIST_WS.clear()
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 REC_BF16 = True       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
@@ -406,6 +423,7 @@ class _LstmStack(torch.autograd.Function):
                         _lib.check(lib.yt8m_lstm_persist_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["cs"]), _p(st["hs"]),
                                                              _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _p(st["pws"]),
                                                              st["pws"].numel(), _stream()))
+                        _remember_ws(st["pws"])
                         if PERSIST_CHECK:
                             _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
                     else:
@@ -415,7 +433,9 @@ class _LstmStack(torch.autograd.Function):
                     r_done[l][c].record(rs[l])
         for l in range(L):
             main.wait_event(r_done[l][-1])
-        ctx.layers, ctx.nf, ctx.parts = layers, nf, parts
+        # the backward pass may cut time differently (all buffers are whole-layer): its first recurrence chunk runs with nothing
+        # beside it, so shorter chunks shorten that pipeline fill; the forward recurrence owns the chip and wants few launches
+        ctx.layers, ctx.nf, ctx.parts = layers, nf, (_chunks(F, BWD_CHUNKS) if BWD_CHUNKS > 0 else parts)
         ctx.drop = (float(input_keep_prob), tuple(int(v) for v in seeds)) if drop else None
         ctx.set_materialize_grads(False)
         outs = [layers[-1]["out"]]
