@@ -336,6 +336,54 @@ def gap_leg(dev, B=1024, train_steps=768, heldout=16384, signal=3.0):
             "positives_per_video": pos / train_steps, "data": "synthetic teacher shard (MoeModel, configs[1])"}
 
 
+def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048):
+    """The acceptance form of the north-star's second target ("GAP@20 within 0.001 of the reference on a held-out synthetic
+    shard"), at a size the CPU port trains in seconds: the SAME MoeModel from the SAME initial weights on the SAME teacher-shard
+    batches through the HIP path and through the torch-CPU restatement (the checker: oracle/torch_ref.py, TF1 is not runnable);
+    GAP@20 of both on a disjoint held-out shard."""
+    import numpy as np
+    import yt8m_amd.eval_util as eval_util
+    import yt8m_amd.train as train
+    import yt8m_amd.video_level_models as vlm
+    from yt8m_amd.flags import FLAGS
+    from yt8m_amd.variables import reset_default_graph
+    from oracle import torch_ref
+    FLAGS.reset()
+    gen = torch.Generator().manual_seed(7)
+    Wt = torch.randn(D_, V_, generator=gen) / D_ ** 0.5
+
+    def shard(n, seed):
+        g_ = torch.Generator().manual_seed(seed)
+        x = torch.rand(n, D_, generator=g_) * 4.0 - 2.0
+        logit = x @ Wt * 3.0 - 3.0 + 0.5 * torch.randn(n, V_, generator=g_)
+        tau = torch.quantile(logit.flatten()[:200000], 1.0 - 3.4 / V_)
+        return x, logit > tau
+
+    xtr, ytr = shard(B_ * steps, 11)
+    xho, yho = shard(held, 12)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cpu = torch_ref.MoeTrainStepCPU(D=D_, V=V_, M=M_, batch_size=B_, dtype=torch.float32, seed=3)
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(vlm.MoeModel(), batch_size=B_, graph=g)
+    tg.forward(xtr[:B_].to(dev), ytr[:B_].to(dev))
+    tg.ensure_finalized()
+    for k, v in cpu.P.items():
+        g.vars[k].data.copy_(v.detach().to(dev).view(g.vars[k].data.shape))
+    for i in range(steps):
+        xb, yb = xtr[i * B_:(i + 1) * B_], ytr[i * B_:(i + 1) * B_]
+        tg.step(xb.to(dev), yb.to(dev))
+        cpu.step(xb, yb)
+    ph = tg.predict(xho.to(dev), vocab_size=V_).cpu().numpy()
+    with torch.no_grad():
+        pc = torch_ref.moe(torch_ref.l2_normalize(xho, 1), cpu.P["gates/weights"], cpu.P["experts/weights"], cpu.P["experts/biases"],
+                           M_).numpy()
+    yh = yho.numpy().astype(np.float32)
+    gh, gc = eval_util.calculate_gap(ph, yh, 20), eval_util.calculate_gap(pc, yh, 20)
+    return {"gap_hip": gh, "gap_cpu_port": gc, "abs_diff": abs(gh - gc), "target": 0.001, "within_target": bool(abs(gh - gc) < 1e-3),
+            "config": "MoeModel D=%d V=%d M=%d, %d steps x %d videos, held-out %d videos, same initial weights and batches" %
+                      (D_, V_, M_, steps, B_, held)}
+
+
 def _pick_threads(probe_fn):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best, best_t = None, None
@@ -470,6 +518,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_gap and not bf16:
         try:
             gap = gap_leg(dev)
+            gap["cpu_twin"] = gap_twin(dev)
         except Exception as e:                                    # never let the secondary metric break the bench line
             gap = {"value": None, "error": repr(e)}
 
