@@ -1,31 +1,34 @@
-// lstm_persist.hip -- persistent BasicLSTM recurrence for gfx950: ONE launch runs T time steps of a layer
-// (tf.contrib.rnn.BasicLSTMCell under tf.nn.dynamic_rnn; W/all_frame_models/lstm_model.py:34-47).
+// lstm_persist.hip -- persistent BasicLSTM recurrence for gfx950: ONE launch runs T time steps of a layer, forward or backward
+// (tf.contrib.rnn.BasicLSTMCell under tf.nn.dynamic_rnn and its gradient; W/all_frame_models/lstm_model.py:34-47, SURVEY.md K5,
+// App. A.3-A.5, App. G).
 //
 // The per-step kernels (lstm_fused.hip) re-stream W_h from L2 for every step (128 MB / step at B = 128, H = 1024) and pay a
 // launch boundary per step: 19-22 us against a 6.8 us MFMA bound.  Here the recurrent weights never move:
-//   * forward: workgroup (unit group ug = 8 hidden units = their 32 gate columns, row group g) keeps its [H x 32] slice of
-//     W_h in REGISTERS, K split over the 8 waves of a 512-thread workgroup (wave w owns k in [w H/8, (w+1) H/8): NQ = H/128
-//     q-groups of 16 k = 8 NQ float4 B-fragments per lane); no LDS or L2 traffic for weights in the step loop.
-//   * the only per-step traffic is the state itself: h_t (512 KB) is exchanged through an "hx" buffer laid out in MFMA
-//     A-fragment order ([16-row tile][q-group][16 rows][16 k] = 1 KB blocks): a producer workgroup writes the 32 bytes per row
-//     it owns with write-through 16-byte stores (sc0 sc1), a consumer wave fetches one fully coalesced 1 KB block per 4
-//     MFMAs with sc0 sc1 loads (coherent across the 8 XCD-private L2s; no acquire fence, no L1 involvement).
-//   * no grid barrier: work is cut into ITEMS = (time step, 16-row tile).  Item (s, T) needs h_{s-1} of tile T only, so
-//     completion is tracked per tile with monotonic arrival counters (8 shards per tile, one 128-byte line each); a
-//     workgroup with >= 3 tiles prefetches the A fragments of item k+2 while the MFMAs of item k run, so the exchange
-//     latency (write-through drain + flag + fetch ~ 3 us) hides behind two items of matrix work.
-//   * per item a wave issues NQ x 4 x 2 v_mfma_f32_16x16x4_f32 (two independent accumulators = the two 16-column halves of
-//     the unit group), partial tiles of the 8 waves meet in LDS (double-buffered by item parity, ONE workgroup barrier per
-//     item), waves 0-1 run the gate epilogue (sigmoid / tanh, cell update, dynamic_rnn copy-through) for the 128 (row, unit)
-//     pairs while the other waves already issue the next item's MFMAs.
-// Exact fp32 (v_mfma_f32_16x16x4_f32 is an fmaf chain); the summation order over K is fixed, so results are bitwise
-// reproducible run to run.  Every spin is bounded (wall clock); on a timeout the control block's error word is set, all
-// waits fall through and the launch ends (the host reports YT8M_E_HIP on the next status query).
+//   * forward: workgroup = (unit group of 8 hidden units = their 32 gate columns, row group).  K = H is split over 8 "matrix"
+//     waves (wave w owns k in [w H/8, (w+1) H/8) = NQ = H/128 q-groups of 16 k); half of a wave's B fragments stay in registers,
+//     half in LDS (64 KB per workgroup) -- no L2 traffic for weights in the step loop.  Backward: 16 units per workgroup
+//     (K = 4H, output H wide), 128 KB of W_h in registers + 128 KB in LDS.
+//   * the only per-step traffic is the state itself: h_t (forward) / dz_t (backward) is exchanged through a buffer laid out in
+//     MFMA A-fragment order ([parity][16-row tile][q-group][16 rows][16 k] = 1 KB blocks): a producer writes the bytes it owns with
+//     write-through 16-byte stores (sc0 sc1), a consumer wave fetches one fully coalesced 1 KB block per 4 MFMAs with sc0 sc1 loads
+//     (coherent across the 8 XCD-private L2s; no acquire fence, no L1 involvement).
+//   * no grid barrier: work is cut into ITEMS = (time step, 16-row tile).  Item (s, T) needs the state of tile T from step s - 1
+//     only, so completion is tracked per tile with monotonic arrival counters (8 shards per tile, one 128-byte line each) and a
+//     workgroup that owns several tiles has as many independent chains in flight; the A fragments of the next item(s) are
+//     requested while the MFMAs of the current one run, after a speculative counter read whose round trip hides under MFMAs.
+//   * 12 waves per workgroup in two roles, coupled only through LDS counters (no s_barrier in the step loop): 8 matrix waves
+//     (64 v_mfma_f32_16x16x4_f32 per item forward, 128 backward, partial tiles -> LDS slot -> ds_add) and 4 epilogue waves
+//     (s_setprio 3: reduce the 8 partial tiles in a fixed order, gate math, publish the new state FIRST -- write-through stores,
+//     drain, one relaxed agent-scope atomic_add -- then write what the other pass / the caller needs in the standard layouts).
+// Exact fp32 products (v_mfma_f32_16x16x4_f32 is an fmaf chain) with a fixed summation order: bitwise reproducible run to run.
+// The gate non-linearities use v_exp_f32 / v_rcp_f32 (<= 1.5e-7 absolute; the libm forms were a 600-instruction dependent chain
+// on the critical path).  Every spin is bounded (wall clock): on a time-out the control block's error word is set, all waits fall
+// through and the launch ends; yt8m_lstm_persist_status reports YT8M_E_HIP.
 //
-// Deadlock note: a persistent launch needs its whole grid resident (<= 1 workgroup per CU: 512 threads x <=256 VGPRs).  Two
-// such launches on different streams could each hold part of the chip and wait for the rest forever, so the host side
-// chains every persistent launch of a device behind the previous one with an event (PersistGate), whatever stream the
-// caller passes.
+// Deadlock note: a persistent launch needs its whole grid resident (1 workgroup per CU: 768 threads x ~160 VGPRs).  Two such
+// launches on different streams could each hold part of the chip and wait for the rest forever, so the host side chains every
+// persistent launch of a device behind the previous one with an event (PersistGate), whatever stream the caller passes.
+// Measured behaviour, the s_memtime timeline tooling and what was tried and rejected: DESIGN.md section 7.1.
 #include <mutex>
 #include "common.h"
 
