@@ -36,6 +36,13 @@ int yt8m_prof_get(int family, int64_t* launches, double* total_ms);
  * mfma: register-only v_mfma_f32_32x32x2_f32 loop; FLOPs = blocks*4*iters*32*4096.  copy: float4 stream, n%4==0. */
 int yt8m_probe_mfma_f32(int iters, int blocks, float* sink, yt8m_stream_t stream);
 int yt8m_probe_copy_f32(const float* src, float* dst, int64_t n, yt8m_stream_t stream);
+/* placement: out[2 b] = XCC id, out[2 b + 1] = raw HW_ID of workgroup b (each spins spin_ticks of the 100 MHz clock). */
+int yt8m_probe_placement(int* out, int blocks, int spin_ticks, yt8m_stream_t stream);
+/* A stream whose dispatches are confined to the CUs of `mask` (hipExtStreamCreateWithCUMask; bit i of word i/32 = CU i in
+ * the runtime's numbering).  The LSTM backward pass keeps the GEMMs that run beside a half-chip persistent recurrence on
+ * such a stream so the recurrence always finds its CUs free.  No reference counterpart (TF places kernels itself). */
+int yt8m_stream_create_cu_mask(const uint32_t* mask, int words, yt8m_stream_t* stream);
+int yt8m_stream_destroy(yt8m_stream_t stream);
 
 /* ---- GEMM: C[M,N] = op(A)[M,K] . op(B)[K,N] (+ bias[N]) (+ beta*C), exact fp32 on v_mfma_f32_32x32x2_f32.
  * Replaces tf.matmul / slim.fully_connected's MatMul+BiasAdd (W/all_video_models/moe_model.py:40-52,

@@ -25,6 +25,9 @@ SIGNATURES = {
     "yt8m_prof_get": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
     "yt8m_probe_mfma_f32": (c_int, [c_int, c_int, P, P]),
     "yt8m_probe_copy_f32": (c_int, [P, P, c_int64, P]),
+    "yt8m_probe_placement": (c_int, [P, c_int, c_int, P]),
+    "yt8m_stream_create_cu_mask": (c_int, [P, c_int, ctypes.POINTER(P)]),
+    "yt8m_stream_destroy": (c_int, [P]),
     "yt8m_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P]),
     "yt8m_gemm_workspace_bytes": (c_int64, []),
     "yt8m_gemm_f32_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),

@@ -2,6 +2,8 @@
 //   yt8m_probe_mfma_f32 : register-only v_mfma_f32_32x32x2_f32 loop (4 independent accumulators per wave),
 //                         i.e. the matrix-pipe ceiling of THIS box at its sustained clock.
 //   yt8m_probe_copy_f32 : float4 streaming copy (HBM ceiling).
+//   yt8m_probe_placement: which XCD / CU every workgroup of a launch landed on (tools/cu_mask_probe.py: how the bits of a
+//                         hipExtStreamCreateWithCUMask mask map to XCDs -- measured: bit i -> XCD i % 8).
 #include "common.h"
 
 namespace {
@@ -30,9 +32,41 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(int iters, float* __res
 __global__ __launch_bounds__(256) void copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
+
+// where workgroups land: out[2 b] = XCC id, out[2 b + 1] = HW_ID (cu / sh / se fields); a short spin keeps early workgroups
+// resident so the grid spreads over every CU the queue may use
+__global__ __launch_bounds__(256) void placement_probe_kernel(int* __restrict__ out, int spin) {
+  unsigned xcc, hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < spin) {}
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = (int)(xcc & 0xF); out[2 * blockIdx.x + 1] = (int)hw; }
+}
 }  // namespace
 
 using namespace yt8m;
+
+extern "C" int yt8m_probe_placement(int* out, int blocks, int spin_ticks, yt8m_stream_t stream) {
+  YT8M_REQUIRE(out && blocks > 0, YT8M_E_BADARG, "bad probe arguments");
+  hipLaunchKernelGGL(placement_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, spin_ticks);
+  return launch_status("placement_probe_kernel");
+}
+
+// A stream whose dispatches may only use the CUs of `mask` (bit i of word i / 32 = CU i in the runtime's numbering).  seq_ops
+// uses two of them to keep the GEMMs that run beside a half-chip persistent recurrence off the CUs that recurrence needs.
+extern "C" int yt8m_stream_create_cu_mask(const uint32_t* mask, int words, yt8m_stream_t* stream) {
+  YT8M_REQUIRE(mask && words > 0 && stream, YT8M_E_BADARG, "bad mask arguments");
+  hipStream_t s = nullptr;
+  YT8M_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream = (yt8m_stream_t)s;
+  return YT8M_OK;
+}
+
+extern "C" int yt8m_stream_destroy(yt8m_stream_t stream) {
+  YT8M_HIP_CHECK(hipStreamDestroy(as_stream(stream)));
+  return YT8M_OK;
+}
 
 // FLOPs executed = blocks * 4 waves * iters * 32 MFMAs * (2*32*32*2)
 extern "C" int yt8m_probe_mfma_f32(int iters, int blocks, float* sink, yt8m_stream_t stream) {
