@@ -35,6 +35,9 @@ int yt8m_prof_get(int family, int64_t* launches, double* total_ms);
 /* hardware probes (measured ceilings of THIS box, printed next to the roofline numbers):
  * mfma: register-only v_mfma_f32_32x32x2_f32 loop; FLOPs = blocks*4*iters*32*4096.  copy: float4 stream, n%4==0. */
 int yt8m_probe_mfma_f32(int iters, int blocks, float* sink, yt8m_stream_t stream);
+/* 32x32x16 bf16: FLOPs = blocks*4*iters*32*32768; random_operands != 0: full-entropy operand bits (the clock the chip holds
+ * under the data-dependent power of a real GEMM) instead of a few constant values */
+int yt8m_probe_mfma_bf16(int iters, int blocks, int random_operands, float* sink, yt8m_stream_t stream);
 int yt8m_probe_copy_f32(const float* src, float* dst, int64_t n, yt8m_stream_t stream);
 /* placement: out[2 b] = XCC id, out[2 b + 1] = raw HW_ID of workgroup b (each spins spin_ticks of the 100 MHz clock). */
 int yt8m_probe_placement(int* out, int blocks, int spin_ticks, yt8m_stream_t stream);
@@ -82,6 +85,19 @@ int yt8m_gemm_f32_grouped(int transA, int transB, int nprob, const yt8m_gemm_pro
  * LDS-DMA path.  Serves the bf16 configuration (BASELINE config 5): x / W^T / dZ^T are kept as bf16 copies. */
 int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                               yt8m_stream_t stream);
+/* fp32 GEMM on the bf16 matrix pipe (csrc/gemm_x3.hip): every fp32 operand element is split exactly into three bf16 terms
+ * (a = a1 + a2 + a3) and C accumulates, in fp32, the six partial products of weight >= 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2,
+ * a3b1); the dropped terms are <= 2^-23 |a b|, the rounding an fp32 FMA commits on the product.  Same role as yt8m_gemm_f32
+ * (tf.matmul and its autodiff transposes) at up to 2.6x its rate.
+ * yt8m_x3_split: fp32 src [R, C] (row stride ld, every element multiplied by scale first) -> "x3 images"
+ *   [row][ceil(K/16)][3][16] bf16.  plain (rows = R, K = C) serves src as a K-contiguous operand, trans (rows = C, K = R)
+ *   serves src^T; either may be NULL; sizes from yt8m_x3_image_bytes(rows, K); 16-byte aligned.
+ * yt8m_gemm_x3_nt_grouped: C[M,N] (+)= A . B^T (+ bias); problem.A / .B are the x3 images of A ([M rows, K]) and B ([N rows, K]),
+ *   lda / ldb are ignored, K is the logical K.  workspace as for yt8m_gemm_f32_grouped. */
+int64_t yt8m_x3_image_bytes(int64_t rows, int64_t K);
+int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
+int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
+                            yt8m_stream_t stream);
 /* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows].
  * dst_ld: row stride of dst in bf16 elements (0 = dense).  The training path pads it to a multiple of 8 so that every bf16
  * row starts 16-byte aligned and the GEMMs stay on their LDS-DMA path (V*(M+1) = 14148 is not a multiple of 8). */

@@ -24,6 +24,7 @@ SIGNATURES = {
     "yt8m_prof_reset": (c_int, []),
     "yt8m_prof_get": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
     "yt8m_probe_mfma_f32": (c_int, [c_int, c_int, P, P]),
+    "yt8m_probe_mfma_bf16": (c_int, [c_int, c_int, c_int, P, P]),
     "yt8m_probe_copy_f32": (c_int, [P, P, c_int64, P]),
     "yt8m_probe_placement": (c_int, [P, c_int, c_int, P]),
     "yt8m_stream_create_cu_mask": (c_int, [P, c_int, ctypes.POINTER(P)]),
@@ -32,6 +33,9 @@ SIGNATURES = {
     "yt8m_gemm_workspace_bytes": (c_int64, []),
     "yt8m_gemm_f32_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_gemm_bf16_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
+    "yt8m_x3_image_bytes": (c_int64, [c_int64, c_int64]),
+    "yt8m_x3_split": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
+    "yt8m_gemm_x3_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_cast_f32_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int, P]),
     "yt8m_cast_f32_bf16_dual": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P]),
     "yt8m_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64,

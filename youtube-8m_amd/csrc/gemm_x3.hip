@@ -1,0 +1,475 @@
+// gemm_x3.hip -- fp32 GEMM on the bf16 matrix pipe: three-plane bf16 split of both operands, six MFMA products; gfx950, wave64.
+//
+// C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias) for fp32 A, B.  Every operand element is split once into three bf16 terms
+//     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (exact: 3 x 8 significand bits)
+// and the product is accumulated in fp32 from the six partial products whose weight is >= 2^-16 of a1 b1
+//     a b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)
+// Each partial product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (8 x 8 bits); the three dropped terms are
+// <= 2^-23 |a b| together, the size of the rounding an fp32 FMA commits on the product itself.  tests/test_gpu_round2.py holds
+// the comparison with the fp32-MFMA kernel of gemm_f32.hip against an fp64 product (same error, both ~1e-7 relative).
+// The bf16 pipe is 16x the fp32 one on this chip (2.5 PFLOP/s vs 157 TFLOP/s dense), so six products cost 0.375 of the fp32
+// instruction time: the ceiling is 2.5 / 6 = 417 "fp32-equivalent" TFLOP/s.
+//
+// Operand image ("x3 image", written by yt8m_x3_split): [rows / 32][K / 16][plane 0..2][32 rows][2 halves][8] bf16 -- one 1 KiB
+// block per 32 rows, 16-wide K block and plane, stored exactly as a wave's LDS-DMA instruction lays it into LDS (the half-swap
+// that makes the fragment fetch conflict-free included), so every DMA instruction reads 1 KiB of consecutive memory and a wave
+// streams 3 KiB per K-step.  (A [row][K/16][3][16] image with 32-byte pieces per lane pair ran the L2 -> LDS path at 7.7 TB/s
+// and bound the kernel.)  K is zero-padded to a multiple of 16 (no K tail in the GEMM), rows to a multiple of 32 (never stored).
+// Both operands K-contiguous ("NT"): an operand needed with the other orientation is split with the transposing variant.
+//
+// Kernel: 256 x 256 tile per workgroup, 8 waves as 2 (M) x 4 (N), each 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers);
+// K-step = 16 (one MFMA K): 6 planes x 256 rows x 32 B = 48 KiB per step by LDS-DMA into a 3-stage ring (two steps on the wire);
+// per step and wave 18 ds_read_b128 feed 48 MFMAs (LDS busy ~50 %: the matrix pipe is the bound, unlike the plain bf16 kernel of
+// gemm_bf16.hip whose 12 reads feed 16 MFMAs), and the fragment fetch of the next step is interleaved with the products of the
+// current one.  Tile order and the float4 epilogue follow gemm_bf16.hip; the tiles of the last partial round are split along K.
+#include "common.h"
+#include <algorithm>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TM = 256, TN = 256;
+constexpr int PLANE_F = 256 * 8;                      // floats of one plane tile: 256 rows x 32 B
+constexpr int OP_F = 3 * PLANE_F;                     // one operand, three planes (24 KiB)
+constexpr int STAGE_F = 2 * OP_F;                     // A + B (48 KiB)
+constexpr int NST = 3;
+constexpr int RG_F = 256;                             // floats of one image block: 32 rows x 32 B (1 KiB)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct XArgs {
+  const float* A;       // x3 image of A ([M rows, K])
+  const float* B;       // x3 image of B ([N rows, K])
+  float* C;
+  const float* bias;
+  int64_t ldc;
+  int M, N, KB;         // KB: 16-wide K blocks
+  int tiles_m, tiles_n;
+  int accumulate;
+};
+struct XGroup {
+  XArgs p[4];
+  int tile_base[5];
+  int nprob;
+  int full, rem, S;     // see gemm_bf16.hip: `full` whole tiles, `rem` tiles of the last partial round split along K in S parts
+  float* ws;
+};
+
+__device__ __forceinline__ int xcd_remap(int wg, int n) {
+  const int xcd = wg & 7, slot = wg >> 3;
+  const int q = n >> 3, rem = n & 7;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
+}
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int lt, int& tm, int& tn) {
+  constexpr int GM = 4;
+  const int band_tiles = GM * tiles_n;
+  const int band = lt / band_tiles;
+  const int first = band * GM;
+  const int rows = min(GM, tiles_m - first);
+  const int in = lt - band * band_tiles;
+  tn = in / rows;
+  tm = first + (in - tn * rows);
+}
+
+// One operand, one K block: three DMA instructions (one per plane), each 512 lanes x 16 B = a [256 rows][2 slots] plane tile;
+// slot s of row x holds half (s ^ ((x >> 3) & 1)) of the 16-wide block (the image is stored that way), which makes the
+// ds_read_b128 fragment fetch conflict-free.  src: this wave's row group at K block 0, + lane * 16 B.
+__device__ __forceinline__ void fill_op(const float* __restrict__ src, int kb, float* S, int tid) {
+  src += (int64_t)kb * (3 * RG_F);
+  float* dst = S + (tid & ~63) * 4;                    // wave-uniform base; the hardware adds lane * 16 bytes
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * RG_F),
+                                     (__attribute__((address_space(3))) void*)(dst + p * PLANE_F), 16, 0, 0);
+}
+__global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 144 KiB
+  int tile, part = 0, nparts = 1, slot = 0;
+  if ((int)blockIdx.x < G.full) {
+    tile = xcd_remap(blockIdx.x, G.full);
+  } else {
+    slot = blockIdx.x - G.full;
+    const int rt = slot / G.S;
+    part = slot - rt * G.S;
+    nparts = G.S;
+    tile = G.full + rt;
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  const XArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
+  const int nk = kb1 - kb0;
+  // this wave's 32-row group of either operand tile (groups beyond the matrix only feed outputs that are never stored)
+  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.KB * (3 * RG_F) + lane * 4;
+  const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.KB * (3 * RG_F) + lane * 4;
+#define X3_FILL(KBI, STAGE) { fill_op(pa, KBI, (STAGE), tid); fill_op(pb, KBI, (STAGE) + OP_F, tid); }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Software pipeline: the fragments of step kt+1 are fetched from LDS while the MFMAs of step kt run, each plane into the
+  // registers its last product has just released (the product order below is the one for which every fetch is issued >= 1
+  // product = 256 matrix cycles before its first use), so the matrix pipe never waits for LDS.  Ring: at the top of iteration
+  // kt the stages hold steps kt+1 (landed), kt+2 (on the wire) and -- refilled there -- kt+3.
+  const int pro = nk < 3 ? nk : 3;
+  for (int s = 0; s < pro; ++s) X3_FILL(kb0 + s, smem + s * STAGE_F)
+  if (pro == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (pro == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa = (wm + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));      // + t * 256 floats per 32 rows, + p * PLANE_F
+  const int fb = OP_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  bf16x8 a2[4], a1[4], a0[4], b0[2], b1[2], b2[2];
+  auto load_a = [&](bf16x8 (&d)[4], const float* S, int p) __attribute__((always_inline)) {
+#ifdef YT8M_X3_NO_LDS
+    if (S != smem) return;
+#endif
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fa + p * PLANE_F + t * 256]));
+  };
+  auto load_b = [&](bf16x8 (&d)[2], const float* S, int p) __attribute__((always_inline)) {
+#ifdef YT8M_X3_NO_LDS
+    if (S != smem) return;
+#endif
+#pragma unroll
+    for (int t = 0; t < 2; ++t) d[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fb + p * PLANE_F + t * 256]));
+  };
+  auto term = [&](const bf16x8 (&x)[4], const bf16x8 (&y)[2]) __attribute__((always_inline)) {
+#ifdef YT8M_X3_NO_MFMA                                            // tuning variant: DMA + LDS traffic only (wrong results)
+    acc[0][0][0] += (float)x[0][0] + (float)y[0][0];
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[i][j], 0, 0, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  load_a(a2, smem, 2); load_b(b0, smem, 0); load_a(a1, smem, 1); load_b(b1, smem, 1); load_a(a0, smem, 0); load_b(b2, smem, 2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // stage 0 is refilled right behind the first barrier
+  int cur = 0;                                                     // stage of step kt
+  // One step.  Top: step kt+1 landed (step kt+2 may stay on the wire); behind the barrier every wave holds step kt in registers,
+  // so its stage takes step kt+3 (the fragment fetches in flight read stage kt+1, not the one refilled: no LDS wait).
+  // The six LDS-DMA instructions of the refill are spread over the products (an LDS-DMA issue holds the wave for ~60-100 cycles:
+  // six in a row at the top of the step idle the matrix pipe of both waves of a SIMD).
+  const int wbase = (tid & ~63) * 4;                               // wave-uniform LDS base; the hardware adds lane * 16 bytes
+  auto dma = [&](bool on, const float* src, float* dst) __attribute__((always_inline)) {
+#ifndef YT8M_X3_NO_DMA                                             // tuning variant: products + LDS traffic only (wrong results)
+    if (on)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    const int nxt = cur + 1 == NST ? 0 : cur + 1;
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef YT8M_X3_NO_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    const bool rf = kt + 3 < nk;
+    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (3 * RG_F);
+    const float* qb = pb + (int64_t)(kb0 + kt + 3) * (3 * RG_F);
+    float* Sc = smem + cur * STAGE_F + wbase;
+    const float* Sn = smem + nxt * STAGE_F;
+    __builtin_amdgcn_sched_barrier(0);
+    term(a2, b0);
+    load_a(a2, Sn, 2);
+    dma(rf, qa, Sc);
+    term(a1, b0);
+    dma(rf, qa + RG_F, Sc + PLANE_F);
+    term(a1, b1);
+    load_a(a1, Sn, 1);
+    dma(rf, qa + 2 * RG_F, Sc + 2 * PLANE_F);
+    term(a0, b0);
+    load_b(b0, Sn, 0);
+    dma(rf, qb, Sc + OP_F);
+    term(a0, b1);
+    load_b(b1, Sn, 1);
+    dma(rf, qb + RG_F, Sc + OP_F + PLANE_F);
+    dma(rf, qb + 2 * RG_F, Sc + OP_F + 2 * PLANE_F);
+    term(a0, b2);
+    load_a(a0, Sn, 0);
+    load_b(b2, Sn, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+#undef X3_FILL
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                    // the epilogue reuses the ring
+
+  // epilogue: accumulators -> wave-private LDS image [32][68] -> 16-byte stores
+  constexpr int P = 68;
+  float* st = smem + wave * (32 * P);
+  if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace image
+    float* wsl = G.ws + (int64_t)slot * (TM * TN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = lane + 64 * k;
+        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        *reinterpret_cast<float4*>(&wsl[(wm + i * 32 + rr) * TN + wn + c4]) = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+      }
+    }
+    return;
+  }
+  const bool vec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = lane + 64 * k;
+      const int rr = idx >> 4, c4 = (idx & 15) * 4;
+      const int row = m0 + wm + i * 32 + rr, col = n0 + wn + c4;
+      float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+      if (row < g.M && col < g.N) {
+        float* c = g.C + (int64_t)row * g.ldc + col;
+        if (vec && col + 3 < g.N) {
+          if (g.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (g.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(c) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && col + e < g.N; ++e) {
+            float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
+            if (g.accumulate) t += c[e];
+            c[e] = t;
+          }
+        }
+      }
+    }
+  }
+}
+
+// sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
+__global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
+  const int rt = blockIdx.x >> 4, sixteenth = blockIdx.x & 15;      // 16 workgroups per tile, 16 rows each
+  const int tile = G.full + rt;
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  const XArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const float* base = G.ws + (int64_t)rt * G.S * (TM * TN);
+  for (int e = sixteenth * (TM * TN / 16) + threadIdx.x * 4; e < (sixteenth + 1) * (TM * TN / 16); e += 256 * 4) {
+    float4 v = *reinterpret_cast<const float4*>(base + e);
+    for (int s = 1; s < G.S; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * (TM * TN) + e);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int row = m0 + e / TN, col = n0 + (e % TN);
+    if (row >= g.M) continue;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float* c = g.C + (int64_t)row * g.ldc + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (col + k < g.N) {
+        float o = vv[k] + (g.bias ? g.bias[col + k] : 0.f);
+        if (g.accumulate) o += c[k];
+        c[k] = o;
+      }
+    }
+  }
+}
+
+// ---- the split pass -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {        // round to nearest even, finite x
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = bf16_rn_bits(x);
+  const float r1 = x - __uint_as_float(h1 << 16);                   // exact
+  h2 = bf16_rn_bits(r1);
+  const float r2 = r1 - __uint_as_float(h2 << 16);                  // exact
+  h3 = bf16_rn_bits(r2);
+  if ((__float_as_uint(x) & 0x7F800000u) == 0x7F800000u) {          // inf / nan stay in the leading term only
+    h1 = __float_as_uint(x) >> 16;
+    h2 = h3 = 0;
+  }
+}
+// 16 values of one K block of image row `row` -> its two 16-byte halves in each of the three plane blocks at dst (the block of
+// plane 0; half h sits in slot h ^ ((row >> 3) & 1))
+__device__ __forceinline__ void store_block(const float (&v)[16], float* __restrict__ dst, int row) {
+  const int r = row & 31, sw = (r >> 3) & 1;
+  dst += r * 8;
+  unsigned h[3][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) split3(v[j], h[0][j], h[1][j], h[2][j]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    uint4 lo, hi;
+    lo.x = h[p][0] | (h[p][1] << 16);  lo.y = h[p][2] | (h[p][3] << 16);
+    lo.z = h[p][4] | (h[p][5] << 16);  lo.w = h[p][6] | (h[p][7] << 16);
+    hi.x = h[p][8] | (h[p][9] << 16);  hi.y = h[p][10] | (h[p][11] << 16);
+    hi.z = h[p][12] | (h[p][13] << 16); hi.w = h[p][14] | (h[p][15] << 16);
+    *reinterpret_cast<uint4*>(dst + p * RG_F + 4 * sw) = lo;
+    *reinterpret_cast<uint4*>(dst + p * RG_F + 4 * (sw ^ 1)) = hi;
+  }
+}
+
+// src [R, Cc] fp32 (row stride ld), 64 x 64 tiles through LDS; plain image: rows = R, K = Cc; trans image: rows = Cc, K = R.
+// Either destination may be null.  scale multiplies every element before the split (1.0f: none).
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
+                                                       float* __restrict__ trans, float scale) {
+  __shared__ float T[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  {
+    const int c4 = (t & 15) * 4, rr = t >> 4;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 16 * i;
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < R) {
+        const float* p = src + (int64_t)(r0 + r) * ld + c0 + c4;
+        if (vec && c0 + c4 + 3 < Cc) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (c0 + c4 + 0 < Cc) v.x = p[0];
+          if (c0 + c4 + 1 < Cc) v.y = p[1];
+          if (c0 + c4 + 2 < Cc) v.z = p[2];
+          if (c0 + c4 + 3 < Cc) v.w = p[3];
+        }
+      }
+      T[r][c4 + 0] = v.x * scale; T[r][c4 + 1] = v.y * scale; T[r][c4 + 2] = v.z * scale; T[r][c4 + 3] = v.w * scale;
+    }
+  }
+  __syncthreads();
+  const int a = t & 63, blk = t >> 6;                               // row of the image within the tile, K block within the tile
+  if (plain) {
+    const int KB = (Cc + 15) >> 4;
+    const int row = r0 + a, kb = (c0 >> 4) + blk;
+    if (row < ((R + 31) & ~31) && kb < KB) {                        // rows of the last 32-row group beyond R: zeros
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = T[a][blk * 16 + j];
+      store_block(v, plain + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+    }
+  }
+  if (trans) {
+    const int KB = (R + 15) >> 4;
+    const int row = c0 + a, kb = (r0 >> 4) + blk;
+    if (row < ((Cc + 31) & ~31) && kb < KB) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = T[blk * 16 + j][a];
+      store_block(v, trans + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+    }
+  }
+}
+
+}  // namespace
+
+using namespace yt8m;
+
+extern "C" int64_t yt8m_x3_image_bytes(int64_t rows, int64_t K) { return ((rows + 31) / 32) * ((K + 15) / 16) * 3072; }
+
+// fp32 src [R, C] -> x3 images.  plain: rows = R, K = C (operand used K-contiguous as stored); trans: rows = C, K = R (operand
+// used transposed).  One pass over src feeds both (either may be NULL).
+extern "C" int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans,
+                             yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans)) & 15) == 0, YT8M_E_BADARG,
+               "x3 images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale);
+  return launch_status("x3_split_kernel");
+}
+
+// C[M,N] (+)= A . B^T (+ bias) from the x3 images of A ([M rows, K]) and B ([N rows, K]); yt8m_gemm_problem.A / .B are the
+// images, lda / ldb are ignored, K is the logical K (the images are padded to a multiple of 16).  Up to four problems.
+extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
+                                       yt8m_stream_t stream) {
+  YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
+  XGroup G;
+  G.nprob = 0;
+  int64_t T = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    YT8M_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 1 && q.ldc >= q.N, YT8M_E_BADARG, "bad GEMM problem");
+    YT8M_REQUIRE(q.beta == 0.f || q.beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+    if (q.M == 0 || q.N == 0) continue;
+    YT8M_REQUIRE(q.A && q.B && q.C, YT8M_E_BADARG, "null operand");
+    YT8M_REQUIRE((((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0, YT8M_E_BADARG, "x3 images must be 16-byte aligned");
+    XArgs g;
+    g.A = static_cast<const float*>(q.A); g.B = static_cast<const float*>(q.B); g.C = q.C; g.bias = q.bias;
+    g.ldc = q.ldc;
+    g.M = (int)q.M; g.N = (int)q.N; g.KB = (int)((q.K + 15) / 16);
+    g.tiles_m = (int)((q.M + TM - 1) / TM); g.tiles_n = (int)((q.N + TN - 1) / TN);
+    g.accumulate = q.beta != 0.f;
+    G.p[G.nprob] = g;
+    G.tile_base[G.nprob] = (int)T;
+    T += (int64_t)g.tiles_m * g.tiles_n;
+    ++G.nprob;
+  }
+  if (G.nprob == 0) return YT8M_OK;
+  for (int i = G.nprob; i <= 4; ++i) G.tile_base[i] = (int)T;
+  for (int i = G.nprob; i < 4; ++i) G.p[i] = G.p[0];
+  constexpr int SLOTS = 256;                                       // one 144 KiB workgroup per CU
+  G.full = (int)(T / SLOTS) * SLOTS;
+  G.rem = (int)(T - G.full);
+  G.S = 1;
+  G.ws = static_cast<float*>(workspace);
+  if (G.rem > 0 && workspace) {
+    // the last, partial round: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp) + the fixup pass
+    int min_nk = 1 << 30;
+    for (int i = 0; i < G.nprob; ++i) min_nk = std::min(min_nk, G.p[i].KB);
+    const int64_t per_part = (int64_t)TM * TN * sizeof(float);
+    double best = 1e30;
+    for (int S = 1; S <= 8; ++S) {
+      if (S > 1 && (min_nk / S < 8 || (int64_t)G.rem * S * per_part > workspace_bytes)) break;
+      const int rounds = (G.rem * S + SLOTS - 1) / SLOTS;
+      const double cost = rounds * ((double)min_nk / S + 10.0) + (S > 1 ? 4.0 + 0.065 * G.rem * S : 0.0);
+      if (cost < best * 0.98) { best = cost; G.S = S; }
+    }
+  }
+  const int64_t grid = (int64_t)G.full + (int64_t)G.rem * G.S;
+  static bool once = false;
+  if (!once) {
+    YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       NST * STAGE_F * (int)sizeof(float)));
+    once = true;
+  }
+  ProfScope prof(F_GEMM, as_stream(stream));
+  hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)grid), dim3(512), NST * STAGE_F * sizeof(float), as_stream(stream), G);
+  if (G.S > 1) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)G.rem * 16), dim3(256), 0, as_stream(stream), G);
+  return launch_status("gemm_x3_kernel");
+}

@@ -209,6 +209,68 @@ def gemm_bf16_nt_grouped(items):
     return outs
 
 
+class X3Image:
+    """Three-plane bf16 split of an fp32 matrix (csrc/gemm_x3.hip): `rows` x `K` logical shape, [row][ceil(K/16)][3][16] bf16."""
+    __slots__ = ("buf", "rows", "K")
+
+    def __init__(self, buf, rows, K):
+        self.buf, self.rows, self.K = buf, rows, K
+
+
+def _x3_empty(rows, K, device):
+    n = _lib.lib().yt8m_x3_image_bytes(rows, K)
+    return X3Image(torch.empty(max(n, 16), dtype=torch.uint8, device=device), rows, K)
+
+
+def x3_split(x, plain=True, trans=False, scale=1.0):
+    """fp32 [R, C] -> (X3Image of x as an [R rows, K = C] operand or None, X3Image of x^T as a [C rows, K = R] operand or None),
+    both from one pass over x (yt8m_x3_split)."""
+    _dev(x)
+    x, ld = _rowmajor2d(x)
+    R, C = x.shape
+    ip = _x3_empty(R, C, x.device) if plain else None
+    it = _x3_empty(C, R, x.device) if trans else None
+    _lib.check(_lib.lib().yt8m_x3_split(_p(x), R, C, ld, float(scale), _p(ip.buf) if ip else None, _p(it.buf) if it else None,
+                                        _stream()))
+    return ip, it
+
+
+def gemm_x3_grouped(items):
+    """items: dicts(A=X3Image [M rows, K], B=X3Image [N rows, K], out=None fp32 [M,N], bias=None, beta=0.0) -> fp32 outputs
+    C = A . B^T from six bf16 MFMA products of the split operands (yt8m_gemm_x3_nt_grouped): fp32-grade accuracy."""
+    probs, outs, keep = [], [], []
+    for it in items:
+        A, B = it["A"], it["B"]
+        if not isinstance(A, X3Image) or not isinstance(B, X3Image):
+            raise TypeError("gemm_x3: operands must be X3Image")
+        if A.K != B.K:
+            raise ValueError("gemm_x3: inner dimensions differ (%d vs %d)" % (A.K, B.K))
+        M, N, K = A.rows, B.rows, A.K
+        out = it.get("out")
+        beta = it.get("beta", 0.0)
+        _dev(A.buf, B.buf, out, it.get("bias"))
+        if out is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 needs an output tensor")
+            out = torch.empty((M, N), dtype=torch.float32, device=A.buf.device)
+        if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or (out.stride(1) != 1 and N != 1):
+            raise ValueError("gemm_x3: bad output tensor")
+        bias = it.get("bias")
+        if bias is not None:
+            bias = _f32c(bias)
+            if bias.numel() != N:
+                raise ValueError("bias size mismatch")
+        ldc = out.stride(0) if M > 1 else max(N, 1)
+        probs.append(_lib.GemmProblem(M, N, K, A.buf.data_ptr(), 0, B.buf.data_ptr(), 0, out.data_ptr(), ldc,
+                                      bias.data_ptr() if bias is not None else None, float(beta)))
+        outs.append(out)
+        keep.append((A, B, bias))
+    arr = (_lib.GemmProblem * len(probs))(*probs)
+    ws = _workspace(outs[0].device)
+    _lib.check(_lib.lib().yt8m_gemm_x3_nt_grouped(len(probs), arr, _p(ws), ws.numel() * 4, _stream()))
+    return outs
+
+
 def gemm_batched(A, B, out=None, transA=False, transB=False, beta=0.0):
     """Batched over dim 0 of 3-D contiguous tensors.  yt8m_gemm_f32_batched."""
     _dev(A, B, out)

@@ -283,6 +283,8 @@ def check_persist_errors():
     _PERSIST_WS.clear()
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
+X3 = _os.environ.get("YT8M_GEMM_X3", "1") != "0"      # hoisted fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
+X3_MIN_ROWS = 1024                                      # time-chunk rows below which the fp32-MFMA kernel's smaller tiles win
 REC_BF16 = _os.environ.get("YT8M_REC_BF16", "1") != "0"       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
                       # products only
 
@@ -369,6 +371,7 @@ class _LstmStack(torch.autograd.Function):
                 if st["Wp"] is not None:
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
                 st["bf16"] = bf16 and st["Din"] % 2 == 0
+                st["x3"] = X3 and not st["bf16"] and min(T for _, T in parts) * B >= X3_MIN_ROWS and st["H"] >= 128
                 if l == 0 and q_raw is not None and not drop and not st["bf16"]:
                     # 3-way bf16 split of (4/255) W_x, transposed ([4H, 3 D], K-contiguous) + the column sums of W_x
                     Din_, H_ = st["Din"], st["H"]
@@ -377,6 +380,8 @@ class _LstmStack(torch.autograd.Function):
                                                       st["W3T"].stride(0), _stream()))
                     st["Wcs"] = torch.empty((4 * H_,), dtype=torch.float32, device=dev)
                     ops.colsum(st["W"].data[:Din_], st["Wcs"])
+                if st["x3"] and "W3T" not in st:                    # W_x^T as the K-contiguous operand of the projection
+                    st["WxT3"] = ops.x3_split(st["W"].data[:st["Din"]], plain=False, trans=True)[1]
                 st["rec16"] = st["bf16"] and REC_BF16 and lib.yt8m_lstm_packed16_elems(B, st["H"]) > 0
                 if st["rec16"]:
                     st["pws"] = None
@@ -408,6 +413,9 @@ class _LstmStack(torch.autograd.Function):
                     elif st["bf16"]:
                         ops.gemm_bf16_nt_grouped([dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din)), B=st["WxT"],
                                                        out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
+                    elif st["x3"]:
+                        xi = ops.x3_split(st["x"][t0:t0 + T].view(T * B, Din))[0]
+                        ops.gemm_x3_grouped([dict(A=xi, B=st["WxT3"], out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
                     else:
                         ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
                                  bias=st["b"].data)
@@ -457,6 +465,7 @@ class _LstmStack(torch.autograd.Function):
         dx = torch.empty_like(layers[0]["x"]) if need_dx else None
         for st in layers:
             st.pop("WxT", None)
+            st.pop("WxT3", None)
             st.pop("W3T", None)
             st.pop("Wcs", None)
             st.pop("Wp16", None)
@@ -540,11 +549,22 @@ class _LstmStack(torch.autograd.Function):
                             st["Wxb"] = ops.cast_bf16(W.data[:Din])
                         cast_ev = torch.cuda.Event()
                         cast_ev.record(gs[l])
+                dz3 = dzT3 = None
+                if st["x3"]:                                        # dz feeds dx (as stored) and both dW products (transposed)
+                    with torch.cuda.stream(gs[l]):
+                        gs[l].wait_event(rb)
+                        dz3, dzT3 = ops.x3_split(dzc, plain=(l > 0 or need_dx), trans=W.grad is not None)
+                        if "Wx3" not in st and (l > 0 or need_dx):
+                            st["Wx3"] = ops.x3_split(W.data[:Din])[0]
+                        cast_ev = torch.cuda.Event()
+                        cast_ev.record(gs[l])
                 if l > 0 or need_dx:
                     with torch.cuda.stream(gs[l]):
                         gs[l].wait_event(rb)
                         dst = layers[l - 1]["dout"] if l > 0 else dx
-                        if st["bf16"]:
+                        if st["x3"]:
+                            ops.gemm_x3_grouped([dict(A=dz3, B=st["Wx3"], out=dst[t0:t0 + T].view(T * B, Din))])
+                        elif st["bf16"]:
                             ops.gemm_bf16_nt_grouped([dict(A=dzb, B=st["Wxb"], out=dst[t0:t0 + T].view(T * B, Din))])
                         else:
                             ops.gemm(dzc, W.data[:Din], out=dst[t0:t0 + T].view(T * B, Din), transB=True)
@@ -567,6 +587,13 @@ class _LstmStack(torch.autograd.Function):
                             ops.gemm_bf16_nt_grouped([
                                 dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din), transpose=True), B=dzT, out=W.grad[:Din], beta=beta),
                                 dict(A=ops.cast_bf16(st["hs"][t0:t0 + T].view(T * B, H), transpose=True), B=dzT, out=W.grad[Din:], beta=beta)])
+                        elif st["x3"]:
+                            sw.wait_event(cast_ev)
+                            dzT3.buf.record_stream(sw)
+                            xT3 = ops.x3_split(st["x"][t0:t0 + T].view(T * B, Din), plain=False, trans=True)[1]
+                            hT3 = ops.x3_split(st["hs"][t0:t0 + T].view(T * B, H), plain=False, trans=True)[1]
+                            ops.gemm_x3_grouped([dict(A=xT3, B=dzT3, out=W.grad[:Din], beta=beta),
+                                                 dict(A=hT3, B=dzT3, out=W.grad[Din:], beta=beta)])
                         else:
                             ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta)
                             ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta)
