@@ -348,6 +348,10 @@ int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const 
  * yt8m_lstm_persist_status: synchronises `stream` and returns YT8M_E_HIP if a launch on `workspace` gave up waiting. */
 int yt8m_lstm_persist_supported(int64_t B, int64_t H);
 int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H);
+/* A workspace of this size gives every step of a launch of up to T steps its own exchange image; each state byte is then
+ * written once and fetched with plain loads (one fabric read per XCD, the other CUs hit that XCD's L2) instead of sc0 sc1
+ * loads that cross the fabric for every CU.  Launches pick the protocol from the workspace_bytes they are given. */
+int64_t yt8m_lstm_persist_workspace_bytes_steps(int64_t B, int64_t H, int64_t T);
 int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream);
 int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                           const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,

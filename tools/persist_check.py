@@ -80,8 +80,10 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
     cs = torch.zeros((F + 1, B, H), device=dev)
     hs = torch.zeros((F + 1, B, H), device=dev)
     out = torch.empty((F, B, H), device=dev)
-    pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes(B, H), dtype=torch.uint8, device=dev)
-    for it in range(3):
+    for it in range(6):
+        steps = it >= 3                                 # one exchange image per step (XCD-L2-shared fetch) vs two alternating ones
+        pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
+                          dtype=torch.uint8, device=dev)
         z = z0.clone()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -91,8 +93,8 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
         e1.record()
         torch.cuda.synchronize()
         L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
-        print("persistent fwd kernel: %.3f ms for %d steps = %.2f us/step" % (e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F),
-              flush=True)
+        print("persistent fwd kernel (%s): %.3f ms for %d steps = %.2f us/step"
+              % ("image per step" if steps else "two images", e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F), flush=True)
 
 
 def timing_bwd(B=128, F=300, H=1024):
@@ -103,8 +105,10 @@ def timing_bwd(B=128, F=300, H=1024):
     cs = torch.randn((F + 1, B, H), device=dev) * 0.5
     dz = torch.empty((F, B, 4 * H), device=dev)
     dout = torch.randn((F, B, H), device=dev) * 0.01
-    pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes(B, H), dtype=torch.uint8, device=dev)
-    for it in range(3):
+    for it in range(6):
+        steps = it >= 3
+        pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
+                          dtype=torch.uint8, device=dev)
         work = torch.zeros((4, B, H), device=dev)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -114,8 +118,8 @@ def timing_bwd(B=128, F=300, H=1024):
         e1.record()
         torch.cuda.synchronize()
         L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
-        print("persistent bwd kernel: %.3f ms for %d steps = %.2f us/step" % (e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F),
-              flush=True)
+        print("persistent bwd kernel (%s): %.3f ms for %d steps = %.2f us/step"
+              % ("image per step" if steps else "two images", e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F), flush=True)
 
 
 if __name__ == "__main__":

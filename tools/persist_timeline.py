@@ -22,7 +22,7 @@ Wh = (torch.rand((H, 4 * H), device=dev) - 0.5) * 0.06
 cs = torch.zeros((F + 1, B, H), device=dev)
 hs = torch.zeros((F + 1, B, H), device=dev)
 out = torch.empty((F, B, H), device=dev)
-nb = lib.yt8m_lstm_persist_workspace_bytes(B, H)
+nb = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if os.environ.get("PSTEPS") else lib.yt8m_lstm_persist_workspace_bytes(B, H)
 pws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
 gates = torch.rand((F, B, 4 * H), device=dev)

@@ -29,6 +29,7 @@
 // launches on different streams could each hold part of the chip and wait for the rest forever, so the host side chains every
 // persistent launch of a device behind the previous one with an event (PersistGate), whatever stream the caller passes.
 // Measured behaviour, the s_memtime timeline tooling and what was tried and rejected: DESIGN.md section 7.1.
+#include <algorithm>
 #include <mutex>
 #include "common.h"
 
@@ -58,11 +59,12 @@ struct PersistFwdArgs {
   float* hs;            // [F+1,B,H]
   float* out;           // [F,B,H] or null
   const int32_t* nf;    // [B] or null
-  float* hx;            // exchange buffer [2][NT16][H/16][256]
+  float* hx;            // exchange images [nimg][NT16][H/16][256]: one per step (SH) or two alternating ones
   unsigned* ctl;        // control block (zeroed before the launch)
   int t0, T, B, H;
   float fb;
   int NU, RB, NT16, per, pf;
+  int nimg;             // exchange images in the workspace (>= T: one per step)
   unsigned long long* dbg;   // timing variant (-DYT8M_PERSIST_TIMING): s_memtime stamps of workgroup 0
 };
 
@@ -167,7 +169,12 @@ constexpr int NEPI = 4;      // epilogue waves (item k is finished by epilogue w
 // PD = how many items ahead the A fragments are requested: 2 when every workgroup owns >= 4 tiles (three register buffers in
 // rotation; the coherent loads take ~2 us under load, more than one item of matrix work), 1 for 2-3 tiles, 0 (each item waits
 // for and fetches its own operands) for a single tile.
-template <int NQ, int PD>
+// SH: one exchange image per step.  An address is then written once and read only after its tile's arrival count is complete,
+// so no cache can hold an older copy of it within the launch: the consumers fetch with PLAIN loads, the first one of an XCD
+// brings a line into that XCD's L2 and the other 31 CUs hit it -- the fabric carries every state byte 8 times per step instead
+// of 256 times (with two alternating images the loads must be sc0 sc1 = served by the fabric every time: both recurrences then
+// ran at the same ~5.7 TB/s of cross-XCD reads, 11.1 / 23.3 us per step).
+template <int NQ, int PD, bool SH>
 __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a) {
   constexpr int HQ = NQ / 2;                             // q-groups per wave whose weights sit in registers (the rest: LDS)
   __shared__ __attribute__((aligned(16))) float red[NSLOT][8][2][4][64];   // [slot][wave][col half][acc reg][lane]: 64 KB
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
   const int n_it = (NT16 - g + RB - 1) / RB;            // tiles g, g + RB, ... of this workgroup
   const int total = n_it * a.T;
-  const __amdgpu_buffer_rsrc_t hxr = make_rsrc(a.hx, (unsigned)(2u * NT16 * (unsigned)H * 16u * 4u));
+  const unsigned img_bytes = (unsigned)NT16 * (unsigned)H * 16u * 4u;
+  const long long img_f = (long long)NT16 * H * 16;
+  auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.hx + (SH ? s : (s & 1)) * img_f, img_bytes); };
   const int QH = H >> 4;                                // q-groups per row
   const unsigned arrivals = (unsigned)a.NU;             // per (tile, step): one epilogue wave per workgroup
   // B fragment of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kq = lane >> 4) supplies B[k = kq][n]; a float4 covers the four
@@ -216,10 +225,11 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
     // A fragments of item (s, T), this wave's K range: exchange buffer parity s & 1, one coherent 1 KB block load per q-group
     const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQ) * 1024u;
     auto load_item = [&](float4 (&A)[NQ], int s, int T) {
-      const unsigned base = (unsigned)(((s & 1) * NT16 + T) * QH) * 1024u + lane_off;
+      const __amdgpu_buffer_rsrc_t hxr = image(s);
+      const unsigned base = (unsigned)(T * QH) * 1024u + lane_off;
 #pragma unroll
       for (int qg = 0; qg < NQ; ++qg)
-        A[qg] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)qg * 1024u), 0, YT8M_AUX_LD));
+        A[qg] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)qg * 1024u), 0, SH ? 0 : YT8M_AUX_LD));
     };
     float4 A0[NQ], A1[NQ], A2[NQ];
     if (PD >= 1) load_item(A0, 0, g);                   // items 0 (and 1) read the packed initial state: nothing to wait for
@@ -367,9 +377,8 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
             u32x4 v;
             v.x = __float_as_uint(hn[j]); v.y = __float_as_uint(h1); v.z = __float_as_uint(h2); v.w = __float_as_uint(h3);
             const int erow = 8 * j + (lane >> 3);
-            const unsigned off = ((unsigned)((((s + 1) & 1) * NT16 + T) * QH + (ug >> 1)) * 256u +
-                                  (unsigned)(erow * 16 + (ug & 1) * 8 + eunit)) * 4u;
-            __builtin_amdgcn_raw_buffer_store_b128(v, hxr, (int)off, 0, YT8M_AUX_ST);
+            const unsigned off = ((unsigned)(T * QH + (ug >> 1)) * 256u + (unsigned)(erow * 16 + (ug & 1) * 8 + eunit)) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, image(s + 1), (int)off, 0, YT8M_AUX_ST);
           }
         }
         STAMP(3);
@@ -419,16 +428,17 @@ struct PersistBwdArgs {
   float* work;          // [4,B,H]: running (dh, dc) in halves 0 / 1
   float* dbrows;        // [B,4H] or null: per-row running sum of dz over the steps (the bias gradient before its sum over rows)
   const int32_t* nf;
-  float* dzx;           // exchange buffer [2][NT16][4H/16][256]
+  float* dzx;           // exchange images [nimg][NT16][4H/16][256]
   unsigned* ctl;
   int t0, T, B, H, phase;
   int NUB, RB, NT16, per, pf;
+  int nimg;
   unsigned long long* dbg;
 };
 
 constexpr int NSLOT_B = 3;
 
-template <int NQB, bool PF>
+template <int NQB, bool PF, bool SH>
 __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
   constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
   __shared__ __attribute__((aligned(16))) float4 Wl[8][HALF][64];          // LDS-resident half of the weights: 8 * HALF KB
@@ -446,7 +456,10 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   const int n_it = (NT16 - g + RB - 1) / RB;
   const int total = n_it * a.T;
   const int QH4 = H >> 2;                                // q-groups per dz row (4H / 16)
-  const __amdgpu_buffer_rsrc_t dxr = make_rsrc(a.dzx, (unsigned)(2u * NT16 * (unsigned)H * 64u * 4u));
+  const unsigned img_bytes = (unsigned)NT16 * (unsigned)H * 64u * 4u;
+  const long long img_f = (long long)NT16 * H * 64;
+  auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.dzx + (SH ? s : (s & 1)) * img_f, img_bytes); };
+  constexpr int AUX_LD = SH ? 0 : YT8M_AUX_LD;
   const unsigned arrivals = (unsigned)a.NUB * 4u;        // per (tile, publish): four epilogue waves per workgroup
   const int i16 = lane & 15, kq = lane >> 4;
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
@@ -465,15 +478,16 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 #pragma unroll
     for (int qg = 0; qg < HALF; ++qg) Wr[qg] = *reinterpret_cast<const float4*>(wrow + qg * 16);
     const unsigned lane_off = (unsigned)(i16 * 16 + kq * 4) * 4u + (unsigned)(w * NQB) * 1024u;
-    auto blk = [&](int s, int T) -> unsigned { return (unsigned)(((s & 1) * NT16 + T) * QH4) * 1024u + lane_off; };
+    auto blk = [&](int T) -> unsigned { return (unsigned)(T * QH4) * 1024u + lane_off; };
     float4 ring[HALF];
     int s_cur = 0, it_cur = 0, slot = 0, gen = 0;
     if (PF) {                                            // first half of item 0: after every workgroup's prologue publish
       wait_tile(a.ctl, g, arrivals, lane);
-      const unsigned b0 = blk(0, g);
+      const unsigned b0 = blk(g);
+      const __amdgpu_buffer_rsrc_t dx0 = image(0);
 #pragma unroll
       for (int q = 0; q < HALF; ++q)
-        ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(b0 + (unsigned)q * 1024u), 0, YT8M_AUX_LD));
+        ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dx0, (int)(b0 + (unsigned)q * 1024u), 0, AUX_LD));
     }
     for (int k = 0; k < total; ++k) {
       const int s = s_cur, T = g + it_cur * RB;
@@ -484,20 +498,21 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       const int T1 = have1 ? g + it1 * RB : T;
       s1 = have1 ? s1 : s;
       unsigned pv = 0;
-      const unsigned bcur = blk(s, T);
+      const unsigned bcur = blk(T);
+      const __amdgpu_buffer_rsrc_t dxr = image(s);
       if (PF) {
         if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         wait_tile(a.ctl, T, (unsigned)(s + 1) * arrivals, lane);
 #pragma unroll
         for (int q = 0; q < HALF; ++q)
-          ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)q * 1024u), 0, YT8M_AUX_LD));
+          ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)q * 1024u), 0, AUX_LD));
       }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < HALF; ++q) {                   // first half: register-resident weights; refill with this item's 2nd half
         const float4 av = ring[q], bv = Wr[q];
-        ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)(HALF + q) * 1024u), 0, YT8M_AUX_LD));
+        ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)(HALF + q) * 1024u), 0, AUX_LD));
         if (q & 1) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
@@ -511,19 +526,21 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         }
       }
       unsigned bnext = bcur;
+      __amdgpu_buffer_rsrc_t dxn = dxr;
       if (PF) {                                          // mid-item: dz of the next item must be complete before its fetch starts
         unsigned tot = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)pv, i);
         if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
-        bnext = blk(s1, T1);
+        bnext = blk(T1);
+        dxn = image(s1);
         STAMP(1);
       }
 #pragma unroll
       for (int q = 0; q < HALF; ++q) {                   // second half: LDS-resident weights; refill with the next item's 1st half
         const float4 av = ring[q];
         const float4 bv = Wl[w][q][lane];
-        if (PF) ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bnext + (unsigned)q * 1024u), 0, YT8M_AUX_LD));
+        if (PF) ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxn, (int)(bnext + (unsigned)q * 1024u), 0, AUX_LD));
         if (q & 1) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
@@ -558,6 +575,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   const long long BH = (long long)B * H;
   // gate backward of step t1 for this lane's pair of tile T: consumes (dh_in, dc) and produces dz (4 gates), dc', base'
   auto publish = [&](int T, int pub, const float (&dzv)[4]) {
+    const __amdgpu_buffer_rsrc_t dxr = image(pub);
     // dzx block of gate g4 = q-group g4 * (H/16) + ub: [16 rows][16 units]; four neighbouring lanes -> one 16-byte store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       if ((eunit & 3) == 0) {
         u32x4 v;
         v.x = __float_as_uint(v0); v.y = __float_as_uint(v1); v.z = __float_as_uint(v2); v.w = __float_as_uint(v3);
-        const unsigned off = ((unsigned)(((pub & 1) * NT16 + T) * QH4 + g4 * (H >> 4) + ub) * 256u + (unsigned)(erow * 16 + eunit)) * 4u;
+        const unsigned off = ((unsigned)(T * QH4 + g4 * (H >> 4) + ub) * 256u + (unsigned)(erow * 16 + eunit)) * 4u;
         __builtin_amdgcn_raw_buffer_store_b128(v, dxr, (int)off, 0, YT8M_AUX_ST);
       }
     }
@@ -666,11 +684,44 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
-struct PersistGate {            // chains persistent launches of one device (see the deadlock note above)
+// Persistent launches of one device may overlap only while their grids fit the chip TOGETHER (each needs every one of its
+// workgroups resident, one per CU; a third grid taking CUs two others still wait for would hang all three).  The gate keeps the
+// last four launches (completion event, CUs); a new launch waits for every recorded one that does not fit beside it, newest
+// first.  Two half-chip backward recurrences of neighbouring layers thus run side by side, whole-chip forward launches chain.
+struct PersistGate {
   std::mutex mu;
-  hipEvent_t ev[16];
-  bool has[16];
-  PersistGate() { memset(has, 0, sizeof(has)); }
+  static constexpr int R = 4;
+  hipEvent_t ev[16][R];
+  int cus[16][R];          // 0: empty slot
+  int head[16];
+  bool init[16];
+  PersistGate() { memset(cus, 0, sizeof(cus)); memset(head, 0, sizeof(head)); memset(init, 0, sizeof(init)); }
+  // call with mu held, before the launch: makes `s` wait for what must finish first
+  int admit(int dev, int need, int total, hipStream_t s) {
+    static const bool chain_all = getenv("YT8M_PERSIST_CHAIN") != nullptr;   // A/B: strict one-at-a-time chaining
+    if (!init[dev]) {
+      for (int i = 0; i < R; ++i) YT8M_HIP_CHECK(hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming));
+      init[dev] = true;
+    }
+    int room = chain_all ? 0 : total - need;
+    for (int i = 0; i < R; ++i) {
+      const int k = (head[dev] + R - 1 - i) % R;                      // newest first
+      if (cus[dev][k] == 0) continue;
+      const bool oldest = i == R - 1;                                 // its slot is about to be reused
+      if (!oldest && cus[dev][k] <= room) { room -= cus[dev][k]; continue; }
+      room = 0;                                                       // everything older waits too
+      YT8M_HIP_CHECK(hipStreamWaitEvent(s, ev[dev][k], 0));
+    }
+    return YT8M_OK;
+  }
+  // after the launch
+  int done(int dev, int used, hipStream_t s) {
+    const int k = head[dev];
+    YT8M_HIP_CHECK(hipEventRecord(ev[dev][k], s));
+    cus[dev][k] = used;
+    head[dev] = (k + 1) % R;
+    return YT8M_OK;
+  }
 };
 PersistGate g_gate;
 
@@ -720,16 +771,26 @@ bool persist_geometry(int64_t B, int64_t H, Geometry* geo) {
   return true;
 }
 
+template <int NQ, bool SH>
+int launch_fwd_sh(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
+  if (a.pf >= 2) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 2, SH>), dim3(grid), dim3(768), 0, s, a);
+  else if (a.pf == 1) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 1, SH>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 0, SH>), dim3(grid), dim3(768), 0, s, a);
+  return yt8m::launch_status("lstm_persist_fwd_kernel");
+}
 template <int NQ>
 int launch_fwd(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
-  if (a.pf >= 2) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 2>), dim3(grid), dim3(768), 0, s, a);
-  else if (a.pf == 1) hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 1>), dim3(grid), dim3(768), 0, s, a);
-  else hipLaunchKernelGGL((lstm_persist_fwd_kernel<NQ, 0>), dim3(grid), dim3(768), 0, s, a);
-  return yt8m::launch_status("lstm_persist_fwd_kernel");
+  return a.nimg >= a.T ? launch_fwd_sh<NQ, true>(a, grid, s) : launch_fwd_sh<NQ, false>(a, grid, s);
 }
 
 constexpr int64_t DBG_BYTES = 65536;     // tail of the workspace: s_memtime stamps of the timing variant
 int64_t ctl_bytes(int NT16) { return (int64_t)(CTL_HDR + NT16 * 8 * 32) * 4; }
+int64_t ctl_padded(int NT16) { return ((ctl_bytes(NT16) + 255) / 256) * 256; }
+// exchange images (of `width` = H forward, 4H backward) that fit in a workspace
+int images_in(int64_t workspace_bytes, int NT16, int64_t width) {
+  const int64_t n = (workspace_bytes - ctl_padded(NT16) - DBG_BYTES) / ((int64_t)NT16 * 16 * width * 4);
+  return (int)std::min<int64_t>(n, 1 << 20);
+}
 
 }  // namespace
 
@@ -740,8 +801,17 @@ extern "C" int yt8m_lstm_persist_supported(int64_t B, int64_t H) { return persis
 extern "C" int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H) {
   Geometry geo;
   if (!persist_geometry(B, H, &geo)) return 0;
-  // control block + exchange buffer sized for the BACKWARD pass (dz is 4H wide): [2][NT16][4H/16][256] floats
-  return ((ctl_bytes(geo.NT16) + 255) / 256) * 256 + (int64_t)2 * geo.NT16 * 16 * 4 * H * 4 + DBG_BYTES;
+  // control block + two alternating exchange images sized for the BACKWARD pass (dz is 4H wide): [2][NT16][4H/16][256] floats
+  return ctl_padded(geo.NT16) + (int64_t)2 * geo.NT16 * 16 * 4 * H * 4 + DBG_BYTES;
+}
+
+// The workspace that gives every step of a T-step launch its own exchange image (forward and backward): the launches then take
+// the XCD-L2-shared fetch path (see lstm_persist_fwd_kernel).  Smaller workspaces (>= yt8m_lstm_persist_workspace_bytes) run the
+// two-image protocol.
+extern "C" int64_t yt8m_lstm_persist_workspace_bytes_steps(int64_t B, int64_t H, int64_t T) {
+  Geometry geo;
+  if (!persist_geometry(B, H, &geo)) return 0;
+  return ctl_padded(geo.NT16) + std::max<int64_t>(T, 2) * geo.NT16 * 16 * 4 * H * 4 + DBG_BYTES;
 }
 
 extern "C" int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream) {
@@ -772,13 +842,16 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.fb = forget_bias;
   a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
-  a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + yt8m_lstm_persist_workspace_bytes(B, H) - DBG_BYTES);
+  a.nimg = images_in(workspace_bytes, geo.NT16, H);
+  a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES);
   const unsigned grid = (unsigned)(geo.NU * geo.RB);
   int dev = 0;
   device_cus(&dev);
   ProfScope prof(F_LSTM, s);
   std::lock_guard<std::mutex> lk(g_gate.mu);
-  if (g_gate.has[dev]) YT8M_HIP_CHECK(hipStreamWaitEvent(s, g_gate.ev[dev], 0));
+  const int total_cus = device_cus(nullptr);
+  int grc = g_gate.admit(dev, (int)grid, total_cus, s);
+  if (grc != YT8M_OK) return grc;
   YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
   hipLaunchKernelGGL(hx_pack_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, a.hx, (int)B, (int)H, geo.NT16);
   int rc = launch_status("hx_pack_kernel");
@@ -790,12 +863,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
     default: rc = launch_fwd<8>(a, grid, s); break;
   }
   if (rc != YT8M_OK) return rc;
-  if (!g_gate.has[dev]) {
-    YT8M_HIP_CHECK(hipEventCreateWithFlags(&g_gate.ev[dev], hipEventDisableTiming));
-    g_gate.has[dev] = true;
-  }
-  YT8M_HIP_CHECK(hipEventRecord(g_gate.ev[dev], s));
-  return YT8M_OK;
+  return g_gate.done(dev, (int)grid, s);
 }
 
 namespace {
@@ -825,11 +893,15 @@ bool persist_geometry_bwd(int64_t B, int64_t H, GeometryB* geo) {
   return true;
 }
 
+template <int NQB, bool SH>
+int launch_bwd_sh(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
+  if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false, SH>), dim3(grid), dim3(768), 0, s, a);
+  return yt8m::launch_status("lstm_persist_bwd_kernel");
+}
 template <int NQB>
 int launch_bwd(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
-  if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true>), dim3(grid), dim3(768), 0, s, a);
-  else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false>), dim3(grid), dim3(768), 0, s, a);
-  return yt8m::launch_status("lstm_persist_bwd_kernel");
+  return a.nimg >= a.T ? launch_bwd_sh<NQB, true>(a, grid, s) : launch_bwd_sh<NQB, false>(a, grid, s);
 }
 }  // namespace
 
@@ -860,13 +932,16 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   a.dzx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.phase = phase;
   a.NUB = geo.NUB; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
-  a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + yt8m_lstm_persist_workspace_bytes(B, H) - DBG_BYTES);
+  a.nimg = images_in(workspace_bytes, geo.NT16, 4 * H);
+  a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES);
   const unsigned grid = (unsigned)(geo.NUB * geo.RB);
   int dev = 0;
   device_cus(&dev);
   ProfScope prof(F_LSTM, s);
   std::lock_guard<std::mutex> lk(g_gate.mu);
-  if (g_gate.has[dev]) YT8M_HIP_CHECK(hipStreamWaitEvent(s, g_gate.ev[dev], 0));
+  const int total_cus = device_cus(nullptr);
+  int grc = g_gate.admit(dev, (int)grid, total_cus, s);
+  if (grc != YT8M_OK) return grc;
   YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
   int rc;
   switch (geo.NQB) {
@@ -876,10 +951,5 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
     default: rc = launch_bwd<32>(a, grid, s); break;
   }
   if (rc != YT8M_OK) return rc;
-  if (!g_gate.has[dev]) {
-    YT8M_HIP_CHECK(hipEventCreateWithFlags(&g_gate.ev[dev], hipEventDisableTiming));
-    g_gate.has[dev] = true;
-  }
-  YT8M_HIP_CHECK(hipEventRecord(g_gate.ev[dev], s));
-  return YT8M_OK;
+  return g_gate.done(dev, (int)grid, s);
 }

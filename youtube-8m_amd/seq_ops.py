@@ -265,6 +265,8 @@ PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent r
 U8_BETA = 128.0 * 4.0 / 255.0 + (4.0 / 512.0 - 2.0)     # dequantise(q) = (4/255) (q - 128) + U8_BETA
 BWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_BWD_CHUNKS", "0"))    # 0: same partition as the forward pass
 PERSIST_DBROWS = False
+PERSIST_STEP_IMAGES = _os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0"
+PERSIST_STEP_IMAGES_MAX_BYTES = 8 << 30                 # per layer; larger launches keep the two-image exchange
 _PERSIST_WS = {}      # data_ptr -> workspace tensor of recent persistent launches (for check_persist_errors)
 
 
@@ -357,6 +359,12 @@ class _LstmStack(torch.autograd.Function):
             st["Wp"] = torch.empty(npk, dtype=torch.float32, device=dev) if npk else None
             # persistent recurrence (csrc/lstm_persist.hip): one launch per (layer, chunk), W_h resident in registers
             pws = lib.yt8m_lstm_persist_workspace_bytes(B, H) if PERSIST else 0
+            if pws and PERSIST_STEP_IMAGES:
+                # one exchange image per step of the longest launch (forward or backward partition): XCD-L2-shared state fetch
+                tmax = max([T for _, T in parts] + ([T for _, T in _chunks(F, BWD_CHUNKS)] if BWD_CHUNKS > 0 else []))
+                big = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, tmax)
+                if big <= PERSIST_STEP_IMAGES_MAX_BYTES:
+                    pws = big
             st["pws"] = torch.empty(pws, dtype=torch.uint8, device=dev) if pws else None
             layers.append(st)
             inp = st["out"]
