@@ -28,7 +28,7 @@ def check(M, N, K, kind="randn"):
         B = B * torch.exp(torch.randn((N, K), device=dev, generator=g) * 4)
     bias = torch.randn((N,), device=dev, generator=g)
     ref = A.double() @ B.double().t() + bias.double()
-    c32 = ops.gemm(A, B, transB=True, bias=bias)
+    c32 = ops.gemm_simple(A, B, transB=True, bias=bias)
     ia, _ = ops.x3_split(A)
     ib, _ = ops.x3_split(B)
     cx = ops.gemm_x3_grouped([dict(A=ia, B=ib, bias=bias)])[0]
@@ -51,7 +51,12 @@ def timing(M, N, K, reps=10):
     ib, _ = ops.x3_split(B)
     out = torch.empty((M, N), device=dev)
     res = {}
-    for name, fn in (("fp32-mfma", lambda: ops.gemm(A, B, transB=True, out=out)),
+    def f32():
+        ops.X3 = False
+        ops.gemm(A, B, transB=True, out=out)
+        ops.X3 = True
+
+    for name, fn in (("fp32-mfma", f32),
                      ("x3", lambda: ops.gemm_x3_grouped([dict(A=ia, B=ib, out=out)])),
                      ("split A", lambda: ops.x3_split(A)),
                      ("split A dual", lambda: ops.x3_split(A, plain=True, trans=True))):

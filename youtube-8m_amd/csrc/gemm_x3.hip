@@ -48,11 +48,19 @@ struct XArgs {
   int tiles_m, tiles_n;
   int accumulate;
 };
+// Work items of a launch: problem q contributes its first full[q] tiles (whole rounds of 256 workgroups) unsplit, then the
+// rem[q] tiles of its last, partial round as rem[q] * S[q] K-part items, part major -- the wave-quantisation tail costs a fraction
+// of a round instead of a whole one.  full / rem / S come from the shape of problem q ALONE, so a product is summed in the same
+// order whether it is launched by itself or inside a group.  Parts park raw accumulators in ws[slot_base[q] + item][256][256];
+// x3_fixup_kernel sums them in a fixed order.
 struct XGroup {
   XArgs p[4];
-  int tile_base[5];
+  int full_base[5];     // unsplit tiles, cumulative: workgroups [0, full_base[4]) in XCD-contiguous order
+  int part_base[5];     // K-part items, cumulative: the workgroups behind them, in launch order (round-robin over the XCDs)
+  int slot_base[4];
+  int fix_base[5];      // split tiles, cumulative (grid of the fixup pass)
+  int full[4], rem[4], S[4];
   int nprob;
-  int full, rem, S;     // see gemm_bf16.hip: `full` whole tiles, `rem` tiles of the last partial round split along K in S parts
   float* ws;
 };
 
@@ -85,23 +93,27 @@ __device__ __forceinline__ void fill_op(const float* __restrict__ src, int kb, f
 }
 __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 144 KiB
-  int tile, part = 0, nparts = 1, slot = 0;
-  if ((int)blockIdx.x < G.full) {
-    tile = xcd_remap(blockIdx.x, G.full);
-  } else {
-    slot = blockIdx.x - G.full;
-    const int rt = slot / G.S;
-    part = slot - rt * G.S;
-    nparts = G.S;
-    tile = G.full + rt;
-  }
-  int q = 0;
+  int q = 0, nparts = 1, part = 0, slot = 0, lt;
+  if ((int)blockIdx.x < G.full_base[4]) {
+    const int item = xcd_remap(blockIdx.x, G.full_base[4]);
 #pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+    for (int i = 1; i < 4; ++i)
+      if (i < G.nprob && item >= G.full_base[i]) q = i;
+    lt = item - G.full_base[q];
+  } else {
+    const int item = blockIdx.x - G.full_base[4];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < G.nprob && item >= G.part_base[i]) q = i;
+    const int l2 = item - G.part_base[q];
+    nparts = G.S[q];
+    part = l2 / G.rem[q];
+    lt = G.full[q] + (l2 - part * G.rem[q]);
+    slot = G.slot_base[q] + l2;
+  }
   const XArgs& g = G.p[q];
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
   const int m0 = tm * TM, n0 = tn * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
@@ -272,21 +284,22 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
 
 // sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
 __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
-  const int rt = blockIdx.x >> 4, sixteenth = blockIdx.x & 15;      // 16 workgroups per tile, 16 rows each
-  const int tile = G.full + rt;
+  const int ft = blockIdx.x >> 4, sixteenth = blockIdx.x & 15;      // 16 workgroups per tile, 16 rows each
   int q = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i)
-    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+    if (i < G.nprob && ft >= G.fix_base[i]) q = i;
   const XArgs& g = G.p[q];
+  const int rt = ft - G.fix_base[q], S = G.S[q];
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, G.full[q] + rt, tm, tn);
   const int m0 = tm * TM, n0 = tn * TN;
-  const float* base = G.ws + (int64_t)rt * G.S * (TM * TN);
+  const float* base = G.ws + (int64_t)(G.slot_base[q] + rt) * (TM * TN);
+  const int64_t pstride = (int64_t)G.rem[q] * (TM * TN);
   for (int e = sixteenth * (TM * TN / 16) + threadIdx.x * 4; e < (sixteenth + 1) * (TM * TN / 16); e += 256 * 4) {
     float4 v = *reinterpret_cast<const float4*>(base + e);
-    for (int s = 1; s < G.S; ++s) {
-      const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * (TM * TN) + e);
+    for (int s = 1; s < S; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     const int row = m0 + e / TN, col = n0 + (e % TN);
@@ -421,7 +434,9 @@ extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
   XGroup G;
   G.nprob = 0;
-  int64_t T = 0;
+  constexpr int SLOTS = 256;                                       // one 144 KiB workgroup per CU
+  const int64_t per_part = (int64_t)TM * TN * sizeof(float);
+  int64_t nfull = 0, slots = 0, fix = 0;
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     YT8M_REQUIRE(q.M >= 0 && q.N >= 0 && q.K >= 1 && q.ldc >= q.N, YT8M_E_BADARG, "bad GEMM problem");
@@ -435,33 +450,39 @@ extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs
     g.M = (int)q.M; g.N = (int)q.N; g.KB = (int)((q.K + 15) / 16);
     g.tiles_m = (int)((q.M + TM - 1) / TM); g.tiles_n = (int)((q.N + TN - 1) / TN);
     g.accumulate = q.beta != 0.f;
-    G.p[G.nprob] = g;
-    G.tile_base[G.nprob] = (int)T;
-    T += (int64_t)g.tiles_m * g.tiles_n;
+    // the last, partial round of this problem alone: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp)
+    // + the fixup pass
+    const int64_t T = (int64_t)g.tiles_m * g.tiles_n;
+    const int full = (int)(T / SLOTS) * SLOTS, rem = (int)(T - full);
+    int S = 1;
+    if (workspace && rem > 0) {
+      double best = 1e30;
+      for (int c = 1; c <= 8; ++c) {
+        if (c > 1 && (g.KB / c < 8 || (slots + (int64_t)rem * c) * per_part > workspace_bytes)) break;
+        const int rounds = (rem * c + SLOTS - 1) / SLOTS;
+        const double cost = rounds * ((double)g.KB / c + 10.0) + (c > 1 ? 4.0 + 0.065 * rem * c : 0.0);
+        if (cost < best * 0.98) { best = cost; S = c; }
+      }
+    }
+    const int k = G.nprob;
+    G.p[k] = g;
+    G.S[k] = S;
+    G.full[k] = S > 1 ? full : (int)T;
+    G.rem[k] = S > 1 ? rem : 0;
+    G.full_base[k] = (int)nfull;
+    G.part_base[k] = (int)slots;
+    G.slot_base[k] = (int)slots;
+    G.fix_base[k] = (int)fix;
+    nfull += G.full[k];
+    if (S > 1) { slots += (int64_t)rem * S; fix += rem; }
     ++G.nprob;
   }
   if (G.nprob == 0) return YT8M_OK;
-  for (int i = G.nprob; i <= 4; ++i) G.tile_base[i] = (int)T;
-  for (int i = G.nprob; i < 4; ++i) G.p[i] = G.p[0];
-  constexpr int SLOTS = 256;                                       // one 144 KiB workgroup per CU
-  G.full = (int)(T / SLOTS) * SLOTS;
-  G.rem = (int)(T - G.full);
-  G.S = 1;
+  YT8M_REQUIRE(nfull + slots < (1LL << 30), YT8M_E_SHAPE, "too many tiles for one launch");
+  for (int i = G.nprob; i <= 4; ++i) { G.full_base[i] = (int)nfull; G.part_base[i] = (int)slots; G.fix_base[i] = (int)fix; }
+  for (int i = G.nprob; i < 4; ++i) { G.p[i] = G.p[0]; G.S[i] = 1; G.slot_base[i] = 0; G.full[i] = 0; G.rem[i] = 0; }
   G.ws = static_cast<float*>(workspace);
-  if (G.rem > 0 && workspace) {
-    // the last, partial round: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp) + the fixup pass
-    int min_nk = 1 << 30;
-    for (int i = 0; i < G.nprob; ++i) min_nk = std::min(min_nk, G.p[i].KB);
-    const int64_t per_part = (int64_t)TM * TN * sizeof(float);
-    double best = 1e30;
-    for (int S = 1; S <= 8; ++S) {
-      if (S > 1 && (min_nk / S < 8 || (int64_t)G.rem * S * per_part > workspace_bytes)) break;
-      const int rounds = (G.rem * S + SLOTS - 1) / SLOTS;
-      const double cost = rounds * ((double)min_nk / S + 10.0) + (S > 1 ? 4.0 + 0.065 * G.rem * S : 0.0);
-      if (cost < best * 0.98) { best = cost; G.S = S; }
-    }
-  }
-  const int64_t grid = (int64_t)G.full + (int64_t)G.rem * G.S;
+  const int64_t grid = nfull + slots;
   static bool once = false;
   if (!once) {
     YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -470,6 +491,6 @@ extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs
   }
   ProfScope prof(F_GEMM, as_stream(stream));
   hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)grid), dim3(512), NST * STAGE_F * sizeof(float), as_stream(stream), G);
-  if (G.S > 1) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)G.rem * 16), dim3(256), 0, as_stream(stream), G);
+  if (fix > 0) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
 }

@@ -9,6 +9,7 @@ it.  A dummy requires-grad scalar (``graph.token``) is threaded through every op
 even when the op's data input is plain data (first layer).
 """
 import ctypes
+import os
 
 import torch
 
@@ -99,9 +100,44 @@ def _problem(A, B, out, transA, transB, bias, beta):
     return pr, out, (A, B, bias)
 
 
+X3 = os.environ.get("YT8M_GEMM_X3", "1") != "0"        # large fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
+X3_RATE, F32_RATE, SPLIT_RATE = 195e12, 110e12, 3.2e12  # measured: fp32-equivalent FLOP/s of either kernel, bytes/s of the split pass
+
+
+def _x3_wins(shapes, transA, transB):
+    """Cost estimate for a group of (M, N, K) products: six bf16 products of split operands (tile 256 x 256, plus the split
+    passes over both operands) against the fp32-MFMA kernel (tile 128 x 128)."""
+    t32 = tx3 = 0.0
+    for M, N, K in shapes:
+        fl = 2.0 * M * N * K
+        if fl == 0:
+            continue
+        tm, tn = (M + 255) // 256, (N + 255) // 256
+        eff = (M * N) / float(tm * tn * 65536)
+        occ = min(1.0, tm * tn * max(1, min(8, K // 128)) / 256.0)   # remainder tiles are split along K up to 8 ways
+        tx3 += fl / (X3_RATE * eff * occ) + (M * K + N * K) * 10.0 / SPLIT_RATE + 2e-5
+        t32 += fl / (F32_RATE * min(1.0, ((M + 127) // 128) * ((N + 127) // 128) * max(1, min(8, K // 256)) / 768.0))
+    return tx3 < 0.9 * t32
+
+
+def _x3_operand(cache, T, ld, rows_are_k):
+    """X3Image of a row-major fp32 operand T used with K along its rows (rows_are_k: the transposing split) or its columns."""
+    key = (T.data_ptr(), tuple(T.shape), ld, rows_are_k)
+    img = cache.get(key)
+    if img is None:
+        R, C = T.shape
+        img = _x3_empty(C, R, T.device) if rows_are_k else _x3_empty(R, C, T.device)
+        _lib.check(_lib.lib().yt8m_x3_split(_p(T), R, C, ld, 1.0, None if rows_are_k else _p(img.buf), _p(img.buf) if rows_are_k else None,
+                                            _stream()))
+        cache[key] = img
+    return img
+
+
 def gemm_grouped(items, transA=False, transB=False):
     """items: list of dicts(A=, B=, out=None, bias=None, beta=0.0) sharing transA/transB -> list of outputs.
-    One persistent launch (yt8m_gemm_f32_grouped): no wave-quantisation tail across the group."""
+    One persistent launch: no wave-quantisation tail across the group.  fp32 operands either way; large groups run as six bf16
+    MFMA products of three-plane split operands (yt8m_gemm_x3_nt_grouped: fp32-grade error at twice the rate), the rest on the
+    fp32 MFMA kernel (yt8m_gemm_f32_grouped)."""
     probs, outs, keep = [], [], []
     for it in items:
         _dev(it["A"], it["B"], it.get("out"), it.get("bias"))
@@ -109,9 +145,24 @@ def gemm_grouped(items, transA=False, transB=False):
         probs.append(pr)
         outs.append(out)
         keep.append(k)
-    arr = (_lib.GemmProblem * len(probs))(*probs)
     ws = _workspace(outs[0].device)
-    _lib.check(_lib.lib().yt8m_gemm_f32_grouped(int(transA), int(transB), len(probs), arr, _p(ws), ws.numel() * 4, _stream()))
+    # decided per problem (not per group), so that a product takes the same kernel whether it is launched alone or grouped
+    use = [X3 and _x3_wins([(pr.M, pr.N, pr.K)], transA, transB) for pr in probs]
+    px3 = [i for i, u in enumerate(use) if u]
+    p32 = [i for i, u in enumerate(use) if not u]
+    cache = {}
+    for lo in range(0, len(px3), 4):
+        grp = px3[lo:lo + 4]
+        for i in grp:
+            pr, (A, B, bias) = probs[i], keep[i]
+            ia = _x3_operand(cache, A, pr.lda, bool(transA))         # op(A) [M rows, K]
+            ib = _x3_operand(cache, B, pr.ldb, not transB)           # op(B)^T [N rows, K]
+            pr.A, pr.lda, pr.B, pr.ldb = ia.buf.data_ptr(), 0, ib.buf.data_ptr(), 0
+        arr = (_lib.GemmProblem * len(grp))(*[probs[i] for i in grp])
+        _lib.check(_lib.lib().yt8m_gemm_x3_nt_grouped(len(grp), arr, _p(ws), ws.numel() * 4, _stream()))
+    if p32:
+        arr = (_lib.GemmProblem * len(p32))(*[probs[i] for i in p32])
+        _lib.check(_lib.lib().yt8m_gemm_f32_grouped(int(transA), int(transB), len(p32), arr, _p(ws), ws.numel() * 4, _stream()))
     return outs
 
 

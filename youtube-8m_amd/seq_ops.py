@@ -286,7 +286,7 @@ def check_persist_errors():
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 X3 = _os.environ.get("YT8M_GEMM_X3", "1") != "0"      # hoisted fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
-X3_MIN_ROWS = 1024                                      # time-chunk rows below which the fp32-MFMA kernel's smaller tiles win
+X3_MIN_ROWS = 1024                                      # F * B below which the fp32-MFMA kernel's smaller tiles win
 REC_BF16 = _os.environ.get("YT8M_REC_BF16", "1") != "0"       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
                       # products only
 
@@ -379,7 +379,8 @@ class _LstmStack(torch.autograd.Function):
                 if st["Wp"] is not None:
                     _lib.check(lib.yt8m_lstm_pack(_p(st["W"].data[st["Din"]:]), 4 * st["H"], st["H"], _p(st["Wp"]), None, _stream()))
                 st["bf16"] = bf16 and st["Din"] % 2 == 0
-                st["x3"] = X3 and not st["bf16"] and min(T for _, T in parts) * B >= X3_MIN_ROWS and st["H"] >= 128
+                # decided on the whole sequence, not the chunk: every partition of the time axis runs the same arithmetic
+                st["x3"] = X3 and not st["bf16"] and F * B >= X3_MIN_ROWS and st["H"] >= 128
                 if l == 0 and q_raw is not None and not drop and not st["bf16"]:
                     # 3-way bf16 split of (4/255) W_x, transposed ([4H, 3 D], K-contiguous) + the column sums of W_x
                     Din_, H_ = st["Din"], st["H"]
