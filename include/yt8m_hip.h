@@ -98,6 +98,14 @@ int64_t yt8m_x3_image_bytes(int64_t rows, int64_t K);
 int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
 int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                             yt8m_stream_t stream);
+/* The uint8 input projection on the same kernel ("readers.py uint8 -> float dequantise folded into the first GEMM",
+ * W/readers.py:178-187 -> W/all_frame_models/lstm_model.py:34-47):
+ *   C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n]
+ * A1: ONE-plane image of (q - 128) (exact in bf16; yt8m_u8_frames_image), B3: x3 image of (4/255) W^T (yt8m_x3_split with
+ * scale) -> three exact products per element pair.  rowscale / colsum NULL: plain product + bias. */
+int yt8m_gemm_x1x3_nt(int64_t M, int64_t N, int64_t K, const void* A1, const void* B3, float* C, int64_t ldc, const float* bias,
+                      const float* rowscale, const float* colsum, float colsum_scale, void* workspace, int64_t workspace_bytes,
+                      yt8m_stream_t stream);
 /* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows].
  * dst_ld: row stride of dst in bf16 elements (0 = dense).  The training path pads it to a multiple of 8 so that every bf16
  * row starts 16-byte aligned and the GEMMs stay on their LDS-DMA path (V*(M+1) = 14148 is not a multiple of 8). */
@@ -462,6 +470,10 @@ int yt8m_comm_destroy(void* comm);
 int yt8m_u8_proj_supported(int64_t D);
 int yt8m_u8_frames_to_bf16_tm(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps,
                               int copies, void* Qb, int64_t ldq, float* x_tm, float* r_out, yt8m_stream_t stream);
+/* same pass writing (q - 128) as the one-plane operand image of yt8m_gemm_x1x3_nt (ceil(B F / 32) * (D / 16) KiB; rows time-major
+ * f * B + b; D % 16 == 0) instead of bf16 copies */
+int yt8m_u8_frames_image(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
+                         float* x_tm, float* r_out, yt8m_stream_t stream);
 int yt8m_split3_bf16_t(const float* W, int64_t ldw, int64_t K, int64_t N, float scale, void* out, int64_t ldo,
                        yt8m_stream_t stream);
 int yt8m_rowscale_bias_f32(float* z, int64_t M, int64_t N, int64_t ldz, const float* r, const float* cs, float beta,

@@ -36,6 +36,8 @@ SIGNATURES = {
     "yt8m_x3_image_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_x3_split": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "yt8m_gemm_x3_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
+    "yt8m_gemm_x1x3_nt": (c_int, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, P, P, c_float, P, c_int64, P]),
+    "yt8m_u8_frames_image": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, P, P, P, P]),
     "yt8m_cast_f32_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int, P]),
     "yt8m_cast_f32_bf16_dual": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P]),
     "yt8m_gemm_f32_batched": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, P, c_int64, c_int64, P, c_int64, c_int64,

@@ -31,7 +31,6 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int PLANE_F = 256 * 8;                      // floats of one plane tile: 256 rows x 32 B
 constexpr int OP_F = 3 * PLANE_F;                     // one operand, three planes (24 KiB)
-constexpr int STAGE_F = 2 * OP_F;                     // A + B (48 KiB)
 constexpr int NST = 3;
 constexpr int RG_F = 256;                             // floats of one image block: 32 rows x 32 B (1 KiB)
 
@@ -47,6 +46,10 @@ struct XArgs {
   int M, N, KB;         // KB: 16-wide K blocks
   int tiles_m, tiles_n;
   int accumulate;
+  // optional affine epilogue (the uint8 input projection): C = rscale[m] * (acc + cs_scale * cs[n]) + bias[n]
+  const float* rscale;
+  const float* cs;
+  float cs_scale;
 };
 // Work items of a launch: problem q contributes its first full[q] tiles (whole rounds of 256 workgroups) unsplit, then the
 // rem[q] tiles of its last, partial round as rem[q] * S[q] K-part items, part major -- the wave-quantisation tail costs a fraction
@@ -83,16 +86,22 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int lt, in
 // One operand, one K block: three DMA instructions (one per plane), each 512 lanes x 16 B = a [256 rows][2 slots] plane tile;
 // slot s of row x holds half (s ^ ((x >> 3) & 1)) of the 16-wide block (the image is stored that way), which makes the
 // ds_read_b128 fragment fetch conflict-free.  src: this wave's row group at K block 0, + lane * 16 B.
+template <int NP>
 __device__ __forceinline__ void fill_op(const float* __restrict__ src, int kb, float* S, int tid) {
-  src += (int64_t)kb * (3 * RG_F);
+  src += (int64_t)kb * (NP * RG_F);
   float* dst = S + (tid & ~63) * 4;                    // wave-uniform base; the hardware adds lane * 16 bytes
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < NP; ++p)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * RG_F),
                                      (__attribute__((address_space(3))) void*)(dst + p * PLANE_F), 16, 0, 0);
 }
+// PA = planes of the A image: 3 (general fp32 operand, six products) or 1 (an operand whose elements are exact in bf16 -- the
+// uint8 frames minus 128 -- : three products a b1 + a b2 + a b3, exact up to the 2^-26 of the split of b).
+template <int PA>
 __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 144 KiB
+  constexpr int OPA_F = PA * PLANE_F;                              // A planes of a stage, then the three B planes
+  constexpr int STAGE_F = OPA_F + OP_F;
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats (144 KiB at PA = 3)
   int q = 0, nparts = 1, part = 0, slot = 0, lt;
   if ((int)blockIdx.x < G.full_base[4]) {
     const int item = xcd_remap(blockIdx.x, G.full_base[4]);
@@ -121,9 +130,10 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
   const int nk = kb1 - kb0;
   // this wave's 32-row group of either operand tile (groups beyond the matrix only feed outputs that are never stored)
-  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.KB * (3 * RG_F) + lane * 4;
+  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.KB * (PA * RG_F) + lane * 4;
   const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.KB * (3 * RG_F) + lane * 4;
-#define X3_FILL(KBI, STAGE) { fill_op(pa, KBI, (STAGE), tid); fill_op(pb, KBI, (STAGE) + OP_F, tid); }
+#define X3_FILL(KBI, STAGE) { fill_op<PA>(pa, KBI, (STAGE), tid); fill_op<3>(pb, KBI, (STAGE) + OPA_F, tid); }
+  constexpr int DMA = PA + 3;                                      // LDS-DMA instructions per thread and K-step
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -139,12 +149,12 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   // kt the stages hold steps kt+1 (landed), kt+2 (on the wire) and -- refilled there -- kt+3.
   const int pro = nk < 3 ? nk : 3;
   for (int s = 0; s < pro; ++s) X3_FILL(kb0 + s, smem + s * STAGE_F)
-  if (pro == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (pro == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (pro == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA) : "memory");
+  else if (pro == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const int fa = (wm + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));      // + t * 256 floats per 32 rows, + p * PLANE_F
-  const int fb = OP_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  const int fb = OPA_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
   bf16x8 a2[4], a1[4], a0[4], b0[2], b1[2], b2[2];
   auto load_a = [&](bf16x8 (&d)[4], const float* S, int p) __attribute__((always_inline)) {
 #ifdef YT8M_X3_NO_LDS
@@ -171,7 +181,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
 #endif
     __builtin_amdgcn_sched_barrier(0);
   };
-  load_a(a2, smem, 2); load_b(b0, smem, 0); load_a(a1, smem, 1); load_b(b1, smem, 1); load_a(a0, smem, 0); load_b(b2, smem, 2);
+  if constexpr (PA == 3) { load_a(a2, smem, 2); load_a(a1, smem, 1); }
+  load_b(b0, smem, 0); load_b(b1, smem, 1); load_a(a0, smem, 0); load_b(b2, smem, 2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // stage 0 is refilled right behind the first barrier
   int cur = 0;                                                     // stage of step kt
   // One step.  Top: step kt+1 landed (step kt+2 may stay on the wire); behind the barrier every wave holds step kt in registers,
@@ -188,35 +199,49 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   };
   for (int kt = 0; kt < nk; ++kt) {
     const int nxt = cur + 1 == NST ? 0 : cur + 1;
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef YT8M_X3_NO_BARRIER
     __builtin_amdgcn_s_barrier();
 #endif
     const bool rf = kt + 3 < nk;
-    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (3 * RG_F);
+    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (PA * RG_F);
     const float* qb = pb + (int64_t)(kb0 + kt + 3) * (3 * RG_F);
     float* Sc = smem + cur * STAGE_F + wbase;
     const float* Sn = smem + nxt * STAGE_F;
     __builtin_amdgcn_sched_barrier(0);
-    term(a2, b0);
-    load_a(a2, Sn, 2);
-    dma(rf, qa, Sc);
-    term(a1, b0);
-    dma(rf, qa + RG_F, Sc + PLANE_F);
-    term(a1, b1);
-    load_a(a1, Sn, 1);
-    dma(rf, qa + 2 * RG_F, Sc + 2 * PLANE_F);
-    term(a0, b0);
-    load_b(b0, Sn, 0);
-    dma(rf, qb, Sc + OP_F);
-    term(a0, b1);
-    load_b(b1, Sn, 1);
-    dma(rf, qb + RG_F, Sc + OP_F + PLANE_F);
-    dma(rf, qb + 2 * RG_F, Sc + OP_F + 2 * PLANE_F);
-    term(a0, b2);
-    load_a(a0, Sn, 0);
-    load_b(b2, Sn, 2);
+    if constexpr (PA == 3) {
+      term(a2, b0);
+      load_a(a2, Sn, 2);
+      dma(rf, qa, Sc);
+      term(a1, b0);
+      dma(rf, qa + RG_F, Sc + PLANE_F);
+      term(a1, b1);
+      load_a(a1, Sn, 1);
+      dma(rf, qa + 2 * RG_F, Sc + 2 * PLANE_F);
+      term(a0, b0);
+      load_b(b0, Sn, 0);
+      dma(rf, qb, Sc + OPA_F);
+      term(a0, b1);
+      load_b(b1, Sn, 1);
+      dma(rf, qb + RG_F, Sc + OPA_F + PLANE_F);
+      dma(rf, qb + 2 * RG_F, Sc + OPA_F + 2 * PLANE_F);
+      term(a0, b2);
+      load_a(a0, Sn, 0);
+      load_b(b2, Sn, 2);
+    } else {
+      term(a0, b0);
+      load_b(b0, Sn, 0);
+      dma(rf, qa, Sc);
+      dma(rf, qb, Sc + OPA_F);
+      term(a0, b1);
+      load_b(b1, Sn, 1);
+      dma(rf, qb + RG_F, Sc + OPA_F + PLANE_F);
+      dma(rf, qb + 2 * RG_F, Sc + OPA_F + 2 * PLANE_F);
+      term(a0, b2);
+      load_a(a0, Sn, 0);
+      load_b(b2, Sn, 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
   }
@@ -259,6 +284,12 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
       float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
       if (row < g.M && col < g.N) {
         float* c = g.C + (int64_t)row * g.ldc + col;
+        if (g.rscale) {                                            // (N % 4 == 0 and 16-byte aligned cs: checked by the host)
+          const float rs = g.rscale[row];
+          const float4 cv = *reinterpret_cast<const float4*>(g.cs + col);
+          v.x = rs * (v.x + g.cs_scale * cv.x); v.y = rs * (v.y + g.cs_scale * cv.y);
+          v.z = rs * (v.z + g.cs_scale * cv.z); v.w = rs * (v.w + g.cs_scale * cv.w);
+        }
         if (vec && col + 3 < g.N) {
           if (g.bias) {
             const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
@@ -304,6 +335,12 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
     }
     const int row = m0 + e / TN, col = n0 + (e % TN);
     if (row >= g.M) continue;
+    if (g.rscale && col + 3 < g.N) {
+      const float rs = g.rscale[row];
+      const float4 cv = *reinterpret_cast<const float4*>(g.cs + col);
+      v.x = rs * (v.x + g.cs_scale * cv.x); v.y = rs * (v.y + g.cs_scale * cv.y);
+      v.z = rs * (v.z + g.cs_scale * cv.z); v.w = rs * (v.w + g.cs_scale * cv.w);
+    }
     const float vv[4] = {v.x, v.y, v.z, v.w};
     float* c = g.C + (int64_t)row * g.ldc + col;
 #pragma unroll
@@ -427,11 +464,10 @@ extern "C" int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld,
   return launch_status("x3_split_kernel");
 }
 
-// C[M,N] (+)= A . B^T (+ bias) from the x3 images of A ([M rows, K]) and B ([N rows, K]); yt8m_gemm_problem.A / .B are the
-// images, lda / ldb are ignored, K is the logical K (the images are padded to a multiple of 16).  Up to four problems.
-extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
-                                       yt8m_stream_t stream) {
-  YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
+namespace {
+template <int PA>
+int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, void* workspace,
+              int64_t workspace_bytes, yt8m_stream_t stream) {
   XGroup G;
   G.nprob = 0;
   constexpr int SLOTS = 256;                                       // one 144 KiB workgroup per CU
@@ -450,6 +486,7 @@ extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs
     g.M = (int)q.M; g.N = (int)q.N; g.KB = (int)((q.K + 15) / 16);
     g.tiles_m = (int)((q.M + TM - 1) / TM); g.tiles_n = (int)((q.N + TN - 1) / TN);
     g.accumulate = q.beta != 0.f;
+    g.rscale = rscale; g.cs = cs; g.cs_scale = cs_scale;
     // the last, partial round of this problem alone: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp)
     // + the fixup pass
     const int64_t T = (int64_t)g.tiles_m * g.tiles_n;
@@ -483,14 +520,37 @@ extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs
   for (int i = G.nprob; i < 4; ++i) { G.p[i] = G.p[0]; G.S[i] = 1; G.slot_base[i] = 0; G.full[i] = 0; G.rem[i] = 0; }
   G.ws = static_cast<float*>(workspace);
   const int64_t grid = nfull + slots;
+  constexpr int LDS_BYTES = NST * (PA + 3) * PLANE_F * (int)sizeof(float);
   static bool once = false;
   if (!once) {
-    YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       NST * STAGE_F * (int)sizeof(float)));
+    YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<PA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LDS_BYTES));
     once = true;
   }
   ProfScope prof(F_GEMM, as_stream(stream));
-  hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)grid), dim3(512), NST * STAGE_F * sizeof(float), as_stream(stream), G);
+  hipLaunchKernelGGL(gemm_x3_kernel<PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
   if (fix > 0) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
+}
+}  // namespace
+
+// C[M,N] (+)= A . B^T (+ bias) from the x3 images of A ([M rows, K]) and B ([N rows, K]); yt8m_gemm_problem.A / .B are the
+// images, lda / ldb are ignored, K is the logical K (the images are padded to a multiple of 16).  Up to four problems.
+extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
+                                       yt8m_stream_t stream) {
+  YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
+  return x3_launch<3>(nprob, probs, nullptr, nullptr, 0.f, workspace, workspace_bytes, stream);
+}
+
+// The uint8 input projection: C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n], A a ONE-plane image (elements
+// exact in bf16: q - 128, written by yt8m_u8_frames_image), B the three-plane x3 image of (4/255) W^T.
+extern "C" int yt8m_gemm_x1x3_nt(int64_t M, int64_t N, int64_t K, const void* A1, const void* B3, float* C, int64_t ldc,
+                                 const float* bias, const float* rowscale, const float* colsum, float colsum_scale, void* workspace,
+                                 int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE((rowscale == nullptr) == (colsum == nullptr), YT8M_E_BADARG, "rowscale and colsum come together");
+  YT8M_REQUIRE(!rowscale || ((N % 4) == 0 && (reinterpret_cast<uintptr_t>(colsum) & 15) == 0), YT8M_E_SHAPE,
+               "the affine epilogue needs N % 4 == 0 and a 16-byte aligned colsum");
+  yt8m_gemm_problem p;
+  p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = 0; p.B = B3; p.ldb = 0; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = 0.f;
+  return x3_launch<1>(1, &p, rowscale, colsum, colsum_scale, workspace, workspace_bytes, stream);
 }

@@ -25,7 +25,8 @@ __device__ __forceinline__ float bf16_val(uint16_t h) { return __uint_as_float((
 // bit-identical to the float path); output rows are TIME-major (f * B + b): what the recurrence and the hoisted GEMMs use.
 __global__ __launch_bounds__(256) void u8_frames_tm_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
                                                            uint16_t* __restrict__ Qb, long long ldq, int copies, float* __restrict__ xtm,
-                                                           float* __restrict__ rout, int B, int F, int D, float eps) {
+                                                           float* __restrict__ rout, int B, int F, int D, float eps,
+                                                           uint16_t* __restrict__ img) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)B * F) return;
@@ -57,6 +58,13 @@ __global__ __launch_bounds__(256) void u8_frames_tm_kernel(const uint8_t* __rest
 #pragma unroll
     for (int k = 0; k < 4; ++k) h[k] = (uint16_t)(__float_as_uint((float)((int)((w[it] >> (8 * k)) & 255u) - 128)) >> 16);   // exact
     const uint2 pk = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    if (img) {
+      // one-plane x3 image (csrc/gemm_x3.hip): [orow / 32][D / 16][32 rows][2 halves][8] bf16, half h of row r in slot h ^ ((r >> 3) & 1)
+      const int kb = c4 >> 2, r32 = (int)(orow & 31);
+      const int slot = ((c4 >> 1) & 1) ^ ((r32 >> 3) & 1);
+      uint16_t* blk = img + ((orow >> 5) * (long long)(D >> 4) + kb) * 512 + r32 * 16 + slot * 8 + (c4 & 1) * 4;
+      *reinterpret_cast<uint2*>(blk) = pk;
+    }
     for (int j = 0; j < copies; ++j) reinterpret_cast<uint2*>(Qb + orow * ldq + (long long)j * D)[c4] = pk;
     if (xtm) {
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -133,7 +141,24 @@ extern "C" int yt8m_u8_frames_to_bf16_tm(const uint8_t* q, const int32_t* num_fr
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
   hipLaunchKernelGGL(u8_frames_tm_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, static_cast<uint16_t*>(Qb),
-                     (long long)ldq, copies, x_tm, r_out, (int)B, (int)F, (int)D, eps);
+                     (long long)ldq, copies, x_tm, r_out, (int)B, (int)F, (int)D, eps, (uint16_t*)nullptr);
+  return launch_status("u8_frames_tm_kernel");
+}
+
+// Same pass, but (q - 128) goes into the ONE-plane operand image of yt8m_gemm_x1x3_nt (rows time-major: f * B + b;
+// ceil(B F / 32) * (D / 16) KiB, 16-byte aligned; D % 16 == 0) instead of the K-concatenated bf16 copies.
+extern "C" int yt8m_u8_frames_image(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
+                                    float* x_tm, float* r_out, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * D == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_u8_proj_supported(D) && (D % 16) == 0, YT8M_E_SHAPE, "D must be a multiple of 16 and <= 2048");
+  YT8M_REQUIRE(q && image && r_out, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(q) & 3) | (reinterpret_cast<uintptr_t>(image) & 15) |
+                (x_tm ? reinterpret_cast<uintptr_t>(x_tm) & 15 : 0)) == 0, YT8M_E_BADARG, "misaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(u8_frames_tm_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, (uint16_t*)nullptr, 0LL, 0,
+                     x_tm, r_out, (int)B, (int)F, (int)D, eps, static_cast<uint16_t*>(image));
   return launch_status("u8_frames_tm_kernel");
 }
 

@@ -241,14 +241,17 @@ def lnlstm_layer(x_tm, W, gammas, betas, num_frames, forget_bias=1.0, keep_prob=
 _SIDE = {}
 
 
-def _side_streams(device, L):
+def _side_streams(device, L, persistent=False):
     """Per device: one stream per layer (its projection / dx GEMMs and its recurrence run in order on it) and one for the
     weight-gradient GEMMs.  Measured on the 2-layer BASELINE configs[3] stack (B = 128): a separate GEMM stream per layer is
-    no better (51.7 vs 49.0 ms/step) and HIGH-priority recurrence streams are far worse (96 ms: the priority queues throttle
-    the step kernels), so neither is used."""
-    pool = _SIDE.setdefault(device, dict(r=[], w=None))
+    no better (51.7 vs 49.0 ms/step).  The layer streams are HIGH priority when the recurrence is the persistent kernel: it needs
+    every workgroup resident, and behind a high-priority queue it takes freed CUs before the remaining workgroups of a running
+    weight-gradient GEMM do (a partially resident recurrence spins on its CUs while the GEMM crawls on the rest: 28.6 vs 46.6
+    ms/step run to run without it).  With the per-step kernels (600 launches) priority queues are far worse (96 ms), so those
+    keep normal streams."""
+    pool = _SIDE.setdefault((device, bool(persistent)), dict(r=[], w=None))
     while len(pool["r"]) < L:
-        pool["r"].append(torch.cuda.Stream(device=device))
+        pool["r"].append(torch.cuda.Stream(device=device, priority=REC_STREAM_PRIORITY if persistent else 0))
     if pool["w"] is None:
         pool["w"] = torch.cuda.Stream(device=device)
     return pool["r"][:L], pool["r"][:L], pool["w"]
@@ -265,6 +268,7 @@ PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent r
 U8_BETA = 128.0 * 4.0 / 255.0 + (4.0 / 512.0 - 2.0)     # dequantise(q) = (4/255) (q - 128) + U8_BETA
 BWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_BWD_CHUNKS", "0"))    # 0: same partition as the forward pass
 PERSIST_DBROWS = False
+REC_STREAM_PRIORITY = int(_os.environ.get("YT8M_REC_STREAM_PRIORITY", "-1"))
 PERSIST_STEP_IMAGES = _os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0"
 PERSIST_STEP_IMAGES_MAX_BYTES = 8 << 30                 # per layer; larger launches keep the two-image exchange
 _PERSIST_WS = {}      # data_ptr -> workspace tensor of recent persistent launches (for check_persist_errors)
@@ -327,11 +331,18 @@ class _LstmStack(torch.autograd.Function):
             _dev(x_tm)
             q_raw = x_tm.contiguous()
             Bq, Fq, Dq = q_raw.shape
-            Qb = ops._bf16_empty(Fq * Bq, 3 * Dq, q_raw.device)
             rrow = torch.empty((Fq * Bq,), dtype=torch.float32, device=q_raw.device)
             x_tm = torch.empty((Fq, Bq, Dq), dtype=torch.float32, device=q_raw.device)
-            _lib.check(lib.yt8m_u8_frames_to_bf16_tm(_p(q_raw), _p(nf), Bq, Fq, Dq, 1e-12, 3, _p(Qb), Qb.stride(0), _p(x_tm), _p(rrow),
-                                                     _stream()))
+            Qb = Qimg = None
+            # one-plane operand image for the x3 kernel (three exact products per element pair) when every time chunk starts on
+            # a 32-row group of the image; otherwise three bf16 copies side by side for the plain bf16 kernel
+            if X3 and Dq % 16 == 0 and all((t0 * Bq) % 32 == 0 for t0, _ in _chunks(Fq, chunks)):
+                Qimg = torch.empty(((Fq * Bq + 31) // 32) * (Dq // 16) * 1024, dtype=torch.uint8, device=q_raw.device)
+                _lib.check(lib.yt8m_u8_frames_image(_p(q_raw), _p(nf), Bq, Fq, Dq, 1e-12, _p(Qimg), _p(x_tm), _p(rrow), _stream()))
+            else:
+                Qb = ops._bf16_empty(Fq * Bq, 3 * Dq, q_raw.device)
+                _lib.check(lib.yt8m_u8_frames_to_bf16_tm(_p(q_raw), _p(nf), Bq, Fq, Dq, 1e-12, 3, _p(Qb), Qb.stride(0), _p(x_tm), _p(rrow),
+                                                         _stream()))
         x_tm = _f32c(x_tm)
         _dev(x_tm)
         L = len(wb) // 2
@@ -339,7 +350,10 @@ class _LstmStack(torch.autograd.Function):
         F, B, _ = x_tm.shape
         dev = x_tm.device
         main = torch.cuda.current_stream(dev)
-        rs, gs, _ = _side_streams(dev, L)
+        Hs = [w.data.shape[1] // 4 for w in wb[0::2]]
+        pers = PERSIST and all(lib.yt8m_lstm_persist_supported(B, h) for h in Hs)
+        rs, gs, _ = _side_streams(dev, L, pers)
+        ctx.pers = pers
         parts = _chunks(F, chunks)
         bf16 = bool(bf16) and B % 2 == 0 and min(T for _, T in parts) * B >= ops.BF16_MIN_ROWS
         drop = input_keep_prob is not None and float(input_keep_prob) < 1.0
@@ -384,9 +398,12 @@ class _LstmStack(torch.autograd.Function):
                 if l == 0 and q_raw is not None and not drop and not st["bf16"]:
                     # 3-way bf16 split of (4/255) W_x, transposed ([4H, 3 D], K-contiguous) + the column sums of W_x
                     Din_, H_ = st["Din"], st["H"]
-                    st["W3T"] = ops._bf16_empty(4 * H_, 3 * Din_, dev)
-                    _lib.check(lib.yt8m_split3_bf16_t(_p(st["W"].data[:Din_]), 4 * H_, Din_, 4 * H_, 4.0 / 255.0, _p(st["W3T"]),
-                                                      st["W3T"].stride(0), _stream()))
+                    if Qimg is not None:
+                        st["W3T"] = ops.x3_split(st["W"].data[:Din_], plain=False, trans=True, scale=4.0 / 255.0)[1]
+                    else:
+                        st["W3T"] = ops._bf16_empty(4 * H_, 3 * Din_, dev)
+                        _lib.check(lib.yt8m_split3_bf16_t(_p(st["W"].data[:Din_]), 4 * H_, Din_, 4 * H_, 4.0 / 255.0, _p(st["W3T"]),
+                                                          st["W3T"].stride(0), _stream()))
                     st["Wcs"] = torch.empty((4 * H_,), dtype=torch.float32, device=dev)
                     ops.colsum(st["W"].data[:Din_], st["Wcs"])
                 if st["x3"] and "W3T" not in st:                    # W_x^T as the K-contiguous operand of the projection
@@ -414,7 +431,13 @@ class _LstmStack(torch.autograd.Function):
                         src = x_tm[t0:t0 + T] if l == 0 else xc
                         _lib.check(lib.yt8m_dropout_f32(_p(src), _p(xc), xc.numel(), float(input_keep_prob), int(seeds[l]),
                                                         t0 * B * Din, _stream()))
-                    if "W3T" in st:
+                    if "W3T" in st and Qimg is not None:
+                        zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
+                        ws = ops._workspace(dev)
+                        _lib.check(lib.yt8m_gemm_x1x3_nt(T * B, 4 * H, Din, _p(Qimg[(t0 * B // 32) * (Din // 16) * 1024:]), _p(st["W3T"].buf),
+                                                         _p(zc), 4 * H, _p(st["b"].data), _p(rrow[t0 * B:]), _p(st["Wcs"]), U8_BETA,
+                                                         _p(ws), ws.numel() * 4, _stream()))
+                    elif "W3T" in st:
                         zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
                         ops.gemm_bf16_nt_grouped([dict(A=Qb[t0 * B:(t0 + T) * B], B=st["W3T"], out=zc)])
                         _lib.check(lib.yt8m_rowscale_bias_f32(_p(zc), T * B, 4 * H, 4 * H, _p(rrow[t0 * B:]), _p(st["Wcs"]),
@@ -469,7 +492,7 @@ class _LstmStack(torch.autograd.Function):
         dev = layers[0]["x"].device
         lib = _lib.lib()
         main = torch.cuda.current_stream(dev)
-        rs, gs, sw = _side_streams(dev, L)
+        rs, gs, sw = _side_streams(dev, L, ctx.pers)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(layers[0]["x"]) if need_dx else None
         for st in layers:
