@@ -470,17 +470,19 @@ def test_dbof_model_with_batch_norm_vs_oracle(dev, flags, quantized):
 
 
 # ---- uint8 operand path of the hoisted LSTM input projection (csrc/u8proj.hip) -----------------------------
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_lstm_uint8_projection_matches_float_path_and_oracle(dev, flags, chunks):
+@pytest.mark.parametrize("chunks,B,D", [(1, 10, 72), (3, 10, 72), (1, 32, 64), (3, 32, 64)])
+def test_lstm_uint8_projection_matches_float_path_and_oracle(dev, flags, chunks, B, D):
     """LstmModel on RAW uint8 frames: the layer-0 projection on exact bf16 operands ((q - 128) x 3-way split of (4/255) W) with
     the row-norm / rank-1 epilogue equals (a) the float path (DefaultTransformer first, fp32 GEMM) on the same weights and (b) the
-    fp64 oracle on dequantise + l2-normalise, for predictions, loss and all gradients; ragged num_frames incl. 0 and F."""
+    fp64 oracle on dequantise + l2-normalise, for predictions, loss and all gradients; ragged num_frames incl. 0 and F.
+    B = 32, D = 64 takes the one-plane image + x3 kernel (every chunk starts on a 32-row group, D % 16 == 0); B = 10, D = 72 the
+    K-concatenated bf16 copies."""
     from oracle import np_ref, torch_ref
     flags.lstm_cells, flags.lstm_pipeline_chunks = "128", chunks
     rs = np.random.RandomState(41)
-    B, F, D, V = 10, 9, 72, 17
+    F, V = 9, 17
     q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
-    nf = np.array([9, 0, 1, 4, 9, 7, 2, 9, 5, 3], dtype=np.int32)
+    nf = np.resize(np.array([9, 0, 1, 4, 9, 7, 2, 9, 5, 3], dtype=np.int32), B)
     y = rs.rand(B, V) < 0.15
     qd, yd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
     outs = {}

@@ -1,0 +1,184 @@
+"""-m gpu: the fp32-on-bf16-pipe GEMM (csrc/gemm_x3.hip), the uint8 input projection on it, the per-step exchange images of
+the persistent recurrence, and the CU-masked stream / placement probe."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import yt8m_amd._lib as L
+import yt8m_amd.ops as ops
+from yt8m_amd.ops import _p, _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(c, ref):
+    return float((c.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,kind", [
+    (300, 77, 50, "randn"),          # partial tiles in both dimensions, K not a multiple of 16
+    (256, 256, 16, "randn"),         # one tile, one K block
+    (1000, 515, 1153, "randn"),
+    (513, 4716, 2304, "wide"),       # 12 decades of dynamic range inside one reduction
+    (2176, 4096, 4800, "randn"),     # the weight-gradient shape of the headline step (K shortened): split along K
+])
+def test_gemm_x3_error_is_fp32_grade(dev, M, N, K, kind):
+    """Six bf16 products of the three-plane split against an fp64 product: the error is that of the fp32-MFMA kernel (both a few
+    1e-7 of max|C|, growing with sqrt(K)), bias and the accumulate form included; the transposing split writes the same image."""
+    g = torch.Generator(device=dev).manual_seed(M * 31 + N * 7 + K)
+    A = torch.randn((M, K), device=dev, generator=g)
+    B = torch.randn((N, K), device=dev, generator=g)
+    if kind == "wide":
+        A = A * torch.exp(torch.randn((M, K), device=dev, generator=g) * 4)
+        B = B * torch.exp(torch.randn((N, K), device=dev, generator=g) * 4)
+    bias = torch.randn((N,), device=dev, generator=g)
+    ref = A.double() @ B.double().t() + bias.double()
+    c32 = ops.gemm_simple(A, B, transB=True, bias=bias)
+    ia, _ = ops.x3_split(A)
+    ib, _ = ops.x3_split(B)
+    cx = ops.gemm_x3_grouped([dict(A=ia, B=ib, bias=bias)])[0]
+    e32, ex = _rel(c32, ref), _rel(cx, ref)
+    assert ex < max(4 * e32, 3e-7), (ex, e32)
+    c0 = torch.randn((M, N), device=dev, generator=g)
+    cacc = ops.gemm_x3_grouped([dict(A=ia, B=ib, out=c0.clone(), beta=1.0)])[0]
+    assert _rel(cacc, ref - bias.double() + c0.double()) < max(4 * e32, 3e-7)
+    _, iat = ops.x3_split(A.t().contiguous(), plain=False, trans=True)
+    assert torch.equal(iat.buf, ia.buf)
+
+
+def test_x3_split_is_exact(dev):
+    """a1 + a2 + a3 reproduces every fp32 value exactly (also tiny, huge and negative ones); K padding is zero."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    R, C = 70, 37
+    x = torch.randn((R, C), device=dev, generator=g) * torch.exp(torch.randn((R, C), device=dev, generator=g) * 10)
+    x[0, 0], x[1, 1], x[2, 2] = 0.0, -1.0, 3.0e38
+    img, _ = ops.x3_split(x)
+    KB = (C + 15) // 16
+    blocks = img.buf.view(torch.bfloat16).view((R + 31) // 32, KB, 3, 32, 2, 8).float().cpu().numpy().astype(np.float64)
+    xs = x.cpu().numpy().astype(np.float64)
+    for r in range(R):
+        sw = (r % 32 >> 3) & 1
+        for kb in range(KB):
+            row = np.concatenate([blocks[r // 32, kb, :, r % 32, sw, :], blocks[r // 32, kb, :, r % 32, sw ^ 1, :]], axis=1).sum(0)
+            want = np.zeros(16)
+            n = min(16, C - kb * 16)
+            want[:n] = xs[r, kb * 16:kb * 16 + n]
+            assert np.array_equal(row, want), (r, kb)
+
+
+def test_gemm_dispatch_grouped_equals_single(dev):
+    """ops.gemm_grouped decides per problem and the x3 launch splits K per problem: a product launched alone or inside a group
+    gives the same bits (the data-parallel path launches the weight-gradient products one by one, the plain step grouped)."""
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn((1024, 1152), device=dev, generator=g)
+    d1 = torch.randn((1024, 9432), device=dev, generator=g)
+    d2 = torch.randn((1024, 14148), device=dev, generator=g)
+    assert ops._x3_wins([(1152, 9432, 1024)], True, False)
+    a = ops.gemm_grouped([dict(A=x, B=d1), dict(A=x, B=d2)], transA=True)
+    b1 = ops.gemm(x, d1, transA=True)
+    b2 = ops.gemm(x, d2, transA=True)
+    assert torch.equal(a[0], b1) and torch.equal(a[1], b2)
+    ref = x.double().t() @ d1.double()
+    assert _rel(b1, ref) < 3e-6
+
+
+@pytest.mark.parametrize("t0", [0, 3])
+def test_u8_projection_on_the_x3_kernel(dev, t0):
+    """(q - 128) as a one-plane image x three-plane image of (4/255) W^T with the affine epilogue = fp64 x.W + b to fp32
+    rounding at D = 1152, for a time chunk that starts inside the image (t0 * B a multiple of 32) and ends on a partial row
+    group; x_tm / r from the image pass are bit-identical to the dequantise kernel."""
+    from oracle import np_ref
+    import yt8m_amd.seq_ops as seq_ops
+    rs = np.random.RandomState(6)
+    B, F, D, N = 32, 7, 1152, 512
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(0, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 0
+    W = (rs.randn(D, N) * 0.05).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    qd, nfd, Wd, bd = (torch.from_numpy(a).to(dev) for a in (q, nf, W, bias))
+    lib = L.lib()
+    img = torch.empty(((F * B + 31) // 32) * (D // 16) * 1024, dtype=torch.uint8, device=dev)
+    r = torch.empty((F * B,), dtype=torch.float32, device=dev)
+    xtm = torch.empty((F, B, D), dtype=torch.float32, device=dev)
+    L.check(lib.yt8m_u8_frames_image(_p(qd), _p(nfd), B, F, D, 1e-12, _p(img), _p(xtm), _p(r), _stream()))
+    assert torch.equal(xtm, ops.dequant_l2norm(qd, nfd).transpose(0, 1).contiguous())
+    w3 = ops.x3_split(Wd, plain=False, trans=True, scale=4.0 / 255.0)[1]
+    cs = torch.empty((N,), dtype=torch.float32, device=dev)
+    ops.colsum(Wd, cs)
+    T = F - t0
+    rows = T * B - 5                                     # stop inside the last row group
+    z = torch.full((rows, N), float("nan"), device=dev)
+    ws = ops._workspace(dev)
+    L.check(lib.yt8m_gemm_x1x3_nt(rows, N, D, _p(img[(t0 * B // 32) * (D // 16) * 1024:]), _p(w3.buf), _p(z), N, _p(bd), _p(r[t0 * B:]),
+                                  _p(cs), seq_ops.U8_BETA, _p(ws), ws.numel() * 4, _stream()))
+    x64 = np_ref.dequant_l2norm_folded(q, nf).transpose(1, 0, 2).reshape(F * B, D)[t0 * B:t0 * B + rows]
+    zr = x64 @ W.astype(np.float64) + bias
+    assert np.abs(z.cpu().numpy() - zr).max() < 2e-6 * max(1.0, np.abs(zr).max())
+
+
+def test_persistent_recurrence_step_images_equal_two_images(dev):
+    """One exchange image per step (plain, XCD-L2-shared fetch) against two alternating images (sc0 sc1 fetch): the same
+    arithmetic in the same order, so forward and backward results are bit-identical."""
+    lib = L.lib()
+    B, F, H = 128, 12, 1024
+    if not lib.yt8m_lstm_persist_bwd_supported(B, H):
+        pytest.skip("persistent recurrence not available on this device")
+    g = torch.Generator(device=dev).manual_seed(9)
+    z0 = torch.randn((F, B, 4 * H), device=dev, generator=g) * 0.3
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.06
+    dout = torch.randn((F, B, H), device=dev, generator=g) * 0.01
+    res = []
+    for nbytes in (lib.yt8m_lstm_persist_workspace_bytes(B, H), lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F)):
+        pws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        z = z0.clone()
+        cs = torch.zeros((F + 1, B, H), device=dev)
+        hs = torch.zeros((F + 1, B, H), device=dev)
+        out = torch.empty((F, B, H), device=dev)
+        L.check(lib.yt8m_lstm_persist_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), None, 0, F, B, H, 1.0, _p(pws), nbytes, _stream()))
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        dz = torch.empty((F, B, 4 * H), device=dev)
+        work = torch.zeros((4, B, H), device=dev)
+        L.check(lib.yt8m_lstm_persist_bwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), nbytes,
+                                          _stream()))
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        res.append((out.clone(), cs.clone(), dz.clone(), work.clone()))
+    assert lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) > lib.yt8m_lstm_persist_workspace_bytes(B, H)
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    assert float(res[0][2].abs().max()) > 0
+
+
+def test_cu_masked_stream_confines_workgroups(dev):
+    """A stream created with the low 128 mask bits set runs on 16 CUs of each of the 8 XCDs (mask bit i -> XCD i % 8); the
+    placement probe sees every CU from an unmasked stream."""
+    lib = L.lib()
+    props = torch.cuda.get_device_properties(dev)
+    if props.multi_processor_count != 256:
+        pytest.skip("mask layout measured on the 256-CU part")
+
+    def cus(stream_ptr, sync):
+        out = torch.full((4096, 2), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        L.check(lib.yt8m_probe_placement(_p(out), 4096, 2000, stream_ptr))
+        sync()
+        o = out.cpu().numpy()
+        return {(int(x), (int(h) >> 8) & 0xFF) for x, h in o}
+
+    allc = cus(_stream(), torch.cuda.synchronize)
+    assert len(allc) == 256
+    words = (ctypes.c_uint32 * 8)(*([0xFFFFFFFF] * 4 + [0] * 4))
+    h = ctypes.c_void_p()
+    L.check(lib.yt8m_stream_create_cu_mask(words, 8, ctypes.byref(h)))
+    try:
+        s = torch.cuda.ExternalStream(h.value, device=dev)
+        half = cus(ctypes.c_void_p(h.value), s.synchronize)
+        assert len(half) == 128 and half < allc
+        per = {}
+        for x, c in half:
+            per[x] = per.get(x, 0) + 1
+        assert sorted(per) == list(range(8)) and set(per.values()) == {16}
+    finally:
+        L.check(lib.yt8m_stream_destroy(ctypes.c_void_p(h.value)))
