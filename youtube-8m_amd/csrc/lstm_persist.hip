@@ -50,6 +50,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // aux 17 = sc0 sc1: write-through store / coherent load (MI355X_MICROARCH.md, inter-workgroup visibility)
 constexpr long long SPIN_TIMEOUT = 300000000;  // wall_clock64 ticks (100 MHz): 3 s
 constexpr int CTL_HDR = 32;                    // control block: [0] error word, counters from word 32
+#ifndef YT8M_PERSIST_SHARDS
+#define YT8M_PERSIST_SHARDS 8
+#endif
+// Arrival counter shards per tile, one 128-byte line each (the single polling wave of a workgroup reads all of them with one
+// load instruction).  Measured at B = 128, H = 1024: 8 and 16 shards run alike (10.6 us / step forward), 64 are slower (12.4:
+// the poll costs more than the shorter add queues save).
+constexpr int NSH = YT8M_PERSIST_SHARDS;
 
 struct PersistFwdArgs {
   float* z;             // [F,B,4H] hoisted input projection + bias on entry, gate activations on exit
@@ -86,17 +93,23 @@ __device__ __forceinline__ float4 as_f4(u32x4 v) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// Waits until the 8 shard counters of `tile` sum to >= target.  Lanes 0-7 poll one shard each with relaxed agent-scope
+// sum of lanes 0 .. NSH-1 (wave-uniform result)
+__device__ __forceinline__ unsigned shard_sum(unsigned v) {
+  unsigned tot = 0;
+#pragma unroll
+  for (int i = 0; i < NSH; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)v, i);
+  return tot;
+}
+
+// Waits until the NSH shard counters of `tile` sum to >= target.  Lanes 0-7 poll one shard each with relaxed agent-scope
 // loads; bounded: after SPIN_TIMEOUT the error word is set and every later wait falls through at once.
 __device__ __forceinline__ void wait_tile(unsigned* ctl, int tile, unsigned target, int lane) {
-  unsigned* c = ctl + CTL_HDR + (tile * 8 + (lane & 7)) * 32;
+  unsigned* c = ctl + CTL_HDR + (tile * NSH + (lane & (NSH - 1))) * 32;
   long long t_start = 0;
   for (unsigned spins = 0;; ++spins) {
     unsigned v = 0;
-    if (lane < 8) v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned tot = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)v, i);
+    if (lane < NSH) v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tot = shard_sum(v);
     if (tot >= target) return;
     if (spins >= 16) {
       __builtin_amdgcn_s_sleep(1);
@@ -154,6 +167,7 @@ __device__ __forceinline__ void lds_wait_ge(const unsigned* p, unsigned target, 
   }
 }
 
+constexpr int MAX_LOCAL_TILES = 64;   // 16-row tiles one workgroup may own (persist_geometry refuses larger batches)
 constexpr int NSLOT = 4;     // partial-tile slots in LDS (items k, k+4, ... share slot k & 3)
 constexpr int NEPI = 4;      // epilogue waves (item k is finished by epilogue wave k & 3)
 
@@ -180,6 +194,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   __shared__ __attribute__((aligned(16))) float red[NSLOT][8][2][4][64];   // [slot][wave][col half][acc reg][lane]: 64 KB
   __shared__ __attribute__((aligned(16))) float4 Wl[8][HQ][2][64];         // LDS-resident half of W_h's slice: 8 * HQ * 2 KB
   __shared__ unsigned lds_cnt[NSLOT], lds_free[NSLOT];
+  // Only matrix wave 0 polls the arrival counters in memory; it posts what it has seen per local tile here and the other seven
+  // matrix waves wait on LDS (eight waves x 256 workgroups polling the same lines was the bulk of the fabric's request traffic).
+  __shared__ unsigned lds_seen[MAX_LOCAL_TILES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ug, g;
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
     return make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
   };
   if (tid < NSLOT) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
+  for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
 #pragma unroll
     for (int qq = 0; qq < HQ; ++qq) {
@@ -239,28 +257,38 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
     auto item = [&](float4 (&A)[NQ], float4 (&Areq)[NQ], int k) {
       const int s = s_cur, T = g + it_cur * RB;
       STAMP(0);
-      int sr = s, Tr = T;                               // item k + PD (the last PD items re-request themselves: no branch
+      int sr = s, Tr = T, itr = it_cur;                 // item k + PD (the last PD items re-request themselves: no branch
       unsigned pv = 0;                                  // around the loads, that data is long published)
       if (PD >= 1) {
-        int itr = it_cur + PD;
+        itr = it_cur + PD;
         while (itr >= n_it) { itr -= n_it; ++sr; }
         const bool have = k + PD < total;
         Tr = have ? g + itr * RB : T;
+        itr = have ? itr : it_cur;
         sr = have ? sr : s;
         // speculative poll: the counter read travels under the first MFMAs
-        if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (Tr * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0 && lane < NSH)
+          pv = __hip_atomic_load(a.ctl + CTL_HDR + (Tr * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        wait_tile(a.ctl, T, (unsigned)s * arrivals, lane);
+        if (w == 0) {
+          wait_tile(a.ctl, T, (unsigned)s * arrivals, lane);
+          if (lane == 0) __hip_atomic_store(&lds_seen[it_cur], (unsigned)s * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          lds_wait_ge(&lds_seen[it_cur], (unsigned)s * arrivals, a.ctl);
+        }
         load_item(A, s, T);
       }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int qg = 0; qg < NQ; ++qg) {
         if (PD >= 1 && qg == (NQ * YT8M_FWD_POLLQ) / 4) {   // request point: the state of item k + PD must be complete now
-          unsigned tot = 0;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)pv, i);
-          if (tot < (unsigned)sr * arrivals) wait_tile(a.ctl, Tr, (unsigned)sr * arrivals, lane);
+          if (w == 0) {
+            const unsigned tot = shard_sum(pv);
+            if (tot < (unsigned)sr * arrivals) wait_tile(a.ctl, Tr, (unsigned)sr * arrivals, lane);
+            if (lane == 0) __hip_atomic_store(&lds_seen[itr], (unsigned)sr * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            lds_wait_ge(&lds_seen[itr], (unsigned)sr * arrivals, a.ctl);
+          }
           load_item(Areq, sr, Tr);
           STAMP(1);
         }
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
         STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the write-through stores, then count the arrival
         if (lane == 0)
-          __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * 8 + (blockIdx.x & 7)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * NSH + (blockIdx.x & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         STAMP(4);
       }
       // everything the backward pass / the caller needs, in the standard layouts (nobody inside this launch waits for these)
@@ -444,6 +472,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   __shared__ __attribute__((aligned(16))) float4 Wl[8][HALF][64];          // LDS-resident half of the weights: 8 * HALF KB
   __shared__ __attribute__((aligned(16))) float red[NSLOT_B][8][4][64];    // [slot][wave][acc reg][lane]: 24 KB
   __shared__ unsigned lds_cnt[NSLOT_B], lds_free[NSLOT_B];
+  __shared__ unsigned lds_seen[MAX_LOCAL_TILES];           // see the forward kernel: only matrix wave 0 polls memory
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ub, g;
@@ -463,6 +492,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   const unsigned arrivals = (unsigned)a.NUB * 4u;        // per (tile, publish): four epilogue waves per workgroup
   const int i16 = lane & 15, kq = lane >> 4;
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
+  for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
     // B fragment: lane (n = unit, kq) supplies W_h[16 ub + n][k = 16 q + 4 kq + e], e = 0..3: a float4 of a W_h row
     const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * NQB) * 16 + kq * 4;
@@ -481,8 +511,16 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
     auto blk = [&](int T) -> unsigned { return (unsigned)(T * QH4) * 1024u + lane_off; };
     float4 ring[HALF];
     int s_cur = 0, it_cur = 0, slot = 0, gen = 0;
+    auto seen_wait = [&](int it, int T, unsigned target) {   // wave 0 polls memory and posts; the others wait on LDS
+      if (w == 0) {
+        wait_tile(a.ctl, T, target, lane);
+        if (lane == 0) __hip_atomic_store(&lds_seen[it], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        lds_wait_ge(&lds_seen[it], target, a.ctl);
+      }
+    };
     if (PF) {                                            // first half of item 0: after every workgroup's prologue publish
-      wait_tile(a.ctl, g, arrivals, lane);
+      seen_wait(0, g, arrivals);
       const unsigned b0 = blk(g);
       const __amdgpu_buffer_rsrc_t dx0 = image(0);
 #pragma unroll
@@ -501,9 +539,10 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       const unsigned bcur = blk(T);
       const __amdgpu_buffer_rsrc_t dxr = image(s);
       if (PF) {
-        if (lane < 8) pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * 8 + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0 && lane < NSH)
+          pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        wait_tile(a.ctl, T, (unsigned)(s + 1) * arrivals, lane);
+        seen_wait(it_cur, T, (unsigned)(s + 1) * arrivals);
 #pragma unroll
         for (int q = 0; q < HALF; ++q)
           ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)q * 1024u), 0, AUX_LD));
@@ -528,10 +567,14 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       unsigned bnext = bcur;
       __amdgpu_buffer_rsrc_t dxn = dxr;
       if (PF) {                                          // mid-item: dz of the next item must be complete before its fetch starts
-        unsigned tot = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tot += (unsigned)__builtin_amdgcn_readlane((int)pv, i);
-        if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
+        const int it1l = have1 ? it1 : it_cur;
+        if (w == 0) {
+          const unsigned tot = shard_sum(pv);
+          if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
+          if (lane == 0) __hip_atomic_store(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          lds_wait_ge(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, a.ctl);
+        }
         bnext = blk(T1);
         dxn = image(s1);
         STAMP(1);
@@ -590,7 +633,8 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
-      __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * 8 + (blockIdx.x & 7)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * NSH + ((blockIdx.x * 4 + ew) & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
   };
   struct GateIn { float gi, gj, gf, go, cp, cn, dout; bool live; };
   auto gate_load = [&](int t1, int br) -> GateIn {
@@ -763,6 +807,7 @@ bool persist_geometry(int64_t B, int64_t H, Geometry* geo) {
   if (RB > NT16) RB = NT16;
   if (RB > NT16 / 4) RB = NT16 / 4;                      // >= 4 tiles per workgroup when the batch allows: four independent chains
   if (RB < 1) RB = 1;                                    // hide the exchange latency (publish -> visible -> fetched ~ 2 item times)
+  if ((NT16 + RB - 1) / RB > MAX_LOCAL_TILES) return false;   // lds_seen: tiles one workgroup may own
   const int nit_min = NT16 / RB;                          // the last row group has floor(NT16 / RB) or one more
   int per = 0;
   if (RB <= 8 && (8 % RB) == 0 && (NU % (8 / RB)) == 0) per = 8 / RB;
@@ -784,7 +829,7 @@ int launch_fwd(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
 }
 
 constexpr int64_t DBG_BYTES = 65536;     // tail of the workspace: s_memtime stamps of the timing variant
-int64_t ctl_bytes(int NT16) { return (int64_t)(CTL_HDR + NT16 * 8 * 32) * 4; }
+int64_t ctl_bytes(int NT16) { return (int64_t)(CTL_HDR + NT16 * NSH * 32) * 4; }
 int64_t ctl_padded(int NT16) { return ((ctl_bytes(NT16) + 255) / 256) * 256; }
 // exchange images (of `width` = H forward, 4H backward) that fit in a workspace
 int images_in(int64_t workspace_bytes, int NT16, int64_t width) {
@@ -886,6 +931,7 @@ bool persist_geometry_bwd(int64_t B, int64_t H, GeometryB* geo) {
   int RB = persist_cu_budget(cus, true) / NUB;
   if (RB > NT16 / 2) RB = NT16 / 2;                      // >= 2 tiles per workgroup when the batch allows: one chain's exchange
   if (RB < 1) RB = 1;                                    // latency hides behind the other chain's matrix work
+  if ((NT16 + RB - 1) / RB > MAX_LOCAL_TILES) return false;
   const int nit_min = NT16 / RB;
   int per = 0;
   if (RB <= 8 && (8 % RB) == 0 && (NUB % (8 / RB)) == 0) per = 8 / RB;
