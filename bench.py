@@ -44,7 +44,8 @@ LSTM_H, LSTM_L = 1024, 2
 PEAK_F32_MATRIX_TFLOPS = 157.3
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by bf16 VARIANT lines
 PEAK_HBM_GBS = 8000.0
-FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad"]
+FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3"]
+X3_PRODUCTS = 6.0                    # bf16 MFMA products per fp32 product in csrc/gemm_x3.hip
 
 
 def parse():
@@ -123,7 +124,7 @@ def lstm_flops(B):
     S = 2 * L * H
     head = 3 * 2.0 * B * S * VOCAB * (2 * MIX + 1)
     rec = 2 * L * 2.0 * F * B * H * 4 * H             # forward + backward recurrent products
-    return {"gemm": proj_fwd + dw + dx + head, "lstm_recurrence": rec}
+    return {"gemm": proj_fwd + dw + dx + head, "lstm_recurrence": rec / 2, "lstm_recurrence_bwd": rec / 2}
 
 
 def moe_flops(B):
@@ -182,32 +183,51 @@ def make_pool(workload, B, dev, rank, n=None):
 def family_times(lib, steps):
     n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
     fam = {}
+    fl = ctypes.c_double(0.0)
     for fid, name in enumerate(FAMILIES):
         lib.yt8m_prof_get(fid, ctypes.byref(n), ctypes.byref(ms))
+        lib.yt8m_prof_get_flops(fid, ctypes.byref(fl))
         if n.value:
             fam[name] = {"launches_per_step": n.value / float(steps), "ms_per_step": ms.value / steps,
                          "avg_launch_ms": ms.value / n.value}
+            if fl.value > 0:
+                fam[name]["declared_flops_per_step"] = fl.value / steps       # counted by the library at launch time
     return fam
 
 
-def roofline_from(fam, flops, bf16, extra_note=None):
-    """Dominant family = the one with the largest hipEvent time among the MFMA families that have an algorithmic FLOP
-    count.  achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch)."""
-    peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
+def family_peak(name, bf16, bwd_cus=None):
+    """(peak TFLOP/s, what it is) of the pipe a family's dominant kernel runs on."""
+    if name == "gemm_x3":
+        return PEAK_BF16_MATRIX_TFLOPS / X3_PRODUCTS, ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d products per fp32 product "
+                                                       "(v_mfma_f32_32x32x16_bf16 on three-plane split operands)" % (PEAK_BF16_MATRIX_TFLOPS, X3_PRODUCTS))
+    if name == "lstm_recurrence_bwd" and bwd_cus:
+        return PEAK_F32_MATRIX_TFLOPS * bwd_cus / 256.0, ("fp32 MFMA peak of the %d CUs the backward recurrence is launched on (the rest of "
+                                                          "the chip runs the weight-gradient GEMMs beside it)" % bwd_cus)
+    if bf16 and name == "gemm":
+        return PEAK_BF16_MATRIX_TFLOPS, "dense bf16 MFMA peak"
+    return PEAK_F32_MATRIX_TFLOPS, "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"
+
+
+def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None):
+    """Dominant family = the one with the largest hipEvent time among the MFMA families that have an algorithmic FLOP count
+    (declared by the library at launch time for the GEMM and recurrence entry points, else the workload's formula).
+    achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch)."""
     rows = {}
-    for name, f in flops.items():
-        if name in fam and fam[name]["ms_per_step"] > 0:
-            ach = f / (fam[name]["ms_per_step"] * 1e-3) / 1e12
-            rows[name] = {"achieved": ach, "frac": ach / peak, "ms_per_step": fam[name]["ms_per_step"],
-                          "launches_per_step": fam[name]["launches_per_step"], "avg_launch_ms": fam[name]["avg_launch_ms"],
+    for name, v in fam.items():
+        f = v.get("declared_flops_per_step") or flops.get(name)
+        if f and v["ms_per_step"] > 0:
+            peak, what = family_peak(name, bf16, bwd_cus)
+            ach = f / (v["ms_per_step"] * 1e-3) / 1e12
+            rows[name] = {"achieved": ach, "peak": peak, "peak_is": what, "frac": ach / peak, "ms_per_step": v["ms_per_step"],
+                          "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
                           "algorithmic_flops_per_step": f,
-                          "algorithmic_flops_per_launch": f / max(fam[name]["launches_per_step"], 1e-9)}
+                          "algorithmic_flops_per_launch": f / max(v["launches_per_step"], 1e-9)}
     if not rows:
         return None
     dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
     r = rows[dom]
-    roof = {"bound": "mfma", "kernel": dom + (" (bf16 operands)" if bf16 else " (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact fp32)"),
-            "achieved": r["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": r["frac"], "traffic": None,
+    roof = {"bound": "mfma", "kernel": dom, "achieved": r["achieved"], "peak": r["peak"], "peak_is": r["peak_is"], "unit": "TFLOP/s",
+            "frac": r["frac"], "traffic": None,
             "launches_per_step": r["launches_per_step"], "avg_launch_ms": r["avg_launch_ms"],
             "algorithmic_flops_per_launch": r["algorithmic_flops_per_launch"],
             "families": rows,
@@ -473,7 +493,10 @@ def main():
     if not a.no_roofline:
         fam = profile_pass(lib, run, min(a.steps, 5 if a.workload != "moe" else 20), rank)
         if rank == 0:
-            roof = roofline_from(fam, cfg["flops"](B), bf16)
+            bwd_cus = None
+            if a.workload == "lstm" and lib.yt8m_lstm_persist_bwd_supported(B, LSTM_H):
+                bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
+            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus)
             if a.workload == "moe" and B == 1024 and not bf16 and roof:
                 try:                   # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_traffic.md)
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
@@ -486,7 +509,7 @@ def main():
             elif a.workload == "lstm" and roof:
                 try:                   # PMC passes of the headline step, committed with the round's profiles
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_lstm.json")))
-                    key = "gemm" if roof["kernel"].startswith("gemm") else "lstm_recurrence"
+                    key = roof["kernel"]
                     roof["traffic"] = pm["families"][key]["hbm_bytes_per_launch"]
                     roof["traffic_unit"] = pm["unit"]
                     roof["traffic_kernel"] = pm["families"][key]["kernel"]
@@ -498,7 +521,9 @@ def main():
                 # are hipEvent durations of launches that share the chip across streams, so they overlap and add up to more)
                 tot = sum(cfg["flops"](B).values())
                 roof["step_level"] = {"algorithmic_flops_per_step": tot, "achieved": tot / (el / a.steps) / 1e12,
-                                      "frac": tot / (el / a.steps) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS)}
+                                      "frac": tot / (el / a.steps) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS),
+                                      "frac_is": "all algorithmic FLOPs of the step over wall time, against the dense %s MFMA peak"
+                                                 % ("bf16" if bf16 else "fp32")}
     del tg, g, pool
     torch.cuda.empty_cache()
 

@@ -31,6 +31,10 @@ int yt8m_prof_enable(int on);
 int yt8m_prof_reset(void);
 /* synchronises the device; returns launches and total ms for a family */
 int yt8m_prof_get(int family, int64_t* launches, double* total_ms);
+/* algorithmic FLOPs the launches of a family declared while the profiler was on (GEMM: 2 M N K per problem; recurrence:
+ * 2 T B H 4H per launch); families: 0 gemm (fp32 MFMA), 1 moe_fused, 2 elementwise, 3 optimizer, 4 lstm_recurrence (forward),
+ * 5 netvlad, 6 lstm_recurrence_bwd, 7 gemm_x3 (fp32 products on the bf16 pipe) */
+int yt8m_prof_get_flops(int family, double* flops);
 
 /* hardware probes (measured ceilings of THIS box, printed next to the roofline numbers):
  * mfma: register-only v_mfma_f32_32x32x2_f32 loop; FLOPs = blocks*4*iters*32*4096.  copy: float4 stream, n%4==0. */

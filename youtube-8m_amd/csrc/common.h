@@ -34,14 +34,16 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
   } while (0)
 
 // ---- per-family hipEvent profiling (bench.py roofline leg) -----------------------------------
-enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LSTM = 4, F_NETVLAD = 5, F_COUNT = 6 };
+enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LSTM = 4, F_NETVLAD = 5, F_LSTM_BWD = 6, F_GEMM_X3 = 7,
+              F_COUNT = 8 };
 
 struct ProfScope {
   int fam;
   hipStream_t s;
   bool on;
   hipEvent_t e0, e1;
-  ProfScope(int family, hipStream_t stream);
+  double flops;           // algorithmic FLOPs of the launches inside the scope (0: not counted)
+  ProfScope(int family, hipStream_t stream, double algorithmic_flops = 0.0);
   ~ProfScope();
 };
 

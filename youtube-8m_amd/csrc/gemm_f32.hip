@@ -709,7 +709,7 @@ static int gemm_launch(int transA, int transB, int64_t M, int64_t N, int64_t K, 
   const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n;
   YT8M_REQUIRE(nwg < (1LL << 31), YT8M_E_SHAPE, "grid too large");
   hipStream_t s = as_stream(stream);
-  ProfScope prof(F_GEMM, s);
+  ProfScope prof(F_GEMM, s, 2.0 * (double)M * (double)N * (double)K * (double)batch);
   launch_by_layout<GemmArgs>(transA, transB, gemm_f32_kernel<true, false>, gemm_f32_kernel<false, false>,
                              gemm_f32_kernel<true, true>, gemm_f32_kernel<false, true>,
                              dim3((unsigned)nwg, (unsigned)batch), s, g);
@@ -786,7 +786,9 @@ static int grouped_launch(int transA, int transB, int bf16, int nprob, const yt8
     G.S = S;
   }
   hipStream_t s = as_stream(stream);
-  ProfScope prof(F_GEMM, s);
+  double fl = 0.0;
+  for (int i = 0; i < G.nprob; ++i) fl += 2.0 * (double)G.p[i].M * (double)G.p[i].N * (double)G.p[i].K;
+  ProfScope prof(F_GEMM, s, fl);
   const int64_t grid = (int64_t)G.full_rounds * G.P + (int64_t)G.rem * G.S;
   int kmax = 0;
   for (int i = 0; i < G.nprob; ++i) kmax = std::max(kmax, G.p[i].K);
@@ -823,7 +825,9 @@ extern "C" int yt8m_gemm_bf16_nt_grouped(int nprob, const yt8m_gemm_problem* pro
              (q.beta == 0.f || q.beta == 1.f);
   }
   if (simple && gemm_bf16_big_ok(nprob, probs)) {
-    ProfScope prof(F_GEMM, as_stream(stream));
+    double fl = 0.0;
+    for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
+    ProfScope prof(F_GEMM, as_stream(stream), fl);
     return gemm_bf16_big_launch(nprob, probs, workspace, workspace_bytes, as_stream(stream));
   }
   return grouped_launch(0, 1, 1, nprob, probs, workspace, workspace_bytes, stream);

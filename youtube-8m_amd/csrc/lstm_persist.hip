@@ -892,7 +892,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   const unsigned grid = (unsigned)(geo.NU * geo.RB);
   int dev = 0;
   device_cus(&dev);
-  ProfScope prof(F_LSTM, s);
+  ProfScope prof(F_LSTM, s, 2.0 * (double)T * (double)B * (double)H * 4.0 * (double)H);
   std::lock_guard<std::mutex> lk(g_gate.mu);
   const int total_cus = device_cus(nullptr);
   int grc = g_gate.admit(dev, (int)grid, total_cus, s);
@@ -983,7 +983,7 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   const unsigned grid = (unsigned)(geo.NUB * geo.RB);
   int dev = 0;
   device_cus(&dev);
-  ProfScope prof(F_LSTM, s);
+  ProfScope prof(F_LSTM_BWD, s, 2.0 * (double)T * (double)B * (double)H * 4.0 * (double)H);
   std::lock_guard<std::mutex> lk(g_gate.mu);
   const int total_cus = device_cus(nullptr);
   int grc = g_gate.admit(dev, (int)grid, total_cus, s);
