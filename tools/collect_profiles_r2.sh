@@ -17,6 +17,8 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/moe -o mo
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/netvlad -o nv -- python $R/bench.py --workload netvlad --steps 20 --warmup 3 --no-cpu-baseline --no-gap --no-extra < /dev/null > $O/netvlad_line.json 2>/dev/null
 # 5. un-profiled micro-benches
 timeout 200 python $R/tools/persist_check.py time < /dev/null > $O/persist_check.txt 2>&1
+timeout 200 python $R/tools/x3_check.py time < /dev/null > $O/x3_check.txt 2>&1
+timeout 100 python $R/tools/probe_mfma.py < /dev/null > $O/probe_mfma.txt 2>&1
 timeout 100 python $R/tools/gemm_shapes.py lstm < /dev/null > $O/gemm_shapes_lstm.txt 2>&1
 timeout 400 python $R/tools/model_bench.py < /dev/null > $O/model_bench.txt 2>&1
 find $O -name "*.csv" | head -40

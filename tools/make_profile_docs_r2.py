@@ -35,7 +35,8 @@ def main():
     shutil.copy(os.path.join(O, "moe", "moe_kernel_stats.csv"), os.path.join(P, "r2_moe_kernel_stats.csv"))
     shutil.copy(os.path.join(O, "netvlad", "nv_kernel_stats.csv"), os.path.join(P, "r2_netvlad_kernel_stats.csv"))
     for f, t in (("bench_line.json", "r2_bench_line.json"), ("persist_check.txt", "r2_persist_check.txt"),
-                 ("gemm_shapes_lstm.txt", "r2_gemm_shapes_lstm.txt"), ("model_bench.txt", "r2_plugin_step_times.txt")):
+                 ("gemm_shapes_lstm.txt", "r2_gemm_shapes_lstm.txt"), ("model_bench.txt", "r2_plugin_step_times.txt"),
+                 ("x3_check.txt", "r2_x3_check.txt"), ("probe_mfma.txt", "r2_probe_mfma.txt")):
         shutil.copy(os.path.join(O, f), os.path.join(P, t))
     import pmc_summary
     sys.argv = ["pmc_summary", os.path.join(O, "pmc", "fetch_counter_collection.csv"), os.path.join(O, "pmc", "write_counter_collection.csv")]
@@ -52,19 +53,37 @@ def main():
 
     T = F // 2                                     # steps per chunk at lstm_pipeline_chunks = 2
     fam = {}
-    # dominant GEMM instantiation of the headline step: the weight-gradient products x^T dz / h^T dz (one launch per layer, chunk
-    # and operand; K = T * B rows per launch)
-    g = "gemm_grouped_kernel<false, false, false, false>"
-    alg = 4.0 * (T * B * ((D + H) / 2.0) + T * B * 4 * H + ((D + H) / 2.0) * 4 * H)
-    fam["gemm"] = {"kernel": g, "hbm_bytes_per_launch": tot(g), "algorithmic_bytes_per_launch": alg}
-    f = "lstm_persist_fwd_kernel<8, 1>"
+
+    def pick(prefix):
+        ks = [n for n in k if n.startswith(prefix)]
+        return max(ks, key=lambda n: k[n]["launches"]) if ks else None
+
+    # x3 GEMMs of the headline step (per step: 2 projections of layer 1, 2 dx, 2 + 2 grouped weight-gradient launches, 1 head
+    # product); operands are x3 images (6 B / element), C is fp32
+    def x3_bytes(M, N, K):
+        return 6.0 * (M * K + N * K) + 4.0 * M * N
+
+    shapes = [(T * B, 4 * H, H)] * 2 + [(T * B, H, 4 * H)] * 2 + [(H, 4 * H, T * B), (H, 4 * H, T * B)] * 2 + \
+             [(D, 4 * H, T * B), (H, 4 * H, T * B)] * 2
+    launches = 2 + 2 + 2 + 2
+    g = pick("gemm_x3_kernel<3>")
+    if g:
+        fam["gemm_x3"] = {"kernel": g, "hbm_bytes_per_launch": tot(g),
+                          "algorithmic_bytes_per_launch": sum(x3_bytes(*sh) for sh in shapes) / launches,
+                          "note": "average over the step's x3 launches (projection, dx and grouped weight-gradient products)"}
+    f = pick("lstm_persist_fwd_kernel")
     algf = float(T * (B * 4 * H * 4 * 2 + 3 * B * H * 4))
-    note = ("algorithmic = the saved activations only (z in, gates / c / h / out written); the state exchange (64 MB per step forward, "
-            "256 MB backward at 128 CUs, of coherent loads) is served from the XCD L2s / Infinity Cache and mostly stays below the "
-            "memory-side counters")
-    fam["lstm_recurrence"] = {"kernel": f, "hbm_bytes_per_launch": tot(f), "algorithmic_bytes_per_launch": algf, "note": note}
-    b = "lstm_persist_bwd_kernel<32, true>"
-    fam["lstm_recurrence_bwd"] = {"kernel": b, "hbm_bytes_per_launch": tot(b), "algorithmic_bytes_per_launch": algf}
+    note = ("algorithmic = the saved activations only (z in, gates / c / h / out written); the state exchange (one 512 KB image per "
+            "step forward, 2 MB backward) is written through once and fetched once per XCD into its L2")
+    if f:
+        fam["lstm_recurrence"] = {"kernel": f, "hbm_bytes_per_launch": tot(f), "algorithmic_bytes_per_launch": algf, "note": note}
+    bk = pick("lstm_persist_bwd_kernel")
+    if bk:
+        fam["lstm_recurrence_bwd"] = {"kernel": bk, "hbm_bytes_per_launch": tot(bk), "algorithmic_bytes_per_launch": algf}
+    g32 = pick("gemm_grouped_kernel")
+    if g32:
+        fam["gemm"] = {"kernel": g32, "hbm_bytes_per_launch": tot(g32), "algorithmic_bytes_per_launch": None,
+                       "note": "the MoE head products at B = 128 (fp32 MFMA kernel)"}
     out = {"unit": "bytes/launch (memory-side; PMC FETCH_SIZE x %.3f + WRITE_SIZE x %.3f, separate passes, calibrated on the 256 MiB "
                    "copy probe of the same run as MI355X_MICROARCH.md prescribes)" % (pm["fetch_factor"], pm["write_factor"]),
            "fetch_factor": pm["fetch_factor"], "write_factor": pm["write_factor"], "families": fam, "kernels": pm["kernels"]}
@@ -80,8 +99,10 @@ def main():
     if sl:
         md.append("* whole-step matrix utilisation: %.1f TFLOP/s = %.2f of the fp32 MFMA peak (all algorithmic FLOPs of the step over "
                   "wall time)." % (sl["achieved"], sl["frac"]))
-    md += ["* Launches of different streams share the chip (the half-chip backward recurrence runs beside the weight-gradient GEMMs), so "
-           "the per-kernel durations below overlap: they add up to more than the step.", "",
+    md += ["* Launches of different streams share the chip (two half-chip backward recurrences run side by side, the weight-gradient "
+           "GEMMs take the CUs they leave), so the per-kernel durations below overlap and include time spent waiting for CUs: they add "
+           "up to more than the step.  Stand-alone rates: `profiles/r2_x3_check.txt` (GEMMs), `profiles/r2_persist_check.txt` "
+           "(recurrences), `profiles/r2_probe_mfma.txt` (matrix-pipe ceilings of this box).", "",
            stats_table(os.path.join(O, "bench", "bench_kernel_stats.csv"), steps), "",
            "Full table: `profiles/r2_bench_kernel_stats.csv`.  PMC traffic: `profiles/r2_pmc_traffic_lstm.json`.", "",
            "## Extra lines under the tracer", "",
