@@ -38,7 +38,7 @@ def test_algorithmic_work_matches_baseline_md():
     proj_fwd = 2.0 * F * (D * 4 * H + H * 4 * H)
     rec_fwd = 2.0 * F * L * H * 4 * H
     assert proj_fwd + rec_fwd == fwd_lstm
-    assert f["lstm_recurrence"] == 2 * rec_fwd                      # forward + backward recurrent products
+    assert f["lstm_recurrence"] == rec_fwd and f["lstm_recurrence_bwd"] == rec_fwd   # forward / backward recurrent products
     head = 3 * 2.0 * (2 * L * H) * V * (2 * M + 1)
     assert 2.0 * 4096 * V * (2 * M + 1) == 193167360.0
     assert f["gemm"] == proj_fwd + (fwd_lstm) + 2.0 * F * 4 * H * H + head      # projections + dW (= forward FLOPs) + dx1 + head
