@@ -267,6 +267,20 @@ import os as _os
 PERSIST = _os.environ.get("YT8M_LSTM_PERSIST", "1") != "0"        # persistent recurrence kernels (csrc/lstm_persist.hip)
 U8_BETA = 128.0 * 4.0 / 255.0 + (4.0 / 512.0 - 2.0)     # dequantise(q) = (4/255) (q - 128) + U8_BETA
 BWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_BWD_CHUNKS", "0"))    # 0: same partition as the forward pass
+# explicit backward partition as fractions of F in forward-time order, e.g. "1,2,3" -> chunks of F/6, F/3, F/2 (the backward pass
+# runs them last to first: a long first launch, a short last one whose weight-gradient tail is short)
+BWD_PARTS = [float(v) for v in _os.environ.get("YT8M_LSTM_BWD_PARTS", "").split(",") if v]
+
+
+def _bwd_parts(F, fwd_parts):
+    if BWD_PARTS:
+        tot, edges, acc = sum(BWD_PARTS), [0], 0.0
+        for v in BWD_PARTS:
+            acc += v
+            edges.append(min(F, int(round(F * acc / tot))))
+        edges[-1] = F
+        return [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+    return _chunks(F, BWD_CHUNKS) if BWD_CHUNKS > 0 else fwd_parts
 PERSIST_DBROWS = False
 REC_STREAM_PRIORITY = int(_os.environ.get("YT8M_REC_STREAM_PRIORITY", "-1"))
 PERSIST_STEP_IMAGES = _os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0"
@@ -375,7 +389,7 @@ class _LstmStack(torch.autograd.Function):
             pws = lib.yt8m_lstm_persist_workspace_bytes(B, H) if PERSIST else 0
             if pws and PERSIST_STEP_IMAGES:
                 # one exchange image per step of the longest launch (forward or backward partition): XCD-L2-shared state fetch
-                tmax = max([T for _, T in parts] + ([T for _, T in _chunks(F, BWD_CHUNKS)] if BWD_CHUNKS > 0 else []))
+                tmax = max([T for _, T in parts] + [T for _, T in _bwd_parts(F, parts)])
                 big = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, tmax)
                 if big <= PERSIST_STEP_IMAGES_MAX_BYTES:
                     pws = big
@@ -475,7 +489,7 @@ class _LstmStack(torch.autograd.Function):
             main.wait_event(r_done[l][-1])
         # the backward pass may cut time differently (all buffers are whole-layer): its first recurrence chunk runs with nothing
         # beside it, so shorter chunks shorten that pipeline fill; the forward recurrence owns the chip and wants few launches
-        ctx.layers, ctx.nf, ctx.parts = layers, nf, (_chunks(F, BWD_CHUNKS) if BWD_CHUNKS > 0 else parts)
+        ctx.layers, ctx.nf, ctx.parts = layers, nf, _bwd_parts(F, parts)
         ctx.drop = (float(input_keep_prob), tuple(int(v) for v in seeds)) if drop else None
         ctx.set_materialize_grads(False)
         outs = [layers[-1]["out"]]
