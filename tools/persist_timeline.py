@@ -50,15 +50,18 @@ for it in range(2):
 dbg = pws[nb - 65536:].view(torch.int64).cpu().numpy()[:4096].reshape(2, 256, 8)
 for wsel, wname, names in ((0, "matrix wave 0", ["start", "polled + next loads issued", "mfma done", "partials written"]),
                            (1, "epilogue wave 8 (every 4th item)", ["start (operand loads issued)", "partials arrived", "reduced",
-                                                                    "stores issued", "drained"])):
+                                                                    "stores issued", "drained"] + ([] if BWD else ["gate math done"]))):
     d = dbg[wsel]
     ks = np.arange(40, 104) if (wsel == 0 or BWD) else np.arange(40, 104, 4)
     print(wname, "-- cycles (mean / min / max)")
     period = np.diff(d[ks, 0])
     print("  %-34s %8.0f %8.0f %8.0f" % ("period", period.mean(), period.min(), period.max()))
-    for i in range(len(names) - 1):
+    for i in range(min(len(names), 5) - 1):
         seg = d[ks, i + 1] - d[ks, i]
         print("  %-34s %8.0f %8.0f %8.0f" % (names[i] + " -> " + names[i + 1][:12], seg.mean(), seg.min(), seg.max()))
+    if len(names) > 5:
+        seg = d[ks, 5] - d[ks, 2]
+        print("  %-34s %8.0f %8.0f %8.0f" % ("reduced -> gate math done", seg.mean(), seg.min(), seg.max()))
 m, e = dbg[0], dbg[1]
 ks = np.arange(40, 104) if BWD else np.arange(40, 104, 4)
 lag = e[ks, 4] - m[ks, 3]

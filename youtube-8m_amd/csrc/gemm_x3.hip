@@ -59,7 +59,7 @@ struct XArgs {
 struct XGroup {
   XArgs p[4];
   int full_base[5];     // unsplit tiles, cumulative: workgroups [0, full_base[4]) in XCD-contiguous order
-  int part_base[5];     // K-part items, cumulative: the workgroups behind them, in launch order (round-robin over the XCDs)
+  int part_base[5];     // K-part items, cumulative: the workgroups behind them, XCD-contiguous among themselves
   int slot_base[4];
   int fix_base[5];      // split tiles, cumulative (grid of the fixup pass)
   int full[4], rem[4], S[4];
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
       if (i < G.nprob && item >= G.full_base[i]) q = i;
     lt = item - G.full_base[q];
   } else {
-    const int item = blockIdx.x - G.full_base[4];
+    // the K-part items are all equally long: each XCD takes a contiguous run of them too (32 neighbouring tiles of one K range
+    // share 4 + 8 operand panels in that XCD's L2)
+    const int item = xcd_remap(blockIdx.x - G.full_base[4], G.part_base[4]);
 #pragma unroll
     for (int i = 1; i < 4; ++i)
       if (i < G.nprob && item >= G.part_base[i]) q = i;

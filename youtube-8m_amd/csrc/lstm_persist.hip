@@ -202,7 +202,14 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   int ug, g;
   {
     const int b = blockIdx.x;
-    if (a.per > 0) { const int x = b & 7; g = x / a.per; ug = (b >> 3) * a.per + (x % a.per); }   // row group <-> XCD set (speed only)
+    // row group <-> XCD set (speed only).  Within a row group the unit groups of an XCD come in runs of four: a unit group's z / c /
+    // h accesses are 32-byte pieces of 128-byte lines, and the four workgroups that share a line then share an L2 (with unit
+    // groups dealt round-robin over the XCDs every XCD fetched every line for a quarter of it: 3.4x the algorithmic HBM bytes).
+    if (a.per > 0 && (a.NU % (4 * a.per)) == 0) {
+      const int x = b & 7, sl = b >> 3;
+      g = x / a.per;
+      ug = ((sl >> 2) * a.per + (x % a.per)) * 4 + (sl & 3);
+    } else if (a.per > 0) { const int x = b & 7; g = x / a.per; ug = (b >> 3) * a.per + (x % a.per); }
     else { g = b / a.NU; ug = b % a.NU; }
   }
   const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
@@ -397,6 +404,10 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
         hn[j] = live[j] ? h1 : hpre[j];
         if (!evalid[j]) hn[j] = 0.f;                     // rows >= B publish zeros
       }
+#ifdef YT8M_PERSIST_TIMING
+      asm volatile("" ::"v"(hn[0]), "v"(hn[1]), "v"(cn[0]), "v"(cn[1]));   // the stamp below must not move above the gate math
+#endif
+      STAMP(5);
       if (s + 1 < a.T) {                                 // publish h_t of this tile first: it is what the other workgroups wait for
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -478,7 +489,12 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   int ub, g;
   {
     const int b = blockIdx.x;
-    if (a.per > 0) { const int x = b & 7; g = x / a.per; ub = (b >> 3) * a.per + (x % a.per); }
+    // as in the forward kernel: the two 16-unit groups that share a 128-byte line of gates / cs / dz sit on one XCD
+    if (a.per > 0 && (a.NUB % (2 * a.per)) == 0) {
+      const int x = b & 7, sl = b >> 3;
+      g = x / a.per;
+      ub = ((sl >> 1) * a.per + (x % a.per)) * 2 + (sl & 1);
+    } else if (a.per > 0) { const int x = b & 7; g = x / a.per; ub = (b >> 3) * a.per + (x % a.per); }
     else { g = b / a.NUB; ub = b % a.NUB; }
   }
   const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
