@@ -44,6 +44,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef YT8M_AUX_ST
 #define YT8M_AUX_ST 17
 #endif
+#ifndef YT8M_EPI_PRIO
+#define YT8M_EPI_PRIO 3
+#endif
 #ifndef YT8M_AUX_LD
 #define YT8M_AUX_LD 17
 #endif
@@ -143,12 +146,17 @@ __global__ __launch_bounds__(256) void hx_pack_kernel(const float* __restrict__ 
 // the per-step kernels -- the epilogue is a single wave's dependent chain on the critical path of the state exchange, and the
 // exact forms cost ~10x the instructions.  Absolute error <= ~1.5e-7 per value (checked against the exact kernels and the fp64
 // oracle by the parity tests; north_star tolerance 1e-3).
+#ifdef YT8M_EPI_FAKE   // timing experiment only (wrong results): how much of the chain is the gate math?
+__device__ __forceinline__ float fast_sigmoid(float x) { return 0.5f + 0.01f * x; }
+__device__ __forceinline__ float fast_tanh(float x) { return 0.01f * x; }
+#else
 __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
+#endif
 
 // value of lane + N within a row of 16 lanes (DPP row_shl: one VALU op; __shfl_down is a ds_bpermute round trip through LDS)
 template <int N>
@@ -303,6 +311,11 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
         float4 b0, b1;
         if (qg < HQ) { b0 = Wr[qg < HQ ? qg : 0][0]; b1 = Wr[qg < HQ ? qg : 0][1]; }
         else { b0 = Wl[w][qg - HQ][0][lane]; b1 = Wl[w][qg - HQ][1][lane]; }
+#ifdef YT8M_MFMA_CUT   // timing experiment only (wrong results): 3 of 8 MFMAs, the matrix time of six bf16 products
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z + av.w, b0.z + b1.w, acc0, 0, 0, 0);
+#else
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
+#endif
       }
       STAMP(2);
       const int slot = k & (NSLOT - 1);
@@ -343,9 +357,6 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   // are its own stores of step s (same wave: program order), never another wave's.
   const int ew = w - 8;
   const int eunit = lane & 7;
-#ifndef YT8M_EPI_PRIO
-#define YT8M_EPI_PRIO 3
-#endif
   __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);             // the epilogue is the latency-critical chain: win VALU issue arbitration
   for (int s = 0; s < a.T; ++s) {
     const int t = a.t0 + s;
@@ -427,6 +438,301 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
         STAMP(4);
       }
       // everything the backward pass / the caller needs, in the standard layouts (nobody inside this launch waits for these)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (evalid[j]) {
+          const int brow = T * 16 + 8 * j + (lane >> 3);
+          const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
+          if (live[j]) {
+            float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
+            zr[0] = gi[j]; zr[H] = gj[j]; zr[2 * H] = gf[j]; zr[3 * H] = go[j];
+          }
+          a.cs[idx1] = cn[j];
+          a.hs[idx1] = hn[j];
+          if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live[j] ? hn[j] : 0.f;
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// Forward recurrence with the recurrent product on the bf16 pipe (the x3 scheme of gemm_x3.hip): h_t and W_h are split exactly
+// into three bf16 planes and h . W_h accumulates, in fp32, the six partial products of weight >= 2^-16 -- fp32-grade results at
+// 3/8 of the fp32-MFMA matrix time (v_mfma_f32_16x16x32_bf16: 48 MFMAs of 16 cycles per item and wave instead of 64 of 32).  The
+// fp32 kernel above is matrix-bound for 64 % of a step and its epilogue shares the SIMDs with those MFMAs; with the matrix time of
+// this kernel (timing experiment on the fp32 kernel with 3 of 8 MFMAs) a step takes 7.1 us instead of 10.3.
+//   * the producer splits: an epilogue lane splits its h value and the eight units of a (row, workgroup) are gathered with DPP
+//     into ONE 16-byte store per plane (an MFMA A fragment of the 32-wide K block the workgroup's units belong to); the exchange
+//     image per step is [tile][H / 32][plane][4 k-groups x 16 rows][8 bf16] = 1 KiB blocks, 1.5x the fp32 image.
+//   * the [H x 32] slice of W_h is split once per launch: 24 B fragments per wave (H = 1024), 10 in registers, 14 in LDS.
+//   * A fragments travel in half items (three half buffers in rotation): the state of item k + 1 is requested in the middle of
+//     item k, its second half into the registers the first half of item k has just left.  Two partial-tile slots (LDS: 112 KB of
+//     weights + 32 KB of partial tiles).
+// Needs one exchange image per step (plain L2-shared fetch), >= 2 tiles per workgroup and H in {512, 1024}; otherwise the fp32
+// kernel runs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {        // round to nearest even, finite x
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3_bits(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = bf16_rn_bits(x);
+  const float r1 = x - __uint_as_float(h1 << 16);                   // exact
+  h2 = bf16_rn_bits(r1);
+  h3 = bf16_rn_bits(r1 - __uint_as_float(h2 << 16));
+}
+template <int N>
+__device__ __forceinline__ unsigned row_shl_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
+}
+
+// image 0 of a launch <- h_{t0-1} (standard layout), split into the three planes
+__global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict__ h, u32x4* __restrict__ img, int B, int H, int NT16) {
+  const int KBH = H >> 5;
+  const long long n = (long long)NT16 * KBH * 3 * 64;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int l = (int)(e & 63), p = (int)((e >> 6) % 3);
+    const long long blk = e / 192;
+    const int kbg = (int)(blk % KBH), T = (int)(blk / KBH);
+    const int row = T * 16 + (l & 15), k0 = kbg * 32 + (l >> 4) * 8;
+    unsigned hb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned h1, h2, h3;
+      split3_bits(row < B ? h[(long long)row * H + k0 + j] : 0.f, h1, h2, h3);
+      hb[j] = p == 0 ? h1 : (p == 1 ? h2 : h3);
+    }
+    u32x4 v;
+    v.x = hb[0] | (hb[1] << 16); v.y = hb[2] | (hb[3] << 16); v.z = hb[4] | (hb[5] << 16); v.w = hb[6] | (hb[7] << 16);
+    img[e] = v;
+  }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs a) {
+  constexpr int NS = 2;                                  // partial-tile slots
+  constexpr int NF = NKB * 6;                            // B fragments of a wave: [K block][column half][plane]
+  constexpr int NREG = NF < 10 ? NF : 10, NLDS = NF - NREG;
+  constexpr int HK = NKB / 2;                            // K blocks per half item
+  static_assert(NKB % 2 == 0, "half items");
+  __shared__ __attribute__((aligned(16))) float red[NS][8][2][4][64];                 // 32 KB
+  __shared__ __attribute__((aligned(16))) u32x4 Wl[8][NLDS > 0 ? NLDS : 1][64];       // 112 KB at H = 1024
+  __shared__ unsigned lds_cnt[NS], lds_free[NS];
+  __shared__ unsigned lds_seen[MAX_LOCAL_TILES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int ug, g;
+  {
+    const int b = blockIdx.x;                            // same placement as lstm_persist_fwd_kernel
+    if (a.per > 0 && (a.NU % (4 * a.per)) == 0) {
+      const int x = b & 7, sl = b >> 3;
+      g = x / a.per;
+      ug = ((sl >> 2) * a.per + (x % a.per)) * 4 + (sl & 3);
+    } else if (a.per > 0) { const int x = b & 7; g = x / a.per; ug = (b >> 3) * a.per + (x % a.per); }
+    else { g = b / a.NU; ug = b % a.NU; }
+  }
+  const int H = a.H, B = a.B, NT16 = a.NT16, RB = a.RB;
+  const int n_it = (NT16 - g + RB - 1) / RB;
+  const int total = n_it * a.T;
+  const int KBH = H >> 5;                                // 32-wide K blocks per row
+  const long long img_f = (long long)NT16 * KBH * 3 * 256;
+  const unsigned img_bytes = (unsigned)(img_f * 4);
+  auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.hx + s * img_f, img_bytes); };
+  const unsigned arrivals = (unsigned)a.NU;
+  // B fragment of v_mfma_f32_16x16x32_bf16: lane (n = lane & 15, kg = lane >> 4) supplies B[k = 8 kg + j][n], j = 0..7.
+  // Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4), as in the fp32 kernel.
+  auto w_frag = [&](int kb, int ct, int p) -> u32x4 {
+    const int n16 = lane & 15, kg = lane >> 4;
+    const long long k = (long long)(w * NKB + kb) * 32 + kg * 8;
+    const long long col = (long long)(n16 & 3) * H + ug * 8 + ct * 4 + (n16 >> 2);
+    const float* q = a.Wh + k * a.ldw + col;
+    unsigned hb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned h1, h2, h3;
+      split3_bits(q[j * a.ldw], h1, h2, h3);
+      hb[j] = p == 0 ? h1 : (p == 1 ? h2 : h3);
+    }
+    u32x4 v;
+    v.x = hb[0] | (hb[1] << 16); v.y = hb[2] | (hb[3] << 16); v.z = hb[4] | (hb[5] << 16); v.w = hb[6] | (hb[7] << 16);
+    return v;
+  };
+  if (tid < NS) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
+  for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
+  if (w < 8) {
+#pragma unroll
+    for (int f = NREG; f < NF; ++f) Wl[w][f - NREG][lane] = w_frag(f / 6, (f / 3) & 1, f % 3);
+  }
+  __syncthreads();
+
+  if (w < 8) {
+    // =============================== matrix waves ===============================
+    u32x4 Wr[NREG];
+#pragma unroll
+    for (int f = 0; f < NREG; ++f) Wr[f] = w_frag(f / 6, (f / 3) & 1, f % 3);
+    const unsigned lane_off = (unsigned)lane * 16u + (unsigned)(w * NKB) * 3072u;
+    // half `half` (K blocks half * HK ..) of the A fragments of item (s, T): plain loads, one 1 KiB block per K block and plane
+    auto load_half = [&](u32x4 (&Hh)[HK][3], int s, int T, int half) {
+      const __amdgpu_buffer_rsrc_t hxr = image(s);
+      const unsigned base = (unsigned)(T * KBH) * 3072u + lane_off + (unsigned)(half * HK) * 3072u;
+#pragma unroll
+      for (int kbl = 0; kbl < HK; ++kbl)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          Hh[kbl][p] = __builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)(kbl * 3 + p) * 1024u), 0, 0);
+    };
+    u32x4 H0[HK][3], H1[HK][3], H2[HK][3];
+    load_half(H0, 0, g, 0);                              // item 0 reads the packed initial state: nothing to wait for
+    load_half(H1, 0, g, 1);
+    int s_cur = 0, it_cur = 0;
+    // Ha / Hb: the halves of this item; the state of the next item goes to Hc (first half) and Ha (second half)
+    auto item = [&](u32x4 (&Ha)[HK][3], u32x4 (&Hb)[HK][3], u32x4 (&Hc)[HK][3], int k) {
+      const int s = s_cur, T = g + it_cur * RB;
+      STAMP(0);
+      int sr = s, itr = it_cur + 1;
+      if (itr >= n_it) { itr -= n_it; ++sr; }
+      const bool have = k + 1 < total;
+      const int Tr = have ? g + itr * RB : T;
+      itr = have ? itr : it_cur;
+      sr = have ? sr : s;
+      unsigned pv = 0;                                   // speculative poll: the counter read travels under the first MFMAs
+      if (w == 0 && lane < NSH)
+        pv = __hip_atomic_load(a.ctl + CTL_HDR + (Tr * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb == HK) {                                  // request point: the state of item k + 1 must be complete now
+          if (w == 0) {
+            const unsigned tot = shard_sum(pv);
+            if (tot < (unsigned)sr * arrivals) wait_tile(a.ctl, Tr, (unsigned)sr * arrivals, lane);
+            if (lane == 0) __hip_atomic_store(&lds_seen[itr], (unsigned)sr * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            lds_wait_ge(&lds_seen[itr], (unsigned)sr * arrivals, a.ctl);
+          }
+          load_half(Hc, sr, Tr, 0);
+          load_half(Ha, sr, Tr, 1);                      // the MFMAs that read Ha have been issued
+          STAMP(1);
+        }
+        bf16x8 av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) av[p] = __builtin_bit_cast(bf16x8, kb < HK ? Ha[kb < HK ? kb : 0][p] : Hb[kb >= HK ? kb - HK : 0][p]);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          bf16x8 bv[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const int f = (kb * 2 + ct) * 3 + p;
+            bv[p] = __builtin_bit_cast(bf16x8, f < NREG ? Wr[f < NREG ? f : 0] : Wl[w][f >= NREG ? f - NREG : 0][lane]);
+          }
+          acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][0], 0, 0, 0);
+          acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[1], acc[ct][1], 0, 0, 0);
+          acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[0], acc[ct][0], 0, 0, 0);
+          acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[2], acc[ct][1], 0, 0, 0);
+          acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[1], acc[ct][0], 0, 0, 0);
+          acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], acc[ct][1], 0, 0, 0);
+        }
+      }
+      STAMP(2);
+      const int slot = k & (NS - 1);
+      if (k >= NS) lds_wait_ge(&lds_free[slot], (unsigned)(k / NS), a.ctl);
+      float* rw = &red[slot][w][0][0][lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { rw[r * 64] = acc[0][0][r] + acc[0][1][r]; rw[256 + r * 64] = acc[1][0][r] + acc[1][1][r]; }
+      if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      STAMP(3);
+      if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+    };
+    for (int k = 0; k < total; k += 3) {
+      item(H0, H1, H2, k);
+      if (k + 1 < total) item(H2, H0, H1, k + 1);
+      if (k + 2 < total) item(H1, H2, H0, k + 2);
+    }
+    return;
+  }
+
+  // =============================== epilogue waves (as in lstm_persist_fwd_kernel; the publish splits) ===============================
+  const int ew = w - 8;
+  const int eunit = lane & 7;
+  __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);
+  for (int s = 0; s < a.T; ++s) {
+    const int t = a.t0 + s;
+    for (int it = ew; it < n_it; it += NEPI) {
+      const int k = s * n_it + it;
+      const int T = g + it * RB;
+      STAMP(0);
+      float zpre[2][4], cpre[2], hpre[2];
+      bool live[2], evalid[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int brow = T * 16 + 8 * j + (lane >> 3);
+        evalid[j] = brow < B;
+        const int br = evalid[j] ? brow : B - 1;
+        const float* zr = a.z + ((long long)t * B + br) * 4 * H + ug * 8 + eunit;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) zpre[j][g4] = zr[g4 * H];
+        const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
+        cpre[j] = a.cs[idx];
+        hpre[j] = a.hs[idx];
+        live[j] = a.nf ? (t < a.nf[br]) : true;
+      }
+      const int slot = k & (NS - 1);
+      lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(k / NS + 1), a.ctl);
+      STAMP(1);
+      float4 sum[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int erow = 8 * j + (lane >> 3);
+        const int ct = eunit >> 2, r = erow & 3, l0 = (erow >> 2) * 16 + (eunit & 3) * 4;
+        sum[j] = *reinterpret_cast<const float4*>(&red[slot][0][ct][r][l0]);
+#pragma unroll
+        for (int wv = 1; wv < 8; ++wv) {
+          const float4 p = *reinterpret_cast<const float4*>(&red[slot][wv][ct][r][l0]);
+          sum[j].x += p.x; sum[j].y += p.y; sum[j].z += p.z; sum[j].w += p.w;
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      STAMP(2);
+      float gi[2], gj[2], gf[2], go[2], cn[2], hn[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        gi[j] = fast_sigmoid(zpre[j][0] + sum[j].x);
+        gj[j] = fast_tanh(zpre[j][1] + sum[j].y);
+        gf[j] = fast_sigmoid(zpre[j][2] + sum[j].z + a.fb);
+        go[j] = fast_sigmoid(zpre[j][3] + sum[j].w);
+        const float c1 = cpre[j] * gf[j] + gi[j] * gj[j];
+        const float h1 = fast_tanh(c1) * go[j];
+        cn[j] = live[j] ? c1 : cpre[j];
+        hn[j] = live[j] ? h1 : hpre[j];
+        if (!evalid[j]) hn[j] = 0.f;
+      }
+      if (s + 1 < a.T) {                                 // publish h_t of this tile first, as three bf16 planes
+        const __amdgpu_buffer_rsrc_t hxr = image(s + 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned hb[3];
+          split3_bits(hn[j], hb[0], hb[1], hb[2]);
+          const int erow = 8 * j + (lane >> 3);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            // units 0..7 of this row are lanes l .. l + 7: pairs first, then the four pair words into the lane of unit 0
+            const unsigned d = hb[p] | (row_shl_u<1>(hb[p]) << 16);
+            const unsigned d2 = row_shl_u<2>(d), d4 = row_shl_u<4>(d), d6 = row_shl_u<6>(d);
+            if (eunit == 0) {
+              u32x4 v;
+              v.x = d; v.y = d2; v.z = d4; v.w = d6;
+              const unsigned off = ((unsigned)((T * KBH + (ug >> 2)) * 3 + p) * 256u + (unsigned)(((ug & 3) * 16 + erow) * 4)) * 4u;
+              __builtin_amdgcn_raw_buffer_store_b128(v, hxr, (int)off, 0, YT8M_AUX_ST);
+            }
+          }
+        }
+        STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * NSH + (blockIdx.x & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        STAMP(4);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (evalid[j]) {
@@ -914,14 +1220,29 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   int grc = g_gate.admit(dev, (int)grid, total_cus, s);
   if (grc != YT8M_OK) return grc;
   YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
-  hipLaunchKernelGGL(hx_pack_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, a.hx, (int)B, (int)H, geo.NT16);
-  int rc = launch_status("hx_pack_kernel");
-  if (rc != YT8M_OK) return rc;
-  switch (geo.NQ) {
-    case 2: rc = launch_fwd<2>(a, grid, s); break;
-    case 4: rc = launch_fwd<4>(a, grid, s); break;
-    case 6: rc = launch_fwd<6>(a, grid, s); break;
-    default: rc = launch_fwd<8>(a, grid, s); break;
+  // the recurrent product on the bf16 pipe (lstm_persist_fwd_x3_kernel) when its preconditions hold: an exchange image (1.5x the
+  // fp32 one) per step, >= 2 tiles per workgroup, H in {512, 1024}
+  static const bool x3_off = getenv("YT8M_PERSIST_X3") != nullptr && atoi(getenv("YT8M_PERSIST_X3")) == 0;
+  const bool x3 = !x3_off && (H == 512 || H == 1024) && geo.pf >= 1 && images_in(workspace_bytes, geo.NT16, H + H / 2) >= T;
+  int rc;
+  if (x3) {
+    hipLaunchKernelGGL(hx_pack_x3_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
+                       geo.NT16);
+    rc = launch_status("hx_pack_x3_kernel");
+    if (rc != YT8M_OK) return rc;
+    if (H == 1024) hipLaunchKernelGGL((lstm_persist_fwd_x3_kernel<4>), dim3(grid), dim3(768), 0, s, a);
+    else hipLaunchKernelGGL((lstm_persist_fwd_x3_kernel<2>), dim3(grid), dim3(768), 0, s, a);
+    rc = launch_status("lstm_persist_fwd_x3_kernel");
+  } else {
+    hipLaunchKernelGGL(hx_pack_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, a.hx, (int)B, (int)H, geo.NT16);
+    rc = launch_status("hx_pack_kernel");
+    if (rc != YT8M_OK) return rc;
+    switch (geo.NQ) {
+      case 2: rc = launch_fwd<2>(a, grid, s); break;
+      case 4: rc = launch_fwd<4>(a, grid, s); break;
+      case 6: rc = launch_fwd<6>(a, grid, s); break;
+      default: rc = launch_fwd<8>(a, grid, s); break;
+    }
   }
   if (rc != YT8M_OK) return rc;
   return g_gate.done(dev, (int)grid, s);

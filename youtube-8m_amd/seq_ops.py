@@ -595,15 +595,13 @@ class _LstmStack(torch.autograd.Function):
                             st["Wxb"] = ops.cast_bf16(W.data[:Din])
                         cast_ev = torch.cuda.Event()
                         cast_ev.record(gs[l])
-                dz3 = dzT3 = None
-                if st["x3"]:                                        # dz feeds dx (as stored) and both dW products (transposed)
-                    with torch.cuda.stream(gs[l]):
+                dz3 = None
+                if st["x3"] and (l > 0 or need_dx):                 # dz as stored feeds dx: on the layer stream (critical path);
+                    with torch.cuda.stream(gs[l]):                  # its transposed image (both dW products) is made on `sw`
                         gs[l].wait_event(rb)
-                        dz3, dzT3 = ops.x3_split(dzc, plain=(l > 0 or need_dx), trans=W.grad is not None)
-                        if "Wx3" not in st and (l > 0 or need_dx):
+                        dz3 = ops.x3_split(dzc)[0]
+                        if "Wx3" not in st:
                             st["Wx3"] = ops.x3_split(W.data[:Din])[0]
-                        cast_ev = torch.cuda.Event()
-                        cast_ev.record(gs[l])
                 if l > 0 or need_dx:
                     with torch.cuda.stream(gs[l]):
                         gs[l].wait_event(rb)
@@ -634,8 +632,7 @@ class _LstmStack(torch.autograd.Function):
                                 dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din), transpose=True), B=dzT, out=W.grad[:Din], beta=beta),
                                 dict(A=ops.cast_bf16(st["hs"][t0:t0 + T].view(T * B, H), transpose=True), B=dzT, out=W.grad[Din:], beta=beta)])
                         elif st["x3"]:
-                            sw.wait_event(cast_ev)
-                            dzT3.buf.record_stream(sw)
+                            dzT3 = ops.x3_split(dzc, plain=False, trans=True)[1]
                             xT3 = ops.x3_split(st["x"][t0:t0 + T].view(T * B, Din), plain=False, trans=True)[1]
                             hT3 = ops.x3_split(st["hs"][t0:t0 + T].view(T * B, H), plain=False, trans=True)[1]
                             ops.gemm_x3_grouped([dict(A=xT3, B=dzT3, out=W.grad[:Din], beta=beta),
