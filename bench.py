@@ -195,8 +195,12 @@ def family_times(lib, steps):
     return fam
 
 
-def family_peak(name, bf16, bwd_cus=None):
+def family_peak(name, bf16, bwd_cus=None, fwd_x3=False):
     """(peak TFLOP/s, what it is) of the pipe a family's dominant kernel runs on."""
+    if name == "lstm_recurrence" and fwd_x3:
+        return PEAK_BF16_MATRIX_TFLOPS / X3_PRODUCTS, ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d products per fp32 product "
+                                                       "(v_mfma_f32_16x16x32_bf16 on three-plane splits of h and W_h)"
+                                                       % (PEAK_BF16_MATRIX_TFLOPS, X3_PRODUCTS))
     if name == "gemm_x3":
         return PEAK_BF16_MATRIX_TFLOPS / X3_PRODUCTS, ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d products per fp32 product "
                                                        "(v_mfma_f32_32x32x16_bf16 on three-plane split operands)" % (PEAK_BF16_MATRIX_TFLOPS, X3_PRODUCTS))
@@ -208,7 +212,7 @@ def family_peak(name, bf16, bwd_cus=None):
     return PEAK_F32_MATRIX_TFLOPS, "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"
 
 
-def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None):
+def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False):
     """Dominant family = the one with the largest hipEvent time among the MFMA families that have an algorithmic FLOP count
     (declared by the library at launch time for the GEMM and recurrence entry points, else the workload's formula).
     achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch)."""
@@ -216,7 +220,7 @@ def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None):
     for name, v in fam.items():
         f = v.get("declared_flops_per_step") or flops.get(name)
         if f and v["ms_per_step"] > 0:
-            peak, what = family_peak(name, bf16, bwd_cus)
+            peak, what = family_peak(name, bf16, bwd_cus, fwd_x3)
             ach = f / (v["ms_per_step"] * 1e-3) / 1e12
             rows[name] = {"achieved": ach, "peak": peak, "peak_is": what, "frac": ach / peak, "ms_per_step": v["ms_per_step"],
                           "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
@@ -496,7 +500,9 @@ def main():
             bwd_cus = None
             if a.workload == "lstm" and lib.yt8m_lstm_persist_bwd_supported(B, LSTM_H):
                 bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
-            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus)
+            fwd_x3 = (a.workload == "lstm" and not bf16 and os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0" and
+                      bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H)))
+            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3)
             if a.workload == "moe" and B == 1024 and not bf16 and roof:
                 try:                   # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_traffic.md)
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))

@@ -94,7 +94,9 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
         torch.cuda.synchronize()
         L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
         print("persistent fwd kernel (%s): %.3f ms for %d steps = %.2f us/step"
-              % ("image per step" if steps else "two images", e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F), flush=True)
+              % ("image per step, recurrent product as six bf16 products" if steps and lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H)
+                 else ("image per step" if steps else "two images, fp32 MFMA"), e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F),
+              flush=True)
 
 
 def timing_bwd(B=128, F=300, H=1024):

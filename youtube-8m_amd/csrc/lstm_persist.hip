@@ -1165,6 +1165,20 @@ using namespace yt8m;
 
 extern "C" int yt8m_lstm_persist_supported(int64_t B, int64_t H) { return persist_geometry(B, H, nullptr) ? 1 : 0; }
 
+namespace {
+bool fwd_x3_shape(int64_t H, int pf) {
+  static const bool x3_off = getenv("YT8M_PERSIST_X3") != nullptr && atoi(getenv("YT8M_PERSIST_X3")) == 0;
+  return !x3_off && (H == 512 || H == 1024) && pf >= 1;
+}
+}  // namespace
+
+// 1 when a forward launch on a per-step-image workspace (yt8m_lstm_persist_workspace_bytes_steps) runs the recurrent product as
+// six bf16 products (lstm_persist_fwd_x3_kernel) rather than on the fp32 MFMA pipe
+extern "C" int yt8m_lstm_persist_fwd_on_bf16_pipe(int64_t B, int64_t H) {
+  Geometry geo;
+  return (persist_geometry(B, H, &geo) && fwd_x3_shape(H, geo.pf)) ? 1 : 0;
+}
+
 extern "C" int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H) {
   Geometry geo;
   if (!persist_geometry(B, H, &geo)) return 0;
@@ -1222,8 +1236,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
   // the recurrent product on the bf16 pipe (lstm_persist_fwd_x3_kernel) when its preconditions hold: an exchange image (1.5x the
   // fp32 one) per step, >= 2 tiles per workgroup, H in {512, 1024}
-  static const bool x3_off = getenv("YT8M_PERSIST_X3") != nullptr && atoi(getenv("YT8M_PERSIST_X3")) == 0;
-  const bool x3 = !x3_off && (H == 512 || H == 1024) && geo.pf >= 1 && images_in(workspace_bytes, geo.NT16, H + H / 2) >= T;
+  const bool x3 = fwd_x3_shape(H, geo.pf) && images_in(workspace_bytes, geo.NT16, H + H / 2) >= T;
   int rc;
   if (x3) {
     hipLaunchKernelGGL(hx_pack_x3_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
