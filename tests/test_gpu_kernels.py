@@ -245,6 +245,14 @@ def test_topk_rows(dev):
     assert idx[0, :3].tolist() == [5, 10, 20]
     v2, i2 = ops.topk_rows(D(p[:, :7], dev), 20)                       # k > V clamps like eval_util.top_k_triplets
     assert v2.shape == (B, 7)
+    # rows with fewer than k scores above -inf (NaN / -inf entries): the indices stay valid and distinct
+    bad = np.full((3, 40), np.nan, dtype=np.float32)
+    bad[1, :] = -np.inf
+    bad[2, 7], bad[2, 30] = 0.5, 0.9
+    v3, i3 = ops.topk_rows(D(bad, dev), 20)
+    i3 = i3.cpu().numpy()
+    assert i3.min() >= 0 and i3.max() < 40 and all(len(set(r.tolist())) == 20 for r in i3)
+    assert i3[2, :2].tolist() == [30, 7] and i3[0, :3].tolist() == [0, 1, 2]
 
 
 @pytest.mark.parametrize("B,F,Din,Hh", [(5, 9, 6, 4), (37, 6, 20, 128), (64, 4, 16, 256)])

@@ -175,9 +175,19 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       int fi = ri[0];
       for (int q = 1; q < 4; ++q)
         if (rv[q] > fv || (rv[q] == fv && ri[q] < fi)) { fv = rv[q]; fi = ri[q]; }
+      if (fi < 0 || fi >= (int)V) {
+        // nothing above -inf is left (NaN / -inf scores, or k > the number of finite ones): hand out the lowest class index not
+        // returned yet, with its original score, so that callers can always gather with the indices
+        for (int c = 0; c < (int)V; ++c) {
+          bool used = false;
+          for (int q = 0; q < r; ++q) used = used || idx[b * k + q] == c;
+          if (!used) { fi = c; break; }
+        }
+        fv = pr[fi];
+      }
       vals[b * k + r] = fv;
       idx[b * k + r] = fi;
-      if (fi >= 0 && fi < (int)V) row[fi] = -INFINITY;
+      row[fi] = -INFINITY;
     }
     __syncthreads();
   }
