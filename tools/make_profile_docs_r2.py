@@ -71,15 +71,21 @@ def main():
         fam["gemm_x3"] = {"kernel": g, "hbm_bytes_per_launch": tot(g),
                           "algorithmic_bytes_per_launch": sum(x3_bytes(*sh) for sh in shapes) / launches,
                           "note": "average over the step's x3 launches (projection, dx and grouped weight-gradient products)"}
-    f = pick("lstm_persist_fwd_kernel")
+    f = pick("lstm_persist_fwd")
     algf = float(T * (B * 4 * H * 4 * 2 + 3 * B * H * 4))
-    note = ("algorithmic = the saved activations only (z in, gates / c / h / out written); the state exchange (one 512 KB image per "
-            "step forward, 2 MB backward) is written through once and fetched once per XCD into its L2")
+    note = ("algorithmic = the saved activations only (z in, gates / c / h / out written); the state exchange (one 768 KB image of "
+            "bf16 planes per step forward, 2 MB fp32 backward) is written through once and fetched once per XCD into its L2: these "
+            "bytes pass the memory-side counters too (the Infinity Cache serves most of them)")
+    # the state exchange crosses the L2s by design: every image is written through once and fetched once by each of the 8 XCDs
+    img_f = B * H * (6 if f and "x3" in f else 4)
+    img_b = B * 4 * H * 4
     if f:
-        fam["lstm_recurrence"] = {"kernel": f, "hbm_bytes_per_launch": tot(f), "algorithmic_bytes_per_launch": algf, "note": note}
+        fam["lstm_recurrence"] = {"kernel": f, "hbm_bytes_per_launch": tot(f), "algorithmic_bytes_per_launch": algf,
+                                  "state_exchange_bytes_per_launch": float(T * img_f * 9), "note": note}
     bk = pick("lstm_persist_bwd_kernel")
     if bk:
-        fam["lstm_recurrence_bwd"] = {"kernel": bk, "hbm_bytes_per_launch": tot(bk), "algorithmic_bytes_per_launch": algf}
+        fam["lstm_recurrence_bwd"] = {"kernel": bk, "hbm_bytes_per_launch": tot(bk), "algorithmic_bytes_per_launch": algf,
+                                      "state_exchange_bytes_per_launch": float(T * img_b * 9)}
     g32 = pick("gemm_grouped_kernel")
     if g32:
         fam["gemm"] = {"kernel": g32, "hbm_bytes_per_launch": tot(g32), "algorithmic_bytes_per_launch": None,
