@@ -367,6 +367,9 @@ int64_t yt8m_lstm_persist_workspace_bytes_steps(int64_t B, int64_t H, int64_t T)
 /* 1 when a forward launch on such a workspace runs the recurrent product h.W_h as six bf16 MFMA products of exact three-plane
  * splits (fp32-grade results, 3/8 of the fp32-MFMA matrix time; H in {512, 1024}, >= 2 tiles per workgroup), 0: fp32 MFMA */
 int yt8m_lstm_persist_fwd_on_bf16_pipe(int64_t B, int64_t H);
+/* CUs the following forward / backward launches may occupy (0: whole chip, -1: environment / default = whole chip forward, 128
+ * backward).  Two forward launches of neighbouring layers run side by side when each takes half the chip. */
+int yt8m_lstm_persist_set_cus(int fwd_cus, int bwd_cus);
 int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream);
 int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                           const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,

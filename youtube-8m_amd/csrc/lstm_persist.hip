@@ -1093,10 +1093,13 @@ PersistGate g_gate;
 
 // CUs a persistent launch may occupy: the whole chip, or YT8M_PERSIST_CUS of them (the rest stays free for kernels of other
 // streams -- the hoisted GEMMs of the layer pipeline -- to run beside the recurrence)
+int g_cap_fwd = -1, g_cap_bwd = -1;      // yt8m_lstm_persist_set_cus (calling thread's choice for its next launches); -1: environment
 int persist_cu_budget(int cus, bool bwd = false) {
   static const int cap = getenv("YT8M_PERSIST_CUS") ? atoi(getenv("YT8M_PERSIST_CUS")) : 0;
   static const int cap_b = getenv("YT8M_PERSIST_CUS_BWD") ? atoi(getenv("YT8M_PERSIST_CUS_BWD")) : 128;
-  const int c = bwd ? cap_b : cap;
+  int c = bwd ? cap_b : cap;
+  if (bwd && g_cap_bwd >= 0) c = g_cap_bwd;
+  if (!bwd && g_cap_fwd >= 0) c = g_cap_fwd;
   return (c > 0 && c < cus) ? c : cus;
 }
 
@@ -1162,6 +1165,16 @@ int images_in(int64_t workspace_bytes, int NT16, int64_t width) {
 }  // namespace
 
 using namespace yt8m;
+
+// CUs the following forward / backward launches (and shape queries) may occupy: 0 = the whole chip, -1 = the environment's choice
+// (YT8M_PERSIST_CUS, YT8M_PERSIST_CUS_BWD; defaults: whole chip forward, 128 backward).  Process-wide tuning state: a caller that
+// wants two layers' forward recurrences side by side sets 128 before launching them.
+extern "C" int yt8m_lstm_persist_set_cus(int fwd_cus, int bwd_cus) {
+  YT8M_REQUIRE(fwd_cus >= -1 && bwd_cus >= -1, YT8M_E_BADARG, "CU counts must be >= -1");
+  g_cap_fwd = fwd_cus;
+  g_cap_bwd = bwd_cus;
+  return YT8M_OK;
+}
 
 extern "C" int yt8m_lstm_persist_supported(int64_t B, int64_t H) { return persist_geometry(B, H, nullptr) ? 1 : 0; }
 

@@ -241,19 +241,25 @@ def lnlstm_layer(x_tm, W, gammas, betas, num_frames, forget_bias=1.0, keep_prob=
 _SIDE = {}
 
 
-def _side_streams(device, L, persistent=False):
+def _side_streams(device, L, persistent=False, separate_gemm=False):
     """Per device: one stream per layer (its projection / dx GEMMs and its recurrence run in order on it) and one for the
     weight-gradient GEMMs.  Measured on the 2-layer BASELINE configs[3] stack (B = 128): a separate GEMM stream per layer is
     no better (51.7 vs 49.0 ms/step).  The layer streams are HIGH priority when the recurrence is the persistent kernel: it needs
     every workgroup resident, and behind a high-priority queue it takes freed CUs before the remaining workgroups of a running
     weight-gradient GEMM do (a partially resident recurrence spins on its CUs while the GEMM crawls on the rest: 28.6 vs 46.6
     ms/step run to run without it).  With the per-step kernels (600 launches) priority queues are far worse (96 ms), so those
-    keep normal streams."""
-    pool = _SIDE.setdefault((device, bool(persistent)), dict(r=[], w=None))
+    keep normal streams.  separate_gemm (forward wavefront of half-chip recurrences): the projections get normal-priority streams
+    of their own -- on the layer stream a projection's workgroups compete at high priority with the OTHER layer's recurrence for
+    the CUs it needs (one run in three took 41 instead of 24.6 ms/step)."""
+    pool = _SIDE.setdefault((device, bool(persistent)), dict(r=[], g=[], w=None))
     while len(pool["r"]) < L:
         pool["r"].append(torch.cuda.Stream(device=device, priority=REC_STREAM_PRIORITY if persistent else 0))
     if pool["w"] is None:
         pool["w"] = torch.cuda.Stream(device=device)
+    if separate_gemm:
+        while len(pool["g"]) < L:
+            pool["g"].append(torch.cuda.Stream(device=device))
+        return pool["r"][:L], pool["g"][:L], pool["w"]
     return pool["r"][:L], pool["r"][:L], pool["w"]
 
 
@@ -282,6 +288,11 @@ def _bwd_parts(F, fwd_parts):
         return [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b > a]
     return _chunks(F, BWD_CHUNKS) if BWD_CHUNKS > 0 else fwd_parts
 PERSIST_DBROWS = False
+# half-chip forward recurrences of two layers side by side (opt-in: 24.6 ms/step against 25.3 at B = 128, H = 1024 when the
+# projections share the high-priority layer streams, but one run in three then took 41 ms; with projection streams of their own --
+# what the code does -- it is stable at 27.9)
+FWD_WAVEFRONT = _os.environ.get("YT8M_LSTM_FWD_WAVEFRONT", "0") != "0"
+FWD_WAVEFRONT_CHUNKS = int(_os.environ.get("YT8M_LSTM_FWD_WAVEFRONT_CHUNKS", "10"))
 REC_STREAM_PRIORITY = int(_os.environ.get("YT8M_REC_STREAM_PRIORITY", "-1"))
 PERSIST_STEP_IMAGES = _os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0"
 PERSIST_STEP_IMAGES_MAX_BYTES = 8 << 30                 # per layer; larger launches keep the two-image exchange
@@ -337,6 +348,23 @@ class _LstmStack(torch.autograd.Function):
         lib = _lib.lib()
         nf = _nf(num_frames)
         q_raw = None
+        L = len(wb) // 2
+        Hs = [w.data.shape[1] // 4 for w in wb[0::2]]
+        if x_tm.dtype == torch.uint8:
+            B, F = x_tm.shape[0], x_tm.shape[1]                    # raw reader output is batch-major
+        else:
+            F, B = x_tm.shape[0], x_tm.shape[1]
+        pers = PERSIST and all(lib.yt8m_lstm_persist_supported(B, h) for h in Hs)
+        parts = _chunks(F, chunks)
+        bwd_parts = _bwd_parts(F, parts)
+        # Wavefront of half-chip forward recurrences (opt-in, see FWD_WAVEFRONT): with the recurrent product on the bf16 pipe a layer's
+        # recurrence is bound by its dependency chain, not by matrix time, so two layers can run side by side on half the chip each
+        # (8 chains per workgroup) at 11.4 us / step and layer against 8.5 on the whole chip one after the other; finer time chunks
+        # shorten the ramps.  The backward pass keeps the caller's partition.
+        half_fwd = (FWD_WAVEFRONT and pers and L >= 2 and PERSIST_STEP_IMAGES and not bf16 and F >= 8 * FWD_WAVEFRONT_CHUNKS and
+                    all(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, h) for h in Hs) and _os.environ.get("YT8M_PERSIST_CUS") is None)
+        if half_fwd:
+            parts = _chunks(F, max(int(chunks), FWD_WAVEFRONT_CHUNKS))
         if x_tm.dtype == torch.uint8:
             # raw reader output [B,F,D] (batch-major): the layer-0 projection takes the bytes themselves (csrc/u8proj.hip) --
             # one conversion pass writes (q - 128) as bf16 in time-major order (three copies side by side: the three bf16
@@ -350,7 +378,7 @@ class _LstmStack(torch.autograd.Function):
             Qb = Qimg = None
             # one-plane operand image for the x3 kernel (three exact products per element pair) when every time chunk starts on
             # a 32-row group of the image; otherwise three bf16 copies side by side for the plain bf16 kernel
-            if X3 and Dq % 16 == 0 and all((t0 * Bq) % 32 == 0 for t0, _ in _chunks(Fq, chunks)):
+            if X3 and Dq % 16 == 0 and all((t0 * Bq) % 32 == 0 for t0, _ in parts):
                 Qimg = torch.empty(((Fq * Bq + 31) // 32) * (Dq // 16) * 1024, dtype=torch.uint8, device=q_raw.device)
                 _lib.check(lib.yt8m_u8_frames_image(_p(q_raw), _p(nf), Bq, Fq, Dq, 1e-12, _p(Qimg), _p(x_tm), _p(rrow), _stream()))
             else:
@@ -359,16 +387,12 @@ class _LstmStack(torch.autograd.Function):
                                                          _stream()))
         x_tm = _f32c(x_tm)
         _dev(x_tm)
-        L = len(wb) // 2
         Ws, bs = wb[0::2], wb[1::2]
-        F, B, _ = x_tm.shape
+        assert (F, B) == tuple(x_tm.shape[:2])
         dev = x_tm.device
         main = torch.cuda.current_stream(dev)
-        Hs = [w.data.shape[1] // 4 for w in wb[0::2]]
-        pers = PERSIST and all(lib.yt8m_lstm_persist_supported(B, h) for h in Hs)
-        rs, gs, _ = _side_streams(dev, L, pers)
+        rs, gs, _ = _side_streams(dev, L, pers, separate_gemm=half_fwd)
         ctx.pers = pers
-        parts = _chunks(F, chunks)
         bf16 = bool(bf16) and B % 2 == 0 and min(T for _, T in parts) * B >= ops.BF16_MIN_ROWS
         drop = input_keep_prob is not None and float(input_keep_prob) < 1.0
         layers, inp = [], x_tm
@@ -389,7 +413,7 @@ class _LstmStack(torch.autograd.Function):
             pws = lib.yt8m_lstm_persist_workspace_bytes(B, H) if PERSIST else 0
             if pws and PERSIST_STEP_IMAGES:
                 # one exchange image per step of the longest launch (forward or backward partition): XCD-L2-shared state fetch
-                tmax = max([T for _, T in parts] + [T for _, T in _bwd_parts(F, parts)])
+                tmax = max([T for _, T in parts] + [T for _, T in bwd_parts])
                 big = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, tmax)
                 if big <= PERSIST_STEP_IMAGES_MAX_BYTES:
                     pws = big
@@ -434,6 +458,8 @@ class _LstmStack(torch.autograd.Function):
                     st["Wp16"] = torch.empty(H_ * 4 * H_, dtype=torch.bfloat16, device=dev)
                     _lib.check(lib.yt8m_lstm_pack_bf16(_p(st["W"].data[st["Din"]:]), 4 * H_, H_, _p(st["Wp16"]), None, _stream()))
         r_done = [[torch.cuda.Event() for _ in parts] for _ in range(L)]
+        if half_fwd:
+            _lib.check(lib.yt8m_lstm_persist_set_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2, -1))
         for c, (t0, T) in enumerate(parts):
             for l, st in enumerate(layers):
                 Din, H = st["Din"], st["H"]
@@ -489,7 +515,9 @@ class _LstmStack(torch.autograd.Function):
             main.wait_event(r_done[l][-1])
         # the backward pass may cut time differently (all buffers are whole-layer): its first recurrence chunk runs with nothing
         # beside it, so shorter chunks shorten that pipeline fill; the forward recurrence owns the chip and wants few launches
-        ctx.layers, ctx.nf, ctx.parts = layers, nf, _bwd_parts(F, parts)
+        if half_fwd:
+            _lib.check(lib.yt8m_lstm_persist_set_cus(-1, -1))
+        ctx.layers, ctx.nf, ctx.parts = layers, nf, bwd_parts
         ctx.drop = (float(input_keep_prob), tuple(int(v) for v in seeds)) if drop else None
         ctx.set_materialize_grads(False)
         outs = [layers[-1]["out"]]
