@@ -146,3 +146,34 @@ def test_single_process_reducer_is_identity():
     v.grad_done()
     assert red.finish() == 1.0 and torch.all(v.grad == 2.0)
     assert parallel.shard_batch(8, 1, 4) == (2, 4)
+
+
+def test_grad_done_fires_after_the_last_use_of_a_shared_variable():
+    """A variable fetched twice in one forward pass (get_variable is get-or-create) has two gradient contributions: the
+    graph's gradient-complete hook -- the reducer's all-reduce trigger -- fires on the second grad_done(), not the first, and
+    the second contribution accumulates (beta = 1) instead of raising (shared variables under data parallelism)."""
+    __graft_entry__.load_package()
+    from yt8m_amd.variables import Graph, zeros
+    g = Graph(device="cpu")
+    g.begin_step()
+    a = g.get_variable("shared", (3,), zeros)
+    b = g.get_variable("single", (2,), zeros)
+    g.finalize()
+    fired = []
+    g.grad_ready_hook = lambda v: fired.append(v.name)
+    for step in range(2):                                   # the per-step counters reset in begin_step
+        g.begin_step()
+        assert g.get_variable("shared", (3,), zeros) is a and g.get_variable("shared", (3,), zeros) is a
+        assert g.get_variable("single", (2,), zeros) is b
+        fired.clear()
+        assert a.grad_beta() == 0.0
+        a.grad_done()
+        assert fired == []                                  # one of two uses reported
+        assert a.grad_beta() == 1.0                         # the second contribution accumulates, no error
+        a.grad_done()
+        assert fired == ["shared"]
+        assert b.grad_beta() == 0.0
+        b.grad_done()
+        assert fired == ["shared", "single"]
+        with pytest.raises(RuntimeError):                   # a third contribution after the hook fired is an error
+            a.grad_beta()

@@ -50,8 +50,12 @@ class Variable(object):
         return beta
 
     def grad_done(self):
-        """Called by the op that produced the LAST contribution of this step (single-use variables: right after
-        the first write).  Lets the data-parallel reducer start this slice's all-reduce early."""
+        """Called by an op when its gradient contribution to this variable is enqueued.  Once every use of this step has reported
+        (uses = get_variable calls since begin_step) the graph's hook fires: the data-parallel reducer starts this slice's
+        all-reduce, the single-device step starts its clip + Adam on a side stream."""
+        self._done_count = getattr(self, "_done_count", 0) + 1
+        if self._done_count < getattr(self, "_uses", 1):
+            return
         self._done_reported = True
         if self._graph is not None and self._graph.grad_ready_hook is not None:
             self._graph.grad_ready_hook(self)
@@ -128,6 +132,8 @@ class Graph(object):
         for v in self.vars.values():
             v.grad_written = False
             v._done_reported = False
+            v._done_count = 0
+            v._uses = 0
         if self.token is None:
             self.token = torch.zeros((), dtype=torch.float32, device=self.device, requires_grad=True)
 
@@ -150,6 +156,7 @@ class Graph(object):
         if v is not None:
             if tuple(v.data.shape) != tuple(shape):
                 raise ValueError("variable %s exists with shape %s, requested %s" % (full, tuple(v.data.shape), tuple(shape)))
+            v._uses = getattr(v, "_uses", 0) + 1
             return v
         if self.finalized:
             raise RuntimeError("variable %s requested after Graph.finalize(); the model must create the same "
@@ -157,6 +164,7 @@ class Graph(object):
         data = initializer(tuple(shape), self._generator(), self.device)
         v = Variable(full, data, l2=l2, trainable=trainable)
         v._graph = self
+        v._uses = 1
         self.vars[full] = v
         return v
 
