@@ -166,8 +166,9 @@ class GradReducer(object):
         """Marks var ready; launches an async all-reduce for every maximal run of ready, unlaunched, adjacent
         variables whose size reaches the bucket threshold."""
         if self._launched[var.index]:
-            # a Variable used twice in one forward pass reports grad_done() after its FIRST backward contribution; the later
-            # one would add into a buffer whose all-reduce is already in flight (ADVICE r1): refuse loudly
+            # Variable.grad_done() fires this hook once, after the last of the variable's uses of this step (uses = get_variable
+            # calls); a second report means an op contributed without fetching the variable through the graph: its gradient would
+            # be added into a buffer whose all-reduce is already in flight (ADVICE r1): refuse loudly
             raise RuntimeError("gradient of %s was reported done twice in one step (variable shared between ops?): its "
                                "all-reduce is already in flight" % var.name)
         self._ready[var.index] = True
