@@ -492,6 +492,13 @@ def main():
     params = sum(v.numel() for v in g.trainable_variables())
     import yt8m_amd.seq_ops as seq_ops
     seq_ops.check_persist_errors()              # a persistent launch that timed out must fail the bench, not skew it
+    placement = None
+    if rank == 0 and a.workload == "lstm":
+        # diagnostics of the timed region (+ warm-up): persistent recurrence workgroups that did not land on the XCD their index
+        # suggests lose the L2 sharing of the state fetch -- tells an unlucky placement from a slow kernel
+        nl, nw, off = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), ctypes.byref(nw), ctypes.byref(off), 1)
+        placement = {"persistent_launches": nl.value, "workgroups": nw.value, "workgroups_off_their_xcd": off.value}
 
     roof = None
     if not a.no_roofline:
@@ -565,7 +572,7 @@ def main():
                                          "+RCCL all-reduce" if world > 1 else ""),
                           "per_gpu_batch": B, "global_batch": B * world, "frames": FRAMES if cfg["frame"] else None,
                           "parallelism": "dp%d" % world, "params": params},
-               "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra}
+               "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -371,6 +371,10 @@ int yt8m_lstm_persist_fwd_on_bf16_pipe(int64_t B, int64_t H);
  * backward).  Two forward launches of neighbouring layers run side by side when each takes half the chip. */
 int yt8m_lstm_persist_set_cus(int fwd_cus, int bwd_cus);
 int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream);
+/* diagnostics: persistent launches / workgroups since the last reset on the current device and how many workgroups did not run on
+ * the XCD their block index suggests (a launch that finds CUs busy is placed wherever some are free: correct, but the state fetch
+ * loses its L2 sharing).  Synchronises the device. */
+int yt8m_lstm_persist_placement_stats(int64_t* launches, int64_t* workgroups, int64_t* off_xcd, int reset);
 int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                           const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
                           void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_supported": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_lstm_persist_workspace_bytes_steps": (c_int64, [c_int64, c_int64, c_int64]),
+    "yt8m_lstm_persist_placement_stats": (c_int, [ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int]),
     "yt8m_lstm_persist_fwd_on_bf16_pipe": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_set_cus": (c_int, [c_int, c_int]),
     "yt8m_lstm_persist_status": (c_int, [P, P]),

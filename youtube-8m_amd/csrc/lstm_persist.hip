@@ -71,6 +71,7 @@ struct PersistFwdArgs {
   const int32_t* nf;    // [B] or null
   float* hx;            // exchange images [nimg][NT16][H/16][256]: one per step (SH) or two alternating ones
   unsigned* ctl;        // control block (zeroed before the launch)
+  unsigned* stats;      // device-wide placement statistics (see note_placement)
   int t0, T, B, H;
   float fb;
   int NU, RB, NT16, per, pf;
@@ -94,6 +95,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 __device__ __forceinline__ float4 as_f4(u32x4 v) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// The kernels take "block b runs on XCD (b + k) % 8 for one k per launch" as a placement hint (row groups <-> XCD sets,
+// line-sharing unit groups on one XCD).  A launch that finds part of the chip busy is placed wherever CUs are free; nothing breaks,
+// but the state fetch loses its L2 sharing.  Counted so that a slow step can be told from an unlucky placement: workgroup 0 posts
+// its offset k in the control block at the start, every workgroup compares its own with it at the end: stats[0] += mismatches.
+__device__ __forceinline__ unsigned placement_offset() {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return ((xcc & 7u) - (blockIdx.x & 7u)) & 7u;
+}
+__device__ __forceinline__ void note_placement(unsigned* ctl) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(ctl + 2, placement_offset() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void check_placement(unsigned* ctl, unsigned* stats) {      // one lane, at the end of the kernel
+  if (!stats) return;
+  const unsigned k0 = __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (k0 != 0u && k0 - 1u != placement_offset()) __hip_atomic_fetch_add(stats, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sum of lanes 0 .. NSH-1 (wave-uniform result)
@@ -238,6 +257,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
     const float* p = a.Wh + k * a.ldw + col;
     return make_float4(p[0], p[a.ldw], p[2 * a.ldw], p[3 * a.ldw]);
   };
+  note_placement(a.ctl);
   if (tid < NSLOT) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
@@ -454,6 +474,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
       }
     }
   }
+  if (ew == 0 && lane == 0) check_placement(a.ctl, a.stats);
 }
 
 // =====================================================================================================================
@@ -559,6 +580,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
     v.x = hb[0] | (hb[1] << 16); v.y = hb[2] | (hb[3] << 16); v.z = hb[4] | (hb[5] << 16); v.w = hb[6] | (hb[7] << 16);
     return v;
   };
+  note_placement(a.ctl);
   if (tid < NS) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
@@ -749,6 +771,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       }
     }
   }
+  if (ew == 0 && lane == 0) check_placement(a.ctl, a.stats);
 }
 
 // =====================================================================================================================
@@ -775,6 +798,7 @@ struct PersistBwdArgs {
   const int32_t* nf;
   float* dzx;           // exchange images [nimg][NT16][4H/16][256]
   unsigned* ctl;
+  unsigned* stats;
   int t0, T, B, H, phase;
   int NUB, RB, NT16, per, pf;
   int nimg;
@@ -813,6 +837,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   constexpr int AUX_LD = SH ? 0 : YT8M_AUX_LD;
   const unsigned arrivals = (unsigned)a.NUB * 4u;        // per (tile, publish): four epilogue waves per workgroup
   const int i16 = lane & 15, kq = lane >> 4;
+  note_placement(a.ctl);
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
@@ -1047,6 +1072,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       if (valid) store_std(t1, brow, dzv, dc_out, base_out, half ^ 1);
     }
   }
+  if (ew == 0 && lane == 0) check_placement(a.ctl, a.stats);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -1090,6 +1116,17 @@ struct PersistGate {
   }
 };
 PersistGate g_gate;
+
+// placement statistics: one device word per device, allocated on first use; launches / workgroups counted on the host
+unsigned* g_stats[16] = {nullptr};
+int64_t g_stat_launches[16] = {0}, g_stat_wgs[16] = {0};
+unsigned* stats_ptr(int dev) {
+  if (!g_stats[dev]) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_stats[dev]), 64) != hipSuccess) return nullptr;
+    (void)hipMemset(g_stats[dev], 0, 64);
+  }
+  return g_stats[dev];
+}
 
 // CUs a persistent launch may occupy: the whole chip, or YT8M_PERSIST_CUS of them (the rest stays free for kernels of other
 // streams -- the hoisted GEMMs of the layer pipeline -- to run beside the recurrence)
@@ -1208,6 +1245,24 @@ extern "C" int64_t yt8m_lstm_persist_workspace_bytes_steps(int64_t B, int64_t H,
   return ctl_padded(geo.NT16) + std::max<int64_t>(T, 2) * geo.NT16 * 16 * 4 * H * 4 + DBG_BYTES;
 }
 
+// Since the last reset on the current device: persistent launches, their workgroups, and how many of those did not run on the XCD
+// their block index suggests (blockIdx % 8).  Synchronises the device.  reset != 0 zeroes the counters afterwards.
+extern "C" int yt8m_lstm_persist_placement_stats(int64_t* launches, int64_t* workgroups, int64_t* off_xcd, int reset) {
+  int dev = 0;
+  device_cus(&dev);
+  unsigned v = 0;
+  if (g_stats[dev]) YT8M_HIP_CHECK(hipMemcpy(&v, g_stats[dev], 4, hipMemcpyDeviceToHost));
+  if (launches) *launches = g_stat_launches[dev];
+  if (workgroups) *workgroups = g_stat_wgs[dev];
+  if (off_xcd) *off_xcd = v;
+  if (reset) {
+    if (g_stats[dev]) YT8M_HIP_CHECK(hipMemset(g_stats[dev], 0, 64));
+    g_stat_launches[dev] = 0;
+    g_stat_wgs[dev] = 0;
+  }
+  return YT8M_OK;
+}
+
 extern "C" int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream) {
   YT8M_REQUIRE(workspace, YT8M_E_BADARG, "null workspace");
   unsigned err = 0;
@@ -1241,6 +1296,9 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   const unsigned grid = (unsigned)(geo.NU * geo.RB);
   int dev = 0;
   device_cus(&dev);
+  a.stats = stats_ptr(dev);
+  ++g_stat_launches[dev];
+  g_stat_wgs[dev] += grid;
   ProfScope prof(F_LSTM, s, 2.0 * (double)T * (double)B * (double)H * 4.0 * (double)H);
   std::lock_guard<std::mutex> lk(g_gate.mu);
   const int total_cus = device_cus(nullptr);
@@ -1346,6 +1404,9 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   const unsigned grid = (unsigned)(geo.NUB * geo.RB);
   int dev = 0;
   device_cus(&dev);
+  a.stats = stats_ptr(dev);
+  ++g_stat_launches[dev];
+  g_stat_wgs[dev] += grid;
   ProfScope prof(F_LSTM_BWD, s, 2.0 * (double)T * (double)B * (double)H * 4.0 * (double)H);
   std::lock_guard<std::mutex> lk(g_gate.mu);
   const int total_cus = device_cus(nullptr);
