@@ -571,7 +571,11 @@ def main():
                                       % (cfg["name"], "bf16-operand VARIANT (not the fp32 headline) of the" if bf16 else "fp32",
                                          "+RCCL all-reduce" if world > 1 else ""),
                           "per_gpu_batch": B, "global_batch": B * world, "frames": FRAMES if cfg["frame"] else None,
-                          "parallelism": "dp%d" % world, "params": params},
+                          "parallelism": "dp%d" % world, "params": params,
+                          "arithmetic": ("bf16 operands, fp32 accumulate" if bf16 else
+                                         "fp32 values throughout; large matrix products run on the bf16 MFMA pipe as six exact partial "
+                                         "products of a three-plane bf16 split of both operands with fp32 accumulation (error <= the "
+                                         "rounding of an fp32 FMA; YT8M_GEMM_X3=0 / YT8M_PERSIST_X3=0 select the fp32 MFMA kernels)")},
                "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement}
         print(json.dumps(out))
     if world > 1:
