@@ -200,3 +200,38 @@ def test_cu_masked_stream_confines_workgroups(dev):
         assert sorted(per) == list(range(8)) and set(per.values()) == {16}
     finally:
         L.check(lib.yt8m_stream_destroy(ctypes.c_void_p(h.value)))
+
+
+def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch):
+    """The opt-in forward wavefront (half-chip forward recurrences of neighbouring layers side by side, finer time chunks, the
+    projections on streams of their own) and an explicit CU budget change WHERE the recurrences run, not what they compute: same
+    outputs and gradients as the default placement to fp32 rounding; the placement counters see every launch."""
+    import ctypes
+    import yt8m_amd.seq_ops as seq_ops
+    from test_gpu_round2 import _stack_run
+    lib = L.lib()
+    B, F, D, H = 128, 24, 96, 1024
+    if not lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H):
+        pytest.skip("bf16-pipe forward recurrence not available for this shape / device")
+    nf = torch.randint(0, F + 1, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(3), dtype=torch.int32)
+    nf[0], nf[1] = F, 0
+    nl, nw, off = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(lib.yt8m_lstm_persist_placement_stats(None, None, None, 1))
+    ref, gref, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)
+    L.check(lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), ctypes.byref(nw), ctypes.byref(off), 1))
+    assert nl.value == 8 and nw.value == 4 * 256 + 4 * 128 and 0 <= off.value <= nw.value   # 2 layers x 2 chunks, forward + backward
+    monkeypatch.setattr(seq_ops, "FWD_WAVEFRONT", True)
+    monkeypatch.setattr(seq_ops, "FWD_WAVEFRONT_CHUNKS", 3)
+    a, ga, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)
+    L.check(lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), ctypes.byref(nw), None, 1))
+    assert nl.value == 6 + 4 and nw.value == 10 * 128          # three half-chip forward chunks per layer, two backward ones
+    for u, v in zip(a + ga, ref + gref):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
+    monkeypatch.setattr(seq_ops, "FWD_WAVEFRONT", False)
+    try:
+        L.check(lib.yt8m_lstm_persist_set_cus(128, 128))
+        b, gb, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)
+    finally:
+        L.check(lib.yt8m_lstm_persist_set_cus(-1, -1))
+    for u, v in zip(b + gb, ref + gref):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
