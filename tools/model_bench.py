@@ -93,7 +93,7 @@ def run(name, steps=5):
     el = (time.perf_counter() - t0) / steps
     lib.yt8m_prof_enable(0)
     fam = []
-    for fid, fname in enumerate(["gemm", "fused", "elementwise", "optim", "lstm", "netvlad"]):
+    for fid, fname in enumerate(["gemm", "fused", "elementwise", "optim", "lstm", "netvlad", "lstm_bwd", "gemm_x3"]):
         n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
         lib.yt8m_prof_get(fid, ctypes.byref(n), ctypes.byref(ms))
         if n.value:
