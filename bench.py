@@ -148,6 +148,10 @@ WORKLOADS = {
     "netvlad": dict(name="BASELINE configs[2]: NetVLADModel (64 clusters, hidden 1024) on raw uint8 [B,300,1152] frames + "
                          "MoeModel head (2 mixtures, V=4716)",
                     batch=1024, pool=2, frame=True, flops=netvlad_flops),
+    # extra line only (bf16, the config's own dtype; per-GPU share of the global batch of 8192 on 8 GPUs)
+    "composite": dict(name="BASELINE configs[4]: GatedNetVLADAttentionChainModel (gated NetVLAD 64 clusters + attention pooling + 3-layer "
+                           "chained MoE, multitask loss) on raw uint8 [B,300,1152] frames",
+                      batch=1024, pool=1, frame=True, flops=lambda B: {}),
 }
 
 
@@ -167,9 +171,16 @@ def build(workload, B, world, rank, dev, reducer, bf16):
             k, v = kv.split("=", 1)
             cur = getattr(FLAGS, k)
             setattr(FLAGS, k, (v == "1") if isinstance(cur, bool) else type(cur)(v))
-    model = {"lstm": flm.LstmModel, "moe": vlm.MoeModel, "netvlad": flm.NetVLADModel}[workload]()
+    multitask = None
+    if workload == "composite":                           # SURVEY.md App. B / tools/model_bench.py "config5"
+        FLAGS.deep_chain_layers, FLAGS.deep_chain_relu_cells, FLAGS.support_type = 3, 128, ",".join(["label"] * 3)
+        multitask = True
+    model = {"lstm": flm.LstmModel, "moe": vlm.MoeModel, "netvlad": flm.NetVLADModel,
+             "composite": flm.GatedNetVLADAttentionChainModel}[workload]()
     g = reset_default_graph(device=dev, seed=0)
-    tg = train.TrainGraph(model, batch_size=B * world, graph=g, reducer=reducer)
+    import yt8m_amd.losses as losses
+    tg = train.TrainGraph(model, batch_size=B * world, graph=g, reducer=reducer, multitask=multitask,
+                          label_loss_fn=losses.MultiTaskCrossEntropyLoss() if multitask else None)
     w = make_pool(workload, B, dev, rank)
     return g, tg, w
 
@@ -296,6 +307,8 @@ def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None):
     el, run = timed_run(tg, pool, steps, warmup or 3, 1, dev, None)
     fam = profile_pass(lib, run, min(steps, 10), 0)
     roof = roofline_from(fam, cfg["flops"](B), bf16)
+    if roof is None and fam:
+        roof = {"families": {}, "other_families": fam}
     if workload == "netvlad" and fam and "netvlad" in fam:
         # the pooling kernels are HBM-bound on the uint8 frames: report the frame-byte rate too
         passes = 3.0                                                  # forward rows+cols share one pass when fused; see DESIGN
@@ -542,7 +555,7 @@ def main():
 
     extra = []
     if rank == 0 and world == 1 and not a.no_extra and a.workload == "lstm" and not bf16:
-        for wl, b16 in (("moe", False), ("netvlad", False), ("lstm", True)):
+        for wl, b16 in (("moe", False), ("netvlad", False), ("lstm", True), ("composite", True)):
             try:
                 extra.append(extra_line(wl, dev, lib, bf16=b16))
             except Exception as e:                                    # an extra line must never break the headline
