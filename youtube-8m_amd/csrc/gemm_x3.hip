@@ -201,8 +201,10 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   };
   for (int kt = 0; kt < nk; ++kt) {
     const int nxt = cur + 1 == NST ? 0 : cur + 1;
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // step kt+1 landed (step kt+2 may stay on the wire) and this wave's fragment fetches of step kt -- the last of them issued at
+    // the end of the previous iteration -- have returned: behind the barrier the stage they read is refilled
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifndef YT8M_X3_NO_BARRIER
     __builtin_amdgcn_s_barrier();
 #endif
