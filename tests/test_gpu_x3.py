@@ -235,3 +235,44 @@ def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch)
         L.check(lib.yt8m_lstm_persist_set_cus(-1, -1))
     for u, v in zip(b + gb, ref + gref):
         assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
+
+
+def test_bf16_pipe_forward_recurrence_over_the_full_sequence(dev):
+    """F = 300 steps (the BASELINE length) of the forward recurrence with the recurrent product as six bf16 products, against an
+    fp64 recurrence on the same inputs: the error does not grow along the sequence (every h_t and the final c within 2e-5),
+    ragged lengths included (copy-through of the state, zero output after the last frame)."""
+    lib = L.lib()
+    B, F, H = 64, 300, 1024
+    if not lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H):
+        pytest.skip("bf16-pipe forward recurrence not available for this shape / device")
+    g = torch.Generator(device=dev).manual_seed(21)
+    z0 = torch.randn((F, B, 4 * H), device=dev, generator=g) * 0.5
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.08
+    nf = torch.randint(0, F + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+    nf[0], nf[1], nf[2] = F, 0, 1
+    c = torch.zeros((B, H), dtype=torch.float64, device=dev)
+    h = torch.zeros((B, H), dtype=torch.float64, device=dev)
+    Wd = Wh.double()
+    outs = []
+    for t in range(F):
+        zz = z0[t].double() + h @ Wd
+        i, j, f, o = zz.split(H, dim=1)
+        c1 = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+        h1 = torch.tanh(c1) * torch.sigmoid(o)
+        live = (t < nf).unsqueeze(1)
+        c = torch.where(live, c1, c)
+        h = torch.where(live, h1, h)
+        outs.append(torch.where(live, h1, torch.zeros_like(h1)))
+    ref = torch.stack(outs)
+    nbytes = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F)
+    pws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    z = z0.clone()
+    cs = torch.zeros((F + 1, B, H), device=dev)
+    hs = torch.zeros((F + 1, B, H), device=dev)
+    out = torch.empty((F, B, H), device=dev)
+    L.check(lib.yt8m_lstm_persist_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nf), 0, F, B, H, 1.0, _p(pws), nbytes, _stream()))
+    L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+    err_t = (out.double() - ref).abs().amax(dim=(1, 2))
+    assert float(err_t.max()) < 2e-5, float(err_t.max())
+    assert float(err_t[-50:].max()) < 4 * float(err_t[:50].max()) + 1e-6         # no growth along the sequence
+    assert float((cs[F].double() - c).abs().max()) < 2e-5 and float((hs[F].double() - h).abs().max()) < 2e-5
