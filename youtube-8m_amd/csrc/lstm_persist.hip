@@ -534,6 +534,10 @@ __global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict
 template <int NKB>
 __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs a) {
   constexpr int NS = 2;                                  // partial-tile slots
+#ifndef YT8M_X3_EPW
+#define YT8M_X3_EPW 2
+#endif
+  constexpr int EPW = YT8M_X3_EPW;                       // epilogue waves per item (1: a whole tile per wave, 2: half a tile each)
   constexpr int NF = NKB * 6;                            // B fragments of a wave: [K block][column half][plane]
   constexpr int NREG = NF < 10 ? NF : 10, NLDS = NF - NREG;
   constexpr int HK = NKB / 2;                            // K blocks per half item
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   const long long img_f = (long long)NT16 * KBH * 3 * 256;
   const unsigned img_bytes = (unsigned)(img_f * 4);
   auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.hx + s * img_f, img_bytes); };
-  const unsigned arrivals = (unsigned)a.NU;
+  const unsigned arrivals = (unsigned)a.NU * EPW;       // per (tile, step): EPW epilogue waves per workgroup
   // B fragment of v_mfma_f32_16x16x32_bf16: lane (n = lane & 15, kg = lane >> 4) supplies B[k = 8 kg + j][n], j = 0..7.
   // Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4), as in the fp32 kernel.
   auto w_frag = [&](int kb, int ct, int p) -> u32x4 {
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       }
       STAMP(2);
       const int slot = k & (NS - 1);
-      if (k >= NS) lds_wait_ge(&lds_free[slot], (unsigned)(k / NS), a.ctl);
+      if (k >= NS) lds_wait_ge(&lds_free[slot], (unsigned)(EPW * (k / NS)), a.ctl);   // every epilogue wave of item k - NS has read
       float* rw = &red[slot][w][0][0][lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { rw[r * 64] = acc[0][0][r] + acc[0][1][r]; rw[256 + r * 64] = acc[1][0][r] + acc[1][1][r]; }
@@ -675,50 +679,55 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   }
 
   // =============================== epilogue waves (as in lstm_persist_fwd_kernel; the publish splits) ===============================
+  // EPW epilogue waves share an item (EPW = 2: wave pair (ew >> 1) owns the tiles it = pair, pair + 2, ...; its two waves take
+  // rows 0-7 / 8-15, ONE (row, unit) pair per lane, so the dependent gate / split / store sequence of the publish is half as long)
   const int ew = w - 8;
   const int eunit = lane & 7;
+  constexpr int JP = 2 / EPW;                            // (row, unit) pairs per lane
   __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);
   for (int s = 0; s < a.T; ++s) {
     const int t = a.t0 + s;
-    for (int it = ew; it < n_it; it += NEPI) {
+    for (int it = EPW == 2 ? (ew >> 1) : ew; it < n_it; it += NEPI / EPW) {
       const int k = s * n_it + it;
       const int T = g + it * RB;
       STAMP(0);
-      float zpre[2][4], cpre[2], hpre[2];
-      bool live[2], evalid[2];
+      float zpre[JP][4], cpre[JP], hpre[JP];
+      bool live[JP], evalid[JP];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = EPW == 2 ? (ew & 1) : jj;
         const int brow = T * 16 + 8 * j + (lane >> 3);
-        evalid[j] = brow < B;
-        const int br = evalid[j] ? brow : B - 1;
+        evalid[jj] = brow < B;
+        const int br = evalid[jj] ? brow : B - 1;
         const float* zr = a.z + ((long long)t * B + br) * 4 * H + ug * 8 + eunit;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) zpre[j][g4] = zr[g4 * H];
+        for (int g4 = 0; g4 < 4; ++g4) zpre[jj][g4] = zr[g4 * H];
         const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
-        cpre[j] = a.cs[idx];
-        hpre[j] = a.hs[idx];
-        live[j] = a.nf ? (t < a.nf[br]) : true;
+        cpre[jj] = a.cs[idx];
+        hpre[jj] = a.hs[idx];
+        live[jj] = a.nf ? (t < a.nf[br]) : true;
       }
       const int slot = k & (NS - 1);
       lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(k / NS + 1), a.ctl);
       STAMP(1);
-      float4 sum[2];
+      float4 sum[JP];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = EPW == 2 ? (ew & 1) : jj;
         const int erow = 8 * j + (lane >> 3);
         const int ct = eunit >> 2, r = erow & 3, l0 = (erow >> 2) * 16 + (eunit & 3) * 4;
-        sum[j] = *reinterpret_cast<const float4*>(&red[slot][0][ct][r][l0]);
+        sum[jj] = *reinterpret_cast<const float4*>(&red[slot][0][ct][r][l0]);
 #pragma unroll
         for (int wv = 1; wv < 8; ++wv) {
           const float4 p = *reinterpret_cast<const float4*>(&red[slot][wv][ct][r][l0]);
-          sum[j].x += p.x; sum[j].y += p.y; sum[j].z += p.z; sum[j].w += p.w;
+          sum[jj].x += p.x; sum[jj].y += p.y; sum[jj].z += p.z; sum[jj].w += p.w;
         }
       }
       if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       STAMP(2);
-      float gi[2], gj[2], gf[2], go[2], cn[2], hn[2];
+      float gi[JP], gj[JP], gf[JP], go[JP], cn[JP], hn[JP];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < JP; ++j) {
         gi[j] = fast_sigmoid(zpre[j][0] + sum[j].x);
         gj[j] = fast_tanh(zpre[j][1] + sum[j].y);
         gf[j] = fast_sigmoid(zpre[j][2] + sum[j].z + a.fb);
@@ -732,9 +741,10 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       if (s + 1 < a.T) {                                 // publish h_t of this tile first, as three bf16 planes
         const __amdgpu_buffer_rsrc_t hxr = image(s + 1);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int jj = 0; jj < JP; ++jj) {
+          const int j = EPW == 2 ? (ew & 1) : jj;
           unsigned hb[3];
-          split3_bits(hn[j], hb[0], hb[1], hb[2]);
+          split3_bits(hn[jj], hb[0], hb[1], hb[2]);
           const int erow = 8 * j + (lane >> 3);
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
@@ -752,21 +762,23 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
-          __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * NSH + (blockIdx.x & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * NSH + ((blockIdx.x * EPW + (ew & (EPW - 1))) & (NSH - 1))) * 32, 1u,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         STAMP(4);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (evalid[j]) {
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = EPW == 2 ? (ew & 1) : jj;
+        if (evalid[jj]) {
           const int brow = T * 16 + 8 * j + (lane >> 3);
           const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
-          if (live[j]) {
+          if (live[jj]) {
             float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
-            zr[0] = gi[j]; zr[H] = gj[j]; zr[2 * H] = gf[j]; zr[3 * H] = go[j];
+            zr[0] = gi[jj]; zr[H] = gj[jj]; zr[2 * H] = gf[jj]; zr[3 * H] = go[jj];
           }
-          a.cs[idx1] = cn[j];
-          a.hs[idx1] = hn[j];
-          if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live[j] ? hn[j] : 0.f;
+          a.cs[idx1] = cn[jj];
+          a.hs[idx1] = hn[jj];
+          if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live[jj] ? hn[jj] : 0.f;
         }
       }
     }
