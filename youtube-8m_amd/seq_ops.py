@@ -296,13 +296,25 @@ FWD_WAVEFRONT_CHUNKS = int(_os.environ.get("YT8M_LSTM_FWD_WAVEFRONT_CHUNKS", "10
 REC_STREAM_PRIORITY = int(_os.environ.get("YT8M_REC_STREAM_PRIORITY", "-1"))
 PERSIST_STEP_IMAGES = _os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0"
 PERSIST_STEP_IMAGES_MAX_BYTES = 8 << 30                 # per layer; larger launches keep the two-image exchange
-_PERSIST_WS = {}      # data_ptr -> workspace tensor of recent persistent launches (for check_persist_errors)
+_PERSIST_WS = {}      # (device, caller's stream, layer, bytes) -> scratch workspace of that layer's persistent launches
+_PERSIST_WS_MAX = 16
 
 
-def _remember_ws(ws):
-    if len(_PERSIST_WS) > 64:
-        _PERSIST_WS.clear()
-    _PERSIST_WS[ws.data_ptr()] = ws
+def _persist_ws(dev, main, l, nbytes):
+    """Scratch of the persistent recurrence launches of layer `l` (control words + exchange images; nothing in it outlives a
+    launch): ONE resident buffer per (device, calling stream, layer, size), reused by every step.  Every launch that touches it is
+    ordered through the calling stream -- a stack's forward and backward both start from an event of that stream and join it
+    before they return -- so two users of one key never overlap on the GPU.  Allocating it per step pinned ~0.6 GB per layer and
+    step (32 steps' worth before the old table was cleared) and put two hipMalloc calls into every backward pass; on some boxes
+    each of those waits ~17 ms on a DMA fence inside the driver, which made the step host-bound (25 -> 38-42 ms)."""
+    key = (dev.index, main.cuda_stream, l, int(nbytes))
+    ws = _PERSIST_WS.get(key)
+    if ws is None:
+        if len(_PERSIST_WS) >= _PERSIST_WS_MAX:                    # other shapes: drop the oldest entry (dicts keep insertion order)
+            _PERSIST_WS.pop(next(iter(_PERSIST_WS)))
+        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)   # zeroed once: a never-launched buffer reads "no error"
+        _PERSIST_WS[key] = ws
+    return ws
 
 
 def check_persist_errors():
@@ -311,7 +323,6 @@ def check_persist_errors():
     lib = _lib.lib()
     for ws in list(_PERSIST_WS.values()):
         _lib.check(lib.yt8m_lstm_persist_status(_p(ws), _stream()))
-    _PERSIST_WS.clear()
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 X3 = _os.environ.get("YT8M_GEMM_X3", "1") != "0"      # hoisted fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
@@ -417,7 +428,7 @@ class _LstmStack(torch.autograd.Function):
                 big = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, tmax)
                 if big <= PERSIST_STEP_IMAGES_MAX_BYTES:
                     pws = big
-            st["pws"] = torch.empty(pws, dtype=torch.uint8, device=dev) if pws else None
+            st["pws"] = _persist_ws(dev, main, l, pws) if pws else None
             layers.append(st)
             inp = st["out"]
         start = torch.cuda.Event()
@@ -503,7 +514,6 @@ class _LstmStack(torch.autograd.Function):
                         _lib.check(lib.yt8m_lstm_persist_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["cs"]), _p(st["hs"]),
                                                              _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _p(st["pws"]),
                                                              st["pws"].numel(), _stream()))
-                        _remember_ws(st["pws"])
                         if PERSIST_CHECK:
                             _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
                     else:
