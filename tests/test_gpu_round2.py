@@ -650,3 +650,37 @@ def test_two_rank_rccl_step_equals_one_rank_on_the_global_batch(dev):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---- no device allocation in a steady-state training step ---------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["LstmModel", "MoeModel"])
+def test_steady_state_step_makes_no_device_allocation(dev, flags, model):
+    """After the first steps every buffer of a training step comes from the caching allocator's pools and the recurrence scratch
+    is the resident one (seq_ops._persist_ws): hipMalloc inside a step can wait on a driver fence for tens of ms and makes the step
+    host-bound.  The allocator's device-allocation counter and its reserved bytes must not move over 6 more steps."""
+    rs = np.random.RandomState(2)
+    V = 23
+    if model == "LstmModel":
+        B, F, D = 32, 24, 64
+        flags.lstm_cells, flags.lstm_pipeline_chunks = "512", 2          # persistent recurrence + x3 products engage
+        x = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
+        nf = torch.from_numpy(rs.randint(1, F + 1, size=B).astype(np.int32)).to(dev)
+        mk = flm.LstmModel
+    else:
+        B, D = 256, 96
+        x = torch.from_numpy(rs.randn(B, D).astype(np.float32)).to(dev)
+        nf = None
+        mk = vlm.MoeModel
+    y = torch.from_numpy(rs.rand(B, V) < 0.2).to(dev)
+    g = reset_default_graph(device=dev, seed=1)
+    tg = train.TrainGraph(mk(), batch_size=B, graph=g)
+    for _ in range(4):
+        tg.step(x, y, nf)
+    torch.cuda.synchronize()
+    ms = torch.cuda.memory_stats()
+    before = (ms.get("num_device_alloc", 0), ms["reserved_bytes.all.current"])
+    for _ in range(6):
+        tg.step(x, y, nf)
+    torch.cuda.synchronize()
+    ms = torch.cuda.memory_stats()
+    assert (ms.get("num_device_alloc", 0), ms["reserved_bytes.all.current"]) == before
