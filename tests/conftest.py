@@ -36,3 +36,15 @@ def dev():
         pytest.skip("no GPU")
     torch.cuda.set_device(0)
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def honour_lstm_chunks():
+    """Tests parametrise the time partition of the LSTM stack (multi-launch recurrences, t0 > 0 paths): make the persistent path
+    follow the caller's `chunks` as the per-step path does.  The product's own partition (1 forward chunk, 3 backward parts) is
+    exercised by test_gpu_x3.py::test_persistent_partition_defaults and by bench.py / smoke()."""
+    import yt8m_amd.seq_ops as seq_ops
+    saved = seq_ops.PERSIST_FWD_CHUNKS, seq_ops.PERSIST_BWD_CHUNKS
+    seq_ops.PERSIST_FWD_CHUNKS = seq_ops.PERSIST_BWD_CHUNKS = 0
+    yield
+    seq_ops.PERSIST_FWD_CHUNKS, seq_ops.PERSIST_BWD_CHUNKS = saved

@@ -237,6 +237,31 @@ def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch)
         assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
 
 
+def test_persistent_partition_defaults(dev, monkeypatch):
+    """The partition the product picks for the persistent kernels (ONE forward launch per layer, THREE backward parts, whatever
+    `chunks` the caller passes) changes how many launches run, not the results: same outputs and gradients as the caller's 2 + 2
+    partition to fp32 rounding; the placement counters see 2 forward + 6 backward launches."""
+    import ctypes
+    import yt8m_amd.seq_ops as seq_ops
+    from test_gpu_round2 import _stack_run
+    lib = L.lib()
+    B, F, D, H = 128, 24, 96, 1024
+    if not lib.yt8m_lstm_persist_supported(B, H):
+        pytest.skip("persistent recurrence not available for this shape / device")
+    nf = torch.randint(0, F + 1, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(5), dtype=torch.int32)
+    nf[0], nf[1] = F, 0
+    nl = ctypes.c_int64(0)
+    ref, gref, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)          # the autouse fixture honours chunks = 2
+    monkeypatch.setattr(seq_ops, "PERSIST_FWD_CHUNKS", 1)
+    monkeypatch.setattr(seq_ops, "PERSIST_BWD_CHUNKS", 3)
+    L.check(lib.yt8m_lstm_persist_placement_stats(None, None, None, 1))
+    a, ga, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)
+    L.check(lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), None, None, 1))
+    assert nl.value == 2 + 6
+    for u, v in zip(a + ga, ref + gref):
+        assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
+
+
 def test_bf16_pipe_forward_recurrence_over_the_full_sequence(dev):
     """F = 300 steps (the BASELINE length) of the forward recurrence with the recurrent product as six bf16 products, against an
     fp64 recurrence on the same inputs: the error does not grow along the sequence (every h_t and the final c within 2e-5),

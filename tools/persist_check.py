@@ -16,6 +16,7 @@ from yt8m_amd.variables import reset_default_graph, xavier_uniform, zeros  # noq
 
 dev = torch.device("cuda:0")
 seq_ops.PERSIST_CHECK = True
+seq_ops.PERSIST_FWD_CHUNKS = seq_ops.PERSIST_BWD_CHUNKS = 0       # this tool times / checks the partition it is given
 MODE = 1 if os.environ.get("PCHECK_FWD_ONLY") else 2      # 1: persistent forward only, 2: forward + backward
 
 

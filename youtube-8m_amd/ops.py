@@ -316,9 +316,11 @@ def gemm_x3_grouped(items):
                                       bias.data_ptr() if bias is not None else None, float(beta)))
         outs.append(out)
         keep.append((A, B, bias))
-    arr = (_lib.GemmProblem * len(probs))(*probs)
     ws = _workspace(outs[0].device)
-    _lib.check(_lib.lib().yt8m_gemm_x3_nt_grouped(len(probs), arr, _p(ws), ws.numel() * 4, _stream()))
+    for i in range(0, len(probs), 4):                               # the library takes 1..4 problems per launch
+        part = probs[i:i + 4]
+        arr = (_lib.GemmProblem * len(part))(*part)
+        _lib.check(_lib.lib().yt8m_gemm_x3_nt_grouped(len(part), arr, _p(ws), ws.numel() * 4, _stream()))
     return outs
 
 

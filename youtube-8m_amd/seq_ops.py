@@ -278,7 +278,7 @@ BWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_BWD_CHUNKS", "0"))    # 0: same part
 BWD_PARTS = [float(v) for v in _os.environ.get("YT8M_LSTM_BWD_PARTS", "").split(",") if v]
 
 
-def _bwd_parts(F, fwd_parts):
+def _bwd_parts(F, fwd_parts, persistent=False):
     if BWD_PARTS:
         tot, edges, acc = sum(BWD_PARTS), [0], 0.0
         for v in BWD_PARTS:
@@ -286,12 +286,23 @@ def _bwd_parts(F, fwd_parts):
             edges.append(min(F, int(round(F * acc / tot))))
         edges[-1] = F
         return [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b > a]
-    return _chunks(F, BWD_CHUNKS) if BWD_CHUNKS > 0 else fwd_parts
+    if BWD_CHUNKS > 0:
+        return _chunks(F, BWD_CHUNKS)
+    if persistent and PERSIST_BWD_CHUNKS > 0:
+        return _chunks(F, PERSIST_BWD_CHUNKS)
+    return fwd_parts
+# Partition of the time axis when the recurrence runs on the persistent kernels (0: the caller's `chunks`).  A whole-chip forward
+# launch leaves no CU for the other layer's projection, so cutting the forward pass only adds launches: ONE chunk.  The backward
+# launches take half the chip and run beside the weight-gradient GEMMs: three parts (shorter lone first / last phases and a
+# shorter GEMM tail than two; BASELINE configs[3], B = 128: 24.3 ms/step against 24.8 with 2 + 2, 24.4 with 1 + 4).
+PERSIST_FWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_PERSIST_FWD_CHUNKS", "1"))
+PERSIST_BWD_CHUNKS = int(_os.environ.get("YT8M_LSTM_PERSIST_BWD_CHUNKS", "3"))
 PERSIST_DBROWS = False
 # half-chip forward recurrences of two layers side by side (opt-in: 24.6 ms/step against 25.3 at B = 128, H = 1024 when the
 # projections share the high-priority layer streams, but one run in three then took 41 ms; with projection streams of their own --
 # what the code does -- it is stable at 27.9)
 FWD_WAVEFRONT = _os.environ.get("YT8M_LSTM_FWD_WAVEFRONT", "0") != "0"
+FWD_WAVEFRONT_SHARED = _os.environ.get("YT8M_LSTM_FWD_WAVEFRONT", "0") == "2"   # projections on the (high-priority) layer streams
 FWD_WAVEFRONT_CHUNKS = int(_os.environ.get("YT8M_LSTM_FWD_WAVEFRONT_CHUNKS", "10"))
 REC_STREAM_PRIORITY = int(_os.environ.get("YT8M_REC_STREAM_PRIORITY", "-1"))
 PERSIST_STEP_IMAGES = _os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0"
@@ -367,7 +378,12 @@ class _LstmStack(torch.autograd.Function):
             F, B = x_tm.shape[0], x_tm.shape[1]
         pers = PERSIST and all(lib.yt8m_lstm_persist_supported(B, h) for h in Hs)
         parts = _chunks(F, chunks)
-        bwd_parts = _bwd_parts(F, parts)
+        # fp32 stack on the persistent kernels: the partition is the stack's own (see PERSIST_FWD_CHUNKS), `chunks` is the caller's
+        # hint for the per-step kernels' layer pipeline
+        own = pers and not bf16 and _os.environ.get("YT8M_PERSIST_CUS") is None
+        if own and PERSIST_FWD_CHUNKS > 0:
+            parts = _chunks(F, PERSIST_FWD_CHUNKS)
+        bwd_parts = _bwd_parts(F, _chunks(F, chunks), own)
         # Wavefront of half-chip forward recurrences (opt-in, see FWD_WAVEFRONT): with the recurrent product on the bf16 pipe a layer's
         # recurrence is bound by its dependency chain, not by matrix time, so two layers can run side by side on half the chip each
         # (8 chains per workgroup) at 11.4 us / step and layer against 8.5 on the whole chip one after the other; finer time chunks
@@ -402,7 +418,7 @@ class _LstmStack(torch.autograd.Function):
         assert (F, B) == tuple(x_tm.shape[:2])
         dev = x_tm.device
         main = torch.cuda.current_stream(dev)
-        rs, gs, _ = _side_streams(dev, L, pers, separate_gemm=half_fwd)
+        rs, gs, _ = _side_streams(dev, L, pers, separate_gemm=half_fwd and not FWD_WAVEFRONT_SHARED)
         ctx.pers = pers
         bf16 = bool(bf16) and B % 2 == 0 and min(T for _, T in parts) * B >= ops.BF16_MIN_ROWS
         drop = input_keep_prob is not None and float(input_keep_prob) < 1.0
