@@ -64,3 +64,38 @@ def test_checkpoint_round_trip_and_rotation(tmp_path):
     sd = load_file(path)
     assert {"gates/weights", "gates/weights/Adam", "gates/weights/Adam_1", "experts/biases", "global_step"} <= set(sd)
     assert tuple(sd["gates/weights"].shape) == (6, 9)
+
+
+def test_lstm_time_partitions(monkeypatch):
+    """Host logic of the LSTM stack's time partition (seq_ops._chunks / _bwd_parts): chunks cover [0, F) exactly once in order;
+    an explicit backward partition (fractions or a count) wins; the persistent path's own backward parts apply only when asked
+    for, and every variant degrades gracefully when F is smaller than the number of parts."""
+    import yt8m_amd.seq_ops as seq_ops
+
+    def covers(parts, F):
+        t = 0
+        for t0, T in parts:
+            assert t0 == t and T > 0
+            t += T
+        assert t == F
+
+    for F in (1, 2, 7, 24, 300, 301):
+        for n in (1, 2, 3, 4, 10, 400):
+            parts = seq_ops._chunks(F, n)
+            covers(parts, F)
+            assert len(parts) <= min(n, F)
+    fwd = seq_ops._chunks(300, 2)
+    monkeypatch.setattr(seq_ops, "BWD_PARTS", [])
+    monkeypatch.setattr(seq_ops, "BWD_CHUNKS", 0)
+    monkeypatch.setattr(seq_ops, "PERSIST_BWD_CHUNKS", 3)
+    assert seq_ops._bwd_parts(300, fwd, False) == fwd                      # per-step kernels: the caller's partition
+    assert seq_ops._bwd_parts(300, fwd, True) == [(0, 100), (100, 100), (200, 100)]
+    covers(seq_ops._bwd_parts(2, seq_ops._chunks(2, 2), True), 2)
+    monkeypatch.setattr(seq_ops, "PERSIST_BWD_CHUNKS", 0)
+    assert seq_ops._bwd_parts(300, fwd, True) == fwd
+    monkeypatch.setattr(seq_ops, "BWD_CHUNKS", 4)
+    assert seq_ops._bwd_parts(300, fwd, True) == seq_ops._chunks(300, 4)
+    monkeypatch.setattr(seq_ops, "BWD_PARTS", [1.0, 2.0, 3.0])
+    parts = seq_ops._bwd_parts(300, fwd, True)
+    assert parts == [(0, 50), (50, 100), (150, 150)]
+    covers(seq_ops._bwd_parts(2, fwd, False), 2)                           # empty parts are dropped
