@@ -68,6 +68,41 @@ def test_x3_split_is_exact(dev):
             assert np.array_equal(row, want), (r, kb)
 
 
+@pytest.mark.parametrize("R,C,scale", [(70, 37, 1.0), (64, 64, 1.0), (129, 1152, 4.0 / 255.0), (33, 16, 1.0)])
+def test_x3_images_equal_the_oracle_bit_for_bit(dev, R, C, scale):
+    """Plain and transposed operand images of yt8m_x3_split against oracle/x3_ref.image (numpy integer rounding): same bytes,
+    padding rows / columns included, with and without the fp32 pre-scale."""
+    from oracle import x3_ref
+    rs = np.random.RandomState(R * 7 + C)
+    x = (rs.randn(R, C) * np.exp(rs.randn(R, C) * 6)).astype(np.float32)
+    x[0, 0], x[R - 1, C - 1] = 0.0, -1.0
+    ip, it = ops.x3_split(torch.from_numpy(x).to(dev), plain=True, trans=True, scale=scale)
+    want_p = x3_ref.image(x, scale=scale)
+    want_t = x3_ref.image(np.ascontiguousarray((x * np.float32(scale)).astype(np.float32).T) if scale != 1.0 else np.ascontiguousarray(x.T))
+    got_p = ip.buf.cpu().numpy().view(np.uint16).reshape(want_p.shape)
+    got_t = it.buf.cpu().numpy().view(np.uint16).reshape(want_t.shape)
+    assert (ip.rows, ip.K, it.rows, it.K) == (R, C, C, R)
+    assert np.array_equal(got_p, want_p)
+    assert np.array_equal(got_t, want_t)
+
+
+def test_gemm_x3_against_the_six_product_oracle(dev):
+    """The device's six-product sum against the oracle's (fp64 accumulation of the same six partial products): they differ only
+    by the fp32 accumulation inside the MFMAs (held to 2^-19 sum |a| |b| here, K = 528) and the oracle itself is within 2^-24
+    sum |a| |b| of the exact product (tests/test_oracle_x3.py)."""
+    from oracle import x3_ref
+    rs = np.random.RandomState(4)
+    M, N, K = 96, 80, 528
+    A = (rs.randn(M, K) * np.exp(rs.randn(M, K) * 2)).astype(np.float32)
+    B = (rs.randn(N, K) * np.exp(rs.randn(N, K) * 2)).astype(np.float32)
+    ia, _ = ops.x3_split(torch.from_numpy(A).to(dev))
+    ib, _ = ops.x3_split(torch.from_numpy(B).to(dev))
+    got = ops.gemm_x3_grouped([dict(A=ia, B=ib)])[0].cpu().numpy().astype(np.float64)
+    want = x3_ref.six_products(A, B)
+    bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+    assert np.all(np.abs(got - want) <= 2.0 ** -19 * bound)       # a plain bf16 product would be off by ~2^-9 of it
+
+
 def test_gemm_dispatch_grouped_equals_single(dev):
     """ops.gemm_grouped decides per problem and the x3 launch splits K per problem: a product launched alone or inside a group
     gives the same bits (the data-parallel path launches the weight-gradient products one by one, the plain step grouped)."""
