@@ -400,14 +400,27 @@ def multitask_cross_entropy_loss(p, support_p, labels, support_labels, support_l
             + cross_entropy_loss(support_p, support_labels) * support_loss_percent)
 
 
-def get_support_label_type(labels, support_type):
-    """W/losses.py:222-257 for support_type made of "label" / "frequent" items (comma list)."""
+def load_vertical_mapping(lines, num_classes, num_verticals):
+    """W/losses.py:233-243: `lines` of text; a line of exactly two integers "class vertical" sets vm[class, vertical] = 1."""
+    vm = np.zeros((num_classes, num_verticals), dtype=np.float64)
+    for line in lines:
+        group = [int(t) for t in line.strip().split()]
+        if len(group) == 2:
+            vm[group[0], group[1]] = 1
+    return vm
+
+
+def get_support_label_type(labels, support_type, num_frequents=200, vertical_mapping=None):
+    """W/losses.py:221-257 for a comma list of "label" (:251-253), "frequent" (:246-250: the first num_frequents classes) and
+    "vertical" (:229-245: labels . vm > 0.2 with the 0/1 class -> vertical table)."""
     outs = []
     for st in support_type.split(","):
         if st == "label":
             outs.append(labels.astype(np.float64))
-        elif st.startswith("frequent"):
-            raise NotImplementedError
+        elif st == "frequent":
+            outs.append(labels[:, :num_frequents].astype(np.float64))
+        elif st == "vertical":
+            outs.append((labels.astype(np.float64) @ np.asarray(vertical_mapping, dtype=np.float64) > 0.2).astype(np.float64))
         else:
             raise NotImplementedError(st)
     return np.concatenate(outs, axis=1)

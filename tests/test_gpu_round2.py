@@ -684,3 +684,31 @@ def test_steady_state_step_makes_no_device_allocation(dev, flags, model):
     torch.cuda.synchronize()
     ms = torch.cuda.memory_stats()
     assert (ms.get("num_device_alloc", 0), ms["reserved_bytes.all.current"]) == before
+
+
+def test_vertical_and_frequent_supports_on_the_device(dev, flags, tmp_path):
+    """support_type = "vertical,frequent,label" (W/losses.py:221-257) on device labels: labels . vm > 0.2 through the HIP GEMM with
+    the table of --vertical_file, the first num_frequents classes, the labels themselves -- equal to the oracle bit for bit; and
+    MultiTaskCrossEntropyLoss on those supports equals the oracle's loss."""
+    import yt8m_amd.losses as losses
+    from oracle import np_ref
+    rs = np.random.RandomState(3)
+    B, V, NV, NFQ = 19, 157, 7, 20
+    lines = ["%d %d" % (c, rs.randint(NV)) for c in range(V) if c % 3 != 2] + ["", "1 2 3"]
+    path = tmp_path / "vertical.tsv"
+    path.write_text("\n".join(lines) + "\n")
+    flags.vertical_file, flags.num_classes, flags.num_verticals, flags.num_frequents = str(path), V, NV, NFQ
+    flags.support_type, flags.support_loss_percent = "vertical,frequent,label", 0.25
+    y = rs.rand(B, V) < 0.05
+    y[0] = False
+    yd = torch.from_numpy(y).to(dev)
+    vm = np_ref.load_vertical_mapping(lines, V, NV)
+    want = np_ref.get_support_label_type(y, "vertical,frequent,label", num_frequents=NFQ, vertical_mapping=vm)
+    got = losses.MultiTaskCrossEntropyLoss().get_support(yd)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (B, NV + NFQ + V)
+    assert np.array_equal(got.cpu().numpy().astype(np.float64), want)
+    p = rs.rand(B, V).astype(np.float32)
+    sp = rs.rand(B, NV + NFQ + V).astype(np.float32)
+    loss = losses.MultiTaskCrossEntropyLoss().calculate_loss(torch.from_numpy(p).to(dev), torch.from_numpy(sp).to(dev), yd)
+    ref = np_ref.multitask_cross_entropy_loss(p.astype(np.float64), sp.astype(np.float64), y, want, 0.25)
+    assert abs(float(loss) - ref) < 1e-5 * abs(ref)

@@ -99,3 +99,30 @@ def test_lstm_time_partitions(monkeypatch):
     parts = seq_ops._bwd_parts(300, fwd, True)
     assert parts == [(0, 50), (50, 100), (150, 150)]
     covers(seq_ops._bwd_parts(2, fwd, False), 2)                           # empty parts are dropped
+
+
+def test_support_label_types(tmp_path, flags):
+    """MultiTaskLoss.get_support (W/losses.py:221-257): the vertical table loader (two-integer lines only) equals the oracle's; the
+    "label" / "frequent" supports -- pure slicing, host tensors allowed -- equal the oracle; an unknown type raises as the
+    reference does."""
+    import numpy as np
+    import pytest
+    import torch
+    import yt8m_amd.losses as losses
+    from oracle import np_ref
+    text = "0 1\n3 2\n\n1 2 3\n5\n3 0\n9 4\n"
+    path = tmp_path / "vertical.tsv"
+    path.write_text(text)
+    vm = losses.load_vertical_mapping(str(path), 10, 5)
+    want = np_ref.load_vertical_mapping(text.splitlines(), 10, 5)
+    assert vm.dtype == np.float32 and np.array_equal(vm, want) and vm.sum() == 4 and vm[3, 0] == vm[3, 2] == vm[9, 4] == 1
+    rs = np.random.RandomState(0)
+    y = rs.rand(6, 10) < 0.3
+    flags.num_frequents = 4
+    got = losses.MultiTaskLoss().get_support(torch.from_numpy(y), "label,frequent,frequent")
+    assert got.dtype == torch.float32
+    assert np.array_equal(got.numpy(), np_ref.get_support_label_type(y, "label,frequent,frequent", num_frequents=4))
+    assert np.array_equal(np_ref.get_support_label_type(y, "vertical", vertical_mapping=want),
+                          (y.astype(np.float64) @ want > 0.2).astype(np.float64))
+    with pytest.raises(NotImplementedError):
+        losses.MultiTaskLoss().get_support(torch.from_numpy(y), "nonsense")

@@ -9,7 +9,9 @@ DEFINE_integer("num_classes", 4716, "number of classes")
 DEFINE_float("support_loss_percent", 0.1, "the part that support loss (in multi-task scenario) take in the whole loss function.")
 DEFINE_string("support_type", "vertical", "type of support label, vertical or frequent or vertical,frequent.")
 DEFINE_integer("num_supports", 25, "Number of total support categories.")
+DEFINE_integer("num_verticals", 25, "Number of total vertical categories.")
 DEFINE_integer("num_frequents", 200, "Number of total frequent categories.")
+DEFINE_string("vertical_file", "resources/vertical.tsv", "Location of label-vertical mapping file.")
 DEFINE_bool("label_smoothing", False, "whether do label smoothing")
 DEFINE_float("label_smoothing_epsilon", 0.1, "whether do label smoothing")
 
@@ -20,6 +22,32 @@ def smoothing(labels):
     y = labels.to(torch.float32)
     prior = y.sum(dim=1, keepdim=True) / y.shape[1]
     return y * (1.0 - epsilon) + prior * epsilon
+
+
+def load_vertical_mapping(path, num_classes, num_verticals):
+    """W/losses.py:233-243: every line holding exactly two integers "class vertical" sets vm[class, vertical] = 1; other lines
+    are skipped (a non-integer token raises, as in the reference).  Returns a float32 numpy array [num_classes, num_verticals]."""
+    import numpy as np
+    vm = np.zeros((num_classes, num_verticals), dtype=np.float32)
+    with open(path) as fh:
+        for line in fh:
+            group = [int(t) for t in line.strip().split()]
+            if len(group) == 2:
+                x, y = group
+                vm[x, y] = 1
+    return vm
+
+
+_VERTICAL_MAPPINGS = {}      # (file, num_classes, num_verticals, device) -> device tensor (the reference's untrainable variable "vm")
+
+
+def _vertical_mapping(device):
+    key = (FLAGS.vertical_file, FLAGS.num_classes, FLAGS.num_verticals, str(device))
+    vm = _VERTICAL_MAPPINGS.get(key)
+    if vm is None:
+        vm = torch.from_numpy(load_vertical_mapping(FLAGS.vertical_file, FLAGS.num_classes, FLAGS.num_verticals)).to(device)
+        _VERTICAL_MAPPINGS[key] = vm
+    return vm
 
 
 class BaseLoss(object):
@@ -54,7 +82,13 @@ class MultiTaskLoss(BaseLoss):
         if support_type == "frequent":
             return labels[:, :FLAGS.num_frequents].to(torch.float32)
         if support_type == "vertical":
-            raise NotImplementedError("vertical supports need resources/vertical.tsv (eda/, out of scope: SURVEY.md 2.1)")
+            # W/losses.py:229-246: labels . vm > 0.2 with vm the 0/1 class -> vertical table of --vertical_file (the file itself
+            # comes from the reference's eda/ tooling, SURVEY.md 2.1: supply it; a missing file raises here as open() does there)
+            float_labels = labels.to(torch.float32).contiguous()
+            if float_labels.shape[1] != FLAGS.num_classes:
+                raise ValueError("labels have %d classes, --num_classes is %d" % (float_labels.shape[1], FLAGS.num_classes))
+            vertical_labels = ops.gemm(float_labels, _vertical_mapping(labels.device))
+            return (vertical_labels > 0.2).to(torch.float32)
         raise NotImplementedError()
 
 
