@@ -126,3 +126,24 @@ def test_support_label_types(tmp_path, flags):
                           (y.astype(np.float64) @ want > 0.2).astype(np.float64))
     with pytest.raises(NotImplementedError):
         losses.MultiTaskLoss().get_support(torch.from_numpy(y), "nonsense")
+
+
+def test_gemm_dispatch_cost_model():
+    """ops._x3_wins (host decision between the six-product bf16-pipe GEMM and the fp32-MFMA kernel): the large products of the
+    BASELINE configurations take the bf16 pipe, tiny / skinny ones do not, empty problems are ignored, and the decision is made
+    per product -- so it cannot depend on how products are grouped into launches (the data-parallel path launches the
+    weight-gradient products one by one, the plain step grouped; tests/test_gpu_x3.py checks the bits)."""
+    import yt8m_amd.ops as ops
+    big = [(19200, 4096, 1152),       # LSTM layer-0 projection of one time chunk
+           (38400, 4096, 1024),       # layer-1 projection, whole sequence
+           (1152, 4096, 12800),       # weight gradient of one backward part
+           (1024, 23580, 1152),       # MoE head at B = 1024
+           (1152, 9432, 1024)]        # its gate weight gradient
+    small = [(128, 64, 64), (8, 4716, 1024), (300, 77, 50), (128, 23580, 16)]
+    for shp in big:
+        assert ops._x3_wins([shp], False, False), shp
+    for shp in small:
+        assert not ops._x3_wins([shp], False, False), shp
+    assert not ops._x3_wins([(0, 4096, 1024)], False, False) and not ops._x3_wins([], False, False)
+    # monotone in every dimension once it wins
+    assert ops._x3_wins([(2 * 19200, 4096, 1152)], False, False) and ops._x3_wins([(19200, 2 * 4096, 1152)], False, False)
