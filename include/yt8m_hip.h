@@ -357,7 +357,11 @@ int yt8m_lstm_layer_bwd(const float* gates, const float* Wh, int64_t ldw, const 
  * per-tile arrival counters; no grid barrier).  Same arguments and semantics as the time-range forms; `workspace`
  * (yt8m_lstm_persist_workspace_bytes) is scratch owned by the caller for the duration of the call chain of one layer.
  * Launches of one device are chained behind each other inside the library (whole-chip residency).
- * yt8m_lstm_persist_status: synchronises `stream` and returns YT8M_E_HIP if a launch on `workspace` gave up waiting. */
+ * The first 128 bytes of `workspace` hold a STICKY error word: zero them once when the buffer is allocated; no launch ever
+ * clears them.  A launch that gives up waiting (bounded spins) sets the word and later launches on the same workspace leave it
+ * alone, so yt8m_lstm_persist_status -- which synchronises `stream`, returns YT8M_E_HIP if ANY launch on `workspace` since the
+ * previous status call gave up, and then clears the word -- cannot miss a time-out of an earlier launch.
+ * yt8m_lstm_persist_debug_fault marks `workspace` exactly as a timed-out launch would (test hook for that path). */
 int yt8m_lstm_persist_supported(int64_t B, int64_t H);
 int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H);
 /* A workspace of this size gives every step of a launch of up to T steps its own exchange image; each state byte is then
@@ -371,6 +375,7 @@ int yt8m_lstm_persist_fwd_on_bf16_pipe(int64_t B, int64_t H);
  * backward).  Two forward launches of neighbouring layers run side by side when each takes half the chip. */
 int yt8m_lstm_persist_set_cus(int fwd_cus, int bwd_cus);
 int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream);
+int yt8m_lstm_persist_debug_fault(void* workspace, yt8m_stream_t stream);
 /* diagnostics: persistent launches / workgroups since the last reset on the current device and how many workgroups did not run on
  * the XCD their block index suggests (a launch that finds CUs busy is placed wherever some are free: correct, but the state fetch
  * loses its L2 sharing).  Synchronises the device. */

@@ -38,13 +38,29 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True)
-def honour_lstm_chunks():
-    """Tests parametrise the time partition of the LSTM stack (multi-launch recurrences, t0 > 0 paths): make the persistent path
-    follow the caller's `chunks` as the per-step path does.  The product's own partition (1 forward chunk, 3 backward parts) is
-    exercised by test_gpu_x3.py::test_persistent_partition_defaults and by bench.py / smoke()."""
+def _set_partition(mode):
     import yt8m_amd.seq_ops as seq_ops
     saved = seq_ops.PERSIST_FWD_CHUNKS, seq_ops.PERSIST_BWD_CHUNKS
-    seq_ops.PERSIST_FWD_CHUNKS = seq_ops.PERSIST_BWD_CHUNKS = 0
+    if mode == "caller":
+        seq_ops.PERSIST_FWD_CHUNKS = seq_ops.PERSIST_BWD_CHUNKS = 0
+    return saved
+
+
+@pytest.fixture()
+def honour_lstm_chunks():
+    """For tests whose SUBJECT is the time partition of the LSTM stack (multi-launch recurrences, t0 > 0 paths, launch counts):
+    makes the persistent path follow the caller's `chunks` as the per-step path does.  Not autouse: every other test
+    runs the product's own partition (1 forward launch per layer, 3 backward parts -- what bench.py and smoke() run)."""
+    import yt8m_amd.seq_ops as seq_ops
+    saved = _set_partition("caller")
     yield
+    seq_ops.PERSIST_FWD_CHUNKS, seq_ops.PERSIST_BWD_CHUNKS = saved
+
+
+@pytest.fixture(params=["product-partition", "callers-chunks"])
+def lstm_partition(request):
+    """Model-level LSTM tests run twice: on the product's default time partition and on the caller's `chunks`."""
+    import yt8m_amd.seq_ops as seq_ops
+    saved = _set_partition("caller" if request.param == "callers-chunks" else "product")
+    yield request.param
     seq_ops.PERSIST_FWD_CHUNKS, seq_ops.PERSIST_BWD_CHUNKS = saved

@@ -137,7 +137,7 @@ def _lstm_ref_layers(tp, L):
 
 @pytest.mark.parametrize("chunks", [1, 4, 10])
 @pytest.mark.parametrize("cls", ["LstmModel", "LstmMemoryModel"])
-def test_lstm_models(dev, flags, cls, chunks):
+def test_lstm_models(dev, flags, cls, chunks, honour_lstm_chunks):
     rs = np.random.RandomState(2)
     B, F, Dm, Hh, V = 6, 10, 12, 8, 17
     flags.lstm_cells, flags.lstm_layers = str(Hh), 2
@@ -162,7 +162,7 @@ def test_lstm_models(dev, flags, cls, chunks):
     check_grads(g, tp, tol=5e-4)
 
 
-def test_lstm_stack_pipelined_equals_sequential(dev, flags):
+def test_lstm_stack_pipelined_equals_sequential(dev, flags, honour_lstm_chunks):
     """The layer-pipelined stack (time chunks on separate streams, fused step kernels: H % 128 == 0) against the same op
     with one chunk: forward results are bit-identical (same kernels, same per-step arithmetic); weight gradients differ only
     by the chunk-wise accumulation order of the hoisted dW GEMMs.  Repeated to catch stream races."""
@@ -757,7 +757,7 @@ def _small_lstm_params(rs, Dm, Hh, V):
 
 
 @pytest.mark.parametrize("chunks,Hh", [(1, 128), (3, 128), (1, 256), (3, 256)])
-def test_lstm_model_bf16_projections(dev, flags, chunks, Hh, monkeypatch):
+def test_lstm_model_bf16_projections(dev, flags, chunks, Hh, monkeypatch, honour_lstm_chunks):
     """--compute_dtype=bfloat16 on LstmModel: the hoisted products of the stack (input projection, dW, dx) take bf16 operands,
     and -- for H % 256 == 0 -- the recurrent product too (csrc/lstm_bf16.hip: bf16 h / dz / W_h operands, fp32 state and
     accumulation).  Predictions stay within bf16 operand noise of the fp32 oracle and every gradient within 6 % of its scale
@@ -891,7 +891,7 @@ def test_deep_combine_chain_with_dropout(dev, flags):
 
 
 @pytest.mark.parametrize("chunks", [1, 4])
-def test_lstm_memory_model_with_dropout_wrapper(dev, flags, chunks):
+def test_lstm_memory_model_with_dropout_wrapper(dev, flags, chunks, honour_lstm_chunks):
     """DropoutWrapper(BasicLSTMCell, input_keep_prob) on both layers (W/all_frame_models/lstm_memory_model.py:36-45): masks on
     the layer inputs only, a fresh one per time step, the recurrent state untouched; chunking does not change the masks."""
     rs = np.random.RandomState(12)

@@ -188,7 +188,7 @@ def _stack_run(dev, B, F, D, H, L_, chunks, nf, persist, seed=0):
     (128, 24, 1152, 1024, 2, 4, True),    # ragged num_frames incl. 0 and F, four chunks
     (512, 6, 128, 1024, 1, 1, True),      # 32 tiles: several per workgroup
 ])
-def test_persistent_lstm_matches_step_kernels(dev, B, F, D, H, L_, chunks, ragged):
+def test_persistent_lstm_matches_step_kernels(dev, B, F, D, H, L_, chunks, ragged, honour_lstm_chunks):
     """Forward outputs / final states and all gradients of the persistent recurrence agree with the per-step kernels (which are
     checked against the oracle elsewhere) to fp32 rounding: the only arithmetic differences are the K summation order and the
     v_exp_f32 / v_rcp_f32 gate non-linearities (<= 1.5e-7 absolute each)."""
@@ -207,7 +207,7 @@ def test_persistent_lstm_matches_step_kernels(dev, B, F, D, H, L_, chunks, ragge
         assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-9
 
 
-def test_persistent_lstm_vs_fp64_oracle_full_width(dev):
+def test_persistent_lstm_vs_fp64_oracle_full_width(dev, lstm_partition):
     """H = 1024 (the BASELINE width) forward AND backward against fp64 autograd of the oracle restatement on three videos'
     worth of rows per tile pattern: B = 20 (two 16-row tiles, the second padded), F = 10, ragged lengths."""
     from oracle import torch_ref
@@ -471,7 +471,7 @@ def test_dbof_model_with_batch_norm_vs_oracle(dev, flags, quantized):
 
 # ---- uint8 operand path of the hoisted LSTM input projection (csrc/u8proj.hip) -----------------------------
 @pytest.mark.parametrize("chunks,B,D", [(1, 10, 72), (3, 10, 72), (1, 32, 64), (3, 32, 64)])
-def test_lstm_uint8_projection_matches_float_path_and_oracle(dev, flags, chunks, B, D):
+def test_lstm_uint8_projection_matches_float_path_and_oracle(dev, flags, chunks, B, D, honour_lstm_chunks):
     """LstmModel on RAW uint8 frames: the layer-0 projection on exact bf16 operands ((q - 128) x 3-way split of (4/255) W) with
     the row-norm / rank-1 epilogue equals (a) the float path (DefaultTransformer first, fp32 GEMM) on the same weights and (b) the
     fp64 oracle on dequantise + l2-normalise, for predictions, loss and all gradients; ragged num_frames incl. 0 and F.

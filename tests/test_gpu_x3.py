@@ -180,7 +180,7 @@ def test_persistent_recurrence_step_images_vs_two_images(dev):
     ref = torch.stack(ref)
     res, fwd0 = [], None
     for nbytes in (lib.yt8m_lstm_persist_workspace_bytes(B, H), lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F)):
-        pws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         z = z0.clone()
         cs = torch.zeros((F + 1, B, H), device=dev)
         hs = torch.zeros((F + 1, B, H), device=dev)
@@ -237,7 +237,7 @@ def test_cu_masked_stream_confines_workgroups(dev):
         L.check(lib.yt8m_stream_destroy(ctypes.c_void_p(h.value)))
 
 
-def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch):
+def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch, honour_lstm_chunks):
     """The opt-in forward wavefront (half-chip forward recurrences of neighbouring layers side by side, finer time chunks, the
     projections on streams of their own) and an explicit CU budget change WHERE the recurrences run, not what they compute: same
     outputs and gradients as the default placement to fp32 rounding; the placement counters see every launch."""
@@ -272,7 +272,7 @@ def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch)
         assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
 
 
-def test_persistent_partition_defaults(dev, monkeypatch):
+def test_persistent_partition_defaults(dev, monkeypatch, honour_lstm_chunks):
     """The partition the product picks for the persistent kernels (ONE forward launch per layer, THREE backward parts, whatever
     `chunks` the caller passes) changes how many launches run, not the results: same outputs and gradients as the caller's 2 + 2
     partition to fp32 rounding; the placement counters see 2 forward + 6 backward launches."""
@@ -286,7 +286,7 @@ def test_persistent_partition_defaults(dev, monkeypatch):
     nf = torch.randint(0, F + 1, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(5), dtype=torch.int32)
     nf[0], nf[1] = F, 0
     nl = ctypes.c_int64(0)
-    ref, gref, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)          # the autouse fixture honours chunks = 2
+    ref, gref, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)          # honour_lstm_chunks: the caller's chunks = 2
     monkeypatch.setattr(seq_ops, "PERSIST_FWD_CHUNKS", 1)
     monkeypatch.setattr(seq_ops, "PERSIST_BWD_CHUNKS", 3)
     L.check(lib.yt8m_lstm_persist_placement_stats(None, None, None, 1))
@@ -325,7 +325,7 @@ def test_bf16_pipe_forward_recurrence_over_the_full_sequence(dev):
         outs.append(torch.where(live, h1, torch.zeros_like(h1)))
     ref = torch.stack(outs)
     nbytes = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F)
-    pws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     z = z0.clone()
     cs = torch.zeros((F + 1, B, H), device=dev)
     hs = torch.zeros((F + 1, B, H), device=dev)

@@ -83,7 +83,7 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
     out = torch.empty((F, B, H), device=dev)
     for it in range(6):
         steps = it >= 3                                 # one exchange image per step (XCD-L2-shared fetch) vs two alternating ones
-        pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
+        pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
                           dtype=torch.uint8, device=dev)
         z = z0.clone()
         torch.cuda.synchronize()
@@ -110,7 +110,7 @@ def timing_bwd(B=128, F=300, H=1024):
     dout = torch.randn((F, B, H), device=dev) * 0.01
     for it in range(6):
         steps = it >= 3
-        pws = torch.empty(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
+        pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
                           dtype=torch.uint8, device=dev)
         work = torch.zeros((4, B, H), device=dev)
         torch.cuda.synchronize()

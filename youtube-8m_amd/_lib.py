@@ -103,6 +103,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_fwd_on_bf16_pipe": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_set_cus": (c_int, [c_int, c_int]),
     "yt8m_lstm_persist_status": (c_int, [P, P]),
+    "yt8m_lstm_persist_debug_fault": (c_int, [P, P]),
     "yt8m_lstm_persist_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),

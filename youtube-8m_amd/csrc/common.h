@@ -57,11 +57,28 @@ struct GraphKey {
   int64_t v[8];
 };
 }  // namespace yt8m
+#include <atomic>
 #include <functional>
 namespace yt8m {
 int run_chain(const GraphKey& key, hipStream_t s, const std::function<int()>& launch_all);
 
 inline hipStream_t as_stream(yt8m_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute and launch functions run on several host threads (one per
+// stream of the layer pipeline): one flag per (call site, device).  Usage: static DeviceOnce once; once.lds(kernel, bytes);
+struct DeviceOnce {
+  std::atomic<bool> done[64];
+  DeviceOnce() { for (auto& d : done) d.store(false); }
+  hipError_t lds(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+    return e;
+  }
+};
 
 inline int launch_status(const char* what) {
   hipError_t e = hipGetLastError();

@@ -350,12 +350,8 @@ int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, void* worksp
     G.S = S;
   }
   const int64_t grid = (int64_t)G.full + (int64_t)G.rem * G.S;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NST * STAGE_F * (int)sizeof(float));
-    once = true;
-  }
+  static DeviceOnce lds_once;
+  YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_bf16_big_kernel), NST * STAGE_F * (int)sizeof(float)));
   hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3((unsigned)grid), dim3(512), NST * STAGE_F * sizeof(float), s, G);
   if (G.S > 1) hipLaunchKernelGGL(bf16_fixup_kernel, dim3((unsigned)G.rem * 16), dim3(256), 0, s, G);
   return launch_status("gemm_bf16_big_kernel");

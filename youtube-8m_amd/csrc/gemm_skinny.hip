@@ -264,14 +264,14 @@ extern "C" int yt8m_skinny_fwd_f32(const float* x, int64_t ldx, const float* W, 
   const unsigned grid = (unsigned)((M + rows_per_wg - 1) / rows_per_wg);
   if (N <= 8) {
     const size_t lds = (size_t)J * 8 * 64 * 4 * sizeof(float);
-    static bool once8 = false;
-    if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once8 = true; }
+    static DeviceOnce once8;
+    YT8M_HIP_CHECK(once8.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), 144 * 1024));
     hipLaunchKernelGGL(skinny_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, (int64_t)1, bias, y, ldy, M, (int)K, (int)N,
                        beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0);
   } else {
     const size_t lds = (size_t)J * 16 * 64 * 4 * sizeof(float);
-    static bool once16 = false;
-    if (!once16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once16 = true; }
+    static DeviceOnce once16;
+    YT8M_HIP_CHECK(once16.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), 144 * 1024));
     hipLaunchKernelGGL(skinny_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, x, ldx, W, ldw, (int64_t)1, bias, y, ldy, M, (int)K, (int)N,
                        beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0);
   }
@@ -377,13 +377,13 @@ extern "C" int yt8m_attn_pool_bwd(const float* w, const float* x, const float* d
     rows_per_wg = (rows_per_wg + 15) / 16 * 16;
     const dim3 grid((unsigned)((F + rows_per_wg - 1) / rows_per_wg), (unsigned)B);
     if (A <= 8) {
-      static bool once = false;
-      if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once = true; }
+      static DeviceOnce once;
+      YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8>), 144 * 1024));
       hipLaunchKernelGGL(skinny_fwd_kernel<8>, grid, dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, x, H, dC, (int64_t)1, H,
                          (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A);
     } else {
-      static bool once = false;
-      if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); once = true; }
+      static DeviceOnce once;
+      YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<16>), 144 * 1024));
       hipLaunchKernelGGL(skinny_fwd_kernel<16>, grid, dim3(256), (size_t)J * 16 * 64 * 4 * sizeof(float), s, x, H, dC, (int64_t)1, H,
                          (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A);
     }

@@ -525,12 +525,8 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   G.ws = static_cast<float*>(workspace);
   const int64_t grid = nfull + slots;
   constexpr int LDS_BYTES = NST * (PA + 3) * PLANE_F * (int)sizeof(float);
-  static bool once = false;
-  if (!once) {
-    YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<PA>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       LDS_BYTES));
-    once = true;
-  }
+  static DeviceOnce lds_once;                                      // per device (a process-wide flag broke cuda:1)
+  YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA>), LDS_BYTES));
   double fl = 0.0;
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
   ProfScope prof(F_GEMM_X3, as_stream(stream), fl);

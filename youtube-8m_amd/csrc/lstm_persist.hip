@@ -115,6 +115,17 @@ __device__ __forceinline__ void check_placement(unsigned* ctl, unsigned* stats) 
   if (k0 != 0u && k0 - 1u != placement_offset()) __hip_atomic_fetch_add(stats, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sticky error word.  ctl[0] is the PER-LAUNCH flag (zeroed with the counters before every launch: a time-out makes the waits of
+// THAT launch fall through and must not poison the next one).  The word the host reads -- yt8m_lstm_persist_status -- is ctl[-32],
+// the first word of the workspace, outside the region a launch zeroes: every workgroup that leaves a timed-out launch ORs the
+// flag into it (one lane, at the end of the kernel), and only the status call clears it.  A time-out in ANY launch since the last
+// status call is therefore reported, whatever ran on the workspace afterwards.
+constexpr int CTL_STICKY = 32;                 // words between the sticky word (workspace word 0) and ctl[0]
+__device__ __forceinline__ void propagate_error(unsigned* ctl) {                        // one lane, at the end of the kernel
+  if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    __hip_atomic_store(ctl - CTL_STICKY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // sum of lanes 0 .. NSH-1 (wave-uniform result)
 __device__ __forceinline__ unsigned shard_sum(unsigned v) {
   unsigned tot = 0;
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
       }
     }
   }
-  if (ew == 0 && lane == 0) check_placement(a.ctl, a.stats);
+  if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
 }
 
 // =====================================================================================================================
@@ -783,7 +794,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       }
     }
   }
-  if (ew == 0 && lane == 0) check_placement(a.ctl, a.stats);
+  if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
 }
 
 // =====================================================================================================================
@@ -1084,7 +1095,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       if (valid) store_std(t1, brow, dzv, dc_out, base_out, half ^ 1);
     }
   }
-  if (ew == 0 && lane == 0) check_placement(a.ctl, a.stats);
+  if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -1203,8 +1214,10 @@ int launch_fwd(const PersistFwdArgs& a, unsigned grid, hipStream_t s) {
 }
 
 constexpr int64_t DBG_BYTES = 65536;     // tail of the workspace: s_memtime stamps of the timing variant
+// workspace head: [sticky error line, 128 B, never zeroed by a launch][control block: zeroed before every launch], padded to 256 B
+constexpr int64_t STICKY_BYTES = CTL_STICKY * 4;
 int64_t ctl_bytes(int NT16) { return (int64_t)(CTL_HDR + NT16 * NSH * 32) * 4; }
-int64_t ctl_padded(int NT16) { return ((ctl_bytes(NT16) + 255) / 256) * 256; }
+int64_t ctl_padded(int NT16) { return ((STICKY_BYTES + ctl_bytes(NT16) + 255) / 256) * 256; }
 // exchange images (of `width` = H forward, 4H backward) that fit in a workspace
 int images_in(int64_t workspace_bytes, int NT16, int64_t width) {
   const int64_t n = (workspace_bytes - ctl_padded(NT16) - DBG_BYTES) / ((int64_t)NT16 * 16 * width * 4);
@@ -1280,8 +1293,24 @@ extern "C" int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t str
   unsigned err = 0;
   YT8M_HIP_CHECK(hipMemcpyAsync(&err, workspace, 4, hipMemcpyDeviceToHost, as_stream(stream)));
   YT8M_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-  if (err != 0) return fail(YT8M_E_HIP, "persistent LSTM launch timed out waiting for a tile%s", "");
+  if (err != 0) {                                        // sticky word: reported once, then cleared
+    YT8M_HIP_CHECK(hipMemsetAsync(const_cast<void*>(workspace), 0, 4, as_stream(stream)));
+    return fail(YT8M_E_HIP, "a persistent LSTM launch on this workspace timed out waiting for a tile since the last status call%s", "");
+  }
   return YT8M_OK;
+}
+
+namespace {
+__global__ void persist_fault_kernel(unsigned* ctl) {   // what a timed-out wait + the kernel's exit path do
+  __hip_atomic_store(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  propagate_error(ctl);
+}
+}  // namespace
+
+extern "C" int yt8m_lstm_persist_debug_fault(void* workspace, yt8m_stream_t stream) {
+  YT8M_REQUIRE(workspace, YT8M_E_BADARG, "null workspace");
+  hipLaunchKernelGGL(persist_fault_kernel, dim3(1), dim3(1), 0, as_stream(stream), static_cast<unsigned*>(workspace) + CTL_STICKY);
+  return launch_status("persist_fault_kernel");
 }
 
 extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
@@ -1296,10 +1325,10 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   YT8M_REQUIRE(workspace_bytes >= yt8m_lstm_persist_workspace_bytes(B, H), YT8M_E_SHAPE, "workspace too small");
   YT8M_REQUIRE(T < (1 << 20), YT8M_E_SHAPE, "T too large");
   hipStream_t s = as_stream(stream);
-  const int64_t cb = ((ctl_bytes(geo.NT16) + 255) / 256) * 256;
+  const int64_t cb = ctl_padded(geo.NT16);
   PersistFwdArgs a;
   a.z = z; a.Wh = Wh; a.ldw = ldw; a.cs = cs; a.hs = hs; a.out = out; a.nf = num_frames;
-  a.ctl = static_cast<unsigned*>(workspace);
+  a.ctl = static_cast<unsigned*>(workspace) + CTL_STICKY;
   a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.fb = forget_bias;
   a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
@@ -1316,7 +1345,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   const int total_cus = device_cus(nullptr);
   int grc = g_gate.admit(dev, (int)grid, total_cus, s);
   if (grc != YT8M_OK) return grc;
-  YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
+  YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
   // the recurrent product on the bf16 pipe (lstm_persist_fwd_x3_kernel) when its preconditions hold: an exchange image (1.5x the
   // fp32 one) per step, >= 2 tiles per workgroup, H in {512, 1024}
   const bool x3 = fwd_x3_shape(H, geo.pf) && images_in(workspace_bytes, geo.NT16, H + H / 2) >= T;
@@ -1403,11 +1432,11 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   YT8M_REQUIRE(workspace_bytes >= yt8m_lstm_persist_workspace_bytes(B, H), YT8M_E_SHAPE, "workspace too small");
   YT8M_REQUIRE(T < (1 << 20), YT8M_E_SHAPE, "T too large");
   hipStream_t s = as_stream(stream);
-  const int64_t cb = ((ctl_bytes(geo.NT16) + 255) / 256) * 256;
+  const int64_t cb = ctl_padded(geo.NT16);
   PersistBwdArgs a;
   a.gates = gates; a.Wh = Wh; a.ldw = ldw; a.cs = cs; a.dout = dout; a.dz = dz; a.work = work; a.nf = num_frames;
   a.dbrows = dbias_rows;
-  a.ctl = static_cast<unsigned*>(workspace);
+  a.ctl = static_cast<unsigned*>(workspace) + CTL_STICKY;
   a.dzx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.phase = phase;
   a.NUB = geo.NUB; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
@@ -1424,7 +1453,7 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   const int total_cus = device_cus(nullptr);
   int grc = g_gate.admit(dev, (int)grid, total_cus, s);
   if (grc != YT8M_OK) return grc;
-  YT8M_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)ctl_bytes(geo.NT16), s));
+  YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
   int rc;
   switch (geo.NQB) {
     case 8: rc = launch_bwd<8>(a, grid, s); break;

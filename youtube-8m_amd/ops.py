@@ -147,7 +147,9 @@ def gemm_grouped(items, transA=False, transB=False):
         keep.append(k)
     ws = _workspace(outs[0].device)
     # decided per problem (not per group), so that a product takes the same kernel whether it is launched alone or grouped
-    use = [X3 and _x3_wins([(pr.M, pr.N, pr.K)], transA, transB) for pr in probs]
+    # (the x3 launch takes beta in {0, 1} and its split pass at most 64 * 65535 rows per operand: anything else stays on the fp32 kernel)
+    use = [X3 and pr.beta in (0.0, 1.0) and max(pr.M, pr.N, pr.K) < 64 * 65535 and _x3_wins([(pr.M, pr.N, pr.K)], transA, transB)
+           for pr in probs]
     px3 = [i for i, u in enumerate(use) if u]
     p32 = [i for i, u in enumerate(use) if not u]
     cache = {}

@@ -1,5 +1,7 @@
 """Frame-axis autograd ops over the C ABI: BasicLSTM layer (whole recurrence in one call), attention weights,
 NetVLAD assignment / aggregation, batched pooling GEMMs.  See include/yt8m_hip.h for the kernel contracts."""
+import ctypes
+
 import torch
 
 from . import _lib, ops
@@ -317,23 +319,47 @@ def _persist_ws(dev, main, l, nbytes):
     ordered through the calling stream -- a stack's forward and backward both start from an event of that stream and join it
     before they return -- so two users of one key never overlap on the GPU.  Allocating it per step pinned ~0.6 GB per layer and
     step (32 steps' worth before the old table was cleared) and put two hipMalloc calls into every backward pass; on some boxes
-    each of those waits ~17 ms on a DMA fence inside the driver, which made the step host-bound (25 -> 38-42 ms)."""
+    each of those waits ~17 ms on a DMA fence inside the driver, which made the step host-bound (25 -> 38-42 ms).
+    The buffer's first line is the sticky error word of include/yt8m_hip.h: zeroed here, once; a buffer is only dropped from the
+    table after its status has been read (a time-out is never lost with the eviction)."""
     key = (dev.index, main.cuda_stream, l, int(nbytes))
-    ws = _PERSIST_WS.get(key)
-    if ws is None:
+    ent = _PERSIST_WS.get(key)
+    if ent is None:
         if len(_PERSIST_WS) >= _PERSIST_WS_MAX:                    # other shapes: drop the oldest entry (dicts keep insertion order)
-            _PERSIST_WS.pop(next(iter(_PERSIST_WS)))
-        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)   # zeroed once: a never-launched buffer reads "no error"
-        _PERSIST_WS[key] = ws
-    return ws
+            old = next(iter(_PERSIST_WS))
+            _check_ws(*_PERSIST_WS.pop(old))
+            global _PERSIST_EVICTIONS
+            _PERSIST_EVICTIONS += 1
+            if _PERSIST_EVICTIONS in (64, 1024):                     # a model cycling through > 16 shapes re-zeroes ~0.6 GB per miss
+                import warnings
+                warnings.warn("yt8m_amd: %d persistent-recurrence workspaces evicted; raise seq_ops._PERSIST_WS_MAX" % _PERSIST_EVICTIONS)
+        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)   # zeroed once: the sticky error word starts clear
+        ent = (ws, main)
+        _PERSIST_WS[key] = ent
+    return ent[0]
+
+
+_PERSIST_EVICTIONS = 0
+
+
+def _check_ws(ws, stream):
+    """Reads (and clears) the sticky error word of one workspace on ITS device and the stream its launches are ordered through."""
+    with torch.cuda.device(ws.device):
+        _lib.check(_lib.lib().yt8m_lstm_persist_status(_p(ws), ctypes.c_void_p(stream.cuda_stream)))
 
 
 def check_persist_errors():
-    """Synchronises and raises if any recent persistent-recurrence launch gave up waiting for a tile (bounded spins set an error
-    word instead of hanging the GPU).  The training loop calls this at its checkpoints; tests run with PERSIST_CHECK per launch."""
-    lib = _lib.lib()
-    for ws in list(_PERSIST_WS.values()):
-        _lib.check(lib.yt8m_lstm_persist_status(_p(ws), _stream()))
+    """Synchronises and raises if ANY persistent-recurrence launch since the previous check gave up waiting for a tile (bounded
+    spins set a sticky error word instead of hanging the GPU; no later launch clears it).  The training loop calls this at its
+    checkpoints; tests run with PERSIST_CHECK per launch."""
+    err = None
+    for ws, stream in list(_PERSIST_WS.values()):
+        try:
+            _check_ws(ws, stream)
+        except _lib.Yt8mHipError as e:                               # read (= clear) every word before raising
+            err = e
+    if err is not None:
+        raise err
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 X3 = _os.environ.get("YT8M_GEMM_X3", "1") != "0"      # hoisted fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
@@ -487,62 +513,64 @@ class _LstmStack(torch.autograd.Function):
         r_done = [[torch.cuda.Event() for _ in parts] for _ in range(L)]
         if half_fwd:
             _lib.check(lib.yt8m_lstm_persist_set_cus(torch.cuda.get_device_properties(dev).multi_processor_count // 2, -1))
-        for c, (t0, T) in enumerate(parts):
-            for l, st in enumerate(layers):
-                Din, H = st["Din"], st["H"]
-                with torch.cuda.stream(gs[l]):                      # hoisted input projection of the chunk
-                    if l > 0:
-                        gs[l].wait_event(r_done[l - 1][c])
-                    if drop:
-                        xc = st["x"][t0:t0 + T]
-                        src = x_tm[t0:t0 + T] if l == 0 else xc
-                        _lib.check(lib.yt8m_dropout_f32(_p(src), _p(xc), xc.numel(), float(input_keep_prob), int(seeds[l]),
-                                                        t0 * B * Din, _stream()))
-                    if "W3T" in st and Qimg is not None:
-                        zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
+        try:
+            for c, (t0, T) in enumerate(parts):
+                for l, st in enumerate(layers):
+                    Din, H = st["Din"], st["H"]
+                    with torch.cuda.stream(gs[l]):                      # hoisted input projection of the chunk
+                        if l > 0:
+                            gs[l].wait_event(r_done[l - 1][c])
+                        if drop:
+                            xc = st["x"][t0:t0 + T]
+                            src = x_tm[t0:t0 + T] if l == 0 else xc
+                            _lib.check(lib.yt8m_dropout_f32(_p(src), _p(xc), xc.numel(), float(input_keep_prob), int(seeds[l]),
+                                                            t0 * B * Din, _stream()))
+                        if "W3T" in st and Qimg is not None:
+                            zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
+                            ws = ops._workspace(dev)
+                            _lib.check(lib.yt8m_gemm_x1x3_nt(T * B, 4 * H, Din, _p(Qimg[(t0 * B // 32) * (Din // 16) * 1024:]), _p(st["W3T"].buf),
+                                                             _p(zc), 4 * H, _p(st["b"].data), _p(rrow[t0 * B:]), _p(st["Wcs"]), U8_BETA,
+                                                             _p(ws), ws.numel() * 4, _stream()))
+                        elif "W3T" in st:
+                            zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
+                            ops.gemm_bf16_nt_grouped([dict(A=Qb[t0 * B:(t0 + T) * B], B=st["W3T"], out=zc)])
+                            _lib.check(lib.yt8m_rowscale_bias_f32(_p(zc), T * B, 4 * H, 4 * H, _p(rrow[t0 * B:]), _p(st["Wcs"]),
+                                                                  U8_BETA, _p(st["b"].data), _stream()))
+                        elif st["bf16"]:
+                            ops.gemm_bf16_nt_grouped([dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din)), B=st["WxT"],
+                                                           out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
+                        elif st["x3"]:
+                            xi = ops.x3_split(st["x"][t0:t0 + T].view(T * B, Din))[0]
+                            ops.gemm_x3_grouped([dict(A=xi, B=st["WxT3"], out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
+                        else:
+                            ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
+                                     bias=st["b"].data)
+                        g_ev = torch.cuda.Event()
+                        g_ev.record(gs[l])
+                    with torch.cuda.stream(rs[l]):                      # recurrence steps of the chunk
+                        rs[l].wait_event(g_ev)
                         ws = ops._workspace(dev)
-                        _lib.check(lib.yt8m_gemm_x1x3_nt(T * B, 4 * H, Din, _p(Qimg[(t0 * B // 32) * (Din // 16) * 1024:]), _p(st["W3T"].buf),
-                                                         _p(zc), 4 * H, _p(st["b"].data), _p(rrow[t0 * B:]), _p(st["Wcs"]), U8_BETA,
-                                                         _p(ws), ws.numel() * 4, _stream()))
-                    elif "W3T" in st:
-                        zc = st["z"][t0:t0 + T].view(T * B, 4 * H)
-                        ops.gemm_bf16_nt_grouped([dict(A=Qb[t0 * B:(t0 + T) * B], B=st["W3T"], out=zc)])
-                        _lib.check(lib.yt8m_rowscale_bias_f32(_p(zc), T * B, 4 * H, 4 * H, _p(rrow[t0 * B:]), _p(st["Wcs"]),
-                                                              U8_BETA, _p(st["b"].data), _stream()))
-                    elif st["bf16"]:
-                        ops.gemm_bf16_nt_grouped([dict(A=ops.cast_bf16(st["x"][t0:t0 + T].view(T * B, Din)), B=st["WxT"],
-                                                       out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
-                    elif st["x3"]:
-                        xi = ops.x3_split(st["x"][t0:t0 + T].view(T * B, Din))[0]
-                        ops.gemm_x3_grouped([dict(A=xi, B=st["WxT3"], out=st["z"][t0:t0 + T].view(T * B, 4 * H), bias=st["b"].data)])
-                    else:
-                        ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), st["W"].data[:Din], out=st["z"][t0:t0 + T].view(T * B, 4 * H),
-                                 bias=st["b"].data)
-                    g_ev = torch.cuda.Event()
-                    g_ev.record(gs[l])
-                with torch.cuda.stream(rs[l]):                      # recurrence steps of the chunk
-                    rs[l].wait_event(g_ev)
-                    ws = ops._workspace(dev)
-                    if st["rec16"]:
-                        _lib.check(lib.yt8m_lstm_steps_fwd_bf16(_p(st["z"]), _p(st["Wp16"]), _p(st["cs"]), _p(st["hs"]), _p(st["hs16"]),
-                                                                _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _stream()))
-                    elif st["pws"] is not None:
-                        _lib.check(lib.yt8m_lstm_persist_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["cs"]), _p(st["hs"]),
-                                                             _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _p(st["pws"]),
-                                                             st["pws"].numel(), _stream()))
-                        if PERSIST_CHECK:
-                            _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
-                    else:
-                        _lib.check(lib.yt8m_lstm_steps_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["Wp"]), _p(st["cs"]),
-                                                           _p(st["hs"]), _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias),
-                                                           _p(ws), ws.numel() * 4, _stream()))
-                    r_done[l][c].record(rs[l])
+                        if st["rec16"]:
+                            _lib.check(lib.yt8m_lstm_steps_fwd_bf16(_p(st["z"]), _p(st["Wp16"]), _p(st["cs"]), _p(st["hs"]), _p(st["hs16"]),
+                                                                    _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _stream()))
+                        elif st["pws"] is not None:
+                            _lib.check(lib.yt8m_lstm_persist_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["cs"]), _p(st["hs"]),
+                                                                 _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias), _p(st["pws"]),
+                                                                 st["pws"].numel(), _stream()))
+                            if PERSIST_CHECK:
+                                _lib.check(lib.yt8m_lstm_persist_status(_p(st["pws"]), _stream()))
+                        else:
+                            _lib.check(lib.yt8m_lstm_steps_fwd(_p(st["z"]), _p(st["W"].data[Din:]), 4 * H, _p(st["Wp"]), _p(st["cs"]),
+                                                               _p(st["hs"]), _p(st["out"]), _p(nf), t0, T, B, H, float(forget_bias),
+                                                               _p(ws), ws.numel() * 4, _stream()))
+                        r_done[l][c].record(rs[l])
+        finally:
+            if half_fwd:                                        # process-wide CU budget: restored whatever happens in the loop
+                _lib.check(lib.yt8m_lstm_persist_set_cus(-1, -1))
         for l in range(L):
             main.wait_event(r_done[l][-1])
         # the backward pass may cut time differently (all buffers are whole-layer): its first recurrence chunk runs with nothing
         # beside it, so shorter chunks shorten that pipeline fill; the forward recurrence owns the chip and wants few launches
-        if half_fwd:
-            _lib.check(lib.yt8m_lstm_persist_set_cus(-1, -1))
         ctx.layers, ctx.nf, ctx.parts = layers, nf, bwd_parts
         ctx.drop = (float(input_keep_prob), tuple(int(v) for v in seeds)) if drop else None
         ctx.set_materialize_grads(False)
