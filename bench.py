@@ -44,7 +44,7 @@ LSTM_H, LSTM_L = 1024, 2
 PEAK_F32_MATRIX_TFLOPS = 157.3
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by bf16 VARIANT lines
 PEAK_HBM_GBS = 8000.0
-FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3"]
+FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3", "gemm_x1x3"]
 X3_PRODUCTS = 6.0                    # bf16 MFMA products per fp32 product in csrc/gemm_x3.hip
 
 
@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[2] / bf16-variant extra lines")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="lower bound of the cpu_baseline sample (it also runs >= --cpu-steps steps)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the cpu_baseline leg at least (SURVEY.md 8d: >= 10)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's arithmetic (the headline).  bf16 = bf16 MFMA operands, fp32 accumulate / "
                          "master weights / Adam: a separately labelled line, never the headline.")
@@ -206,47 +207,75 @@ def family_times(lib, steps):
     return fam
 
 
-def family_peak(name, bf16, bwd_cus=None, fwd_x3=False):
-    """(peak TFLOP/s, what it is) of the pipe a family's dominant kernel runs on."""
-    if name == "lstm_recurrence" and fwd_x3:
-        return PEAK_BF16_MATRIX_TFLOPS / X3_PRODUCTS, ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d products per fp32 product "
-                                                       "(v_mfma_f32_16x16x32_bf16 on three-plane splits of h and W_h)"
-                                                       % (PEAK_BF16_MATRIX_TFLOPS, X3_PRODUCTS))
+def family_peak(name, bf16, fwd_x3=False):
+    """(chip-level peak TFLOP/s, what it is) of the matrix pipe a family's kernels ISSUE on, in the units its algorithmic FLOPs are
+    counted in (fp32-equivalent FLOPs: a family that spends k bf16 / f16 MFMA products per fp32 product has peak 2500 / k).
+    VERDICT r2: never price a bf16-pipe kernel against the fp32 peak, nor the other way round."""
+    bfp = PEAK_BF16_MATRIX_TFLOPS
     if name == "gemm_x3":
-        return PEAK_BF16_MATRIX_TFLOPS / X3_PRODUCTS, ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d products per fp32 product "
-                                                       "(v_mfma_f32_32x32x16_bf16 on three-plane split operands)" % (PEAK_BF16_MATRIX_TFLOPS, X3_PRODUCTS))
-    if name == "lstm_recurrence_bwd" and bwd_cus:
-        return PEAK_F32_MATRIX_TFLOPS * bwd_cus / 256.0, ("fp32 MFMA peak of the %d CUs the backward recurrence is launched on (the rest of "
-                                                          "the chip runs the weight-gradient GEMMs beside it)" % bwd_cus)
+        return bfp / X3_PRODUCTS, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / %d products per fp32 product "
+                                   "(v_mfma_f32_32x32x16_bf16 on three-plane split operands)" % (bfp, X3_PRODUCTS))
+    if name == "gemm_x1x3":
+        return bfp / 3.0, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (one exact bf16 plane "
+                           "-- uint8 frames minus 128 -- against a three-plane split operand)" % bfp)
+    if name == "netvlad":
+        if bf16:
+            return bfp, "f16 MFMA pipe, one product per element pair (v_mfma_f32_16x16x32_f16, nsplit = 1): dense peak"
+        return bfp / 2.0, ("f16 MFMA pipe, fp32-equivalent: dense peak %.0f / 2 products per fp32 product (exact f16 (q - 128) "
+                           "against the f16 hi + lo split of the fp32 operand)" % bfp)
+    if name == "lstm_recurrence":
+        if bf16:
+            return bfp, "bf16 MFMA pipe (lstm_step_fwd16_kernel: bf16 h / W_h operands, one product): dense peak"
+        if fwd_x3:
+            return bfp / X3_PRODUCTS, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / %d products per fp32 product "
+                                       "(v_mfma_f32_16x16x32_bf16 on three-plane splits of h and W_h)" % (bfp, X3_PRODUCTS))
+    if name == "lstm_recurrence_bwd" and bf16:
+        return bfp, "bf16 MFMA pipe (lstm_step_bwd16_kernel: bf16 dz / W_h operands, one product): dense peak"
     if bf16 and name == "gemm":
-        return PEAK_BF16_MATRIX_TFLOPS, "dense bf16 MFMA peak"
-    return PEAK_F32_MATRIX_TFLOPS, "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"
+        return bfp, "bf16 MFMA pipe: dense peak"
+    return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA pipe (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): dense peak of the whole chip"
 
 
-def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False):
+def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False, step_ms=None):
     """Dominant family = the one with the largest hipEvent time among the MFMA families that have an algorithmic FLOP count
     (declared by the library at launch time for the GEMM and recurrence entry points, else the workload's formula).
-    achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch)."""
+    achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch).
+    `frac` is ALWAYS against the whole chip's peak of the pipe the family issues on; a family whose launches occupy only part
+    of the chip (the half-chip backward recurrence) also reports `frac_of_occupied_cus` next to it.
+    `blended_bound`: sum over the MFMA families of (algorithmic FLOPs / chip peak of their pipe) = the time the step's matrix
+    work would take with every pipe at its peak and nothing overlapped, against the measured wall time of a step."""
     rows = {}
     for name, v in fam.items():
         f = v.get("declared_flops_per_step") or flops.get(name)
         if f and v["ms_per_step"] > 0:
-            peak, what = family_peak(name, bf16, bwd_cus, fwd_x3)
+            peak, what = family_peak(name, bf16, fwd_x3)
             ach = f / (v["ms_per_step"] * 1e-3) / 1e12
             rows[name] = {"achieved": ach, "peak": peak, "peak_is": what, "frac": ach / peak, "ms_per_step": v["ms_per_step"],
                           "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
                           "algorithmic_flops_per_step": f,
                           "algorithmic_flops_per_launch": f / max(v["launches_per_step"], 1e-9)}
+            if name == "lstm_recurrence_bwd" and bwd_cus and not bf16 and bwd_cus < 256:
+                rows[name]["occupied_cus"] = bwd_cus
+                rows[name]["frac_of_occupied_cus"] = ach / (peak * bwd_cus / 256.0)
+                rows[name]["occupancy_note"] = ("launched on %d of 256 CUs (two of them run side by side for part of the backward pass, "
+                                                "the weight-gradient GEMMs take the other CUs): `frac` is against the WHOLE chip" % bwd_cus)
     if not rows:
         return None
     dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
     r = rows[dom]
     roof = {"bound": "mfma", "kernel": dom, "achieved": r["achieved"], "peak": r["peak"], "peak_is": r["peak_is"], "unit": "TFLOP/s",
-            "frac": r["frac"], "traffic": None,
+            "frac": r["frac"], "traffic": None, "traffic_source": None,
             "launches_per_step": r["launches_per_step"], "avg_launch_ms": r["avg_launch_ms"],
             "algorithmic_flops_per_launch": r["algorithmic_flops_per_launch"],
             "families": rows,
             "other_families": {k: v for k, v in fam.items() if k not in rows}}
+    for k in ("occupied_cus", "frac_of_occupied_cus", "occupancy_note"):
+        if k in r:
+            roof[k] = r[k]
+    bound_ms = sum(v["algorithmic_flops_per_step"] / (v["peak"] * 1e12) * 1e3 for v in rows.values())
+    roof["blended_bound"] = {"ms_per_step": bound_ms,
+                             "is": "sum over the MFMA families of algorithmic FLOPs / whole-chip peak of the pipe each issues on",
+                             "frac": (bound_ms / step_ms) if step_ms else None}
     if extra_note:
         roof["note"] = extra_note
     return roof
@@ -377,7 +406,7 @@ def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None):
     steps = steps or (200 if probe < 5e-3 else max(10, min(50, int(1.0 / probe))))
     el, run = timed_run(tg, pool, steps, warmup or 3, 1, dev, None)
     fam = profile_pass(lib, run, min(steps, 10), 0)
-    roof = roofline_from(fam, cfg["flops"](B), bf16)
+    roof = roofline_from(fam, cfg["flops"](B), bf16, step_ms=el / steps * 1e3)
     if roof is None and fam:
         roof = {"families": {}, "other_families": fam}
     if workload == "netvlad" and fam and "netvlad" in fam:
@@ -507,12 +536,17 @@ def _pick_threads(probe_fn):
     return best, usable
 
 
-def cpu_baseline(workload, seconds):
+def cpu_baseline(workload, seconds, min_steps=10):
     """Times the torch-CPU fp32 restatement of the same training step on the host cores (a reported baseline, not a
-    target; TF1 itself is not runnable here).  Bounded sample: reduced batch for the frame-level step.  Thread count: the
-    best of {all usable cores, 64, 32, 16} on a cheap probe (oversubscribed MKL is far slower)."""
+    target; TF1 itself is not runnable here).  Bounded sample: reduced batch for the frame-level step (its time per step barely
+    depends on B below ~16: every frame re-streams the 35 MB cell weights and accumulates a 35 MB weight gradient, as the
+    reference's while_loop does), at least `min_steps` timed steps.  Thread count: the best of {all usable cores, 64, 32, 16} on a
+    cheap probe for the video-level step; 32 for the frame-level one (oversubscribed MKL is far slower on its small products) --
+    the same step on ALL usable cores is timed beside it (`all_cores`, 2 steps)."""
     from oracle import torch_ref
     gen = torch.Generator().manual_seed(1)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    allc = None
     if workload == "moe":
         B = 1024
         x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
@@ -528,11 +562,17 @@ def cpu_baseline(workload, seconds):
         y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
         nf = torch.full((B,), FRAMES, dtype=torch.int32)
         st = torch_ref.LstmTrainStepCPU(D=D_IN, H=LSTM_H, L=LSTM_L, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
-        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = min(usable, 32)                                     # the per-frame products are small: more threads lose
-        torch.set_num_threads(cores)
         stepf = lambda: st.step(q, nf, y)
         what = "fp32 LstmModel (2x1024, F=300) + MoE head training step"
+        if usable > cores:                                          # the all-cores number beside it
+            torch.set_num_threads(usable)
+            stepf()
+            t0 = time.perf_counter()
+            stepf()
+            stepf()
+            allc = {"cores": usable, "value": 2 * B / (time.perf_counter() - t0), "unit": "videos/s", "steps": 2}
+        torch.set_num_threads(cores)
     else:
         return None
     stepf()                                          # warm-up
@@ -541,11 +581,26 @@ def cpu_baseline(workload, seconds):
         stepf()
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
+        if (el >= seconds and n >= min_steps) or n >= 200:
             break
-    return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port",
+    return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port", "timed_steps": n, "batch": B, "seconds": el,
+            "usable_cores": usable, "all_cores": allc,
             "sample": "%d steps of the same %s at B=%d on torch-CPU (oracle/torch_ref.py; TF1 itself is not runnable "
-                      "here), %.1f s, %d usable cores" % (n, what, B, el, usable)}
+                      "here), %.1f s, %d threads of %d usable cores" % (n, what, B, el, cores, usable)}
+
+
+def library_identity():
+    """Which library produced the numbers: path (YT8M_LIB overrides the in-tree build), sha256 of the file, and every YT8M_*
+    environment variable of the process -- tuning / timing-experiment builds and knobs must be visible in the line."""
+    import hashlib
+    import yt8m_amd._lib as L
+    h = hashlib.sha256()
+    with open(L.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return {"path": os.path.relpath(L.LIB_PATH, ROOT) if L.LIB_PATH.startswith(ROOT) else L.LIB_PATH,
+            "in_tree_default": os.path.abspath(L.LIB_PATH) == os.path.join(ROOT, "youtube-8m_amd", "libyt8m_hip.so"),
+            "sha256": h.hexdigest(), "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("YT8M_")}}
 
 
 def main():
@@ -593,20 +648,25 @@ def main():
                 bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
             fwd_x3 = (a.workload == "lstm" and not bf16 and os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0" and
                       bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H)))
-            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3)
+            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / a.steps * 1e3)
             if a.workload == "moe" and B == 1024 and not bf16 and roof:
                 try:                   # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_traffic.md)
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
                     ks = [v for k, v in pm["kernels"].items() if k.startswith("gemm_grouped_kernel")]
                     roof["traffic"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in ks) / len(ks)
                     roof["traffic_unit"] = "bytes/launch (L2-miss side, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.md)"
+                    roof["traffic_source"] = "profiles/r1_pmc_traffic.json -- a committed rocprofv3 --pmc pass, NOT measured in this run"
                     roof["algorithmic_bytes_per_launch"] = 4.0 * (B * D_IN + D_IN * VOCAB * (2 * MIX + 1) + B * VOCAB * (2 * MIX + 1))
                 except Exception:
                     pass
             elif a.workload == "lstm" and roof:
                 try:                   # PMC passes of the headline step, committed with the round's profiles
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_lstm.json")))
+                    src = next(f for f in ("r3_pmc_traffic_lstm.json", "r2_pmc_traffic_lstm.json")
+                               if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                    pm = json.load(open(os.path.join(ROOT, "profiles", src)))
                     key = roof["kernel"]
+                    roof["traffic_source"] = ("profiles/%s -- committed rocprofv3 --pmc passes of this workload (tools/pmc_run_lstm.py), "
+                                              "NOT measured in this run" % src)
                     roof["traffic"] = pm["families"][key]["hbm_bytes_per_launch"]
                     roof["traffic_unit"] = pm["unit"]
                     roof["traffic_kernel"] = pm["families"][key]["kernel"]
@@ -617,10 +677,9 @@ def main():
                 # whole-step view: every algorithmic FLOP of the step over the WALL time of the timed region (the families above
                 # are hipEvent durations of launches that share the chip across streams, so they overlap and add up to more)
                 tot = sum(cfg["flops"](B).values())
-                roof["step_level"] = {"algorithmic_flops_per_step": tot, "achieved": tot / (el / a.steps) / 1e12,
-                                      "frac": tot / (el / a.steps) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS),
-                                      "frac_is": "all algorithmic FLOPs of the step over wall time, against the dense %s MFMA peak"
-                                                 % ("bf16" if bf16 else "fp32")}
+                roof["step_level"] = {"algorithmic_flops_per_step": tot, "achieved": tot / (el / a.steps) / 1e12, "unit": "TFLOP/s",
+                                      "is": "all algorithmic (fp32-equivalent) FLOPs of the step over wall time: a rate, not a roofline "
+                                            "fraction -- the step's products run on two pipes; see blended_bound"}
     del tg, g, pool
     torch.cuda.empty_cache()
 
@@ -634,13 +693,15 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.workload, a.cpu_seconds)
+        cpu = cpu_baseline(a.workload, a.cpu_seconds, a.cpu_steps)
 
     gap = None
     if rank == 0 and world == 1 and not a.no_gap and not bf16:
         try:
             gap = gap_leg(dev)
             gap["cpu_twin"] = gap_twin(dev)
+            # the same acceptance check at the FULL model size (D = 1152, V = 4716; fewer steps: the CPU port trains them in seconds)
+            gap["cpu_twin_full_size"] = gap_twin(dev, D_=D_IN, V_=VOCAB, M_=MIX, B_=256, steps=24, held=2048)
         except Exception as e:                                    # never let the secondary metric break the bench line
             gap = {"value": None, "error": repr(e)}
 
@@ -660,7 +721,8 @@ def main():
                                          "fp32 values throughout; large matrix products run on the bf16 MFMA pipe as six exact partial "
                                          "products of a three-plane bf16 split of both operands with fp32 accumulation (error <= the "
                                          "rounding of an fp32 FMA; YT8M_GEMM_X3=0 / YT8M_PERSIST_X3=0 select the fp32 MFMA kernels)")},
-               "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement}
+               "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement,
+               "library": library_identity()}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -26,7 +26,8 @@ const char* yt8m_last_error(void);
 const char* yt8m_built_arch(void);
 
 /* ---- profiling hooks used by bench.py (roofline leg): per-kernel-family hipEvent timing -------- */
-/* family ids: 0 gemm_f32, 1 moe_head_fused, 2 elementwise, 3 optimizer, 4 lstm, 5 netvlad */
+/* family ids: 0 gemm_f32 (and the plain bf16 GEMMs), 1 moe_head_fused, 2 elementwise, 3 optimizer, 4 lstm (forward recurrence),
+ * 5 netvlad, 6 lstm backward recurrence, 7 gemm_x3 (six bf16 products per fp32 product), 8 gemm_x1x3 (three) */
 int yt8m_prof_enable(int on);
 int yt8m_prof_reset(void);
 /* synchronises the device; returns launches and total ms for a family */

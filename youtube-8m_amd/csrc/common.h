@@ -35,7 +35,8 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
 
 // ---- per-family hipEvent profiling (bench.py roofline leg) -----------------------------------
 enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LSTM = 4, F_NETVLAD = 5, F_LSTM_BWD = 6, F_GEMM_X3 = 7,
-              F_COUNT = 8 };
+              F_GEMM_X1X3 = 8,   // x3 kernel with a ONE-plane A operand (three bf16 products per fp32 product)
+              F_COUNT = 9 };
 
 struct ProfScope {
   int fam;

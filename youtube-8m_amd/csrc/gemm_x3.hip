@@ -529,7 +529,7 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA>), LDS_BYTES));
   double fl = 0.0;
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
-  ProfScope prof(F_GEMM_X3, as_stream(stream), fl);
+  ProfScope prof(PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3, as_stream(stream), fl);
   hipLaunchKernelGGL(gemm_x3_kernel<PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
   if (fix > 0) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
