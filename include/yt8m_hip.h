@@ -111,6 +111,19 @@ int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
 int yt8m_gemm_x1x3_nt(int64_t M, int64_t N, int64_t K, const void* A1, const void* B3, float* C, int64_t ldc, const float* bias,
                       const float* rowscale, const float* colsum, float colsum_scale, void* workspace, int64_t workspace_bytes,
                       yt8m_stream_t stream);
+/* General form of the one-plane product: C[M,N] (+)= alpha * rowscale[m] * (A1 . B3^T + colsum_scale * colsum[n]) + bias[n];
+ * rowscale / colsum may be NULL independently.  ska / skb: 16-wide K blocks between consecutive 32-row groups of either image
+ * (0: the image is exactly K wide) -- a product may read a K RANGE of a larger image (A1 / B3 then point at the first block of the
+ * range and K % 16 == 0).  The same convention holds for yt8m_gemm_problem.lda / .ldb in yt8m_gemm_x3_nt_grouped.
+ * Use: the layer-0 weight gradient of the recurrent models on raw uint8 frames (W/readers.py:178-187 folded into the gradient
+ * of W/all_frame_models/lstm_model.py:34-47): dW_x = alpha ((q - 128)^T . (r (.) dz) + (beta / alpha) colsum(r (.) dz)). */
+int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B3, int64_t skb, float* C,
+                         int64_t ldc, const float* bias, float alpha, const float* rowscale, const float* colsum,
+                         float colsum_scale, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* yt8m_x3_split with a third output from the same pass: trans_scaled = x3 image of (diag(rowscale) . scale . src)^T
+ * ([C rows, K = R]; rowscale [R]).  Any image may be NULL; rowscale and trans_scaled come together. */
+int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
+                     void* trans, void* trans_scaled, yt8m_stream_t stream);
 /* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows].
  * dst_ld: row stride of dst in bf16 elements (0 = dense).  The training path pads it to a multiple of 8 so that every bf16
  * row starts 16-byte aligned and the GEMMs stay on their LDS-DMA path (V*(M+1) = 14148 is not a multiple of 8). */
@@ -280,6 +293,10 @@ int yt8m_act_bwd_f32(int act, const float* y, const float* dy, float* dx, int64_
 int64_t yt8m_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta, void* workspace,
                     int64_t workspace_bytes, yt8m_stream_t stream);
+/* Two column sums from one pass: out[c] (+)= sum_r X[r][c] (beta 0 / 1) and out_weighted[c] = sum_r row_weights[r] X[r][c]
+ * (overwritten).  workspace: 2 * yt8m_colsum_workspace_bytes(rows, cols), may be NULL. */
+int yt8m_colsum_weighted_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, const float* row_weights, float* out, float beta,
+                             float* out_weighted, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
 /* ---- loss: CrossEntropyLoss (W/losses.py:110-130), probability space, eps = 1e-5 ---------------
  * loss = mean_b sum_l -[y log(p+eps) + (1-y) log(1-p+eps)] * (w_b);  dp = dloss/dp * upstream.
@@ -393,6 +410,47 @@ int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, cons
                           float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                           int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
+/* ---- the whole recurrent stack as two calls (csrc/lstm_stack.hip; SURVEY.md 8(b): yt8m_lstm_fwd / yt8m_lstm_bwd) --------------
+ * MultiRNNCell([BasicLSTMCell(H)] * L) under tf.nn.dynamic_rnn(sequence_length = num_frames) and its gradient
+ * (W/all_frame_models/lstm_model.py:34-47, lstm_memory_model.py:36-52 without DropoutWrapper; W/train.py:435-466), with the
+ * reader's dequantise + l2-normalise (W/readers.py:178-187, W/train.py:343-344) folded into the layer-0 products when the input
+ * is the raw uint8 [B,F,D] batch.  The time partition, the stream layout (one high-priority stream per layer + one for the weight
+ * gradients, created once per device inside the library), the bf16-pipe product forms and all operand images are the library's:
+ * this is the path bench.py measures.  The caller owns two buffers:
+ *   tape    (yt8m_lstm_stack_tape_bytes)    activations kept from forward to backward; read them with yt8m_lstm_stack_view
+ *   scratch (yt8m_lstm_stack_scratch_bytes) everything else; ZERO IT ONCE after allocation (its head holds the sticky time-out
+ *           words of the persistent recurrence, see yt8m_lstm_persist_status) and keep it for the life of the model
+ * both 256-byte aligned.  All work is ordered after what `stream` holds at the call and `stream` waits for all of it before the
+ * call returns (asynchronously: nothing synchronises the host).  W[l]: [Din_l + H, 4H] row-major (Din_0 = D, else H), b[l]: [4H].
+ * yt8m_lstm_stack_supported: 1 if the description is covered (else 0 and yt8m_last_error says why; use the per-call entry points). */
+typedef struct yt8m_lstm_stack_desc {
+  int64_t B, F, D, H;     /* videos, frames, input features, cells per layer */
+  int32_t L;              /* layers, 1..8 */
+  int32_t input_u8;       /* 1: x = raw uint8 [B,F,D] (batch-major, as the reader hands it over); 0: float [F,B,D] (time-major) */
+  float forget_bias;
+  int32_t fwd_chunks;     /* time partition of the forward pass; 0 = the library's (1: one persistent launch per layer) */
+  int32_t bwd_chunks;     /* ... of the backward pass; 0 = the library's (3 parts) */
+  int32_t need_dx;        /* backward also produces dL/dx [F,B,D] (float input only) */
+} yt8m_lstm_stack_desc;
+int yt8m_lstm_stack_supported(const yt8m_lstm_stack_desc* desc);
+int64_t yt8m_lstm_stack_tape_bytes(const yt8m_lstm_stack_desc* desc);
+int64_t yt8m_lstm_stack_scratch_bytes(const yt8m_lstm_stack_desc* desc);
+int yt8m_lstm_stack_partition(const yt8m_lstm_stack_desc* desc, int* fwd_chunks, int* bwd_chunks);
+int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W,
+                        const float* const* b, void* tape, int64_t tape_bytes, void* scratch, int64_t scratch_bytes,
+                        yt8m_stream_t stream);
+/* which: 0 outputs of `layer` [F,B,H] (time-major, zeros beyond num_frames), 1 final c [B,H], 2 final h [B,H], 3 gates [F,B,4H] */
+int yt8m_lstm_stack_view(const yt8m_lstm_stack_desc* desc, void* tape, int layer, int which, float** out);
+/* dout_top [F,B,H] (may be NULL), dc_final / dh_final: L pointers to [B,H] (arrays or entries may be NULL);
+ * dW[l] [Din_l + H, 4H], db[l] [4H] (entries may be NULL), beta_W / beta_b: L host floats, 0 = overwrite, 1 = accumulate (NULL: 0);
+ * dx [F,B,D] when need_dx.  x and num_frames: the forward call's. */
+int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W, void* tape,
+                        int64_t tape_bytes, void* scratch, int64_t scratch_bytes, const float* dout_top,
+                        const float* const* dc_final, const float* const* dh_final, float* const* dW, float* const* db,
+                        const float* beta_W, const float* beta_b, float* dx, yt8m_stream_t stream);
+/* YT8M_E_HIP if any persistent launch of the stack gave up waiting since the previous status call.  Synchronises `stream`. */
+int yt8m_lstm_stack_status(const yt8m_lstm_stack_desc* desc, void* scratch, yt8m_stream_t stream);
+
 /* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the
  * re-packed recurrent weights owned by the caller (yt8m_lstm_pack; yt8m_lstm_packed_floats() floats each for the forward
  * image Wp and the backward image Wq; 0 = shape not covered, pass NULL and the generic per-step GEMM path runs).
@@ -494,6 +552,10 @@ int yt8m_u8_frames_to_bf16_tm(const uint8_t* q, const int32_t* num_frames, int64
  * f * B + b; D % 16 == 0) instead of bf16 copies */
 int yt8m_u8_frames_image(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
                          float* x_tm, float* r_out, yt8m_stream_t stream);
+/* (q - 128)^T as a ONE-plane x3 operand image: rows = features (D), K = time-major frame rows f * B + b (zeros for padding frames);
+ * ceil(D / 32) * ceil(B F / 16) KiB.  The A operand of yt8m_gemm_x1x3_nt_ex for the layer-0 weight gradient. */
+int yt8m_u8_frames_image_t(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, void* image_t,
+                           yt8m_stream_t stream);
 int yt8m_split3_bf16_t(const float* W, int64_t ldw, int64_t K, int64_t N, float scale, void* out, int64_t ldo,
                        yt8m_stream_t stream);
 int yt8m_rowscale_bias_f32(float* z, int64_t M, int64_t N, int64_t ldz, const float* r, const float* cs, float beta,

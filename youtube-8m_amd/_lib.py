@@ -15,6 +15,15 @@ class GemmProblem(ctypes.Structure):
                 ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64), ("bias", c_void_p), ("beta", c_float)]
 
 
+class LstmStackDesc(ctypes.Structure):
+    """yt8m_lstm_stack_desc (include/yt8m_hip.h)."""
+    _fields_ = [("B", c_int64), ("F", c_int64), ("D", c_int64), ("H", c_int64), ("L", ctypes.c_int32), ("input_u8", ctypes.c_int32),
+                ("forget_bias", c_float), ("fwd_chunks", ctypes.c_int32), ("bwd_chunks", ctypes.c_int32), ("need_dx", ctypes.c_int32)]
+
+
+DESC = ctypes.POINTER(LstmStackDesc)
+PP = ctypes.POINTER(c_void_p)      # array of device pointers
+
 # name -> (restype, argtypes); one row per function declared in include/yt8m_hip.h
 SIGNATURES = {
     "yt8m_abi_version": (c_int, []),
@@ -38,6 +47,19 @@ SIGNATURES = {
     "yt8m_x3_split": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "yt8m_gemm_x3_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_gemm_x1x3_nt": (c_int, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, P, P, c_float, P, c_int64, P]),
+    "yt8m_gemm_x1x3_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, c_float, c_float, P,
+                                     c_int64, P]),
+    "yt8m_x3_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
+    "yt8m_u8_frames_image_t": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),
+    "yt8m_lstm_stack_supported": (c_int, [DESC]),
+    "yt8m_lstm_stack_tape_bytes": (c_int64, [DESC]),
+    "yt8m_lstm_stack_scratch_bytes": (c_int64, [DESC]),
+    "yt8m_lstm_stack_partition": (c_int, [DESC, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "yt8m_lstm_stack_fwd": (c_int, [DESC, P, P, PP, PP, P, c_int64, P, c_int64, P]),
+    "yt8m_lstm_stack_view": (c_int, [DESC, P, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "yt8m_lstm_stack_bwd": (c_int, [DESC, P, P, PP, P, c_int64, P, c_int64, P, PP, PP, PP, PP, ctypes.POINTER(c_float),
+                                    ctypes.POINTER(c_float), P, P]),
+    "yt8m_lstm_stack_status": (c_int, [DESC, P, P]),
     "yt8m_u8_frames_image": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, P, P, P, P]),
     "yt8m_cast_f32_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int, P]),
     "yt8m_cast_f32_bf16_dual": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P]),
@@ -85,6 +107,7 @@ SIGNATURES = {
     "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),
     "yt8m_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_colsum_f32": (c_int, [P, c_int64, c_int64, c_int64, P, c_float, P, c_int64, P]),
+    "yt8m_colsum_weighted_f32": (c_int, [P, c_int64, c_int64, c_int64, P, P, c_float, P, P, c_int64, P]),
     "yt8m_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_xent_fwd_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P, P]),
     "yt8m_xent_bwd": (c_int, [P, P, c_int, P, P, P, c_int64, c_int64, c_float, c_float, P]),

@@ -193,6 +193,43 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
 }
 
+// Two column sums from one pass: out[col] = sum_r X[r][col] and outw[col] = sum_r w[r] X[r][col] (the bias gradient and the
+// rank-1 term of the layer-0 weight gradient on uint8 frames).  Same decomposition and fixed summation order as colsum_kernel.
+__global__ __launch_bounds__(1024) void colsum2_kernel(const float* __restrict__ X, const float* __restrict__ w, int64_t rows_total,
+                                                       int64_t cols, int64_t ldx, float* __restrict__ out, float* __restrict__ outw,
+                                                       int accumulate, int64_t rows_per) {
+  __shared__ float red[2][16][65];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  if (gridDim.y > 1) {
+    X += (int64_t)blockIdx.y * rows_per * ldx;
+    w += (int64_t)blockIdx.y * rows_per;
+    out += (int64_t)blockIdx.y * cols;
+    outw += (int64_t)blockIdx.y * cols;
+  }
+  const int64_t rows = gridDim.y > 1 ? min(rows_per, rows_total - (int64_t)blockIdx.y * rows_per) : rows_total;
+  float s = 0.f, sw = 0.f;
+  if (col < cols) {
+    int64_t r = rg;
+    for (; r + 48 < rows; r += 64) {
+      const float a = X[r * ldx + col], b = X[(r + 16) * ldx + col], d = X[(r + 32) * ldx + col], e = X[(r + 48) * ldx + col];
+      s += (a + b) + (d + e);
+      sw += (a * w[r] + b * w[r + 16]) + (d * w[r + 32] + e * w[r + 48]);
+    }
+    for (; r < rows; r += 16) { const float a = X[r * ldx + col]; s += a; sw += a * w[r]; }
+  }
+  red[0][rg][c] = s;
+  red[1][rg][c] = sw;
+  __syncthreads();
+  if (rg < 2 && col < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[rg][k][c];
+    float* o = rg == 0 ? out : outw;
+    o[col] = (accumulate && rg == 0) ? o[col] + t : t;             // only the plain sum accumulates (bias gradient over chunks)
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nsplit, int64_t cols,
                                                             float* __restrict__ out, int accumulate) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -683,6 +720,39 @@ extern "C" int yt8m_cast_f32_bf16_dual(const float* src, int64_t rows, int64_t c
 extern "C" int64_t yt8m_colsum_workspace_bytes(int64_t rows, int64_t cols) {
   (void)rows;
   return cols > 0 ? 256 * cols * (int64_t)sizeof(float) : 0;
+}
+
+// out[col] (+)= sum_r X[r][col] (beta 0 / 1) and out_weighted[col] = sum_r row_weights[r] X[r][col] (always overwritten) from one
+// pass over X.  workspace: 2 * yt8m_colsum_workspace_bytes(rows, cols).
+extern "C" int yt8m_colsum_weighted_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, const float* row_weights, float* out,
+                                        float beta, float* out_weighted, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0 && ldx >= cols, YT8M_E_SHAPE, "bad shape");
+  YT8M_REQUIRE(beta == 0.f || beta == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  if (cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(out && out_weighted && ((X && row_weights) || rows == 0), YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t colblocks = (cols + 63) / 64;
+  int64_t nsplit = 1;
+  if (workspace && colblocks < 512 && rows >= 4096) {
+    nsplit = std::min<int64_t>(std::min<int64_t>(256, (1024 + colblocks - 1) / colblocks), rows / 1024);
+    if (2 * nsplit * cols * (int64_t)sizeof(float) > workspace_bytes) nsplit = 1;
+  }
+  if (nsplit <= 1) {
+    hipLaunchKernelGGL(colsum2_kernel, dim3((unsigned)colblocks), dim3(1024), 0, s, X, row_weights, rows, cols, ldx, out, out_weighted,
+                       beta != 0.f ? 1 : 0, rows);
+  } else {
+    const int64_t rows_per = (rows + nsplit - 1) / nsplit;
+    nsplit = (rows + rows_per - 1) / rows_per;
+    float* p0 = static_cast<float*>(workspace);
+    float* p1 = p0 + nsplit * cols;
+    hipLaunchKernelGGL(colsum2_kernel, dim3((unsigned)colblocks, (unsigned)nsplit), dim3(1024), 0, s, X, row_weights, rows, cols, ldx, p0, p1,
+                       0, rows_per);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, p0, (int)nsplit, cols, out,
+                       beta != 0.f ? 1 : 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, p1, (int)nsplit, cols, out_weighted, 0);
+  }
+  return launch_status("colsum2_kernel");
 }
 
 extern "C" int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, float* out, float beta, void* workspace,

@@ -43,14 +43,28 @@ struct XArgs {
   float* C;
   const float* bias;
   int64_t ldc;
-  int M, N, KB;         // KB: 16-wide K blocks
+  int M, N, KB;         // KB: 16-wide K blocks of THIS product
+  int ska, skb;         // K blocks between consecutive 32-row groups of the A / B image (= KB unless the product reads a K range
+                        // of a larger image: the weight-gradient products of one time chunk out of whole-sequence images)
   int tiles_m, tiles_n;
   int accumulate;
-  // optional affine epilogue (the uint8 input projection): C = rscale[m] * (acc + cs_scale * cs[n]) + bias[n]
+  // optional affine epilogue (the uint8 operand paths): C = alpha * rscale[m] * (acc + cs_scale * cs[n]) + bias[n]
+  // (rscale NULL: 1; cs NULL: no rank-1 term).  Forward projection: rscale = 1 / ||x_m||, cs = colsum(W), cs_scale = beta;
+  // layer-0 weight gradient: alpha = 4/255, cs = colsum(r (.) dz), cs_scale = beta / alpha.
   const float* rscale;
   const float* cs;
   float cs_scale;
+  float alpha;
 };
+__device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int col) {
+  if (g.cs) {                                                        // (N % 4 == 0 and 16-byte aligned cs: checked by the host)
+    const float4 cv = *reinterpret_cast<const float4*>(g.cs + col);
+    v.x += g.cs_scale * cv.x; v.y += g.cs_scale * cv.y; v.z += g.cs_scale * cv.z; v.w += g.cs_scale * cv.w;
+  }
+  if (g.rscale) { const float rs = g.rscale[row]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+  if (g.alpha != 1.0f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+  return v;
+}
 // Work items of a launch: problem q contributes its first full[q] tiles (whole rounds of 256 workgroups) unsplit, then the
 // rem[q] tiles of its last, partial round as rem[q] * S[q] K-part items, part major -- the wave-quantisation tail costs a fraction
 // of a round instead of a whole one.  full / rem / S come from the shape of problem q ALONE, so a product is summed in the same
@@ -132,8 +146,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
   const int nk = kb1 - kb0;
   // this wave's 32-row group of either operand tile (groups beyond the matrix only feed outputs that are never stored)
-  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.KB * (PA * RG_F) + lane * 4;
-  const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.KB * (3 * RG_F) + lane * 4;
+  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska * (PA * RG_F) + lane * 4;
+  const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.skb * (3 * RG_F) + lane * 4;
 #define X3_FILL(KBI, STAGE) { fill_op<PA>(pa, KBI, (STAGE), tid); fill_op<3>(pb, KBI, (STAGE) + OPA_F, tid); }
   constexpr int DMA = PA + 3;                                      // LDS-DMA instructions per thread and K-step
 
@@ -288,12 +302,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
       float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
       if (row < g.M && col < g.N) {
         float* c = g.C + (int64_t)row * g.ldc + col;
-        if (g.rscale) {                                            // (N % 4 == 0 and 16-byte aligned cs: checked by the host)
-          const float rs = g.rscale[row];
-          const float4 cv = *reinterpret_cast<const float4*>(g.cs + col);
-          v.x = rs * (v.x + g.cs_scale * cv.x); v.y = rs * (v.y + g.cs_scale * cv.y);
-          v.z = rs * (v.z + g.cs_scale * cv.z); v.w = rs * (v.w + g.cs_scale * cv.w);
-        }
+        if (g.rscale || g.cs) v = affine(g, v, row, col);
         if (vec && col + 3 < g.N) {
           if (g.bias) {
             const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
@@ -339,12 +348,7 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
     }
     const int row = m0 + e / TN, col = n0 + (e % TN);
     if (row >= g.M) continue;
-    if (g.rscale && col + 3 < g.N) {
-      const float rs = g.rscale[row];
-      const float4 cv = *reinterpret_cast<const float4*>(g.cs + col);
-      v.x = rs * (v.x + g.cs_scale * cv.x); v.y = rs * (v.y + g.cs_scale * cv.y);
-      v.z = rs * (v.z + g.cs_scale * cv.z); v.w = rs * (v.w + g.cs_scale * cv.w);
-    }
+    if ((g.rscale || g.cs) && col + 3 < g.N) v = affine(g, v, row, col);
     const float vv[4] = {v.x, v.y, v.z, v.w};
     float* c = g.C + (int64_t)row * g.ldc + col;
 #pragma unroll
@@ -396,8 +400,11 @@ __device__ __forceinline__ void store_block(const float (&v)[16], float* __restr
 
 // src [R, Cc] fp32 (row stride ld), 64 x 64 tiles through LDS; plain image: rows = R, K = Cc; trans image: rows = Cc, K = R.
 // Either destination may be null.  scale multiplies every element before the split (1.0f: none).
+// rowscale / trans_s (both or neither): a second transposed image whose element (c, r) is rowscale[r] * scale * src[r][c] -- the
+// operand r (.) dz of the layer-0 weight gradient on uint8 frames -- from the same pass over src.
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
-                                                       float* __restrict__ trans, float scale) {
+                                                       float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
+                                                       float* __restrict__ trans_s) {
   __shared__ float T[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
@@ -433,14 +440,22 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
       store_block(v, plain + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
     }
   }
-  if (trans) {
+  if (trans || trans_s) {
     const int KB = (R + 15) >> 4;
     const int row = c0 + a, kb = (r0 >> 4) + blk;
     if (row < ((Cc + 31) & ~31) && kb < KB) {
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = T[blk * 16 + j][a];
-      store_block(v, trans + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+      if (trans) store_block(v, trans + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+      if (trans_s) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int r = r0 + blk * 16 + j;
+          v[j] *= r < R ? rowscale[r] : 0.f;
+        }
+        store_block(v, trans_s + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+      }
     }
   }
 }
@@ -464,14 +479,32 @@ extern "C" int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld,
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
-                     static_cast<float*>(trans), scale);
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr);
+  return launch_status("x3_split_kernel");
+}
+
+// The same pass with a third output: trans_scaled = the x3 image of (diag(rowscale) . scale . src)^T ([C rows, K = R]); any of the
+// three images may be NULL (rowscale and trans_scaled come together).
+extern "C" int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
+                                void* trans, void* trans_scaled, yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans || trans_scaled), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE((rowscale != nullptr) == (trans_scaled != nullptr), YT8M_E_BADARG, "rowscale and trans_scaled come together");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans) | reinterpret_cast<uintptr_t>(trans_scaled)) & 15) == 0,
+               YT8M_E_BADARG, "x3 images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled));
   return launch_status("x3_split_kernel");
 }
 
 namespace {
 template <int PA>
-int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, void* workspace,
-              int64_t workspace_bytes, yt8m_stream_t stream) {
+int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, float alpha,
+              void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   XGroup G;
   G.nprob = 0;
   constexpr int SLOTS = 256;                                       // one 144 KiB workgroup per CU
@@ -488,9 +521,14 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     g.A = static_cast<const float*>(q.A); g.B = static_cast<const float*>(q.B); g.C = q.C; g.bias = q.bias;
     g.ldc = q.ldc;
     g.M = (int)q.M; g.N = (int)q.N; g.KB = (int)((q.K + 15) / 16);
+    // lda / ldb of an x3 problem: K blocks between the 32-row groups of the image (0: the image holds exactly this K range)
+    YT8M_REQUIRE(q.lda >= 0 && q.ldb >= 0 && q.lda < (1LL << 30) && q.ldb < (1LL << 30) && (q.lda == 0 || q.lda >= g.KB) &&
+                 (q.ldb == 0 || q.ldb >= g.KB), YT8M_E_BADARG, "bad image K-block stride");
+    YT8M_REQUIRE((q.lda <= g.KB && q.ldb <= g.KB) || (q.K % 16) == 0, YT8M_E_SHAPE, "a K range of a larger image must be a multiple of 16");
+    g.ska = q.lda ? (int)q.lda : g.KB; g.skb = q.ldb ? (int)q.ldb : g.KB;
     g.tiles_m = (int)((q.M + TM - 1) / TM); g.tiles_n = (int)((q.N + TN - 1) / TN);
     g.accumulate = q.beta != 0.f;
-    g.rscale = rscale; g.cs = cs; g.cs_scale = cs_scale;
+    g.rscale = rscale; g.cs = cs; g.cs_scale = cs_scale; g.alpha = alpha;
     // the last, partial round of this problem alone: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp)
     // + the fixup pass
     const int64_t T = (int64_t)g.tiles_m * g.tiles_n;
@@ -541,7 +579,7 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
 extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                                        yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
-  return x3_launch<3>(nprob, probs, nullptr, nullptr, 0.f, workspace, workspace_bytes, stream);
+  return x3_launch<3>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream);
 }
 
 // The uint8 input projection: C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n], A a ONE-plane image (elements
@@ -554,5 +592,23 @@ extern "C" int yt8m_gemm_x1x3_nt(int64_t M, int64_t N, int64_t K, const void* A1
                "the affine epilogue needs N % 4 == 0 and a 16-byte aligned colsum");
   yt8m_gemm_problem p;
   p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = 0; p.B = B3; p.ldb = 0; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = 0.f;
-  return x3_launch<1>(1, &p, rowscale, colsum, colsum_scale, workspace, workspace_bytes, stream);
+  return x3_launch<1>(1, &p, rowscale, colsum, colsum_scale, 1.0f, workspace, workspace_bytes, stream);
+}
+
+// General form: C[M,N] (+)= alpha * rowscale[m] * (A1 . B3^T + colsum_scale * colsum[n]) + bias[n]; rowscale / colsum may be NULL
+// independently; ska / skb = K blocks (of 16) between the 32-row groups of either image (0: the image is exactly K wide), so a
+// product may read a K range of whole-sequence images (A1 / B3 then point at the first block of the range; K % 16 == 0).
+// The layer-0 weight gradient of the recurrent models on raw uint8 frames is this product:
+//   dW_x[d,n] = sum_m x[m,d] dz[m,n],  x = r (.) (alpha (q - 128) + beta)
+//             = alpha ( (q - 128)^T . (r (.) dz) + (beta / alpha) colsum(r (.) dz) )
+// with A1 = the transposed one-plane image of q - 128 (yt8m_u8_frames_image_t), B3 = the transposed x3 image of r (.) dz
+// (yt8m_x3_split_ex), beta = 1 to accumulate over time chunks (W/readers.py:178-187 folded into W/train.py's gradient).
+extern "C" int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B3, int64_t skb, float* C,
+                                    int64_t ldc, const float* bias, float alpha, const float* rowscale, const float* colsum,
+                                    float colsum_scale, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(!(rowscale || colsum) || (N % 4) == 0, YT8M_E_SHAPE, "the affine epilogue needs N % 4 == 0");
+  YT8M_REQUIRE(!colsum || (reinterpret_cast<uintptr_t>(colsum) & 15) == 0, YT8M_E_SHAPE, "colsum must be 16-byte aligned");
+  yt8m_gemm_problem p;
+  p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = ska; p.B = B3; p.ldb = skb; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
+  return x3_launch<1>(1, &p, rowscale, colsum, colsum_scale, alpha, workspace, workspace_bytes, stream);
 }

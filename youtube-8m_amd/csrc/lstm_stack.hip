@@ -1,0 +1,431 @@
+// lstm_stack.hip -- the whole MultiRNNCell([BasicLSTMCell] * L) under tf.nn.dynamic_rnn as TWO library calls (forward, backward):
+// W/all_frame_models/lstm_model.py:34-47 (lstm_memory_model.py:36-52 without its DropoutWrapper) and the gradient tf.gradients
+// builds through them (W/train.py:435-466), SURVEY.md section 8(b) last row, VERDICT r2 #9.
+//
+// Everything the measured headline step does for its recurrent stack lives here, behind the C ABI: the time partition (one
+// forward launch per layer, three backward parts), the stream layout (one HIGH-priority stream per layer for its projection /
+// recurrence / dx chain, one stream for the weight-gradient products), the events between them, the operand images of the
+// bf16-pipe GEMMs (csrc/gemm_x3.hip) and the choice of product form.  A host binds three functions and owns two buffers
+// (tape = activations kept for the backward pass, scratch = everything else); nothing is allocated in here.
+//
+// Data path of one training step (B videos, F frames, D features, H cells; rows are TIME-major m = f * B + b):
+//   forward   raw uint8 frames -> ONE conversion pass: (q - 128) as a one-plane bf16 operand image + row norms r (csrc/u8proj.hip;
+//             the dequantise + l2-normalise of W/readers.py:178-187 / W/train.py:343-344 never materialises an fp32 copy)
+//             layer 0:  z = r (.) ((q - 128) . (alpha W_x) + beta colsum(W_x)) + b     three exact bf16 products   (x1x3)
+//             layer l:  z = out_{l-1} . W_x + b                                        six bf16 products           (x3)
+//             recurrence: one persistent launch per (layer, chunk)                     (csrc/lstm_persist.hip)
+//   backward  per time part, last to first, top layer first:
+//             recurrence (half chip) -> dz;  dx = dz . W_x^T (x3, releases the layer below);  on the weight-gradient stream:
+//             dW_h += h^T dz, dW_x += out_{l-1}^T dz (x3, K ranges of whole-sequence transposed images made ONCE per step while the
+//             first lone recurrence runs), db += colsum(dz);
+//             layer 0 on uint8 frames: dW_x += alpha ((q - 128)^T . (r (.) dz) + (beta / alpha) colsum(r (.) dz))   (x1x3: three
+//             products instead of six, and the fp32 time-major copy of the frames the round-2 path kept for it is gone).
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+using namespace yt8m;
+
+namespace {
+
+constexpr int MAXL = 8, MAXP = 64;
+constexpr float U8_ALPHA = 4.0f / 255.0f;
+constexpr float U8_BETA = 128.0f * (4.0f / 255.0f) + (4.0f / 512.0f - 2.0f);   // dequantise(q) = alpha (q - 128) + beta
+constexpr int64_t X3_MIN_ROWS = 1024;                      // F * B below which the fp32-MFMA kernel's smaller tiles win (seq_ops.py)
+constexpr int64_t STEP_IMAGES_MAX_BYTES = 8LL << 30;       // per layer; larger launches keep the two-image exchange
+
+int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct Part { int64_t t0, T; };
+int chunks(int64_t F, int n, Part* out) {
+  if (n < 1) n = 1;
+  if (n > F) n = (int)F;
+  if (n > MAXP) n = MAXP;
+  const int64_t step = (F + n - 1) / n;
+  int k = 0;
+  for (int64_t t0 = 0; t0 < F; t0 += step) out[k++] = {t0, std::min(step, F - t0)};
+  return k;
+}
+
+struct Plan {
+  int64_t B, F, D, H, FB;
+  int L, u8, need_dx;
+  int nf, nb;
+  Part fp[MAXP], bp[MAXP];
+  // tape (bytes from its base)
+  int64_t z[MAXL], cs[MAXL], hs[MAXL], out[MAXL], rrow, tape_bytes;
+  // scratch
+  int64_t pws[MAXL], pws_bytes;                            // persistent-recurrence workspaces: FIRST in the scratch (zero once)
+  int64_t gws[MAXL + 1], gws_bytes;                        // split-K workspace per layer stream + weight-gradient stream
+  int64_t qimg, w3t, wcs, wxt3[MAXL], xi[MAXL];            // forward operand images
+  int64_t dz[MAXL], dbuf[MAXL], work[MAXL];                // backward: dz [F,B,4H], dout of the layer below [F,B,H], running (dh, dc)
+  int64_t dz3[MAXL], wx3[MAXL], dzT3, dzT3s, csr, dbdummy; // chunk images
+  int64_t xT[MAXL], hT[MAXL];                              // whole-sequence transposed images (layer input / h_{t-1})
+  int64_t scratch_bytes;
+};
+
+int64_t x3_bytes(int64_t rows, int64_t K) { return yt8m_x3_image_bytes(rows, K); }
+int64_t x1_bytes(int64_t rows, int64_t K) { return ((rows + 31) / 32) * ((K + 15) / 16) * 1024; }
+
+// why a description is not covered (NULL: it is)
+const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
+  if (!d) return "null description";
+  if (d->L < 1 || d->L > MAXL) return "1..8 layers";
+  if (d->B < 1 || d->F < 1 || d->D < 1 || d->H < 1) return "empty dimension";
+  Plan& p = *P;
+  p.B = d->B; p.F = d->F; p.D = d->D; p.H = d->H; p.L = d->L; p.u8 = d->input_u8 != 0; p.need_dx = d->need_dx != 0;
+  p.FB = p.F * p.B;
+  if (p.FB >= (1LL << 31) - 64) return "too many frame rows";
+  if (!yt8m_lstm_persist_supported(p.B, p.H) || !yt8m_lstm_persist_bwd_supported(p.B, p.H))
+    return "shape not covered by the persistent recurrence kernels";
+  if (p.FB < X3_MIN_ROWS || p.H < 128) return "too small for the bf16-pipe products";
+  if (p.u8 && (p.D % 16 != 0 || p.D > 2048)) return "uint8 input needs D % 16 == 0 and D <= 2048";
+  if (p.u8 && p.need_dx) return "no gradient with respect to uint8 frames";
+  if (p.FB % 16 != 0) return "F * B must be a multiple of 16 (K ranges of the transposed operand images)";
+  p.nf = chunks(p.F, d->fwd_chunks > 0 ? d->fwd_chunks : 1, p.fp);
+  p.nb = chunks(p.F, d->bwd_chunks > 0 ? d->bwd_chunks : 3, p.bp);
+  int64_t tmax = 0;
+  for (int c = 0; c < p.nf; ++c) {
+    if (p.u8 && (p.fp[c].t0 * p.B) % 32 != 0) return "a forward chunk does not start on a 32-row group of the frame image";
+    tmax = std::max(tmax, p.fp[c].T);
+  }
+  for (int c = 0; c < p.nb; ++c) {
+    if ((p.bp[c].t0 * p.B) % 16 != 0 || (p.bp[c].T * p.B) % 16 != 0) return "a backward part is not a multiple of 16 frame rows";
+    tmax = std::max(tmax, p.bp[c].T);
+  }
+  const int64_t BH = p.B * p.H, FBH = p.FB * p.H;
+  int64_t o = 0;
+  for (int l = 0; l < p.L; ++l) {
+    p.z[l] = o; o += up256(FBH * 4 * 4);
+    p.cs[l] = o; o += up256((FBH + BH) * 4);
+    p.hs[l] = o; o += up256((FBH + BH) * 4);
+    p.out[l] = o; o += up256(FBH * 4);
+  }
+  p.rrow = o; o += up256(p.FB * 4);
+  p.tape_bytes = o;
+  // scratch
+  int64_t pb = yt8m_lstm_persist_workspace_bytes_steps(p.B, p.H, tmax);
+  if (pb > STEP_IMAGES_MAX_BYTES) pb = yt8m_lstm_persist_workspace_bytes(p.B, p.H);
+  p.pws_bytes = up256(pb);
+  o = 0;
+  for (int l = 0; l < p.L; ++l) { p.pws[l] = o; o += p.pws_bytes; }
+  p.gws_bytes = up256(yt8m_gemm_workspace_bytes());
+  for (int l = 0; l <= p.L; ++l) { p.gws[l] = o; o += p.gws_bytes; }
+  const int64_t H4 = 4 * p.H;
+  p.qimg = o; o += p.u8 ? up256(x1_bytes(p.FB, p.D)) : 0;
+  p.w3t = o; o += p.u8 ? up256(x3_bytes(H4, p.D)) : 0;
+  p.wcs = o; o += up256(H4 * 4);
+  int64_t fmax = 0, bmax = 0;
+  for (int c = 0; c < p.nf; ++c) fmax = std::max(fmax, p.fp[c].T * p.B);
+  for (int c = 0; c < p.nb; ++c) bmax = std::max(bmax, p.bp[c].T * p.B);
+  for (int l = 0; l < p.L; ++l) {
+    const int64_t Din = l ? p.H : p.D;
+    const bool x1 = l == 0 && p.u8;
+    p.wxt3[l] = o; o += x1 ? 0 : up256(x3_bytes(H4, Din));
+    p.xi[l] = o; o += x1 ? 0 : up256(x3_bytes(fmax, Din));
+    p.dz[l] = o; o += up256(FBH * 4 * 4);
+    p.dbuf[l] = o; o += l + 1 < p.L ? up256(FBH * 4) : 0;
+    p.work[l] = o; o += up256(4 * BH * 4);
+    const bool dxl = l > 0 || p.need_dx;
+    p.dz3[l] = o; o += dxl ? up256(x3_bytes(bmax, H4)) : 0;
+    p.wx3[l] = o; o += dxl ? up256(x3_bytes(Din, H4)) : 0;
+    p.xT[l] = o; o += x1 ? up256(x1_bytes(p.D, p.FB)) : up256(x3_bytes(Din, p.FB));
+    p.hT[l] = o; o += up256(x3_bytes(p.H, p.FB));
+  }
+  p.dzT3 = o; o += up256(x3_bytes(H4, bmax));
+  p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, bmax)) : 0;
+  p.csr = o; o += up256(H4 * 4);
+  p.dbdummy = o; o += up256(H4 * 4);
+  p.scratch_bytes = o;
+  return nullptr;
+}
+
+// ---- per-device streams and events (created once, never destroyed: they live as long as the library) ----------------------------
+struct DevState {
+  bool init = false;
+  hipStream_t rs[MAXL];
+  hipStream_t sw;
+  std::vector<hipEvent_t> ev[2];      // forward / backward pools
+  size_t used[2] = {0, 0};
+};
+std::mutex g_mu;
+DevState g_dev[16];
+
+int dev_state(int L, DevState** out) {
+  int dev = 0;
+  YT8M_HIP_CHECK(hipGetDevice(&dev));
+  YT8M_REQUIRE(dev >= 0 && dev < 16, YT8M_E_BADARG, "device index out of range");
+  DevState& S = g_dev[dev];
+  if (!S.init) {
+    int least = 0, greatest = 0;
+    YT8M_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // the layer streams are HIGH priority: a persistent recurrence needs every workgroup resident and must take freed CUs before
+    // the queued workgroups of a weight-gradient GEMM do ("Scheduling around them")
+    for (int l = 0; l < MAXL; ++l) YT8M_HIP_CHECK(hipStreamCreateWithPriority(&S.rs[l], hipStreamNonBlocking, greatest));
+    YT8M_HIP_CHECK(hipStreamCreateWithFlags(&S.sw, hipStreamNonBlocking));
+    S.init = true;
+  }
+  (void)L;
+  *out = &S;
+  return YT8M_OK;
+}
+
+struct Ev {
+  DevState& S;
+  int dir;
+  int rc = YT8M_OK;
+  Ev(DevState& s, int d) : S(s), dir(d) { S.used[d] = 0; }
+  hipEvent_t record(hipStream_t st) {
+    if (S.used[dir] == S.ev[dir].size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(YT8M_E_HIP, "hipEventCreate failed%s", ""); return nullptr; }
+      S.ev[dir].push_back(e);
+    }
+    hipEvent_t e = S.ev[dir][S.used[dir]++];
+    if (hipEventRecord(e, st) != hipSuccess) rc = fail(YT8M_E_HIP, "hipEventRecord failed%s", "");
+    return e;
+  }
+  void wait(hipStream_t st, hipEvent_t e) {
+    if (e && hipStreamWaitEvent(st, e, 0) != hipSuccess) rc = fail(YT8M_E_HIP, "hipStreamWaitEvent failed%s", "");
+  }
+};
+
+#define RC(expr) do { int _rc = (expr); if (_rc != YT8M_OK) return _rc; } while (0)
+
+template <typename T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+
+}  // namespace
+
+extern "C" int yt8m_lstm_stack_supported(const yt8m_lstm_stack_desc* desc) {
+  Plan P;
+  const char* why = plan(desc, &P);
+  if (why) { snprintf(g_err, sizeof(g_err), "yt8m_lstm_stack: %s", why); return 0; }
+  return 1;
+}
+extern "C" int64_t yt8m_lstm_stack_tape_bytes(const yt8m_lstm_stack_desc* desc) {
+  Plan P;
+  return plan(desc, &P) ? 0 : P.tape_bytes;
+}
+extern "C" int64_t yt8m_lstm_stack_scratch_bytes(const yt8m_lstm_stack_desc* desc) {
+  Plan P;
+  return plan(desc, &P) ? 0 : P.scratch_bytes;
+}
+extern "C" int yt8m_lstm_stack_partition(const yt8m_lstm_stack_desc* desc, int* fwd_chunks, int* bwd_chunks) {
+  Plan P;
+  const char* why = plan(desc, &P);
+  YT8M_REQUIRE(!why, YT8M_E_SHAPE, why ? why : "");
+  if (fwd_chunks) *fwd_chunks = P.nf;
+  if (bwd_chunks) *bwd_chunks = P.nb;
+  return YT8M_OK;
+}
+
+// Views into the tape after yt8m_lstm_stack_fwd: which = 0 outputs of the layer [F,B,H] (time-major; zeros beyond num_frames),
+// 1 final cell state c [B,H], 2 final hidden state h [B,H] (copy-through beyond num_frames), 3 gate activations [F,B,4H].
+extern "C" int yt8m_lstm_stack_view(const yt8m_lstm_stack_desc* desc, void* tape, int layer, int which, float** out) {
+  Plan P;
+  const char* why = plan(desc, &P);
+  YT8M_REQUIRE(!why, YT8M_E_SHAPE, why ? why : "");
+  YT8M_REQUIRE(tape && out && layer >= 0 && layer < P.L && which >= 0 && which <= 3, YT8M_E_BADARG, "bad view");
+  const int64_t FBH = P.FB * P.H;
+  switch (which) {
+    case 0: *out = at<float>(tape, P.out[layer]); break;
+    case 1: *out = at<float>(tape, P.cs[layer]) + FBH; break;
+    case 2: *out = at<float>(tape, P.hs[layer]) + FBH; break;
+    default: *out = at<float>(tape, P.z[layer]); break;
+  }
+  return YT8M_OK;
+}
+
+// Sticky time-out words of the stack's persistent-recurrence workspaces (include/yt8m_hip.h, yt8m_lstm_persist_status): YT8M_E_HIP
+// if any launch of any layer since the previous status call gave up waiting.  Synchronises `stream`.
+extern "C" int yt8m_lstm_stack_status(const yt8m_lstm_stack_desc* desc, void* scratch, yt8m_stream_t stream) {
+  Plan P;
+  const char* why = plan(desc, &P);
+  YT8M_REQUIRE(!why, YT8M_E_SHAPE, why ? why : "");
+  YT8M_REQUIRE(scratch, YT8M_E_BADARG, "null scratch");
+  int rc = YT8M_OK;
+  for (int l = 0; l < P.L; ++l) {
+    const int r = yt8m_lstm_persist_status(at<char>(scratch, P.pws[l]), stream);
+    if (r != YT8M_OK) rc = r;                              // read (= clear) every word
+  }
+  return rc;
+}
+
+extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W,
+                                   const float* const* b, void* tape, int64_t tape_bytes, void* scratch, int64_t scratch_bytes,
+                                   yt8m_stream_t stream) {
+  Plan P;
+  const char* why = plan(desc, &P);
+  YT8M_REQUIRE(!why, YT8M_E_SHAPE, why ? why : "");
+  YT8M_REQUIRE(x && W && b && tape && scratch, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(tape_bytes >= P.tape_bytes && scratch_bytes >= P.scratch_bytes, YT8M_E_BADARG, "tape / scratch too small");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(tape) | reinterpret_cast<uintptr_t>(scratch)) & 255) == 0, YT8M_E_BADARG,
+               "tape and scratch must be 256-byte aligned");
+  for (int l = 0; l < P.L; ++l) YT8M_REQUIRE(W[l] && b[l], YT8M_E_BADARG, "null weights");
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevState* S = nullptr;
+  RC(dev_state(P.L, &S));
+  Ev ev(*S, 0);
+  hipStream_t main = as_stream(stream);
+  const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H;
+  hipEvent_t start = ev.record(main);
+  for (int l = 0; l < P.L; ++l) ev.wait(S->rs[l], start);
+  // per layer, once: zero initial state, operand images of the input weights
+  for (int l = 0; l < P.L; ++l) {
+    hipStream_t s = S->rs[l];
+    const int64_t Din = l ? H : D;
+    YT8M_HIP_CHECK(hipMemsetAsync(at<char>(tape, P.cs[l]), 0, (size_t)BH * 4, s));
+    YT8M_HIP_CHECK(hipMemsetAsync(at<char>(tape, P.hs[l]), 0, (size_t)BH * 4, s));
+    if (l == 0 && P.u8) {
+      RC(yt8m_u8_frames_image(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, 1e-12f, at<char>(scratch, P.qimg), nullptr,
+                              at<float>(tape, P.rrow), s));
+      RC(yt8m_x3_split(W[0], D, H4, H4, U8_ALPHA, nullptr, at<char>(scratch, P.w3t), s));          // (alpha W_x)^T: rows 4H, K = D
+      RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
+    } else {
+      RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, nullptr, at<char>(scratch, P.wxt3[l]), s));         // W_x^T: rows 4H, K = Din
+    }
+  }
+  std::vector<hipEvent_t> done((size_t)P.L * P.nf, nullptr);
+  for (int c = 0; c < P.nf; ++c) {
+    const int64_t t0 = P.fp[c].t0, T = P.fp[c].T, M = T * B;
+    for (int l = 0; l < P.L; ++l) {
+      hipStream_t s = S->rs[l];
+      const int64_t Din = l ? H : D;
+      if (l > 0) ev.wait(s, done[(size_t)(l - 1) * P.nf + c]);
+      float* zc = at<float>(tape, P.z[l]) + t0 * B * H4;
+      void* gw = at<char>(scratch, P.gws[l]);
+      if (l == 0 && P.u8) {
+        RC(yt8m_gemm_x1x3_nt(M, H4, D, at<char>(scratch, P.qimg) + (t0 * B / 32) * (D / 16) * 1024, at<char>(scratch, P.w3t), zc, H4, b[0],
+                             at<float>(tape, P.rrow) + t0 * B, at<float>(scratch, P.wcs), U8_BETA, gw, P.gws_bytes, s));
+      } else {
+        const float* src = l ? at<float>(tape, P.out[l - 1]) + t0 * B * H : static_cast<const float*>(x) + t0 * B * D;
+        RC(yt8m_x3_split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
+        yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, at<char>(scratch, P.wxt3[l]), 0, zc, H4, b[l], 0.0f};
+        RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s));
+      }
+      RC(yt8m_lstm_persist_fwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), at<float>(tape, P.hs[l]),
+                               at<float>(tape, P.out[l]), num_frames, t0, T, B, H, desc->forget_bias, at<char>(scratch, P.pws[l]),
+                               P.pws_bytes, s));
+      done[(size_t)l * P.nf + c] = ev.record(s);
+    }
+  }
+  for (int l = 0; l < P.L; ++l) ev.wait(main, done[(size_t)l * P.nf + P.nf - 1]);
+  return ev.rc;
+}
+
+extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W,
+                                   void* tape, int64_t tape_bytes, void* scratch, int64_t scratch_bytes, const float* dout_top,
+                                   const float* const* dc_final, const float* const* dh_final, float* const* dW, float* const* db,
+                                   const float* beta_W, const float* beta_b, float* dx, yt8m_stream_t stream) {
+  Plan P;
+  const char* why = plan(desc, &P);
+  YT8M_REQUIRE(!why, YT8M_E_SHAPE, why ? why : "");
+  YT8M_REQUIRE(x && W && tape && scratch && dW && db, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(tape_bytes >= P.tape_bytes && scratch_bytes >= P.scratch_bytes, YT8M_E_BADARG, "tape / scratch too small");
+  YT8M_REQUIRE(!P.need_dx || dx, YT8M_E_BADARG, "need_dx is set but dx is NULL");
+  for (int l = 0; l < P.L; ++l) {
+    YT8M_REQUIRE(W[l], YT8M_E_BADARG, "null weights");
+    YT8M_REQUIRE(!beta_W || beta_W[l] == 0.f || beta_W[l] == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+    YT8M_REQUIRE(!beta_b || beta_b[l] == 0.f || beta_b[l] == 1.f, YT8M_E_BADARG, "beta must be 0 or 1");
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevState* S = nullptr;
+  RC(dev_state(P.L, &S));
+  Ev ev(*S, 1);
+  hipStream_t main = as_stream(stream), sw = S->sw;
+  const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H, FB = P.FB;
+  const int64_t KBtot = FB / 16;
+  hipEvent_t start = ev.record(main);
+  ev.wait(sw, start);
+  for (int l = 0; l < P.L; ++l) ev.wait(S->rs[l], start);
+  // weight-gradient stream: the whole-sequence transposed operands (K = frame rows), made while the first recurrence runs alone
+  for (int l = 0; l < P.L; ++l) {
+    if (!dW[l]) continue;
+    if (l == 0 && P.u8) {
+      RC(yt8m_u8_frames_image_t(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, at<char>(scratch, P.xT[0]), sw));
+    } else {
+      const float* src = l ? at<float>(tape, P.out[l - 1]) : static_cast<const float*>(x);
+      const int64_t Din = l ? H : D;
+      RC(yt8m_x3_split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
+    }
+    RC(yt8m_x3_split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));    // h_{t-1}: hs[0 .. F)
+  }
+  int phase[MAXL];
+  bool wx3_done[MAXL];
+  for (int l = 0; l < P.L; ++l) {
+    hipStream_t s = S->rs[l];
+    float* work = at<float>(scratch, P.work[l]);
+    const float* dh = dh_final ? dh_final[l] : nullptr;
+    const float* dc = dc_final ? dc_final[l] : nullptr;
+    if (dh) YT8M_HIP_CHECK(hipMemcpyAsync(work, dh, (size_t)BH * 4, hipMemcpyDeviceToDevice, s));
+    else YT8M_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)BH * 4, s));
+    if (dc) YT8M_HIP_CHECK(hipMemcpyAsync(work + BH, dc, (size_t)BH * 4, hipMemcpyDeviceToDevice, s));
+    else YT8M_HIP_CHECK(hipMemsetAsync(work + BH, 0, (size_t)BH * 4, s));
+    phase[l] = 0;
+    wx3_done[l] = false;
+  }
+  std::vector<hipEvent_t> last;
+  for (int c = P.nb - 1; c >= 0; --c) {
+    const int64_t t0 = P.bp[c].t0, T = P.bp[c].T, M = T * B;
+    const int64_t kb0 = t0 * B / 16;
+    const bool first = c == P.nb - 1;
+    hipEvent_t dx_ev = nullptr;
+    for (int l = P.L - 1; l >= 0; --l) {
+      hipStream_t s = S->rs[l];
+      const int64_t Din = l ? H : D;
+      if (dx_ev) ev.wait(s, dx_ev);
+      const float* dout = l == P.L - 1 ? dout_top : at<float>(scratch, P.dbuf[l]);
+      float* dz = at<float>(scratch, P.dz[l]);
+      RC(yt8m_lstm_persist_bwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
+                               at<float>(scratch, P.work[l]), phase[l], nullptr, num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]),
+                               P.pws_bytes, s));
+      phase[l] = (int)((phase[l] + T) % 2);
+      hipEvent_t rb = ev.record(s);
+      const float* dzc = dz + t0 * B * H4;
+      dx_ev = nullptr;
+      if (l > 0 || P.need_dx) {                            // dz as stored feeds dx: on the layer stream (critical path)
+        RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), nullptr, s));
+        if (!wx3_done[l]) {
+          RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, s));       // W_x: rows Din, K = 4H
+          wx3_done[l] = true;
+        }
+        float* dst = l ? at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H : dx + t0 * B * D;
+        yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 0.0f};
+        RC(yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, P.gws[l]), P.gws_bytes, s));
+        dx_ev = ev.record(s);
+        if (c == 0) last.push_back(dx_ev);
+      }
+      // weight-gradient stream: transposed image(s) of this part's dz, the two products, the bias gradient
+      ev.wait(sw, rb);
+      void* gw = at<char>(scratch, P.gws[P.L]);
+      const float bW = first ? (beta_W ? beta_W[l] : 0.f) : 1.f;
+      const float bb = first ? (beta_b ? beta_b[l] : 0.f) : 1.f;
+      bool db_done = false;
+      if (dW[l]) {
+        if (l == 0 && P.u8) {
+          const float* rr = at<float>(tape, P.rrow) + t0 * B;
+          RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3), at<char>(scratch, P.dzT3s), sw));
+          float* dbo = db[0] ? db[0] : at<float>(scratch, P.dbdummy);
+          RC(yt8m_colsum_weighted_f32(dzc, M, H4, H4, rr, dbo, db[0] ? bb : 0.f, at<float>(scratch, P.csr), gw, P.gws_bytes, sw));
+          db_done = true;
+          RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, at<char>(scratch, P.dzT3s), 0, dW[0], H4,
+                                  nullptr, U8_ALPHA, nullptr, at<float>(scratch, P.csr), U8_BETA / U8_ALPHA, bW, gw, P.gws_bytes, sw));
+          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3), 0,
+                                  dW[0] + D * H4, H4, nullptr, bW};
+          RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, sw));
+        } else {
+          RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3), sw));
+          yt8m_gemm_problem pr[2] = {
+              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3), 0, dW[l], H4, nullptr, bW},
+              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3), 0, dW[l] + Din * H4, H4, nullptr, bW}};
+          RC(yt8m_gemm_x3_nt_grouped(2, pr, gw, P.gws_bytes, sw));
+        }
+      }
+      if (db[l] && !db_done) RC(yt8m_colsum_f32(dzc, M, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+    }
+  }
+  hipEvent_t fin = ev.record(sw);                          // sw waited for every recurrence part
+  ev.wait(main, fin);
+  for (hipEvent_t e : last) ev.wait(main, e);
+  return ev.rc;
+}

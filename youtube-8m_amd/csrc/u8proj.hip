@@ -79,6 +79,47 @@ __global__ __launch_bounds__(256) void u8_frames_tm_kernel(const uint8_t* __rest
   }
 }
 
+// (q - 128)^T as a ONE-plane operand image of the x3 kernel: rows = features d (D of them), K = time-major frame rows
+// m = f * B + b.  [d / 32][m / 16][32 rows][2 halves][8] bf16, half h of row r in slot h ^ ((r >> 3) & 1) -- the A operand of the
+// layer-0 weight-gradient product (yt8m_gemm_x1x3_nt_ex).  One workgroup per 16-wide K block: its 16 source rows (16 videos of one
+// frame index when B % 16 == 0) are staged in LDS and leave as 16-byte pieces (8 consecutive m of one feature).
+__global__ __launch_bounds__(256) void u8_frames_image_t_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
+                                                                uint16_t* __restrict__ img, int B, int F, int D, int KB) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t tile[];       // [16][D]
+  const int kb = blockIdx.x;
+  const long long MB = (long long)B * F;
+  const int nd = D >> 2;
+  for (int i = threadIdx.x; i < 16 * nd; i += 256) {
+    const int j = i / nd, c4 = i - j * nd;
+    const long long m = (long long)kb * 16 + j;
+    uint32_t w = 0x80808080u;                                          // q - 128 = 0: padding frames and the K tail
+    if (m < MB) {
+      const int f = (int)(m / B), b = (int)(m - (long long)f * B);
+      if (!nf || f < nf[b]) w = reinterpret_cast<const uint32_t*>(q + ((long long)b * F + f) * D)[c4];
+    }
+    reinterpret_cast<uint32_t*>(tile + (size_t)j * D)[c4] = w;
+  }
+  __syncthreads();
+  const int Dp = (D + 31) & ~31;
+  for (int i = threadIdx.x; i < 2 * Dp; i += 256) {
+    const int d = i >> 1, half = i & 1;
+    uint32_t pk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t h2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int v = d < D ? (int)tile[(size_t)(half * 8 + 2 * e + u) * D + d] - 128 : 0;
+        h2[u] = __float_as_uint((float)v) >> 16;                       // exact: |v| <= 128
+      }
+      pk[e] = h2[0] | (h2[1] << 16);
+    }
+    const int r32 = d & 31, slot = half ^ ((r32 >> 3) & 1);
+    uint16_t* dst = img + ((long long)(d >> 5) * KB + kb) * 512 + r32 * 16 + slot * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+
 // W [K, ldw] fp32 -> out [N, ldo] bf16 with out[n][j K + k] = term j of the 3-way bf16 split of scale * W[k][n]  (64 x 64 tiles
 // through LDS: reads coalesced along n, writes along k)
 __global__ __launch_bounds__(256) void split3_bf16_t_kernel(const float* __restrict__ W, long long ldw, int K, int N, float scale,
@@ -160,6 +201,23 @@ extern "C" int yt8m_u8_frames_image(const uint8_t* q, const int32_t* num_frames,
   hipLaunchKernelGGL(u8_frames_tm_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, (uint16_t*)nullptr, 0LL, 0,
                      x_tm, r_out, (int)B, (int)F, (int)D, eps, static_cast<uint16_t*>(image));
   return launch_status("u8_frames_tm_kernel");
+}
+
+// (q - 128)^T as a one-plane image: ceil(D / 32) * ceil(B F / 16) KiB, 16-byte aligned; K runs over the time-major rows f * B + b.
+extern "C" int yt8m_u8_frames_image_t(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, void* image_t,
+                                      yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * D == 0) return YT8M_OK;
+  YT8M_REQUIRE(D <= 2048 && (D % 4) == 0, YT8M_E_SHAPE, "D must be a multiple of 4 and <= 2048");
+  YT8M_REQUIRE(q && image_t, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(q) & 3) | (reinterpret_cast<uintptr_t>(image_t) & 15)) == 0, YT8M_E_BADARG, "misaligned operand");
+  YT8M_REQUIRE(B * F < (1LL << 31) - 16, YT8M_E_SHAPE, "too many frame rows");
+  hipStream_t s = as_stream(stream);
+  const int KB = (int)((B * F + 15) / 16);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(u8_frames_image_t_kernel, dim3((unsigned)KB), dim3(256), (size_t)16 * D, s, q, num_frames,
+                     static_cast<uint16_t*>(image_t), (int)B, (int)F, (int)D, KB);
+  return launch_status("u8_frames_image_t_kernel");
 }
 
 extern "C" int yt8m_split3_bf16_t(const float* W, int64_t ldw, int64_t K, int64_t N, float scale, void* out, int64_t ldo,

@@ -358,6 +358,11 @@ def check_persist_errors():
             _check_ws(ws, stream)
         except _lib.Yt8mHipError as e:                               # read (= clear) every word before raising
             err = e
+    for ent in list(_STACK_SCRATCH.values()):
+        try:
+            _check_stack(*ent)
+        except _lib.Yt8mHipError as e:
+            err = e
     if err is not None:
         raise err
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
@@ -366,6 +371,44 @@ X3 = _os.environ.get("YT8M_GEMM_X3", "1") != "0"      # hoisted fp32 products on
 X3_MIN_ROWS = 1024                                      # F * B below which the fp32-MFMA kernel's smaller tiles win
 REC_BF16 = _os.environ.get("YT8M_REC_BF16", "1") != "0"       # compute_dtype=bfloat16: bf16 operands for the recurrent product too (csrc/lstm_bf16.hip); False = hoisted
                       # products only
+
+
+NATIVE_STACK = _os.environ.get("YT8M_LSTM_STACK_NATIVE", "1") != "0"   # whole stack behind yt8m_lstm_stack_fwd / _bwd (csrc/lstm_stack.hip)
+_STACK_SCRATCH = {}   # (device, calling stream, description) -> zero-initialised scratch of the native stack (resident, like _PERSIST_WS)
+NATIVE_CALLS = {"fwd": 0, "bwd": 0}     # how often the native path ran (tests assert that it engaged)
+
+
+def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx):
+    return _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)), float(forget_bias), int(PERSIST_FWD_CHUNKS),
+                              int(PERSIST_BWD_CHUNKS), int(bool(need_dx)))
+
+
+def _stack_scratch(dev, main, desc):
+    key = (dev.index, main.cuda_stream) + tuple(getattr(desc, f) for f, _ in desc._fields_ if f != "forget_bias")
+    ent = _STACK_SCRATCH.get(key)
+    if ent is None:
+        if len(_STACK_SCRATCH) >= 4:                                 # a few GB each: keep the table small
+            old = next(iter(_STACK_SCRATCH))
+            _check_stack(*_STACK_SCRATCH.pop(old))
+        n = _lib.lib().yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc))
+        ent = (torch.zeros(n, dtype=torch.uint8, device=dev), main, desc)      # zeroed ONCE: the sticky time-out words start clear
+        _STACK_SCRATCH[key] = ent
+    return ent[0]
+
+
+def _check_stack(scratch, stream, desc):
+    with torch.cuda.device(scratch.device):
+        _lib.check(_lib.lib().yt8m_lstm_stack_status(ctypes.byref(desc), _p(scratch), ctypes.c_void_p(stream.cuda_stream)))
+
+
+def _tape_view(lib, desc, tape, layer, which, shape):
+    ptr = ctypes.c_void_p()
+    _lib.check(lib.yt8m_lstm_stack_view(ctypes.byref(desc), _p(tape), layer, which, ctypes.byref(ptr)))
+    off = ptr.value - tape.data_ptr()
+    n = 4
+    for d in shape:
+        n *= d
+    return tape[off:off + n].view(torch.float32).view(*shape)
 
 
 class _LstmStack(torch.autograd.Function):
@@ -407,6 +450,17 @@ class _LstmStack(torch.autograd.Function):
         # fp32 stack on the persistent kernels: the partition is the stack's own (see PERSIST_FWD_CHUNKS), `chunks` is the caller's
         # hint for the per-step kernels' layer pipeline
         own = pers and not bf16 and _os.environ.get("YT8M_PERSIST_CUS") is None
+        # The product's own configuration runs entirely inside the library (csrc/lstm_stack.hip: partition, streams, operand images,
+        # product forms -- the path bench.py measures); everything else (caller's chunks, dropout, bf16 operands, per-step kernels,
+        # tuning knobs) keeps the orchestration below, built from the same per-call entry points.
+        drop_ = input_keep_prob is not None and float(input_keep_prob) < 1.0
+        if (NATIVE_STACK and own and X3 and PERSIST_BWD and PERSIST_STEP_IMAGES and not drop_ and not FWD_WAVEFRONT and
+                PERSIST_FWD_CHUNKS > 0 and PERSIST_BWD_CHUNKS > 0 and BWD_CHUNKS == 0 and not BWD_PARTS and len(set(Hs)) == 1):
+            u8 = x_tm.dtype == torch.uint8
+            D0 = x_tm.shape[2]
+            desc = _stack_desc(B, F, D0, Hs[0], L, u8, forget_bias, (not u8) and bool(ctx.needs_input_grad[0]))
+            if (u8 or x_tm.dtype == torch.float32) and wb[0].data.shape[0] == D0 + Hs[0] and lib.yt8m_lstm_stack_supported(ctypes.byref(desc)):
+                return _LstmStack._native_forward(ctx, lib, desc, x_tm, nf, wb)
         if own and PERSIST_FWD_CHUNKS > 0:
             parts = _chunks(F, PERSIST_FWD_CHUNKS)
         bwd_parts = _bwd_parts(F, _chunks(F, chunks), own)
@@ -580,7 +634,74 @@ class _LstmStack(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    def _native_forward(ctx, lib, desc, x, nf, wb):
+        x = x.contiguous()
+        _dev(x)
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        L, B, F, H = desc.L, desc.B, desc.F, desc.H
+        Ws, bs = wb[0::2], wb[1::2]
+        for l, w in enumerate(Ws):
+            assert w.data.is_contiguous() and tuple(w.data.shape) == ((desc.D if l == 0 else H) + H, 4 * H), "cell weights must be [in + H, 4H]"
+        tape = torch.empty(lib.yt8m_lstm_stack_tape_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+        scratch = _stack_scratch(dev, main, desc)
+        Wp = (ctypes.c_void_p * L)(*[w.data.data_ptr() for w in Ws])
+        bp = (ctypes.c_void_p * L)(*[b.data.data_ptr() for b in bs])
+        _lib.check(lib.yt8m_lstm_stack_fwd(ctypes.byref(desc), _p(x), _p(nf), Wp, bp, _p(tape), tape.numel(), _p(scratch), scratch.numel(),
+                                           _stream()))
+        NATIVE_CALLS["fwd"] += 1
+        if PERSIST_CHECK:
+            _check_stack(scratch, main, desc)
+        ctx.native = (desc, tape, scratch, x, nf, Ws, bs)
+        ctx.layers = None
+        ctx.set_materialize_grads(False)
+        outs = [_tape_view(lib, desc, tape, L - 1, 0, (F, B, H))]
+        for l in range(L):
+            outs += [_tape_view(lib, desc, tape, l, 1, (B, H)), _tape_view(lib, desc, tape, l, 2, (B, H))]
+        return tuple(outs)
+
+    @staticmethod
+    def _native_backward(ctx, dout_top, dfinal):
+        desc, tape, scratch, x, nf, Ws, bs = ctx.native
+        ctx.native = None
+        lib = _lib.lib()
+        L = desc.L
+        dev = x.device
+        keep = []
+
+        def c32(t):
+            if t is None:
+                return None
+            t = _f32c(t)
+            keep.append(t)
+            return t
+
+        dout_top = c32(dout_top)
+        dcs = [c32(dfinal[2 * l]) for l in range(L)]
+        dhs = [c32(dfinal[2 * l + 1]) for l in range(L)]
+        arr = lambda ts: (ctypes.c_void_p * L)(*[None if t is None else t.data_ptr() for t in ts])
+        dW = [w.grad if w.grad is not None else None for w in Ws]
+        db = [b.grad if b.grad is not None else None for b in bs]
+        for g in dW + db:
+            assert g is None or g.is_contiguous()
+        bW = (ctypes.c_float * L)(*[float(w.grad_beta()) if w.grad is not None else 0.0 for w in Ws])
+        bb = (ctypes.c_float * L)(*[float(b.grad_beta()) if b.grad is not None else 0.0 for b in bs])
+        dx = torch.empty((desc.F, desc.B, desc.D), dtype=torch.float32, device=dev) if desc.need_dx else None
+        Wp = (ctypes.c_void_p * L)(*[w.data.data_ptr() for w in Ws])
+        _lib.check(lib.yt8m_lstm_stack_bwd(ctypes.byref(desc), _p(x), _p(nf), Wp, _p(tape), tape.numel(), _p(scratch), scratch.numel(),
+                                           _p(dout_top), arr(dcs), arr(dhs), arr(dW), arr(db), bW, bb, _p(dx), _stream()))
+        NATIVE_CALLS["bwd"] += 1
+        if PERSIST_CHECK:
+            _check_stack(scratch, torch.cuda.current_stream(dev), desc)
+        for v in list(Ws) + list(bs):
+            if v.grad is not None:
+                v.grad_done()
+        return (dx, None, None, None, None, None, None, None) + (None,) * (2 * L)
+
+    @staticmethod
     def backward(ctx, dout_top, *dfinal):
+        if getattr(ctx, "native", None) is not None:
+            return _LstmStack._native_backward(ctx, dout_top, dfinal)
         layers, nf, parts = ctx.layers, ctx.nf, ctx.parts
         ctx.layers = None
         L = len(layers)
