@@ -103,6 +103,18 @@ int64_t yt8m_x3_image_bytes(int64_t rows, int64_t K);
 int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
 int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                             yt8m_stream_t stream);
+/* fp32 products through the LIBRARY's choice of kernel (csrc/gemm_auto.hip): per problem -- never per group, so a product takes
+ * the same kernel and summation order alone or grouped -- a cost estimate (yt8m_gemm_x3_pays: tile efficiency at 256 x 256,
+ * occupancy, the split passes) picks the six-product bf16-pipe kernel or the fp32-MFMA kernel.  Arguments as yt8m_gemm_f32_grouped
+ * (up to 64 problems); image_scratch (yt8m_gemm_auto_scratch_bytes of the same arguments, 256-byte aligned) holds the operand
+ * images -- an operand shared by several problems is split once; with too little of it the problems that do not fit stay on the
+ * fp32 kernel.  used_x3 (may be NULL): bit i = problem i ran on the bf16 pipe.  YT8M_GEMM_X3=0 keeps everything on the fp32 kernel.
+ * Replaces every slim.fully_connected / tf.matmul site outside the recurrent stack (W/all_video_models/moe_model.py:43-55, ...). */
+int yt8m_gemm_x3_pays(int64_t M, int64_t N, int64_t K);
+int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt8m_gemm_problem* probs);
+int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+                           int64_t workspace_bytes, void* image_scratch, int64_t image_scratch_bytes, uint64_t* used_x3,
+                           yt8m_stream_t stream);
 /* The uint8 input projection on the same kernel ("readers.py uint8 -> float dequantise folded into the first GEMM",
  * W/readers.py:178-187 -> W/all_frame_models/lstm_model.py:34-47):
  *   C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n]
@@ -182,6 +194,9 @@ int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, int label_dt
  * workspace >= yt8m_moe_workspace_bytes(B, V).  LogisticModel (logistic_model.py:12-26): p = sigmoid(x W + b), same
  * loss; Z [B,V] is scratch (dL/dz); labels == NULL -> forward only; workspace >= yt8m_moe_workspace_bytes(B, V). */
 int64_t yt8m_moe_workspace_bytes(int64_t B, int64_t V);
+/* ... plus room for the operand images of the head's three product stages on the bf16 pipe (csrc/gemm_auto.hip); with only
+ * yt8m_moe_workspace_bytes the head's products stay on the fp32-MFMA kernel */
+int64_t yt8m_moe_workspace_bytes_ex(int64_t B, int64_t D, int64_t V, int M);
 int yt8m_moe_fwd(const float* x, const float* Wg, const float* We, const float* be, const void* labels, int label_dtype,
                  int64_t B, int64_t D, int64_t V, int M, float eps, float* Zg, float* Ze, float* p, float* loss_out,
                  void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);

@@ -43,6 +43,9 @@ SIGNATURES = {
     "yt8m_gemm_workspace_bytes": (c_int64, []),
     "yt8m_gemm_f32_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_gemm_bf16_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
+    "yt8m_gemm_x3_pays": (c_int, [c_int64, c_int64, c_int64]),
+    "yt8m_gemm_auto_scratch_bytes": (c_int64, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem)]),
+    "yt8m_gemm_auto_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P, c_int64, ctypes.POINTER(ctypes.c_uint64), P]),
     "yt8m_x3_image_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_x3_split": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "yt8m_gemm_x3_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
@@ -70,6 +73,7 @@ SIGNATURES = {
     "yt8m_dequant_l2norm_u8": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_dequant_mean_l2norm_u8": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_moe_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "yt8m_moe_workspace_bytes_ex": (c_int64, [c_int64, c_int64, c_int64, c_int]),
     "yt8m_moe_fwd": (c_int, [P, P, P, P, P, c_int, c_int64, c_int64, c_int64, c_int, c_float, P, P, P, P, P, c_int64, P]),
     "yt8m_moe_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int64, c_int64, c_int64, c_int, c_float, c_float, P, P, P, c_float, P, P,
                              c_int64, P]),

@@ -1,0 +1,118 @@
+// gemm_auto.hip -- fp32 products through the library's own choice of kernel (the x3-vs-fp32 dispatch lived in
+// youtube-8m_amd/ops.py).  Every fp32 GEMM of the package that is not hand-placed (csrc/lstm_stack.hip places its own) comes through
+// yt8m_gemm_auto_grouped: per PROBLEM -- never per group, so a product takes the same kernel and the same summation order
+// whether it is launched alone or inside a group -- a cost estimate decides between
+//   * six bf16 MFMA products of three-plane split operands (csrc/gemm_x3.hip: 256 x 256 tiles, fp32-grade error, ~2x the rate on
+//     large shapes, plus one split pass per operand: 4 B read + 6 B written per element), and
+//   * the exact fp32-MFMA kernel (csrc/gemm_f32.hip: 128 x 128 tiles, no preparation).
+// The operand images live in a caller-provided scratch (yt8m_gemm_auto_scratch_bytes); an operand shared by several problems of a
+// call (the activations of the MoE head's gate and expert products) is split once.  Too little scratch is never an error: the
+// problems whose images do not fit stay on the fp32 kernel.
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "common.h"
+
+using namespace yt8m;
+
+namespace {
+
+// measured: fp32-equivalent FLOP/s of either kernel, bytes/s of the split pass (profiles/r2_x3_check.txt)
+constexpr double X3_RATE = 195e12, F32_RATE = 110e12, SPLIT_RATE = 3.2e12;
+
+bool x3_pays(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return false;
+  const double fl = 2.0 * (double)M * (double)N * (double)K;
+  const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
+  const double eff = (double)M * (double)N / ((double)(tm * tn) * 65536.0);
+  const double occ = std::min(1.0, (double)(tm * tn) * (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 128)) / 256.0);
+  const double tx3 = fl / (X3_RATE * eff * occ) + ((double)M * K + (double)N * K) * 10.0 / SPLIT_RATE + 2e-5;
+  const double t32 = fl / (F32_RATE * std::min(1.0, (double)(((M + 127) / 128) * ((N + 127) / 128)) *
+                                                        (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 256)) / 768.0));
+  return tx3 < 0.9 * t32;
+}
+
+bool x3_allowed(const yt8m_gemm_problem& q) {
+  static const bool off = getenv("YT8M_GEMM_X3") != nullptr && atoi(getenv("YT8M_GEMM_X3")) == 0;
+  // the x3 launch takes beta in {0, 1} and its split pass at most 64 * 65535 rows per operand
+  return !off && (q.beta == 0.f || q.beta == 1.f) && std::max(q.M, std::max(q.N, q.K)) < 64LL * 65535 && x3_pays(q.M, q.N, q.K);
+}
+
+int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; };
+
+}  // namespace
+
+extern "C" int yt8m_gemm_x3_pays(int64_t M, int64_t N, int64_t K) { return x3_pays(M, N, K) ? 1 : 0; }
+
+// bytes of image scratch with which every problem of the call that should run on the bf16 pipe does
+extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt8m_gemm_problem* probs) {
+  (void)transA; (void)transB;
+  if (nprob < 1 || !probs) return 0;
+  int64_t n = 0;
+  for (int i = 0; i < nprob; ++i)
+    if (x3_allowed(probs[i])) n += up256(yt8m_x3_image_bytes(probs[i].M, probs[i].K)) + up256(yt8m_x3_image_bytes(probs[i].N, probs[i].K));
+  return n;
+}
+
+// C_i = op(A_i) . op(B_i) (+ bias_i) (+ C_i) for nprob problems sharing transA / transB (fp32 row-major operands, as
+// yt8m_gemm_f32_grouped).  workspace: split-K scratch (yt8m_gemm_workspace_bytes, may be NULL); image_scratch: see above (may be
+// NULL / small).  used_x3 (may be NULL): bit i set when problem i ran on the bf16 pipe.
+extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+                                      int64_t workspace_bytes, void* image_scratch, int64_t image_scratch_bytes, uint64_t* used_x3,
+                                      yt8m_stream_t stream) {
+  YT8M_REQUIRE(nprob >= 1 && nprob <= 64 && probs, YT8M_E_BADARG, "1..64 problems per call");
+  YT8M_REQUIRE((reinterpret_cast<uintptr_t>(image_scratch) & 255) == 0, YT8M_E_BADARG, "image scratch must be 256-byte aligned");
+  std::vector<Img> imgs;
+  std::vector<yt8m_gemm_problem> px, p32;
+  uint64_t mask = 0;
+  int64_t off = 0;
+  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, int64_t* at) -> bool {
+    for (const Img& m : imgs)
+      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans) { *at = m.off; return true; }
+    const int64_t bytes = up256(trans ? yt8m_x3_image_bytes(C, R) : yt8m_x3_image_bytes(R, C));
+    if (!image_scratch || off + bytes > image_scratch_bytes) return false;
+    imgs.push_back({src, R, C, ld, trans, off});
+    *at = off;
+    off += bytes;
+    return true;
+  };
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    bool x3 = q.M > 0 && q.N > 0 && x3_allowed(q) && q.A && q.B;
+    int64_t ia = 0, ib = 0;
+    if (x3) {
+      const int64_t mark = off;
+      const size_t nimg = imgs.size();
+      // op(A) as [M rows, K]: A is stored [M,K] (plain) or [K,M] (transA: the transposing split); op(B)^T as [N rows, K]
+      x3 = image_of(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0, &ia) &&
+           image_of(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0, &ib);
+      if (!x3) { imgs.resize(nimg); off = mark; }          // not enough scratch for this one: fp32 kernel
+    }
+    if (x3) {
+      yt8m_gemm_problem t = q;
+      t.A = static_cast<char*>(image_scratch) + ia; t.lda = 0;
+      t.B = static_cast<char*>(image_scratch) + ib; t.ldb = 0;
+      px.push_back(t);
+      mask |= 1ULL << i;
+    } else {
+      p32.push_back(q);
+    }
+  }
+  for (const Img& m : imgs) {
+    void* dst = static_cast<char*>(image_scratch) + m.off;
+    int rc = yt8m_x3_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, m.trans ? nullptr : dst, m.trans ? dst : nullptr, stream);
+    if (rc != YT8M_OK) return rc;
+  }
+  for (size_t lo = 0; lo < px.size(); lo += 4) {
+    int rc = yt8m_gemm_x3_nt_grouped((int)std::min<size_t>(4, px.size() - lo), &px[lo], workspace, workspace_bytes, stream);
+    if (rc != YT8M_OK) return rc;
+  }
+  for (size_t lo = 0; lo < p32.size(); lo += 4) {
+    int rc = yt8m_gemm_f32_grouped(transA, transB, (int)std::min<size_t>(4, p32.size() - lo), &p32[lo], workspace, workspace_bytes, stream);
+    if (rc != YT8M_OK) return rc;
+  }
+  if (used_x3) *used_x3 = mask;
+  return YT8M_OK;
+}

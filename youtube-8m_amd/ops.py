@@ -101,43 +101,20 @@ def _problem(A, B, out, transA, transB, bias, beta):
 
 
 X3 = os.environ.get("YT8M_GEMM_X3", "1") != "0"        # large fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
-X3_RATE, F32_RATE, SPLIT_RATE = 195e12, 110e12, 3.2e12  # measured: fp32-equivalent FLOP/s of either kernel, bytes/s of the split pass
 
 
-def _x3_wins(shapes, transA, transB):
-    """Cost estimate for a group of (M, N, K) products: six bf16 products of split operands (tile 256 x 256, plus the split
-    passes over both operands) against the fp32-MFMA kernel (tile 128 x 128)."""
-    t32 = tx3 = 0.0
-    for M, N, K in shapes:
-        fl = 2.0 * M * N * K
-        if fl == 0:
-            continue
-        tm, tn = (M + 255) // 256, (N + 255) // 256
-        eff = (M * N) / float(tm * tn * 65536)
-        occ = min(1.0, tm * tn * max(1, min(8, K // 128)) / 256.0)   # remainder tiles are split along K up to 8 ways
-        tx3 += fl / (X3_RATE * eff * occ) + (M * K + N * K) * 10.0 / SPLIT_RATE + 2e-5
-        t32 += fl / (F32_RATE * min(1.0, ((M + 127) // 128) * ((N + 127) // 128) * max(1, min(8, K // 256)) / 768.0))
-    return tx3 < 0.9 * t32
-
-
-def _x3_operand(cache, T, ld, rows_are_k):
-    """X3Image of a row-major fp32 operand T used with K along its rows (rows_are_k: the transposing split) or its columns."""
-    key = (T.data_ptr(), tuple(T.shape), ld, rows_are_k)
-    img = cache.get(key)
-    if img is None:
-        R, C = T.shape
-        img = _x3_empty(C, R, T.device) if rows_are_k else _x3_empty(R, C, T.device)
-        _lib.check(_lib.lib().yt8m_x3_split(_p(T), R, C, ld, 1.0, None if rows_are_k else _p(img.buf), _p(img.buf) if rows_are_k else None,
-                                            _stream()))
-        cache[key] = img
-    return img
+def _x3_wins(shapes, transA=False, transB=False):
+    """The library's cost estimate (csrc/gemm_auto.hip: six bf16 products of split operands on 256 x 256 tiles plus the split passes
+    against the fp32-MFMA kernel on 128 x 128 tiles) for every (M, N, K) of a group; the dispatch itself is per product."""
+    shapes = [s_ for s_ in shapes if s_[0] * s_[1] * s_[2] != 0]
+    return bool(shapes) and all(_lib.lib().yt8m_gemm_x3_pays(int(M), int(N), int(K)) for M, N, K in shapes)
 
 
 def gemm_grouped(items, transA=False, transB=False):
     """items: list of dicts(A=, B=, out=None, bias=None, beta=0.0) sharing transA/transB -> list of outputs.
-    One persistent launch: no wave-quantisation tail across the group.  fp32 operands either way; large groups run as six bf16
-    MFMA products of three-plane split operands (yt8m_gemm_x3_nt_grouped: fp32-grade error at twice the rate), the rest on the
-    fp32 MFMA kernel (yt8m_gemm_f32_grouped)."""
+    fp32 operands either way; the library picks the kernel per product (yt8m_gemm_auto_grouped: large products run as six bf16
+    MFMA products of three-plane split operands -- fp32-grade error at twice the rate --, the rest on the fp32 MFMA kernel) and
+    groups the launches; the operand images live in a scratch tensor sized by the library's own query."""
     probs, outs, keep = [], [], []
     for it in items:
         _dev(it["A"], it["B"], it.get("out"), it.get("bias"))
@@ -146,25 +123,18 @@ def gemm_grouped(items, transA=False, transB=False):
         outs.append(out)
         keep.append(k)
     ws = _workspace(outs[0].device)
-    # decided per problem (not per group), so that a product takes the same kernel whether it is launched alone or grouped
-    # (the x3 launch takes beta in {0, 1} and its split pass at most 64 * 65535 rows per operand: anything else stays on the fp32 kernel)
-    use = [X3 and pr.beta in (0.0, 1.0) and max(pr.M, pr.N, pr.K) < 64 * 65535 and _x3_wins([(pr.M, pr.N, pr.K)], transA, transB)
-           for pr in probs]
-    px3 = [i for i, u in enumerate(use) if u]
-    p32 = [i for i, u in enumerate(use) if not u]
-    cache = {}
-    for lo in range(0, len(px3), 4):
-        grp = px3[lo:lo + 4]
-        for i in grp:
-            pr, (A, B, bias) = probs[i], keep[i]
-            ia = _x3_operand(cache, A, pr.lda, bool(transA))         # op(A) [M rows, K]
-            ib = _x3_operand(cache, B, pr.ldb, not transB)           # op(B)^T [N rows, K]
-            pr.A, pr.lda, pr.B, pr.ldb = ia.buf.data_ptr(), 0, ib.buf.data_ptr(), 0
-        arr = (_lib.GemmProblem * len(grp))(*[probs[i] for i in grp])
-        _lib.check(_lib.lib().yt8m_gemm_x3_nt_grouped(len(grp), arr, _p(ws), ws.numel() * 4, _stream()))
-    if p32:
-        arr = (_lib.GemmProblem * len(p32))(*[probs[i] for i in p32])
-        _lib.check(_lib.lib().yt8m_gemm_f32_grouped(int(transA), int(transB), len(p32), arr, _p(ws), ws.numel() * 4, _stream()))
+    lib = _lib.lib()
+    for lo in range(0, len(probs), 64):
+        part = probs[lo:lo + 64]
+        arr = (_lib.GemmProblem * len(part))(*part)
+        if not X3:
+            for i in range(0, len(part), 4):
+                sub = (_lib.GemmProblem * len(part[i:i + 4]))(*part[i:i + 4])
+                _lib.check(lib.yt8m_gemm_f32_grouped(int(transA), int(transB), len(part[i:i + 4]), sub, _p(ws), ws.numel() * 4, _stream()))
+            continue
+        nb = lib.yt8m_gemm_auto_scratch_bytes(int(transA), int(transB), len(part), arr)
+        img = torch.empty(nb, dtype=torch.uint8, device=outs[0].device) if nb else None
+        _lib.check(lib.yt8m_gemm_auto_grouped(int(transA), int(transB), len(part), arr, _p(ws), ws.numel() * 4, _p(img), nb, None, _stream()))
     return outs
 
 
