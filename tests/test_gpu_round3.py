@@ -141,7 +141,8 @@ def test_lstm_model_on_persistent_kernels_vs_oracle(dev, flags, lstm_partition):
     tg = train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g)
     tg.forward(qd, yd, nfd)
     g.finalize()
-    P = {k: (rs.randn(*v.shape) * 0.3).astype(np.float32) for k, v in g.vars.items()}
+    # (a contractive recurrence: with large weights 40 steps amplify fp32 rounding chaotically on ANY implementation)
+    P = {k: (rs.randn(*v.shape) * 0.06).astype(np.float32) for k, v in g.vars.items()}
     for k, v in g.vars.items():
         v.data.copy_(torch.from_numpy(P[k]).to(dev).view(v.data.shape))
     res = tg.forward(qd, yd, nfd, fuse_loss=False)
@@ -186,7 +187,8 @@ def test_u8_frames_image_t_equals_oracle_bit_for_bit(dev):
         want = x3_ref.image(np.ascontiguousarray(xm.T))                                                # [RG, KB, 3, 32, 2, 8]
         assert not want[:, :, 1:].any()
         img = torch.full((want[:, :, 0].size * 2,), 0x55, dtype=torch.uint8, device=dev)
-        L.check(lib.yt8m_u8_frames_image_t(_p(torch.from_numpy(q).to(dev)), _p(torch.from_numpy(nf).to(dev)), B, F, D, _p(img), _stream()))
+        qd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev)      # (named: a temporary would be freed before the launch)
+        L.check(lib.yt8m_u8_frames_image_t(_p(qd), _p(nfd), B, F, D, _p(img), _stream()))
         got = img.cpu().numpy().view(np.uint16).reshape(want[:, :, 0].shape)
         rows = np.arange(want.shape[0] * 32).reshape(-1, 32) < D                                       # rows beyond D are never read
         assert np.array_equal(got[rows[:, None, :].repeat(want.shape[1], 1)], want[:, :, 0][rows[:, None, :].repeat(want.shape[1], 1)])

@@ -3,11 +3,11 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1700 python -m pytest tests -m gpu -q -x --timeout=600 -p no:cacheprovider > gpurun_out/r3_tests1.log 2>&1
+timeout 1100 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider > gpurun_out/r3_tests1.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/r3_tests1.log
 tail -25 gpurun_out/r3_tests1.log
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gap --no-extra"
-run() { name=$1; shift; env "$@" timeout 300 $B > gpurun_out/r3_b_$name.json 2> gpurun_out/r3_b_$name.err; python tools/bench_brief.py gpurun_out/r3_b_$name.json 2>/dev/null | head -3; echo "$name: $(python -c "import json,sys;d=json.load(open('gpurun_out/r3_b_$name.json'));print(round(d['ms_per_step'],3),'ms/step')" 2>&1 | tail -1)"; }
+run() { name=$1; shift; env "$@" timeout 300 $B > gpurun_out/r3_b_$name.json 2> gpurun_out/r3_b_$name.err; python tools/bench_brief.py $name < gpurun_out/r3_b_$name.json 2>&1 | head -3; tail -3 gpurun_out/r3_b_$name.err; }
 run native YT8M_X=1
 run python YT8M_LSTM_STACK_NATIVE=0
 run native_b4 YT8M_LSTM_PERSIST_BWD_CHUNKS=4
