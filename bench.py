@@ -623,6 +623,11 @@ def main():
     cfg = WORKLOADS[a.workload]
     B = a.batch or cfg["batch"]
     bf16 = a.dtype == "bf16"
+    if a.force_reducer and world == 1 and not dist.is_initialized():
+        # a 1-rank RCCL group: the whole data-parallel machinery (bucketed async all-reduce, per-bucket clip + Adam, the CU headroom of
+        # the persistent recurrences) runs on one GPU -- what a single-GPU box can measure of the N > 1 path
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                                device_id=dev)
     reducer = parallel.GradReducer() if (world > 1 or a.force_reducer) else None
     g, tg, pool = build(a.workload, B, world, rank, dev, reducer, bf16)
     if a.pool:
@@ -722,9 +727,11 @@ def main():
                                          "products of a three-plane bf16 split of both operands with fp32 accumulation (error <= the "
                                          "rounding of an fp32 FMA; YT8M_GEMM_X3=0 / YT8M_PERSIST_X3=0 select the fp32 MFMA kernels)")},
                "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement,
-               "library": library_identity()}
+               "library": library_identity(),
+               "reducer": None if reducer is None else {"algo": reducer.algo, "reserved_cus": reducer.reserve_cus, "world": reducer.world,
+                                                        "forced_at_world_1": bool(a.force_reducer and world == 1)}}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -407,6 +407,10 @@ int yt8m_lstm_persist_fwd_on_bf16_pipe(int64_t B, int64_t H);
 /* CUs the following forward / backward launches may occupy (0: whole chip, -1: environment / default = whole chip forward, 128
  * backward).  Two forward launches of neighbouring layers run side by side when each takes half the chip. */
 int yt8m_lstm_persist_set_cus(int fwd_cus, int bwd_cus);
+/* CUs the library leaves out of its "do these persistent launches fit the chip together" arithmetic: a data-parallel host reserves
+ * room for the RCCL kernels of the gradient all-reduce that run beside the backward pass (launches that no longer fit side by side
+ * are chained instead of spinning on a partly resident grid).  Env default: YT8M_PERSIST_RESERVED_CUS, else 0. */
+int yt8m_lstm_persist_reserve_cus(int cus, int* previous);
 int yt8m_lstm_persist_status(const void* workspace, yt8m_stream_t stream);
 int yt8m_lstm_persist_debug_fault(void* workspace, yt8m_stream_t stream);
 /* diagnostics: persistent launches / workgroups since the last reset on the current device and how many workgroups did not run on
@@ -548,6 +552,9 @@ int yt8m_comm_init(int rank, int world, const void* unique_id, void** comm_out);
 int yt8m_comm_size(void* comm, int* rank, int* world);
 int yt8m_comm_allreduce_f32(void* comm, float* buf, int64_t n, int mean, yt8m_stream_t stream);
 int yt8m_comm_allreduce_mean(void* comm, float* buf, int64_t n, yt8m_stream_t stream);
+/* the same reduction as reduce-scatter + all-gather (two RCCL launches, in place; phase 0 = both, 1 = reduce-scatter only: rank r
+ * then owns the reduced slice [r * (n / world), (r + 1) * (n / world)) plus the all-reduced n % world tail, 2 = all-gather only) */
+int yt8m_comm_allreduce_rsag_f32(void* comm, float* buf, int64_t n, int mean, int phase, yt8m_stream_t stream);
 int yt8m_comm_broadcast_f32(void* comm, float* buf, int64_t n, int root, yt8m_stream_t stream);
 int yt8m_comm_destroy(void* comm);
 

@@ -385,3 +385,95 @@ def test_full_lstm_model_step_through_the_c_abi_only(dev, flags):
     torch.cuda.synchronize()
     err = float((g.params - want).abs().max())
     assert err <= 1e-6 * max(1.0, float(want.abs().max())), err
+
+
+# ---- data-parallel readiness one GPU can prove --------------------------------------------------------------------
+@pytest.fixture()
+def one_rank_rccl(dev):
+    """A 1-rank RCCL (torch.distributed "nccl") group in this process: the whole reducer machinery runs, collectives are real RCCL
+    kernels on this GPU."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        yield dist
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+def _lstm_steps(dev, reducer, q, y, nf, steps=2, hog=None):
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(flm.LstmModel(), batch_size=q.shape[0], graph=g, reducer=reducer)
+    outs = []
+    for _ in range(steps):
+        if hog is not None:
+            hog()
+        outs.append(tg.step(q, y, nf)["predictions"].clone())
+    torch.cuda.synchronize()
+    seq_ops.check_persist_errors()
+    if reducer is not None:
+        reducer.detach()
+    return g.params.detach().clone(), outs
+
+
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_lstm_step_under_a_one_rank_reducer_is_bitwise_the_plain_step(dev, flags, one_rank_rccl, algo):
+    """The headline model (persistent kernels, native stack) under parallel.GradReducer on a 1-rank RCCL group -- bucketed async
+    all-reduce (or reduce-scatter + all-gather) of every gradient bucket, per-bucket clip + Adam, the CU headroom policy active --
+    ends two steps with bit-identical parameters and predictions to the plain single-GPU step."""
+    import yt8m_amd.parallel as parallel
+    flags.lstm_cells, flags.lstm_layers = "512", 2
+    rs = np.random.RandomState(5)
+    B, F, D, V = 64, 24, 64, 300
+    q = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
+    y = torch.from_numpy(rs.rand(B, V) < 0.02).to(dev)
+    nf = torch.from_numpy(rs.randint(1, F + 1, size=B).astype(np.int32)).to(dev)
+    n0 = seq_ops.NATIVE_CALLS["bwd"]
+    want, pw = _lstm_steps(dev, None, q, y, nf)
+    red = parallel.GradReducer(bucket_bytes=1 << 20, algo=algo)
+    got, pg = _lstm_steps(dev, red, q, y, nf)
+    assert seq_ops.NATIVE_CALLS["bwd"] == n0 + 4 and red.world == 1 and red.active
+    prev = ctypes.c_int(-1)
+    L.check(L.lib().yt8m_lstm_persist_reserve_cus(0, ctypes.byref(prev)))
+    assert prev.value == 0, "detach() must give the CU headroom back"
+    assert torch.equal(want, got)
+    for a, b in zip(pw, pg):
+        assert torch.equal(a, b)
+
+
+def test_persistent_recurrences_next_to_a_cu_hogging_kernel(dev, flags, one_rank_rccl):
+    """A long-running kernel on a side stream holds 48 CUs (what the RCCL kernels of a large all-reduce do during the backward pass
+    under data parallelism) while the step's persistent recurrences -- which need every workgroup resident -- are launched: with the
+    reducer's CU headroom they neither time out nor change a bit, and the step stays within a bounded factor of the unloaded one."""
+    import time
+    import yt8m_amd.parallel as parallel
+    flags.lstm_cells, flags.lstm_layers = "1024", 2
+    rs = np.random.RandomState(6)
+    B, F, D, V = 128, 24, 128, 300
+    q = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
+    y = torch.from_numpy(rs.rand(B, V) < 0.02).to(dev)
+    nf = torch.full((B,), F, dtype=torch.int32, device=dev)
+    want, _ = _lstm_steps(dev, None, q, y, nf, steps=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _lstm_steps(dev, None, q, y, nf, steps=3)
+    base = time.perf_counter() - t0
+    side = torch.cuda.Stream()
+    sink = torch.zeros((4,), device=dev)
+
+    def hog():                                                  # ~48 workgroups x ~10 ms of back-to-back MFMAs
+        L.check(L.lib().yt8m_probe_mfma_f32(10000, 48, _p(sink), ctypes.c_void_p(side.cuda_stream)))
+
+    red = parallel.GradReducer(bucket_bytes=1 << 20, reserve_cus=64)
+    t0 = time.perf_counter()
+    got, _ = _lstm_steps(dev, red, q, y, nf, steps=3, hog=hog)
+    loaded = time.perf_counter() - t0
+    assert torch.equal(want, got)
+    assert loaded < 8 * base + 0.5, (loaded, base)

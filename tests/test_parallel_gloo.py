@@ -35,7 +35,10 @@ def _worker(rank, world, port, overlap, q):
         shapes = {"gates/weights": (40, 90), "experts/weights": (40, 60), "experts/biases": (60,), "tiny": (3,)}
         vs = {k: g.get_variable(k, s, random_normal(0.1)) for k, s in shapes.items()}
         g.finalize()
-        red = parallel.GradReducer(bucket_bytes=4 * 2000, overlap=overlap)
+        # (the non-overlapped run also takes the reduce-scatter + all-gather form: on gloo, which has no reduce-scatter, it must
+        # fall back to one all-reduce per bucket and give the same sums)
+        red = parallel.GradReducer(bucket_bytes=4 * 2000, overlap=overlap, algo="allreduce" if overlap else "rs_ag")
+        assert red.algo == ("allreduce" if overlap else "rs_ag")
         red.attach(g)
         # 0. the random-op stream (dropout / noise keys) is rank-dependent and reproducible from (seed, rank, pass, call)
         from yt8m_amd.variables import random_seed

@@ -130,6 +130,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_fwd_on_bf16_pipe": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_set_cus": (c_int, [c_int, c_int]),
     "yt8m_lstm_persist_status": (c_int, [P, P]),
+    "yt8m_lstm_persist_reserve_cus": (c_int, [c_int, ctypes.POINTER(c_int)]),
     "yt8m_lstm_persist_debug_fault": (c_int, [P, P]),
     "yt8m_lstm_persist_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
@@ -171,6 +172,7 @@ SIGNATURES = {
     "yt8m_comm_size": (c_int, [P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "yt8m_comm_allreduce_f32": (c_int, [P, P, c_int64, c_int, P]),
     "yt8m_comm_allreduce_mean": (c_int, [P, P, c_int64, P]),
+    "yt8m_comm_allreduce_rsag_f32": (c_int, [P, P, c_int64, c_int, c_int, P]),
     "yt8m_comm_broadcast_f32": (c_int, [P, P, c_int64, c_int, P]),
     "yt8m_comm_destroy": (c_int, [P]),
     "yt8m_u8_proj_supported": (c_int, [c_int64]),

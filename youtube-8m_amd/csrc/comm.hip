@@ -19,6 +19,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   bool ok = false;
@@ -40,6 +42,8 @@ void rccl_load() {
   YT8M_SYM(CommDestroy, "ncclCommDestroy");
   YT8M_SYM(AllReduce, "ncclAllReduce");
   YT8M_SYM(Broadcast, "ncclBroadcast");
+  YT8M_SYM(ReduceScatter, "ncclReduceScatter");
+  YT8M_SYM(AllGather, "ncclAllGather");
   YT8M_SYM(GetErrorString, "ncclGetErrorString");
   YT8M_SYM(CommCount, "ncclCommCount");
 #undef YT8M_SYM
@@ -109,6 +113,39 @@ extern "C" int yt8m_comm_allreduce_f32(void* comm, float* buf, int64_t n, int me
   Comm* c = static_cast<Comm*>(comm);
   const ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, mean ? ncclAvg : ncclSum, c->c, as_stream(stream));
   if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+  return YT8M_OK;
+}
+
+// The same result as yt8m_comm_allreduce_f32 as TWO collectives: reduce-scatter (every rank ends up owning the reduced values of
+// its n / world slice) + all-gather of the slices, in place; the n % world tail goes through a small all-reduce.  Same bytes on
+// the wire as a ring all-reduce, but the two halves are separate launches: a host can put work between them that only needs the
+// rank's own slice (a sharded optimiser pass: clip + Adam on 1 / world of the parameters, then all-gather the PARAMETERS), and
+// RCCL's algorithm choice for each half is independent of its all-reduce heuristics (on point-to-point xGMI a
+// single ring is bound by one link).  `phase`: 0 = both, 1 = reduce-scatter (+ tail all-reduce) only, 2 = all-gather only.
+extern "C" int yt8m_comm_allreduce_rsag_f32(void* comm, float* buf, int64_t n, int mean, int phase, yt8m_stream_t stream) {
+  YT8M_REQUIRE(comm, YT8M_E_BADARG, "null communicator");
+  YT8M_REQUIRE(n >= 0 && phase >= 0 && phase <= 2, YT8M_E_SHAPE, "negative count / bad phase");
+  if (n == 0) return YT8M_OK;
+  YT8M_REQUIRE(buf, YT8M_E_BADARG, "null buffer");
+  YT8M_REQUIRE(g_rccl.ReduceScatter && g_rccl.AllGather, YT8M_E_RCCL, "this RCCL has no ncclReduceScatter / ncclAllGather");
+  Comm* c = static_cast<Comm*>(comm);
+  const int64_t per = n / c->world, tail = n - per * c->world;
+  const ncclRedOp_t op = mean ? ncclAvg : ncclSum;
+  hipStream_t s = as_stream(stream);
+  if (phase != 2) {
+    if (per > 0) {
+      const ncclResult_t r = g_rccl.ReduceScatter(buf, buf + (int64_t)c->rank * per, (size_t)per, ncclFloat32, op, c->c, s);
+      if (r != ncclSuccess) return rccl_fail("ncclReduceScatter", r);
+    }
+    if (tail > 0) {
+      const ncclResult_t r = g_rccl.AllReduce(buf + per * c->world, buf + per * c->world, (size_t)tail, ncclFloat32, op, c->c, s);
+      if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    }
+  }
+  if (phase != 1 && per > 0) {
+    const ncclResult_t r = g_rccl.AllGather(buf + (int64_t)c->rank * per, buf, (size_t)per, ncclFloat32, c->c, s);
+    if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  }
   return YT8M_OK;
 }
 

@@ -1154,6 +1154,11 @@ unsigned* stats_ptr(int dev) {
 // CUs a persistent launch may occupy: the whole chip, or YT8M_PERSIST_CUS of them (the rest stays free for kernels of other
 // streams -- the hoisted GEMMs of the layer pipeline -- to run beside the recurrence)
 int g_cap_fwd = -1, g_cap_bwd = -1;      // yt8m_lstm_persist_set_cus (calling thread's choice for its next launches); -1: environment
+// CUs the gate keeps out of its residency arithmetic (yt8m_lstm_persist_reserve_cus): under data parallelism the RCCL kernels of
+// the gradient all-reduce occupy CUs during the backward recurrences -- two half-chip launches admitted side by side would then
+// not both fit, and the second would spin on the CUs it got until the collective's kernels leave (a slowdown, never a deadlock:
+// RCCL's kernels do not wait for ours).  With a reserve the gate chains such launches instead.
+int g_reserved_cus = getenv("YT8M_PERSIST_RESERVED_CUS") ? atoi(getenv("YT8M_PERSIST_RESERVED_CUS")) : 0;
 int persist_cu_budget(int cus, bool bwd = false) {
   static const int cap = getenv("YT8M_PERSIST_CUS") ? atoi(getenv("YT8M_PERSIST_CUS")) : 0;
   static const int cap_b = getenv("YT8M_PERSIST_CUS_BWD") ? atoi(getenv("YT8M_PERSIST_CUS_BWD")) : 128;
@@ -1235,6 +1240,16 @@ extern "C" int yt8m_lstm_persist_set_cus(int fwd_cus, int bwd_cus) {
   YT8M_REQUIRE(fwd_cus >= -1 && bwd_cus >= -1, YT8M_E_BADARG, "CU counts must be >= -1");
   g_cap_fwd = fwd_cus;
   g_cap_bwd = bwd_cus;
+  return YT8M_OK;
+}
+
+// CUs to leave out of the gate's "do these persistent launches fit the chip together" arithmetic (0: none; the data-parallel
+// reducer reserves some for the RCCL kernels that run beside the backward pass).  Returns the previous value through *previous.
+extern "C" int yt8m_lstm_persist_reserve_cus(int cus, int* previous) {
+  YT8M_REQUIRE(cus >= 0 && cus <= 4096, YT8M_E_BADARG, "CU count out of range");
+  std::lock_guard<std::mutex> lk(g_gate.mu);
+  if (previous) *previous = g_reserved_cus;
+  g_reserved_cus = cus;
   return YT8M_OK;
 }
 
@@ -1343,7 +1358,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   ProfScope prof(F_LSTM, s, 2.0 * (double)T * (double)B * (double)H * 4.0 * (double)H);
   std::lock_guard<std::mutex> lk(g_gate.mu);
   const int total_cus = device_cus(nullptr);
-  int grc = g_gate.admit(dev, (int)grid, total_cus, s);
+  int grc = g_gate.admit(dev, (int)grid, std::max(0, total_cus - g_reserved_cus), s);
   if (grc != YT8M_OK) return grc;
   YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
   // the recurrent product on the bf16 pipe (lstm_persist_fwd_x3_kernel) when its preconditions hold: an exchange image (1.5x the
@@ -1451,7 +1466,7 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   ProfScope prof(F_LSTM_BWD, s, 2.0 * (double)T * (double)B * (double)H * 4.0 * (double)H);
   std::lock_guard<std::mutex> lk(g_gate.mu);
   const int total_cus = device_cus(nullptr);
-  int grc = g_gate.admit(dev, (int)grid, total_cus, s);
+  int grc = g_gate.admit(dev, (int)grid, std::max(0, total_cus - g_reserved_cus), s);
   if (grc != YT8M_OK) return grc;
   YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
   int rc;

@@ -71,15 +71,20 @@ class CabiComm(object):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         return ctypes.c_void_p(t.data_ptr())
 
-    def all_reduce(self, t, mean=False):
+    def all_reduce(self, t, mean=False, algo="allreduce"):
         """In place SUM (or mean) of a contiguous fp32 device tensor; returns a handle whose wait() orders the CURRENT stream
-        behind the collective."""
+        behind the collective.  algo "rs_ag": the same reduction as reduce-scatter + all-gather (yt8m_comm_allreduce_rsag_f32)."""
         import ctypes
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self.stream.wait_event(ready)
-        self._lib.check(self._lib.lib().yt8m_comm_allreduce_f32(self.handle, self._p(t), t.numel(), int(bool(mean)),
-                                                                ctypes.c_void_p(self.stream.cuda_stream)))
+        L = self._lib.lib()
+        if algo == "rs_ag":
+            self._lib.check(L.yt8m_comm_allreduce_rsag_f32(self.handle, self._p(t), t.numel(), int(bool(mean)), 0,
+                                                           ctypes.c_void_p(self.stream.cuda_stream)))
+        else:
+            self._lib.check(L.yt8m_comm_allreduce_f32(self.handle, self._p(t), t.numel(), int(bool(mean)),
+                                                      ctypes.c_void_p(self.stream.cuda_stream)))
         done = torch.cuda.Event()
         done.record(self.stream)
         t.record_stream(self.stream)
@@ -117,13 +122,56 @@ class _CabiHandle(object):
         torch.cuda.current_stream().wait_event(self.ev)
 
 
+class _Chain(object):
+    """Handles of collectives that were enqueued in order: waiting for the last one covers them all."""
+
+    def __init__(self, hs):
+        self.hs = hs
+
+    def wait(self):
+        for h in self.hs:
+            h.wait()
+
+
+def _rsag_torch(t, group):
+    """SUM all-reduce of a contiguous fp32 tensor as reduce-scatter + all-gather through torch.distributed (RCCL); the n % world tail
+    takes a small all-reduce.  Backends without reduce-scatter (gloo) fall back to one all-reduce."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    rank = dist.get_rank(group)
+    per = t.numel() // world
+    hs = []
+    if per > 0:
+        body = t[:per * world]
+        mine = body[rank * per:(rank + 1) * per]
+        hs.append(dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        hs.append(dist.all_gather_into_tensor(body, mine, group=group, async_op=True))
+    if t.numel() > per * world:
+        hs.append(dist.all_reduce(t[per * world:], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return _Chain(hs)
+
+
+DP_ALGO = os.environ.get("YT8M_DP_ALGO", "allreduce")              # "allreduce" | "rs_ag"
+DP_RESERVED_CUS = int(os.environ.get("YT8M_DP_RESERVED_CUS", "32"))   # CU headroom of the persistent recurrences for RCCL's kernels
+
+
 class GradReducer(object):
     """All-reduces the gradient arena of a variables.Graph; SUM over ranks, mean applied later via gscale.  Transport:
-    torch.distributed (backend "nccl" = RCCL) by default, or a CabiComm (the library's own RCCL binding) when `comm` is given."""
+    torch.distributed (backend "nccl" = RCCL) by default, or a CabiComm (the library's own RCCL binding) when `comm` is given.
+    algo: "allreduce" (one collective per bucket) or "rs_ag" (reduce-scatter + all-gather per bucket; same result).
+    While a reducer is attached the persistent recurrence launches leave `reserve_cus` CUs out of their residency arithmetic
+    (yt8m_lstm_persist_reserve_cus): RCCL's kernels run beside the backward pass, and two half-chip recurrences admitted side by
+    side would not both be resident next to them."""
 
-    def __init__(self, group=None, bucket_bytes=32 << 20, overlap=True, comm=None):
+    def __init__(self, group=None, bucket_bytes=32 << 20, overlap=True, comm=None, algo=None, reserve_cus=None):
         self.group = group
         self.comm = comm
+        self.algo = algo or DP_ALGO
+        if self.algo not in ("allreduce", "rs_ag"):
+            raise ValueError("algo must be 'allreduce' or 'rs_ag'")
+        self.reserve_cus = DP_RESERVED_CUS if reserve_cus is None else int(reserve_cus)
+        self._prev_reserve = None
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
@@ -149,6 +197,21 @@ class GradReducer(object):
         nv = len(graph.trainable_variables())
         self._ready = [False] * nv
         self._launched = [False] * nv
+        if self.active and self.reserve_cus > 0 and torch.cuda.is_available():
+            import ctypes
+            from . import _lib
+            prev = ctypes.c_int(0)
+            _lib.check(_lib.lib().yt8m_lstm_persist_reserve_cus(self.reserve_cus, ctypes.byref(prev)))
+            self._prev_reserve = prev.value
+
+    def detach(self):
+        """Gives the CU headroom back (end of data-parallel training in this process)."""
+        if self._prev_reserve is not None:
+            from . import _lib
+            _lib.check(_lib.lib().yt8m_lstm_persist_reserve_cus(self._prev_reserve, None))
+            self._prev_reserve = None
+        if self.graph is not None:
+            self.graph.grad_ready_hook = None
 
     def begin_step(self):
         self._handles = []
@@ -192,7 +255,9 @@ class GradReducer(object):
                 while pos < hi:
                     end = min(hi, pos + 4 * self.bucket_elems)
                     if self.comm is not None:
-                        hs.append(self.comm.all_reduce(self.graph.grads[pos:end]))
+                        hs.append(self.comm.all_reduce(self.graph.grads[pos:end], algo=self.algo))
+                    elif self.algo == "rs_ag":
+                        hs.append(_rsag_torch(self.graph.grads[pos:end], self.group))
                     else:
                         hs.append(dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     pos = end
