@@ -1,14 +1,15 @@
 """One training step of a rocprofv3 kernel trace as a timeline: kernels >= min_us in start order with start offset, duration
 and stream (queue).  The step is found between two consecutive adam_chunk_kernel launches.
-usage: python tools/trace_step.py <kernel_trace.csv> [min_us] [which step from the end, default 2]"""
+usage: python tools/trace_step.py <kernel_trace.csv> [min_us] [which step from the end, default 2] [delimiter kernel]"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 mn = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+delim = sys.argv[4] if len(sys.argv) > 4 else "adam_chunk_kernel"     # a kernel launched exactly once per step
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows)
-adam = [i for i, e in enumerate(ev) if "adam_chunk_kernel" in e[2]]
+adam = [i for i, e in enumerate(ev) if delim in e[2]]
 lo, hi = adam[-back - 1], adam[-back]
 t0 = ev[lo][1]
 print("step: %.3f ms between optimizer launches" % ((ev[hi][1] - ev[lo][1]) / 1e6))

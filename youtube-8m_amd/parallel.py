@@ -153,7 +153,13 @@ def _rsag_torch(t, group):
 
 
 DP_ALGO = os.environ.get("YT8M_DP_ALGO", "allreduce")              # "allreduce" | "rs_ag"
-DP_RESERVED_CUS = int(os.environ.get("YT8M_DP_RESERVED_CUS", "32"))   # CU headroom of the persistent recurrences for RCCL's kernels
+# CU headroom of the persistent recurrences for RCCL's kernels (0: none).  Measured on one MI355X with a 1-rank RCCL group
+# (profiles/r3_force_reducer.md): 32 reserved CUs chain the half-chip backward recurrences one at a time, +2.0 ms on a 24.4 ms step;
+# without a reserve a recurrence launched while a collective's kernels hold CUs spins on the part of its grid that is resident
+# until they leave -- bounded, never a deadlock (tests/test_gpu_round3.py::test_persistent_recurrences_next_to_a_cu_hogging_kernel).
+# The head's all-reduce (386 MB, launched ~0.3 ms into the backward pass) mostly runs beside the first, lone, half-chip recurrence,
+# so the default keeps the side-by-side schedule; set 32 on a node where the collectives are slow enough to collide with it.
+DP_RESERVED_CUS = int(os.environ.get("YT8M_DP_RESERVED_CUS", "0"))
 
 
 class GradReducer(object):
