@@ -312,6 +312,9 @@ int yt8m_colsum_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, flo
  * (overwritten).  workspace: 2 * yt8m_colsum_workspace_bytes(rows, cols), may be NULL. */
 int yt8m_colsum_weighted_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, const float* row_weights, float* out, float beta,
                              float* out_weighted, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* C[r][c] += scale * v[c] for every row r (cols % 4 == 0): the rank-1 remainder beta * 1 (x) colsum(r (.) dz) of the layer-0 weight
+ * gradient on uint8 frames, applied once per step */
+int yt8m_rank1_add_rows_f32(float* C, int64_t rows, int64_t cols, int64_t ldc, const float* v, float scale, yt8m_stream_t stream);
 
 /* ---- loss: CrossEntropyLoss (W/losses.py:110-130), probability space, eps = 1e-5 ---------------
  * loss = mean_b sum_l -[y log(p+eps) + (1-y) log(1-p+eps)] * (w_b);  dp = dloss/dp * upstream.

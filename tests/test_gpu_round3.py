@@ -477,3 +477,25 @@ def test_persistent_recurrences_next_to_a_cu_hogging_kernel(dev, flags, one_rank
     loaded = time.perf_counter() - t0
     assert torch.equal(want, got)
     assert loaded < 8 * base + 0.5, (loaded, base)
+
+
+def test_x1x3_alpha_without_a_rank1_term(dev):
+    """yt8m_gemm_x1x3_nt_ex with alpha != 1 and neither rowscale nor colsum (the per-part layer-0 weight-gradient product since the
+    rank-1 remainder moved to one pass per step): C (+)= alpha * A1 . B3^T."""
+    lib = L.lib()
+    rs = np.random.RandomState(3)
+    B, F, D, N = 16, 4, 64, 256
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    dz = rs.randn(F * B, N).astype(np.float32)
+    qd, dzd = torch.from_numpy(q).to(dev), torch.from_numpy(dz).to(dev)
+    FB = F * B
+    qT = torch.empty(((D + 31) // 32) * ((FB + 15) // 16) * 1024, dtype=torch.uint8, device=dev)
+    L.check(lib.yt8m_u8_frames_image_t(_p(qd), None, B, F, D, _p(qT), _stream()))
+    dzT = torch.empty(lib.yt8m_x3_image_bytes(N, FB), dtype=torch.uint8, device=dev)
+    L.check(lib.yt8m_x3_split(_p(dzd), FB, N, N, 1.0, None, _p(dzT), _stream()))
+    C = torch.full((D, N), 1.5, device=dev)
+    ws = torch.empty(lib.yt8m_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+    L.check(lib.yt8m_gemm_x1x3_nt_ex(D, N, FB, _p(qT), 0, _p(dzT), 0, _p(C), N, None, 0.25, None, None, 0.0, 1.0, _p(ws), ws.numel(), _stream()))
+    xm = _tm(q.astype(np.float64) - 128.0, B, F)
+    ref = 1.5 + 0.25 * xm.T @ dz.astype(np.float64)
+    assert np.abs(C.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()

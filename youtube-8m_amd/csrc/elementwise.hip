@@ -722,6 +722,32 @@ extern "C" int64_t yt8m_colsum_workspace_bytes(int64_t rows, int64_t cols) {
   return cols > 0 ? 256 * cols * (int64_t)sizeof(float) : 0;
 }
 
+// C[r][c] += scale * v[c] for every row r: the rank-1 remainder of a product whose operand is affine in an exact integer matrix
+// (the layer-0 weight gradient on uint8 frames: beta * 1 (x) colsum(r (.) dz), applied once per step)
+__global__ __launch_bounds__(256) void rank1_rows_kernel(float* __restrict__ C, int64_t rows, int64_t cols4, int64_t ldc,
+                                                         const float* __restrict__ v, float scale) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * cols4) return;
+  const int64_t r = e / cols4, c = (e - r * cols4) * 4;
+  const float4 a = *reinterpret_cast<const float4*>(v + c);
+  float4* p = reinterpret_cast<float4*>(C + r * ldc + c);
+  float4 o = *p;
+  o.x += scale * a.x; o.y += scale * a.y; o.z += scale * a.z; o.w += scale * a.w;
+  *p = o;
+}
+extern "C" int yt8m_rank1_add_rows_f32(float* C, int64_t rows, int64_t cols, int64_t ldc, const float* v, float scale, yt8m_stream_t stream) {
+  YT8M_REQUIRE(rows >= 0 && cols >= 0 && ldc >= cols, YT8M_E_SHAPE, "bad shape");
+  if (rows * cols == 0) return YT8M_OK;
+  YT8M_REQUIRE(C && v, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE((cols % 4) == 0 && (ldc % 4) == 0 && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(v)) & 15) == 0, YT8M_E_SHAPE,
+               "cols and ldc must be multiples of 4, operands 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t n = rows * (cols / 4);
+  hipLaunchKernelGGL(rank1_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, rows, cols / 4, ldc, v, scale);
+  return launch_status("rank1_rows_kernel");
+}
+
 // out[col] (+)= sum_r X[r][col] (beta 0 / 1) and out_weighted[col] = sum_r row_weights[r] X[r][col] (always overwritten) from one
 // pass over X.  workspace: 2 * yt8m_colsum_workspace_bytes(rows, cols).
 extern "C" int yt8m_colsum_weighted_f32(const float* X, int64_t rows, int64_t cols, int64_t ldx, const float* row_weights, float* out,

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
       float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
       if (row < g.M && col < g.N) {
         float* c = g.C + (int64_t)row * g.ldc + col;
-        if (g.rscale || g.cs) v = affine(g, v, row, col);
+        if (g.rscale || g.cs || g.alpha != 1.0f) v = affine(g, v, row, col);
         if (vec && col + 3 < g.N) {
           if (g.bias) {
             const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
     }
     const int row = m0 + e / TN, col = n0 + (e % TN);
     if (row >= g.M) continue;
-    if ((g.rscale || g.cs) && col + 3 < g.N) v = affine(g, v, row, col);
+    if ((g.rscale || g.cs || g.alpha != 1.0f) && col + 3 < g.N) v = affine(g, v, row, col);
     const float vv[4] = {v.x, v.y, v.z, v.w};
     float* c = g.C + (int64_t)row * g.ldc + col;
 #pragma unroll
@@ -606,7 +606,7 @@ extern "C" int yt8m_gemm_x1x3_nt(int64_t M, int64_t N, int64_t K, const void* A1
 extern "C" int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B3, int64_t skb, float* C,
                                     int64_t ldc, const float* bias, float alpha, const float* rowscale, const float* colsum,
                                     float colsum_scale, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
-  YT8M_REQUIRE(!(rowscale || colsum) || (N % 4) == 0, YT8M_E_SHAPE, "the affine epilogue needs N % 4 == 0");
+  YT8M_REQUIRE(!(rowscale || colsum || alpha != 1.0f) || (N % 4) == 0, YT8M_E_SHAPE, "the affine epilogue needs N % 4 == 0");
   YT8M_REQUIRE(!colsum || (reinterpret_cast<uintptr_t>(colsum) & 15) == 0, YT8M_E_SHAPE, "colsum must be 16-byte aligned");
   yt8m_gemm_problem p;
   p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = ska; p.B = B3; p.ldb = skb; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;

@@ -20,6 +20,7 @@
 //             first lone recurrence runs), db += colsum(dz);
 //             layer 0 on uint8 frames: dW_x += alpha ((q - 128)^T . (r (.) dz) + (beta / alpha) colsum(r (.) dz))   (x1x3: three
 //             products instead of six, and the fp32 time-major copy of the frames the round-2 path kept for it is gone).
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -35,6 +36,9 @@ constexpr int64_t X3_MIN_ROWS = 1024;                      // F * B below which 
 constexpr int64_t STEP_IMAGES_MAX_BYTES = 8LL << 30;       // per layer; larger launches keep the two-image exchange
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+
+// scheduling knobs (tuning aids; defaults are the measured best)
+int knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 struct Part { int64_t t0, T; };
 int chunks(int64_t F, int n, Part* out) {
@@ -57,9 +61,10 @@ struct Plan {
   // scratch
   int64_t pws[MAXL], pws_bytes;                            // persistent-recurrence workspaces: FIRST in the scratch (zero once)
   int64_t gws[MAXL + 1], gws_bytes;                        // split-K workspace per layer stream + weight-gradient stream
+  int64_t gwx[MAXL], gws2;                                 // ... per dx stream, second weight-gradient stream
   int64_t qimg, w3t, wcs, wxt3[MAXL], xi[MAXL];            // forward operand images
   int64_t dz[MAXL], dbuf[MAXL], work[MAXL];                // backward: dz [F,B,4H], dout of the layer below [F,B,H], running (dh, dc)
-  int64_t dz3[MAXL], wx3[MAXL], dzT3, dzT3s, csr, dbdummy; // chunk images
+  int64_t dz3[MAXL], wx3[MAXL], dzT3[MAXL], dzT3s, csr, dbdummy; // chunk images (dzT3 per layer: the chains may run on two streams)
   int64_t xT[MAXL], hT[MAXL];                              // whole-sequence transposed images (layer input / h_{t-1})
   int64_t scratch_bytes;
 };
@@ -84,6 +89,30 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   if (p.FB % 16 != 0) return "F * B must be a multiple of 16 (K ranges of the transposed operand images)";
   p.nf = chunks(p.F, d->fwd_chunks > 0 ? d->fwd_chunks : 1, p.fp);
   p.nb = chunks(p.F, d->bwd_chunks > 0 ? d->bwd_chunks : 3, p.bp);
+  // The library's own backward partition (bwd_chunks == 0): three parts of relative length 3 : 2 : 1 in forward-time order.  The
+  // backward pass runs them last to first: a SHORT first part (the top layer's recurrence runs alone on half the chip while it
+  // lasts, and the weight-gradient stream has nothing to do yet) and a long last one.  Measured on BASELINE configs[3]
+  // (profiles/r3_sched_knobs.md): 23.5-23.6 ms/step for 3:2:1, 7:4:2, 8:5:3, 5:3:1 against 24.0 for three equal parts.
+  static const char* dflt_parts = "3,2,1";
+  const char* spec = getenv("YT8M_STACK_BWD_PARTS");
+  if (!spec && d->bwd_chunks <= 0 && p.F >= 12) spec = dflt_parts;
+  if (spec) {                                                   // relative lengths in forward-time order
+    double w[MAXP], tot = 0;
+    int n = 0;
+    for (const char* q = spec; *q && n < MAXP;) { w[n] = atof(q); tot += w[n++]; while (*q && *q != ',') ++q; if (*q) ++q; }
+    if (n >= 1 && tot > 0) {
+      int64_t t0 = 0; double acc = 0; int k = 0;
+      Part pp[MAXP];
+      for (int i = 0; i < n; ++i) {
+        acc += w[i];
+        int64_t t1 = i + 1 == n ? p.F : (int64_t)(p.F * acc / tot + 0.5);
+        if (t1 > t0) { pp[k++] = {t0, t1 - t0}; t0 = t1; }
+      }
+      bool ok = k >= 1;
+      for (int i = 0; i < k; ++i) ok = ok && (pp[i].t0 * p.B) % 16 == 0 && (pp[i].T * p.B) % 16 == 0;
+      if (ok) { p.nb = k; for (int i = 0; i < k; ++i) p.bp[i] = pp[i]; }        // else: the equal parts above
+    }
+  }
   int64_t tmax = 0;
   for (int c = 0; c < p.nf; ++c) {
     if (p.u8 && (p.fp[c].t0 * p.B) % 32 != 0) return "a forward chunk does not start on a 32-row group of the frame image";
@@ -111,6 +140,8 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   for (int l = 0; l < p.L; ++l) { p.pws[l] = o; o += p.pws_bytes; }
   p.gws_bytes = up256(yt8m_gemm_workspace_bytes());
   for (int l = 0; l <= p.L; ++l) { p.gws[l] = o; o += p.gws_bytes; }
+  for (int l = 0; l < p.L; ++l) { p.gwx[l] = o; o += p.gws_bytes; }
+  p.gws2 = o; o += p.gws_bytes;
   const int64_t H4 = 4 * p.H;
   p.qimg = o; o += p.u8 ? up256(x1_bytes(p.FB, p.D)) : 0;
   p.w3t = o; o += p.u8 ? up256(x3_bytes(H4, p.D)) : 0;
@@ -132,7 +163,7 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
     p.xT[l] = o; o += x1 ? up256(x1_bytes(p.D, p.FB)) : up256(x3_bytes(Din, p.FB));
     p.hT[l] = o; o += up256(x3_bytes(p.H, p.FB));
   }
-  p.dzT3 = o; o += up256(x3_bytes(H4, bmax));
+  for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(x3_bytes(H4, bmax)); }
   p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, bmax)) : 0;
   p.csr = o; o += up256(H4 * 4);
   p.dbdummy = o; o += up256(H4 * 4);
@@ -144,7 +175,8 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
 struct DevState {
   bool init = false;
   hipStream_t rs[MAXL];
-  hipStream_t sw;
+  hipStream_t dxs[MAXL];              // dz split + dx product of a layer (high priority): frees the layer stream for its next part
+  hipStream_t sw, sw2;
   std::vector<hipEvent_t> ev[2];      // forward / backward pools
   size_t used[2] = {0, 0};
 };
@@ -162,7 +194,9 @@ int dev_state(int L, DevState** out) {
     // the layer streams are HIGH priority: a persistent recurrence needs every workgroup resident and must take freed CUs before
     // the queued workgroups of a weight-gradient GEMM do ("Scheduling around them")
     for (int l = 0; l < MAXL; ++l) YT8M_HIP_CHECK(hipStreamCreateWithPriority(&S.rs[l], hipStreamNonBlocking, greatest));
+    for (int l = 0; l < MAXL; ++l) YT8M_HIP_CHECK(hipStreamCreateWithPriority(&S.dxs[l], hipStreamNonBlocking, greatest));
     YT8M_HIP_CHECK(hipStreamCreateWithFlags(&S.sw, hipStreamNonBlocking));
+    YT8M_HIP_CHECK(hipStreamCreateWithFlags(&S.sw2, hipStreamNonBlocking));
     S.init = true;
   }
   (void)L;
@@ -333,11 +367,13 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   RC(dev_state(P.L, &S));
   Ev ev(*S, 1);
   hipStream_t main = as_stream(stream), sw = S->sw;
+  static const int dx_stream = knob("YT8M_STACK_DX_STREAM", 0), two_sw = knob("YT8M_STACK_SW2", 0);
   const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H, FB = P.FB;
   const int64_t KBtot = FB / 16;
   hipEvent_t start = ev.record(main);
   ev.wait(sw, start);
-  for (int l = 0; l < P.L; ++l) ev.wait(S->rs[l], start);
+  if (two_sw) ev.wait(S->sw2, start);
+  for (int l = 0; l < P.L; ++l) { ev.wait(S->rs[l], start); if (dx_stream) ev.wait(S->dxs[l], start); }
   // weight-gradient stream: the whole-sequence transposed operands (K = frame rows), made while the first recurrence runs alone
   for (int l = 0; l < P.L; ++l) {
     if (!dW[l]) continue;
@@ -350,6 +386,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     }
     RC(yt8m_x3_split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));    // h_{t-1}: hs[0 .. F)
   }
+  if (two_sw) ev.wait(S->sw2, ev.record(sw));              // layer 0's chain reads images made on sw
   int phase[MAXL];
   bool wx3_done[MAXL];
   for (int l = 0; l < P.L; ++l) {
@@ -383,49 +420,61 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       hipEvent_t rb = ev.record(s);
       const float* dzc = dz + t0 * B * H4;
       dx_ev = nullptr;
-      if (l > 0 || P.need_dx) {                            // dz as stored feeds dx: on the layer stream (critical path)
-        RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), nullptr, s));
+      if (l > 0 || P.need_dx) {                            // dz as stored feeds dx: the critical path to the layer below
+        hipStream_t sx = dx_stream ? S->dxs[l] : s;        // (on its own stream the layer's next part starts at once)
+        if (dx_stream) ev.wait(sx, rb);
+        RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), nullptr, sx));
         if (!wx3_done[l]) {
-          RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, s));       // W_x: rows Din, K = 4H
+          RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));      // W_x: rows Din, K = 4H
           wx3_done[l] = true;
         }
         float* dst = l ? at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H : dx + t0 * B * D;
         yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 0.0f};
-        RC(yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, P.gws[l]), P.gws_bytes, s));
-        dx_ev = ev.record(s);
+        RC(yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx));
+        dx_ev = ev.record(sx);
         if (c == 0) last.push_back(dx_ev);
       }
       // weight-gradient stream: transposed image(s) of this part's dz, the two products, the bias gradient
+      hipStream_t sw = (two_sw && l == 0) ? S->sw2 : S->sw;       // (knob: layer 0's chain on a second weight-gradient stream)
       ev.wait(sw, rb);
-      void* gw = at<char>(scratch, P.gws[P.L]);
+      void* gw = at<char>(scratch, (two_sw && l == 0) ? P.gws2 : P.gws[P.L]);
       const float bW = first ? (beta_W ? beta_W[l] : 0.f) : 1.f;
-      const float bb = first ? (beta_b ? beta_b[l] : 0.f) : 1.f;
-      bool db_done = false;
+      // Bias gradient and the rank-1 remainder of layer 0's uint8 product: ONE pass over the layer's whole dz after its last part
+      // (c == 0) instead of a column sum per part -- three launches fewer per part on the chain that ends the backward pass.
+      const bool lastpart = c == 0;
       if (dW[l]) {
         if (l == 0 && P.u8) {
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
-          RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3), at<char>(scratch, P.dzT3s), sw));
-          float* dbo = db[0] ? db[0] : at<float>(scratch, P.dbdummy);
-          RC(yt8m_colsum_weighted_f32(dzc, M, H4, H4, rr, dbo, db[0] ? bb : 0.f, at<float>(scratch, P.csr), gw, P.gws_bytes, sw));
-          db_done = true;
+          RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), sw));
           RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, at<char>(scratch, P.dzT3s), 0, dW[0], H4,
-                                  nullptr, U8_ALPHA, nullptr, at<float>(scratch, P.csr), U8_BETA / U8_ALPHA, bW, gw, P.gws_bytes, sw));
-          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3), 0,
+                                  nullptr, U8_ALPHA, nullptr, nullptr, 0.f, bW, gw, P.gws_bytes, sw));
+          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0,
                                   dW[0] + D * H4, H4, nullptr, bW};
           RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, sw));
         } else {
-          RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3), sw));
+          RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
           yt8m_gemm_problem pr[2] = {
-              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3), 0, dW[l], H4, nullptr, bW},
-              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3), 0, dW[l] + Din * H4, H4, nullptr, bW}};
+              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
+              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
           RC(yt8m_gemm_x3_nt_grouped(2, pr, gw, P.gws_bytes, sw));
         }
       }
-      if (db[l] && !db_done) RC(yt8m_colsum_f32(dzc, M, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+      if (lastpart) {
+        const float bb = beta_b ? beta_b[l] : 0.f;
+        if (dW[l] && l == 0 && P.u8) {
+          float* dbo = db[0] ? db[0] : at<float>(scratch, P.dbdummy);
+          RC(yt8m_colsum_weighted_f32(dz, FB, H4, H4, at<float>(tape, P.rrow), dbo, db[0] ? bb : 0.f, at<float>(scratch, P.csr), gw,
+                                      P.gws_bytes, sw));
+          RC(yt8m_rank1_add_rows_f32(dW[0], D, H4, H4, at<float>(scratch, P.csr), U8_BETA, sw));
+        } else if (db[l]) {
+          RC(yt8m_colsum_f32(dz, FB, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+        }
+      }
     }
   }
   hipEvent_t fin = ev.record(sw);                          // sw waited for every recurrence part
   ev.wait(main, fin);
+  if (two_sw) ev.wait(main, ev.record(S->sw2));
   for (hipEvent_t e : last) ev.wait(main, e);
   return ev.rc;
 }

@@ -379,8 +379,12 @@ NATIVE_CALLS = {"fwd": 0, "bwd": 0}     # how often the native path ran (tests a
 
 
 def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx):
-    return _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)), float(forget_bias), int(PERSIST_FWD_CHUNKS),
-                              int(PERSIST_BWD_CHUNKS), int(bool(need_dx)))
+    # 0 = the library's own partition (csrc/lstm_stack.hip: one forward launch per layer, three unequal backward parts) unless the
+    # environment / a test names a number of parts
+    fwd = PERSIST_FWD_CHUNKS if (PERSIST_FWD_CHUNKS != 1 or "YT8M_LSTM_PERSIST_FWD_CHUNKS" in _os.environ) else 0
+    bwd = PERSIST_BWD_CHUNKS if (PERSIST_BWD_CHUNKS != 3 or "YT8M_LSTM_PERSIST_BWD_CHUNKS" in _os.environ) else 0
+    return _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)), float(forget_bias), int(fwd), int(bwd),
+                              int(bool(need_dx)))
 
 
 def _stack_scratch(dev, main, desc):
