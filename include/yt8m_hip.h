@@ -458,6 +458,10 @@ int yt8m_lstm_stack_supported(const yt8m_lstm_stack_desc* desc);
 int64_t yt8m_lstm_stack_tape_bytes(const yt8m_lstm_stack_desc* desc);
 int64_t yt8m_lstm_stack_scratch_bytes(const yt8m_lstm_stack_desc* desc);
 int yt8m_lstm_stack_partition(const yt8m_lstm_stack_desc* desc, int* fwd_chunks, int* bwd_chunks);
+/* the library's per-device streams: L high-priority layer streams + the weight-gradient stream (created on first use, never
+ * destroyed).  Hosts that orchestrate the per-call entry points themselves should reuse them: all streams of a process share a
+ * few hardware queues, and kernels of streams that land on one queue serialise. */
+int yt8m_lstm_stack_streams(int L, yt8m_stream_t* layer_streams, yt8m_stream_t* wgrad_stream);
 int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W,
                         const float* const* b, void* tape, int64_t tape_bytes, void* scratch, int64_t scratch_bytes,
                         yt8m_stream_t stream);

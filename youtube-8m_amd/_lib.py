@@ -58,6 +58,7 @@ SIGNATURES = {
     "yt8m_lstm_stack_tape_bytes": (c_int64, [DESC]),
     "yt8m_lstm_stack_scratch_bytes": (c_int64, [DESC]),
     "yt8m_lstm_stack_partition": (c_int, [DESC, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "yt8m_lstm_stack_streams": (c_int, [c_int, PP, ctypes.POINTER(c_void_p)]),
     "yt8m_lstm_stack_fwd": (c_int, [DESC, P, P, PP, PP, P, c_int64, P, c_int64, P]),
     "yt8m_lstm_stack_view": (c_int, [DESC, P, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "yt8m_lstm_stack_bwd": (c_int, [DESC, P, P, PP, P, c_int64, P, c_int64, P, PP, PP, PP, PP, ctypes.POINTER(c_float),

@@ -172,34 +172,51 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
 }
 
 // ---- per-device streams and events (created once, never destroyed: they live as long as the library) ----------------------------
+// Streams are created on demand and only as many as a step uses: the runtime multiplexes every stream of a process onto a few
+// hardware queues (4 by default), and kernels of two streams that share a queue serialise -- sixteen idle high-priority streams
+// created here once pushed the layer streams of the Python orchestration onto one queue (the bf16 variant of the bench: 19.9 ->
+// 46 ms/step).  With L = 2 a step uses the caller's stream + 2 layer streams + 1 weight-gradient stream = 4.
 struct DevState {
-  bool init = false;
-  hipStream_t rs[MAXL];
-  hipStream_t dxs[MAXL];              // dz split + dx product of a layer (high priority): frees the layer stream for its next part
-  hipStream_t sw, sw2;
+  hipStream_t rs[MAXL] = {nullptr};
+  hipStream_t dxs[MAXL] = {nullptr};  // dz split + dx product of a layer (knob YT8M_STACK_DX_STREAM): frees the layer stream
+  hipStream_t sw = nullptr, sw2 = nullptr;
+  int prio = 0;
+  bool prio_known = false;
   std::vector<hipEvent_t> ev[2];      // forward / backward pools
   size_t used[2] = {0, 0};
 };
 std::mutex g_mu;
 DevState g_dev[16];
 
+int high_stream(DevState& S, hipStream_t* s) {
+  if (*s) return YT8M_OK;
+  if (!S.prio_known) {
+    int least = 0, greatest = 0;
+    YT8M_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    S.prio = greatest;
+    S.prio_known = true;
+  }
+  // HIGH priority: a persistent recurrence needs every workgroup resident and must take freed CUs before the queued workgroups
+  // of a weight-gradient GEMM do ("Scheduling around them")
+  YT8M_HIP_CHECK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, S.prio));
+  return YT8M_OK;
+}
+int plain_stream(hipStream_t* s) {
+  if (*s) return YT8M_OK;
+  YT8M_HIP_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  return YT8M_OK;
+}
+
 int dev_state(int L, DevState** out) {
   int dev = 0;
   YT8M_HIP_CHECK(hipGetDevice(&dev));
   YT8M_REQUIRE(dev >= 0 && dev < 16, YT8M_E_BADARG, "device index out of range");
   DevState& S = g_dev[dev];
-  if (!S.init) {
-    int least = 0, greatest = 0;
-    YT8M_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // the layer streams are HIGH priority: a persistent recurrence needs every workgroup resident and must take freed CUs before
-    // the queued workgroups of a weight-gradient GEMM do ("Scheduling around them")
-    for (int l = 0; l < MAXL; ++l) YT8M_HIP_CHECK(hipStreamCreateWithPriority(&S.rs[l], hipStreamNonBlocking, greatest));
-    for (int l = 0; l < MAXL; ++l) YT8M_HIP_CHECK(hipStreamCreateWithPriority(&S.dxs[l], hipStreamNonBlocking, greatest));
-    YT8M_HIP_CHECK(hipStreamCreateWithFlags(&S.sw, hipStreamNonBlocking));
-    YT8M_HIP_CHECK(hipStreamCreateWithFlags(&S.sw2, hipStreamNonBlocking));
-    S.init = true;
-  }
-  (void)L;
+  for (int l = 0; l < L; ++l) { int rc = high_stream(S, &S.rs[l]); if (rc != YT8M_OK) return rc; }
+  { int rc = plain_stream(&S.sw); if (rc != YT8M_OK) return rc; }
+  if (knob("YT8M_STACK_DX_STREAM", 0))
+    for (int l = 0; l < L; ++l) { int rc = high_stream(S, &S.dxs[l]); if (rc != YT8M_OK) return rc; }
+  if (knob("YT8M_STACK_SW2", 0)) { int rc = plain_stream(&S.sw2); if (rc != YT8M_OK) return rc; }
   *out = &S;
   return YT8M_OK;
 }
@@ -250,6 +267,19 @@ extern "C" int yt8m_lstm_stack_partition(const yt8m_lstm_stack_desc* desc, int* 
   YT8M_REQUIRE(!why, YT8M_E_SHAPE, why ? why : "");
   if (fwd_chunks) *fwd_chunks = P.nf;
   if (bwd_chunks) *bwd_chunks = P.nb;
+  return YT8M_OK;
+}
+
+// The library's per-device streams (created on first use): L high-priority layer streams and the weight-gradient stream.  A host
+// that runs its own orchestration of the per-call entry points beside the stack (the Python fallback paths do) should use THESE
+// streams rather than create more: the runtime multiplexes all streams of a process onto a few hardware queues.
+extern "C" int yt8m_lstm_stack_streams(int L, yt8m_stream_t* layer_streams, yt8m_stream_t* wgrad_stream) {
+  YT8M_REQUIRE(L >= 1 && L <= MAXL && layer_streams, YT8M_E_BADARG, "1..8 layers, non-null output");
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevState* S = nullptr;
+  RC(dev_state(L, &S));
+  for (int l = 0; l < L; ++l) layer_streams[l] = (yt8m_stream_t)S->rs[l];
+  if (wgrad_stream) *wgrad_stream = (yt8m_stream_t)S->sw;
   return YT8M_OK;
 }
 

@@ -254,6 +254,15 @@ def _side_streams(device, L, persistent=False, separate_gemm=False):
     of their own -- on the layer stream a projection's workgroups compete at high priority with the OTHER layer's recurrence for
     the CUs it needs (one run in three took 41 instead of 24.6 ms/step)."""
     pool = _SIDE.setdefault((device, bool(persistent)), dict(r=[], g=[], w=None))
+    if persistent and len(pool["r"]) < L:
+        # the library's own streams (csrc/lstm_stack.hip): every stream of a process is multiplexed onto a few hardware queues, and a
+        # second set of layer streams next to the native stack's put both layers of this orchestration on ONE queue (bf16 variant of
+        # the bench: 19.9 -> 46 ms/step)
+        with torch.cuda.device(device):
+            arr, w = (ctypes.c_void_p * L)(), ctypes.c_void_p()
+            _lib.check(_lib.lib().yt8m_lstm_stack_streams(L, arr, ctypes.byref(w)))
+        pool["r"] = [torch.cuda.ExternalStream(int(arr[l]), device=device) for l in range(L)]
+        pool["w"] = torch.cuda.ExternalStream(int(w.value), device=device)
     while len(pool["r"]) < L:
         pool["r"].append(torch.cuda.Stream(device=device, priority=REC_STREAM_PRIORITY if persistent else 0))
     if pool["w"] is None:
