@@ -132,6 +132,14 @@ int yt8m_gemm_x1x3_nt(int64_t M, int64_t N, int64_t K, const void* A1, const voi
 int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B3, int64_t skb, float* C,
                          int64_t ldc, const float* bias, float alpha, const float* rowscale, const float* colsum,
                          float colsum_scale, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* bf16 operands as ONE-plane images (BASELINE configs[4] / --compute_dtype=bfloat16): yt8m_bf16_image rounds an fp32 matrix to
+ * bfloat16 (nearest even) straight into the image layout ([rows / 32][K / 16][32 rows][2 halves][8] bf16 = yt8m_x3_image_bytes / 3
+ * bytes; plain: rows = R, K = C; trans: rows = C, K = R) and yt8m_gemm_b1_nt_grouped multiplies two such images, C (+)= A . B^T
+ * (+ bias), fp32 accumulate / output.  A wave's LDS-DMA instruction on an image moves 1 KiB of consecutive memory; the row-major
+ * bf16 kernel (yt8m_gemm_bf16_nt_grouped) is bound by operand delivery at 64-128 bytes per row.  Problems as in
+ * yt8m_gemm_x3_nt_grouped (lda / ldb = K-block strides, 0 = exact). */
+int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
+int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* yt8m_x3_split with a third output from the same pass: trans_scaled = x3 image of (diag(rowscale) . scale . src)^T
  * ([C rows, K = R]; rowscale [R]).  Any image may be NULL; rowscale and trans_scaled come together. */
 int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
@@ -296,6 +304,12 @@ int yt8m_moe_mix_bwd_bf16(const float* Zg, const float* Ze, const float* dp, con
                           int M, float eps, float dscale, const float* upstream_dev, void* dZg_b, int64_t gb_ld, void* dZg_t,
                           int64_t gt_ld, void* dZe_b, int64_t eb_ld, void* dZe_t, int64_t et_ld, float* be_part,
                           yt8m_stream_t stream);
+/* the same pass with the four bf16 outputs as ONE-plane operand images of yt8m_gemm_b1_nt_grouped (plain images: rows = B,
+ * K = V (M+1) resp. V M; transposed: rows = V (M+1) resp. V M, K = B); *_kb = K-block counts ceil(K / 16) of the images */
+int yt8m_moe_mix_bwd_bf16_images(const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype,
+                                 int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev,
+                                 void* dZg_img, int64_t g_kb, void* dZg_t_img, int64_t gt_kb, void* dZe_img, int64_t e_kb,
+                                 void* dZe_t_img, int64_t et_kb, float* be_part, yt8m_stream_t stream);
 
 /* ---- elementwise activations + column sums (bias gradients) ------------------------------------ */
 enum yt8m_act { YT8M_ACT_SIGMOID = 0, YT8M_ACT_RELU = 1, YT8M_ACT_RELU6 = 2, YT8M_ACT_TANH = 3, YT8M_ACT_ELU = 4 };

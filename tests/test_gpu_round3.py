@@ -499,3 +499,71 @@ def test_x1x3_alpha_without_a_rank1_term(dev):
     xm = _tm(q.astype(np.float64) - 128.0, B, F)
     ref = 1.5 + 0.25 * xm.T @ dz.astype(np.float64)
     assert np.abs(C.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+# ---- the bf16 configuration's products on one-plane operand images ------------------------------------------------
+def test_b1_image_gemm_matches_row_major_bf16(dev):
+    """yt8m_bf16_image + yt8m_gemm_b1_nt_grouped against the row-major bf16 kernel on the same bfloat16 values (identical products,
+    fp32 accumulation in another order): ragged shapes, bias, accumulate, grouped launch; and the image equals plane 0 of the
+    three-plane split bit for bit (round to nearest even)."""
+    from oracle import x3_ref
+    import yt8m_amd.ops as ops
+    rs = np.random.RandomState(2)
+    x = (rs.randn(70, 37) * np.exp(rs.randn(70, 37) * 3)).astype(np.float32)
+    ip, it = ops.bf16_image(torch.from_numpy(x).to(dev), both=True)
+    wp, wt = x3_ref.image(x)[:, :, 0], x3_ref.image(np.ascontiguousarray(x.T))[:, :, 0]
+    assert np.array_equal(ip.buf.cpu().numpy().view(np.uint16).reshape(wp.shape), wp)
+    assert np.array_equal(it.buf.cpu().numpy().view(np.uint16).reshape(wt.shape), wt)
+    g = torch.Generator(device=dev).manual_seed(4)
+    items_i, items_r = [], []
+    for (M, N, K) in ((1000, 777, 1000), (300, 5000, 72), (2048, 4800, 1024)):
+        A, Bm = torch.randn((M, K), device=dev, generator=g), torch.randn((N, K), device=dev, generator=g)
+        bias = torch.randn((N,), device=dev, generator=g)
+        c0 = torch.randn((M, N), device=dev, generator=g)
+        items_i.append(dict(A=ops.bf16_image(A), B=ops.bf16_image(Bm), bias=bias, out=c0.clone(), beta=1.0))
+        Ab, Bb = ops._bf16_empty(M, K, dev), ops._bf16_empty(N, K, dev)
+        Ab.copy_(A)
+        Bb.copy_(Bm)
+        items_r.append(dict(A=Ab, B=Bb, bias=bias, out=c0.clone(), beta=1.0))
+    got = ops.gemm_b1_grouped(items_i)
+    want = ops.gemm_bf16_nt_grouped(items_r)
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+def test_moe_head_bf16_on_images_matches_row_major(dev, flags, monkeypatch):
+    """MoeModel with --compute_dtype=bfloat16 at a size where the head's three products take the image kernel (the fused mixing
+    backward writes dL/dZ straight into operand images): predictions, loss and all gradients against the row-major bf16 path --
+    same bfloat16 operands, so they agree to fp32 accumulation order."""
+    import yt8m_amd.ops as ops
+    import yt8m_amd.video_level_models as vlm
+    flags.compute_dtype = "bfloat16"
+    rs = np.random.RandomState(9)
+    B, D, V = 2048, 1024, 1600
+    x = torch.from_numpy(rs.randn(B, D).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rs.rand(B, V) < 0.01).to(dev)
+    res = {}
+    for images in (True, False):
+        monkeypatch.setattr(ops, "B1_IMAGES", images)
+        calls = {"b1": 0}
+        real = ops.gemm_b1_grouped
+
+        def spy(items, _real=real, _c=calls):
+            _c["b1"] += len(items)
+            return _real(items)
+
+        monkeypatch.setattr(ops, "gemm_b1_grouped", spy)
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g)
+        out = tg.forward(x, y)
+        g.finalize()
+        out = tg.forward(x, y)
+        loss = tg.loss(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert (calls["b1"] >= 4) == images, calls
+        res[images] = (out["predictions"].detach().clone(), float(loss), g.grads.detach().clone())
+        monkeypatch.setattr(ops, "gemm_b1_grouped", real)
+    (pa, la, ga), (pb, lb, gb) = res[True], res[False]
+    assert float((pa - pb).abs().max()) < 1e-5 and abs(la - lb) <= 1e-5 * abs(lb)
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())

@@ -52,6 +52,8 @@ SIGNATURES = {
     "yt8m_gemm_x1x3_nt": (c_int, [c_int64, c_int64, c_int64, P, P, P, c_int64, P, P, P, c_float, P, c_int64, P]),
     "yt8m_gemm_x1x3_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, c_float, c_float, P,
                                      c_int64, P]),
+    "yt8m_bf16_image": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
+    "yt8m_gemm_b1_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
     "yt8m_x3_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "yt8m_u8_frames_image_t": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),
     "yt8m_lstm_stack_supported": (c_int, [DESC]),
@@ -107,6 +109,8 @@ SIGNATURES = {
     "yt8m_add_noise_f32": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, c_int64, P]),
     "yt8m_moe_mix_bwd_bf16_partial_rows": (c_int64, [c_int64]),
     "yt8m_moe_mix_bwd_bf16": (c_int, [P, P, P, P, c_int, c_int64, c_int64, c_int, c_float, c_float, P, P, c_int64, P, c_int64,
+                                      P, c_int64, P, c_int64, P, P]),
+    "yt8m_moe_mix_bwd_bf16_images": (c_int, [P, P, P, P, c_int, c_int64, c_int64, c_int, c_float, c_float, P, P, c_int64, P, c_int64,
                                       P, c_int64, P, c_int64, P, P]),
     "yt8m_act_fwd_f32": (c_int, [c_int, P, P, c_int64, P]),
     "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),

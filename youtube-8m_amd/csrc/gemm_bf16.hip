@@ -23,6 +23,9 @@ constexpr int TILE_F = BKF * 256;                     // floats of one operand t
 #ifndef YT8M_BF16_GM
 #define YT8M_BF16_GM 4
 #endif
+#ifndef YT8M_BF16_STAGGER
+#define YT8M_BF16_STAGGER 0        // two wave groups half a K-step apart (0: every wave in lockstep, one barrier per step)
+#endif
 constexpr int NST = YT8M_BF16_NST;                    // LDS-DMA ring depth (tools/build_variant.sh -DYT8M_BF16_NST=3 for A/B)
 constexpr int STAGE_F = 2 * TILE_F;                   // A tile + B tile
 
@@ -121,86 +124,10 @@ __device__ __forceinline__ void wait_dma(int younger_steps) {      // 4 DMA inst
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 128 KiB
-  int tile, part = 0, nparts = 1, slot = 0;
-  if ((int)blockIdx.x < G.full) {
-    tile = xcd_remap(blockIdx.x, G.full);
-  } else {
-    slot = blockIdx.x - G.full;
-    const int rt = slot / G.S;
-    part = slot - rt * G.S;
-    nparts = G.S;
-    tile = G.full + rt;
-  }
-  int q = 0;
-#pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
-  const BArgs& g = G.p[q];
-  int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-  const int li = lane & 31, lk = lane >> 5;
-  const int nk_all = (g.K + BKF - 1) / BKF;
-  const int kb = (int)((int64_t)nk_all * part / nparts), ke = (int)((int64_t)nk_all * (part + 1) / nparts);
-  const int nk = ke - kb;                                          // K-steps kb .. ke-1 of this tile (local index 0 .. nk-1)
-  const bool tail = ke == nk_all && nk_all * BKF != g.K;           // the last step is a guarded (non-DMA) fill
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // prologue: steps 0, 1, 2 on the wire; wait for step 0 only
-  const int pro = nk < 3 ? nk : 3;
-  for (int s = 0; s < pro; ++s) fill_step(g, m0, n0, kb + s, smem + s * STAGE_F, tid);
-  // DMA steps younger than step 0 that are still allowed in flight; once the guarded tail has been stored (its register
-  // loads completed in order behind every DMA) everything has landed and a full drain is exact
-  {
-    const bool tail_issued = tail && pro == nk;
-    wait_dma(tail_issued ? 0 : pro - 1);
-  }
-  __builtin_amdgcn_s_barrier();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 3 < nk) fill_step(g, m0, n0, kb + kt + 3, smem + ((cur + 3) & 3) * STAGE_F, tid);
-    const float* As = smem + cur * STAGE_F;
-    const float* Bs = As + TILE_F;
-    bf16x8 a[2][4], b[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[h][t] = frag(As, wm + t * 32 + li, h, lk);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) b[h][t] = frag(Bs, wn + t * 32 + li, h, lk);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // step kt+1 must have landed; kt+2 and kt+3 may stay on the wire
-    {
-      const int last_issued = kt + 3 < nk ? kt + 3 : nk - 1;
-      const bool tail_issued = tail && last_issued == nk - 1;
-      int younger = last_issued - (kt + 1);
-      if (younger < 0) younger = 0;
-      wait_dma(tail_issued ? 0 : younger);
-    }
-    __builtin_amdgcn_s_barrier();
-    cur = (cur + 1) & 3;
-  }
-
-  // epilogue: accumulators -> wave-private LDS image [32][68] -> 16-byte stores (the store pipe is issue-bound)
+// epilogue shared by both large-tile kernels: accumulators -> wave-private LDS image [32][68] -> 16-byte stores (the store pipe is
+// issue-bound); split-K parts park raw accumulators in the workspace
+__device__ __forceinline__ void tile_epilogue(const BGroup& G, const BArgs& g, f32x16 (&acc)[4][2], float* smem, int m0, int n0, int wm,
+                                              int wn, int lane, int wave, int li, int lk, int nparts, int slot) {
   constexpr int P = 68;
   float* st = smem + wave * (32 * P);
   if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace image
@@ -256,6 +183,289 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats = 128 KiB
+  int tile, part = 0, nparts = 1, slot = 0;
+  if ((int)blockIdx.x < G.full) {
+    tile = xcd_remap(blockIdx.x, G.full);
+  } else {
+    slot = blockIdx.x - G.full;
+    const int rt = slot / G.S;
+    part = slot - rt * G.S;
+    nparts = G.S;
+    tile = G.full + rt;
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  const BArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int nk_all = (g.K + BKF - 1) / BKF;
+  const int kb = (int)((int64_t)nk_all * part / nparts), ke = (int)((int64_t)nk_all * (part + 1) / nparts);
+  const int nk = ke - kb;                                          // K-steps kb .. ke-1 of this tile (local index 0 .. nk-1)
+  const bool tail = ke == nk_all && nk_all * BKF != g.K;           // the last step is a guarded (non-DMA) fill
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: steps 0, 1, 2 on the wire; wait for step 0 only
+  const int pro = nk < 3 ? nk : 3;
+  for (int s = 0; s < pro; ++s) fill_step(g, m0, n0, kb + s, smem + s * STAGE_F, tid);
+  // DMA steps younger than step 0 that are still allowed in flight; once the guarded tail has been stored (its register
+  // loads completed in order behind every DMA) everything has landed and a full drain is exact
+  {
+    const bool tail_issued = tail && pro == nk;
+    wait_dma(tail_issued ? 0 : pro - 1);
+  }
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+#if YT8M_BF16_STAGGER
+  // Two wave groups (waves 0-3 / 4-7: one wave of each on every SIMD) run the K-step in two phases, HALF A STEP APART:
+  //   load phase  : LDS-DMA of step kt+3, the 12 fragment reads of step kt, the counted wait for this wave's share of step kt+1
+  //   matrix phase: 16 MFMAs at raised priority
+  // so that while one wave of a SIMD is held by its DMA issues (~60-100 cycles each) and LDS reads, its partner owns the matrix
+  // pipe.  In lockstep (one barrier per step, every wave loading at the same time) the pipe idled through every load phase: the
+  // kernel sat at 0.80-0.90 PFLOP/s whatever was done to the instruction order inside a wave.
+  // Hazards (interval = span between two barriers; group 0 loads in the even ones, group 1 in the odd ones):
+  //   RAW  a stage is read only after BOTH groups waited for their DMA share of it and passed a barrier: group g waits for its
+  //        share of step kt+1 at the end of its load phase of step kt, one full interval before the other group reads it.
+  //   WAR  the DMA of step kt+3 overwrites the stage of step kt-1, whose last reader (group 1, one interval earlier) drained
+  //        lgkmcnt before the barrier that separates the two.
+  const int grp = wave >> 2;
+  if (grp == 1) __builtin_amdgcn_s_barrier();                      // the half-step offset (group 0 pays it back after the loop)
+  for (int kt = 0; kt < nk; ++kt) {
+#ifndef YT8M_BF16_NO_DMA
+    if (kt + 3 < nk) fill_step(g, m0, n0, kb + kt + 3, smem + ((cur + 3) & 3) * STAGE_F, tid);
+#endif
+    const float* As = smem + cur * STAGE_F;
+    const float* Bs = As + TILE_F;
+    bf16x8 a[2][4], b[2][2];
+#ifdef YT8M_BF16_NO_LDS
+    if (kt == 0)
+#endif
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[h][t] = frag(As, wm + t * 32 + li, h, lk);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[h][t] = frag(Bs, wn + t * 32 + li, h, lk);
+    }
+    {
+      const int last_issued = kt + 3 < nk ? kt + 3 : nk - 1;
+      const bool tail_issued = tail && last_issued == nk - 1;
+      int younger = last_issued - (kt + 1);
+      if (younger < 0) younger = 0;
+      if (tail_issued || younger == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#ifdef YT8M_BF16_NO_MFMA
+    acc[0][0][0] += (float)a[0][0][0] + (float)b[1][1][0] + (float)a[1][3][7];
+#else
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
+#endif
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    cur = (cur + 1) & 3;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+#else
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 3 < nk) fill_step(g, m0, n0, kb + kt + 3, smem + ((cur + 3) & 3) * STAGE_F, tid);
+    const float* As = smem + cur * STAGE_F;
+    const float* Bs = As + TILE_F;
+    bf16x8 a[2][4], b[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[h][t] = frag(As, wm + t * 32 + li, h, lk);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[h][t] = frag(Bs, wn + t * 32 + li, h, lk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // step kt+1 must have landed; kt+2 and kt+3 may stay on the wire
+    {
+      const int last_issued = kt + 3 < nk ? kt + 3 : nk - 1;
+      const bool tail_issued = tail && last_issued == nk - 1;
+      int younger = last_issued - (kt + 1);
+      if (younger < 0) younger = 0;
+      wait_dma(tail_issued ? 0 : younger);
+    }
+    __builtin_amdgcn_s_barrier();
+    cur = (cur + 1) & 3;
+  }
+
+#endif
+
+  tile_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot);
+}
+
+// ---- K-step 64: whole 128-byte lines per row and step ---------------------------------------------------------------------------
+// Ablations of the kernel above (tools/r3_call12.sh: no DMA / no LDS reads / no MFMA builds) show what bounds it: without the
+// MFMAs it runs as long as with them, without the LDS-DMA 1.4-1.75x faster -- the L2 -> LDS operand delivery, at ~6.5 TB/s for
+// this access pattern: a K-step of 32 bf16 is 64 bytes per row, HALF a cache line, 16 rows per wave instruction, and every line is
+// fetched by two different K-steps.  Here a step carries 64 bf16 = one whole 128-byte line per row (8 rows per wave instruction),
+// two 64 KiB stages (double buffer: the refill of a stage is issued at the top of the step after its last read and has a whole
+// step of 32 MFMAs per wave to land), one barrier per step, the eight LDS-DMA instructions of the refill spread over the
+// products.  LDS image: row x of a tile = 8 chunks of 16 bytes, chunk c stored in slot c ^ ((x >> 1) & 7): the 16 rows of a
+// ds_read_b128 lane group cover all 16 sixteen-byte slots of the 256-byte bank row (conflict-free).
+constexpr int BKF2 = 32;                              // floats per row and step (= 64 bf16)
+constexpr int TILE2_F = BKF2 * 256;                   // 32 KiB per operand tile
+constexpr int STAGE2_F = 2 * TILE2_F;
+
+__device__ __forceinline__ const float* dma64_src(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, int idx) {
+  const int x = idx >> 3;
+  int gx = x0 + x;
+  if (gx >= X) gx = X - 1;
+  return P + (int64_t)gx * ld + k0 + 4 * ((idx & 7) ^ ((x >> 1) & 7));
+}
+__device__ __forceinline__ void dma64(const float* src, float* S, int idx) {
+  float* dst = S + (idx & ~63) * 4;                    // wave-uniform base; the hardware adds lane * 16 bytes
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void fill64_guarded(const float* __restrict__ P, int64_t ld, int x0, int k0, int X, int K, float* S, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * 512;
+    const int x = idx >> 3;
+    const int gx = x0 + x, gk = k0 + 4 * ((idx & 7) ^ ((x >> 1) & 7));
+    float4 r = {0.f, 0.f, 0.f, 0.f};
+    if (gx < X) {
+      const float* p = P + (int64_t)gx * ld + gk;
+      if (gk + 3 < K) r = *reinterpret_cast<const float4*>(p);
+      else {
+        if (gk + 0 < K) r.x = p[0];
+        if (gk + 1 < K) r.y = p[1];
+        if (gk + 2 < K) r.z = p[2];
+      }
+    }
+    *reinterpret_cast<float4*>(&S[idx * 4]) = r;
+  }
+}
+__device__ __forceinline__ bf16x8 frag64(const float* __restrict__ S, int row, int h, int lk) {
+  const float4 q = *reinterpret_cast<const float4*>(&S[row * 32 + 4 * ((2 * h + lk) ^ ((row >> 1) & 7))]);
+  return __builtin_bit_cast(bf16x8, q);
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16_k64_kernel(const BGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // 2 * STAGE2_F floats = 128 KiB
+  int tile, part = 0, nparts = 1, slot = 0;
+  if ((int)blockIdx.x < G.full) {
+    tile = xcd_remap(blockIdx.x, G.full);
+  } else {
+    slot = blockIdx.x - G.full;
+    const int rt = slot / G.S;
+    part = slot - rt * G.S;
+    nparts = G.S;
+    tile = G.full + rt;
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < G.nprob && tile >= G.tile_base[i]) q = i;
+  const BArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tile - G.tile_base[q], tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int nk_all = (g.K + BKF2 - 1) / BKF2;
+  const int kb = (int)((int64_t)nk_all * part / nparts), ke = (int)((int64_t)nk_all * (part + 1) / nparts);
+  const int nk = ke - kb;
+  const bool tail = ke == nk_all && nk_all * BKF2 != g.K;         // the last step is a guarded (non-DMA) fill
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // whole-step fill (prologue, and the guarded tail): A then B, four 16-byte chunks per thread and operand
+  auto fill_all = [&](int kt, float* stage) {
+    if (tail && kt == ke - 1) {
+      fill64_guarded(g.A, g.lda, m0, kt * BKF2, g.M, g.K, stage, tid);
+      fill64_guarded(g.B, g.ldb, n0, kt * BKF2, g.N, g.K, stage + TILE2_F, tid);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma64(dma64_src(g.A, g.lda, m0, kt * BKF2, g.M, tid + i * 512), stage, tid + i * 512);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma64(dma64_src(g.B, g.ldb, n0, kt * BKF2, g.N, tid + i * 512), stage + TILE2_F, tid + i * 512);
+    }
+  };
+  if (nk > 0) fill_all(kb, smem);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* As = smem + (kt & 1) * STAGE2_F;
+    const float* Bs = As + TILE2_F;
+    float* nxt = smem + ((kt + 1) & 1) * STAGE2_F;
+    const bool refill = kt + 1 < nk;
+    const bool guarded = refill && tail && kb + kt + 1 == ke - 1;
+    const int kn = (kb + kt + 1) * BKF2;
+    if (guarded) fill_all(kb + kt + 1, nxt);                       // (once per tile at most: plain loads + LDS stores)
+    // the refill's source addresses (8 per thread), computed once; issued between the MFMA groups below
+    const float* sa[4];
+    const float* sb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sa[i] = dma64_src(g.A, g.lda, m0, kn, g.M, tid + i * 512);
+      sb[i] = dma64_src(g.B, g.ldb, n0, kn, g.N, tid + i * 512);
+    }
+    const bool dma_on = refill && !guarded;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {                                  // four 16-wide sub-steps: 6 fragment reads + 8 MFMAs each
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = frag64(As, wm + t * 32 + li, h, lk);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = frag64(Bs, wn + t * 32 + li, h, lk);
+      if (dma_on) {
+        dma64(sa[h], nxt, tid + h * 512);
+        dma64(sb[h], nxt + TILE2_F, tid + h * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the next step landed; this wave's fragment reads are done
+    __builtin_amdgcn_s_barrier();
+  }
+  tile_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot);
 }
 
 // sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
@@ -350,9 +560,16 @@ int gemm_bf16_big_launch(int nprob, const yt8m_gemm_problem* probs, void* worksp
     G.S = S;
   }
   const int64_t grid = (int64_t)G.full + (int64_t)G.rem * G.S;
+  static const int k64 = getenv("YT8M_BF16_K64") ? atoi(getenv("YT8M_BF16_K64")) : 1;      // A/B: 0 = the K-step-32 ring kernel
+  if (k64) {
+    static DeviceOnce lds_once64;
+    YT8M_HIP_CHECK(lds_once64.lds(reinterpret_cast<const void*>(gemm_bf16_k64_kernel), 2 * STAGE2_F * (int)sizeof(float)));
+    hipLaunchKernelGGL(gemm_bf16_k64_kernel, dim3((unsigned)grid), dim3(512), 2 * STAGE2_F * sizeof(float), s, G);
+  } else {
   static DeviceOnce lds_once;
   YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_bf16_big_kernel), NST * STAGE_F * (int)sizeof(float)));
   hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3((unsigned)grid), dim3(512), NST * STAGE_F * sizeof(float), s, G);
+  }
   if (G.S > 1) hipLaunchKernelGGL(bf16_fixup_kernel, dim3((unsigned)G.rem * 16), dim3(256), 0, s, G);
   return launch_status("gemm_bf16_big_kernel");
 }

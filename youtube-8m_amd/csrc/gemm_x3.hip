@@ -97,26 +97,9 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int lt, in
   tm = first + (in - tn * rows);
 }
 
-// One operand, one K block: three DMA instructions (one per plane), each 512 lanes x 16 B = a [256 rows][2 slots] plane tile;
-// slot s of row x holds half (s ^ ((x >> 3) & 1)) of the 16-wide block (the image is stored that way), which makes the
-// ds_read_b128 fragment fetch conflict-free.  src: this wave's row group at K block 0, + lane * 16 B.
-template <int NP>
-__device__ __forceinline__ void fill_op(const float* __restrict__ src, int kb, float* S, int tid) {
-  src += (int64_t)kb * (NP * RG_F);
-  float* dst = S + (tid & ~63) * 4;                    // wave-uniform base; the hardware adds lane * 16 bytes
-#pragma unroll
-  for (int p = 0; p < NP; ++p)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * RG_F),
-                                     (__attribute__((address_space(3))) void*)(dst + p * PLANE_F), 16, 0, 0);
-}
-// PA = planes of the A image: 3 (general fp32 operand, six products) or 1 (an operand whose elements are exact in bf16 -- the
-// uint8 frames minus 128 -- : three products a b1 + a b2 + a b3, exact up to the 2^-26 of the split of b).
-template <int PA>
-__global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
-  constexpr int OPA_F = PA * PLANE_F;                              // A planes of a stage, then the three B planes
-  constexpr int STAGE_F = OPA_F + OP_F;
-  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats (144 KiB at PA = 3)
-  int q = 0, nparts = 1, part = 0, slot = 0, lt;
+// which (problem, tile, K part, workspace slot) a workgroup of a launch works on
+__device__ __forceinline__ void x_work_item(const XGroup& G, int& q, int& nparts, int& part, int& slot, int& lt) {
+  q = 0; nparts = 1; part = 0; slot = 0;
   if ((int)blockIdx.x < G.full_base[4]) {
     const int item = xcd_remap(blockIdx.x, G.full_base[4]);
 #pragma unroll
@@ -136,6 +119,91 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
     lt = G.full[q] + (l2 - part * G.rem[q]);
     slot = G.slot_base[q] + l2;
   }
+}
+
+// epilogue of the image kernels: accumulators -> wave-private LDS image [32][68] -> 16-byte stores (split-K parts: raw
+// accumulators to the workspace image)
+__device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x16 (&acc)[4][2], float* smem, int m0, int n0, int wm, int wn,
+                                           int lane, int wave, int li, int lk, int nparts, int slot) {
+  constexpr int P = 68;
+  float* st = smem + wave * (32 * P);
+  if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace image
+    float* wsl = G.ws + (int64_t)slot * (TM * TN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = lane + 64 * k;
+        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        *reinterpret_cast<float4*>(&wsl[(wm + i * 32 + rr) * TN + wn + c4]) = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+      }
+    }
+    return;
+  }
+  const bool vec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = lane + 64 * k;
+      const int rr = idx >> 4, c4 = (idx & 15) * 4;
+      const int row = m0 + wm + i * 32 + rr, col = n0 + wn + c4;
+      float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+      if (row < g.M && col < g.N) {
+        float* c = g.C + (int64_t)row * g.ldc + col;
+        if (g.rscale || g.cs || g.alpha != 1.0f) v = affine(g, v, row, col);
+        if (vec && col + 3 < g.N) {
+          if (g.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (g.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(c) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && col + e < g.N; ++e) {
+            float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
+            if (g.accumulate) t += c[e];
+            c[e] = t;
+          }
+        }
+      }
+    }
+  }
+}
+
+// One operand, one K block: three DMA instructions (one per plane), each 512 lanes x 16 B = a [256 rows][2 slots] plane tile;
+// slot s of row x holds half (s ^ ((x >> 3) & 1)) of the 16-wide block (the image is stored that way), which makes the
+// ds_read_b128 fragment fetch conflict-free.  src: this wave's row group at K block 0, + lane * 16 B.
+template <int NP>
+__device__ __forceinline__ void fill_op(const float* __restrict__ src, int kb, float* S, int tid) {
+  src += (int64_t)kb * (NP * RG_F);
+  float* dst = S + (tid & ~63) * 4;                    // wave-uniform base; the hardware adds lane * 16 bytes
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * RG_F),
+                                     (__attribute__((address_space(3))) void*)(dst + p * PLANE_F), 16, 0, 0);
+}
+// PA = planes of the A image: 3 (general fp32 operand, six products) or 1 (an operand whose elements are exact in bf16 -- the
+// uint8 frames minus 128 -- : three products a b1 + a b2 + a b3, exact up to the 2^-26 of the split of b).
+template <int PA>
+__global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
+  constexpr int OPA_F = PA * PLANE_F;                              // A planes of a stage, then the three B planes
+  constexpr int STAGE_F = OPA_F + OP_F;
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats (144 KiB at PA = 3)
+  int q, nparts, part, slot, lt;
+  x_work_item(G, q, nparts, part, slot, lt);
   const XArgs& g = G.p[q];
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
@@ -267,63 +335,90 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                    // the epilogue reuses the ring
 
-  // epilogue: accumulators -> wave-private LDS image [32][68] -> 16-byte stores
-  constexpr int P = 68;
-  float* st = smem + wave * (32 * P);
-  if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace image
-    float* wsl = G.ws + (int64_t)slot * (TM * TN);
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot);
+}
+
+// ---- one plane x one plane: the plain bf16 product on operand images ("b1") -------------------------------------------------------
+// C = A . B^T for operands that ARE bfloat16 (--compute_dtype=bfloat16: BASELINE configs[4] and the bf16 variants), both given as
+// ONE-plane images -- [rows / 32][K / 16][32 rows][2 halves][8] bf16, what yt8m_bf16_image writes straight from the fp32 source.
+// Why images: the row-major kernels of gemm_bf16.hip are bound by L2 -> LDS operand delivery (~6.5 TB/s: 16 rows x 64 bytes, or 8
+// rows x 128 bytes, per wave instruction; with the MFMAs removed they take as long as with them -- tools/r3_call12.sh), while a wave
+// instruction on an image moves 1 KiB of consecutive memory and four K blocks of a row group are 4 KiB in a row.
+// Step = four K blocks (K = 64): 64 KiB per stage, two stages (the refill of a stage is issued block by block between the MFMA
+// groups of the step after its last read), one barrier per step; per block and wave 6 ds_read_b128 feed 8 MFMAs.
+constexpr int B1_KBS = 4;                                           // K blocks per step
+constexpr int B1_STAGE_F = 2 * B1_KBS * PLANE_F;                    // A blocks, then B blocks (64 KiB)
+
+__global__ __launch_bounds__(512) void gemm_b1_kernel(const XGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // 2 * B1_STAGE_F floats (128 KiB)
+  int q, nparts, part, slot, lt;
+  x_work_item(G, q, nparts, part, slot, lt);
+  const XArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
+  const int nkb = kb1 - kb0, nst = (nkb + B1_KBS - 1) / B1_KBS;
+  // this wave's 32-row group of either operand tile, at K block kb0 (groups beyond the matrix only feed outputs never stored)
+  const float* pa = g.A + ((int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska + kb0) * RG_F + lane * 4;
+  const float* pb = g.B + ((int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.skb + kb0) * RG_F + lane * 4;
+  const int wbase = (tid & ~63) * 4;                               // wave-uniform LDS base of the wave's row group inside a block
+  auto dma = [&](const float* src, float* dst) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  f32x16 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int idx = lane + 64 * k;
-        const int rr = idx >> 4, c4 = (idx & 15) * 4;
-        *reinterpret_cast<float4*>(&wsl[(wm + i * 32 + rr) * TN + wn + c4]) = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
-      }
-    }
-    return;
-  }
-  const bool vec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lk) * P + j * 32 + li] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // prologue: step 0
+  for (int j = 0; j < B1_KBS && j < nkb; ++j) {
+    dma(pa + (int64_t)j * RG_F, smem + j * PLANE_F + wbase);
+    dma(pb + (int64_t)j * RG_F, smem + (B1_KBS + j) * PLANE_F + wbase);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa = (wm + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));        // + t * 256 floats per 32 rows, + block * PLANE_F
+  const int fb = B1_KBS * PLANE_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  for (int st = 0; st < nst; ++st) {
+    const float* S = smem + (st & 1) * B1_STAGE_F;
+    float* N = smem + ((st + 1) & 1) * B1_STAGE_F + wbase;
+    const int here = min(B1_KBS, nkb - st * B1_KBS);                 // K blocks of this step (the last one may be short)
+    const int next = min(B1_KBS, nkb - (st + 1) * B1_KBS);           // ... of the next one (<= 0: none)
+    const float* qa = pa + (int64_t)(st + 1) * B1_KBS * RG_F;
+    const float* qb = pb + (int64_t)(st + 1) * B1_KBS * RG_F;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int idx = lane + 64 * k;
-      const int rr = idx >> 4, c4 = (idx & 15) * 4;
-      const int row = m0 + wm + i * 32 + rr, col = n0 + wn + c4;
-      float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
-      if (row < g.M && col < g.N) {
-        float* c = g.C + (int64_t)row * g.ldc + col;
-        if (g.rscale || g.cs || g.alpha != 1.0f) v = affine(g, v, row, col);
-        if (vec && col + 3 < g.N) {
-          if (g.bias) {
-            const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-          }
-          if (g.accumulate) {
-            const float4 o = *reinterpret_cast<const float4*>(c);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-          }
-          *reinterpret_cast<float4*>(c) = v;
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int e = 0; e < 4 && col + e < g.N; ++e) {
-            float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
-            if (g.accumulate) t += c[e];
-            c[e] = t;
-          }
+    for (int j = 0; j < B1_KBS; ++j) {
+      if (j < here) {
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fa + j * PLANE_F + t * 256]));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fb + j * PLANE_F + t * 256]));
+        if (j < next) {
+          dma(qa + (int64_t)j * RG_F, N + j * PLANE_F);
+          dma(qb + (int64_t)j * RG_F, N + (B1_KBS + j) * PLANE_F);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (j < next) {                                       // (a short step followed by blocks cannot happen; kept for safety)
+        dma(qa + (int64_t)j * RG_F, N + j * PLANE_F);
+        dma(qb + (int64_t)j * RG_F, N + (B1_KBS + j) * PLANE_F);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the next step landed; this wave's fragment reads are done
+    __builtin_amdgcn_s_barrier();
   }
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot);
 }
 
 // sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
@@ -380,6 +475,7 @@ __device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsi
 }
 // 16 values of one K block of image row `row` -> its two 16-byte halves in each of the three plane blocks at dst (the block of
 // plane 0; half h sits in slot h ^ ((row >> 3) & 1))
+template <int NP = 3>
 __device__ __forceinline__ void store_block(const float (&v)[16], float* __restrict__ dst, int row) {
   const int r = row & 31, sw = (r >> 3) & 1;
   dst += r * 8;
@@ -387,7 +483,7 @@ __device__ __forceinline__ void store_block(const float (&v)[16], float* __restr
 #pragma unroll
   for (int j = 0; j < 16; ++j) split3(v[j], h[0][j], h[1][j], h[2][j]);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < NP; ++p) {
     uint4 lo, hi;
     lo.x = h[p][0] | (h[p][1] << 16);  lo.y = h[p][2] | (h[p][3] << 16);
     lo.z = h[p][4] | (h[p][5] << 16);  lo.w = h[p][6] | (h[p][7] << 16);
@@ -402,6 +498,8 @@ __device__ __forceinline__ void store_block(const float (&v)[16], float* __restr
 // Either destination may be null.  scale multiplies every element before the split (1.0f: none).
 // rowscale / trans_s (both or neither): a second transposed image whose element (c, r) is rowscale[r] * scale * src[r][c] -- the
 // operand r (.) dz of the layer-0 weight gradient on uint8 frames -- from the same pass over src.
+// NP = 1: the ONE-plane image of the bfloat16 roundings (operands of the b1 kernel: yt8m_bf16_image).
+template <int NP>
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
                                                        float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
                                                        float* __restrict__ trans_s) {
@@ -437,7 +535,7 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = T[a][blk * 16 + j];
-      store_block(v, plain + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+      store_block<NP>(v, plain + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
     }
   }
   if (trans || trans_s) {
@@ -447,14 +545,14 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = T[blk * 16 + j][a];
-      if (trans) store_block(v, trans + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+      if (trans) store_block<NP>(v, trans + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
       if (trans_s) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int r = r0 + blk * 16 + j;
           v[j] *= r < R ? rowscale[r] : 0.f;
         }
-        store_block(v, trans_s + ((int64_t)(row >> 5) * KB + kb) * (3 * RG_F), row);
+        store_block<NP>(v, trans_s + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
       }
     }
   }
@@ -478,7 +576,25 @@ extern "C" int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld,
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
-  hipLaunchKernelGGL(x3_split_kernel, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+  hipLaunchKernelGGL(x3_split_kernel<3>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr);
+  return launch_status("x3_split_kernel");
+}
+
+// fp32 src [R, C] -> ONE-plane images of its bfloat16 rounding (round to nearest even): plain [R rows, K = C] and / or trans
+// [C rows, K = R]; yt8m_x3_image_bytes(rows, K) / 3 bytes each.  The operands of yt8m_gemm_b1_nt_grouped; replaces the row-major
+// casts (yt8m_cast_f32_bf16) of the bf16 configuration at the same cost: one pass over the source.
+extern "C" int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans,
+                               yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans)) & 15) == 0, YT8M_E_BADARG,
+               "images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<1>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr);
   return launch_status("x3_split_kernel");
 }
@@ -496,7 +612,7 @@ extern "C" int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t 
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
-  hipLaunchKernelGGL(x3_split_kernel, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+  hipLaunchKernelGGL(x3_split_kernel<3>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled));
   return launch_status("x3_split_kernel");
 }
@@ -537,7 +653,7 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     if (workspace && rem > 0) {
       double best = 1e30;
       for (int c = 1; c <= 8; ++c) {
-        if (c > 1 && (g.KB / c < 8 || (slots + (int64_t)rem * c) * per_part > workspace_bytes)) break;
+        if (c > 1 && (g.KB / c < (PA == 0 ? 32 : 8) || (slots + (int64_t)rem * c) * per_part > workspace_bytes)) break;
         const int rounds = (rem * c + SLOTS - 1) / SLOTS;
         const double cost = rounds * ((double)g.KB / c + 10.0) + (c > 1 ? 4.0 + 0.065 * rem * c : 0.0);
         if (cost < best * 0.98) { best = cost; S = c; }
@@ -562,13 +678,15 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   for (int i = G.nprob; i < 4; ++i) { G.p[i] = G.p[0]; G.S[i] = 1; G.slot_base[i] = 0; G.full[i] = 0; G.rem[i] = 0; }
   G.ws = static_cast<float*>(workspace);
   const int64_t grid = nfull + slots;
-  constexpr int LDS_BYTES = NST * (PA + 3) * PLANE_F * (int)sizeof(float);
+  constexpr int LDS_BYTES = PA == 0 ? 2 * B1_STAGE_F * (int)sizeof(float) : NST * (PA + 3) * PLANE_F * (int)sizeof(float);
   static DeviceOnce lds_once;                                      // per device (a process-wide flag broke cuda:1)
-  YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA>), LDS_BYTES));
+  if constexpr (PA == 0) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_b1_kernel), LDS_BYTES));
+  else YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA == 0 ? 3 : PA>), LDS_BYTES));
   double fl = 0.0;
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
-  ProfScope prof(PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3, as_stream(stream), fl);
-  hipLaunchKernelGGL(gemm_x3_kernel<PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+  ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3), as_stream(stream), fl);
+  if constexpr (PA == 0) hipLaunchKernelGGL(gemm_b1_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+  else hipLaunchKernelGGL(gemm_x3_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
   if (fix > 0) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
 }
@@ -580,6 +698,14 @@ extern "C" int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs
                                        yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
   return x3_launch<3>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream);
+}
+
+// C[M,N] (+)= A . B^T (+ bias) for bf16 operands given as ONE-plane images (yt8m_bf16_image); yt8m_gemm_problem as in
+// yt8m_gemm_x3_nt_grouped (A / B = images, lda / ldb = K-block strides or 0).  Up to four problems per launch.
+extern "C" int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
+                                       yt8m_stream_t stream) {
+  YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
+  return x3_launch<0>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream);
 }
 
 // The uint8 input projection: C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n], A a ONE-plane image (elements

@@ -27,7 +27,15 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
 
 // MODE 0: d = dp[b, l].  MODE 1: d from the labels (uint8 / float), CrossEntropyLoss fused (eps, dscale * up_dev[0]).
-template <int MODE, typename LT>
+// IMG: the four outputs are ONE-plane operand images of the b1 kernel (csrc/gemm_x3.hip: [rows / 32][K / 16][32 rows][2 halves][8]
+// bf16, half h of row r in slot h ^ ((r >> 3) & 1)) instead of row-major matrices; the *_ld arguments then carry the K-block
+// counts of the images (plain: ceil(columns / 16), transposed: ceil(B / 16)).  Same 16-byte pieces, other addresses; the zero
+// padding of the last K block is written too (the GEMM reads whole blocks).
+__device__ __forceinline__ int64_t img_piece(int64_t row, int64_t k8, int64_t KB) {     // uint16 offset of (row, 8 values from K = k8)
+  const int r = (int)(row & 31);
+  return ((row >> 5) * KB + (k8 >> 4)) * 512 + r * 16 + ((int)((k8 >> 3) & 1) ^ ((r >> 3) & 1)) * 8;
+}
+template <int MODE, typename LT, bool IMG>
 __global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __restrict__ Zg, const float* __restrict__ Ze,
                                                                const float* __restrict__ dp, const LT* __restrict__ y,
                                                                int64_t B, int64_t V, float eps, float dscale,
@@ -95,9 +103,32 @@ __global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __re
       }
     }
     // plain bf16 rows
+    if (IMG) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int64_t c = l0 * 3 + 8 * k;
+        if (c < gb_ld * 16) {
+          uint4 v;
+          v.x = og[8 * k] | ((unsigned)og[8 * k + 1] << 16); v.y = og[8 * k + 2] | ((unsigned)og[8 * k + 3] << 16);
+          v.z = og[8 * k + 4] | ((unsigned)og[8 * k + 5] << 16); v.w = og[8 * k + 6] | ((unsigned)og[8 * k + 7] << 16);
+          *reinterpret_cast<uint4*>(gb + img_piece(b, c, gb_ld)) = v;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t c = l0 * 2 + 8 * k;
+        if (c < eb_ld * 16) {
+          uint4 v;
+          v.x = oe[8 * k] | ((unsigned)oe[8 * k + 1] << 16); v.y = oe[8 * k + 2] | ((unsigned)oe[8 * k + 3] << 16);
+          v.z = oe[8 * k + 4] | ((unsigned)oe[8 * k + 5] << 16); v.w = oe[8 * k + 6] | ((unsigned)oe[8 * k + 7] << 16);
+          *reinterpret_cast<uint4*>(eb + img_piece(b, c, eb_ld)) = v;
+        }
+      }
+    }
     unsigned short* pg = gb + b * gb_ld + l0 * 3;
     unsigned short* pe = eb + b * eb_ld + l0 * 2;
-    if (l0 + 16 <= V && ((reinterpret_cast<uintptr_t>(pg) | reinterpret_cast<uintptr_t>(pe)) & 15) == 0) {
+    if (IMG) {
+    } else if (l0 + 16 <= V && ((reinterpret_cast<uintptr_t>(pg) | reinterpret_cast<uintptr_t>(pe)) & 15) == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         uint4 v;
@@ -132,8 +163,13 @@ __global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __re
     const bool gate = col < GC;
     const int64_t gcol = gate ? (int64_t)blockIdx.x * GC + col : (int64_t)blockIdx.x * EC + (col - GC);
     if (gcol >= (gate ? V * 3 : V * 2)) continue;
-    unsigned short* dst = (gate ? gt + gcol * gt_ld : et + gcol * et_ld) + r0 + piece * 8;
     const unsigned short* src = tile + col * PITCH + piece * 8;
+    if (IMG) {                                                   // rows of the transposed images = logit columns, K = batch rows
+      if (r0 + piece * 8 < (gate ? gt_ld : et_ld) * 16)
+        *reinterpret_cast<uint4*>((gate ? gt : et) + img_piece(gcol, r0 + piece * 8, gate ? gt_ld : et_ld)) = *reinterpret_cast<const uint4*>(src);
+      continue;
+    }
+    unsigned short* dst = (gate ? gt + gcol * gt_ld : et + gcol * et_ld) + r0 + piece * 8;
     if (rows_full && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
       *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
     } else {
@@ -160,34 +196,62 @@ using namespace yt8m;
 
 extern "C" int64_t yt8m_moe_mix_bwd_bf16_partial_rows(int64_t B) { return (B + TR - 1) / TR; }
 
-extern "C" int yt8m_moe_mix_bwd_bf16(const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype,
-                                     int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev, void* dZg_b,
-                                     int64_t gb_ld, void* dZg_t, int64_t gt_ld, void* dZe_b, int64_t eb_ld, void* dZe_t,
-                                     int64_t et_ld, float* be_part, yt8m_stream_t stream) {
+namespace {
+int mix_bwd_bf16_launch(bool img, const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype, int64_t B, int64_t V,
+                        int M, float eps, float dscale, const float* upstream_dev, void* dZg_b, int64_t gb_ld, void* dZg_t, int64_t gt_ld,
+                        void* dZe_b, int64_t eb_ld, void* dZe_t, int64_t et_ld, float* be_part, yt8m_stream_t stream) {
   YT8M_REQUIRE(M == 2, YT8M_E_BADARG, "the bf16 mixing backward is built for num_mixtures == 2");
   YT8M_REQUIRE(B >= 0 && V >= 0, YT8M_E_SHAPE, "negative dimension");
   if (B * V == 0) return YT8M_OK;
   YT8M_REQUIRE(Zg && Ze && (dp || labels) && dZg_b && dZg_t && dZe_b && dZe_t, YT8M_E_BADARG, "null operand");
   YT8M_REQUIRE(!(dp && labels), YT8M_E_BADARG, "give either dp or labels");
-  YT8M_REQUIRE(gb_ld >= V * 3 && eb_ld >= V * 2 && gt_ld >= B && et_ld >= B, YT8M_E_SHAPE, "leading dimension too small");
+  if (img) {
+    YT8M_REQUIRE(gb_ld == (V * 3 + 15) / 16 && eb_ld == (V * 2 + 15) / 16 && gt_ld == (B + 15) / 16 && et_ld == (B + 15) / 16, YT8M_E_SHAPE,
+                 "image mode: pass the K-block counts of the four images");
+    YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(dZg_b) | reinterpret_cast<uintptr_t>(dZg_t) | reinterpret_cast<uintptr_t>(dZe_b) |
+                   reinterpret_cast<uintptr_t>(dZe_t)) & 15) == 0, YT8M_E_BADARG, "images must be 16-byte aligned");
+  } else {
+    YT8M_REQUIRE(gb_ld >= V * 3 && eb_ld >= V * 2 && gt_ld >= B && et_ld >= B, YT8M_E_SHAPE, "leading dimension too small");
+  }
   YT8M_REQUIRE((B + TR - 1) / TR <= 65535, YT8M_E_SHAPE, "too many rows");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
   const dim3 grid((unsigned)((V + TL - 1) / TL), (unsigned)((B + TR - 1) / TR));
   unsigned short *gb = static_cast<unsigned short*>(dZg_b), *gt = static_cast<unsigned short*>(dZg_t);
   unsigned short *eb = static_cast<unsigned short*>(dZe_b), *et = static_cast<unsigned short*>(dZe_t);
+#define YT8M_MIX_LAUNCH(MODE, LT, IMGV, DP, LAB)                                                                                   \
+  hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<MODE, LT, IMGV>), grid, dim3(256), 0, s, Zg, Ze, DP, LAB, B, V, eps, dscale, upstream_dev, \
+                     gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld, be_part)
   if (dp) {
-    hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<0, uint8_t>), grid, dim3(256), 0, s, Zg, Ze, dp, (const uint8_t*)nullptr, B, V, eps, dscale,
-                       upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld, be_part);
+    if (img) YT8M_MIX_LAUNCH(0, uint8_t, true, dp, (const uint8_t*)nullptr);
+    else YT8M_MIX_LAUNCH(0, uint8_t, false, dp, (const uint8_t*)nullptr);
   } else if (label_dtype == 0) {
-    hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<1, uint8_t>), grid, dim3(256), 0, s, Zg, Ze, (const float*)nullptr,
-                       static_cast<const uint8_t*>(labels), B, V, eps, dscale, upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld,
-                       be_part);
+    if (img) YT8M_MIX_LAUNCH(1, uint8_t, true, (const float*)nullptr, static_cast<const uint8_t*>(labels));
+    else YT8M_MIX_LAUNCH(1, uint8_t, false, (const float*)nullptr, static_cast<const uint8_t*>(labels));
   } else {
     YT8M_REQUIRE(label_dtype == 1, YT8M_E_BADARG, "label_dtype must be 0 (uint8) or 1 (float32)");
-    hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<1, float>), grid, dim3(256), 0, s, Zg, Ze, (const float*)nullptr,
-                       static_cast<const float*>(labels), B, V, eps, dscale, upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld,
-                       be_part);
+    if (img) YT8M_MIX_LAUNCH(1, float, true, (const float*)nullptr, static_cast<const float*>(labels));
+    else YT8M_MIX_LAUNCH(1, float, false, (const float*)nullptr, static_cast<const float*>(labels));
   }
+#undef YT8M_MIX_LAUNCH
   return launch_status("moe_mix_bwd_bf16_kernel");
+}
+}  // namespace
+
+extern "C" int yt8m_moe_mix_bwd_bf16(const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype,
+                                     int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev, void* dZg_b,
+                                     int64_t gb_ld, void* dZg_t, int64_t gt_ld, void* dZe_b, int64_t eb_ld, void* dZe_t,
+                                     int64_t et_ld, float* be_part, yt8m_stream_t stream) {
+  return mix_bwd_bf16_launch(false, Zg, Ze, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_b, gb_ld, dZg_t, gt_ld, dZe_b,
+                             eb_ld, dZe_t, et_ld, be_part, stream);
+}
+
+// The same pass with the four outputs as ONE-plane operand images of yt8m_gemm_b1_nt_grouped (plain: rows = B, K = V (M+1) / V M;
+// transposed: rows = V (M+1) / V M, K = B); the *_kb arguments are the images' K-block counts (ceil(K / 16)).
+extern "C" int yt8m_moe_mix_bwd_bf16_images(const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype,
+                                            int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev,
+                                            void* dZg_img, int64_t g_kb, void* dZg_t_img, int64_t gt_kb, void* dZe_img, int64_t e_kb,
+                                            void* dZe_t_img, int64_t et_kb, float* be_part, yt8m_stream_t stream) {
+  return mix_bwd_bf16_launch(true, Zg, Ze, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_img, g_kb, dZg_t_img, gt_kb,
+                             dZe_img, e_kb, dZe_t_img, et_kb, be_part, stream);
 }

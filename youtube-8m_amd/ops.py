@@ -296,6 +296,60 @@ def gemm_x3_grouped(items):
     return outs
 
 
+B1_IMAGES = os.environ.get("YT8M_BF16_IMAGES", "1") != "0"   # bf16 configuration: large products on one-plane operand images (gemm_b1_kernel)
+
+
+def _b1_ok(M, N, K):
+    """Large enough for the 256 x 256 image kernel to pay (at least half a round of tiles, a few K steps)."""
+    return B1_IMAGES and ((M + 255) // 256) * ((N + 255) // 256) >= 64 and K >= 256
+
+
+def bf16_image(x, transpose=False, both=False):
+    """fp32 [R, C] -> one-plane bf16 operand image(s) of csrc/gemm_x3.hip (yt8m_bf16_image): the matrix as an [R rows, K = C]
+    operand, its transpose as a [C rows, K = R] operand (transpose=True), or both from one pass (both=True -> (plain, trans))."""
+    _dev(x)
+    x, ld = _rowmajor2d(x)
+    R, C = x.shape
+    lib = _lib.lib()
+    mk = lambda rows, K: X3Image(torch.empty(max(lib.yt8m_x3_image_bytes(rows, K) // 3, 16), dtype=torch.uint8, device=x.device), rows, K)
+    ip = mk(R, C) if (both or not transpose) else None
+    it = mk(C, R) if (both or transpose) else None
+    _lib.check(lib.yt8m_bf16_image(_p(x), R, C, ld, 1.0, _p(ip.buf) if ip else None, _p(it.buf) if it else None, _stream()))
+    return (ip, it) if both else (it if transpose else ip)
+
+
+def gemm_b1_grouped(items):
+    """items: dicts(A=image [M rows, K], B=image [N rows, K], out=None fp32 [M,N], bias=None, beta=0.0) -> fp32 outputs;
+    C = A . B^T on v_mfma_f32_32x32x16_bf16 from ONE-plane bf16 operand images (yt8m_gemm_b1_nt_grouped)."""
+    probs, outs, keep = [], [], []
+    for it in items:
+        A, B = it["A"], it["B"]
+        if A.K != B.K:
+            raise ValueError("gemm_b1: inner dimensions differ (%d vs %d)" % (A.K, B.K))
+        M, N, K = A.rows, B.rows, A.K
+        out, beta, bias = it.get("out"), it.get("beta", 0.0), it.get("bias")
+        _dev(A.buf, B.buf, out, bias)
+        if out is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 needs an output tensor")
+            out = torch.empty((M, N), dtype=torch.float32, device=A.buf.device)
+        if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or (out.stride(1) != 1 and N != 1):
+            raise ValueError("gemm_b1: bad output tensor")
+        if bias is not None:
+            bias = _f32c(bias)
+        ldc = out.stride(0) if M > 1 else max(N, 1)
+        probs.append(_lib.GemmProblem(M, N, K, A.buf.data_ptr(), 0, B.buf.data_ptr(), 0, out.data_ptr(), ldc,
+                                      bias.data_ptr() if bias is not None else None, float(beta)))
+        outs.append(out)
+        keep.append((A, B, bias))
+    ws = _workspace(outs[0].device)
+    for i in range(0, len(probs), 4):
+        part = probs[i:i + 4]
+        arr = (_lib.GemmProblem * len(part))(*part)
+        _lib.check(_lib.lib().yt8m_gemm_b1_nt_grouped(len(part), arr, _p(ws), ws.numel() * 4, _stream()))
+    return outs
+
+
 def gemm_batched(A, B, out=None, transA=False, transB=False, beta=0.0):
     """Batched over dim 0 of 3-D contiguous tensors.  yt8m_gemm_f32_batched."""
     _dev(A, B, out)
@@ -926,6 +980,8 @@ def _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, dp=None, labels=N
     L = _lib.lib()
     B = Zg.shape[0]
     dev = Zg.device
+    if _b1_ok(B, Zg.shape[1], x.shape[1]) and _b1_ok(x.shape[1], Zg.shape[1], B):
+        return _moe_head_bwd_bf16_images(ctx, x, Zg, Ze, Wg, We, be, V, M, dp, labels, ldt, dscale, up)
     Zgb, ZgT = _bf16_empty(B, Zg.shape[1], dev), _bf16_empty(Zg.shape[1], B, dev)
     Zeb, ZeT = _bf16_empty(B, Ze.shape[1], dev), _bf16_empty(Ze.shape[1], B, dev)
     part = torch.empty((L.yt8m_moe_mix_bwd_bf16_partial_rows(B), Ze.shape[1]), dtype=torch.float32, device=dev) \
@@ -958,6 +1014,44 @@ def _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, dp=None, labels=N
     return dx
 
 
+def _moe_head_bwd_bf16_images(ctx, x, Zg, Ze, Wg, We, be, V, M, dp, labels, ldt, dscale, up):
+    """_moe_head_bwd_bf16_fused on operand images: the mixing backward writes dL/dZ straight into the one-plane images the b1
+    kernel reads (both orientations), the weights and x^T are rounded into images by one pass each; three image products."""
+    L = _lib.lib()
+    B, Ng, Ne = Zg.shape[0], Zg.shape[1], Ze.shape[1]
+    dev = Zg.device
+    mk = lambda rows, K: X3Image(torch.empty(max(L.yt8m_x3_image_bytes(rows, K) // 3, 16), dtype=torch.uint8, device=dev), rows, K)
+    Zgi, ZgTi, Zei, ZeTi = mk(B, Ng), mk(Ng, B), mk(B, Ne), mk(Ne, B)
+    part = torch.empty((L.yt8m_moe_mix_bwd_bf16_partial_rows(B), Ne), dtype=torch.float32, device=dev) if be.grad is not None else None
+    kb = lambda K: (K + 15) // 16
+    _lib.check(L.yt8m_moe_mix_bwd_bf16_images(_p(Zg), _p(Ze), _p(dp), _p(labels), ldt, B, V, M, XENT_EPS, float(dscale), _p(up),
+                                              _p(Zgi.buf), kb(Ng), _p(ZgTi.buf), kb(B), _p(Zei.buf), kb(Ne), _p(ZeTi.buf), kb(B),
+                                              _p(part), _stream()))
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dx, = gemm_b1_grouped([dict(A=Zgi, B=bf16_image(Wg.data))])           # W [D, N] as [D rows, K = N]
+        gemm_b1_grouped([dict(A=Zei, B=bf16_image(We.data), out=dx, beta=1.0)])
+    del Zgi, Zei
+    if Wg.grad is not None and We.grad is not None:
+        xT = bf16_image(x, transpose=True)                                      # [D rows, K = B]
+        overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
+        pg = dict(A=xT, B=ZgTi, out=Wg.grad, beta=Wg.grad_beta())
+        pe = dict(A=xT, B=ZeTi, out=We.grad, beta=We.grad_beta())
+        if overlap:
+            gemm_b1_grouped([pg])
+            Wg.grad_done()
+            gemm_b1_grouped([pe])
+            We.grad_done()
+        else:
+            gemm_b1_grouped([pg, pe])
+            Wg.grad_done()
+            We.grad_done()
+    if be.grad is not None:
+        colsum(part, be.grad.view(-1), beta=be.grad_beta())
+        be.grad_done()
+    return dx
+
+
 def _fused_mix_bf16_ok(ctx, x, Zg, Ze, M):
     return (FUSED_MIX_BF16 and getattr(ctx, "bf16", False) and M == 2 and _bf16_ok(x) and Zg.shape[1] % 2 == 0
             and Ze.shape[1] % 2 == 0 and Zg.is_contiguous() and Ze.is_contiguous())
@@ -972,6 +1066,10 @@ def _bf16_ok(x2):
 def _moe_logits(x2, Wg, We, be, bf16):
     """Zg = x.Wg, Ze = x.We + be as ONE persistent launch; bf16: operands are bf16 copies (x, Wg^T, We^T: both sides
     K-contiguous), accumulation and outputs stay fp32."""
+    if bf16 and _bf16_ok(x2) and _b1_ok(x2.shape[0], Wg.data.shape[1], x2.shape[1]):
+        xi = bf16_image(x2)                                  # [B rows, K = D]; W^T as [N rows, K = D]: the transposing image pass
+        return gemm_b1_grouped([dict(A=xi, B=bf16_image(Wg.data, transpose=True)),
+                                dict(A=xi, B=bf16_image(We.data, transpose=True), bias=be.data)])
     if bf16 and _bf16_ok(x2):
         xb = cast_bf16(x2)
         return gemm_bf16_nt_grouped([dict(A=xb, B=cast_bf16(Wg.data, transpose=True)),
