@@ -987,7 +987,15 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   const int t_hi = a.t0 + a.T - 1;
   const long long BH = (long long)B * H;
   // gate backward of step t1 for this lane's pair of tile T: consumes (dh_in, dc) and produces dz (4 gates), dc', base'
-  auto publish = [&](int T, int pub, const float (&dzv)[4]) {
+  // Publishing dz of an item = (1) write-through stores of its image bytes, (2) wait until they have left this CU, (3) one
+  // arrival on the tile's counter.  (2) sits right behind (1): ~3.6k cycles of waiting per item in which all four epilogue waves
+  // do nothing (tools/persist_timeline.py: epilogue 1.0k reduce + 2.7k gate math + 3.6k drain per item).  Round 3 tried to hide
+  // it (-DYT8M_BWD_DEFER_ARRIVE: go on with the standard-layout stores of item k and the operand loads of item k + 1, arrive for
+  // item k when those loads are back or at once if item k + 1's partial tiles are not there yet): correct, and NO faster (21.5
+  // vs 21.4 us/step stand-alone, 23.3 vs 23.2 ms for the training step) -- the step time is the chain of a tile through ALL 64
+  // unit-group workgroups of its row group (the slowest of 64 publishes gates every consumer), not the epilogue's throughput.
+  int pend_T = -1;
+  auto publish_stores = [&](int T, int pub, const float (&dzv)[4]) {
     const __amdgpu_buffer_rsrc_t dxr = image(pub);
     // dzx block of gate g4 = q-group g4 * (H/16) + ub: [16 rows][16 units]; four neighbouring lanes -> one 16-byte store
 #pragma unroll
@@ -1001,10 +1009,15 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         __builtin_amdgcn_raw_buffer_store_b128(v, dxr, (int)off, 0, YT8M_AUX_ST);
       }
     }
+    pend_T = T;
+  };
+  auto arrive = [&]() {                                   // every vector memory operation of this wave issued so far has completed
+    if (pend_T < 0) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
-      __hip_atomic_fetch_add(a.ctl + CTL_HDR + (T * NSH + ((blockIdx.x * 4 + ew) & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED,
+      __hip_atomic_fetch_add(a.ctl + CTL_HDR + (pend_T * NSH + ((blockIdx.x * 4 + ew) & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
+    pend_T = -1;
   };
   struct GateIn { float gi, gj, gf, go, cp, cn, dout; bool live; };
   auto gate_load = [&](int t1, int br) -> GateIn {
@@ -1052,8 +1065,9 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
     float dzv[4], dc_out, base_out;
     gate_bwd(q, dh0, dc0, dzv, dc_out, base_out);
     if (!valid) { dzv[0] = dzv[1] = dzv[2] = dzv[3] = 0.f; }
-    publish(T, 0, dzv);
+    publish_stores(T, 0, dzv);
     if (valid) store_std(t_hi, brow, dzv, dc_out, base_out, a.phase ^ 1);
+    arrive();
   }
   int slot = 0, gen = 0;
   for (int s = 0; s < a.T; ++s) {
@@ -1072,6 +1086,10 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       const float base = wk[0], dc = wk[BH];
       GateIn q;
       if (!last) q = gate_load(t1, br);
+#ifdef YT8M_BWD_DEFER_ARRIVE
+      // the previous item's arrival: at once when this item's partial tiles are not there yet (nothing to overlap the drain with)
+      if (pend_T >= 0 && lds_load(&lds_cnt[slot]) < 8u * (unsigned)(gen + 1)) arrive();
+#endif
       lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(gen + 1), a.ctl);
       STAMP(1);
       // C layout: column = lane & 15 (unit), row = 4 (lane >> 4) + r  ->  pair (row 4 ew + er, unit): register er, lane 16 ew + unit
@@ -1081,7 +1099,8 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (++slot == NSLOT_B) { slot = 0; ++gen; }
       STAMP(2);
-      const float dh_in = base + p;
+      const float dh_in = base + p;                      // (base / dc / the gate operands: loads issued at the top of the item)
+      arrive();                                          // previous item: its image stores are older than those loads -> complete
       if (last) {                                        // dL/dh_{t_lo - 1}: handed to the caller (next chunk / initial state)
         if (valid) wk[0] = dh_in;
         continue;
@@ -1090,11 +1109,15 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       gate_bwd(q, dh_in, dc, dzv, dc_out, base_out);
       if (!valid) { dzv[0] = dzv[1] = dzv[2] = dzv[3] = 0.f; }
       STAMP(3);
-      publish(T, s + 1, dzv);
+      publish_stores(T, s + 1, dzv);
+#ifndef YT8M_BWD_DEFER_ARRIVE
+      arrive();                                          // drain right behind the image stores (default; see above)
+#endif
       STAMP(4);
       if (valid) store_std(t1, brow, dzv, dc_out, base_out, half ^ 1);
     }
   }
+  arrive();
   if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
 }
 
