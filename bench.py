@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[2] / bf16-variant extra lines")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="lower bound of the cpu_baseline sample (it also runs >= --cpu-steps steps)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the cpu_baseline leg at least (SURVEY.md 8d: >= 10)")
+    ap.add_argument("--cpu-max-seconds", type=float, default=120.0, help="hard wall budget of the cpu_baseline sample (it stops early "
+                    "and reports the steps it did); the all-cores twin runs in a subprocess with a 45 s limit of its own")
+    ap.add_argument("--cpu-allcores-probe", type=int, default=0, help=argparse.SUPPRESS)     # internal: child of the all-cores twin
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's arithmetic (the headline).  bf16 = bf16 MFMA operands, fp32 accumulate / "
                          "master weights / Adam: a separately labelled line, never the headline.")
@@ -468,12 +471,13 @@ def gap_leg(dev, B=1024, train_steps=768, heldout=16384, signal=3.0):
         pos += float(y.float().sum(1).mean())
         tg.step(x, y)
     m = evaluate(heldout)
-    return {"value": m["gap"], "hit_at_one": m["avg_hit_at_one"], "perr": m.get("avg_perr"), "untrained": before,
+    state = (Wt.cpu(), float(tau), {k: v.data.detach().cpu().clone() for k, v in g.vars.items()})
+    return {"_state": state, "value": m["gap"], "hit_at_one": m["avg_hit_at_one"], "perr": m.get("avg_perr"), "untrained": before,
             "train_steps": train_steps, "batch": B, "heldout_videos": (heldout // B) * B,
             "positives_per_video": pos / train_steps, "data": "synthetic teacher shard (MoeModel, configs[1])"}
 
 
-def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048):
+def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048, state=None):
     """The acceptance form of the north-star's second target ("GAP@20 within 0.001 of the reference on a held-out synthetic
     shard"), at a size the CPU port trains in seconds: the SAME MoeModel from the SAME initial weights on the SAME teacher-shard
     batches through the HIP path and through the torch-CPU restatement (the checker: oracle/torch_ref.py, TF1 is not runnable);
@@ -488,12 +492,15 @@ def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048):
     FLAGS.reset()
     gen = torch.Generator().manual_seed(7)
     Wt = torch.randn(D_, V_, generator=gen) / D_ ** 0.5
+    tau0 = None
+    if state is not None:                                # continue from the GAP leg's trained model on ITS teacher shard
+        Wt, tau0, init = state
 
     def shard(n, seed):
         g_ = torch.Generator().manual_seed(seed)
         x = torch.rand(n, D_, generator=g_) * 4.0 - 2.0
         logit = x @ Wt * 3.0 - 3.0 + 0.5 * torch.randn(n, V_, generator=g_)
-        tau = torch.quantile(logit.flatten()[:200000], 1.0 - 3.4 / V_)
+        tau = tau0 if tau0 is not None else torch.quantile(logit.flatten()[:200000], 1.0 - 3.4 / V_)
         return x, logit > tau
 
     xtr, ytr = shard(B_ * steps, 11)
@@ -504,6 +511,10 @@ def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048):
     tg = train.TrainGraph(vlm.MoeModel(), batch_size=B_, graph=g)
     tg.forward(xtr[:B_].to(dev), ytr[:B_].to(dev))
     tg.ensure_finalized()
+    if state is not None:
+        with torch.no_grad():
+            for k, v in cpu.P.items():
+                v.copy_(init[k].view(v.shape))
     for k, v in cpu.P.items():
         g.vars[k].data.copy_(v.detach().to(dev).view(g.vars[k].data.shape))
     for i in range(steps):
@@ -517,8 +528,9 @@ def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048):
     yh = yho.numpy().astype(np.float32)
     gh, gc = eval_util.calculate_gap(ph, yh, 20), eval_util.calculate_gap(pc, yh, 20)
     return {"gap_hip": gh, "gap_cpu_port": gc, "abs_diff": abs(gh - gc), "target": 0.001, "within_target": bool(abs(gh - gc) < 1e-3),
-            "config": "MoeModel D=%d V=%d M=%d, %d steps x %d videos, held-out %d videos, same initial weights and batches" %
-                      (D_, V_, M_, steps, B_, held)}
+            "config": "MoeModel D=%d V=%d M=%d, %d steps x %d videos, held-out %d videos, same initial weights and batches%s" %
+                      (D_, V_, M_, steps, B_, held, "" if state is None else
+                       " -- continued from the GAP leg's trained weights (fresh Adam state on both sides) on its teacher shard")}
 
 
 def _pick_threads(probe_fn):
@@ -536,7 +548,7 @@ def _pick_threads(probe_fn):
     return best, usable
 
 
-def cpu_baseline(workload, seconds, min_steps=10):
+def cpu_baseline(workload, seconds, min_steps=10, max_seconds=120.0):
     """Times the torch-CPU fp32 restatement of the same training step on the host cores (a reported baseline, not a
     target; TF1 itself is not runnable here).  Bounded sample: reduced batch for the frame-level step (its time per step barely
     depends on B below ~16: every frame re-streams the 35 MB cell weights and accumulates a 35 MB weight gradient, as the
@@ -566,12 +578,7 @@ def cpu_baseline(workload, seconds, min_steps=10):
         stepf = lambda: st.step(q, nf, y)
         what = "fp32 LstmModel (2x1024, F=300) + MoE head training step"
         if usable > cores:                                          # the all-cores number beside it
-            torch.set_num_threads(usable)
-            stepf()
-            t0 = time.perf_counter()
-            stepf()
-            stepf()
-            allc = {"cores": usable, "value": 2 * B / (time.perf_counter() - t0), "unit": "videos/s", "steps": 2}
+            allc = _allcores_twin(B, usable)
         torch.set_num_threads(cores)
     else:
         return None
@@ -581,12 +588,45 @@ def cpu_baseline(workload, seconds, min_steps=10):
         stepf()
         n += 1
         el = time.perf_counter() - t0
-        if (el >= seconds and n >= min_steps) or n >= 200:
+        if (el >= seconds and n >= min_steps) or n >= 200 or el >= max_seconds:
             break
     return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port", "timed_steps": n, "batch": B, "seconds": el,
             "usable_cores": usable, "all_cores": allc,
             "sample": "%d steps of the same %s at B=%d on torch-CPU (oracle/torch_ref.py; TF1 itself is not runnable "
                       "here), %.1f s, %d threads of %d usable cores" % (n, what, B, el, cores, usable)}
+
+
+def _allcores_twin(B, usable, limit=45.0):
+    """The frame-level CPU step on ALL usable cores, in a child process with a wall limit: with one thread per core the small
+    per-frame products of the port oversubscribe the BLAS pool badly (minutes per step on a 256-core host), and a torch op cannot
+    be interrupted from inside the process."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-allcores-probe", str(B)]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit).stdout
+        line = [l for l in out.splitlines() if l.startswith("{")]
+        if line:
+            return json.loads(line[-1])
+        return {"cores": usable, "value": None, "unit": "videos/s", "note": "child produced no line"}
+    except subprocess.TimeoutExpired:
+        return {"cores": usable, "value": None, "unit": "videos/s", "steps": 0,
+                "note": "one step of the same port on all %d cores did not finish within %.0f s (oversubscribed BLAS pool): slower than "
+                        "the %d-thread figure" % (usable, time.perf_counter() - t0, min(usable, 32))}
+
+
+def _allcores_child(B):
+    from oracle import torch_ref
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(usable)
+    gen = torch.Generator().manual_seed(1)
+    q = torch.randint(0, 256, (B, FRAMES, D_IN), generator=gen, dtype=torch.uint8)
+    y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
+    nf = torch.full((B,), FRAMES, dtype=torch.int32)
+    st = torch_ref.LstmTrainStepCPU(D=D_IN, H=LSTM_H, L=LSTM_L, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+    t0 = time.perf_counter()
+    st.step(q, nf, y)
+    el = time.perf_counter() - t0
+    print(json.dumps({"cores": usable, "value": B / el, "unit": "videos/s", "steps": 1, "note": "first (cold) step"}))
 
 
 def library_identity():
@@ -603,8 +643,20 @@ def library_identity():
             "sha256": h.hexdigest(), "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("YT8M_")}}
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (the JSON line on stdout is printed last: a leg that overruns must be visible in the log)"""
+    sys.stderr.write("[bench %7.1f s] %s\n" % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
 def main():
     a = parse()
+    if a.cpu_allcores_probe:
+        _allcores_child(a.cpu_allcores_probe)
+        return
     maybe_relaunch(a)
     __graft_entry__.load_package()
     import yt8m_amd._lib as L
@@ -632,7 +684,9 @@ def main():
     g, tg, pool = build(a.workload, B, world, rank, dev, reducer, bf16)
     if a.pool:
         pool = make_pool(a.workload, B, dev, rank, a.pool)
+    note("built %s, B = %d per GPU, world %d" % (a.workload, B, world))
     el, run = timed_run(tg, pool, a.steps, a.warmup, world, dev, dist)
+    note("timed region: %.2f ms/step" % (el / a.steps * 1e3))
     params = sum(v.numel() for v in g.trainable_variables())
     import yt8m_amd.seq_ops as seq_ops
     seq_ops.check_persist_errors()              # a persistent launch that timed out must fail the bench, not skew it
@@ -693,20 +747,30 @@ def main():
         for wl, b16 in (("moe", False), ("netvlad", False), ("lstm", True), ("composite", True)):
             try:
                 extra.append(extra_line(wl, dev, lib, bf16=b16))
+                note("extra line %s%s done" % (wl, " bf16" if b16 else ""))
             except Exception as e:                                    # an extra line must never break the headline
                 extra.append({"workload": WORKLOADS[wl]["name"], "error": repr(e)})
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.workload, a.cpu_seconds, a.cpu_steps)
+        note("cpu_baseline starts")
+        cpu = cpu_baseline(a.workload, a.cpu_seconds, a.cpu_steps, a.cpu_max_seconds)
+        note("cpu_baseline done: %s" % (cpu and cpu.get("sample")))
 
     gap = None
     if rank == 0 and world == 1 and not a.no_gap and not bf16:
         try:
             gap = gap_leg(dev)
-            gap["cpu_twin"] = gap_twin(dev)
-            # the same acceptance check at the FULL model size (D = 1152, V = 4716; fewer steps: the CPU port trains them in seconds)
-            gap["cpu_twin_full_size"] = gap_twin(dev, D_=D_IN, V_=VOCAB, M_=MIX, B_=256, steps=24, held=2048)
+            state = gap.pop("_state")
+            note("gap leg done")
+            for key, kw in (("cpu_twin", {}),
+                            # the same acceptance check at the FULL model size (D = 1152, V = 4716), continued from the leg's trained model
+                            ("cpu_twin_full_size", dict(D_=D_IN, V_=VOCAB, M_=MIX, B_=256, steps=24, held=2048, state=state))):
+                try:
+                    gap[key] = gap_twin(dev, **kw)
+                except Exception as e:
+                    gap[key] = {"error": repr(e)}
+                note("%s done" % key)
         except Exception as e:                                    # never let the secondary metric break the bench line
             gap = {"value": None, "error": repr(e)}
 
