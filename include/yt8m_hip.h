@@ -252,6 +252,25 @@ int yt8m_attn_pool_fwd(const float* w, const float* x, float* C, int64_t B, int6
 int yt8m_attn_pool_bwd(const float* w, const float* x, const float* dC, float* dw, float* dx, int64_t B, int64_t F, int64_t A,
                        int64_t H, yt8m_stream_t stream);
 
+/* The same layers straight from the reader's RAW uint8 frames (W/readers.py:178-187 hands uint8; W/utils.py:23-38 Dequantize and
+ * W/all_feature_transform/default_transformer.py:4-8 l2-normalise + mask are folded in: no fp32 [B,F,D] tensor is written):
+ *   x = diag(rs) (a0 q + c0 1 1^T),  a0 = 4/255, c0 = 4/512 - 2,  rs = yt8m_u8_frame_scales (1 / ||a0 q + c0||, 0 for padding frames)
+ *   yt8m_skinny_fwd_u8    y[M,N] (+)= rs (.) (a0 q.W + c0 colsum_w) (+ bias)       colsum_w [N] = column sums of W[0:K]
+ *   yt8m_skinny_dw_u8     dW[K,N] (+)= a0 q^T (rs (.) dy) + c0 1 (x) colsum(rs (.) dy)
+ *   yt8m_attn_pool_fwd_u8 C[b] = (w[b] (.) rs[b])^T (a0 q[b] + c0)                 q [B,F,H] uint8, w [B,F,A], rs [B,F], C [B,A,H]
+ *   yt8m_attn_pool_dw_u8  dw[b,f,a] = rs[b,f] (a0 q[b,f,:].dC[b,a,:] + c0 dCsum[b,a]),  dCsum [B,A] = sum_h dC
+ * q rows 4-byte aligned, row stride % 4 == 0; rs may be NULL (= 1).  There is no dx: the frames are the input. */
+int yt8m_u8_frame_scales(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, float* rs,
+                         yt8m_stream_t stream);
+int yt8m_skinny_fwd_u8(const uint8_t* q, int64_t ldq, const float* W, int64_t ldw, const float* bias, const float* rs,
+                       const float* colsum_w, float* y, int64_t ldy, int64_t M, int64_t K, int64_t N, float beta, yt8m_stream_t stream);
+int yt8m_skinny_dw_u8(const uint8_t* q, int64_t ldq, const float* dy, int64_t ldy, const float* rs, float* dW, int64_t lddw, int64_t M,
+                      int64_t K, int64_t N, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_attn_pool_fwd_u8(const float* w, const uint8_t* q, const float* rs, float* C, int64_t B, int64_t F, int64_t A, int64_t H,
+                          yt8m_stream_t stream);
+int yt8m_attn_pool_dw_u8(const uint8_t* q, const float* rs, const float* dC, const float* dCsum, float* dw, int64_t B, int64_t F,
+                         int64_t A, int64_t H, yt8m_stream_t stream);
+
 /* ---- GRUCell / LayerNormBasicLSTMCell layers (csrc/cells.hip), time-major, generic per-step form --------------------
  * tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn (W/all_frame_models/gru_pooling_model.py:34-47):
  *   zg [F,B,2H]: in = x.Wg[:in] + b_gates (hoisted by the caller), out = the gates r | u;

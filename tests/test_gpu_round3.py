@@ -567,3 +567,109 @@ def test_moe_head_bf16_on_images_matches_row_major(dev, flags, monkeypatch):
     (pa, la, ga), (pb, lb, gb) = res[True], res[False]
     assert float((pa - pb).abs().max()) < 1e-5 and abs(la - lb) <= 1e-5 * abs(lb)
     assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+
+
+# ---- the composite's attention branch straight from the reader's uint8 frames ------------------------------
+def _u8_case(dev, B, F, D, A, seed):
+    rs = np.random.RandomState(seed)
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(0, F + 1, size=B).astype(np.int32)
+    nf[0] = F
+    if B > 1:
+        nf[1] = 1
+    a0, c0 = 4.0 / 255.0, 4.0 / 512.0 - 2.0
+    xt = a0 * q.astype(np.float64) + c0                                  # W/utils.py:23-38
+    live = np.arange(F)[None, :] < nf[:, None]
+    r64 = live / np.maximum(np.sqrt((xt ** 2).sum(-1)), 1e-6)            # default_transformer.py:4-8: mask, l2-normalise
+    x64 = xt * r64[..., None]
+    return q, nf, r64, x64, rs
+
+
+@pytest.mark.parametrize("B,F,D,A", [(3, 10, 64, 3), (5, 37, 1152, 8), (2, 300, 1152, 8), (4, 21, 260, 12)])
+def test_u8_attention_primitives_vs_fp64(dev, B, F, D, A):
+    """yt8m_u8_frame_scales / yt8m_skinny_fwd_u8 / yt8m_skinny_dw_u8 / yt8m_attn_pool_fwd_u8 / yt8m_attn_pool_dw_u8 against the
+    float64 form on the dequantised, masked, l2-normalised frames (ragged num_frames incl. 0, 1 and F; D with a partial 256-wide
+    lane block; A on both register widths)."""
+    lib = L.lib()
+    q, nf, r64, x64, rs = _u8_case(dev, B, F, D, A, seed=B * 1000 + D)
+    qd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev)
+    r = seq_ops.u8_frame_scales(qd, nfd)
+    assert np.abs(r.cpu().numpy() - r64).max() <= 2e-6 * r64.max()
+    assert (r.cpu().numpy()[np.arange(F)[None, :] >= nf[:, None]] == 0).all()
+    # logit FC: y = x . W + bias
+    W = (rs.randn(D, A) * 0.3).astype(np.float32)
+    bias = rs.randn(A).astype(np.float32)
+    Wd, bd = torch.from_numpy(W).to(dev), torch.from_numpy(bias).to(dev)
+    cs = Wd.sum(dim=0)
+    y = torch.empty((B * F, A), device=dev)
+    L.check(lib.yt8m_skinny_fwd_u8(_p(qd), D, _p(Wd), A, _p(bd), _p(r), _p(cs), _p(y), A, B * F, D, A, 0.0, _stream()))
+    ref = x64.reshape(B * F, D) @ W.astype(np.float64) + bias
+    assert np.abs(y.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    # weight gradient: dW = x^T dy (accumulating on top of an existing gradient)
+    dy = rs.randn(B * F, A).astype(np.float32)
+    dyd = torch.from_numpy(dy).to(dev)
+    ws = torch.empty(max(1, lib.yt8m_skinny_workspace_bytes(B * F, D, A)), dtype=torch.uint8, device=dev)
+    dW = torch.full((D, A), 0.5, device=dev)
+    L.check(lib.yt8m_skinny_dw_u8(_p(qd), D, _p(dyd), A, _p(r), _p(dW), A, B * F, D, A, 1.0, _p(ws), ws.numel(), _stream()))
+    refw = 0.5 + x64.reshape(B * F, D).T @ dy.astype(np.float64)
+    assert np.abs(dW.cpu().numpy() - refw).max() < 2e-5 * max(1.0, np.abs(refw).max())
+    # pooling and its weight gradient
+    w = rs.rand(B, F, A).astype(np.float32)
+    wd = torch.from_numpy(w).to(dev)
+    C = seq_ops.pool_u8_raw(wd, qd, r)
+    refC = np.einsum("bfa,bfd->bad", w.astype(np.float64), x64)
+    assert np.abs(C.cpu().numpy() - refC).max() < 2e-5 * max(1.0, np.abs(refC).max())
+    dC = rs.randn(B, A, D).astype(np.float32)
+    dCd = torch.from_numpy(dC).to(dev)
+    wg = wd.clone().requires_grad_(True)
+    seq_ops.pool_tn_u8(wg, qd, r).backward(dCd)
+    refdw = np.einsum("bfd,bad->bfa", x64, dC.astype(np.float64))
+    assert np.abs(wg.grad.cpu().numpy() - refdw).max() < 2e-5 * max(1.0, np.abs(refdw).max())
+
+
+def test_composite_attention_branch_never_materialises_float_frames(dev, flags, monkeypatch):
+    """configs[4] composite on raw uint8 frames: no call of the [B,F,D] dequantise (yt8m_dequant_l2norm_u8) in a training step, and
+    the step equals the one taken on the float frames (same weights) to fp32 rounding."""
+    import yt8m_amd.losses as losses
+    import yt8m_amd.ops as ops
+    import yt8m_amd.feature_transform as ft
+    rs = np.random.RandomState(41)
+    B, F, D, V, A, Lc = 6, 24, 128, 40, 4, 2
+    flags.netvlad_cluster_size, flags.netvlad_hidden_size, flags.lstm_attentions = 16, 32, A
+    flags.deep_chain_layers, flags.deep_chain_relu_cells = Lc, 8
+    flags.support_type = ",".join(["label"] * Lc)
+    q = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
+    nf = torch.from_numpy(np.array([24, 1, 7, 24, 13, 2], dtype=np.int32)).to(dev)
+    y = torch.from_numpy(rs.rand(B, V) < 0.1).to(dev)
+    calls = {"dequant": 0}
+    real = ops.dequant_l2norm
+
+    def spy(*a, **kw):
+        calls["dequant"] += 1
+        return real(*a, **kw)
+
+    outs = {}
+    for mode in ("u8", "float"):
+        g = reset_default_graph(device=dev, seed=3)
+        tg = train.TrainGraph(flm.GatedNetVLADAttentionChainModel(), batch_size=B, graph=g, multitask=True,
+                              label_loss_fn=losses.MultiTaskCrossEntropyLoss(),
+                              transformer_class=ft.DefaultTransformer if mode == "u8" else ft.IdenticalTransformer)
+        x = q if mode == "u8" else real(q, nf)
+        monkeypatch.setattr(ops, "dequant_l2norm", spy)
+        calls["dequant"] = 0
+        res = tg.forward(x, y, nf)
+        g.finalize()
+        res = tg.forward(x, y, nf)
+        loss = tg.loss(res, y)
+        loss.backward()
+        monkeypatch.setattr(ops, "dequant_l2norm", real)
+        if mode == "u8":
+            assert calls["dequant"] == 0, "the uint8 composite wrote a float copy of the frames"
+        outs[mode] = (res["predictions"].detach().clone(), float(loss.detach()),
+                      {k: v.grad.detach().clone() for k, v in g.vars.items() if v.trainable and v.grad is not None})
+    pu, lu, gu = outs["u8"]
+    pf, lf, gf = outs["float"]
+    assert float((pu - pf).abs().max()) < 2e-5 and abs(lu - lf) < 2e-5 * abs(lf)
+    for k in gf:
+        scale = max(1e-6, float(gf[k].abs().max()))
+        assert float((gu[k] - gf[k]).abs().max()) < 5e-4 * scale, k

@@ -96,6 +96,11 @@ SIGNATURES = {
     "yt8m_lstm_pack_bf16": (c_int, [P, c_int64, c_int64, P, P, P]),
     "yt8m_lstm_steps_fwd_bf16": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_lstm_steps_bwd_bf16": (c_int, [P, P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "yt8m_u8_frame_scales": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, P, P]),
+    "yt8m_skinny_fwd_u8": (c_int, [P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_skinny_dw_u8": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_attn_pool_fwd_u8": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "yt8m_attn_pool_dw_u8": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "yt8m_attn_pool_supported": (c_int, [c_int64, c_int64, c_int64, c_int64]),
     "yt8m_attn_pool_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "yt8m_attn_pool_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),

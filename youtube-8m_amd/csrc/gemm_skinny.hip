@@ -6,20 +6,40 @@
 //   dW        dW[K,N] (+)= x[M,K]^T . dy[M,N]             x read once; row chunks -> partials -> fixed-order reduction
 //   dx        dx[M,K] (+)= dy[M,N] . W[K,N]^T             output-write-bound
 // N <= 16 (padded to NT = 8 or 16 in registers), K % 4 == 0, fp32.  Algorithmic bytes: 4*M*K (+ 4*M*N) per pass.
+//
+// uint8 rows (round 3): the same three kernels read the reader's RAW frames q [M, K] uint8 (W/readers.py:178-187) for
+//   x = diag(rs) (a0 q + c0 1 1^T),  a0 = 4/255, c0 = 4/512 - 2 (W/utils.py:23-38 Dequantize),  rs = 1 / ||a0 q + c0|| or 0 for padding
+// (the l2-normalised, masked frames of W/all_feature_transform/default_transformer.py:4-8) so that no fp32 [B, F, D] tensor exists:
+//   fwd : y = rs (.) (a0 q.W + c0 colsum(W)) + bias        dW : a0 q^T (rs (.) dy) + c0 1 (x) colsum(rs (.) dy)
+// 1 B instead of 4 B per input element; q in [0, 255] is exact in fp32.
+#include <type_traits>
 #include "common.h"
 
 namespace {
+
+constexpr float U8_A0 = 4.0f / 255.0f, U8_C0 = 4.0f / 512.0f - 2.0f;
+
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const uint8_t* p) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  return float4{(float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24)};
+}
 
 // ---- forward: a wave owns 4 rows at a time; lane l covers k = 256 j + 4 l + e; W lives in LDS as [j][q = 2e+h][lane][4]
 //      (n = 4h..4h+3 for NT = 8; q = 4e + h for NT = 16) so that the per-lane b128 reads are conflict-free -------------------
 // Batched form (blockIdx.y = batch, element strides bx / bw / by): the attention pooling backward dw[b] = x[b] . dC[b]^T of
 // lstm_attention_max_pooling_model.py:63, with W[k][n] = dC[b][n][k] addressed through (wsk, wsn).
-template <int NT>
-__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W,
+// XT = uint8_t: rs [M] (batch stride brs, may be NULL) and cs [N] = colsum(W) (batch stride bcs) complete the affine form above.
+template <int NT, typename XT = float>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const XT* __restrict__ x, int64_t ldx, const float* __restrict__ W,
                                                          int64_t wsk, int64_t wsn, const float* __restrict__ bias,
                                                          float* __restrict__ y, int64_t ldy, int64_t M, int K, int N, float beta,
-                                                         int rows_per_wg, int64_t bx, int64_t bw, int64_t by) {
+                                                         int rows_per_wg, int64_t bx, int64_t bw, int64_t by,
+                                                         const float* __restrict__ rs = nullptr, int64_t brs = 0,
+                                                         const float* __restrict__ cs = nullptr, int64_t bcs = 0) {
   extern __shared__ __attribute__((aligned(16))) float wl[];           // J * (NT) * 64 * 4 floats
+  constexpr bool U8 = std::is_same<XT, uint8_t>::value;
+  if constexpr (U8) { if (rs) rs += (int64_t)blockIdx.y * brs; if (cs) cs += (int64_t)blockIdx.y * bcs; }
   x += (int64_t)blockIdx.y * bx;
   W += (int64_t)blockIdx.y * bw;
   y += (int64_t)blockIdx.y * by;
@@ -46,14 +66,14 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     float acc[R * NT];
 #pragma unroll
     for (int i = 0; i < R * NT; ++i) acc[i] = 0.f;
-    const float* xr[R];
+    const XT* xr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) xr[r] = x + (r0 + r < M ? r0 + r : M - 1) * ldx + 4 * lane;
     for (int j = 0; j < J; ++j) {
       float4 xv[R];
       const bool in = 256 * j + 4 * lane < K;                          // K % 4 == 0: a float4 is inside or outside
 #pragma unroll
-      for (int r = 0; r < R; ++r) xv[r] = in ? *reinterpret_cast<const float4*>(xr[r] + 256 * j) : float4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < R; ++r) xv[r] = in ? load4(xr[r] + 256 * j) : float4{0.f, 0.f, 0.f, 0.f};
       const float* wj = wl + ((int64_t)j * 4 * QN * 64 + lane) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -98,7 +118,12 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
       const int r = vi / NT, nn = vi % NT;
       if (r0 + r < r_end && nn < N) {
         float* yp = y + (r0 + r) * ldy + nn;
-        float v = acc[0] + (bias ? bias[nn] : 0.f);
+        float v = acc[0];
+        if constexpr (U8) {
+          v = fmaf(U8_A0, v, cs ? U8_C0 * cs[nn] : 0.f);
+          if (rs) v *= rs[r0 + r];
+        }
+        v += bias ? bias[nn] : 0.f;
         if (beta != 0.f) v += *yp;
         *yp = v;
       }
@@ -109,15 +134,24 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 // ---- dW / dx: a thread owns 4 consecutive k of a 1024-wide k slice; the dy rows of the chunk sit in LDS (broadcast reads) ----
 // Batched form (blockIdx.z = batch): `direct` (dW only, one row chunk) writes out[b][n * ldo + k] itself -- the attention
 // pooling C[b] = w[b]^T . x[b] of lstm_attention_max_pooling_model.py:63 ([A, H] per video, k contiguous).
-template <int NT, bool DX, bool BATCH>
-__global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+// XT = uint8_t (dW / pooling only): the staged dy rows are scaled by rs [M] (batch stride brs, may be NULL) and the result is
+// a0 acc + c0 colsum(rs (.) dy) -- the affine form of the file header.
+template <int NT, bool DX, bool BATCH, typename XT = float>
+__global__ __launch_bounds__(256) void skinny_bwd_kernel(const XT* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                          int64_t ldy, const float* __restrict__ W, int64_t wsk, int64_t wsn,
                                                          float* __restrict__ out, int64_t ldo, int64_t M, int K, int N,
                                                          float beta, int rows_per_chunk, int kslice, int direct, int64_t bx,
-                                                         int64_t bdy, int64_t bw, int64_t bo) {
+                                                         int64_t bdy, int64_t bw, int64_t bo, const float* __restrict__ rs = nullptr,
+                                                         int64_t brs = 0) {
   constexpr int RC = 64;                                               // dy rows staged per pass
+  constexpr bool U8 = std::is_same<XT, uint8_t>::value;
+  static_assert(!(U8 && DX), "the frames are an input: no dx from uint8 rows");
   __shared__ __attribute__((aligned(16))) float dyl[RC * NT];
   const int tid = threadIdx.x;
+  if constexpr (U8 && BATCH) if (rs) rs += (int64_t)blockIdx.z * brs;
+  float sdy[U8 ? NT : 1];
+#pragma unroll
+  for (int i = 0; i < (U8 ? NT : 1); ++i) sdy[i] = 0.f;
   if (BATCH) {                      // a separate instantiation: the un-batched kernels keep their (faster) code
     if (!DX) x += (int64_t)blockIdx.z * bx;
     dy += (int64_t)blockIdx.z * bdy;
@@ -142,7 +176,9 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     for (int e = tid; e < RC * NT; e += 256) {
       const int64_t r = rb + e / NT;
       const int n = e % NT;
-      dyl[e] = (r < r_end && n < N) ? dy[r * ldy + n] : 0.f;
+      float v = (r < r_end && n < N) ? dy[r * ldy + n] : 0.f;
+      if constexpr (U8) { if (rs && r < r_end) v *= rs[r]; }
+      dyl[e] = v;
     }
     __syncthreads();
     if (!kin) continue;
@@ -167,7 +203,11 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
         if (beta != 0.f) { const float4 p = *op; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
         *op = o;
       } else {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (rb + r) * ldx + k0);
+        const float4 xv = load4(x + (rb + r) * ldx + k0);
+        if constexpr (U8) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) sdy[n] += dv[n];
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           acc[0 * NT + n] = fmaf(xv.x, dv[n], acc[0 * NT + n]);
@@ -176,6 +216,13 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
           acc[3 * NT + n] = fmaf(xv.w, dv[n], acc[3 * NT + n]);
         }
       }
+    }
+  }
+  if constexpr (U8) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e * NT + n] = fmaf(U8_A0, acc[e * NT + n], U8_C0 * sdy[n]);
     }
   }
   if (BATCH && !DX && kin && direct) {                                          // single row chunk: out[n][k0..k0+3] (+)= acc
@@ -401,4 +448,165 @@ extern "C" int yt8m_attn_pool_bwd(const float* w, const float* x, const float* d
                          dx, H, F, (int)H, (int)A, 0.f, rows, kslice, 0, (int64_t)0, F * A, A * H, F * H);
   }
   return launch_status("attention pooling backward");
+}
+
+// ---- the same layers on the reader's raw uint8 frames (file header: x = diag(rs) (a0 q + c0)) -------------------------------------
+namespace {
+
+// rs[row] = 1 / max(||a0 q_row + c0||, sqrt(eps)), 0 for padding rows (f >= num_frames[b]); one wave per frame row, the arithmetic
+// and summation order of dequant_l2norm_kernel (csrc/elementwise.hip) and u8_frames_tm_kernel (csrc/u8proj.hip).
+__global__ __launch_bounds__(256) void u8_frame_scales_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
+                                                              float* __restrict__ rs, int64_t rows, int F, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = (int)(row / F), f = (int)(row - (int64_t)b * F);
+  const bool live = nf ? (f < nf[b]) : true;
+  float ss = 0.f;
+  if (live) {
+    const uint32_t* qr = reinterpret_cast<const uint32_t*>(q + row * D);
+    for (int c4 = lane; c4 < (D >> 2); c4 += 64) {
+      const uint32_t w = qr[c4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float v = fmaf((float)((w >> (8 * k)) & 255u), U8_A0, U8_C0); ss += v * v; }
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) rs[row] = live ? rsqrtf(fmaxf(ss, eps)) : 0.f;
+}
+
+int u8_check(const void* q, int64_t ldq) {
+  YT8M_REQUIRE(q && ldq % 4 == 0 && ((uintptr_t)q & 3) == 0, YT8M_E_SHAPE, "uint8 rows must be 4-byte aligned with a row stride % 4 == 0");
+  return YT8M_OK;
+}
+
+}  // namespace
+
+extern "C" int yt8m_u8_frame_scales(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, float* rs,
+                                    yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F == 0) return YT8M_OK;
+  YT8M_REQUIRE(D >= 4 && D % 4 == 0 && B * F < (int64_t)4 * 0x7fffffff, YT8M_E_SHAPE, "D must be a multiple of 4");
+  YT8M_REQUIRE(q && rs && ((uintptr_t)q & 3) == 0, YT8M_E_BADARG, "null / unaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(u8_frame_scales_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, rs, B * F, (int)F, (int)D, eps);
+  return launch_status("u8_frame_scales_kernel");
+}
+
+// y[M,N] (+)= rs (.) (a0 q . W + c0 colsum_w) (+ bias); colsum_w [N] = column sums of W[0:K] (yt8m_colsum_f32), rs may be NULL (= 1)
+extern "C" int yt8m_skinny_fwd_u8(const uint8_t* q, int64_t ldq, const float* W, int64_t ldw, const float* bias, const float* rs,
+                                  const float* colsum_w, float* y, int64_t ldy, int64_t M, int64_t K, int64_t N, float beta,
+                                  yt8m_stream_t stream) {
+  int rc = skinny_check(M, K, N, beta);
+  if (rc != YT8M_OK) return rc;
+  if (M == 0 || N == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_skinny_supported(M, K, N), YT8M_E_SHAPE, "K too large for the LDS-resident weight image");
+  YT8M_REQUIRE(W && y && colsum_w, YT8M_E_BADARG, "null operand");
+  if ((rc = u8_check(q, ldq)) != YT8M_OK) return rc;
+  YT8M_REQUIRE(ldq >= K && ldw >= N && ldy >= N, YT8M_E_SHAPE, "bad leading dimension");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int J = (int)((K + 255) / 256);
+  int rows_per_wg = (int)((M + 1023) / 1024);
+  rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+  const unsigned grid = (unsigned)((M + rows_per_wg - 1) / rows_per_wg);
+  if (N <= 8) {
+    static DeviceOnce once8;
+    YT8M_HIP_CHECK(once8.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t>), 144 * 1024));
+    hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t>), dim3(grid), dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, ldq, W, ldw,
+                       (int64_t)1, bias, y, ldy, M, (int)K, (int)N, beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0, rs, (int64_t)0,
+                       colsum_w, (int64_t)0);
+  } else {
+    static DeviceOnce once16;
+    YT8M_HIP_CHECK(once16.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<16, uint8_t>), 144 * 1024));
+    hipLaunchKernelGGL((skinny_fwd_kernel<16, uint8_t>), dim3(grid), dim3(256), (size_t)J * 16 * 64 * 4 * sizeof(float), s, q, ldq, W, ldw,
+                       (int64_t)1, bias, y, ldy, M, (int)K, (int)N, beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0, rs, (int64_t)0,
+                       colsum_w, (int64_t)0);
+  }
+  return launch_status("skinny_fwd_kernel<u8>");
+}
+
+// dW[K,N] (+)= a0 q^T . (rs (.) dy) + c0 1 (x) colsum(rs (.) dy)   (workspace as yt8m_skinny_dw_f32)
+extern "C" int yt8m_skinny_dw_u8(const uint8_t* q, int64_t ldq, const float* dy, int64_t ldy, const float* rs, float* dW, int64_t lddw,
+                                 int64_t M, int64_t K, int64_t N, float beta, void* workspace, int64_t workspace_bytes,
+                                 yt8m_stream_t stream) {
+  int rc = skinny_check(M, K, N, beta);
+  if (rc != YT8M_OK) return rc;
+  if (K == 0 || N == 0) return YT8M_OK;
+  YT8M_REQUIRE(dW && (M == 0 || dy), YT8M_E_BADARG, "null operand");
+  if (M > 0 && (rc = u8_check(q, ldq)) != YT8M_OK) return rc;
+  YT8M_REQUIRE(ldq >= K && ldy >= N && lddw >= N, YT8M_E_SHAPE, "bad leading dimension");
+  YT8M_REQUIRE(workspace && workspace_bytes >= yt8m_skinny_workspace_bytes(M, K, N), YT8M_E_BADARG, "workspace too small");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const BwdPlan pl = bwd_plan(M, K);
+  float* ws = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)pl.nslices, (unsigned)(pl.chunks > 0 ? pl.chunks : 1));
+  if (N <= 8) {
+    if (pl.chunks > 0)
+      hipLaunchKernelGGL((skinny_bwd_kernel<8, false, false, uint8_t>), grid, dim3(256), 0, s, q, ldq, dy, ldy, (const float*)nullptr,
+                         (int64_t)0, (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, pl.rows, pl.kslice, 0, (int64_t)0, (int64_t)0,
+                         (int64_t)0, (int64_t)0, rs, (int64_t)0);
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, pl.chunks, dW, lddw, (int)K,
+                       (int)N, beta);
+  } else {
+    if (pl.chunks > 0)
+      hipLaunchKernelGGL((skinny_bwd_kernel<16, false, false, uint8_t>), grid, dim3(256), 0, s, q, ldq, dy, ldy, (const float*)nullptr,
+                         (int64_t)0, (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, pl.rows, pl.kslice, 0, (int64_t)0, (int64_t)0,
+                         (int64_t)0, (int64_t)0, rs, (int64_t)0);
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, pl.chunks, dW, lddw,
+                       (int)K, (int)N, beta);
+  }
+  return launch_status("skinny_bwd_kernel<dW, u8>");
+}
+
+// attention pooling of the raw frames (W/all_frame_models/lstm_attention_max_pooling_model.py:63 on x above):
+//   fwd: C[b] = (w[b] (.) rs[b])^T (a0 q[b] + c0)      q [B,F,H] uint8, w [B,F,A], rs [B,F], C [B,A,H]
+//   dw : dw[b,f,a] = rs[b,f] (a0 q[b,f,:] . dC[b,a,:] + c0 dCsum[b,a]),  dCsum[b,a] = sum_h dC[b,a,h]
+extern "C" int yt8m_attn_pool_fwd_u8(const float* w, const uint8_t* q, const float* rs, float* C, int64_t B, int64_t F, int64_t A,
+                                     int64_t H, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && A >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * A * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_attn_pool_supported(B, F, A, H), YT8M_E_SHAPE, "attention pooling needs A <= 16, H % 4 == 0");
+  YT8M_REQUIRE(w && q && C && ((uintptr_t)C & 15) == 0 && ((uintptr_t)q & 3) == 0, YT8M_E_BADARG, "null / unaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int nsl = (int)((H + 1023) / 1024);
+  const int kslice = (int)(((H + nsl - 1) / nsl + 3) / 4 * 4);
+  const dim3 grid((unsigned)nsl, 1, (unsigned)B);
+  const int rows = (int)((F + 63) / 64 * 64);
+  if (A <= 8)
+    hipLaunchKernelGGL((skinny_bwd_kernel<8, false, true, uint8_t>), grid, dim3(256), 0, s, q, H, w, A, (const float*)nullptr, (int64_t)0,
+                       (int64_t)0, C, H, F, (int)H, (int)A, 0.f, rows, kslice, 1, F * H, F * A, (int64_t)0, A * H, rs, F);
+  else
+    hipLaunchKernelGGL((skinny_bwd_kernel<16, false, true, uint8_t>), grid, dim3(256), 0, s, q, H, w, A, (const float*)nullptr, (int64_t)0,
+                       (int64_t)0, C, H, F, (int)H, (int)A, 0.f, rows, kslice, 1, F * H, F * A, (int64_t)0, A * H, rs, F);
+  return launch_status("skinny_bwd_kernel<pool, u8>");
+}
+
+extern "C" int yt8m_attn_pool_dw_u8(const uint8_t* q, const float* rs, const float* dC, const float* dCsum, float* dw, int64_t B,
+                                    int64_t F, int64_t A, int64_t H, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && A >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * A == 0) return YT8M_OK;
+  YT8M_REQUIRE(H > 0 && yt8m_attn_pool_supported(B, F, A, H), YT8M_E_SHAPE, "attention pooling needs A <= 16, H % 4 == 0");
+  YT8M_REQUIRE(q && dC && dCsum && dw && ((uintptr_t)q & 3) == 0, YT8M_E_BADARG, "null / unaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_GEMM, s);
+  const int J = (int)((H + 255) / 256);
+  int rows_per_wg = (int)((F + 3) / 4);
+  rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+  const dim3 grid((unsigned)((F + rows_per_wg - 1) / rows_per_wg), (unsigned)B);
+  if (A <= 8) {
+    static DeviceOnce once;
+    YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t>), 144 * 1024));
+    hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t>), grid, dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, H, dC, (int64_t)1, H,
+                       (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A, rs, F, dCsum, A);
+  } else {
+    static DeviceOnce once;
+    YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<16, uint8_t>), 144 * 1024));
+    hipLaunchKernelGGL((skinny_fwd_kernel<16, uint8_t>), grid, dim3(256), (size_t)J * 16 * 64 * 4 * sizeof(float), s, q, H, dC, (int64_t)1, H,
+                       (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A, rs, F, dCsum, A);
+  }
+  return launch_status("skinny_fwd_kernel<pool dw, u8>");
 }

@@ -457,12 +457,26 @@ class GatedNetVLADAttentionChainModel(GatedNetVLADModel):
         A = FLAGS.lstm_attentions
         B, F, D = model_input.shape
         h = self.descriptor(model_input, num_frames)                                       # [B,Hfc] (uint8 stays fused)
-        x = ops.dequant_l2norm(model_input, num_frames) if model_input.dtype == torch.uint8 else model_input
-        nf = num_frames.to(x.dtype).clamp(min=1).view(B, 1, 1) if num_frames is not None else float(F)
-        mean_x = (x.sum(dim=1, keepdim=True) / nf).view(B, D)                              # tiled over the frames by the FC
-        act = video_level_models.fully_connected_cat([x], A, "attention-", l2_penalty=l2_penalty, group_parts=[mean_x])
-        w = seq_ops.attention_weights(act, num_frames)                                     # [B,F,A]
-        att = seq_ops.pool_tn(w, x)                                                        # [B,A,D]
+        if seq_ops.u8_attention_supported(model_input, A):
+            # raw reader bytes all the way: the logit FC, the pooling and their gradients read uint8 (csrc/gemm_skinny.hip)
+            q = model_input.contiguous()
+            rs = seq_ops.u8_frame_scales(q, num_frames)                                    # [B,F]; 0 on the padding frames
+            inv = (1.0 / num_frames.to(torch.float32).clamp(min=1)) if num_frames is not None else \
+                torch.full((B,), 1.0 / F, dtype=torch.float32, device=q.device)
+            mean_x = seq_ops.pool_u8_raw(inv.view(B, 1, 1).expand(B, F, 1).contiguous(), q, rs).view(B, D)
+            g = video_level_models.get_default_graph()
+            W = g.get_variable("attention-/weights", (2 * D, A), video_level_models.xavier_uniform, l2=l2_penalty)
+            b = g.get_variable("attention-/biases", (A,), video_level_models.zeros)
+            act = seq_ops.attention_logits_u8(q, rs, mean_x, W, b)
+            w = seq_ops.attention_weights(act, num_frames)                                 # [B,F,A]
+            att = seq_ops.pool_tn_u8(w, q, rs)                                             # [B,A,D]
+        else:
+            x = ops.dequant_l2norm(model_input, num_frames) if model_input.dtype == torch.uint8 else model_input
+            nf = num_frames.to(x.dtype).clamp(min=1).view(B, 1, 1) if num_frames is not None else float(F)
+            mean_x = (x.sum(dim=1, keepdim=True) / nf).view(B, D)                          # tiled over the frames by the FC
+            act = video_level_models.fully_connected_cat([x], A, "attention-", l2_penalty=l2_penalty, group_parts=[mean_x])
+            w = seq_ops.attention_weights(act, num_frames)                                 # [B,F,A]
+            att = seq_ops.pool_tn(w, x)                                                    # [B,A,D]
         chain_in = torch.cat([h.unsqueeze(1).expand(B, A, h.shape[1]), att], dim=2).reshape(B * A, -1)
         unused_params.pop("original_input", None)
         res = video_level_models.DeepCombineChainModel().create_model(chain_in, vocab_size, l2_penalty=l2_penalty,

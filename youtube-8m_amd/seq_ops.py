@@ -994,6 +994,111 @@ def pool_tn(w, x):
     return _PoolTN.apply(w, x)
 
 
+# ---- attention branch straight from the reader's uint8 frames (csrc/gemm_skinny.hip, uint8 rows) -----------------------------
+# x = diag(rs) (a0 q + c0): Dequantize (W/utils.py:23-38), mask and l2-normalise (W/all_feature_transform/default_transformer.py:4-8)
+# of the frames W/readers.py:178-187 hands over as uint8, folded into the logit FC, the pooling and their gradients.
+
+def u8_attention_supported(q, A):
+    if q.dtype != torch.uint8 or q.dim() != 3 or not q.is_cuda:
+        return False
+    B, F, D = q.shape
+    L = _lib.lib()
+    return bool(D % 4 == 0 and L.yt8m_attn_pool_supported(B, F, A, D) == 1 and L.yt8m_skinny_supported(B * F, D, A) == 1)
+
+
+def u8_frame_scales(q, num_frames, eps=1e-12):
+    """rs [B,F] = 1 / ||a0 q + c0|| per frame, 0 for the padding frames."""
+    q = q.contiguous()
+    _dev(q)
+    B, F, D = q.shape
+    rs = torch.empty((B, F), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().yt8m_u8_frame_scales(_p(q), _p(_nf(num_frames)), B, F, D, float(eps), _p(rs), _stream()))
+    return rs
+
+
+def pool_u8_raw(w, q, rs):
+    """C [B,A,D] = (w (.) rs)^T (a0 q + c0) without autograd (w [B,F,A])."""
+    B, F, A = w.shape
+    D = q.shape[2]
+    C = torch.empty((B, A, D), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().yt8m_attn_pool_fwd_u8(_p(w), _p(q), _p(rs), _p(C), B, F, A, D, _stream()))
+    return C
+
+
+class _PoolU8(torch.autograd.Function):
+    """att[b] = w[b]^T x[b] of W/all_frame_models/lstm_attention_max_pooling_model.py:63 with x from the raw frames; the
+    gradient goes to the weights only (the frames are the input)."""
+
+    @staticmethod
+    def forward(ctx, w, q, rs):
+        w = _f32c(w)
+        _dev(w, q, rs)
+        ctx.save_for_backward(q, rs)
+        ctx.shape = tuple(w.shape)
+        return pool_u8_raw(w, q, rs)
+
+    @staticmethod
+    def backward(ctx, dC):
+        q, rs = ctx.saved_tensors
+        dC = _f32c(dC)
+        B, F, A = ctx.shape
+        D = q.shape[2]
+        dCsum = dC.sum(dim=2)                                         # [B,A]: the rank-1 remainder of the dequantise affine
+        dw = torch.empty((B, F, A), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().yt8m_attn_pool_dw_u8(_p(q), _p(rs), _p(dC), _p(dCsum), _p(dw), B, F, A, D, _stream()))
+        return dw, None, None
+
+
+def pool_tn_u8(w, q, rs):
+    return _PoolU8.apply(w, q, rs)
+
+
+class _AttnLogitsU8(torch.autograd.Function):
+    """act [B,F,A] = slim.fully_connected(concat(x, tile(mean_x))) of lstm_attention_max_pooling_model.py:51-56 with x from the
+    raw frames: W rows [0, D) meet the frames, rows [D, D + Dm) the per-video vector mean_x [B, Dm]."""
+
+    @staticmethod
+    def forward(ctx, token, W, b, q, rs, mean_x):
+        _dev(q, rs, mean_x)
+        B, F, D = q.shape
+        N = W.data.shape[1]
+        assert W.data.shape[0] == D + mean_x.shape[1]
+        Wx, Wm = W.data[:D], W.data[D:]
+        cs = Wx.sum(dim=0)
+        y = torch.empty((B * F, N), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().yt8m_skinny_fwd_u8(_p(q), D, _p(Wx), Wx.stride(0), _p(b.data if b is not None else None), _p(rs), _p(cs),
+                                                 _p(y), N, B * F, D, N, 0.0, _stream()))
+        t = ops.gemm(mean_x, Wm)                                      # [B, N]: tiny
+        y.view(B, F, N).add_(t.view(B, 1, N))
+        ctx.save_for_backward(q, rs, mean_x)
+        ctx.W, ctx.b = W, b
+        return y.view(B, F, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        q, rs, mean_x = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        B, F, D = q.shape
+        dy = _f32c(dy).view(B * F, -1)
+        N = dy.shape[1]
+        if W.trainable and W.grad is not None:
+            wbeta = W.grad_beta()
+            gx = W.grad[:D]
+            ws = ops._workspace(q.device)
+            _lib.check(_lib.lib().yt8m_skinny_dw_u8(_p(q), D, _p(dy), N, _p(rs), _p(gx), gx.stride(0), B * F, D, N, float(wbeta),
+                                                    _p(ws), ws.numel() * 4, _stream()))
+            ops.gemm(mean_x, dy.view(B, F, N).sum(dim=1), out=W.grad[D:], transA=True, beta=wbeta)
+            W.grad_done()
+        if b is not None and b.trainable and b.grad is not None:
+            ops.colsum(dy, b.grad.view(-1), beta=b.grad_beta())
+            b.grad_done()
+        return None, None, None, None, None, None
+
+
+def attention_logits_u8(q, rs, mean_x, W, b):
+    return _AttnLogitsU8.apply(_token(W._graph), W, b, q, rs, mean_x)
+
+
 class _VladFinish(torch.autograd.Function):
     """vlad[b,k,:] = l2norm_D(agg[b,k,:] - (sum_f a[b,f,k]) * c[k,:])   (residual aggregation +
     intra-normalisation in one pass, yt8m_vlad_finish_fwd/bwd); c is a Variable."""
