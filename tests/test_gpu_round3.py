@@ -635,7 +635,7 @@ def test_composite_attention_branch_never_materialises_float_frames(dev, flags, 
     import yt8m_amd.feature_transform as ft
     rs = np.random.RandomState(41)
     B, F, D, V, A, Lc = 6, 24, 128, 40, 4, 2
-    flags.netvlad_cluster_size, flags.netvlad_hidden_size, flags.lstm_attentions = 16, 32, A
+    flags.netvlad_cluster_size, flags.netvlad_hidden_size, flags.lstm_attentions = 64, 32, A
     flags.deep_chain_layers, flags.deep_chain_relu_cells = Lc, 8
     flags.support_type = ",".join(["label"] * Lc)
     q = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
@@ -671,5 +671,5 @@ def test_composite_attention_branch_never_materialises_float_frames(dev, flags, 
     pf, lf, gf = outs["float"]
     assert float((pu - pf).abs().max()) < 2e-5 and abs(lu - lf) < 2e-5 * abs(lf)
     for k in gf:
-        scale = max(1e-6, float(gf[k].abs().max()))
-        assert float((gu[k] - gf[k]).abs().max()) < 5e-4 * scale, k
+        scale = float(gf[k].abs().max())               # the logit bias gradient is zero up to rounding (softmax over the frames)
+        assert float((gu[k] - gf[k]).abs().max()) < 5e-4 * scale + 1e-7, k

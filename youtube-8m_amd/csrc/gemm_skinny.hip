@@ -20,10 +20,10 @@ namespace {
 constexpr float U8_A0 = 4.0f / 255.0f, U8_C0 = 4.0f / 512.0f - 2.0f;
 
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 load4(const uint8_t* p) {
-  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+__device__ __forceinline__ float4 unpack4(uint32_t u) {
   return float4{(float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24)};
 }
+__device__ __forceinline__ float4 load4(const uint8_t* p) { return unpack4(*reinterpret_cast<const uint32_t*>(p)); }
 
 // ---- forward: a wave owns 4 rows at a time; lane l covers k = 256 j + 4 l + e; W lives in LDS as [j][q = 2e+h][lane][4]
 //      (n = 4h..4h+3 for NT = 8; q = 4e + h for NT = 16) so that the per-lane b128 reads are conflict-free -------------------
@@ -62,18 +62,26 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const XT* __restrict__ 
   __syncthreads();
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r_end = r_begin + rows_per_wg < M ? r_begin + rows_per_wg : M;
+  // uint8 rows: a whole row group (R rows x up to 2048 bytes = JM words per lane) is fetched one group AHEAD of the arithmetic --
+  // a 4-byte load per lane carries a quarter of the float4's bytes, so the loads in flight, not the bytes, bound the stream
+  constexpr int JM = U8 ? 8 : 1;
+  uint32_t nxt[R][JM];
+  auto fetch = [&](int64_t r0) {
+    if constexpr (U8) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(x + (r0 + r < M ? r0 + r : M - 1) * ldx) + lane;
+#pragma unroll
+        for (int j = 0; j < JM; ++j) nxt[r][j] = (j < J && 256 * j + 4 * lane < K) ? p[64 * j] : 0u;
+      }
+    }
+  };
+  if (r_begin + w * R < r_end) fetch(r_begin + w * R);
   for (int64_t r0 = r_begin + w * R; r0 < r_end; r0 += 4 * R) {
     float acc[R * NT];
 #pragma unroll
     for (int i = 0; i < R * NT; ++i) acc[i] = 0.f;
-    const XT* xr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) xr[r] = x + (r0 + r < M ? r0 + r : M - 1) * ldx + 4 * lane;
-    for (int j = 0; j < J; ++j) {
-      float4 xv[R];
-      const bool in = 256 * j + 4 * lane < K;                          // K % 4 == 0: a float4 is inside or outside
-#pragma unroll
-      for (int r = 0; r < R; ++r) xv[r] = in ? load4(xr[r] + 256 * j) : float4{0.f, 0.f, 0.f, 0.f};
+    auto fma_block = [&](int j, const float4 (&xv)[R]) {
       const float* wj = wl + ((int64_t)j * 4 * QN * 64 + lane) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -89,6 +97,34 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const XT* __restrict__ 
             acc[r * NT + 4 * h + 3] = fmaf(xk, wv.w, acc[r * NT + 4 * h + 3]);
           }
         }
+      }
+    };
+    if constexpr (U8) {
+      uint32_t cur[R][JM];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < JM; ++j) cur[r][j] = nxt[r][j];
+      if (r0 + 4 * R < r_end) fetch(r0 + 4 * R);
+#pragma unroll
+      for (int j = 0; j < JM; ++j) {
+        if (j < J) {
+          float4 xv[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) xv[r] = unpack4(cur[r][j]);
+          fma_block(j, xv);
+        }
+      }
+    } else {
+      const XT* xr[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) xr[r] = x + (r0 + r < M ? r0 + r : M - 1) * ldx + 4 * lane;
+      for (int j = 0; j < J; ++j) {
+        float4 xv[R];
+        const bool in = 256 * j + 4 * lane < K;                        // K % 4 == 0: a float4 is inside or outside
+#pragma unroll
+        for (int r = 0; r < R; ++r) xv[r] = in ? load4(xr[r] + 256 * j) : float4{0.f, 0.f, 0.f, 0.f};
+        fma_block(j, xv);
       }
     }
     // transposing butterfly: R*NT values x 64 lanes -> every value summed over the wave with R*NT (+ tail) shuffles instead
@@ -183,6 +219,32 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const XT* __restrict__ 
     __syncthreads();
     if (!kin) continue;
     const int nr = (int)(r_end - rb < RC ? r_end - rb : RC);
+    if constexpr (U8) {                                                // 8 rows of 4-byte loads in flight per thread (see forward)
+      for (int rr = 0; rr < nr; rr += 8) {
+        uint32_t xw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xw[i] = rr + i < nr ? *reinterpret_cast<const uint32_t*>(x + (rb + rr + i) * ldx + k0) : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                                  // staged rows past r_end are zero
+          float dv[NT];
+#pragma unroll
+          for (int q = 0; q < NT / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(dyl + (rr + i) * NT + 4 * q);
+            dv[4 * q] = t.x; dv[4 * q + 1] = t.y; dv[4 * q + 2] = t.z; dv[4 * q + 3] = t.w;
+          }
+          const float4 xv = unpack4(xw[i]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            sdy[n] += dv[n];
+            acc[0 * NT + n] = fmaf(xv.x, dv[n], acc[0 * NT + n]);
+            acc[1 * NT + n] = fmaf(xv.y, dv[n], acc[1 * NT + n]);
+            acc[2 * NT + n] = fmaf(xv.z, dv[n], acc[2 * NT + n]);
+            acc[3 * NT + n] = fmaf(xv.w, dv[n], acc[3 * NT + n]);
+          }
+        }
+      }
+      continue;
+    }
     for (int r = 0; r < nr; ++r) {
       float dv[NT];
 #pragma unroll
@@ -204,10 +266,6 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const XT* __restrict__ 
         *op = o;
       } else {
         const float4 xv = load4(x + (rb + r) * ldx + k0);
-        if constexpr (U8) {
-#pragma unroll
-          for (int n = 0; n < NT; ++n) sdy[n] += dv[n];
-        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           acc[0 * NT + n] = fmaf(xv.x, dv[n], acc[0 * NT + n]);
@@ -239,15 +297,24 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const XT* __restrict__ 
   }
 }
 
+// 32 elements x 8 chunk lanes per workgroup: chunk lane c sums chunks c, c + 8, ... and the 8 partial sums are added in lane
+// order -- a fixed order, so the result is deterministic; K * NT / 32 workgroups instead of K * NT / 256
 template <int NT>
 __global__ __launch_bounds__(256) void skinny_dw_reduce_kernel(const float* __restrict__ ws, int chunks, float* __restrict__ dW,
                                                                int64_t lddw, int K, int N, float beta) {
-  const int e = blockIdx.x * 256 + threadIdx.x;                        // (k, n) of the padded [K][NT] image
-  if (e >= K * NT) return;
+  __shared__ float part[8][33];
+  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;                                  // (k, n) of the padded [K][NT] image
+  float s = 0.f;
+  if (e < K * NT)
+    for (int c = cl; c < chunks; c += 8) s += ws[(int64_t)c * K * NT + e];
+  part[cl][el] = s;
+  __syncthreads();
+  if (cl != 0 || e >= K * NT) return;
   const int k = e / NT, n = e % NT;
   if (n >= N) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += ws[(int64_t)c * K * NT + e];   // fixed order: deterministic
+#pragma unroll
+  for (int c = 1; c < 8; ++c) s += part[c][el];
   float* d = dW + (int64_t)k * lddw + n;
   *d = beta != 0.f ? *d + s : s;
 }
@@ -345,14 +412,14 @@ extern "C" int yt8m_skinny_dw_f32(const float* x, int64_t ldx, const float* dy, 
       hipLaunchKernelGGL((skinny_bwd_kernel<8, false, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
                          (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0,
                          (int64_t)0);
-    hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw, (int)K,
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 31) / 32)), dim3(256), 0, s, ws, chunks, dW, lddw, (int)K,
                        (int)N, beta);
   } else {
     if (chunks > 0)
       hipLaunchKernelGGL((skinny_bwd_kernel<16, false, false>), grid, dim3(256), 0, s, x, ldx, dy, ldy, (const float*)nullptr, (int64_t)0,
                          (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, rows, kslice, 0, (int64_t)0, (int64_t)0, (int64_t)0,
                          (int64_t)0);
-    hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, chunks, dW, lddw,
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 31) / 32)), dim3(256), 0, s, ws, chunks, dW, lddw,
                        (int)K, (int)N, beta);
   }
   return launch_status("skinny_bwd_kernel<dW>");
@@ -465,17 +532,25 @@ __global__ __launch_bounds__(256) void u8_frame_scales_kernel(const uint8_t* __r
   float ss = 0.f;
   if (live) {
     const uint32_t* qr = reinterpret_cast<const uint32_t*>(q + row * D);
-    for (int c4 = lane; c4 < (D >> 2); c4 += 64) {
-      const uint32_t w = qr[c4];
+    for (int c0 = 0; c0 < (D >> 2); c0 += 512) {                       // 8 loads in flight per lane
+      uint32_t w[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const float v = fmaf((float)((w >> (8 * k)) & 255u), U8_A0, U8_C0); ss += v * v; }
+      for (int it = 0; it < 8; ++it) w[it] = c0 + lane + 64 * it < (D >> 2) ? qr[c0 + lane + 64 * it] : 0u;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        if (c0 + lane + 64 * it < (D >> 2)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const float v = fmaf((float)((w[it] >> (8 * k)) & 255u), U8_A0, U8_C0); ss += v * v; }
+        }
+      }
     }
   }
   ss = wave_sum(ss);
   if (lane == 0) rs[row] = live ? rsqrtf(fmaxf(ss, eps)) : 0.f;
 }
 
-int u8_check(const void* q, int64_t ldq) {
+int u8_check(const void* q, int64_t ldq, int64_t K) {
+  YT8M_REQUIRE(K <= 2048, YT8M_E_SHAPE, "uint8 rows: K <= 2048 (a row group is held in registers)");
   YT8M_REQUIRE(q && ldq % 4 == 0 && ((uintptr_t)q & 3) == 0, YT8M_E_SHAPE, "uint8 rows must be 4-byte aligned with a row stride % 4 == 0");
   return YT8M_OK;
 }
@@ -503,7 +578,7 @@ extern "C" int yt8m_skinny_fwd_u8(const uint8_t* q, int64_t ldq, const float* W,
   if (M == 0 || N == 0) return YT8M_OK;
   YT8M_REQUIRE(yt8m_skinny_supported(M, K, N), YT8M_E_SHAPE, "K too large for the LDS-resident weight image");
   YT8M_REQUIRE(W && y && colsum_w, YT8M_E_BADARG, "null operand");
-  if ((rc = u8_check(q, ldq)) != YT8M_OK) return rc;
+  if ((rc = u8_check(q, ldq, K)) != YT8M_OK) return rc;
   YT8M_REQUIRE(ldq >= K && ldw >= N && ldy >= N, YT8M_E_SHAPE, "bad leading dimension");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);
@@ -535,7 +610,7 @@ extern "C" int yt8m_skinny_dw_u8(const uint8_t* q, int64_t ldq, const float* dy,
   if (rc != YT8M_OK) return rc;
   if (K == 0 || N == 0) return YT8M_OK;
   YT8M_REQUIRE(dW && (M == 0 || dy), YT8M_E_BADARG, "null operand");
-  if (M > 0 && (rc = u8_check(q, ldq)) != YT8M_OK) return rc;
+  if (M > 0 && (rc = u8_check(q, ldq, K)) != YT8M_OK) return rc;
   YT8M_REQUIRE(ldq >= K && ldy >= N && lddw >= N, YT8M_E_SHAPE, "bad leading dimension");
   YT8M_REQUIRE(workspace && workspace_bytes >= yt8m_skinny_workspace_bytes(M, K, N), YT8M_E_BADARG, "workspace too small");
   hipStream_t s = as_stream(stream);
@@ -548,14 +623,14 @@ extern "C" int yt8m_skinny_dw_u8(const uint8_t* q, int64_t ldq, const float* dy,
       hipLaunchKernelGGL((skinny_bwd_kernel<8, false, false, uint8_t>), grid, dim3(256), 0, s, q, ldq, dy, ldy, (const float*)nullptr,
                          (int64_t)0, (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, pl.rows, pl.kslice, 0, (int64_t)0, (int64_t)0,
                          (int64_t)0, (int64_t)0, rs, (int64_t)0);
-    hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 255) / 256)), dim3(256), 0, s, ws, pl.chunks, dW, lddw, (int)K,
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<8>, dim3((unsigned)((K * 8 + 31) / 32)), dim3(256), 0, s, ws, pl.chunks, dW, lddw, (int)K,
                        (int)N, beta);
   } else {
     if (pl.chunks > 0)
       hipLaunchKernelGGL((skinny_bwd_kernel<16, false, false, uint8_t>), grid, dim3(256), 0, s, q, ldq, dy, ldy, (const float*)nullptr,
                          (int64_t)0, (int64_t)0, ws, (int64_t)0, M, (int)K, (int)N, 0.f, pl.rows, pl.kslice, 0, (int64_t)0, (int64_t)0,
                          (int64_t)0, (int64_t)0, rs, (int64_t)0);
-    hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 255) / 256)), dim3(256), 0, s, ws, pl.chunks, dW, lddw,
+    hipLaunchKernelGGL(skinny_dw_reduce_kernel<16>, dim3((unsigned)((K * 16 + 31) / 32)), dim3(256), 0, s, ws, pl.chunks, dW, lddw,
                        (int)K, (int)N, beta);
   }
   return launch_status("skinny_bwd_kernel<dW, u8>");
@@ -589,7 +664,7 @@ extern "C" int yt8m_attn_pool_dw_u8(const uint8_t* q, const float* rs, const flo
                                     int64_t F, int64_t A, int64_t H, yt8m_stream_t stream) {
   YT8M_REQUIRE(B >= 0 && F >= 0 && A >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   if (B * F * A == 0) return YT8M_OK;
-  YT8M_REQUIRE(H > 0 && yt8m_attn_pool_supported(B, F, A, H), YT8M_E_SHAPE, "attention pooling needs A <= 16, H % 4 == 0");
+  YT8M_REQUIRE(H > 0 && H <= 2048 && yt8m_attn_pool_supported(B, F, A, H), YT8M_E_SHAPE, "attention pooling needs A <= 16, H % 4 == 0, H <= 2048");
   YT8M_REQUIRE(q && dC && dCsum && dw && ((uintptr_t)q & 3) == 0, YT8M_E_BADARG, "null / unaligned operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_GEMM, s);

@@ -1003,7 +1003,7 @@ def u8_attention_supported(q, A):
         return False
     B, F, D = q.shape
     L = _lib.lib()
-    return bool(D % 4 == 0 and L.yt8m_attn_pool_supported(B, F, A, D) == 1 and L.yt8m_skinny_supported(B * F, D, A) == 1)
+    return bool(D % 4 == 0 and D <= 2048 and L.yt8m_attn_pool_supported(B, F, A, D) == 1 and L.yt8m_skinny_supported(B * F, D, A) == 1)
 
 
 def u8_frame_scales(q, num_frames, eps=1e-12):
