@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+timeout 300 python tools/model_bench.py netvlad chain config5 2>&1 | grep "B=" | cut -c1-330

@@ -25,7 +25,11 @@ bool x3_pays(int64_t M, int64_t N, int64_t K) {
   const double fl = 2.0 * (double)M * (double)N * (double)K;
   const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
   const double eff = (double)M * (double)N / ((double)(tm * tn) * 65536.0);
-  const double occ = std::min(1.0, (double)(tm * tn) * (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 128)) / 256.0);
+  // K parts per tile the launch will cut (csrc/gemm_x3.hip x3_launch): up to 8, up to 16 for a very long reduction -- measured: the
+  // NetVLAD hidden FC [1024 x 73728] . [73728 x 1024] 1.12 ms against 1.44 on the fp32 kernel; at K ~ 14 000 the 16-part form of an
+  // 18-tile product is slower than the fp32 kernel (MoE-chain dx shapes, tools/gemm_auto_probe.py)
+  const int64_t kparts = K >= 32768 ? 16 : 8;
+  const double occ = std::min(1.0, (double)(tm * tn) * (double)std::max<int64_t>(1, std::min<int64_t>(kparts, K / 128)) / 256.0);
   const double tx3 = fl / (X3_RATE * eff * occ) + ((double)M * K + (double)N * K) * 10.0 / SPLIT_RATE + 2e-5;
   const double t32 = fl / (F32_RATE * std::min(1.0, (double)(((M + 127) / 128) * ((N + 127) / 128)) *
                                                         (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 256)) / 768.0));

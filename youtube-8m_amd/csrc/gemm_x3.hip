@@ -652,7 +652,7 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     int S = 1;
     if (workspace && rem > 0) {
       double best = 1e30;
-      for (int c = 1; c <= 8; ++c) {
+      for (int c = 1; c <= 16; ++c) {                              // > 8 parts only pay for a handful of tiles with a very long K
         if (c > 1 && (g.KB / c < (PA == 0 ? 32 : 8) || (slots + (int64_t)rem * c) * per_part > workspace_bytes)) break;
         const int rounds = (rem * c + SLOTS - 1) / SLOTS;
         const double cost = rounds * ((double)g.KB / c + 10.0) + (c > 1 ? 4.0 + 0.065 * rem * c : 0.0);
