@@ -947,7 +947,8 @@ class _MoeHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, token, Wg, We, be, V, M, bf16):
         x2 = _f32c(x)
-        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16)
+        ctx.images = {} if (bf16 and FUSED_MIX_BF16 and M == 2 and ctx.needs_input_grad[1]) else None
+        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images)
         ctx.bf16 = bf16
         p = moe_mix_fwd(Zg, Ze, V, M)
         ctx.save_for_backward(x2)
@@ -1027,13 +1028,15 @@ def _moe_head_bwd_bf16_images(ctx, x, Zg, Ze, Wg, We, be, V, M, dp, labels, ldt,
     _lib.check(L.yt8m_moe_mix_bwd_bf16_images(_p(Zg), _p(Ze), _p(dp), _p(labels), ldt, B, V, M, XENT_EPS, float(dscale), _p(up),
                                               _p(Zgi.buf), kb(Ng), _p(ZgTi.buf), kb(B), _p(Zei.buf), kb(Ne), _p(ZeTi.buf), kb(B),
                                               _p(part), _stream()))
+    kept = getattr(ctx, "images", None) or {}                                   # written by the forward's image passes
+    ctx.images = None
     dx = None
     if ctx.needs_input_grad[0]:
-        dx, = gemm_b1_grouped([dict(A=Zgi, B=bf16_image(Wg.data))])           # W [D, N] as [D rows, K = N]
-        gemm_b1_grouped([dict(A=Zei, B=bf16_image(We.data), out=dx, beta=1.0)])
+        dx, = gemm_b1_grouped([dict(A=Zgi, B=kept.get("Wg") or bf16_image(Wg.data))])           # W [D, N] as [D rows, K = N]
+        gemm_b1_grouped([dict(A=Zei, B=kept.get("We") or bf16_image(We.data), out=dx, beta=1.0)])
     del Zgi, Zei
     if Wg.grad is not None and We.grad is not None:
-        xT = bf16_image(x, transpose=True)                                      # [D rows, K = B]
+        xT = kept.get("xT") or bf16_image(x, transpose=True)                    # [D rows, K = B]
         overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
         pg = dict(A=xT, B=ZgTi, out=Wg.grad, beta=Wg.grad_beta())
         pe = dict(A=xT, B=ZeTi, out=We.grad, beta=We.grad_beta())
@@ -1063,10 +1066,16 @@ def _bf16_ok(x2):
     return x2.shape[0] % 2 == 0 and x2.shape[1] % 2 == 0 and x2.shape[0] >= BF16_MIN_ROWS
 
 
-def _moe_logits(x2, Wg, We, be, bf16):
+def _moe_logits(x2, Wg, We, be, bf16, keep=None):
     """Zg = x.Wg, Ze = x.We + be as ONE persistent launch; bf16: operands are bf16 copies (x, Wg^T, We^T: both sides
-    K-contiguous), accumulation and outputs stay fp32."""
+    K-contiguous), accumulation and outputs stay fp32.  keep (a dict, training only): the image pass of x / Wg / We writes the
+    OTHER orientation too -- what the backward products read (x^T for dW, W for dx) -- so each tensor is read once per step."""
     if bf16 and _bf16_ok(x2) and _b1_ok(x2.shape[0], Wg.data.shape[1], x2.shape[1]):
+        if keep is not None and _b1_ok(x2.shape[1], Wg.data.shape[1], x2.shape[0]):
+            xi, keep["xT"] = bf16_image(x2, both=True)
+            keep["Wg"], WgT = bf16_image(Wg.data, both=True)
+            keep["We"], WeT = bf16_image(We.data, both=True)
+            return gemm_b1_grouped([dict(A=xi, B=WgT), dict(A=xi, B=WeT, bias=be.data)])
         xi = bf16_image(x2)                                  # [B rows, K = D]; W^T as [N rows, K = D]: the transposing image pass
         return gemm_b1_grouped([dict(A=xi, B=bf16_image(Wg.data, transpose=True)),
                                 dict(A=xi, B=bf16_image(We.data, transpose=True), bias=be.data)])
@@ -1084,7 +1093,8 @@ class _MoeHeadXent(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, token, Wg, We, be, labels, V, M, bf16):
         x2 = _f32c(x)
-        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16)
+        ctx.images = {} if (bf16 and FUSED_MIX_BF16 and M == 2 and ctx.needs_input_grad[1]) else None
+        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images)
         ctx.bf16 = bf16
         B = x2.shape[0]
         lab, ldt = _labels_arg(labels)
