@@ -47,114 +47,135 @@ __global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __re
                                                                float* __restrict__ be_part) {
   __shared__ __attribute__((aligned(16))) unsigned short tile[(GC + EC) * PITCH];   // 320 x 72 x 2 B = 45 KiB
   const int tid = threadIdx.x;
-  const int r = tid >> 2, lq = tid & 3;
-  const int64_t b = (int64_t)blockIdx.y * TR + r;
-  const int64_t l0 = (int64_t)blockIdx.x * TL + lq * 16;
+  // A thread owns (row, 4 consecutive labels) of four 16-row groups: 12 gate + 8 expert logits = 3 + 2 float4 whose lane stride
+  // (48 / 32 bytes) keeps every cache line a wave instruction touches inside the next two instructions -- with 16 labels per
+  // thread (192-byte lane stride) a line was revisited over 8 instructions and 64 lines per wave: the 2 x 4 waves of a CU ran
+  // out of L1 and the read side alone took 273 of the kernel's 530 us (tools/mixb_bench.py).
+  const int q = tid & 15, rs = tid >> 4;                              // label quad of the 64-label tile, row of a 16-row group
+  const int64_t l0 = (int64_t)blockIdx.x * TL + q * 4;
+  const int64_t b0 = (int64_t)blockIdx.y * TR + rs;
   if (MODE == 1 && up_dev) dscale *= up_dev[0];
-  unsigned short og[48], oe[32];
+  float g[4][12], e[4][8], dd[4][4];
 #pragma unroll
-  for (int k = 0; k < 48; ++k) og[k] = 0;
+  for (int it = 0; it < 4; ++it) {
+    const int64_t b = b0 + it * 16;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) oe[k] = 0;
-  if (b < B) {
+    for (int k = 0; k < 12; ++k) g[it][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[it][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dd[it][k] = 0.f;
+    if (b >= B || l0 >= V) continue;
     const float* zg = Zg + b * V * 3 + l0 * 3;
     const float* ze = Ze + b * V * 2 + l0 * 2;
-    const bool full = l0 + 16 <= V && ((reinterpret_cast<uintptr_t>(zg) | reinterpret_cast<uintptr_t>(ze)) & 15) == 0;
-    float g[48], e[32];
-    if (full) {
+    const bool full = l0 + 4 <= V;
+    if (full && ((reinterpret_cast<uintptr_t>(zg) | reinterpret_cast<uintptr_t>(ze)) & 15) == 0) {
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
+      for (int k = 0; k < 3; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(zg + 4 * k);
-        g[4 * k] = v.x; g[4 * k + 1] = v.y; g[4 * k + 2] = v.z; g[4 * k + 3] = v.w;
+        g[it][4 * k] = v.x; g[it][4 * k + 1] = v.y; g[it][4 * k + 2] = v.z; g[it][4 * k + 3] = v.w;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 2; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(ze + 4 * k);
-        e[4 * k] = v.x; e[4 * k + 1] = v.y; e[4 * k + 2] = v.z; e[4 * k + 3] = v.w;
+        e[it][4 * k] = v.x; e[it][4 * k + 1] = v.y; e[it][4 * k + 2] = v.z; e[it][4 * k + 3] = v.w;
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 48; ++k) g[k] = (l0 + k / 3 < V) ? zg[k] : 0.f;
+      for (int k = 0; k < 12; ++k) if (l0 + k / 3 < V) g[it][k] = zg[k];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) e[k] = (l0 + k / 2 < V) ? ze[k] : 0.f;
+      for (int k = 0; k < 8; ++k) if (l0 + k / 2 < V) e[it][k] = ze[k];
     }
+    if (MODE == 0) {
+      const float* d = dp + b * V + l0;
+      if (full && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(d);
+        dd[it][0] = v.x; dd[it][1] = v.y; dd[it][2] = v.z; dd[it][3] = v.w;
+      } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (l0 + j < V) {
-        const float g0 = g[3 * j], g1 = g[3 * j + 1], g2 = g[3 * j + 2];
-        const float mx = fmaxf(g0, fmaxf(g1, g2));
-        const float x0 = expf(g0 - mx), x1 = expf(g1 - mx), x2 = expf(g2 - mx);
-        const float inv = 1.0f / (x0 + x1 + x2);
-        const float s0 = x0 * inv, s1 = x1 * inv, s2 = x2 * inv;
-        const float e0 = 1.0f / (1.0f + expf(-e[2 * j])), e1 = 1.0f / (1.0f + expf(-e[2 * j + 1]));
-        const float pv = s0 * e0 + s1 * e1;
-        float d;
-        if (MODE == 0) {
-          d = dp[b * V + l0 + j];
-        } else {
-          const float yv = (float)y[b * V + l0 + j];
-          d = -(yv / (pv + eps) - (1.0f - yv) / (1.0f - pv + eps)) * dscale;
-        }
-        og[3 * j] = f2bf(d * s0 * (e0 - pv));
-        og[3 * j + 1] = f2bf(d * s1 * (e1 - pv));
-        og[3 * j + 2] = f2bf(d * s2 * (0.f - pv));
-        oe[2 * j] = f2bf(d * s0 * e0 * (1.0f - e0));
-        oe[2 * j + 1] = f2bf(d * s1 * e1 * (1.0f - e1));
-      }
-    }
-    // plain bf16 rows
-    if (IMG) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int64_t c = l0 * 3 + 8 * k;
-        if (c < gb_ld * 16) {
-          uint4 v;
-          v.x = og[8 * k] | ((unsigned)og[8 * k + 1] << 16); v.y = og[8 * k + 2] | ((unsigned)og[8 * k + 3] << 16);
-          v.z = og[8 * k + 4] | ((unsigned)og[8 * k + 5] << 16); v.w = og[8 * k + 6] | ((unsigned)og[8 * k + 7] << 16);
-          *reinterpret_cast<uint4*>(gb + img_piece(b, c, gb_ld)) = v;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t c = l0 * 2 + 8 * k;
-        if (c < eb_ld * 16) {
-          uint4 v;
-          v.x = oe[8 * k] | ((unsigned)oe[8 * k + 1] << 16); v.y = oe[8 * k + 2] | ((unsigned)oe[8 * k + 3] << 16);
-          v.z = oe[8 * k + 4] | ((unsigned)oe[8 * k + 5] << 16); v.w = oe[8 * k + 6] | ((unsigned)oe[8 * k + 7] << 16);
-          *reinterpret_cast<uint4*>(eb + img_piece(b, c, eb_ld)) = v;
-        }
-      }
-    }
-    unsigned short* pg = gb + b * gb_ld + l0 * 3;
-    unsigned short* pe = eb + b * eb_ld + l0 * 2;
-    if (IMG) {
-    } else if (l0 + 16 <= V && ((reinterpret_cast<uintptr_t>(pg) | reinterpret_cast<uintptr_t>(pe)) & 15) == 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        uint4 v;
-        v.x = og[8 * k] | ((unsigned)og[8 * k + 1] << 16); v.y = og[8 * k + 2] | ((unsigned)og[8 * k + 3] << 16);
-        v.z = og[8 * k + 4] | ((unsigned)og[8 * k + 5] << 16); v.w = og[8 * k + 6] | ((unsigned)og[8 * k + 7] << 16);
-        *reinterpret_cast<uint4*>(pg + 8 * k) = v;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint4 v;
-        v.x = oe[8 * k] | ((unsigned)oe[8 * k + 1] << 16); v.y = oe[8 * k + 2] | ((unsigned)oe[8 * k + 3] << 16);
-        v.z = oe[8 * k + 4] | ((unsigned)oe[8 * k + 5] << 16); v.w = oe[8 * k + 6] | ((unsigned)oe[8 * k + 7] << 16);
-        *reinterpret_cast<uint4*>(pe + 8 * k) = v;
+        for (int k = 0; k < 4; ++k) if (l0 + k < V) dd[it][k] = d[k];
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 48; ++k) if (l0 + k / 3 < V) pg[k] = og[k];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) if (l0 + k / 2 < V) pe[k] = oe[k];
+      for (int k = 0; k < 4; ++k) if (l0 + k < V) dd[it][k] = (float)y[b * V + l0 + k];
     }
   }
-  // transposed image: tile[column][row]; rows beyond B / labels beyond V hold zeros
 #pragma unroll
-  for (int k = 0; k < 48; ++k) tile[(lq * 48 + k) * PITCH + r] = og[k];
+  for (int it = 0; it < 4; ++it) {
+    const int64_t b = b0 + it * 16;
+    const int row = rs + it * 16;
+    unsigned short og[12], oe[8];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) tile[(GC + lq * 32 + k) * PITCH + r] = oe[k];
+    for (int k = 0; k < 12; ++k) og[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) oe[k] = 0;
+    if (b < B) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (l0 + j < V) {
+          const float g0 = g[it][3 * j], g1 = g[it][3 * j + 1], g2 = g[it][3 * j + 2];
+          const float mx = fmaxf(g0, fmaxf(g1, g2));
+          const float x0 = __expf(g0 - mx), x1 = __expf(g1 - mx), x2 = __expf(g2 - mx);
+          const float inv = 1.0f / (x0 + x1 + x2);
+          const float s0 = x0 * inv, s1 = x1 * inv, s2 = x2 * inv;
+          const float e0 = 1.0f / (1.0f + __expf(-e[it][2 * j])), e1 = 1.0f / (1.0f + __expf(-e[it][2 * j + 1]));
+          const float pv = s0 * e0 + s1 * e1;
+          float d;
+          if (MODE == 0) {
+            d = dd[it][j];
+          } else {
+            const float yv = dd[it][j];
+            d = -(yv / (pv + eps) - (1.0f - yv) / (1.0f - pv + eps)) * dscale;
+          }
+          og[3 * j] = f2bf(d * s0 * (e0 - pv));
+          og[3 * j + 1] = f2bf(d * s1 * (e1 - pv));
+          og[3 * j + 2] = f2bf(d * s2 * (0.f - pv));
+          oe[2 * j] = f2bf(d * s0 * e0 * (1.0f - e0));
+          oe[2 * j + 1] = f2bf(d * s1 * e1 * (1.0f - e1));
+        }
+      }
+    }
+    // plain outputs in 16-byte pieces of 8 columns.  Gate: a thread holds 12 columns = one and a half pieces; the even lane of
+    // a pair writes its first 8 and the piece made of its last 4 + the odd lane's first 4, the odd lane writes its last 8.
+    unsigned int w[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = og[2 * k] | ((unsigned)og[2 * k + 1] << 16);
+    const unsigned int n0 = __shfl_down(w[0], 1, 64), n1 = __shfl_down(w[1], 1, 64);     // the odd neighbour's first 4 columns
+    const bool odd = (q & 1) != 0;
+    const int64_t cg = (int64_t)blockIdx.x * GC + (odd ? q * 12 + 4 : q * 12);              // first column of this lane's first piece
+    const int64_t ce = (int64_t)blockIdx.x * EC + q * 8;
+    uint4 pg0, pg1, pe0;
+    if (odd) { pg0 = uint4{w[2], w[3], w[4], w[5]}; pg1 = pg0; }
+    else { pg0 = uint4{w[0], w[1], w[2], w[3]}; pg1 = uint4{w[4], w[5], n0, n1}; }
+    pe0.x = oe[0] | ((unsigned)oe[1] << 16); pe0.y = oe[2] | ((unsigned)oe[3] << 16);
+    pe0.z = oe[4] | ((unsigned)oe[5] << 16); pe0.w = oe[6] | ((unsigned)oe[7] << 16);
+    if (b < B) {
+      if (IMG) {
+        if (cg < gb_ld * 16) *reinterpret_cast<uint4*>(gb + img_piece(b, cg, gb_ld)) = pg0;
+        if (!odd && cg + 8 < gb_ld * 16) *reinterpret_cast<uint4*>(gb + img_piece(b, cg + 8, gb_ld)) = pg1;
+        if (ce < eb_ld * 16) *reinterpret_cast<uint4*>(eb + img_piece(b, ce, eb_ld)) = pe0;
+      } else {
+        // row-major: whole pieces where they fit into the row (columns up to the pitch are the caller's padding), else by element
+        unsigned short* rg = gb + b * gb_ld;
+        unsigned short* re = eb + b * eb_ld;
+        const bool al = ((reinterpret_cast<uintptr_t>(rg) | reinterpret_cast<uintptr_t>(re)) & 15) == 0;
+        auto put = [&](unsigned short* rowp, int64_t c, int64_t ncols, const uint4& v) {
+          if (c >= ncols) return;
+          if (al && c + 8 <= ncols) { *reinterpret_cast<uint4*>(rowp + c) = v; return; }
+          const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+          for (int k = 0; k < 8 && c + k < ncols; ++k) rowp[c + k] = (unsigned short)(u[k >> 1] >> (16 * (k & 1)));
+        };
+        put(rg, cg, V * 3, pg0);
+        if (!odd) put(rg, cg + 8, V * 3, pg1);
+        put(re, ce, V * 2, pe0);
+      }
+    }
+    // transposed image: tile[column][row]; rows beyond B / labels beyond V hold zeros
+#pragma unroll
+    for (int k = 0; k < 12; ++k) tile[(q * 12 + k) * PITCH + row] = og[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[(GC + q * 8 + k) * PITCH + row] = oe[k];
+  }
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.y * TR;
   const bool rows_full = r0 + TR <= B;
