@@ -362,13 +362,15 @@ def test_sample_frames_bit_exact_vs_oracle(dev, dtype):
     assert np.array_equal(out.cpu().numpy(), np.take_along_axis(x, ridx[:, :, None].astype(np.int64), axis=1))
 
 
+@pytest.mark.parametrize("shape", [(5, 6, 70), (3, 8, 72), (2, 19, 64), (4, 1, 12), (2, 30, 33)])
 @pytest.mark.parametrize("method", ["max", "average"])
-def test_frame_pool_with_ties(dev, method):
-    """FramePooling over relu6-clamped activations (ties at 0 and 6 everywhere): forward and the tie-splitting gradient vs torch."""
+def test_frame_pool_with_ties(dev, method, shape):
+    """FramePooling over relu6-clamped activations (ties at 0 and 6 everywhere): forward and the tie-splitting gradient vs torch;
+    scalar and 16-byte column paths (C % 4), S below / above the 16 frames the backward keeps in registers, S = 1."""
     rs = np.random.RandomState(2)
-    x = np.clip(rs.randn(5, 6, 70) * 4 + 3, 0, 6).astype(np.float32)
+    x = np.clip(rs.randn(*shape) * 4 + 3, 0, 6).astype(np.float32)
     xd = torch.from_numpy(x).to(dev).requires_grad_(True)
-    w = torch.from_numpy(rs.randn(5, 70).astype(np.float32))
+    w = torch.from_numpy(rs.randn(shape[0], shape[2]).astype(np.float32))
     out = ops.frame_pool(xd, method)
     (out * w.to(dev)).sum().backward()
     xr = torch.from_numpy(x).double().requires_grad_(True)

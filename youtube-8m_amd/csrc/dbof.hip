@@ -45,37 +45,85 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const T* __restrict_
 }
 
 // ---- frame pooling -----------------------------------------------------------------------------------------------------------
-// x [B,S,C] -> out [B,C]; one thread per (b, c), lanes along c (coalesced)
+// x [B,S,C] -> out [B,C]; a thread owns VEC consecutive c of one b (lanes along c: coalesced 16-byte accesses for VEC = 4); the S
+// values of a column are fetched eight at a time before they are reduced (one 4-byte load in flight per thread ran the max over
+// the 8 attention copies of BASELINE configs[4] at 1.6 TB/s), and the backward keeps up to 16 of them in registers so that x is
+// read once (ties share the gradient, as tf.reduce_max's gradient does).
+template <int VEC> struct PoolVec;
+template <> struct PoolVec<4> { using T = float4; };
+template <> struct PoolVec<1> { using T = float; };
+__device__ __forceinline__ float4 vmax(float4 a, float4 b) { return float4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vscale(float4 a, float k) { return float4{a.x * k, a.y * k, a.z * k, a.w * k}; }
+__device__ __forceinline__ float vscale(float a, float k) { return a * k; }
+__device__ __forceinline__ float4 vdiv(float4 a, float k) { return float4{a.x / k, a.y / k, a.z / k, a.w / k}; }
+__device__ __forceinline__ float vdiv(float a, float k) { return a / k; }
+__device__ __forceinline__ float4 veq(float4 a, float4 m) { return float4{a.x == m.x ? 1.f : 0.f, a.y == m.y ? 1.f : 0.f, a.z == m.z ? 1.f : 0.f, a.w == m.w ? 1.f : 0.f}; }
+__device__ __forceinline__ float veq(float a, float m) { return a == m ? 1.f : 0.f; }
+__device__ __forceinline__ float4 vshare(float4 g, float4 t) { return float4{g.x / fmaxf(t.x, 1.f), g.y / fmaxf(t.y, 1.f), g.z / fmaxf(t.z, 1.f), g.w / fmaxf(t.w, 1.f)}; }
+__device__ __forceinline__ float vshare(float g, float t) { return g / fmaxf(t, 1.f); }
+__device__ __forceinline__ float4 vmul(float4 a, float4 b) { return float4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ void vzero(float4& a) { a = float4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void vzero(float& a) { a = 0.f; }
+
+template <int VEC>
 __global__ __launch_bounds__(256) void frame_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int S, int C, int mode) {
-  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  using T = typename PoolVec<VEC>::T;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC, b = blockIdx.y;
   if (c >= C) return;
-  const float* p = x + (long long)b * S * C + c;
-  float acc = mode == 0 ? p[0] : 0.f;
-  if (mode == 0) {
-    for (int s = 1; s < S; ++s) acc = fmaxf(acc, p[(long long)s * C]);
-  } else {
-    for (int s = 0; s < S; ++s) acc += p[(long long)s * C];
-    acc /= (float)S;
+  const T* p = reinterpret_cast<const T*>(x + (long long)b * S * C + c);
+  const long long cs = C / VEC;                                       // elements of T between frames
+  T acc = p[0];                                                       // max: seed; average: first term (added in frame order)
+  for (int s0 = 1; s0 < S; s0 += 8) {
+    T v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = s0 + i < S ? p[(long long)(s0 + i) * cs] : acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (s0 + i < S) acc = mode == 0 ? vmax(acc, v[i]) : vadd(acc, v[i]);
   }
-  out[(long long)b * C + c] = acc;
+  if (mode != 0) acc = vdiv(acc, (float)S);
+  *reinterpret_cast<T*>(out + (long long)b * C + c) = acc;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void frame_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ out,
                                                              const float* __restrict__ dy, float* __restrict__ dx, int S, int C, int mode) {
-  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  using T = typename PoolVec<VEC>::T;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC, b = blockIdx.y;
   if (c >= C) return;
-  const long long base = (long long)b * S * C + c;
-  const float g = dy[(long long)b * C + c];
-  if (mode == 0) {
-    const float m = out[(long long)b * C + c];
-    int ties = 0;
-    for (int s = 0; s < S; ++s) ties += x[base + (long long)s * C] == m ? 1 : 0;
-    const float share = g / (float)(ties > 0 ? ties : 1);
-    for (int s = 0; s < S; ++s) dx[base + (long long)s * C] = x[base + (long long)s * C] == m ? share : 0.f;
-  } else {
-    const float share = g / (float)S;
-    for (int s = 0; s < S; ++s) dx[base + (long long)s * C] = share;
+  const long long base = (long long)b * S * C + c, cs = C / VEC;
+  const T g = *reinterpret_cast<const T*>(dy + (long long)b * C + c);
+  const T* xp = reinterpret_cast<const T*>(x + base);
+  T* dp = reinterpret_cast<T*>(dx + base);
+  if (mode != 0) {
+    const T share = vdiv(g, (float)S);
+    for (int s = 0; s < S; ++s) dp[(long long)s * cs] = share;
+    return;
   }
+  const T m = *reinterpret_cast<const T*>(out + (long long)b * C + c);
+  T ties;
+  vzero(ties);
+  if (S <= 16) {
+    T v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < S) v[i] = xp[(long long)i * cs];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < S) { v[i] = veq(v[i], m); ties = vadd(ties, v[i]); }
+    const T share = vshare(g, ties);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < S) dp[(long long)i * cs] = vmul(v[i], share);
+    return;
+  }
+  for (int s = 0; s < S; ++s) ties = vadd(ties, veq(xp[(long long)s * cs], m));
+  const T share = vshare(g, ties);
+  for (int s = 0; s < S; ++s) dp[(long long)s * cs] = vmul(veq(xp[(long long)s * cs], m), share);
 }
 
 // ---- batch norm -----------------------------------------------------------------------------------------------------------
@@ -216,7 +264,10 @@ extern "C" int yt8m_frame_pool_fwd(const float* x, int64_t B, int64_t S, int64_t
   YT8M_REQUIRE(x && out, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(frame_pool_fwd_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, x, out, (int)S, (int)C, mode);
+  if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+    hipLaunchKernelGGL(frame_pool_fwd_kernel<4>, dim3((unsigned)((C / 4 + 255) / 256), (unsigned)B), dim3(256), 0, s, x, out, (int)S, (int)C, mode);
+  else
+    hipLaunchKernelGGL(frame_pool_fwd_kernel<1>, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, x, out, (int)S, (int)C, mode);
   return launch_status("frame_pool_fwd_kernel");
 }
 
@@ -228,8 +279,13 @@ extern "C" int yt8m_frame_pool_bwd(const float* x, const float* out, const float
   YT8M_REQUIRE(x && out && dy && dx, YT8M_E_BADARG, "null operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(frame_pool_bwd_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, x, out, dy, dx, (int)S,
-                     (int)C, mode);
+  if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dy) |
+                         reinterpret_cast<uintptr_t>(dx)) & 15) == 0)
+    hipLaunchKernelGGL(frame_pool_bwd_kernel<4>, dim3((unsigned)((C / 4 + 255) / 256), (unsigned)B), dim3(256), 0, s, x, out, dy, dx, (int)S,
+                       (int)C, mode);
+  else
+    hipLaunchKernelGGL(frame_pool_bwd_kernel<1>, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, x, out, dy, dx, (int)S,
+                       (int)C, mode);
   return launch_status("frame_pool_bwd_kernel");
 }
 
