@@ -1,5 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$(pwd); O=$R/gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_round3.py tests/test_gpu_round2.py tests/test_gpu_models.py tests/test_gpu_kernels.py -m gpu -q --timeout=600 -p no:cacheprovider -k "u8 or composite or config5 or attention or skinny" 2>&1 | tail -3
-for i in 1 2; do YT8M_NO_PROF=1 timeout 300 python tools/model_bench.py config5_bf16_b1024 2>&1 | grep "B=" | cut -c1-100; done
+rm -rf $O/prof_c5; mkdir -p $O/prof_c5
+cd /tmp && YT8M_NO_PROF=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c5 --output-format csv -- python $R/tools/model_bench.py config5_bf16_b1024 2>&1 | grep "B=" | cut -c1-200
+find $O/prof_c5 -name "*kernel_trace.csv" -delete
