@@ -556,6 +556,16 @@ int yt8m_vlad_finish_fwd(const float* agg, const float* a, const float* centres,
 int yt8m_vlad_finish_bwd(const float* agg, const float* n_in, const float* centres, const float* dvlad, float* dagg,
                          float* dn, float* dcentres, float dcentres_beta, int64_t B, int64_t K, int64_t D, float eps,
                          yt8m_stream_t stream);
+/* The same two passes with q_out [B,K] = ||vlad[b,k,:]||^2 (1 unless the row norm was clamped) and its gradient dq (may be NULL):
+ * the l2-normalisation of the whole [K D] descriptor that follows then needs no pass over [B,K,D] -- its
+ * scale rsqrt(max(sum_k q, eps)) is applied to the [B, hidden] output of the next layer.  D % 4 == 0, D <= 2048, 16-byte aligned
+ * operands (yt8m_vlad_finish_q_supported). */
+int yt8m_vlad_finish_q_supported(int64_t D);
+int yt8m_vlad_finish_q_fwd(const float* agg, const float* a, const float* centres, float* vlad, float* n_out, float* q_out, int64_t B,
+                           int64_t F, int64_t K, int64_t D, float eps, yt8m_stream_t stream);
+int yt8m_vlad_finish_q_bwd(const float* agg, const float* n_in, const float* centres, const float* dvlad, const float* dq, float* dagg,
+                           float* dn, float* dcentres, float dcentres_beta, int64_t B, int64_t K, int64_t D, float eps,
+                           yt8m_stream_t stream);
 
 /* ---- fused NetVLAD pooling on RAW uint8 frames (SURVEY.md section 8b "yt8m_netvlad_fwd/bwd", Appendix B) -----------
  * Replaces, for the NetVLAD plugin, the chain  Dequantize (W/utils.py:23-38) -> zero padding (W/readers.py:178-187) ->

@@ -673,3 +673,54 @@ def test_composite_attention_branch_never_materialises_float_frames(dev, flags, 
     for k in gf:
         scale = float(gf[k].abs().max())               # the logit bias gradient is zero up to rounding (softmax over the frames)
         assert float((gu[k] - gf[k]).abs().max()) < 5e-4 * scale + 1e-7, k
+
+
+# ---- NetVLAD tail: descriptor-wide l2-normalisation as a per-video scale of the hidden layer (no pass over [B,K,D]) ------------
+@pytest.mark.parametrize("B,F,K,D", [(5, 9, 8, 64), (3, 7, 64, 1152), (2, 5, 4, 260)])
+def test_vlad_finish_q_scale_equals_l2_normalize_long_form(dev, B, F, K, D):
+    """vlad, q = vlad_finish(..., want_q=True); (vlad . W) * rsqrt(max(sum_k q, eps)) against float64 autograd of
+    l2_normalize(intra_normalise(agg - n c)) . W: value and the gradients w.r.t. agg, the assignments, the centres and W --
+    including a video without frames (all rows clamped at zero) and a cluster whose residual norm is below sqrt(eps) (the one case
+    where the gradient through q is not zero)."""
+    from yt8m_amd.variables import xavier_uniform
+    import yt8m_amd.ops as ops
+    rs = np.random.RandomState(B * 100 + K)
+    Hh = 16
+    g = reset_default_graph(device=dev, seed=0)
+    g.begin_step()
+    cen = g.get_variable("c", (K, D), xavier_uniform)
+    W = g.get_variable("w", (K * D, Hh), xavier_uniform)
+    g.finalize()
+    cnp = (rs.randn(K, D) * 0.3).astype(np.float32)
+    Wnp = (rs.randn(K * D, Hh) / np.sqrt(K * D)).astype(np.float32)
+    cen.data.copy_(torch.from_numpy(cnp).to(dev))
+    W.data.copy_(torch.from_numpy(Wnp).to(dev).view(W.data.shape))
+    a = rs.rand(B, F, K).astype(np.float32)
+    a[0] = 0.0                                                        # a video without frames: n = 0, agg = 0 -> every row clamped
+    agg = rs.randn(B, K, D).astype(np.float32)
+    agg[0] = 0.0
+    cnp[1] = 0.0                                                      # (exact residual: a centre at the origin)
+    cen.data.copy_(torch.from_numpy(cnp).to(dev))
+    agg[1, 1] = (rs.randn(D) * 1e-8).astype(np.float32)               # residual norm ~ 1e-8 * sqrt(D) < sqrt(eps) = 1e-6
+    wout = rs.randn(B, Hh).astype(np.float32)
+    g.begin_step()
+    ad, aggd = torch.from_numpy(a).to(dev).requires_grad_(True), torch.from_numpy(agg).to(dev).requires_grad_(True)
+    vlad, q = seq_ops.vlad_finish(aggd, ad, cen, want_q=True)
+    scale = torch.rsqrt(torch.clamp(q.sum(dim=1), min=1e-12)).unsqueeze(1)
+    h = ops.linear(vlad.reshape(B, K * D), W, None) * scale
+    (h * torch.from_numpy(wout).to(dev)).sum().backward()
+    # float64 long form
+    a64, agg64 = T64(a).requires_grad_(True), T64(agg).requires_grad_(True)
+    c64, W64 = T64(cnp).requires_grad_(True), T64(Wnp).requires_grad_(True)
+    pre = agg64 - a64.sum(1).unsqueeze(2) * c64.unsqueeze(0)
+    u = pre * torch.rsqrt(torch.clamp((pre * pre).sum(2, keepdim=True), min=1e-12))
+    v = u.reshape(B, K * D)
+    v = v * torch.rsqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))
+    h64 = v @ W64
+    (h64 * T64(wout)).sum().backward()
+    tol = lambda ref: 2e-5 * max(1e-6, float(ref.abs().max()))
+    assert float((h.detach().cpu().double() - h64.detach()).abs().max()) < tol(h64.detach())
+    assert float((aggd.grad.cpu().double() - agg64.grad).abs().max()) < tol(agg64.grad)
+    assert float((ad.grad.cpu().double() - a64.grad).abs().max()) < tol(a64.grad)
+    assert float((cen.grad.cpu().double().view(K, D) - c64.grad).abs().max()) < tol(c64.grad)
+    assert float((W.grad.cpu().double().view(K * D, Hh) - W64.grad).abs().max()) < tol(W64.grad)

@@ -162,6 +162,9 @@ SIGNATURES = {
                                     P, c_int64, P]),
     "yt8m_vlad_finish_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_vlad_finish_bwd": (c_int, [P, P, P, P, P, P, P, c_float, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_vlad_finish_q_supported": (c_int, [c_int64]),
+    "yt8m_vlad_finish_q_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),
+    "yt8m_vlad_finish_q_bwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int64, c_int64, c_int64, c_float, P]),
     "yt8m_crc32c": (ctypes.c_uint32, [P, c_int64]),
     "yt8m_crc32c_masked": (ctypes.c_uint32, [P, c_int64]),
     "yt8m_prefetch_open": (c_int, [ctypes.POINTER(ctypes.c_char_p), c_int, c_int, ctypes.POINTER(ctypes.c_char_p),

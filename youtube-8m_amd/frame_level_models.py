@@ -414,18 +414,29 @@ class NetVLADModel(models.BaseModel):
         Wc = g.get_variable("netvlad/cluster_weights", (D, K), random_normal(1 / math.sqrt(D)))
         bc = g.get_variable("netvlad/cluster_biases", (K,), zeros)
         centres = g.get_variable("netvlad/centres", (K, D), random_normal(1 / math.sqrt(D)))
+        # The descriptor-wide l2-normalisation needs no pass over [B,K,D]: the intra-normalised rows have the squared norms q
+        # (1 unless clamped) the finishing kernel hands out, so v = vlad * s with s = rsqrt(max(sum_k q, eps)) per video, and
+        # v . W = s * (vlad . W): the scale goes onto the [B, hidden] output (same function and gradients as l2_normalize first).
+        want_q = seq_ops.vlad_q_supported(D)
         if model_input.dtype == torch.uint8 and seq_ops.netvlad_fused_supported(model_input, K):
             nsplit = 1 if FLAGS.compute_dtype == "bfloat16" else 2        # f16 operands vs f16 hi+lo (fp32-class)
-            vlad = seq_ops.netvlad_pool_u8(model_input, num_frames, Wc, bc, centres, nsplit)
+            vlad = seq_ops.netvlad_pool_u8(model_input, num_frames, Wc, bc, centres, nsplit, want_q=want_q)
         else:
             if model_input.dtype == torch.uint8:                          # shapes outside the fused kernels' cover
                 model_input = ops.dequant_l2norm(model_input, num_frames)
             s = ops.linear(model_input, Wc, bc)                           # [B,F,K] assignment logits
             a = seq_ops.masked_softmax_rows(s, num_frames)                # softmax_k * mask
             agg = seq_ops.pool_tn(a, model_input)                         # [B,K,D] = a^T x per video
-            vlad = seq_ops.vlad_finish(agg, a, centres)                   # (agg - n*c), intra-normalised per cluster
-        v = ops.l2_normalize(vlad.reshape(B, K * D))
-        h = video_level_models.fully_connected(v, Hfc, "netvlad/hidden")
+            vlad = seq_ops.vlad_finish(agg, a, centres, want_q=want_q)    # (agg - n*c), intra-normalised per cluster
+        if want_q:
+            vlad, qn = vlad
+            scale = torch.rsqrt(torch.clamp(qn.sum(dim=1), min=1e-12)).unsqueeze(1)          # [B,1]; eps of ops.l2_normalize
+            Wh = g.get_variable("netvlad/hidden/weights", (K * D, Hfc), video_level_models.xavier_uniform)
+            bh = g.get_variable("netvlad/hidden/biases", (Hfc,), video_level_models.zeros)
+            h = ops.linear(vlad.reshape(B, K * D), Wh, None) * scale + ops.as_tensor(bh)
+        else:
+            v = ops.l2_normalize(vlad.reshape(B, K * D))
+            h = video_level_models.fully_connected(v, Hfc, "netvlad/hidden")
         if gating:
             gate = video_level_models.fully_connected(h, Hfc, "netvlad/gating", activation="sigmoid")
             h = h * gate

@@ -1099,43 +1099,68 @@ def attention_logits_u8(q, rs, mean_x, W, b):
     return _AttnLogitsU8.apply(_token(W._graph), W, b, q, rs, mean_x)
 
 
+def vlad_q_supported(D):
+    """The intra-normalisation can hand out q = ||vlad[b,k,:]||^2 (csrc/netvlad.hip, register-resident kernels)."""
+    return bool(_lib.lib().yt8m_vlad_finish_q_supported(int(D)))
+
+
+def _finish_fwd(agg, a, n, centres, eps, want_q):
+    B, K, D = agg.shape
+    vlad = torch.empty_like(agg)
+    q = torch.empty((B, K), dtype=torch.float32, device=agg.device) if want_q else None
+    F = a.shape[1] if a is not None else 0
+    if want_q:
+        _lib.check(_lib.lib().yt8m_vlad_finish_q_fwd(_p(agg), _p(a), _p(centres.data), _p(vlad), _p(n), _p(q), B, F, K, D, eps, _stream()))
+    else:
+        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), _p(a), _p(centres.data), _p(vlad), _p(n), B, F, K, D, eps, _stream()))
+    return vlad, q
+
+
+def _finish_bwd(agg, n, c, dvlad, dq, eps):
+    B, K, D = agg.shape
+    dagg = torch.empty_like(agg)
+    dn = torch.empty((B, K), dtype=torch.float32, device=agg.device)
+    dc = c.grad if c.grad is not None else None
+    beta = c.grad_beta() if dc is not None else 0.0
+    if dq is not None:
+        _lib.check(_lib.lib().yt8m_vlad_finish_q_bwd(_p(agg), _p(n), _p(c.data), _p(dvlad), _p(dq), _p(dagg), _p(dn), _p(dc), beta, B, K,
+                                                     D, eps, _stream()))
+    else:
+        _lib.check(_lib.lib().yt8m_vlad_finish_bwd(_p(agg), _p(n), _p(c.data), _p(dvlad), _p(dagg), _p(dn), _p(dc), beta, B, K, D, eps,
+                                                   _stream()))
+    if dc is not None:
+        c.grad_done()
+    return dagg, dn
+
+
 class _VladFinish(torch.autograd.Function):
     """vlad[b,k,:] = l2norm_D(agg[b,k,:] - (sum_f a[b,f,k]) * c[k,:])   (residual aggregation +
-    intra-normalisation in one pass, yt8m_vlad_finish_fwd/bwd); c is a Variable."""
+    intra-normalisation in one pass, yt8m_vlad_finish_fwd/bwd); c is a Variable.  want_q: also q [B,K] = ||vlad[b,k,:]||^2
+    (differentiable: its gradient reaches the clamped rows only), for the caller's descriptor-wide l2-normalisation."""
 
     @staticmethod
-    def forward(ctx, agg, a, token, centres, eps):
+    def forward(ctx, agg, a, token, centres, eps, want_q):
         agg, a = _f32c(agg), _f32c(a)
         _dev(agg, a)
         B, K, D = agg.shape
-        F = a.shape[1]
-        vlad = torch.empty_like(agg)
         n = torch.empty((B, K), dtype=torch.float32, device=agg.device)
-        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), _p(a), _p(centres.data), _p(vlad), _p(n), B, F, K, D, eps, _stream()))
+        vlad, q = _finish_fwd(agg, a, n, centres, eps, want_q)
         ctx.save_for_backward(agg, n)
-        ctx.centres, ctx.F, ctx.eps = centres, F, eps
-        return vlad
+        ctx.centres, ctx.F, ctx.eps, ctx.want_q = centres, a.shape[1], eps, want_q
+        return (vlad, q) if want_q else vlad
 
     @staticmethod
-    def backward(ctx, dvlad):
+    def backward(ctx, dvlad, dq=None):
         agg, n = ctx.saved_tensors
-        c = ctx.centres
-        dvlad = _f32c(dvlad)
-        B, K, D = agg.shape
-        dagg = torch.empty_like(agg)
-        dn = torch.empty((B, K), dtype=torch.float32, device=agg.device)
-        dc = c.grad if c.grad is not None else None
-        beta = c.grad_beta() if dc is not None else 0.0
-        _lib.check(_lib.lib().yt8m_vlad_finish_bwd(_p(agg), _p(n), _p(c.data), _p(dvlad), _p(dagg), _p(dn), _p(dc), beta, B, K, D,
-                                                   ctx.eps, _stream()))
-        if dc is not None:
-            c.grad_done()
+        if dvlad is None:
+            dvlad = torch.zeros_like(agg)
+        dagg, dn = _finish_bwd(agg, n, ctx.centres, _f32c(dvlad), None if dq is None else _f32c(dq), ctx.eps)
         da = dn.unsqueeze(1).expand(-1, ctx.F, -1) if ctx.needs_input_grad[1] else None   # broadcast view, no copy
-        return dagg, da, None, None, None
+        return dagg, da, None, None, None, None
 
 
-def vlad_finish(agg, a, centres, eps=1e-12):
-    return _VladFinish.apply(agg, a, _token(centres._graph), centres, eps)
+def vlad_finish(agg, a, centres, eps=1e-12, want_q=False):
+    return _VladFinish.apply(agg, a, _token(centres._graph), centres, eps, bool(want_q))
 
 
 # ---- fused NetVLAD pooling on raw uint8 frames (csrc/netvlad_fused.hip) ---------------------------------------------
@@ -1186,43 +1211,34 @@ def netvlad_bwd_u8(q, num_frames, cT, dagg, dn, dWc, dWc_beta, dbc, dbc_beta, ns
 
 class _NetVladPoolU8(torch.autograd.Function):
     """uint8 frames -> intra-normalised VLAD descriptor [B,K,D], the dequantise + l2-normalise of
-    the input pipeline folded into the two GEMMs; backward writes dW_c, db_c, dcentres into the gradient arena."""
+    the input pipeline folded into the two GEMMs; backward writes dW_c, db_c, dcentres into the gradient arena.  want_q: as
+    _VladFinish."""
 
     @staticmethod
-    def forward(ctx, q, num_frames, token, Wc, bc, centres, nsplit, eps):
+    def forward(ctx, q, num_frames, token, Wc, bc, centres, nsplit, eps, want_q):
         q = q.contiguous()
         cT, n, agg = netvlad_fwd_u8(q, num_frames, Wc.data, bc.data, nsplit)
-        B, K, D = agg.shape
-        vlad = torch.empty_like(agg)
-        _lib.check(_lib.lib().yt8m_vlad_finish_fwd(_p(agg), None, _p(centres.data), _p(vlad), _p(n), B, q.shape[1], K, D, eps,
-                                                   _stream()))
+        vlad, qn = _finish_fwd(agg, None, n, centres, eps, want_q)
         ctx.saved = (q, num_frames, cT, agg, n)
         ctx.vars = (Wc, bc, centres)
         ctx.cfg = (nsplit, eps)
-        return vlad
+        return (vlad, qn) if want_q else vlad
 
     @staticmethod
-    def backward(ctx, dvlad):
+    def backward(ctx, dvlad, dq=None):
         q, num_frames, cT, agg, n = ctx.saved
         Wc, bc, c = ctx.vars
         nsplit, eps = ctx.cfg
         ctx.saved = None
-        dvlad = _f32c(dvlad)
-        B, K, D = agg.shape
-        dagg = torch.empty_like(agg)
-        dn = torch.empty((B, K), dtype=torch.float32, device=agg.device)
-        dc = c.grad if c.grad is not None else None
-        beta = c.grad_beta() if dc is not None else 0.0
-        _lib.check(_lib.lib().yt8m_vlad_finish_bwd(_p(agg), _p(n), _p(c.data), _p(dvlad), _p(dagg), _p(dn), _p(dc), beta, B, K, D,
-                                                   eps, _stream()))
-        if dc is not None:
-            c.grad_done()
+        if dvlad is None:
+            dvlad = torch.zeros_like(agg)
+        dagg, dn = _finish_bwd(agg, n, c, _f32c(dvlad), None if dq is None else _f32c(dq), eps)
         if Wc.grad is not None and bc.grad is not None:
             netvlad_bwd_u8(q, num_frames, cT, dagg, dn, Wc.grad, Wc.grad_beta(), bc.grad.view(-1), bc.grad_beta(), nsplit)
             Wc.grad_done()
             bc.grad_done()
-        return (None,) * 8
+        return (None,) * 9
 
 
-def netvlad_pool_u8(q, num_frames, Wc, bc, centres, nsplit=2, eps=1e-12):
-    return _NetVladPoolU8.apply(q, num_frames, _token(Wc._graph), Wc, bc, centres, int(nsplit), eps)
+def netvlad_pool_u8(q, num_frames, Wc, bc, centres, nsplit=2, eps=1e-12, want_q=False):
+    return _NetVladPoolU8.apply(q, num_frames, _token(Wc._graph), Wc, bc, centres, int(nsplit), eps, bool(want_q))
