@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_round3.py tests/test_gpu_round2.py tests/test_gpu_models.py -m gpu -q --timeout=600 -p no:cacheprovider -k "bf16 or composite or config5 or images" 2>&1 | tail -3
-for i in 1 2; do YT8M_NO_PROF=1 timeout 300 python tools/model_bench.py config5_bf16_b1024 2>&1 | grep "B=" | cut -c1-100; done
+timeout 300 python tools/model_bench.py cnn_chain netvlad chain 2>&1 | grep "B=" | cut -c1-330

@@ -25,11 +25,16 @@ bool x3_pays(int64_t M, int64_t N, int64_t K) {
   const double fl = 2.0 * (double)M * (double)N * (double)K;
   const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
   const double eff = (double)M * (double)N / ((double)(tm * tn) * 65536.0);
-  // K parts per tile the launch will cut (csrc/gemm_x3.hip x3_launch): up to 8, up to 16 for a very long reduction -- measured: the
-  // NetVLAD hidden FC [1024 x 73728] . [73728 x 1024] 1.12 ms against 1.44 on the fp32 kernel; at K ~ 14 000 the 16-part form of an
-  // 18-tile product is slower than the fp32 kernel (MoE-chain dx shapes, tools/gemm_auto_probe.py)
-  const int64_t kparts = K >= 32768 ? 16 : 8;
-  const double occ = std::min(1.0, (double)(tm * tn) * (double)std::max<int64_t>(1, std::min<int64_t>(kparts, K / 128)) / 256.0);
+  // K parts per tile the launch will cut (csrc/gemm_x3.hip x3_launch): up to 8, up to 16 for a very long reduction.  Measured
+  // (tools/gemm_auto_probe.py, profiles/r3_plugin_step_times.txt): a product that needs more than 8 parts to fill the chip runs
+  // at ~0.7 of the nominal rate (the NetVLAD hidden FC [1024 x 73728] . [73728 x 1024]: 1.12 ms against 1.44 on the fp32 kernel --
+  // taken; the einsum-CNN weight gradients [3456 x 38400] . [38400 x 1024], 20 tiles: slower than the fp32 kernel once their split
+  // passes are paid -- not taken; its 5- and 9-tile siblings [1152 | 2304 x 38400] . [38400 x 128] run faster on the fp32 kernel's own
+  // deep K split than this estimate of it says -- kept there by the 16-tile floor); at K ~ 14 000 the 16-part form of an 18-tile
+  // product loses outright (MoE-chain dx shapes).
+  const double tiles = (double)(tm * tn);
+  double occ = std::min(1.0, tiles * (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 128)) / 256.0);
+  if (occ < 1.0 && K >= 32768 && tiles >= 16.0) occ = std::max(occ, 0.7 * std::min(1.0, tiles * 16.0 / 256.0));
   const double tx3 = fl / (X3_RATE * eff * occ) + ((double)M * K + (double)N * K) * 10.0 / SPLIT_RATE + 2e-5;
   const double t32 = fl / (F32_RATE * std::min(1.0, (double)(((M + 127) / 128) * ((N + 127) / 128)) *
                                                         (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 256)) / 768.0));
