@@ -145,5 +145,11 @@ def test_gemm_dispatch_cost_model():
     for shp in small:
         assert not ops._x3_wins([shp], False, False), shp
     assert not ops._x3_wins([(0, 4096, 1024)], False, False) and not ops._x3_wins([], False, False)
+    # few tiles, very long reduction (round 3: up to 16 K parts): the NetVLAD hidden FC goes to the bf16 pipe, the einsum-CNN
+    # weight gradients (5 / 9 / 20 tiles at K = 38 400) and the MoE-chain dx shapes (18 tiles at K ~ 14 000) stay where they measured
+    # faster (tools/gemm_auto_probe.py, profiles/r3_plugin_step_times.txt)
+    assert ops._x3_wins([(1024, 1024, 73728)], False, False)
+    for shp in [(1152, 128, 38400), (2304, 128, 38400), (1152, 1024, 38400), (512, 2304, 14148)]:
+        assert not ops._x3_wins([shp], False, False), shp
     # monotone in every dimension once it wins
     assert ops._x3_wins([(2 * 19200, 4096, 1152)], False, False) and ops._x3_wins([(19200, 2 * 4096, 1152)], False, False)
