@@ -30,7 +30,9 @@ __device__ __forceinline__ float4 load4(const uint8_t* p) { return unpack4(*rein
 // Batched form (blockIdx.y = batch, element strides bx / bw / by): the attention pooling backward dw[b] = x[b] . dC[b]^T of
 // lstm_attention_max_pooling_model.py:63, with W[k][n] = dC[b][n][k] addressed through (wsk, wsn).
 // XT = uint8_t: rs [M] (batch stride brs, may be NULL) and cs [N] = colsum(W) (batch stride bcs) complete the affine form above.
-template <int NT, typename XT = float>
+// JMAX: 4-byte words of a uint8 row a lane holds (K <= 256 JMAX): 5 covers the 1152-wide frames with 24 fewer registers than 8
+// (three waves per SIMD instead of two).
+template <int NT, typename XT = float, int JMAX = 8>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const XT* __restrict__ x, int64_t ldx, const float* __restrict__ W,
                                                          int64_t wsk, int64_t wsn, const float* __restrict__ bias,
                                                          float* __restrict__ y, int64_t ldy, int64_t M, int K, int N, float beta,
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const XT* __restrict__ 
   const int64_t r_end = r_begin + rows_per_wg < M ? r_begin + rows_per_wg : M;
   // uint8 rows: a whole row group (R rows x up to 2048 bytes = JM words per lane) is fetched one group AHEAD of the arithmetic --
   // a 4-byte load per lane carries a quarter of the float4's bytes, so the loads in flight, not the bytes, bound the stream
-  constexpr int JM = U8 ? 8 : 1;
+  constexpr int JM = U8 ? JMAX : 1;
   uint32_t nxt[R][JM];
   auto fetch = [&](int64_t r0) {
     if constexpr (U8) {
@@ -587,11 +589,18 @@ extern "C" int yt8m_skinny_fwd_u8(const uint8_t* q, int64_t ldq, const float* W,
   rows_per_wg = (rows_per_wg + 15) / 16 * 16;
   const unsigned grid = (unsigned)((M + rows_per_wg - 1) / rows_per_wg);
   if (N <= 8) {
-    static DeviceOnce once8;
-    YT8M_HIP_CHECK(once8.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t>), 144 * 1024));
-    hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t>), dim3(grid), dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, ldq, W, ldw,
-                       (int64_t)1, bias, y, ldy, M, (int)K, (int)N, beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0, rs, (int64_t)0,
-                       colsum_w, (int64_t)0);
+    static DeviceOnce once8, once85;
+    if (K <= 1280) {
+      YT8M_HIP_CHECK(once85.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t, 5>), 144 * 1024));
+      hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t, 5>), dim3(grid), dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, ldq, W, ldw,
+                         (int64_t)1, bias, y, ldy, M, (int)K, (int)N, beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0, rs, (int64_t)0,
+                         colsum_w, (int64_t)0);
+    } else {
+      YT8M_HIP_CHECK(once8.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t>), 144 * 1024));
+      hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t>), dim3(grid), dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, ldq, W, ldw,
+                         (int64_t)1, bias, y, ldy, M, (int)K, (int)N, beta, rows_per_wg, (int64_t)0, (int64_t)0, (int64_t)0, rs, (int64_t)0,
+                         colsum_w, (int64_t)0);
+    }
   } else {
     static DeviceOnce once16;
     YT8M_HIP_CHECK(once16.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<16, uint8_t>), 144 * 1024));
@@ -673,10 +682,16 @@ extern "C" int yt8m_attn_pool_dw_u8(const uint8_t* q, const float* rs, const flo
   rows_per_wg = (rows_per_wg + 15) / 16 * 16;
   const dim3 grid((unsigned)((F + rows_per_wg - 1) / rows_per_wg), (unsigned)B);
   if (A <= 8) {
-    static DeviceOnce once;
-    YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t>), 144 * 1024));
-    hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t>), grid, dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, H, dC, (int64_t)1, H,
-                       (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A, rs, F, dCsum, A);
+    static DeviceOnce once, once5;
+    if (H <= 1280) {
+      YT8M_HIP_CHECK(once5.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t, 5>), 144 * 1024));
+      hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t, 5>), grid, dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, H, dC, (int64_t)1, H,
+                         (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A, rs, F, dCsum, A);
+    } else {
+      YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<8, uint8_t>), 144 * 1024));
+      hipLaunchKernelGGL((skinny_fwd_kernel<8, uint8_t>), grid, dim3(256), (size_t)J * 8 * 64 * 4 * sizeof(float), s, q, H, dC, (int64_t)1, H,
+                         (const float*)nullptr, dw, A, F, (int)H, (int)A, 0.f, rows_per_wg, F * H, A * H, F * A, rs, F, dCsum, A);
+    }
   } else {
     static DeviceOnce once;
     YT8M_HIP_CHECK(once.lds(reinterpret_cast<const void*>(skinny_fwd_kernel<16, uint8_t>), 144 * 1024));
