@@ -509,6 +509,11 @@ int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void* x, const i
                         const float* beta_W, const float* beta_b, float* dx, yt8m_stream_t stream);
 /* YT8M_E_HIP if any persistent launch of the stack gave up waiting since the previous status call.  Synchronises `stream`. */
 int yt8m_lstm_stack_status(const yt8m_lstm_stack_desc* desc, void* scratch, yt8m_stream_t stream);
+/* Makes `stream` wait until the weight / bias gradients of `layer` from the most recent yt8m_lstm_stack_bwd call on the current
+ * device are final -- layer L-1 first, a whole last time part of weight-gradient work before layer 0.  A data-parallel host starts
+ * each layer's gradient all-reduce from this point instead of the end of the call (W/train.py:624-639 averages the tower
+ * gradients after the whole backward pass). */
+int yt8m_lstm_stack_layer_done_wait(int layer, yt8m_stream_t stream);
 
 /* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the
  * re-packed recurrent weights owned by the caller (yt8m_lstm_pack; yt8m_lstm_packed_floats() floats each for the forward

@@ -424,7 +424,7 @@ def _lstm_steps(dev, reducer, q, y, nf, steps=2, hog=None):
 
 
 @pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
-def test_lstm_step_under_a_one_rank_reducer_is_bitwise_the_plain_step(dev, flags, one_rank_rccl, algo):
+def test_lstm_step_under_a_one_rank_reducer_is_bitwise_the_plain_step(dev, flags, one_rank_rccl, algo, monkeypatch):
     """The headline model (persistent kernels, native stack) under parallel.GradReducer on a 1-rank RCCL group -- bucketed async
     all-reduce (or reduce-scatter + all-gather) of every gradient bucket, per-bucket clip + Adam, the CU headroom policy active --
     ends two steps with bit-identical parameters and predictions to the plain single-GPU step."""
@@ -435,11 +435,16 @@ def test_lstm_step_under_a_one_rank_reducer_is_bitwise_the_plain_step(dev, flags
     q = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
     y = torch.from_numpy(rs.rand(B, V) < 0.02).to(dev)
     nf = torch.from_numpy(rs.randint(1, F + 1, size=B).astype(np.int32)).to(dev)
-    n0 = seq_ops.NATIVE_CALLS["bwd"]
+    monkeypatch.setattr(seq_ops, "DP_LAYER_BUCKETS", algo == "allreduce")   # one transport with per-layer reports, one without
+    n0, l0 = seq_ops.NATIVE_CALLS["bwd"], seq_ops.DP_LAYER_BUCKETS_USED[0]
     want, pw = _lstm_steps(dev, None, q, y, nf)
+    assert seq_ops.DP_LAYER_BUCKETS_USED[0] == l0, "no reducer: the gradients are reported on the step's own stream"
     red = parallel.GradReducer(bucket_bytes=1 << 20, algo=algo)
     got, pg = _lstm_steps(dev, red, q, y, nf)
     assert seq_ops.NATIVE_CALLS["bwd"] == n0 + 4 and red.world == 1 and red.active
+    # per-layer buckets: each layer's gradients were reported from the side stream that waits for that layer's completion point
+    # (yt8m_lstm_stack_layer_done_wait), layer 1 before layer 0
+    assert seq_ops.DP_LAYER_BUCKETS_USED[0] == l0 + (2 if algo == "allreduce" else 0)
     prev = ctypes.c_int(-1)
     L.check(L.lib().yt8m_lstm_persist_reserve_cus(0, ctypes.byref(prev)))
     assert prev.value == 0, "detach() must give the CU headroom back"
@@ -724,3 +729,38 @@ def test_vlad_finish_q_scale_equals_l2_normalize_long_form(dev, B, F, K, D):
     assert float((ad.grad.cpu().double() - a64.grad).abs().max()) < tol(a64.grad)
     assert float((cen.grad.cpu().double().view(K, D) - c64.grad).abs().max()) < tol(c64.grad)
     assert float((W.grad.cpu().double().view(K * D, Hh) - W64.grad).abs().max()) < tol(W64.grad)
+
+
+def test_lstm_stack_layer_done_wait_contract(dev, flags):
+    """yt8m_lstm_stack_layer_done_wait: refuses a layer no backward call has recorded; after a backward call both layers can be
+    waited for from another stream, and a stream that waited sees the layer's final gradient (same bits as after a device sync)."""
+    lib = L.lib()
+    flags.lstm_cells, flags.lstm_layers = "256", 2
+    rs = np.random.RandomState(9)
+    B, F, D, V = 32, 40, 64, 50
+    q = torch.from_numpy(rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)).to(dev)
+    y = torch.from_numpy(rs.rand(B, V) < 0.05).to(dev)
+    nf = torch.from_numpy(rs.randint(1, F + 1, size=B).astype(np.int32)).to(dev)
+    assert lib.yt8m_lstm_stack_layer_done_wait(7, None) != 0                  # never recorded (2 layers at most so far)
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g)
+    n0 = seq_ops.NATIVE_CALLS["bwd"]
+    res = tg.forward(q, y, nf)
+    g.finalize()
+    res = tg.forward(q, y, nf)
+    tg.loss(res, y).backward()
+    if seq_ops.NATIVE_CALLS["bwd"] == n0:
+        pytest.skip("native stack not engaged for this shape")
+    side = torch.cuda.Stream(device=dev)
+    w1 = [v for k, v in g.vars.items() if "cell_1" in k and "kernel" in k or k.endswith("multi_rnn_cell/cell_1/basic_lstm_cell/kernel")]
+    ws = [v for v in g.trainable_variables() if v.grad is not None and v.grad.numel() >= 256 * 4 * 256]
+    copies = []
+    for layer in (1, 0):
+        L.check(lib.yt8m_lstm_stack_layer_done_wait(layer, ctypes.c_void_p(side.cuda_stream)))
+        with torch.cuda.stream(side):
+            copies.append([v.grad.clone() for v in ws])
+    torch.cuda.synchronize()
+    final = [v.grad.clone() for v in ws]
+    # after waiting for layer 0 (the last one to finish) every LSTM gradient is final
+    for a, b in zip(copies[1], final):
+        assert torch.equal(a, b)

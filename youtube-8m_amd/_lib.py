@@ -66,6 +66,7 @@ SIGNATURES = {
     "yt8m_lstm_stack_bwd": (c_int, [DESC, P, P, PP, P, c_int64, P, c_int64, P, PP, PP, PP, PP, ctypes.POINTER(c_float),
                                     ctypes.POINTER(c_float), P, P]),
     "yt8m_lstm_stack_status": (c_int, [DESC, P, P]),
+    "yt8m_lstm_stack_layer_done_wait": (c_int, [c_int, P]),
     "yt8m_u8_frames_image": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, P, P, P, P]),
     "yt8m_cast_f32_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int, P]),
     "yt8m_cast_f32_bf16_dual": (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P]),

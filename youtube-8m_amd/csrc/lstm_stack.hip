@@ -184,6 +184,8 @@ struct DevState {
   bool prio_known = false;
   std::vector<hipEvent_t> ev[2];      // forward / backward pools
   size_t used[2] = {0, 0};
+  hipEvent_t layer_done[MAXL] = {nullptr};   // most recent backward call: layer l's dW / db are final (yt8m_lstm_stack_layer_done_wait)
+  int layers_done = 0;
 };
 std::mutex g_mu;
 DevState g_dev[16];
@@ -297,6 +299,23 @@ extern "C" int yt8m_lstm_stack_view(const yt8m_lstm_stack_desc* desc, void* tape
     case 2: *out = at<float>(tape, P.hs[layer]) + FBH; break;
     default: *out = at<float>(tape, P.z[layer]); break;
   }
+  return YT8M_OK;
+}
+
+// Makes `stream` wait until the weight and bias gradients of `layer` written by the most recent yt8m_lstm_stack_bwd call on the
+// current device are final (they are, in the order L-1 ... 0, well before the call's own stream is released: layer l's last
+// products precede those of the layers below on the weight-gradient stream).  For per-layer gradient all-reduces (W/train.py:
+// 624-639 averages tower gradients after the whole backward pass; here layer L-1's bucket is on the wire while layer 0's last
+// weight-gradient products still run).
+extern "C" int yt8m_lstm_stack_layer_done_wait(int layer, yt8m_stream_t stream) {
+  int dev = 0;
+  YT8M_HIP_CHECK(hipGetDevice(&dev));
+  YT8M_REQUIRE(dev >= 0 && dev < 16, YT8M_E_BADARG, "device index out of range");
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevState& S = g_dev[dev];
+  YT8M_REQUIRE(layer >= 0 && layer < S.layers_done && S.layer_done[layer], YT8M_E_BADARG,
+               "no backward call on this device has recorded that layer");
+  YT8M_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), S.layer_done[layer], 0));
   return YT8M_OK;
 }
 
@@ -499,9 +518,13 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         } else if (db[l]) {
           RC(yt8m_colsum_f32(dz, FB, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
         }
+        // the layer's gradients are final here -- layer L-1 first, a whole last part of weight-gradient work before layer 0's: a
+        // data-parallel host starts each layer's all-reduce from this point (yt8m_lstm_stack_layer_done_wait)
+        S->layer_done[l] = ev.record(sw);
       }
     }
   }
+  S->layers_done = P.L;
   hipEvent_t fin = ev.record(sw);                          // sw waited for every recurrence part
   ev.wait(main, fin);
   if (two_sw) ev.wait(main, ev.record(S->sw2));

@@ -424,6 +424,23 @@ def _tape_view(lib, desc, tape, layer, which, shape):
     return tape[off:off + n].view(torch.float32).view(*shape)
 
 
+# Per-layer reports of the native stack's gradients under a reducer (each layer's collective starts when THAT layer's last
+# weight-gradient product is done: yt8m_lstm_stack_layer_done_wait).  Opt-in: on one GPU with a 1-rank RCCL group the extra stream
+# costs 1.5-1.7 ms of the 23.6 ms step (profiles/r3_force_reducer.md; more hardware queues -- GPU_MAX_HW_QUEUES=8 -- do not help),
+# more than the ~0.3 ms of layer-1 all-reduce it can hide on eight.
+DP_LAYER_BUCKETS = _os.environ.get("YT8M_DP_LAYER_BUCKETS", "0") != "0"
+DP_LAYER_BUCKETS_USED = [0]
+_DP_SIDE = {}
+
+
+def _dp_side_stream(dev):
+    st = _DP_SIDE.get(dev)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _DP_SIDE[dev] = st
+    return st
+
+
 class _LstmStack(torch.autograd.Function):
     """MultiRNNCell([BasicLSTMCell] * L) under tf.nn.dynamic_rnn (W/all_frame_models/lstm_model.py:34-47), time-major, as ONE
     op so that the layers can be pipelined: the sequence is cut into time chunks; layer l's hoisted input projection of
@@ -706,9 +723,23 @@ class _LstmStack(torch.autograd.Function):
         NATIVE_CALLS["bwd"] += 1
         if PERSIST_CHECK:
             _check_stack(scratch, torch.cuda.current_stream(dev), desc)
-        for v in list(Ws) + list(bs):
-            if v.grad is not None:
-                v.grad_done()
+        g = Ws[0]._graph
+        if g is not None and g.grad_ready_hook is not None and DP_LAYER_BUCKETS:
+            # data parallel: report each layer's gradients from a side stream that waits for THAT layer only (the library records
+            # the point on its weight-gradient stream: layer L-1's gradients are final a whole last part before layer 0's), so
+            # the reducer's collective for layer L-1 is on the wire while layer 0's last weight-gradient products still run
+            side = _dp_side_stream(dev)
+            for l in reversed(range(L)):
+                _lib.check(lib.yt8m_lstm_stack_layer_done_wait(l, ctypes.c_void_p(side.cuda_stream)))
+                with torch.cuda.stream(side):
+                    for v in (Ws[l], bs[l]):
+                        if v.grad is not None:
+                            v.grad_done()
+            DP_LAYER_BUCKETS_USED[0] += 1
+        else:
+            for v in list(Ws) + list(bs):
+                if v.grad is not None:
+                    v.grad_done()
         return (dx, None, None, None, None, None, None, None) + (None,) * (2 * L)
 
     @staticmethod
