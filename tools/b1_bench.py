@@ -44,6 +44,8 @@ for label, probs in SHAPES:
     items, pr, keep, fl = [], [], [], 0.0
     for (M, N, K) in probs:
         A32, B32 = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+        if os.environ.get("B1_ZEROS"):                      # operand entropy probe: zero-filled operands draw less power (higher clock)
+            A32.zero_(); B32.zero_()
         bias = torch.randn(N, device=dev)
         A = ops._bf16_empty(M, K, dev); A.copy_(A32)
         B = ops._bf16_empty(N, K, dev); B.copy_(B32)
