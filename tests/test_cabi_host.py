@@ -33,6 +33,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.yt8m_built_arch() == b"gfx950"
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """The reverse direction: every yt8m_* symbol the shared library exports is declared in include/yt8m_hip.h (an entry point a
+    host can bind but cannot find documented would be a boundary leak).  Needs binutils' nm; skipped without it."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or shutil.which("llvm-nm") or ("/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else None)
+    if nm is None:
+        pytest.skip("no nm in this environment")
+    out = subprocess.run([nm, "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("yt8m_")})
+    assert exported == _declared(), sorted(set(exported) ^ set(_declared()))
+
+
 def test_argument_validation_without_device():
     lib = L.lib()
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
