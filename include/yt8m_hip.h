@@ -20,6 +20,8 @@ typedef void* yt8m_stream_t; /* hipStream_t */
 enum yt8m_status { YT8M_OK = 0, YT8M_E_BADARG = -1, YT8M_E_SHAPE = -2, YT8M_E_HIP = -3, YT8M_E_RCCL = -4 };
 enum yt8m_label_dtype { YT8M_LABEL_U8 = 0, YT8M_LABEL_F32 = 1 };
 
+/* 2 since round 3: persistent-recurrence workspaces begin with a sticky error word the host zeroes once (yt8m_lstm_persist_status
+ * reads AND clears it), the image GEMMs read yt8m_gemm_problem.lda / ldb as K-block strides.  A host must check it. */
 int yt8m_abi_version(void);
 const char* yt8m_last_error(void);
 /* name of the gfx target the device code was built for ("gfx950") */

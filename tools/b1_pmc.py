@@ -1,4 +1,4 @@
-"""One shape of the b1 kernel a few times (PMC passes: tools/r3_call23.sh)."""
+"""One shape of the b1 kernel a few times (PMC passes: tools/pmc_run.py)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

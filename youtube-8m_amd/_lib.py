@@ -205,6 +205,9 @@ SIGNATURES = {
     "yt8m_perr_rows": (c_int, [P, P, c_int64, c_int64, P, P]),
 }
 
+# The ABI this host binds (include/yt8m_hip.h, yt8m_abi_version): workspace layouts and argument meanings, not just symbols.
+ABI_VERSION = 2
+
 _lib = None
 
 
@@ -225,6 +228,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.yt8m_abi_version() != ABI_VERSION:
+            raise Yt8mHipError("libyt8m_hip.so speaks ABI %d, this host was written for ABI %d: rebuild with `make -C youtube-8m_amd/csrc`"
+                               % (L.yt8m_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const BGroup G) {
 }
 
 // ---- K-step 64: whole 128-byte lines per row and step ---------------------------------------------------------------------------
-// Ablations of the kernel above (tools/r3_call12.sh: no DMA / no LDS reads / no MFMA builds) show what bounds it: without the
+// Ablations of the kernel above (tools/build_variant.sh -DYT8M_* ablation builds: no DMA / no LDS reads / no MFMA builds) show what bounds it: without the
 // MFMAs it runs as long as with them, without the LDS-DMA 1.4-1.75x faster -- the L2 -> LDS operand delivery, at ~6.5 TB/s for
 // this access pattern: a K-step of 32 bf16 is 64 bytes per row, HALF a cache line, 16 rows per wave instruction, and every line is
 // fetched by two different K-steps.  Here a step carries 64 bf16 = one whole 128-byte line per row (8 rows per wave instruction),

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
 // C = A . B^T for operands that ARE bfloat16 (--compute_dtype=bfloat16: BASELINE configs[4] and the bf16 variants), both given as
 // ONE-plane images -- [rows / 32][K / 16][32 rows][2 halves][8] bf16, what yt8m_bf16_image writes straight from the fp32 source.
 // Why images: the row-major kernels of gemm_bf16.hip are bound by L2 -> LDS operand delivery (~6.5 TB/s: 16 rows x 64 bytes, or 8
-// rows x 128 bytes, per wave instruction; with the MFMAs removed they take as long as with them -- tools/r3_call12.sh), while a wave
+// rows x 128 bytes, per wave instruction; with the MFMAs removed they take as long as with them), while a wave
 // instruction on an image moves 1 KiB of consecutive memory and four K blocks of a row group are 4 KiB in a row.
 // Step = four K blocks (K = 64): 64 KiB per stage, two stages (the refill of a stage is issued block by block between the MFMA
 // groups of the step after its last read), one barrier per step; per block and wave 6 ds_read_b128 feed 8 MFMAs.

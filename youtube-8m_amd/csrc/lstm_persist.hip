@@ -53,6 +53,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // aux 17 = sc0 sc1: write-through store / coherent load (MI355X_MICROARCH.md, inter-workgroup visibility)
 constexpr long long SPIN_TIMEOUT = 300000000;  // wall_clock64 ticks (100 MHz): 3 s
 constexpr int CTL_HDR = 32;                    // control block: [0] error word, counters from word 32
+constexpr int CTL_STICKY = 32;                 // words between the sticky error word (workspace word 0) and ctl[0]
 #ifndef YT8M_PERSIST_SHARDS
 #define YT8M_PERSIST_SHARDS 8
 #endif
@@ -120,7 +121,8 @@ __device__ __forceinline__ void check_placement(unsigned* ctl, unsigned* stats) 
 // the first word of the workspace, outside the region a launch zeroes: every workgroup that leaves a timed-out launch ORs the
 // flag into it (one lane, at the end of the kernel), and only the status call clears it.  A time-out in ANY launch since the last
 // status call is therefore reported, whatever ran on the workspace afterwards.
-constexpr int CTL_STICKY = 32;                 // words between the sticky word (workspace word 0) and ctl[0]
+// The wave that times out also writes the sticky word itself (wait_tile): the exit path below only covers workgroups whose
+// wave 8 leaves after the flag was set.
 __device__ __forceinline__ void propagate_error(unsigned* ctl) {                        // one lane, at the end of the kernel
   if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
     __hip_atomic_store(ctl - CTL_STICKY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -151,7 +153,10 @@ __device__ __forceinline__ void wait_tile(unsigned* ctl, int tile, unsigned targ
         const long long now = wall_clock64();
         if (t_start == 0) t_start = now;
         else if (now - t_start > SPIN_TIMEOUT) {
-          if (lane == 0) __hip_atomic_store(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            __hip_atomic_store(ctl - CTL_STICKY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky word first: the host's view
+            __hip_atomic_store(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           return;
         }
       }

@@ -333,10 +333,11 @@ def _persist_ws(dev, main, l, nbytes):
     table after its status has been read (a time-out is never lost with the eviction)."""
     key = (dev.index, main.cuda_stream, l, int(nbytes))
     ent = _PERSIST_WS.get(key)
-    if ent is None:
-        if len(_PERSIST_WS) >= _PERSIST_WS_MAX:                    # other shapes: drop the oldest entry (dicts keep insertion order)
-            old = next(iter(_PERSIST_WS))
-            _check_ws(*_PERSIST_WS.pop(old))
+    if ent is not None:
+        _PERSIST_WS[key] = _PERSIST_WS.pop(key)                    # LRU order (dicts keep insertion order)
+    else:
+        if len(_PERSIST_WS) >= _PERSIST_WS_MAX:                    # other shapes: drop the least recently used entry
+            _retire(_PERSIST_WS.pop(next(iter(_PERSIST_WS))), _check_ws)
             global _PERSIST_EVICTIONS
             _PERSIST_EVICTIONS += 1
             if _PERSIST_EVICTIONS in (64, 1024):                     # a model cycling through > 16 shapes re-zeroes ~0.6 GB per miss
@@ -349,6 +350,18 @@ def _persist_ws(dev, main, l, nbytes):
 
 
 _PERSIST_EVICTIONS = 0
+_STACK_SCRATCH_MAX = int(_os.environ.get("YT8M_STACK_SCRATCH_MAX", "8"))
+# Evicted workspaces that something may still launch on (an autograd ctx between its forward and its backward keeps the tensor
+# alive): weak references, checked -- and dropped -- by the next check_persist_errors(), so a time-out in such a backward pass is
+# still reported.  A tensor nobody holds any more cannot be launched on and needs no check beyond the one at eviction.
+_RETIRED = []
+
+
+def _retire(ent, checker):
+    import weakref
+    checker(*ent)                                                    # what ran so far (synchronises that stream)
+    _RETIRED.append((weakref.ref(ent[0]), ent[1:], checker))
+    del ent
 
 
 def _check_ws(ws, stream):
@@ -372,6 +385,16 @@ def check_persist_errors():
             _check_stack(*ent)
         except _lib.Yt8mHipError as e:
             err = e
+    retired, _RETIRED[:] = list(_RETIRED), []
+    for ref, rest, checker in retired:
+        ws = ref()
+        if ws is None:
+            continue
+        try:
+            checker(ws, *rest)
+        except _lib.Yt8mHipError as e:
+            err = e
+        _RETIRED.append((ref, rest, checker))                        # still alive: stays on the list
     if err is not None:
         raise err
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
@@ -399,10 +422,11 @@ def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx):
 def _stack_scratch(dev, main, desc):
     key = (dev.index, main.cuda_stream) + tuple(getattr(desc, f) for f, _ in desc._fields_ if f != "forget_bias")
     ent = _STACK_SCRATCH.get(key)
-    if ent is None:
-        if len(_STACK_SCRATCH) >= 4:                                 # a few GB each: keep the table small
-            old = next(iter(_STACK_SCRATCH))
-            _check_stack(*_STACK_SCRATCH.pop(old))
+    if ent is not None:
+        _STACK_SCRATCH[key] = _STACK_SCRATCH.pop(key)                # least recently USED goes first (dicts keep insertion order)
+    else:
+        if len(_STACK_SCRATCH) >= _STACK_SCRATCH_MAX:                # a few GB each: keep the table small
+            _retire(_STACK_SCRATCH.pop(next(iter(_STACK_SCRATCH))), _check_stack)
         n = _lib.lib().yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc))
         ent = (torch.zeros(n, dtype=torch.uint8, device=dev), main, desc)      # zeroed ONCE: the sticky time-out words start clear
         _STACK_SCRATCH[key] = ent

@@ -210,6 +210,20 @@ class TrainGraph(object):
         return {"loss": label_loss.detach(), "predictions": result["predictions"].detach(),
                 "global_step": self.global_step, "learning_rate": lr}
 
+    def close(self):
+        """End of training (where W/train.py:612-622 leaves the Supervisor's session): gives back what the step holds
+        process-wide -- the reducer's CU reserve of the persistent recurrences (parallel.GradReducer.detach)."""
+        if self.reducer is not None and getattr(self, "_finalized_here", False):
+            self.reducer.detach()
+            self._finalized_here = False                          # a later step() re-attaches
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     @torch.no_grad()
     def predict(self, model_input_raw, num_frames=None, vocab_size=None):
         g = set_default_graph(self.graph)
