@@ -24,6 +24,7 @@
 // current one.  Tile order and the float4 epilogue follow gemm_bf16.hip; the tiles of the last partial round are split along K.
 #include "common.h"
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 
 namespace {
@@ -68,8 +69,12 @@ __device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int 
 // Work items of a launch: problem q contributes its first full[q] tiles (whole rounds of 256 workgroups) unsplit, then the
 // rem[q] tiles of its last, partial round as rem[q] * S[q] K-part items, part major -- the wave-quantisation tail costs a fraction
 // of a round instead of a whole one.  full / rem / S come from the shape of problem q ALONE, so a product is summed in the same
-// order whether it is launched by itself or inside a group.  Parts park raw accumulators in ws[slot_base[q] + item][256][256];
-// x3_fixup_kernel sums them in a fixed order.
+// order whether it is launched by itself or inside a group.  Parts park raw accumulators in ws[slot_base[q] + item][256][256]
+// with write-through stores and take a ticket on the tile's arrival counter; the part that arrives LAST sums all S slabs in the
+// fixed order 0 .. S-1 (so the result does not depend on which part that was) and runs the epilogue -- the combine rides on the
+// GEMM launch instead of a kernel of its own (round 4: the 13 x3_fixup_kernel launches of a headline step were 0.68 ms of the
+// weight-gradient stream plus two launch seams each; MI355X_MICROARCH.md "splitk-seam": write-through slabs + ticket).
+// x3_fixup_kernel is kept as the checked alternative (YT8M_X3_FIXUP_KERNEL=1, or when no counter block could be allocated).
 struct XGroup {
   XArgs p[4];
   int full_base[5];     // unsplit tiles, cumulative: workgroups [0, full_base[4]) in XCD-contiguous order
@@ -79,6 +84,7 @@ struct XGroup {
   int full[4], rem[4], S[4];
   int nprob;
   float* ws;
+  unsigned* cnt;        // arrival counters of the split tiles (one per tile, zero between launches); NULL: separate fix-up pass
 };
 
 __device__ __forceinline__ int xcd_remap(int wg, int n) {
@@ -121,14 +127,47 @@ __device__ __forceinline__ void x_work_item(const XGroup& G, int& q, int& nparts
   }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int AUX_WT = 17;                                         // sc0 sc1: write-through store / fabric-coherent load
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, TM * TN * (int)sizeof(float), 0x00020000);
+}
+// the summed value of four consecutive elements of a split tile -> C (affine / bias / accumulate), exactly as the unsplit epilogue
+__device__ __forceinline__ void finish_store(const XArgs& g, float4 v, int row, int col) {
+  if (row >= g.M) return;
+  if ((g.rscale || g.cs || g.alpha != 1.0f) && col + 3 < g.N) v = affine(g, v, row, col);
+  float* c = g.C + (int64_t)row * g.ldc + col;
+  if ((g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0 && col + 3 < g.N) {
+    if (g.bias) {                                                  // the same additions in the same order as the scalar path
+      const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (g.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(c);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(c) = v;
+    return;
+  }
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (col + k < g.N) {
+      float o = vv[k] + (g.bias ? g.bias[col + k] : 0.f);
+      if (g.accumulate) o += c[k];
+      c[k] = o;
+    }
+  }
+}
+
 // epilogue of the image kernels: accumulators -> wave-private LDS image [32][68] -> 16-byte stores (split-K parts: raw
-// accumulators to the workspace image)
+// accumulators to the workspace slab; the last part to arrive combines)
 __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x16 (&acc)[4][2], float* smem, int m0, int n0, int wm, int wn,
-                                           int lane, int wave, int li, int lk, int nparts, int slot) {
+                                           int lane, int wave, int li, int lk, int nparts, int slot, int q, int lt) {
   constexpr int P = 68;
   float* st = smem + wave * (32 * P);
-  if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace image
-    float* wsl = G.ws + (int64_t)slot * (TM * TN);
+  if (nparts > 1) {                                                // split-K part: raw accumulators to the workspace slab
+    const __amdgpu_buffer_rsrc_t wr = slab_rsrc(G.ws + (int64_t)slot * (TM * TN));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -139,7 +178,48 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
       for (int k = 0; k < 8; ++k) {
         const int idx = lane + 64 * k;
         const int rr = idx >> 4, c4 = (idx & 15) * 4;
-        *reinterpret_cast<float4*>(&wsl[(wm + i * 32 + rr) * TN + wn + c4]) = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&st[rr * P + c4]);
+        // write-through: a part of this launch reads the slab back (the guide's publish-large row: also the faster form)
+        __builtin_amdgcn_raw_buffer_store_b128(v, wr, ((wm + i * 32 + rr) * TN + wn + c4) * 4, 0, AUX_WT);
+      }
+    }
+    if (!G.cnt) return;                                            // x3_fixup_kernel combines
+    // ticket: every slab store of this workgroup has left the CU (vmcnt) before the arrival; the LAST part of the tile combines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int rt = lt - G.full[q];                                 // which split tile of problem q
+    unsigned* flag = reinterpret_cast<unsigned*>(smem + 8 * 32 * P);
+    if (threadIdx.x == 0) {
+      unsigned* c = G.cnt + G.fix_base[q] + rt;
+      const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)nparts - 1u) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+      *flag = old;
+    }
+    __syncthreads();
+    if (*flag != (unsigned)nparts - 1u) return;
+    // slab of part s of this tile: slot_base + s * rem + rt  (the fixed order 0 .. S-1 of x3_fixup_kernel: bitwise the same sums)
+    const float* base = G.ws + (int64_t)(G.slot_base[q] + rt) * (TM * TN);
+    const int64_t pstride = (int64_t)G.rem[q] * (TM * TN);
+    for (int i0 = 0; i0 < TM * TN / 4 / 512; i0 += 4) {            // 32 float4 per thread, four in flight per part
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = (int)threadIdx.x + 512 * (i0 + u);
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc(base), f * 16, 0, AUX_WT));
+      }
+      for (int sp = 1; sp < nparts; ++sp) {
+        const __amdgpu_buffer_rsrc_t rr = slab_rsrc(base + (int64_t)sp * pstride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int f = (int)threadIdx.x + 512 * (i0 + u);
+          const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, f * 16, 0, AUX_WT));
+          v[u].x += t.x; v[u].y += t.y; v[u].z += t.z; v[u].w += t.w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = ((int)threadIdx.x + 512 * (i0 + u)) * 4;
+        finish_store(g, v[u], m0 + e / TN, n0 + (e % TN));
       }
     }
     return;
@@ -335,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                    // the epilogue reuses the ring
 
-  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot);
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
 // ---- one plane x one plane: the plain bf16 product on operand images ("b1") -------------------------------------------------------
@@ -418,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(const XGroup G) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the next step landed; this wave's fragment reads are done
     __builtin_amdgcn_s_barrier();
   }
-  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot);
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
 // sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
@@ -441,19 +521,7 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
       const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
-    const int row = m0 + e / TN, col = n0 + (e % TN);
-    if (row >= g.M) continue;
-    if ((g.rscale || g.cs || g.alpha != 1.0f) && col + 3 < g.N) v = affine(g, v, row, col);
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-    float* c = g.C + (int64_t)row * g.ldc + col;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (col + k < g.N) {
-        float o = vv[k] + (g.bias ? g.bias[col + k] : 0.f);
-        if (g.accumulate) o += c[k];
-        c[k] = o;
-      }
-    }
+    finish_store(g, v, m0 + e / TN, n0 + (e % TN));
   }
 }
 
@@ -618,6 +686,39 @@ extern "C" int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t 
 }
 
 namespace {
+// Arrival counters of split tiles: one block of 64 Ki words per device, zeroed once (every completed tile leaves its counter at
+// zero again), handed out to launches as a ring -- two launches can only share a counter if more than 64 Ki split tiles lie between
+// them, i.e. never while the first one is still running.
+constexpr uint32_t CNT_CAP = 1u << 16;
+struct TileCounters {
+  std::mutex mu;
+  unsigned* base[16] = {nullptr};
+  bool failed[16] = {false};
+  uint32_t next[16] = {0};
+  unsigned* take(int n) {
+    static const bool off = getenv("YT8M_X3_FIXUP_KERNEL") != nullptr && atoi(getenv("YT8M_X3_FIXUP_KERNEL")) != 0;
+    int dev = 0;
+    if (off || n <= 0 || (uint32_t)n > CNT_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (failed[dev]) return nullptr;
+    if (!base[dev]) {
+      unsigned* p = nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&p), CNT_CAP * sizeof(unsigned)) != hipSuccess ||
+          hipMemset(p, 0, CNT_CAP * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        failed[dev] = true;                                        // the separate fix-up pass still works
+        return nullptr;
+      }
+      base[dev] = p;
+    }
+    if (next[dev] + (uint32_t)n > CNT_CAP) next[dev] = 0;
+    unsigned* r = base[dev] + next[dev];
+    next[dev] += (uint32_t)n;
+    return r;
+  }
+};
+TileCounters g_cnt;
+
 template <int PA>
 int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, float alpha,
               void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
@@ -677,6 +778,7 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   for (int i = G.nprob; i <= 4; ++i) { G.full_base[i] = (int)nfull; G.part_base[i] = (int)slots; G.fix_base[i] = (int)fix; }
   for (int i = G.nprob; i < 4; ++i) { G.p[i] = G.p[0]; G.S[i] = 1; G.slot_base[i] = 0; G.full[i] = 0; G.rem[i] = 0; }
   G.ws = static_cast<float*>(workspace);
+  G.cnt = fix > 0 ? g_cnt.take((int)fix) : nullptr;
   const int64_t grid = nfull + slots;
   constexpr int LDS_BYTES = PA == 0 ? 2 * B1_STAGE_F * (int)sizeof(float) : NST * (PA + 3) * PLANE_F * (int)sizeof(float);
   static DeviceOnce lds_once;                                      // per device (a process-wide flag broke cuda:1)
@@ -687,7 +789,7 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3), as_stream(stream), fl);
   if constexpr (PA == 0) hipLaunchKernelGGL(gemm_b1_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
   else hipLaunchKernelGGL(gemm_x3_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
-  if (fix > 0) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
+  if (fix > 0 && !G.cnt) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
 }
 }  // namespace

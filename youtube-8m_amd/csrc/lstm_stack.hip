@@ -417,6 +417,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   Ev ev(*S, 1);
   hipStream_t main = as_stream(stream), sw = S->sw;
   static const int dx_stream = knob("YT8M_STACK_DX_STREAM", 0), two_sw = knob("YT8M_STACK_SW2", 0);
+  const int fuse_dz = knob("YT8M_STACK_FUSE_DZ_SPLIT", 0);
   const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H, FB = P.FB;
   const int64_t KBtot = FB / 16;
   hipEvent_t start = ev.record(main);
@@ -438,6 +439,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   if (two_sw) ev.wait(S->sw2, ev.record(sw));              // layer 0's chain reads images made on sw
   int phase[MAXL];
   bool wx3_done[MAXL];
+  hipEvent_t dzT_free[MAXL] = {nullptr};
   for (int l = 0; l < P.L; ++l) {
     hipStream_t s = S->rs[l];
     float* work = at<float>(scratch, P.work[l]);
@@ -451,15 +453,36 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     wx3_done[l] = false;
   }
   std::vector<hipEvent_t> last;
+  // Sub-parts of the BOTTOM layer (knob YT8M_STACK_SUB0 = "n0,n1,.." per backward part in forward-time order; default: the part
+  // that runs last is cut in three).  The bottom layer's last recurrence runs alone on half the chip and everything behind it --
+  // the transposed dz image, two weight-gradient products, the bias pass -- is the tail of the backward pass: with the part cut
+  // into sub-launches only the LAST sub-part's products remain behind the recurrence (profiles/r4_sched_knobs.md).
+  int sub0[MAXP];
+  for (int c = 0; c < P.nb; ++c) sub0[c] = (c == 0 && P.L > 1 && P.nb > 1 && !getenv("YT8M_STACK_SUB0")) ? knob("YT8M_STACK_SUB0_LAST", 3) : 1;
+  if (const char* spec = getenv("YT8M_STACK_SUB0")) {
+    int n = 0;
+    for (const char* q = spec; *q && n < P.nb;) { sub0[n++] = std::max(1, atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+  }
   for (int c = P.nb - 1; c >= 0; --c) {
-    const int64_t t0 = P.bp[c].t0, T = P.bp[c].T, M = T * B;
-    const int64_t kb0 = t0 * B / 16;
-    const bool first = c == P.nb - 1;
     hipEvent_t dx_ev = nullptr;
     for (int l = P.L - 1; l >= 0; --l) {
+     Part sp[MAXP];
+     int nsub = (l == 0 && P.L > 1) ? std::min(sub0[c], MAXP) : 1;
+     if (nsub > 1) {                                         // equal sub-parts on 16-frame-row boundaries, else the whole part
+       const int64_t step = (P.bp[c].T + nsub - 1) / nsub;
+       int k = 0;
+       bool ok = (step * B) % 16 == 0;
+       for (int64_t u = 0; ok && u < P.bp[c].T; u += step) sp[k++] = {P.bp[c].t0 + u, std::min(step, P.bp[c].T - u)};
+       nsub = ok ? k : 1;
+     }
+     if (nsub == 1) sp[0] = P.bp[c];
+     for (int j = nsub - 1; j >= 0; --j) {
+      const int64_t t0 = sp[j].t0, T = sp[j].T, M = T * B;
+      const int64_t kb0 = t0 * B / 16;
+      const bool first = c == P.nb - 1 && j == nsub - 1;
       hipStream_t s = S->rs[l];
       const int64_t Din = l ? H : D;
-      if (dx_ev) ev.wait(s, dx_ev);
+      if (dx_ev && j == nsub - 1) ev.wait(s, dx_ev);
       const float* dout = l == P.L - 1 ? dout_top : at<float>(scratch, P.dbuf[l]);
       float* dz = at<float>(scratch, P.dz[l]);
       RC(yt8m_lstm_persist_bwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
@@ -467,12 +490,18 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
                                P.pws_bytes, s));
       phase[l] = (int)((phase[l] + T) % 2);
       hipEvent_t rb = ev.record(s);
+      bool fused_t = false;
       const float* dzc = dz + t0 * B * H4;
-      dx_ev = nullptr;
+      if (j == nsub - 1) dx_ev = nullptr;
       if (l > 0 || P.need_dx) {                            // dz as stored feeds dx: the critical path to the layer below
         hipStream_t sx = dx_stream ? S->dxs[l] : s;        // (on its own stream the layer's next part starts at once)
         if (dx_stream) ev.wait(sx, rb);
-        RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), nullptr, sx));
+        // knob YT8M_STACK_FUSE_DZ_SPLIT: ONE pass over dz writes the plain image (dx, this stream) and the transposed one (the
+        // weight-gradient stream then waits for this pass instead of reading dz again)
+        fused_t = fuse_dz && dW[l] && !(l == 0 && P.u8);
+        if (fused_t && dzT_free[l]) ev.wait(sx, dzT_free[l]);       // the previous part's products have read the image
+        RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
+        if (fused_t) rb = ev.record(sx);
         if (!wx3_done[l]) {
           RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));      // W_x: rows Din, K = 4H
           wx3_done[l] = true;
@@ -481,7 +510,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 0.0f};
         RC(yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx));
         dx_ev = ev.record(sx);
-        if (c == 0) last.push_back(dx_ev);
+        if (c == 0 && j == 0) last.push_back(dx_ev);
       }
       // weight-gradient stream: transposed image(s) of this part's dz, the two products, the bias gradient
       hipStream_t sw = (two_sw && l == 0) ? S->sw2 : S->sw;       // (knob: layer 0's chain on a second weight-gradient stream)
@@ -490,7 +519,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       const float bW = first ? (beta_W ? beta_W[l] : 0.f) : 1.f;
       // Bias gradient and the rank-1 remainder of layer 0's uint8 product: ONE pass over the layer's whole dz after its last part
       // (c == 0) instead of a column sum per part -- three launches fewer per part on the chain that ends the backward pass.
-      const bool lastpart = c == 0;
+      const bool lastpart = c == 0 && j == 0;
       if (dW[l]) {
         if (l == 0 && P.u8) {
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
@@ -501,11 +530,12 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
                                   dW[0] + D * H4, H4, nullptr, bW};
           RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, sw));
         } else {
-          RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
+          if (!fused_t) RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
           yt8m_gemm_problem pr[2] = {
               {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
               {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
           RC(yt8m_gemm_x3_nt_grouped(2, pr, gw, P.gws_bytes, sw));
+          if (fused_t) dzT_free[l] = ev.record(sw);
         }
       }
       if (lastpart) {
@@ -522,6 +552,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // data-parallel host starts each layer's all-reduce from this point (yt8m_lstm_stack_layer_done_wait)
         S->layer_done[l] = ev.record(sw);
       }
+     }
     }
   }
   S->layers_done = P.L;
