@@ -44,7 +44,8 @@ LSTM_H, LSTM_L = 1024, 2
 PEAK_F32_MATRIX_TFLOPS = 157.3
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by bf16 VARIANT lines
 PEAK_HBM_GBS = 8000.0
-FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3", "gemm_x1x3"]
+FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3", "gemm_x1x3",
+            "vlad_rows", "vlad_cols"]          # the last two: the streaming kernels of "netvlad", timed inside it, bytes declared
 X3_PRODUCTS = 6.0                    # bf16 MFMA products per fp32 product in csrc/gemm_x3.hip
 
 
@@ -62,15 +63,23 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[2] / bf16-variant extra lines")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="lower bound of the cpu_baseline sample (it also runs >= --cpu-steps steps)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps of the cpu_baseline leg at least (SURVEY.md 8d: >= 10)")
-    ap.add_argument("--cpu-max-seconds", type=float, default=120.0, help="hard wall budget of the cpu_baseline sample (it stops early "
-                    "and reports the steps it did); the all-cores twin runs in a subprocess with a 45 s limit of its own")
-    ap.add_argument("--cpu-allcores-probe", type=int, default=0, help=argparse.SUPPRESS)     # internal: child of the all-cores twin
+    ap.add_argument("--cpu-max-seconds", type=float, default=120.0, help="hard wall budget of the cpu_baseline sample, shared by its two "
+                    "implementations (it stops early and reports the steps it did)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's arithmetic (the headline).  bf16 = bf16 MFMA operands, fp32 accumulate / "
                          "master weights / Adam: a separately labelled line, never the headline.")
     ap.add_argument("--no-gap", action="store_true", help="skip the GAP@20 leg (BASELINE.json's second metric)")
     ap.add_argument("--force-reducer", action="store_true", help="exercise the RCCL reducer even at world size 1 (test aid)")
-    return ap.parse_args()
+    # data-parallel knobs (also YT8M_DP_ALGO / YT8M_DP_RESERVED_CUS / YT8M_DP_LAYER_BUCKETS); recorded in the line's "reducer" object
+    ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag"], default=None, help="gradient collective per bucket")
+    ap.add_argument("--dp-reserved-cus", type=int, default=None, help="CUs the persistent recurrences leave to RCCL's kernels")
+    ap.add_argument("--dp-layer-buckets", type=int, choices=[0, 1], default=None, help="report the LSTM layers' gradients separately")
+    ap.add_argument("--dp-bucket-mb", type=int, default=None, help="all-reduce bucket threshold in MiB (default 32)")
+    a = ap.parse_args()
+    for flag, env in ((a.dp_algo, "YT8M_DP_ALGO"), (a.dp_reserved_cus, "YT8M_DP_RESERVED_CUS"), (a.dp_layer_buckets, "YT8M_DP_LAYER_BUCKETS")):
+        if flag is not None:                             # read at import time by parallel.py / seq_ops.py, inherited by the ranks
+            os.environ[env] = str(flag)
+    return a
 
 
 # ---- self-launch: `python bench.py --gpus N` must run N ranks even without torchrun -------------------
@@ -207,6 +216,9 @@ def family_times(lib, steps):
                          "avg_launch_ms": ms.value / n.value}
             if fl.value > 0:
                 fam[name]["declared_flops_per_step"] = fl.value / steps       # counted by the library at launch time
+            lib.yt8m_prof_get_bytes(fid, ctypes.byref(fl))
+            if fl.value > 0:
+                fam[name]["declared_bytes_per_step"] = fl.value / steps       # algorithmic HBM bytes, same mechanism
     return fam
 
 
@@ -249,6 +261,8 @@ def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False,
     work would take with every pipe at its peak and nothing overlapped, against the measured wall time of a step."""
     rows = {}
     for name, v in fam.items():
+        if name in ("vlad_rows", "vlad_cols"):                       # sub-kernels of "netvlad": reported under roofline.hbm
+            continue
         f = v.get("declared_flops_per_step") or flops.get(name)
         if f and v["ms_per_step"] > 0:
             peak, what = family_peak(name, bf16, fwd_x3)
@@ -271,7 +285,7 @@ def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False,
             "launches_per_step": r["launches_per_step"], "avg_launch_ms": r["avg_launch_ms"],
             "algorithmic_flops_per_launch": r["algorithmic_flops_per_launch"],
             "families": rows,
-            "other_families": {k: v for k, v in fam.items() if k not in rows}}
+            "other_families": {k: v for k, v in fam.items() if k not in rows and k not in ("vlad_rows", "vlad_cols")}}
     for k in ("occupied_cus", "frac_of_occupied_cus", "occupancy_note"):
         if k in r:
             roof[k] = r[k]
@@ -393,10 +407,33 @@ def profile_pass(lib, run, steps, rank):
     return fam
 
 
-def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None):
+def netvlad_hbm(fam, bf16):
+    """The two streaming kernels of the fused NetVLAD pooling against the HBM roof ("NetVLAD: report both"):
+    achieved = the algorithmic bytes the library declares per launch (uint8 frames once + the transposed assignment + the
+    aggregate / partials) / hipEvent time; next to it the same launches as a fraction of the f16 MFMA pipe."""
+    out = {"peak_GBps": PEAK_HBM_GBS, "kernels": {}}
+    peak, what = family_peak("netvlad", bf16)
+    for k in ("vlad_rows", "vlad_cols"):
+        v = fam[k]
+        by, fl = v.get("declared_bytes_per_step", 0.0), v.get("declared_flops_per_step", 0.0)
+        gbps = by / (v["ms_per_step"] * 1e-3) / 1e9
+        out["kernels"][k] = {"launches_per_step": v["launches_per_step"], "avg_launch_us": v["avg_launch_ms"] * 1e3,
+                             "algorithmic_bytes_per_launch": by / max(v["launches_per_step"], 1e-9), "achieved_GBps": gbps,
+                             "frac_of_hbm": gbps / PEAK_HBM_GBS,
+                             "mfma_TFLOPs": fl / (v["ms_per_step"] * 1e-3) / 1e12, "frac_of_mfma_pipe": fl / (v["ms_per_step"] * 1e-3) / 1e12 / peak}
+    out["mfma_pipe"] = what
+    out["north_star_note"] = ("BASELINE.json asks for >= 70 % of the bf16 MFMA roofline on the assignment GEMM.  That GEMM does 128 FLOP per "
+                              "uint8 input byte ([B*300,1152] x [1152,64]), below the ~312 FLOP/B ridge of a 2.5 PFLOP/s pipe over 8 TB/s: "
+                              "reading the frames alone caps it at <= 41 % of the MFMA peak, assignment + aggregation fused in one pass "
+                              "over the frames at <= 82 % (SURVEY.md section 7).  The bound that applies is HBM: frac_of_hbm is the "
+                              "roofline fraction of these kernels, frac_of_mfma_pipe is printed for completeness.")
+    return out
+
+
+def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None, batch=None, tag=""):
     """One more configuration, rank 0 / N=1 only: its own timed region (>= 200 steps when a step is < 5 ms) + family times."""
     cfg = WORKLOADS[workload]
-    B = cfg["batch"]
+    B = batch or cfg["batch"]
     g, tg, pool = build(workload, B, 1, 0, dev, None, bf16)
     x, y, nf = pool[0]
     for _ in range(2):
@@ -409,19 +446,20 @@ def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None):
     steps = steps or (200 if probe < 5e-3 else max(10, min(50, int(1.0 / probe))))
     el, run = timed_run(tg, pool, steps, warmup or 3, 1, dev, None)
     fam = profile_pass(lib, run, min(steps, 10), 0)
-    roof = roofline_from(fam, cfg["flops"](B), bf16, step_ms=el / steps * 1e3)
+    bwd_cus = None
+    fwd_x3 = False
+    if workload == "lstm" and not bf16:
+        if lib.yt8m_lstm_persist_bwd_supported(B, LSTM_H):
+            bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
+        fwd_x3 = bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H))
+    roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / steps * 1e3)
     if roof is None and fam:
         roof = {"families": {}, "other_families": fam}
-    if workload == "netvlad" and fam and "netvlad" in fam:
-        # the pooling kernels are HBM-bound on the uint8 frames: report the frame-byte rate too
-        passes = 3.0                                                  # forward rows+cols share one pass when fused; see DESIGN
-        qbytes = float(B) * FRAMES * D_IN
-        roof["hbm"] = {"frame_bytes_per_pass": qbytes, "family_ms_per_step": fam["netvlad"]["ms_per_step"],
-                       "frame_GBps_if_%d_passes" % int(passes): passes * qbytes / (fam["netvlad"]["ms_per_step"] * 1e-3) / 1e9,
-                       "peak_GBps": PEAK_HBM_GBS}
+    if workload == "netvlad" and fam and "vlad_rows" in fam:
+        roof["hbm"] = netvlad_hbm(fam, bf16)
     del tg, g, pool
     torch.cuda.empty_cache()
-    return {"workload": cfg["name"] + (" -- bf16-operand VARIANT" if bf16 else ", fp32"), "dtype": "bf16" if bf16 else "f32",
+    return {"workload": cfg["name"] + (" -- bf16-operand VARIANT" if bf16 else ", fp32") + tag, "dtype": "bf16" if bf16 else "f32",
             "per_gpu_batch": B, "steps": steps, "ms_per_step": el / steps * 1e3, "value": steps * B / el, "unit": "videos/s",
             "roofline": roof}
 
@@ -533,10 +571,10 @@ def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048, state=None):
                        " -- continued from the GAP leg's trained weights (fresh Adam state on both sides) on its teacher shard")}
 
 
-def _pick_threads(probe_fn):
+def _pick_threads(probe_fn, candidates=None):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best, best_t = None, None
-    for cores in sorted({c for c in (usable, 64, 32, 16) if 1 <= c <= usable}, reverse=True):
+    for cores in sorted({c for c in (candidates or (usable, 64, 32, 16)) if 1 <= c <= usable}, reverse=True):
         torch.set_num_threads(cores)
         probe_fn()
         t0 = time.perf_counter()
@@ -549,16 +587,15 @@ def _pick_threads(probe_fn):
 
 
 def cpu_baseline(workload, seconds, min_steps=10, max_seconds=120.0):
-    """Times the torch-CPU fp32 restatement of the same training step on the host cores (a reported baseline, not a
-    target; TF1 itself is not runnable here).  Bounded sample: reduced batch for the frame-level step (its time per step barely
-    depends on B below ~16: every frame re-streams the 35 MB cell weights and accumulates a 35 MB weight gradient, as the
-    reference's while_loop does), at least `min_steps` timed steps.  Thread count: the best of {all usable cores, 64, 32, 16} on a
-    cheap probe for the video-level step; 32 for the frame-level one (oversubscribed MKL is far slower on its small products) --
-    the same step on ALL usable cores is timed beside it (`all_cores`, 2 steps)."""
+    """Times the torch-CPU fp32 restatement of the same training step on the host cores (a reported baseline, not a target; TF1
+    itself is not runnable here).  Bounded sample.  Frame-level step: B = 32 videos x 300 frames, thread count
+    chosen by a probe (a 12-frame cut of the same step at every candidate count), and TWO implementations of the same function
+    side by side -- the per-frame port (oracle/torch_ref.LstmTrainStepCPU: a Python loop over frames like dynamic_rnn's
+    while_loop) and its torch.nn.LSTM twin (LstmTrainStepOneDNN: PyTorch's fused CPU LSTM; tests/test_oracle_thirdparty.py proves
+    it computes the same cell) -- `value` is the FASTER of the two: a baseline should not lose because its loop is in Python."""
     from oracle import torch_ref
     gen = torch.Generator().manual_seed(1)
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    allc = None
     if workload == "moe":
         B = 1024
         x = torch.rand((B, D_IN), generator=gen) * 4.0 - 2.0
@@ -566,22 +603,38 @@ def cpu_baseline(workload, seconds, min_steps=10, max_seconds=120.0):
         probe = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=128, dtype=torch.float32, seed=0)
         cores, usable = _pick_threads(lambda: probe.step(x[:128], y[:128]))
         st = torch_ref.MoeTrainStepCPU(D=D_IN, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
-        stepf = lambda: st.step(x, y)
-        what = "fp32 MoeModel training step"
-    elif workload == "lstm":
-        B = 8                                                       # bounded sample: 8 videos x 300 frames per CPU step
-        q = torch.randint(0, 256, (B, FRAMES, D_IN), generator=gen, dtype=torch.uint8)
-        y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
-        nf = torch.full((B,), FRAMES, dtype=torch.int32)
-        st = torch_ref.LstmTrainStepCPU(D=D_IN, H=LSTM_H, L=LSTM_L, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
-        cores = min(usable, 32)                                     # the per-frame products are small: more threads lose
-        stepf = lambda: st.step(q, nf, y)
-        what = "fp32 LstmModel (2x1024, F=300) + MoE head training step"
-        if usable > cores:                                          # the all-cores number beside it
-            allc = _allcores_twin(B, usable)
-        torch.set_num_threads(cores)
-    else:
+        r = _time_steps(lambda: st.step(x, y), seconds, min_steps, max_seconds)
+        return {"value": r["steps"] * B / r["seconds"], "unit": "videos/s", "cores": cores, "kind": "port", "timed_steps": r["steps"],
+                "batch": B, "seconds": r["seconds"], "usable_cores": usable,
+                "sample": "%d steps of the same fp32 MoeModel training step at B=%d on torch-CPU (oracle/torch_ref.py; TF1 itself is not "
+                          "runnable here), %.1f s, %d threads of %d usable cores" % (r["steps"], B, r["seconds"], cores, usable)}
+    if workload != "lstm":
         return None
+    B = 32
+    q = torch.randint(0, 256, (B, FRAMES, D_IN), generator=gen, dtype=torch.uint8)
+    y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
+    nf = torch.full((B,), FRAMES, dtype=torch.int32)
+    impls = {}
+    budget = max_seconds / 2.0
+    for name, cls, steps_min in (("per_frame_port", torch_ref.LstmTrainStepCPU, 3), ("nn_lstm_twin", torch_ref.LstmTrainStepOneDNN, min_steps)):
+        st = cls(D=D_IN, H=LSTM_H, L=LSTM_L, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
+        short_q, short_nf = q[:, :12].contiguous(), torch.full((B,), 12, dtype=torch.int32)
+        cores, _ = _pick_threads(lambda: st.step(short_q, short_nf, y), candidates=(min(usable, 128), 64, 32, 16))
+        r = _time_steps(lambda: st.step(q, nf, y), min(seconds, budget), steps_min, budget)
+        impls[name] = {"value": r["steps"] * B / r["seconds"], "unit": "videos/s", "cores": cores, "timed_steps": r["steps"],
+                       "seconds": r["seconds"], "is": cls.__doc__.split(".")[0].strip()[:160]}
+        del st
+    best = max(impls, key=lambda k: impls[k]["value"])
+    bi = impls[best]
+    return {"value": bi["value"], "unit": "videos/s", "cores": bi["cores"], "kind": "port", "implementation": best,
+            "timed_steps": bi["timed_steps"], "batch": B, "seconds": bi["seconds"], "usable_cores": usable, "implementations": impls,
+            "sample": "%d steps of the same fp32 LstmModel (2x1024, F=300) + MoE head training step at B=%d on torch-CPU (oracle/"
+                      "torch_ref.py, %s; TF1 itself is not runnable here), %.1f s, %d threads (chosen by probe) of %d usable cores; the "
+                      "other implementation is timed beside it under `implementations`" % (bi["timed_steps"], B, best, bi["seconds"],
+                                                                                           bi["cores"], usable)}
+
+
+def _time_steps(stepf, seconds, min_steps, max_seconds):
     stepf()                                          # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -589,44 +642,7 @@ def cpu_baseline(workload, seconds, min_steps=10, max_seconds=120.0):
         n += 1
         el = time.perf_counter() - t0
         if (el >= seconds and n >= min_steps) or n >= 200 or el >= max_seconds:
-            break
-    return {"value": n * B / el, "unit": "videos/s", "cores": cores, "kind": "port", "timed_steps": n, "batch": B, "seconds": el,
-            "usable_cores": usable, "all_cores": allc,
-            "sample": "%d steps of the same %s at B=%d on torch-CPU (oracle/torch_ref.py; TF1 itself is not runnable "
-                      "here), %.1f s, %d threads of %d usable cores" % (n, what, B, el, cores, usable)}
-
-
-def _allcores_twin(B, usable, limit=45.0):
-    """The frame-level CPU step on ALL usable cores, in a child process with a wall limit: with one thread per core the small
-    per-frame products of the port oversubscribe the BLAS pool badly (minutes per step on a 256-core host), and a torch op cannot
-    be interrupted from inside the process."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-allcores-probe", str(B)]
-    t0 = time.perf_counter()
-    try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit).stdout
-        line = [l for l in out.splitlines() if l.startswith("{")]
-        if line:
-            return json.loads(line[-1])
-        return {"cores": usable, "value": None, "unit": "videos/s", "note": "child produced no line"}
-    except subprocess.TimeoutExpired:
-        return {"cores": usable, "value": None, "unit": "videos/s", "steps": 0,
-                "note": "one step of the same port on all %d cores did not finish within %.0f s (oversubscribed BLAS pool): slower than "
-                        "the %d-thread figure" % (usable, time.perf_counter() - t0, min(usable, 32))}
-
-
-def _allcores_child(B):
-    from oracle import torch_ref
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(usable)
-    gen = torch.Generator().manual_seed(1)
-    q = torch.randint(0, 256, (B, FRAMES, D_IN), generator=gen, dtype=torch.uint8)
-    y = torch.rand((B, VOCAB), generator=gen) < (3.4 / VOCAB)
-    nf = torch.full((B,), FRAMES, dtype=torch.int32)
-    st = torch_ref.LstmTrainStepCPU(D=D_IN, H=LSTM_H, L=LSTM_L, V=VOCAB, M=MIX, batch_size=B, dtype=torch.float32, seed=0)
-    t0 = time.perf_counter()
-    st.step(q, nf, y)
-    el = time.perf_counter() - t0
-    print(json.dumps({"cores": usable, "value": B / el, "unit": "videos/s", "steps": 1, "note": "first (cold) step"}))
+            return {"steps": n, "seconds": el}
 
 
 def library_identity():
@@ -654,9 +670,6 @@ def note(msg):
 
 def main():
     a = parse()
-    if a.cpu_allcores_probe:
-        _allcores_child(a.cpu_allcores_probe)
-        return
     maybe_relaunch(a)
     __graft_entry__.load_package()
     import yt8m_amd._lib as L
@@ -680,7 +693,9 @@ def main():
         # the persistent recurrences) runs on one GPU -- what a single-GPU box can measure of the N > 1 path
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
                                 device_id=dev)
-    reducer = parallel.GradReducer() if (world > 1 or a.force_reducer) else None
+    reducer = None
+    if world > 1 or a.force_reducer:
+        reducer = parallel.GradReducer(**({"bucket_bytes": a.dp_bucket_mb << 20} if a.dp_bucket_mb else {}))
     g, tg, pool = build(a.workload, B, world, rank, dev, reducer, bf16)
     if a.pool:
         pool = make_pool(a.workload, B, dev, rank, a.pool)
@@ -689,14 +704,36 @@ def main():
     note("timed region: %.2f ms/step" % (el / a.steps * 1e3))
     params = sum(v.numel() for v in g.trainable_variables())
     import yt8m_amd.seq_ops as seq_ops
-    seq_ops.check_persist_errors()              # a persistent launch that timed out must fail the bench, not skew it
+    persist_timeout = None
+    try:
+        seq_ops.check_persist_errors()          # a persistent launch that timed out must fail the bench, not skew it
+    except Exception as e:                      # ... but every rank's word goes into the line first (a SCALE run must explain itself)
+        persist_timeout = repr(e)
     placement = None
-    if rank == 0 and a.workload == "lstm":
+    if a.workload == "lstm":
         # diagnostics of the timed region (+ warm-up): persistent recurrence workgroups that did not land on the XCD their index
         # suggests lose the L2 sharing of the state fetch -- tells an unlucky placement from a slow kernel
         nl, nw, off = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), ctypes.byref(nw), ctypes.byref(off), 1)
         placement = {"persistent_launches": nl.value, "workgroups": nw.value, "workgroups_off_their_xcd": off.value}
+    # data-parallel timeline of two more (untimed) steps: when each gradient bucket's collective was enqueued and landed relative to
+    # the backward pass, the all-reduce time left exposed behind it -- per rank (parallel.GradReducer.trace)
+    dp_trace = None
+    if reducer is not None and reducer.active:
+        reducer.trace = True
+        run(2, 0)
+        dp_trace = reducer.trace_report()
+        reducer.trace = False
+    per_rank = {"rank": rank, "ms_per_step_local": None, "persist_timeout": persist_timeout, "placement": placement, "dp_trace": dp_trace}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank)
+        per_rank_all = gathered
+    else:
+        per_rank_all = [per_rank]
+    if persist_timeout is not None:
+        raise RuntimeError("rank %d: %s" % (rank, persist_timeout))
+    placement = placement if rank == 0 else None
 
     roof = None
     if not a.no_roofline:
@@ -744,10 +781,13 @@ def main():
 
     extra = []
     if rank == 0 and world == 1 and not a.no_extra and a.workload == "lstm" and not bf16:
-        for wl, b16 in (("moe", False), ("netvlad", False), ("lstm", True), ("composite", True)):
+        for wl, b16, bb in (("moe", False, None), ("netvlad", False, None), ("lstm", True, None), ("composite", True, None),
+                            # per-GPU batch sweep of the headline configuration: more rows per workgroup = more independent
+                            # chains per persistent workgroup; tells the 8-GPU run which per-GPU batch to use
+                            ("lstm", False, 256), ("lstm", False, 512)):
             try:
-                extra.append(extra_line(wl, dev, lib, bf16=b16))
-                note("extra line %s%s done" % (wl, " bf16" if b16 else ""))
+                extra.append(extra_line(wl, dev, lib, bf16=b16, batch=bb, tag=" -- per-GPU batch sweep, B = %d" % bb if bb else ""))
+                note("extra line %s%s%s done" % (wl, " bf16" if b16 else "", " B=%d" % bb if bb else ""))
             except Exception as e:                                    # an extra line must never break the headline
                 extra.append({"workload": WORKLOADS[wl]["name"], "error": repr(e)})
 
@@ -793,7 +833,11 @@ def main():
                "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement,
                "library": library_identity(),
                "reducer": None if reducer is None else {"algo": reducer.algo, "reserved_cus": reducer.reserve_cus, "world": reducer.world,
-                                                        "forced_at_world_1": bool(a.force_reducer and world == 1)}}
+                                                        "bucket_MiB": reducer.bucket_elems * 4 / 2 ** 20,
+                                                        "layer_buckets": bool(seq_ops.DP_LAYER_BUCKETS),
+                                                        "transport": "CabiComm" if reducer.comm is not None else "torch.distributed",
+                                                        "forced_at_world_1": bool(a.force_reducer and world == 1),
+                                                        "per_rank": per_rank_all}}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -38,6 +38,9 @@ int yt8m_prof_get(int family, int64_t* launches, double* total_ms);
  * 2 T B H 4H per launch); families: 0 gemm (fp32 MFMA), 1 moe_fused, 2 elementwise, 3 optimizer, 4 lstm_recurrence (forward),
  * 5 netvlad, 6 lstm_recurrence_bwd, 7 gemm_x3 (fp32 products on the bf16 pipe) */
 int yt8m_prof_get_flops(int family, double* flops);
+/* algorithmic HBM bytes declared the same way by the streaming kernels that are priced against the HBM roof: families 9 vlad_rows,
+ * 10 vlad_cols (the two kernels of the fused NetVLAD pooling, timed inside family 5: uint8 frames + cT / agg) */
+int yt8m_prof_get_bytes(int family, double* bytes);
 
 /* hardware probes (measured ceilings of THIS box, printed next to the roofline numbers):
  * mfma: register-only v_mfma_f32_32x32x2_f32 loop; FLOPs = blocks*4*iters*32*4096.  copy: float4 stream, n%4==0. */

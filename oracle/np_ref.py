@@ -344,6 +344,19 @@ def dbof_model_hidden(x_sampled, Wc, bc, Wh, bh, pooling="max"):
     return relu6(pooled @ Wh + bh)
 
 
+def dbof_model_bn(x_sampled, P, pooling="max", eps=1e-3):
+    """W/all_frame_models/dbof_model.py:57-116 with add_batch_norm=True (the default, :52) on already sampled frames [B,S,D]:
+    input_bn (:66-71) -> cluster matmul (:73-78, no bias under batch norm) -> cluster_bn (:79-84) -> relu6 (:91) -> pooling over
+    frames (:95-96) -> hidden matmul (:98-102) -> hidden1_bn (:103-108) -> relu6 (:115).  P as in torch_ref.dbof_model_bn."""
+    B, S, D = x_sampled.shape
+    r, _, _ = batch_norm_train(x_sampled.reshape(-1, D), P["input_bn/gamma"], P["input_bn/beta"], eps)
+    a, _, _ = batch_norm_train(r @ P["Variable"], P["cluster_bn/gamma"], P["cluster_bn/beta"], eps)
+    a = relu6(a).reshape(B, S, -1)
+    pooled = a.max(axis=1) if pooling == "max" else a.mean(axis=1)
+    h, _, _ = batch_norm_train(pooled @ P["Variable_1"], P["hidden1_bn/gamma"], P["hidden1_bn/beta"], eps)
+    return relu6(h)
+
+
 def netvlad(x, num_frames, Wc, bc, centres, eps=1e-12):
     """SURVEY.md Appendix B (NOT in the reference): soft-assignment + residual aggregation +
     intra-normalisation + L2.  x [B,F,D] (already normalised), Wc [D,K], bc [K], centres [K,D].

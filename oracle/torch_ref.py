@@ -438,3 +438,41 @@ class LstmTrainStepCPU:
         loss.backward()
         self.opt.step()
         return loss.detach(), p.detach()
+
+
+class LstmTrainStepOneDNN:
+    """The same training step as LstmTrainStepCPU with the recurrent stack on torch.nn.LSTM (PyTorch's fused CPU LSTM: one library
+    call per layer and direction instead of 300 Python-level cell steps).  tests/test_oracle_thirdparty.py proves nn.LSTM computes
+    the restatement's function under the gate re-ordering (i, j, f, o) -> (i, f, g, o) with forget_bias folded into the bias; this
+    class only TIMES that form next to the per-frame port (bench.py cpu_baseline: a CPU baseline should not be slow because its
+    loop is written in Python).  Parameters live in nn.LSTM's own layout (weight_ih / weight_hh per layer); every video is F
+    frames long here (the bench's throughput batches), so no packing."""
+
+    def __init__(self, D=1152, H=1024, L=2, V=4716, M=2, batch_size=32, dtype=torch.float32, seed=0, base_lr=0.01):
+        torch.manual_seed(seed)
+        self.M = M
+        self.lstm = torch.nn.LSTM(D, H, num_layers=L, batch_first=True).to(dtype)
+        with torch.no_grad():
+            for l in range(L):
+                getattr(self.lstm, "bias_ih_l%d" % l)[H:2 * H] += 1.0          # forget_bias = 1 (BasicLSTMCell)
+        gen = torch.Generator().manual_seed(seed)
+        S = 2 * L * H
+        self.P = {"gates/weights": xavier_uniform_(torch.empty(S, V * (M + 1), dtype=dtype), gen).requires_grad_(True),
+                  "experts/weights": xavier_uniform_(torch.empty(S, V * M, dtype=dtype), gen).requires_grad_(True),
+                  "experts/biases": torch.zeros(V * M, dtype=dtype).requires_grad_(True)}
+        allp = dict(self.P)
+        for n, p_ in self.lstm.named_parameters():
+            allp["lstm/" + n] = p_
+        reg = ["gates/weights", "experts/weights"] + ["lstm/" + n for n, _ in self.lstm.named_parameters() if n.startswith("weight")]
+        self.opt = TFAdam(allp, reg, base_lr=base_lr, batch_size=batch_size)
+        self.dtype = dtype
+
+    def step(self, q_frames, num_frames, labels):
+        x = l2_normalize(dequantize(q_frames, self.dtype), 2)
+        _, (hn, cn) = self.lstm(x)
+        state = torch.cat([t for l in range(hn.shape[0]) for t in (cn[l], hn[l])], 1)       # [c0 || h0 || c1 || h1]
+        p = moe_fast(state, self.P["gates/weights"], self.P["experts/weights"], self.P["experts/biases"], self.M)
+        loss = cross_entropy(p, labels)
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), p.detach()

@@ -70,7 +70,7 @@ def test_gpus_n_relaunches_itself(monkeypatch):
 
 
 def _latest_line():
-    for name in ("r3_bench_line.json", "r2_bench_line.json"):
+    for name in ("r4_bench_line.json", "r3_bench_line.json", "r2_bench_line.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             line = [l for l in open(path) if l.startswith("{")][-1]
@@ -98,10 +98,53 @@ def test_recorded_line_has_the_contract_fields():
     assert r["blended_bound"]["ms_per_step"] > 0 and 0 < r["blended_bound"]["frac"] <= 1.0
     bwd = r["families"]["lstm_recurrence_bwd"]
     assert bwd["peak"] == 157.3 and bwd["occupied_cus"] == 128 and abs(bwd["frac_of_occupied_cus"] - 2 * bwd["frac"]) < 1e-9
-    assert c["timed_steps"] >= 10 and (c["all_cores"] is None or c["all_cores"]["cores"] == c["usable_cores"])
+    if name.startswith("r3"):
+        assert c["timed_steps"] >= 10 and (c["all_cores"] is None or c["all_cores"]["cores"] == c["usable_cores"])
+    else:                                                           # round 4: see test_round4_line_fields
+        _round4_fields(d)
     lib = d["library"]
     assert len(lib["sha256"]) == 64 and lib["in_tree_default"] and isinstance(lib["env"], dict)
     assert "cpu_twin_full_size" in d["gap_at_20"] and d["gap_at_20"]["cpu_twin_full_size"]["within_target"]
+
+
+def _round4_fields(d):
+    """cpu_baseline at B = 32 with the thread count probed and both implementations of the step; NetVLAD's two streaming kernels
+    against the HBM roof with the north-star note; the per-GPU batch sweep of the headline as extra lines."""
+    c = d["cpu_baseline"]
+    assert c["batch"] == 32 and set(c["implementations"]) == {"per_frame_port", "nn_lstm_twin"} and c["implementation"] in c["implementations"]
+    assert c["value"] == max(v["value"] for v in c["implementations"].values())
+    assert c["implementations"]["nn_lstm_twin"]["timed_steps"] >= 10 and all(v["cores"] >= 1 for v in c["implementations"].values())
+    nv = next(e for e in d["extra"] if e["workload"].startswith("BASELINE configs[2]"))
+    hbm = nv["roofline"]["hbm"]
+    assert set(hbm["kernels"]) == {"vlad_rows", "vlad_cols"} and "41 %" in hbm["north_star_note"] and "82 %" in hbm["north_star_note"]
+    for k in hbm["kernels"].values():
+        assert 0 < k["frac_of_hbm"] <= 1.0 and abs(k["frac_of_hbm"] - k["achieved_GBps"] / 8000.0) < 1e-12 and k["algorithmic_bytes_per_launch"] > 0
+    sweep = {e["per_gpu_batch"]: e for e in d["extra"] if "batch sweep" in e["workload"]}
+    assert set(sweep) == {256, 512}
+    for e in sweep.values():
+        assert e["workload"].startswith("BASELINE configs[3]") and e["dtype"] == "f32" and "lstm_recurrence_bwd" in e["roofline"]["families"]
+
+
+def test_reducer_trace_report_shape():
+    """parallel.GradReducer.trace_report(): nothing traced -> None (the bench line then carries dp_trace: null)."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.load_package()
+    import yt8m_amd.parallel as parallel
+    r = parallel.GradReducer()
+    assert r.trace is False and r.trace_report() is None
+
+
+def test_dp_flags_reach_the_environment(monkeypatch):
+    b = _bench()
+    for k in ("YT8M_DP_ALGO", "YT8M_DP_RESERVED_CUS", "YT8M_DP_LAYER_BUCKETS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--dp-algo", "rs_ag", "--dp-reserved-cus", "32", "--dp-layer-buckets", "1", "--dp-bucket-mb", "64"])
+    a = b.parse()
+    assert os.environ["YT8M_DP_ALGO"] == "rs_ag" and os.environ["YT8M_DP_RESERVED_CUS"] == "32" and os.environ["YT8M_DP_LAYER_BUCKETS"] == "1"
+    assert a.dp_bucket_mb == 64
+    for k in ("YT8M_DP_ALGO", "YT8M_DP_RESERVED_CUS", "YT8M_DP_LAYER_BUCKETS"):
+        monkeypatch.delenv(k, raising=False)                          # parse() wrote os.environ directly
 
 
 def test_family_peaks_follow_the_pipe_the_kernel_issues_on():

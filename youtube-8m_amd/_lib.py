@@ -33,6 +33,7 @@ SIGNATURES = {
     "yt8m_prof_reset": (c_int, []),
     "yt8m_prof_get": (c_int, [c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
     "yt8m_prof_get_flops": (c_int, [c_int, ctypes.POINTER(c_double)]),
+    "yt8m_prof_get_bytes": (c_int, [c_int, ctypes.POINTER(ctypes.c_double)]),
     "yt8m_probe_mfma_f32": (c_int, [c_int, c_int, P, P]),
     "yt8m_probe_mfma_bf16": (c_int, [c_int, c_int, c_int, P, P]),
     "yt8m_probe_copy_f32": (c_int, [P, P, c_int64, P]),

@@ -36,7 +36,9 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
 // ---- per-family hipEvent profiling (bench.py roofline leg) -----------------------------------
 enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LSTM = 4, F_NETVLAD = 5, F_LSTM_BWD = 6, F_GEMM_X3 = 7,
               F_GEMM_X1X3 = 8,   // x3 kernel with a ONE-plane A operand (three bf16 products per fp32 product)
-              F_COUNT = 9 };
+              F_VLAD_ROWS = 9,   // the two streaming kernels of the fused NetVLAD pooling, timed inside the F_NETVLAD scope with their
+              F_VLAD_COLS = 10,  // algorithmic HBM bytes declared (HBM-bound: bench.py reports bytes / time against 8 TB/s)
+              F_COUNT = 11 };
 
 struct ProfScope {
   int fam;
@@ -44,7 +46,8 @@ struct ProfScope {
   bool on;
   hipEvent_t e0, e1;
   double flops;           // algorithmic FLOPs of the launches inside the scope (0: not counted)
-  ProfScope(int family, hipStream_t stream, double algorithmic_flops = 0.0);
+  double bytes;           // algorithmic HBM bytes of the launches inside the scope (0: not counted)
+  ProfScope(int family, hipStream_t stream, double algorithmic_flops = 0.0, double algorithmic_bytes = 0.0);
   ~ProfScope();
 };
 

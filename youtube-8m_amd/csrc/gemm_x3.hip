@@ -200,24 +200,35 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
     // slab of part s of this tile: slot_base + s * rem + rt  (the fixed order 0 .. S-1 of x3_fixup_kernel: bitwise the same sums)
     const float* base = G.ws + (int64_t)(G.slot_base[q] + rt) * (TM * TN);
     const int64_t pstride = (int64_t)G.rem[q] * (TM * TN);
-    for (int i0 = 0; i0 < TM * TN / 4 / 512; i0 += 4) {            // 32 float4 per thread, four in flight per part
-      float4 v[4];
+    // 32 float4 per thread and part.  One workgroup combines a whole tile, so the loads must be deep in flight: eight per part and
+    // up to four parts at once = 32 x 16 B per lane (the accumulators are dead here), summed in part order afterwards.  (The first
+    // form -- four loads, one part at a time -- made the combine a 250 us latency chain per tile: slower than the fix-up kernel.)
+    for (int i0 = 0; i0 < TM * TN / 4 / 512; i0 += 8) {
+      float4 v[8];
+      for (int sp0 = 0; sp0 < nparts; sp0 += 4) {
+        float4 t[4][8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int f = (int)threadIdx.x + 512 * (i0 + u);
-        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc(base), f * 16, 0, AUX_WT));
-      }
-      for (int sp = 1; sp < nparts; ++sp) {
-        const __amdgpu_buffer_rsrc_t rr = slab_rsrc(base + (int64_t)sp * pstride);
+        for (int pp = 0; pp < 4; ++pp) {
+          if (sp0 + pp < nparts) {
+            const __amdgpu_buffer_rsrc_t rr = slab_rsrc(base + (int64_t)(sp0 + pp) * pstride);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int f = (int)threadIdx.x + 512 * (i0 + u);
-          const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, f * 16, 0, AUX_WT));
-          v[u].x += t.x; v[u].y += t.y; v[u].z += t.z; v[u].w += t.w;
+            for (int u = 0; u < 8; ++u)
+              t[pp][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ((int)threadIdx.x + 512 * (i0 + u)) * 16, 0, AUX_WT));
+          }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          if (sp0 + pp < nparts) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (sp0 + pp == 0) v[u] = t[pp][u];
+              else { v[u].x += t[pp][u].x; v[u].y += t[pp][u].y; v[u].z += t[pp][u].z; v[u].w += t[pp][u].w; }
+            }
+          }
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int e = ((int)threadIdx.x + 512 * (i0 + u)) * 4;
         finish_store(g, v[u], m0 + e / TN, n0 + (e % TN));
       }

@@ -453,12 +453,14 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     wx3_done[l] = false;
   }
   std::vector<hipEvent_t> last;
-  // Sub-parts of the BOTTOM layer (knob YT8M_STACK_SUB0 = "n0,n1,.." per backward part in forward-time order; default: the part
-  // that runs last is cut in three).  The bottom layer's last recurrence runs alone on half the chip and everything behind it --
-  // the transposed dz image, two weight-gradient products, the bias pass -- is the tail of the backward pass: with the part cut
-  // into sub-launches only the LAST sub-part's products remain behind the recurrence (profiles/r4_sched_knobs.md).
+  // Sub-parts of the BOTTOM layer (knobs YT8M_STACK_SUB0 = "n0,n1,.." per backward part in forward-time order, or
+  // YT8M_STACK_SUB0_LAST = n for the part that runs last; default 1 = none).  The bottom layer's last recurrence runs alone on half
+  // the chip and its transposed dz image, two weight-gradient products and the bias pass are the tail of the backward pass; cutting
+  // that part into sub-launches leaves only the last sub-part's products behind the recurrence -- measured (profiles/
+  // r4_sched_knobs.md): 23.25 / 23.16 / 23.37 / 23.57 ms/step for 1 / 2 / 3 / 5 sub-parts, i.e. nothing: the weight-gradient stream
+  // is busy from the first double phase to the end, what leaves the tail queues up in front of it.
   int sub0[MAXP];
-  for (int c = 0; c < P.nb; ++c) sub0[c] = (c == 0 && P.L > 1 && P.nb > 1 && !getenv("YT8M_STACK_SUB0")) ? knob("YT8M_STACK_SUB0_LAST", 3) : 1;
+  for (int c = 0; c < P.nb; ++c) sub0[c] = (c == 0 && P.L > 1 && P.nb > 1 && !getenv("YT8M_STACK_SUB0")) ? knob("YT8M_STACK_SUB0_LAST", 1) : 1;
   if (const char* spec = getenv("YT8M_STACK_SUB0")) {
     int n = 0;
     for (const char* q = spec; *q && n < P.nb;) { sub0[n++] = std::max(1, atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }

@@ -783,8 +783,12 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = 0; ra.cs = cssum; ra.cs_bstride = 0; ra.wscale = scale;
   ra.wscale_bstride = 0; ra.bias = bc; ra.bias_bstride = 0; ra.cfw = nullptr; ra.outT = cT; ra.wgmax = wgmax; ra.colpart = colpart;
   ra.B = (int)B; ra.F = (int)F; ra.D = (int)D; ra.Fp = (int)L.Fp; ra.eps = eps;
-  if (nsplit == 2) launch_rows<2, false>(ra, L.nt, L.ranges, s);
-  else launch_rows<1, false>(ra, L.nt, L.ranges, s);
+  const double qbytes = (double)B * (double)F * (double)D, ctbytes = (double)B * NK * (double)L.Fp * 4.0;
+  {                                                              // algorithmic bytes: the frames once + the transposed assignment
+    ProfScope pr(F_VLAD_ROWS, s, 2.0 * qbytes * NK, qbytes + ctbytes + (double)L.nblk * 4096 * 2 * nsplit);
+    if (nsplit == 2) launch_rows<2, false>(ra, L.nt, L.ranges, s);
+    else launch_rows<1, false>(ra, L.nt, L.ranges, s);
+  }
   hipLaunchKernelGGL(vlad_max_to_scale_kernel, dim3(1), dim3(256), 0, s, wgmax, B * L.ranges, escale);
   hipLaunchKernelGGL(vlad_sum_parts_kernel, dim3((unsigned)((B * NK + 255) / 256)), dim3(256), 0, s, colpart, (int)L.ranges, B * NK,
                      n_out);
@@ -792,7 +796,10 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   ca.q = q; ca.cT = cT; ca.scale = escale; ca.out = agg_out; ca.B = (int)B; ca.F = (int)F; ca.D = (int)D; ca.Fp = (int)L.Fp;
   ca.vids = 1;
   const dim3 cgrid((unsigned)((D + 383) / 384), (unsigned)B);
-  launch_cols(ca, nsplit, cgrid, s);
+  {
+    ProfScope pc(F_VLAD_COLS, s, 2.0 * qbytes * NK, qbytes + ctbytes + (double)B * NK * (double)D * 4.0);
+    launch_cols(ca, nsplit, cgrid, s);
+  }
   return launch_status("yt8m_netvlad_fwd_u8");
 }
 
@@ -832,14 +839,21 @@ extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, 
   ra.wscale = scale; ra.wscale_bstride = 1; ra.bias = dn; ra.bias_bstride = NK; ra.cfw = cT; ra.outT = eT;
   ra.wgmax = wgmax; ra.colpart = colpart;
   ra.B = (int)B; ra.F = (int)F; ra.D = (int)D; ra.Fp = (int)L.Fp; ra.eps = eps;
-  if (nsplit == 2) launch_rows<2, true>(ra, L.nt, L.ranges, s);
-  else launch_rows<1, true>(ra, L.nt, L.ranges, s);
+  const double qbytes = (double)B * (double)F * (double)D, ctbytes = (double)B * NK * (double)L.Fp * 4.0;
+  {                                                              // frames + per-video packed weights + c^T read, e^T written
+    ProfScope pr(F_VLAD_ROWS, s, 2.0 * qbytes * NK, qbytes + 2.0 * ctbytes + (double)B * (double)L.nblk * 4096 * 2 * nsplit);
+    if (nsplit == 2) launch_rows<2, true>(ra, L.nt, L.ranges, s);
+    else launch_rows<1, true>(ra, L.nt, L.ranges, s);
+  }
   hipLaunchKernelGGL(vlad_max_to_scale_kernel, dim3(1), dim3(256), 0, s, wgmax, B * L.ranges, escale);
   ColsArgs ca;
   ca.q = q; ca.cT = eT; ca.scale = escale; ca.out = part; ca.B = (int)B; ca.F = (int)F; ca.D = (int)D; ca.Fp = (int)L.Fp;
   ca.vids = (int)L.vids;
   const dim3 cgrid((unsigned)((D + 383) / 384), (unsigned)L.groups);
-  launch_cols(ca, nsplit, cgrid, s);
+  {
+    ProfScope pc(F_VLAD_COLS, s, 2.0 * qbytes * NK, qbytes + ctbytes + (double)L.groups * NK * (double)D * 4.0);
+    launch_cols(ca, nsplit, cgrid, s);
+  }
   if (L.groups > RED2) {
     const int64_t n = NK * D;
     hipLaunchKernelGGL(vlad_part_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256), RED2), dim3(256), 0, s, part, (int)L.groups, n,

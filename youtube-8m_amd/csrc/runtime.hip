@@ -15,9 +15,10 @@ static std::vector<Pending> g_pending;
 static int64_t g_launches[F_COUNT];
 static double g_ms[F_COUNT];
 static double g_flops[F_COUNT];
+static double g_bytes[F_COUNT];
 
-ProfScope::ProfScope(int family, hipStream_t stream, double algorithmic_flops)
-    : fam(family), s(stream), on(g_prof_on), flops(algorithmic_flops) {
+ProfScope::ProfScope(int family, hipStream_t stream, double algorithmic_flops, double algorithmic_bytes)
+    : fam(family), s(stream), on(g_prof_on), flops(algorithmic_flops), bytes(algorithmic_bytes) {
   if (!on) return;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
   (void)hipEventRecord(e0, s);
@@ -27,6 +28,7 @@ ProfScope::~ProfScope() {
   (void)hipEventRecord(e1, s);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_flops[fam] += flops;
+  g_bytes[fam] += bytes;
   g_pending.push_back({fam, e0, e1});
 }
 
@@ -153,7 +155,7 @@ extern "C" int yt8m_graph_cache_clear(void) {
 }
 extern "C" int yt8m_prof_reset(void) {
   yt8m::drain();
-  for (int i = 0; i < yt8m::F_COUNT; ++i) { yt8m::g_launches[i] = 0; yt8m::g_ms[i] = 0.0; yt8m::g_flops[i] = 0.0; }
+  for (int i = 0; i < yt8m::F_COUNT; ++i) { yt8m::g_launches[i] = 0; yt8m::g_ms[i] = 0.0; yt8m::g_flops[i] = 0.0; yt8m::g_bytes[i] = 0.0; }
   return YT8M_OK;
 }
 extern "C" int yt8m_prof_get_flops(int family, double* flops) {
@@ -161,6 +163,13 @@ extern "C" int yt8m_prof_get_flops(int family, double* flops) {
   YT8M_REQUIRE(family >= 0 && family < F_COUNT && flops, YT8M_E_BADARG, "bad family / null out");
   std::lock_guard<std::mutex> lk(g_prof_mu);
   *flops = g_flops[family];
+  return YT8M_OK;
+}
+extern "C" int yt8m_prof_get_bytes(int family, double* bytes) {
+  using namespace yt8m;
+  YT8M_REQUIRE(family >= 0 && family < F_COUNT && bytes, YT8M_E_BADARG, "bad family / null out");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *bytes = g_bytes[family];
   return YT8M_OK;
 }
 extern "C" int yt8m_prof_get(int family, int64_t* launches, double* total_ms) {

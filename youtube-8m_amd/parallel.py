@@ -224,6 +224,46 @@ class GradReducer(object):
         for i in range(len(self._ready)):
             self._ready[i] = False
             self._launched[i] = False
+        if self.trace and torch.cuda.is_available():            # called right before final_loss.backward() (train.TrainGraph.step)
+            self._t_start = torch.cuda.Event(enable_timing=True)
+            self._t_start.record()
+            self._t_buckets = []
+            self._t_end = None
+
+    # ---- tracing (bench.py --gpus N: "a SCALE line that comes back at 4x explains itself") ---------------------------------
+    # With `trace` set, every bucket records when its collective was enqueued (stream order of the compute stream = the moment its
+    # gradients were final) and when it landed (an event on a side stream that waited for the collective only), both relative to the
+    # start of the backward pass; finished_buckets() marks the end of the backward pass.  Off in timed regions: the side stream is a
+    # fifth active stream of the process and costs 0.1-1.7 ms of a headline step on its own.
+    trace = False
+
+    def _trace_launch(self, lo, hi, hs):
+        if not (self.trace and torch.cuda.is_available()):
+            return
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        if getattr(self, "_trace_stream", None) is None:
+            self._trace_stream = torch.cuda.Stream()
+        ev1 = torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self._trace_stream):
+            for h in hs:
+                h.wait()
+            ev1.record()
+        self._t_buckets.append((lo, hi, ev0, ev1))
+
+    def trace_report(self):
+        """Timeline of the most recent traced step (synchronises): per bucket [element range, MB, enqueue / land in ms after the start
+        of the backward pass], the length of the backward pass and the all-reduce time left exposed behind it."""
+        if not getattr(self, "_t_buckets", None) or self._t_end is None:
+            return None
+        torch.cuda.synchronize()
+        t0 = self._t_start
+        bw = t0.elapsed_time(self._t_end)
+        rows = [{"elements": [int(lo), int(hi)], "MB": (hi - lo) * 4 / 1e6, "enqueued_ms": t0.elapsed_time(e0), "landed_ms": t0.elapsed_time(e1)}
+                for lo, hi, e0, e1 in self._t_buckets]
+        last = max(r["landed_ms"] for r in rows)
+        return {"backward_ms": bw, "buckets": rows, "exposed_allreduce_ms": max(0.0, last - bw),
+                "note": "times relative to the start of the backward pass on this rank; exposed = last landing - end of backward"}
 
     def _span(self, i, j):
         tv = self.graph.trainable_variables()
@@ -267,6 +307,7 @@ class GradReducer(object):
                     else:
                         hs.append(dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     pos = end
+                self._trace_launch(lo, hi, hs)
                 self._handles.append((i, j + 1, hs))      # trainable variables [i, j+1) ride on these handles
                 for k in range(i, j + 1):
                     self._launched[k] = True
@@ -280,6 +321,9 @@ class GradReducer(object):
         if not self.active:
             yield (0, n)
             return
+        if self.trace and torch.cuda.is_available() and getattr(self, "_t_end", 0) is None:
+            self._t_end = torch.cuda.Event(enable_timing=True)  # the caller's backward() has returned: end of the pass in stream order
+            self._t_end.record()
         self._flush(final=True)
         for lo, hi, hs in self._handles:
             for h in hs:

@@ -79,6 +79,7 @@ def _prefetched(reader, filenames, batch_size, device, check_crc, num_threads, q
     _lib.check(L.yt8m_prefetch_open(paths, len(files), int(frame_level), names, sizes, len(reader.feature_names),
                                     getattr(reader, "max_frames", 1), reader.num_classes, batch_size, int(num_threads),
                                     int(queue_depth), int(check_crc), ctypes.byref(h)))
+    copy_stream = None
     try:
         data, nfp, labp, idp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         stride, n, pinned = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
@@ -98,10 +99,19 @@ def _prefetched(reader, filenames, batch_size, device, check_crc, num_threads, q
             else:
                 feat = _view(data.value, (k, D), torch.float32)
                 extra = None
-            if device is not None:                       # the slot is lent: the copies must finish before the next acquire
-                feat, lab = feat.to(device, non_blocking=True), lab.to(device, non_blocking=True).bool()
-                extra = extra.to(device, non_blocking=True) if extra is not None else torch.ones(k, device=device)
-                torch.cuda.current_stream().synchronize()
+            if device is not None:
+                # The slot is lent: its copies must finish before the next acquire.  They run on a copy stream of their own, and only
+                # THAT stream is waited for -- synchronising the consumer's stream here would also wait for the training step it has
+                # queued, i.e. serialise the PCIe transfer with the step instead of hiding it under it (tools/reader_bench.py).
+                cur = torch.cuda.current_stream(device)
+                if copy_stream is None:
+                    copy_stream = torch.cuda.Stream(device=device)
+                with torch.cuda.stream(copy_stream):
+                    feat, lab = feat.to(device, non_blocking=True), lab.to(device, non_blocking=True).bool()
+                    extra = extra.to(device, non_blocking=True) if extra is not None else torch.ones(k, device=device)
+                copy_stream.synchronize()
+                for t in (feat, lab, extra):
+                    t.record_stream(cur)                 # allocated on the copy stream, consumed on the caller's
             else:
                 feat, lab = feat.clone(), lab.bool()
                 extra = extra.clone() if extra is not None else torch.ones(k)

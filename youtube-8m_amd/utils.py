@@ -1,4 +1,6 @@
 """Helpers mirroring W/utils.py that sit on the hot path."""
+import logging
+
 import torch
 
 from . import ops
@@ -17,9 +19,9 @@ def GetListOfFeatureNamesAndSizes(feature_names, feature_sizes):
     """W/utils.py:140-161."""
     list_of_feature_names = [n.strip() for n in feature_names.split(",")]
     list_of_feature_sizes = [int(s) for s in feature_sizes.split(",")]
-    if len(list_of_feature_names) != len(list_of_feature_sizes):
-        raise ValueError("length of the feature names (=%r) != length of feature sizes (=%r)"
-                         % (len(list_of_feature_names), len(list_of_feature_sizes)))
+    if len(list_of_feature_names) != len(list_of_feature_sizes):          # the reference logs and carries on (:155-158)
+        logging.error("length of the feature names (=" + str(len(list_of_feature_names)) + ") != length of feature "
+                      "sizes (=" + str(len(list_of_feature_sizes)) + ")")
     return list_of_feature_names, list_of_feature_sizes
 
 
