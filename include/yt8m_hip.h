@@ -149,6 +149,12 @@ int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
  * ([C rows, K = R]; rowscale [R]).  Any image may be NULL; rowscale and trans_scaled come together. */
 int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
                      void* trans, void* trans_scaled, yt8m_stream_t stream);
+/* the same pass with per-tile column sums: colpart / colpart_scaled (either may be NULL; [ceil(R / 64), C] floats each) receive the
+ * sums over the 64-row tiles of scale * src, plain and rowscale-weighted.  The recurrent stack takes the bias gradient colsum(dz)
+ * (BasicLSTMCell's biases, W/all_frame_models/lstm_model.py:34-40) and the rank-1 remainder colsum(r (.) dz) of the uint8 layer-0
+ * weight gradient from the pass that writes dz's operand images: one yt8m_colsum_f32 over the partial matrix finishes them. */
+int yt8m_x3_split_colsum(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
+                         void* trans, void* trans_scaled, float* colpart, float* colpart_scaled, yt8m_stream_t stream);
 /* fp32 [rows, cols] (row stride ld) -> bf16 (round to nearest even); transpose != 0 writes dst as [cols, rows].
  * dst_ld: row stride of dst in bf16 elements (0 = dense).  The training path pads it to a multiple of 8 so that every bf16
  * row starts 16-byte aligned and the GEMMs stay on their LDS-DMA path (V*(M+1) = 14148 is not a multiple of 8). */

@@ -30,9 +30,14 @@ def _check(name, got, ref, rel):
     to its largest entry (top-20 values)."""
     assert got.numel() == ref["n"], (name, got.numel(), ref["n"])
     g = got.detach().double().flatten()
-    scale = ref["abs_sum"] + 1e-30
+    # floor: a tensor whose true value is zero (the attention biases: a constant added to an attention's logits over all frames does
+    # not move its softmax over frames, so their gradient vanishes identically -- fp64 gives 1e-17, fp32 products 1e-9) is compared on
+    # the scale of fp32 rounding of O(1) terms, not on its own
+    scale = ref["abs_sum"] + 1e-6 * ref["n"]
     assert abs(float(g.sum()) - ref["sum"]) <= rel * scale, (name, "sum", float(g.sum()), ref["sum"], scale)
     assert abs(float(g.abs().sum()) - ref["abs_sum"]) <= rel * scale, (name, "abs_sum", float(g.abs().sum()), ref["abs_sum"])
+    if ref["abs_sum"] < 1e-9 * ref["n"]:
+        return                                                      # nothing but rounding noise to rank
     idx = torch.tensor(ref["top_idx"], device=g.device)
     vals = g[idx].cpu().numpy()
     top = np.asarray(ref["top_val"])

@@ -113,6 +113,7 @@ def run_config(name, model_cls, B, paths, nvid, rec_bytes, threads, steps, dev):
     it = rd.prepare_reader(paths, batch_size=B, device=dev, check_crc=False, num_threads=4)
     _, q0, y0, nf0 = next(it)
     it.close()
+    assert q0.shape[0] == B, "short batch %d: shards hold fewer than B videos" % q0.shape[0]
     for _ in range(3):
         tg.step(q0, y0, nf0)
     torch.cuda.synchronize()
@@ -127,7 +128,7 @@ def run_config(name, model_cls, B, paths, nvid, rec_bytes, threads, steps, dev):
             res = {}
             for mode in ("decode", "feed", "fed"):
                 it = rd.prepare_reader(paths, batch_size=B, device=None if mode == "decode" else dev, check_crc=crc, num_threads=nt,
-                                       queue_depth=4)
+                                       queue_depth=nt + 2, copy=False)      # a worker decodes a whole batch into one slot: slots >= threads
                 n, t0 = 0, None
                 for _, q, y, nf in it:
                     if t0 is None:                                   # the first batch pays thread start-up and the first page faults
@@ -155,9 +156,9 @@ def run_config(name, model_cls, B, paths, nvid, rec_bytes, threads, steps, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--videos", type=int, default=4096)
-    ap.add_argument("--shards", type=int, default=16)
-    ap.add_argument("--threads", default="4,8,16,32")
+    ap.add_argument("--videos", type=int, default=8192)
+    ap.add_argument("--shards", type=int, default=8, help="batches never span shards: videos / shards must be >= the largest batch (1024)")
+    ap.add_argument("--threads", default="4,8,16")
     ap.add_argument("--steps", type=int, default=24)
     a = ap.parse_args()
     lib = L.lib()
@@ -169,6 +170,7 @@ def main():
     print("host: %d usable cores; device: %s" % (len(os.sched_getaffinity(0)), torch.cuda.get_device_name(0)))
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
         t0 = time.perf_counter()
+        assert a.videos // a.shards >= 1024, "a shard must hold at least one configs[2] batch of 1024 videos"
         paths, nvid, rec_bytes = write_shards(d, a.videos, a.shards, lib)
         print("wrote %d videos (%.2f GB) into %s in %.1f s (page-cache resident: this measures decode + copy, not the disks)" % (
             nvid, nvid * rec_bytes / 1e9, d, time.perf_counter() - t0))

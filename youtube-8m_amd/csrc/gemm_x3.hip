@@ -203,8 +203,21 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
     // 32 float4 per thread and part.  One workgroup combines a whole tile, so the loads must be deep in flight: eight per part and
     // up to four parts at once = 32 x 16 B per lane (the accumulators are dead here), summed in part order afterwards.  (The first
     // form -- four loads, one part at a time -- made the combine a 250 us latency chain per tile: slower than the fix-up kernel.)
+    const bool cvec = (g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
     for (int i0 = 0; i0 < TM * TN / 4 / 512; i0 += 8) {
-      float4 v[8];
+      float4 v[8], oldc[8];
+      bool fast[8];
+      // the values C already holds (beta = 1: weight gradients accumulate over time parts) are requested FIRST, with the slabs: read
+      // one by one inside the store loop they were eight dependent round trips per chunk (the second form of this combine: 23.7 ms
+      // per headline step against 23.0 with the separate fix-up kernel)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = ((int)threadIdx.x + 512 * (i0 + u)) * 4;
+        const int row = m0 + e / TN, col = n0 + (e % TN);
+        fast[u] = cvec && row < g.M && col + 3 < g.N;
+        oldc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fast[u] && g.accumulate) oldc[u] = *reinterpret_cast<const float4*>(g.C + (int64_t)row * g.ldc + col);
+      }
       for (int sp0 = 0; sp0 < nparts; sp0 += 4) {
         float4 t[4][8];
 #pragma unroll
@@ -230,7 +243,16 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = ((int)threadIdx.x + 512 * (i0 + u)) * 4;
-        finish_store(g, v[u], m0 + e / TN, n0 + (e % TN));
+        const int row = m0 + e / TN, col = n0 + (e % TN);
+        if (!fast[u]) { finish_store(g, v[u], row, col); continue; }      // edges / unaligned C: the general path
+        float4 w = v[u];
+        if (g.rscale || g.cs || g.alpha != 1.0f) w = affine(g, w, row, col);
+        if (g.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+          w.x += bv.x; w.y += bv.y; w.z += bv.z; w.w += bv.w;
+        }
+        if (g.accumulate) { w.x += oldc[u].x; w.y += oldc[u].y; w.z += oldc[u].z; w.w += oldc[u].w; }
+        *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = w;
       }
     }
     return;
@@ -578,10 +600,15 @@ __device__ __forceinline__ void store_block(const float (&v)[16], float* __restr
 // rowscale / trans_s (both or neither): a second transposed image whose element (c, r) is rowscale[r] * scale * src[r][c] -- the
 // operand r (.) dz of the layer-0 weight gradient on uint8 frames -- from the same pass over src.
 // NP = 1: the ONE-plane image of the bfloat16 roundings (operands of the b1 kernel: yt8m_bf16_image).
+// colpart / colpart_s (either may be null): per-tile column sums of the (scaled) source -- row blockIdx.y of a [ceil(R / 64), Cc]
+// matrix of partial sums, plain and rowscale-weighted -- so that the bias gradient colsum(dz) and the rank-1 remainder
+// colsum(r (.) dz) of the recurrent layers ride on the pass that reads dz anyway instead of two more passes over it at the very end
+// of the backward pass (a fixed-order sum of the partials follows: deterministic).
 template <int NP>
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
                                                        float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
-                                                       float* __restrict__ trans_s) {
+                                                       float* __restrict__ trans_s, float* __restrict__ colpart = nullptr,
+                                                       float* __restrict__ colpart_s = nullptr) {
   __shared__ float T[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
@@ -606,6 +633,20 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
     }
   }
   __syncthreads();
+  if ((colpart || colpart_s) && t < 128) {                          // threads 0-63: plain sums, 64-127: weighted sums (rows >= R are 0)
+    const int c = t & 63;
+    const bool weighted = t >= 64;
+    float* dst = weighted ? colpart_s : colpart;
+    if (dst && c0 + c < Cc) {
+      float acc = 0.f;
+      if (weighted) {
+        for (int r = 0; r < 64; ++r) acc += (r0 + r < R ? rowscale[r0 + r] : 0.f) * T[r][c];
+      } else {
+        for (int r = 0; r < 64; ++r) acc += T[r][c];
+      }
+      dst[(int64_t)blockIdx.y * Cc + c0 + c] = acc;
+    }
+  }
   const int a = t & 63, blk = t >> 6;                               // row of the image within the tile, K block within the tile
   if (plain) {
     const int KB = (Cc + 15) >> 4;
@@ -656,7 +697,7 @@ extern "C" int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld,
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<3>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
-                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr);
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   return launch_status("x3_split_kernel");
 }
 
@@ -674,7 +715,7 @@ extern "C" int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t l
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<1>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
-                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr);
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   return launch_status("x3_split_kernel");
 }
 
@@ -693,6 +734,27 @@ extern "C" int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t 
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<3>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled));
+  return launch_status("x3_split_kernel");
+}
+
+// yt8m_x3_split_ex plus per-tile column sums from the same pass: colpart / colpart_scaled (either may be NULL) receive rows
+// [0, ceil(R / 64)) of a [*, C] matrix of partial sums over 64-row tiles of `src` (x scale; the scaled one weighted by rowscale).
+// A caller that splits a tall matrix in several row ranges (the recurrent stack's time parts, each a multiple of 64 rows) points
+// colpart at the range's first tile row and finishes with ONE yt8m_colsum_f32 over the whole partial matrix.
+extern "C" int yt8m_x3_split_colsum(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
+                                    void* trans, void* trans_scaled, float* colpart, float* colpart_scaled, yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans || trans_scaled), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE((rowscale != nullptr) == (trans_scaled != nullptr || colpart_scaled != nullptr), YT8M_E_BADARG,
+               "rowscale comes with trans_scaled / colpart_scaled");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans) | reinterpret_cast<uintptr_t>(trans_scaled)) & 15) == 0,
+               YT8M_E_BADARG, "x3 images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<3>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled), colpart, colpart_scaled);
   return launch_status("x3_split_kernel");
 }
 

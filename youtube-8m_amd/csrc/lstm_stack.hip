@@ -66,6 +66,8 @@ struct Plan {
   int64_t dz[MAXL], dbuf[MAXL], work[MAXL];                // backward: dz [F,B,4H], dout of the layer below [F,B,H], running (dh, dc)
   int64_t dz3[MAXL], wx3[MAXL], dzT3[MAXL], dzT3s, csr, dbdummy; // chunk images (dzT3 per layer: the chains may run on two streams)
   int64_t xT[MAXL], hT[MAXL];                              // whole-sequence transposed images (layer input / h_{t-1})
+  int64_t cpart[MAXL], cparts;                             // [F B / 64, 4H] per-tile column sums of dz (plain; layer 0 on uint8: r-weighted)
+  bool colparts;                                           // every backward part is a multiple of 64 frame rows: the sums ride on the split
   int64_t scratch_bytes;
 };
 
@@ -167,6 +169,11 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, bmax)) : 0;
   p.csr = o; o += up256(H4 * 4);
   p.dbdummy = o; o += up256(H4 * 4);
+  p.colparts = knob("YT8M_STACK_COLPARTS", 1) != 0;
+  for (int c = 0; c < p.nb; ++c) p.colparts = p.colparts && (p.bp[c].t0 * p.B) % 64 == 0 && (p.bp[c].T * p.B) % 64 == 0;
+  const int64_t cp = p.colparts ? up256(((p.FB + 63) / 64) * H4 * 4) : 0;
+  for (int l = 0; l < p.L; ++l) { p.cpart[l] = o; o += cp; }
+  p.cparts = o; o += p.u8 ? cp : 0;
   p.scratch_bytes = o;
   return nullptr;
 }
@@ -473,7 +480,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
      if (nsub > 1) {                                         // equal sub-parts on 16-frame-row boundaries, else the whole part
        const int64_t step = (P.bp[c].T + nsub - 1) / nsub;
        int k = 0;
-       bool ok = (step * B) % 16 == 0;
+       bool ok = (step * B) % (P.colparts ? 64 : 16) == 0;
        for (int64_t u = 0; ok && u < P.bp[c].T; u += step) sp[k++] = {P.bp[c].t0 + u, std::min(step, P.bp[c].T - u)};
        nsub = ok ? k : 1;
      }
@@ -525,14 +532,24 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       if (dW[l]) {
         if (l == 0 && P.u8) {
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
-          RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), sw));
+          if (P.colparts)                                    // bias gradient + rank-1 remainder: per-tile sums from this pass
+            RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s),
+                                    at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4, at<float>(scratch, P.cparts) + (t0 * B / 64) * H4, sw));
+          else
+            RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), sw));
           RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, at<char>(scratch, P.dzT3s), 0, dW[0], H4,
                                   nullptr, U8_ALPHA, nullptr, nullptr, 0.f, bW, gw, P.gws_bytes, sw));
           yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0,
                                   dW[0] + D * H4, H4, nullptr, bW};
           RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, sw));
         } else {
-          if (!fused_t) RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
+          if (!fused_t) {
+            if (P.colparts && db[l])
+              RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, nullptr, nullptr, at<char>(scratch, P.dzT3[l]), nullptr,
+                                      at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4, nullptr, sw));
+            else
+              RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
+          }
           yt8m_gemm_problem pr[2] = {
               {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
               {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
@@ -542,13 +559,20 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       }
       if (lastpart) {
         const float bb = beta_b ? beta_b[l] : 0.f;
+        const int64_t ntile = (FB + 63) / 64;                 // rows of the per-tile partial sums (P.colparts)
         if (dW[l] && l == 0 && P.u8) {
           float* dbo = db[0] ? db[0] : at<float>(scratch, P.dbdummy);
-          RC(yt8m_colsum_weighted_f32(dz, FB, H4, H4, at<float>(tape, P.rrow), dbo, db[0] ? bb : 0.f, at<float>(scratch, P.csr), gw,
-                                      P.gws_bytes, sw));
+          if (P.colparts) {                                  // fixed-order sums of the partials the split passes left: 10 MB instead of
+            RC(yt8m_colsum_f32(at<float>(scratch, P.cparts), ntile, H4, H4, at<float>(scratch, P.csr), 0.f, gw, P.gws_bytes, sw));   // 629
+            if (db[0]) RC(yt8m_colsum_f32(at<float>(scratch, P.cpart[0]), ntile, H4, H4, db[0], bb, gw, P.gws_bytes, sw));
+          } else {
+            RC(yt8m_colsum_weighted_f32(dz, FB, H4, H4, at<float>(tape, P.rrow), dbo, db[0] ? bb : 0.f, at<float>(scratch, P.csr), gw,
+                                        P.gws_bytes, sw));
+          }
           RC(yt8m_rank1_add_rows_f32(dW[0], D, H4, H4, at<float>(scratch, P.csr), U8_BETA, sw));
         } else if (db[l]) {
-          RC(yt8m_colsum_f32(dz, FB, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+          if (P.colparts && dW[l] && !fuse_dz) RC(yt8m_colsum_f32(at<float>(scratch, P.cpart[l]), ntile, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+          else RC(yt8m_colsum_f32(dz, FB, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
         }
         // the layer's gradients are final here -- layer L-1 first, a whole last part of weight-gradient work before layer 0's: a
         // data-parallel host starts each layer's all-reduce from this point (yt8m_lstm_stack_layer_done_wait)

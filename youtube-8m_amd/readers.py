@@ -67,7 +67,7 @@ def _view(ptr, shape, dtype):
     return torch.from_numpy(arr).view(*shape)
 
 
-def _prefetched(reader, filenames, batch_size, device, check_crc, num_threads, queue_depth, frame_level):
+def _prefetched(reader, filenames, batch_size, device, check_crc, num_threads, queue_depth, frame_level, copy=True):
     """Batches from the native multi-threaded shard prefetcher (yt8m_prefetch_*): the reference's num_readers reader threads
     (W/train.py:199-209).  Same tuples as the sequential path; batches never span shards."""
     files = _files(filenames)
@@ -112,9 +112,11 @@ def _prefetched(reader, filenames, batch_size, device, check_crc, num_threads, q
                 copy_stream.synchronize()
                 for t in (feat, lab, extra):
                     t.record_stream(cur)                 # allocated on the copy stream, consumed on the caller's
-            else:
+            elif copy:
                 feat, lab = feat.clone(), lab.bool()
                 extra = extra.clone() if extra is not None else torch.ones(k)
+            else:                                        # zero-copy views of the lent slot: valid until the next batch is requested
+                extra = extra if extra is not None else torch.ones(k)
             yield vids, feat, lab, extra
     finally:
         L.yt8m_prefetch_close(h)
@@ -182,12 +184,13 @@ class YT8MFrameFeatureReader(BaseReader):
         self.feature_names = list(feature_names)
         self.max_frames = max_frames
 
-    def prepare_reader(self, filenames, batch_size=128, device=None, check_crc=True, num_threads=0, queue_depth=4):
+    def prepare_reader(self, filenames, batch_size=128, device=None, check_crc=True, num_threads=0, queue_depth=4, copy=True):
         """Yields (video_ids, q uint8 [n, max_frames, D], labels bool [n, num_classes], num_frames int32 [n]).
-        num_threads > 0: the native multi-threaded shard prefetcher (--num_readers)."""
+        num_threads > 0: the native multi-threaded shard prefetcher (--num_readers); with device=None and copy=False its batches
+        are zero-copy views of the prefetcher's pinned slot (labels stay uint8), valid until the next batch is requested."""
         assert len(self.feature_names) > 0, "No feature selected: feature_names is empty!"
         if num_threads > 0:
-            yield from _prefetched(self, filenames, batch_size, device, check_crc, num_threads, queue_depth, True)
+            yield from _prefetched(self, filenames, batch_size, device, check_crc, num_threads, queue_depth, True, copy)
             return
         names, sizes = _c_names(self.feature_names, self.feature_sizes)
         D = sum(self.feature_sizes)
