@@ -100,7 +100,7 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
               flush=True)
 
 
-def timing_bwd(B=128, F=300, H=1024):
+def timing_bwd(B=int(os.environ.get("PCHECK_B", "128")), F=300, H=1024):
     lib = L.lib()
     from yt8m_amd.ops import _p, _stream
     gates = torch.rand((F, B, 4 * H), device=dev)
@@ -127,6 +127,9 @@ def timing_bwd(B=128, F=300, H=1024):
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bwd":           # stand-alone backward kernel only (A/B of kernel variants)
+        timing_bwd()
+        sys.exit(0)
     compare("small cold H=256", 8, 9, 64, 256, 2, 1, 1)
     compare("pad rows H=512", 50, 12, 96, 512, 2, 2, 1)
     compare("headline shape short", 128, 16, 1152, 1024, 2, 1, 0)

@@ -123,6 +123,7 @@ def run_config(name, model_cls, B, paths, nvid, rec_bytes, threads, steps, dev):
     torch.cuda.synchronize()
     resident = steps * B / (time.perf_counter() - t0)
     print("   resident (inputs in HBM): %9.0f videos/s  (%.2f ms/step)" % (resident, B / resident * 1e3))
+    paths = list(paths) * (4 if B >= 1024 else 2)                # several passes over the shards: steady state, not the pre-filled queue
     for crc in (False, True):
         for nt in threads:
             res = {}
@@ -137,8 +138,6 @@ def run_config(name, model_cls, B, paths, nvid, rec_bytes, threads, steps, dev):
                     if mode == "fed":
                         tg.step(q, y, nf)
                     n += q.shape[0]
-                    if mode == "fed" and n >= steps * B:
-                        break
                 if mode != "decode":
                     torch.cuda.synchronize()
                 el = time.perf_counter() - t0

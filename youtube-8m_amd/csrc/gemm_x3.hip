@@ -71,10 +71,10 @@ __device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int 
 // of a round instead of a whole one.  full / rem / S come from the shape of problem q ALONE, so a product is summed in the same
 // order whether it is launched by itself or inside a group.  Parts park raw accumulators in ws[slot_base[q] + item][256][256]
 // with write-through stores and take a ticket on the tile's arrival counter; the part that arrives LAST sums all S slabs in the
-// fixed order 0 .. S-1 (so the result does not depend on which part that was) and runs the epilogue -- the combine rides on the
-// GEMM launch instead of a kernel of its own (round 4: the 13 x3_fixup_kernel launches of a headline step were 0.68 ms of the
-// weight-gradient stream plus two launch seams each; MI355X_MICROARCH.md "splitk-seam": write-through slabs + ticket).
-// x3_fixup_kernel is kept as the checked alternative (YT8M_X3_FIXUP_KERNEL=1, or when no counter block could be allocated).
+// fixed order 0 .. S-1 (so the result does not depend on which part that was) and runs the epilogue -- the combine can ride on the
+// GEMM launch instead of a kernel of its own (MI355X_MICROARCH.md "splitk-seam": write-through slabs + ticket), or x3_fixup_kernel
+// sums the slabs in the same order as a separate pass.
+// Built, parity-checked and measured in round 4 -- and left OFF by default (YT8M_X3_FUSED_COMBINE=1 turns it on): see TileCounters.
 struct XGroup {
   XArgs p[4];
   int full_base[5];     // unsplit tiles, cumulative: workgroups [0, full_base[4]) in XCD-contiguous order
@@ -769,7 +769,12 @@ struct TileCounters {
   bool failed[16] = {false};
   uint32_t next[16] = {0};
   unsigned* take(int n) {
-    static const bool off = getenv("YT8M_X3_FIXUP_KERNEL") != nullptr && atoi(getenv("YT8M_X3_FIXUP_KERNEL")) != 0;
+    // Measured (profiles/r4_sched_knobs.md): correct and bitwise equal, but NOT faster than the separate pass where it was meant to
+    // pay -- 23.67 against 23.36 ms per headline step, 1.00 / 1.01 ms configs[1], 5.68 / 5.64 configs[2].  A 256-thread fix-up
+    // workgroup needs no LDS and 20 VGPRs: it runs on CUs the persistent recurrences occupy (they leave 44 VGPRs per lane and 4 KB of
+    // LDS), i.e. for free beside them, while a GEMM workgroup that stays to combine keeps its 144 KB of LDS and the recurrence that
+    // is waiting for that CU.  Opt-in: YT8M_X3_FUSED_COMBINE=1.
+    static const bool off = getenv("YT8M_X3_FUSED_COMBINE") == nullptr || atoi(getenv("YT8M_X3_FUSED_COMBINE")) == 0;
     int dev = 0;
     if (off || n <= 0 || (uint32_t)n > CNT_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     std::lock_guard<std::mutex> lk(mu);

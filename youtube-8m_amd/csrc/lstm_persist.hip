@@ -835,9 +835,18 @@ struct PersistBwdArgs {
 
 constexpr int NSLOT_B = 3;
 
-template <int NQB, bool PF, bool SH>
+// ROT (round 4): the four epilogue waves take whole items IN ROTATION (wave e finishes the items of the workgroup's tiles e, e + 4,
+// ...: one lane = one unit x four rows) instead of finishing every item together.  An epilogue is two memory round trips long (the
+// saved activations in, the write-through drain of dz out: ~7k cycles of a ~12k-cycle item); as a team of four the waves ran them
+// strictly one item after the other, so item k + 1's partial tiles queued behind item k's drain and the wait went onto the chain of
+// tile k + 1 through all 64 unit groups.  In rotation each wave has four item times for its epilogue, requests its next item's
+// operands as soon as it has published the previous one, and the matrix waves only ever wait for the partial-tile slot.  Needs
+// every workgroup to own a multiple of four tiles (a tile then always meets the same wave: its running (dh, dc) are re-read by the
+// lanes that wrote them); the host falls back to the team form otherwise (YT8M_BWD_ROT=0 forces it).
+template <int NQB, bool PF, bool SH, bool ROT>
 __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
   constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
+  constexpr unsigned EPW = ROT ? 1u : 4u;                // epilogue waves that read a partial-tile slot / publish a tile
   __shared__ __attribute__((aligned(16))) float4 Wl[8][HALF][64];          // LDS-resident half of the weights: 8 * HALF KB
   __shared__ __attribute__((aligned(16))) float red[NSLOT_B][8][4][64];    // [slot][wave][acc reg][lane]: 24 KB
   __shared__ unsigned lds_cnt[NSLOT_B], lds_free[NSLOT_B];
@@ -863,7 +872,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   const long long img_f = (long long)NT16 * H * 64;
   auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.dzx + (SH ? s : (s & 1)) * img_f, img_bytes); };
   constexpr int AUX_LD = SH ? 0 : YT8M_AUX_LD;
-  const unsigned arrivals = (unsigned)a.NUB * 4u;        // per (tile, publish): four epilogue waves per workgroup
+  const unsigned arrivals = (unsigned)a.NUB * EPW;       // per (tile, publish): EPW epilogue waves per workgroup
   const int i16 = lane & 15, kq = lane >> 4;
   note_placement(a.ctl);
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         }
       }
       STAMP(2);
-      if (gen > 0) lds_wait_ge(&lds_free[slot], 4u * (unsigned)gen, a.ctl);   // all four epilogue waves have read item k - 3
+      if (gen > 0) lds_wait_ge(&lds_free[slot], EPW * (unsigned)gen, a.ctl);  // its epilogue wave(s) have read item k - 3
       float* rw = &red[slot][w][0][lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) rw[r * 64] = acc0[r] + acc1[r];
@@ -987,6 +996,153 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   // =============================== epilogue waves ===============================
   const int ew = w - 8;
   __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);
+  if constexpr (ROT) {
+    // lane = (row quad rq, unit): its four pairs are rows 4 rq + r, r = 0..3, of the tile -- exactly the four accumulator registers
+    // of that lane in every matrix wave's partial tile (C layout: column = lane & 15, row = 4 (lane >> 4) + r)
+    const int rq = lane >> 4, eunit = lane & 15;
+    const int t_hi = a.t0 + a.T - 1;
+    const long long BH = (long long)B * H;
+    int pend_T = -1;
+    auto arrive = [&]() {
+      if (pend_T < 0) return;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_fetch_add(a.ctl + CTL_HDR + (pend_T * NSH + ((blockIdx.x * 4 + ew) & (NSH - 1))) * 32, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      pend_T = -1;
+    };
+    auto publish_stores = [&](int T, int pub, const float (&dzv)[4][4]) {
+      const __amdgpu_buffer_rsrc_t dxr = image(pub);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float v0 = dzv[r][g4];
+          const float v1 = row_shl<1>(v0), v2 = row_shl<2>(v0), v3 = row_shl<3>(v0);
+          if ((eunit & 3) == 0) {
+            u32x4 v;
+            v.x = __float_as_uint(v0); v.y = __float_as_uint(v1); v.z = __float_as_uint(v2); v.w = __float_as_uint(v3);
+            const unsigned off = ((unsigned)(T * QH4 + g4 * (H >> 4) + ub) * 256u + (unsigned)((4 * rq + r) * 16 + eunit)) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, dxr, (int)off, 0, YT8M_AUX_ST);
+          }
+        }
+      }
+      pend_T = T;
+    };
+    struct GateIn { float gi, gj, gf, go, cp, cn, dout; bool live; };
+    auto gate_load = [&](int t1, int br) -> GateIn {
+      GateIn q;
+      const float* gr = a.gates + ((long long)t1 * B + br) * 4 * H + ub * 16 + eunit;
+      q.gi = gr[0]; q.gj = gr[H]; q.gf = gr[2 * H]; q.go = gr[3 * H];
+      const long long idx = (long long)t1 * BH + (long long)br * H + ub * 16 + eunit;
+      q.cp = a.cs[idx];
+      q.cn = a.cs[idx + BH];
+      q.dout = a.dout ? a.dout[idx] : 0.f;
+      q.live = a.nf ? (t1 < a.nf[br]) : true;
+      return q;
+    };
+    auto gate_bwd = [&](const GateIn& q, float dh_in, float dc, float (&dzv)[4], float& dc_out, float& base_out) {
+      const float tc = fast_tanh(q.cn);
+      const float dht = dh_in + q.dout;
+      const float dct = dc + dht * q.go * (1.0f - tc * tc);
+      dzv[0] = q.live ? dct * q.gj * q.gi * (1.0f - q.gi) : 0.f;
+      dzv[1] = q.live ? dct * q.gi * (1.0f - q.gj * q.gj) : 0.f;
+      dzv[2] = q.live ? dct * q.cp * q.gf * (1.0f - q.gf) : 0.f;
+      dzv[3] = q.live ? dht * tc * q.go * (1.0f - q.go) : 0.f;
+      dc_out = q.live ? dct * q.gf : dc;
+      base_out = q.live ? 0.f : dh_in;
+    };
+    auto store_std = [&](int t1, int brow, const float (&dzv)[4], float dc_out, float base_out, int half) {
+      float* dzr = a.dz + ((long long)t1 * B + brow) * 4 * H + ub * 16 + eunit;
+      dzr[0] = dzv[0]; dzr[H] = dzv[1]; dzr[2 * H] = dzv[2]; dzr[3 * H] = dzv[3];
+      if (a.dbrows) {
+        float* db = a.dbrows + (long long)brow * 4 * H + ub * 16 + eunit;
+        db[0] += dzv[0]; db[H] += dzv[1]; db[2 * H] += dzv[2]; db[3 * H] += dzv[3];
+      }
+      float* wk = a.work + (long long)(2 * half) * BH + (long long)brow * H + ub * 16 + eunit;
+      wk[0] = base_out;
+      wk[BH] = dc_out;
+    };
+    // ---- prologue: gate backward of step t_hi from the caller's running (dh, dc) in half `phase`; publish #1 of this wave's tiles
+    for (int it = ew; it < n_it; it += 4) {
+      const int T = g + it * RB;
+      float dzv[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int brow = T * 16 + 4 * rq + r;
+        const bool valid = brow < B;
+        const int br = valid ? brow : B - 1;
+        const float* wk = a.work + (long long)(2 * a.phase) * BH + (long long)br * H + ub * 16 + eunit;
+        const float dh0 = wk[0], dc0 = wk[BH];
+        const GateIn q = gate_load(t_hi, br);
+        float dc_out, base_out;
+        gate_bwd(q, dh0, dc0, dzv[r], dc_out, base_out);
+        if (!valid) { dzv[r][0] = dzv[r][1] = dzv[r][2] = dzv[r][3] = 0.f; }
+        if (valid) store_std(t_hi, brow, dzv[r], dc_out, base_out, a.phase ^ 1);
+      }
+      publish_stores(T, 0, dzv);
+      arrive();
+    }
+    for (int s = 0; s < a.T; ++s) {
+      const int t1 = t_hi - s - 1;
+      const bool last = s + 1 == a.T;
+      const int half = (a.phase + s + 1) & 1;
+      for (int it = ew; it < n_it; it += 4) {
+        const int k = s * n_it + it;                      // n_it % 4 == 0: item k is always this wave's
+        const int slot = k % NSLOT_B, gen = k / NSLOT_B;
+        const int T = g + it * RB;
+        STAMP(0);
+        float base[4], dc[4];
+        GateIn q[4];
+        bool valid[4];
+        int brow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                     // everything this item needs from memory, requested before the wait
+          brow[r] = T * 16 + 4 * rq + r;
+          valid[r] = brow[r] < B;
+          const int br = valid[r] ? brow[r] : B - 1;
+          const float* wk = a.work + (long long)(2 * half) * BH + (long long)br * H + ub * 16 + eunit;
+          base[r] = wk[0];
+          dc[r] = wk[BH];
+          if (!last) q[r] = gate_load(t1, br);
+        }
+        lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(gen + 1), a.ctl);
+        STAMP(1);
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = red[slot][0][r][lane];
+#pragma unroll
+          for (int wv = 1; wv < 8; ++wv) p[r] += red[slot][wv][r][lane];
+        }
+        if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        STAMP(2);
+        if (last) {                                       // dL/dh_{t_lo - 1}: handed to the caller (next chunk / initial state)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (valid[r]) a.work[(long long)(2 * half) * BH + (long long)brow[r] * H + ub * 16 + eunit] = base[r] + p[r];
+          }
+          continue;
+        }
+        float dzv[4][4], dc_out[4], base_out[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gate_bwd(q[r], base[r] + p[r], dc[r], dzv[r], dc_out[r], base_out[r]);
+          if (!valid[r]) { dzv[r][0] = dzv[r][1] = dzv[r][2] = dzv[r][3] = 0.f; }
+        }
+        STAMP(3);
+        publish_stores(T, s + 1, dzv);
+        arrive();                                         // drain + arrival: nothing else of this wave is waiting behind it
+        STAMP(4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (valid[r]) store_std(t1, brow[r], dzv[r], dc_out[r], base_out[r], half ^ 1);
+      }
+    }
+    arrive();
+    if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
+    return;
+  }
   const int er = lane >> 4, eunit = lane & 15;           // pair of this lane: (row 4 ew + er of the tile, unit eunit of the group)
   const int erow = 4 * ew + er;
   const int t_hi = a.t0 + a.T - 1;
@@ -1446,8 +1602,12 @@ bool persist_geometry_bwd(int64_t B, int64_t H, GeometryB* geo) {
 
 template <int NQB, bool SH>
 int launch_bwd_sh(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
-  if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH>), dim3(grid), dim3(768), 0, s, a);
-  else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false, SH>), dim3(grid), dim3(768), 0, s, a);
+  static const bool rot_off = getenv("YT8M_BWD_ROT") != nullptr && atoi(getenv("YT8M_BWD_ROT")) == 0;
+  // rotation needs a multiple of four tiles in EVERY workgroup (row group g owns tiles g, g + RB, ...) and the prefetching form
+  const bool rot = !rot_off && a.pf && (a.NT16 % (4 * a.RB)) == 0;
+  if (rot) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, true>), dim3(grid), dim3(768), 0, s, a);
+  else if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, false>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false, SH, false>), dim3(grid), dim3(768), 0, s, a);
   return yt8m::launch_status("lstm_persist_bwd_kernel");
 }
 template <int NQB>
