@@ -475,6 +475,28 @@ int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H);
 int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                           float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                           int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* The same launch with the operand images of dz[t0 .. t0 + T) written by the recurrence itself (round 4): what yt8m_x3_split /
+ * yt8m_x3_split_colsum would make of that part of dz in separate passes -- bit for bit -- for the products that follow it in the
+ * backward pass of BasicLSTMCell under dynamic_rnn (W/all_frame_models/lstm_model.py:34-47 through tf.gradients, W/train.py:461):
+ *   plain        x3 image [T B rows, K = 4H]  (A operand of dx = dz . W_x^T)                    yt8m_x3_image_bytes(T B, 4H)
+ *   trans        x3 image [4H rows, K = T B]  (B operand of dW = x^T dz, dW_h = h^T dz)         yt8m_x3_image_bytes(4H, T B)
+ *   trans_scaled the same of diag(rowscale) dz (layer-0 weight gradient on uint8 frames); rowscale: [F B] by absolute frame row
+ *   colpart / colpart_scaled: [yt8m_lstm_persist_bwd_images_rows(B, H)][4H] column sums of dz (of diag(rowscale) dz) over the
+ *                launch; their sum over the rows is colsum(dz[t0 .. t0 + T)) -- the bias gradient / the rank-1 remainder
+ * Any member may be NULL.  The launch still writes dz in the standard layout.  Needs yt8m_lstm_persist_bwd_images_rows(B, H) > 0
+ * (B % 16 == 0, a multiple of four 16-row tiles per workgroup) and a workspace from yt8m_lstm_persist_workspace_bytes_steps. */
+typedef struct yt8m_persist_bwd_images {
+  void* plain;
+  void* trans;
+  void* trans_scaled;
+  const float* rowscale;
+  float* colpart;
+  float* colpart_scaled;
+} yt8m_persist_bwd_images;
+int yt8m_lstm_persist_bwd_images_rows(int64_t B, int64_t H);
+int yt8m_lstm_persist_bwd_images(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                                 float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
+                                 void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* images, yt8m_stream_t stream);
 
 /* ---- the whole recurrent stack as two calls (csrc/lstm_stack.hip; SURVEY.md 8(b): yt8m_lstm_fwd / yt8m_lstm_bwd) --------------
  * MultiRNNCell([BasicLSTMCell(H)] * L) under tf.nn.dynamic_rnn(sequence_length = num_frames) and its gradient

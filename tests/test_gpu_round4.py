@@ -1,0 +1,98 @@
+"""-m gpu, round 4: the backward recurrence that writes the operand images of its own dz (csrc/lstm_persist.hip, rotated epilogue)
+against the separate split pass -- bit for bit -- and the in-kernel column sums; the split pass's per-tile column sums."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import yt8m_amd._lib as L
+from yt8m_amd.ops import _p, _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _x3_bytes(lib, rows, K):
+    return lib.yt8m_x3_image_bytes(rows, K)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_recurrence_written_images_equal_the_split_pass_bit_for_bit(dev, scaled):
+    lib = L.lib()
+    B, F, H, t0, T = 128, 9, 1024, 2, 6
+    rows = lib.yt8m_lstm_persist_bwd_images_rows(B, H)
+    if rows <= 0:
+        pytest.skip("this device / environment does not take the rotated epilogue at B = 128, H = 1024")
+    gen = torch.Generator(device=dev).manual_seed(11)
+    gates = torch.rand((F, B, 4 * H), device=dev, generator=gen)
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=gen) - 0.5) * 0.06
+    cs = torch.randn((F + 1, B, H), device=dev, generator=gen) * 0.5
+    dout = torch.randn((F, B, H), device=dev, generator=gen) * 0.01
+    nf = torch.randint(0, F + 1, (B,), device=dev, generator=gen, dtype=torch.int32)
+    nf[0], nf[1] = F, 0
+    rsc = torch.rand((F * B,), device=dev, generator=gen) + 0.5
+    work0 = torch.randn((4, B, H), device=dev, generator=gen) * 0.01
+    M = T * B
+
+    def run(images):
+        dz = torch.zeros((F, B, 4 * H), device=dev)
+        work = work0.clone()
+        pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, T), dtype=torch.uint8, device=dev)
+        if images is None:
+            L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, _p(nf), t0, T, B, H,
+                                              _p(pws), pws.numel(), _stream()))
+        else:
+            L.check(lib.yt8m_lstm_persist_bwd_images(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, _p(nf), t0, T, B, H,
+                                                     _p(pws), pws.numel(), ctypes.byref(images), _stream()))
+        torch.cuda.synchronize()
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        return dz, work
+
+    plain = torch.zeros(_x3_bytes(lib, M, 4 * H), dtype=torch.uint8, device=dev)
+    trans = torch.zeros(_x3_bytes(lib, 4 * H, M), dtype=torch.uint8, device=dev)
+    trans_s = torch.zeros_like(trans)
+    cp = torch.zeros((rows, 4 * H), device=dev)
+    cps = torch.zeros((rows, 4 * H), device=dev)
+    im = L.PersistBwdImages(plain.data_ptr(), trans.data_ptr(), trans_s.data_ptr() if scaled else None, rsc.data_ptr() if scaled else None,
+                            cp.data_ptr(), cps.data_ptr() if scaled else None)
+    dz_i, work_i = run(im)
+    dz_r, work_r = run(None)
+    assert torch.equal(dz_i, dz_r) and torch.equal(work_i, work_r)            # the images change nothing else
+    part = dz_r[t0:t0 + T].reshape(M, 4 * H)
+    assert float(part.abs().max()) > 0
+    ref_p = torch.zeros_like(plain)
+    ref_t = torch.zeros_like(trans)
+    ref_ts = torch.zeros_like(trans)
+    L.check(lib.yt8m_x3_split_ex(_p(part), M, 4 * H, 4 * H, 1.0, _p(rsc[t0 * B:]) if scaled else None, _p(ref_p), _p(ref_t),
+                                 _p(ref_ts) if scaled else None, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(plain, ref_p), "plain image differs from yt8m_x3_split"
+    assert torch.equal(trans, ref_t), "transposed image differs from yt8m_x3_split"
+    if scaled:
+        assert torch.equal(trans_s, ref_ts), "scaled transposed image differs from yt8m_x3_split_ex"
+    col = part.double().sum(0)
+    assert float((cp.double().sum(0) - col).abs().max()) <= 1e-5 * float(part.abs().sum(0).max())
+    if scaled:
+        cols = (part.double() * rsc[t0 * B:(t0 + T) * B, None].double()).sum(0)
+        assert float((cps.double().sum(0) - cols).abs().max()) <= 1e-5 * float(part.abs().sum(0).max()) * 1.5
+
+
+def test_split_pass_column_sums(dev):
+    lib = L.lib()
+    R, C = 200, 192
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((R, C), device=dev, generator=gen)
+    rsc = torch.rand((R,), device=dev, generator=gen) + 0.5
+    tr = torch.zeros(lib.yt8m_x3_image_bytes(C, R), dtype=torch.uint8, device=dev)
+    trs = torch.zeros_like(tr)
+    nt = (R + 63) // 64
+    cp, cps = torch.zeros((nt, C), device=dev), torch.zeros((nt, C), device=dev)
+    L.check(lib.yt8m_x3_split_colsum(_p(x), R, C, C, 1.0, _p(rsc), None, _p(tr), _p(trs), _p(cp), _p(cps), _stream()))
+    ref, refs = torch.zeros_like(tr), torch.zeros_like(tr)
+    L.check(lib.yt8m_x3_split_ex(_p(x), R, C, C, 1.0, _p(rsc), None, _p(ref), _p(refs), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(tr, ref) and torch.equal(trs, refs)
+    for t in range(nt):
+        blk = x[64 * t:64 * (t + 1)].double()
+        assert float((cp[t].double() - blk.sum(0)).abs().max()) < 1e-5
+        assert float((cps[t].double() - (blk * rsc[64 * t:64 * (t + 1), None].double()).sum(0)).abs().max()) < 1e-5

@@ -15,6 +15,12 @@ class GemmProblem(ctypes.Structure):
                 ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64), ("bias", c_void_p), ("beta", c_float)]
 
 
+class PersistBwdImages(ctypes.Structure):
+    """yt8m_persist_bwd_images (include/yt8m_hip.h): where yt8m_lstm_persist_bwd_images leaves the operand images of its dz."""
+    _fields_ = [("plain", ctypes.c_void_p), ("trans", ctypes.c_void_p), ("trans_scaled", ctypes.c_void_p), ("rowscale", ctypes.c_void_p),
+                ("colpart", ctypes.c_void_p), ("colpart_scaled", ctypes.c_void_p)]
+
+
 class LstmStackDesc(ctypes.Structure):
     """yt8m_lstm_stack_desc (include/yt8m_hip.h)."""
     _fields_ = [("B", c_int64), ("F", c_int64), ("D", c_int64), ("H", c_int64), ("L", ctypes.c_int32), ("input_u8", ctypes.c_int32),
@@ -149,6 +155,8 @@ SIGNATURES = {
     "yt8m_lstm_persist_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
+    "yt8m_lstm_persist_bwd_images_rows": (c_int, [c_int64, c_int64]),
+    "yt8m_lstm_persist_bwd_images": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P, P]),
     "yt8m_lstm_packed_floats": (c_int64, [c_int64, c_int64]),
     "yt8m_lstm_pack": (c_int, [P, c_int64, c_int64, P, P, P]),
     "yt8m_lstm_steps_fwd": (c_int, [P, P, c_int64, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),

@@ -770,10 +770,10 @@ struct TileCounters {
   uint32_t next[16] = {0};
   unsigned* take(int n) {
     // Measured (profiles/r4_sched_knobs.md): correct and bitwise equal, but NOT faster than the separate pass where it was meant to
-    // pay -- 23.67 against 23.36 ms per headline step, 1.00 / 1.01 ms configs[1], 5.68 / 5.64 configs[2].  A 256-thread fix-up
-    // workgroup needs no LDS and 20 VGPRs: it runs on CUs the persistent recurrences occupy (they leave 44 VGPRs per lane and 4 KB of
-    // LDS), i.e. for free beside them, while a GEMM workgroup that stays to combine keeps its 144 KB of LDS and the recurrence that
-    // is waiting for that CU.  Opt-in: YT8M_X3_FUSED_COMBINE=1.
+    // pay -- 23.67 against 23.36 ms per headline step, 1.00 / 1.01 ms configs[1], 5.68 / 5.64 configs[2].  The likely reason (not
+    // isolated by a counter): a 256-thread fix-up workgroup needs no LDS and 20 VGPRs, so it fits on CUs the persistent recurrences
+    // occupy (they leave ~32 VGPRs per lane and ~7 KB of LDS) and runs beside them, while a GEMM workgroup that stays to combine
+    // keeps its 144 KB of LDS -- and the recurrence launch that is waiting for that CU.  Opt-in: YT8M_X3_FUSED_COMBINE=1.
     static const bool off = getenv("YT8M_X3_FUSED_COMBINE") == nullptr || atoi(getenv("YT8M_X3_FUSED_COMBINE")) == 0;
     int dev = 0;
     if (off || n <= 0 || (uint32_t)n > CNT_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;

@@ -831,9 +831,35 @@ struct PersistBwdArgs {
   int NUB, RB, NT16, per, pf;
   int nimg;
   unsigned long long* dbg;
+  // IMG (rotated epilogue only): the operand images of this launch's dz written by the epilogue itself -- what yt8m_x3_split would
+  // make of dz[t0 .. t0 + T) in separate passes (csrc/gemm_x3.hip image layout: 1 KiB blocks of 32 rows x 16 k per plane).
+  float* img_plain;     // [T B rows, K = 4H]: A operand of dx = dz . W_x^T                       (or null)
+  float* img_trans;     // [4H rows, K = T B]: B operand of dW = x^T dz                           (or null)
+  float* img_trans_s;   // the same of diag(rowscale) dz: layer-0 weight gradient on uint8 frames (or null)
+  const float* rowscale;// [F B] by absolute frame row t B + b
+  float* colpart;       // [4 RB rows][4H] column sums of dz over this launch, one row per (row group, epilogue wave)   (or null)
+  float* colpart_s;     // ... of diag(rowscale) dz                                                                    (or null)
 };
 
 constexpr int NSLOT_B = 3;
+
+// round-to-nearest-even bf16 bits / exact three-term split: the arithmetic of csrc/gemm_x3.hip's split pass, bit for bit
+__device__ __forceinline__ unsigned p_bf16_rn_bits(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void p_split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = p_bf16_rn_bits(x);
+  const float r1 = x - __uint_as_float(h1 << 16);
+  h2 = p_bf16_rn_bits(r1);
+  const float r2 = r1 - __uint_as_float(h2 << 16);
+  h3 = p_bf16_rn_bits(r2);
+  if ((__float_as_uint(x) & 0x7F800000u) == 0x7F800000u) {
+    h1 = __float_as_uint(x) >> 16;
+    h2 = h3 = 0;
+  }
+}
+
 
 // ROT (round 4): the four epilogue waves take whole items IN ROTATION (wave e finishes the items of the workgroup's tiles e, e + 4,
 // ...: one lane = one unit x four rows) instead of finishing every item together.  An epilogue is two memory round trips long (the
@@ -843,8 +869,9 @@ constexpr int NSLOT_B = 3;
 // operands as soon as it has published the previous one, and the matrix waves only ever wait for the partial-tile slot.  Needs
 // every workgroup to own a multiple of four tiles (a tile then always meets the same wave: its running (dh, dc) are re-read by the
 // lanes that wrote them); the host falls back to the team form otherwise (YT8M_BWD_ROT=0 forces it).
-template <int NQB, bool PF, bool SH, bool ROT>
+template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false>
 __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
+  static_assert(!IMG || ROT, "the operand images are written by the rotated epilogue");
   constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
   constexpr unsigned EPW = ROT ? 1u : 4u;                // epilogue waves that read a partial-tile slot / publish a tile
   __shared__ __attribute__((aligned(16))) float4 Wl[8][HALF][64];          // LDS-resident half of the weights: 8 * HALF KB
@@ -1063,6 +1090,86 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       wk[0] = base_out;
       wk[BH] = dc_out;
     };
+    // Operand images of dz (IMG): the wave holds a whole 16-row x 16-unit tile of every gate after the gate backward -- one
+    // 16-wide K block of the transposed image (K = frame rows) for 16 image rows, and 16 rows of one K block of the plain image
+    // (K = gate columns).  Issued AFTER the tile's arrival: nothing on the state's dependency chain waits for these ~500 VALU
+    // operations, the wave has four item times until its next tile.  Image geometry: csrc/gemm_x3.hip store_block.
+    float csum[4] = {0.f, 0.f, 0.f, 0.f}, csum_s[4] = {0.f, 0.f, 0.f, 0.f};
+    auto emit_images = [&](int t1, int T, const float (&dzv)[4][4]) {
+      if constexpr (!IMG) return;
+      const int MKB = (a.T * B) >> 4;                     // K blocks of the transposed image (K = the launch's frame rows)
+      const int mrow0 = (t1 - a.t0) * B + T * 16;         // first frame row of the tile within the launch
+      float rs[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.rowscale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int brow = T * 16 + 4 * rq + r;
+          rs[r] = brow < B ? a.rowscale[(long long)t1 * B + brow] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        unsigned h[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p_split3(dzv[r][g4], h[0][r], h[1][r], h[2][r]);
+          csum[g4] += dzv[r][g4];
+        }
+        // transposed image: image row = gate column g4 H + 16 ub + unit, K block = this tile-step; this lane's four rows are
+        // 8 bytes of the 16-byte half (rows 0-7 / 8-15 of the tile): [(row & 31) * 32 B][half slot * 16 B][(rq & 1) * 8 B]
+        const int irow = g4 * H + ub * 16 + eunit;
+        const int ir = irow & 31, isw = (ir >> 3) & 1;
+        const long long tblk = ((long long)(irow >> 5) * MKB + (mrow0 >> 4)) * 768;            // floats: 3 planes x 256
+        const int toff = ir * 8 + 4 * ((rq >> 1) ^ isw) + 2 * (rq & 1);
+        if (a.img_trans) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            uint2 v;
+            v.x = h[pl][0] | (h[pl][1] << 16);
+            v.y = h[pl][2] | (h[pl][3] << 16);
+            *reinterpret_cast<uint2*>(a.img_trans + tblk + pl * 256 + toff) = v;
+          }
+        }
+        if (a.img_trans_s) {
+          unsigned hs[3][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sv = dzv[r][g4] * rs[r];
+            p_split3(sv, hs[0][r], hs[1][r], hs[2][r]);
+            csum_s[g4] += sv;
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            uint2 v;
+            v.x = hs[pl][0] | (hs[pl][1] << 16);
+            v.y = hs[pl][2] | (hs[pl][3] << 16);
+            *reinterpret_cast<uint2*>(a.img_trans_s + tblk + pl * 256 + toff) = v;
+          }
+        }
+        // plain image: image row = frame row, K block = g4 H / 16 + ub, k = unit: eight units of a row = one 16-byte half,
+        // gathered along the 16-lane DPP row (lane = unit) into the lanes with unit % 8 == 0
+        if (a.img_plain) {
+          const int kbp = g4 * (H >> 4) + ub;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mrow0 + 4 * rq + r;
+            const int pr = m & 31, psw = (pr >> 3) & 1;
+            float* pb = a.img_plain + ((long long)(m >> 5) * (H >> 2) + kbp) * 768 + pr * 8 + 4 * ((eunit >> 3) ^ psw);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              const unsigned d0 = h[pl][r] | (row_shl_u<1>(h[pl][r]) << 16);       // units (u, u + 1) on even lanes
+              const unsigned d1 = row_shl_u<2>(d0);
+              const unsigned d2 = row_shl_u<4>(d0), d3 = row_shl_u<4>(d1);
+              if ((eunit & 7) == 0) {
+                uint4 v;
+                v.x = d0; v.y = d1; v.z = d2; v.w = d3;
+                *reinterpret_cast<uint4*>(pb + pl * 256) = v;
+              }
+            }
+          }
+        }
+      }
+    };
     // ---- prologue: gate backward of step t_hi from the caller's running (dh, dc) in half `phase`; publish #1 of this wave's tiles
     for (int it = ew; it < n_it; it += 4) {
       const int T = g + it * RB;
@@ -1082,6 +1189,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       }
       publish_stores(T, 0, dzv);
       arrive();
+      emit_images(t_hi, T, dzv);
     }
     for (int s = 0; s < a.T; ++s) {
       const int t1 = t_hi - s - 1;
@@ -1137,9 +1245,26 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (valid[r]) store_std(t1, brow[r], dzv[r], dc_out[r], base_out[r], half ^ 1);
+        emit_images(t1, T, dzv);
       }
     }
     arrive();
+    if constexpr (IMG) {
+      // column sums of this wave's tiles over the launch: the four row quads of a unit meet in the lane with rq == 0 (fixed order)
+      if (a.colpart || a.colpart_s) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float c = csum[g4], cs_ = csum_s[g4];
+          const float c1 = __shfl(c, lane + 16, 64), c2 = __shfl(c, lane + 32, 64), c3 = __shfl(c, lane + 48, 64);
+          const float s1 = __shfl(cs_, lane + 16, 64), s2 = __shfl(cs_, lane + 32, 64), s3 = __shfl(cs_, lane + 48, 64);
+          if (rq == 0) {
+            const long long o = (long long)(g * 4 + ew) * 4 * H + g4 * H + ub * 16 + eunit;
+            if (a.colpart) a.colpart[o] = ((c + c1) + c2) + c3;
+            if (a.colpart_s) a.colpart_s[o] = ((cs_ + s1) + s2) + s3;
+          }
+        }
+      }
+    }
     if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
     return;
   }
@@ -1600,11 +1725,26 @@ bool persist_geometry_bwd(int64_t B, int64_t H, GeometryB* geo) {
   return true;
 }
 
+bool bwd_rot_off() {
+  static const bool off = getenv("YT8M_BWD_ROT") != nullptr && atoi(getenv("YT8M_BWD_ROT")) == 0;
+  return off;
+}
+// rotation needs a multiple of four tiles in EVERY workgroup (row group g owns tiles g, g + RB, ...) and the prefetching form
+bool bwd_rot(int pf, int NT16, int RB) { return !bwd_rot_off() && pf && (NT16 % (4 * RB)) == 0; }
+
 template <int NQB, bool SH>
 int launch_bwd_sh(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
-  static const bool rot_off = getenv("YT8M_BWD_ROT") != nullptr && atoi(getenv("YT8M_BWD_ROT")) == 0;
-  // rotation needs a multiple of four tiles in EVERY workgroup (row group g owns tiles g, g + RB, ...) and the prefetching form
-  const bool rot = !rot_off && a.pf && (a.NT16 % (4 * a.RB)) == 0;
+  const bool rot = bwd_rot(a.pf, a.NT16, a.RB);
+  const bool img = a.img_plain || a.img_trans || a.img_trans_s || a.colpart || a.colpart_s;
+  if (img) {
+    if constexpr (SH) {
+      if (!rot) return yt8m::fail(YT8M_E_SHAPE, "operand images need the rotated backward epilogue%s", "");
+      hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, true, true, true>), dim3(grid), dim3(768), 0, s, a);
+      return yt8m::launch_status("lstm_persist_bwd_kernel");
+    } else {
+      return yt8m::fail(YT8M_E_SHAPE, "operand images need one exchange image per step%s", "");
+    }
+  }
   if (rot) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, true>), dim3(grid), dim3(768), 0, s, a);
   else if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, false>), dim3(grid), dim3(768), 0, s, a);
   else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false, SH, false>), dim3(grid), dim3(768), 0, s, a);
@@ -1620,9 +1760,50 @@ extern "C" int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H) {
   return (persist_geometry(B, H, nullptr) && persist_geometry_bwd(B, H, nullptr)) ? 1 : 0;
 }
 
+// Rows of the column-sum partials a launch with operand images writes (4 per row group), 0 when the shape cannot take the images
+// (they are written by the rotated epilogue: B % 16 == 0 and a multiple of four 16-row tiles per workgroup).
+extern "C" int yt8m_lstm_persist_bwd_images_rows(int64_t B, int64_t H) {
+  GeometryB geo;
+  if (!persist_geometry(B, H, nullptr) || !persist_geometry_bwd(B, H, &geo)) return 0;
+  if ((B % 16) != 0 || !bwd_rot(geo.pf, geo.NT16, geo.RB)) return 0;
+  return 4 * geo.RB;
+}
+
+namespace {
+int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                     float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                     int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
+                     yt8m_stream_t stream);
+}
+
 extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, dbias_rows, num_frames, t0, T, B, H, workspace, workspace_bytes,
+                          nullptr, stream);
+}
+
+// yt8m_lstm_persist_bwd that also leaves the operand images of dz[t0 .. t0 + T) for the products that follow (include/yt8m_hip.h).
+extern "C" int yt8m_lstm_persist_bwd_images(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                                            float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B,
+                                            int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* images,
+                                            yt8m_stream_t stream) {
+  YT8M_REQUIRE(images, YT8M_E_BADARG, "null image description");
+  YT8M_REQUIRE(yt8m_lstm_persist_bwd_images_rows(B, H) > 0, YT8M_E_SHAPE, "shape cannot take the operand images (yt8m_lstm_persist_bwd_images_rows)");
+  YT8M_REQUIRE((images->rowscale != nullptr) == (images->trans_scaled != nullptr || images->colpart_scaled != nullptr), YT8M_E_BADARG,
+               "rowscale comes with trans_scaled / colpart_scaled");
+  YT8M_REQUIRE((((uintptr_t)images->plain | (uintptr_t)images->trans | (uintptr_t)images->trans_scaled) & 15) == 0, YT8M_E_BADARG,
+               "images must be 16-byte aligned");
+  return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, nullptr, num_frames, t0, T, B, H, workspace, workspace_bytes, images,
+                          stream);
+}
+
+namespace {
+int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                     float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                     int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
+                     yt8m_stream_t stream) {
+  using namespace yt8m;
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
   if (T * B * H == 0) return YT8M_OK;
@@ -1639,6 +1820,12 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   PersistBwdArgs a;
   a.gates = gates; a.Wh = Wh; a.ldw = ldw; a.cs = cs; a.dout = dout; a.dz = dz; a.work = work; a.nf = num_frames;
   a.dbrows = dbias_rows;
+  a.img_plain = img ? static_cast<float*>(img->plain) : nullptr;
+  a.img_trans = img ? static_cast<float*>(img->trans) : nullptr;
+  a.img_trans_s = img ? static_cast<float*>(img->trans_scaled) : nullptr;
+  a.rowscale = img ? img->rowscale : nullptr;
+  a.colpart = img ? img->colpart : nullptr;
+  a.colpart_s = img ? img->colpart_scaled : nullptr;
   a.ctl = static_cast<unsigned*>(workspace) + CTL_STICKY;
   a.dzx = reinterpret_cast<float*>(static_cast<char*>(workspace) + cb);
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.phase = phase;
@@ -1667,3 +1854,4 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
   if (rc != YT8M_OK) return rc;
   return g_gate.done(dev, (int)grid, s);
 }
+}  // namespace

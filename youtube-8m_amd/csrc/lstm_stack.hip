@@ -68,6 +68,8 @@ struct Plan {
   int64_t xT[MAXL], hT[MAXL];                              // whole-sequence transposed images (layer input / h_{t-1})
   int64_t cpart[MAXL], cparts;                             // [F B / 64, 4H] per-tile column sums of dz (plain; layer 0 on uint8: r-weighted)
   bool colparts;                                           // every backward part is a multiple of 64 frame rows: the sums ride on the split
+  int img_rows;                                            // > 0: the backward recurrences write dz's operand images themselves (round 4)
+  int64_t cimg[MAXL], cimgs;                               // their column-sum partials: [img_rows x launches][4H] per layer
   int64_t scratch_bytes;
 };
 
@@ -92,10 +94,12 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.nf = chunks(p.F, d->fwd_chunks > 0 ? d->fwd_chunks : 1, p.fp);
   p.nb = chunks(p.F, d->bwd_chunks > 0 ? d->bwd_chunks : 3, p.bp);
   // The library's own backward partition (bwd_chunks == 0): three parts of relative length 3 : 2 : 1 in forward-time order.  The
-  // backward pass runs them last to first: a SHORT first part (the top layer's recurrence runs alone on half the chip while it
-  // lasts, and the weight-gradient stream has nothing to do yet) and a long last one.  Measured on BASELINE configs[3]
-  // (profiles/r3_sched_knobs.md): 23.5-23.6 ms/step for 3:2:1, 7:4:2, 8:5:3, 5:3:1 against 24.0 for three equal parts.
-  static const char* dflt_parts = "3,2,1";
+  // backward pass runs them last to first: SHORT first parts (the top layer's recurrence runs alone on half the chip while the
+  // first one lasts, and the weight-gradient stream has nothing to do yet) and long last ones.  Round 3 (profiles/
+  // r3_sched_knobs.md): 23.5-23.6 ms/step for 3:2:1, 7:4:2, 8:5:3, 5:3:1 against 24.0 for three equal parts.
+  // Round 4 (profiles/r4_sched_knobs.md, with the column sums taken from the split pass and the rotated backward epilogue): four
+  // parts 2 : 2 : 1 : 1 run at 22.30-22.35 ms/step against 23.17 for 3 : 2 : 1 (22.5-22.9 for five / six parts and 1:1:1:1).
+  static const char* dflt_parts = "2,2,1,1";
   const char* spec = getenv("YT8M_STACK_BWD_PARTS");
   if (!spec && d->bwd_chunks <= 0 && p.F >= 12) spec = dflt_parts;
   if (spec) {                                                   // relative lengths in forward-time order
@@ -165,8 +169,16 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
     p.xT[l] = o; o += x1 ? up256(x1_bytes(p.D, p.FB)) : up256(x3_bytes(Din, p.FB));
     p.hT[l] = o; o += up256(x3_bytes(p.H, p.FB));
   }
-  for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(x3_bytes(H4, bmax)); }
-  p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, bmax)) : 0;
+  // Images written by the recurrences (img_rows > 0) are consumed by products on OTHER streams that may lag a whole part behind, so
+  // every launch gets its own K range of a whole-sequence image (944 MB per layer at the headline shape) instead of one re-used
+  // part-sized buffer that stream order used to protect.
+  p.img_rows = knob("YT8M_STACK_FUSED_IMAGES", 1) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
+  const int64_t trows = p.img_rows ? p.FB : bmax;
+  for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(x3_bytes(H4, trows)); }
+  p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, trows)) : 0;
+  const int64_t ci = p.img_rows ? up256((int64_t)p.img_rows * MAXP * 2 * H4 * 4) : 0;
+  for (int l = 0; l < p.L; ++l) { p.cimg[l] = o; o += ci; }
+  p.cimgs = o; o += p.u8 ? ci : 0;
   p.csr = o; o += up256(H4 * 4);
   p.dbdummy = o; o += up256(H4 * 4);
   p.colparts = knob("YT8M_STACK_COLPARTS", 1) != 0;
@@ -447,6 +459,9 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   int phase[MAXL];
   bool wx3_done[MAXL];
   hipEvent_t dzT_free[MAXL] = {nullptr};
+  const bool fused_img = P.img_rows > 0 && !dx_stream && !fuse_dz;
+  int64_t img_done_rows[MAXL] = {0};                       // frame rows whose images the layer's launches have written so far
+  int img_launches[MAXL] = {0};
   for (int l = 0; l < P.L; ++l) {
     hipStream_t s = S->rs[l];
     float* work = at<float>(scratch, P.work[l]);
@@ -494,9 +509,30 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       if (dx_ev && j == nsub - 1) ev.wait(s, dx_ev);
       const float* dout = l == P.L - 1 ? dout_top : at<float>(scratch, P.dbuf[l]);
       float* dz = at<float>(scratch, P.dz[l]);
-      RC(yt8m_lstm_persist_bwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
-                               at<float>(scratch, P.work[l]), phase[l], nullptr, num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]),
-                               P.pws_bytes, s));
+      // this launch's K range of the whole-sequence transposed image(s) (fused_img): (4H / 32) row groups x (rows / 16) K blocks
+      const int64_t toff = fused_img ? (H4 / 32) * (img_done_rows[l] / 16) * 3072 : 0;
+      char* dzT_img = at<char>(scratch, P.dzT3[l]) + toff;
+      char* dzTs_img = at<char>(scratch, P.dzT3s) + toff;
+      if (fused_img && img_launches[l] < 2 * MAXP) {
+        const bool dxl = l > 0 || P.need_dx;
+        yt8m_persist_bwd_images im;
+        im.plain = dxl ? at<char>(scratch, P.dz3[l]) : nullptr;
+        im.trans = dW[l] ? dzT_img : nullptr;
+        const bool sc = dW[l] && l == 0 && P.u8;
+        im.trans_scaled = sc ? dzTs_img : nullptr;
+        im.rowscale = sc ? at<float>(tape, P.rrow) : nullptr;
+        im.colpart = at<float>(scratch, P.cimg[l]) + (int64_t)img_launches[l] * P.img_rows * H4;
+        im.colpart_scaled = sc ? at<float>(scratch, P.cimgs) + (int64_t)img_launches[l] * P.img_rows * H4 : nullptr;
+        RC(yt8m_lstm_persist_bwd_images(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
+                                        at<float>(scratch, P.work[l]), phase[l], num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]),
+                                        P.pws_bytes, &im, s));
+        img_done_rows[l] += M;
+        ++img_launches[l];
+      } else {
+        RC(yt8m_lstm_persist_bwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
+                                 at<float>(scratch, P.work[l]), phase[l], nullptr, num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]),
+                                 P.pws_bytes, s));
+      }
       phase[l] = (int)((phase[l] + T) % 2);
       hipEvent_t rb = ev.record(s);
       bool fused_t = false;
@@ -509,7 +545,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // weight-gradient stream then waits for this pass instead of reading dz again)
         fused_t = fuse_dz && dW[l] && !(l == 0 && P.u8);
         if (fused_t && dzT_free[l]) ev.wait(sx, dzT_free[l]);       // the previous part's products have read the image
-        RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
+        if (!fused_img)
+          RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
         if (fused_t) rb = ev.record(sx);
         if (!wx3_done[l]) {
           RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));      // W_x: rows Din, K = 4H
@@ -532,18 +569,20 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       if (dW[l]) {
         if (l == 0 && P.u8) {
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
-          if (P.colparts)                                    // bias gradient + rank-1 remainder: per-tile sums from this pass
+          if (fused_img) {                                   // images and column sums came with the recurrence
+          } else if (P.colparts)                             // bias gradient + rank-1 remainder: per-tile sums from this pass
             RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s),
                                     at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4, at<float>(scratch, P.cparts) + (t0 * B / 64) * H4, sw));
           else
             RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), sw));
-          RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, at<char>(scratch, P.dzT3s), 0, dW[0], H4,
+          RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, dzTs_img, 0, dW[0], H4,
                                   nullptr, U8_ALPHA, nullptr, nullptr, 0.f, bW, gw, P.gws_bytes, sw));
-          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0,
+          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, dzT_img, 0,
                                   dW[0] + D * H4, H4, nullptr, bW};
           RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, sw));
         } else {
-          if (!fused_t) {
+          if (fused_img) {
+          } else if (!fused_t) {
             if (P.colparts && db[l])
               RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, nullptr, nullptr, at<char>(scratch, P.dzT3[l]), nullptr,
                                       at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4, nullptr, sw));
@@ -551,8 +590,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
               RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
           }
           yt8m_gemm_problem pr[2] = {
-              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
-              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
+              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, dzT_img, 0, dW[l], H4, nullptr, bW},
+              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, dzT_img, 0, dW[l] + Din * H4, H4, nullptr, bW}};
           RC(yt8m_gemm_x3_nt_grouped(2, pr, gw, P.gws_bytes, sw));
           if (fused_t) dzT_free[l] = ev.record(sw);
         }
@@ -560,9 +599,13 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       if (lastpart) {
         const float bb = beta_b ? beta_b[l] : 0.f;
         const int64_t ntile = (FB + 63) / 64;                 // rows of the per-tile partial sums (P.colparts)
+        const int64_t nimg = (int64_t)img_launches[l] * P.img_rows;   // ... of the recurrences' own partial sums (fused_img)
         if (dW[l] && l == 0 && P.u8) {
           float* dbo = db[0] ? db[0] : at<float>(scratch, P.dbdummy);
-          if (P.colparts) {                                  // fixed-order sums of the partials the split passes left: 10 MB instead of
+          if (fused_img) {
+            RC(yt8m_colsum_f32(at<float>(scratch, P.cimgs), nimg, H4, H4, at<float>(scratch, P.csr), 0.f, gw, P.gws_bytes, sw));
+            if (db[0]) RC(yt8m_colsum_f32(at<float>(scratch, P.cimg[0]), nimg, H4, H4, db[0], bb, gw, P.gws_bytes, sw));
+          } else if (P.colparts) {                                  // fixed-order sums of the partials the split passes left: 10 MB instead of
             RC(yt8m_colsum_f32(at<float>(scratch, P.cparts), ntile, H4, H4, at<float>(scratch, P.csr), 0.f, gw, P.gws_bytes, sw));   // 629
             if (db[0]) RC(yt8m_colsum_f32(at<float>(scratch, P.cpart[0]), ntile, H4, H4, db[0], bb, gw, P.gws_bytes, sw));
           } else {
@@ -571,7 +614,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           }
           RC(yt8m_rank1_add_rows_f32(dW[0], D, H4, H4, at<float>(scratch, P.csr), U8_BETA, sw));
         } else if (db[l]) {
-          if (P.colparts && dW[l] && !fuse_dz) RC(yt8m_colsum_f32(at<float>(scratch, P.cpart[l]), ntile, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+          if (fused_img) RC(yt8m_colsum_f32(at<float>(scratch, P.cimg[l]), nimg, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
+          else if (P.colparts && dW[l] && !fuse_dz) RC(yt8m_colsum_f32(at<float>(scratch, P.cpart[l]), ntile, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
           else RC(yt8m_colsum_f32(dz, FB, H4, H4, db[l], bb, gw, P.gws_bytes, sw));
         }
         // the layer's gradients are final here -- layer L-1 first, a whole last part of weight-gradient work before layer 0's: a
