@@ -546,6 +546,13 @@ int yt8m_lstm_stack_status(const yt8m_lstm_stack_desc* desc, void* scratch, yt8m
  * device are final -- layer L-1 first, a whole last time part of weight-gradient work before layer 0.  A data-parallel host starts
  * each layer's gradient all-reduce from this point instead of the end of the call (W/train.py:624-639 averages the tower
  * gradients after the whole backward pass). */
+/* One-shot host callback of the calling thread's next yt8m_lstm_stack_bwd, invoked right after its first backward recurrence is
+ * enqueued, with the library's weight-gradient stream: what the callback enqueues there runs while that recurrence holds half the
+ * chip and the stream has nothing else to do yet.  TrainGraph.step uses it to clip + Adam-update the variables whose gradients are
+ * final before the recurrent stack's backward pass starts (W/train.py:461-466 applies all gradients after the whole backward pass;
+ * the arithmetic per variable is the same, only its place in the step moves).  hook == NULL clears. */
+typedef void (*yt8m_stream_hook)(void* user, yt8m_stream_t stream);
+int yt8m_lstm_stack_set_prep_hook(yt8m_stream_hook hook, void* user);
 int yt8m_lstm_stack_layer_done_wait(int layer, yt8m_stream_t stream);
 
 /* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the

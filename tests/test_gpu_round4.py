@@ -96,3 +96,39 @@ def test_split_pass_column_sums(dev):
         blk = x[64 * t:64 * (t + 1)].double()
         assert float((cp[t].double() - blk.sum(0)).abs().max()) < 1e-5
         assert float((cps[t].double() - (blk * rsc[64 * t:64 * (t + 1), None].double()).sum(0)).abs().max()) < 1e-5
+
+
+def test_early_head_optimizer_pass_is_bitwise_the_end_of_step_pass(dev, flags, monkeypatch):
+    """LstmModel on the native stack: clip + Adam of the MoE head inside the stack's backward pass (on the library's weight-gradient
+    stream, seq_ops._early_optimizer_hook) leaves exactly the parameters, Adam slots and norms of the plain end-of-step pass."""
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.seq_ops as seq_ops
+    import yt8m_amd.train as train
+    from yt8m_amd.variables import reset_default_graph
+    flags.lstm_cells = "256"
+    B, F, D, V = 32, 32, 64, 4716
+    gen = torch.Generator(device=dev).manual_seed(3)
+    q = torch.randint(0, 256, (B, F, D), device=dev, generator=gen, dtype=torch.uint8)
+    y = torch.rand((B, V), device=dev, generator=gen) < 3.4 / V
+    nf = torch.randint(1, F + 1, (B,), device=dev, generator=gen, dtype=torch.int32)
+
+    def run(early):
+        monkeypatch.setattr(seq_ops, "EARLY_ADAM", early)
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g)
+        for _ in range(3):
+            out = tg.step(q, y, nf)
+        torch.cuda.synchronize()
+        return g.params.clone(), g.adam_m.clone(), g.adam_v.clone(), g.norms.clone(), float(out["loss"])
+
+    n0, b0 = seq_ops.EARLY_ADAM_RUNS[0], seq_ops.NATIVE_CALLS["bwd"]
+    a = run(True)
+    if seq_ops.NATIVE_CALLS["bwd"] == b0:
+        pytest.skip("the native stack did not take this shape on this device")
+    assert seq_ops.EARLY_ADAM_RUNS[0] == n0 + 3, "the early pass did not engage"
+    n1 = seq_ops.EARLY_ADAM_RUNS[0]
+    b = run(False)
+    assert seq_ops.EARLY_ADAM_RUNS[0] == n1
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    assert a[4] == b[4]

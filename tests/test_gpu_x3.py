@@ -292,7 +292,12 @@ def test_persistent_partition_defaults(dev, monkeypatch, honour_lstm_chunks):
     L.check(lib.yt8m_lstm_persist_placement_stats(None, None, None, 1))
     a, ga, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)
     L.check(lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), None, None, 1))
-    assert nl.value == 2 + 6
+    # one forward launch per layer; backward: the library's own partition for F >= 12 -- four parts 2 : 2 : 1 : 1 since round 4
+    # (three parts 3 : 2 : 1 before) -- for each of the two layers
+    nb = ctypes.c_int(0)
+    desc = seq_ops._stack_desc(B, F, D, H, 2, False, 1.0, True)
+    L.check(lib.yt8m_lstm_stack_partition(ctypes.byref(desc), None, ctypes.byref(nb)))
+    assert nb.value == 4 and nl.value == 2 + 2 * nb.value
     for u, v in zip(a + ga, ref + gref):
         assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 5e-6
 

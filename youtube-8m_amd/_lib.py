@@ -15,6 +15,9 @@ class GemmProblem(ctypes.Structure):
                 ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64), ("bias", c_void_p), ("beta", c_float)]
 
 
+STREAM_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)       # yt8m_stream_hook
+
+
 class PersistBwdImages(ctypes.Structure):
     """yt8m_persist_bwd_images (include/yt8m_hip.h): where yt8m_lstm_persist_bwd_images leaves the operand images of its dz."""
     _fields_ = [("plain", ctypes.c_void_p), ("trans", ctypes.c_void_p), ("trans_scaled", ctypes.c_void_p), ("rowscale", ctypes.c_void_p),
@@ -68,6 +71,7 @@ SIGNATURES = {
     "yt8m_lstm_stack_tape_bytes": (c_int64, [DESC]),
     "yt8m_lstm_stack_scratch_bytes": (c_int64, [DESC]),
     "yt8m_lstm_stack_partition": (c_int, [DESC, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "yt8m_lstm_stack_set_prep_hook": (c_int, [P, P]),
     "yt8m_lstm_stack_streams": (c_int, [c_int, PP, ctypes.POINTER(c_void_p)]),
     "yt8m_lstm_stack_fwd": (c_int, [DESC, P, P, PP, PP, P, c_int64, P, c_int64, P]),
     "yt8m_lstm_stack_view": (c_int, [DESC, P, c_int, c_int, ctypes.POINTER(c_void_p)]),

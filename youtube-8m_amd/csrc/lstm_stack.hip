@@ -172,7 +172,10 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // Images written by the recurrences (img_rows > 0) are consumed by products on OTHER streams that may lag a whole part behind, so
   // every launch gets its own K range of a whole-sequence image (944 MB per layer at the headline shape) instead of one re-used
   // part-sized buffer that stream order used to protect.
-  p.img_rows = knob("YT8M_STACK_FUSED_IMAGES", 1) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
+  // Built, bit-exact (tests/test_gpu_round4.py) and measured SLOWER (profiles/r4_sched_knobs.md: 23.35 against 22.45 ms per headline
+  // step): the extra stores and ~600 VALU operations per item slow the recurrence itself by more than the split passes cost -- the
+  // same verdict as round 3's attempt in the team epilogue.  Off by default; YT8M_STACK_FUSED_IMAGES=1 opts in.
+  p.img_rows = knob("YT8M_STACK_FUSED_IMAGES", 0) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
   const int64_t trows = p.img_rows ? p.FB : bmax;
   for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(x3_bytes(H4, trows)); }
   p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, trows)) : 0;
@@ -208,6 +211,9 @@ struct DevState {
 };
 std::mutex g_mu;
 DevState g_dev[16];
+// One-shot host callback of the NEXT yt8m_lstm_stack_bwd call of this thread (yt8m_lstm_stack_set_prep_hook).
+thread_local yt8m_stream_hook g_prep_hook = nullptr;
+thread_local void* g_prep_user = nullptr;
 
 int high_stream(DevState& S, hipStream_t* s) {
   if (*s) return YT8M_OK;
@@ -353,6 +359,15 @@ extern "C" int yt8m_lstm_stack_status(const yt8m_lstm_stack_desc* desc, void* sc
   return rc;
 }
 
+// Registers a one-shot callback for the calling thread's NEXT yt8m_lstm_stack_bwd: invoked on the host, once, right after the first
+// backward recurrence has been enqueued, with the library's weight-gradient stream (everything the callback enqueues there runs
+// behind the operand-image preparation and before the first weight-gradient product).  NULL clears it.
+extern "C" int yt8m_lstm_stack_set_prep_hook(yt8m_stream_hook hook, void* user) {
+  g_prep_hook = hook;
+  g_prep_user = user;
+  return YT8M_OK;
+}
+
 extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W,
                                    const float* const* b, void* tape, int64_t tape_bytes, void* scratch, int64_t scratch_bytes,
                                    yt8m_stream_t stream) {
@@ -455,6 +470,14 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     }
     RC(yt8m_x3_split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));    // h_{t-1}: hs[0 .. F)
   }
+  // Host hook (yt8m_lstm_stack_set_prep_hook): work the caller wants on the weight-gradient stream in the window where that stream
+  // is idle and half the chip is free -- behind the image preparation, while the top layer's first recurrence (enqueued below on
+  // its high-priority stream, i.e. holding its CUs first) runs alone.  The training step puts clip + Adam of the variables whose
+  // gradients are already final (the classifier head: 85 % of LstmModel's parameters) there.
+  yt8m_stream_hook hook = g_prep_hook;
+  void* hook_user = g_prep_user;
+  g_prep_hook = nullptr;
+  g_prep_user = nullptr;
   if (two_sw) ev.wait(S->sw2, ev.record(sw));              // layer 0's chain reads images made on sw
   int phase[MAXL];
   bool wx3_done[MAXL];
@@ -535,6 +558,10 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       }
       phase[l] = (int)((phase[l] + T) % 2);
       hipEvent_t rb = ev.record(s);
+      if (hook) {                                          // the very first recurrence is enqueued: now the caller's work on sw
+        hook(hook_user, (yt8m_stream_t)S->sw);
+        hook = nullptr;
+      }
       bool fused_t = false;
       const float* dzc = dz + t0 * B * H4;
       if (j == nsub - 1) dx_ev = nullptr;

@@ -465,6 +465,62 @@ def _dp_side_stream(dev):
     return st
 
 
+# ---- clip + Adam of the already-final gradients inside the recurrent stack's backward pass ---------------------------------------
+# train.TrainGraph.step (single device) leaves its optimiser arguments in graph.early_optimizer before backward(); when the native
+# stack's backward pass starts, every trainable variable that has reported its gradient final (Variable.grad_done: for LstmModel the
+# MoE head, 97 of 114 M parameters) gets its per-tensor clip + Adam update on the library's weight-gradient stream, behind the
+# operand-image preparation and while the top layer's first recurrence runs alone on half the chip
+# (yt8m_lstm_stack_set_prep_hook).  The same two kernels on the same numbers as the end-of-step pass -- which then only covers what
+# is left (graph.early_done).  A side stream that started at once took CUs from that recurrence (25.2 -> 26.7 ms/step in round 2);
+# here the recurrence is enqueued first.  YT8M_EARLY_ADAM=0 turns it off.
+EARLY_ADAM = _os.environ.get("YT8M_EARLY_ADAM", "1") != "0"
+EARLY_ADAM_RUNS = [0]      # how often the early pass ran (tests assert that it engaged)
+
+
+class _EarlyOpt(object):
+    def __init__(self, graph, ranges):
+        self.graph, self.ranges, self.ran = graph, ranges, False
+        self.cb = _lib.STREAM_HOOK(self._run)                        # keeps the ctypes thunk alive until finish()
+
+    def _run(self, user, stream):
+        g, a = self.graph, self.graph.early_optimizer
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=g.device)):
+            for lo, hi in self.ranges:
+                ops.sqnorm_and_adam(g, a["lr_t"], gscale=1.0, clip=a["clip"], beta1=a["beta1"], beta2=a["beta2"], eps=a["eps"], tensors=(lo, hi))
+        self.ran = True
+        EARLY_ADAM_RUNS[0] += 1
+
+    def finish(self, lib):
+        _lib.check(lib.yt8m_lstm_stack_set_prep_hook(None, None))    # (a failed call may have left it registered)
+        if self.ran:                                                 # an exception inside the callback leaves ran False: the
+            self.graph.early_done = list(self.ranges)                # end-of-step pass then covers everything, nothing is lost
+
+
+def _early_optimizer_hook(graph, lib):
+    if not EARLY_ADAM or graph is None or getattr(graph, "early_optimizer", None) is None or graph.grad_ready_hook is not None:
+        return None
+    if getattr(graph, "early_done", None):
+        return None                                                  # one recurrent stack per step takes the head
+    tv = graph.trainable_variables()
+    ready = [bool(getattr(v, "_done_reported", False)) and v.grad_written for v in tv]
+    ranges, i = [], 0
+    while i < len(tv):
+        if ready[i]:
+            j = i
+            while j + 1 < len(tv) and ready[j + 1]:
+                j += 1
+            ranges.append((i, j + 1))
+            i = j + 1
+        else:
+            i += 1
+    # worth a launch pair only for a substantial share of the parameters
+    if not ranges or sum(tv[k].numel() for lo, hi in ranges for k in range(lo, hi)) < (1 << 22):
+        return None
+    e = _EarlyOpt(graph, ranges)
+    _lib.check(lib.yt8m_lstm_stack_set_prep_hook(e.cb, None))
+    return e
+
+
 class _LstmStack(torch.autograd.Function):
     """MultiRNNCell([BasicLSTMCell] * L) under tf.nn.dynamic_rnn (W/all_frame_models/lstm_model.py:34-47), time-major, as ONE
     op so that the layers can be pipelined: the sequence is cut into time chunks; layer l's hoisted input projection of
@@ -742,8 +798,11 @@ class _LstmStack(torch.autograd.Function):
         bb = (ctypes.c_float * L)(*[float(b.grad_beta()) if b.grad is not None else 0.0 for b in bs])
         dx = torch.empty((desc.F, desc.B, desc.D), dtype=torch.float32, device=dev) if desc.need_dx else None
         Wp = (ctypes.c_void_p * L)(*[w.data.data_ptr() for w in Ws])
+        early = _early_optimizer_hook(Ws[0]._graph, lib)
         _lib.check(lib.yt8m_lstm_stack_bwd(ctypes.byref(desc), _p(x), _p(nf), Wp, _p(tape), tape.numel(), _p(scratch), scratch.numel(),
                                            _p(dout_top), arr(dcs), arr(dhs), arr(dW), arr(db), bW, bb, _p(dx), _stream()))
+        if early is not None:
+            early.finish(lib)
         NATIVE_CALLS["bwd"] += 1
         if PERSIST_CHECK:
             _check_stack(scratch, torch.cuda.current_stream(dev), desc)

@@ -188,18 +188,29 @@ class TrainGraph(object):
             if callable(op):
                 op()
         self.ensure_finalized()
+        lr = exponential_decay(self.base_learning_rate, self.global_step, self.batch_size, self.decay_examples, self.decay)
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
         if self.reducer is not None:
             self.reducer.begin_step()
+            g.early_optimizer = None
+        else:
+            # single device: a recurrent stack's backward pass may apply clip + Adam to the variables whose gradients are final when
+            # it starts (seq_ops._early_optimizer_hook); what it covered comes back in g.early_done
+            g.early_optimizer = {"lr_t": lr_t, "clip": self.clip, "beta1": self.b1, "beta2": self.b2, "eps": self.eps}
+        g.early_done = []
         final_loss.backward()
+        g.early_optimizer = None
         for v in g.trainable_variables():                       # variables the step did not touch: TF skips them
             if not v.grad_written:                              # (None gradient); here their gradient is zero
                 v.grad.zero_()
                 v.grad_written = True
-        lr = exponential_decay(self.base_learning_rate, self.global_step, self.batch_size, self.decay_examples, self.decay)
-        t = self.global_step + 1
-        lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
         if self.reducer is None:
-            ops.sqnorm_and_adam(g, lr_t, gscale=1.0, clip=self.clip, beta1=self.b1, beta2=self.b2, eps=self.eps)
+            nt, pos = len(g.trainable_variables()), 0
+            for lo, hi in sorted(g.early_done) + [(nt, nt)]:    # everything the early pass did not cover
+                ops.sqnorm_and_adam(g, lr_t, gscale=1.0, clip=self.clip, beta1=self.b1, beta2=self.b2, eps=self.eps, tensors=(pos, lo))
+                pos = hi
+            g.early_done = []
         else:
             # gradients are SUMMED over ranks bucket by bucket; the 1/world mean is folded into the optimiser pass, and
             # each bucket is clipped + updated as soon as ITS all-reduce has landed (later buckets still on the wire)
