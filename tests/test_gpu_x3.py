@@ -273,9 +273,9 @@ def test_forward_wavefront_and_cu_budget_give_the_same_results(dev, monkeypatch,
 
 
 def test_persistent_partition_defaults(dev, monkeypatch, honour_lstm_chunks):
-    """The partition the product picks for the persistent kernels (ONE forward launch per layer, THREE backward parts, whatever
-    `chunks` the caller passes) changes how many launches run, not the results: same outputs and gradients as the caller's 2 + 2
-    partition to fp32 rounding; the placement counters see 2 forward + 6 backward launches."""
+    """The partition the product picks for the persistent kernels (ONE forward launch per layer, the library's own backward parts,
+    whatever `chunks` the caller passes) changes how many launches run, not the results: same outputs and gradients as the caller's
+    2 + 2 partition to fp32 rounding; the placement counters see 2 forward + 2 x (parts) backward launches."""
     import ctypes
     import yt8m_amd.seq_ops as seq_ops
     from test_gpu_round2 import _stack_run
@@ -287,8 +287,9 @@ def test_persistent_partition_defaults(dev, monkeypatch, honour_lstm_chunks):
     nf[0], nf[1] = F, 0
     nl = ctypes.c_int64(0)
     ref, gref, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)          # honour_lstm_chunks: the caller's chunks = 2
-    monkeypatch.setattr(seq_ops, "PERSIST_FWD_CHUNKS", 1)
-    monkeypatch.setattr(seq_ops, "PERSIST_BWD_CHUNKS", 3)
+    # plain assignments: honour_lstm_chunks restores the saved values at teardown (monkeypatch would be undone AFTER that fixture and
+    # put its zeros back, switching the native stack off for every later test of the process)
+    seq_ops.PERSIST_FWD_CHUNKS, seq_ops.PERSIST_BWD_CHUNKS = 1, 3
     L.check(lib.yt8m_lstm_persist_placement_stats(None, None, None, 1))
     a, ga, _, _ = _stack_run(dev, B, F, D, H, 2, 2, nf, True)
     L.check(lib.yt8m_lstm_persist_placement_stats(ctypes.byref(nl), None, None, 1))

@@ -534,7 +534,12 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(const XGroup G) {
   x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
-// sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate
+// sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate.
+// Footprint matters more than speed-of-light here: with no LDS and <= 32 VGPRs a workgroup of this kernel fits on a CU that a
+// persistent recurrence occupies (768 threads x 160 VGPRs leave 32 per lane), so in the LSTM step it runs BESIDE the recurrences
+// instead of waiting for a CU like the GEMM it follows -- but alone on its CU, where loads in flight are what it lives on: two
+// positions x two parts are requested at a time (one load at a time made a fix-up 150-280 us beside two recurrences, 1.2 ms of the
+// weight-gradient stream per headline step).
 __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
   const int ft = blockIdx.x >> 4, sixteenth = blockIdx.x & 15;      // 16 workgroups per tile, 16 rows each
   int q = 0;
@@ -548,13 +553,28 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
   const int m0 = tm * TM, n0 = tn * TN;
   const float* base = G.ws + (int64_t)(G.slot_base[q] + rt) * (TM * TN);
   const int64_t pstride = (int64_t)G.rem[q] * (TM * TN);
-  for (int e = sixteenth * (TM * TN / 16) + threadIdx.x * 4; e < (sixteenth + 1) * (TM * TN / 16); e += 256 * 4) {
-    float4 v = *reinterpret_cast<const float4*>(base + e);
-    for (int s = 1; s < S; ++s) {
-      const float4 u = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  for (int e = sixteenth * (TM * TN / 16) + threadIdx.x * 4; e < (sixteenth + 1) * (TM * TN / 16); e += 2 * 256 * 4) {
+    const int e1 = e + 256 * 4;                                      // (4096 floats per slice: both positions are inside it)
+    float4 v0 = *reinterpret_cast<const float4*>(base + e), v1 = *reinterpret_cast<const float4*>(base + e1);
+    int s = 1;
+    for (; s + 1 < S; s += 2) {
+      const float4 a0 = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e);
+      const float4 a1 = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e1);
+      const float4 b0 = *reinterpret_cast<const float4*>(base + (int64_t)(s + 1) * pstride + e);
+      const float4 b1 = *reinterpret_cast<const float4*>(base + (int64_t)(s + 1) * pstride + e1);
+      v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w;
+      v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+      v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+      v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
     }
-    finish_store(g, v, m0 + e / TN, n0 + (e % TN));
+    if (s < S) {
+      const float4 a0 = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e);
+      const float4 a1 = *reinterpret_cast<const float4*>(base + (int64_t)s * pstride + e1);
+      v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w;
+      v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+    }
+    finish_store(g, v0, m0 + e / TN, n0 + (e % TN));
+    finish_store(g, v1, m0 + e1 / TN, n0 + (e1 % TN));
   }
 }
 
@@ -802,7 +822,10 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
               void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   XGroup G;
   G.nprob = 0;
-  constexpr int SLOTS = 256;                                       // one 144 KiB workgroup per CU
+  // one 144 KiB workgroup per CU.  YT8M_X3_SLOTS (tuning aid): the CU count the K-part choice assumes -- beside a half-chip
+  // persistent recurrence only 128 CUs take GEMM workgroups, and fewer K parts mean fewer slabs for the fix-up pass to sum.
+  static const int SLOTS_ENV = getenv("YT8M_X3_SLOTS") ? atoi(getenv("YT8M_X3_SLOTS")) : 0;
+  const int SLOTS = SLOTS_ENV >= 32 && SLOTS_ENV <= 256 ? SLOTS_ENV : 256;
   const int64_t per_part = (int64_t)TM * TN * sizeof(float);
   int64_t nfull = 0, slots = 0, fix = 0;
   for (int i = 0; i < nprob; ++i) {
