@@ -757,7 +757,7 @@ def main():
                     pass
             elif a.workload == "lstm" and roof:
                 try:                   # PMC passes of the headline step, committed with the round's profiles
-                    src = next(f for f in ("r3_pmc_traffic_lstm.json", "r2_pmc_traffic_lstm.json")
+                    src = next(f for f in ("r4_pmc_traffic_lstm.json", "r3_pmc_traffic_lstm.json", "r2_pmc_traffic_lstm.json")
                                if os.path.exists(os.path.join(ROOT, "profiles", f)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", src)))
                     key = roof["kernel"]

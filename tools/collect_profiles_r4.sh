@@ -11,7 +11,7 @@ timeout 900 python $R/bench.py --steps 20 --warmup 5 < /dev/null > $O/bench_line
 # 2. the same workload under kernel trace + stats (no CPU / GAP / extra legs: they are not the measured region)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gap --no-extra < /dev/null > $O/bench_line_profiled.json 2> $O/bench_prof.err
 f=$(find $O/bench -name "*kernel_trace.csv" | head -1)
-python $R/tools/trace_step.py $f 40 3 > $O/step_timeline.txt 2>&1
+python $R/tools/trace_step.py $f 40 3 u8_frames_tm_kernel > $O/step_timeline.txt 2>&1
 # 3. PMC passes of the headline step
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc -o fetch -- python $R/tools/pmc_run_lstm.py 3 < /dev/null > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc -o write -- python $R/tools/pmc_run_lstm.py 3 < /dev/null > /dev/null 2>&1

@@ -79,18 +79,18 @@ def main():
         return 2.0 * pa * M * K + 6.0 * N * K + 4.0 * M * N
 
     # the step's six-product launches (native stack: layer-1 projection over the whole sequence, dx and the grouped layer-1 weight
-    # gradient per backward part of 150 / 100 / 50 steps, layer 0's h-part weight gradient per part)
-    parts = [150, 100, 50]
+    # gradient per backward part of 100 / 100 / 50 / 50 steps, layer 0's h-part weight gradient per part)
+    parts = [100, 100, 50, 50]
     shapes = [(F * B, 4 * H, H)] + [(T * B, H, 4 * H) for T in parts] + [(H, 4 * H, T * B) for T in parts for _ in range(3)]
-    launches = 1 + 3 + 3 + 3
+    launches = 1 + 4 + 4 + 4
     g = pick("gemm_x3_kernel<3>")
     if g:
         fam["gemm_x3"] = {"kernel": g, "hbm_bytes_per_launch": tot(g), "algorithmic_bytes_per_launch": sum(x3_bytes(*sh) for sh in shapes) / launches,
-                          "note": "average over the step's x3 launches (layer-1 projection, dx and weight-gradient products of the three backward parts)"}
+                          "note": "average over the step's x3 launches (layer-1 projection, dx and weight-gradient products of the four backward parts)"}
     g1 = pick("gemm_x3_kernel<1>")
     if g1:
         sh1 = [(F * B, 4 * H, D)] + [(D, 4 * H, T * B) for T in parts]
-        fam["gemm_x1x3"] = {"kernel": g1, "hbm_bytes_per_launch": tot(g1), "algorithmic_bytes_per_launch": sum(x3_bytes(*sh, pa=1) for sh in sh1) / 4.0,
+        fam["gemm_x1x3"] = {"kernel": g1, "hbm_bytes_per_launch": tot(g1), "algorithmic_bytes_per_launch": sum(x3_bytes(*sh, pa=1) for sh in sh1) / 5.0,
                             "note": "one-plane uint8 operand (2 B / element) against a three-plane operand: layer-0 projection and weight gradient"}
     f = pick("lstm_persist_fwd")
     per_step = float(B * 4 * H * 4 * 2 + 3 * B * H * 4)          # z in, gates / c / h / out written
@@ -103,9 +103,9 @@ def main():
                                   "state_exchange_bytes_per_launch": float(F * img_f * 9), "note": note}
     bk = pick("lstm_persist_bwd_kernel")
     if bk:
-        fam["lstm_recurrence_bwd"] = {"kernel": bk, "hbm_bytes_per_launch": tot(bk), "algorithmic_bytes_per_launch": 100 * per_step,
-                                      "state_exchange_bytes_per_launch": float(100 * img_b * 9),
-                                      "note": "six launches per step of 150 / 100 / 50 time steps (two layers): averages per launch = 100 steps"}
+        fam["lstm_recurrence_bwd"] = {"kernel": bk, "hbm_bytes_per_launch": tot(bk), "algorithmic_bytes_per_launch": 75 * per_step,
+                                      "state_exchange_bytes_per_launch": float(75 * img_b * 9),
+                                      "note": "eight launches per step of 100 / 100 / 50 / 50 time steps (two layers): averages per launch = 75 steps"}
     g32 = pick("gemm_grouped_kernel")
     if g32:
         fam["gemm"] = {"kernel": g32, "hbm_bytes_per_launch": tot(g32), "algorithmic_bytes_per_launch": None,

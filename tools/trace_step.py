@@ -1,5 +1,5 @@
 """One training step of a rocprofv3 kernel trace as a timeline: kernels >= min_us in start order with start offset, duration
-and stream (queue).  The step is found between two consecutive adam_chunk_kernel launches.
+and stream (queue).  The step is found between two consecutive launches of a kernel that runs once per step (default adam_chunk_kernel; the LSTM step runs the optimiser twice since round 4: pass u8_frames_tm_kernel).
 usage: python tools/trace_step.py <kernel_trace.csv> [min_us] [which step from the end, default 2] [delimiter kernel]"""
 import csv
 import sys
