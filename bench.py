@@ -16,11 +16,16 @@ Extra lines in the same JSON ("extra", rank 0, N=1 only; each with its own per-f
   configs[1]  MoeModel (2 mixtures) on video-level [1024,1152] features, fp32 (>= 200 timed steps: the step is ~1 ms)
   configs[2]  NetVLADModel (64 clusters) on raw uint8 [B,300,1152] frames + MoE head, fp32
   configs[3]  in bfloat16 operand mode (a labelled VARIANT, never the headline)
+  configs[4]  GatedNetVLADAttentionChainModel in bfloat16 at B = 1024 (its own dtype; the per-GPU share of 8192 on 8 GPUs)
+  configs[3]  at per-GPU batch 256 and 512 (batch sweep of the headline configuration, fp32)
 Other legs (rank 0):
   roofline     : hipEvent timing of every kernel family inside the library (separate pass after the timed region);
                  algorithmic FLOPs / family time vs the fp32 matrix peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline : the torch-CPU fp32 restatement of the same step (oracle/torch_ref.py, kind "port") on the host cores,
-                 bounded sample (reduced batch); N=1 only.
+                 bounded sample (B = 32, thread count by probe, per-frame port and its torch.nn.LSTM twin: the faster is
+                 `value`); N=1 only.
+  reducer      : N > 1 (or --force-reducer): algorithm / bucket / CU-reserve settings and, per rank, the time-out word of the
+                 persistent recurrences, placement statistics and a traced bucket timeline of two extra steps.
   gap_at_20    : BASELINE.json's second metric -- GAP@20 on a held-out synthetic teacher shard after 768 training steps
                  of a fresh MoeModel (outside the timed region, ~1.5 s; N=1 only; --no-gap skips it).
 """

@@ -108,6 +108,10 @@ int64_t yt8m_x3_image_bytes(int64_t rows, int64_t K);
 int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
 int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes,
                             yt8m_stream_t stream);
+/* Where the K parts of a split tile are summed by the following x3 / x1x3 / b1 launches OF THE CALLING THREAD: 0 = process default
+ * (separate fix-up pass; YT8M_X3_FUSED_COMBINE=1 flips it), 1 = by the last part to arrive, inside the launch (no second kernel on
+ * the stream: for products on a critical chain), 2 = separate pass.  Same sums in the same order either way. */
+int yt8m_x3_set_combine(int mode);
 /* fp32 products through the LIBRARY's choice of kernel (csrc/gemm_auto.hip): per problem -- never per group, so a product takes
  * the same kernel and summation order alone or grouped -- a cost estimate (yt8m_gemm_x3_pays: tile efficiency at 256 x 256,
  * occupancy, the split passes) picks the six-product bf16-pipe kernel or the fp32-MFMA kernel.  Arguments as yt8m_gemm_f32_grouped

@@ -783,6 +783,9 @@ namespace {
 // zero again), handed out to launches as a ring -- two launches can only share a counter if more than 64 Ki split tiles lie between
 // them, i.e. never while the first one is still running.
 constexpr uint32_t CNT_CAP = 1u << 16;
+// yt8m_x3_set_combine: per-thread override of where the K parts of the following image-GEMM launches are summed
+// (0 = the process default: separate fix-up pass unless YT8M_X3_FUSED_COMBINE=1; 1 = inside the launch; 2 = separate pass).
+thread_local int g_combine_mode = 0;
 struct TileCounters {
   std::mutex mu;
   unsigned* base[16] = {nullptr};
@@ -796,7 +799,8 @@ struct TileCounters {
     // keeps its 144 KB of LDS -- and the recurrence launch that is waiting for that CU.  Opt-in: YT8M_X3_FUSED_COMBINE=1.
     static const bool off = getenv("YT8M_X3_FUSED_COMBINE") == nullptr || atoi(getenv("YT8M_X3_FUSED_COMBINE")) == 0;
     int dev = 0;
-    if (off || n <= 0 || (uint32_t)n > CNT_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    const bool fused = g_combine_mode == 1 || (g_combine_mode == 0 && !off);
+    if (!fused || n <= 0 || (uint32_t)n > CNT_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     if (failed[dev]) return nullptr;
     if (!base[dev]) {
@@ -894,6 +898,12 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   return launch_status("gemm_x3_kernel");
 }
 }  // namespace
+
+extern "C" int yt8m_x3_set_combine(int mode) {
+  YT8M_REQUIRE(mode >= 0 && mode <= 2, YT8M_E_BADARG, "mode must be 0 (default), 1 (inside the launch) or 2 (separate pass)");
+  g_combine_mode = mode;
+  return YT8M_OK;
+}
 
 // C[M,N] (+)= A . B^T (+ bias) from the x3 images of A ([M rows, K]) and B ([N rows, K]); yt8m_gemm_problem.A / .B are the
 // images, lda / ldb are ignored, K is the logical K (the images are padded to a multiple of 16).  Up to four problems.

@@ -411,14 +411,22 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       if (l > 0) ev.wait(s, done[(size_t)(l - 1) * P.nf + c]);
       float* zc = at<float>(tape, P.z[l]) + t0 * B * H4;
       void* gw = at<char>(scratch, P.gws[l]);
+      // products on the critical chain (forward projections, dx): their K parts are summed inside the launch -- the separate
+      // fix-up pass is one more kernel (and two launch seams) between a recurrence and the next.  Measured: 22.07-22.11 ms/step with it
+      // against 21.96-21.97 without -- off; knob YT8M_STACK_CHAIN_COMBINE=1
+      static const int chain_combine = knob("YT8M_STACK_CHAIN_COMBINE", 0);
+      if (chain_combine) yt8m_x3_set_combine(1);
       if (l == 0 && P.u8) {
         RC(yt8m_gemm_x1x3_nt(M, H4, D, at<char>(scratch, P.qimg) + (t0 * B / 32) * (D / 16) * 1024, at<char>(scratch, P.w3t), zc, H4, b[0],
                              at<float>(tape, P.rrow) + t0 * B, at<float>(scratch, P.wcs), U8_BETA, gw, P.gws_bytes, s));
+        yt8m_x3_set_combine(0);
       } else {
         const float* src = l ? at<float>(tape, P.out[l - 1]) + t0 * B * H : static_cast<const float*>(x) + t0 * B * D;
         RC(yt8m_x3_split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
         yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, at<char>(scratch, P.wxt3[l]), 0, zc, H4, b[l], 0.0f};
-        RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s));
+        const int grc = yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
+        yt8m_x3_set_combine(0);
+        RC(grc);
       }
       RC(yt8m_lstm_persist_fwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), at<float>(tape, P.hs[l]),
                                at<float>(tape, P.out[l]), num_frames, t0, T, B, H, desc->forget_bias, at<char>(scratch, P.pws[l]),
@@ -581,7 +589,11 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         }
         float* dst = l ? at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H : dx + t0 * B * D;
         yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 0.0f};
-        RC(yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx));
+        static const int chain_combine_b = knob("YT8M_STACK_CHAIN_COMBINE", 0);
+        if (chain_combine_b) yt8m_x3_set_combine(1);
+        const int grc = yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx);
+        yt8m_x3_set_combine(0);
+        RC(grc);
         dx_ev = ev.record(sx);
         if (c == 0 && j == 0) last.push_back(dx_ev);
       }
