@@ -132,3 +132,65 @@ def test_early_head_optimizer_pass_is_bitwise_the_end_of_step_pass(dev, flags, m
     for u, v in zip(a[:4], b[:4]):
         assert torch.equal(u, v)
     assert a[4] == b[4]
+
+
+# ---- reduce-scatter + all-gather == all-reduce on real RCCL, two ranks (needs >= 2 GPUs, skipped on the 1-GPU box) ------
+def _rsag_worker(rank, world, port, q):
+    try:
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import __graft_entry__
+        __graft_entry__.load_package()
+        import torch as th
+        import torch.distributed as dist
+        import yt8m_amd.parallel as parallel
+        th.cuda.set_device(rank)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                                device_id=th.device("cuda", rank))
+        n = 1000003                                                    # n % world != 0: the tail takes its own all-reduce
+        gen = th.Generator(device="cuda").manual_seed(100 + rank)
+        src = th.randn(n, device="cuda", generator=gen)
+        a, b = src.clone(), src.clone()
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        parallel._rsag_torch(b, None).wait()
+        th.cuda.synchronize()
+        ok = bool(th.equal(a, b))
+        # the library's own transport (yt8m_comm_allreduce_rsag_f32) against its all-reduce
+        store = dist.TCPStore("127.0.0.1", port + 1, world, rank == 0)
+
+        def exchange(uid):
+            if rank == 0:
+                store.set("uid", uid)
+                return uid
+            return store.get("uid")
+
+        comm = parallel.CabiComm(rank, world, exchange=exchange, device=rank)
+        c, d = src.clone(), src.clone()
+        comm.all_reduce(c, algo="allreduce").wait()
+        comm.all_reduce(d, algo="rs_ag").wait()
+        th.cuda.synchronize()
+        ok = ok and bool(th.equal(c, d)) and bool(th.allclose(a, c, rtol=0, atol=0))
+        comm.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok" if ok else "mismatch"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_rsag_equals_allreduce_bitwise_on_two_ranks(dev):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rsag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
