@@ -799,10 +799,12 @@ class _LstmStack(torch.autograd.Function):
         dx = torch.empty((desc.F, desc.B, desc.D), dtype=torch.float32, device=dev) if desc.need_dx else None
         Wp = (ctypes.c_void_p * L)(*[w.data.data_ptr() for w in Ws])
         early = _early_optimizer_hook(Ws[0]._graph, lib)
-        _lib.check(lib.yt8m_lstm_stack_bwd(ctypes.byref(desc), _p(x), _p(nf), Wp, _p(tape), tape.numel(), _p(scratch), scratch.numel(),
-                                           _p(dout_top), arr(dcs), arr(dhs), arr(dW), arr(db), bW, bb, _p(dx), _stream()))
-        if early is not None:
-            early.finish(lib)
+        try:
+            _lib.check(lib.yt8m_lstm_stack_bwd(ctypes.byref(desc), _p(x), _p(nf), Wp, _p(tape), tape.numel(), _p(scratch), scratch.numel(),
+                                               _p(dout_top), arr(dcs), arr(dhs), arr(dW), arr(db), bW, bb, _p(dx), _stream()))
+        finally:
+            if early is not None:                                    # also on failure: the library must not keep a pointer to a
+                early.finish(lib)                                    # callback thunk that is about to be collected
         NATIVE_CALLS["bwd"] += 1
         if PERSIST_CHECK:
             _check_stack(scratch, torch.cuda.current_stream(dev), desc)
