@@ -130,6 +130,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bwd":           # stand-alone backward kernel only (A/B of kernel variants)
         timing_bwd()
         sys.exit(0)
+    compare("audio stack H=128", 128, 12, 128, 128, 2, 2, 1)
+    compare("audio stack H=128 b=40", 40, 7, 128, 128, 2, 1, 1)
     compare("small cold H=256", 8, 9, 64, 256, 2, 1, 1)
     compare("pad rows H=512", 50, 12, 96, 512, 2, 2, 1)
     compare("headline shape short", 128, 16, 1152, 1024, 2, 1, 0)

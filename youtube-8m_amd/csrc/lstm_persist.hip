@@ -234,8 +234,10 @@ constexpr int NEPI = 4;      // epilogue waves (item k is finished by epilogue w
 template <int NQ, int PD, bool SH>
 __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a) {
   constexpr int HQ = NQ / 2;                             // q-groups per wave whose weights sit in registers (the rest: LDS)
+  constexpr int NL = NQ - HQ;                            // ... in LDS (NQ = 1, H = 128: the single q-group; HQ = 0)
+  constexpr int HQA = HQ > 0 ? HQ : 1;                   // array extents (no zero-length arrays)
   __shared__ __attribute__((aligned(16))) float red[NSLOT][8][2][4][64];   // [slot][wave][col half][acc reg][lane]: 64 KB
-  __shared__ __attribute__((aligned(16))) float4 Wl[8][HQ][2][64];         // LDS-resident half of W_h's slice: 8 * HQ * 2 KB
+  __shared__ __attribute__((aligned(16))) float4 Wl[8][NL][2][64];         // LDS-resident half of W_h's slice: 8 * NL * 2 KB
   __shared__ unsigned lds_cnt[NSLOT], lds_free[NSLOT];
   // Only matrix wave 0 polls the arrival counters in memory; it posts what it has seen per local tile here and the other seven
   // matrix waves wait on LDS (eight waves x 256 workgroups polling the same lines was the bulk of the fabric's request traffic).
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
 #pragma unroll
-    for (int qq = 0; qq < HQ; ++qq) {
+    for (int qq = 0; qq < NL; ++qq) {
       Wl[w][qq][0][lane] = w_frag(HQ + qq, 0);
       Wl[w][qq][1][lane] = w_frag(HQ + qq, 1);
     }
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
   if (w < 8) {
     // =============================== matrix waves ===============================
     const int i16 = lane & 15, kq = lane >> 4;
-    float4 Wr[HQ][2];
+    float4 Wr[HQA][2];
 #pragma unroll
     for (int qg = 0; qg < HQ; ++qg) { Wr[qg][0] = w_frag(qg, 0); Wr[qg][1] = w_frag(qg, 1); }
     // A fragments of item (s, T), this wave's K range: exchange buffer parity s & 1, one coherent 1 KB block load per q-group
@@ -1494,9 +1496,11 @@ struct Geometry { int NQ, NU, RB, NT16, per, pf; };
 
 bool persist_geometry(int64_t B, int64_t H, Geometry* geo) {
   static const bool off = getenv("YT8M_NO_PERSIST") != nullptr;
-  if (off || B < 1 || H < 256 || (H % 128) != 0 || H > 1024) return false;
+  if (off || B < 1 || H < 128 || (H % 128) != 0 || H > 1024) return false;
   const int NQ = (int)(H / 128);
-  if (!(NQ == 2 || NQ == 4 || NQ == 6 || NQ == 8)) return false;
+  // (NQ odd > 1 would split the register / LDS halves unevenly: not instantiated.  NQ = 1 -- H = 128, the audio stack of the
+  // parallel rgb / audio models, lstm_parallel_finaloutput_model.py:13-73 -- keeps its single q-group per wave in LDS.)
+  if (!(NQ == 1 || NQ == 2 || NQ == 4 || NQ == 6 || NQ == 8)) return false;
   int dev = 0;
   const int cus = device_cus(&dev);
   const int NU = (int)(H / 8);
@@ -1687,6 +1691,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
     rc = launch_status("hx_pack_kernel");
     if (rc != YT8M_OK) return rc;
     switch (geo.NQ) {
+      case 1: rc = launch_fwd<1>(a, grid, s); break;
       case 2: rc = launch_fwd<2>(a, grid, s); break;
       case 4: rc = launch_fwd<4>(a, grid, s); break;
       case 6: rc = launch_fwd<6>(a, grid, s); break;
@@ -1702,9 +1707,9 @@ struct GeometryB { int NQB, NUB, RB, NT16, per, pf; };
 
 bool persist_geometry_bwd(int64_t B, int64_t H, GeometryB* geo) {
   static const bool off = getenv("YT8M_NO_PERSIST") != nullptr || getenv("YT8M_NO_PERSIST_BWD") != nullptr;
-  if (off || B < 1 || H < 256 || (H % 256) != 0 || H > 1024) return false;
+  if (off || B < 1 || H > 1024 || !(H == 128 || (H >= 256 && (H % 256) == 0))) return false;
   const int NQB = (int)(H / 32);
-  if (!(NQB == 8 || NQB == 16 || NQB == 24 || NQB == 32)) return false;
+  if (!(NQB == 4 || NQB == 8 || NQB == 16 || NQB == 24 || NQB == 32)) return false;
   int dev = 0;
   const int cus = device_cus(&dev);
   const int NUB = (int)(H / 16);
@@ -1846,6 +1851,7 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
   YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
   int rc;
   switch (geo.NQB) {
+    case 4: rc = launch_bwd<4>(a, grid, s); break;
     case 8: rc = launch_bwd<8>(a, grid, s); break;
     case 16: rc = launch_bwd<16>(a, grid, s); break;
     case 24: rc = launch_bwd<24>(a, grid, s); break;
