@@ -149,6 +149,13 @@ int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_
  * yt8m_gemm_x3_nt_grouped (lda / ldb = K-block strides, 0 = exact). */
 int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
 int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* one-plane forms of yt8m_x3_split_colsum and yt8m_gemm_x1x3_nt_ex (the recurrent stack in bf16-operand mode: hoisted products on
+ * bf16 roundings of their operands, the recurrence itself stays fp32-grade) */
+int yt8m_bf16_image_colsum(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
+                           void* trans, void* trans_scaled, float* colpart, float* colpart_scaled, yt8m_stream_t stream);
+int yt8m_gemm_b1_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B1, int64_t skb, float* C, int64_t ldc,
+                       const float* bias, float alpha, const float* rowscale, const float* colsum, float colsum_scale, float beta,
+                       void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* yt8m_x3_split with a third output from the same pass: trans_scaled = x3 image of (diag(rowscale) . scale . src)^T
  * ([C rows, K = R]; rowscale [R]).  Any image may be NULL; rowscale and trans_scaled come together. */
 int yt8m_x3_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,

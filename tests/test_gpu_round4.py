@@ -194,3 +194,67 @@ def test_rsag_equals_allreduce_bitwise_on_two_ranks(dev):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---- --compute_dtype=bfloat16 on the native recurrent stack: hoisted products on one-plane bf16 images, fp32-grade recurrence ------
+@pytest.mark.parametrize("u8", [True, False])
+def test_native_stack_in_bf16_operand_mode(dev, flags, u8):
+    """LstmModel with --compute_dtype=bfloat16 at a shape the library's stack takes (F B >= 1024, H = 256): the input projections,
+    dx and the weight gradients run on the b1 kernel over bf16 roundings of their operands, the recurrence on the persistent
+    fp32-grade kernels.  Predictions against the value emulation of exactly that (torch_ref.lstm_stack(bf16_operands="input"));
+    gradients against the fp32 oracle within bf16 operand noise."""
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.seq_ops as seq_ops
+    import yt8m_amd.train as train
+    from oracle import np_ref, torch_ref
+    from yt8m_amd.feature_transform import IdenticalTransformer
+    from yt8m_amd.variables import reset_default_graph
+    flags.lstm_cells, flags.lstm_layers, flags.compute_dtype = "256", 2, "bfloat16"
+    rs = np.random.RandomState(61)
+    B, F, D, V = 32, 32, 64, 19
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 1
+    y = rs.rand(B, V) < 0.15
+    if u8:
+        q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+        x64 = np_ref.dequant_l2norm_folded(q, nf)
+        xin = torch.from_numpy(q).to(dev)
+        tcls = None
+    else:
+        x64 = rs.randn(B, F, D) * (np.arange(F)[None, :, None] < nf[:, None, None])
+        xin = torch.from_numpy(x64.astype(np.float32)).to(dev)
+        x64 = x64.astype(np.float32).astype(np.float64)
+        tcls = IdenticalTransformer
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g, transformer_class=tcls)
+    yd, nfd = torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+    tg.forward(xin, yd, nfd)
+    g.finalize()
+    # small weights: with O(1) gains a 32-step recurrence amplifies the 2^-9 operand rounding chaotically and no emulation tracks it
+    P = {k: (rs.randn(*v.shape) * (0.06 if "RNN" in k else 0.05)).astype(np.float32) for k, v in g.vars.items()}
+    for k, v in P.items():
+        g.vars[k].data.copy_(torch.from_numpy(v).to(dev).view(g.vars[k].data.shape))
+    n0 = seq_ops.NATIVE_CALLS["fwd"]
+    res = tg.forward(xin, yd, nfd)
+    if seq_ops.NATIVE_CALLS["fwd"] == n0:
+        pytest.skip("the native stack did not take this shape on this device")
+    loss = tg.loss(res, yd)
+    loss.backward()
+    T = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    tp = {k: T(v).requires_grad_(True) for k, v in P.items()}
+    layers = [(tp["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l], tp["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l])
+              for l in range(2)]
+    with torch.no_grad():
+        ste = torch_ref.lstm_model_state(T(x64), torch.from_numpy(nf.astype(np.int64)), layers, bf16_operands="input")
+        pre = torch_ref.moe(ste, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    got = res["predictions"].detach().cpu().double().numpy()
+    assert np.abs(got - pre.numpy()).max() < 3e-3
+    st = torch_ref.lstm_model_state(T(x64), torch.from_numpy(nf.astype(np.int64)), layers)
+    pr = torch_ref.moe(st, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, T(y))
+    lr.backward()
+    assert np.abs(got - pr.detach().numpy()).max() < 3e-2
+    for k, t in tp.items():
+        ref = t.grad.numpy()
+        gk = g.vars[k].grad.detach().cpu().double().numpy().reshape(ref.shape)
+        assert np.abs(gk - ref).max() <= 6e-2 * max(np.abs(ref).max(), 1e-3), k

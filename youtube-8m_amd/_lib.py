@@ -67,6 +67,9 @@ SIGNATURES = {
     "yt8m_x3_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "yt8m_x3_split_colsum": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P]),
     "yt8m_x3_set_combine": (c_int, [c_int]),
+    "yt8m_bf16_image_colsum": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P]),
+    "yt8m_gemm_b1_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, c_float, c_float, P,
+                                   c_int64, P]),
     "yt8m_u8_frames_image_t": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),
     "yt8m_lstm_stack_supported": (c_int, [DESC]),
     "yt8m_lstm_stack_tape_bytes": (c_int64, [DESC]),

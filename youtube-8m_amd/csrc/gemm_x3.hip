@@ -778,6 +778,25 @@ extern "C" int yt8m_x3_split_colsum(const float* src, int64_t R, int64_t C, int6
   return launch_status("x3_split_kernel");
 }
 
+// The one-plane (bf16 rounding) form of yt8m_x3_split_colsum: plain / trans / trans_scaled are ONE-plane images (operands of
+// yt8m_gemm_b1_nt_grouped / _ex), the column sums are those of the fp32 source.  The recurrent stack in bf16-operand mode.
+extern "C" int yt8m_bf16_image_colsum(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,
+                                      void* trans, void* trans_scaled, float* colpart, float* colpart_scaled, yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans || trans_scaled), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE((rowscale != nullptr) == (trans_scaled != nullptr || colpart_scaled != nullptr), YT8M_E_BADARG,
+               "rowscale comes with trans_scaled / colpart_scaled");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans) | reinterpret_cast<uintptr_t>(trans_scaled)) & 15) == 0,
+               YT8M_E_BADARG, "images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<1>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled), colpart, colpart_scaled);
+  return launch_status("x3_split_kernel");
+}
+
 namespace {
 // Arrival counters of split tiles: one block of 64 Ki words per device, zeroed once (every completed tile leaves its counter at
 // zero again), handed out to launches as a ring -- two launches can only share a counter if more than 64 Ki split tiles lie between
@@ -950,4 +969,17 @@ extern "C" int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void*
   yt8m_gemm_problem p;
   p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = ska; p.B = B3; p.ldb = skb; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
   return x3_launch<1>(1, &p, rowscale, colsum, colsum_scale, alpha, workspace, workspace_bytes, stream);
+}
+
+// One-plane x one-plane product with the affine epilogue of yt8m_gemm_x1x3_nt_ex: C (+)= alpha * rowscale[m] * (A1 . B1^T +
+// colsum_scale * colsum[n]) + bias[n].  The uint8 layer-0 projection and weight gradient of the recurrent stack in bf16-operand
+// mode ((q - 128) is exact in bf16; the other operand is the bf16 rounding of (4/255) W^T or of r (.) dz).
+extern "C" int yt8m_gemm_b1_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B1, int64_t skb, float* C,
+                                  int64_t ldc, const float* bias, float alpha, const float* rowscale, const float* colsum,
+                                  float colsum_scale, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(!(rowscale || colsum || alpha != 1.0f) || (N % 4) == 0, YT8M_E_SHAPE, "the affine epilogue needs N % 4 == 0");
+  YT8M_REQUIRE(!colsum || (reinterpret_cast<uintptr_t>(colsum) & 15) == 0, YT8M_E_SHAPE, "colsum must be 16-byte aligned");
+  yt8m_gemm_problem p;
+  p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = ska; p.B = B1; p.ldb = skb; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
+  return x3_launch<0>(1, &p, rowscale, colsum, colsum_scale, alpha, workspace, workspace_bytes, stream);
 }

@@ -54,6 +54,7 @@ int chunks(int64_t F, int n, Part* out) {
 struct Plan {
   int64_t B, F, D, H, FB;
   int L, u8, need_dx;
+  int bf16;                                                // hoisted products on ONE-plane bf16 operand images (input_u8 bit 1)
   int nf, nb;
   Part fp[MAXP], bp[MAXP];
   // tape (bytes from its base)
@@ -82,7 +83,8 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   if (d->L < 1 || d->L > MAXL) return "1..8 layers";
   if (d->B < 1 || d->F < 1 || d->D < 1 || d->H < 1) return "empty dimension";
   Plan& p = *P;
-  p.B = d->B; p.F = d->F; p.D = d->D; p.H = d->H; p.L = d->L; p.u8 = d->input_u8 != 0; p.need_dx = d->need_dx != 0;
+  p.B = d->B; p.F = d->F; p.D = d->D; p.H = d->H; p.L = d->L; p.u8 = (d->input_u8 & 1) != 0; p.need_dx = d->need_dx != 0;
+  p.bf16 = (d->input_u8 & 2) != 0;
   p.FB = p.F * p.B;
   if (p.FB >= (1LL << 31) - 64) return "too many frame rows";
   if (!yt8m_lstm_persist_supported(p.B, p.H) || !yt8m_lstm_persist_bwd_supported(p.B, p.H))
@@ -148,9 +150,10 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   for (int l = 0; l <= p.L; ++l) { p.gws[l] = o; o += p.gws_bytes; }
   for (int l = 0; l < p.L; ++l) { p.gwx[l] = o; o += p.gws_bytes; }
   p.gws2 = o; o += p.gws_bytes;
+  auto ib = [&](int64_t rows, int64_t K) { return p.bf16 ? x1_bytes(rows, K) : x3_bytes(rows, K); };
   const int64_t H4 = 4 * p.H;
   p.qimg = o; o += p.u8 ? up256(x1_bytes(p.FB, p.D)) : 0;
-  p.w3t = o; o += p.u8 ? up256(x3_bytes(H4, p.D)) : 0;
+  p.w3t = o; o += p.u8 ? up256(ib(H4, p.D)) : 0;
   p.wcs = o; o += up256(H4 * 4);
   int64_t fmax = 0, bmax = 0;
   for (int c = 0; c < p.nf; ++c) fmax = std::max(fmax, p.fp[c].T * p.B);
@@ -158,16 +161,16 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   for (int l = 0; l < p.L; ++l) {
     const int64_t Din = l ? p.H : p.D;
     const bool x1 = l == 0 && p.u8;
-    p.wxt3[l] = o; o += x1 ? 0 : up256(x3_bytes(H4, Din));
-    p.xi[l] = o; o += x1 ? 0 : up256(x3_bytes(fmax, Din));
+    p.wxt3[l] = o; o += x1 ? 0 : up256(ib(H4, Din));
+    p.xi[l] = o; o += x1 ? 0 : up256(ib(fmax, Din));
     p.dz[l] = o; o += up256(FBH * 4 * 4);
     p.dbuf[l] = o; o += l + 1 < p.L ? up256(FBH * 4) : 0;
     p.work[l] = o; o += up256(4 * BH * 4);
     const bool dxl = l > 0 || p.need_dx;
-    p.dz3[l] = o; o += dxl ? up256(x3_bytes(bmax, H4)) : 0;
-    p.wx3[l] = o; o += dxl ? up256(x3_bytes(Din, H4)) : 0;
-    p.xT[l] = o; o += x1 ? up256(x1_bytes(p.D, p.FB)) : up256(x3_bytes(Din, p.FB));
-    p.hT[l] = o; o += up256(x3_bytes(p.H, p.FB));
+    p.dz3[l] = o; o += dxl ? up256(ib(bmax, H4)) : 0;
+    p.wx3[l] = o; o += dxl ? up256(ib(Din, H4)) : 0;
+    p.xT[l] = o; o += x1 ? up256(x1_bytes(p.D, p.FB)) : up256(ib(Din, p.FB));
+    p.hT[l] = o; o += up256(ib(p.H, p.FB));
   }
   // Images written by the recurrences (img_rows > 0) are consumed by products on OTHER streams that may lag a whole part behind, so
   // every launch gets its own K range of a whole-sequence image (944 MB per layer at the headline shape) instead of one re-used
@@ -175,10 +178,10 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // Built, bit-exact (tests/test_gpu_round4.py) and measured SLOWER (profiles/r4_sched_knobs.md: 23.35 against 22.45 ms per headline
   // step): the extra stores and ~600 VALU operations per item slow the recurrence itself by more than the split passes cost -- the
   // same verdict as round 3's attempt in the team epilogue.  Off by default; YT8M_STACK_FUSED_IMAGES=1 opts in.
-  p.img_rows = knob("YT8M_STACK_FUSED_IMAGES", 0) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
+  p.img_rows = (knob("YT8M_STACK_FUSED_IMAGES", 0) && !p.bf16) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
   const int64_t trows = p.img_rows ? p.FB : bmax;
-  for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(x3_bytes(H4, trows)); }
-  p.dzT3s = o; o += p.u8 ? up256(x3_bytes(H4, trows)) : 0;
+  for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(ib(H4, trows)); }
+  p.dzT3s = o; o += p.u8 ? up256(ib(H4, trows)) : 0;
   const int64_t ci = p.img_rows ? up256((int64_t)p.img_rows * MAXP * 2 * H4 * 4) : 0;
   for (int l = 0; l < p.L; ++l) { p.cimg[l] = o; o += ci; }
   p.cimgs = o; o += p.u8 ? ci : 0;
@@ -385,6 +388,12 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
   Ev ev(*S, 0);
   hipStream_t main = as_stream(stream);
   const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H;
+  // bf16-operand mode (--compute_dtype=bfloat16): the hoisted products take ONE-plane images (the bf16 roundings of their operands)
+  // on the b1 kernel instead of three-plane images on the x3 kernel; the recurrence stays what it is (fp32-grade)
+  const bool bf = P.bf16 != 0;
+  auto split = [&](const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, hipStream_t st) {
+    return bf ? yt8m_bf16_image(src, R, C, ld, scale, plain, trans, (yt8m_stream_t)st) : yt8m_x3_split(src, R, C, ld, scale, plain, trans, (yt8m_stream_t)st);
+  };
   hipEvent_t start = ev.record(main);
   for (int l = 0; l < P.L; ++l) ev.wait(S->rs[l], start);
   // per layer, once: zero initial state, operand images of the input weights
@@ -396,10 +405,10 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
     if (l == 0 && P.u8) {
       RC(yt8m_u8_frames_image(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, 1e-12f, at<char>(scratch, P.qimg), nullptr,
                               at<float>(tape, P.rrow), s));
-      RC(yt8m_x3_split(W[0], D, H4, H4, U8_ALPHA, nullptr, at<char>(scratch, P.w3t), s));          // (alpha W_x)^T: rows 4H, K = D
+      RC(split(W[0], D, H4, H4, U8_ALPHA, nullptr, at<char>(scratch, P.w3t), s));                  // (alpha W_x)^T: rows 4H, K = D
       RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
     } else {
-      RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, nullptr, at<char>(scratch, P.wxt3[l]), s));         // W_x^T: rows 4H, K = Din
+      RC(split(W[l], Din, H4, H4, 1.0f, nullptr, at<char>(scratch, P.wxt3[l]), s));                 // W_x^T: rows 4H, K = Din
     }
   }
   std::vector<hipEvent_t> done((size_t)P.L * P.nf, nullptr);
@@ -417,14 +426,18 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       static const int chain_combine = knob("YT8M_STACK_CHAIN_COMBINE", 0);
       if (chain_combine) yt8m_x3_set_combine(1);
       if (l == 0 && P.u8) {
-        RC(yt8m_gemm_x1x3_nt(M, H4, D, at<char>(scratch, P.qimg) + (t0 * B / 32) * (D / 16) * 1024, at<char>(scratch, P.w3t), zc, H4, b[0],
-                             at<float>(tape, P.rrow) + t0 * B, at<float>(scratch, P.wcs), U8_BETA, gw, P.gws_bytes, s));
+        const char* qi = at<char>(scratch, P.qimg) + (t0 * B / 32) * (D / 16) * 1024;
+        const int prc = bf ? yt8m_gemm_b1_nt_ex(M, H4, D, qi, 0, at<char>(scratch, P.w3t), 0, zc, H4, b[0], 1.0f, at<float>(tape, P.rrow) + t0 * B,
+                                                at<float>(scratch, P.wcs), U8_BETA, 0.f, gw, P.gws_bytes, s)
+                           : yt8m_gemm_x1x3_nt(M, H4, D, qi, at<char>(scratch, P.w3t), zc, H4, b[0], at<float>(tape, P.rrow) + t0 * B,
+                                               at<float>(scratch, P.wcs), U8_BETA, gw, P.gws_bytes, s);
         yt8m_x3_set_combine(0);
+        RC(prc);
       } else {
         const float* src = l ? at<float>(tape, P.out[l - 1]) + t0 * B * H : static_cast<const float*>(x) + t0 * B * D;
-        RC(yt8m_x3_split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
+        RC(split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
         yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, at<char>(scratch, P.wxt3[l]), 0, zc, H4, b[l], 0.0f};
-        const int grc = yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
+        const int grc = bf ? yt8m_gemm_b1_nt_grouped(1, &pr, gw, P.gws_bytes, s) : yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
         yt8m_x3_set_combine(0);
         RC(grc);
       }
@@ -462,6 +475,14 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   const int fuse_dz = knob("YT8M_STACK_FUSE_DZ_SPLIT", 0);
   const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H, FB = P.FB;
   const int64_t KBtot = FB / 16;
+  const bool bf = P.bf16 != 0;                             // one-plane operand images + the b1 kernel (see yt8m_lstm_stack_fwd)
+  const int64_t KBB = bf ? 1024 : 3072;                    // bytes of one K block of a 32-row group in an operand image
+  auto split = [&](const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, hipStream_t st) {
+    return bf ? yt8m_bf16_image(src, R, C, ld, scale, plain, trans, (yt8m_stream_t)st) : yt8m_x3_split(src, R, C, ld, scale, plain, trans, (yt8m_stream_t)st);
+  };
+  auto gemm = [&](int n, const yt8m_gemm_problem* pr, void* ws, int64_t wsb, hipStream_t st) {
+    return bf ? yt8m_gemm_b1_nt_grouped(n, pr, ws, wsb, (yt8m_stream_t)st) : yt8m_gemm_x3_nt_grouped(n, pr, ws, wsb, (yt8m_stream_t)st);
+  };
   hipEvent_t start = ev.record(main);
   ev.wait(sw, start);
   if (two_sw) ev.wait(S->sw2, start);
@@ -474,9 +495,9 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     } else {
       const float* src = l ? at<float>(tape, P.out[l - 1]) : static_cast<const float*>(x);
       const int64_t Din = l ? H : D;
-      RC(yt8m_x3_split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
+      RC(split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
     }
-    RC(yt8m_x3_split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));    // h_{t-1}: hs[0 .. F)
+    RC(split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));            // h_{t-1}: hs[0 .. F)
   }
   // Host hook (yt8m_lstm_stack_set_prep_hook): work the caller wants on the weight-gradient stream in the window where that stream
   // is idle and half the chip is free -- behind the image preparation, while the top layer's first recurrence (enqueued below on
@@ -541,7 +562,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       const float* dout = l == P.L - 1 ? dout_top : at<float>(scratch, P.dbuf[l]);
       float* dz = at<float>(scratch, P.dz[l]);
       // this launch's K range of the whole-sequence transposed image(s) (fused_img): (4H / 32) row groups x (rows / 16) K blocks
-      const int64_t toff = fused_img ? (H4 / 32) * (img_done_rows[l] / 16) * 3072 : 0;
+      const int64_t toff = fused_img ? (H4 / 32) * (img_done_rows[l] / 16) * 3072 : 0;            // (fused_img: three-plane mode only)
       char* dzT_img = at<char>(scratch, P.dzT3[l]) + toff;
       char* dzTs_img = at<char>(scratch, P.dzT3s) + toff;
       if (fused_img && img_launches[l] < 2 * MAXP) {
@@ -581,17 +602,17 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         fused_t = fuse_dz && dW[l] && !(l == 0 && P.u8);
         if (fused_t && dzT_free[l]) ev.wait(sx, dzT_free[l]);       // the previous part's products have read the image
         if (!fused_img)
-          RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
+          RC(split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
         if (fused_t) rb = ev.record(sx);
         if (!wx3_done[l]) {
-          RC(yt8m_x3_split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));      // W_x: rows Din, K = 4H
+          RC(split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));              // W_x: rows Din, K = 4H
           wx3_done[l] = true;
         }
         float* dst = l ? at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H : dx + t0 * B * D;
         yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 0.0f};
         static const int chain_combine_b = knob("YT8M_STACK_CHAIN_COMBINE", 0);
         if (chain_combine_b) yt8m_x3_set_combine(1);
-        const int grc = yt8m_gemm_x3_nt_grouped(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx);
+        const int grc = gemm(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx);
         yt8m_x3_set_combine(0);
         RC(grc);
         dx_ev = ev.record(sx);
@@ -609,29 +630,37 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         if (l == 0 && P.u8) {
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
           if (fused_img) {                                   // images and column sums came with the recurrence
-          } else if (P.colparts)                             // bias gradient + rank-1 remainder: per-tile sums from this pass
-            RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s),
-                                    at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4, at<float>(scratch, P.cparts) + (t0 * B / 64) * H4, sw));
-          else
+          } else if (P.colparts || bf) {                     // bias gradient + rank-1 remainder: per-tile sums from this pass
+            float* cp = P.colparts ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
+            float* cps = P.colparts ? at<float>(scratch, P.cparts) + (t0 * B / 64) * H4 : nullptr;
+            if (bf) RC(yt8m_bf16_image_colsum(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), cp, cps, sw));
+            else RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), cp, cps, sw));
+          } else
             RC(yt8m_x3_split_ex(dzc, M, H4, H4, 1.0f, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), sw));
-          RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, dzTs_img, 0, dW[0], H4,
+          if (bf)
+            RC(yt8m_gemm_b1_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, dzTs_img, 0, dW[0], H4,
                                   nullptr, U8_ALPHA, nullptr, nullptr, 0.f, bW, gw, P.gws_bytes, sw));
-          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 3072, KBtot, dzT_img, 0,
+          else
+            RC(yt8m_gemm_x1x3_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, dzTs_img, 0, dW[0], H4,
+                                    nullptr, U8_ALPHA, nullptr, nullptr, 0.f, bW, gw, P.gws_bytes, sw));
+          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * KBB, KBtot, dzT_img, 0,
                                   dW[0] + D * H4, H4, nullptr, bW};
-          RC(yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, sw));
+          RC(gemm(1, &pr, gw, P.gws_bytes, sw));
         } else {
           if (fused_img) {
           } else if (!fused_t) {
-            if (P.colparts && db[l])
-              RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, nullptr, nullptr, at<char>(scratch, P.dzT3[l]), nullptr,
-                                      at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4, nullptr, sw));
-            else
-              RC(yt8m_x3_split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
+            if (P.colparts && db[l]) {
+              float* cp = at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4;
+              if (bf) RC(yt8m_bf16_image_colsum(dzc, M, H4, H4, 1.0f, nullptr, nullptr, at<char>(scratch, P.dzT3[l]), nullptr, cp, nullptr, sw));
+              else RC(yt8m_x3_split_colsum(dzc, M, H4, H4, 1.0f, nullptr, nullptr, at<char>(scratch, P.dzT3[l]), nullptr, cp, nullptr, sw));
+            } else {
+              RC(split(dzc, M, H4, H4, 1.0f, nullptr, at<char>(scratch, P.dzT3[l]), sw));
+            }
           }
           yt8m_gemm_problem pr[2] = {
-              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 3072, KBtot, dzT_img, 0, dW[l], H4, nullptr, bW},
-              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 3072, KBtot, dzT_img, 0, dW[l] + Din * H4, H4, nullptr, bW}};
-          RC(yt8m_gemm_x3_nt_grouped(2, pr, gw, P.gws_bytes, sw));
+              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * KBB, KBtot, dzT_img, 0, dW[l], H4, nullptr, bW},
+              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * KBB, KBtot, dzT_img, 0, dW[l] + Din * H4, H4, nullptr, bW}};
+          RC(gemm(2, pr, gw, P.gws_bytes, sw));
           if (fused_t) dzT_free[l] = ev.record(sw);
         }
       }

@@ -410,13 +410,20 @@ _STACK_SCRATCH = {}   # (device, calling stream, description) -> zero-initialise
 NATIVE_CALLS = {"fwd": 0, "bwd": 0}     # how often the native path ran (tests assert that it engaged)
 
 
-def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx):
+# --compute_dtype=bfloat16 on the native stack (round 4): hoisted products on one-plane bf16 operand images (b1 kernel), the
+# recurrence itself on the fp32-grade persistent kernels -- i.e. "bf16 operands" applies to the input projections, dx and the
+# weight gradients only (torch_ref.lstm_stack(bf16_operands="input") is its value emulation).  YT8M_LSTM_STACK_BF16=0 keeps the
+# Python orchestration with the per-step bf16 recurrence kernels (csrc/lstm_bf16.hip).
+NATIVE_BF16 = _os.environ.get("YT8M_LSTM_STACK_BF16", "1") != "0"
+
+
+def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx, bf16=False):
     # 0 = the library's own partition (csrc/lstm_stack.hip: one forward launch per layer, three unequal backward parts) unless the
     # environment / a test names a number of parts
     fwd = PERSIST_FWD_CHUNKS if (PERSIST_FWD_CHUNKS != 1 or "YT8M_LSTM_PERSIST_FWD_CHUNKS" in _os.environ) else 0
     bwd = PERSIST_BWD_CHUNKS if (PERSIST_BWD_CHUNKS != 3 or "YT8M_LSTM_PERSIST_BWD_CHUNKS" in _os.environ) else 0
-    return _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)), float(forget_bias), int(fwd), int(bwd),
-                              int(bool(need_dx)))
+    return _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)) | (2 if bf16 else 0), float(forget_bias), int(fwd),
+                              int(bwd), int(bool(need_dx)))                    # input_u8: bit 0 uint8 frames, bit 1 bf16 operand images
 
 
 def _stack_scratch(dev, main, desc):
@@ -564,11 +571,12 @@ class _LstmStack(torch.autograd.Function):
         # product forms -- the path bench.py measures); everything else (caller's chunks, dropout, bf16 operands, per-step kernels,
         # tuning knobs) keeps the orchestration below, built from the same per-call entry points.
         drop_ = input_keep_prob is not None and float(input_keep_prob) < 1.0
-        if (NATIVE_STACK and own and X3 and PERSIST_BWD and PERSIST_STEP_IMAGES and not drop_ and not FWD_WAVEFRONT and
+        nat_ok = pers and _os.environ.get("YT8M_PERSIST_CUS") is None and (not bf16 or NATIVE_BF16)
+        if (NATIVE_STACK and nat_ok and X3 and PERSIST_BWD and PERSIST_STEP_IMAGES and not drop_ and not FWD_WAVEFRONT and
                 PERSIST_FWD_CHUNKS > 0 and PERSIST_BWD_CHUNKS > 0 and BWD_CHUNKS == 0 and not BWD_PARTS and len(set(Hs)) == 1):
             u8 = x_tm.dtype == torch.uint8
             D0 = x_tm.shape[2]
-            desc = _stack_desc(B, F, D0, Hs[0], L, u8, forget_bias, (not u8) and bool(ctx.needs_input_grad[0]))
+            desc = _stack_desc(B, F, D0, Hs[0], L, u8, forget_bias, (not u8) and bool(ctx.needs_input_grad[0]), bf16=bool(bf16))
             if (u8 or x_tm.dtype == torch.float32) and wb[0].data.shape[0] == D0 + Hs[0] and lib.yt8m_lstm_stack_supported(ctypes.byref(desc)):
                 return _LstmStack._native_forward(ctx, lib, desc, x_tm, nf, wb)
         if own and PERSIST_FWD_CHUNKS > 0:
