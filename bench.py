@@ -843,9 +843,14 @@ def main():
                                                         "transport": "CabiComm" if reducer.comm is not None else "torch.distributed",
                                                         "forced_at_world_1": bool(a.force_reducer and world == 1),
                                                         "per_rank": per_rank_all}}
-        print(json.dumps(out))
+    else:
+        out = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    if out is not None:
+        # the ONE line, last and flushed: librccl prints its version banner on stdout when the communicator goes away
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
