@@ -845,12 +845,17 @@ def main():
                                                         "per_rank": per_rank_all}}
     else:
         out = None
-    if dist.is_initialized():
+    rccl_loaded = dist.is_initialized()
+    if rccl_loaded:
         dist.destroy_process_group()
     if out is not None:
-        # the ONE line, last and flushed: librccl prints its version banner on stdout when the communicator goes away
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    if rccl_loaded:
+        # librccl writes a version banner ("RCCL version : ...", five lines) to stdout when the process exits: the contract is ONE
+        # line, so every rank leaves without running the C runtime's exit handlers (everything of ours is flushed above)
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
