@@ -153,3 +153,18 @@ def test_gemm_dispatch_cost_model():
         assert not ops._x3_wins([shp], False, False), shp
     # monotone in every dimension once it wins
     assert ops._x3_wins([(2 * 19200, 4096, 1152)], False, False) and ops._x3_wins([(19200, 2 * 4096, 1152)], False, False)
+
+
+def test_early_optimizer_ranges_and_the_complement_the_step_covers():
+    """seq_ops._ready_ranges (which variables the recurrent stack's backward pass may update early) and the complement loop of
+    train.TrainGraph.step: together they cover every trainable variable exactly once."""
+    import yt8m_amd.seq_ops as seq_ops
+    for ready in ([False, False, True, True, True], [True, False, True, False, True, True], [True] * 4, [False] * 3, []):
+        rng = seq_ops._ready_ranges(ready)
+        assert [i for lo, hi in rng for i in range(lo, hi)] == [i for i, r in enumerate(ready) if r]
+        assert all(hi > lo for lo, hi in rng) and all(rng[k][1] < rng[k + 1][0] for k in range(len(rng) - 1))
+        nt, pos, rest = len(ready), 0, []
+        for lo, hi in sorted(rng) + [(nt, nt)]:                   # the loop of TrainGraph.step
+            rest += list(range(pos, lo))
+            pos = hi
+        assert sorted(rest + [i for lo, hi in rng for i in range(lo, hi)]) == list(range(nt))

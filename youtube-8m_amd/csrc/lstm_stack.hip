@@ -3,7 +3,7 @@
 // builds through them (W/train.py:435-466), SURVEY.md section 8(b) last row, VERDICT r2 #9.
 //
 // Everything the measured headline step does for its recurrent stack lives here, behind the C ABI: the time partition (one
-// forward launch per layer, three backward parts), the stream layout (one HIGH-priority stream per layer for its projection /
+// forward launch per layer, four backward parts 2 : 2 : 1 : 1), the stream layout (one HIGH-priority stream per layer for its projection /
 // recurrence / dx chain, one stream for the weight-gradient products), the events between them, the operand images of the
 // bf16-pipe GEMMs (csrc/gemm_x3.hip) and the choice of product form.  A host binds three functions and owns two buffers
 // (tape = activations kept for the backward pass, scratch = everything else); nothing is allocated in here.
@@ -95,7 +95,8 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   if (p.FB % 16 != 0) return "F * B must be a multiple of 16 (K ranges of the transposed operand images)";
   p.nf = chunks(p.F, d->fwd_chunks > 0 ? d->fwd_chunks : 1, p.fp);
   p.nb = chunks(p.F, d->bwd_chunks > 0 ? d->bwd_chunks : 3, p.bp);
-  // The library's own backward partition (bwd_chunks == 0): three parts of relative length 3 : 2 : 1 in forward-time order.  The
+  // The library's own backward partition (bwd_chunks == 0): parts of relative length 2 : 2 : 1 : 1 in forward-time order (round 3:
+  // 3 : 2 : 1).  The
   // backward pass runs them last to first: SHORT first parts (the top layer's recurrence runs alone on half the chip while the
   // first one lasts, and the weight-gradient stream has nothing to do yet) and long last ones.  Round 3 (profiles/
   // r3_sched_knobs.md): 23.5-23.6 ms/step for 3:2:1, 7:4:2, 8:5:3, 5:3:1 against 24.0 for three equal parts.

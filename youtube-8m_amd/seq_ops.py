@@ -503,23 +503,28 @@ class _EarlyOpt(object):
             self.graph.early_done = list(self.ranges)                # end-of-step pass then covers everything, nothing is lost
 
 
+def _ready_ranges(ready):
+    """Maximal runs [lo, hi) of True in `ready` (trainable-variable indices whose gradients are final)."""
+    ranges, i, n = [], 0, len(ready)
+    while i < n:
+        if ready[i]:
+            j = i
+            while j + 1 < n and ready[j + 1]:
+                j += 1
+            ranges.append((i, j + 1))
+            i = j + 1
+        else:
+            i += 1
+    return ranges
+
+
 def _early_optimizer_hook(graph, lib):
     if not EARLY_ADAM or graph is None or getattr(graph, "early_optimizer", None) is None or graph.grad_ready_hook is not None:
         return None
     if getattr(graph, "early_done", None):
         return None                                                  # one recurrent stack per step takes the head
     tv = graph.trainable_variables()
-    ready = [bool(getattr(v, "_done_reported", False)) and v.grad_written for v in tv]
-    ranges, i = [], 0
-    while i < len(tv):
-        if ready[i]:
-            j = i
-            while j + 1 < len(tv) and ready[j + 1]:
-                j += 1
-            ranges.append((i, j + 1))
-            i = j + 1
-        else:
-            i += 1
+    ranges = _ready_ranges([bool(getattr(v, "_done_reported", False)) and v.grad_written for v in tv])
     # worth a launch pair only for a substantial share of the parameters
     if not ranges or sum(tv[k].numel() for lo, hi in ranges for k in range(lo, hi)) < (1 << 22):
         return None
