@@ -34,12 +34,14 @@ def timeit(fn, n=10):
 
 
 w = torch.randn(4096, 4096, device=dev)
-for _ in range(40):
+for _ in range(0 if os.environ.get("B1_ONLY") else 40):
     ops.gemm(w, w)
 ws = ops._workspace(dev)
 SHAPES = [("head fwd", [(8192, 14148, 2304), (8192, 9432, 2304)]), ("head dW", [(2304, 14148, 8192), (2304, 9432, 8192)]),
           ("head dx g", [(8192, 2304, 14148)]), ("head dx e", [(8192, 2304, 9432)]), ("cfg1 fwd", [(1024, 14148, 1152), (1024, 9432, 1152)]),
-          ("ragged", [(1000, 777, 1000), (300, 5000, 72)])]
+          ("ragged", [(1000, 777, 1000), (300, 5000, 72)]), ("sq4k", [(4096, 4096, 4096)]), ("sq8k", [(8192, 8192, 8192)])]
+if os.environ.get("B1_ONLY"):                              # restrict to one shape set (counter passes)
+    SHAPES = [x for x in SHAPES if x[0] == os.environ["B1_ONLY"]]
 for label, probs in SHAPES:
     items, pr, keep, fl = [], [], [], 0.0
     for (M, N, K) in probs:

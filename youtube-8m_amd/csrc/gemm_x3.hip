@@ -23,6 +23,7 @@
 // gemm_bf16.hip whose 12 reads feed 16 MFMAs), and the fragment fetch of the next step is interleaved with the products of the
 // current one.  Tile order and the float4 epilogue follow gemm_bf16.hip; the tiles of the last partial round are split along K.
 #include "common.h"
+#include <type_traits>
 #include <algorithm>
 #include <mutex>
 #include <stdlib.h>
@@ -534,6 +535,138 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(const XGroup G) {
   x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
+// ---- the same product as gemm_b1_kernel with a deeper request ring and fragments carried across the barrier (round 4) ------------------
+// What the counters said about gemm_b1_kernel: its K step ends on vmcnt(0) for requests the wave issued one
+// block earlier, so every step exposes most of an L2 / fabric round trip; and each block's MFMAs wait for fragment reads issued
+// just before them.  Here LDS is a ring of eight 16 KiB slots (A block, B block), a step is TWO blocks, and:
+//   * the requests of step s + 3 are issued in step s (into the slots step s - 1 just vacated), and the counted vmcnt at the end of
+//     step s retires step s + 2 -- two steps of landing time, never vmcnt(0) in steady state;
+//   * a step's blocks were therefore published one barrier EARLIER than they are read, so the fragments of block n + 1 are read
+//     during block n's MFMAs, across the step boundary too: no wave waits on LDS after a barrier.
+// (A phased variant -- two barriers per block, the two M-half wave groups one barrier apart, after the hardware guide's "eight
+// phase" description -- measured 8-15 % SLOWER than gemm_b1_kernel on every head shape and on 8192^3: 921 vs 1096 TFLOP/s; removed.)
+constexpr int BQ_SLOTS = 8;
+constexpr int BQ_SLOT_F = 2 * PLANE_F;                               // A block (8 KiB), B block (8 KiB)
+
+__global__ __launch_bounds__(512) void gemm_b1q_kernel(const XGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // BQ_SLOTS * BQ_SLOT_F floats (128 KiB)
+  int q, nparts, part, slot, lt;
+  x_work_item(G, q, nparts, part, slot, lt);
+  const XArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int wm = grp * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
+  const int nkb = kb1 - kb0;
+  const float* pa = g.A + ((int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska + kb0) * RG_F + lane * 4;
+  const float* pb = g.B + ((int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.skb + kb0) * RG_F + lane * 4;
+  const int wbase = (tid & ~63) * 4;
+  auto dma = [&](const float* src, float* dst) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto request = [&](int n) __attribute__((always_inline)) {         // block n of both operands -> slot n & 7 (this wave's row groups)
+    float* S = smem + (n & (BQ_SLOTS - 1)) * BQ_SLOT_F + wbase;
+    dma(pa + (int64_t)n * RG_F, S);
+    dma(pb + (int64_t)n * RG_F, S + PLANE_F);
+  };
+  const int fa = (wm + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  const int fb = PLANE_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  auto frags = [&](int n, bf16x8 (&a)[4], bf16x8 (&b)[2]) __attribute__((always_inline)) {
+    const float* S = smem + (n & (BQ_SLOTS - 1)) * BQ_SLOT_F;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fb + t * 256]));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fa + t * 256]));
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // prologue: steps 0..2 requested; steps 0 and 1 retired by this wave, then by every wave
+  for (int n = 0; n < 6 && n < nkb; ++n) request(n);
+  if (nkb >= 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (nkb == 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 a0[4], b0[2], a1[4], b1[2];
+  // One block = eight MFMAs with ONE other instruction behind each: the six fragment reads of the next block and the block's two
+  // requests.  (Issued as a group, six reads or two requests outlast the 32 cycles the last-issued MFMA keeps the pipe busy, and
+  // the two waves of a SIMD -- aligned by the barriers -- both sit in that gap at once: the counters showed 31 % of the pipe idle
+  // even with the requests compiled out.)  The two wave groups take their requests in different slots (V = 0: behind MFMAs 6, 7;
+  // V = 1: behind MFMAs 0, 1).  The reads are inline asm with hand-counted lgkmcnt: hipcc waits lgkmcnt(0) before the first MFMA
+  // that uses ANY fragment of a set, i.e. for the read issued one instruction earlier.  LDS returns in order; fragment order
+  // b0 a0 b1 a1 a2 a3, MFMA m uses a[m / 2], b[m % 2]: the waits below allow exactly the reads issued after the needed one.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  auto frag1 = [&](int n, int t, bf16x8 (&a)[4], bf16x8 (&b)[2]) __attribute__((always_inline)) {   // t: b0 a0 b1 a1 a2 a3
+    const uint32_t S = lds0 + (uint32_t)((n & (BQ_SLOTS - 1)) * BQ_SLOT_F) * 4u;
+    if (t == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(S + (uint32_t)fb * 4u) : "memory");
+    else if (t == 1) asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(S + (uint32_t)fa * 4u) : "memory");
+    else if (t == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(b[1]) : "v"(S + (uint32_t)(fb + 256) * 4u) : "memory");
+    else asm volatile("ds_read_b128 %0, %1" : "=v"(a[t - 2]) : "v"(S + (uint32_t)(fa + (t - 2) * 256) * 4u) : "memory");
+  };
+#pragma unroll
+  for (int t = 0; t < 6; ++t) frag1(0, t, a0, b0);
+  auto block = [&](bf16x8 (&ca)[4], bf16x8 (&cb)[2], bf16x8 (&na)[4], bf16x8 (&nb)[2], int nread, int nreq, auto variant, auto dma_on)
+                   __attribute__((always_inline)) {
+    constexpr int V = decltype(variant)::value;
+    constexpr bool D = decltype(dma_on)::value;
+    float* R = smem + (nreq & (BQ_SLOTS - 1)) * BQ_SLOT_F + wbase;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      // the fragment this MFMA is the first to use (index into b0 a0 b1 a1 a2 a3), and the reads of the NEXT set issued so far
+      const int need = m == 0 ? 1 : m == 1 ? 2 : m == 2 ? 3 : m == 4 ? 4 : m == 6 ? 5 : -1;
+      const int newer = V == 0 ? (m < 6 ? m : 6) : (m < 2 ? 0 : m - 2);
+      if (need >= 0) {
+        const int allow = (5 - need) + newer;
+        if (m == 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ca[0]), "+v"(cb[0]), "+v"(ca[1]), "+v"(cb[1]) : "n"(allow) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ca[m >> 1]), "+v"(cb[m & 1]), "+v"(ca[3]), "+v"(ca[2]) : "n"(allow) : "memory");
+      }
+      acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[m >> 1], cb[m & 1], acc[m >> 1][m & 1], 0, 0, 0);
+      const int rd = V == 0 ? m : m - 2;                            // which fragment read sits behind this MFMA (0..5), if any
+      if (rd >= 0 && rd < 6) frag1(nread, rd, na, nb);
+      if (D) {
+        const int rq = V == 0 ? m - 6 : m;                          // which request (0: A, 1: B), if any
+        if (rq == 0) dma(pa + (int64_t)nreq * RG_F, R);
+        if (rq == 1) dma(pb + (int64_t)nreq * RG_F, R + PLANE_F);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto run = [&](auto variant) __attribute__((always_inline)) {
+    int n = 0;
+    for (; n + 7 < nkb; n += 2) {                                   // steady state: every step requests step s + 3
+      block(a0, b0, a1, b1, n + 1, n + 6, variant, std::true_type{});
+      block(a1, b1, a0, b0, n + 2, n + 7, variant, std::true_type{});
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // step s + 2 retired by this wave; this step's four may fly
+      __builtin_amdgcn_s_barrier();
+    }
+    if (n + 6 < nkb) request(n + 6);                                 // (odd K-block count: one block left to request)
+    for (; n + 1 < nkb; n += 2) {                                   // last steps: nothing left to request
+      block(a0, b0, a1, b1, n + 1, 0, variant, std::false_type{});
+      block(a1, b1, a0, b0, n + 2, 0, variant, std::false_type{});  // (the read of block n + 2 past the end fetches an unused slot)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (n < nkb) {                                                   // odd tail block (its fragments are in a0 / b0)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1])::"memory");
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[m >> 1], b0[m & 1], acc[m >> 1][m & 1], 0, 0, 0);
+    }
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                      // the epilogue reuses the ring
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
+}
+
 // sums the S parts of every remainder tile in a fixed order (deterministic) and applies bias / accumulate.
 // Footprint matters more than speed-of-light here: with no LDS and <= 32 VGPRs a workgroup of this kernel fits on a CU that a
 // persistent recurrence occupies (768 threads x 160 VGPRs leave 32 per lane), so in the LSTM step it runs BESIDE the recurrences
@@ -911,7 +1044,17 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   double fl = 0.0;
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
   ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3), as_stream(stream), fl);
-  if constexpr (PA == 0) hipLaunchKernelGGL(gemm_b1_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+  // YT8M_B1_PIPE=0: the round-3 kernel (two 64 KiB stages, one barrier per four blocks) instead of gemm_b1q_kernel
+  static const bool piped = getenv("YT8M_B1_PIPE") == nullptr || atoi(getenv("YT8M_B1_PIPE")) != 0;
+  if constexpr (PA == 0) {
+    if (piped) {
+      static DeviceOnce lds_once_q;
+      YT8M_HIP_CHECK(lds_once_q.lds(reinterpret_cast<const void*>(gemm_b1q_kernel), BQ_SLOTS * BQ_SLOT_F * (int)sizeof(float)));
+      hipLaunchKernelGGL(gemm_b1q_kernel, dim3((unsigned)grid), dim3(512), BQ_SLOTS * BQ_SLOT_F * (int)sizeof(float), as_stream(stream), G);
+    } else {
+      hipLaunchKernelGGL(gemm_b1_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+    }
+  }
   else hipLaunchKernelGGL(gemm_x3_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
   if (fix > 0 && !G.cnt) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
