@@ -452,6 +452,171 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const XGroup G) {
   x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
+// ---- gemm_x3_kernel with every LDS read / LDS-DMA request placed singly behind an MFMA (round 4) --------------------------------------
+// Same ring (three one-block stages, step kt+3 requested into the stage step kt was read from, counted vmcnt), same product order
+// and therefore the same sums bit for bit.  What changes is issue placement, after the counters on the one-plane kernel (DESIGN.md
+// 9.9): four reads or a request issued in a row outlast the 32 cycles the last MFMA keeps the pipe busy, and the two waves of a
+// SIMD, aligned by the barrier, sit in that gap together.  Here each of the step's 18 (10) reads and 6 (4) requests follows its
+// own MFMA; a register is re-read as soon as the LAST MFMA that uses it has been issued (i-major MFMA order inside a product
+// frees the A fragments one by one); and the two planes the last product holds to its end (a0, b2) alternate between two
+// register sets, so the step's last read sits five MFMAs before the barrier instead of right in front of the lgkmcnt(0) the
+// refill needs.  The two wave groups (M halves, one wave per SIMD each) take their requests in different slots.
+template <int PA>
+__global__ __launch_bounds__(512) void gemm_x3q_kernel(const XGroup G) {
+  constexpr int OPA_F = PA * PLANE_F;
+  constexpr int STAGE_F = OPA_F + OP_F;
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * STAGE_F floats
+  int q, nparts, part, slot, lt;
+  x_work_item(G, q, nparts, part, slot, lt);
+  const XArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int wm = grp * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
+  const int nk = kb1 - kb0;
+  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska * (PA * RG_F) + lane * 4;
+  const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.skb * (3 * RG_F) + lane * 4;
+  constexpr int DMA = PA + 3;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int pro = nk < 3 ? nk : 3;
+  for (int s = 0; s < pro; ++s) { fill_op<PA>(pa, kb0 + s, smem + s * STAGE_F, tid); fill_op<3>(pb, kb0 + s, smem + s * STAGE_F + OPA_F, tid); }
+  if (pro == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA) : "memory");
+  else if (pro == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa = (wm + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  const int fb = OPA_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  auto rd_a = [&](const float* S, int p, int t) __attribute__((always_inline)) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fa + p * PLANE_F + t * 256]));
+  };
+  auto rd_b = [&](const float* S, int p, int t) __attribute__((always_inline)) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(&S[fb + p * PLANE_F + t * 256]));
+  };
+  bf16x8 a2[4], a1[4], b0[2], b1[2], a0x[4], b2x[2], a0y[4], b2y[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if constexpr (PA == 3) { a2[t] = rd_a(smem, 2, t); a1[t] = rd_a(smem, 1, t); }
+    a0x[t] = rd_a(smem, 0, t);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { b0[t] = rd_b(smem, 0, t); b1[t] = rd_b(smem, 1, t); b2x[t] = rd_b(smem, 2, t); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int wbase = (tid & ~63) * 4;
+  auto dma = [&](bool on, const float* src, float* dst) __attribute__((always_inline)) {
+    if (on)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  // one product: eight MFMAs, i-major, `behind(m)` issued after the m-th
+  auto term = [&](const bf16x8 (&x)[4], const bf16x8 (&y)[2], auto behind) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[m >> 1], y[m & 1], acc[m >> 1][m & 1], 0, 0, 0);
+      behind(m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int cur = 0;
+  // one step: products of step kt from (a2, a1, b0, b1, A0, B2); step kt+1 read into (a2, a1, b0, b1, A0n, B2n)
+  auto step = [&](int kt, bf16x8 (&A0)[4], bf16x8 (&B2)[2], bf16x8 (&A0n)[4], bf16x8 (&B2n)[2], auto variant) __attribute__((always_inline)) {
+    constexpr int V = decltype(variant)::value;
+    constexpr int RQ = V == 0 ? 1 : 5;                             // the request slot of this wave group
+    const int nxt = cur + 1 == NST ? 0 : cur + 1;
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool rf = kt + 3 < nk;
+    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (PA * RG_F);
+    const float* qb = pb + (int64_t)(kb0 + kt + 3) * (3 * RG_F);
+    float* Sc = smem + cur * STAGE_F + wbase;
+    const float* Sn = smem + nxt * STAGE_F;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PA == 3) {
+      term(a2, b0, [&](int m) __attribute__((always_inline)) {
+        if (m == RQ) dma(rf, qa, Sc);
+        if (m == 2) a2[0] = rd_a(Sn, 2, 0);
+        if (m == 4) a2[1] = rd_a(Sn, 2, 1);
+        if (m == 6) a2[2] = rd_a(Sn, 2, 2);
+      });
+      term(a1, b0, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) a2[3] = rd_a(Sn, 2, 3);
+        if (m == RQ) dma(rf, qa + RG_F, Sc + PLANE_F);
+        if (m == 2) A0n[0] = rd_a(Sn, 0, 0);
+        if (m == 4) A0n[1] = rd_a(Sn, 0, 1);
+        if (m == 6) A0n[2] = rd_a(Sn, 0, 2);
+      });
+      term(a1, b1, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) A0n[3] = rd_a(Sn, 0, 3);
+        if (m == RQ) dma(rf, qa + 2 * RG_F, Sc + 2 * PLANE_F);
+        if (m == 2) a1[0] = rd_a(Sn, 1, 0);
+        if (m == 4) a1[1] = rd_a(Sn, 1, 1);
+        if (m == 6) a1[2] = rd_a(Sn, 1, 2);
+      });
+      term(A0, b0, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) a1[3] = rd_a(Sn, 1, 3);
+        if (m == RQ) dma(rf, qb, Sc + OPA_F);
+        if (m == 2) B2n[0] = rd_b(Sn, 2, 0);
+        if (m == 4) B2n[1] = rd_b(Sn, 2, 1);
+      });
+      term(A0, b1, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) b0[0] = rd_b(Sn, 0, 0);
+        if (m == RQ) dma(rf, qb + RG_F, Sc + OPA_F + PLANE_F);
+        if (m == 2) b0[1] = rd_b(Sn, 0, 1);
+      });
+      term(A0, B2, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) b1[0] = rd_b(Sn, 1, 0);
+        if (m == RQ) dma(rf, qb + 2 * RG_F, Sc + OPA_F + 2 * PLANE_F);
+        if (m == 2) b1[1] = rd_b(Sn, 1, 1);
+      });
+    } else {
+      term(A0, b0, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) A0n[0] = rd_a(Sn, 0, 0);
+        if (m == RQ) dma(rf, qa, Sc);
+        if (m == 2) A0n[1] = rd_a(Sn, 0, 1);
+        if (m == 4) A0n[2] = rd_a(Sn, 0, 2);
+        if (m == 6) A0n[3] = rd_a(Sn, 0, 3);
+      });
+      term(A0, b1, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) b0[0] = rd_b(Sn, 0, 0);
+        if (m == RQ) dma(rf, qb, Sc + OPA_F);
+        if (m == 2) b0[1] = rd_b(Sn, 0, 1);
+        if (m == RQ + 2) dma(rf, qb + RG_F, Sc + OPA_F + PLANE_F);
+        if (m == 4) B2n[0] = rd_b(Sn, 2, 0);
+        if (m == 6) B2n[1] = rd_b(Sn, 2, 1);
+      });
+      term(A0, B2, [&](int m) __attribute__((always_inline)) {
+        if (m == 0) b1[0] = rd_b(Sn, 1, 0);
+        if (m == RQ) dma(rf, qb + 2 * RG_F, Sc + OPA_F + 2 * PLANE_F);
+        if (m == 2) b1[1] = rd_b(Sn, 1, 1);
+      });
+    }
+    cur = nxt;
+  };
+  auto run = [&](auto variant) __attribute__((always_inline)) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(kt, a0x, b2x, a0y, b2y, variant);
+      step(kt + 1, a0y, b2y, a0x, b2x, variant);
+    }
+    if (kt < nk) step(kt, a0x, b2x, a0y, b2y, variant);
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                    // the epilogue reuses the ring
+
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
+}
+
 // ---- one plane x one plane: the plain bf16 product on operand images ("b1") -------------------------------------------------------
 // C = A . B^T for operands that ARE bfloat16 (--compute_dtype=bfloat16: BASELINE configs[4] and the bf16 variants), both given as
 // ONE-plane images -- [rows / 32][K / 16][32 rows][2 halves][8] bf16, what yt8m_bf16_image writes straight from the fp32 source.
@@ -1055,7 +1220,17 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
       hipLaunchKernelGGL(gemm_b1_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
     }
   }
-  else hipLaunchKernelGGL(gemm_x3_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+  else {
+    // YT8M_X3_PIPE=0: the round-3 kernel (reads and requests issued in groups between the products)
+    static const bool xpiped = getenv("YT8M_X3_PIPE") == nullptr || atoi(getenv("YT8M_X3_PIPE")) != 0;
+    if (xpiped) {
+      static DeviceOnce lds_once_xq;
+      YT8M_HIP_CHECK(lds_once_xq.lds(reinterpret_cast<const void*>(gemm_x3q_kernel<PA == 0 ? 3 : PA>), LDS_BYTES));
+      hipLaunchKernelGGL(gemm_x3q_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+    } else {
+      hipLaunchKernelGGL(gemm_x3_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+    }
+  }
   if (fix > 0 && !G.cnt) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
   return launch_status("gemm_x3_kernel");
 }
