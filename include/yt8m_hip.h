@@ -112,6 +112,10 @@ int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
  * (separate fix-up pass; YT8M_X3_FUSED_COMBINE=1 flips it), 1 = by the last part to arrive, inside the launch (no second kernel on
  * the stream: for products on a critical chain), 2 = separate pass.  Same sums in the same order either way. */
 int yt8m_x3_set_combine(int mode);
+/* Main-loop schedule of the following x3 / x1x3 / b1 launches OF THE CALLING THREAD: 0 = process default (the interleaved
+ * kernels; YT8M_X3_PIPE=0 / YT8M_B1_PIPE=0 flip it), 1 = interleaved (one LDS read or LDS-DMA request behind each MFMA, request
+ * ring three steps deep), 2 = the round-3 kernels.  Same products in the same order: bit-identical results; kept for A/B runs. */
+int yt8m_x3_set_schedule(int mode);
 /* fp32 products through the LIBRARY's choice of kernel (csrc/gemm_auto.hip): per problem -- never per group, so a product takes
  * the same kernel and summation order alone or grouped -- a cost estimate (yt8m_gemm_x3_pays: tile efficiency at 256 x 256,
  * occupancy, the split passes) picks the six-product bf16-pipe kernel or the fp32-MFMA kernel.  Arguments as yt8m_gemm_f32_grouped

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import yt8m_amd._lib as L
+import yt8m_amd.ops as ops
 from yt8m_amd.ops import _p, _stream
 
 pytestmark = pytest.mark.gpu
@@ -258,3 +259,59 @@ def test_native_stack_in_bf16_operand_mode(dev, flags, u8):
         ref = t.grad.numpy()
         gk = g.vars[k].grad.detach().cpu().double().numpy().reshape(ref.shape)
         assert np.abs(gk - ref).max() <= 6e-2 * max(np.abs(ref).max(), 1e-3), k
+
+
+# ---- the interleaved image-GEMM kernels against the round-3 kernels --------------------------------------------------------------------
+def _with_schedule(mode, fn):
+    lib = L.lib()
+    L.check(lib.yt8m_x3_set_schedule(mode))
+    try:
+        return fn()
+    finally:
+        L.check(lib.yt8m_x3_set_schedule(0))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 520, 16), (256, 256, 48), (257, 255, 80), (512, 300, 96), (300, 260, 112), (256, 512, 128),
+                                   (1000, 777, 1000), (300, 5000, 72), (256, 256, 8192 + 16), (2304, 1024, 8192), (4096, 4096, 1152)])
+def test_interleaved_image_gemms_equal_the_round3_kernels_bit_for_bit(dev, M, N, K):
+    """gemm_b1q_kernel / gemm_x3q_kernel<3> / gemm_x3q_kernel<1> run the same products in the same order per accumulator as the
+    round-3 kernels: identical bits, for K-block counts around the request ring's depth (1, 3, 5, 6, 7, 8), odd counts, ragged
+    M / N, tiles whose K range is split into parts (few tiles, long K) and a many-tile shape."""
+    g = torch.Generator(device=dev).manual_seed(M * 131 + N * 17 + K)
+    A = torch.randn((M, K), device=dev, generator=g)
+    B = torch.randn((N, K), device=dev, generator=g)
+    bias = torch.randn((N,), device=dev, generator=g)
+    # one-plane (bf16) images
+    ia, ib = ops.bf16_image(A), ops.bf16_image(B)
+    new = _with_schedule(1, lambda: ops.gemm_b1_grouped([dict(A=ia, B=ib, bias=bias)])[0].clone())
+    old = _with_schedule(2, lambda: ops.gemm_b1_grouped([dict(A=ia, B=ib, bias=bias)])[0].clone())
+    assert torch.equal(new, old)
+    ref = A.bfloat16().double() @ B.bfloat16().double().t() + bias.double()
+    assert float((new.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    # three-plane images (six products)
+    xa, xb = ops.x3_split(A)[0], ops.x3_split(B)[0]
+    new = _with_schedule(1, lambda: ops.gemm_x3_grouped([dict(A=xa, B=xb, bias=bias)])[0].clone())
+    old = _with_schedule(2, lambda: ops.gemm_x3_grouped([dict(A=xa, B=xb, bias=bias)])[0].clone())
+    assert torch.equal(new, old)
+    ref = A.double() @ B.double().t() + bias.double()
+    assert float((new.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+    # one-plane x three-plane (the uint8 layer-0 form): A exact in bf16
+    Aq = torch.randint(-128, 128, (M, K), device=dev, generator=g).float()
+    i1 = ops.bf16_image(Aq)
+    lib = L.lib()
+    ws = ops._workspace(dev)
+    r = torch.rand((M,), device=dev, generator=g) + 0.5
+    cs = torch.randn((N,), device=dev, generator=g)
+
+    affine = N % 4 == 0                                   # the affine epilogue needs N % 4 == 0; plain product + bias otherwise
+
+    def x1x3():
+        z = torch.full((M, N), float("nan"), device=dev)
+        L.check(lib.yt8m_gemm_x1x3_nt(M, N, K, _p(i1.buf), _p(xb.buf), _p(z), N, _p(bias), _p(r) if affine else None,
+                                      _p(cs) if affine else None, 0.25, _p(ws), ws.numel() * 4, _stream()))
+        return z
+    new, old = _with_schedule(1, x1x3), _with_schedule(2, x1x3)
+    assert torch.equal(new, old)
+    ref = Aq.double() @ B.double().t()
+    ref = (r.double()[:, None] * (ref + 0.25 * cs.double()) if affine else ref) + bias.double()
+    assert float((new.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))

@@ -67,6 +67,7 @@ SIGNATURES = {
     "yt8m_x3_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "yt8m_x3_split_colsum": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P]),
     "yt8m_x3_set_combine": (c_int, [c_int]),
+    "yt8m_x3_set_schedule": (c_int, [c_int]),
     "yt8m_bf16_image_colsum": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P]),
     "yt8m_gemm_b1_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, c_float, c_float, P,
                                    c_int64, P]),

@@ -1103,6 +1103,10 @@ constexpr uint32_t CNT_CAP = 1u << 16;
 // yt8m_x3_set_combine: per-thread override of where the K parts of the following image-GEMM launches are summed
 // (0 = the process default: separate fix-up pass unless YT8M_X3_FUSED_COMBINE=1; 1 = inside the launch; 2 = separate pass).
 thread_local int g_combine_mode = 0;
+// yt8m_x3_set_schedule: per-thread choice of the main-loop schedule of the following image-GEMM launches (0 = the process default:
+// the interleaved kernels gemm_x3q_kernel / gemm_b1q_kernel unless YT8M_X3_PIPE=0 / YT8M_B1_PIPE=0; 1 = interleaved; 2 = the
+// round-3 kernels).  Same products in the same order per accumulator: bit-identical results (tests/test_gpu_round4.py).
+thread_local int g_schedule_mode = 0;
 struct TileCounters {
   std::mutex mu;
   unsigned* base[16] = {nullptr};
@@ -1210,7 +1214,8 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
   ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3), as_stream(stream), fl);
   // YT8M_B1_PIPE=0: the round-3 kernel (two 64 KiB stages, one barrier per four blocks) instead of gemm_b1q_kernel
-  static const bool piped = getenv("YT8M_B1_PIPE") == nullptr || atoi(getenv("YT8M_B1_PIPE")) != 0;
+  static const bool piped_env = getenv("YT8M_B1_PIPE") == nullptr || atoi(getenv("YT8M_B1_PIPE")) != 0;
+  const bool piped = g_schedule_mode == 1 || (g_schedule_mode == 0 && piped_env);
   if constexpr (PA == 0) {
     if (piped) {
       static DeviceOnce lds_once_q;
@@ -1222,7 +1227,8 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   }
   else {
     // YT8M_X3_PIPE=0: the round-3 kernel (reads and requests issued in groups between the products)
-    static const bool xpiped = getenv("YT8M_X3_PIPE") == nullptr || atoi(getenv("YT8M_X3_PIPE")) != 0;
+    static const bool xpiped_env = getenv("YT8M_X3_PIPE") == nullptr || atoi(getenv("YT8M_X3_PIPE")) != 0;
+    const bool xpiped = g_schedule_mode == 1 || (g_schedule_mode == 0 && xpiped_env);
     if (xpiped) {
       static DeviceOnce lds_once_xq;
       YT8M_HIP_CHECK(lds_once_xq.lds(reinterpret_cast<const void*>(gemm_x3q_kernel<PA == 0 ? 3 : PA>), LDS_BYTES));
@@ -1239,6 +1245,12 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
 extern "C" int yt8m_x3_set_combine(int mode) {
   YT8M_REQUIRE(mode >= 0 && mode <= 2, YT8M_E_BADARG, "mode must be 0 (default), 1 (inside the launch) or 2 (separate pass)");
   g_combine_mode = mode;
+  return YT8M_OK;
+}
+
+extern "C" int yt8m_x3_set_schedule(int mode) {
+  YT8M_REQUIRE(mode >= 0 && mode <= 2, YT8M_E_BADARG, "mode must be 0 (default), 1 (interleaved kernels) or 2 (round-3 kernels)");
+  g_schedule_mode = mode;
   return YT8M_OK;
 }
 
