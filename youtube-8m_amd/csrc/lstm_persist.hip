@@ -961,10 +961,15 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
           ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)q * 1024u), 0, AUX_LD));
       }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // (sched_barrier on either side of every q-group: left to itself hipcc issues the half's 64 MFMAs first and its 16 refill
+      // loads in a clump behind them -- the loaded registers are the MFMAs' own sources -- so the next half starts by waiting a whole
+      // L2 round trip for loads issued a moment earlier.  Pinned, each load goes out ahead of its group's MFMAs into four fresh
+      // registers and has half an item to land.)
 #pragma unroll
       for (int q = 0; q < HALF; ++q) {                   // first half: register-resident weights; refill with this item's 2nd half
         const float4 av = ring[q], bv = Wr[q];
         ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)(HALF + q) * 1024u), 0, AUX_LD));
+        __builtin_amdgcn_sched_barrier(0);
         if (q & 1) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
@@ -976,7 +981,9 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      float4 bvn = Wl[w][0][lane];                       // LDS-resident weights, one q-group ahead of their MFMAs
       unsigned bnext = bcur;
       __amdgpu_buffer_rsrc_t dxn = dxr;
       if (PF) {                                          // mid-item: dz of the next item must be complete before its fetch starts
@@ -995,20 +1002,30 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 #pragma unroll
       for (int q = 0; q < HALF; ++q) {                   // second half: LDS-resident weights; refill with the next item's 1st half
         const float4 av = ring[q];
-        const float4 bv = Wl[w][q][lane];
-        if (PF) ring[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxn, (int)(bnext + (unsigned)q * 1024u), 0, AUX_LD));
+        const float4 bv = bvn;
+        // the next group's weights are read behind this group's FIRST MFMA: three MFMAs and a refill ahead of their use (read in
+        // front of their own group, every group began with an exposed LDS round trip)
+        if (q & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < HALF) bvn = Wl[w][q + 1][lane];
+        __builtin_amdgcn_sched_barrier(0);
         if (q & 1) {
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc1, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
         } else {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc0, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
         }
+        if (PF && q >= 1) {                              // one group late: ring[q - 1]'s registers are free by now
+          __builtin_amdgcn_sched_barrier(0);
+          ring[q - 1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxn, (int)(bnext + (unsigned)(q - 1) * 1024u), 0, AUX_LD));
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      if (PF) ring[HALF - 1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(dxn, (int)(bnext + (unsigned)(HALF - 1) * 1024u), 0, AUX_LD));
       STAMP(2);
       if (gen > 0) lds_wait_ge(&lds_free[slot], EPW * (unsigned)gen, a.ctl);  // its epilogue wave(s) have read item k - 3
       float* rw = &red[slot][w][0][lane];
