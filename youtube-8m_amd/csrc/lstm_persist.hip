@@ -645,6 +645,10 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       if (w == 0 && lane < NSH)
         pv = __hip_atomic_load(a.ctl + CTL_HDR + (Tr * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+      u32x4 ls[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (p >= NREG) ls[0][p] = Wl[w][p >= NREG ? p - NREG : 0][lane];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         if (kb == HK) {                                  // request point: the state of item k + 1 must be complete now
@@ -655,20 +659,39 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           } else {
             lds_wait_ge(&lds_seen[itr], (unsigned)sr * arrivals, a.ctl);
           }
-          load_half(Hc, sr, Tr, 0);
-          load_half(Ha, sr, Tr, 1);                      // the MFMAs that read Ha have been issued
-          STAMP(1);
+          STAMP(1);                                      // (the 3 NKB loads of the request go out three per MFMA group below)
         }
         bf16x8 av[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) av[p] = __builtin_bit_cast(bf16x8, kb < HK ? Ha[kb < HK ? kb : 0][p] : Hb[kb >= HK ? kb - HK : 0][p]);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
+          // LDS-resident weight fragments travel one six-MFMA group ahead of their use (two register sets in rotation): read in
+          // front of their own group every group began with an exposed LDS round trip, in a kernel paced by its item time
+          const int gi = kb * 2 + ct;
+          if (kb >= HK) {                                // the state of item k + 1: first half -> Hc, second half -> Ha (the MFMAs
+            const __amdgpu_buffer_rsrc_t hxr = image(sr);   // that read Ha have been issued), three 1 KiB blocks per group
+            const unsigned base = (unsigned)(Tr * KBH) * 3072u + lane_off;
+#pragma unroll
+            for (int j = 3 * (gi - NKB); j < 3 * (gi - NKB) + 3; ++j) {
+              const int kbl = (j % (3 * HK)) / 3, pl = j % 3;
+              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)j * 1024u), 0, 0);
+              if (j < 3 * HK) Hc[kbl][pl] = v; else Ha[kbl][pl] = v;
+            }
+          }
+          if (gi + 1 < 2 * NKB) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              const int f = (gi + 1) * 3 + p;
+              if (f >= NREG) ls[(gi + 1) & 1][p] = Wl[w][f >= NREG ? f - NREG : 0][lane];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
           bf16x8 bv[3];
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
-            const int f = (kb * 2 + ct) * 3 + p;
-            bv[p] = __builtin_bit_cast(bf16x8, f < NREG ? Wr[f < NREG ? f : 0] : Wl[w][f >= NREG ? f - NREG : 0][lane]);
+            const int f = gi * 3 + p;
+            bv[p] = __builtin_bit_cast(bf16x8, f < NREG ? Wr[f < NREG ? f : 0] : ls[gi & 1][p]);
           }
           acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][0], 0, 0, 0);
           acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[1], acc[ct][1], 0, 0, 0);
@@ -676,6 +699,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[2], acc[ct][1], 0, 0, 0);
           acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[1], acc[ct][0], 0, 0, 0);
           acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], acc[ct][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       STAMP(2);
