@@ -535,7 +535,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   // r4_sched_knobs.md): 23.25 / 23.16 / 23.37 / 23.57 ms/step for 1 / 2 / 3 / 5 sub-parts, i.e. nothing: the weight-gradient stream
   // is busy from the first double phase to the end, what leaves the tail queues up in front of it.
   int sub0[MAXP];
-  for (int c = 0; c < P.nb; ++c) sub0[c] = (c == 0 && P.L > 1 && P.nb > 1 && !getenv("YT8M_STACK_SUB0")) ? knob("YT8M_STACK_SUB0_LAST", 1) : 1;
+  for (int c = 0; c < P.nb; ++c) sub0[c] = (c == 0 && P.L > 1 && P.nb > 1 && !getenv("YT8M_STACK_SUB0")) ? std::max(1, knob("YT8M_STACK_SUB0_LAST", 1)) : 1;   // (0 would skip the part)
   if (const char* spec = getenv("YT8M_STACK_SUB0")) {
     int n = 0;
     for (const char* q = spec; *q && n < P.nb;) { sub0[n++] = std::max(1, atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
