@@ -187,6 +187,7 @@ def _stack_run(dev, B, F, D, H, L_, chunks, nf, persist, seed=0):
     (128, 16, 1152, 1024, 2, 1, False),   # BASELINE configs[3] shape (short sequence)
     (128, 24, 1152, 1024, 2, 4, True),    # ragged num_frames incl. 0 and F, four chunks
     (512, 6, 128, 1024, 1, 1, True),      # 32 tiles: several per workgroup
+    (256, 40, 1152, 1024, 2, 4, True),    # the batch sweep's B = 256 (eight tiles per workgroup), F = 40, four chunks, ragged
 ])
 def test_persistent_lstm_matches_step_kernels(dev, B, F, D, H, L_, chunks, ragged, honour_lstm_chunks):
     """Forward outputs / final states and all gradients of the persistent recurrence agree with the per-step kernels (which are
