@@ -490,6 +490,13 @@ int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H);
 int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                           float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                           int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* --compute_dtype=bfloat16 (our variant flag; the reference is fp32 throughout): the recurrent product dz_t . W_h^T of the same backward
+ * pass (W/all_frame_models/lstm_model.py:34-47 through tf.gradients) on ONE bf16 plane -- dz_t and W_h rounded to nearest even, fp32
+ * accumulation, dz as stored stays fp32.  Same arguments.  A permission, not a demand: launches that cannot take the bf16 form (H
+ * other than 512 / 1024, fewer than four 16-row tiles per workgroup, no room for one exchange image per step) run the fp32 form. */
+int yt8m_lstm_persist_bwd_bf16(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                               float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                               int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* The same launch with the operand images of dz[t0 .. t0 + T) written by the recurrence itself (round 4): what yt8m_x3_split /
  * yt8m_x3_split_colsum would make of that part of dz in separate passes -- bit for bit -- for the products that follow it in the
  * backward pass of BasicLSTMCell under dynamic_rnn (W/all_frame_models/lstm_model.py:34-47 through tf.gradients, W/train.py:461):

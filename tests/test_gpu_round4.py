@@ -315,3 +315,54 @@ def test_interleaved_image_gemms_equal_the_round3_kernels_bit_for_bit(dev, M, N,
     ref = Aq.double() @ B.double().t()
     ref = (r.double()[:, None] * (ref + 0.25 * cs.double()) if affine else ref) + bias.double()
     assert float((new.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+
+
+# ---- backward recurrence on one bf16 plane (--compute_dtype=bfloat16) -------------------------------------------------------------------
+@pytest.mark.parametrize("B,F,H", [(128, 24, 1024), (256, 10, 512), (100, 9, 1024)])
+def test_bf16_backward_recurrence_against_a_rounding_emulation(dev, B, F, H):
+    """yt8m_lstm_persist_bwd_bf16 = the BasicLSTM backward recurrence with dh_{t-1} = bf16(dz_t) . bf16(W_h)^T (round to nearest
+    even, fp32 accumulation), everything else as in the fp32 launch: against a torch restatement of exactly that (fp64 products of
+    the rounded operands) to 2e-3 of max|dz| -- what is left is where a dz value sits within 1e-7 of a bf16 rounding boundary -- and
+    within 5 % of the fp32 launch, from which it must differ (the bf16 form was taken) unless the shape cannot take it (the
+    third case: B = 100 is not a multiple of four 16-row tiles per workgroup, so the request falls back to the fp32 form)."""
+    lib = L.lib()
+    if not lib.yt8m_lstm_persist_bwd_supported(B, H):
+        pytest.skip("persistent backward recurrence not available for this shape / device")
+    g = torch.Generator(device=dev).manual_seed(B + F + H)
+    gates = torch.rand((F, B, 4 * H), device=dev, generator=g)
+    gates[:, :, H:2 * H] = gates[:, :, H:2 * H] * 2.0 - 1.0           # j = tanh(.)
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.06
+    cs = torch.randn((F + 1, B, H), device=dev, generator=g) * 0.5
+    dout = torch.randn((F, B, H), device=dev, generator=g) * 0.01
+
+    def run(fn):
+        pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F), dtype=torch.uint8, device=dev)
+        work = torch.zeros((4, B, H), device=dev)
+        dz = torch.full((F, B, 4 * H), float("nan"), device=dev)
+        L.check(fn(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), pws.numel(), _stream()))
+        torch.cuda.synchronize()
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        return dz
+    dz32 = run(lib.yt8m_lstm_persist_bwd)
+    dzb = run(lib.yt8m_lstm_persist_bwd_bf16)
+    assert torch.isfinite(dzb).all()
+    takes_bf16 = lib.yt8m_lstm_persist_bwd_images_rows(B, H) > 0 and H in (512, 1024)   # rotated, prefetching form
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    Wr = rnd(Wh) if takes_bf16 else Wh.double()
+    dh = torch.zeros((B, H), dtype=torch.float64, device=dev)
+    dc = torch.zeros((B, H), dtype=torch.float64, device=dev)
+    ref = torch.empty((F, B, 4 * H), dtype=torch.float64, device=dev)
+    for t in range(F - 1, -1, -1):
+        gi, gj, gf, go = gates[t].double().chunk(4, 1)
+        cp, cn = cs[t].double(), cs[t + 1].double()
+        tc = torch.tanh(cn)
+        dht = dh + dout[t].double()
+        dct = dc + dht * go * (1.0 - tc * tc)
+        ref[t] = torch.cat([dct * gj * gi * (1.0 - gi), dct * gi * (1.0 - gj * gj), dct * cp * gf * (1.0 - gf), dht * tc * go * (1.0 - go)], 1)
+        dc = dct * gf
+        dzt = ref[t].float()
+        dh = (rnd(dzt) if takes_bf16 else dzt.double()) @ Wr.t()
+    scale = float(ref.abs().max())
+    assert float((dzb.double() - ref).abs().max()) < (2e-3 if takes_bf16 else 2e-5) * scale
+    assert float((dzb - dz32).abs().max()) < 5e-2 * scale
+    assert torch.equal(dzb, dz32) != takes_bf16

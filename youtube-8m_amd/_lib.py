@@ -164,6 +164,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
+    "yt8m_lstm_persist_bwd_bf16": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_images_rows": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd_images": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P, P]),
     "yt8m_lstm_packed_floats": (c_int64, [c_int64, c_int64]),

@@ -856,6 +856,7 @@ struct PersistBwdArgs {
   int t0, T, B, H, phase;
   int NUB, RB, NT16, per, pf;
   int nimg;
+  int bf;               // one-plane bf16 recurrent product requested (taken when the launch has the rotated, prefetching, image-per-step form)
   unsigned long long* dbg;
   // IMG (rotated epilogue only): the operand images of this launch's dz written by the epilogue itself -- what yt8m_x3_split would
   // make of dz[t0 .. t0 + T) in separate passes (csrc/gemm_x3.hip image layout: 1 KiB blocks of 32 rows x 16 k per plane).
@@ -895,12 +896,18 @@ __device__ __forceinline__ void p_split3(float x, unsigned& h1, unsigned& h2, un
 // operands as soon as it has published the previous one, and the matrix waves only ever wait for the partial-tile slot.  Needs
 // every workgroup to own a multiple of four tiles (a tile then always meets the same wave: its running (dh, dc) are re-read by the
 // lanes that wrote them); the host falls back to the team form otherwise (YT8M_BWD_ROT=0 forces it).
-template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false>
+// BF (round 4, --compute_dtype=bfloat16 on the native stack): the recurrent product on ONE bf16 plane -- dz travels as bf16 (round
+// to nearest even, A fragments of v_mfma_f32_16x16x32_bf16: [tile][4H / 32][4 k-groups x 16 rows][8 bf16] = 1 KiB blocks, half the
+// fp32 exchange), the workgroup's [16 x 4H] slice of W_h^T is rounded once per launch and is register-resident in full (64 VGPRs),
+// a wave's K range is NQB / 2 blocks of 32: NQB / 2 MFMAs of 16 cycles per item instead of 4 NQB of 32.  dz as STORED (the operand of
+// dx and of the weight gradients, which round it themselves) stays fp32; fp32 accumulation and gate arithmetic as in the fp32 form.
+template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false, bool BF = false>
 __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
   static_assert(!IMG || ROT, "the operand images are written by the rotated epilogue");
+  static_assert(!BF || (PF && SH && ROT && !IMG && (NQB % 4) == 0), "the bf16-operand form: prefetching, one image per step, rotated epilogue");
   constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
   constexpr unsigned EPW = ROT ? 1u : 4u;                // epilogue waves that read a partial-tile slot / publish a tile
-  __shared__ __attribute__((aligned(16))) float4 Wl[8][HALF][64];          // LDS-resident half of the weights: 8 * HALF KB
+  __shared__ __attribute__((aligned(16))) float4 Wl[8][BF ? 1 : HALF][64];  // LDS-resident half of the weights: 8 * HALF KB (BF: none)
   __shared__ __attribute__((aligned(16))) float red[NSLOT_B][8][4][64];    // [slot][wave][acc reg][lane]: 24 KB
   __shared__ unsigned lds_cnt[NSLOT_B], lds_free[NSLOT_B];
   __shared__ unsigned lds_seen[MAX_LOCAL_TILES];           // see the forward kernel: only matrix wave 0 polls memory
@@ -921,8 +928,8 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   const int n_it = (NT16 - g + RB - 1) / RB;
   const int total = n_it * a.T;
   const int QH4 = H >> 2;                                // q-groups per dz row (4H / 16)
-  const unsigned img_bytes = (unsigned)NT16 * (unsigned)H * 64u * 4u;
-  const long long img_f = (long long)NT16 * H * 64;
+  const unsigned img_bytes = (unsigned)NT16 * (unsigned)H * (BF ? 32u : 64u) * 4u;     // BF: 2 bytes per dz element
+  const long long img_f = (long long)NT16 * H * (BF ? 32 : 64);
   auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.dzx + (SH ? s : (s & 1)) * img_f, img_bytes); };
   constexpr int AUX_LD = SH ? 0 : YT8M_AUX_LD;
   const unsigned arrivals = (unsigned)a.NUB * EPW;       // per (tile, publish): EPW epilogue waves per workgroup
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   note_placement(a.ctl);
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
-  if (w < 8) {
+  if (!BF && w < 8) {
     // B fragment: lane (n = unit, kq) supplies W_h[16 ub + n][k = 16 q + 4 kq + e], e = 0..3: a float4 of a W_h row
     const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * NQB) * 16 + kq * 4;
 #pragma unroll
@@ -938,7 +945,95 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   }
   __syncthreads();
 
-  if (w < 8) {
+  if constexpr (BF) {
+    if (w < 8) {
+      // =============================== matrix waves, one bf16 plane ===============================
+      constexpr int KBW = NQB / 2, HB = KBW / 2;           // 32-wide K blocks per wave / per half item
+      // B fragment of v_mfma_f32_16x16x32_bf16: lane (n = unit, kg) supplies W_h[16 ub + n][k = 32 kb + 8 kg + j], j = 0..7
+      const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * KBW) * 32 + kq * 8;
+      u32x4 Wb[KBW];
+#pragma unroll
+      for (int kb = 0; kb < KBW; ++kb) {
+        const float4 lo = *reinterpret_cast<const float4*>(wrow + kb * 32), hi = *reinterpret_cast<const float4*>(wrow + kb * 32 + 4);
+        Wb[kb].x = p_bf16_rn_bits(lo.x) | (p_bf16_rn_bits(lo.y) << 16);
+        Wb[kb].y = p_bf16_rn_bits(lo.z) | (p_bf16_rn_bits(lo.w) << 16);
+        Wb[kb].z = p_bf16_rn_bits(hi.x) | (p_bf16_rn_bits(hi.y) << 16);
+        Wb[kb].w = p_bf16_rn_bits(hi.z) | (p_bf16_rn_bits(hi.w) << 16);
+      }
+      const int QB = H >> 3;                               // 32-wide K blocks per dz row (4H / 32)
+      const unsigned lane_off = (unsigned)lane * 16u + (unsigned)(w * KBW) * 1024u;
+      auto blk = [&](int T) -> unsigned { return (unsigned)(T * QB) * 1024u + lane_off; };
+      u32x4 ring[HB];
+      int s_cur = 0, it_cur = 0, slot = 0, gen = 0;
+      {
+        if (w == 0) {
+          wait_tile(a.ctl, g, arrivals, lane);
+          if (lane == 0) __hip_atomic_store(&lds_seen[0], arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          lds_wait_ge(&lds_seen[0], arrivals, a.ctl);
+        }
+        const unsigned b0 = blk(g);
+        const __amdgpu_buffer_rsrc_t dx0 = image(0);
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) ring[kb] = __builtin_amdgcn_raw_buffer_load_b128(dx0, (int)(b0 + (unsigned)kb * 1024u), 0, 0);
+      }
+      for (int k = 0; k < total; ++k) {
+        const int s = s_cur, T = g + it_cur * RB;
+        int s1 = s, it1 = it_cur + 1;
+        if (it1 == n_it) { it1 = 0; ++s1; }
+        const bool have1 = k + 1 < total;
+        const int T1 = have1 ? g + it1 * RB : T;
+        s1 = have1 ? s1 : s;
+        unsigned pv = 0;
+        const unsigned bcur = blk(T);
+        const __amdgpu_buffer_rsrc_t dxr = image(s);
+        if (w == 0 && lane < NSH)
+          pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // same placement as the fp32 form: first half -- refill (this item's second half) ahead of its MFMA, into fresh registers;
+        // second half -- the refill of entry kb - 1 (the next item's first half) behind MFMA kb
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, ring[kb]), bv = __builtin_bit_cast(bf16x8, Wb[kb]);
+          ring[kb] = __builtin_amdgcn_raw_buffer_load_b128(dxr, (int)(bcur + (unsigned)(HB + kb) * 1024u), 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc1, 0, 0, 0);
+          else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const int it1l = have1 ? it1 : it_cur;
+        if (w == 0) {
+          const unsigned tot = shard_sum(pv);
+          if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
+          if (lane == 0) __hip_atomic_store(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          lds_wait_ge(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, a.ctl);
+        }
+        const unsigned bnext = blk(T1);
+        const __amdgpu_buffer_rsrc_t dxn = image(s1);
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, ring[kb]), bv = __builtin_bit_cast(bf16x8, Wb[HB + kb]);
+          if (kb & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc1, 0, 0, 0);
+          else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc0, 0, 0, 0);
+          if (kb >= 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            ring[kb - 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, (int)(bnext + (unsigned)(kb - 1) * 1024u), 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        ring[HB - 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, (int)(bnext + (unsigned)(HB - 1) * 1024u), 0, 0);
+        if (gen > 0) lds_wait_ge(&lds_free[slot], EPW * (unsigned)gen, a.ctl);
+        float* rw = &red[slot][w][0][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[r * 64] = acc0[r] + acc1[r];
+        if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (++slot == NSLOT_B) { slot = 0; ++gen; }
+        if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+      }
+      return;
+    }
+  } else if (w < 8) {
     // =============================== matrix waves ===============================
     const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * NQB) * 16 + kq * 4;
     float4 Wr[HALF];
@@ -1083,6 +1178,31 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
     };
     auto publish_stores = [&](int T, int pub, const float (&dzv)[4][4]) {
       const __amdgpu_buffer_rsrc_t dxr = image(pub);
+      if constexpr (BF) {
+        // A fragments of v_mfma_f32_16x16x32_bf16: block (T, kbg) = [4 k-groups][16 rows][8 bf16]; this workgroup's 16 units of gate
+        // g4 are k = g4 H + 16 ub + unit: K block g4 (H / 32) + ub / 2, k-groups 2 (ub & 1) + unit / 8.  Eight units of a row = one
+        // 16-byte piece, gathered along the 16-lane DPP row (lane = unit) into the lanes with unit % 8 == 0.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const unsigned hb = p_bf16_rn_bits(dzv[r][g4]);
+            const unsigned d0 = hb | (row_shl_u<1>(hb) << 16);           // units (u, u + 1) on even lanes
+            const unsigned d1 = row_shl_u<2>(d0);
+            const unsigned d2 = row_shl_u<4>(d0), d3 = row_shl_u<4>(d1);
+            if ((eunit & 7) == 0) {
+              u32x4 v;
+              v.x = d0; v.y = d1; v.z = d2; v.w = d3;
+              const unsigned kbg = (unsigned)(g4 * (H >> 5) + (ub >> 1));
+              const unsigned kgrp = (unsigned)(((ub & 1) << 1) + (eunit >> 3));
+              const unsigned off = ((unsigned)(T * (H >> 3)) + kbg) * 1024u + (kgrp * 16u + (unsigned)(4 * rq + r)) * 16u;
+              __builtin_amdgcn_raw_buffer_store_b128(v, dxr, (int)off, 0, YT8M_AUX_ST);
+            }
+          }
+        }
+        pend_T = T;
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -1791,6 +1911,12 @@ int launch_bwd_sh(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
       return yt8m::fail(YT8M_E_SHAPE, "operand images need one exchange image per step%s", "");
     }
   }
+  if constexpr (SH && (NQB == 16 || NQB == 32)) {
+    if (a.bf && rot) {
+      hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, true, true, false, true>), dim3(grid), dim3(768), 0, s, a);
+      return yt8m::launch_status("lstm_persist_bwd_kernel");
+    }
+  }
   if (rot) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, true>), dim3(grid), dim3(768), 0, s, a);
   else if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, false>), dim3(grid), dim3(768), 0, s, a);
   else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false, SH, false>), dim3(grid), dim3(768), 0, s, a);
@@ -1819,7 +1945,7 @@ namespace {
 int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
-                     yt8m_stream_t stream);
+                     yt8m_stream_t stream, bool bf16 = false);
 }
 
 extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
@@ -1827,6 +1953,16 @@ extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_
                                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, dbias_rows, num_frames, t0, T, B, H, workspace, workspace_bytes,
                           nullptr, stream);
+}
+
+// yt8m_lstm_persist_bwd with the recurrent product dz . W_h^T on ONE bf16 plane (dz and W_h rounded to nearest even, fp32 accumulation;
+// --compute_dtype=bfloat16).  Shapes / launches that cannot take the bf16 form (H not 512 or 1024, fewer than four 16-row tiles per
+// workgroup, no room for one exchange image per step) run the fp32 form: the request is a permission, never an error.
+extern "C" int yt8m_lstm_persist_bwd_bf16(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                                          float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                                          int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, dbias_rows, num_frames, t0, T, B, H, workspace, workspace_bytes,
+                          nullptr, stream, true);
 }
 
 // yt8m_lstm_persist_bwd that also leaves the operand images of dz[t0 .. t0 + T) for the products that follow (include/yt8m_hip.h).
@@ -1848,7 +1984,7 @@ namespace {
 int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
-                     yt8m_stream_t stream) {
+                     yt8m_stream_t stream, bool bf16) {
   using namespace yt8m;
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
@@ -1877,6 +2013,7 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H; a.phase = phase;
   a.NUB = geo.NUB; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
   a.nimg = images_in(workspace_bytes, geo.NT16, 4 * H);
+  a.bf = (bf16 && !img) ? 1 : 0;
   a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES);
   const unsigned grid = (unsigned)(geo.NUB * geo.RB);
   int dev = 0;

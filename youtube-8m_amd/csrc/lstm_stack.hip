@@ -582,9 +582,12 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         img_done_rows[l] += M;
         ++img_launches[l];
       } else {
-        RC(yt8m_lstm_persist_bwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
-                                 at<float>(scratch, P.work[l]), phase[l], nullptr, num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]),
-                                 P.pws_bytes, s));
+        // bf16-operand mode: the recurrent product of the backward pass on one bf16 plane too (knob YT8M_STACK_BF16_RECUR, default 1;
+        // the launch falls back to the fp32 form by itself where the shape cannot take it)
+        static const int bf_recur = knob("YT8M_STACK_BF16_RECUR", 1);
+        RC((bf && bf_recur ? yt8m_lstm_persist_bwd_bf16 : yt8m_lstm_persist_bwd)(
+            at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz, at<float>(scratch, P.work[l]), phase[l],
+            nullptr, num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]), P.pws_bytes, s));
       }
       phase[l] = (int)((phase[l] + T) % 2);
       hipEvent_t rb = ev.record(s);
