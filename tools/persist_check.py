@@ -108,21 +108,23 @@ def timing_bwd(B=int(os.environ.get("PCHECK_B", "128")), F=300, H=1024):
     cs = torch.randn((F + 1, B, H), device=dev) * 0.5
     dz = torch.empty((F, B, 4 * H), device=dev)
     dout = torch.randn((F, B, H), device=dev) * 0.01
-    for it in range(6):
+    for it in range(9):
         steps = it >= 3
+        bf16 = it >= 6                                    # the recurrent product on one bf16 plane (yt8m_lstm_persist_bwd_bf16)
         pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
                           dtype=torch.uint8, device=dev)
         work = torch.zeros((4, B, H), device=dev)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws),
-                                          pws.numel(), _stream()))
+        L.check((lib.yt8m_lstm_persist_bwd_bf16 if bf16 else lib.yt8m_lstm_persist_bwd)(
+            _p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), pws.numel(), _stream()))
         e1.record()
         torch.cuda.synchronize()
         L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
         print("persistent bwd kernel (%s): %.3f ms for %d steps = %.2f us/step"
-              % ("image per step" if steps else "two images", e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F), flush=True)
+              % (("image per step, bf16 recurrent product" if bf16 else "image per step") if steps else "two images", e0.elapsed_time(e1), F,
+                 e0.elapsed_time(e1) * 1e3 / F), flush=True)
 
 
 if __name__ == "__main__":
