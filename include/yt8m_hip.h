@@ -482,6 +482,12 @@ int yt8m_lstm_persist_placement_stats(int64_t* launches, int64_t* workgroups, in
 int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                           const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
                           void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* --compute_dtype=bfloat16 (our variant flag): the recurrent product h_{t-1} . W_h of the same forward recurrence
+ * (W/all_frame_models/lstm_model.py:34-47) on ONE bf16 plane -- h and W_h rounded to nearest even, fp32 accumulation.  Same arguments.
+ * A permission: launches that cannot take the bf16-pipe kernel run the fp32 form. */
+int yt8m_lstm_persist_fwd_bf16(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
+                               const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                               void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* backward: steps t0+T-1 down to t0; (gates, cs, dout, dz, work, phase) exactly as yt8m_lstm_steps_bwd.  The backward of
  * dynamic_rnn's while_loop (tf.gradients through W/all_frame_models/lstm_model.py:44-47).  dbias_rows (may be NULL):
  * [B,4H] running sums of dz over the processed steps, accumulated IN PLACE (zero it before the first chunk); the bias

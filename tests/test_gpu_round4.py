@@ -366,3 +366,50 @@ def test_bf16_backward_recurrence_against_a_rounding_emulation(dev, B, F, H):
     assert float((dzb.double() - ref).abs().max()) < (2e-3 if takes_bf16 else 2e-5) * scale
     assert float((dzb - dz32).abs().max()) < 5e-2 * scale
     assert torch.equal(dzb, dz32) != takes_bf16
+
+
+@pytest.mark.parametrize("B,F,H", [(128, 12, 1024), (64, 9, 512), (8, 5, 1024)])
+def test_bf16_forward_recurrence_against_a_rounding_emulation(dev, B, F, H):
+    """yt8m_lstm_persist_fwd_bf16 = BasicLSTMCell under dynamic_rnn (W/all_frame_models/lstm_model.py:34-47) with the recurrent
+    product bf16(h_{t-1}) . bf16(W_h), fp32 accumulation, everything else as the fp32 launch: states and gates against a torch
+    restatement of exactly that (fp64 products of the rounded operands) to 2e-3, within 2e-2 of the fp32 launch, and different from it
+    where the shape takes the bf16-pipe kernel (the third case, one 16-row tile, does not: the request falls back)."""
+    lib = L.lib()
+    if not lib.yt8m_lstm_persist_supported(B, H):
+        pytest.skip("persistent recurrence not available for this shape / device")
+    g = torch.Generator(device=dev).manual_seed(B * 3 + F + H)
+    z_in = torch.randn((F, B, 4 * H), device=dev, generator=g) * 0.7
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.08
+    nf = torch.randint(0, F + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+    nf[0], nf[1] = F, 0
+    h0 = torch.randn((B, H), device=dev, generator=g) * 0.3
+    c0 = torch.randn((B, H), device=dev, generator=g) * 0.3
+
+    def run(fn):
+        pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F), dtype=torch.uint8, device=dev)
+        z = z_in.clone()
+        cs = torch.zeros((F + 1, B, H), device=dev)
+        hs = torch.zeros((F + 1, B, H), device=dev)
+        cs[0], hs[0] = c0, h0
+        out = torch.full((F, B, H), float("nan"), device=dev)
+        L.check(fn(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nf), 0, F, B, H, 1.0, _p(pws), pws.numel(), _stream()))
+        torch.cuda.synchronize()
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        return hs, cs, out
+    hs32, cs32, out32 = run(lib.yt8m_lstm_persist_fwd)
+    hsb, csb, outb = run(lib.yt8m_lstm_persist_fwd_bf16)
+    takes_bf16 = H in (512, 1024) and B > 16
+    rnd = (lambda t: t.to(torch.bfloat16).to(torch.float64)) if takes_bf16 else (lambda t: t.double())
+    Wr = rnd(Wh)
+    h, c = h0.double(), c0.double()
+    for t in range(F):
+        live = (t < nf).unsqueeze(1)
+        i, j, f, o = (z_in[t].double() + rnd(h.float()) @ Wr).chunk(4, 1)
+        cn = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+        hn = torch.tanh(cn) * torch.sigmoid(o)
+        c, h = torch.where(live, cn, c), torch.where(live, hn, h)
+        tol = 2e-3 if takes_bf16 else 2e-5
+        assert float((hsb[t + 1].double() - h).abs().max()) < tol and float((csb[t + 1].double() - c).abs().max()) < tol
+        assert float((outb[t].double() - torch.where(live, h, torch.zeros_like(h))).abs().max()) < tol
+    assert float((hsb - hs32).abs().max()) < 2e-2
+    assert torch.equal(hsb, hs32) != takes_bf16

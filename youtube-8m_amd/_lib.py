@@ -162,6 +162,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_reserve_cus": (c_int, [c_int, ctypes.POINTER(c_int)]),
     "yt8m_lstm_persist_debug_fault": (c_int, [P, P]),
     "yt8m_lstm_persist_fwd": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
+    "yt8m_lstm_persist_fwd_bf16": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_bf16": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),

@@ -528,12 +528,13 @@ __device__ __forceinline__ unsigned row_shl_u(unsigned v) {
 }
 
 // image 0 of a launch <- h_{t0-1} (standard layout), split into the three planes
+template <int NP>
 __global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict__ h, u32x4* __restrict__ img, int B, int H, int NT16) {
   const int KBH = H >> 5;
-  const long long n = (long long)NT16 * KBH * 3 * 64;
+  const long long n = (long long)NT16 * KBH * NP * 64;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
-    const int l = (int)(e & 63), p = (int)((e >> 6) % 3);
-    const long long blk = e / 192;
+    const int l = (int)(e & 63), p = (int)((e >> 6) % NP);
+    const long long blk = e / (64 * NP);
     const int kbg = (int)(blk % KBH), T = (int)(blk / KBH);
     const int row = T * 16 + (l & 15), k0 = kbg * 32 + (l >> 4) * 8;
     unsigned hb[8];
@@ -549,14 +550,16 @@ __global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict
   }
 }
 
-template <int NKB>
+// NP = 1 (round 4, --compute_dtype=bfloat16): ONE plane -- h_t travels as bf16 (a third of the exchange), W_h is rounded once per
+// launch and is register-resident in full, one MFMA per (K block, column half) instead of six.
+template <int NKB, int NP = 3>
 __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs a) {
   constexpr int NS = 2;                                  // partial-tile slots
 #ifndef YT8M_X3_EPW
 #define YT8M_X3_EPW 2
 #endif
   constexpr int EPW = YT8M_X3_EPW;                       // epilogue waves per item (1: a whole tile per wave, 2: half a tile each)
-  constexpr int NF = NKB * 6;                            // B fragments of a wave: [K block][column half][plane]
+  constexpr int NF = NKB * 2 * NP;                       // B fragments of a wave: [K block][column half][plane]
   constexpr int NREG = NF < 10 ? NF : 10, NLDS = NF - NREG;
   constexpr int HK = NKB / 2;                            // K blocks per half item
   static_assert(NKB % 2 == 0, "half items");
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   const int n_it = (NT16 - g + RB - 1) / RB;
   const int total = n_it * a.T;
   const int KBH = H >> 5;                                // 32-wide K blocks per row
-  const long long img_f = (long long)NT16 * KBH * 3 * 256;
+  const long long img_f = (long long)NT16 * KBH * NP * 256;
   const unsigned img_bytes = (unsigned)(img_f * 4);
   auto image = [&](int s) -> __amdgpu_buffer_rsrc_t { return make_rsrc(a.hx + s * img_f, img_bytes); };
   const unsigned arrivals = (unsigned)a.NU * EPW;       // per (tile, step): EPW epilogue waves per workgroup
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
   if (w < 8) {
 #pragma unroll
-    for (int f = NREG; f < NF; ++f) Wl[w][f - NREG][lane] = w_frag(f / 6, (f / 3) & 1, f % 3);
+    for (int f = NREG; f < NF; ++f) Wl[w][f - NREG][lane] = w_frag(f / (2 * NP), (f / NP) & 1, f % NP);
   }
   __syncthreads();
 
@@ -615,24 +618,24 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
     // =============================== matrix waves ===============================
     u32x4 Wr[NREG];
 #pragma unroll
-    for (int f = 0; f < NREG; ++f) Wr[f] = w_frag(f / 6, (f / 3) & 1, f % 3);
-    const unsigned lane_off = (unsigned)lane * 16u + (unsigned)(w * NKB) * 3072u;
+    for (int f = 0; f < NREG; ++f) Wr[f] = w_frag(f / (2 * NP), (f / NP) & 1, f % NP);
+    const unsigned lane_off = (unsigned)lane * 16u + (unsigned)(w * NKB) * (NP * 1024u);
     // half `half` (K blocks half * HK ..) of the A fragments of item (s, T): plain loads, one 1 KiB block per K block and plane
-    auto load_half = [&](u32x4 (&Hh)[HK][3], int s, int T, int half) {
+    auto load_half = [&](u32x4 (&Hh)[HK][NP], int s, int T, int half) {
       const __amdgpu_buffer_rsrc_t hxr = image(s);
-      const unsigned base = (unsigned)(T * KBH) * 3072u + lane_off + (unsigned)(half * HK) * 3072u;
+      const unsigned base = (unsigned)(T * KBH) * (NP * 1024u) + lane_off + (unsigned)(half * HK) * (NP * 1024u);
 #pragma unroll
       for (int kbl = 0; kbl < HK; ++kbl)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          Hh[kbl][p] = __builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)(kbl * 3 + p) * 1024u), 0, 0);
+        for (int p = 0; p < NP; ++p)
+          Hh[kbl][p] = __builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)(kbl * NP + p) * 1024u), 0, 0);
     };
-    u32x4 H0[HK][3], H1[HK][3], H2[HK][3];
+    u32x4 H0[HK][NP], H1[HK][NP], H2[HK][NP];
     load_half(H0, 0, g, 0);                              // item 0 reads the packed initial state: nothing to wait for
     load_half(H1, 0, g, 1);
     int s_cur = 0, it_cur = 0;
     // Ha / Hb: the halves of this item; the state of the next item goes to Hc (first half) and Ha (second half)
-    auto item = [&](u32x4 (&Ha)[HK][3], u32x4 (&Hb)[HK][3], u32x4 (&Hc)[HK][3], int k) {
+    auto item = [&](u32x4 (&Ha)[HK][NP], u32x4 (&Hb)[HK][NP], u32x4 (&Hc)[HK][NP], int k) {
       const int s = s_cur, T = g + it_cur * RB;
       STAMP(0);
       int sr = s, itr = it_cur + 1;
@@ -645,9 +648,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       if (w == 0 && lane < NSH)
         pv = __hip_atomic_load(a.ctl + CTL_HDR + (Tr * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-      u32x4 ls[2][3];
+      u32x4 ls[2][NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
         if (p >= NREG) ls[0][p] = Wl[w][p >= NREG ? p - NREG : 0][lane];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
@@ -661,9 +664,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           }
           STAMP(1);                                      // (the 3 NKB loads of the request go out three per MFMA group below)
         }
-        bf16x8 av[3];
+        bf16x8 av[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) av[p] = __builtin_bit_cast(bf16x8, kb < HK ? Ha[kb < HK ? kb : 0][p] : Hb[kb >= HK ? kb - HK : 0][p]);
+        for (int p = 0; p < NP; ++p) av[p] = __builtin_bit_cast(bf16x8, kb < HK ? Ha[kb < HK ? kb : 0][p] : Hb[kb >= HK ? kb - HK : 0][p]);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           // LDS-resident weight fragments travel one six-MFMA group ahead of their use (two register sets in rotation): read in
@@ -671,34 +674,38 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           const int gi = kb * 2 + ct;
           if (kb >= HK) {                                // the state of item k + 1: first half -> Hc, second half -> Ha (the MFMAs
             const __amdgpu_buffer_rsrc_t hxr = image(sr);   // that read Ha have been issued), three 1 KiB blocks per group
-            const unsigned base = (unsigned)(Tr * KBH) * 3072u + lane_off;
+            const unsigned base = (unsigned)(Tr * KBH) * (NP * 1024u) + lane_off;
 #pragma unroll
-            for (int j = 3 * (gi - NKB); j < 3 * (gi - NKB) + 3; ++j) {
-              const int kbl = (j % (3 * HK)) / 3, pl = j % 3;
+            for (int j = NP * (gi - NKB); j < NP * (gi - NKB) + NP; ++j) {
+              const int kbl = (j % (NP * HK)) / NP, pl = j % NP;
               const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hxr, (int)(base + (unsigned)j * 1024u), 0, 0);
-              if (j < 3 * HK) Hc[kbl][pl] = v; else Ha[kbl][pl] = v;
+              if (j < NP * HK) Hc[kbl][pl] = v; else Ha[kbl][pl] = v;
             }
           }
           if (gi + 1 < 2 * NKB) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              const int f = (gi + 1) * 3 + p;
+            for (int p = 0; p < NP; ++p) {
+              const int f = (gi + 1) * NP + p;
               if (f >= NREG) ls[(gi + 1) & 1][p] = Wl[w][f >= NREG ? f - NREG : 0][lane];
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          bf16x8 bv[3];
+          bf16x8 bv[NP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const int f = gi * 3 + p;
+          for (int p = 0; p < NP; ++p) {
+            const int f = gi * NP + p;
             bv[p] = __builtin_bit_cast(bf16x8, f < NREG ? Wr[f < NREG ? f : 0] : ls[gi & 1][p]);
           }
-          acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][0], 0, 0, 0);
-          acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[1], acc[ct][1], 0, 0, 0);
-          acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[0], acc[ct][0], 0, 0, 0);
-          acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[2], acc[ct][1], 0, 0, 0);
-          acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[1], acc[ct][0], 0, 0, 0);
-          acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], acc[ct][1], 0, 0, 0);
+          if constexpr (NP == 3) {
+            acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][0], 0, 0, 0);
+            acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[1], acc[ct][1], 0, 0, 0);
+            acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[0], acc[ct][0], 0, 0, 0);
+            acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[2], acc[ct][1], 0, 0, 0);
+            acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[1], acc[ct][0], 0, 0, 0);
+            acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], acc[ct][1], 0, 0, 0);
+          } else {
+            acc[ct][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][kb & 1], 0, 0, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -786,17 +793,18 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         for (int jj = 0; jj < JP; ++jj) {
           const int j = EPW == 2 ? (ew & 1) : jj;
           unsigned hb[3];
-          split3_bits(hn[jj], hb[0], hb[1], hb[2]);
+          if constexpr (NP == 3) split3_bits(hn[jj], hb[0], hb[1], hb[2]);
+          else hb[0] = bf16_rn_bits(hn[jj]);
           const int erow = 8 * j + (lane >> 3);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NP; ++p) {
             // units 0..7 of this row are lanes l .. l + 7: pairs first, then the four pair words into the lane of unit 0
             const unsigned d = hb[p] | (row_shl_u<1>(hb[p]) << 16);
             const unsigned d2 = row_shl_u<2>(d), d4 = row_shl_u<4>(d), d6 = row_shl_u<6>(d);
             if (eunit == 0) {
               u32x4 v;
               v.x = d; v.y = d2; v.z = d4; v.w = d6;
-              const unsigned off = ((unsigned)((T * KBH + (ug >> 2)) * 3 + p) * 256u + (unsigned)(((ug & 3) * 16 + erow) * 4)) * 4u;
+              const unsigned off = ((unsigned)((T * KBH + (ug >> 2)) * NP + p) * 256u + (unsigned)(((ug & 3) * 16 + erow) * 4)) * 4u;
               __builtin_amdgcn_raw_buffer_store_b128(v, hxr, (int)off, 0, YT8M_AUX_ST);
             }
           }
@@ -1802,9 +1810,29 @@ extern "C" int yt8m_lstm_persist_debug_fault(void* workspace, yt8m_stream_t stre
   return launch_status("persist_fault_kernel");
 }
 
+namespace {
+int persist_fwd_impl(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out, const int32_t* num_frames, int64_t t0,
+                     int64_t T, int64_t B, int64_t H, float forget_bias, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream,
+                     bool bf16);
+}
 extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                                      const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
                                      void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  return persist_fwd_impl(z, Wh, ldw, cs, hs, out, num_frames, t0, T, B, H, forget_bias, workspace, workspace_bytes, stream, false);
+}
+// yt8m_lstm_persist_fwd with the recurrent product h_{t-1} . W_h on ONE bf16 plane (h and W_h rounded to nearest even, fp32
+// accumulation; --compute_dtype=bfloat16).  A permission: launches that cannot take the bf16-pipe kernel (H other than 512 / 1024,
+// fewer than two 16-row tiles per workgroup, no room for one exchange image per step) run the fp32 form.
+extern "C" int yt8m_lstm_persist_fwd_bf16(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
+                                          const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                                          void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  return persist_fwd_impl(z, Wh, ldw, cs, hs, out, num_frames, t0, T, B, H, forget_bias, workspace, workspace_bytes, stream, true);
+}
+namespace {
+int persist_fwd_impl(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out, const int32_t* num_frames, int64_t t0,
+                     int64_t T, int64_t B, int64_t H, float forget_bias, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream,
+                     bool bf16) {
+  using namespace yt8m;
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   if (T * B * H == 0) return YT8M_OK;
   YT8M_REQUIRE(z && Wh && cs && hs && workspace, YT8M_E_BADARG, "null operand");
@@ -1839,8 +1867,16 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   // fp32 one) per step, >= 2 tiles per workgroup, H in {512, 1024}
   const bool x3 = fwd_x3_shape(H, geo.pf) && images_in(workspace_bytes, geo.NT16, H + H / 2) >= T;
   int rc;
-  if (x3) {
-    hipLaunchKernelGGL(hx_pack_x3_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
+  if (x3 && bf16) {
+    hipLaunchKernelGGL(hx_pack_x3_kernel<1>, dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
+                       geo.NT16);
+    rc = launch_status("hx_pack_x3_kernel");
+    if (rc != YT8M_OK) return rc;
+    if (H == 1024) hipLaunchKernelGGL((lstm_persist_fwd_x3_kernel<4, 1>), dim3(grid), dim3(768), 0, s, a);
+    else hipLaunchKernelGGL((lstm_persist_fwd_x3_kernel<2, 1>), dim3(grid), dim3(768), 0, s, a);
+    rc = launch_status("lstm_persist_fwd_x3_kernel");
+  } else if (x3) {
+    hipLaunchKernelGGL(hx_pack_x3_kernel<3>, dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
                        geo.NT16);
     rc = launch_status("hx_pack_x3_kernel");
     if (rc != YT8M_OK) return rc;
@@ -1862,6 +1898,7 @@ extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, flo
   if (rc != YT8M_OK) return rc;
   return g_gate.done(dev, (int)grid, s);
 }
+}  // namespace
 
 namespace {
 struct GeometryB { int NQB, NUB, RB, NT16, per, pf; };

@@ -442,9 +442,11 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
         yt8m_x3_set_combine(0);
         RC(grc);
       }
-      RC(yt8m_lstm_persist_fwd(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), at<float>(tape, P.hs[l]),
-                               at<float>(tape, P.out[l]), num_frames, t0, T, B, H, desc->forget_bias, at<char>(scratch, P.pws[l]),
-                               P.pws_bytes, s));
+      // bf16-operand mode: the recurrent product on one bf16 plane (knob YT8M_STACK_BF16_RECUR, default 1)
+      static const int bf_recur_f = knob("YT8M_STACK_BF16_RECUR", 1);
+      RC((bf && bf_recur_f ? yt8m_lstm_persist_fwd_bf16 : yt8m_lstm_persist_fwd)(
+          at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), at<float>(tape, P.hs[l]), at<float>(tape, P.out[l]),
+          num_frames, t0, T, B, H, desc->forget_bias, at<char>(scratch, P.pws[l]), P.pws_bytes, s));
       done[(size_t)l * P.nf + c] = ev.record(s);
     }
   }
