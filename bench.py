@@ -664,6 +664,118 @@ def library_identity():
             "sha256": h.hexdigest(), "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("YT8M_")}}
 
 
+LINE_LIMIT = 8192                    # the driver keeps ~8.9 KB of stdout: the ONE line must fit
+SIDECAR = "bench_extra.json"
+
+
+def _r(x, nd=5):
+    """floats to `nd` significant digits (the line is a summary; the sidecar keeps full precision)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    return x
+
+
+def _short(s, n):
+    return s if s is None or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(out, sidecar=SIDECAR):
+    """The ONE stdout line of the contract, <= LINE_LIMIT bytes: headline fields + `roofline` (dominant kernel and a compact
+    {frac, ms_per_step} map of the families) + `cpu_baseline` + `gap_at_20` + library sha256.  Everything else of `out` (the extra
+    configurations with their per-family detail, placement, data-parallel trace, notes) stays in the sidecar file named here."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step",
+                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    c = out.get("config") or {}
+    line["config"] = {k: c.get(k) for k in ("workload", "per_gpu_batch", "global_batch", "frames", "parallelism", "params")}
+    line["config"]["workload"] = _short(line["config"]["workload"], 260)
+    r = out.get("roofline")
+    if r:
+        cr = {k: (r.get(k) if k in ("achieved", "peak", "frac") else _r(r.get(k)))
+              for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
+                                        "avg_launch_ms", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch",
+                                        "occupied_cus", "frac_of_occupied_cus") if r.get(k) is not None or k == "traffic"}
+        cr["peak_is"] = _short(r.get("peak_is"), 90)
+        if r.get("traffic_source"):
+            cr["traffic_source"] = _short(r["traffic_source"], 120)
+        cr["families"] = {k: {"frac": _r(v["frac"], 4), "ms_per_step": _r(v["ms_per_step"], 4), "peak": _r(v["peak"], 4)}
+                          for k, v in (r.get("families") or {}).items()}
+        cr["other_ms_per_step"] = {k: _r(v["ms_per_step"], 4) for k, v in (r.get("other_families") or {}).items()}
+        if r.get("blended_bound"):
+            cr["blended_bound"] = {k: _r(r["blended_bound"].get(k), 4) for k in ("ms_per_step", "frac")}
+        line["roofline"] = cr
+    else:
+        line["roofline"] = None
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "implementation", "batch", "timed_steps",
+                                                           "seconds", "usable_cores") if k in cb}
+        line["cpu_baseline"]["sample"] = _short(cb.get("sample"), 240)
+    else:
+        line["cpu_baseline"] = None
+    gp = out.get("gap_at_20")
+    if gp:
+        cg = {k: _r(gp.get(k)) for k in ("value", "hit_at_one", "perr", "train_steps", "batch", "heldout_videos", "error") if k in gp}
+        for k, v in gp.items():
+            if isinstance(v, dict) and k.startswith(("cpu_twin", "frame_twin")):
+                cg[k] = ({"error": _short(v["error"], 120)} if "error" in v else
+                         {kk: _r(v.get(kk)) for kk in ("gap_hip", "gap_cpu_port", "abs_diff", "within_target")})
+        line["gap_at_20"] = cg
+    else:
+        line["gap_at_20"] = None
+    ex = []
+    for e in out.get("extra") or []:
+        if "error" in e:
+            ex.append({"workload": _short(e.get("workload"), 60), "error": _short(e["error"], 120)})
+            continue
+        er = e.get("roofline") or {}
+        row = {"workload": _short(e["workload"], 60), "dtype": e["dtype"], "per_gpu_batch": e["per_gpu_batch"], "steps": e["steps"],
+               "ms_per_step": _r(e["ms_per_step"]), "value": _r(e["value"])}
+        if er.get("kernel"):
+            row["dominant"] = {"kernel": er["kernel"], "frac": _r(er.get("frac"), 4), "bound": er.get("bound")}
+        if er.get("blended_bound"):
+            row["blended_frac"] = _r(er["blended_bound"].get("frac"), 4)
+        if er.get("hbm"):
+            row["hbm"] = {k: {"frac_of_hbm": _r(v.get("frac_of_hbm"), 4), "frac_of_hbm_8d_bytes": _r(v.get("frac_of_hbm_8d_bytes"), 4),
+                              "avg_launch_us": _r(v.get("avg_launch_us"), 4)} for k, v in er["hbm"]["kernels"].items()}
+        ex.append(row)
+    line["extra"] = ex
+    lib = out.get("library") or {}
+    line["library"] = {"sha256": lib.get("sha256"), "in_tree_default": lib.get("in_tree_default"), "env": lib.get("env")}
+    rd = out.get("reducer")
+    if rd:
+        line["reducer"] = {k: rd.get(k) for k in ("algo", "reserved_cus", "world", "bucket_MiB", "layer_buckets", "transport",
+                                                  "forced_at_world_1")}
+        pr = rd.get("per_rank") or []
+        line["reducer"]["persist_timeouts"] = sum(1 for x in pr if x and x.get("persist_timeout"))
+        exposed = [x["dp_trace"].get("exposed_ms") for x in pr if x and isinstance(x.get("dp_trace"), dict) and "exposed_ms" in x["dp_trace"]]
+        if exposed:
+            line["reducer"]["exposed_allreduce_ms_max"] = _r(max(exposed), 4)
+    line["sidecar"] = sidecar
+    # the contract is the size: shed the optional detail, in this order, until the line fits
+    for drop in (lambda: line["library"].pop("env", None), lambda: line["roofline"] and line["roofline"].pop("other_ms_per_step", None),
+                 lambda: [e.pop("hbm", None) for e in line["extra"]], lambda: line.update(extra=[{"workload": e["workload"], "ms_per_step":
+                                                                                                e.get("ms_per_step")} for e in line["extra"]]),
+                 lambda: line.pop("extra", None), lambda: line.pop("gap_at_20", None)):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        drop()
+    return line
+
+
+def write_sidecar(out):
+    """Full detail next to the line (and under gpurun_out/ when that exists, so a gpurun call brings it back)."""
+    paths = [os.path.join(ROOT, SIDECAR)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", SIDECAR))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:                                   # a read-only tree must not cost the line
+            sys.stderr.write("bench: could not write %s: %r\n" % (p, e))
+    return paths[0]
+
+
 _T0 = time.perf_counter()
 
 
@@ -849,8 +961,9 @@ def main():
     if rccl_loaded:
         dist.destroy_process_group()
     if out is not None:
+        write_sidecar(out)
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact_line(out)), flush=True)
     if rccl_loaded:
         # librccl writes a version banner ("RCCL version : ...", five lines) to stdout when the process exits: the contract is ONE
         # line, so every rank leaves without running the C runtime's exit handlers (everything of ours is flushed above)

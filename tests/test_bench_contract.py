@@ -78,6 +78,33 @@ def _latest_line():
     raise AssertionError("no recorded bench line under profiles/")
 
 
+def test_recorded_line_is_small():
+    """the driver keeps ~8.9 KB of stdout, so the ONE line bench.py prints must stay under 8 KB whatever the full
+    record holds.  The r4 record (24.7 KB, unparsed by the driver) goes through the same trimming function bench.py prints through;
+    the result must fit, keep `roofline` and `cpu_baseline` with their contract fields, and name the sidecar with the rest."""
+    b = _bench()
+    full = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r4_bench_line.json")) if l.startswith("{")][-1])
+    assert len(json.dumps(full)) > 20000
+    out = b.compact_line(full)
+    text = json.dumps(out)
+    assert len(text) < 8192 and "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "sidecar"):
+        assert k in out, k
+    assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"]
+    r, c = out["roofline"], out["cpu_baseline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "lstm_recurrence_bwd" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["unit"] == "TFLOP/s" and "traffic" in r and set(r["families"]) == set(full["roofline"]["families"])
+    assert all(set(v) == {"frac", "ms_per_step", "peak"} for v in r["families"].values())
+    assert c["kind"] == "port" and c["cores"] == 16 and c["value"] > 0 and c["batch"] == 32 and c["implementation"] == "nn_lstm_twin"
+    assert out["gap_at_20"]["cpu_twin_full_size"]["within_target"] and len(out["library"]["sha256"]) == 64
+    assert len(out["extra"]) == len(full["extra"]) and out["sidecar"] == b.SIDECAR
+    # a record ten times as verbose still fits: the optional detail is shed, the contract fields never are
+    fat = dict(full, extra=full["extra"] * 12, library=dict(full["library"], env={"YT8M_%d" % i: "x" * 40 for i in range(60)}))
+    small = b.compact_line(fat)
+    assert len(json.dumps(small)) < 8192 and small["roofline"]["frac"] == r["frac"] and small["cpu_baseline"]["value"] == c["value"]
+
+
 def test_recorded_line_has_the_contract_fields():
     """The newest driver-style line under profiles/ carries every field the contract names (round 3 on: also the honesty fields
     of VERDICT r2 #5 -- chip-level fraction next to the occupied-CU one, the blended bound, where `traffic` comes from, the CPU

@@ -1,5 +1,6 @@
 """CPU tests of the section-8f widening pieces that are pure host logic: CSV line format and checkpoint round trip."""
 import numpy as np
+import pytest
 import torch
 
 import yt8m_amd.checkpoint as checkpoint
@@ -168,3 +169,36 @@ def test_early_optimizer_ranges_and_the_complement_the_step_covers():
             rest += list(range(pos, lo))
             pos = hi
         assert sorted(rest + [i for lo, hi in rng for i in range(lo, hi)]) == list(range(nt))
+
+
+def test_close_then_step_does_not_rescale_the_l2_table():
+    """TrainGraph.close() detaches the data-parallel reducer and a later step() re-attaches it, but the
+    --regularization_penalty scaling of the per-variable l2 table must happen exactly once per TrainGraph."""
+    class Reducer(object):
+        attached = detached = 0
+
+        def attach(self, g):
+            self.attached += 1
+
+        def detach(self):
+            self.detached += 1
+
+    class TG(object):
+        ensure_finalized = train.TrainGraph.ensure_finalized
+        close = train.TrainGraph.close
+
+    tg = TG()
+    tg.graph = Graph(device="cpu", seed=0)
+    tg.graph.begin_step()
+    tg.graph.get_variable("gates/weights", (6, 9), random_normal(0.3), l2=1e-8)
+    tg.reg_penalty, tg.reducer = 3.0, Reducer()
+    tg.ensure_finalized()
+    l2 = tg.graph.l2.clone()
+    assert float(l2.max()) == pytest.approx(3e-8) and tg.reducer.attached == 1
+    for cycle in range(3):
+        tg.ensure_finalized()                                   # idempotent while attached
+        tg.close()
+        tg.close()                                              # idempotent while detached
+        tg.ensure_finalized()
+        assert torch.equal(tg.graph.l2, l2)
+    assert tg.reducer.attached == 4 and tg.reducer.detached == 3

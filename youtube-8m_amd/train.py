@@ -153,16 +153,15 @@ class TrainGraph(object):
         --regularization_penalty to the per-variable l2 table and attaches the data-parallel reducer -- once.  Called by
         step() after the first forward pass and by checkpoint.restore() (the Adam slots live in the arenas)."""
         g = self.graph
-        if g.finalized and getattr(self, "_finalized_here", False):
-            return
         if not g.finalized:
             g.finalize()
-        if not getattr(self, "_finalized_here", False):
+        if not getattr(self, "_finalized_here", False):          # the l2 table is scaled exactly once per TrainGraph
             if self.reg_penalty != 1:
                 g.l2.mul_(float(self.reg_penalty))
-            if self.reducer is not None:
-                self.reducer.attach(g)
             self._finalized_here = True
+        if self.reducer is not None and not getattr(self, "_reducer_attached", False):
+            self.reducer.attach(g)                                # its own flag: close() detaches, a later step() re-attaches
+            self._reducer_attached = True
 
     # ---- one optimisation step -----------------------------------------------------------------------
     def step(self, model_input_raw, labels_batch, num_frames=None, weights=None, distill_labels_batch=None):
@@ -224,9 +223,9 @@ class TrainGraph(object):
     def close(self):
         """End of training (where W/train.py:612-622 leaves the Supervisor's session): gives back what the step holds
         process-wide -- the reducer's CU reserve of the persistent recurrences (parallel.GradReducer.detach)."""
-        if self.reducer is not None and getattr(self, "_finalized_here", False):
+        if self.reducer is not None and getattr(self, "_reducer_attached", False):
             self.reducer.detach()
-            self._finalized_here = False                          # a later step() re-attaches
+            self._reducer_attached = False                        # a later step() re-attaches (the l2 table is NOT rescaled)
 
     def __enter__(self):
         return self
