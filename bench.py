@@ -576,6 +576,71 @@ def gap_twin(dev, D_=64, V_=300, M_=2, B_=256, steps=60, held=2048, state=None):
                        " -- continued from the GAP leg's trained weights (fresh Adam state on both sides) on its teacher shard")}
 
 
+def gap_twin_frames(dev, D_=64, H_=256, L_=2, F_=40, V_=300, M_=2, B_=128, steps=100, held=2048, base_lr=0.001):
+    """The same acceptance check on a FRAME-LEVEL model (W/eval_util.py:102-120): LstmModel (L_ x BasicLSTMCell(H_)
+    under dynamic_rnn over <= F_ ragged frames of raw uint8 features + MoE head) trained from the SAME initial weights on the
+    SAME batches by the HIP path and by the torch-CPU restatement (oracle/torch_ref.LstmTrainStepCPU: the checker), GAP@20 of
+    both on a disjoint held-out shard.  The teacher labels a video from its base frame (the frames are the base + uniform byte
+    noise), so the recurrent stack has something to integrate.  base_learning_rate 0.001 on both sides: at the reference's default
+    0.01 this small model saturates to p = 0 within ten steps on either implementation and there is no ranking left to compare."""
+    import numpy as np
+    import yt8m_amd.eval_util as eval_util
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.train as train
+    from yt8m_amd.flags import FLAGS
+    from yt8m_amd.variables import reset_default_graph
+    from oracle import torch_ref
+    FLAGS.reset()
+    FLAGS.lstm_cells, FLAGS.lstm_layers = H_, L_
+    gen = torch.Generator().manual_seed(17)
+    Wt = torch.randn(D_, V_, generator=gen) / D_ ** 0.5
+    tau = [None]
+
+    def shard(n, seed):
+        g_ = torch.Generator().manual_seed(seed)
+        base = torch.randint(0, 256, (n, 1, D_), generator=g_)
+        q = (base + torch.randint(-12, 13, (n, F_, D_), generator=g_)).clamp_(0, 255).to(torch.uint8)
+        nf = torch.randint(F_ // 2, F_ + 1, (n,), generator=g_, dtype=torch.int32)
+        q = q * (torch.arange(F_)[None, :, None] < nf[:, None, None]).to(torch.uint8)      # the reader pads with zero BYTES
+        logit = torch_ref.dequantize(base[:, 0].to(torch.uint8)) @ Wt * 4.0 - 3.0 + 0.5 * torch.randn(n, V_, generator=g_)
+        if tau[0] is None:
+            tau[0] = torch.quantile(logit.flatten()[:200000], 1.0 - 3.4 / V_)
+        return q, nf, logit > tau[0]
+
+    qtr, ntr, ytr = shard(B_ * steps, 21)
+    qho, nho, yho = shard(held, 22)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cpu = torch_ref.LstmTrainStepCPU(D=D_, H=H_, L=L_, V=V_, M=M_, batch_size=B_, dtype=torch.float32, seed=5, base_lr=base_lr)
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(flm.LstmModel(), batch_size=B_, graph=g, base_learning_rate=base_lr)
+    tg.forward(qtr[:B_].to(dev), ytr[:B_].to(dev), ntr[:B_].to(dev))
+    tg.ensure_finalized()
+    assert set(cpu.P) == set(v for v in g.vars), (sorted(cpu.P), sorted(g.vars))
+    for k, v in cpu.P.items():
+        g.vars[k].data.copy_(v.detach().to(dev).view(g.vars[k].data.shape))
+    worst = 0.0
+    for i in range(steps):
+        sl = slice(i * B_, (i + 1) * B_)
+        lh = float(tg.step(qtr[sl].to(dev), ytr[sl].to(dev), ntr[sl].to(dev))["loss"])
+        lc = float(cpu.step(qtr[sl], ntr[sl], ytr[sl])[0])
+        worst = max(worst, abs(lh - lc) / max(abs(lc), 1e-30))
+    ph = torch.cat([tg.predict(qho[i:i + B_].to(dev), nho[i:i + B_].to(dev), vocab_size=V_).cpu() for i in range(0, held, B_)]).numpy()
+    with torch.no_grad():
+        x = torch_ref.l2_normalize(torch_ref.dequantize(qho), 2)
+        layers = [(cpu.P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l],
+                   cpu.P["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l]) for l in range(L_)]
+        pc = torch_ref.moe(torch_ref.lstm_model_state(x, nho, layers), cpu.P["gates/weights"], cpu.P["experts/weights"],
+                           cpu.P["experts/biases"], M_).numpy()
+    yh = yho.numpy().astype(np.float32)
+    gh, gc = eval_util.calculate_gap(ph, yh, 20), eval_util.calculate_gap(pc, yh, 20)
+    FLAGS.reset()
+    return {"gap_hip": gh, "gap_cpu_port": gc, "abs_diff": abs(gh - gc), "target": 0.001,
+            "within_target": bool(abs(gh - gc) < 1e-3 and gc > 0.05),          # ... of a model that LEARNED the shard (untrained: ~0.001)
+            "max_rel_loss_diff_while_training": worst, "max_abs_prediction_diff": float(np.abs(ph - pc).max()),
+            "config": "LstmModel %d x BasicLSTMCell(%d) over <= %d ragged uint8 frames (D=%d) + MoE head V=%d M=%d, %d steps x %d videos, "
+                      "base_learning_rate %g, held-out %d videos, same initial weights and batches" % (L_, H_, F_, D_, V_, M_, steps, B_, base_lr, held)}
+
+
 def _pick_threads(probe_fn, candidates=None):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best, best_t = None, None
@@ -920,6 +985,11 @@ def main():
             gap = gap_leg(dev)
             state = gap.pop("_state")
             note("gap leg done")
+            try:                                                      # the acceptance check on a frame-level model
+                gap["frame_twin_lstm"] = gap_twin_frames(dev)
+            except Exception as e:
+                gap["frame_twin_lstm"] = {"error": repr(e)}
+            note("frame_twin_lstm done")
             for key, kw in (("cpu_twin", {}),
                             # the same acceptance check at the FULL model size (D = 1152, V = 4716), continued from the leg's trained model
                             ("cpu_twin_full_size", dict(D_=D_IN, V_=VOCAB, M_=MIX, B_=256, steps=24, held=2048, state=state))):

@@ -88,21 +88,24 @@ def test_check_persist_errors_sees_an_early_launch(dev, flags, monkeypatch, nati
 
 
 # ---- headline backward at headline length ------------------------------------------------------------------
-def test_headline_recurrence_full_length_vs_fp64(dev):
-    """H = 1024, two layers, F = 300, B = 32 (two 16-row tiles per row group), ragged lengths incl. 0 and F, the product's own time
+@pytest.mark.parametrize("B,F", [(32, 300), (256, 24)])
+def test_headline_recurrence_full_length_vs_fp64(dev, B, F):
+    """(B = 256, F = 24: VERDICT r4 #8 -- the persistent-recurrence variants bench.py's per-GPU batch sweep runs, eight 32-row groups per
+    workgroup column, against fp64 on their own instead of only against the per-step kernels.)
+    H = 1024, two layers, F = 300, B = 32 (two 16-row tiles per row group), ragged lengths incl. 0 and F, the product's own time
     partition (one forward launch per layer, three backward parts -- NOT the test fixture's override): outputs, final states, dx
     and every weight / bias gradient against fp64 autograd of torch_ref.lstm_stack.  300 steps x 2 layers of dh feed-through:
     the tolerances are the F = 10 test's (test_gpu_round2.py::test_persistent_lstm_vs_fp64_oracle_full_width), i.e. no error
     growth with sequence length is tolerated beyond them."""
     from oracle import torch_ref
     from test_gpu_round2 import _stack_run
-    B, F, D, H = 32, 300, 128, 1024
+    D, H = 128, 1024
     if not L.lib().yt8m_lstm_persist_bwd_supported(B, H):
         pytest.skip("persistent recurrence not available on this device")
     assert seq_ops.PERSIST_FWD_CHUNKS == 1 and seq_ops.PERSIST_BWD_CHUNKS == 3, "this test must run the product's partition"
     rs = np.random.RandomState(12)
     nfh = rs.randint(1, F + 1, size=B).astype(np.int32)
-    nfh[:6] = [F, 0, 1, F, 299, 150]
+    nfh[:6] = [F, 0, 1, F, F - 1, F // 2]
     nf = torch.from_numpy(nfh).to(dev)
     res, grads, x64, P = _stack_run(dev, B, F, D, H, 2, 4, nf, True)
     xs = x64.transpose(0, 1).clone().requires_grad_(True)          # oracle takes [B,F,D]
