@@ -410,6 +410,66 @@ int yt8m_adam_multi(float* w, float* m, float* v, const float* g, const int32_t*
                     const float* l2, float gscale, const float* norms, float clip,
                     float lr_t, float beta1, float beta2, float eps, yt8m_stream_t stream);
 
+/* ---- Resident operand images of the weight matrices, kept current by the optimiser pass (csrc/wimg.hip, csrc/optim.hip; round 5).
+ * Replaces: the per-step re-split of every weight matrix in front of its products -- in the reference the variable is read by
+ * tf.matmul directly (W/all_video_models/moe_model.py:40-52, W/all_frame_models/lstm_model.py:34-47) and changes only in
+ * tf.train.AdamOptimizer.apply_gradients (W/train.py:459-466); here the operand image (yt8m_x3_split / yt8m_bf16_image format) is the
+ * form the matrix pipe reads, so it is rewritten exactly where the weight is.
+ *
+ * Registry (host side, process wide, thread safe): (src, R, C, ld, trans, planes, scale) -> image.  trans = 0: the image of
+ * src[R, C] as an [R rows, K = C] operand ("plain" of yt8m_x3_split); trans = 1: of its transpose ([C rows, K = R]).  planes = 3
+ * (x3 image) or 1 (bf16 image).  yt8m_gemm_auto_grouped, yt8m_lstm_stack_fwd / _bwd and the Python helpers look a weight operand up
+ * before splitting it; a miss falls back to the split they always did.  The OWNER of the source keeps the image valid: every write to
+ * the source goes through yt8m_adam_tiles(do_adam = 1) or is followed by yt8m_adam_tiles(do_adam = 0) before the next product, and
+ * yt8m_wimg_unregister covers the source's memory before it is released.
+ * Demand recording: yt8m_x3_split / yt8m_bf16_image note every (src, shape, orientation, planes, scale) they are asked for when src lies
+ * in a watched range (yt8m_wimg_watch), so the owner of a parameter arena learns which images a step of its model needs. */
+typedef struct yt8m_wimg_demand {
+  const float* src;
+  int64_t R, C, ld;
+  int32_t trans, planes;
+  float scale;
+  int32_t pad;
+} yt8m_wimg_demand;
+int yt8m_wimg_register(const float* src, int64_t R, int64_t C, int64_t ld, int trans, int planes, float scale, void* image);
+int64_t yt8m_wimg_unregister(const void* lo, const void* hi);      /* sources in [lo, hi); NULL, NULL: all.  Returns the number dropped */
+void* yt8m_wimg_lookup(const float* src, int64_t R, int64_t C, int64_t ld, int trans, int planes, float scale);   /* NULL: not resident */
+int64_t yt8m_wimg_count(void);
+int yt8m_wimg_watch(const void* lo, const void* hi, int on);       /* 1: note the demands on memory in [lo, hi); 0: stop + forget them */
+int yt8m_wimg_note_demand(const float* src, int64_t R, int64_t C, int64_t ld, int trans, int planes, float scale);
+int64_t yt8m_wimg_demands(yt8m_wimg_demand* out, int64_t max);      /* copies <= max entries, returns how many were recorded */
+/* One matrix of the parameter arena and the images it owns.  offset: floats from the arena base (w, m, v, g share it) to the
+ * row-major contiguous matrix [R, C]; tensor: its index into l2 / norms.  Each spec covers the row window [row0, row0 + rows)
+ * (row0 % 64 == 0; rows % 64 == 0 or the window ends with the matrix -- the input rows [0, Din) of an LSTM weight [Din + H, 4H]):
+ * plain = image of the window as an [rows, K = C] operand, trans = image of its transpose ([C rows, K = rows]); either may be NULL;
+ * every element times `scale`; planes 3 or 1.  tile_base is filled by yt8m_wimg_jobs_layout. */
+typedef struct yt8m_wimg_spec {
+  void* plain;
+  void* trans;
+  int64_t row0, rows;
+  float scale;
+  int32_t planes;
+} yt8m_wimg_spec;
+typedef struct yt8m_wimg_job {
+  int64_t offset;
+  int64_t R, C;
+  int32_t tensor;
+  int32_t nspec;                /* 0..4 (0: plain Adam on 64 x 64 tiles) */
+  int64_t tile_base;
+  yt8m_wimg_spec spec[4];
+} yt8m_wimg_job;
+int64_t yt8m_wimg_jobs_layout(yt8m_wimg_job* jobs_host, int64_t njobs);   /* validates, fills tile_base; returns total tiles (< 0: status) */
+/* clip + TF-Adam of the matrices jobs[0 .. njobs) (DEVICE copy of a laid-out array, or a sub-range of one: tile0 = tile_base of its
+ * first job, ntiles = the range's tile count) with the same per-element arithmetic as yt8m_adam_multi -- bitwise the same w, m, v --
+ * and, in the same pass, the images of every spec.  do_adam = 0: images only (first build, refresh after a host-side write).
+ * yt8m_adam_multi_ex = yt8m_adam_multi that leaves the tensors flagged in skip_tensor (device uint8[all tensors]) to this call. */
+int yt8m_adam_tiles(float* w, float* m, float* v, const float* g, const yt8m_wimg_job* jobs, int64_t njobs, int64_t tile0,
+                    int64_t ntiles, const float* l2, float gscale, const float* norms, float clip, float lr_t, float beta1,
+                    float beta2, float eps, int do_adam, yt8m_stream_t stream);
+int yt8m_adam_multi_ex(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
+                       const float* l2, float gscale, const float* norms, float clip, float lr_t, float beta1, float beta2,
+                       float eps, const uint8_t* skip_tensor, yt8m_stream_t stream);
+
 /* ---- BasicLSTMCell gate block (tf.contrib.rnn.BasicLSTMCell via W/all_frame_models/lstm_model.py:34-47)
  * z [B,4H] = pre-activations in the order i, j, f, o.  live[b] = (t < num_frames[b]) implements
  * dynamic_rnn's copy-through (Z/rnn_residual.py:61-188): dead rows keep (c,h) and emit out = 0.

@@ -30,6 +30,24 @@ class LstmStackDesc(ctypes.Structure):
                 ("forget_bias", c_float), ("fwd_chunks", ctypes.c_int32), ("bwd_chunks", ctypes.c_int32), ("need_dx", ctypes.c_int32)]
 
 
+class WimgDemand(ctypes.Structure):
+    """yt8m_wimg_demand (include/yt8m_hip.h)."""
+    _fields_ = [("src", c_void_p), ("R", c_int64), ("C", c_int64), ("ld", c_int64), ("trans", ctypes.c_int32), ("planes", ctypes.c_int32),
+                ("scale", c_float), ("pad", ctypes.c_int32)]
+
+
+class WimgSpec(ctypes.Structure):
+    """yt8m_wimg_spec (include/yt8m_hip.h)."""
+    _fields_ = [("plain", c_void_p), ("trans", c_void_p), ("row0", c_int64), ("rows", c_int64), ("scale", c_float),
+                ("planes", ctypes.c_int32)]
+
+
+class WimgJob(ctypes.Structure):
+    """yt8m_wimg_job (include/yt8m_hip.h)."""
+    _fields_ = [("offset", c_int64), ("R", c_int64), ("C", c_int64), ("tensor", ctypes.c_int32), ("nspec", ctypes.c_int32),
+                ("tile_base", c_int64), ("spec", WimgSpec * 4)]
+
+
 DESC = ctypes.POINTER(LstmStackDesc)
 PP = ctypes.POINTER(c_void_p)      # array of device pointers
 
@@ -222,6 +240,17 @@ SIGNATURES = {
     "yt8m_batchnorm_fwd": (c_int, [P, c_int64, c_int64, P, P, P, P, c_int, c_float, c_float, P, P, P, P]),
     "yt8m_batchnorm_workspace_bytes": (c_int64, [c_int64]),
     "yt8m_batchnorm_bwd": (c_int, [P, P, c_int64, c_int64, P, P, P, c_int, P, P, c_float, P, c_float, P, c_int64, P]),
+    "yt8m_wimg_register": (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int, c_float, P]),
+    "yt8m_wimg_unregister": (c_int64, [P, P]),
+    "yt8m_wimg_lookup": (c_void_p, [P, c_int64, c_int64, c_int64, c_int, c_int, c_float]),
+    "yt8m_wimg_count": (c_int64, []),
+    "yt8m_wimg_watch": (c_int, [P, P, c_int]),
+    "yt8m_wimg_note_demand": (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int, c_float]),
+    "yt8m_wimg_demands": (c_int64, [ctypes.POINTER(WimgDemand), c_int64]),
+    "yt8m_wimg_jobs_layout": (c_int64, [ctypes.POINTER(WimgJob), c_int64]),
+    "yt8m_adam_tiles": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float,
+                                c_int, P]),
+    "yt8m_adam_multi_ex": (c_int, [P, P, P, P, P, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float, P, P]),
     "yt8m_topk_rows": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
     "yt8m_perr_rows": (c_int, [P, P, c_int64, c_int64, P, P]),
 }

@@ -51,17 +51,25 @@ int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; };
 
+// operand image kept current by the optimiser pass (csrc/wimg.hip): no split, no scratch
+const void* resident(const void* src, int64_t R, int64_t C, int64_t ld, bool trans) {
+  return yt8m_wimg_lookup(static_cast<const float*>(src), R, C, ld, trans ? 1 : 0, 3, 1.0f);
+}
+
 }  // namespace
 
 extern "C" int yt8m_gemm_x3_pays(int64_t M, int64_t N, int64_t K) { return x3_pays(M, N, K) ? 1 : 0; }
 
 // bytes of image scratch with which every problem of the call that should run on the bf16 pipe does
 extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt8m_gemm_problem* probs) {
-  (void)transA; (void)transB;
   if (nprob < 1 || !probs) return 0;
   int64_t n = 0;
-  for (int i = 0; i < nprob; ++i)
-    if (x3_allowed(probs[i])) n += up256(yt8m_x3_image_bytes(probs[i].M, probs[i].K)) + up256(yt8m_x3_image_bytes(probs[i].N, probs[i].K));
+  for (int i = 0; i < nprob; ++i) {
+    const yt8m_gemm_problem& q = probs[i];
+    if (!x3_allowed(q)) continue;
+    if (!resident(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0)) n += up256(yt8m_x3_image_bytes(q.M, q.K));
+    if (!resident(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0)) n += up256(yt8m_x3_image_bytes(q.N, q.K));
+  }
   return n;
 }
 
@@ -77,20 +85,23 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
   std::vector<yt8m_gemm_problem> px, p32;
   uint64_t mask = 0;
   int64_t off = 0;
-  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, int64_t* at) -> bool {
+  char* const base = static_cast<char*>(image_scratch);
+  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, const void** at) -> bool {
+    if (const void* r = resident(src, R, C, ld, trans)) { *at = r; return true; }      // a weight matrix with a resident image
     for (const Img& m : imgs)
-      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans) { *at = m.off; return true; }
+      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans) { *at = base + m.off; return true; }
     const int64_t bytes = up256(trans ? yt8m_x3_image_bytes(C, R) : yt8m_x3_image_bytes(R, C));
     if (!image_scratch || off + bytes > image_scratch_bytes) return false;
     imgs.push_back({src, R, C, ld, trans, off});
-    *at = off;
+    *at = base + off;
     off += bytes;
     return true;
   };
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     bool x3 = q.M > 0 && q.N > 0 && x3_allowed(q) && q.A && q.B;
-    int64_t ia = 0, ib = 0;
+    const void* ia = nullptr;
+    const void* ib = nullptr;
     if (x3) {
       const int64_t mark = off;
       const size_t nimg = imgs.size();
@@ -101,8 +112,8 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
     }
     if (x3) {
       yt8m_gemm_problem t = q;
-      t.A = static_cast<char*>(image_scratch) + ia; t.lda = 0;
-      t.B = static_cast<char*>(image_scratch) + ib; t.ldb = 0;
+      t.A = ia; t.lda = 0;
+      t.B = ib; t.ldb = 0;
       px.push_back(t);
       mask |= 1ULL << i;
     } else {

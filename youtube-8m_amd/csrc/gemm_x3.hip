@@ -23,6 +23,7 @@
 // gemm_bf16.hip whose 12 reads feed 16 MFMAs), and the fragment fetch of the next step is interleaved with the products of the
 // current one.  Tile order and the float4 epilogue follow gemm_bf16.hip; the tiles of the last partial round are split along K.
 #include "common.h"
+#include "x3_image.h"
 #include <type_traits>
 #include <algorithm>
 #include <mutex>
@@ -34,7 +35,8 @@ constexpr int TM = 256, TN = 256;
 constexpr int PLANE_F = 256 * 8;                      // floats of one plane tile: 256 rows x 32 B
 constexpr int OP_F = 3 * PLANE_F;                     // one operand, three planes (24 KiB)
 constexpr int NST = 3;
-constexpr int RG_F = 256;                             // floats of one image block: 32 rows x 32 B (1 KiB)
+using yt8m_x3::RG_F;
+using yt8m_x3::store_block;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -877,42 +879,6 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
 }
 
 // ---- the split pass -----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned bf16_rn_bits(float x) {        // round to nearest even, finite x
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
-  h1 = bf16_rn_bits(x);
-  const float r1 = x - __uint_as_float(h1 << 16);                   // exact
-  h2 = bf16_rn_bits(r1);
-  const float r2 = r1 - __uint_as_float(h2 << 16);                  // exact
-  h3 = bf16_rn_bits(r2);
-  if ((__float_as_uint(x) & 0x7F800000u) == 0x7F800000u) {          // inf / nan stay in the leading term only
-    h1 = __float_as_uint(x) >> 16;
-    h2 = h3 = 0;
-  }
-}
-// 16 values of one K block of image row `row` -> its two 16-byte halves in each of the three plane blocks at dst (the block of
-// plane 0; half h sits in slot h ^ ((row >> 3) & 1))
-template <int NP = 3>
-__device__ __forceinline__ void store_block(const float (&v)[16], float* __restrict__ dst, int row) {
-  const int r = row & 31, sw = (r >> 3) & 1;
-  dst += r * 8;
-  unsigned h[3][16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) split3(v[j], h[0][j], h[1][j], h[2][j]);
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    uint4 lo, hi;
-    lo.x = h[p][0] | (h[p][1] << 16);  lo.y = h[p][2] | (h[p][3] << 16);
-    lo.z = h[p][4] | (h[p][5] << 16);  lo.w = h[p][6] | (h[p][7] << 16);
-    hi.x = h[p][8] | (h[p][9] << 16);  hi.y = h[p][10] | (h[p][11] << 16);
-    hi.z = h[p][12] | (h[p][13] << 16); hi.w = h[p][14] | (h[p][15] << 16);
-    *reinterpret_cast<uint4*>(dst + p * RG_F + 4 * sw) = lo;
-    *reinterpret_cast<uint4*>(dst + p * RG_F + 4 * (sw ^ 1)) = hi;
-  }
-}
-
 // src [R, Cc] fp32 (row stride ld), 64 x 64 tiles through LDS; plain image: rows = R, K = Cc; trans image: rows = Cc, K = R.
 // Either destination may be null.  scale multiplies every element before the split (1.0f: none).
 // rowscale / trans_s (both or neither): a second transposed image whose element (c, r) is rowscale[r] * scale * src[r][c] -- the
@@ -1011,6 +977,8 @@ extern "C" int yt8m_x3_split(const float* src, int64_t R, int64_t C, int64_t ld,
   YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans)) & 15) == 0, YT8M_E_BADARG,
                "x3 images must be 16-byte aligned");
   if (R == 0 || C == 0) return YT8M_OK;
+  if (plain) yt8m_wimg_note_demand(src, R, C, ld, 0, 3, scale);     // (only while the owner of a parameter arena records: wimg.hip)
+  if (trans) yt8m_wimg_note_demand(src, R, C, ld, 1, 3, scale);
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
@@ -1029,6 +997,8 @@ extern "C" int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t l
   YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans)) & 15) == 0, YT8M_E_BADARG,
                "images must be 16-byte aligned");
   if (R == 0 || C == 0) return YT8M_OK;
+  if (plain) yt8m_wimg_note_demand(src, R, C, ld, 0, 1, scale);     // (only while the owner of a parameter arena records: wimg.hip)
+  if (trans) yt8m_wimg_note_demand(src, R, C, ld, 1, 1, scale);
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));

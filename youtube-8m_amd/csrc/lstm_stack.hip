@@ -397,6 +397,7 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
   };
   hipEvent_t start = ev.record(main);
   for (int l = 0; l < P.L; ++l) ev.wait(S->rs[l], start);
+  const void* wxt_img[MAXL] = {nullptr};                   // image of W_x^T per layer: resident, or split into the scratch below
   // per layer, once: zero initial state, operand images of the input weights
   for (int l = 0; l < P.L; ++l) {
     hipStream_t s = S->rs[l];
@@ -406,10 +407,19 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
     if (l == 0 && P.u8) {
       RC(yt8m_u8_frames_image(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, 1e-12f, at<char>(scratch, P.qimg), nullptr,
                               at<float>(tape, P.rrow), s));
-      RC(split(W[0], D, H4, H4, U8_ALPHA, nullptr, at<char>(scratch, P.w3t), s));                  // (alpha W_x)^T: rows 4H, K = D
+      // (alpha W_x)^T: rows 4H, K = D -- resident when the optimiser pass keeps the weight's images current (csrc/wimg.hip)
+      wxt_img[0] = yt8m_wimg_lookup(W[0], D, H4, H4, 1, bf ? 1 : 3, U8_ALPHA);
+      if (!wxt_img[0]) {
+        RC(split(W[0], D, H4, H4, U8_ALPHA, nullptr, at<char>(scratch, P.w3t), s));
+        wxt_img[0] = at<char>(scratch, P.w3t);
+      }
       RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
     } else {
-      RC(split(W[l], Din, H4, H4, 1.0f, nullptr, at<char>(scratch, P.wxt3[l]), s));                 // W_x^T: rows 4H, K = Din
+      wxt_img[l] = yt8m_wimg_lookup(W[l], Din, H4, H4, 1, bf ? 1 : 3, 1.0f);                       // W_x^T: rows 4H, K = Din
+      if (!wxt_img[l]) {
+        RC(split(W[l], Din, H4, H4, 1.0f, nullptr, at<char>(scratch, P.wxt3[l]), s));
+        wxt_img[l] = at<char>(scratch, P.wxt3[l]);
+      }
     }
   }
   std::vector<hipEvent_t> done((size_t)P.L * P.nf, nullptr);
@@ -428,16 +438,16 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       if (chain_combine) yt8m_x3_set_combine(1);
       if (l == 0 && P.u8) {
         const char* qi = at<char>(scratch, P.qimg) + (t0 * B / 32) * (D / 16) * 1024;
-        const int prc = bf ? yt8m_gemm_b1_nt_ex(M, H4, D, qi, 0, at<char>(scratch, P.w3t), 0, zc, H4, b[0], 1.0f, at<float>(tape, P.rrow) + t0 * B,
+        const int prc = bf ? yt8m_gemm_b1_nt_ex(M, H4, D, qi, 0, wxt_img[0], 0, zc, H4, b[0], 1.0f, at<float>(tape, P.rrow) + t0 * B,
                                                 at<float>(scratch, P.wcs), U8_BETA, 0.f, gw, P.gws_bytes, s)
-                           : yt8m_gemm_x1x3_nt(M, H4, D, qi, at<char>(scratch, P.w3t), zc, H4, b[0], at<float>(tape, P.rrow) + t0 * B,
+                           : yt8m_gemm_x1x3_nt(M, H4, D, qi, wxt_img[0], zc, H4, b[0], at<float>(tape, P.rrow) + t0 * B,
                                                at<float>(scratch, P.wcs), U8_BETA, gw, P.gws_bytes, s);
         yt8m_x3_set_combine(0);
         RC(prc);
       } else {
         const float* src = l ? at<float>(tape, P.out[l - 1]) + t0 * B * H : static_cast<const float*>(x) + t0 * B * D;
         RC(split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
-        yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, at<char>(scratch, P.wxt3[l]), 0, zc, H4, b[l], 0.0f};
+        yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, wxt_img[l], 0, zc, H4, b[l], 0.0f};
         const int grc = bf ? yt8m_gemm_b1_nt_grouped(1, &pr, gw, P.gws_bytes, s) : yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
         yt8m_x3_set_combine(0);
         RC(grc);
@@ -513,6 +523,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   if (two_sw) ev.wait(S->sw2, ev.record(sw));              // layer 0's chain reads images made on sw
   int phase[MAXL];
   bool wx3_done[MAXL];
+  const void* wx_img[MAXL] = {nullptr};
   hipEvent_t dzT_free[MAXL] = {nullptr};
   const bool fused_img = P.img_rows > 0 && !dx_stream && !fuse_dz;
   int64_t img_done_rows[MAXL] = {0};                       // frame rows whose images the layer's launches have written so far
@@ -610,12 +621,16 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         if (!fused_img)
           RC(split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
         if (fused_t) rb = ev.record(sx);
-        if (!wx3_done[l]) {
-          RC(split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));              // W_x: rows Din, K = 4H
+        if (!wx3_done[l]) {                                  // W_x: rows Din, K = 4H (resident image, or split once per step)
+          wx_img[l] = yt8m_wimg_lookup(W[l], Din, H4, H4, 0, bf ? 1 : 3, 1.0f);
+          if (!wx_img[l]) {
+            RC(split(W[l], Din, H4, H4, 1.0f, at<char>(scratch, P.wx3[l]), nullptr, sx));
+            wx_img[l] = at<char>(scratch, P.wx3[l]);
+          }
           wx3_done[l] = true;
         }
         float* dst = l ? at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H : dx + t0 * B * D;
-        yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 0.0f};
+        yt8m_gemm_problem pr = {M, Din, H4, at<char>(scratch, P.dz3[l]), 0, wx_img[l], 0, dst, Din, nullptr, 0.0f};
         static const int chain_combine_b = knob("YT8M_STACK_CHAIN_COMBINE", 0);
         if (chain_combine_b) yt8m_x3_set_combine(1);
         const int grc = gemm(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx);

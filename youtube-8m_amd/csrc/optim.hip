@@ -6,6 +6,7 @@
 // workgroup streams it as 4 float4 per lane.  Reductions are fixed-order => bitwise reproducible, which
 // keeps data-parallel ranks identical after the gradient all-reduce.
 #include "common.h"
+#include "x3_image.h"
 
 namespace {
 
@@ -77,8 +78,9 @@ __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, flo
 __global__ __launch_bounds__(256) void adam_chunk_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                          const float* __restrict__ g, const int4* __restrict__ chunks,
                                                          const float* __restrict__ l2, const float* __restrict__ norms,
-                                                         const AdamHyper h) {
+                                                         const AdamHyper h, const uint8_t* __restrict__ skip) {
   const int4 ch = chunks[blockIdx.x];
+  if (skip && skip[ch.z]) return;                       // this tensor is updated by adam_tile_kernel (it owns operand images)
   const float l2c = l2[ch.z];
   float cs = 1.0f;
   if (h.clip > 0.f) cs = h.clip / fmaxf(sqrtf(norms[ch.z]), h.clip);
@@ -103,6 +105,111 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(float* __restrict__ w, 
       *reinterpret_cast<float4*>(vp + i) = vv;
     } else {
       for (int j = i; j < ch.y && j < i + 4; ++j) adam1(wp[j], mp[j], vp[j], gp[j], l2c, cs, h);
+    }
+  }
+}
+
+// ---- the same update as a 64 x 64 tile pass that also writes the matrix's operand images (round 5; see wimg.hip) --------------------
+// One workgroup per tile of a row-major contiguous matrix [R, C] at `offset` floats into the arenas.  ADAM: update w, m, v exactly as
+// adam_chunk_kernel does (same adam1, same operands: bitwise the same result); the updated tile stays in LDS and every image spec of
+// the job whose row window contains the tile gets its blocks: the plain image of rows [row0, row0 + rows) as an [rows, K = C] operand
+// and / or the transposed one ([C rows, K = rows]), three planes or one, times `scale`.  !ADAM: images only (first build / refresh
+// after a host-side write to the weights).  Window contract (checked by the host): row0 % 64 == 0 and (rows % 64 == 0 or the window
+// ends with the matrix), so a tile is wholly inside or wholly outside a window and rows beyond R are zeros in LDS.
+template <bool ADAM>
+__global__ __launch_bounds__(256) void adam_tile_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ g, const yt8m_wimg_job* __restrict__ jobs, int njobs,
+                                                        int64_t tile0, const float* __restrict__ l2, const float* __restrict__ norms,
+                                                        const AdamHyper h) {
+  __shared__ float T[64][65];
+  const int64_t tile = tile0 + blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && tile >= jobs[j + 1].tile_base) ++j;
+  const yt8m_wimg_job& J = jobs[j];
+  const int R = (int)J.R, C = (int)J.C;
+  const int tiles_c = (C + 63) >> 6;
+  const int lt = (int)(tile - J.tile_base);
+  const int ty = lt / tiles_c, tx = lt - ty * tiles_c;
+  const int r0 = ty * 64, c0 = tx * 64;
+  const int t = threadIdx.x;
+  float l2c = 0.f, cs = 1.0f;
+  if (ADAM) {
+    l2c = l2[J.tensor];
+    if (h.clip > 0.f) cs = h.clip / fmaxf(sqrtf(norms[J.tensor]), h.clip);
+  }
+  {
+    const int c4 = (t & 15) * 4, rr = t >> 4;
+    const bool vec = (C & 3) == 0;                                   // arena tensors start on 256-byte boundaries
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 16 * i;
+      float4 wv = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < R) {
+        const int64_t at = J.offset + (int64_t)(r0 + r) * C + c0 + c4;
+        if (vec && c0 + c4 + 3 < C) {
+          wv = *reinterpret_cast<const float4*>(w + at);
+          if (ADAM) {
+            float4 mv = *reinterpret_cast<const float4*>(m + at);
+            float4 vv = *reinterpret_cast<const float4*>(v + at);
+            const float4 gv = *reinterpret_cast<const float4*>(g + at);
+            adam1(wv.x, mv.x, vv.x, gv.x, l2c, cs, h);
+            adam1(wv.y, mv.y, vv.y, gv.y, l2c, cs, h);
+            adam1(wv.z, mv.z, vv.z, gv.z, l2c, cs, h);
+            adam1(wv.w, mv.w, vv.w, gv.w, l2c, cs, h);
+            *reinterpret_cast<float4*>(w + at) = wv;
+            *reinterpret_cast<float4*>(m + at) = mv;
+            *reinterpret_cast<float4*>(v + at) = vv;
+          }
+        } else {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (c0 + c4 + k < C) {
+              e[k] = w[at + k];
+              if (ADAM) {
+                float mk = m[at + k], vk = v[at + k];
+                adam1(e[k], mk, vk, g[at + k], l2c, cs, h);
+                w[at + k] = e[k]; m[at + k] = mk; v[at + k] = vk;
+              }
+            }
+          }
+          wv.x = e[0]; wv.y = e[1]; wv.z = e[2]; wv.w = e[3];
+        }
+      }
+      T[r][c4 + 0] = wv.x; T[r][c4 + 1] = wv.y; T[r][c4 + 2] = wv.z; T[r][c4 + 3] = wv.w;
+    }
+  }
+  __syncthreads();
+  const int a = t & 63, blk = t >> 6;                               // row of the image within the tile, K block within the tile
+  for (int si = 0; si < J.nspec; ++si) {
+    const yt8m_wimg_spec& S = J.spec[si];
+    const int w0 = (int)S.row0, wr = (int)S.rows;
+    if (r0 < w0 || r0 >= w0 + wr) continue;                         // tile outside this window (uniform per workgroup)
+    const float sc = S.scale;
+    const int NPF = S.planes * yt8m_x3::RG_F;
+    if (S.plain) {
+      const int KB = (C + 15) >> 4;
+      const int row = r0 - w0 + a, kb = (c0 >> 4) + blk;
+      if (row < ((wr + 31) & ~31) && kb < KB) {
+        float e[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e[k] = T[a][blk * 16 + k] * sc;
+        float* dst = static_cast<float*>(S.plain) + ((int64_t)(row >> 5) * KB + kb) * NPF;
+        if (S.planes == 3) yt8m_x3::store_block<3>(e, dst, row);
+        else yt8m_x3::store_block<1>(e, dst, row);
+      }
+    }
+    if (S.trans) {
+      const int KB = (wr + 15) >> 4;
+      const int row = c0 + a, kb = ((r0 - w0) >> 4) + blk;
+      if (row < ((C + 31) & ~31) && kb < KB) {
+        float e[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e[k] = T[blk * 16 + k][a] * sc;
+        float* dst = static_cast<float*>(S.trans) + ((int64_t)(row >> 5) * KB + kb) * NPF;
+        if (S.planes == 3) yt8m_x3::store_block<3>(e, dst, row);
+        else yt8m_x3::store_block<1>(e, dst, row);
+      }
     }
   }
 }
@@ -133,6 +240,14 @@ extern "C" int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* 
 extern "C" int yt8m_adam_multi(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
                                const float* l2, float gscale, const float* norms, float clip, float lr_t, float beta1,
                                float beta2, float eps, yt8m_stream_t stream) {
+  return yt8m_adam_multi_ex(w, m, v, g, chunks, nchunks, l2, gscale, norms, clip, lr_t, beta1, beta2, eps, nullptr, stream);
+}
+
+// skip_tensor (device uint8[all tensors], may be NULL): chunks of a flagged tensor are left alone -- its update belongs to
+// yt8m_adam_tiles, which also rewrites the tensor's operand images.
+extern "C" int yt8m_adam_multi_ex(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
+                                  const float* l2, float gscale, const float* norms, float clip, float lr_t, float beta1,
+                                  float beta2, float eps, const uint8_t* skip_tensor, yt8m_stream_t stream) {
   YT8M_REQUIRE(nchunks >= 0 && nchunks < (1LL << 31), YT8M_E_SHAPE, "bad chunk count");
   if (nchunks == 0) return YT8M_OK;
   YT8M_REQUIRE(w && m && v && g && chunks && l2, YT8M_E_BADARG, "null operand");
@@ -141,6 +256,55 @@ extern "C" int yt8m_adam_multi(float* w, float* m, float* v, const float* g, con
   ProfScope prof(F_OPTIM, s);
   AdamHyper h{gscale, clip, lr_t, beta1, beta2, eps};
   hipLaunchKernelGGL(adam_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, w, m, v, g,
-                     reinterpret_cast<const int4*>(chunks), l2, norms, h);
+                     reinterpret_cast<const int4*>(chunks), l2, norms, h, skip_tensor);
   return launch_status("adam_chunk_kernel");
+}
+
+// Fills tile_base of a HOST job array (cumulative 64 x 64 tile counts) and validates it; returns the total number of tiles or a
+// negative status.  The caller uploads the array and hands the device copy to yt8m_adam_tiles.
+extern "C" int64_t yt8m_wimg_jobs_layout(yt8m_wimg_job* jobs, int64_t njobs) {
+  YT8M_REQUIRE(jobs && njobs >= 1 && njobs <= 4096, YT8M_E_BADARG, "1..4096 jobs");
+  int64_t tiles = 0;
+  for (int64_t j = 0; j < njobs; ++j) {
+    yt8m_wimg_job& J = jobs[j];
+    YT8M_REQUIRE(J.R >= 1 && J.C >= 1 && J.R < (1LL << 31) && J.C < (1LL << 31) && J.offset >= 0 && (J.offset & 3) == 0, YT8M_E_SHAPE,
+                 "bad matrix");
+    YT8M_REQUIRE(J.nspec >= 0 && J.nspec <= 4 && J.tensor >= 0, YT8M_E_BADARG, "0..4 image specs per job");
+    for (int i = 0; i < J.nspec; ++i) {
+      const yt8m_wimg_spec& S = J.spec[i];
+      YT8M_REQUIRE(S.planes == 1 || S.planes == 3, YT8M_E_BADARG, "planes must be 1 or 3");
+      YT8M_REQUIRE(S.plain || S.trans, YT8M_E_BADARG, "a spec needs an image");
+      YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(S.plain) | reinterpret_cast<uintptr_t>(S.trans)) & 15) == 0, YT8M_E_BADARG,
+                   "images must be 16-byte aligned");
+      YT8M_REQUIRE(S.row0 >= 0 && S.rows >= 1 && S.row0 + S.rows <= J.R && (S.row0 & 63) == 0 &&
+                       ((S.rows & 63) == 0 || S.row0 + S.rows == J.R), YT8M_E_SHAPE,
+                   "row window must start on a 64-row tile and end on one or with the matrix");
+    }
+    J.tile_base = tiles;
+    tiles += ((J.R + 63) / 64) * ((J.C + 63) / 64);
+  }
+  YT8M_REQUIRE(tiles < (1LL << 31), YT8M_E_SHAPE, "too many tiles");
+  return tiles;
+}
+
+// Adam (do_adam != 0) + operand images of the matrices jobs[0 .. njobs) (DEVICE array laid out by yt8m_wimg_jobs_layout; a sub-range
+// of a larger array is fine: tile0 = tile_base of its first job, ntiles = the range's tile count).  Hyper-parameters as yt8m_adam_multi.
+// do_adam == 0: images only, the arenas are not written (m, v, g, l2, norms may be NULL).
+extern "C" int yt8m_adam_tiles(float* w, float* m, float* v, const float* g, const yt8m_wimg_job* jobs, int64_t njobs, int64_t tile0,
+                               int64_t ntiles, const float* l2, float gscale, const float* norms, float clip, float lr_t, float beta1,
+                               float beta2, float eps, int do_adam, yt8m_stream_t stream) {
+  YT8M_REQUIRE(njobs >= 0 && ntiles >= 0 && ntiles < (1LL << 31) && tile0 >= 0, YT8M_E_SHAPE, "bad job / tile count");
+  if (njobs == 0 || ntiles == 0) return YT8M_OK;
+  YT8M_REQUIRE(w && jobs, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(!do_adam || (m && v && g && l2), YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(!do_adam || clip <= 0.f || norms, YT8M_E_BADARG, "clip > 0 needs norms");
+  YT8M_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0, YT8M_E_BADARG, "arena must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_OPTIM, s);
+  AdamHyper h{gscale, clip, lr_t, beta1, beta2, eps};
+  if (do_adam)
+    hipLaunchKernelGGL(adam_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, w, m, v, g, jobs, (int)njobs, tile0, l2, norms, h);
+  else
+    hipLaunchKernelGGL(adam_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, w, m, v, g, jobs, (int)njobs, tile0, l2, norms, h);
+  return launch_status("adam_tile_kernel");
 }

@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import _lib
+from . import wimg as _wimg
 from .flags import FLAGS, DEFINE_string
 from .variables import get_default_graph
 
@@ -251,10 +252,21 @@ def x3_split(x, plain=True, trans=False, scale=1.0):
     _dev(x)
     x, ld = _rowmajor2d(x)
     R, C = x.shape
-    ip = _x3_empty(R, C, x.device) if plain else None
-    it = _x3_empty(C, R, x.device) if trans else None
-    _lib.check(_lib.lib().yt8m_x3_split(_p(x), R, C, ld, float(scale), _p(ip.buf) if ip else None, _p(it.buf) if it else None,
-                                        _stream()))
+    ip = it = None
+    if plain:                                                # a weight matrix whose image the optimiser pass keeps current (wimg.py)
+        r = _wimg.resident_image(x, R, C, ld, 0, 3, scale)
+        ip = X3Image(r[0], R, C) if r else None
+    if trans:
+        r = _wimg.resident_image(x, R, C, ld, 1, 3, scale)
+        it = X3Image(r[0], C, R) if r else None
+    mk_p, mk_t = plain and ip is None, trans and it is None
+    if mk_p:
+        ip = _x3_empty(R, C, x.device)
+    if mk_t:
+        it = _x3_empty(C, R, x.device)
+    if mk_p or mk_t:
+        _lib.check(_lib.lib().yt8m_x3_split(_p(x), R, C, ld, float(scale), _p(ip.buf) if mk_p else None, _p(it.buf) if mk_t else None,
+                                            _stream()))
     return ip, it
 
 
@@ -312,9 +324,21 @@ def bf16_image(x, transpose=False, both=False):
     R, C = x.shape
     lib = _lib.lib()
     mk = lambda rows, K: X3Image(torch.empty(max(lib.yt8m_x3_image_bytes(rows, K) // 3, 16), dtype=torch.uint8, device=x.device), rows, K)
-    ip = mk(R, C) if (both or not transpose) else None
-    it = mk(C, R) if (both or transpose) else None
-    _lib.check(lib.yt8m_bf16_image(_p(x), R, C, ld, 1.0, _p(ip.buf) if ip else None, _p(it.buf) if it else None, _stream()))
+    want_p, want_t = both or not transpose, both or transpose
+    ip = it = None
+    if want_p:                                               # resident one-plane image of a weight matrix (wimg.py)
+        r = _wimg.resident_image(x, R, C, ld, 0, 1)
+        ip = X3Image(r[0], R, C) if r else None
+    if want_t:
+        r = _wimg.resident_image(x, R, C, ld, 1, 1)
+        it = X3Image(r[0], C, R) if r else None
+    mk_p, mk_t = want_p and ip is None, want_t and it is None
+    if mk_p:
+        ip = mk(R, C)
+    if mk_t:
+        it = mk(C, R)
+    if mk_p or mk_t:
+        _lib.check(lib.yt8m_bf16_image(_p(x), R, C, ld, 1.0, _p(ip.buf) if mk_p else None, _p(it.buf) if mk_t else None, _stream()))
     return (ip, it) if both else (it if transpose else ip)
 
 
@@ -618,8 +642,15 @@ def sqnorm_and_adam(graph, lr_t, gscale=1.0, clip=1.0, beta1=0.9, beta2=0.999, e
     if clip > 0:
         _lib.check(L.yt8m_sqnorm_multi(_p(graph.params), _p(graph.grads), chunks, c1 - c0, _p(graph.l2), gscale, partial,
                                        _p(graph.norms), lo, hi - lo, _p(graph.chunk_start_dev), c0, s))
-    _lib.check(L.yt8m_adam_multi(_p(graph.params), _p(graph.adam_m), _p(graph.adam_v), _p(graph.grads), chunks, c1 - c0,
-                                 _p(graph.l2), gscale, _p(graph.norms), clip, lr_t, beta1, beta2, eps, s))
+    wi = getattr(graph, "wimg", None)
+    tiles = wi is not None and wi.active
+    # tensors that own operand images are updated by the tile pass, which rewrites the images where it rewrites the weight
+    # (csrc/optim.hip adam_tile_kernel: bitwise the chunk kernel's arithmetic); the chunk pass leaves them alone
+    _lib.check(L.yt8m_adam_multi_ex(_p(graph.params), _p(graph.adam_m), _p(graph.adam_v), _p(graph.grads), chunks, c1 - c0,
+                                    _p(graph.l2), gscale, _p(graph.norms), clip, lr_t, beta1, beta2, eps,
+                                    _p(wi.skip_dev) if tiles else None, s))
+    if tiles:
+        wi.adam(lo, hi, (gscale, clip, lr_t, beta1, beta2, eps), s)
 
 
 # ------------------------------------------------------------------------------------------ autograd ops

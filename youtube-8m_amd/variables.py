@@ -111,6 +111,12 @@ class Graph(object):
         self.chunks = self.l2 = self.norms = self.partial = None
         self.total = 0
         self.nchunks = 0
+        self.wimg = None               # wimg.WeightImages after finalize(): operand images of the weight matrices, kept by Adam
+
+    def __del__(self):
+        w = getattr(self, "wimg", None)
+        if w is not None:
+            w.close()                  # the library's lookup table must not outlive the arena it points into
 
     # -- scoping --------------------------------------------------------------------------------------
     @contextlib.contextmanager
@@ -136,6 +142,8 @@ class Graph(object):
             v._uses = 0
         if self.token is None:
             self.token = torch.zeros((), dtype=torch.float32, device=self.device, requires_grad=True)
+        if self.wimg is not None:
+            self.wimg.begin_step()     # new demands -> resident images; torch-side write to the arena -> refresh
 
     def next_random_seed(self):
         """64-bit Philox key of the next random op (dropout / noise) of this forward pass."""
@@ -213,6 +221,9 @@ class Graph(object):
         self.norms = torch.zeros(max(len(tv), 1), dtype=torch.float32, device=dev)
         self.partial = torch.zeros(max(self.nchunks, 1), dtype=torch.float32, device=dev)
         self.finalized = True
+        if self.params.is_cuda:
+            from .wimg import WeightImages
+            self.wimg = WeightImages(self)
 
     # -- checkpoint-style access (TF variable names -> arrays) -----------------------------------------
     def state_dict(self):
