@@ -714,6 +714,10 @@ int yt8m_vlad_finish_q_bwd(const float* agg, const float* n_in, const float* cen
  * nsplit = 1: single f16 operand (the reduced-precision variant, ~5e-4 relative on the weights).
  * Supported when yt8m_netvlad_supported() != 0 (K == 64, D % 64 == 0); workspace from yt8m_netvlad_workspace_bytes(). */
 int yt8m_netvlad_supported(int64_t B, int64_t F, int64_t D, int64_t K);
+/* 1 when yt8m_netvlad_fwd_u8 takes the single-pass form for this shape (one workgroup per video: assignment, softmax and aggregation in
+ * one launch, the frames read from HBM once; K = 64, D % 128 == 0, D <= 1152, F <= 320), 0 when it runs the rows + cols pair. */
+int yt8m_netvlad_single_pass(int64_t B, int64_t F, int64_t D, int64_t K);
+int yt8m_netvlad_set_single(int mode);      /* -1: YT8M_NETVLAD_SINGLE / default (on); 0: always the pair; 1: single pass where covered (A/B, tests) */
 int64_t yt8m_netvlad_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t K);
 int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, const float* Wc, const float* bc, int64_t B,
                         int64_t F, int64_t D, int64_t K, int nsplit, float eps, float* cT_out, float* n_out,

@@ -173,3 +173,47 @@ def test_lstm_model_with_resident_images_is_bitwise_the_run_that_resplits(dev, f
     w0, w1 = ("RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l for l in range(2))
     alpha = float(np.float32(4.0 / 255.0))
     assert (w0, 0, 64, 1, 3, alpha) in on[3] and (w1, 0, 256, 1, 3, 1.0) in on[3] and (w1, 0, 256, 0, 3, 1.0) in on[3], on[3]
+
+
+# ---- single-pass NetVLAD forward (csrc/netvlad_fused.hip vlad_video_kernel) ---------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 300, 1152), (5, 50, 128), (2, 37, 1024), (4, 320, 1152), (6, 1, 256), (3, 33, 384)])
+@pytest.mark.parametrize("nsplit", [2, 1])
+def test_netvlad_single_pass_equals_the_rows_cols_pair(dev, shape, nsplit):
+    """One workgroup per video (assignment GEMM, softmax, aggregation GEMM in ONE launch, the frames read from HBM once) against the
+    two-kernel pair on the same inputs: cT is the same arithmetic bit for bit (same fragments, same summation order over the
+    64-feature blocks, same epilogue), n and agg differ only by summation order / the per-video instead of per-batch f16 scale of c
+    -- fp32-grade either way.  Shapes: the headline one, a partial last 32-frame step, D = 1024 (8 groups per wave), F = 320 (every
+    LDS step in use), a single frame, D = 384.  (The oracle comparison of whichever form is the default: test_gpu_kernels.py::
+    test_netvlad_fused_u8, which runs the single-pass kernel wherever it covers the shape.)"""
+    import yt8m_amd.seq_ops as seq_ops
+    lib = L.lib()
+    B, F, Dm = shape
+    K = 64
+    rs = np.random.RandomState(F * 7 + Dm)
+    q = rs.randint(0, 256, size=(B, F, Dm)).astype(np.uint8)
+    q[0, 0] = 0
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0] = F
+    if B > 2:
+        nf[1], nf[2] = 1, 0
+    Wc = torch.from_numpy((rs.randn(Dm, K) * 3.0 / np.sqrt(Dm)).astype(np.float32)).to(dev)
+    bc = torch.from_numpy((rs.randn(K) * 0.5).astype(np.float32)).to(dev)
+    qd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev)
+    try:
+        L.check(lib.yt8m_netvlad_set_single(1))
+        assert lib.yt8m_netvlad_single_pass(B, F, Dm, K) == 1
+        c1, n1, a1 = seq_ops.netvlad_fwd_u8(qd, nfd, Wc, bc, nsplit=nsplit)
+        c1b, n1b, a1b = seq_ops.netvlad_fwd_u8(qd, nfd, Wc, bc, nsplit=nsplit)
+        L.check(lib.yt8m_netvlad_set_single(0))
+        assert lib.yt8m_netvlad_single_pass(B, F, Dm, K) == 0
+        c0, n0, a0 = seq_ops.netvlad_fwd_u8(qd, nfd, Wc, bc, nsplit=nsplit)
+    finally:
+        L.check(lib.yt8m_netvlad_set_single(-1))
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c1b) and torch.equal(n1, n1b) and torch.equal(a1, a1b)        # deterministic
+    assert torch.equal(c1, c0)
+    assert float((n1 - n0).abs().max()) <= 1e-5 * max(1.0, float(n0.abs().max()))
+    tol = 2e-6 if nsplit == 2 else 3e-3
+    assert float((a1 - a0).abs().max()) <= tol * max(1.0, float(a0.abs().max()))
+    if B > 2:
+        assert float(a1[2].abs().max()) == 0.0 and float(c1[2].abs().max()) == 0.0        # a video without frames

@@ -196,6 +196,8 @@ SIGNATURES = {
     "yt8m_softmax_rows_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_softmax_rows_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "yt8m_netvlad_supported": (c_int, [c_int64, c_int64, c_int64, c_int64]),
+    "yt8m_netvlad_single_pass": (c_int, [c_int64, c_int64, c_int64, c_int64]),
+    "yt8m_netvlad_set_single": (c_int, [c_int]),
     "yt8m_netvlad_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int64]),
     "yt8m_netvlad_fwd_u8": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_float, P, P, P, P, c_int64, P]),
     "yt8m_netvlad_bwd_u8": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_float, P, c_float, P, c_float,

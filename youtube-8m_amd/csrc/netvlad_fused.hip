@@ -30,6 +30,7 @@
 //                 operands stream through a 3-stage LDS-DMA ring with counted s_waitcnt vmcnt.
 // Bound: HBM (345.6 KB of uint8 per video against 44 MFLOP per GEMM = 128 FLOP/B, below the f16 ridge of 312 FLOP/B).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <algorithm>
 
@@ -591,6 +592,353 @@ __global__ __launch_bounds__(256) void vlad_cols_kernel(ColsArgs g) {
     }
 }
 
+// ---- single-pass forward: ONE workgroup owns a video (round 5) ----------------------------
+// The rows + cols pair reads the frames twice from HBM and round-trips the assignment through it.  Here a 512-thread workgroup (8
+// waves, one workgroup per CU: the LDS is its working set) does both GEMMs of a video in one launch:
+//   phase 1  s = x W_c + b_c, a = softmax_k(s) [f < num_frames]: the video's frames stream HBM -> LDS by LDS-DMA in 64-feature blocks
+//            (384 frame rows x 64 B, 16-byte chunks swizzled so that the fragment fetch is conflict-free) next to the packed W block
+//            (L2 -> LDS, fragment order), three stages with counted vmcnt; wave w owns the row tiles w, w + 8, w + 16.  The
+//            softmax epilogue is the rows kernel's (DPP row reductions); c = a r goes to cT (the backward reads it) AND stays in LDS
+//            ([64 clusters][320 frames] fp32, 80 KB) -- it never comes back from memory.
+//   phase 2  agg[k, :] = sum_f c[k, f] x[f, :]: the video's own 346 KB of frames again, now from L2 / Infinity Cache (this CU read
+//            them microseconds ago), 32 frames x D bytes per step through a two-stage LDS-DMA ring; wave (ct = w >> 1, fh = w & 1)
+//            keeps its 16 clusters x D / 2 features of agg in registers (9 groups x 4 tiles x 4 = 144) for the whole video: the
+//            frames are passed over ONCE for the aggregation too (the cols kernel needs three 384-feature slices).
+// HBM sees: the frames once, cT + agg written once, the packed weights from L2.  Outputs and their meaning are exactly those of the
+// rows + cols pair (the f16 scale of c is per video here, a power of two either way), so the finishing kernels and the backward are
+// unchanged.  Cover: K = 64, D % 128 == 0, D <= 1152, F <= 320 (else the pair runs).
+struct VideoArgs {
+  const uint8_t* q;        // [B,F,D]
+  const int32_t* nf;       // [B] or null
+  const _Float16* Wp;      // packed W_c (vlad_pack_kernel<false>)
+  const float* cs;         // [64] column sums of the packed weights
+  const float* wscale;     // [1]
+  const float* bias;       // [64]
+  float* cT;               // [B,64,Fp]  a * r
+  float* n_out;            // [B,64]     sum_f a
+  float* agg;              // [B,64,D]
+  int B, F, D, Fp;
+  float eps;
+};
+
+constexpr int VF = 320;                        // frames of the LDS assignment buffer (10 steps of 32)
+constexpr int VROWS = 384;                     // frame rows of a phase-1 block: 8 waves x 3 tiles x 16
+constexpr int VC_PITCH = VF * 4;               // bytes per cluster row of the assignment buffer
+constexpr int VRING = 2 * 32 * 1152;           // phase-2 ring (two stages of 32 frames x <= 1152 B) = 73728: phase 1's 3 stages alias it and c
+constexpr int VGMAX = 9;                       // 64-feature groups per wave in phase 2 (D / 128)
+
+// where (cluster row, frame f) of c lives in the LDS buffer: the 128-byte step of odd rows swaps with its neighbour and the 16-byte
+// chunks are XOR-swizzled so that the A-fragment fetch (16 rows x 8 chunks per ds_read_b128 group) touches 16 distinct slots
+__device__ __forceinline__ uint32_t vc_addr(int row, int f) {
+  const int s = f >> 5, chunk = (f >> 2) & 7;
+  const int sig = ((row >> 1) & 1) | (row & 4);
+  return (uint32_t)(row * VC_PITCH + ((s ^ (row & 1)) << 7) + ((chunk ^ sig) << 4) + ((f & 3) << 2));
+}
+// phase-1 frame block: row r holds its four 16-byte chunks at positions chunk ^ g[(r >> 2) & 3], g = {0, 2, 3, 1}
+__device__ __forceinline__ int vq_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // {0, 2, 3, 1} in 2-bit fields
+
+template <int NSPLIT>
+__global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
+  constexpr int WB = 8192 * NSPLIT;                                  // packed W block (64 features)
+  constexpr int QB1 = VROWS * 64;                                    // phase-1 frame block (24 KB)
+  constexpr int ST1 = QB1 + WB;
+  constexpr int PER1 = 3 + NSPLIT;                                   // DMA instructions per thread and phase-1 stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [ring | c buffer | reduction scratch]
+  char* const cbuf = smem + VRING;
+  float (*red)[NK + 1] = reinterpret_cast<float (*)[NK + 1]>(smem + VRING + NK * VC_PITCH);
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m = lane & 15, kg = lane >> 4;
+  const int nblk = g.D >> 6;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((AS3 char*)smem);
+  const int wave_off = (tid & ~63) * 16;
+  const uint8_t* qv = g.q + (int64_t)b * g.F * g.D;
+
+  // ---- phase 1 ------------------------------------------------------------------------------------------------------------------
+  // DMA slots of this thread: three 16-byte chunks of the frame block (LDS position idx -> frame row idx / 4, chunk slot idx % 4)
+  const uint8_t* qsrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 512 * i, row = idx >> 2, slot = idx & 3;
+    const int f = row < g.F ? row : g.F - 1;                          // rows beyond the video only feed outputs never stored
+    qsrc[i] = qv + (int64_t)f * g.D + 16 * (slot ^ vq_swz(row));
+  }
+  const char* wsrc = reinterpret_cast<const char*>(g.Wp) + tid * 16;
+  auto issue1 = [&](int j, int stage) {
+    char* st = smem + stage * ST1 + wave_off;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dma16(qsrc[i] + 64 * j, st + i * 8192);
+#pragma unroll
+    for (int i = 0; i < NSPLIT; ++i) dma16(wsrc + (int64_t)j * WB + i * 8192, st + QB1 + i * 8192);
+  };
+  uint32_t afrag[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int row = 16 * (w + 8 * t) + m;
+    afrag[t] = lds0 + (uint32_t)(row * 64 + ((kg ^ vq_swz(row)) << 4));
+  }
+  const uint32_t wfrag = lds0 + (uint32_t)QB1 + (uint32_t)lane * 16u;
+
+  f4 acc[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = (f4){0.f, 0.f, 0.f, 0.f};
+  uint32_t s1[3], s2[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) s1[t] = s2[t] = 0u;
+
+  issue1(0, 0);
+  if (nblk > 1) issue1(1, 1);
+  for (int j = 0, st = 0; j < nblk; ++j) {
+    if (j + 1 < nblk) wait_vmcnt<PER1>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                                     // stage j landed for every wave; stage j - 1 is free again
+    if (j + 2 < nblk) issue1(j + 2, st >= 1 ? st - 1 : 2);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t so = (uint32_t)(st * ST1);
+    u4 qc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(qc[t]) : "v"(afrag[t] + so) : "memory");
+#pragma unroll
+    for (int t = 0; t < 3; ++t) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qc[t]) : : "memory");
+    h8 af[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t d0 = qc[t][2 * ks], d1 = qc[t][2 * ks + 1];
+        u4 av;
+        av[0] = __builtin_amdgcn_perm(0x64646464u, d0, 0x04010400u);      // [0x64 b1 | 0x64 b0] = f16 (1024+b1, 1024+b0)
+        av[1] = __builtin_amdgcn_perm(0x64646464u, d0, 0x04030402u);
+        av[2] = __builtin_amdgcn_perm(0x64646464u, d1, 0x04010400u);
+        av[3] = __builtin_amdgcn_perm(0x64646464u, d1, 0x04030402u);
+        af[t][ks] = __builtin_bit_cast(h8, av) - (_Float16)1152.0f;       // (1024 + q) - 1152 = q - 128, exact
+        s1[t] = __builtin_amdgcn_udot4(d0, 0x01010101u, s1[t], false);
+        s1[t] = __builtin_amdgcn_udot4(d1, 0x01010101u, s1[t], false);
+        s2[t] = __builtin_amdgcn_udot4(d0, d0, s2[t], false);
+        s2[t] = __builtin_amdgcn_udot4(d1, d1, s2[t], false);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h8 bf[4][NSPLIT];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp) bf[ct][sp] = lds_read_h8(wfrag + so + (uint32_t)(((ks * 4 + ct) * NSPLIT + sp) * 1024));
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[ct][sp]) : : "memory");
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int sp = 0; sp < NSPLIT; ++sp)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t][ks], bf[ct][sp], acc[t][ct], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    st = st == 2 ? 0 : st + 1;
+  }
+  __syncthreads();                                                    // the ring is free: phase 2's first frames can start flying
+
+  // ---- phase 2 DMA plumbing (step 0 is issued before the softmax epilogue and lands while it runs) -------------------------------
+  const int Dc = g.D >> 4;                                            // 16-byte chunks per frame row
+  const int SB2 = 32 * g.D;                                           // bytes of a phase-2 stage
+  const int rounds2 = (2 * g.D + 511) >> 9;                           // DMA instructions per thread and stage (the last may cover
+  const int steps = g.Fp >> 5;                                        // only the first waves: 2 D chunks, a multiple of 256)
+  int r2[5], c2[5];                                                   // this thread's DMA slots of a stage: frame row, source chunk
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int idx = tid + 512 * i;
+    const int r = idx / Dc, pc = idx - r * Dc;
+    int c = pc - 4 * (r >> 3);                                        // the rotation that spreads the kg groups over the banks
+    r2[i] = idx < 2 * g.D ? r : -1;                                   // (wave-uniform: 2 D % 64 == 0)
+    c2[i] = 16 * (c < 0 ? c + Dc : c);
+  }
+  (void)rounds2;
+  auto issue2 = [&](int s, int stage) {
+    char* st = smem + stage * SB2 + wave_off;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (r2[i] >= 0) {
+        int f = 32 * s + r2[i];
+        f = f < g.F ? f : g.F - 1;                                    // padded frames carry c = 0
+        dma16(qv + (int64_t)f * g.D + c2[i], st + i * 8192);
+      }
+    }
+  };
+  if (steps > 0) issue2(0, 0);
+
+  // ---- phase-1 epilogue: softmax over the 64 clusters, c = a r -> cT and the LDS buffer, n = sum_f a -----------------------------
+  float ssq[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    uint32_t a1 = s1[t], a2 = s2[t];
+    a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+    a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+    ssq[t] = fmaxf((DQ_A * DQ_A) * (float)a2 + (2.0f * DQ_A * DQ_B) * (float)a1 + (float)g.D * (DQ_B * DQ_B), g.eps);
+  }
+  const float SW = g.wscale[0];
+  const float A1 = DQ_A / SW;
+  const int n = m;
+  float cb[4], bs[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    cb[ct] = DQ_C * g.cs[16 * ct + n];
+    bs[ct] = g.bias[16 * ct + n];
+  }
+  const int nfb = g.nf ? min(max(g.nf[b], 0), g.F) : g.F;
+  float vmax = 0.f;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int fb = 16 * (w + 8 * t) + 4 * kg;                         // first of this lane's 4 result frames
+    f4 ov[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = fb + i;
+      const float ss = __shfl(ssq[t], 4 * kg + i, 64);
+      const float r = rsqrtf(ss);
+      float v[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) v[ct] = r * (A1 * acc[t][ct][i] + cb[ct]) + bs[ct];
+      const float mx = grp16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      float e[4], sum = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) { e[ct] = __expf(v[ct] - mx); sum += e[ct]; }
+      sum = grp16_sum(sum);
+      const float inv = f < nfb ? 1.0f / sum : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float av = e[ct] * inv;
+        csum[ct] += av;
+        ov[ct][i] = av * r;
+        vmax = fmaxf(vmax, av * r);
+      }
+    }
+    if (fb < VF) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        *reinterpret_cast<f4*>(cbuf + vc_addr(16 * ct + n, fb)) = ov[ct];
+        if (fb < g.Fp) *reinterpret_cast<f4*>(g.cT + ((int64_t)b * NK + 16 * ct + n) * g.Fp + fb) = ov[ct];
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    float t = csum[ct];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (kg == 0) red[w][16 * ct + n] = t;
+  }
+  vmax = wave_max(vmax);
+  if (lane == 0) red[w][NK] = vmax;
+  __syncthreads();                                                    // c buffer + partial sums complete
+  if (tid < NK) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][tid];
+    g.n_out[(int64_t)b * NK + tid] = t;
+  }
+  float vm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) vm = fmaxf(vm, red[i][NK]);
+  const float S = pow2_scale(vm);                                     // |c| * S < 2^12: both f16 parts stay normal
+
+  // ---- phase 2 ------------------------------------------------------------------------------------------------------------------
+  const int ct2 = w >> 1, fh = w & 1;
+  const int G = g.D >> 7;                                             // 64-feature groups of this wave's half
+  uint32_t cfrag[2];
+  {
+    const int row = 16 * ct2 + n;
+    const int sig = ((row >> 1) & 1) | (row & 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) cfrag[h] = lds0 + (uint32_t)(VRING + row * VC_PITCH + (((2 * kg + h) ^ sig) << 4));
+  }
+  const int crow1 = (16 * ct2 + n) & 1;
+  f4 acc2[VGMAX][4], acc1 = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int gq = 0; gq < VGMAX; ++gq)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[gq][t] = (f4){0.f, 0.f, 0.f, 0.f};
+  u4 onesv = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+  const h8 ones = __builtin_bit_cast(h8, onesv);
+  // byte address (inside a stage) of this lane's dword of group gq in frame row 8 kg: chunk 4 (G fh + gq) + n / 4, rotated by 4 kg
+  const uint32_t qrow0 = (uint32_t)(8 * kg * g.D + (n & 3) * 4);
+
+  for (int s = 0; s < steps; ++s) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                                     // step s landed for every wave, and every wave is done with
+    if (s + 1 < steps) issue2(s + 1, (s + 1) & 1);                    // step s - 1: its stage takes step s + 1 while s is consumed
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t so = lds0 + (uint32_t)((s & 1) * SB2);
+    f4 cr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) cr[h] = lds_read_f4(cfrag[h] + (uint32_t)(((s ^ crow1)) << 7));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cr[h]) : : "memory");
+    h8 af2[NSPLIT];
+    {
+      h8 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = cr[i >> 2][i & 3] * S;
+        hi[i] = (_Float16)x;
+        lo[i] = (_Float16)(x - (float)hi[i]);
+      }
+      af2[0] = hi;
+      if (NSPLIT == 2) af2[NSPLIT - 1] = lo;
+    }
+#pragma unroll
+    for (int sp = 0; sp < NSPLIT; ++sp) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2[sp], ones, acc1, 0, 0, 0);
+#pragma unroll
+    for (int gq = 0; gq < VGMAX; ++gq) {
+      if (gq < G) {
+        int pc = 4 * (G * fh + gq) + (n >> 2) + 4 * kg;
+        pc = pc >= Dc ? pc - Dc : pc;
+        const uint32_t qa = so + qrow0 + (uint32_t)(pc << 4);
+        uint32_t qr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qr[i] = lds_read_u32(qa + (uint32_t)(i * g.D));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qr[i]) : : "memory");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t sel = 0x0c040c00u + (uint32_t)t * 0x00010001u;     // [0, S0.byte t, 0, S1.byte t]
+          u4 bv;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) bv[p] = __builtin_amdgcn_perm(qr[2 * p + 1], qr[2 * p], sel) | BIAS2;
+          const h8 bq = __builtin_bit_cast(h8, bv) - (_Float16)1152.0f;
+#pragma unroll
+          for (int sp = 0; sp < NSPLIT; ++sp) acc2[gq][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af2[sp], bq, acc2[gq][t], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // agg[k, d] = sum_f c x = (alpha / S) acc + ((beta + 128 alpha) / S) m1,  m1 = sum_f (scaled, rounded) c
+  const float A2 = DQ_A / S, CB = DQ_C / S;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = 16 * ct2 + 4 * kg + i;
+    const float corr = CB * acc1[i];
+    float* orow = g.agg + ((int64_t)b * NK + k) * g.D + (int64_t)G * 64 * fh + 4 * n;
+#pragma unroll
+    for (int gq = 0; gq < VGMAX; ++gq) {
+      if (gq < G) {
+        f4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = A2 * acc2[gq][t][i] + corr;
+        *reinterpret_cast<f4*>(orow + 64 * gq) = o;
+      }
+    }
+  }
+}
+
 // first level of the dW reduction: out[r][k][d] = sum over groups g = r, r + RED2, ... of part[g][k][d]  (fixed order)
 constexpr int RED2 = 16;
 __global__ __launch_bounds__(256) void vlad_part_reduce_kernel(const float* __restrict__ part, int groups, int64_t n,
@@ -748,6 +1096,20 @@ extern "C" int yt8m_netvlad_supported(int64_t B, int64_t F, int64_t D, int64_t K
   return (K == NK && D >= 64 && (D % 64) == 0 && B >= 1 && F >= 1 && B <= 65535 && F * D < (int64_t)1 << 31) ? 1 : 0;
 }
 
+// 1 when yt8m_netvlad_fwd_u8 runs the single-pass kernel (one workgroup per video: vlad_video_kernel) for this shape, 0 when it runs
+// the rows + cols pair.  Knob YT8M_NETVLAD_SINGLE=0 keeps the pair everywhere (A/B).
+static std::atomic<int> g_single_mode{-1};
+extern "C" int yt8m_netvlad_set_single(int mode) {               // -1: environment / default (on), 0: rows + cols pair, 1: single pass
+  g_single_mode.store(mode < 0 ? -1 : (mode ? 1 : 0));
+  return YT8M_OK;
+}
+extern "C" int yt8m_netvlad_single_pass(int64_t B, int64_t F, int64_t D, int64_t K) {
+  static const int env = getenv("YT8M_NETVLAD_SINGLE") ? atoi(getenv("YT8M_NETVLAD_SINGLE")) : 1;
+  const int mode = g_single_mode.load();
+  const int on = mode < 0 ? env : mode;
+  return (on != 0 && yt8m_netvlad_supported(B, F, D, K) && (D % 128) == 0 && D <= 1152 && F <= VF) ? 1 : 0;
+}
+
 extern "C" int64_t yt8m_netvlad_workspace_bytes(int64_t B, int64_t F, int64_t D, int64_t K) {
   if (!yt8m_netvlad_supported(B, F, D, K)) return 0;
   return make_layout(B, F, D).total;
@@ -779,11 +1141,27 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   float* wgmax = reinterpret_cast<float*>(ws + L.o_wgmax);
   float* cssum = reinterpret_cast<float*>(ws + L.o_cssum);
   hipLaunchKernelGGL(vlad_cs_sum_kernel, dim3(1), dim3(256), 0, s, cs, (int)L.nblk, (int64_t)NK, cssum);
+  const double qbytes = (double)B * (double)F * (double)D, ctbytes = (double)B * NK * (double)L.Fp * 4.0;
+  if (yt8m_netvlad_single_pass(B, F, D, K)) {                      // one workgroup per video, the frames read from HBM once
+    VideoArgs va;
+    va.q = q; va.nf = num_frames; va.Wp = Wp; va.cs = cssum; va.wscale = scale; va.bias = bc; va.cT = cT; va.n_out = n_out;
+    va.agg = agg_out; va.B = (int)B; va.F = (int)F; va.D = (int)D; va.Fp = (int)L.Fp; va.eps = eps;
+    const int lds = VRING + NK * VC_PITCH + 8 * (NK + 1) * (int)sizeof(float);
+    // SURVEY.md 8(d) bytes: the uint8 frames once + the parameters (the packed W_c)
+    ProfScope pv(F_VLAD_ROWS, s, 4.0 * qbytes * NK, qbytes + (double)L.nblk * 4096 * 2 * nsplit);
+    if (nsplit == 2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_video_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(vlad_video_kernel<2>, dim3((unsigned)B), dim3(512), lds, s, va);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_video_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(vlad_video_kernel<1>, dim3((unsigned)B), dim3(512), lds, s, va);
+    }
+    return launch_status("yt8m_netvlad_fwd_u8 (single pass)");
+  }
   RowsArgs ra;
   ra.q = q; ra.nf = num_frames; ra.Wp = Wp; ra.wp_bstride = 0; ra.cs = cssum; ra.cs_bstride = 0; ra.wscale = scale;
   ra.wscale_bstride = 0; ra.bias = bc; ra.bias_bstride = 0; ra.cfw = nullptr; ra.outT = cT; ra.wgmax = wgmax; ra.colpart = colpart;
   ra.B = (int)B; ra.F = (int)F; ra.D = (int)D; ra.Fp = (int)L.Fp; ra.eps = eps;
-  const double qbytes = (double)B * (double)F * (double)D, ctbytes = (double)B * NK * (double)L.Fp * 4.0;
   {                                                              // algorithmic bytes: the frames once + the transposed assignment
     ProfScope pr(F_VLAD_ROWS, s, 2.0 * qbytes * NK, qbytes + ctbytes + (double)L.nblk * 4096 * 2 * nsplit);
     if (nsplit == 2) launch_rows<2, false>(ra, L.nt, L.ranges, s);
