@@ -21,7 +21,10 @@ enum yt8m_status { YT8M_OK = 0, YT8M_E_BADARG = -1, YT8M_E_SHAPE = -2, YT8M_E_HI
 enum yt8m_label_dtype { YT8M_LABEL_U8 = 0, YT8M_LABEL_F32 = 1 };
 
 /* 2 since round 3: persistent-recurrence workspaces begin with a sticky error word the host zeroes once (yt8m_lstm_persist_status
- * reads AND clears it), the image GEMMs read yt8m_gemm_problem.lda / ldb as K-block strides.  A host must check it. */
+ * reads AND clears it), the image GEMMs read yt8m_gemm_problem.lda / ldb as K-block strides.
+ * 3 since round 5: yt8m_lstm_stack_desc.input_u8 is a bit field (bit 1 selects bf16 operand images: a truthy 2 from an older host
+ * would change behaviour), yt8m_gemm_auto_grouped / yt8m_lstm_stack_* consult the resident weight-image table (yt8m_wimg_*).
+ * A host must check it. */
 int yt8m_abi_version(void);
 const char* yt8m_last_error(void);
 /* name of the gfx target the device code was built for ("gfx950") */
@@ -602,7 +605,9 @@ int yt8m_lstm_persist_bwd_images(const float* gates, const float* Wh, int64_t ld
 typedef struct yt8m_lstm_stack_desc {
   int64_t B, F, D, H;     /* videos, frames, input features, cells per layer */
   int32_t L;              /* layers, 1..8 */
-  int32_t input_u8;       /* 1: x = raw uint8 [B,F,D] (batch-major, as the reader hands it over); 0: float [F,B,D] (time-major) */
+  int32_t input_u8;       /* BIT FIELD.  bit 0: x = raw uint8 [B,F,D] (batch-major, as the reader hands it over); clear: float [F,B,D]
+                           * (time-major).  bit 1 (ABI >= 3): the hoisted products take ONE-plane bf16 operand images (the
+                           * --compute_dtype=bfloat16 variant).  A host written against ABI 2 passes 0 / 1 only. */
   float forget_bias;
   int32_t fwd_chunks;     /* time partition of the forward pass; 0 = the library's (1: one persistent launch per layer) */
   int32_t bwd_chunks;     /* ... of the backward pass; 0 = the library's (3 parts) */
@@ -634,14 +639,45 @@ int yt8m_lstm_stack_status(const yt8m_lstm_stack_desc* desc, void* scratch, yt8m
  * device are final -- layer L-1 first, a whole last time part of weight-gradient work before layer 0.  A data-parallel host starts
  * each layer's gradient all-reduce from this point instead of the end of the call (W/train.py:624-639 averages the tower
  * gradients after the whole backward pass). */
+int yt8m_lstm_stack_layer_done_wait(int layer, yt8m_stream_t stream);
 /* One-shot host callback of the calling thread's next yt8m_lstm_stack_bwd, invoked right after its first backward recurrence is
  * enqueued, with the library's weight-gradient stream: what the callback enqueues there runs while that recurrence holds half the
- * chip and the stream has nothing else to do yet.  TrainGraph.step uses it to clip + Adam-update the variables whose gradients are
- * final before the recurrent stack's backward pass starts (W/train.py:461-466 applies all gradients after the whole backward pass;
- * the arithmetic per variable is the same, only its place in the step moves).  hook == NULL clears. */
+ * chip and the stream has nothing else to do yet.  hook == NULL clears.  (The training step's own use of this window -- clip + Adam
+ * of the variables whose gradients are already final -- no longer needs a callback: yt8m_lstm_stack_set_early_optimizer.) */
 typedef void (*yt8m_stream_hook)(void* user, yt8m_stream_t stream);
 int yt8m_lstm_stack_set_prep_hook(yt8m_stream_hook hook, void* user);
-int yt8m_lstm_stack_layer_done_wait(int layer, yt8m_stream_t stream);
+/* clip + TF-Adam of tensor RANGES of a flat parameter arena (the arguments of yt8m_sqnorm_multi / yt8m_adam_multi_ex / yt8m_adam_tiles
+ * for the whole arena, plus the ranges): W/train.py:459-466 applied to the variables lo .. hi-1 of every range.  tensor_chunk_start
+ * comes twice (device for the kernels, host for the launch arithmetic); jobs / job_tensor_host / job_tile_base_host describe the
+ * image-owning matrices (yt8m_wimg_jobs_layout; njobs = 0: none).
+ *   yt8m_optimizer_ranges: enqueues the passes on `stream` -- what a host's end-of-step pass calls.
+ *   yt8m_lstm_stack_set_early_optimizer: the SAME passes, enqueued by the calling thread's next yt8m_lstm_stack_bwd itself on its
+ *     weight-gradient stream right after its first backward recurrence (the window the prep hook describes): the variables whose
+ *     gradients are final before the recurrent stack's backward pass starts (LstmModel: the MoE head, 85 % of the parameters) are
+ *     updated while that recurrence holds half the chip.  The descriptor is copied; NULL clears; consumed by one call.  W/train.py
+ *     applies all gradients after the whole backward pass; the arithmetic per variable is the same, only its place in the step moves. */
+typedef struct yt8m_opt_ranges {
+  float* w;
+  float* m;
+  float* v;
+  const float* g;
+  const int32_t* chunks;                  /* device int32[nchunks * 4]: the whole chunk table */
+  const int32_t* tensor_chunk_start;      /* device int32[ntensors + 1] */
+  const int32_t* tensor_chunk_start_host; /* host copy */
+  const float* l2;                        /* device float[ntensors] */
+  float* partial;                         /* device float[nchunks] */
+  float* norms;                           /* device float[ntensors] */
+  const uint8_t* skip_tensor;             /* device uint8[ntensors] or NULL: tensors updated by the tile pass (image owners) */
+  const yt8m_wimg_job* jobs;              /* device, laid out; NULL when njobs == 0 */
+  const int32_t* job_tensor_host;         /* host int32[njobs]: tensor index of job j, ascending */
+  const int64_t* job_tile_base_host;      /* host int64[njobs + 1] */
+  int32_t njobs;
+  int32_t nranges;                        /* 1..8 */
+  int32_t range_lo[8], range_hi[8];
+  float gscale, clip, lr_t, beta1, beta2, eps;
+} yt8m_opt_ranges;
+int yt8m_optimizer_ranges(const yt8m_opt_ranges* opt, yt8m_stream_t stream);
+int yt8m_lstm_stack_set_early_optimizer(const yt8m_opt_ranges* opt);
 
 /* Time-range forms of the same recurrence: steps [t0, t0+T) of a layer (backward: t0+T-1 down to t0), with the
  * re-packed recurrent weights owned by the caller (yt8m_lstm_pack; yt8m_lstm_packed_floats() floats each for the forward

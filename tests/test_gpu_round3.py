@@ -306,7 +306,8 @@ def test_native_stack_equals_the_python_orchestration(dev, monkeypatch, B, F, D,
 def test_full_lstm_model_step_through_the_c_abi_only(dev, flags):
     """One complete training step of LstmModel (uint8 frames -> recurrent stack -> MoE head + CrossEntropyLoss -> backward -> clip
     + Adam) driven through ctypes calls into libyt8m_hip.so ONLY: yt8m_lstm_stack_fwd, yt8m_moe_fwd, yt8m_moe_bwd,
-    yt8m_lstm_stack_bwd, yt8m_sqnorm_multi, yt8m_adam_multi.  torch is the device allocator (plus one concatenation / split of the
+    yt8m_lstm_stack_bwd (with the head's early optimiser pass handed over as a descriptor: yt8m_lstm_stack_set_early_optimizer) and
+    yt8m_optimizer_ranges.  torch is the device allocator (plus one concatenation / split of the
     [c0|h0|c1|h1] state, pure data movement); the Graph object only lends its flat parameter / gradient / Adam arenas and chunk table.
     Result: the same updated parameters as TrainGraph.step of the Python host from the same initial weights."""
     import math
@@ -339,54 +340,79 @@ def test_full_lstm_model_step_through_the_c_abi_only(dev, flags):
     want = g0.params.detach().clone()
     ref_p, ref_loss = ref["predictions"].clone(), float(ref["loss"])
 
-    g, tg = fresh()                                            # arenas + chunk table only from here on
-    load(g)
-    g.begin_step()
-    cell = lambda l, n: g.vars["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/%s" % (l, n)]
-    Wg, We, be = g.vars["gates/weights"], g.vars["experts/weights"], g.vars["experts/biases"]
-    desc = L.LstmStackDesc(B, F, D, H, NL, 1, 1.0, 0, 0, 0)
-    assert lib.yt8m_lstm_stack_supported(ctypes.byref(desc)), lib.yt8m_last_error()
-    tape = torch.empty(lib.yt8m_lstm_stack_tape_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
-    scratch = torch.zeros(lib.yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
-    ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
-    Wp, bp = ptrs([cell(l, "weights").data for l in range(NL)]), ptrs([cell(l, "biases").data for l in range(NL)])
-    L.check(lib.yt8m_lstm_stack_fwd(ctypes.byref(desc), _p(q), _p(nf), Wp, bp, _p(tape), tape.numel(), _p(scratch), scratch.numel(), _stream()))
-    finals = []
-    for l in range(NL):
-        for which in (1, 2):                                   # c_l, h_l
-            finals.append(seq_ops._tape_view(lib, desc, tape, l, which, (B, H)))
-    state = torch.cat(finals, dim=1).contiguous()              # [c0|h0|c1|h1]  (W/all_frame_models/lstm_model.py:52-57)
-    S = state.shape[1]
-    Zg = torch.empty((B, V * (M + 1)), device=dev)
-    Ze = torch.empty((B, V * M), device=dev)
-    p = torch.empty((B, V), device=dev)
-    loss = torch.zeros((1,), device=dev)
-    yu8 = y.to(torch.uint8).contiguous()
-    nws = lib.yt8m_moe_workspace_bytes_ex(B, S, V, M)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    L.check(lib.yt8m_moe_fwd(_p(state), _p(Wg.data), _p(We.data), _p(be.data), _p(yu8), 0, B, S, V, M, 1e-5, _p(Zg), _p(Ze), _p(p), _p(loss),
-                             _p(ws), nws, _stream()))
-    assert float((p - ref_p).abs().max()) < 1e-6 and abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
-    dstate = torch.empty_like(state)
-    L.check(lib.yt8m_moe_bwd(_p(state), _p(Wg.data), _p(We.data), _p(Zg), _p(Ze), _p(yu8), 0, B, S, V, M, 1e-5, 1.0, _p(Wg.grad), _p(We.grad),
-                             _p(be.grad), 0.0, _p(dstate), _p(ws), nws, _stream()))
-    parts = [dstate[:, k * H:(k + 1) * H].contiguous() for k in range(2 * NL)]
-    dcs, dhs = ptrs(parts[0::2]), ptrs(parts[1::2])
-    dW, db = ptrs([cell(l, "weights").grad for l in range(NL)]), ptrs([cell(l, "biases").grad for l in range(NL)])
-    zero = (ctypes.c_float * NL)(*([0.0] * NL))
-    L.check(lib.yt8m_lstm_stack_bwd(ctypes.byref(desc), _p(q), _p(nf), Wp, _p(tape), tape.numel(), _p(scratch), scratch.numel(), None, dcs, dhs,
-                                    dW, db, zero, zero, None, _stream()))
-    L.check(lib.yt8m_lstm_stack_status(ctypes.byref(desc), _p(scratch), _stream()))
-    lr = 0.01                                                  # --base_learning_rate, first step: no decay yet
-    lr_t = lr * math.sqrt(1.0 - 0.999) / (1.0 - 0.9)
-    assert abs(float(ref["learning_rate"]) - lr) < 1e-12
-    nT = len(g.trainable_variables())
-    L.check(lib.yt8m_sqnorm_multi(_p(g.params), _p(g.grads), _p(g.chunks), g.nchunks, _p(g.l2), 1.0, _p(g.partial), _p(g.norms), 0, nT,
-                                  _p(g.chunk_start_dev), 0, _stream()))
-    L.check(lib.yt8m_adam_multi(_p(g.params), _p(g.adam_m), _p(g.adam_v), _p(g.grads), _p(g.chunks), g.nchunks, _p(g.l2), 1.0, _p(g.norms),
-                                float(tg.clip), lr_t, 0.9, 0.999, 1e-8, _stream()))
-    torch.cuda.synchronize()
-    err = float((g.params - want).abs().max())
+    def cabi_step(early):
+        g, tg = fresh()                                        # arenas + chunk table only from here on
+        load(g)
+        g.begin_step()
+        cell = lambda l, n: g.vars["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/%s" % (l, n)]
+        Wg, We, be = g.vars["gates/weights"], g.vars["experts/weights"], g.vars["experts/biases"]
+        desc = L.LstmStackDesc(B, F, D, H, NL, 1, 1.0, 0, 0, 0)
+        assert lib.yt8m_lstm_stack_supported(ctypes.byref(desc)), lib.yt8m_last_error()
+        tape = torch.empty(lib.yt8m_lstm_stack_tape_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+        scratch = torch.zeros(lib.yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+        ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        Wp, bp = ptrs([cell(l, "weights").data for l in range(NL)]), ptrs([cell(l, "biases").data for l in range(NL)])
+        L.check(lib.yt8m_lstm_stack_fwd(ctypes.byref(desc), _p(q), _p(nf), Wp, bp, _p(tape), tape.numel(), _p(scratch), scratch.numel(), _stream()))
+        finals = []
+        for l in range(NL):
+            for which in (1, 2):                               # c_l, h_l
+                finals.append(seq_ops._tape_view(lib, desc, tape, l, which, (B, H)))
+        state = torch.cat(finals, dim=1).contiguous()          # [c0|h0|c1|h1]  (W/all_frame_models/lstm_model.py:52-57)
+        S = state.shape[1]
+        Zg = torch.empty((B, V * (M + 1)), device=dev)
+        Ze = torch.empty((B, V * M), device=dev)
+        p = torch.empty((B, V), device=dev)
+        loss = torch.zeros((1,), device=dev)
+        yu8 = y.to(torch.uint8).contiguous()
+        nws = lib.yt8m_moe_workspace_bytes_ex(B, S, V, M)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        L.check(lib.yt8m_moe_fwd(_p(state), _p(Wg.data), _p(We.data), _p(be.data), _p(yu8), 0, B, S, V, M, 1e-5, _p(Zg), _p(Ze), _p(p), _p(loss),
+                                 _p(ws), nws, _stream()))
+        assert float((p - ref_p).abs().max()) < 1e-6 and abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+        dstate = torch.empty_like(state)
+        L.check(lib.yt8m_moe_bwd(_p(state), _p(Wg.data), _p(We.data), _p(Zg), _p(Ze), _p(yu8), 0, B, S, V, M, 1e-5, 1.0, _p(Wg.grad), _p(We.grad),
+                                 _p(be.grad), 0.0, _p(dstate), _p(ws), nws, _stream()))
+        parts = [dstate[:, k * H:(k + 1) * H].contiguous() for k in range(2 * NL)]
+        dcs, dhs = ptrs(parts[0::2]), ptrs(parts[1::2])
+        dW, db = ptrs([cell(l, "weights").grad for l in range(NL)]), ptrs([cell(l, "biases").grad for l in range(NL)])
+        zero = (ctypes.c_float * NL)(*([0.0] * NL))
+        lr = 0.01                                              # --base_learning_rate, first step: no decay yet
+        lr_t = lr * math.sqrt(1.0 - 0.999) / (1.0 - 0.9)
+        assert abs(float(ref["learning_rate"]) - lr) < 1e-12
+        nT = len(g.trainable_variables())
+        # the optimiser pass as ONE descriptor (yt8m_opt_ranges): the head's variables -- final before the recurrent stack's backward
+        # pass starts -- are updated by yt8m_lstm_stack_bwd itself in its idle window (yt8m_lstm_stack_set_early_optimizer), the rest
+        # by yt8m_optimizer_ranges at the end; early = False: everything at the end.  Same kernels, same numbers: bitwise equal.
+        tcs = (ctypes.c_int32 * len(g.chunk_start))(*g.chunk_start)
+
+        def ranges(rs_):
+            o = L.OptRanges()
+            o.w, o.m, o.v, o.g = g.params.data_ptr(), g.adam_m.data_ptr(), g.adam_v.data_ptr(), g.grads.data_ptr()
+            o.chunks, o.tensor_chunk_start = g.chunks.data_ptr(), g.chunk_start_dev.data_ptr()
+            o.tensor_chunk_start_host = ctypes.cast(tcs, ctypes.c_void_p)
+            o.l2, o.partial, o.norms = g.l2.data_ptr(), g.partial.data_ptr(), g.norms.data_ptr()
+            o.nranges = len(rs_)
+            for i, (lo, hi) in enumerate(rs_):
+                o.range_lo[i], o.range_hi[i] = lo, hi
+            o.gscale, o.clip, o.lr_t, o.beta1, o.beta2, o.eps = 1.0, float(tg.clip), lr_t, 0.9, 0.999, 1e-8
+            return o
+
+        head = sorted(v.index for v in (Wg, We, be))
+        assert head == list(range(head[0], head[0] + 3))
+        rest = [(lo, hi) for lo, hi in ((0, head[0]), (head[-1] + 1, nT)) if hi > lo]
+        if early:
+            L.check(lib.yt8m_lstm_stack_set_early_optimizer(ctypes.byref(ranges([(head[0], head[-1] + 1)]))))
+        L.check(lib.yt8m_lstm_stack_bwd(ctypes.byref(desc), _p(q), _p(nf), Wp, _p(tape), tape.numel(), _p(scratch), scratch.numel(), None, dcs, dhs,
+                                        dW, db, zero, zero, None, _stream()))
+        L.check(lib.yt8m_lstm_stack_status(ctypes.byref(desc), _p(scratch), _stream()))
+        L.check(lib.yt8m_optimizer_ranges(ctypes.byref(ranges(rest if early else [(0, nT)])), _stream()))
+        torch.cuda.synchronize()
+        return g.params.detach().clone(), g.adam_m.detach().clone()
+
+    got_e, m_e = cabi_step(True)
+    got_l, m_l = cabi_step(False)
+    assert torch.equal(got_e, got_l) and torch.equal(m_e, m_l)  # the early pass is the same arithmetic, moved
+    err = float((got_e - want).abs().max())
     assert err <= 1e-6 * max(1.0, float(want.abs().max())), err
 
 

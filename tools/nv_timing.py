@@ -18,3 +18,6 @@ for B in (1024,):
         torch.cuda.synchronize()
         print("B", B, "nsplit", nsplit, "loop cycles mean %.0f min %.0f max %.0f | epilogue mean %.0f min %.0f max %.0f"
               % (n[:, 0].mean(), n[:, 0].min(), n[:, 0].max(), n[:, 1].mean(), n[:, 1].min(), n[:, 1].max()))
+        # single-pass kernel (vlad_video_kernel): phase 1 / its epilogue / phase 2 / store tail (100 MHz s_memtime ticks -> see the ratio)
+        print("   video kernel sections: " + " | ".join("%s mean %.0f max %.0f" % (k, n[:, i].mean(), n[:, i].max())
+                                                         for i, k in enumerate(("phase1", "epilogue1", "phase2", "tail"))))

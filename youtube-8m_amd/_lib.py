@@ -48,6 +48,15 @@ class WimgJob(ctypes.Structure):
                 ("tile_base", c_int64), ("spec", WimgSpec * 4)]
 
 
+class OptRanges(ctypes.Structure):
+    """yt8m_opt_ranges (include/yt8m_hip.h)."""
+    _fields_ = [("w", c_void_p), ("m", c_void_p), ("v", c_void_p), ("g", c_void_p), ("chunks", c_void_p), ("tensor_chunk_start", c_void_p),
+                ("tensor_chunk_start_host", c_void_p), ("l2", c_void_p), ("partial", c_void_p), ("norms", c_void_p), ("skip_tensor", c_void_p),
+                ("jobs", c_void_p), ("job_tensor_host", c_void_p), ("job_tile_base_host", c_void_p), ("njobs", ctypes.c_int32),
+                ("nranges", ctypes.c_int32), ("range_lo", ctypes.c_int32 * 8), ("range_hi", ctypes.c_int32 * 8), ("gscale", c_float),
+                ("clip", c_float), ("lr_t", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float)]
+
+
 DESC = ctypes.POINTER(LstmStackDesc)
 PP = ctypes.POINTER(c_void_p)      # array of device pointers
 
@@ -253,12 +262,14 @@ SIGNATURES = {
     "yt8m_adam_tiles": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float,
                                 c_int, P]),
     "yt8m_adam_multi_ex": (c_int, [P, P, P, P, P, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float, P, P]),
+    "yt8m_optimizer_ranges": (c_int, [ctypes.POINTER(OptRanges), P]),
+    "yt8m_lstm_stack_set_early_optimizer": (c_int, [ctypes.POINTER(OptRanges)]),
     "yt8m_topk_rows": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
     "yt8m_perr_rows": (c_int, [P, P, c_int64, c_int64, P, P]),
 }
 
 # The ABI this host binds (include/yt8m_hip.h, yt8m_abi_version): workspace layouts and argument meanings, not just symbols.
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -21,6 +21,7 @@
 //             layer 0 on uint8 frames: dW_x += alpha ((q - 128)^T . (r (.) dz) + (beta / alpha) colsum(r (.) dz))   (x1x3: three
 //             products instead of six, and the fp32 time-major copy of the frames the round-2 path kept for it is gone).
 #include <stdlib.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -218,6 +219,14 @@ DevState g_dev[16];
 // One-shot host callback of the NEXT yt8m_lstm_stack_bwd call of this thread (yt8m_lstm_stack_set_prep_hook).
 thread_local yt8m_stream_hook g_prep_hook = nullptr;
 thread_local void* g_prep_user = nullptr;
+// ... and its early optimiser pass (yt8m_lstm_stack_set_early_optimizer): the descriptor and the host tables it points to, copied
+struct EarlyOpt {
+  bool set = false;
+  yt8m_opt_ranges o;
+  std::vector<int32_t> tcs, job_tensor;
+  std::vector<int64_t> tile_base;
+};
+thread_local EarlyOpt g_early;
 
 int high_stream(DevState& S, hipStream_t* s) {
   if (*s) return YT8M_OK;
@@ -372,6 +381,33 @@ extern "C" int yt8m_lstm_stack_set_prep_hook(yt8m_stream_hook hook, void* user) 
   return YT8M_OK;
 }
 
+// clip + Adam of the tensor ranges in `opt` enqueued by the calling thread's NEXT yt8m_lstm_stack_bwd on its weight-gradient stream,
+// right after its first backward recurrence (see the hook above for the window).  Copies the descriptor and its host tables.
+extern "C" int yt8m_lstm_stack_set_early_optimizer(const yt8m_opt_ranges* opt) {
+  g_early.set = false;
+  if (!opt) return YT8M_OK;
+  YT8M_REQUIRE(opt->nranges >= 1 && opt->nranges <= 8 && opt->tensor_chunk_start_host, YT8M_E_BADARG, "1..8 ranges + the host chunk starts");
+  int hi = 0;
+  for (int r = 0; r < opt->nranges; ++r) {
+    YT8M_REQUIRE(opt->range_lo[r] >= 0 && opt->range_hi[r] >= opt->range_lo[r], YT8M_E_BADARG, "bad tensor range");
+    hi = std::max(hi, (int)opt->range_hi[r]);
+  }
+  YT8M_REQUIRE(opt->njobs >= 0 && (opt->njobs == 0 || (opt->job_tensor_host && opt->job_tile_base_host)), YT8M_E_BADARG, "job tables");
+  g_early.o = *opt;
+  g_early.tcs.assign(opt->tensor_chunk_start_host, opt->tensor_chunk_start_host + hi + 1);
+  g_early.o.tensor_chunk_start_host = g_early.tcs.data();
+  g_early.job_tensor.clear();
+  g_early.tile_base.clear();
+  if (opt->njobs) {
+    g_early.job_tensor.assign(opt->job_tensor_host, opt->job_tensor_host + opt->njobs);
+    g_early.tile_base.assign(opt->job_tile_base_host, opt->job_tile_base_host + opt->njobs + 1);
+    g_early.o.job_tensor_host = g_early.job_tensor.data();
+    g_early.o.job_tile_base_host = g_early.tile_base.data();
+  }
+  g_early.set = true;
+  return YT8M_OK;
+}
+
 extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void* x, const int32_t* num_frames, const float* const* W,
                                    const float* const* b, void* tape, int64_t tape_bytes, void* scratch, int64_t scratch_bytes,
                                    yt8m_stream_t stream) {
@@ -520,6 +556,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   void* hook_user = g_prep_user;
   g_prep_hook = nullptr;
   g_prep_user = nullptr;
+  bool early = g_early.set;                                // one-shot, like the hook
+  g_early.set = false;
   if (two_sw) ev.wait(S->sw2, ev.record(sw));              // layer 0's chain reads images made on sw
   int phase[MAXL];
   bool wx3_done[MAXL];
@@ -595,6 +633,9 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         img_done_rows[l] += M;
         ++img_launches[l];
       } else {
+        // (opt-in knobs YT8M_STACK_FUSED_IMAGES + YT8M_STACK_SUB0 together can ask for more launches per layer than there are
+        // column-sum slots: the products below would then read images nobody wrote -- refuse instead)
+        YT8M_REQUIRE(!fused_img, YT8M_E_SHAPE, "YT8M_STACK_FUSED_IMAGES: more backward launches per layer than image slots (YT8M_STACK_SUB0)");
         // bf16-operand mode: the recurrent product of the backward pass on one bf16 plane too (knob YT8M_STACK_BF16_RECUR, default 1;
         // the launch falls back to the fp32 form by itself where the shape cannot take it)
         static const int bf_recur = knob("YT8M_STACK_BF16_RECUR", 1);
@@ -607,6 +648,10 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       if (hook) {                                          // the very first recurrence is enqueued: now the caller's work on sw
         hook(hook_user, (yt8m_stream_t)S->sw);
         hook = nullptr;
+      }
+      if (early) {                                         // ... and the early clip + Adam pass (yt8m_lstm_stack_set_early_optimizer)
+        early = false;
+        RC(yt8m_optimizer_ranges(&g_early.o, (yt8m_stream_t)S->sw));
       }
       bool fused_t = false;
       const float* dzc = dz + t0 * B * H4;

@@ -688,6 +688,9 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) s1[t] = s2[t] = 0u;
 
+#ifdef NV_TIMING
+  const uint64_t vt0 = __builtin_amdgcn_s_memtime();
+#endif
   issue1(0, 0);
   if (nblk > 1) issue1(1, 1);
   for (int j = 0, st = 0; j < nblk; ++j) {
@@ -743,6 +746,9 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
     st = st == 2 ? 0 : st + 1;
   }
   __syncthreads();                                                    // the ring is free: phase 2's first frames can start flying
+#ifdef NV_TIMING
+  const uint64_t vt1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- phase 2 DMA plumbing (step 0 is issued before the softmax epilogue and lands while it runs) -------------------------------
   const int Dc = g.D >> 4;                                            // 16-byte chunks per frame row
@@ -754,9 +760,9 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
   for (int i = 0; i < 5; ++i) {
     const int idx = tid + 512 * i;
     const int r = idx / Dc, pc = idx - r * Dc;
-    int c = pc - 4 * (r >> 3);                                        // the rotation that spreads the kg groups over the banks
+    const int c = (pc + 4 * Dc - 4 * (r >> 3)) % Dc;                  // the rotation that spreads the kg groups over the banks
     r2[i] = idx < 2 * g.D ? r : -1;                                   // (wave-uniform: 2 D % 64 == 0)
-    c2[i] = 16 * (c < 0 ? c + Dc : c);
+    c2[i] = 16 * c;
   }
   (void)rounds2;
   auto issue2 = [&](int s, int stage) {
@@ -847,6 +853,9 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) vm = fmaxf(vm, red[i][NK]);
   const float S = pow2_scale(vm);                                     // |c| * S < 2^12: both f16 parts stay normal
+#ifdef NV_TIMING
+  const uint64_t vt2 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- phase 2 ------------------------------------------------------------------------------------------------------------------
   const int ct2 = w >> 1, fh = w & 1;
@@ -867,7 +876,10 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
   u4 onesv = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
   const h8 ones = __builtin_bit_cast(h8, onesv);
   // byte address (inside a stage) of this lane's dword of group gq in frame row 8 kg: chunk 4 (G fh + gq) + n / 4, rotated by 4 kg
-  const uint32_t qrow0 = (uint32_t)(8 * kg * g.D + (n & 3) * 4);
+  uint32_t qoff[VGMAX];
+#pragma unroll
+  for (int gq = 0; gq < VGMAX; ++gq)
+    qoff[gq] = (uint32_t)(8 * kg * g.D + (n & 3) * 4 + (((4 * (G * fh + gq) + (n >> 2) + 4 * kg) % Dc) << 4));
 
   for (int s = 0; s < steps; ++s) {
     wait_vmcnt<0>();
@@ -897,9 +909,7 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
 #pragma unroll
     for (int gq = 0; gq < VGMAX; ++gq) {
       if (gq < G) {
-        int pc = 4 * (G * fh + gq) + (n >> 2) + 4 * kg;
-        pc = pc >= Dc ? pc - Dc : pc;
-        const uint32_t qa = so + qrow0 + (uint32_t)(pc << 4);
+        const uint32_t qa = so + qoff[gq];
         uint32_t qr[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) qr[i] = lds_read_u32(qa + (uint32_t)(i * g.D));
@@ -920,6 +930,9 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
+#ifdef NV_TIMING
+  const uint64_t vt3 = __builtin_amdgcn_s_memtime();
+#endif
   // agg[k, d] = sum_f c x = (alpha / S) acc + ((beta + 128 alpha) / S) m1,  m1 = sum_f (scaled, rounded) c
   const float A2 = DQ_A / S, CB = DQ_C / S;
 #pragma unroll
@@ -937,6 +950,16 @@ __global__ __launch_bounds__(512, 2) void vlad_video_kernel(VideoArgs g) {
       }
     }
   }
+#ifdef NV_TIMING   // (timing experiments only) cycles of phase 1 / its epilogue / phase 2 / the store tail land in n_out[b, 0..3]
+  __syncthreads();
+  if (tid == 0) {
+    const uint64_t vt4 = __builtin_amdgcn_s_memtime();
+    g.n_out[(int64_t)b * NK + 0] = (float)(vt1 - vt0);
+    g.n_out[(int64_t)b * NK + 1] = (float)(vt2 - vt1);
+    g.n_out[(int64_t)b * NK + 2] = (float)(vt3 - vt2);
+    g.n_out[(int64_t)b * NK + 3] = (float)(vt4 - vt3);
+  }
+#endif
 }
 
 // first level of the dW reduction: out[r][k][d] = sum over groups g = r, r + RED2, ... of part[g][k][d]  (fixed order)
@@ -1104,7 +1127,7 @@ extern "C" int yt8m_netvlad_set_single(int mode) {               // -1: environm
   return YT8M_OK;
 }
 extern "C" int yt8m_netvlad_single_pass(int64_t B, int64_t F, int64_t D, int64_t K) {
-  static const int env = getenv("YT8M_NETVLAD_SINGLE") ? atoi(getenv("YT8M_NETVLAD_SINGLE")) : 1;
+  static const int env = getenv("YT8M_NETVLAD_SINGLE") ? atoi(getenv("YT8M_NETVLAD_SINGLE")) : 0;   // measured slower than the pair: opt-in
   const int mode = g_single_mode.load();
   const int on = mode < 0 ? env : mode;
   return (on != 0 && yt8m_netvlad_supported(B, F, D, K) && (D % 128) == 0 && D <= 1152 && F <= VF) ? 1 : 0;

@@ -308,3 +308,41 @@ extern "C" int yt8m_adam_tiles(float* w, float* m, float* v, const float* g, con
     hipLaunchKernelGGL(adam_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, w, m, v, g, jobs, (int)njobs, tile0, l2, norms, h);
   return launch_status("adam_tile_kernel");
 }
+
+// clip + Adam of tensor ranges of an arena: what youtube-8m_amd/ops.py sqnorm_and_adam enqueues per range -- the two chunk passes over
+// the range's slice of the chunk table and, for the image-owning matrices in it, the tile pass -- for a host that is not Python
+// (and for yt8m_lstm_stack_bwd's early pass: lstm_stack.hip).
+extern "C" int yt8m_optimizer_ranges(const yt8m_opt_ranges* o, yt8m_stream_t stream) {
+  YT8M_REQUIRE(o && o->nranges >= 1 && o->nranges <= 8, YT8M_E_BADARG, "1..8 ranges");
+  YT8M_REQUIRE(o->w && o->m && o->v && o->g && o->chunks && o->tensor_chunk_start && o->tensor_chunk_start_host && o->l2 && o->partial &&
+                   o->norms, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(o->njobs >= 0 && (o->njobs == 0 || (o->jobs && o->job_tensor_host && o->job_tile_base_host && o->skip_tensor)), YT8M_E_BADARG,
+               "image jobs need their tables and the skip flags");
+  for (int r = 0; r < o->nranges; ++r) {
+    const int lo = o->range_lo[r], hi = o->range_hi[r];
+    YT8M_REQUIRE(lo >= 0 && hi >= lo, YT8M_E_BADARG, "bad tensor range");
+    if (hi == lo) continue;
+    const int64_t c0 = o->tensor_chunk_start_host[lo], c1 = o->tensor_chunk_start_host[hi];
+    if (o->clip > 0.f) {
+      const int rc = yt8m_sqnorm_multi(o->w, o->g, o->chunks + 4 * c0, c1 - c0, o->l2, o->gscale, o->partial + c0, o->norms, lo, hi - lo,
+                                       o->tensor_chunk_start, c0, stream);
+      if (rc != YT8M_OK) return rc;
+    }
+    int rc = yt8m_adam_multi_ex(o->w, o->m, o->v, o->g, o->chunks + 4 * c0, c1 - c0, o->l2, o->gscale, o->norms, o->clip, o->lr_t, o->beta1,
+                                o->beta2, o->eps, o->njobs ? o->skip_tensor : nullptr, stream);
+    if (rc != YT8M_OK) return rc;
+    if (o->njobs) {
+      int j0 = 0, j1 = 0;
+      while (j0 < o->njobs && o->job_tensor_host[j0] < lo) ++j0;
+      j1 = j0;
+      while (j1 < o->njobs && o->job_tensor_host[j1] < hi) ++j1;
+      if (j1 > j0) {
+        rc = yt8m_adam_tiles(o->w, o->m, o->v, o->g, o->jobs + j0, j1 - j0, o->job_tile_base_host[j0],
+                             o->job_tile_base_host[j1] - o->job_tile_base_host[j0], o->l2, o->gscale, o->norms, o->clip, o->lr_t, o->beta1,
+                             o->beta2, o->eps, 1, stream);
+        if (rc != YT8M_OK) return rc;
+      }
+    }
+  }
+  return YT8M_OK;
+}

@@ -198,8 +198,11 @@ class TrainGraph(object):
             # it starts (seq_ops._early_optimizer_hook); what it covered comes back in g.early_done
             g.early_optimizer = {"lr_t": lr_t, "clip": self.clip, "beta1": self.b1, "beta2": self.b2, "eps": self.eps}
         g.early_done = []
-        final_loss.backward()
-        g.early_optimizer = None
+        try:
+            final_loss.backward()
+        finally:                                                # (a failed backward must not leave the pass armed)
+            g.early_optimizer = None
+            g.early_active = None
         for v in g.trainable_variables():                       # variables the step did not touch: TF skips them
             if not v.grad_written:                              # (None gradient); here their gradient is zero
                 v.grad.zero_()

@@ -46,6 +46,12 @@ class Variable(object):
                 and getattr(self, "_done_reported", False):
             raise RuntimeError("second gradient contribution to %s after grad_done(): under data parallelism its all-reduce "
                                "is already in flight" % self.name)
+        act = getattr(self._graph, "early_active", None) if self._graph is not None else None
+        done = getattr(self._graph, "early_done", None) if self._graph is not None else None
+        if self.grad_written and self.index >= 0 and any(lo <= self.index < hi for lo, hi in (act or []) + (done or [])):
+            #  the recurrent stack's early clip + Adam pass has taken this variable's gradient as final: a contribution
+            # that arrives now would land in a slot Adam has already consumed and be dropped at the end of the step
+            raise RuntimeError("second gradient contribution to %s after its early optimiser update was enqueued" % self.name)
         self.grad_written = True
         return beta
 
