@@ -50,7 +50,8 @@ PEAK_F32_MATRIX_TFLOPS = 157.3
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md); only used by bf16 VARIANT lines
 PEAK_HBM_GBS = 8000.0
 FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3", "gemm_x1x3",
-            "vlad_rows", "vlad_cols"]          # the last two: the streaming kernels of "netvlad", timed inside it, bytes declared
+            "vlad_rows", "vlad_cols",          # the streaming kernels of "netvlad", timed inside it, bytes declared
+            "netvlad_fwd"]                     # the whole forward pooling call with SURVEY.md 8(d)'s bytes (frames once + parameters)
 X3_PRODUCTS = 6.0                    # bf16 MFMA products per fp32 product in csrc/gemm_x3.hip
 
 
@@ -266,7 +267,7 @@ def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False,
     work would take with every pipe at its peak and nothing overlapped, against the measured wall time of a step."""
     rows = {}
     for name, v in fam.items():
-        if name in ("vlad_rows", "vlad_cols"):                       # sub-kernels of "netvlad": reported under roofline.hbm
+        if name in ("vlad_rows", "vlad_cols", "netvlad_fwd"):        # sub-scopes of "netvlad": reported under roofline.hbm
             continue
         f = v.get("declared_flops_per_step") or flops.get(name)
         if f and v["ms_per_step"] > 0:
@@ -290,7 +291,7 @@ def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False,
             "launches_per_step": r["launches_per_step"], "avg_launch_ms": r["avg_launch_ms"],
             "algorithmic_flops_per_launch": r["algorithmic_flops_per_launch"],
             "families": rows,
-            "other_families": {k: v for k, v in fam.items() if k not in rows and k not in ("vlad_rows", "vlad_cols")}}
+            "other_families": {k: v for k, v in fam.items() if k not in rows and k not in ("vlad_rows", "vlad_cols", "netvlad_fwd")}}
     for k in ("occupied_cus", "frac_of_occupied_cus", "occupancy_note"):
         if k in r:
             roof[k] = r[k]
@@ -426,6 +427,12 @@ def netvlad_hbm(fam, bf16):
                              "algorithmic_bytes_per_launch": by / max(v["launches_per_step"], 1e-9), "achieved_GBps": gbps,
                              "frac_of_hbm": gbps / PEAK_HBM_GBS,
                              "mfma_TFLOPs": fl / (v["ms_per_step"] * 1e-3) / 1e12, "frac_of_mfma_pipe": fl / (v["ms_per_step"] * 1e-3) / 1e12 / peak}
+    fw = fam.get("netvlad_fwd")
+    if fw:                     # the forward pooling against the HBM roof on SURVEY.md 8(d)'s bytes (345 600 B / video + params)
+        by = fw.get("declared_bytes_per_step", 0.0)
+        gb = by / (fw["ms_per_step"] * 1e-3) / 1e9
+        out["forward_8d"] = {"us": fw["ms_per_step"] * 1e3, "bytes_8d": by, "achieved_GBps": gb, "frac_of_hbm_8d_bytes": gb / PEAK_HBM_GBS,
+                             "is": "whole yt8m_netvlad_fwd_u8 call (pack + rows + cols, or the single-pass kernel) / (uint8 frames once + W_c, b_c)"}
     out["mfma_pipe"] = what
     out["north_star_note"] = ("BASELINE.json asks for >= 70 % of the bf16 MFMA roofline on the assignment GEMM.  That GEMM does 128 FLOP per "
                               "uint8 input byte ([B*300,1152] x [1152,64]), below the ~312 FLOP/B ridge of a 2.5 PFLOP/s pipe over 8 TB/s: "
@@ -800,8 +807,11 @@ def compact_line(out, sidecar=SIDECAR):
         if er.get("blended_bound"):
             row["blended_frac"] = _r(er["blended_bound"].get("frac"), 4)
         if er.get("hbm"):
-            row["hbm"] = {k: {"frac_of_hbm": _r(v.get("frac_of_hbm"), 4), "frac_of_hbm_8d_bytes": _r(v.get("frac_of_hbm_8d_bytes"), 4),
-                              "avg_launch_us": _r(v.get("avg_launch_us"), 4)} for k, v in er["hbm"]["kernels"].items()}
+            row["hbm"] = {k: {"frac_of_hbm": _r(v.get("frac_of_hbm"), 4), "avg_launch_us": _r(v.get("avg_launch_us"), 4)}
+                          for k, v in er["hbm"]["kernels"].items()}
+            f8 = er["hbm"].get("forward_8d")
+            if f8:
+                row["hbm"]["forward_8d"] = {"us": _r(f8["us"], 4), "frac_of_hbm_8d_bytes": _r(f8["frac_of_hbm_8d_bytes"], 4)}
         ex.append(row)
     line["extra"] = ex
     lib = out.get("library") or {}

@@ -1150,6 +1150,8 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   YT8M_REQUIRE(workspace_bytes >= L.total, YT8M_E_BADARG, "workspace too small");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_NETVLAD, s);
+  // "NetVLAD: bytes = 345 600 B + params" -- the frames once, W_c / b_c (the outputs are the next kernel's inputs)
+  ProfScope prof8d(F_NETVLAD_FWD, s, 4.0 * (double)B * (double)F * (double)D * NK, (double)B * (double)F * (double)D + 4.0 * (D * NK + NK));
   char* ws = static_cast<char*>(workspace);
   float* scale = reinterpret_cast<float*>(ws + L.o_scale);
   _Float16* Wp = reinterpret_cast<_Float16*>(ws + L.o_wp);

@@ -490,9 +490,9 @@ class GatedNetVLADAttentionChainModel(GatedNetVLADModel):
             att = seq_ops.pool_tn(w, x)                                                    # [B,A,D]
         chain_in = torch.cat([h.unsqueeze(1).expand(B, A, h.shape[1]), att], dim=2).reshape(B * A, -1)
         unused_params.pop("original_input", None)
+        # max over the A attention rows of a video (lstm_attention_max_pooling_model.py:64-66), stage by stage: the support
+        # predictions are pooled to [B, V] BEFORE they are concatenated (max over rows commutes with concatenation along columns)
+        pool = lambda p_: ops.frame_pool(p_.view(B, A, vocab_size), "max")
         res = video_level_models.DeepCombineChainModel().create_model(chain_in, vocab_size, l2_penalty=l2_penalty,
-                                                                      original_input=model_input, **unused_params)
-        out = {"predictions": ops.frame_pool(res["predictions"].view(B, A, vocab_size), "max")}
-        sup = res["support_predictions"]
-        out["support_predictions"] = ops.frame_pool(sup.view(B, A, sup.shape[1]), "max")
-        return out
+                                                                      original_input=model_input, support_pool=pool, **unused_params)
+        return {"predictions": pool(res["predictions"]), "support_predictions": res["support_predictions"]}

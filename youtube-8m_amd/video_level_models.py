@@ -90,7 +90,11 @@ class DeepCombineChainModel(models.BaseModel):
 
     def create_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="",
                      original_input=None, dropout=False, keep_prob=None, noise_level=None, num_frames=None,
-                     **unused_params):
+                     support_pool=None, **unused_params):
+        """support_pool (this build's addition, None = the reference's behaviour): a callable applied to every stage's
+        sub-prediction BEFORE the concatenation into "support_predictions" -- a caller that reduces the rows anyway (the attention
+        composite takes the max over its A attention rows per video) then concatenates [B, V] pieces instead of [B * A, V] ones: the
+        [B * A, L * V] copy (464 MB at B * A = 8192, L = 3) and the strided gradient slices it leaves behind disappear."""
         num_layers = FLAGS.deep_chain_layers
         relu_cells = FLAGS.deep_chain_relu_cells
         relu_type = FLAGS.deep_chain_relu_type
@@ -105,7 +109,7 @@ class DeepCombineChainModel(models.BaseModel):
                 sub_relu = ops.add_noise(sub_relu, noise_level)
             relu_norm = ops.l2_normalize(sub_relu)
             next_input = torch.cat([next_input, relu_norm], dim=1)
-            support_predictions.append(sub_prediction)
+            support_predictions.append(sub_prediction if support_pool is None else support_pool(sub_prediction))
         main_predictions = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "-main")
         return {"predictions": main_predictions, "support_predictions": torch.cat(support_predictions, dim=1)}
 
