@@ -70,12 +70,41 @@ def test_gpus_n_relaunches_itself(monkeypatch):
 
 
 def _latest_line():
-    for name in ("r4_bench_line.json", "r3_bench_line.json", "r2_bench_line.json"):
+    """(name, full record).  Round 5 on: bench.py prints a compact line (profiles/r5_bench_line.json, checked by
+    test_round5_line_is_compact_and_names_its_sidecar) and writes the full record to the sidecar it names -- the detailed field
+    checks below run on the sidecar."""
+    for name in ("r5_bench_extra.json", "r4_bench_line.json", "r3_bench_line.json", "r2_bench_line.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
+            if name.endswith("_extra.json"):
+                return name, json.load(open(path))
             line = [l for l in open(path) if l.startswith("{")][-1]
             return name, json.loads(line)
     raise AssertionError("no recorded bench line under profiles/")
+
+
+def test_round5_line_is_compact_and_names_its_sidecar():
+    """The line the driver-style run of round 5 printed (profiles/r5_bench_line.json): ONE line under 8 KB with every contract field,
+    `roofline` and `cpu_baseline` included, equal to what compact_line() makes of the recorded sidecar."""
+    path = os.path.join(ROOT, "profiles", "r5_bench_line.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-5 line recorded yet")
+    text = open(path).read().strip()
+    assert text.count("\n") == 0 and len(text) < 8192
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "sidecar"):
+        assert k in d, k
+    assert d["metric"] == "training videos/sec" and d["unit"] == "videos/s" and d["n_gpus"] == 1 and d["dtype"] == "f32"
+    assert d["config"]["workload"].startswith("BASELINE configs[3]") and d["config"]["per_gpu_batch"] == 128
+    assert abs(d["value"] - d["config"]["per_gpu_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "TFLOP/s" and r["traffic"] > 0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["timed_steps"] >= 10
+    g = d["gap_at_20"]
+    assert g["frame_twin_lstm"]["within_target"] and g["cpu_twin"]["within_target"] and g["cpu_twin_full_size"]["within_target"]
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_extra.json")))
+    assert _bench().compact_line(full) == d
 
 
 def test_recorded_line_is_small():
