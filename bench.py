@@ -31,6 +31,7 @@ Other legs (rank 0):
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import socket
@@ -470,6 +471,7 @@ def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None, batch=No
     if workload == "netvlad" and fam and "vlad_rows" in fam:
         roof["hbm"] = netvlad_hbm(fam, bf16)
     del tg, g, pool
+    gc.collect()                         # Graph <-> Variable <-> WeightImages are reference cycles: release the arenas and images now
     torch.cuda.empty_cache()
     return {"workload": cfg["name"] + (" -- bf16-operand VARIANT" if bf16 else ", fp32") + tag, "dtype": "bf16" if bf16 else "f32",
             "per_gpu_batch": B, "steps": steps, "ms_per_step": el / steps * 1e3, "value": steps * B / el, "unit": "videos/s",
@@ -969,6 +971,7 @@ def main():
                                       "is": "all algorithmic (fp32-equivalent) FLOPs of the step over wall time: a rate, not a roofline "
                                             "fraction -- the step's products run on two pipes; see blended_bound"}
     del tg, g, pool
+    gc.collect()
     torch.cuda.empty_cache()
 
     extra = []

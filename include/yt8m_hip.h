@@ -675,6 +675,8 @@ typedef struct yt8m_opt_ranges {
   int32_t nranges;                        /* 1..8 */
   int32_t range_lo[8], range_hi[8];
   float gscale, clip, lr_t, beta1, beta2, eps;
+  yt8m_stream_t after_stream;             /* NULL, or a stream whose work enqueued so far must finish before the pass starts (the
+                                           * stream the host computed some of these gradients on); honoured by both entry points */
 } yt8m_opt_ranges;
 int yt8m_optimizer_ranges(const yt8m_opt_ranges* opt, yt8m_stream_t stream);
 int yt8m_lstm_stack_set_early_optimizer(const yt8m_opt_ranges* opt);

@@ -217,3 +217,35 @@ def test_netvlad_single_pass_equals_the_rows_cols_pair(dev, shape, nsplit):
     assert float((a1 - a0).abs().max()) <= tol * max(1.0, float(a0.abs().max()))
     if B > 2:
         assert float(a1[2].abs().max()) == 0.0 and float(c1[2].abs().max()) == 0.0        # a video without frames
+
+
+def test_head_weight_gradients_on_a_side_stream_are_the_same_step(dev, flags, monkeypatch):
+    """LstmModel: when the native recurrent stack's backward follows, the MoE head leaves dW_g / dW_e / db_e to a side stream (the
+    first backward recurrence waits for dx only) and the optimiser passes -- the early one inside yt8m_lstm_stack_bwd through
+    yt8m_opt_ranges.after_stream, the end-of-step one through ops.join_side_work -- wait for it.  Same arithmetic, other stream:
+    bitwise the step that computes them on the main stream; at the headline's head size the early pass engages in both runs."""
+    import yt8m_amd.seq_ops as seq_ops
+
+    def run(defer):
+        monkeypatch.setattr(ops, "DEFER_HEAD_DW", defer)
+        flags.reset()
+        flags.lstm_cells, flags.lstm_layers = "256", 2
+        B, F, D, V = 32, 32, 64, 4716                       # V = 4716: the head holds > 2^22 parameters, the early pass engages
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(flm.LstmModel(), batch_size=B, graph=g)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        early0 = seq_ops.EARLY_ADAM_RUNS[0]
+        losses = []
+        for i in range(4):
+            q = torch.randint(0, 256, (B, F, D), device=dev, generator=gen, dtype=torch.uint8)
+            nf = torch.randint(1, F + 1, (B,), device=dev, generator=gen, dtype=torch.int32)
+            y = torch.rand((B, V), device=dev, generator=gen) < 0.001
+            losses.append(float(tg.step(q, y, nf)["loss"]))
+            assert g.side_pending == [] and not g.defer_head_dw
+        torch.cuda.synchronize()
+        seq_ops.check_persist_errors()
+        return losses, g.params.clone(), g.adam_v.clone(), seq_ops.EARLY_ADAM_RUNS[0] - early0
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == 4 and b[3] == 4, (a[3], b[3])

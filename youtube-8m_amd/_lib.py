@@ -54,7 +54,7 @@ class OptRanges(ctypes.Structure):
                 ("tensor_chunk_start_host", c_void_p), ("l2", c_void_p), ("partial", c_void_p), ("norms", c_void_p), ("skip_tensor", c_void_p),
                 ("jobs", c_void_p), ("job_tensor_host", c_void_p), ("job_tile_base_host", c_void_p), ("njobs", ctypes.c_int32),
                 ("nranges", ctypes.c_int32), ("range_lo", ctypes.c_int32 * 8), ("range_hi", ctypes.c_int32 * 8), ("gscale", c_float),
-                ("clip", c_float), ("lr_t", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float)]
+                ("clip", c_float), ("lr_t", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("after_stream", c_void_p)]
 
 
 DESC = ctypes.POINTER(LstmStackDesc)

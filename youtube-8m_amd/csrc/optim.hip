@@ -318,6 +318,14 @@ extern "C" int yt8m_optimizer_ranges(const yt8m_opt_ranges* o, yt8m_stream_t str
                    o->norms, YT8M_E_BADARG, "null operand");
   YT8M_REQUIRE(o->njobs >= 0 && (o->njobs == 0 || (o->jobs && o->job_tensor_host && o->job_tile_base_host && o->skip_tensor)), YT8M_E_BADARG,
                "image jobs need their tables and the skip flags");
+  if (o->after_stream && o->after_stream != stream) {                // gradients some other stream is still writing
+    hipEvent_t e;
+    YT8M_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t rc1 = hipEventRecord(e, as_stream(o->after_stream));
+    hipError_t rc2 = rc1 == hipSuccess ? hipStreamWaitEvent(as_stream(stream), e, 0) : rc1;
+    (void)hipEventDestroy(e);                                        // (released once the recorded work has completed)
+    YT8M_HIP_CHECK(rc2);
+  }
   for (int r = 0; r < o->nranges; ++r) {
     const int lo = o->range_lo[r], hi = o->range_hi[r];
     YT8M_REQUIRE(lo >= 0 && hi >= lo, YT8M_E_BADARG, "bad tensor range");

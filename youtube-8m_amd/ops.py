@@ -1203,6 +1203,34 @@ def _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be):
     return dx
 
 
+_SIDE = {}
+DEFER_HEAD_DW = os.environ.get("YT8M_DEFER_HEAD_DW", "1") != "0"
+
+
+def side_stream(graph):
+    """The side stream on which an op may leave weight-gradient work that nothing later in the backward pass reads (round 5): the
+    classifier head's dW products when a recurrent stack's backward pass follows -- its first recurrence holds half the chip for a
+    millisecond and waits only for dx.  None when the step must not defer (no stack follows, data parallel: the reducer starts a
+    gradient's all-reduce from the current stream)."""
+    if not DEFER_HEAD_DW or graph is None or not getattr(graph, "defer_head_dw", False) or graph.grad_ready_hook is not None:
+        return None
+    st = _SIDE.get(graph.device)
+    if st is None:
+        st = torch.cuda.Stream(device=graph.device)
+        _SIDE[graph.device] = st
+    return st
+
+
+def join_side_work(graph):
+    """Makes the current stream wait for everything ops left on side streams in this backward pass (called by the recurrent
+    stack's backward and by TrainGraph.step before the optimiser pass)."""
+    if graph is None:
+        return
+    for st in getattr(graph, "side_pending", None) or ():
+        torch.cuda.current_stream(graph.device).wait_stream(st)
+    graph.side_pending = []
+
+
 def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
     """dW_g = x^T dZ_g, dW_e = x^T dZ_e, db_e = colsum(dZ_e), dx = dZ_g W_g^T + dZ_e W_e^T."""
     if getattr(ctx, "bf16", False) and _bf16_ok(x):
@@ -1212,6 +1240,24 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
         dx = gemm(Zg, Wg.data, transB=True)
         gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
     overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
+    side = side_stream(Wg._graph) if (dx is not None and Wg.grad is not None and We.grad is not None and be.grad is not None) else None
+    if side is not None:
+        # dx is on its way to the recurrent stack; the parameter gradients are read by the optimiser only: off the critical chain
+        g = Wg._graph
+        side.wait_stream(torch.cuda.current_stream(g.device))
+        for t in (x, Zg, Ze):
+            t.record_stream(side)                  # (their memory must not be handed out again before the side stream is done)
+        bw, bwe, bbe = Wg.grad_beta(), We.grad_beta(), be.grad_beta()
+        with torch.cuda.stream(side):
+            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw), dict(A=x, B=Ze, out=We.grad, beta=bwe)], transA=True)
+            colsum(Ze, be.grad.view(-1), beta=bbe)
+        if not hasattr(g, "side_pending") or g.side_pending is None:
+            g.side_pending = []
+        g.side_pending.append(side)
+        Wg.grad_done()
+        We.grad_done()
+        be.grad_done()
+        return dx
     if Wg.grad is not None and We.grad is not None and not overlap:
         gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
                       dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True)

@@ -509,6 +509,9 @@ class _EarlyOpt(object):
         for i, (lo, hi) in enumerate(ranges):
             o.range_lo[i], o.range_hi[i] = lo, hi
         o.gscale, o.clip, o.lr_t, o.beta1, o.beta2, o.eps = 1.0, a["clip"], a["lr_t"], a["beta1"], a["beta2"], a["eps"]
+        side = getattr(graph, "side_pending", None)
+        if side:                                                     # the head's weight gradients may still be on their side stream
+            o.after_stream = side[-1].cuda_stream
         self.desc = o
 
     def finish(self, lib, ok):
@@ -795,6 +798,11 @@ class _LstmStack(torch.autograd.Function):
         if PERSIST_CHECK:
             _check_stack(scratch, main, desc)
         ctx.native = (desc, tape, scratch, x, nf, Ws, bs)
+        g_ = Ws[0]._graph
+        if g_ is not None and torch.is_grad_enabled():
+            # the stack's backward pass will follow whatever consumes these outputs: ops that run before it in the backward pass (the
+            # classifier head) may leave their weight gradients to a side stream instead of the chain the first recurrence waits on
+            g_.defer_head_dw = True
         ctx.layers = None
         ctx.set_materialize_grads(False)
         outs = [_tape_view(lib, desc, tape, L - 1, 0, (F, B, H))]
@@ -840,6 +848,7 @@ class _LstmStack(torch.autograd.Function):
             if early is not None:
                 early.finish(lib, ok)
         NATIVE_CALLS["bwd"] += 1
+        ops.join_side_work(Ws[0]._graph)                             # gradients an earlier op left on a side stream: visible from here on
         if PERSIST_CHECK:
             _check_stack(scratch, torch.cuda.current_stream(dev), desc)
         g = Ws[0]._graph

@@ -203,6 +203,8 @@ class TrainGraph(object):
         finally:                                                # (a failed backward must not leave the pass armed)
             g.early_optimizer = None
             g.early_active = None
+            g.defer_head_dw = False
+        ops.join_side_work(g)                                   # gradients left on a side stream: before any optimiser pass reads them
         for v in g.trainable_variables():                       # variables the step did not touch: TF skips them
             if not v.grad_written:                              # (None gradient); here their gradient is zero
                 v.grad.zero_()

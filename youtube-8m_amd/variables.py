@@ -118,6 +118,8 @@ class Graph(object):
         self.total = 0
         self.nchunks = 0
         self.wimg = None               # wimg.WeightImages after finalize(): operand images of the weight matrices, kept by Adam
+        self.defer_head_dw = False     # set by the recurrent stack's forward: ops before it in the backward pass may defer their dW
+        self.side_pending = []         # side streams holding such work in the current backward pass (ops.join_side_work)
 
     def __del__(self):
         w = getattr(self, "wimg", None)
@@ -141,6 +143,7 @@ class Graph(object):
         self._anon_counter = 0
         self._rng_step += 1
         self._rng_calls = 0
+        self.defer_head_dw = False
         for v in self.vars.values():
             v.grad_written = False
             v._done_reported = False
