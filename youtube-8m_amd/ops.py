@@ -1204,7 +1204,7 @@ def _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be):
 
 
 _SIDE = {}
-DEFER_HEAD_DW = os.environ.get("YT8M_DEFER_HEAD_DW", "1") != "0"
+DEFER_HEAD_DW = os.environ.get("YT8M_DEFER_HEAD_DW", "0") != "0"   # measured: no gain (the backward pass is work-bound), opt-in
 
 
 def side_stream(graph):
