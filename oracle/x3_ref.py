@@ -79,3 +79,39 @@ def six_products(A, B):
     for p, q in TERMS:
         C += pa[p] @ pb[q].T
     return C
+
+
+# ---- "h2": two IEEE-half planes, three products (csrc/x3_image.h split_h2, csrc/gemm_x3.hip gemm_h2q_kernel; round 5) -----------------
+def split_h2(x, scale=1.0):
+    """fp32 array -> (hi, lo) float16 arrays of scale * x: hi = half(clamp(scale x)), lo = half(scale x - hi); numpy's float32 ->
+    float16 cast rounds to nearest even like the device's v_cvt_f16_f32."""
+    v = (np.asarray(x, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    v = np.clip(v, np.float32(-65504.0), np.float32(65504.0))
+    hi = v.astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def image_h2(x, scale=1.0):
+    """x: fp32 [rows, K] -> uint16 [ceil(rows/32), ceil(K/16), 2, 32, 2, 8]: the bytes yt8m_h2_split writes for its `plain` output."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    R, K = x.shape
+    RG, KB = (R + 31) // 32, (K + 15) // 16
+    pad = np.zeros((RG * 32, KB * 16), dtype=np.float32)
+    pad[:R, :K] = x
+    hi, lo = split_h2(pad, scale)
+    h = np.stack([hi.view(np.uint16), lo.view(np.uint16)])        # [2, RG*32, KB*16]
+    h = h.reshape(2, RG, 32, KB, 2, 8).transpose(1, 3, 0, 2, 4, 5)
+    out = np.empty_like(h)
+    sw = (np.arange(32) >> 3) & 1
+    for r in range(32):
+        out[:, :, :, r, sw[r], :] = h[:, :, :, r, 0, :]
+        out[:, :, :, r, sw[r] ^ 1, :] = h[:, :, :, r, 1, :]
+    return np.ascontiguousarray(out)
+
+
+def three_products(A, B, sa=1.0, sb=1.0):
+    """A [M, K], B [N, K] fp32 -> fp64 [M, N]: (hi hi + hi lo + lo hi) / (sa sb) of the h2 splits, accumulated in fp64."""
+    ah, al = (t.astype(np.float64) for t in split_h2(A, sa))
+    bh, bl = (t.astype(np.float64) for t in split_h2(B, sb))
+    return (ah @ bh.T + ah @ bl.T + al @ bh.T) / (float(sa) * float(sb))

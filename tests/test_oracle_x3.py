@@ -68,3 +68,28 @@ def test_image_layout():
     assert not flat[:, 2][..., kcols + 32 >= K].any()             # columns 37..47 of the last K block
     s = np.float32(4.0 / 255.0)
     assert np.array_equal(x3_ref.image(x, scale=float(s)), x3_ref.image((x * s).astype(np.float32)))
+
+
+def test_h2_split_properties():
+    """The two-half split of the h2 products (round 5): hi + lo reproduces scale * x to 2^-23 relative while lo is a normal half, the
+    kept three products are within 2^-21 sum |a||b| of the exact product, and values beyond the half range clamp instead of
+    overflowing."""
+    from oracle import x3_ref
+    rs = np.random.RandomState(5)
+    x = (rs.randn(64, 96) * np.exp(rs.randn(64, 96) * 1.5)).astype(np.float32)
+    S = np.float32(2.0 ** (13 - np.ceil(np.log2(np.abs(x).max()))))
+    hi, lo = x3_ref.split_h2(x, S)
+    v = (x * S).astype(np.float64)
+    r = hi.astype(np.float64) + lo.astype(np.float64) - v
+    big = np.abs(v) >= 2.0 ** -3
+    assert np.all(np.abs(r[big]) <= 2.0 ** -22 * np.abs(v[big])) and np.all(np.abs(r[~big]) <= 2.0 ** -24)
+    assert np.isfinite(hi.astype(np.float32)).all() and np.abs(hi.astype(np.float32)).max() < 2.0 ** 14
+    A = (rs.randn(40, 300)).astype(np.float32)
+    B = (rs.randn(24, 300) * 0.05).astype(np.float32)
+    got = x3_ref.three_products(A, B, 2.0 ** 11, 2.0 ** 15)
+    exact = A.astype(np.float64) @ B.astype(np.float64).T
+    bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+    assert np.all(np.abs(got - exact) <= 2.0 ** -21 * bound)
+    h, _ = x3_ref.split_h2(np.array([1e9, -1e9, np.float32(70000.0)], dtype=np.float32))
+    assert np.all(np.abs(h.astype(np.float32)) == 65504.0)
+    assert x3_ref.image_h2(x, S).shape == (2, 6, 2, 32, 2, 8)

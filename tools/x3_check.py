@@ -56,8 +56,13 @@ def timing(M, N, K, reps=10):
         ops.gemm(A, B, transB=True, out=out)
         ops.X3 = True
 
+    ha, _ = ops.h2_split(A, scale=2.0 ** 10)
+    hb, _ = ops.h2_split(B, dynamic=True)
     for name, fn in (("fp32-mfma", f32),
                      ("x3", lambda: ops.gemm_x3_grouped([dict(A=ia, B=ib, out=out)])),
+                     ("h2", lambda: ops.gemm_h2_grouped([dict(A=ha, B=hb, out=out)])),
+                     ("h2 split A dual", lambda: ops.h2_split(A, plain=True, trans=True, scale=2.0 ** 10)),
+                     ("h2 split A dual dyn", lambda: ops.h2_split(A, plain=True, trans=True, dynamic=True)),
                      ("split A", lambda: ops.x3_split(A)),
                      ("split A dual", lambda: ops.x3_split(A, plain=True, trans=True))):
         fn()
@@ -71,9 +76,10 @@ def timing(M, N, K, reps=10):
         res[name] = e0.elapsed_time(e1) / reps
     fl = 2.0 * M * N * K
     print("M=%6d N=%6d K=%6d  fp32-mfma %.3f ms (%.0f TF)   x3 %.3f ms (%.0f TF fp32-equivalent, %.0f TF of bf16 MFMA)   split A %.3f ms  "
-          "(dual %.3f ms, %.2f TB/s)" % (M, N, K, res["fp32-mfma"], fl / res["fp32-mfma"] / 1e9, res["x3"], fl / res["x3"] / 1e9,
-                                         6 * fl / res["x3"] / 1e9, res["split A"], res["split A dual"],
-                                         M * K * 16.0 / res["split A dual"] / 1e9), flush=True)
+          "(dual %.3f ms, %.2f TB/s)   h2 %.3f ms (%.0f TF fp32-equivalent, %.0f TF of f16 MFMA; dual split %.3f ms, with device scale %.3f)"
+          % (M, N, K, res["fp32-mfma"], fl / res["fp32-mfma"] / 1e9, res["x3"], fl / res["x3"] / 1e9,
+             6 * fl / res["x3"] / 1e9, res["split A"], res["split A dual"], M * K * 16.0 / res["split A dual"] / 1e9,
+             res["h2"], fl / res["h2"] / 1e9, 3 * fl / res["h2"] / 1e9, res["h2 split A dual"], res["h2 split A dual dyn"]), flush=True)
 
 
 if __name__ == "__main__":

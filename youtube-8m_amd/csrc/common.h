@@ -39,7 +39,9 @@ enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LST
               F_VLAD_ROWS = 9,   // the two streaming kernels of the fused NetVLAD pooling, timed inside the F_NETVLAD scope with their
               F_VLAD_COLS = 10,  // algorithmic HBM bytes declared (HBM-bound: bench.py reports bytes / time against 8 TB/s)
               F_NETVLAD_FWD = 11,  // the whole yt8m_netvlad_fwd_u8 call with SURVEY.md 8(d)'s bytes (uint8 frames once + parameters):
-              F_COUNT = 12 };      // the forward pooling against the HBM roof on the bytes the ALGORITHM needs
+                                   // the forward pooling against the HBM roof on the bytes the ALGORITHM needs
+              F_GEMM_H2 = 12,      // fp32 products as three f16 MFMA products of two-plane half images (gemm_h2q_kernel, round 5)
+              F_COUNT = 13 };
 
 struct ProfScope {
   int fam;

@@ -59,6 +59,9 @@ struct XArgs {
   const float* cs;
   float cs_scale;
   float alpha;
+  // device-side factors of alpha (NULL: 1): the inverse scales of h2 images whose scale was chosen on the device (round 5)
+  const float* dsa;
+  const float* dsb;
 };
 __device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int col) {
   if (g.cs) {                                                        // (N % 4 == 0 and 16-byte aligned cs: checked by the host)
@@ -66,9 +69,13 @@ __device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int 
     v.x += g.cs_scale * cv.x; v.y += g.cs_scale * cv.y; v.z += g.cs_scale * cv.z; v.w += g.cs_scale * cv.w;
   }
   if (g.rscale) { const float rs = g.rscale[row]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-  if (g.alpha != 1.0f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+  if (g.alpha != 1.0f || g.dsa || g.dsb) {
+    const float al = g.alpha * (g.dsa ? g.dsa[0] : 1.0f) * (g.dsb ? g.dsb[0] : 1.0f);      // (powers of two: exact)
+    v.x *= al; v.y *= al; v.z *= al; v.w *= al;
+  }
   return v;
 }
+__device__ __forceinline__ bool has_affine(const XArgs& g) { return g.rscale || g.cs || g.alpha != 1.0f || g.dsa || g.dsb; }
 // Work items of a launch: problem q contributes its first full[q] tiles (whole rounds of 256 workgroups) unsplit, then the
 // rem[q] tiles of its last, partial round as rem[q] * S[q] K-part items, part major -- the wave-quantisation tail costs a fraction
 // of a round instead of a whole one.  full / rem / S come from the shape of problem q ALONE, so a product is summed in the same
@@ -138,7 +145,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const float* p) {
 // the summed value of four consecutive elements of a split tile -> C (affine / bias / accumulate), exactly as the unsplit epilogue
 __device__ __forceinline__ void finish_store(const XArgs& g, float4 v, int row, int col) {
   if (row >= g.M) return;
-  if ((g.rscale || g.cs || g.alpha != 1.0f) && col + 3 < g.N) v = affine(g, v, row, col);
+  if (has_affine(g) && col + 3 < g.N) v = affine(g, v, row, col);
   float* c = g.C + (int64_t)row * g.ldc + col;
   if ((g.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0 && col + 3 < g.N) {
     if (g.bias) {                                                  // the same additions in the same order as the scalar path
@@ -249,7 +256,7 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
         const int row = m0 + e / TN, col = n0 + (e % TN);
         if (!fast[u]) { finish_store(g, v[u], row, col); continue; }      // edges / unaligned C: the general path
         float4 w = v[u];
-        if (g.rscale || g.cs || g.alpha != 1.0f) w = affine(g, w, row, col);
+        if (has_affine(g)) w = affine(g, w, row, col);
         if (g.bias) {
           const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
           w.x += bv.x; w.y += bv.y; w.z += bv.z; w.w += bv.w;
@@ -275,7 +282,7 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
       float4 v = *reinterpret_cast<const float4*>(&st[rr * P + c4]);
       if (row < g.M && col < g.N) {
         float* c = g.C + (int64_t)row * g.ldc + col;
-        if (g.rscale || g.cs || g.alpha != 1.0f) v = affine(g, v, row, col);
+        if (has_affine(g)) v = affine(g, v, row, col);
         if (vec && col + 3 < g.N) {
           if (g.bias) {
             const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
@@ -619,6 +626,135 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(const XGroup G) {
   x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
+// ---- two f16 planes x two f16 planes, three products ("h2", round 5) ----------------------------------------------------------------
+// C = alpha . A . B^T for fp32 operands given as h2 images (csrc/x3_image.h: a S_a = hi + lo in IEEE half): the products hi hi,
+// hi lo, lo hi accumulate in fp32 on v_mfma_f32_32x32x16_f16 -- the same pipe and rate as the bf16 form, HALF the matrix
+// instructions of the six-product split, 4 instead of 6 bytes per operand element.  Error: 2^-21 |a b| per term (the dropped lo lo
+// product 2^-22, the two representations 2^-23 each), i.e. three fp32 roundings; an fp32 FMA chain over K terms commits ~sqrt(K) of
+// them, so for K >= 16 this is inside the error of the exact-fp32 MFMA kernel (tests/test_gpu_h2.py measures both against fp64).
+// What it needs that the bf16 split does not: the operands' magnitudes (half has 5 exponent bits) -- alpha carries 1 / (S_a S_b), from
+// the host for operands with known bounds (l2-normalised inputs, LSTM outputs) and / or from device words for gradients whose scale
+// is measured on the device (dsa / dsb).  Use: products whose result is a SUM over the operand's rows (weight gradients) or whose
+// operand rows are uniformly scaled; a per-row dynamic range (dx of vanishing time steps) stays on the bf16 split.
+// Schedule: gemm_x3q_kernel's (three one-block stages, step kt + 3 requested into the stage step kt was read from, every LDS read and
+// DMA request behind its own MFMA); per step 24 MFMAs, 12 fragment reads, 4 requests.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H2_STAGE_F = 4 * PLANE_F;                              // A hi, A lo, B hi, B lo (32 KiB)
+
+__global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
+  constexpr int OPA_F = 2 * PLANE_F;
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * H2_STAGE_F floats (96 KiB)
+  int q, nparts, part, slot, lt;
+  x_work_item(G, q, nparts, part, slot, lt);
+  const XArgs& g = G.p[q];
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, lt, tm, tn);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int wm = grp * 128, wn = (wave & 3) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
+  const int nk = kb1 - kb0;
+  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska * (2 * RG_F) + lane * 4;
+  const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.skb * (2 * RG_F) + lane * 4;
+  constexpr int DMA = 4;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int pro = nk < 3 ? nk : 3;
+  for (int s = 0; s < pro; ++s) { fill_op<2>(pa, kb0 + s, smem + s * H2_STAGE_F, tid); fill_op<2>(pb, kb0 + s, smem + s * H2_STAGE_F + OPA_F, tid); }
+  if (pro == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA) : "memory");
+  else if (pro == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa = (wm + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  const int fb = OPA_F + (wn + li) * 8 + 4 * (lk ^ ((li >> 3) & 1));
+  auto rd_a = [&](const float* S, int p, int t) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const float4*>(&S[fa + p * PLANE_F + t * 256]));
+  };
+  auto rd_b = [&](const float* S, int p, int t) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const float4*>(&S[fb + p * PLANE_F + t * 256]));
+  };
+  // hi planes of A and lo planes of B are held to the end of a step: two register sets in alternation (as a0 / b2 of gemm_x3q_kernel)
+  f16x8 al[4], bh[2], ahx[4], blx[2], ahy[4], bly[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { al[t] = rd_a(smem, 1, t); ahx[t] = rd_a(smem, 0, t); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { bh[t] = rd_b(smem, 0, t); blx[t] = rd_b(smem, 1, t); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int wbase = (tid & ~63) * 4;
+  auto dma = [&](bool on, const float* src, float* dst) __attribute__((always_inline)) {
+    if (on)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto term = [&](const f16x8 (&x)[4], const f16x8 (&y)[2], auto behind) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[m >> 1], y[m & 1], acc[m >> 1][m & 1], 0, 0, 0);
+      behind(m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int cur = 0;
+  // one step: lo hi, hi hi, hi lo of step kt from (al, bh, AH, BL); step kt + 1 read into (al, bh, AHn, BLn)
+  auto step = [&](int kt, f16x8 (&AH)[4], f16x8 (&BL)[2], f16x8 (&AHn)[4], f16x8 (&BLn)[2], auto variant) __attribute__((always_inline)) {
+    constexpr int V = decltype(variant)::value;
+    constexpr int RQ = V == 0 ? 1 : 5;                             // the request slots of this wave group (odd: reads take the even ones)
+    const int nxt = cur + 1 == NST ? 0 : cur + 1;
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool rf = kt + 3 < nk;
+    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (2 * RG_F);
+    const float* qb = pb + (int64_t)(kb0 + kt + 3) * (2 * RG_F);
+    float* Sc = smem + cur * H2_STAGE_F + wbase;
+    const float* Sn = smem + nxt * H2_STAGE_F;
+    __builtin_amdgcn_sched_barrier(0);
+    term(al, bh, [&](int m) __attribute__((always_inline)) {          // lo hi; meanwhile the next step's A hi
+      if (m == 0) AHn[0] = rd_a(Sn, 0, 0);
+      if (m == RQ) dma(rf, qa, Sc);
+      if (m == 2) AHn[1] = rd_a(Sn, 0, 1);
+      if (m == 4) AHn[2] = rd_a(Sn, 0, 2);
+      if (m == 6) AHn[3] = rd_a(Sn, 0, 3);
+    });
+    term(AH, bh, [&](int m) __attribute__((always_inline)) {          // hi hi; A lo is free: the next step's
+      if (m == 0) al[0] = rd_a(Sn, 1, 0);
+      if (m == RQ) dma(rf, qa + RG_F, Sc + PLANE_F);
+      if (m == 2) al[1] = rd_a(Sn, 1, 1);
+      if (m == RQ + 2) dma(rf, qb, Sc + OPA_F);
+      if (m == 4) al[2] = rd_a(Sn, 1, 2);
+      if (m == 6) al[3] = rd_a(Sn, 1, 3);
+    });
+    term(AH, BL, [&](int m) __attribute__((always_inline)) {          // hi lo; B hi is free: the next step's, and B lo into the other set
+      if (m == 0) bh[0] = rd_b(Sn, 0, 0);
+      if (m == RQ) dma(rf, qb + RG_F, Sc + OPA_F + PLANE_F);
+      if (m == 2) bh[1] = rd_b(Sn, 0, 1);
+      if (m == 4) BLn[0] = rd_b(Sn, 1, 0);
+      if (m == 6) BLn[1] = rd_b(Sn, 1, 1);
+    });
+    cur = nxt;
+  };
+  auto run = [&](auto variant) __attribute__((always_inline)) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(kt, ahx, blx, ahy, bly, variant);
+      step(kt + 1, ahy, bly, ahx, blx, variant);
+    }
+    if (kt < nk) step(kt, ahx, blx, ahy, bly, variant);
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                    // the epilogue reuses the ring
+
+  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
+}
+
 // ---- one plane x one plane: the plain bf16 product on operand images ("b1") -------------------------------------------------------
 // C = A . B^T for operands that ARE bfloat16 (--compute_dtype=bfloat16: BASELINE configs[4] and the bf16 variants), both given as
 // ONE-plane images -- [rows / 32][K / 16][32 rows][2 halves][8] bf16, what yt8m_bf16_image writes straight from the fp32 source.
@@ -888,12 +1024,14 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
 // matrix of partial sums, plain and rowscale-weighted -- so that the bias gradient colsum(dz) and the rank-1 remainder
 // colsum(r (.) dz) of the recurrent layers ride on the pass that reads dz anyway instead of two more passes over it at the very end
 // of the backward pass (a fixed-order sum of the partials follows: deterministic).
+// NP = 2: h2 images (two IEEE-half planes, csrc/x3_image.h) of dscale[0] . scale . src (dscale: device word or NULL).
 template <int NP>
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
                                                        float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
                                                        float* __restrict__ trans_s, float* __restrict__ colpart = nullptr,
-                                                       float* __restrict__ colpart_s = nullptr) {
+                                                       float* __restrict__ colpart_s = nullptr, const float* __restrict__ dscale = nullptr) {
   __shared__ float T[64][65];
+  if (dscale) scale *= dscale[0];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
   {
@@ -939,7 +1077,8 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = T[a][blk * 16 + j];
-      store_block<NP>(v, plain + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+      if constexpr (NP == 2) yt8m_x3::store_block_h2(v, plain + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+      else store_block<NP>(v, plain + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
     }
   }
   if (trans || trans_s) {
@@ -949,14 +1088,18 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = T[blk * 16 + j][a];
-      if (trans) store_block<NP>(v, trans + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+      if (trans) {
+        if constexpr (NP == 2) yt8m_x3::store_block_h2(v, trans + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+        else store_block<NP>(v, trans + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+      }
       if (trans_s) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int r = r0 + blk * 16 + j;
           v[j] *= r < R ? rowscale[r] : 0.f;
         }
-        store_block<NP>(v, trans_s + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+        if constexpr (NP == 2) yt8m_x3::store_block_h2(v, trans_s + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
+        else store_block<NP>(v, trans_s + ((int64_t)(row >> 5) * KB + kb) * (NP * RG_F), row);
       }
     }
   }
@@ -1005,6 +1148,70 @@ extern "C" int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t l
   hipLaunchKernelGGL(x3_split_kernel<1>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   return launch_status("x3_split_kernel");
+}
+
+// fp32 src [R, C] -> h2 images (two IEEE-half planes, yt8m_x3_image_bytes(rows, K) * 2 / 3 bytes each): plain [R rows, K = C] and / or
+// trans [C rows, K = R] of dscale[0] . scale . src.  The caller owns the scale: |scale . src| must stay below 65504 (it is clamped),
+// and the product's alpha carries its inverse.  colpart (may be NULL): per-64-row-tile column sums of the SCALED source, as
+// yt8m_x3_split_colsum (divide by the scale to use them).
+extern "C" int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* dscale, void* plain, void* trans,
+                             float* colpart, yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans)) & 15) == 0, YT8M_E_BADARG,
+               "images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  if (!dscale) {
+    if (plain) yt8m_wimg_note_demand(src, R, C, ld, 0, 2, scale);
+    if (trans) yt8m_wimg_note_demand(src, R, C, ld, 1, 2, scale);
+  }
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, colpart, (float*)nullptr, dscale);
+  return launch_status("x3_split_kernel<2>");
+}
+
+namespace {
+// max |src| -> the bit pattern of a non-negative float orders like the float: one atomicMax per workgroup, order independent
+__global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, unsigned* __restrict__ word) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const int64_t n = (int64_t)R * Cc;
+  if (ld == Cc && (Cc & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+      const float4 x = *reinterpret_cast<const float4*>(src + i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / Cc, c = i - r * Cc;
+      m = fmaxf(m, fabsf(src[r * ld + c]));
+    }
+  }
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0 && m > 0.f && m < 3.0e38f) atomicMax(word, __float_as_uint(m));
+}
+__global__ void h2_scale_kernel(unsigned* __restrict__ word, int target, float* __restrict__ out) {
+  const float m = __uint_as_float(word[0]);
+  const float S = yt8m_x3::pow2_scale_for(m, target);
+  out[0] = S;
+  out[1] = 1.0f / S;                                                   // a power of two: exact
+  word[0] = 0u;                                                       // clean for the next use
+}
+}  // namespace
+
+// Chooses the scale of an h2 image ON THE DEVICE: out[0] = S = the power of two with max |src| S in [2^13, 2^14), out[1] = 1 / S (what
+// the product's dsa / dsb points at).  scratch: one zero-initialised 32-bit device word per concurrent call (left zero again).
+extern "C" int yt8m_h2_dynamic_scale(const float* src, int64_t R, int64_t C, int64_t ld, float* out, void* scratch, yt8m_stream_t stream) {
+  YT8M_REQUIRE(src && out && scratch && R >= 1 && C >= 1 && ld >= C && R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "bad arguments");
+  const int64_t n = R * C;
+  const unsigned blocks = (unsigned)std::min<int64_t>(2048, (n + 4095) / 4096);
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(h2_absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<unsigned*>(scratch));
+  hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(1), 0, as_stream(stream), static_cast<unsigned*>(scratch), 14, out);
+  return launch_status("h2_absmax_kernel");
 }
 
 // The same pass with a third output: trans_scaled = the x3 image of (diag(rowscale) . scale . src)^T ([C rows, K = R]); any of the
@@ -1112,9 +1319,11 @@ struct TileCounters {
 };
 TileCounters g_cnt;
 
+// PA: 3 / 1 = planes of the A image of the bf16 split kernels, 0 = the one-plane bf16 kernels, 2 = the h2 kernel (two f16 planes each)
 template <int PA>
 int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, float alpha,
-              void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+              void* workspace, int64_t workspace_bytes, yt8m_stream_t stream, const float* const* dsa = nullptr,
+              const float* const* dsb = nullptr, const float* alphas = nullptr) {
   XGroup G;
   G.nprob = 0;
   // one 144 KiB workgroup per CU.  YT8M_X3_SLOTS (tuning aid): the CU count the K-part choice assumes -- beside a half-chip
@@ -1141,7 +1350,9 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     g.ska = q.lda ? (int)q.lda : g.KB; g.skb = q.ldb ? (int)q.ldb : g.KB;
     g.tiles_m = (int)((q.M + TM - 1) / TM); g.tiles_n = (int)((q.N + TN - 1) / TN);
     g.accumulate = q.beta != 0.f;
-    g.rscale = rscale; g.cs = cs; g.cs_scale = cs_scale; g.alpha = alpha;
+    g.rscale = rscale; g.cs = cs; g.cs_scale = cs_scale; g.alpha = alphas ? alphas[i] : alpha;
+    g.dsa = dsa ? dsa[i] : nullptr; g.dsb = dsb ? dsb[i] : nullptr;
+    YT8M_REQUIRE(!(g.dsa || g.dsb || g.alpha != 1.0f) || (q.N % 4) == 0, YT8M_E_SHAPE, "a scaled product needs N % 4 == 0");
     // the last, partial round of this problem alone: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp)
     // + the fixup pass
     const int64_t T = (int64_t)g.tiles_m * g.tiles_n;
@@ -1176,13 +1387,15 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   G.ws = static_cast<float*>(workspace);
   G.cnt = fix > 0 ? g_cnt.take((int)fix) : nullptr;
   const int64_t grid = nfull + slots;
-  constexpr int LDS_BYTES = PA == 0 ? 2 * B1_STAGE_F * (int)sizeof(float) : NST * (PA + 3) * PLANE_F * (int)sizeof(float);
+  constexpr int LDS_BYTES = PA == 0 ? 2 * B1_STAGE_F * (int)sizeof(float)
+                            : PA == 2 ? NST * H2_STAGE_F * (int)sizeof(float) : NST * (PA + 3) * PLANE_F * (int)sizeof(float);
   static DeviceOnce lds_once;                                      // per device (a process-wide flag broke cuda:1)
   if constexpr (PA == 0) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_b1_kernel), LDS_BYTES));
-  else YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA == 0 ? 3 : PA>), LDS_BYTES));
+  else if constexpr (PA == 2) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_h2q_kernel), LDS_BYTES));
+  else YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA == 1 ? 1 : 3>), LDS_BYTES));
   double fl = 0.0;
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
-  ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : F_GEMM_X3), as_stream(stream), fl);
+  ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : (PA == 2 ? F_GEMM_H2 : F_GEMM_X3)), as_stream(stream), fl);
   // YT8M_B1_PIPE=0: the round-3 kernel (two 64 KiB stages, one barrier per four blocks) instead of gemm_b1q_kernel
   static const bool piped_env = getenv("YT8M_B1_PIPE") == nullptr || atoi(getenv("YT8M_B1_PIPE")) != 0;
   const bool piped = g_schedule_mode == 1 || (g_schedule_mode == 0 && piped_env);
@@ -1195,16 +1408,19 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
       hipLaunchKernelGGL(gemm_b1_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
     }
   }
+  else if constexpr (PA == 2) {
+    hipLaunchKernelGGL(gemm_h2q_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+  }
   else {
     // YT8M_X3_PIPE=0: the round-3 kernel (reads and requests issued in groups between the products)
     static const bool xpiped_env = getenv("YT8M_X3_PIPE") == nullptr || atoi(getenv("YT8M_X3_PIPE")) != 0;
     const bool xpiped = g_schedule_mode == 1 || (g_schedule_mode == 0 && xpiped_env);
     if (xpiped) {
       static DeviceOnce lds_once_xq;
-      YT8M_HIP_CHECK(lds_once_xq.lds(reinterpret_cast<const void*>(gemm_x3q_kernel<PA == 0 ? 3 : PA>), LDS_BYTES));
-      hipLaunchKernelGGL(gemm_x3q_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+      YT8M_HIP_CHECK(lds_once_xq.lds(reinterpret_cast<const void*>(gemm_x3q_kernel<PA == 1 ? 1 : 3>), LDS_BYTES));
+      hipLaunchKernelGGL(gemm_x3q_kernel<PA == 1 ? 1 : 3>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
     } else {
-      hipLaunchKernelGGL(gemm_x3_kernel<PA == 0 ? 3 : PA>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+      hipLaunchKernelGGL(gemm_x3_kernel<PA == 1 ? 1 : 3>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
     }
   }
   if (fix > 0 && !G.cnt) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
@@ -1238,6 +1454,16 @@ extern "C" int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs
                                        yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
   return x3_launch<0>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream);
+}
+
+// C[M,N] (+)= alpha_i . dsa_i[0] . dsb_i[0] . A . B^T (+ bias) from the h2 images of A ([M rows, K]) and B ([N rows, K]) (yt8m_h2_split):
+// three f16 MFMA products per element pair, fp32 accumulation.  alpha = 1 / (S_a S_b) of the images' scales where the host knows
+// them; dsa / dsb (arrays of nprob device pointers, entries or the arrays themselves may be NULL) point at device words holding
+// inverse scales chosen on the device (yt8m_h2_dynamic_scale).  yt8m_gemm_problem as in yt8m_gemm_x3_nt_grouped.
+extern "C" int yt8m_gemm_h2_nt_grouped(int nprob, const yt8m_gemm_problem* probs, const float* alphas, const float* const* dsa,
+                                       const float* const* dsb, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
+  return x3_launch<2>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream, dsa, dsb, alphas);
 }
 
 // The uint8 input projection: C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n], A a ONE-plane image (elements

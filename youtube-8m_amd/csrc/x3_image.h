@@ -45,4 +45,43 @@ __device__ __forceinline__ void store_block(const float (&v)[16], float* __restr
   }
 }
 
+
+// ---- "h2" images (round 5): TWO fp16 planes, a S = hi + lo ---------------------------------------------------------------------------
+// The same block layout with NP = 2 planes of IEEE half instead of bfloat16: hi = f16(a S), lo = f16(a S - hi) for a power-of-two
+// scale S that brings the operand's magnitude into the half range (|a S| is clamped to the largest half: an operand that outgrew its
+// scale degrades, it does not turn into inf).  11 + 11 significand bits: a S = hi + lo + r, |r| <= 2^-23 |a S| while lo is a normal
+// half (|a S| >= 2^-3), an absolute 2^-25 below that.  Three products (hi hi, hi lo, lo hi) then carry a b to 2^-21 relative --
+// the size of three fp32 roundings -- at HALF the matrix-pipe time of the six-product bf16 split (csrc/gemm_x3.hip gemm_h2q_kernel).
+__device__ __forceinline__ void split_h2(float x, unsigned& h1, unsigned& h2) {
+  x = fminf(fmaxf(x, -65504.f), 65504.f);                           // (NaN passes through fminf / fmaxf as the other operand: -> finite)
+  const _Float16 hi = (_Float16)x;
+  const _Float16 lo = (_Float16)(x - (float)hi);                    // exact difference, rounded once
+  h1 = (unsigned)__builtin_bit_cast(unsigned short, hi);
+  h2 = (unsigned)__builtin_bit_cast(unsigned short, lo);
+}
+__device__ __forceinline__ void store_block_h2(const float (&v)[16], float* __restrict__ dst, int row) {
+  const int r = row & 31, sw = (r >> 3) & 1;
+  dst += r * 8;
+  unsigned h[2][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) split_h2(v[j], h[0][j], h[1][j]);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    uint4 lo, hi;
+    lo.x = h[p][0] | (h[p][1] << 16);  lo.y = h[p][2] | (h[p][3] << 16);
+    lo.z = h[p][4] | (h[p][5] << 16);  lo.w = h[p][6] | (h[p][7] << 16);
+    hi.x = h[p][8] | (h[p][9] << 16);  hi.y = h[p][10] | (h[p][11] << 16);
+    hi.z = h[p][12] | (h[p][13] << 16); hi.w = h[p][14] | (h[p][15] << 16);
+    *reinterpret_cast<uint4*>(dst + p * RG_F + 4 * sw) = lo;
+    *reinterpret_cast<uint4*>(dst + p * RG_F + 4 * (sw ^ 1)) = hi;
+  }
+}
+// power-of-two scale that brings a magnitude m just below 2^target (vanishing / non-finite operands keep scale 1)
+__device__ __forceinline__ float pow2_scale_for(float m, int target) {
+  if (!(m > 7.9e-31f) || !(m < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(m, &e);
+  return ldexpf(1.f, target - e);
+}
+
 }  // namespace yt8m_x3

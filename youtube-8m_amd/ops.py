@@ -308,6 +308,83 @@ def gemm_x3_grouped(items):
     return outs
 
 
+# ---- h2: fp32 products as three f16 MFMA products of two-plane half images (csrc/gemm_x3.hip gemm_h2q_kernel, round 5) -------------
+class H2Image(X3Image):
+    """Two IEEE-half planes of S x (csrc/x3_image.h); `scale` = the host-side S (the caller's alpha carries 1 / S), `dinv` = a device
+    tensor whose element [1] is 1 / S_device when part of the scale was chosen on the device (yt8m_h2_dynamic_scale), else None."""
+    __slots__ = ("scale", "dinv")
+
+    def __init__(self, buf, rows, K, scale=1.0, dinv=None):
+        X3Image.__init__(self, buf, rows, K)
+        self.scale, self.dinv = float(scale), dinv
+
+
+def h2_dynamic_scale(x):
+    """Device tensor [S, 1 / S]: the power of two with max |x| S in [2^13, 2^14) (yt8m_h2_dynamic_scale)."""
+    _dev(x)
+    x, ld = _rowmajor2d(x)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    word = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().yt8m_h2_dynamic_scale(_p(x), x.shape[0], x.shape[1], ld, _p(out), _p(word), _stream()))
+    return out
+
+
+def h2_split(x, plain=True, trans=False, scale=1.0, dynamic=False):
+    """fp32 [R, C] -> (H2Image of x as an [R rows, K = C] operand or None, H2Image of x^T or None).  scale: host power of two with
+    |scale x| < 65504; dynamic=True: the scale is measured on the device instead (one more pass over x)."""
+    _dev(x)
+    x, ld = _rowmajor2d(x)
+    R, C = x.shape
+    lib = _lib.lib()
+    ds = h2_dynamic_scale(x) if dynamic else None
+    mk = lambda rows, K: torch.empty(max(lib.yt8m_x3_image_bytes(rows, K) // 3 * 2, 16), dtype=torch.uint8, device=x.device)
+    bp = mk(R, C) if plain else None
+    bt = mk(C, R) if trans else None
+    _lib.check(lib.yt8m_h2_split(_p(x), R, C, ld, float(scale), _p(ds), _p(bp), _p(bt), None, _stream()))
+    return (H2Image(bp, R, C, scale, ds) if plain else None, H2Image(bt, C, R, scale, ds) if trans else None)
+
+
+def gemm_h2_grouped(items):
+    """items: dicts(A=H2Image [M rows, K], B=H2Image [N rows, K], out=None fp32 [M,N], bias=None, beta=0.0) -> fp32 outputs
+    C = A . B^T from three f16 MFMA products of the two-plane operands (yt8m_gemm_h2_nt_grouped); the images' scales are undone in
+    the epilogue (host part as alpha, device part through pointers)."""
+    probs, outs, keep, alphas, dsa, dsb = [], [], [], [], [], []
+    for it in items:
+        A, B = it["A"], it["B"]
+        if not isinstance(A, H2Image) or not isinstance(B, H2Image):
+            raise TypeError("gemm_h2: operands must be H2Image")
+        if A.K != B.K:
+            raise ValueError("gemm_h2: inner dimensions differ (%d vs %d)" % (A.K, B.K))
+        M, N, K = A.rows, B.rows, A.K
+        out, beta, bias = it.get("out"), it.get("beta", 0.0), it.get("bias")
+        _dev(A.buf, B.buf, out, bias)
+        if out is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 needs an output tensor")
+            out = torch.empty((M, N), dtype=torch.float32, device=A.buf.device)
+        if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or (out.stride(1) != 1 and N != 1):
+            raise ValueError("gemm_h2: bad output tensor")
+        if bias is not None:
+            bias = _f32c(bias)
+        ldc = out.stride(0) if M > 1 else max(N, 1)
+        probs.append(_lib.GemmProblem(M, N, K, A.buf.data_ptr(), 0, B.buf.data_ptr(), 0, out.data_ptr(), ldc,
+                                      bias.data_ptr() if bias is not None else None, float(beta)))
+        alphas.append(1.0 / (A.scale * B.scale))
+        dsa.append(A.dinv.data_ptr() + 4 if A.dinv is not None else None)
+        dsb.append(B.dinv.data_ptr() + 4 if B.dinv is not None else None)
+        outs.append(out)
+        keep.append((A, B, bias))
+    ws = _workspace(outs[0].device)
+    for i in range(0, len(probs), 4):
+        n = len(probs[i:i + 4])
+        arr = (_lib.GemmProblem * n)(*probs[i:i + 4])
+        al = (ctypes.c_float * n)(*alphas[i:i + 4])
+        pa = (ctypes.c_void_p * n)(*dsa[i:i + 4])
+        pb = (ctypes.c_void_p * n)(*dsb[i:i + 4])
+        _lib.check(_lib.lib().yt8m_gemm_h2_nt_grouped(n, arr, al, pa, pb, _p(ws), ws.numel() * 4, _stream()))
+    return outs
+
+
 B1_IMAGES = os.environ.get("YT8M_BF16_IMAGES", "1") != "0"   # bf16 configuration: large products on one-plane operand images (gemm_b1_kernel)
 
 
