@@ -52,7 +52,8 @@ PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3", "gemm_x1x3",
             "vlad_rows", "vlad_cols",          # the streaming kernels of "netvlad", timed inside it, bytes declared
-            "netvlad_fwd"]                     # the whole forward pooling call with SURVEY.md 8(d)'s bytes (frames once + parameters)
+            "netvlad_fwd",                     # the whole forward pooling call with SURVEY.md 8(d)'s bytes (frames once + parameters)
+            "gemm_h2"]                         # fp32 products as three f16 MFMA products of two-plane half images (round 5)
 X3_PRODUCTS = 6.0                    # bf16 MFMA products per fp32 product in csrc/gemm_x3.hip
 
 
@@ -237,6 +238,9 @@ def family_peak(name, bf16, fwd_x3=False):
     if name == "gemm_x3":
         return bfp / X3_PRODUCTS, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / %d products per fp32 product "
                                    "(v_mfma_f32_32x32x16_bf16 on three-plane split operands)" % (bfp, X3_PRODUCTS))
+    if name == "gemm_h2":
+        return bfp / 3.0, ("f16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (v_mfma_f32_32x32x16_f16 on "
+                           "two-plane half splits of both operands: hi hi + hi lo + lo hi)" % bfp)
     if name == "gemm_x1x3":
         return bfp / 3.0, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (one exact bf16 plane "
                            "-- uint8 frames minus 128 -- against a three-plane split operand)" % bfp)

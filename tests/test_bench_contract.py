@@ -211,6 +211,7 @@ def test_family_peaks_follow_the_pipe_the_kernel_issues_on():
     pk = lambda *a, **k: b.family_peak(*a, **k)[0]
     assert pk("gemm", False) == 157.3 and pk("gemm", True) == 2500.0
     assert abs(pk("gemm_x3", False) - 2500.0 / 6) < 1e-9 and abs(pk("gemm_x1x3", False) - 2500.0 / 3) < 1e-9
+    assert abs(pk("gemm_h2", False) - 2500.0 / 3) < 1e-9
     assert pk("netvlad", False) == 1250.0 and pk("netvlad", True) == 2500.0
     assert pk("lstm_recurrence", False) == 157.3 and abs(pk("lstm_recurrence", False, fwd_x3=True) - 2500.0 / 6) < 1e-9
     assert pk("lstm_recurrence", True) == 2500.0 and pk("lstm_recurrence_bwd", True) == 2500.0 and pk("lstm_recurrence_bwd", False) == 157.3

@@ -95,7 +95,9 @@ def test_gemm_h2_grouped_equals_single_and_split_k(dev):
     b1 = ops.gemm_h2_grouped([dict(A=xt, B=t2)])[0]
     assert torch.equal(a, a1) and torch.equal(b, b1)
     ref = x.double().t() @ d1.double()
-    assert float((a.double() - ref).abs().max() / ref.abs().max()) < 6e-7
+    e32 = float((ops.gemm_simple(x, d1, transA=True).double() - ref).abs().max() / ref.abs().max())
+    eh = float((a.double() - ref).abs().max() / ref.abs().max())
+    assert eh < max(2.0 * e32, 6e-7), (eh, e32)
     # K = 19200 on 64 tiles: split along K
     A = torch.randn((1024, 19200), device=dev, generator=g)
     B = torch.randn((4096, 19200), device=dev, generator=g) * 1e-6
@@ -103,4 +105,6 @@ def test_gemm_h2_grouped_equals_single_and_split_k(dev):
     hb, _ = ops.h2_split(B, dynamic=True)
     c = ops.gemm_h2_grouped([dict(A=ha, B=hb)])[0]
     ref = A.double() @ B.double().t()
-    assert float((c.double() - ref).abs().max() / ref.abs().max()) < 1e-6
+    e32 = float((ops.gemm_simple(A, B, transB=True).double() - ref).abs().max() / ref.abs().max())
+    eh = float((c.double() - ref).abs().max() / ref.abs().max())
+    assert eh < max(2.0 * e32, 6e-7), (eh, e32)

@@ -172,7 +172,8 @@ def test_lstm_model_with_resident_images_is_bitwise_the_run_that_resplits(dev, f
     assert torch.equal(on[1], off[1]) and torch.equal(on[2], off[2])
     w0, w1 = ("RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l for l in range(2))
     alpha = float(np.float32(4.0 / 255.0))
-    assert (w0, 0, 64, 1, 3, alpha) in on[3] and (w1, 0, 256, 1, 3, 1.0) in on[3] and (w1, 0, 256, 0, 3, 1.0) in on[3], on[3]
+    # (the forward projection of layer 1 reads an h2 image under a device-measured scale since the h2 products: no resident x3 one)
+    assert (w0, 0, 64, 1, 3, alpha) in on[3] and (w1, 0, 256, 0, 3, 1.0) in on[3], on[3]
 
 
 # ---- single-pass NetVLAD forward (csrc/netvlad_fused.hip vlad_video_kernel) ---------------------------------------------

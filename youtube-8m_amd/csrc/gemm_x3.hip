@@ -1066,7 +1066,8 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
       } else {
         for (int r = 0; r < 64; ++r) acc += T[r][c];
       }
-      dst[(int64_t)blockIdx.y * Cc + c0 + c] = acc;
+      if constexpr (NP == 2) acc *= 1.0f / scale;                    // h2: T holds scale . src; the scale is a power of two, so this
+      dst[(int64_t)blockIdx.y * Cc + c0 + c] = acc;                  // is the sum of the unscaled column, bit for bit
     }
   }
   const int a = t & 63, blk = t >> 6;                               // row of the image within the tile, K block within the tile

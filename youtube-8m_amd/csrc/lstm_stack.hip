@@ -35,6 +35,7 @@ constexpr float U8_ALPHA = 4.0f / 255.0f;
 constexpr float U8_BETA = 128.0f * (4.0f / 255.0f) + (4.0f / 512.0f - 2.0f);   // dequantise(q) = alpha (q - 128) + beta
 constexpr int64_t X3_MIN_ROWS = 1024;                      // F * B below which the fp32-MFMA kernel's smaller tiles win (seq_ops.py)
 constexpr int64_t STEP_IMAGES_MAX_BYTES = 8LL << 30;       // per layer; larger launches keep the two-image exchange
+constexpr float H2_S = 8192.0f;                            // static scale of h2 images of operands bounded by 1 (LSTM outputs / states)
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
@@ -71,6 +72,8 @@ struct Plan {
   int64_t cpart[MAXL], cparts;                             // [F B / 64, 4H] per-tile column sums of dz (plain; layer 0 on uint8: r-weighted)
   bool colparts;                                           // every backward part is a multiple of 64 frame rows: the sums ride on the split
   int img_rows;                                            // > 0: the backward recurrences write dz's operand images themselves (round 4)
+  int h2;                                                  // layers >= 1: projection and weight gradients as three f16 products (round 5)
+  int64_t hsc;                                             // ... their device-side scale words: 256 B per layer
   int64_t cimg[MAXL], cimgs;                               // their column-sum partials: [img_rows x launches][4H] per layer
   int64_t scratch_bytes;
 };
@@ -180,7 +183,14 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // Built, bit-exact (tests/test_gpu_round4.py) and measured SLOWER (profiles/r4_sched_knobs.md: 23.35 against 22.45 ms per headline
   // step): the extra stores and ~600 VALU operations per item slow the recurrence itself by more than the split passes cost -- the
   // same verdict as round 3's attempt in the team epilogue.  Off by default; YT8M_STACK_FUSED_IMAGES=1 opts in.
-  p.img_rows = (knob("YT8M_STACK_FUSED_IMAGES", 0) && !p.bf16) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
+  // Round 5: the hoisted products of the layers above the first whose result is a sum over frame rows or whose operand rows share one
+  // magnitude -- the input projection (outputs of the layer below: |h| < 1) and both weight gradients (h^T / out^T against dz^T) -- run
+  // as THREE f16 products of two-plane half images (gemm_h2q_kernel: 1.6x the six-product kernel) with a static scale 2^13 on the
+  // bounded operand and a device-measured scale on the weights / on each backward part's dz.  dx = dz . W_x^T keeps the six-product
+  // form (a time step whose gradient has decayed by 2^-15 against the part's largest would lose precision under one scale per part),
+  // and so does layer 0 (its uint8 products are three-product forms already).  YT8M_STACK_H2=0 keeps every product on the bf16 split.
+  p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16 && p.L >= 2) ? 1 : 0;
+  p.img_rows = (knob("YT8M_STACK_FUSED_IMAGES", 0) && !p.bf16 && !p.h2) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
   const int64_t trows = p.img_rows ? p.FB : bmax;
   for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(ib(H4, trows)); }
   p.dzT3s = o; o += p.u8 ? up256(ib(H4, trows)) : 0;
@@ -189,6 +199,7 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.cimgs = o; o += p.u8 ? ci : 0;
   p.csr = o; o += up256(H4 * 4);
   p.dbdummy = o; o += up256(H4 * 4);
+  p.hsc = o; o += 256 * MAXL;
   p.colparts = knob("YT8M_STACK_COLPARTS", 1) != 0;
   for (int c = 0; c < p.nb; ++c) p.colparts = p.colparts && (p.bp[c].t0 * p.B) % 64 == 0 && (p.bp[c].T * p.B) % 64 == 0;
   const int64_t cp = p.colparts ? up256(((p.FB + 63) / 64) * H4 * 4) : 0;
@@ -451,6 +462,14 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       }
       RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
     } else {
+      if (P.h2 && l >= 1) {                                  // W_x^T as an h2 image under a scale measured on the device
+        float* sc = at<float>(scratch, P.hsc + 256 * l);     // [S, 1 / S] at +0, the absmax scratch word at +32
+        YT8M_HIP_CHECK(hipMemsetAsync(sc + 8, 0, 4, s));
+        RC(yt8m_h2_dynamic_scale(W[l], Din, H4, H4, sc, sc + 8, (yt8m_stream_t)s));
+        RC(yt8m_h2_split(W[l], Din, H4, H4, 1.0f, sc, nullptr, at<char>(scratch, P.wxt3[l]), nullptr, (yt8m_stream_t)s));
+        wxt_img[l] = at<char>(scratch, P.wxt3[l]);
+        continue;
+      }
       wxt_img[l] = yt8m_wimg_lookup(W[l], Din, H4, H4, 1, bf ? 1 : 3, 1.0f);                       // W_x^T: rows 4H, K = Din
       if (!wxt_img[l]) {
         RC(split(W[l], Din, H4, H4, 1.0f, nullptr, at<char>(scratch, P.wxt3[l]), s));
@@ -482,9 +501,17 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
         RC(prc);
       } else {
         const float* src = l ? at<float>(tape, P.out[l - 1]) + t0 * B * H : static_cast<const float*>(x) + t0 * B * D;
-        RC(split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
         yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, wxt_img[l], 0, zc, H4, b[l], 0.0f};
-        const int grc = bf ? yt8m_gemm_b1_nt_grouped(1, &pr, gw, P.gws_bytes, s) : yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
+        int grc;
+        if (P.h2 && l >= 1) {                                // |out_{l-1}| < 1: static scale 2^13; the weights' inverse scale from the device
+          RC(yt8m_h2_split(src, M, Din, Din, H2_S, nullptr, at<char>(scratch, P.xi[l]), nullptr, nullptr, (yt8m_stream_t)s));
+          const float alpha = 1.0f / H2_S;
+          const float* dsb = at<float>(scratch, P.hsc + 256 * l) + 1;
+          grc = yt8m_gemm_h2_nt_grouped(1, &pr, &alpha, nullptr, &dsb, gw, P.gws_bytes, (yt8m_stream_t)s);
+        } else {
+          RC(split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
+          grc = bf ? yt8m_gemm_b1_nt_grouped(1, &pr, gw, P.gws_bytes, s) : yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
+        }
         yt8m_x3_set_combine(0);
         RC(grc);
       }
@@ -521,7 +548,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   Ev ev(*S, 1);
   hipStream_t main = as_stream(stream), sw = S->sw;
   static const int dx_stream = knob("YT8M_STACK_DX_STREAM", 0), two_sw = knob("YT8M_STACK_SW2", 0);
-  const int fuse_dz = knob("YT8M_STACK_FUSE_DZ_SPLIT", 0);
+  const int fuse_dz = P.h2 ? 0 : knob("YT8M_STACK_FUSE_DZ_SPLIT", 0);
   const int64_t B = P.B, D = P.D, H = P.H, H4 = 4 * H, BH = B * H, FB = P.FB;
   const int64_t KBtot = FB / 16;
   const bool bf = P.bf16 != 0;                             // one-plane operand images + the b1 kernel (see yt8m_lstm_stack_fwd)
@@ -544,9 +571,11 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     } else {
       const float* src = l ? at<float>(tape, P.out[l - 1]) : static_cast<const float*>(x);
       const int64_t Din = l ? H : D;
-      RC(split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
+      if (P.h2 && l >= 1) RC(yt8m_h2_split(src, FB, Din, Din, H2_S, nullptr, nullptr, at<char>(scratch, P.xT[l]), nullptr, (yt8m_stream_t)sw));
+      else RC(split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
     }
-    RC(split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));            // h_{t-1}: hs[0 .. F)
+    if (P.h2 && l >= 1) RC(yt8m_h2_split(at<float>(tape, P.hs[l]), FB, H, H, H2_S, nullptr, nullptr, at<char>(scratch, P.hT[l]), nullptr, (yt8m_stream_t)sw));
+    else RC(split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));            // h_{t-1}: hs[0 .. F)
   }
   // Host hook (yt8m_lstm_stack_set_prep_hook): work the caller wants on the weight-gradient stream in the window where that stream
   // is idle and half the chip is free -- behind the image preparation, while the top layer's first recurrence (enqueued below on
@@ -712,6 +741,20 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * KBB, KBtot, dzT_img, 0,
                                   dW[0] + D * H4, H4, nullptr, bW};
           RC(gemm(1, &pr, gw, P.gws_bytes, sw));
+        } else if (P.h2 && l >= 1) {
+          // three f16 products: dz^T of this part under a scale measured on the device (a sum over the part's frame rows: one scale
+          // serves it), h^T / out^T under the static 2^13; the bias gradient's per-tile column sums ride on the split as before
+          float* sc = at<float>(scratch, P.hsc + 256 * l) + 16;                                  // [S, 1 / S] at +64 B, word at +96 B
+          YT8M_HIP_CHECK(hipMemsetAsync(sc + 8, 0, 4, sw));
+          RC(yt8m_h2_dynamic_scale(dzc, M, H4, H4, sc, sc + 8, (yt8m_stream_t)sw));
+          float* cp = (P.colparts && db[l]) ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
+          RC(yt8m_h2_split(dzc, M, H4, H4, 1.0f, sc, nullptr, at<char>(scratch, P.dzT3[l]), cp, (yt8m_stream_t)sw));
+          yt8m_gemm_problem pr[2] = {
+              {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
+              {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
+          const float alphas[2] = {1.0f / H2_S, 1.0f / H2_S};
+          const float* dsb[2] = {sc + 1, sc + 1};
+          RC(yt8m_gemm_h2_nt_grouped(2, pr, alphas, nullptr, dsb, gw, P.gws_bytes, (yt8m_stream_t)sw));
         } else {
           if (fused_img) {
           } else if (!fused_t) {
