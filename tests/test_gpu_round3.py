@@ -279,12 +279,17 @@ def test_layer0_weight_gradient_from_uint8_frames(dev):
 
 
 # ---- the whole stack behind the C ABI ----------------------------------------------------------------------------
+@pytest.mark.parametrize("h2", [0, 1])
 @pytest.mark.parametrize("B,F,D,H,L_,ragged", [(32, 40, 96, 256, 2, True), (128, 24, 1152, 1024, 2, True), (64, 32, 128, 512, 1, False)])
-def test_native_stack_equals_the_python_orchestration(dev, monkeypatch, B, F, D, H, L_, ragged):
+def test_native_stack_equals_the_python_orchestration(dev, monkeypatch, B, F, D, H, L_, ragged, h2):
     """yt8m_lstm_stack_fwd / _bwd (float input, dx requested) against the Python orchestration of the same per-call entry points on
-    the same partition: forward results are bit-identical (same kernels, same operands); gradients agree to fp32 rounding (the
-    weight-gradient products read K ranges of whole-sequence images instead of per-part images: same values, same summation)."""
+    the same partition.  h2 = 0 (YT8M_STACK_H2=0: every hoisted product on the six-product bf16 split, as the orchestration):
+    forward results are bit-identical (same kernels, same operands); gradients agree to fp32 rounding (the weight-gradient products
+    read K ranges of whole-sequence images instead of per-part images: same values, same summation).  h2 = 1 (the default since
+    round 5: layers >= 1 take their projection and weight gradients as three f16 products): the same function to the products'
+    2^-21 -- outputs to 5e-6, gradients to 2e-5 of their scale."""
     from test_gpu_round2 import _stack_run
+    monkeypatch.setenv("YT8M_STACK_H2", str(h2))
     if not L.lib().yt8m_lstm_persist_bwd_supported(B, H):
         pytest.skip("persistent recurrence not available for this shape / device")
     nf = None
@@ -298,9 +303,10 @@ def test_native_stack_equals_the_python_orchestration(dev, monkeypatch, B, F, D,
     b, gb, _, _ = _stack_run(dev, B, F, D, H, L_, 2, nf, True)
     assert seq_ops.NATIVE_CALLS["fwd"] == n0["fwd"] + 1
     for u, v in zip(a, b):
-        assert torch.equal(u, v)
+        assert torch.equal(u, v) if (h2 == 0 or L_ == 1) else float((u - v).abs().max()) <= 5e-6
+    tol = 2e-6 if (h2 == 0 or L_ == 1) else 2e-5
     for u, v in zip(ga, gb):
-        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-9
+        assert float((u - v).abs().max()) <= tol * float(v.abs().max()) + 1e-9
 
 
 def test_full_lstm_model_step_through_the_c_abi_only(dev, flags):

@@ -49,7 +49,17 @@ bool x3_allowed(const yt8m_gemm_problem& q) {
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
-struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; };
+struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; bool h2; };
+
+// Round 5: a weight gradient dW = x^T . dz (transA, !transB) sums over the rows of BOTH stored operands, neither of which is a weight:
+// one power-of-two scale per operand, measured on the device, serves every term of every output element -- such a product runs as
+// THREE f16 products of two-plane half images (gemm_h2q_kernel, 1.6x the six-product kernel).  Forward products and dx read a weight
+// (whose six-product image is resident, csrc/wimg.hip) and keep the bf16 split.  YT8M_GEMM_H2=0 turns it off.
+bool h2_role(int transA, int transB) {
+  static const bool off = getenv("YT8M_GEMM_H2") != nullptr && atoi(getenv("YT8M_GEMM_H2")) == 0;
+  return !off && transA != 0 && transB == 0;
+}
+constexpr int64_t H2_SCALE_BYTES = 256;                  // [S, 1 / S] + the absmax scratch word, in front of an h2 image in the scratch
 
 // operand image kept current by the optimiser pass (csrc/wimg.hip): no split, no scratch
 const void* resident(const void* src, int64_t R, int64_t C, int64_t ld, bool trans) {
@@ -67,6 +77,10 @@ extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int npro
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     if (!x3_allowed(q)) continue;
+    if (h2_role(transA, transB) && (q.N % 4) == 0) {      // (h2 images are 2/3 of these sizes; the scale words sit in front)
+      n += 2 * H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.M, q.K)) + up256(yt8m_x3_image_bytes(q.N, q.K));
+      continue;
+    }
     if (!resident(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0)) n += up256(yt8m_x3_image_bytes(q.M, q.K));
     if (!resident(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0)) n += up256(yt8m_x3_image_bytes(q.N, q.K));
   }
@@ -82,18 +96,21 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
   YT8M_REQUIRE(nprob >= 1 && nprob <= 64 && probs, YT8M_E_BADARG, "1..64 problems per call");
   YT8M_REQUIRE((reinterpret_cast<uintptr_t>(image_scratch) & 255) == 0, YT8M_E_BADARG, "image scratch must be 256-byte aligned");
   std::vector<Img> imgs;
-  std::vector<yt8m_gemm_problem> px, p32;
+  std::vector<yt8m_gemm_problem> px, p32, ph;
+  std::vector<const float*> hda, hdb;                     // device inverse scales of the h2 problems' operands
   uint64_t mask = 0;
   int64_t off = 0;
   char* const base = static_cast<char*>(image_scratch);
+  const bool h2 = h2_role(transA, transB);
   auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, const void** at) -> bool {
-    if (const void* r = resident(src, R, C, ld, trans)) { *at = r; return true; }      // a weight matrix with a resident image
+    if (!h2)
+      if (const void* r = resident(src, R, C, ld, trans)) { *at = r; return true; }    // a weight matrix with a resident image
     for (const Img& m : imgs)
-      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans) { *at = base + m.off; return true; }
-    const int64_t bytes = up256(trans ? yt8m_x3_image_bytes(C, R) : yt8m_x3_image_bytes(R, C));
+      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans && m.h2 == h2) { *at = base + m.off; return true; }
+    const int64_t bytes = up256(trans ? yt8m_x3_image_bytes(C, R) : yt8m_x3_image_bytes(R, C)) + (h2 ? H2_SCALE_BYTES : 0);
     if (!image_scratch || off + bytes > image_scratch_bytes) return false;
-    imgs.push_back({src, R, C, ld, trans, off});
-    *at = base + off;
+    imgs.push_back({src, R, C, ld, trans, off + (h2 ? H2_SCALE_BYTES : 0), h2});      // (h2: [scale words | image])
+    *at = base + off + (h2 ? H2_SCALE_BYTES : 0);
     off += bytes;
     return true;
   };
@@ -110,11 +127,18 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
            image_of(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0, &ib);
       if (!x3) { imgs.resize(nimg); off = mark; }          // not enough scratch for this one: fp32 kernel
     }
+    if (x3 && h2 && (q.N % 4) != 0) { x3 = false; }          // (the scaled epilogue stores float4: odd widths stay on the fp32 kernel)
     if (x3) {
       yt8m_gemm_problem t = q;
       t.A = ia; t.lda = 0;
       t.B = ib; t.ldb = 0;
-      px.push_back(t);
+      if (h2) {
+        ph.push_back(t);
+        hda.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ia) - H2_SCALE_BYTES) + 1);
+        hdb.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ib) - H2_SCALE_BYTES) + 1);
+      } else {
+        px.push_back(t);
+      }
       mask |= 1ULL << i;
     } else {
       p32.push_back(q);
@@ -122,7 +146,21 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
   }
   for (const Img& m : imgs) {
     void* dst = static_cast<char*>(image_scratch) + m.off;
-    int rc = yt8m_x3_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, m.trans ? nullptr : dst, m.trans ? dst : nullptr, stream);
+    int rc;
+    if (m.h2) {                                            // scale measured on the device, then the two-plane half image under it
+      float* sc = reinterpret_cast<float*>(static_cast<char*>(dst) - H2_SCALE_BYTES);
+      YT8M_HIP_CHECK(hipMemsetAsync(sc + 8, 0, 4, as_stream(stream)));
+      rc = yt8m_h2_dynamic_scale(static_cast<const float*>(m.src), m.R, m.C, m.ld, sc, sc + 8, stream);
+      if (rc != YT8M_OK) return rc;
+      rc = yt8m_h2_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, sc, m.trans ? nullptr : dst, m.trans ? dst : nullptr, nullptr, stream);
+    } else {
+      rc = yt8m_x3_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, m.trans ? nullptr : dst, m.trans ? dst : nullptr, stream);
+    }
+    if (rc != YT8M_OK) return rc;
+  }
+  for (size_t lo = 0; lo < ph.size(); lo += 4) {
+    const int n = (int)std::min<size_t>(4, ph.size() - lo);
+    int rc = yt8m_gemm_h2_nt_grouped(n, &ph[lo], nullptr, &hda[lo], &hdb[lo], workspace, workspace_bytes, stream);
     if (rc != YT8M_OK) return rc;
   }
   for (size_t lo = 0; lo < px.size(); lo += 4) {
