@@ -115,15 +115,17 @@ int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
  * every operand element times a power-of-two scale S is split into two IEEE halves a S = hi + lo ("h2 image": the x3 image layout
  * with two half planes, yt8m_x3_image_bytes(rows, K) * 2 / 3 bytes) and C accumulates hi hi + hi lo + lo hi in fp32: 2^-21 |a b| per
  * term.  Half has five exponent bits, so the CALLER owns the scales: |scale . src| < 65504 (clamped), alpha = 1 / (S_a S_b) from the host
- * and / or dsa / dsb device words written by yt8m_h2_dynamic_scale.  Meant for products that sum over an operand's rows (weight
+ * and / or dsa / dsb device words written by yt8m_h2_absmax.  Meant for products that sum over an operand's rows (weight
  * gradients) or whose rows share one magnitude (l2-normalised inputs, LSTM outputs); per-row dynamic range stays on the x3 form.
- *   yt8m_h2_split         : src [R, C] -> plain ([R rows, K = C]) and / or trans ([C rows, K = R]) h2 images of dscale[0] . scale . src
- *                           (dscale may be NULL); colpart as yt8m_x3_split_colsum, of the scaled source.
- *   yt8m_h2_dynamic_scale : out[0] = S with max |src| S in [2^13, 2^14), out[1] = 1 / S; scratch = one zeroed 32-bit device word.
- *   yt8m_gemm_h2_nt_grouped: C_i (+)= alphas[i] . dsa[i][0] . dsb[i][0] . A_i . B_i^T (+ bias); alphas / dsa / dsb (or entries) may be NULL. */
+ *   yt8m_h2_absmax        : max |src| as float bits into a zeroed 32-bit device word (atomicMax).  The device-chosen scale of an operand
+ *                           is S_d = the power of two with max S_d in [2^13, 2^14); split and product both derive it from the word.
+ *   yt8m_h2_split         : src [R, C] -> plain ([R rows, K = C]) and / or trans ([C rows, K = R]) h2 images of S_d . scale . src
+ *                           (dscale = the operand's absmax word, or NULL: S_d = 1); colpart as yt8m_x3_split_colsum (of the UNscaled source).
+ *   yt8m_gemm_h2_nt_grouped: C_i (+)= alphas[i] / (S_d,a S_d,b) . A_i . B_i^T (+ bias); alphas / dsa / dsb (or entries) may be NULL
+ *                           (dsa[i] / dsb[i] = the absmax words of operands split with a device-chosen scale). */
 int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* dscale, void* plain, void* trans,
                   float* colpart, yt8m_stream_t stream);
-int yt8m_h2_dynamic_scale(const float* src, int64_t R, int64_t C, int64_t ld, float* out, void* scratch, yt8m_stream_t stream);
+int yt8m_h2_absmax(const float* src, int64_t R, int64_t C, int64_t ld, void* word, yt8m_stream_t stream);
 int yt8m_gemm_h2_nt_grouped(int nprob, const yt8m_gemm_problem* probs, const float* alphas, const float* const* dsa,
                             const float* const* dsb, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* Where the K parts of a split tile are summed by the following x3 / x1x3 / b1 launches OF THE CALLING THREAD: 0 = process default

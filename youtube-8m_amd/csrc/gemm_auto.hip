@@ -59,7 +59,7 @@ bool h2_role(int transA, int transB) {
   static const bool off = getenv("YT8M_GEMM_H2") != nullptr && atoi(getenv("YT8M_GEMM_H2")) == 0;
   return !off && transA != 0 && transB == 0;
 }
-constexpr int64_t H2_SCALE_BYTES = 256;                  // [S, 1 / S] + the absmax scratch word, in front of an h2 image in the scratch
+constexpr int64_t H2_SCALE_BYTES = 256;                  // the operand's absmax word (yt8m_h2_absmax), in front of its h2 image in the scratch
 
 // operand image kept current by the optimiser pass (csrc/wimg.hip): no split, no scratch
 const void* resident(const void* src, int64_t R, int64_t C, int64_t ld, bool trans) {
@@ -134,8 +134,8 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
       t.B = ib; t.ldb = 0;
       if (h2) {
         ph.push_back(t);
-        hda.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ia) - H2_SCALE_BYTES) + 1);
-        hdb.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ib) - H2_SCALE_BYTES) + 1);
+        hda.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ia) - H2_SCALE_BYTES));
+        hdb.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ib) - H2_SCALE_BYTES));
       } else {
         px.push_back(t);
       }
@@ -148,11 +148,11 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
     void* dst = static_cast<char*>(image_scratch) + m.off;
     int rc;
     if (m.h2) {                                            // scale measured on the device, then the two-plane half image under it
-      float* sc = reinterpret_cast<float*>(static_cast<char*>(dst) - H2_SCALE_BYTES);
-      YT8M_HIP_CHECK(hipMemsetAsync(sc + 8, 0, 4, as_stream(stream)));
-      rc = yt8m_h2_dynamic_scale(static_cast<const float*>(m.src), m.R, m.C, m.ld, sc, sc + 8, stream);
+      float* word = reinterpret_cast<float*>(static_cast<char*>(dst) - H2_SCALE_BYTES);    // max |src| as float bits
+      YT8M_HIP_CHECK(hipMemsetAsync(word, 0, 4, as_stream(stream)));
+      rc = yt8m_h2_absmax(static_cast<const float*>(m.src), m.R, m.C, m.ld, word, stream);
       if (rc != YT8M_OK) return rc;
-      rc = yt8m_h2_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, sc, m.trans ? nullptr : dst, m.trans ? dst : nullptr, nullptr, stream);
+      rc = yt8m_h2_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, word, m.trans ? nullptr : dst, m.trans ? dst : nullptr, nullptr, stream);
     } else {
       rc = yt8m_x3_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, m.trans ? nullptr : dst, m.trans ? dst : nullptr, stream);
     }

@@ -59,7 +59,8 @@ struct XArgs {
   const float* cs;
   float cs_scale;
   float alpha;
-  // device-side factors of alpha (NULL: 1): the inverse scales of h2 images whose scale was chosen on the device (round 5)
+  // device words with max |operand| (float bits; NULL: none): h2 images whose scale was chosen on the device (round 5) -- see
+  // fold_device_scales
   const float* dsa;
   const float* dsb;
 };
@@ -69,13 +70,19 @@ __device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int 
     v.x += g.cs_scale * cv.x; v.y += g.cs_scale * cv.y; v.z += g.cs_scale * cv.z; v.w += g.cs_scale * cv.w;
   }
   if (g.rscale) { const float rs = g.rscale[row]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-  if (g.alpha != 1.0f || g.dsa || g.dsb) {
-    const float al = g.alpha * (g.dsa ? g.dsa[0] : 1.0f) * (g.dsb ? g.dsb[0] : 1.0f);      // (powers of two: exact)
-    v.x *= al; v.y *= al; v.z *= al; v.w *= al;
-  }
+  if (g.alpha != 1.0f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
   return v;
 }
-__device__ __forceinline__ bool has_affine(const XArgs& g) { return g.rscale || g.cs || g.alpha != 1.0f || g.dsa || g.dsb; }
+__device__ __forceinline__ bool has_affine(const XArgs& g) { return g.rscale || g.cs || g.alpha != 1.0f; }
+// dsa / dsb: device words holding max |operand| as float bits (yt8m_h2_absmax): the operand's h2 image was made under the power of two
+// S = pow2_scale_for(max, 14), so the product is scaled back by 1 / (S_a S_b) -- folded into alpha ONCE per workgroup (exact: powers of two)
+__device__ __forceinline__ XArgs fold_device_scales(const XArgs& g) {
+  XArgs r = g;
+  if (g.dsa) r.alpha *= 1.0f / yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(g.dsa)[0]), 14);
+  if (g.dsb) r.alpha *= 1.0f / yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(g.dsb)[0]), 14);
+  r.dsa = r.dsb = nullptr;
+  return r;
+}
 // Work items of a launch: problem q contributes its first full[q] tiles (whole rounds of 256 workgroups) unsplit, then the
 // rem[q] tiles of its last, partial round as rem[q] * S[q] K-part items, part major -- the wave-quantisation tail costs a fraction
 // of a round instead of a whole one.  full / rem / S come from the shape of problem q ALONE, so a product is summed in the same
@@ -752,7 +759,8 @@ __global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                    // the epilogue reuses the ring
 
-  x_epilogue(G, g, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
+  const XArgs ge = fold_device_scales(g);
+  x_epilogue(G, ge, acc, smem, m0, n0, wm, wn, lane, wave, li, lk, nparts, slot, q, lt);
 }
 
 // ---- one plane x one plane: the plain bf16 product on operand images ("b1") -------------------------------------------------------
@@ -982,7 +990,7 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
 #pragma unroll
   for (int i = 1; i < 4; ++i)
     if (i < G.nprob && ft >= G.fix_base[i]) q = i;
-  const XArgs& g = G.p[q];
+  const XArgs g = fold_device_scales(G.p[q]);
   const int rt = ft - G.fix_base[q], S = G.S[q];
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, G.full[q] + rt, tm, tn);
@@ -1024,14 +1032,15 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const XGroup G) {
 // matrix of partial sums, plain and rowscale-weighted -- so that the bias gradient colsum(dz) and the rank-1 remainder
 // colsum(r (.) dz) of the recurrent layers ride on the pass that reads dz anyway instead of two more passes over it at the very end
 // of the backward pass (a fixed-order sum of the partials follows: deterministic).
-// NP = 2: h2 images (two IEEE-half planes, csrc/x3_image.h) of dscale[0] . scale . src (dscale: device word or NULL).
+// NP = 2: h2 images (two IEEE-half planes, csrc/x3_image.h) of S_d . scale . src, S_d = the power of two that brings the max |src| held
+// (as float bits) by the device word `dscale` into [2^13, 2^14) (NULL: 1).
 template <int NP>
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
                                                        float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
                                                        float* __restrict__ trans_s, float* __restrict__ colpart = nullptr,
                                                        float* __restrict__ colpart_s = nullptr, const float* __restrict__ dscale = nullptr) {
   __shared__ float T[64][65];
-  if (dscale) scale *= dscale[0];
+  if (dscale) scale *= yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(dscale)[0]), 14);
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
   {
@@ -1152,7 +1161,7 @@ extern "C" int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t l
 }
 
 // fp32 src [R, C] -> h2 images (two IEEE-half planes, yt8m_x3_image_bytes(rows, K) * 2 / 3 bytes each): plain [R rows, K = C] and / or
-// trans [C rows, K = R] of dscale[0] . scale . src.  The caller owns the scale: |scale . src| must stay below 65504 (it is clamped),
+// trans [C rows, K = R] of S_d . scale . src (S_d from the absmax word `dscale`, NULL: 1).  The caller owns `scale`: |scale . src| must stay below 65504 (it is clamped),
 // and the product's alpha carries its inverse.  colpart (may be NULL): per-64-row-tile column sums of the SCALED source, as
 // yt8m_x3_split_colsum (divide by the scale to use them).
 extern "C" int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* dscale, void* plain, void* trans,
@@ -1194,24 +1203,16 @@ __global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict_
   m = block_max_256(m, red);
   if (threadIdx.x == 0 && m > 0.f && m < 3.0e38f) atomicMax(word, __float_as_uint(m));
 }
-__global__ void h2_scale_kernel(unsigned* __restrict__ word, int target, float* __restrict__ out) {
-  const float m = __uint_as_float(word[0]);
-  const float S = yt8m_x3::pow2_scale_for(m, target);
-  out[0] = S;
-  out[1] = 1.0f / S;                                                   // a power of two: exact
-  word[0] = 0u;                                                       // clean for the next use
-}
 }  // namespace
 
-// Chooses the scale of an h2 image ON THE DEVICE: out[0] = S = the power of two with max |src| S in [2^13, 2^14), out[1] = 1 / S (what
-// the product's dsa / dsb points at).  scratch: one zero-initialised 32-bit device word per concurrent call (left zero again).
-extern "C" int yt8m_h2_dynamic_scale(const float* src, int64_t R, int64_t C, int64_t ld, float* out, void* scratch, yt8m_stream_t stream) {
-  YT8M_REQUIRE(src && out && scratch && R >= 1 && C >= 1 && ld >= C && R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "bad arguments");
+// max |src| into a device word (float bits, atomicMax: order independent; the word must be zero before, several calls may share it):
+// what yt8m_h2_split (dscale) and yt8m_gemm_h2_nt_grouped (dsa / dsb) turn into the image's scale S = 2^(14 - exponent) and its inverse.
+extern "C" int yt8m_h2_absmax(const float* src, int64_t R, int64_t C, int64_t ld, void* word, yt8m_stream_t stream) {
+  YT8M_REQUIRE(src && word && R >= 1 && C >= 1 && ld >= C && R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "bad arguments");
   const int64_t n = R * C;
   const unsigned blocks = (unsigned)std::min<int64_t>(2048, (n + 4095) / 4096);
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
-  hipLaunchKernelGGL(h2_absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<unsigned*>(scratch));
-  hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(1), 0, as_stream(stream), static_cast<unsigned*>(scratch), 14, out);
+  hipLaunchKernelGGL(h2_absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<unsigned*>(word));
   return launch_status("h2_absmax_kernel");
 }
 
@@ -1457,10 +1458,10 @@ extern "C" int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs
   return x3_launch<0>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream);
 }
 
-// C[M,N] (+)= alpha_i . dsa_i[0] . dsb_i[0] . A . B^T (+ bias) from the h2 images of A ([M rows, K]) and B ([N rows, K]) (yt8m_h2_split):
-// three f16 MFMA products per element pair, fp32 accumulation.  alpha = 1 / (S_a S_b) of the images' scales where the host knows
-// them; dsa / dsb (arrays of nprob device pointers, entries or the arrays themselves may be NULL) point at device words holding
-// inverse scales chosen on the device (yt8m_h2_dynamic_scale).  yt8m_gemm_problem as in yt8m_gemm_x3_nt_grouped.
+// C[M,N] (+)= alpha_i / (S_a S_b) . A . B^T (+ bias) from the h2 images of A ([M rows, K]) and B ([N rows, K]) (yt8m_h2_split):
+// three f16 MFMA products per element pair, fp32 accumulation.  alpha = 1 / (host-side scales of the images); dsa / dsb (arrays of
+// nprob device pointers, entries or the arrays themselves may be NULL) point at the absmax words (yt8m_h2_absmax) of operands whose
+// scale S was chosen on the device.  yt8m_gemm_problem as in yt8m_gemm_x3_nt_grouped.
 extern "C" int yt8m_gemm_h2_nt_grouped(int nprob, const yt8m_gemm_problem* probs, const float* alphas, const float* const* dsa,
                                        const float* const* dsb, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");

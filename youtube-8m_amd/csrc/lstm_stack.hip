@@ -463,10 +463,10 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
     } else {
       if (P.h2 && l >= 1) {                                  // W_x^T as an h2 image under a scale measured on the device
-        float* sc = at<float>(scratch, P.hsc + 256 * l);     // [S, 1 / S] at +0, the absmax scratch word at +32
-        YT8M_HIP_CHECK(hipMemsetAsync(sc + 8, 0, 4, s));
-        RC(yt8m_h2_dynamic_scale(W[l], Din, H4, H4, sc, sc + 8, (yt8m_stream_t)s));
-        RC(yt8m_h2_split(W[l], Din, H4, H4, 1.0f, sc, nullptr, at<char>(scratch, P.wxt3[l]), nullptr, (yt8m_stream_t)s));
+        float* word = at<float>(scratch, P.hsc + 256 * l);   // max |W_x| as float bits (the forward's word of this layer)
+        YT8M_HIP_CHECK(hipMemsetAsync(word, 0, 4, s));
+        RC(yt8m_h2_absmax(W[l], Din, H4, H4, word, (yt8m_stream_t)s));
+        RC(yt8m_h2_split(W[l], Din, H4, H4, 1.0f, word, nullptr, at<char>(scratch, P.wxt3[l]), nullptr, (yt8m_stream_t)s));
         wxt_img[l] = at<char>(scratch, P.wxt3[l]);
         continue;
       }
@@ -506,7 +506,7 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
         if (P.h2 && l >= 1) {                                // |out_{l-1}| < 1: static scale 2^13; the weights' inverse scale from the device
           RC(yt8m_h2_split(src, M, Din, Din, H2_S, nullptr, at<char>(scratch, P.xi[l]), nullptr, nullptr, (yt8m_stream_t)s));
           const float alpha = 1.0f / H2_S;
-          const float* dsb = at<float>(scratch, P.hsc + 256 * l) + 1;
+          const float* dsb = at<float>(scratch, P.hsc + 256 * l);
           grc = yt8m_gemm_h2_nt_grouped(1, &pr, &alpha, nullptr, &dsb, gw, P.gws_bytes, (yt8m_stream_t)s);
         } else {
           RC(split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
@@ -563,6 +563,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   ev.wait(sw, start);
   if (two_sw) ev.wait(S->sw2, start);
   for (int l = 0; l < P.L; ++l) { ev.wait(S->rs[l], start); if (dx_stream) ev.wait(S->dxs[l], start); }
+  if (P.h2) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc), 0, (size_t)256 * P.L, sw));      // the parts' absmax words (the forward's are done)
   // weight-gradient stream: the whole-sequence transposed operands (K = frame rows), made while the first recurrence runs alone
   for (int l = 0; l < P.L; ++l) {
     if (!dW[l]) continue;
@@ -744,16 +745,15 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         } else if (P.h2 && l >= 1) {
           // three f16 products: dz^T of this part under a scale measured on the device (a sum over the part's frame rows: one scale
           // serves it), h^T / out^T under the static 2^13; the bias gradient's per-tile column sums ride on the split as before
-          float* sc = at<float>(scratch, P.hsc + 256 * l) + 16;                                  // [S, 1 / S] at +64 B, word at +96 B
-          YT8M_HIP_CHECK(hipMemsetAsync(sc + 8, 0, 4, sw));
-          RC(yt8m_h2_dynamic_scale(dzc, M, H4, H4, sc, sc + 8, (yt8m_stream_t)sw));
+          float* word = at<float>(scratch, P.hsc + 256 * l) + 1 + c;                             // one word per backward part (zeroed at the start)
+          RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
           float* cp = (P.colparts && db[l]) ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
-          RC(yt8m_h2_split(dzc, M, H4, H4, 1.0f, sc, nullptr, at<char>(scratch, P.dzT3[l]), cp, (yt8m_stream_t)sw));
+          RC(yt8m_h2_split(dzc, M, H4, H4, 1.0f, word, nullptr, at<char>(scratch, P.dzT3[l]), cp, (yt8m_stream_t)sw));
           yt8m_gemm_problem pr[2] = {
               {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
               {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
           const float alphas[2] = {1.0f / H2_S, 1.0f / H2_S};
-          const float* dsb[2] = {sc + 1, sc + 1};
+          const float* dsb[2] = {word, word};
           RC(yt8m_gemm_h2_nt_grouped(2, pr, alphas, nullptr, dsb, gw, P.gws_bytes, (yt8m_stream_t)sw));
         } else {
           if (fused_img) {

@@ -310,8 +310,8 @@ def gemm_x3_grouped(items):
 
 # ---- h2: fp32 products as three f16 MFMA products of two-plane half images (csrc/gemm_x3.hip gemm_h2q_kernel, round 5) -------------
 class H2Image(X3Image):
-    """Two IEEE-half planes of S x (csrc/x3_image.h); `scale` = the host-side S (the caller's alpha carries 1 / S), `dinv` = a device
-    tensor whose element [1] is 1 / S_device when part of the scale was chosen on the device (yt8m_h2_dynamic_scale), else None."""
+    """Two IEEE-half planes of S x (csrc/x3_image.h); `scale` = the host-side S (the caller's alpha carries 1 / S), `dinv` = the device
+    word with max |x| (yt8m_h2_absmax) when the rest of the scale was chosen on the device, else None."""
     __slots__ = ("scale", "dinv")
 
     def __init__(self, buf, rows, K, scale=1.0, dinv=None):
@@ -319,14 +319,13 @@ class H2Image(X3Image):
         self.scale, self.dinv = float(scale), dinv
 
 
-def h2_dynamic_scale(x):
-    """Device tensor [S, 1 / S]: the power of two with max |x| S in [2^13, 2^14) (yt8m_h2_dynamic_scale)."""
+def h2_absmax(x):
+    """Device int32 word holding max |x| as float bits (yt8m_h2_absmax): the handle of a device-chosen h2 scale."""
     _dev(x)
     x, ld = _rowmajor2d(x)
-    out = torch.empty(2, dtype=torch.float32, device=x.device)
     word = torch.zeros(1, dtype=torch.int32, device=x.device)
-    _lib.check(_lib.lib().yt8m_h2_dynamic_scale(_p(x), x.shape[0], x.shape[1], ld, _p(out), _p(word), _stream()))
-    return out
+    _lib.check(_lib.lib().yt8m_h2_absmax(_p(x), x.shape[0], x.shape[1], ld, _p(word), _stream()))
+    return word
 
 
 def h2_split(x, plain=True, trans=False, scale=1.0, dynamic=False):
@@ -336,7 +335,7 @@ def h2_split(x, plain=True, trans=False, scale=1.0, dynamic=False):
     x, ld = _rowmajor2d(x)
     R, C = x.shape
     lib = _lib.lib()
-    ds = h2_dynamic_scale(x) if dynamic else None
+    ds = h2_absmax(x) if dynamic else None
     mk = lambda rows, K: torch.empty(max(lib.yt8m_x3_image_bytes(rows, K) // 3 * 2, 16), dtype=torch.uint8, device=x.device)
     bp = mk(R, C) if plain else None
     bt = mk(C, R) if trans else None
@@ -370,8 +369,8 @@ def gemm_h2_grouped(items):
         probs.append(_lib.GemmProblem(M, N, K, A.buf.data_ptr(), 0, B.buf.data_ptr(), 0, out.data_ptr(), ldc,
                                       bias.data_ptr() if bias is not None else None, float(beta)))
         alphas.append(1.0 / (A.scale * B.scale))
-        dsa.append(A.dinv.data_ptr() + 4 if A.dinv is not None else None)
-        dsb.append(B.dinv.data_ptr() + 4 if B.dinv is not None else None)
+        dsa.append(A.dinv.data_ptr() if A.dinv is not None else None)
+        dsb.append(B.dinv.data_ptr() if B.dinv is not None else None)
         outs.append(out)
         keep.append((A, B, bias))
     ws = _workspace(outs[0].device)
