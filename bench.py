@@ -53,7 +53,8 @@ PEAK_HBM_GBS = 8000.0
 FAMILIES = ["gemm", "moe_fused", "elementwise", "optimizer", "lstm_recurrence", "netvlad", "lstm_recurrence_bwd", "gemm_x3", "gemm_x1x3",
             "vlad_rows", "vlad_cols",          # the streaming kernels of "netvlad", timed inside it, bytes declared
             "netvlad_fwd",                     # the whole forward pooling call with SURVEY.md 8(d)'s bytes (frames once + parameters)
-            "gemm_h2"]                         # fp32 products as three f16 MFMA products of two-plane half images (round 5)
+            "gemm_h2",                         # fp32 products as three f16 MFMA products of two-plane half images (round 5)
+            "gemm_h1x2"]                       # ... with a one-plane exact operand (uint8 frames minus 128): two products
 X3_PRODUCTS = 6.0                    # bf16 MFMA products per fp32 product in csrc/gemm_x3.hip
 
 
@@ -241,6 +242,9 @@ def family_peak(name, bf16, fwd_x3=False):
     if name == "gemm_h2":
         return bfp / 3.0, ("f16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (v_mfma_f32_32x32x16_f16 on "
                            "two-plane half splits of both operands: hi hi + hi lo + lo hi)" % bfp)
+    if name == "gemm_h1x2":
+        return bfp / 2.0, ("f16 MFMA pipe, fp32-equivalent: dense peak %.0f / 2 products per fp32 product (one exact half plane -- uint8 "
+                           "frames minus 128 -- against a two-plane half split)" % bfp)
     if name == "gemm_x1x3":
         return bfp / 3.0, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (one exact bf16 plane "
                            "-- uint8 frames minus 128 -- against a three-plane split operand)" % bfp)

@@ -126,6 +126,19 @@ int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
 int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* dscale, void* plain, void* trans,
                   float* colpart, yt8m_stream_t stream);
 int yt8m_h2_absmax(const float* src, int64_t R, int64_t C, int64_t ld, void* word, yt8m_stream_t stream);
+/* h2 forms of yt8m_x3_split_colsum and yt8m_gemm_x1x3_nt_ex -- the uint8 layer-0 projection and weight gradient of the recurrent stack
+ * (readers.py:178-187 folded into lstm_model.py:34-47 and its gradient) as TWO f16 products: A1 = (q - 128) as a one-plane HALF image
+ * (exact; yt8m_u8_frames_image_f16 / _t_f16: the half forms of yt8m_u8_frames_image / _t), B2 = an h2 image under the device-chosen
+ * scale of the absmax word dsb.  C (+)= alpha . rowscale[m] . (A1 . B^T / S_b + colsum_scale . colsum[n]) + bias[n]. */
+int yt8m_h2_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const void* dscale, const float* rowscale, void* plain,
+                     void* trans, void* trans_scaled, float* colpart, float* colpart_scaled, yt8m_stream_t stream);
+int yt8m_gemm_h1x2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B2, int64_t skb, float* C, int64_t ldc,
+                         const float* bias, float alpha, const void* dsb, const float* rowscale, const float* colsum, float colsum_scale,
+                         float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_u8_frames_image_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
+                             float* x_tm, float* r_out, yt8m_stream_t stream);
+int yt8m_u8_frames_image_t_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, void* image_t,
+                               yt8m_stream_t stream);
 int yt8m_gemm_h2_nt_grouped(int nprob, const yt8m_gemm_problem* probs, const float* alphas, const float* const* dsa,
                             const float* const* dsb, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* Where the K parts of a split tile are summed by the following x3 / x1x3 / b1 launches OF THE CALLING THREAD: 0 = process default

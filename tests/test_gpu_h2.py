@@ -107,3 +107,75 @@ def test_gemm_h2_grouped_equals_single_and_split_k(dev):
     e32 = float((ops.gemm_simple(A, B, transB=True).double() - ref).abs().max() / ref.abs().max())
     eh = float((c.double() - ref).abs().max() / ref.abs().max())
     assert eh < max(2.0 * e32, 6e-7), (eh, e32)
+
+
+@pytest.mark.parametrize("t0", [0, 2])
+def test_u8_projection_and_weight_gradient_on_two_f16_products(dev, t0):
+    """The uint8 layer-0 products in their round-5 form (yt8m_gemm_h1x2_nt_ex): (q - 128) as a ONE-plane half image (exact) against
+    the two-plane half image of (4/255) W^T under a device-measured scale, affine epilogue = fp64 x . W + b to fp32 rounding; and the
+    weight gradient dW_x = x^T dz from the transposed half image of the frames against (r (.) dz)^T written by yt8m_h2_split_ex in
+    the pass that also writes dz^T and both per-tile column sums."""
+    import ctypes
+    import yt8m_amd._lib as L
+    from yt8m_amd.ops import _p, _stream
+    from oracle import np_ref
+    import yt8m_amd.seq_ops as seq_ops
+    rs = np.random.RandomState(6)
+    B, F, D, N = 32, 8, 1152, 512
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(0, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 0
+    W = (rs.randn(D, N) * 0.05).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    qd, nfd, Wd, bd = (torch.from_numpy(a).to(dev) for a in (q, nf, W, bias))
+    lib = L.lib()
+    img = torch.empty(((F * B + 31) // 32) * (D // 16) * 1024, dtype=torch.uint8, device=dev)
+    r = torch.empty((F * B,), dtype=torch.float32, device=dev)
+    L.check(lib.yt8m_u8_frames_image_f16(_p(qd), _p(nfd), B, F, D, 1e-12, _p(img), None, _p(r), _stream()))
+    alpha = 4.0 / 255.0
+    _, w2 = ops.h2_split(Wd, plain=False, trans=True, scale=alpha, dynamic=True)
+    cs = torch.empty((N,), dtype=torch.float32, device=dev)
+    ops.colsum(Wd, cs)
+    T = F - t0
+    rows = T * B - 5
+    z = torch.full((rows, N), float("nan"), device=dev)
+    ws = ops._workspace(dev)
+    L.check(lib.yt8m_gemm_h1x2_nt_ex(rows, N, D, _p(img[(t0 * B // 32) * (D // 16) * 1024:]), 0, _p(w2.buf), 0, _p(z), N, _p(bd), 1.0,
+                                     _p(w2.dinv), _p(r[t0 * B:]), _p(cs), seq_ops.U8_BETA, 0.0, _p(ws), ws.numel() * 4, _stream()))
+    x64 = np_ref.dequant_l2norm_folded(q, nf).transpose(1, 0, 2).reshape(F * B, D)
+    zr = x64[t0 * B:t0 * B + rows] @ W.astype(np.float64) + bias
+    assert np.abs(z.cpu().numpy() - zr).max() < 2e-6 * max(1.0, np.abs(zr).max())
+    # weight gradient of the time range [t0, F): dW_x = x^T dz
+    M = T * B
+    dz = (rs.randn(F * B, N) * 1e-4 * np.exp(rs.randn(F * B, 1))).astype(np.float32)
+    dzd = torch.from_numpy(dz).to(dev)
+    qT = torch.empty(((D + 31) // 32) * ((F * B + 15) // 16) * 1024, dtype=torch.uint8, device=dev)
+    L.check(lib.yt8m_u8_frames_image_t_f16(_p(qd), _p(nfd), B, F, D, _p(qT), _stream()))
+    part = dzd[t0 * B:]
+    word = ops.h2_absmax(part)
+    nb = lambda rows_, K: lib.yt8m_x3_image_bytes(rows_, K) // 3 * 2
+    dzT = torch.empty(nb(N, M), dtype=torch.uint8, device=dev)
+    dzTs = torch.empty(nb(N, M), dtype=torch.uint8, device=dev)
+    ntile = (M + 63) // 64
+    cp = torch.empty((ntile, N), device=dev)
+    cps = torch.empty((ntile, N), device=dev)
+    L.check(lib.yt8m_h2_split_ex(_p(part), M, N, N, 1.0, _p(word), _p(r[t0 * B:]), None, _p(dzT), _p(dzTs), _p(cp), _p(cps), _stream()))
+    dW = torch.full((D, N), 0.25, device=dev)
+    qTk = ctypes.c_void_p(qT.data_ptr() + (t0 * B // 16) * 1024)
+    csr = cps.sum(0).contiguous()
+    L.check(lib.yt8m_gemm_h1x2_nt_ex(D, N, M, qTk, F * B // 16, _p(dzTs), 0, _p(dW), N, None, alpha, _p(word), None, _p(csr),
+                                     seq_ops.U8_BETA / alpha, 1.0, _p(ws), ws.numel() * 4, _stream()))
+    ref = 0.25 + x64[t0 * B:].T @ dz[t0 * B:].astype(np.float64)
+    err = np.abs(dW.cpu().numpy().astype(np.float64) - ref).max()
+    assert err <= 2e-6 * np.abs(ref - 0.25).max() + 1e-7, err
+    # the per-tile column sums are those of the UNscaled source, plain and r-weighted
+    assert float((cp.sum(0).double() - torch.from_numpy(dz[t0 * B:].astype(np.float64).sum(0)).to(dev)).abs().max()) < 1e-5 * float(np.abs(dz).max()) * M
+    rw = r[t0 * B:].double().cpu().numpy()
+    assert np.abs(cps.sum(0).double().cpu().numpy() - (dz[t0 * B:].astype(np.float64) * rw[:, None]).sum(0)).max() < 1e-5 * float(np.abs(dz).max()) * M
+    # dz^T from the same pass serves the h-part gradient: h^T dz on three products
+    h = (rs.rand(F * B, 256) * 2 - 1).astype(np.float32)
+    _, hT = ops.h2_split(torch.from_numpy(h).to(dev)[t0 * B:], plain=False, trans=True, scale=8192.0)
+    dzT_img = ops.H2Image(dzT, N, M, 1.0, word)
+    dWh = ops.gemm_h2_grouped([dict(A=hT, B=dzT_img)])[0]
+    refh = h[t0 * B:].astype(np.float64).T @ dz[t0 * B:].astype(np.float64)
+    assert np.abs(dWh.cpu().numpy() - refh).max() <= 2e-6 * np.abs(refh).max() + 1e-9

@@ -41,7 +41,8 @@ enum Family { F_GEMM = 0, F_MOE_FUSED = 1, F_ELEMENTWISE = 2, F_OPTIM = 3, F_LST
               F_NETVLAD_FWD = 11,  // the whole yt8m_netvlad_fwd_u8 call with SURVEY.md 8(d)'s bytes (uint8 frames once + parameters):
                                    // the forward pooling against the HBM roof on the bytes the ALGORITHM needs
               F_GEMM_H2 = 12,      // fp32 products as three f16 MFMA products of two-plane half images (gemm_h2q_kernel, round 5)
-              F_COUNT = 13 };
+              F_GEMM_H1X2 = 13,    // ... with a ONE-plane exact A operand (uint8 frames minus 128): two products
+              F_COUNT = 14 };
 
 struct ProfScope {
   int fam;

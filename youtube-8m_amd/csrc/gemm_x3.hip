@@ -78,8 +78,11 @@ __device__ __forceinline__ bool has_affine(const XArgs& g) { return g.rscale || 
 // S = pow2_scale_for(max, 14), so the product is scaled back by 1 / (S_a S_b) -- folded into alpha ONCE per workgroup (exact: powers of two)
 __device__ __forceinline__ XArgs fold_device_scales(const XArgs& g) {
   XArgs r = g;
-  if (g.dsa) r.alpha *= 1.0f / yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(g.dsa)[0]), 14);
-  if (g.dsb) r.alpha *= 1.0f / yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(g.dsb)[0]), 14);
+  float S = 1.0f;
+  if (g.dsa) S *= yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(g.dsa)[0]), 14);
+  if (g.dsb) S *= yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(g.dsb)[0]), 14);
+  r.alpha *= 1.0f / S;
+  r.cs_scale *= S;                                                 // the rank-1 term joins the accumulator BEFORE alpha: it must carry the scale too
   r.dsa = r.dsb = nullptr;
   return r;
 }
@@ -646,11 +649,14 @@ __global__ __launch_bounds__(512) void gemm_x3q_kernel(const XGroup G) {
 // Schedule: gemm_x3q_kernel's (three one-block stages, step kt + 3 requested into the stage step kt was read from, every LDS read and
 // DMA request behind its own MFMA); per step 24 MFMAs, 12 fragment reads, 4 requests.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int H2_STAGE_F = 4 * PLANE_F;                              // A hi, A lo, B hi, B lo (32 KiB)
 
+// PA = 1: the A operand is ONE half plane whose elements are exact in half -- the uint8 frames minus 128 -- : two products a b_hi + a b_lo
+// (the uint8 layer-0 projection and weight gradient of the recurrent stack: "h1x2").
+template <int PA>
 __global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
-  constexpr int OPA_F = 2 * PLANE_F;
-  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * H2_STAGE_F floats (96 KiB)
+  constexpr int OPA_F = PA * PLANE_F;
+  constexpr int H2_STAGE_F = (PA + 2) * PLANE_F;                   // A planes, then B hi, B lo
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // NST * H2_STAGE_F floats (96 KiB at PA = 2)
   int q, nparts, part, slot, lt;
   x_work_item(G, q, nparts, part, slot, lt);
   const XArgs& g = G.p[q];
@@ -663,9 +669,9 @@ __global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
   const int li = lane & 31, lk = lane >> 5;
   const int kb0 = (int)((int64_t)g.KB * part / nparts), kb1 = (int)((int64_t)g.KB * (part + 1) / nparts);
   const int nk = kb1 - kb0;
-  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska * (2 * RG_F) + lane * 4;
+  const float* pa = g.A + (int64_t)min(m0 / 32 + wave, (g.M + 31) / 32 - 1) * g.ska * (PA * RG_F) + lane * 4;
   const float* pb = g.B + (int64_t)min(n0 / 32 + wave, (g.N + 31) / 32 - 1) * g.skb * (2 * RG_F) + lane * 4;
-  constexpr int DMA = 4;
+  constexpr int DMA = PA + 2;
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int pro = nk < 3 ? nk : 3;
-  for (int s = 0; s < pro; ++s) { fill_op<2>(pa, kb0 + s, smem + s * H2_STAGE_F, tid); fill_op<2>(pb, kb0 + s, smem + s * H2_STAGE_F + OPA_F, tid); }
+  for (int s = 0; s < pro; ++s) { fill_op<PA>(pa, kb0 + s, smem + s * H2_STAGE_F, tid); fill_op<2>(pb, kb0 + s, smem + s * H2_STAGE_F + OPA_F, tid); }
   if (pro == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA) : "memory");
   else if (pro == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -690,7 +696,10 @@ __global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
   // hi planes of A and lo planes of B are held to the end of a step: two register sets in alternation (as a0 / b2 of gemm_x3q_kernel)
   f16x8 al[4], bh[2], ahx[4], blx[2], ahy[4], bly[2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { al[t] = rd_a(smem, 1, t); ahx[t] = rd_a(smem, 0, t); }
+  for (int t = 0; t < 4; ++t) {
+    if constexpr (PA == 2) al[t] = rd_a(smem, 1, t);
+    ahx[t] = rd_a(smem, 0, t);
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) { bh[t] = rd_b(smem, 0, t); blx[t] = rd_b(smem, 1, t); }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -717,11 +726,30 @@ __global__ __launch_bounds__(512) void gemm_h2q_kernel(const XGroup G) {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool rf = kt + 3 < nk;
-    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (2 * RG_F);
+    const float* qa = pa + (int64_t)(kb0 + kt + 3) * (PA * RG_F);
     const float* qb = pb + (int64_t)(kb0 + kt + 3) * (2 * RG_F);
     float* Sc = smem + cur * H2_STAGE_F + wbase;
     const float* Sn = smem + nxt * H2_STAGE_F;
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PA == 1) {
+      term(AH, bh, [&](int m) __attribute__((always_inline)) {        // a b_hi; meanwhile the next step's A into the other set
+        if (m == 0) AHn[0] = rd_a(Sn, 0, 0);
+        if (m == RQ) dma(rf, qa, Sc);
+        if (m == 2) AHn[1] = rd_a(Sn, 0, 1);
+        if (m == 4) AHn[2] = rd_a(Sn, 0, 2);
+        if (m == 6) AHn[3] = rd_a(Sn, 0, 3);
+      });
+      term(AH, BL, [&](int m) __attribute__((always_inline)) {        // a b_lo; B hi is free: the next step's, and B lo into the other set
+        if (m == 0) bh[0] = rd_b(Sn, 0, 0);
+        if (m == RQ) dma(rf, qb, Sc + OPA_F);
+        if (m == 2) bh[1] = rd_b(Sn, 0, 1);
+        if (m == RQ + 2) dma(rf, qb + RG_F, Sc + OPA_F + PLANE_F);
+        if (m == 4) BLn[0] = rd_b(Sn, 1, 0);
+        if (m == 6) BLn[1] = rd_b(Sn, 1, 1);
+      });
+      cur = nxt;
+      return;
+    }
     term(al, bh, [&](int m) __attribute__((always_inline)) {          // lo hi; meanwhile the next step's A hi
       if (m == 0) AHn[0] = rd_a(Sn, 0, 0);
       if (m == RQ) dma(rf, qa, Sc);
@@ -1183,6 +1211,26 @@ extern "C" int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld,
   return launch_status("x3_split_kernel<2>");
 }
 
+// yt8m_h2_split with the outputs of yt8m_x3_split_colsum: trans_scaled = the h2 image of (diag(rowscale) . S_d . scale . src)^T, the
+// per-tile column sums plain and rowscale-weighted (of the UNscaled source); any output may be NULL (rowscale comes with its two).
+extern "C" int yt8m_h2_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const void* dscale, const float* rowscale,
+                                void* plain, void* trans, void* trans_scaled, float* colpart, float* colpart_scaled, yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && ld >= C && (plain || trans || trans_scaled), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE((rowscale != nullptr) == (trans_scaled != nullptr || colpart_scaled != nullptr), YT8M_E_BADARG,
+               "rowscale comes with trans_scaled / colpart_scaled");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans) | reinterpret_cast<uintptr_t>(trans_scaled)) & 15) == 0,
+               YT8M_E_BADARG, "images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled), colpart, colpart_scaled,
+                     static_cast<const float*>(dscale));
+  return launch_status("x3_split_kernel<2>");
+}
+
 namespace {
 // max |src| -> the bit pattern of a non-negative float orders like the float: one atomicMax per workgroup, order independent
 __global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, unsigned* __restrict__ word) {
@@ -1321,7 +1369,8 @@ struct TileCounters {
 };
 TileCounters g_cnt;
 
-// PA: 3 / 1 = planes of the A image of the bf16 split kernels, 0 = the one-plane bf16 kernels, 2 = the h2 kernel (two f16 planes each)
+// PA: 3 / 1 = planes of the A image of the bf16 split kernels, 0 = the one-plane bf16 kernels, 2 = the h2 kernel (two f16 planes each),
+// 4 = the h2 kernel with a ONE-plane exact A operand ("h1x2")
 template <int PA>
 int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, float alpha,
               void* workspace, int64_t workspace_bytes, yt8m_stream_t stream, const float* const* dsa = nullptr,
@@ -1390,14 +1439,16 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
   G.cnt = fix > 0 ? g_cnt.take((int)fix) : nullptr;
   const int64_t grid = nfull + slots;
   constexpr int LDS_BYTES = PA == 0 ? 2 * B1_STAGE_F * (int)sizeof(float)
-                            : PA == 2 ? NST * H2_STAGE_F * (int)sizeof(float) : NST * (PA + 3) * PLANE_F * (int)sizeof(float);
+                            : PA == 2 ? NST * 4 * PLANE_F * (int)sizeof(float)
+                            : PA == 4 ? NST * 3 * PLANE_F * (int)sizeof(float) : NST * (PA + 3) * PLANE_F * (int)sizeof(float);
   static DeviceOnce lds_once;                                      // per device (a process-wide flag broke cuda:1)
   if constexpr (PA == 0) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_b1_kernel), LDS_BYTES));
-  else if constexpr (PA == 2) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_h2q_kernel), LDS_BYTES));
-  else YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<PA == 1 ? 1 : 3>), LDS_BYTES));
+  else if constexpr (PA == 2) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_h2q_kernel<2>), LDS_BYTES));
+  else if constexpr (PA == 4) YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_h2q_kernel<1>), LDS_BYTES));
+  else YT8M_HIP_CHECK(lds_once.lds(reinterpret_cast<const void*>(gemm_x3_kernel<(PA == 1) ? 1 : 3>), LDS_BYTES));
   double fl = 0.0;
   for (int i = 0; i < nprob; ++i) fl += 2.0 * (double)probs[i].M * (double)probs[i].N * (double)probs[i].K;
-  ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : (PA == 2 ? F_GEMM_H2 : F_GEMM_X3)), as_stream(stream), fl);
+  ProfScope prof(PA == 0 ? F_GEMM : (PA == 1 ? F_GEMM_X1X3 : (PA == 2 ? F_GEMM_H2 : (PA == 4 ? F_GEMM_H1X2 : F_GEMM_X3))), as_stream(stream), fl);
   // YT8M_B1_PIPE=0: the round-3 kernel (two 64 KiB stages, one barrier per four blocks) instead of gemm_b1q_kernel
   static const bool piped_env = getenv("YT8M_B1_PIPE") == nullptr || atoi(getenv("YT8M_B1_PIPE")) != 0;
   const bool piped = g_schedule_mode == 1 || (g_schedule_mode == 0 && piped_env);
@@ -1411,7 +1462,10 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     }
   }
   else if constexpr (PA == 2) {
-    hipLaunchKernelGGL(gemm_h2q_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+    hipLaunchKernelGGL(gemm_h2q_kernel<2>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+  }
+  else if constexpr (PA == 4) {
+    hipLaunchKernelGGL(gemm_h2q_kernel<1>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
   }
   else {
     // YT8M_X3_PIPE=0: the round-3 kernel (reads and requests issued in groups between the products)
@@ -1419,10 +1473,10 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     const bool xpiped = g_schedule_mode == 1 || (g_schedule_mode == 0 && xpiped_env);
     if (xpiped) {
       static DeviceOnce lds_once_xq;
-      YT8M_HIP_CHECK(lds_once_xq.lds(reinterpret_cast<const void*>(gemm_x3q_kernel<PA == 1 ? 1 : 3>), LDS_BYTES));
-      hipLaunchKernelGGL(gemm_x3q_kernel<PA == 1 ? 1 : 3>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+      YT8M_HIP_CHECK(lds_once_xq.lds(reinterpret_cast<const void*>(gemm_x3q_kernel<(PA == 1) ? 1 : 3>), LDS_BYTES));
+      hipLaunchKernelGGL(gemm_x3q_kernel<(PA == 1) ? 1 : 3>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
     } else {
-      hipLaunchKernelGGL(gemm_x3_kernel<PA == 1 ? 1 : 3>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
+      hipLaunchKernelGGL(gemm_x3_kernel<(PA == 1) ? 1 : 3>, dim3((unsigned)grid), dim3(512), LDS_BYTES, as_stream(stream), G);
     }
   }
   if (fix > 0 && !G.cnt) hipLaunchKernelGGL(x3_fixup_kernel, dim3((unsigned)fix * 16), dim3(256), 0, as_stream(stream), G);
@@ -1466,6 +1520,21 @@ extern "C" int yt8m_gemm_h2_nt_grouped(int nprob, const yt8m_gemm_problem* probs
                                        const float* const* dsb, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
   return x3_launch<2>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream, dsa, dsb, alphas);
+}
+
+// C[M,N] (+)= alpha . rowscale[m] . (A1 . B^T / S_b + colsum_scale . colsum[n]) + bias[n]: A1 a ONE-plane HALF image whose elements are
+// exact (q - 128: yt8m_u8_frames_image_f16 / _t_f16), B an h2 image under the device-chosen scale S_b of the absmax word dsb (NULL:
+// S_b = 1): two f16 products per element pair -- the uint8 layer-0 projection and weight gradient (yt8m_gemm_x1x3_nt_ex's role at 2/3
+// of its matrix time).  ska / skb / beta / rowscale / colsum as there.
+extern "C" int yt8m_gemm_h1x2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B2, int64_t skb, float* C,
+                                    int64_t ldc, const float* bias, float alpha, const void* dsb, const float* rowscale, const float* colsum,
+                                    float colsum_scale, float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE((N % 4) == 0, YT8M_E_SHAPE, "the scaled epilogue needs N % 4 == 0");
+  YT8M_REQUIRE(!colsum || (reinterpret_cast<uintptr_t>(colsum) & 15) == 0, YT8M_E_SHAPE, "colsum must be 16-byte aligned");
+  yt8m_gemm_problem p;
+  p.M = M; p.N = N; p.K = K; p.A = A1; p.lda = ska; p.B = B2; p.ldb = skb; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
+  const float* dw = static_cast<const float*>(dsb);
+  return x3_launch<4>(1, &p, rowscale, colsum, colsum_scale, alpha, workspace, workspace_bytes, stream, nullptr, dsb ? &dw : nullptr);
 }
 
 // The uint8 input projection: C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n], A a ONE-plane image (elements

@@ -189,7 +189,7 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // bounded operand and a device-measured scale on the weights / on each backward part's dz.  dx = dz . W_x^T keeps the six-product
   // form (a time step whose gradient has decayed by 2^-15 against the part's largest would lose precision under one scale per part),
   // and so does layer 0 (its uint8 products are three-product forms already).  YT8M_STACK_H2=0 keeps every product on the bf16 split.
-  p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16 && p.L >= 2) ? 1 : 0;
+  p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16 && (p.L >= 2 || p.u8)) ? 1 : 0;
   p.img_rows = (knob("YT8M_STACK_FUSED_IMAGES", 0) && !p.bf16 && !p.h2) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
   const int64_t trows = p.img_rows ? p.FB : bmax;
   for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(ib(H4, trows)); }
@@ -452,6 +452,16 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
     YT8M_HIP_CHECK(hipMemsetAsync(at<char>(tape, P.cs[l]), 0, (size_t)BH * 4, s));
     YT8M_HIP_CHECK(hipMemsetAsync(at<char>(tape, P.hs[l]), 0, (size_t)BH * 4, s));
     if (l == 0 && P.u8) {
+      if (P.h2) {
+        // (q - 128) as a ONE-plane half image (exact), (alpha W_x)^T as an h2 image under a device-measured scale: two f16 products
+        RC(yt8m_u8_frames_image_f16(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, 1e-12f, at<char>(scratch, P.qimg), nullptr,
+                                    at<float>(tape, P.rrow), s));
+        float* word = at<float>(scratch, P.hsc);
+        YT8M_HIP_CHECK(hipMemsetAsync(word, 0, 4, s));
+        RC(yt8m_h2_absmax(W[0], D, H4, H4, word, (yt8m_stream_t)s));
+        RC(yt8m_h2_split(W[0], D, H4, H4, U8_ALPHA, word, nullptr, at<char>(scratch, P.w3t), nullptr, (yt8m_stream_t)s));
+        wxt_img[0] = at<char>(scratch, P.w3t);
+      } else {
       RC(yt8m_u8_frames_image(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, 1e-12f, at<char>(scratch, P.qimg), nullptr,
                               at<float>(tape, P.rrow), s));
       // (alpha W_x)^T: rows 4H, K = D -- resident when the optimiser pass keeps the weight's images current (csrc/wimg.hip)
@@ -459,6 +469,7 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       if (!wxt_img[0]) {
         RC(split(W[0], D, H4, H4, U8_ALPHA, nullptr, at<char>(scratch, P.w3t), s));
         wxt_img[0] = at<char>(scratch, P.w3t);
+      }
       }
       RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
     } else {
@@ -493,7 +504,9 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       if (chain_combine) yt8m_x3_set_combine(1);
       if (l == 0 && P.u8) {
         const char* qi = at<char>(scratch, P.qimg) + (t0 * B / 32) * (D / 16) * 1024;
-        const int prc = bf ? yt8m_gemm_b1_nt_ex(M, H4, D, qi, 0, wxt_img[0], 0, zc, H4, b[0], 1.0f, at<float>(tape, P.rrow) + t0 * B,
+        const int prc = P.h2 ? yt8m_gemm_h1x2_nt_ex(M, H4, D, qi, 0, wxt_img[0], 0, zc, H4, b[0], 1.0f, at<float>(scratch, P.hsc),
+                                                    at<float>(tape, P.rrow) + t0 * B, at<float>(scratch, P.wcs), U8_BETA, 0.f, gw, P.gws_bytes, s)
+                           : bf ? yt8m_gemm_b1_nt_ex(M, H4, D, qi, 0, wxt_img[0], 0, zc, H4, b[0], 1.0f, at<float>(tape, P.rrow) + t0 * B,
                                                 at<float>(scratch, P.wcs), U8_BETA, 0.f, gw, P.gws_bytes, s)
                            : yt8m_gemm_x1x3_nt(M, H4, D, qi, wxt_img[0], zc, H4, b[0], at<float>(tape, P.rrow) + t0 * B,
                                                at<float>(scratch, P.wcs), U8_BETA, gw, P.gws_bytes, s);
@@ -568,14 +581,15 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   for (int l = 0; l < P.L; ++l) {
     if (!dW[l]) continue;
     if (l == 0 && P.u8) {
-      RC(yt8m_u8_frames_image_t(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, at<char>(scratch, P.xT[0]), sw));
+      if (P.h2) RC(yt8m_u8_frames_image_t_f16(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, at<char>(scratch, P.xT[0]), sw));
+      else RC(yt8m_u8_frames_image_t(static_cast<const uint8_t*>(x), num_frames, B, P.F, D, at<char>(scratch, P.xT[0]), sw));
     } else {
       const float* src = l ? at<float>(tape, P.out[l - 1]) : static_cast<const float*>(x);
       const int64_t Din = l ? H : D;
       if (P.h2 && l >= 1) RC(yt8m_h2_split(src, FB, Din, Din, H2_S, nullptr, nullptr, at<char>(scratch, P.xT[l]), nullptr, (yt8m_stream_t)sw));
       else RC(split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
     }
-    if (P.h2 && l >= 1) RC(yt8m_h2_split(at<float>(tape, P.hs[l]), FB, H, H, H2_S, nullptr, nullptr, at<char>(scratch, P.hT[l]), nullptr, (yt8m_stream_t)sw));
+    if (P.h2 && (l >= 1 || P.u8)) RC(yt8m_h2_split(at<float>(tape, P.hs[l]), FB, H, H, H2_S, nullptr, nullptr, at<char>(scratch, P.hT[l]), nullptr, (yt8m_stream_t)sw));
     else RC(split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));            // h_{t-1}: hs[0 .. F)
   }
   // Host hook (yt8m_lstm_stack_set_prep_hook): work the caller wants on the weight-gradient stream in the window where that stream
@@ -723,7 +737,24 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       // (c == 0) instead of a column sum per part -- three launches fewer per part on the chain that ends the backward pass.
       const bool lastpart = c == 0 && j == 0;
       if (dW[l]) {
-        if (l == 0 && P.u8) {
+        if (l == 0 && P.u8 && P.h2) {
+          // layer 0 on uint8 frames as f16 products: ONE pass over this part's dz (after its absmax) writes dz^T and (r (.) dz)^T as h2
+          // images + the per-tile column sums; dW_x = (q - 128)^T . (r (.) dz) on two products, dW_h = h^T . dz on three
+          const float* rr = at<float>(tape, P.rrow) + t0 * B;
+          float* word = at<float>(scratch, P.hsc) + 1 + c;
+          RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
+          float* cp = P.colparts ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
+          float* cps = P.colparts ? at<float>(scratch, P.cparts) + (t0 * B / 64) * H4 : nullptr;
+          RC(yt8m_h2_split_ex(dzc, M, H4, H4, 1.0f, word, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), cp, cps,
+                              (yt8m_stream_t)sw));
+          RC(yt8m_gemm_h1x2_nt_ex(D, H4, M, at<char>(scratch, P.xT[0]) + kb0 * 1024, KBtot, at<char>(scratch, P.dzT3s), 0, dW[0], H4, nullptr,
+                                  U8_ALPHA, word, nullptr, nullptr, 0.f, bW, gw, P.gws_bytes, (yt8m_stream_t)sw));
+          yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0,
+                                  dW[0] + D * H4, H4, nullptr, bW};
+          const float alpha = 1.0f / H2_S;
+          const float* dsb = word;
+          RC(yt8m_gemm_h2_nt_grouped(1, &pr, &alpha, nullptr, &dsb, gw, P.gws_bytes, (yt8m_stream_t)sw));
+        } else if (l == 0 && P.u8) {
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
           if (fused_img) {                                   // images and column sums came with the recurrence
           } else if (P.colparts || bf) {                     // bias gradient + rank-1 remainder: per-tile sums from this pass

@@ -23,6 +23,11 @@ __device__ __forceinline__ float bf16_val(uint16_t h) { return __uint_as_float((
 
 // One wave per frame row of raw uint8 [B,F,D] (same arithmetic and summation order as dequant_l2norm_kernel, so r and x are
 // bit-identical to the float path); output rows are TIME-major (f * B + b): what the recurrence and the hoisted GEMMs use.
+// HALF: the one-plane image holds (q - 128) as IEEE half instead of bfloat16 (exact either way; the h1x2 product of round 5 reads half)
+__device__ __forceinline__ uint32_t small_int_bits(int v, bool half) {
+  return half ? (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)v) : (__float_as_uint((float)v) >> 16);
+}
+template <bool HALF>
 __global__ __launch_bounds__(256) void u8_frames_tm_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
                                                            uint16_t* __restrict__ Qb, long long ldq, int copies, float* __restrict__ xtm,
                                                            float* __restrict__ rout, int B, int F, int D, float eps,
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void u8_frames_tm_kernel(const uint8_t* __rest
     if (c4 >= nd) continue;
     uint16_t h[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) h[k] = (uint16_t)(__float_as_uint((float)((int)((w[it] >> (8 * k)) & 255u) - 128)) >> 16);   // exact
+    for (int k = 0; k < 4; ++k) h[k] = (uint16_t)small_int_bits((int)((w[it] >> (8 * k)) & 255u) - 128, HALF);   // exact
     const uint2 pk = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
     if (img) {
       // one-plane x3 image (csrc/gemm_x3.hip): [orow / 32][D / 16][32 rows][2 halves][8] bf16, half h of row r in slot h ^ ((r >> 3) & 1)
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(256) void u8_frames_tm_kernel(const uint8_t* __rest
 // m = f * B + b.  [d / 32][m / 16][32 rows][2 halves][8] bf16, half h of row r in slot h ^ ((r >> 3) & 1) -- the A operand of the
 // layer-0 weight-gradient product (yt8m_gemm_x1x3_nt_ex).  One workgroup per 16-wide K block: its 16 source rows (16 videos of one
 // frame index when B % 16 == 0) are staged in LDS and leave as 16-byte pieces (8 consecutive m of one feature).
+template <bool HALF>
 __global__ __launch_bounds__(256) void u8_frames_image_t_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nf,
                                                                 uint16_t* __restrict__ img, int B, int F, int D, int KB) {
   extern __shared__ __attribute__((aligned(16))) uint8_t tile[];       // [16][D]
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void u8_frames_image_t_kernel(const uint8_t* _
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int v = d < D ? (int)tile[(size_t)(half * 8 + 2 * e + u) * D + d] - 128 : 0;
-        h2[u] = __float_as_uint((float)v) >> 16;                       // exact: |v| <= 128
+        h2[u] = small_int_bits(v, HALF);                               // exact: |v| <= 128
       }
       pk[e] = h2[0] | (h2[1] << 16);
     }
@@ -181,7 +187,7 @@ extern "C" int yt8m_u8_frames_to_bf16_tm(const uint8_t* q, const int32_t* num_fr
                 (x_tm ? reinterpret_cast<uintptr_t>(x_tm) & 15 : 0)) == 0, YT8M_E_BADARG, "misaligned operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(u8_frames_tm_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, static_cast<uint16_t*>(Qb),
+  hipLaunchKernelGGL(u8_frames_tm_kernel<false>, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, static_cast<uint16_t*>(Qb),
                      (long long)ldq, copies, x_tm, r_out, (int)B, (int)F, (int)D, eps, (uint16_t*)nullptr);
   return launch_status("u8_frames_tm_kernel");
 }
@@ -198,7 +204,7 @@ extern "C" int yt8m_u8_frames_image(const uint8_t* q, const int32_t* num_frames,
                 (x_tm ? reinterpret_cast<uintptr_t>(x_tm) & 15 : 0)) == 0, YT8M_E_BADARG, "misaligned operand");
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(u8_frames_tm_kernel, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, (uint16_t*)nullptr, 0LL, 0,
+  hipLaunchKernelGGL(u8_frames_tm_kernel<false>, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, (uint16_t*)nullptr, 0LL, 0,
                      x_tm, r_out, (int)B, (int)F, (int)D, eps, static_cast<uint16_t*>(image));
   return launch_status("u8_frames_tm_kernel");
 }
@@ -215,7 +221,40 @@ extern "C" int yt8m_u8_frames_image_t(const uint8_t* q, const int32_t* num_frame
   hipStream_t s = as_stream(stream);
   const int KB = (int)((B * F + 15) / 16);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(u8_frames_image_t_kernel, dim3((unsigned)KB), dim3(256), (size_t)16 * D, s, q, num_frames,
+  hipLaunchKernelGGL(u8_frames_image_t_kernel<false>, dim3((unsigned)KB), dim3(256), (size_t)16 * D, s, q, num_frames,
+                     static_cast<uint16_t*>(image_t), (int)B, (int)F, (int)D, KB);
+  return launch_status("u8_frames_image_t_kernel");
+}
+
+// The same two images with (q - 128) as IEEE half (operands of yt8m_gemm_h1x2_nt_ex).
+extern "C" int yt8m_u8_frames_image_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
+                                    float* x_tm, float* r_out, yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * D == 0) return YT8M_OK;
+  YT8M_REQUIRE(yt8m_u8_proj_supported(D) && (D % 16) == 0, YT8M_E_SHAPE, "D must be a multiple of 16 and <= 2048");
+  YT8M_REQUIRE(q && image && r_out, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(q) & 3) | (reinterpret_cast<uintptr_t>(image) & 15) |
+                (x_tm ? reinterpret_cast<uintptr_t>(x_tm) & 15 : 0)) == 0, YT8M_E_BADARG, "misaligned operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(u8_frames_tm_kernel<true>, dim3((unsigned)((B * F + 3) / 4)), dim3(256), 0, s, q, num_frames, (uint16_t*)nullptr, 0LL, 0,
+                     x_tm, r_out, (int)B, (int)F, (int)D, eps, static_cast<uint16_t*>(image));
+  return launch_status("u8_frames_tm_kernel");
+}
+
+// (q - 128)^T as a one-plane image: ceil(D / 32) * ceil(B F / 16) KiB, 16-byte aligned; K runs over the time-major rows f * B + b.
+extern "C" int yt8m_u8_frames_image_t_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, void* image_t,
+                                      yt8m_stream_t stream) {
+  YT8M_REQUIRE(B >= 0 && F >= 0 && D >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * F * D == 0) return YT8M_OK;
+  YT8M_REQUIRE(D <= 2048 && (D % 4) == 0, YT8M_E_SHAPE, "D must be a multiple of 4 and <= 2048");
+  YT8M_REQUIRE(q && image_t, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(q) & 3) | (reinterpret_cast<uintptr_t>(image_t) & 15)) == 0, YT8M_E_BADARG, "misaligned operand");
+  YT8M_REQUIRE(B * F < (1LL << 31) - 16, YT8M_E_SHAPE, "too many frame rows");
+  hipStream_t s = as_stream(stream);
+  const int KB = (int)((B * F + 15) / 16);
+  ProfScope prof(F_ELEMENTWISE, s);
+  hipLaunchKernelGGL(u8_frames_image_t_kernel<true>, dim3((unsigned)KB), dim3(256), (size_t)16 * D, s, q, num_frames,
                      static_cast<uint16_t*>(image_t), (int)B, (int)F, (int)D, KB);
   return launch_status("u8_frames_image_t_kernel");
 }
