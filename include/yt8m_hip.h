@@ -135,6 +135,14 @@ int yt8m_h2_split_ex(const float* src, int64_t R, int64_t C, int64_t ld, float s
 int yt8m_gemm_h1x2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_t ska, const void* B2, int64_t skb, float* C, int64_t ldc,
                          const float* bias, float alpha, const void* dsb, const float* rowscale, const float* colsum, float colsum_scale,
                          float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* An h2 operand whose ROWS each keep their own precision (dx = dz . W_x^T of time steps whose gradients differ by decades): one power of
+ * two per row -- S[r] with max |src[r, :]| S[r] in [2^13, 2^14), inv[r] = 1 / S[r] --, the plain image of diag(S) . src, and the product
+ * with rowscale = inv. */
+int yt8m_h2_rowscales(const float* src, int64_t R, int64_t C, int64_t ld, float* S, float* inv, yt8m_stream_t stream);
+int yt8m_h2_split_rows(const float* src, int64_t R, int64_t C, int64_t ld, const float* S, void* plain, yt8m_stream_t stream);
+int yt8m_gemm_h2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A2, int64_t ska, const void* B2, int64_t skb, float* C, int64_t ldc,
+                       const float* bias, float alpha, const void* dsa, const void* dsb, const float* rowscale, float beta, void* workspace,
+                       int64_t workspace_bytes, yt8m_stream_t stream);
 int yt8m_u8_frames_image_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
                              float* x_tm, float* r_out, yt8m_stream_t stream);
 int yt8m_u8_frames_image_t_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, void* image_t,

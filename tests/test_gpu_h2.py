@@ -179,3 +179,41 @@ def test_u8_projection_and_weight_gradient_on_two_f16_products(dev, t0):
     dWh = ops.gemm_h2_grouped([dict(A=hT, B=dzT_img)])[0]
     refh = h[t0 * B:].astype(np.float64).T @ dz[t0 * B:].astype(np.float64)
     assert np.abs(dWh.cpu().numpy() - refh).max() <= 2e-6 * np.abs(refh).max() + 1e-9
+
+
+def test_h2_rows_keep_their_own_precision(dev):
+    """dx = dz . W^T with one power-of-two scale PER ROW of dz (yt8m_h2_rowscales / _split_rows / yt8m_gemm_h2_nt_ex): rows whose
+    magnitudes differ by 24 decades -- vanishing time steps next to live ones, an all-zero row -- are each exact to 1e-6 of THEIR OWN
+    scale; one scale for the whole operand would flush the small rows to zero (checked too: that is why dx takes this form)."""
+    import yt8m_amd._lib as L
+    from yt8m_amd.ops import _p, _stream
+    lib = L.lib()
+    g = torch.Generator(device=dev).manual_seed(12)
+    M, N, K = 640, 1024, 4096
+    A = torch.randn((M, K), device=dev, generator=g)
+    mag = torch.pow(10.0, -torch.linspace(0, 24, M, device=dev))           # row r scaled by 10^-(24 r / M)
+    A = A * mag[:, None]
+    A[5] = 0.0
+    W = torch.randn((N, K), device=dev, generator=g) * 0.03
+    S = torch.empty(M, device=dev)
+    inv = torch.empty(M, device=dev)
+    L.check(lib.yt8m_h2_rowscales(_p(A), M, K, K, _p(S), _p(inv), _stream()))
+    img = torch.empty(lib.yt8m_x3_image_bytes(M, K) // 3 * 2, dtype=torch.uint8, device=dev)
+    L.check(lib.yt8m_h2_split_rows(_p(A), M, K, K, _p(S), _p(img), _stream()))
+    hw, _ = ops.h2_split(W, dynamic=True)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ws = ops._workspace(dev)
+    L.check(lib.yt8m_gemm_h2_nt_ex(M, N, K, _p(img), 0, _p(hw.buf), 0, _p(C), N, None, 1.0, None, _p(hw.dinv), _p(inv), 0.0, _p(ws),
+                                   ws.numel() * 4, _stream()))
+    ref = A.double() @ W.double().t()
+    rowscale = ref.abs().max(dim=1).values
+    err = (C.double() - ref).abs().max(dim=1).values
+    live = rowscale > 0
+    assert float((err[live] / rowscale[live]).max()) < 2e-6
+    assert float(C[5].abs().max()) == 0.0 and float(S[5]) == 1.0
+    rm = A.abs().max(dim=1).values
+    assert bool(((rm[live] * S[live] >= 2.0 ** 13) & (rm[live] * S[live] < 2.0 ** 14)).all()) and torch.equal(inv, 1.0 / S)
+    # one scale for the whole operand: the rows 2^-26 below the largest are gone
+    ha, _ = ops.h2_split(A, dynamic=True)
+    C1 = ops.gemm_h2_grouped([dict(A=ha, B=hw)])[0]
+    assert float(C1[M - 1].abs().max()) == 0.0 and float(ref[M - 1].abs().max()) > 0.0

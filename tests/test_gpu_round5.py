@@ -171,9 +171,9 @@ def test_lstm_model_with_resident_images_is_bitwise_the_run_that_resplits(dev, f
     assert off[3] == [] and on[0] == off[0], (on[0], off[0])
     assert torch.equal(on[1], off[1]) and torch.equal(on[2], off[2])
     w0, w1 = ("RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l for l in range(2))
-    alpha = float(np.float32(4.0 / 255.0))
-    # (the forward projection of layer 1 reads an h2 image under a device-measured scale since the h2 products: no resident x3 one)
-    assert (w0, 0, 64, 1, 3, alpha) in on[3] and (w1, 0, 256, 0, 3, 1.0) in on[3], on[3]
+    # (the projections read h2 images under device-measured scales since the round-5 f16 products: the resident x3 image left is
+    # the plain one of dx = dz . W_x^T above layer 0 -- while that product stays on the six-product form)
+    assert on[3] == [] or all(k[0] == w1 and k[3] == 0 for k in on[3]), on[3]
 
 
 # ---- single-pass NetVLAD forward (csrc/netvlad_fused.hip vlad_video_kernel) ---------------------------------------------

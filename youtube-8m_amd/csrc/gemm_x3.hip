@@ -1066,7 +1066,10 @@ template <int NP>
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ plain,
                                                        float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
                                                        float* __restrict__ trans_s, float* __restrict__ colpart = nullptr,
-                                                       float* __restrict__ colpart_s = nullptr, const float* __restrict__ dscale = nullptr) {
+                                                       float* __restrict__ colpart_s = nullptr, const float* __restrict__ dscale = nullptr,
+                                                       const float* __restrict__ rowS = nullptr) {
+  // rowS (NP = 2, plain image only): row r of the source is scaled by rowS[r] -- one power of two PER ROW (yt8m_h2_rowscales): the
+  // operand of a product whose rows must each keep their own precision (dx = dz . W^T of time steps whose gradients differ by decades)
   __shared__ float T[64][65];
   if (dscale) scale *= yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(dscale)[0]), 14);
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -1088,7 +1091,8 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
           if (c0 + c4 + 3 < Cc) v.w = p[3];
         }
       }
-      T[r][c4 + 0] = v.x * scale; T[r][c4 + 1] = v.y * scale; T[r][c4 + 2] = v.z * scale; T[r][c4 + 3] = v.w * scale;
+      const float sr = (rowS && r0 + r < R) ? scale * rowS[r0 + r] : scale;
+      T[r][c4 + 0] = v.x * sr; T[r][c4 + 1] = v.y * sr; T[r][c4 + 2] = v.z * sr; T[r][c4 + 3] = v.w * sr;
     }
   }
   __syncthreads();
@@ -1252,6 +1256,55 @@ __global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict_
   if (threadIdx.x == 0 && m > 0.f && m < 3.0e38f) atomicMax(word, __float_as_uint(m));
 }
 }  // namespace
+
+namespace {
+// one wave per row: S[r] = the power of two with max |src[r, :]| S in [2^13, 2^14) (1 for an all-zero row), inv[r] = 1 / S[r]
+__global__ __launch_bounds__(256) void h2_rowscale_kernel(const float* __restrict__ src, int64_t ld, int R, int Cc, float* __restrict__ S,
+                                                          float* __restrict__ inv) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* p = src + (int64_t)row * ld;
+  float m = 0.f;
+  if ((ld & 3) == 0 && (Cc & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int c = lane * 4; c < Cc; c += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(p + c);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+    }
+  } else {
+    for (int c = lane; c < Cc; c += 64) m = fmaxf(m, fabsf(p[c]));
+  }
+  m = wave_max(m);
+  if (lane == 0) {
+    const float s = yt8m_x3::pow2_scale_for(m, 14);
+    S[row] = s;
+    inv[row] = 1.0f / s;
+  }
+}
+}  // namespace
+
+// Per-ROW scales of an h2 operand: S[r] = the power of two with max |src[r, :]| S[r] in [2^13, 2^14), inv[r] = 1 / S[r] (what the
+// product's rowscale takes); yt8m_h2_split_rows writes the plain h2 image [R rows, K = C] of diag(S) . src.
+extern "C" int yt8m_h2_rowscales(const float* src, int64_t R, int64_t C, int64_t ld, float* S, float* inv, yt8m_stream_t stream) {
+  YT8M_REQUIRE(src && S && inv && R >= 1 && C >= 1 && ld >= C && R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "bad arguments");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(h2_rowscale_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, S, inv);
+  return launch_status("h2_rowscale_kernel");
+}
+extern "C" int yt8m_h2_split_rows(const float* src, int64_t R, int64_t C, int64_t ld, const float* S, void* plain, yt8m_stream_t stream) {
+  YT8M_REQUIRE(src && S && plain && R >= 1 && C >= 1 && ld >= C && R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "bad arguments");
+  YT8M_REQUIRE((reinterpret_cast<uintptr_t>(plain) & 15) == 0, YT8M_E_BADARG, "images must be 16-byte aligned");
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     (float*)nullptr, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, S);
+  return launch_status("x3_split_kernel<2>");
+}
+// C[M,N] (+)= alpha . rowscale[m] / (S_a S_b) . A . B^T (+ bias): yt8m_gemm_h2_nt_grouped for one product with a per-row factor
+// (rowscale = inv of yt8m_h2_rowscales when A was split by rows; dsa / dsb = absmax words or NULL; ska / skb as the x3 forms).
+extern "C" int yt8m_gemm_h2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A2, int64_t ska, const void* B2, int64_t skb, float* C,
+                                  int64_t ldc, const float* bias, float alpha, const void* dsa, const void* dsb, const float* rowscale,
+                                  float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 
 // max |src| into a device word (float bits, atomicMax: order independent; the word must be zero before, several calls may share it):
 // what yt8m_h2_split (dscale) and yt8m_gemm_h2_nt_grouped (dsa / dsb) turn into the image's scale S = 2^(14 - exponent) and its inverse.
@@ -1520,6 +1573,17 @@ extern "C" int yt8m_gemm_h2_nt_grouped(int nprob, const yt8m_gemm_problem* probs
                                        const float* const* dsb, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
   return x3_launch<2>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream, dsa, dsb, alphas);
+}
+
+extern "C" int yt8m_gemm_h2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A2, int64_t ska, const void* B2, int64_t skb, float* C,
+                                  int64_t ldc, const float* bias, float alpha, const void* dsa, const void* dsb, const float* rowscale,
+                                  float beta, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE((N % 4) == 0, YT8M_E_SHAPE, "the scaled epilogue needs N % 4 == 0");
+  yt8m_gemm_problem p;
+  p.M = M; p.N = N; p.K = K; p.A = A2; p.lda = ska; p.B = B2; p.ldb = skb; p.C = C; p.ldc = ldc; p.bias = bias; p.beta = beta;
+  const float* wa = static_cast<const float*>(dsa);
+  const float* wb = static_cast<const float*>(dsb);
+  return x3_launch<2>(1, &p, rowscale, nullptr, 0.f, alpha, workspace, workspace_bytes, stream, dsa ? &wa : nullptr, dsb ? &wb : nullptr);
 }
 
 // C[M,N] (+)= alpha . rowscale[m] . (A1 . B^T / S_b + colsum_scale . colsum[n]) + bias[n]: A1 a ONE-plane HALF image whose elements are

@@ -74,6 +74,7 @@ struct Plan {
   int img_rows;                                            // > 0: the backward recurrences write dz's operand images themselves (round 4)
   int h2;                                                  // layers >= 1: projection and weight gradients as three f16 products (round 5)
   int64_t hsc;                                             // ... their device-side scale words: 256 B per layer
+  int64_t hrow, hrow_stride;                               // ... per-row scales of dz for dx (S then 1 / S), per layer
   int64_t cimg[MAXL], cimgs;                               // their column-sum partials: [img_rows x launches][4H] per layer
   int64_t scratch_bytes;
 };
@@ -200,6 +201,8 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.csr = o; o += up256(H4 * 4);
   p.dbdummy = o; o += up256(H4 * 4);
   p.hsc = o; o += 256 * MAXL;
+  p.hrow_stride = up256(bmax * 4);
+  p.hrow = o; o += p.h2 ? p.hrow_stride * 2 * MAXL : 0;   // per-row scales / inverses of a backward part's dz (dx operand), per layer
   p.colparts = knob("YT8M_STACK_COLPARTS", 1) != 0;
   for (int c = 0; c < p.nb; ++c) p.colparts = p.colparts && (p.bp[c].t0 * p.B) % 64 == 0 && (p.bp[c].T * p.B) % 64 == 0;
   const int64_t cp = p.colparts ? up256(((p.FB + 63) / 64) * H4 * 4) : 0;
@@ -576,7 +579,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   ev.wait(sw, start);
   if (two_sw) ev.wait(S->sw2, start);
   for (int l = 0; l < P.L; ++l) { ev.wait(S->rs[l], start); if (dx_stream) ev.wait(S->dxs[l], start); }
-  if (P.h2) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc), 0, (size_t)256 * P.L, sw));      // the parts' absmax words (the forward's are done)
+  if (P.h2)                                                // the parts' absmax words; word 0 of a layer (max |W_x|, the forward's) stays
+    for (int l = 0; l < P.L; ++l) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc + 256 * l + 4), 0, 64, sw));
   // weight-gradient stream: the whole-sequence transposed operands (K = frame rows), made while the first recurrence runs alone
   for (int l = 0; l < P.L; ++l) {
     if (!dW[l]) continue;
@@ -707,6 +711,25 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // weight-gradient stream then waits for this pass instead of reading dz again)
         fused_t = fuse_dz && dW[l] && !(l == 0 && P.u8);
         if (fused_t && dzT_free[l]) ev.wait(sx, dzT_free[l]);       // the previous part's products have read the image
+        const bool dx_h2 = P.h2 && l >= 1 && knob("YT8M_STACK_H2_DX", 1);
+        if (dx_h2) {
+          // dx = dz . W_x^T as three f16 products: dz split ROW by ROW (one power of two per frame row: a time step whose gradient
+          // has decayed by decades keeps its own 22 bits), W_x under the scale of its absmax word (measured by the forward pass)
+          float* rS = at<float>(scratch, P.hrow + 2 * l * P.hrow_stride);
+          float* rI = at<float>(scratch, P.hrow + (2 * l + 1) * P.hrow_stride);
+          RC(yt8m_h2_rowscales(dzc, M, H4, H4, rS, rI, (yt8m_stream_t)sx));
+          RC(yt8m_h2_split_rows(dzc, M, H4, H4, rS, at<char>(scratch, P.dz3[l]), (yt8m_stream_t)sx));
+          const float* wword = at<float>(scratch, P.hsc + 256 * l);
+          if (!wx3_done[l]) {
+            RC(yt8m_h2_split(W[l], Din, H4, H4, 1.0f, wword, at<char>(scratch, P.wx3[l]), nullptr, nullptr, (yt8m_stream_t)sx));
+            wx3_done[l] = true;
+          }
+          float* dst = at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H;
+          RC(yt8m_gemm_h2_nt_ex(M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 1.0f, nullptr,
+                                wword, rI, 0.0f, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, (yt8m_stream_t)sx));
+          dx_ev = ev.record(sx);
+          if (c == 0 && j == 0) last.push_back(dx_ev);
+        } else {
         if (!fused_img)
           RC(split(dzc, M, H4, H4, 1.0f, at<char>(scratch, P.dz3[l]), fused_t ? at<char>(scratch, P.dzT3[l]) : nullptr, sx));
         if (fused_t) rb = ev.record(sx);
@@ -727,6 +750,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         RC(grc);
         dx_ev = ev.record(sx);
         if (c == 0 && j == 0) last.push_back(dx_ev);
+        }
       }
       // weight-gradient stream: transposed image(s) of this part's dz, the two products, the bias gradient
       hipStream_t sw = (two_sw && l == 0) ? S->sw2 : S->sw;       // (knob: layer 0's chain on a second weight-gradient stream)
