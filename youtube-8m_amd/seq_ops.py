@@ -427,15 +427,17 @@ def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx, bf16=False):
 
 
 def _stack_scratch(dev, main, desc):
-    key = (dev.index, main.cuda_stream) + tuple(getattr(desc, f) for f, _ in desc._fields_ if f != "forget_bias")
+    # (the size is part of the key: the library's layout depends on its knobs too -- a test that flips YT8M_STACK_H2 in-process must
+    # not be handed the other layout's buffer)
+    need = _lib.lib().yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc))
+    key = (dev.index, main.cuda_stream, need) + tuple(getattr(desc, f) for f, _ in desc._fields_ if f != "forget_bias")
     ent = _STACK_SCRATCH.get(key)
     if ent is not None:
         _STACK_SCRATCH[key] = _STACK_SCRATCH.pop(key)                # least recently USED goes first (dicts keep insertion order)
     else:
         if len(_STACK_SCRATCH) >= _STACK_SCRATCH_MAX:                # a few GB each: keep the table small
             _retire(_STACK_SCRATCH.pop(next(iter(_STACK_SCRATCH))), _check_stack)
-        n = _lib.lib().yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc))
-        ent = (torch.zeros(n, dtype=torch.uint8, device=dev), main, desc)      # zeroed ONCE: the sticky time-out words start clear
+        ent = (torch.zeros(need, dtype=torch.uint8, device=dev), main, desc)      # zeroed ONCE: the sticky time-out words start clear
         _STACK_SCRATCH[key] = ent
     return ent[0]
 
