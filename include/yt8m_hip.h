@@ -604,6 +604,18 @@ int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, cons
 int yt8m_lstm_persist_bwd_bf16(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                                float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                                int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* Round 5: the fp32 configuration's recurrent product dz_t . W_h^T of the same backward pass (W/all_frame_models/lstm_model.py:34-47
+ * through tf.gradients) OFF the fp32 matrix pipe, fp32-grade: dz_t and W_h^T as two IEEE-half planes each (x S = hi + lo to 2^-22), three
+ * products hi.hi + lo.hi + hi.lo of v_mfma_f32_16x16x32_f16, fp32 accumulation; every producer workgroup scales its 16 rows x 64 values of
+ * dz_t by one power of two per row and publishes the inverse exponents beside the tile (no scale is guessed).  Results differ from
+ * yt8m_lstm_persist_bwd by rounding of the fp32 grade only (2^-21 relative per product term).  wh_absmax: device word with max |W_h| as
+ * float bits (yt8m_h2_absmax over the [H, 4H] block W_h; zero the word first).  A permission like the bf16 form: H other than 512 / 1024,
+ * tiles per workgroup not a multiple of four, or a workspace smaller than yt8m_lstm_persist_workspace_bytes_steps(B, H, T) -> the fp32
+ * form runs.  yt8m_lstm_persist_bwd_on_f16_pipe: 1 when the shape takes the f16 form.  YT8M_PERSIST_BWD_H2=0: never. */
+int yt8m_lstm_persist_bwd_h2(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                             float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                             int64_t B, int64_t H, const void* wh_absmax, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H);
 /* The same launch with the operand images of dz[t0 .. t0 + T) written by the recurrence itself (round 4): what yt8m_x3_split /
  * yt8m_x3_split_colsum would make of that part of dz in separate passes -- bit for bit -- for the products that follow it in the
  * backward pass of BasicLSTMCell under dynamic_rnn (W/all_frame_models/lstm_model.py:34-47 through tf.gradients, W/train.py:461):

@@ -1,0 +1,123 @@
+"""-m gpu, round 5: the backward recurrence's product dz_t . W_h^T as three f16 products of two-half-plane splits
+(csrc/lstm_persist.hip lstm_persist_bwd_kernel<.., H2>, yt8m_lstm_persist_bwd_h2) against the fp32-pipe form of the same launch
+(yt8m_lstm_persist_bwd, itself pinned to fp64 autograd by tests/test_gpu_round3.py) and against an fp64 restatement of the recurrence
+(W/all_frame_models/lstm_model.py:34-47 through tf.gradients)."""
+import ctypes
+
+import pytest
+import torch
+
+import yt8m_amd._lib as _lib
+from yt8m_amd.ops import _p, _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(dev, B, F, H, seed, decades):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    gates = torch.rand((F, B, 4 * H), device=dev, generator=g)
+    gates[:, :, H:2 * H] = gates[:, :, H:2 * H] * 2 - 1                     # the tanh gate
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.08
+    cs = torch.randn((F + 1, B, H), device=dev, generator=g) * 0.7
+    dout = torch.randn((F, B, H), device=dev, generator=g) * 0.01
+    if decades:                                                             # rows whose gradients differ by decades; a few all-zero ones
+        row = 10.0 ** (-decades * torch.rand((B,), device=dev, generator=g))
+        row[::7] = 0.0
+        dout = dout * row[None, :, None]
+    nf = torch.randint(1, F + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+    nf[0], nf[1] = F, 1
+    return gates, Wh, cs, dout, nf
+
+
+def _run(lib, which, gates, Wh, cs, dout, nf, t0, T, wword=None):
+    F, B, H4 = gates.shape
+    H = H4 // 4
+    dev = gates.device
+    dz = torch.zeros((F, B, 4 * H), device=dev)
+    work = torch.zeros((4, B, H), device=dev)
+    g = torch.Generator(device=dev).manual_seed(99)
+    work[0] = torch.randn((B, H), device=dev, generator=g) * 0.02          # running (dh, dc) handed in by the caller
+    work[1] = torch.randn((B, H), device=dev, generator=g) * 0.02
+    pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, T), dtype=torch.uint8, device=dev)
+    args = [_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, _p(nf), t0, T, B, H]
+    if which == "h2":
+        _lib.check(lib.yt8m_lstm_persist_bwd_h2(*args, _p(wword), _p(pws), pws.numel(), _stream()))
+    else:
+        _lib.check(lib.yt8m_lstm_persist_bwd(*args, _p(pws), pws.numel(), _stream()))
+    torch.cuda.synchronize()
+    _lib.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+    return dz, work
+
+
+def _absmax_word(lib, Wh):
+    H, H4 = Wh.shape
+    word = torch.zeros(64, dtype=torch.int32, device=Wh.device)
+    _lib.check(lib.yt8m_h2_absmax(_p(Wh), H, H4, H4, _p(word), _stream()))
+    return word
+
+
+@pytest.mark.parametrize("B,F,H,decades", [(128, 24, 1024, 0), (128, 40, 1024, 6), (256, 12, 512, 3), (256, 9, 1024, 0)])
+def test_f16_form_of_the_backward_recurrence_equals_the_fp32_form_to_fp32_rounding(dev, B, F, H, decades):
+    lib = _lib.lib()
+    assert lib.yt8m_lstm_persist_bwd_on_f16_pipe(B, H) == 1
+    gates, Wh, cs, dout, nf = _inputs(dev, B, F, H, B + F + H, decades)
+    word = _absmax_word(lib, Wh)
+    t0, T = 2, F - 2                                                       # a part that does not start at frame 0
+    dz32, w32 = _run(lib, "f32", gates, Wh, cs, dout, nf, t0, T)
+    dzh, wh = _run(lib, "h2", gates, Wh, cs, dout, nf, t0, T, word)
+    assert torch.equal(dzh[:t0], dz32[:t0])                                # untouched frames
+    # every (frame, row) on its OWN scale: a row whose gradient is six decades below its neighbours' keeps fp32-grade digits
+    num = (dzh - dz32).abs().amax(dim=2)
+    den = dz32.abs().amax(dim=2)
+    live = den > 0
+    assert float((num[live] / den[live]).max()) < 3e-6
+    assert torch.equal(dzh[~live[:, :, None].expand_as(dzh)], dz32[~live[:, :, None].expand_as(dz32)])   # ended videos / zero rows: exact zeros
+    half = (0 + T) & 1                                                    # the running (dh, dc) handed back
+    for k in (2 * half, 2 * half + 1):
+        rown = (wh[k] - w32[k]).abs().amax(dim=1)
+        rowd = w32[k].abs().amax(dim=1)
+        ok = rowd > 0
+        assert float((rown[ok] / rowd[ok]).max()) < 3e-6
+
+
+def test_f16_form_against_fp64_restatement(dev):
+    """The recurrence restated in fp64 on the host arithmetic of torch (same saved activations): the f16 form's error is of the size of
+    the fp32 form's, both far inside the tolerance the fp32 stack is tested to."""
+    lib = _lib.lib()
+    B, F, H = 128, 16, 1024
+    gates, Wh, cs, dout, nf = _inputs(dev, B, F, H, 5, 0)
+    word = _absmax_word(lib, Wh)
+    dz32, w32 = _run(lib, "f32", gates, Wh, cs, dout, nf, 0, F)
+    dzh, wh = _run(lib, "h2", gates, Wh, cs, dout, nf, 0, F, word)
+    g64, W64, c64, d64 = gates.double(), Wh.double(), cs.double(), dout.double()
+    gen = torch.Generator(device=dev).manual_seed(99)
+    dh = (torch.randn((B, H), device=dev, generator=gen) * 0.02).double()
+    dc = (torch.randn((B, H), device=dev, generator=gen) * 0.02).double()
+    ref = torch.zeros_like(g64)
+    for t in range(F - 1, -1, -1):
+        live = (t < nf.long())[:, None]
+        gi, gj, gf, go = g64[t, :, :H], g64[t, :, H:2 * H], g64[t, :, 2 * H:3 * H], g64[t, :, 3 * H:]
+        tc = torch.tanh(c64[t + 1])
+        dht = dh + d64[t]
+        dct = dc + dht * go * (1 - tc * tc)
+        dz = torch.cat([dct * gj * gi * (1 - gi), dct * gi * (1 - gj * gj), dct * c64[t] * gf * (1 - gf), dht * tc * go * (1 - go)], dim=1)
+        dz = torch.where(live, dz, torch.zeros_like(dz))
+        ref[t] = dz
+        dc = torch.where(live, dct * gf, dc)
+        dh = torch.where(live, dz @ W64.t(), dh)
+    scale = ref.abs().amax(dim=2) + 1e-300
+    e32 = float(((dz32.double() - ref).abs().amax(dim=2) / scale).max())
+    eh = float(((dzh.double() - ref).abs().amax(dim=2) / scale).max())
+    assert e32 < 2e-5 and eh < 2e-5 and eh < 4 * e32 + 1e-6, (e32, eh)
+
+
+def test_f16_form_is_a_permission(dev, monkeypatch):
+    """Shapes / workspaces that cannot take the f16 form run the fp32 form: bit-identical results."""
+    lib = _lib.lib()
+    B, F, H = 48, 6, 256                                                   # H = 256: never the f16 form
+    assert lib.yt8m_lstm_persist_bwd_on_f16_pipe(B, H) == 0
+    gates, Wh, cs, dout, nf = _inputs(dev, B, F, H, 3, 0)
+    word = _absmax_word(lib, Wh)
+    a = _run(lib, "f32", gates, Wh, cs, dout, nf, 0, F)
+    b = _run(lib, "h2", gates, Wh, cs, dout, nf, 0, F, word)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

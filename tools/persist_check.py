@@ -108,23 +108,38 @@ def timing_bwd(B=int(os.environ.get("PCHECK_B", "128")), F=300, H=1024):
     cs = torch.randn((F + 1, B, H), device=dev) * 0.5
     dz = torch.empty((F, B, 4 * H), device=dev)
     dout = torch.randn((F, B, H), device=dev) * 0.01
-    for it in range(9):
+    wword = torch.zeros(64, dtype=torch.int32, device=dev)
+    L.check(lib.yt8m_h2_absmax(_p(Wh), H, 4 * H, 4 * H, _p(wword), _stream()))
+    ref = None
+    for it in range(12):
         steps = it >= 3
-        bf16 = it >= 6                                    # the recurrent product on one bf16 plane (yt8m_lstm_persist_bwd_bf16)
+        bf16 = 6 <= it < 9                                # the recurrent product on one bf16 plane (yt8m_lstm_persist_bwd_bf16)
+        h2 = it >= 9                                      # ... as three f16 products of two-half-plane splits (yt8m_lstm_persist_bwd_h2)
         pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
                           dtype=torch.uint8, device=dev)
         work = torch.zeros((4, B, H), device=dev)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check((lib.yt8m_lstm_persist_bwd_bf16 if bf16 else lib.yt8m_lstm_persist_bwd)(
-            _p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), pws.numel(), _stream()))
+        if h2:
+            L.check(lib.yt8m_lstm_persist_bwd_h2(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H,
+                                                 _p(wword), _p(pws), pws.numel(), _stream()))
+        else:
+            L.check((lib.yt8m_lstm_persist_bwd_bf16 if bf16 else lib.yt8m_lstm_persist_bwd)(
+                _p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), pws.numel(), _stream()))
         e1.record()
         torch.cuda.synchronize()
         L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
-        print("persistent bwd kernel (%s): %.3f ms for %d steps = %.2f us/step"
-              % (("image per step, bf16 recurrent product" if bf16 else "image per step") if steps else "two images", e0.elapsed_time(e1), F,
-                 e0.elapsed_time(e1) * 1e3 / F), flush=True)
+        note = ""
+        if steps and not bf16 and not h2:
+            ref = (dz.clone(), work.clone())
+        if h2 and ref is not None:                        # against the fp32-pipe form of the same launch, on each time step's own scale
+            d = (dz - ref[0]).abs().amax(dim=(1, 2)) / (ref[0].abs().amax(dim=(1, 2)) + 1e-30)
+            note = "  max over steps of |dz - dz_fp32| / max|dz_t| = %.3g (step %d), final dh %.3g" % (
+                float(d.max()), int(d.argmax()), float((work - ref[1]).abs().max() / (ref[1].abs().max() + 1e-30)))
+        print("persistent bwd kernel (%s): %.3f ms for %d steps = %.2f us/step%s"
+              % (("image per step, three f16 products" if h2 else "image per step, bf16 recurrent product" if bf16 else "image per step")
+                 if steps else "two images", e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F, note), flush=True)
 
 
 if __name__ == "__main__":

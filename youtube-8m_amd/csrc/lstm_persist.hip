@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <mutex>
 #include "common.h"
+#include "x3_image.h"
 
 namespace {
 
@@ -511,6 +512,17 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_kernel(PersistFwdArgs a)
 // Needs one exchange image per step (plain L2-shared fetch), >= 2 tiles per workgroup and H in {512, 1024}; otherwise the fp32
 // kernel runs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 as_u4(float4 v) {
+  u32x4 r;
+  r.x = __float_as_uint(v.x); r.y = __float_as_uint(v.y); r.z = __float_as_uint(v.z); r.w = __float_as_uint(v.w);
+  return r;
+}
+// value of lane (l + N) mod 16 within a row of 16 lanes (DPP row_ror): four of them make a row-wide all-reduce
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, true));
+}
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float x) {        // round to nearest even, finite x
   const unsigned u = __float_as_uint(x);
@@ -865,6 +877,10 @@ struct PersistBwdArgs {
   int NUB, RB, NT16, per, pf;
   int nimg;
   int bf;               // one-plane bf16 recurrent product requested (taken when the launch has the rotated, prefetching, image-per-step form)
+  int h2;               // two-plane f16 recurrent product (H2 form below) requested; taken under the same conditions + room for the scales
+  const unsigned* wword;// H2: max |W_h| as float bits (yt8m_h2_absmax)
+  unsigned* sc;         // H2: per (publish, tile, producer workgroup, row quad) one word of four inverse-scale exponents
+  unsigned sc_bytes;
   unsigned long long* dbg;
   // IMG (rotated epilogue only): the operand images of this launch's dz written by the epilogue itself -- what yt8m_x3_split would
   // make of dz[t0 .. t0 + T) in separate passes (csrc/gemm_x3.hip image layout: 1 KiB blocks of 32 rows x 16 k per plane).
@@ -909,10 +925,23 @@ __device__ __forceinline__ void p_split3(float x, unsigned& h1, unsigned& h2, un
 // fp32 exchange), the workgroup's [16 x 4H] slice of W_h^T is rounded once per launch and is register-resident in full (64 VGPRs),
 // a wave's K range is NQB / 2 blocks of 32: NQB / 2 MFMAs of 16 cycles per item instead of 4 NQB of 32.  dz as STORED (the operand of
 // dx and of the weight gradients, which round it themselves) stays fp32; fp32 accumulation and gate arithmetic as in the fp32 form.
-template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false, bool BF = false>
+// H2 (round 5): the fp32-GRADE recurrent product off the fp32 pipe -- dz and W_h^T as TWO IEEE-half planes each (csrc/x3_image.h
+// split_h2: x S = hi + lo to 2^-22), three products hi.hi + lo.hi + hi.lo of v_mfma_f32_16x16x32_f16: 48 MFMAs of 16 cycles per item and
+// wave instead of 128 of 32, with the fp32 form's footprint everywhere else (4 bytes per exchanged dz element, a 256 KiB weight slice:
+// the hi plane in registers, the lo plane in LDS).  What made this form wait for round 5 is the scale a half plane needs: dz spans
+// decades from row to row and step to step, and a row's maximum over all 4H columns is spread over 64 producer workgroups.  Here every
+// PRODUCER scales its own 16 rows x 64 values by a power of two per row (the maximum is one DPP reduction over the 16 lanes of a row),
+// publishes the four inverse exponents of a row quad as one word beside the tile, and the K order of the exchange is permuted so that a
+// producer's 64 values are two whole 32-wide K blocks: a consumer wave runs the six MFMAs of a producer into a scratch accumulator and
+// adds it, times the producer's inverse scale of each row, to the running one (4 FMAs per 6 MFMAs).  No scale is guessed or lagged.
+//   K slot (block 2 p + uh, k-group kg, j) of the exchange = producer p's value (unit 8 uh + 2 kg + j / 4, gate j % 4): a lane of the
+//   epilogue (one unit x four gates per row) and its neighbour fill one 16-byte A fragment piece -- one DPP move per dword instead of the
+//   one-plane form's three-step gather.
+template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false, bool BF = false, bool H2 = false>
 __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
   static_assert(!IMG || ROT, "the operand images are written by the rotated epilogue");
   static_assert(!BF || (PF && SH && ROT && !IMG && (NQB % 4) == 0), "the bf16-operand form: prefetching, one image per step, rotated epilogue");
+  static_assert(!H2 || (PF && SH && ROT && !IMG && !BF && (NQB % 8) == 0), "the two-half-plane form: prefetching, one image per step, rotated epilogue");
   constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
   constexpr unsigned EPW = ROT ? 1u : 4u;                // epilogue waves that read a partial-tile slot / publish a tile
   __shared__ __attribute__((aligned(16))) float4 Wl[8][BF ? 1 : HALF][64];  // LDS-resident half of the weights: 8 * HALF KB (BF: none)
@@ -945,7 +974,30 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   note_placement(a.ctl);
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
-  if (!BF && w < 8) {
+  // H2: B fragments of v_mfma_f32_16x16x32_f16 in the permuted K order: lane (n = unit, kg) supplies, for local K block kbl of this wave
+  // (global block kbp = w NQB / 2 + kbl: producer kbp / 2, unit half kbp % 2), W_h[16 ub + n][gate (j % 4) H + 16 producer + 8 uh + 2 kg + j / 4]
+  float h2_sw = 1.f;
+  if constexpr (H2) h2_sw = yt8m_x3::pow2_scale_for(__uint_as_float(a.wword[0]), 14);
+  auto w_frag_h2 = [&](int kbl, u32x4& fhi, u32x4& flo) {
+    const int kbp = w * (NQB / 2) + kbl;
+    const float* q = a.Wh + (long long)(ub * 16 + i16) * a.ldw + 16 * (kbp >> 1) + 8 * (kbp & 1) + 2 * kq;
+    unsigned hb[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yt8m_x3::split_h2(q[(long long)(j & 3) * H + (j >> 2)] * h2_sw, hb[j], lb[j]);
+    fhi.x = hb[0] | (hb[1] << 16); fhi.y = hb[2] | (hb[3] << 16); fhi.z = hb[4] | (hb[5] << 16); fhi.w = hb[6] | (hb[7] << 16);
+    flo.x = lb[0] | (lb[1] << 16); flo.y = lb[2] | (lb[3] << 16); flo.z = lb[4] | (lb[5] << 16); flo.w = lb[6] | (lb[7] << 16);
+  };
+  if constexpr (H2) {
+    if (w < 8) {
+#pragma unroll
+      for (int kbl = 0; kbl < HALF; ++kbl) {                // the lo plane of the whole slice lives in LDS, the hi plane in registers
+        u32x4 fhi, flo;
+        w_frag_h2(kbl, fhi, flo);
+        Wl[w][kbl][lane] = as_f4(flo);
+      }
+    }
+  }
+  if (!BF && !H2 && w < 8) {
     // B fragment: lane (n = unit, kq) supplies W_h[16 ub + n][k = 16 q + 4 kq + e], e = 0..3: a float4 of a W_h row
     const float* wrow = a.Wh + (long long)(ub * 16 + i16) * a.ldw + (long long)(w * NQB) * 16 + kq * 4;
 #pragma unroll
@@ -1036,6 +1088,148 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rw[r * 64] = acc0[r] + acc1[r];
         if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (++slot == NSLOT_B) { slot = 0; ++gen; }
+        if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+      }
+      return;
+    }
+  } else if constexpr (H2) {
+    if (w < 8) {
+      // =============================== matrix waves, two half planes ===============================
+      constexpr int NPW = NQB / 4, PH = NPW / 2;           // producers per wave / per half item (a producer = 4 ring blocks: 2 K blocks x 2 planes)
+      u32x4 Wh_[HALF];                                     // hi plane of the wave's HALF = NQB / 2 K blocks
+#pragma unroll
+      for (int kbl = 0; kbl < HALF; ++kbl) { u32x4 flo; w_frag_h2(kbl, Wh_[kbl], flo); }
+      const float inv_sw = 1.0f / h2_sw;
+      // (addresses: the lane's 16 bytes in the VGPR offset, everything uniform -- tile, wave, block -- in the scalar offset: with the
+      // block index folded into per-load VGPR offsets the register allocator keeps a dozen base registers alive)
+      const int lane_off = lane * 16;
+      auto blk = [&](int T) -> int { return __builtin_amdgcn_readfirstlane((T * QH4 + w * NQB) * 1024); };
+      const __amdgpu_buffer_rsrc_t scr = make_rsrc(a.sc, a.sc_bytes);
+      const int kq_off = kq * 4;
+      auto sc_off = [&](int s, int T, int pl) -> int { return __builtin_amdgcn_readfirstlane(((s * NT16 + T) * a.NUB + w * NPW + pl) * 16); };
+      u32x4 ring[HALF];
+      unsigned sc[PH];
+      int s_cur = 0, it_cur = 0, slot = 0, gen = 0;
+      auto seen_wait = [&](int it, int T, unsigned target) {
+        if (w == 0) {
+          wait_tile(a.ctl, T, target, lane);
+          if (lane == 0) __hip_atomic_store(&lds_seen[it], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          lds_wait_ge(&lds_seen[it], target, a.ctl);
+        }
+      };
+      {
+        seen_wait(0, g, arrivals);
+        const int b0 = blk(g);
+        const __amdgpu_buffer_rsrc_t dx0 = image(0);
+#pragma unroll
+        for (int q = 0; q < HALF; ++q) ring[q] = __builtin_amdgcn_raw_buffer_load_b128(dx0, lane_off, b0 + (q) * 1024, 0);
+#pragma unroll
+        for (int pl = 0; pl < PH; ++pl) sc[pl] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(0, g, pl), 0);
+      }
+      auto rescale = [&](f32x4& acc, const f32x4& tmp, unsigned e4) {          // acc[r] += tmp[r] 2^(e_r - 127), e_r = byte r of e4
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(tmp[r], __uint_as_float(((e4 >> (8 * r)) & 0xFFu) << 23), acc[r]);
+        // (pinned: left alone the compiler sinks all eight folds of an item behind its last MFMA and keeps eight scratch tiles alive)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+      };
+      for (int k = 0; k < total; ++k) {
+        const int s = s_cur, T = g + it_cur * RB;
+        STAMP(0);
+        int s1 = s, it1 = it_cur + 1;
+        if (it1 == n_it) { it1 = 0; ++s1; }
+        const bool have1 = k + 1 < total;
+        const int T1 = have1 ? g + it1 * RB : T;
+        s1 = have1 ? s1 : s;
+        unsigned pv = 0;
+        const int bcur = blk(T);
+        const __amdgpu_buffer_rsrc_t dxr = image(s);
+        if (w == 0 && lane < NSH)
+          pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 tmp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        unsigned e_prev = 0;
+        u32x4 wl = as_u4(Wl[w][0][lane]);                   // lo-plane fragment of K block 0; the next one is read a K block ahead
+        // first half: producers 0 .. PH - 1 (K blocks 0 .. HALF / 2 - 1); their ring blocks are refilled with this item's second half
+#pragma unroll
+        for (int kb = 0; kb < HALF / 2; ++kb) {
+          const int pl = kb >> 1;
+          const f16x8 ah = __builtin_bit_cast(f16x8, ring[2 * kb]), al = __builtin_bit_cast(f16x8, ring[2 * kb + 1]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, Wh_[kb]), bl = __builtin_bit_cast(f16x8, wl);
+          unsigned e_cur = 0;
+          if ((kb & 1) == 0) e_cur = sc[pl];
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4& t = tmp[pl & 1];
+          if ((kb & 1) == 0) t = f32x4{0.f, 0.f, 0.f, 0.f};
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          // refills IN PLACE behind the MFMAs that read the registers (the fp32 form loads ahead into fresh registers: 8 more VGPRs than
+          // this form has); the lo-plane fragment of the next K block likewise
+          ring[2 * kb] = __builtin_amdgcn_raw_buffer_load_b128(dxr, lane_off, bcur + (HALF + 2 * kb) * 1024, 0);
+          ring[2 * kb + 1] = __builtin_amdgcn_raw_buffer_load_b128(dxr, lane_off, bcur + (HALF + 2 * kb + 1) * 1024, 0);
+          if ((kb & 1) == 0) sc[pl] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s, T, PH + pl), 0);
+          wl = as_u4(Wl[w][kb + 1][lane]);
+          if ((kb & 1) == 0) {                               // the previous producer's six MFMAs are done by now: fold its tile in
+            if (pl > 0) rescale(acc, tmp[(pl - 1) & 1], e_prev);
+            e_prev = e_cur;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // mid-item: dz (and the scales) of the next item must be complete before its fetch starts
+        {
+          const int it1l = have1 ? it1 : it_cur;
+          if (w == 0) {
+            const unsigned tot = shard_sum(pv);
+            if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
+            if (lane == 0) __hip_atomic_store(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            lds_wait_ge(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, a.ctl);
+          }
+          STAMP(1);
+        }
+        const int bnext = blk(T1);
+        const __amdgpu_buffer_rsrc_t dxn = image(s1);
+        // second half: producers PH .. NPW - 1; the ring is refilled, one K block late, with the next item's first half
+#pragma unroll
+        for (int kb = HALF / 2; kb < HALF; ++kb) {
+          const int kr = kb - HALF / 2, pl = kb >> 1, plr = kr >> 1;
+          const f16x8 ah = __builtin_bit_cast(f16x8, ring[2 * kr]), al = __builtin_bit_cast(f16x8, ring[2 * kr + 1]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, Wh_[kb]), bl = __builtin_bit_cast(f16x8, wl);
+          unsigned e_cur = 0;
+          if ((kb & 1) == 0) e_cur = sc[plr];
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4& t = tmp[pl & 1];
+          if ((kb & 1) == 0) t = f32x4{0.f, 0.f, 0.f, 0.f};
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb + 1 < HALF) wl = as_u4(Wl[w][kb + 1][lane]);
+          if ((kb & 1) == 0) {
+            rescale(acc, tmp[(pl - 1) & 1], e_prev);
+            e_prev = e_cur;
+          }
+          if (kr >= 1) {                                     // one K block late: the registers of K block kr - 1 are free by now
+            ring[2 * kr - 2] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (2 * kr - 2) * 1024, 0);
+            ring[2 * kr - 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (2 * kr - 1) * 1024, 0);
+            if ((kr & 1) == 0) sc[plr - 1] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s1, T1, plr - 1), 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        ring[HALF - 2] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (HALF - 2) * 1024, 0);
+        ring[HALF - 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (HALF - 1) * 1024, 0);
+        sc[PH - 1] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s1, T1, PH - 1), 0);
+        rescale(acc, tmp[(NPW - 1) & 1], e_prev);
+        STAMP(2);
+        if (gen > 0) lds_wait_ge(&lds_free[slot], EPW * (unsigned)gen, a.ctl);
+        float* rw = &red[slot][w][0][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[r * 64] = acc[r] * inv_sw;
+        if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        STAMP(3);
         if (++slot == NSLOT_B) { slot = 0; ++gen; }
         if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
       }
@@ -1186,6 +1380,44 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
     };
     auto publish_stores = [&](int T, int pub, const float (&dzv)[4][4]) {
       const __amdgpu_buffer_rsrc_t dxr = image(pub);
+      if constexpr (H2) {
+        // this workgroup's 16 rows x 64 values of the tile under one power of two per ROW (its maximum over the 16 units x 4 gates
+        // into [2^13, 2^14)): blocks 2 ub + (unit / 8) of the permuted K order, both planes; the inverse exponents of the row quad in
+        // one word (lane unit 0).  An all-zero row (a video that has ended, a padded row) keeps scale 1.
+        const __amdgpu_buffer_rsrc_t scr = make_rsrc(a.sc, a.sc_bytes);
+        unsigned ex = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float m = fmaxf(fmaxf(fabsf(dzv[r][0]), fabsf(dzv[r][1])), fmaxf(fabsf(dzv[r][2]), fabsf(dzv[r][3])));
+          m = fmaxf(m, row_ror<8>(m));
+          m = fmaxf(m, row_ror<4>(m));
+          m = fmaxf(m, row_ror<2>(m));
+          m = fmaxf(m, row_ror<1>(m));
+          const unsigned eb = __float_as_uint(m) >> 23;       // m >= 0: the biased exponent; m = f 2^(eb - 126), f in [0.5, 1)
+          const bool ok = m > 7.9e-31f && m < 3.0e38f;        // (yt8m_x3::pow2_scale_for's guard)
+          const float S = __uint_as_float((ok ? 267u - eb : 127u) << 23);      // 2^(14 - (eb - 126))
+          ex |= (ok ? eb - 13u : 127u) << (8 * r);            // biased exponent of 1 / S
+          unsigned hb[4], lb[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) yt8m_x3::split_h2(dzv[r][g4] * S, hb[g4], lb[g4]);
+          const unsigned h0 = hb[0] | (hb[1] << 16), h1 = hb[2] | (hb[3] << 16), l0 = lb[0] | (lb[1] << 16), l1 = lb[2] | (lb[3] << 16);
+          const unsigned h2_ = row_shl_u<1>(h0), h3 = row_shl_u<1>(h1), l2 = row_shl_u<1>(l0), l3 = row_shl_u<1>(l1);
+          if ((eunit & 1) == 0) {
+            u32x4 vh, vl;
+            vh.x = h0; vh.y = h1; vh.z = h2_; vh.w = h3;
+            vl.x = l0; vl.y = l1; vl.z = l2; vl.w = l3;
+            const unsigned off = (((unsigned)(T * (H >> 3)) + 2u * (unsigned)ub + (unsigned)(eunit >> 3)) * 2u) * 1024u +
+                                 ((unsigned)((eunit >> 1) & 3) * 16u + (unsigned)(4 * rq + r)) * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(vh, dxr, (int)off, 0, YT8M_AUX_ST);
+            __builtin_amdgcn_raw_buffer_store_b128(vl, dxr, (int)(off + 1024u), 0, YT8M_AUX_ST);
+          }
+        }
+        if (eunit == 0)
+          __builtin_amdgcn_raw_buffer_store_b32(ex, scr, (int)((((unsigned)(pub * NT16 + T) * (unsigned)a.NUB + (unsigned)ub) * 4u + (unsigned)rq) * 4u), 0,
+                                                YT8M_AUX_ST);
+        pend_T = T;
+        return;
+      }
       if constexpr (BF) {
         // A fragments of v_mfma_f32_16x16x32_bf16: block (T, kbg) = [4 k-groups][16 rows][8 bf16]; this workgroup's 16 units of gate
         // g4 are k = g4 H + 16 ub + unit: K block g4 (H / 32) + ub / 2, k-groups 2 (ub & 1) + unit / 8.  Eight units of a row = one
@@ -1764,7 +1996,9 @@ extern "C" int64_t yt8m_lstm_persist_workspace_bytes(int64_t B, int64_t H) {
 extern "C" int64_t yt8m_lstm_persist_workspace_bytes_steps(int64_t B, int64_t H, int64_t T) {
   Geometry geo;
   if (!persist_geometry(B, H, &geo)) return 0;
-  return ctl_padded(geo.NT16) + std::max<int64_t>(T, 2) * geo.NT16 * 16 * 4 * H * 4 + DBG_BYTES;
+  // (+ the scale words of the f16 form of the backward recurrence: yt8m_lstm_persist_bwd_h2)
+  return ctl_padded(geo.NT16) + std::max<int64_t>(T, 2) * geo.NT16 * 16 * 4 * H * 4 + ((std::max<int64_t>(T, 2) * geo.NT16 * (H / 16) * 16 + 255) / 256) * 256 +
+         DBG_BYTES;
 }
 
 // Since the last reset on the current device: persistent launches, their workgroups, and how many of those did not run on the XCD
@@ -1954,6 +2188,12 @@ int launch_bwd_sh(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
       return yt8m::launch_status("lstm_persist_bwd_kernel");
     }
   }
+  if constexpr (SH && (NQB == 16 || NQB == 32)) {
+    if (a.h2 && rot) {
+      hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, true, true, false, false, true>), dim3(grid), dim3(768), 0, s, a);
+      return yt8m::launch_status("lstm_persist_bwd_kernel");
+    }
+  }
   if (rot) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, true>), dim3(grid), dim3(768), 0, s, a);
   else if (a.pf) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, SH, false>), dim3(grid), dim3(768), 0, s, a);
   else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, false, SH, false>), dim3(grid), dim3(768), 0, s, a);
@@ -1982,7 +2222,9 @@ namespace {
 int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
-                     yt8m_stream_t stream, bool bf16 = false);
+                     yt8m_stream_t stream, bool bf16 = false, const void* h2_wword = nullptr);
+// bytes of the scale words an H2 launch of T steps publishes (one word per step, tile, producer workgroup and row quad), 256-aligned
+int64_t h2_scale_bytes(int NT16, int64_t H, int64_t T) { return ((T * NT16 * (H / 16) * 16 + 255) / 256) * 256; }
 }
 
 extern "C" int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
@@ -2000,6 +2242,28 @@ extern "C" int yt8m_lstm_persist_bwd_bf16(const float* gates, const float* Wh, i
                                           int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
   return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, dbias_rows, num_frames, t0, T, B, H, workspace, workspace_bytes,
                           nullptr, stream, true);
+}
+
+// yt8m_lstm_persist_bwd with the recurrent product dz . W_h^T as THREE f16 products of two-half-plane splits (fp32-grade: 2^-21 relative per
+// term, like yt8m_gemm_h2_nt_grouped) instead of the fp32 matrix pipe: 48 MFMAs of 16 cycles per item and wave instead of 128 of 32.
+// wh_absmax: device word holding max |W_h| as float bits (yt8m_h2_absmax over the [H, 4H] block).  Results differ from
+// yt8m_lstm_persist_bwd by fp32 rounding only.  A permission like the bf16 form: launches that cannot take it (H not 512 / 1024, tiles per
+// workgroup not a multiple of four, a workspace without one image per step + the scale words: yt8m_lstm_persist_workspace_bytes_steps
+// has the room) run the fp32 form.  YT8M_PERSIST_BWD_H2=0 turns the request off process-wide.
+extern "C" int yt8m_lstm_persist_bwd_h2(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                                        float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
+                                        int64_t B, int64_t H, const void* wh_absmax, void* workspace, int64_t workspace_bytes,
+                                        yt8m_stream_t stream) {
+  YT8M_REQUIRE(wh_absmax, YT8M_E_BADARG, "null absmax word");
+  static const bool off = getenv("YT8M_PERSIST_BWD_H2") != nullptr && atoi(getenv("YT8M_PERSIST_BWD_H2")) == 0;
+  return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, dbias_rows, num_frames, t0, T, B, H, workspace, workspace_bytes,
+                          nullptr, stream, false, off ? nullptr : wh_absmax);
+}
+// 1 when yt8m_lstm_persist_bwd_h2 takes the f16 form for a T-step launch on a workspace of yt8m_lstm_persist_workspace_bytes_steps(B, H, T)
+extern "C" int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H) {
+  GeometryB geo;
+  if (!persist_geometry(B, H, nullptr) || !persist_geometry_bwd(B, H, &geo)) return 0;
+  return ((H == 512 || H == 1024) && bwd_rot(geo.pf, geo.NT16, geo.RB)) ? 1 : 0;
 }
 
 // yt8m_lstm_persist_bwd that also leaves the operand images of dz[t0 .. t0 + T) for the products that follow (include/yt8m_hip.h).
@@ -2021,7 +2285,7 @@ namespace {
 int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
-                     yt8m_stream_t stream, bool bf16) {
+                     yt8m_stream_t stream, bool bf16, const void* h2_wword) {
   using namespace yt8m;
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
@@ -2052,6 +2316,17 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
   a.nimg = images_in(workspace_bytes, geo.NT16, 4 * H);
   a.bf = (bf16 && !img) ? 1 : 0;
   a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES);
+  // H2: the scale words sit between the last exchange image and the debug tail; taken only when T images still fit in front of them
+  a.h2 = 0; a.wword = nullptr; a.sc = nullptr; a.sc_bytes = 0;
+  if (h2_wword && !img && !bf16 && (H == 512 || H == 1024)) {
+    const int64_t scb = h2_scale_bytes(geo.NT16, H, T);
+    if (scb < (1LL << 31) && images_in(workspace_bytes - scb, geo.NT16, 4 * H) >= T) {
+      a.h2 = 1;
+      a.wword = static_cast<const unsigned*>(h2_wword);
+      a.sc = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES - scb);
+      a.sc_bytes = (unsigned)scb;
+    }
+  }
   const unsigned grid = (unsigned)(geo.NUB * geo.RB);
   int dev = 0;
   device_cus(&dev);

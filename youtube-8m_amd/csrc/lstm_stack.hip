@@ -454,6 +454,10 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
     const int64_t Din = l ? H : D;
     YT8M_HIP_CHECK(hipMemsetAsync(at<char>(tape, P.cs[l]), 0, (size_t)BH * 4, s));
     YT8M_HIP_CHECK(hipMemsetAsync(at<char>(tape, P.hs[l]), 0, (size_t)BH * 4, s));
+    if (!bf) {                                             // max |W_h| (word 63 of the layer's scale words): the backward recurrence's f16 form
+      YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc + 256 * l + 252), 0, 4, s));
+      RC(yt8m_h2_absmax(W[l] + Din * H4, H, H4, H4, at<char>(scratch, P.hsc + 256 * l + 252), (yt8m_stream_t)s));
+    }
     if (l == 0 && P.u8) {
       if (P.h2) {
         // (q - 128) as a ONE-plane half image (exact), (alpha W_x)^T as an h2 image under a device-measured scale: two f16 products
@@ -580,7 +584,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   if (two_sw) ev.wait(S->sw2, start);
   for (int l = 0; l < P.L; ++l) { ev.wait(S->rs[l], start); if (dx_stream) ev.wait(S->dxs[l], start); }
   if (P.h2)                                                // the parts' absmax words; word 0 of a layer (max |W_x|, the forward's) stays
-    for (int l = 0; l < P.L; ++l) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc + 256 * l + 4), 0, 64, sw));
+    for (int l = 0; l < P.L; ++l) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc + 256 * l + 4), 0, 248, sw));   // words 1 .. 62
   // weight-gradient stream: the whole-sequence transposed operands (K = frame rows), made while the first recurrence runs alone
   for (int l = 0; l < P.L; ++l) {
     if (!dW[l]) continue;
@@ -687,6 +691,14 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // bf16-operand mode: the recurrent product of the backward pass on one bf16 plane too (knob YT8M_STACK_BF16_RECUR, default 1;
         // the launch falls back to the fp32 form by itself where the shape cannot take it)
         static const int bf_recur = knob("YT8M_STACK_BF16_RECUR", 1);
+        // fp32 configuration: the recurrent product as three f16 products of two-half-plane splits (yt8m_lstm_persist_bwd_h2: fp32-grade,
+        // 14.8 instead of 18.3 us per step; knob YT8M_STACK_H2_RECUR, default 1; falls back by itself where the shape cannot take it)
+        static const int h2_recur = knob("YT8M_STACK_H2_RECUR", 1);
+        if (!bf && h2_recur)
+          RC(yt8m_lstm_persist_bwd_h2(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
+                                      at<float>(scratch, P.work[l]), phase[l], nullptr, num_frames, t0, T, B, H,
+                                      at<char>(scratch, P.hsc + 256 * l + 252), at<char>(scratch, P.pws[l]), P.pws_bytes, s));
+        else
         RC((bf && bf_recur ? yt8m_lstm_persist_bwd_bf16 : yt8m_lstm_persist_bwd)(
             at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz, at<float>(scratch, P.work[l]), phase[l],
             nullptr, num_frames, t0, T, B, H, at<char>(scratch, P.pws[l]), P.pws_bytes, s));
@@ -765,7 +777,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           // layer 0 on uint8 frames as f16 products: ONE pass over this part's dz (after its absmax) writes dz^T and (r (.) dz)^T as h2
           // images + the per-tile column sums; dW_x = (q - 128)^T . (r (.) dz) on two products, dW_h = h^T . dz on three
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
-          float* word = at<float>(scratch, P.hsc) + 1 + c;
+          float* word = at<float>(scratch, P.hsc) + 1 + std::min(c, 61);
           RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
           float* cp = P.colparts ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
           float* cps = P.colparts ? at<float>(scratch, P.cparts) + (t0 * B / 64) * H4 : nullptr;
@@ -800,7 +812,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         } else if (P.h2 && l >= 1) {
           // three f16 products: dz^T of this part under a scale measured on the device (a sum over the part's frame rows: one scale
           // serves it), h^T / out^T under the static 2^13; the bias gradient's per-tile column sums ride on the split as before
-          float* word = at<float>(scratch, P.hsc + 256 * l) + 1 + c;                             // one word per backward part (zeroed at the start)
+          float* word = at<float>(scratch, P.hsc + 256 * l) + 1 + std::min(c, 61);                             // one word per backward part (zeroed at the start)
           RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
           float* cp = (P.colparts && db[l]) ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
           RC(yt8m_h2_split(dzc, M, H4, H4, 1.0f, word, nullptr, at<char>(scratch, P.dzT3[l]), cp, (yt8m_stream_t)sw));
