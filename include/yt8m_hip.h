@@ -126,6 +126,11 @@ int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
 int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* dscale, void* plain, void* trans,
                   float* colpart, yt8m_stream_t stream);
 int yt8m_h2_absmax(const float* src, int64_t R, int64_t C, int64_t ld, void* word, yt8m_stream_t stream);
+/* yt8m_h2_rowscales + yt8m_h2_split_rows in one pass over src when the row maxima are already known (rowmax[r] = max |src[r, :]| as float
+ * bits, e.g. from yt8m_lstm_persist_bwd_ex): the plain h2 image [R rows, K = C] of diag(S) . src, S[r] the power of two that brings the
+ * row's maximum into [2^13, 2^14) (1 for an all-zero row), and inv[r] = 1 / S[r] (the rowscale of yt8m_gemm_h2_nt_ex). */
+int yt8m_h2_split_rowmax(const float* src, int64_t R, int64_t C, int64_t ld, const void* rowmax, float* inv, void* plain,
+                         yt8m_stream_t stream);
 /* h2 forms of yt8m_x3_split_colsum and yt8m_gemm_x1x3_nt_ex -- the uint8 layer-0 projection and weight gradient of the recurrent stack
  * (readers.py:178-187 folded into lstm_model.py:34-47 and its gradient) as TWO f16 products: A1 = (q - 128) as a one-plane HALF image
  * (exact; yt8m_u8_frames_image_f16 / _t_f16: the half forms of yt8m_u8_frames_image / _t), B2 = an h2 image under the device-chosen
@@ -616,6 +621,14 @@ int yt8m_lstm_persist_bwd_h2(const float* gates, const float* Wh, int64_t ldw, c
                              float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                              int64_t B, int64_t H, const void* wh_absmax, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H);
+/* yt8m_lstm_persist_bwd (wh_absmax NULL) / yt8m_lstm_persist_bwd_h2 that also measures, while it writes dz, what the products after it
+ * would otherwise measure in passes over dz (105-210 MB each at the headline shape): rowmax[t B + b] = max |dz[t, b, :]| as float bits ([F B]
+ * words by absolute frame row, zeroed by the caller; the operand of yt8m_h2_split_rowmax) and / or partmax = max |dz| of the launch (one
+ * zeroed word; the dscale / dsb operand of yt8m_h2_split / yt8m_gemm_h2_nt_grouped).  Either may be NULL.  Needs the rotated epilogue
+ * (yt8m_lstm_persist_bwd_images_rows(B, H) > 0) on a workspace of yt8m_lstm_persist_workspace_bytes_steps, else YT8M_E_SHAPE. */
+int yt8m_lstm_persist_bwd_ex(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz, float* work,
+                             int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, const void* wh_absmax,
+                             void* rowmax, void* partmax, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* The same launch with the operand images of dz[t0 .. t0 + T) written by the recurrence itself (round 4): what yt8m_x3_split /
  * yt8m_x3_split_colsum would make of that part of dz in separate passes -- bit for bit -- for the products that follow it in the
  * backward pass of BasicLSTMCell under dynamic_rnn (W/all_frame_models/lstm_model.py:34-47 through tf.gradients, W/train.py:461):

@@ -121,3 +121,52 @@ def test_f16_form_is_a_permission(dev, monkeypatch):
     a = _run(lib, "f32", gates, Wh, cs, dout, nf, 0, F)
     b = _run(lib, "h2", gates, Wh, cs, dout, nf, 0, F, word)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_recurrence_measures_the_row_and_launch_maxima_of_dz(dev, f16):
+    """yt8m_lstm_persist_bwd_ex: rowmax[t B + b] and the launch's word equal max |dz| of what the launch stored -- bit for bit, so the
+    scales derived from them are the ones yt8m_h2_rowscales / yt8m_h2_absmax would derive in their passes over dz -- and dz itself is
+    what the plain entry point produces."""
+    lib = _lib.lib()
+    B, F, H = 128, 20, 1024
+    assert lib.yt8m_lstm_persist_bwd_images_rows(B, H) > 0
+    gates, Wh, cs, dout, nf = _inputs(dev, B, F, H, 17, 4)
+    word = _absmax_word(lib, Wh)
+    t0, T = 4, F - 4
+    ref = _run(lib, "h2" if f16 else "f32", gates, Wh, cs, dout, nf, t0, T, word)
+    dz = torch.zeros((F, B, 4 * H), device=dev)
+    work = torch.zeros((4, B, H), device=dev)
+    g = torch.Generator(device=dev).manual_seed(99)
+    work[0] = torch.randn((B, H), device=dev, generator=g) * 0.02
+    work[1] = torch.randn((B, H), device=dev, generator=g) * 0.02
+    pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, T), dtype=torch.uint8, device=dev)
+    rowmax = torch.zeros(F * B, dtype=torch.int32, device=dev)
+    part = torch.zeros(64, dtype=torch.int32, device=dev)
+    _lib.check(lib.yt8m_lstm_persist_bwd_ex(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), 0, _p(nf), t0, T, B, H,
+                                            _p(word) if f16 else None, _p(rowmax), _p(part), _p(pws), pws.numel(), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dz, ref[0]) and torch.equal(work, ref[1])
+    want = dz.abs().amax(dim=2).reshape(-1)
+    assert torch.equal(rowmax.view(torch.float32), want)
+    assert float(part.view(torch.float32)[0]) == float(want.max())
+    assert int((want == 0).sum()) > 0                                       # ended videos / zero rows were part of the case
+
+
+def test_split_rowmax_equals_rowscales_plus_split_rows(dev):
+    lib = _lib.lib()
+    R, C = 640, 4096
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn((R, C), device=dev, generator=g) * (10.0 ** (-6 * torch.rand((R, 1), device=dev, generator=g)))
+    x[5] = 0.0
+    nbytes = lib.yt8m_x3_image_bytes(R, C) // 3 * 2
+    S, inv = torch.empty(R, device=dev), torch.empty(R, device=dev)
+    a = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.yt8m_h2_rowscales(_p(x), R, C, C, _p(S), _p(inv), _stream()))
+    _lib.check(lib.yt8m_h2_split_rows(_p(x), R, C, C, _p(S), _p(a), _stream()))
+    rowmax = x.abs().amax(dim=1).contiguous()
+    b = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    inv2 = torch.empty(R, device=dev)
+    _lib.check(lib.yt8m_h2_split_rowmax(_p(x), R, C, C, _p(rowmax), _p(inv2), _p(b), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(inv, inv2)

@@ -100,7 +100,7 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
               flush=True)
 
 
-def timing_bwd(B=int(os.environ.get("PCHECK_B", "128")), F=300, H=1024):
+def timing_bwd(B=int(os.environ.get("PCHECK_B", "128")), F=int(os.environ.get("PCHECK_F", "300")), H=1024):
     lib = L.lib()
     from yt8m_amd.ops import _p, _stream
     gates = torch.rand((F, B, 4 * H), device=dev)

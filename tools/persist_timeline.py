@@ -24,7 +24,8 @@ hs = torch.zeros((F + 1, B, H), device=dev)
 out = torch.empty((F, B, H), device=dev)
 nb = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if os.environ.get("PSTEPS") else lib.yt8m_lstm_persist_workspace_bytes(B, H)
 pws = torch.zeros(nb, dtype=torch.uint8, device=dev)
-BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
+BWD = len(sys.argv) > 1 and sys.argv[1] in ("bwd", "bwd_h2", "bwd_bf16")
+MODE = sys.argv[1] if len(sys.argv) > 1 else "fwd"         # bwd_h2 / bwd_bf16: the f16 / one-plane bf16 forms of the recurrent product
 gates = torch.rand((F, B, 4 * H), device=dev)
 csr = torch.randn((F + 1, B, H), device=dev) * 0.5
 dz = torch.empty((F, B, 4 * H), device=dev)
@@ -34,8 +35,14 @@ for it in range(2):
         work = torch.zeros((4, B, H), device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.yt8m_lstm_persist_bwd(_p(gates), _p(Wh), 4 * H, _p(csr), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), nb,
-                                          _stream()))
+        if MODE == "bwd_h2":
+            wword = torch.zeros(64, dtype=torch.int32, device=dev)
+            L.check(lib.yt8m_h2_absmax(_p(Wh), H, 4 * H, 4 * H, _p(wword), _stream()))
+            L.check(lib.yt8m_lstm_persist_bwd_h2(_p(gates), _p(Wh), 4 * H, _p(csr), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H,
+                                                 _p(wword), _p(pws), nb, _stream()))
+        else:
+            L.check((lib.yt8m_lstm_persist_bwd_bf16 if MODE == "bwd_bf16" else lib.yt8m_lstm_persist_bwd)(
+                _p(gates), _p(Wh), 4 * H, _p(csr), _p(dout), _p(dz), _p(work), 0, None, None, 0, F, B, H, _p(pws), nb, _stream()))
         e1.record()
         torch.cuda.synchronize()
         print("bwd kernel %.3f ms = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / F))

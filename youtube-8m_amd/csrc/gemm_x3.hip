@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
                                                        float* __restrict__ trans, float scale, const float* __restrict__ rowscale,
                                                        float* __restrict__ trans_s, float* __restrict__ colpart = nullptr,
                                                        float* __restrict__ colpart_s = nullptr, const float* __restrict__ dscale = nullptr,
-                                                       const float* __restrict__ rowS = nullptr) {
+                                                       const float* __restrict__ rowS = nullptr, const unsigned* __restrict__ rowmaxw = nullptr,
+                                                       float* __restrict__ rowinv = nullptr) {
+  // rowmaxw (NP = 2, plain image only; instead of rowS): max |src[r, :]| as float bits (measured by the producer of src: yt8m_lstm_persist_bwd_ex);
+  // the row's power of two is derived here, the workgroups of the first tile column write its inverse to rowinv (the product's rowscale)
   // rowS (NP = 2, plain image only): row r of the source is scaled by rowS[r] -- one power of two PER ROW (yt8m_h2_rowscales): the
   // operand of a product whose rows must each keep their own precision (dx = dz . W^T of time steps whose gradients differ by decades)
   __shared__ float T[64][65];
@@ -1091,7 +1094,12 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
           if (c0 + c4 + 3 < Cc) v.w = p[3];
         }
       }
-      const float sr = (rowS && r0 + r < R) ? scale * rowS[r0 + r] : scale;
+      float sr = (rowS && r0 + r < R) ? scale * rowS[r0 + r] : scale;
+      if (rowmaxw && r0 + r < R) {
+        const float pr = yt8m_x3::pow2_scale_for(__uint_as_float(rowmaxw[r0 + r]), 14);
+        sr = scale * pr;
+        if (rowinv && blockIdx.x == 0 && (t & 15) == 0) rowinv[r0 + r] = 1.0f / pr;
+      }
       T[r][c4 + 0] = v.x * sr; T[r][c4 + 1] = v.y * sr; T[r][c4 + 2] = v.z * sr; T[r][c4 + 3] = v.w * sr;
     }
   }
@@ -1298,6 +1306,20 @@ extern "C" int yt8m_h2_split_rows(const float* src, int64_t R, int64_t C, int64_
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      (float*)nullptr, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, S);
+  return launch_status("x3_split_kernel<2>");
+}
+// yt8m_h2_rowscales + yt8m_h2_split_rows in ONE pass when the row maxima are already known: rowmax[r] = max |src[r, :]| as float bits
+// (yt8m_lstm_persist_bwd_ex measures them while it writes dz); writes the plain h2 image of diag(S) . src and inv[r] = 1 / S[r].
+extern "C" int yt8m_h2_split_rowmax(const float* src, int64_t R, int64_t C, int64_t ld, const void* rowmax, float* inv, void* plain,
+                                    yt8m_stream_t stream) {
+  YT8M_REQUIRE(src && rowmax && inv && plain && R >= 1 && C >= 1 && ld >= C && R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "bad arguments");
+  YT8M_REQUIRE((reinterpret_cast<uintptr_t>(plain) & 15) == 0, YT8M_E_BADARG, "images must be 16-byte aligned");
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
+                     (float*)nullptr, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, static_cast<const unsigned*>(rowmax), inv);
   return launch_status("x3_split_kernel<2>");
 }
 // C[M,N] (+)= alpha . rowscale[m] / (S_a S_b) . A . B^T (+ bias): yt8m_gemm_h2_nt_grouped for one product with a per-row factor

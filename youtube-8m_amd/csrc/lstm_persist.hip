@@ -881,6 +881,9 @@ struct PersistBwdArgs {
   const unsigned* wword;// H2: max |W_h| as float bits (yt8m_h2_absmax)
   unsigned* sc;         // H2: per (publish, tile, producer workgroup, row quad) one word of four inverse-scale exponents
   unsigned sc_bytes;
+  unsigned* rowmax;     // rotated epilogue, or null: max |dz[t, b, :]| as float bits by absolute frame row t B + b (atomicMax over the 64
+                        // producer workgroups of a row; zeroed by the caller) -- what yt8m_h2_rowscales would measure in a pass over dz
+  unsigned* partmax;    // ... or null: max |dz| of the whole launch into one word (atomicMax; what yt8m_h2_absmax would measure)
   unsigned long long* dbg;
   // IMG (rotated epilogue only): the operand images of this launch's dz written by the epilogue itself -- what yt8m_x3_split would
   // make of dz[t0 .. t0 + T) in separate passes (csrc/gemm_x3.hip image layout: 1 KiB blocks of 32 rows x 16 k per plane).
@@ -1128,6 +1131,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 #pragma unroll
         for (int pl = 0; pl < PH; ++pl) sc[pl] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(0, g, pl), 0);
       }
+      u32x4 wlb[2] = {as_u4(Wl[w][0][lane]), as_u4(Wl[w][1][lane])};
       auto rescale = [&](f32x4& acc, const f32x4& tmp, unsigned e4) {          // acc[r] += tmp[r] 2^(e_r - 127), e_r = byte r of e4
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(tmp[r], __uint_as_float(((e4 >> (8 * r)) & 0xFFu) << 23), acc[r]);
@@ -1148,34 +1152,30 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         if (w == 0 && lane < NSH)
           pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        f32x4 tmp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        unsigned e_prev = 0;
-        u32x4 wl = as_u4(Wl[w][0][lane]);                   // lo-plane fragment of K block 0; the next one is read a K block ahead
-        // first half: producers 0 .. PH - 1 (K blocks 0 .. HALF / 2 - 1); their ring blocks are refilled with this item's second half
+        f32x4 tmp = {0.f, 0.f, 0.f, 0.f};
+        unsigned e_cur = 0;
+        // first half: producers 0 .. PH - 1 (K blocks 0 .. HALF / 2 - 1); their ring blocks are refilled with this item's second half.
+        // The lo-plane weight fragment of a K block is read from LDS TWO K blocks ahead of its MFMA (wlb[kb & 1], carried over the item
+        // boundary): read one block ahead, every K block waited ~100 cycles for it (tools/persist_timeline.py: 1.6k of an 8.1k-cycle item).
 #pragma unroll
         for (int kb = 0; kb < HALF / 2; ++kb) {
           const int pl = kb >> 1;
           const f16x8 ah = __builtin_bit_cast(f16x8, ring[2 * kb]), al = __builtin_bit_cast(f16x8, ring[2 * kb + 1]);
-          const f16x8 bh = __builtin_bit_cast(f16x8, Wh_[kb]), bl = __builtin_bit_cast(f16x8, wl);
-          unsigned e_cur = 0;
+          const f16x8 bh = __builtin_bit_cast(f16x8, Wh_[kb]), bl = __builtin_bit_cast(f16x8, wlb[kb & 1]);
           if ((kb & 1) == 0) e_cur = sc[pl];
           __builtin_amdgcn_sched_barrier(0);
-          f32x4& t = tmp[pl & 1];
-          if ((kb & 1) == 0) t = f32x4{0.f, 0.f, 0.f, 0.f};
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t, 0, 0, 0);
+          if ((kb & 1) == 0) tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, tmp, 0, 0, 0);
+          tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, tmp, 0, 0, 0);
+          tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, tmp, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           // refills IN PLACE behind the MFMAs that read the registers (the fp32 form loads ahead into fresh registers: 8 more VGPRs than
-          // this form has); the lo-plane fragment of the next K block likewise
+          // this form has)
+          wlb[kb & 1] = as_u4(Wl[w][kb + 2][lane]);
           ring[2 * kb] = __builtin_amdgcn_raw_buffer_load_b128(dxr, lane_off, bcur + (HALF + 2 * kb) * 1024, 0);
           ring[2 * kb + 1] = __builtin_amdgcn_raw_buffer_load_b128(dxr, lane_off, bcur + (HALF + 2 * kb + 1) * 1024, 0);
           if ((kb & 1) == 0) sc[pl] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s, T, PH + pl), 0);
-          wl = as_u4(Wl[w][kb + 1][lane]);
-          if ((kb & 1) == 0) {                               // the previous producer's six MFMAs are done by now: fold its tile in
-            if (pl > 0) rescale(acc, tmp[(pl - 1) & 1], e_prev);
-            e_prev = e_cur;
-          }
+          if (kb & 1) rescale(acc, tmp, e_cur);              // the producer's six MFMAs: its tile times its rows' inverse scales
           __builtin_amdgcn_sched_barrier(0);
         }
         // mid-item: dz (and the scales) of the next item must be complete before its fetch starts
@@ -1192,37 +1192,28 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         }
         const int bnext = blk(T1);
         const __amdgpu_buffer_rsrc_t dxn = image(s1);
-        // second half: producers PH .. NPW - 1; the ring is refilled, one K block late, with the next item's first half
+        // second half: producers PH .. NPW - 1; the ring is refilled with the next item's first half
 #pragma unroll
         for (int kb = HALF / 2; kb < HALF; ++kb) {
-          const int kr = kb - HALF / 2, pl = kb >> 1, plr = kr >> 1;
+          const int kr = kb - HALF / 2, plr = kr >> 1;
           const f16x8 ah = __builtin_bit_cast(f16x8, ring[2 * kr]), al = __builtin_bit_cast(f16x8, ring[2 * kr + 1]);
-          const f16x8 bh = __builtin_bit_cast(f16x8, Wh_[kb]), bl = __builtin_bit_cast(f16x8, wl);
-          unsigned e_cur = 0;
+          const f16x8 bh = __builtin_bit_cast(f16x8, Wh_[kb]), bl = __builtin_bit_cast(f16x8, wlb[kb & 1]);
           if ((kb & 1) == 0) e_cur = sc[plr];
           __builtin_amdgcn_sched_barrier(0);
-          f32x4& t = tmp[pl & 1];
-          if ((kb & 1) == 0) t = f32x4{0.f, 0.f, 0.f, 0.f};
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t, 0, 0, 0);
+          if ((kb & 1) == 0) tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, tmp, 0, 0, 0);
+          tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, tmp, 0, 0, 0);
+          tmp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, tmp, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (kb + 1 < HALF) wl = as_u4(Wl[w][kb + 1][lane]);
-          if ((kb & 1) == 0) {
-            rescale(acc, tmp[(pl - 1) & 1], e_prev);
-            e_prev = e_cur;
+          wlb[kb & 1] = as_u4(Wl[w][(kb + 2) % HALF][lane]);   // (the last two: K blocks 0 and 1 of the next item)
+          ring[2 * kr] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (2 * kr) * 1024, 0);
+          ring[2 * kr + 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (2 * kr + 1) * 1024, 0);
+          if (kb & 1) {
+            sc[plr] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s1, T1, plr), 0);
+            rescale(acc, tmp, e_cur);
           }
-          if (kr >= 1) {                                     // one K block late: the registers of K block kr - 1 are free by now
-            ring[2 * kr - 2] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (2 * kr - 2) * 1024, 0);
-            ring[2 * kr - 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (2 * kr - 1) * 1024, 0);
-            if ((kr & 1) == 0) sc[plr - 1] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s1, T1, plr - 1), 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        ring[HALF - 2] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (HALF - 2) * 1024, 0);
-        ring[HALF - 1] = __builtin_amdgcn_raw_buffer_load_b128(dxn, lane_off, bnext + (HALF - 1) * 1024, 0);
-        sc[PH - 1] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s1, T1, PH - 1), 0);
-        rescale(acc, tmp[(NPW - 1) & 1], e_prev);
         STAMP(2);
         if (gen > 0) lds_wait_ge(&lds_free[slot], EPW * (unsigned)gen, a.ctl);
         float* rw = &red[slot][w][0][lane];
@@ -1493,6 +1484,27 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       wk[0] = base_out;
       wk[BH] = dc_out;
     };
+    // Row maxima of dz for the products that follow (a.rowmax / a.partmax): this workgroup's 64 values of each of the lane's four rows,
+    // reduced over the 16 lanes of the DPP row; one atomicMax per (row, workgroup) on the row's word -- the bit pattern of a non-negative
+    // float orders like the float -- issued AFTER the tile's arrival (nothing on the state's chain waits for them), and a running
+    // maximum per lane that becomes one atomicMax per wave at the end of the launch.
+    float part_m = 0.f;
+    auto emit_rowmax = [&](int t1, int T, const float (&dzv)[4][4]) {
+      if (!a.rowmax && !a.partmax) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float m = fmaxf(fmaxf(fabsf(dzv[r][0]), fabsf(dzv[r][1])), fmaxf(fabsf(dzv[r][2]), fabsf(dzv[r][3])));
+        m = fmaxf(m, row_ror<8>(m));
+        m = fmaxf(m, row_ror<4>(m));
+        m = fmaxf(m, row_ror<2>(m));
+        m = fmaxf(m, row_ror<1>(m));
+        const int brow = T * 16 + 4 * rq + r;
+        if (!(m < 3.0e38f)) m = 0.f;                       // (inf / nan: the products clamp; the word keeps a finite maximum)
+        part_m = fmaxf(part_m, m);
+        if (a.rowmax && eunit == 0 && brow < B && m > 0.f)
+          __hip_atomic_fetch_max(a.rowmax + (long long)t1 * B + brow, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
     // Operand images of dz (IMG): the wave holds a whole 16-row x 16-unit tile of every gate after the gate backward -- one
     // 16-wide K block of the transposed image (K = frame rows) for 16 image rows, and 16 rows of one K block of the plain image
     // (K = gate columns).  Issued AFTER the tile's arrival: nothing on the state's dependency chain waits for these ~500 VALU
@@ -1593,6 +1605,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       publish_stores(T, 0, dzv);
       arrive();
       emit_images(t_hi, T, dzv);
+      emit_rowmax(t_hi, T, dzv);
     }
     for (int s = 0; s < a.T; ++s) {
       const int t1 = t_hi - s - 1;
@@ -1649,9 +1662,15 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         for (int r = 0; r < 4; ++r)
           if (valid[r]) store_std(t1, brow[r], dzv[r], dc_out[r], base_out[r], half ^ 1);
         emit_images(t1, T, dzv);
+        emit_rowmax(t1, T, dzv);
       }
     }
     arrive();
+    if (a.partmax) {                                       // the launch's maximum: lanes of unit 0 hold their row quads' running maxima
+      float m = fmaxf(part_m, __shfl_xor(part_m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (lane == 0 && m > 0.f) __hip_atomic_fetch_max(a.partmax, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (IMG) {
       // column sums of this wave's tiles over the launch: the four row quads of a unit meet in the lane with rq == 0 (fixed order)
       if (a.colpart || a.colpart_s) {
@@ -2222,7 +2241,7 @@ namespace {
 int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
-                     yt8m_stream_t stream, bool bf16 = false, const void* h2_wword = nullptr);
+                     yt8m_stream_t stream, bool bf16 = false, const void* h2_wword = nullptr, void* rowmax = nullptr, void* partmax = nullptr);
 // bytes of the scale words an H2 launch of T steps publishes (one word per step, tile, producer workgroup and row quad), 256-aligned
 int64_t h2_scale_bytes(int NT16, int64_t H, int64_t T) { return ((T * NT16 * (H / 16) * 16 + 255) / 256) * 256; }
 }
@@ -2259,6 +2278,19 @@ extern "C" int yt8m_lstm_persist_bwd_h2(const float* gates, const float* Wh, int
   return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, dbias_rows, num_frames, t0, T, B, H, workspace, workspace_bytes,
                           nullptr, stream, false, off ? nullptr : wh_absmax);
 }
+// yt8m_lstm_persist_bwd / _h2 (wh_absmax NULL: the fp32-pipe form) that also measures what the products after it would measure in passes
+// over dz: rowmax[t B + b] = max |dz[t, b, :]| (float bits; [F B] words by absolute frame row, ZEROED by the caller for the launch's
+// frames) and / or partmax = max |dz| of the launch (one zeroed word; several launches may share it) -- the operands of
+// yt8m_h2_split_rowmax and of yt8m_h2_split / yt8m_gemm_h2_nt_grouped (dscale / dsb).  Needs the rotated epilogue
+// (yt8m_lstm_persist_bwd_images_rows(B, H) > 0), else YT8M_E_SHAPE.
+extern "C" int yt8m_lstm_persist_bwd_ex(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
+                                        float* work, int phase, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
+                                        const void* wh_absmax, void* rowmax, void* partmax, void* workspace, int64_t workspace_bytes,
+                                        yt8m_stream_t stream) {
+  static const bool off = getenv("YT8M_PERSIST_BWD_H2") != nullptr && atoi(getenv("YT8M_PERSIST_BWD_H2")) == 0;
+  return persist_bwd_impl(gates, Wh, ldw, cs, dout, dz, work, phase, nullptr, num_frames, t0, T, B, H, workspace, workspace_bytes,
+                          nullptr, stream, false, off ? nullptr : wh_absmax, rowmax, partmax);
+}
 // 1 when yt8m_lstm_persist_bwd_h2 takes the f16 form for a T-step launch on a workspace of yt8m_lstm_persist_workspace_bytes_steps(B, H, T)
 extern "C" int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H) {
   GeometryB geo;
@@ -2285,7 +2317,7 @@ namespace {
 int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                      float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                      int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, const yt8m_persist_bwd_images* img,
-                     yt8m_stream_t stream, bool bf16, const void* h2_wword) {
+                     yt8m_stream_t stream, bool bf16, const void* h2_wword, void* rowmax, void* partmax) {
   using namespace yt8m;
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   YT8M_REQUIRE(phase == 0 || phase == 1, YT8M_E_BADARG, "phase must be 0 or 1");
@@ -2316,6 +2348,10 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
   a.nimg = images_in(workspace_bytes, geo.NT16, 4 * H);
   a.bf = (bf16 && !img) ? 1 : 0;
   a.dbg = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES);
+  a.rowmax = static_cast<unsigned*>(rowmax);
+  a.partmax = static_cast<unsigned*>(partmax);
+  YT8M_REQUIRE(!(rowmax || partmax) || (!img && images_in(workspace_bytes, geo.NT16, 4 * H) >= T && bwd_rot(geo.pf, geo.NT16, geo.RB)), YT8M_E_SHAPE,
+               "row / launch maxima need the rotated backward epilogue on a per-step workspace (yt8m_lstm_persist_bwd_images_rows)");
   // H2: the scale words sit between the last exchange image and the debug tail; taken only when T images still fit in front of them
   a.h2 = 0; a.wword = nullptr; a.sc = nullptr; a.sc_bytes = 0;
   if (h2_wword && !img && !bf16 && (H == 512 || H == 1024)) {

@@ -75,6 +75,8 @@ struct Plan {
   int h2;                                                  // layers >= 1: projection and weight gradients as three f16 products (round 5)
   int64_t hsc;                                             // ... their device-side scale words: 256 B per layer
   int64_t hrow, hrow_stride;                               // ... per-row scales of dz for dx (S then 1 / S), per layer
+  int emit_max;                                            // the backward recurrences measure max |dz| per frame row and per part themselves
+  int64_t rmax, rmax_stride;                               // ... [F B] words per layer
   int64_t cimg[MAXL], cimgs;                               // their column-sum partials: [img_rows x launches][4H] per layer
   int64_t scratch_bytes;
 };
@@ -148,7 +150,8 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.tape_bytes = o;
   // scratch
   int64_t pb = yt8m_lstm_persist_workspace_bytes_steps(p.B, p.H, tmax);
-  if (pb > STEP_IMAGES_MAX_BYTES) pb = yt8m_lstm_persist_workspace_bytes(p.B, p.H);
+  const bool per_step = pb <= STEP_IMAGES_MAX_BYTES;       // one exchange image per step of a launch (else: two alternating ones)
+  if (!per_step) pb = yt8m_lstm_persist_workspace_bytes(p.B, p.H);
   p.pws_bytes = up256(pb);
   o = 0;
   for (int l = 0; l < p.L; ++l) { p.pws[l] = o; o += p.pws_bytes; }
@@ -203,6 +206,10 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.hsc = o; o += 256 * MAXL;
   p.hrow_stride = up256(bmax * 4);
   p.hrow = o; o += p.h2 ? p.hrow_stride * 2 * MAXL : 0;   // per-row scales / inverses of a backward part's dz (dx operand), per layer
+  // maxima of dz measured by the recurrence itself (yt8m_lstm_persist_bwd_ex): per frame row, per layer
+  p.emit_max = (p.h2 && knob("YT8M_STACK_DZ_MAXIMA", 1) && yt8m_lstm_persist_bwd_images_rows(p.B, p.H) > 0 && per_step) ? 1 : 0;
+  p.rmax_stride = up256(p.FB * 4);
+  p.rmax = o; o += p.emit_max ? p.rmax_stride * p.L : 0;
   p.colparts = knob("YT8M_STACK_COLPARTS", 1) != 0;
   for (int c = 0; c < p.nb; ++c) p.colparts = p.colparts && (p.bp[c].t0 * p.B) % 64 == 0 && (p.bp[c].T * p.B) % 64 == 0;
   const int64_t cp = p.colparts ? up256(((p.FB + 63) / 64) * H4 * 4) : 0;
@@ -584,7 +591,10 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
   if (two_sw) ev.wait(S->sw2, start);
   for (int l = 0; l < P.L; ++l) { ev.wait(S->rs[l], start); if (dx_stream) ev.wait(S->dxs[l], start); }
   if (P.h2)                                                // the parts' absmax words; word 0 of a layer (max |W_x|, the forward's) stays
-    for (int l = 0; l < P.L; ++l) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc + 256 * l + 4), 0, 248, sw));   // words 1 .. 62
+    for (int l = 0; l < P.L; ++l) {                        // (on the layer's own stream: its recurrences may write them -- emit_max)
+      YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hsc + 256 * l + 4), 0, 248, S->rs[l]));   // words 1 .. 62
+      if (P.emit_max && l >= 1) YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.rmax + l * P.rmax_stride), 0, (size_t)FB * 4, S->rs[l]));
+    }
   // weight-gradient stream: the whole-sequence transposed operands (K = frame rows), made while the first recurrence runs alone
   for (int l = 0; l < P.L; ++l) {
     if (!dW[l]) continue;
@@ -694,7 +704,13 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // fp32 configuration: the recurrent product as three f16 products of two-half-plane splits (yt8m_lstm_persist_bwd_h2: fp32-grade,
         // 14.8 instead of 18.3 us per step; knob YT8M_STACK_H2_RECUR, default 1; falls back by itself where the shape cannot take it)
         static const int h2_recur = knob("YT8M_STACK_H2_RECUR", 1);
-        if (!bf && h2_recur)
+        if (P.emit_max)                                    // ... and measures max |dz| per frame row (dx operand) and of the part (dW operand)
+          RC(yt8m_lstm_persist_bwd_ex(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
+                                      at<float>(scratch, P.work[l]), phase[l], num_frames, t0, T, B, H,
+                                      h2_recur ? at<char>(scratch, P.hsc + 256 * l + 252) : nullptr,
+                                      (l >= 1 && knob("YT8M_STACK_H2_DX", 1)) ? at<char>(scratch, P.rmax + l * P.rmax_stride) : nullptr,
+                                      at<char>(scratch, P.hsc + 256 * l + 4 * (1 + std::min(c, 61))), at<char>(scratch, P.pws[l]), P.pws_bytes, s));
+        else if (!bf && h2_recur)
           RC(yt8m_lstm_persist_bwd_h2(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
                                       at<float>(scratch, P.work[l]), phase[l], nullptr, num_frames, t0, T, B, H,
                                       at<char>(scratch, P.hsc + 256 * l + 252), at<char>(scratch, P.pws[l]), P.pws_bytes, s));
@@ -729,8 +745,13 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           // has decayed by decades keeps its own 22 bits), W_x under the scale of its absmax word (measured by the forward pass)
           float* rS = at<float>(scratch, P.hrow + 2 * l * P.hrow_stride);
           float* rI = at<float>(scratch, P.hrow + (2 * l + 1) * P.hrow_stride);
-          RC(yt8m_h2_rowscales(dzc, M, H4, H4, rS, rI, (yt8m_stream_t)sx));
-          RC(yt8m_h2_split_rows(dzc, M, H4, H4, rS, at<char>(scratch, P.dz3[l]), (yt8m_stream_t)sx));
+          if (P.emit_max) {                                  // the row maxima came with the recurrence: one pass over dz instead of two
+            RC(yt8m_h2_split_rowmax(dzc, M, H4, H4, at<char>(scratch, P.rmax + l * P.rmax_stride + t0 * B * 4), rI, at<char>(scratch, P.dz3[l]),
+                                    (yt8m_stream_t)sx));
+          } else {
+            RC(yt8m_h2_rowscales(dzc, M, H4, H4, rS, rI, (yt8m_stream_t)sx));
+            RC(yt8m_h2_split_rows(dzc, M, H4, H4, rS, at<char>(scratch, P.dz3[l]), (yt8m_stream_t)sx));
+          }
           const float* wword = at<float>(scratch, P.hsc + 256 * l);
           if (!wx3_done[l]) {
             RC(yt8m_h2_split(W[l], Din, H4, H4, 1.0f, wword, at<char>(scratch, P.wx3[l]), nullptr, nullptr, (yt8m_stream_t)sx));
@@ -778,7 +799,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           // images + the per-tile column sums; dW_x = (q - 128)^T . (r (.) dz) on two products, dW_h = h^T . dz on three
           const float* rr = at<float>(tape, P.rrow) + t0 * B;
           float* word = at<float>(scratch, P.hsc) + 1 + std::min(c, 61);
-          RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
+          if (!P.emit_max) RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
           float* cp = P.colparts ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
           float* cps = P.colparts ? at<float>(scratch, P.cparts) + (t0 * B / 64) * H4 : nullptr;
           RC(yt8m_h2_split_ex(dzc, M, H4, H4, 1.0f, word, rr, nullptr, at<char>(scratch, P.dzT3[l]), at<char>(scratch, P.dzT3s), cp, cps,
@@ -813,7 +834,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           // three f16 products: dz^T of this part under a scale measured on the device (a sum over the part's frame rows: one scale
           // serves it), h^T / out^T under the static 2^13; the bias gradient's per-tile column sums ride on the split as before
           float* word = at<float>(scratch, P.hsc + 256 * l) + 1 + std::min(c, 61);                             // one word per backward part (zeroed at the start)
-          RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
+          if (!P.emit_max) RC(yt8m_h2_absmax(dzc, M, H4, H4, word, (yt8m_stream_t)sw));
           float* cp = (P.colparts && db[l]) ? at<float>(scratch, P.cpart[l]) + (t0 * B / 64) * H4 : nullptr;
           RC(yt8m_h2_split(dzc, M, H4, H4, 1.0f, word, nullptr, at<char>(scratch, P.dzT3[l]), cp, (yt8m_stream_t)sw));
           yt8m_gemm_problem pr[2] = {
