@@ -231,7 +231,7 @@ def family_times(lib, steps):
     return fam
 
 
-def family_peak(name, bf16, fwd_x3=False):
+def family_peak(name, bf16, fwd_x3=False, bwd_f16=False):
     """(chip-level peak TFLOP/s, what it is) of the matrix pipe a family's kernels ISSUE on, in the units its algorithmic FLOPs are
     counted in (fp32-equivalent FLOPs: a family that spends k bf16 / f16 MFMA products per fp32 product has peak 2500 / k).
     VERDICT r2: never price a bf16-pipe kernel against the fp32 peak, nor the other way round."""
@@ -259,6 +259,10 @@ def family_peak(name, bf16, fwd_x3=False):
         if fwd_x3:
             return bfp / X3_PRODUCTS, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / %d products per fp32 product "
                                        "(v_mfma_f32_16x16x32_bf16 on three-plane splits of h and W_h)" % (bfp, X3_PRODUCTS))
+    if name == "lstm_recurrence_bwd" and bwd_f16 and not bf16:
+        return bfp / 3.0, ("f16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (v_mfma_f32_16x16x32_f16 on two-plane "
+                           "half splits of dz and W_h^T; the kernel is bound by the delivery of the exchanged dz -- 1 MiB per workgroup and "
+                           "step through one CU's L2 port -- not by this pipe: roofline.exchange)" % bfp)
     if name == "lstm_recurrence_bwd" and bf16:
         return bfp, "bf16 MFMA pipe (lstm_step_bwd16_kernel: bf16 dz / W_h operands, one product): dense peak"
     if bf16 and name == "gemm":
@@ -266,7 +270,30 @@ def family_peak(name, bf16, fwd_x3=False):
     return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA pipe (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): dense peak of the whole chip"
 
 
-def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False, step_ms=None):
+def bwd_on_f16_pipe(lib, B, H):
+    """True when the native stack's backward recurrences of this shape run the three-f16-product form (yt8m_lstm_persist_bwd_h2 /
+    _ex with a weight scale word; knobs YT8M_STACK_H2_RECUR, YT8M_PERSIST_BWD_H2)."""
+    return (os.environ.get("YT8M_STACK_H2_RECUR", "1") != "0" and os.environ.get("YT8M_PERSIST_BWD_H2", "1") != "0" and
+            os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0" and bool(lib.yt8m_lstm_persist_bwd_on_f16_pipe(B, H)))
+
+
+def exchange_view(row, B, H, cus, f16):
+    """What bounds the backward recurrence in its f16 form: every workgroup (one per CU: 16 units x 64 rows) fetches the dz of its 64
+    rows -- 4H values of 4 bytes, two half planes -- once per step through its CU's L2 port (64 B / clk, MI355X_MICROARCH.md)."""
+    if not f16 or not row:
+        return None
+    per_wg = 64.0 * 4 * H * 4
+    steps_per_launch = row["algorithmic_flops_per_launch"] / (2.0 * B * H * 4 * H)
+    us_per_step = row["avg_launch_ms"] * 1e3 / max(steps_per_launch, 1e-9)
+    ach = per_wg / (us_per_step * 1e-6) / 1e9
+    peak = 64.0 * 2.1                                      # GB/s per CU at the ~2.1 GHz the kernel runs at
+    return {"bytes_per_workgroup_and_step": per_wg, "us_per_step": us_per_step, "achieved_GBps_per_cu": ach, "peak_GBps_per_cu": peak,
+            "frac": ach / peak, "workgroups": cus,
+            "is": "dz_t fetched by each of the launch's workgroups per time step over the launch's average step time, against one CU's "
+                  "64 B/clk L2 port at 2.1 GHz: the bound this kernel runs against (its matrix work is 1/5 of the fp32-pipe form's)"}
+
+
+def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False, step_ms=None, bwd_f16=False):
     """Dominant family = the one with the largest hipEvent time among the MFMA families that have an algorithmic FLOP count
     (declared by the library at launch time for the GEMM and recurrence entry points, else the workload's formula).
     achieved = algorithmic FLOPs of that family per step / its time per step (= FLOPs per launch / average launch).
@@ -280,7 +307,7 @@ def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False,
             continue
         f = v.get("declared_flops_per_step") or flops.get(name)
         if f and v["ms_per_step"] > 0:
-            peak, what = family_peak(name, bf16, fwd_x3)
+            peak, what = family_peak(name, bf16, fwd_x3, bwd_f16)
             ach = f / (v["ms_per_step"] * 1e-3) / 1e12
             rows[name] = {"achieved": ach, "peak": peak, "peak_is": what, "frac": ach / peak, "ms_per_step": v["ms_per_step"],
                           "launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
@@ -473,7 +500,10 @@ def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None, batch=No
         if lib.yt8m_lstm_persist_bwd_supported(B, LSTM_H):
             bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
         fwd_x3 = bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H))
-    roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / steps * 1e3)
+    bwd_f16 = workload == "lstm" and not bf16 and bwd_on_f16_pipe(lib, B, LSTM_H)
+    roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / steps * 1e3, bwd_f16=bwd_f16)
+    if roof and bwd_f16:
+        roof["exchange"] = exchange_view(roof.get("families", {}).get("lstm_recurrence_bwd"), B, LSTM_H, bwd_cus, True)
     if roof is None and fam:
         roof = {"families": {}, "other_families": fam}
     if workload == "netvlad" and fam and "vlad_rows" in fam:
@@ -784,6 +814,8 @@ def compact_line(out, sidecar=SIDECAR):
         cr["other_ms_per_step"] = {k: _r(v["ms_per_step"], 4) for k, v in (r.get("other_families") or {}).items()}
         if r.get("blended_bound"):
             cr["blended_bound"] = {k: _r(r["blended_bound"].get(k), 4) for k in ("ms_per_step", "frac")}
+        if r.get("exchange"):                                              # what the dominant kernel runs against when it is not its matrix pipe
+            cr["exchange"] = {k: _r(r["exchange"].get(k), 4) for k in ("achieved_GBps_per_cu", "peak_GBps_per_cu", "frac", "us_per_step")}
         line["roofline"] = cr
     else:
         line["roofline"] = None
@@ -946,7 +978,10 @@ def main():
                 bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
             fwd_x3 = (a.workload == "lstm" and not bf16 and os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0" and
                       bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H)))
-            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / a.steps * 1e3)
+            bwd_f16 = a.workload == "lstm" and not bf16 and bwd_on_f16_pipe(lib, B, LSTM_H)
+            roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / a.steps * 1e3, bwd_f16=bwd_f16)
+            if roof and bwd_f16:
+                roof["exchange"] = exchange_view(roof.get("families", {}).get("lstm_recurrence_bwd"), B, LSTM_H, bwd_cus, True)
             if a.workload == "moe" and B == 1024 and not bf16 and roof:
                 try:                   # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_traffic.md)
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
@@ -959,7 +994,7 @@ def main():
                     pass
             elif a.workload == "lstm" and roof:
                 try:                   # PMC passes of the headline step, committed with the round's profiles
-                    src = next(f for f in ("r4_pmc_traffic_lstm.json", "r3_pmc_traffic_lstm.json", "r2_pmc_traffic_lstm.json")
+                    src = next(f for f in ("r5_pmc_traffic_lstm.json", "r4_pmc_traffic_lstm.json", "r3_pmc_traffic_lstm.json", "r2_pmc_traffic_lstm.json")
                                if os.path.exists(os.path.join(ROOT, "profiles", f)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", src)))
                     key = roof["kernel"]
@@ -1035,9 +1070,13 @@ def main():
                           "per_gpu_batch": B, "global_batch": B * world, "frames": FRAMES if cfg["frame"] else None,
                           "parallelism": "dp%d" % world, "params": params,
                           "arithmetic": ("bf16 operands, fp32 accumulate" if bf16 else
-                                         "fp32 values throughout; large matrix products run on the bf16 MFMA pipe as six exact partial "
-                                         "products of a three-plane bf16 split of both operands with fp32 accumulation (error <= the "
-                                         "rounding of an fp32 FMA; YT8M_GEMM_X3=0 / YT8M_PERSIST_X3=0 select the fp32 MFMA kernels)")},
+                                         "fp32 values throughout, fp32 accumulation everywhere; large matrix products run on the 16-bit MFMA "
+                                         "pipe from EXACT-TO-2^-22 splits of their fp32 operands: three f16 products of two half planes under "
+                                         "power-of-two scales (h2: recurrent stack projections, dx, weight gradients, backward recurrence; two "
+                                         "products where one operand is the uint8 frame) or six bf16 products of three planes (x3: forward "
+                                         "recurrence, MoE / NetVLAD heads) -- per product term 2^-21 relative, the size of three fp32 roundings, "
+                                         "inside the error of an fp32 FMA chain (tests/test_gpu_h2.py, test_gpu_h2_recur.py against fp64); "
+                                         "YT8M_STACK_H2=0 YT8M_STACK_H2_RECUR=0 YT8M_GEMM_H2=0 select the six-product / fp32-pipe forms")},
                "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement,
                "library": library_identity(),
                "reducer": None if reducer is None else {"algo": reducer.algo, "reserved_cus": reducer.reserve_cus, "world": reducer.world,

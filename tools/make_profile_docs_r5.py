@@ -41,23 +41,9 @@ def trim_stats(src, dst, top=40):
             w.writerow(r)
 
 
-def main():
-    trim_stats(os.path.join(O, "bench", "bench_kernel_stats.csv"), os.path.join(P, "r5_bench_kernel_stats.csv"))
-    trim_stats(os.path.join(O, "moe", "moe_kernel_stats.csv"), os.path.join(P, "r5_moe_kernel_stats.csv"))
-    trim_stats(os.path.join(O, "netvlad", "nv_kernel_stats.csv"), os.path.join(P, "r5_netvlad_kernel_stats.csv"))
-    trim_stats(os.path.join(O, "c5", "c5_kernel_stats.csv"), os.path.join(P, "r5_config5_bf16_kernel_stats.csv"))
-    for f, t in (("persist_check.txt", "r5_persist_check.txt"), ("gemm_shapes_lstm.txt", "r5_gemm_shapes_lstm.txt"),
-                 ("model_bench.txt", "r5_plugin_step_times.txt"), ("x3_check.txt", "r5_x3_check.txt"), ("b1_bench.txt", "r5_b1_bench.txt"),
-                 ("step_timeline.txt", "r5_step_timeline.txt"), ("reader_bench.txt", "r5_reader_bench.txt"),
-                 ("mfma_busy.txt", "r5_pmc_mfma_busy.txt")):
-        if os.path.exists(os.path.join(O, f)):
-            shutil.copy(os.path.join(O, f), os.path.join(P, t))
-    line_path = os.path.join(O, "bench_line.json")
-    shutil.copy(line_path, os.path.join(P, "r5_bench_line.json"))            # the ONE line (<= 8 KB) ...
-    shutil.copy(os.path.join(O, "bench_extra.json"), os.path.join(P, "r5_bench_extra.json"))     # ... and the sidecar it names
-    for f, t in (("netvlad_ab.txt", "r5_netvlad_single_pass_ab.txt"), ("netvlad_single_sections.txt", "r5_netvlad_single_pass_sections.txt")):
-        if os.path.exists(os.path.join(O, f)):
-            shutil.copy(os.path.join(O, f), os.path.join(P, t))
+def pmc_traffic():
+    """profiles/r5_pmc_traffic_lstm.json from the FETCH_SIZE / WRITE_SIZE passes (run on the GPU box BEFORE the bench line of the same
+    collection, which cites it: `python tools/make_profile_docs_r5.py pmc`)."""
     import pmc_summary
     sys.argv = ["pmc_summary", os.path.join(O, "pmc", "fetch_counter_collection.csv"), os.path.join(O, "pmc", "write_counter_collection.csv")]
     buf = io.StringIO()
@@ -80,24 +66,30 @@ def main():
     def x3_bytes(M, N, K, pa=3):
         return 2.0 * pa * M * K + 6.0 * N * K + 4.0 * M * N
 
-    # the step's six-product launches (native stack: layer-1 projection over the whole sequence, dx and the grouped layer-1 weight
-    # gradient per backward part of 100 / 100 / 50 / 50 steps, layer 0's h-part weight gradient per part)
+    # the step's three-product f16 launches (native stack: layer-1 projection over the whole sequence; per backward part of 100 / 100 / 50 /
+    # 50 steps: dx, the grouped layer-1 weight gradient (two products), layer 0's h-part weight gradient; the head's weight gradient):
+    # h2 images are 4 B per operand element (two half planes), C is fp32
     parts = [100, 100, 50, 50]
+
+    def h2_bytes(M, N, K, pa=2):
+        return 2.0 * pa * M * K + 4.0 * N * K + 4.0 * M * N
+
     shapes = [(F * B, 4 * H, H)] + [(T * B, H, 4 * H) for T in parts] + [(H, 4 * H, T * B) for T in parts for _ in range(3)]
     launches = 1 + 4 + 4 + 4
-    g = pick("gemm_x3_kernel<3>")
+    g = pick("gemm_h2q_kernel<2>")
     if g:
-        fam["gemm_x3"] = {"kernel": g, "hbm_bytes_per_launch": tot(g), "algorithmic_bytes_per_launch": sum(x3_bytes(*sh) for sh in shapes) / launches,
-                          "note": "average over the step's x3 launches (layer-1 projection, dx and weight-gradient products of the four backward parts)"}
-    g1 = pick("gemm_x3_kernel<1>")
+        fam["gemm_h2"] = {"kernel": g, "hbm_bytes_per_launch": tot(g), "algorithmic_bytes_per_launch": sum(h2_bytes(*sh) for sh in shapes) / launches,
+                          "note": "average over the recurrent stack's h2 launches (layer-1 projection, dx and weight-gradient products of the four "
+                                  "backward parts; the head's weight-gradient launch of the same kernel is in the measured average, not in this figure)"}
+    g1 = pick("gemm_h2q_kernel<1>")
     if g1:
         sh1 = [(F * B, 4 * H, D)] + [(D, 4 * H, T * B) for T in parts]
-        fam["gemm_x1x3"] = {"kernel": g1, "hbm_bytes_per_launch": tot(g1), "algorithmic_bytes_per_launch": sum(x3_bytes(*sh, pa=1) for sh in sh1) / 5.0,
-                            "note": "one-plane uint8 operand (2 B / element) against a three-plane operand: layer-0 projection and weight gradient"}
+        fam["gemm_h1x2"] = {"kernel": g1, "hbm_bytes_per_launch": tot(g1), "algorithmic_bytes_per_launch": sum(h2_bytes(*sh, pa=1) for sh in sh1) / 5.0,
+                            "note": "one exact half plane of the uint8 frames (2 B / element) against a two-plane operand: layer-0 projection and weight gradient"}
     f = pick("lstm_persist_fwd")
     per_step = float(B * 4 * H * 4 * 2 + 3 * B * H * 4)          # z in, gates / c / h / out written
-    note = ("algorithmic = the saved activations only; the state exchange (one image per step: 768 KB of bf16 planes forward, 2 MB fp32 "
-            "backward) is written through once and fetched once per XCD into its L2 -- those bytes pass the memory-side counters too")
+    note = ("algorithmic = the saved activations only; the state exchange (one image per step: 768 KB of bf16 planes forward, 2 MB of "
+            "half planes + scale words backward) is written through once and fetched once per XCD into its L2 -- those bytes pass the memory-side counters too")
     img_f = B * H * (6 if f and "x3" in f else 4)
     img_b = B * 4 * H * 4
     if f:
@@ -116,6 +108,28 @@ def main():
                    "256 MiB copy probe of the same run as MI355X_MICROARCH.md prescribes)" % (pm["fetch_factor"], pm["write_factor"]),
            "fetch_factor": pm["fetch_factor"], "write_factor": pm["write_factor"], "families": fam, "kernels": pm["kernels"]}
     json.dump(out, open(os.path.join(P, "r5_pmc_traffic_lstm.json"), "w"), indent=1, sort_keys=True)
+    return out
+
+
+def main():
+    trim_stats(os.path.join(O, "bench", "bench_kernel_stats.csv"), os.path.join(P, "r5_bench_kernel_stats.csv"))
+    trim_stats(os.path.join(O, "moe", "moe_kernel_stats.csv"), os.path.join(P, "r5_moe_kernel_stats.csv"))
+    trim_stats(os.path.join(O, "netvlad", "nv_kernel_stats.csv"), os.path.join(P, "r5_netvlad_kernel_stats.csv"))
+    trim_stats(os.path.join(O, "c5", "c5_kernel_stats.csv"), os.path.join(P, "r5_config5_bf16_kernel_stats.csv"))
+    for f, t in (("persist_check.txt", "r5_persist_check.txt"), ("gemm_shapes_lstm.txt", "r5_gemm_shapes_lstm.txt"),
+                 ("model_bench.txt", "r5_plugin_step_times.txt"), ("x3_check.txt", "r5_x3_check.txt"), ("b1_bench.txt", "r5_b1_bench.txt"),
+                 ("step_timeline.txt", "r5_step_timeline.txt"), ("reader_bench.txt", "r5_reader_bench.txt"),
+                 ("mfma_busy.txt", "r5_pmc_mfma_busy.txt"), ("persist_timeline.txt", "r5_persist_bwd_timeline.txt"),
+                 ("fwd_pair_check.txt", "r5_fwd_pair_check.txt")):
+        if os.path.exists(os.path.join(O, f)):
+            shutil.copy(os.path.join(O, f), os.path.join(P, t))
+    line_path = os.path.join(O, "bench_line.json")
+    shutil.copy(line_path, os.path.join(P, "r5_bench_line.json"))            # the ONE line (<= 8 KB) ...
+    shutil.copy(os.path.join(O, "bench_extra.json"), os.path.join(P, "r5_bench_extra.json"))     # ... and the sidecar it names
+    for f, t in (("netvlad_ab.txt", "r5_netvlad_single_pass_ab.txt"), ("netvlad_single_sections.txt", "r5_netvlad_single_pass_sections.txt")):
+        if os.path.exists(os.path.join(O, f)):
+            shutil.copy(os.path.join(O, f), os.path.join(P, t))
+    pmc_traffic()
     line = last_json(os.path.join(P, "r5_bench_line.json"))
     linep = last_json(os.path.join(O, "bench_line_profiled.json"))
     steps = 28.0          # 20 timed + 3 warm-up + 5 hipEvent-profile steps in the traced run
@@ -123,9 +137,9 @@ def main():
     md = ["# Round 5: headline bench (BASELINE configs[3], LstmModel B=128, fp32) under rocprofv3", "",
           "Commands (tools/collect_profiles_r5.sh): the driver-style line `python bench.py` -> `profiles/r5_bench_line.json`; "
           "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gap --no-extra` -> the table below.", "",
-          "* un-profiled: **%.2f ms/step, %.0f videos/s** (round 4: 20.6 / 6221); under the tracer: %.2f ms/step." % (line["ms_per_step"], line["value"], linep["ms_per_step"]),
+          "* un-profiled: **%.2f ms/step, %.0f videos/s** (round 4: 20.6 / 6221; round 5 before the f16 products: 20.45); under the tracer: %.2f ms/step." % (line["ms_per_step"], line["value"], linep["ms_per_step"]),
           "* dominant kernel family by hipEvent time: `%s`: %.1f TFLOP/s = **%.3f of the whole chip's %s peak** (%.3f of the %s CUs it occupies)"
-          % (r["kernel"], r["achieved"], r["frac"], "fp32 MFMA", r.get("frac_of_occupied_cus", float("nan")), r.get("occupied_cus", "?")),
+          % (r["kernel"], r["achieved"], r["frac"], r.get("peak_is", "?").split(":")[0], r.get("frac_of_occupied_cus", float("nan")), r.get("occupied_cus", "?")),
           "* blended matrix bound of the step (sum of family FLOPs / chip peak of the pipe each issues on): %.2f ms = %.2f of the measured step."
           % (r["blended_bound"]["ms_per_step"], r["blended_bound"]["frac"]),
           "* Launches of different streams share the chip (two half-chip backward recurrences run side by side, the weight-gradient GEMMs "
@@ -146,4 +160,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pmc":
+        os.makedirs(P, exist_ok=True)
+        pmc_traffic()
+    else:
+        main()

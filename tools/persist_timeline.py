@@ -59,7 +59,7 @@ for wsel, wname, names in ((0, "matrix wave 0", ["start", "polled + next loads i
                            (1, "epilogue wave 8 (every 4th item)", ["start (operand loads issued)", "partials arrived", "reduced",
                                                                     "stores issued", "drained"] + ([] if BWD else ["gate math done"]))):
     d = dbg[wsel]
-    ks = np.arange(40, 104) if (wsel == 0 or BWD) else np.arange(40, 104, 4)
+    ks = np.arange(40, 104) if wsel == 0 else np.arange(40, 104, 4)      # (an epilogue wave finishes every 4th item: rotation, both passes)
     print(wname, "-- cycles (mean / min / max)")
     period = np.diff(d[ks, 0])
     print("  %-34s %8.0f %8.0f %8.0f" % ("period", period.mean(), period.min(), period.max()))
@@ -70,7 +70,7 @@ for wsel, wname, names in ((0, "matrix wave 0", ["start", "polled + next loads i
         seg = d[ks, 5] - d[ks, 2]
         print("  %-34s %8.0f %8.0f %8.0f" % ("reduced -> gate math done", seg.mean(), seg.min(), seg.max()))
 m, e = dbg[0], dbg[1]
-ks = np.arange(40, 104) if BWD else np.arange(40, 104, 4)
+ks = np.arange(40, 104, 4)
 lag = e[ks, 4] - m[ks, 3]
 print("matrix wave 0 partials written -> epilogue drained (publish latency) %8.0f %8.0f %8.0f" % (lag.mean(), lag.min(), lag.max()))
 chain = m[43:104, 1] - m[40:101, 3]
