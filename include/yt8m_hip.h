@@ -598,6 +598,14 @@ int yt8m_lstm_persist_fwd_bf16(float* z, const float* Wh, int64_t ldw, float* cs
  * dynamic_rnn's while_loop (tf.gradients through W/all_frame_models/lstm_model.py:44-47).  dbias_rows (may be NULL):
  * [B,4H] running sums of dz over the processed steps, accumulated IN PLACE (zero it before the first chunk); the bias
  * gradient is its column sum -- saves the pass over the whole [F*B,4H] dz. */
+/* Round 5: yt8m_lstm_persist_fwd with the recurrent product h_{t-1} . W_h (BasicLSTMCell._linear under dynamic_rnn,
+ * W/all_frame_models/lstm_model.py:34-47) as THREE f16 products of two-half-plane splits instead of six bf16 products of three-plane splits:
+ * the same fp32 grade, half the matrix instructions, 4 instead of 6 exchanged bytes per state element.  wh_absmax: device word with
+ * max |W_h| as float bits (yt8m_h2_absmax).  Taken where yt8m_lstm_persist_fwd_on_bf16_pipe(B, H) holds; elsewhere (or YT8M_PERSIST_FWD_H2=0)
+ * the launch is yt8m_lstm_persist_fwd. */
+int yt8m_lstm_persist_fwd_h2(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out, const int32_t* num_frames,
+                             int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias, const void* wh_absmax, void* workspace,
+                             int64_t workspace_bytes, yt8m_stream_t stream);
 int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H);
 int yt8m_lstm_persist_bwd(const float* gates, const float* Wh, int64_t ldw, const float* cs, const float* dout, float* dz,
                           float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,

@@ -170,3 +170,32 @@ def test_split_rowmax_equals_rowscales_plus_split_rows(dev):
     _lib.check(lib.yt8m_h2_split_rowmax(_p(x), R, C, C, _p(rowmax), _p(inv2), _p(b), _stream()))
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(inv, inv2)
+
+
+def test_f16_form_of_the_forward_recurrence_equals_the_six_product_form_to_fp32_rounding(dev):
+    """yt8m_lstm_persist_fwd_h2 (opt-in in the native stack): h_t and W_h as two half planes, three products -- against the six-product
+    bf16 split of the same launch (pinned to fp64 autograd by tests/test_gpu_round3.py), ragged rows included."""
+    lib = _lib.lib()
+    B, F, H = 128, 40, 1024
+    assert lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H) == 1
+    g = torch.Generator(device=dev).manual_seed(8)
+    z0 = torch.randn((F, B, 4 * H), device=dev, generator=g) * 0.4
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.08
+    nf = torch.randint(1, F + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+    word = _absmax_word(lib, Wh)
+    res = []
+    for f16 in (False, True):
+        z = z0.clone()
+        cs, hs = torch.zeros((F + 1, B, H), device=dev), torch.zeros((F + 1, B, H), device=dev)
+        out = torch.empty((F, B, H), device=dev)
+        pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F), dtype=torch.uint8, device=dev)
+        head = [_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nf), 0, F, B, H, 1.0]
+        if f16:
+            _lib.check(lib.yt8m_lstm_persist_fwd_h2(*head, _p(word), _p(pws), pws.numel(), _stream()))
+        else:
+            _lib.check(lib.yt8m_lstm_persist_fwd(*head, _p(pws), pws.numel(), _stream()))
+        torch.cuda.synchronize()
+        _lib.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
+        res.append((z, cs, hs, out))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(a.abs().max()))

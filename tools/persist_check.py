@@ -81,22 +81,37 @@ def timing(B=128, F=300, D=1152, H=1024, L_=2):
     cs = torch.zeros((F + 1, B, H), device=dev)
     hs = torch.zeros((F + 1, B, H), device=dev)
     out = torch.empty((F, B, H), device=dev)
-    for it in range(6):
+    wword = torch.zeros(64, dtype=torch.int32, device=dev)
+    L.check(lib.yt8m_h2_absmax(_p(Wh), H, 4 * H, 4 * H, _p(wword), _stream()))
+    ref = None
+    for it in range(9):
         steps = it >= 3                                 # one exchange image per step (XCD-L2-shared fetch) vs two alternating ones
+        h2 = it >= 6                                    # the recurrent product as three f16 products (yt8m_lstm_persist_fwd_h2)
         pws = torch.zeros(lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F) if steps else lib.yt8m_lstm_persist_workspace_bytes(B, H),
                           dtype=torch.uint8, device=dev)
         z = z0.clone()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.yt8m_lstm_persist_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), None, 0, F, B, H, 1.0, _p(pws), pws.numel(),
-                                          _stream()))
+        if h2:
+            L.check(lib.yt8m_lstm_persist_fwd_h2(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), None, 0, F, B, H, 1.0, _p(wword), _p(pws),
+                                                 pws.numel(), _stream()))
+        else:
+            L.check(lib.yt8m_lstm_persist_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), None, 0, F, B, H, 1.0, _p(pws), pws.numel(),
+                                              _stream()))
         e1.record()
         torch.cuda.synchronize()
         L.check(lib.yt8m_lstm_persist_status(_p(pws), _stream()))
-        print("persistent fwd kernel (%s): %.3f ms for %d steps = %.2f us/step"
-              % ("image per step, recurrent product as six bf16 products" if steps and lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H)
-                 else ("image per step" if steps else "two images, fp32 MFMA"), e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F),
+        note = ""
+        if steps and not h2:
+            ref = (out.clone(), cs.clone())
+        if h2 and ref is not None:
+            note = "  max |out - out_x3| %.3g, max |c - c_x3| / max |c| %.3g" % (
+                float((out - ref[0]).abs().max()), float((cs - ref[1]).abs().max() / ref[1].abs().max()))
+        print("persistent fwd kernel (%s): %.3f ms for %d steps = %.2f us/step%s"
+              % ("image per step, recurrent product as three f16 products" if h2 else
+                 "image per step, recurrent product as six bf16 products" if steps and lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H)
+                 else ("image per step" if steps else "two images, fp32 MFMA"), e0.elapsed_time(e1), F, e0.elapsed_time(e1) * 1e3 / F, note),
               flush=True)
 
 

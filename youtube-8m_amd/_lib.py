@@ -193,6 +193,7 @@ SIGNATURES = {
     "yt8m_lstm_persist_bwd_supported": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_bf16": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
+    "yt8m_lstm_persist_fwd_h2": (c_int, [P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_h2": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P]),
     "yt8m_lstm_persist_bwd_on_f16_pipe": (c_int, [c_int64, c_int64]),
     "yt8m_lstm_persist_bwd_ex": (c_int, [P, P, c_int64, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, P, P, P, P, c_int64, P]),

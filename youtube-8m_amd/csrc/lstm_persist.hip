@@ -78,6 +78,7 @@ struct PersistFwdArgs {
   float fb;
   int NU, RB, NT16, per, pf;
   int nimg;             // exchange images in the workspace (>= T: one per step)
+  const unsigned* wword;     // f16 form of the recurrent product (lstm_persist_fwd_x3_kernel<.., 2, true>): max |W_h| as float bits
   unsigned long long* dbg;   // timing variant (-DYT8M_PERSIST_TIMING): s_memtime stamps of workgroup 0
 };
 
@@ -539,8 +540,12 @@ __device__ __forceinline__ unsigned row_shl_u(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
 }
 
+// F16 form (round 5): h_t and W_h as TWO IEEE-half planes each (csrc/x3_image.h split_h2), three products hi.hi + hi.lo + lo.hi of
+// v_mfma_f32_16x16x32_f16 -- the same fp32 grade as the six-product bf16 split at half the matrix instructions and 2/3 of the exchange
+// bytes.  |h| < 1: the static scale 2^13; W_h under the power of two that brings max |W_h| (a device word) into [2^13, 2^14).
+constexpr float FWD_H2_S = 8192.f;
 // image 0 of a launch <- h_{t0-1} (standard layout), split into the three planes
-template <int NP>
+template <int NP, bool F16 = false>
 __global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict__ h, u32x4* __restrict__ img, int B, int H, int NT16) {
   const int KBH = H >> 5;
   const long long n = (long long)NT16 * KBH * NP * 64;
@@ -552,8 +557,10 @@ __global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict
     unsigned hb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      unsigned h1, h2, h3;
-      split3_bits(row < B ? h[(long long)row * H + k0 + j] : 0.f, h1, h2, h3);
+      unsigned h1, h2, h3 = 0;
+      const float hv = row < B ? h[(long long)row * H + k0 + j] : 0.f;
+      if constexpr (F16) yt8m_x3::split_h2(hv * FWD_H2_S, h1, h2);
+      else split3_bits(hv, h1, h2, h3);
       hb[j] = p == 0 ? h1 : (p == 1 ? h2 : h3);
     }
     u32x4 v;
@@ -564,15 +571,16 @@ __global__ __launch_bounds__(256) void hx_pack_x3_kernel(const float* __restrict
 
 // NP = 1 (round 4, --compute_dtype=bfloat16): ONE plane -- h_t travels as bf16 (a third of the exchange), W_h is rounded once per
 // launch and is register-resident in full, one MFMA per (K block, column half) instead of six.
-template <int NKB, int NP = 3>
+template <int NKB, int NP = 3, bool F16 = false>
 __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs a) {
+  static_assert(!F16 || NP == 2, "the f16 form has two planes");
   constexpr int NS = 2;                                  // partial-tile slots
 #ifndef YT8M_X3_EPW
 #define YT8M_X3_EPW 2
 #endif
   constexpr int EPW = YT8M_X3_EPW;                       // epilogue waves per item (1: a whole tile per wave, 2: half a tile each)
   constexpr int NF = NKB * 2 * NP;                       // B fragments of a wave: [K block][column half][plane]
-  constexpr int NREG = NF < 10 ? NF : 10, NLDS = NF - NREG;
+  constexpr int NREG = F16 ? NF : (NF < 10 ? NF : 10), NLDS = NF - NREG;   // (the f16 form's 16 fragments all fit in registers)
   constexpr int HK = NKB / 2;                            // K blocks per half item
   static_assert(NKB % 2 == 0, "half items");
   __shared__ __attribute__((aligned(16))) float red[NS][8][2][4][64];                 // 32 KB
@@ -601,6 +609,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   const unsigned arrivals = (unsigned)a.NU * EPW;       // per (tile, step): EPW epilogue waves per workgroup
   // B fragment of v_mfma_f32_16x16x32_bf16: lane (n = lane & 15, kg = lane >> 4) supplies B[k = 8 kg + j][n], j = 0..7.
   // Column n of half ct <-> (unit 4 ct + n / 4, gate n % 4), as in the fp32 kernel.
+  float f16_sw = 1.f;
+  if constexpr (F16) f16_sw = yt8m_x3::pow2_scale_for(__uint_as_float(a.wword[0]), 14);
+  const float f16_inv = F16 ? 1.0f / (f16_sw * FWD_H2_S) : 1.0f;
   auto w_frag = [&](int kb, int ct, int p) -> u32x4 {
     const int n16 = lane & 15, kg = lane >> 4;
     const long long k = (long long)(w * NKB + kb) * 32 + kg * 8;
@@ -609,8 +620,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
     unsigned hb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      unsigned h1, h2, h3;
-      split3_bits(q[j * a.ldw], h1, h2, h3);
+      unsigned h1, h2, h3 = 0;
+      if constexpr (F16) yt8m_x3::split_h2(q[j * a.ldw] * f16_sw, h1, h2);
+      else split3_bits(q[j * a.ldw], h1, h2, h3);
       hb[j] = p == 0 ? h1 : (p == 1 ? h2 : h3);
     }
     u32x4 v;
@@ -676,9 +688,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           }
           STAMP(1);                                      // (the 3 NKB loads of the request go out three per MFMA group below)
         }
-        bf16x8 av[NP];
+        u32x4 av[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) av[p] = __builtin_bit_cast(bf16x8, kb < HK ? Ha[kb < HK ? kb : 0][p] : Hb[kb >= HK ? kb - HK : 0][p]);
+        for (int p = 0; p < NP; ++p) av[p] = kb < HK ? Ha[kb < HK ? kb : 0][p] : Hb[kb >= HK ? kb - HK : 0][p];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           // LDS-resident weight fragments travel one six-MFMA group ahead of their use (two register sets in rotation): read in
@@ -702,21 +714,29 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          bf16x8 bv[NP];
+          u32x4 bv[NP];
 #pragma unroll
           for (int p = 0; p < NP; ++p) {
             const int f = gi * NP + p;
-            bv[p] = __builtin_bit_cast(bf16x8, f < NREG ? Wr[f < NREG ? f : 0] : ls[gi & 1][p]);
+            bv[p] = f < NREG ? Wr[f < NREG ? f : 0] : ls[gi & 1][p];
           }
+          auto mm = [&](const u32x4& x, const u32x4& y, f32x4 c) -> f32x4 {
+            if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+          };
           if constexpr (NP == 3) {
-            acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][0], 0, 0, 0);
-            acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[1], acc[ct][1], 0, 0, 0);
-            acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[0], acc[ct][0], 0, 0, 0);
-            acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[2], acc[ct][1], 0, 0, 0);
-            acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[1], acc[ct][0], 0, 0, 0);
-            acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], acc[ct][1], 0, 0, 0);
+            acc[ct][0] = mm(av[0], bv[0], acc[ct][0]);
+            acc[ct][1] = mm(av[0], bv[1], acc[ct][1]);
+            acc[ct][0] = mm(av[1], bv[0], acc[ct][0]);
+            acc[ct][1] = mm(av[0], bv[2], acc[ct][1]);
+            acc[ct][0] = mm(av[1], bv[1], acc[ct][0]);
+            acc[ct][1] = mm(av[2], bv[0], acc[ct][1]);
+          } else if constexpr (NP == 2) {                   // hi hi + hi lo + lo hi
+            acc[ct][0] = mm(av[0], bv[0], acc[ct][0]);
+            acc[ct][1] = mm(av[0], bv[1], acc[ct][1]);
+            acc[ct][0] = mm(av[1], bv[0], acc[ct][0]);
           } else {
-            acc[ct][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], acc[ct][kb & 1], 0, 0, 0);
+            acc[ct][kb & 1] = mm(av[0], bv[0], acc[ct][kb & 1]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -726,7 +746,10 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
       if (k >= NS) lds_wait_ge(&lds_free[slot], (unsigned)(EPW * (k / NS)), a.ctl);   // every epilogue wave of item k - NS has read
       float* rw = &red[slot][w][0][0][lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { rw[r * 64] = acc[0][0][r] + acc[0][1][r]; rw[256 + r * 64] = acc[1][0][r] + acc[1][1][r]; }
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (F16) { rw[r * 64] = (acc[0][0][r] + acc[0][1][r]) * f16_inv; rw[256 + r * 64] = (acc[1][0][r] + acc[1][1][r]) * f16_inv; }
+        else { rw[r * 64] = acc[0][0][r] + acc[0][1][r]; rw[256 + r * 64] = acc[1][0][r] + acc[1][1][r]; }
+      }
       if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       STAMP(3);
       if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
@@ -805,7 +828,8 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         for (int jj = 0; jj < JP; ++jj) {
           const int j = EPW == 2 ? (ew & 1) : jj;
           unsigned hb[3];
-          if constexpr (NP == 3) split3_bits(hn[jj], hb[0], hb[1], hb[2]);
+          if constexpr (F16) yt8m_x3::split_h2(hn[jj] * FWD_H2_S, hb[0], hb[1]);
+          else if constexpr (NP == 3) split3_bits(hn[jj], hb[0], hb[1], hb[2]);
           else hb[0] = bf16_rn_bits(hn[jj]);
           const int erow = 8 * j + (lane >> 3);
 #pragma unroll
@@ -2066,7 +2090,20 @@ extern "C" int yt8m_lstm_persist_debug_fault(void* workspace, yt8m_stream_t stre
 namespace {
 int persist_fwd_impl(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out, const int32_t* num_frames, int64_t t0,
                      int64_t T, int64_t B, int64_t H, float forget_bias, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream,
-                     bool bf16);
+                     bool bf16, const void* h2_wword = nullptr);
+}
+// yt8m_lstm_persist_fwd with the recurrent product h_{t-1} . W_h as THREE f16 products of two-half-plane splits (csrc/x3_image.h) instead
+// of six bf16 products of three-plane splits: the same fp32 grade (2^-21 relative per term), half the matrix instructions, 4 instead of 6
+// exchanged bytes per state element.  wh_absmax: device word with max |W_h| as float bits (yt8m_h2_absmax over the [H, 4H] block).  Taken
+// where the six-product form would be (yt8m_lstm_persist_fwd_on_bf16_pipe); elsewhere, or with YT8M_PERSIST_FWD_H2=0, the launch is
+// yt8m_lstm_persist_fwd.
+extern "C" int yt8m_lstm_persist_fwd_h2(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
+                                        const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
+                                        const void* wh_absmax, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(wh_absmax, YT8M_E_BADARG, "null absmax word");
+  static const bool off = getenv("YT8M_PERSIST_FWD_H2") != nullptr && atoi(getenv("YT8M_PERSIST_FWD_H2")) == 0;
+  return persist_fwd_impl(z, Wh, ldw, cs, hs, out, num_frames, t0, T, B, H, forget_bias, workspace, workspace_bytes, stream, false,
+                          off ? nullptr : wh_absmax);
 }
 extern "C" int yt8m_lstm_persist_fwd(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out,
                                      const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, float forget_bias,
@@ -2084,7 +2121,7 @@ extern "C" int yt8m_lstm_persist_fwd_bf16(float* z, const float* Wh, int64_t ldw
 namespace {
 int persist_fwd_impl(float* z, const float* Wh, int64_t ldw, float* cs, float* hs, float* out, const int32_t* num_frames, int64_t t0,
                      int64_t T, int64_t B, int64_t H, float forget_bias, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream,
-                     bool bf16) {
+                     bool bf16, const void* h2_wword) {
   using namespace yt8m;
   YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
   if (T * B * H == 0) return YT8M_OK;
@@ -2120,7 +2157,16 @@ int persist_fwd_impl(float* z, const float* Wh, int64_t ldw, float* cs, float* h
   // fp32 one) per step, >= 2 tiles per workgroup, H in {512, 1024}
   const bool x3 = fwd_x3_shape(H, geo.pf) && images_in(workspace_bytes, geo.NT16, H + H / 2) >= T;
   int rc;
-  if (x3 && bf16) {
+  a.wword = static_cast<const unsigned*>(h2_wword);
+  if (x3 && !bf16 && h2_wword) {                         // two half planes: image per step of the fp32 image's size
+    hipLaunchKernelGGL((hx_pack_x3_kernel<2, true>), dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
+                       geo.NT16);
+    rc = launch_status("hx_pack_x3_kernel");
+    if (rc != YT8M_OK) return rc;
+    if (H == 1024) hipLaunchKernelGGL((lstm_persist_fwd_x3_kernel<4, 2, true>), dim3(grid), dim3(768), 0, s, a);
+    else hipLaunchKernelGGL((lstm_persist_fwd_x3_kernel<2, 2, true>), dim3(grid), dim3(768), 0, s, a);
+    rc = launch_status("lstm_persist_fwd_x3_kernel");
+  } else if (x3 && bf16) {
     hipLaunchKernelGGL(hx_pack_x3_kernel<1>, dim3(256), dim3(256), 0, s, hs + t0 * B * H, reinterpret_cast<u32x4*>(a.hx), (int)B, (int)H,
                        geo.NT16);
     rc = launch_status("hx_pack_x3_kernel");
