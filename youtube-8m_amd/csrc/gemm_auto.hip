@@ -55,9 +55,13 @@ struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; bool h2
 // one power-of-two scale per operand, measured on the device, serves every term of every output element -- such a product runs as
 // THREE f16 products of two-plane half images (gemm_h2q_kernel, 1.6x the six-product kernel).  Forward products and dx read a weight
 // (whose six-product image is resident, csrc/wimg.hip) and keep the bf16 split.  YT8M_GEMM_H2=0 turns it off.
-bool h2_role(int transA, int transB) {
+// ... for K >= YT8M_GEMM_H2_MINK (default 512): an h2 operand costs three launches (zero the word, absmax, split) against the six-product
+// form's one, and at K = 128 -- the MoE head's weight gradient at the headline's B = 128 -- the nine tiny launches of three operands
+// (230 us with their launch seams) outlast the product they prepare (130 us).
+bool h2_role(int transA, int transB, int64_t K) {
   static const bool off = getenv("YT8M_GEMM_H2") != nullptr && atoi(getenv("YT8M_GEMM_H2")) == 0;
-  return !off && transA != 0 && transB == 0;
+  static const int64_t mink = getenv("YT8M_GEMM_H2_MINK") ? atoll(getenv("YT8M_GEMM_H2_MINK")) : 512;
+  return !off && transA != 0 && transB == 0 && K >= mink;
 }
 constexpr int64_t H2_SCALE_BYTES = 256;                  // the operand's absmax word (yt8m_h2_absmax), in front of its h2 image in the scratch
 
@@ -77,7 +81,7 @@ extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int npro
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     if (!x3_allowed(q)) continue;
-    if (h2_role(transA, transB) && (q.N % 4) == 0) {      // (h2 images are 2/3 of these sizes; the scale words sit in front)
+    if (h2_role(transA, transB, q.K) && (q.N % 4) == 0) {   // (h2 images are 2/3 of these sizes; the scale words sit in front)
       n += 2 * H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.M, q.K)) + up256(yt8m_x3_image_bytes(q.N, q.K));
       continue;
     }
@@ -101,8 +105,7 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
   uint64_t mask = 0;
   int64_t off = 0;
   char* const base = static_cast<char*>(image_scratch);
-  const bool h2 = h2_role(transA, transB);
-  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, const void** at) -> bool {
+  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, bool h2, const void** at) -> bool {
     if (!h2)
       if (const void* r = resident(src, R, C, ld, trans)) { *at = r; return true; }    // a weight matrix with a resident image
     for (const Img& m : imgs)
@@ -117,17 +120,17 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     bool x3 = q.M > 0 && q.N > 0 && x3_allowed(q) && q.A && q.B;
+    const bool h2 = h2_role(transA, transB, q.K) && (q.N % 4) == 0;   // (the scaled epilogue stores float4: odd widths take the six-product form)
     const void* ia = nullptr;
     const void* ib = nullptr;
     if (x3) {
       const int64_t mark = off;
       const size_t nimg = imgs.size();
       // op(A) as [M rows, K]: A is stored [M,K] (plain) or [K,M] (transA: the transposing split); op(B)^T as [N rows, K]
-      x3 = image_of(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0, &ia) &&
-           image_of(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0, &ib);
+      x3 = image_of(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0, h2, &ia) &&
+           image_of(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0, h2, &ib);
       if (!x3) { imgs.resize(nimg); off = mark; }          // not enough scratch for this one: fp32 kernel
     }
-    if (x3 && h2 && (q.N % 4) != 0) { x3 = false; }          // (the scaled epilogue stores float4: odd widths stay on the fp32 kernel)
     if (x3) {
       yt8m_gemm_problem t = q;
       t.A = ia; t.lda = 0;
