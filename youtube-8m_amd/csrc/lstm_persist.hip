@@ -587,6 +587,9 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   __shared__ __attribute__((aligned(16))) u32x4 Wl[8][NLDS > 0 ? NLDS : 1][64];       // 112 KB at H = 1024
   __shared__ unsigned lds_cnt[NS], lds_free[NS];
   __shared__ unsigned lds_seen[MAX_LOCAL_TILES];
+  // num_frames of this workgroup's rows, read ONCE: as a global load per item it sat last in the epilogue's load queue, and the gate math
+  // of every item waited for it (tools/fwd_h2_check.py: 0.7 us of a 6.3 us step in the f16 form)
+  __shared__ int lds_nf[MAX_LOCAL_TILES * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ug, g;
@@ -632,6 +635,10 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   note_placement(a.ctl);
   if (tid < NS) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
+  for (int i = tid; i < n_it * 16; i += 768) {
+    const int brow = (g + (i >> 4) * RB) * 16 + (i & 15);
+    lds_nf[i] = (a.nf && brow < B) ? a.nf[brow] : 0x7fffffff;
+  }
   if (w < 8) {
 #pragma unroll
     for (int f = NREG; f < NF; ++f) Wl[w][f - NREG][lane] = w_frag(f / (2 * NP), (f / NP) & 1, f % NP);
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
         cpre[jj] = a.cs[idx];
         hpre[jj] = a.hs[idx];
-        live[jj] = a.nf ? (t < a.nf[br]) : true;
+        live[jj] = t < lds_nf[it * 16 + 8 * j + (lane >> 3)];
       }
       const int slot = k & (NS - 1);
       lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(k / NS + 1), a.ctl);
@@ -975,6 +982,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   __shared__ __attribute__((aligned(16))) float red[NSLOT_B][8][4][64];    // [slot][wave][acc reg][lane]: 24 KB
   __shared__ unsigned lds_cnt[NSLOT_B], lds_free[NSLOT_B];
   __shared__ unsigned lds_seen[MAX_LOCAL_TILES];           // see the forward kernel: only matrix wave 0 polls memory
+  __shared__ int lds_nf[ROT ? MAX_LOCAL_TILES * 16 : 1];   // rotated epilogue: num_frames of the workgroup's rows, read once (as the forward kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ub, g;
@@ -1001,6 +1009,12 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   note_placement(a.ctl);
   if (tid < NSLOT_B) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
   for (int i = tid; i < MAX_LOCAL_TILES; i += 768) lds_seen[i] = 0;
+  if constexpr (ROT) {
+    for (int i = tid; i < n_it * 16; i += 768) {
+      const int brow = (g + (i >> 4) * RB) * 16 + (i & 15);
+      lds_nf[i] = (a.nf && brow < B) ? a.nf[brow] : 0x7fffffff;
+    }
+  }
   // H2: B fragments of v_mfma_f32_16x16x32_f16 in the permuted K order: lane (n = unit, kg) supplies, for local K block kbl of this wave
   // (global block kbp = w NQB / 2 + kbl: producer kbp / 2, unit half kbp % 2), W_h[16 ub + n][gate (j % 4) H + 16 producer + 8 uh + 2 kg + j / 4]
   float h2_sw = 1.f;
@@ -1475,7 +1489,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       pend_T = T;
     };
     struct GateIn { float gi, gj, gf, go, cp, cn, dout; bool live; };
-    auto gate_load = [&](int t1, int br) -> GateIn {
+    auto gate_load = [&](int t1, int br, int lrow) -> GateIn {       // lrow: the row's slot in lds_nf (16 it + row of the tile)
       GateIn q;
       const float* gr = a.gates + ((long long)t1 * B + br) * 4 * H + ub * 16 + eunit;
       q.gi = gr[0]; q.gj = gr[H]; q.gf = gr[2 * H]; q.go = gr[3 * H];
@@ -1483,7 +1497,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       q.cp = a.cs[idx];
       q.cn = a.cs[idx + BH];
       q.dout = a.dout ? a.dout[idx] : 0.f;
-      q.live = a.nf ? (t1 < a.nf[br]) : true;
+      q.live = t1 < lds_nf[lrow];
       return q;
     };
     auto gate_bwd = [&](const GateIn& q, float dh_in, float dc, float (&dzv)[4], float& dc_out, float& base_out) {
@@ -1620,7 +1634,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         const int br = valid ? brow : B - 1;
         const float* wk = a.work + (long long)(2 * a.phase) * BH + (long long)br * H + ub * 16 + eunit;
         const float dh0 = wk[0], dc0 = wk[BH];
-        const GateIn q = gate_load(t_hi, br);
+        const GateIn q = gate_load(t_hi, br, it * 16 + 4 * rq + r);
         float dc_out, base_out;
         gate_bwd(q, dh0, dc0, dzv[r], dc_out, base_out);
         if (!valid) { dzv[r][0] = dzv[r][1] = dzv[r][2] = dzv[r][3] = 0.f; }
@@ -1652,7 +1666,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
           const float* wk = a.work + (long long)(2 * half) * BH + (long long)br * H + ub * 16 + eunit;
           base[r] = wk[0];
           dc[r] = wk[BH];
-          if (!last) q[r] = gate_load(t1, br);
+          if (!last) q[r] = gate_load(t1, br, it * 16 + 4 * rq + r);
         }
         lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(gen + 1), a.ctl);
         STAMP(1);

@@ -544,11 +544,11 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       }
       // bf16-operand mode: the recurrent product on one bf16 plane (knob YT8M_STACK_BF16_RECUR, default 1)
       static const int bf_recur_f = knob("YT8M_STACK_BF16_RECUR", 1);
-      // fp32 configuration, opt-in (knob YT8M_STACK_H2_RECUR_FWD=1): the recurrent product as three f16 products of two-half-plane splits
-      // (yt8m_lstm_persist_fwd_h2; the word is this layer's max |W_h| measured above, on this stream).  Stand-alone 6.3 against 6.9-7.5
-      // us/step; in the training step 17.40 / 17.49 against 17.48 / 17.50 ms (alternating A/B, one box): nothing -- the default stays the
-      // six-product form that the Python orchestration of the same stack runs bit for bit.
-      static const int h2_recur_f = knob("YT8M_STACK_H2_RECUR_FWD", 0);
+      // fp32 configuration: the recurrent product as three f16 products of two-half-plane splits (yt8m_lstm_persist_fwd_h2; the word is this
+      // layer's max |W_h| measured above, on this stream): 6.1 against 7.1 us/step, 17.24 -> 16.76 ms/step.  Follows YT8M_STACK_H2 (with
+      // the h2 products off, the stack stays bit for bit what the Python orchestration of the same launches computes); knob
+      // YT8M_STACK_H2_RECUR_FWD overrides.
+      const int h2_recur_f = knob("YT8M_STACK_H2_RECUR_FWD", P.h2);
       if (!bf && h2_recur_f)
         RC(yt8m_lstm_persist_fwd_h2(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), at<float>(tape, P.hs[l]),
                                     at<float>(tape, P.out[l]), num_frames, t0, T, B, H, desc->forget_bias,
