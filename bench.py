@@ -256,6 +256,9 @@ def family_peak(name, bf16, fwd_x3=False, bwd_f16=False):
     if name == "lstm_recurrence":
         if bf16:
             return bfp, "bf16 MFMA pipe (lstm_step_fwd16_kernel: bf16 h / W_h operands, one product): dense peak"
+        if fwd_x3 == "f16":
+            return bfp / 3.0, ("f16 MFMA pipe, fp32-equivalent: dense peak %.0f / 3 products per fp32 product (v_mfma_f32_16x16x32_f16 on "
+                               "two-plane half splits of h and W_h; the kernel is paced by its publish -> fetch chain, not by this pipe)" % bfp)
         if fwd_x3:
             return bfp / X3_PRODUCTS, ("bf16 MFMA pipe, fp32-equivalent: dense peak %.0f / %d products per fp32 product "
                                        "(v_mfma_f32_16x16x32_bf16 on three-plane splits of h and W_h)" % (bfp, X3_PRODUCTS))
@@ -268,6 +271,16 @@ def family_peak(name, bf16, fwd_x3=False, bwd_f16=False):
     if bf16 and name == "gemm":
         return bfp, "bf16 MFMA pipe: dense peak"
     return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA pipe (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): dense peak of the whole chip"
+
+
+def fwd_form(lib, B, H):
+    """False (fp32 pipe), True (six bf16 products) or "f16" (three f16 products: the native stack's default with the h2 products)."""
+    if os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") == "0" or not lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, H):
+        return False
+    h2 = os.environ.get("YT8M_STACK_H2", "1") != "0"
+    if os.environ.get("YT8M_STACK_H2_RECUR_FWD", "1" if h2 else "0") != "0" and os.environ.get("YT8M_PERSIST_FWD_H2", "1") != "0":
+        return "f16"
+    return True
 
 
 def bwd_on_f16_pipe(lib, B, H):
@@ -499,7 +512,7 @@ def extra_line(workload, dev, lib, bf16=False, steps=None, warmup=None, batch=No
     if workload == "lstm" and not bf16:
         if lib.yt8m_lstm_persist_bwd_supported(B, LSTM_H):
             bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
-        fwd_x3 = bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H))
+        fwd_x3 = fwd_form(lib, B, LSTM_H)
     bwd_f16 = workload == "lstm" and not bf16 and bwd_on_f16_pipe(lib, B, LSTM_H)
     roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / steps * 1e3, bwd_f16=bwd_f16)
     if roof and bwd_f16:
@@ -976,8 +989,7 @@ def main():
             bwd_cus = None
             if a.workload == "lstm" and lib.yt8m_lstm_persist_bwd_supported(B, LSTM_H):
                 bwd_cus = int(os.environ.get("YT8M_PERSIST_CUS_BWD", "128"))
-            fwd_x3 = (a.workload == "lstm" and not bf16 and os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0" and
-                      bool(lib.yt8m_lstm_persist_fwd_on_bf16_pipe(B, LSTM_H)))
+            fwd_x3 = fwd_form(lib, B, LSTM_H) if (a.workload == "lstm" and not bf16) else False
             bwd_f16 = a.workload == "lstm" and not bf16 and bwd_on_f16_pipe(lib, B, LSTM_H)
             roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / a.steps * 1e3, bwd_f16=bwd_f16)
             if roof and bwd_f16:

@@ -30,6 +30,7 @@ gates = torch.rand((F, B, 4 * H), device=dev)
 csr = torch.randn((F + 1, B, H), device=dev) * 0.5
 dz = torch.empty((F, B, 4 * H), device=dev)
 dout = torch.randn((F, B, H), device=dev) * 0.01
+nfv = torch.full((B,), F, dtype=torch.int32, device=dev)
 for it in range(2):
     if BWD:
         work = torch.zeros((4, B, H), device=dev)
@@ -50,7 +51,13 @@ for it in range(2):
     z = z0.clone()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    L.check(lib.yt8m_lstm_persist_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), None, 0, F, B, H, 1.0, _p(pws), nb, _stream()))
+    if MODE == "fwd_h2":
+        wword = torch.zeros(64, dtype=torch.int32, device=dev)
+        L.check(lib.yt8m_h2_absmax(_p(Wh), H, 4 * H, 4 * H, _p(wword), _stream()))
+        L.check(lib.yt8m_lstm_persist_fwd_h2(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nfv), 0, F, B, H, 1.0, _p(wword), _p(pws), nb,
+                                             _stream()))
+    else:
+        L.check(lib.yt8m_lstm_persist_fwd(_p(z), _p(Wh), 4 * H, _p(cs), _p(hs), _p(out), _p(nfv), 0, F, B, H, 1.0, _p(pws), nb, _stream()))
     e1.record()
     torch.cuda.synchronize()
     print("kernel %.3f ms = %.2f us/step" % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / F))
