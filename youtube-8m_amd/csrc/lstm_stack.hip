@@ -74,6 +74,7 @@ struct Plan {
   int img_rows;                                            // > 0: the backward recurrences write dz's operand images themselves (round 4)
   int h2;                                                  // layers >= 1: projection and weight gradients as three f16 products (round 5)
   int64_t hsc;                                             // ... their device-side scale words: 256 B per layer
+  int64_t hx0;                                             // ... and the float input's
   int64_t hrow, hrow_stride;                               // ... per-row scales of dz for dx (S then 1 / S), per layer
   int emit_max;                                            // the backward recurrences measure max |dz| per frame row and per part themselves
   int64_t rmax, rmax_stride;                               // ... [F B] words per layer
@@ -193,7 +194,7 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // bounded operand and a device-measured scale on the weights / on each backward part's dz.  dx = dz . W_x^T keeps the six-product
   // form (a time step whose gradient has decayed by 2^-15 against the part's largest would lose precision under one scale per part),
   // and so does layer 0 (its uint8 products are three-product forms already).  YT8M_STACK_H2=0 keeps every product on the bf16 split.
-  p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16 && (p.L >= 2 || p.u8)) ? 1 : 0;
+  p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16) ? 1 : 0;
   p.img_rows = (knob("YT8M_STACK_FUSED_IMAGES", 0) && !p.bf16 && !p.h2) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
   const int64_t trows = p.img_rows ? p.FB : bmax;
   for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(ib(H4, trows)); }
@@ -204,6 +205,7 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.csr = o; o += up256(H4 * 4);
   p.dbdummy = o; o += up256(H4 * 4);
   p.hsc = o; o += 256 * MAXL;
+  p.hx0 = o; o += 256;                                     // max |x| of a float input (layer 0's h2 operand scale)
   p.hrow_stride = up256(bmax * 4);
   p.hrow = o; o += p.h2 ? p.hrow_stride * 2 * MAXL : 0;   // per-row scales / inverses of a backward part's dz (dx operand), per layer
   // maxima of dz measured by the recurrence itself (yt8m_lstm_persist_bwd_ex): per frame row, per layer
@@ -487,12 +489,16 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       }
       RC(yt8m_colsum_f32(W[0], D, H4, H4, at<float>(scratch, P.wcs), 0.f, at<char>(scratch, P.gws[0]), P.gws_bytes, s));
     } else {
-      if (P.h2 && l >= 1) {                                  // W_x^T as an h2 image under a scale measured on the device
+      if (P.h2) {                                            // W_x^T as an h2 image under a scale measured on the device
         float* word = at<float>(scratch, P.hsc + 256 * l);   // max |W_x| as float bits (the forward's word of this layer)
         YT8M_HIP_CHECK(hipMemsetAsync(word, 0, 4, s));
         RC(yt8m_h2_absmax(W[l], Din, H4, H4, word, (yt8m_stream_t)s));
         RC(yt8m_h2_split(W[l], Din, H4, H4, 1.0f, word, nullptr, at<char>(scratch, P.wxt3[l]), nullptr, (yt8m_stream_t)s));
         wxt_img[l] = at<char>(scratch, P.wxt3[l]);
+        if (l == 0) {                                        // a float input has no bound the library knows: its maximum, once per call
+          YT8M_HIP_CHECK(hipMemsetAsync(at<char>(scratch, P.hx0), 0, 4, s));
+          RC(yt8m_h2_absmax(static_cast<const float*>(x), P.FB, D, D, at<char>(scratch, P.hx0), (yt8m_stream_t)s));
+        }
         continue;
       }
       wxt_img[l] = yt8m_wimg_lookup(W[l], Din, H4, H4, 1, bf ? 1 : 3, 1.0f);                       // W_x^T: rows 4H, K = Din
@@ -535,6 +541,12 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
           const float alpha = 1.0f / H2_S;
           const float* dsb = at<float>(scratch, P.hsc + 256 * l);
           grc = yt8m_gemm_h2_nt_grouped(1, &pr, &alpha, nullptr, &dsb, gw, P.gws_bytes, (yt8m_stream_t)s);
+        } else if (P.h2) {                                   // float input: both operands under device-measured scales
+          const float* dsa = at<float>(scratch, P.hx0);
+          const float* dsb = at<float>(scratch, P.hsc);
+          RC(yt8m_h2_split(src, M, Din, Din, 1.0f, dsa, at<char>(scratch, P.xi[0]), nullptr, nullptr, (yt8m_stream_t)s));
+          const float alpha = 1.0f;
+          grc = yt8m_gemm_h2_nt_grouped(1, &pr, &alpha, &dsa, &dsb, gw, P.gws_bytes, (yt8m_stream_t)s);
         } else {
           RC(split(src, M, Din, Din, 1.0f, at<char>(scratch, P.xi[l]), nullptr, s));
           grc = bf ? yt8m_gemm_b1_nt_grouped(1, &pr, gw, P.gws_bytes, s) : yt8m_gemm_x3_nt_grouped(1, &pr, gw, P.gws_bytes, s);
@@ -615,9 +627,10 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
       const float* src = l ? at<float>(tape, P.out[l - 1]) : static_cast<const float*>(x);
       const int64_t Din = l ? H : D;
       if (P.h2 && l >= 1) RC(yt8m_h2_split(src, FB, Din, Din, H2_S, nullptr, nullptr, at<char>(scratch, P.xT[l]), nullptr, (yt8m_stream_t)sw));
+      else if (P.h2) RC(yt8m_h2_split(src, FB, Din, Din, 1.0f, at<float>(scratch, P.hx0), nullptr, at<char>(scratch, P.xT[0]), nullptr, (yt8m_stream_t)sw));
       else RC(split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
     }
-    if (P.h2 && (l >= 1 || P.u8)) RC(yt8m_h2_split(at<float>(tape, P.hs[l]), FB, H, H, H2_S, nullptr, nullptr, at<char>(scratch, P.hT[l]), nullptr, (yt8m_stream_t)sw));
+    if (P.h2) RC(yt8m_h2_split(at<float>(tape, P.hs[l]), FB, H, H, H2_S, nullptr, nullptr, at<char>(scratch, P.hT[l]), nullptr, (yt8m_stream_t)sw));
     else RC(split(at<float>(tape, P.hs[l]), FB, H, H, 1.0f, nullptr, at<char>(scratch, P.hT[l]), sw));            // h_{t-1}: hs[0 .. F)
   }
   // Host hook (yt8m_lstm_stack_set_prep_hook): work the caller wants on the weight-gradient stream in the window where that stream
@@ -840,7 +853,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           yt8m_gemm_problem pr = {H, H4, M, at<char>(scratch, P.hT[0]) + kb0 * KBB, KBtot, dzT_img, 0,
                                   dW[0] + D * H4, H4, nullptr, bW};
           RC(gemm(1, &pr, gw, P.gws_bytes, sw));
-        } else if (P.h2 && l >= 1) {
+        } else if (P.h2) {
           // three f16 products: dz^T of this part under a scale measured on the device (a sum over the part's frame rows: one scale
           // serves it), h^T / out^T under the static 2^13; the bias gradient's per-tile column sums ride on the split as before
           float* word = at<float>(scratch, P.hsc + 256 * l) + 1 + std::min(c, 61);                             // one word per backward part (zeroed at the start)
@@ -850,9 +863,11 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           yt8m_gemm_problem pr[2] = {
               {Din, H4, M, at<char>(scratch, P.xT[l]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l], H4, nullptr, bW},
               {H, H4, M, at<char>(scratch, P.hT[l]) + kb0 * 2048, KBtot, at<char>(scratch, P.dzT3[l]), 0, dW[l] + Din * H4, H4, nullptr, bW}};
-          const float alphas[2] = {1.0f / H2_S, 1.0f / H2_S};
+          // (a float bottom-layer input sits under its device-measured scale instead of the static one)
+          const float alphas[2] = {l ? 1.0f / H2_S : 1.0f, 1.0f / H2_S};
+          const float* dsa[2] = {l ? nullptr : at<float>(scratch, P.hx0), nullptr};
           const float* dsb[2] = {word, word};
-          RC(yt8m_gemm_h2_nt_grouped(2, pr, alphas, nullptr, dsb, gw, P.gws_bytes, (yt8m_stream_t)sw));
+          RC(yt8m_gemm_h2_nt_grouped(2, pr, alphas, dsa, dsb, gw, P.gws_bytes, (yt8m_stream_t)sw));
         } else {
           if (fused_img) {
           } else if (!fused_t) {
