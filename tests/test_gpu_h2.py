@@ -217,3 +217,21 @@ def test_h2_rows_keep_their_own_precision(dev):
     ha, _ = ops.h2_split(A, dynamic=True)
     C1 = ops.gemm_h2_grouped([dict(A=ha, B=hw)])[0]
     assert float(C1[M - 1].abs().max()) == 0.0 and float(ref[M - 1].abs().max()) > 0.0
+
+
+def test_h2_split_keeps_a_nan_a_nan(dev):
+    """Finite and infinite values clamp into the half range (an operand that outgrew its scale degrades, it does not turn into inf);
+    a NaN stays a NaN in both planes -- a diverged step must show as NaN downstream, as it would in fp32 -- exactly as the oracle's
+    numpy arithmetic has it."""
+    from oracle import x3_ref
+    rs = np.random.RandomState(5)
+    x = rs.randn(64, 48).astype(np.float32)
+    x[3, 7], x[40, 0], x[10, 10] = np.nan, np.inf, -np.inf
+    ip, _ = ops.h2_split(torch.from_numpy(x).to(dev), plain=True, trans=False, scale=4.0)
+    want = x3_ref.image_h2(x, 4.0)
+    got = ip.buf.cpu().numpy().view(np.uint16).reshape(want.shape)
+    wf, gf = want.view(np.float16), got.view(np.float16)
+    nan = np.isnan(wf)
+    assert nan.sum() == 2 and np.array_equal(np.isnan(gf), nan)            # hi and lo of the one NaN element
+    assert np.array_equal(got[~nan], want[~nan])
+    assert np.isfinite(gf[~nan]).all()                                     # the infinities were clamped

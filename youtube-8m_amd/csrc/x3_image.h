@@ -49,12 +49,12 @@ __device__ __forceinline__ void store_block(const float (&v)[16], float* __restr
 // ---- "h2" images (round 5): TWO fp16 planes, a S = hi + lo ---------------------------------------------------------------------------
 // The same block layout with NP = 2 planes of IEEE half instead of bfloat16: hi = f16(a S), lo = f16(a S - hi) for a power-of-two
 // scale S that brings the operand's magnitude into the half range (|a S| is clamped to the largest half: an operand that outgrew its
-// scale degrades, it does not turn into inf).  11 + 11 significand bits: a S = hi + lo + r, |r| <= 2^-23 |a S| while lo is a normal
+// scale degrades, it does not turn into inf; NaN stays NaN).  11 + 11 significand bits: a S = hi + lo + r, |r| <= 2^-23 |a S| while lo is a normal
 // half (|a S| >= 2^-3), an absolute 2^-25 below that.  Three products (hi hi, hi lo, lo hi) then carry a b to 2^-21 relative --
 // the size of three fp32 roundings -- at HALF the matrix-pipe time of the six-product bf16 split (csrc/gemm_x3.hip gemm_h2q_kernel).
 __device__ __forceinline__ void split_h2(float x, unsigned& h1, unsigned& h2) {
-  x = fminf(fmaxf(x, -65504.f), 65504.f);                           // (NaN passes through fminf / fmaxf as the other operand: -> finite)
-  const _Float16 hi = (_Float16)x;
+  x = (x != x) ? x : fminf(fmaxf(x, -65504.f), 65504.f);            // finite and infinite values clamp; a NaN stays a NaN (hi = NaN, lo = NaN):
+  const _Float16 hi = (_Float16)x;                                  // a diverged step shows up as NaN downstream, as it would in fp32
   const _Float16 lo = (_Float16)(x - (float)hi);                    // exact difference, rounded once
   h1 = (unsigned)__builtin_bit_cast(unsigned short, hi);
   h2 = (unsigned)__builtin_bit_cast(unsigned short, lo);
