@@ -21,7 +21,7 @@ cp $R/bench_extra.json $O/bench_extra.json          # the sidecar the line names
 # 3. the same workload under kernel trace + stats (no CPU / GAP / extra legs: they are not the measured region)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gap --no-extra < /dev/null > $O/bench_line_profiled.json 2> $O/bench_prof.err
 f=$(find $O/bench -name "*kernel_trace.csv" | head -1)
-python $R/tools/trace_step.py $f 40 3 u8_frames_tm_kernel > $O/step_timeline.txt 2>&1
+python $R/tools/trace_step.py $f 40 10 u8_frames_tm_kernel > $O/step_timeline.txt 2>&1   # (a step of the TIMED region: the last five steps of the run carry the hipEvent profile pass)
 # 4. extras under kernel trace: configs[1], configs[2], configs[4] (bf16)
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/moe -o moe -- python $R/bench.py --workload moe --steps 200 --warmup 10 --no-cpu-baseline --no-gap --no-extra < /dev/null > $O/moe_line.json 2>/dev/null
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/netvlad -o nv -- python $R/bench.py --workload netvlad --steps 20 --warmup 3 --no-cpu-baseline --no-gap --no-extra < /dev/null > $O/netvlad_line.json 2>/dev/null
