@@ -484,6 +484,9 @@ int64_t yt8m_wimg_count(void);
 int yt8m_wimg_watch(const void* lo, const void* hi, int on);       /* 1: note the demands on memory in [lo, hi); 0: stop + forget them */
 int yt8m_wimg_note_demand(const float* src, int64_t R, int64_t C, int64_t ld, int trans, int planes, float scale);
 int64_t yt8m_wimg_demands(yt8m_wimg_demand* out, int64_t max);      /* copies <= max entries, returns how many were recorded */
+int64_t yt8m_wimg_demand_generation(const void* lo, const void* hi); /* demands EVER noted inside the watched range [lo, hi) (monotonic;
+                                                                        -1: not watched): what ONE arena's owner compares, unmoved by
+                                                                        other arenas' demands or by another owner that stops watching */
 /* One matrix of the parameter arena and the images it owns.  offset: floats from the arena base (w, m, v, g share it) to the
  * row-major contiguous matrix [R, C]; tensor: its index into l2 / norms.  Each spec covers the row window [row0, row0 + rows)
  * (row0 % 64 == 0; rows % 64 == 0 or the window ends with the matrix -- the input rows [0, Din) of an LSTM weight [Din + H, 4H]):

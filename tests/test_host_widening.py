@@ -175,10 +175,11 @@ def test_close_then_step_does_not_rescale_the_l2_table():
     """TrainGraph.close() detaches the data-parallel reducer and a later step() re-attaches it, but the
     --regularization_penalty scaling of the per-variable l2 table must happen exactly once per TrainGraph."""
     class Reducer(object):
-        attached = detached = 0
+        attached = detached = broadcasts = 0
 
-        def attach(self, g):
+        def attach(self, g, broadcast=True):
             self.attached += 1
+            self.broadcasts += int(bool(broadcast))
 
         def detach(self):
             self.detached += 1
@@ -202,3 +203,4 @@ def test_close_then_step_does_not_rescale_the_l2_table():
         tg.ensure_finalized()
         assert torch.equal(tg.graph.l2, l2)
     assert tg.reducer.attached == 4 and tg.reducer.detached == 3
+    assert tg.reducer.broadcasts == 1          # a re-attach must not broadcast between a step's forward and backward pass

@@ -263,6 +263,7 @@ SIGNATURES = {
     "yt8m_wimg_watch": (c_int, [P, P, c_int]),
     "yt8m_wimg_note_demand": (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int, c_float]),
     "yt8m_wimg_demands": (c_int64, [ctypes.POINTER(WimgDemand), c_int64]),
+    "yt8m_wimg_demand_generation": (c_int64, [P, P]),
     "yt8m_wimg_jobs_layout": (c_int64, [ctypes.POINTER(WimgJob), c_int64]),
     "yt8m_adam_tiles": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_float, P, c_float, c_float, c_float, c_float, c_float,
                                 c_int, P]),

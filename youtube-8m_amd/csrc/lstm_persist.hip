@@ -1145,7 +1145,11 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       // (addresses: the lane's 16 bytes in the VGPR offset, everything uniform -- tile, wave, block -- in the scalar offset: with the
       // block index folded into per-load VGPR offsets the register allocator keeps a dozen base registers alive)
       const int lane_off = lane * 16;
+#ifdef YT8M_TWIN_TEST    // timing experiment only (wrong results): waves 2j and 2j + 1 fetch the SAME K blocks -- what a twin-wave N = 32 form would move
+      auto blk = [&](int T) -> int { return __builtin_amdgcn_readfirstlane((T * QH4 + (w & ~1) * NQB) * 1024); };
+#else
       auto blk = [&](int T) -> int { return __builtin_amdgcn_readfirstlane((T * QH4 + w * NQB) * 1024); };
+#endif
       const __amdgpu_buffer_rsrc_t scr = make_rsrc(a.sc, a.sc_bytes);
       const int kq_off = kq * 4;
       auto sc_off = [&](int s, int T, int pl) -> int { return __builtin_amdgcn_readfirstlane(((s * NT16 + T) * a.NUB + w * NPW + pl) * 16); };

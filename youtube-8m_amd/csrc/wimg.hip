@@ -34,7 +34,7 @@ struct Entry {
 std::mutex g_mu;
 std::vector<Entry> g_reg;
 std::vector<yt8m_wimg_demand> g_dem;
-struct Range { const char* lo; const char* hi; };
+struct Range { const char* lo; const char* hi; int64_t noted; };   // noted: demands ever recorded inside the range (monotonic)
 std::vector<Range> g_watch;                               // parameter arenas whose splits are noted as demands
 constexpr size_t MAX_DEMANDS = 4096;
 
@@ -94,7 +94,7 @@ extern "C" int yt8m_wimg_watch(const void* lo, const void* hi, int on) {
   for (size_t i = g_watch.size(); i-- > 0;)
     if (g_watch[i].lo == l && g_watch[i].hi == h) g_watch.erase(g_watch.begin() + (long)i);
   if (on) {
-    g_watch.push_back({l, h});
+    g_watch.push_back({l, h, 0});
   } else {
     for (size_t i = g_dem.size(); i-- > 0;) {
       const char* p = reinterpret_cast<const char*>(g_dem[i].src);
@@ -115,7 +115,19 @@ extern "C" int yt8m_wimg_note_demand(const float* src, int64_t R, int64_t C, int
   yt8m_wimg_demand d;
   d.src = src; d.R = R; d.C = C; d.ld = ld; d.trans = trans; d.planes = planes; d.scale = scale; d.pad = 0;
   g_dem.push_back(d);
+  for (Range& r : g_watch)
+    if (reinterpret_cast<const char*>(src) >= r.lo && reinterpret_cast<const char*>(src) < r.hi) ++r.noted;
   return YT8M_OK;
+}
+
+// How many demands were EVER noted inside the watched range [lo, hi) (monotonic while the range is watched; -1: not watched).  The
+// owner of one arena compares this with what it has examined: demands of other arenas, or another owner that stops watching, do not
+// move it (the process-wide count of yt8m_wimg_demands does both).
+extern "C" int64_t yt8m_wimg_demand_generation(const void* lo, const void* hi) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (const Range& r : g_watch)
+    if (r.lo == static_cast<const char*>(lo) && r.hi == static_cast<const char*>(hi)) return r.noted;
+  return -1;
 }
 
 // Copies up to `max` recorded demands to `out` (may be NULL to query the count); returns how many there are.

@@ -187,8 +187,11 @@ class GradReducer(object):
         self._launched = None
         self.active = False
 
-    def attach(self, graph):
-        """Hooks the graph and makes every rank start from rank 0's parameters."""
+    def attach(self, graph, broadcast=True):
+        """Hooks the graph and (broadcast=True) makes every rank start from rank 0's parameters.  The broadcast may write the arena
+        through a raw pointer (CabiComm), which bumps no torch version counter: the resident weight images are rebuilt here, in
+        stream order behind it.  A RE-attach after TrainGraph.close() passes broadcast=False: the ranks' parameters
+        are already identical, and a broadcast between a step's forward and backward pass would change the weights under it."""
         self.graph = graph
         self.active = self.comm is not None or dist.is_initialized()
         if self.comm is not None:
@@ -196,10 +199,12 @@ class GradReducer(object):
         else:
             graph.rank = dist.get_rank(self.group) if self.active else 0     # ranks draw different dropout / noise streams
         graph.grad_ready_hook = self._on_ready if (self.overlap and self.active) else None
-        if self.comm is not None:
+        if broadcast and self.comm is not None:
             self.comm.broadcast(graph.params, 0)
-        elif self.active:
+        elif broadcast and self.active:
             dist.broadcast(graph.params, src=0, group=self.group)
+        if broadcast and self.active and getattr(graph, "wimg", None) is not None:
+            graph.wimg.refresh()
         nv = len(graph.trainable_variables())
         self._ready = [False] * nv
         self._launched = [False] * nv

@@ -160,8 +160,11 @@ class TrainGraph(object):
                 g.l2.mul_(float(self.reg_penalty))
             self._finalized_here = True
         if self.reducer is not None and not getattr(self, "_reducer_attached", False):
-            self.reducer.attach(g)                                # its own flag: close() detaches, a later step() re-attaches
-            self._reducer_attached = True
+            first = not getattr(self, "_reducer_ever_attached", False)
+            self.reducer.attach(g, broadcast=first)               # its own flag: close() detaches, a later step() re-attaches
+            self._reducer_attached = self._reducer_ever_attached = True     # (without a second broadcast: ADVICE r5)
+            return first and getattr(self.reducer, "active", False)
+        return False
 
     # ---- one optimisation step -----------------------------------------------------------------------
     def step(self, model_input_raw, labels_batch, num_frames=None, weights=None, distill_labels_batch=None):
@@ -186,7 +189,17 @@ class TrainGraph(object):
         for op in result.get("update_ops", ()) or ():
             if callable(op):
                 op()
-        self.ensure_finalized()
+        if self.ensure_finalized():
+            # the first step of a data-parallel run: the variables were created (and the forward pass ran) BEFORE rank 0's parameters
+            # arrived.  Run the forward pass again so that the whole step -- activations, weight images, backward -- sees one set of
+            # weights on every rank (once per run; with identical seeds the values do not change).
+            g._rng_step -= 1                                      # the same forward pass again: the same random-op seeds
+            result = self.forward(model_input_raw, labels_batch, num_frames, fuse_loss=fuse,
+                                  distillation_predictions=distill if FLAGS.distillation_as_input else None)
+            final_loss = label_loss = self.loss(result, labels_batch, weights, distill)
+            if "regularization_loss" in result and torch.is_tensor(result["regularization_loss"]) \
+                    and result["regularization_loss"].requires_grad and self.reg_penalty != 0:
+                final_loss = label_loss + float(self.reg_penalty) * result["regularization_loss"]
         lr = exponential_decay(self.base_learning_rate, self.global_step, self.batch_size, self.decay_examples, self.decay)
         t = self.global_step + 1
         lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)

@@ -12,8 +12,12 @@ for and lets the optimiser pass rewrite them where it rewrites the weight:
   built once (``yt8m_adam_tiles(do_adam=0)``);
 * ``ops.sqnorm_and_adam`` updates the owning tensors with ``yt8m_adam_tiles`` (bitwise the chunk kernel's arithmetic + the images
   in the same pass) and everything else with the chunk kernel (``yt8m_adam_multi_ex`` skips the flagged tensors);
-* any torch-side write to the arena (checkpoint restore, a test injecting weights, the data-parallel broadcast) bumps the arena
-  tensor's version counter; ``begin_step`` sees it and refreshes every image before the step's first product.
+* any torch-side write to the arena (checkpoint restore, a test injecting weights, ``dist.broadcast``) bumps the arena tensor's
+  version counter; ``begin_step`` sees it and refreshes every image before the step's first product;
+* a write through a RAW pointer (``yt8m_comm_broadcast_f32`` on ``data_ptr`` -- ``parallel.CabiComm.broadcast`` -- or any C-ABI host
+  writing the arena) bumps nothing: the writer calls ``WeightImages.refresh()`` (rebuild now, in stream order behind the write)
+  or ``invalidate()`` (rebuild at the next ``begin_step``).  ``parallel.GradReducer.attach`` does so after either broadcast
+  (ADVICE r5).
 
 ``YT8M_WIMG=0`` turns the whole mechanism off (every product splits its weight operand per step, as in rounds 2-4).
 """
@@ -40,7 +44,7 @@ class WeightImages(object):
         self.g = graph
         self.lo = graph.params.data_ptr()
         self.hi = self.lo + max(graph.total, 1) * 4
-        self.seen = 0                       # demands of this arena already turned into images (or rejected)
+        self.seen = 0                       # demand generation of THIS arena already examined (yt8m_wimg_demand_generation)
         self.version = None                 # arena version counter the images were last made for
         self.keys = {}                      # (tensor, row0, rows, trans, planes, scale) -> image tensor
         self.jobs_host = None
@@ -93,17 +97,24 @@ class WeightImages(object):
         after a torch-side write to the arena."""
         if not self.watching:
             return
-        L = _lib.lib()
-        if L.yt8m_wimg_demands(None, 0) != self.seen:
+        if self._generation() != self.seen:
             self._extend()
         if self.jobs_dev is not None and self.g.params._version != self.version:
             self.refresh()
+
+    def _generation(self):
+        return _lib.lib().yt8m_wimg_demand_generation(ctypes.c_void_p(self.lo), ctypes.c_void_p(self.hi))
+
+    def invalidate(self):
+        """The arena was written behind torch's back (raw-pointer broadcast, a C-ABI host): every image is rebuilt at the next
+        begin_step."""
+        self.version = None
 
     def _extend(self):
         g = self.g
         L = _lib.lib()
         self._offsets = [v.offset for v in g.trainable_variables()]
-        self.seen = L.yt8m_wimg_demands(None, 0)
+        self.seen = self._generation()
         fresh = []
         for d in self._demands():
             k = self._key_of(d)
@@ -127,7 +138,9 @@ class WeightImages(object):
         for k in keys:
             have = specs.setdefault(k[0], set())
             sp = (k[1], k[2], k[4], k[5])
-            if k in self.keys or (sp not in have and len(have) >= 4):
+            if k in self.keys:                                             # already resident: nothing to do (and nothing to reject)
+                continue
+            if sp not in have and len(have) >= 4:
                 self.rejected.add(k)
                 continue
             have.add(sp)
