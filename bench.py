@@ -873,13 +873,19 @@ def compact_line(out, sidecar=SIDECAR):
     line["library"] = {"sha256": lib.get("sha256"), "in_tree_default": lib.get("in_tree_default"), "env": lib.get("env")}
     rd = out.get("reducer")
     if rd:
-        line["reducer"] = {k: rd.get(k) for k in ("algo", "reserved_cus", "world", "bucket_MiB", "layer_buckets", "transport",
+        line["reducer"] = {k: rd.get(k) for k in ("algo", "reserved_cus", "reserve_rule", "emulated_footprint", "world", "bucket_MiB", "layer_buckets", "transport",
                                                   "forced_at_world_1")}
         pr = rd.get("per_rank") or []
         line["reducer"]["persist_timeouts"] = sum(1 for x in pr if x and x.get("persist_timeout"))
-        exposed = [x["dp_trace"].get("exposed_ms") for x in pr if x and isinstance(x.get("dp_trace"), dict) and "exposed_ms" in x["dp_trace"]]
-        if exposed:
-            line["reducer"]["exposed_allreduce_ms_max"] = _r(max(exposed), 4)
+        traces = [x["dp_trace"] for x in pr if x and isinstance(x.get("dp_trace"), dict) and "exposed_allreduce_ms" in x["dp_trace"]]
+        if traces:
+            # the rank whose all-reduce sticks out furthest behind its backward pass, bucket by bucket: [MB, enqueued, landed, exposed] in ms
+            # after the start of the backward pass (exposed = how far the bucket's landing lies behind the end of the backward pass)
+            w = max(traces, key=lambda t: t["exposed_allreduce_ms"])
+            line["reducer"]["exposed_allreduce_ms_max"] = _r(w["exposed_allreduce_ms"], 4)
+            line["reducer"]["backward_ms"] = _r(w["backward_ms"], 4)
+            line["reducer"]["buckets_MB_enq_land_exposed_ms"] = [[_r(b["MB"], 4), _r(b["enqueued_ms"], 3), _r(b["landed_ms"], 3),
+                                                                  _r(max(0.0, b["landed_ms"] - w["backward_ms"]), 3)] for b in w["buckets"]][:8]
     line["sidecar"] = sidecar
     # the contract is the size: shed the optional detail, in this order, until the line fits
     for drop in (lambda: line["library"].pop("env", None), lambda: line["roofline"] and line["roofline"].pop("other_ms_per_step", None),
@@ -1091,7 +1097,8 @@ def main():
                                          "YT8M_STACK_H2=0 YT8M_STACK_H2_RECUR=0 YT8M_GEMM_H2=0 select the six-product / fp32-pipe forms")},
                "roofline": roof, "cpu_baseline": cpu, "gap_at_20": gap, "extra": extra, "placement": placement,
                "library": library_identity(),
-               "reducer": None if reducer is None else {"algo": reducer.algo, "reserved_cus": reducer.reserve_cus, "world": reducer.world,
+               "reducer": None if reducer is None else {"algo": reducer.algo, "reserved_cus": reducer.reserve_cus, "reserve_rule": reducer.reserve_rule,
+                                                        "emulated_footprint": reducer.emulate, "world": reducer.world,
                                                         "bucket_MiB": reducer.bucket_elems * 4 / 2 ** 20,
                                                         "layer_buckets": bool(seq_ops.DP_LAYER_BUCKETS),
                                                         "transport": "CabiComm" if reducer.comm is not None else "torch.distributed",

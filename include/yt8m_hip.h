@@ -24,6 +24,8 @@ enum yt8m_label_dtype { YT8M_LABEL_U8 = 0, YT8M_LABEL_F32 = 1 };
  * reads AND clears it), the image GEMMs read yt8m_gemm_problem.lda / ldb as K-block strides.
  * 3 since round 5: yt8m_lstm_stack_desc.input_u8 is a bit field (bit 1 selects bf16 operand images: a truthy 2 from an older host
  * would change behaviour), yt8m_gemm_auto_grouped / yt8m_lstm_stack_* consult the resident weight-image table (yt8m_wimg_*).
+ * 4 since round 6: yt8m_lstm_stack_desc grew (input_keep_prob, dropout_seed[8]: a smaller struct from an older host would be read past
+ * its end); yt8m_gemm_auto_* read YT8M_GEMM_ROLE_DW in transA (without it a transA product no longer takes the three-f16-product form).
  * A host must check it. */
 int yt8m_abi_version(void);
 const char* yt8m_last_error(void);
@@ -126,6 +128,15 @@ int yt8m_gemm_x3_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* wor
 int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* dscale, void* plain, void* trans,
                   float* colpart, yt8m_stream_t stream);
 int yt8m_h2_absmax(const float* src, int64_t R, int64_t C, int64_t ld, void* word, yt8m_stream_t stream);
+/* Sticky degradation counters of the h2 split passes on the current device: counts[0] = elements CLAMPED (|x . S| beyond the largest
+ * half: the operand outgrew its scale; results degrade), counts[1] = nonzero elements FLUSHED to a zero half (more than 2^-38 below
+ * their scale's maximum).  Waits for `stream`; reset != 0 zeroes them.  A training host checks counts[0] == 0 now and then. */
+int yt8m_h2_degraded(uint64_t* counts, int reset, yt8m_stream_t stream);
+/* yt8m_h2_split of tf.nn.dropout(src, keep_prob) in one pass: the image(s) of x / keep_prob where the Philox stream of (seed, offset + row C
+ * + col) keeps the element, else 0 -- bit for bit what yt8m_dropout_f32(src, ., R C, keep_prob, seed, offset) followed by yt8m_h2_split
+ * writes.  src is [R, C] contiguous.  (DropoutWrapper(input_keep_prob) inside yt8m_lstm_stack_fwd / _bwd.) */
+int yt8m_h2_split_dropout(const float* src, int64_t R, int64_t C, float scale, const float* dscale, void* plain, void* trans,
+                          float keep_prob, uint64_t seed, int64_t offset, yt8m_stream_t stream);
 /* yt8m_h2_rowscales + yt8m_h2_split_rows in one pass over src when the row maxima are already known (rowmax[r] = max |src[r, :]| as float
  * bits, e.g. from yt8m_lstm_persist_bwd_ex): the plain h2 image [R rows, K = C] of diag(S) . src, S[r] the power of two that brings the
  * row's maximum into [2^13, 2^14) (1 for an all-zero row), and inv[r] = 1 / S[r] (the rowscale of yt8m_gemm_h2_nt_ex). */
@@ -168,7 +179,15 @@ int yt8m_x3_set_schedule(int mode);
  * (up to 64 problems); image_scratch (yt8m_gemm_auto_scratch_bytes of the same arguments, 256-byte aligned) holds the operand
  * images -- an operand shared by several problems is split once; with too little of it the problems that do not fit stay on the
  * fp32 kernel.  used_x3 (may be NULL): bit i = problem i ran on the bf16 pipe.  YT8M_GEMM_X3=0 keeps everything on the fp32 kernel.
- * Replaces every slim.fully_connected / tf.matmul site outside the recurrent stack (W/all_video_models/moe_model.py:43-55, ...). */
+ * Replaces every slim.fully_connected / tf.matmul site outside the recurrent stack (W/all_video_models/moe_model.py:43-55, ...).
+ * ROLE (round 6): transA may carry YT8M_GEMM_ROLE_DW (transA = 1 | YT8M_GEMM_ROLE_DW): the caller DECLARES the product a weight
+ * gradient dW = x^T . dz -- neither stored operand is a weight, the sum runs over the rows of both -- and accepts the "h2" form for it:
+ * three f16 MFMA products of two-half-plane images under ONE power-of-two scale per operand, measured on the device (K >= 512,
+ * N % 4 == 0; YT8M_GEMM_H2=0 turns it off).  Its precision contract: every element of an operand is held to 2^-22 of THAT
+ * operand's largest magnitude, i.e. an element 2^-k below the matrix maximum keeps 22 - k significant bits and elements more than
+ * 2^-38 below it flush to zero; products accumulate in fp32.  Without the flag a product never takes that form, whatever its
+ * transposition flags (six bf16 products of exact three-plane splits, or the fp32-MFMA kernel: fp32-grade for every element). */
+#define YT8M_GEMM_ROLE_DW 0x100
 int yt8m_gemm_x3_pays(int64_t M, int64_t N, int64_t K);
 int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt8m_gemm_problem* probs);
 int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
@@ -665,7 +684,7 @@ int yt8m_lstm_persist_bwd_images(const float* gates, const float* Wh, int64_t ld
 
 /* ---- the whole recurrent stack as two calls (csrc/lstm_stack.hip; SURVEY.md 8(b): yt8m_lstm_fwd / yt8m_lstm_bwd) --------------
  * MultiRNNCell([BasicLSTMCell(H)] * L) under tf.nn.dynamic_rnn(sequence_length = num_frames) and its gradient
- * (W/all_frame_models/lstm_model.py:34-47, lstm_memory_model.py:36-52 without DropoutWrapper; W/train.py:435-466), with the
+ * (W/all_frame_models/lstm_model.py:34-47, lstm_memory_model.py:36-52 with its DropoutWrapper: input_keep_prob below; W/train.py:435-466), with the
  * reader's dequantise + l2-normalise (W/readers.py:178-187, W/train.py:343-344) folded into the layer-0 products when the input
  * is the raw uint8 [B,F,D] batch.  The time partition, the stream layout (one high-priority stream per layer + one for the weight
  * gradients, created once per device inside the library), the bf16-pipe product forms and all operand images are the library's:
@@ -686,6 +705,16 @@ typedef struct yt8m_lstm_stack_desc {
   int32_t fwd_chunks;     /* time partition of the forward pass; 0 = the library's (1: one persistent launch per layer) */
   int32_t bwd_chunks;     /* ... of the backward pass; 0 = the library's (3 parts) */
   int32_t need_dx;        /* backward also produces dL/dx [F,B,D] (float input only) */
+  /* ABI >= 4 (a host written against ABI 3 must zero these): tf.contrib.rnn.DropoutWrapper(cell, input_keep_prob) around EVERY layer
+   * (W/all_frame_models/lstm_memory_model.py:36-44).  input_keep_prob in (0, 1): the input of layer l (the frames for l = 0, the
+   * outputs of layer l - 1 otherwise -- never the recurrent state) is tf.nn.dropout(., keep) under the Philox stream of
+   * dropout_seed[l] with element index = position in the [F,B,Din_l] tensor: the mask yt8m_dropout_f32 draws.  It is applied where
+   * the layer's operand images are built (forward projection, weight gradient) and replayed on dx; the dropped tensors are never
+   * written.  0 or 1: no dropout.  Float input, the f16 product forms (the fp32 configuration's default) and keep >= 0.3 only
+   * (yt8m_lstm_stack_supported says so). */
+  float input_keep_prob;
+  int32_t reserved0;
+  uint64_t dropout_seed[8];
 } yt8m_lstm_stack_desc;
 int yt8m_lstm_stack_supported(const yt8m_lstm_stack_desc* desc);
 int64_t yt8m_lstm_stack_tape_bytes(const yt8m_lstm_stack_desc* desc);

@@ -70,10 +70,11 @@ def make_params(cfg):
     return P
 
 
-def make_inputs(cfg):
+def make_inputs(cfg, step=0):
     """The batch as the reader hands it over: video-level float features in the dequantised range, frame-level raw uint8 +
-    num_frames (ragged, incl. 1 and F); labels ~ Bernoulli(3.4 / V) with at least one per video."""
-    rs = np.random.RandomState(SEED[cfg] + 5000)
+    num_frames (ragged, incl. 1 and F); labels ~ Bernoulli(3.4 / V) with at least one per video.  step: which batch of a training
+    trajectory (tests/golden/make_trajectory_golden.py); step 0 is the batch of the single-pass fixtures."""
+    rs = np.random.RandomState(SEED[cfg] + 5000 + 7919 * step)
     B = BATCH[cfg]
     y = rs.random_sample((B, V)) < 3.4 / V
     y[np.arange(B), rs.randint(0, V, size=B)] = True

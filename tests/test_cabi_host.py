@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(L.LIB_PATH)
     for n in _declared():
         assert hasattr(raw, n), n
-    assert lib.yt8m_abi_version() == 3
+    assert lib.yt8m_abi_version() == 4
     assert lib.yt8m_built_arch() == b"gfx950"
 
 

@@ -235,3 +235,24 @@ def test_h2_split_keeps_a_nan_a_nan(dev):
     assert nan.sum() == 2 and np.array_equal(np.isnan(gf), nan)            # hi and lo of the one NaN element
     assert np.array_equal(got[~nan], want[~nan])
     assert np.isfinite(gf[~nan]).all()                                     # the infinities were clamped
+
+
+def test_the_generic_transA_product_keeps_every_element_fp32_grade_and_the_dw_role_is_declared(dev):
+    """the three-f16-product form (one scale per MATRIX: elements far below the matrix maximum lose bits) is taken only
+    when the caller declares the weight-gradient role (ops.gemm(..., role="dw") = YT8M_GEMM_ROLE_DW in transA).  A generic
+    transA product whose left operand has a column 2^-30 below the rest must keep that column's outputs to fp32 grade ON THEIR
+    OWN SCALE; the declared product is held to the h2 contract (error relative to the whole matrix' scale)."""
+    g = torch.Generator(device=dev).manual_seed(77)
+    K, M, N = 9600, 1024, 4096                 # a weight gradient of the headline's recurrent stack: the library takes the f16 form
+    A = torch.randn((K, M), device=dev, generator=g)
+    A[:, 5] *= 2.0 ** -30
+    Bm = torch.randn((K, N), device=dev, generator=g) * 1e-2
+    ref = A.double().t() @ Bm.double()
+    generic = ops.gemm(A, Bm, transA=True)
+    row = lambda c: float((c[5].double() - ref[5]).abs().max() / ref[5].abs().max())
+    assert row(generic) < 5e-6, row(generic)
+    declared = ops.gemm(A, Bm, transA=True, role="dw")
+    assert float((declared.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert row(declared) > 1e-4                # the role's contract, made visible: that column sits below one scale word's resolution
+    with pytest.raises(ValueError):
+        ops.gemm(A, Bm, transA=True, role="weights")

@@ -204,3 +204,31 @@ def test_close_then_step_does_not_rescale_the_l2_table():
         assert torch.equal(tg.graph.l2, l2)
     assert tg.reducer.attached == 4 and tg.reducer.detached == 3
     assert tg.reducer.broadcasts == 1          # a re-attach must not broadcast between a step's forward and backward pass
+
+
+def test_auto_cu_reserve_rule_of_the_data_parallel_reducer():
+    """the CU headroom of the persistent recurrences is chosen by code when world > 1 (parallel.auto_reserve_cus): nothing
+    at world 1 or without recurrent variables; at world 8 the head's 386 MB bucket at the assumed 300 GB/s bus bandwidth is on the wire
+    2.25 ms, 0.35 ms past the lone first recurrence -- cheaper than chaining every pair of recurrences (2.7 ms): no reserve; a slow
+    fabric (50 GB/s) leaves 11.6 ms of collision: reserve RCCL's CUs."""
+    import yt8m_amd.parallel as parallel
+    head = 96_500_000 * 4
+    assert parallel.auto_reserve_cus(1, head) == 0
+    assert parallel.auto_reserve_cus(8, head, persistent_recurrences=False) == 0
+    assert parallel.allreduce_ms(head, 8, 300.0) == pytest.approx(2.2517, rel=1e-3)
+    assert parallel.auto_reserve_cus(8, head) == 0
+    slow = parallel.DP_BUSBW_GBPS
+    try:
+        parallel.DP_BUSBW_GBPS = 50.0
+        assert parallel.auto_reserve_cus(8, head) == parallel.DP_RCCL_CUS
+    finally:
+        parallel.DP_BUSBW_GBPS = slow
+    # the reducer resolves "auto" at attach(): a graph without recurrent variables gets 0 and the rule is recorded
+    g = Graph(device="cpu", seed=0)
+    g.begin_step()
+    g.get_variable("gates/weights", (6, 9), random_normal(0.3), l2=1e-8)
+    g.finalize()
+    red = parallel.GradReducer(reserve_cus=None)
+    if parallel.DP_RESERVED_CUS is None:
+        red.attach(g)
+        assert red.reserve_cus == 0 and red.reserve_rule["rule"] == "auto"

@@ -1,8 +1,8 @@
 #!/bin/bash
-# builds gpurun_out-independent A/B variants of the library: tools/build_variant.sh <name> <extra hipcc flags...>
+# builds A/B variants of the library (parallel, own object directory): tools/build_variant.sh <name> <extra hipcc flags...>
 set -e
 cd "$(dirname "$0")/../youtube-8m_amd/csrc"
 name=$1; shift
 mkdir -p ../../tools/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on "$@" -shared -o ../../tools/variants/lib_$name.so *.hip
+make -j8 BUILD=build_$name LIB=../../tools/variants/lib_$name.so EXTRA="$*" > /dev/null
 echo built tools/variants/lib_$name.so

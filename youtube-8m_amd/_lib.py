@@ -27,7 +27,8 @@ class PersistBwdImages(ctypes.Structure):
 class LstmStackDesc(ctypes.Structure):
     """yt8m_lstm_stack_desc (include/yt8m_hip.h)."""
     _fields_ = [("B", c_int64), ("F", c_int64), ("D", c_int64), ("H", c_int64), ("L", ctypes.c_int32), ("input_u8", ctypes.c_int32),
-                ("forget_bias", c_float), ("fwd_chunks", ctypes.c_int32), ("bwd_chunks", ctypes.c_int32), ("need_dx", ctypes.c_int32)]
+                ("forget_bias", c_float), ("fwd_chunks", ctypes.c_int32), ("bwd_chunks", ctypes.c_int32), ("need_dx", ctypes.c_int32),
+                ("input_keep_prob", c_float), ("reserved0", ctypes.c_int32), ("dropout_seed", ctypes.c_uint64 * 8)]      # ABI 4
 
 
 class WimgDemand(ctypes.Structure):
@@ -272,6 +273,8 @@ SIGNATURES = {
     "yt8m_lstm_stack_set_early_optimizer": (c_int, [ctypes.POINTER(OptRanges)]),
     "yt8m_h2_split": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "yt8m_h2_absmax": (c_int, [P, c_int64, c_int64, c_int64, P, P]),
+    "yt8m_h2_degraded": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int, P]),
+    "yt8m_h2_split_dropout": (c_int, [P, c_int64, c_int64, c_float, P, P, P, c_float, ctypes.c_uint64, c_int64, P]),
     "yt8m_h2_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P, P]),
     "yt8m_gemm_h1x2_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, P, c_float, c_float, P,
                                      c_int64, P]),
@@ -286,7 +289,7 @@ SIGNATURES = {
 }
 
 # The ABI this host binds (include/yt8m_hip.h, yt8m_abi_version): workspace layouts and argument meanings, not just symbols.
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

@@ -55,13 +55,17 @@ struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; bool h2
 // one power-of-two scale per operand, measured on the device, serves every term of every output element -- such a product runs as
 // THREE f16 products of two-plane half images (gemm_h2q_kernel, 1.6x the six-product kernel).  Forward products and dx read a weight
 // (whose six-product image is resident, csrc/wimg.hip) and keep the bf16 split.  YT8M_GEMM_H2=0 turns it off.
+// Round 6: the role is DECLARED by the caller -- YT8M_GEMM_ROLE_DW or-ed into transA -- never inferred from the
+// transposition flags: a generic transA product keeps the six-product / fp32 contract.  The h2 contract (include/yt8m_hip.h): every
+// element of an operand is held to 2^-22 of THAT OPERAND's largest magnitude (one scale word per matrix), so an element 2^-k below
+// the maximum carries 22 - k significant bits and elements more than 2^-38 below it flush to zero.
 // ... for K >= YT8M_GEMM_H2_MINK (default 512): an h2 operand costs three launches (zero the word, absmax, split) against the six-product
 // form's one, and at K = 128 -- the MoE head's weight gradient at the headline's B = 128 -- the nine tiny launches of three operands
 // (230 us with their launch seams) outlast the product they prepare (130 us).
-bool h2_role(int transA, int transB, int64_t K) {
+bool h2_role(int transA_flags, int transB, int64_t K) {
   static const bool off = getenv("YT8M_GEMM_H2") != nullptr && atoi(getenv("YT8M_GEMM_H2")) == 0;
   static const int64_t mink = getenv("YT8M_GEMM_H2_MINK") ? atoll(getenv("YT8M_GEMM_H2_MINK")) : 512;
-  return !off && transA != 0 && transB == 0 && K >= mink;
+  return !off && (transA_flags & YT8M_GEMM_ROLE_DW) != 0 && (transA_flags & 1) != 0 && transB == 0 && K >= mink;
 }
 constexpr int64_t H2_SCALE_BYTES = 256;                  // the operand's absmax word (yt8m_h2_absmax), in front of its h2 image in the scratch
 
@@ -75,13 +79,14 @@ const void* resident(const void* src, int64_t R, int64_t C, int64_t ld, bool tra
 extern "C" int yt8m_gemm_x3_pays(int64_t M, int64_t N, int64_t K) { return x3_pays(M, N, K) ? 1 : 0; }
 
 // bytes of image scratch with which every problem of the call that should run on the bf16 pipe does
-extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt8m_gemm_problem* probs) {
+extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA_flags, int transB, int nprob, const yt8m_gemm_problem* probs) {
   if (nprob < 1 || !probs) return 0;
+  const int transA = transA_flags & 1;
   int64_t n = 0;
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     if (!x3_allowed(q)) continue;
-    if (h2_role(transA, transB, q.K) && (q.N % 4) == 0) {   // (h2 images are 2/3 of these sizes; the scale words sit in front)
+    if (h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0) {   // (h2 images are 2/3 of these sizes; the scale words sit in front)
       n += 2 * H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.M, q.K)) + up256(yt8m_x3_image_bytes(q.N, q.K));
       continue;
     }
@@ -94,10 +99,12 @@ extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int npro
 // C_i = op(A_i) . op(B_i) (+ bias_i) (+ C_i) for nprob problems sharing transA / transB (fp32 row-major operands, as
 // yt8m_gemm_f32_grouped).  workspace: split-K scratch (yt8m_gemm_workspace_bytes, may be NULL); image_scratch: see above (may be
 // NULL / small).  used_x3 (may be NULL): bit i set when problem i ran on the bf16 pipe.
-extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
+extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
                                       int64_t workspace_bytes, void* image_scratch, int64_t image_scratch_bytes, uint64_t* used_x3,
                                       yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 64 && probs, YT8M_E_BADARG, "1..64 problems per call");
+  YT8M_REQUIRE((transA_flags & ~(1 | YT8M_GEMM_ROLE_DW)) == 0 && (transB & ~1) == 0, YT8M_E_BADARG, "transA: 0 / 1 (| YT8M_GEMM_ROLE_DW), transB: 0 / 1");
+  const int transA = transA_flags & 1;
   YT8M_REQUIRE((reinterpret_cast<uintptr_t>(image_scratch) & 255) == 0, YT8M_E_BADARG, "image scratch must be 256-byte aligned");
   std::vector<Img> imgs;
   std::vector<yt8m_gemm_problem> px, p32, ph;
@@ -120,7 +127,7 @@ extern "C" int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const y
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
     bool x3 = q.M > 0 && q.N > 0 && x3_allowed(q) && q.A && q.B;
-    const bool h2 = h2_role(transA, transB, q.K) && (q.N % 4) == 0;   // (the scaled epilogue stores float4: odd widths take the six-product form)
+    const bool h2 = h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0;   // (the scaled epilogue stores float4: odd widths take the six-product form)
     const void* ia = nullptr;
     const void* ib = nullptr;
     if (x3) {

@@ -24,6 +24,7 @@
 // current one.  Tile order and the float4 epilogue follow gemm_bf16.hip; the tiles of the last partial round are split along K.
 #include "common.h"
 #include "x3_image.h"
+#include "philox.h"
 #include <type_traits>
 #include <algorithm>
 #include <mutex>
@@ -1068,7 +1069,14 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
                                                        float* __restrict__ trans_s, float* __restrict__ colpart = nullptr,
                                                        float* __restrict__ colpart_s = nullptr, const float* __restrict__ dscale = nullptr,
                                                        const float* __restrict__ rowS = nullptr, const unsigned* __restrict__ rowmaxw = nullptr,
-                                                       float* __restrict__ rowinv = nullptr) {
+                                                       float* __restrict__ rowinv = nullptr, unsigned long long* __restrict__ degraded = nullptr,
+                                                       float drop_keep = 0.f, unsigned long long drop_seed = 0ull, long long drop_off = 0) {
+  // drop_keep in (0, 1): the source is tf.nn.dropout(src, keep) -- element (r, c) is element drop_off + r Cc + c of the logical tensor
+  // whose Philox stream (csrc/philox.h, key drop_seed) csrc/random.hip's yt8m_dropout_f32 draws: the image is that of the dropped
+  // tensor, bit for bit, without the tensor ever being written (DropoutWrapper(input_keep_prob) inside the native recurrent stack).
+  // degraded (NP = 2): the process-wide sticky counters of yt8m_h2_degraded -- [0] elements CLAMPED (|x S| beyond the largest half: the
+  // operand outgrew its scale), [1] elements FLUSHED (x != 0 whose scaled value rounds to a zero half: more than 2^-38 below the scale's
+  // maximum).  One wave-uniform test per 64 x 64 tile; atomics only when something was counted.
   // rowmaxw (NP = 2, plain image only; instead of rowS): max |src[r, :]| as float bits (measured by the producer of src: yt8m_lstm_persist_bwd_ex);
   // the row's power of two is derived here, the workgroups of the first tile column write its inverse to rowinv (the product's rowscale)
   // rowS (NP = 2, plain image only): row r of the source is scaled by rowS[r] -- one power of two PER ROW (yt8m_h2_rowscales): the
@@ -1077,6 +1085,7 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
   if (dscale) scale *= yt8m_x3::pow2_scale_for(__uint_as_float(reinterpret_cast<const unsigned*>(dscale)[0]), 14);
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
+  unsigned n_clamp = 0, n_flush = 0;
   {
     const int c4 = (t & 15) * 4, rr = t >> 4;
     const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
@@ -1094,6 +1103,20 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
           if (c0 + c4 + 3 < Cc) v.w = p[3];
         }
       }
+      if (drop_keep > 0.f && r0 + r < R) {
+        const long long e0 = drop_off + (long long)(r0 + r) * Cc + c0 + c4;
+        float* vv = reinterpret_cast<float*>(&v);
+        if ((e0 & 3) == 0) {                                // one Philox block = this float4
+          const yt8m_rng::U4 rn = yt8m_rng::philox4x32_10((unsigned long long)(e0 >> 2), drop_seed);
+          const unsigned rw[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = (drop_keep + yt8m_rng::u01(rw[e])) >= 1.0f ? __fdiv_rn(vv[e], drop_keep) : 0.0f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            vv[e] = (drop_keep + yt8m_rng::uniform_at((unsigned long long)(e0 + e), drop_seed)) >= 1.0f ? __fdiv_rn(vv[e], drop_keep) : 0.0f;
+        }
+      }
       float sr = (rowS && r0 + r < R) ? scale * rowS[r0 + r] : scale;
       if (rowmaxw && r0 + r < R) {
         const float pr = yt8m_x3::pow2_scale_for(__uint_as_float(rowmaxw[r0 + r]), 14);
@@ -1101,6 +1124,28 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
         if (rowinv && blockIdx.x == 0 && (t & 15) == 0) rowinv[r0 + r] = 1.0f / pr;
       }
       T[r][c4 + 0] = v.x * sr; T[r][c4 + 1] = v.y * sr; T[r][c4 + 2] = v.z * sr; T[r][c4 + 3] = v.w * sr;
+#ifndef YT8M_H2_NO_COUNT
+      if constexpr (NP == 2) {
+        const float sv[4] = {v.x * sr, v.y * sr, v.z * sr, v.w * sr};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m = fabsf(sv[e]);
+          n_clamp += (m > 65504.f && m < 3.0e38f) ? 1u : 0u;                 // (inf / nan are not the scale's fault)
+          n_flush += (m != 0.f && m < 2.98023224e-8f) ? 1u : 0u;             // nonzero and < 2^-25: rounds to a zero half
+        }
+      }
+#endif
+    }
+  }
+  if constexpr (NP == 2) {
+    if (degraded && __any((n_clamp | n_flush) != 0u)) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { n_clamp += __shfl_xor(n_clamp, o, 64); n_flush += __shfl_xor(n_flush, o, 64); }
+      if ((t & 63) == 0) {                                  // 256 shards, one 128-byte line each: [shard][0] clamped, [shard][1] flushed
+        unsigned long long* w = degraded + (size_t)((blockIdx.x + blockIdx.y * 7u + (unsigned)(t >> 6) * 61u) & 255u) * 16;
+        if (n_clamp) atomicAdd(w, (unsigned long long)n_clamp);
+        if (n_flush) atomicAdd(w + 1, (unsigned long long)n_flush);
+      }
     }
   }
   __syncthreads();
@@ -1158,6 +1203,50 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
 }  // namespace
 
 using namespace yt8m;
+
+// Sticky counters of the h2 split passes ("nothing at run time reports a clamp"): 256 shards of two 64-bit words per device, allocated on
+// first use and never freed -- [0] elements clamped, [1] nonzero elements flushed to a zero half, summed over every h2 image the
+// process has split on that device since the last reset.  A failed allocation turns the counting off (NULL), never the split.
+namespace {
+constexpr size_t H2_DEGRADED_BYTES = 256 * 128;           // 256 shards x one 128-byte line (a single pair of words serialised the
+                                                          // atomics of every split workgroup: +1.8 ms on the headline step, measured)
+unsigned long long* h2_degraded_words() {
+  static std::mutex mu;
+  static unsigned long long* words[64] = {};
+  static bool tried[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tried[dev]) {
+    tried[dev] = true;
+    void* p = nullptr;
+    if (hipMalloc(&p, H2_DEGRADED_BYTES) == hipSuccess && hipMemset(p, 0, H2_DEGRADED_BYTES) == hipSuccess) words[dev] = static_cast<unsigned long long*>(p);
+    else (void)hipGetLastError();
+  }
+  return words[dev];
+}
+}  // namespace
+
+// counts[0] = elements CLAMPED by an h2 split on the current device since the last reset (|x . S| beyond the largest half: an operand
+// outgrew a static or stale scale -- results are degraded), counts[1] = nonzero elements FLUSHED to a zero half (more than 2^-38
+// below their scale's maximum: their contribution is below one ulp of the product's largest terms).  Waits for `stream`;
+// reset != 0 zeroes the words afterwards.  Covers yt8m_h2_split / _ex / _rows / _rowmax (every operand image of the h2 products); the
+// persistent recurrences scale each producer's values by their own measured maxima and cannot clamp.
+extern "C" int yt8m_h2_degraded(uint64_t* counts, int reset, yt8m_stream_t stream) {
+  YT8M_REQUIRE(counts, YT8M_E_BADARG, "counts is NULL");
+  counts[0] = counts[1] = 0;
+  unsigned long long* w = h2_degraded_words();
+  if (!w) return YT8M_OK;
+  YT8M_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  static thread_local unsigned long long host[H2_DEGRADED_BYTES / 8];
+  YT8M_HIP_CHECK(hipMemcpy(host, w, H2_DEGRADED_BYTES, hipMemcpyDeviceToHost));
+  for (size_t sh = 0; sh < 256; ++sh) {
+    counts[0] += host[sh * 16];
+    counts[1] += host[sh * 16 + 1];
+  }
+  if (reset) YT8M_HIP_CHECK(hipMemset(w, 0, H2_DEGRADED_BYTES));
+  return YT8M_OK;
+}
 
 extern "C" int64_t yt8m_x3_image_bytes(int64_t rows, int64_t K) { return ((rows + 31) / 32) * ((K + 15) / 16) * 3072; }
 
@@ -1219,7 +1308,30 @@ extern "C" int yt8m_h2_split(const float* src, int64_t R, int64_t C, int64_t ld,
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
-                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, colpart, (float*)nullptr, dscale);
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, colpart, (float*)nullptr, dscale,
+                     (const float*)nullptr, (const unsigned*)nullptr, (float*)nullptr, h2_degraded_words());
+  return launch_status("x3_split_kernel<2>");
+}
+
+// yt8m_h2_split of tf.nn.dropout(src, keep_prob): the h2 image(s) of the dropped tensor -- x / keep_prob where the Philox stream of
+// (seed, offset + row * C + col) keeps the element, else 0: exactly what yt8m_dropout_f32(src, ., R * C, keep_prob, seed, offset)
+// followed by yt8m_h2_split would produce -- in one pass, without the dropped copy (tf.contrib.rnn.DropoutWrapper(cell,
+// input_keep_prob), W/all_frame_models/lstm_memory_model.py:36-44, inside yt8m_lstm_stack_fwd / _bwd).  ld == C.
+extern "C" int yt8m_h2_split_dropout(const float* src, int64_t R, int64_t C, float scale, const float* dscale, void* plain, void* trans,
+                                     float keep_prob, uint64_t seed, int64_t offset, yt8m_stream_t stream) {
+  YT8M_REQUIRE(R >= 0 && C >= 0 && (plain || trans), YT8M_E_BADARG, "bad split arguments");
+  YT8M_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f && offset >= 0, YT8M_E_BADARG, "keep_prob in (0, 1], offset >= 0");
+  YT8M_REQUIRE(R < (1LL << 31) && C < (1LL << 31), YT8M_E_BADARG, "matrix too large");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(plain) | reinterpret_cast<uintptr_t>(trans)) & 15) == 0, YT8M_E_BADARG,
+               "images must be 16-byte aligned");
+  if (R == 0 || C == 0) return YT8M_OK;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+  YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
+  ProfScope prof(F_ELEMENTWISE, as_stream(stream));
+  hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, C, (int)R, (int)C, static_cast<float*>(plain),
+                     static_cast<float*>(trans), scale, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, dscale,
+                     (const float*)nullptr, (const unsigned*)nullptr, (float*)nullptr, h2_degraded_words(),
+                     keep_prob < 1.f ? keep_prob : 0.f, (unsigned long long)seed, (long long)offset);
   return launch_status("x3_split_kernel<2>");
 }
 
@@ -1239,7 +1351,7 @@ extern "C" int yt8m_h2_split_ex(const float* src, int64_t R, int64_t C, int64_t 
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      static_cast<float*>(trans), scale, rowscale, static_cast<float*>(trans_scaled), colpart, colpart_scaled,
-                     static_cast<const float*>(dscale));
+                     static_cast<const float*>(dscale), (const float*)nullptr, (const unsigned*)nullptr, (float*)nullptr, h2_degraded_words());
   return launch_status("x3_split_kernel<2>");
 }
 
@@ -1305,7 +1417,8 @@ extern "C" int yt8m_h2_split_rows(const float* src, int64_t R, int64_t C, int64_
   YT8M_REQUIRE(grid.y < 65536, YT8M_E_BADARG, "too many rows for one split launch");
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
-                     (float*)nullptr, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, S);
+                     (float*)nullptr, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, S,
+                     (const unsigned*)nullptr, (float*)nullptr, h2_degraded_words());
   return launch_status("x3_split_kernel<2>");
 }
 // yt8m_h2_rowscales + yt8m_h2_split_rows in ONE pass when the row maxima are already known: rowmax[r] = max |src[r, :]| as float bits
@@ -1319,7 +1432,7 @@ extern "C" int yt8m_h2_split_rowmax(const float* src, int64_t R, int64_t C, int6
   ProfScope prof(F_ELEMENTWISE, as_stream(stream));
   hipLaunchKernelGGL(x3_split_kernel<2>, grid, dim3(256), 0, as_stream(stream), src, ld, (int)R, (int)C, static_cast<float*>(plain),
                      (float*)nullptr, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, static_cast<const unsigned*>(rowmax), inv);
+                     (const float*)nullptr, static_cast<const unsigned*>(rowmax), inv, h2_degraded_words());
   return launch_status("x3_split_kernel<2>");
 }
 // C[M,N] (+)= alpha . rowscale[m] / (S_a S_b) . A . B^T (+ bias): yt8m_gemm_h2_nt_grouped for one product with a per-row factor

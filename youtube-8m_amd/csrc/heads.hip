@@ -45,7 +45,7 @@ extern "C" int64_t yt8m_moe_workspace_bytes_ex(int64_t B, int64_t D, int64_t V, 
   const yt8m_gemm_problem w[2] = {{D, Ng, B, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}, {D, Ne, B, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}};
   const int64_t img = std::max(yt8m_gemm_auto_scratch_bytes(0, 0, 2, f),
                                std::max(std::max(yt8m_gemm_auto_scratch_bytes(0, 1, 1, x), yt8m_gemm_auto_scratch_bytes(0, 1, 1, x + 1)),
-                                        yt8m_gemm_auto_scratch_bytes(1, 0, 2, w)));
+                                        yt8m_gemm_auto_scratch_bytes(1 | YT8M_GEMM_ROLE_DW, 0, 2, w)));
   return up256h(yt8m_moe_mix_xent_workspace_bytes(B, V)) + up256h(yt8m_gemm_workspace_bytes()) + 256 + img;
 }
 
@@ -91,7 +91,7 @@ extern "C" int yt8m_moe_bwd(const float* x, const float* Wg, const float* We, fl
     if (rc != YT8M_OK) return rc;
   }
   yt8m_gemm_problem pw[2] = {{D, Ng, B, x, D, Zg, Ng, dWg, Ng, nullptr, beta}, {D, Ne, B, x, D, Ze, Ne, dWe, Ne, nullptr, beta}};
-  rc = yt8m_gemm_auto_grouped(1, 0, 2, pw, w.gemm, w.gemm_bytes, w.img, w.img_bytes, nullptr, stream);
+  rc = yt8m_gemm_auto_grouped(1 | YT8M_GEMM_ROLE_DW, 0, 2, pw, w.gemm, w.gemm_bytes, w.img, w.img_bytes, nullptr, stream);
   if (rc != YT8M_OK) return rc;
   return yt8m_colsum_f32(Ze, B, Ne, Ne, dbe, beta, w.mix, up256h(yt8m_moe_mix_xent_workspace_bytes(B, V)), stream);
 }

@@ -791,13 +791,37 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         evalid[jj] = brow < B;
         const int br = evalid[jj] ? brow : B - 1;
         const float* zr = a.z + ((long long)t * B + br) * 4 * H + ug * 8 + eunit;
+        const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
+#if defined(YT8M_FWD_EPI_NOLOAD) || defined(YT8M_FWD_EPI_NOZ)     // timing experiments only (wrong results)
+        for (int g4 = 0; g4 < 4; ++g4) zpre[jj][g4] = 0.1f * (float)(g4 + eunit);
+#else
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) zpre[jj][g4] = zr[g4 * H];
-        const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
+#endif
+#if defined(YT8M_FWD_EPI_NOLOAD) || defined(YT8M_FWD_EPI_NOCH)
+        cpre[jj] = 0.2f; hpre[jj] = 0.1f;
+#else
         cpre[jj] = a.cs[idx];
         hpre[jj] = a.hs[idx];
+#endif
         live[jj] = t < lds_nf[it * 16 + 8 * j + (lane >> 3)];
       }
+#ifdef YT8M_FWD_ZPREFETCH   // (opt-in: measured no gain, profiles/r6_recur_ab.txt)
+      // Round 6: z[t] (the hoisted projection, read exactly once) comes from HBM, and the four unit groups that share each of its 128-byte
+      // lines (32 columns of one gate) run on four CUs of one XCD and ask for the line at the same moment: all four hold a slot of their CU's
+      // vector-memory window for the whole HBM round trip (profiles/r6_pmc_recur_tcc.txt: without these reads the step is 26 % shorter;
+      // a CU's 64-request window x latency is what paces the kernel).  Each sharer therefore touches a QUARTER of the next step's lines
+      // one step ahead (rows with row % 4 == ug % 4: one dword per line and gate): three of four demand reads become L2 hits.
+      float zpf = 0.f;
+      if (s + 1 < a.T) {
+        const int j = EPW == 2 ? (ew & 1) : 0;
+        constexpr int NPF = (EPW == 2 ? 2 : 4) * 4;        // rows of this wave with row % 4 == ug % 4, times four gates
+        if (lane < NPF) {
+          const int prow = T * 16 + 8 * j + 4 * (lane >> 2) + (ug & 3);
+          if (prow < B) zpf = a.z[((long long)(t + 1) * B + prow) * 4 * H + (long long)(lane & 3) * H + (ug & ~3) * 8];
+        }
+      }
+#endif
       const int slot = k & (NS - 1);
       lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(k / NS + 1), a.ctl);
       STAMP(1);
@@ -865,6 +889,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         if (evalid[jj]) {
           const int brow = T * 16 + 8 * j + (lane >> 3);
           const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
+#ifndef YT8M_FWD_EPI_NOSTORE  // timing experiment only (wrong results)
           if (live[jj]) {
             float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
             zr[0] = gi[jj]; zr[H] = gj[jj]; zr[2 * H] = gf[jj]; zr[3 * H] = go[jj];
@@ -872,8 +897,12 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           a.cs[idx1] = cn[jj];
           a.hs[idx1] = hn[jj];
           if (a.out) a.out[((long long)t * B + brow) * H + ug * 8 + eunit] = live[jj] ? hn[jj] : 0.f;
+#endif
         }
       }
+#ifdef YT8M_FWD_ZPREFETCH
+      asm volatile("" ::"v"(zpf));                          // (keeps the touch alive; its value is never used)
+#endif
     }
   }
   if (ew == 0 && lane == 0) { check_placement(a.ctl, a.stats); propagate_error(a.ctl); }
@@ -1214,8 +1243,10 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
           // refills IN PLACE behind the MFMAs that read the registers (the fp32 form loads ahead into fresh registers: 8 more VGPRs than
           // this form has)
           wlb[kb & 1] = as_u4(Wl[w][kb + 2][lane]);
+#ifndef YT8M_HALF_TEST   // timing experiment only (wrong results): the second half of an item's dz is never fetched -- the data flow of a K-split pair
           ring[2 * kb] = __builtin_amdgcn_raw_buffer_load_b128(dxr, lane_off, bcur + (HALF + 2 * kb) * 1024, 0);
           ring[2 * kb + 1] = __builtin_amdgcn_raw_buffer_load_b128(dxr, lane_off, bcur + (HALF + 2 * kb + 1) * 1024, 0);
+#endif
           if ((kb & 1) == 0) sc[pl] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(s, T, PH + pl), 0);
           if (kb & 1) rescale(acc, tmp, e_cur);              // the producer's six MFMAs: its tile times its rows' inverse scales
           __builtin_amdgcn_sched_barrier(0);
@@ -1493,14 +1524,35 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       pend_T = T;
     };
     struct GateIn { float gi, gj, gf, go, cp, cn, dout; bool live; };
-    auto gate_load = [&](int t1, int br, int lrow) -> GateIn {       // lrow: the row's slot in lds_nf (16 it + row of the tile)
+    // Round 6: with ONE tile per epilogue wave (n_it == 4: the headline's B = 128) a lane meets the same four (row, unit) pairs every
+    // step, so what it wrote or read the step before travels in registers instead of through memory: the running (dh, dc) of `work`
+    // (two loads + two stores per pair and step) and c_{t+1} = the c_t it read one step earlier.  Every request a CU does not make
+    // frees a slot of its 64-request vector-memory window for the dz stream (profiles/r6_pmc_recur_tcc.txt).
+#ifdef YT8M_BWD_NO_CARRY
+    const bool carry = false;
+#else
+    const bool carry = !IMG && (n_it == 4);                // (the image-writing epilogue has no registers to spare: it keeps the loads)
+#endif
+    float car_base[4] = {0.f, 0.f, 0.f, 0.f}, car_dc[4] = {0.f, 0.f, 0.f, 0.f}, car_cn[4] = {0.f, 0.f, 0.f, 0.f};
+    auto gate_load = [&](int t1, int br, int lrow, bool have_cn = false, float cnv = 0.f) -> GateIn {       // lrow: the row's slot in lds_nf (16 it + row of the tile)
       GateIn q;
+#ifdef YT8M_EPI_NOLOAD   // timing experiment only (wrong results): the epilogue's saved-activation reads never reach memory
+      q.gi = 0.5f; q.gj = 0.3f; q.gf = 0.6f; q.go = 0.4f; q.cp = 0.1f * (float)eunit; q.cn = 0.2f; q.dout = 0.01f; q.live = t1 < lds_nf[lrow];
+      return q;
+#endif
       const float* gr = a.gates + ((long long)t1 * B + br) * 4 * H + ub * 16 + eunit;
-      q.gi = gr[0]; q.gj = gr[H]; q.gf = gr[2 * H]; q.go = gr[3 * H];
       const long long idx = (long long)t1 * BH + (long long)br * H + ub * 16 + eunit;
-      q.cp = a.cs[idx];
-      q.cn = a.cs[idx + BH];
-      q.dout = a.dout ? a.dout[idx] : 0.f;
+#if defined(YT8M_EPI_LD_NT)          // experiments: cache policy of the saved-activation reads (each line is read once, from HBM)
+#define EPI_LD(p) __builtin_nontemporal_load(p)
+#elif defined(YT8M_EPI_LD_SC1)
+#define EPI_LD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define EPI_LD(p) (*(p))
+#endif
+      q.gi = EPI_LD(gr); q.gj = EPI_LD(gr + H); q.gf = EPI_LD(gr + 2 * H); q.go = EPI_LD(gr + 3 * H);
+      q.cp = EPI_LD(a.cs + idx);
+      q.cn = have_cn ? cnv : EPI_LD(a.cs + idx + BH);
+      q.dout = a.dout ? EPI_LD(a.dout + idx) : 0.f;
       q.live = t1 < lds_nf[lrow];
       return q;
     };
@@ -1515,13 +1567,22 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       dc_out = q.live ? dct * q.gf : dc;
       base_out = q.live ? 0.f : dh_in;
     };
-    auto store_std = [&](int t1, int brow, const float (&dzv)[4], float dc_out, float base_out, int half) {
+    auto store_std = [&](int t1, int brow, const float (&dzv)[4], float dc_out, float base_out, int half, bool with_work = true) {
+#ifdef YT8M_EPI_NOSTORE  // timing experiment only (wrong results): no standard-layout dz / running-state stores
+      return;
+#endif
       float* dzr = a.dz + ((long long)t1 * B + brow) * 4 * H + ub * 16 + eunit;
+#ifdef YT8M_EPI_ST_NT
+      __builtin_nontemporal_store(dzv[0], dzr); __builtin_nontemporal_store(dzv[1], dzr + H);
+      __builtin_nontemporal_store(dzv[2], dzr + 2 * H); __builtin_nontemporal_store(dzv[3], dzr + 3 * H);
+#else
       dzr[0] = dzv[0]; dzr[H] = dzv[1]; dzr[2 * H] = dzv[2]; dzr[3 * H] = dzv[3];
+#endif
       if (a.dbrows) {
         float* db = a.dbrows + (long long)brow * 4 * H + ub * 16 + eunit;
         db[0] += dzv[0]; db[H] += dzv[1]; db[2 * H] += dzv[2]; db[3 * H] += dzv[3];
       }
+      if (!with_work) return;
       float* wk = a.work + (long long)(2 * half) * BH + (long long)brow * H + ub * 16 + eunit;
       wk[0] = base_out;
       wk[BH] = dc_out;
@@ -1642,7 +1703,8 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         float dc_out, base_out;
         gate_bwd(q, dh0, dc0, dzv[r], dc_out, base_out);
         if (!valid) { dzv[r][0] = dzv[r][1] = dzv[r][2] = dzv[r][3] = 0.f; }
-        if (valid) store_std(t_hi, brow, dzv[r], dc_out, base_out, a.phase ^ 1);
+        if (valid) store_std(t_hi, brow, dzv[r], dc_out, base_out, a.phase ^ 1, !carry || a.T == 0);
+        car_base[r] = base_out; car_dc[r] = dc_out; car_cn[r] = q.cp;
       }
       publish_stores(T, 0, dzv);
       arrive();
@@ -1667,10 +1729,15 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
           brow[r] = T * 16 + 4 * rq + r;
           valid[r] = brow[r] < B;
           const int br = valid[r] ? brow[r] : B - 1;
-          const float* wk = a.work + (long long)(2 * half) * BH + (long long)br * H + ub * 16 + eunit;
-          base[r] = wk[0];
-          dc[r] = wk[BH];
-          if (!last) q[r] = gate_load(t1, br, it * 16 + 4 * rq + r);
+          if (carry) {
+            base[r] = car_base[r];
+            dc[r] = car_dc[r];
+          } else {
+            const float* wk = a.work + (long long)(2 * half) * BH + (long long)br * H + ub * 16 + eunit;
+            base[r] = wk[0];
+            dc[r] = wk[BH];
+          }
+          if (!last) q[r] = gate_load(t1, br, it * 16 + 4 * rq + r, carry, car_cn[r]);
         }
         lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(gen + 1), a.ctl);
         STAMP(1);
@@ -1686,7 +1753,11 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         if (last) {                                       // dL/dh_{t_lo - 1}: handed to the caller (next chunk / initial state)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (valid[r]) a.work[(long long)(2 * half) * BH + (long long)brow[r] * H + ub * 16 + eunit] = base[r] + p[r];
+            if (valid[r]) {
+              float* wk = a.work + (long long)(2 * half) * BH + (long long)brow[r] * H + ub * 16 + eunit;
+              wk[0] = base[r] + p[r];
+              if (carry) wk[BH] = dc[r];                    // (the carried form never stored it on the way)
+            }
           }
           continue;
         }
@@ -1701,8 +1772,10 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         arrive();                                         // drain + arrival: nothing else of this wave is waiting behind it
         STAMP(4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (valid[r]) store_std(t1, brow[r], dzv[r], dc_out[r], base_out[r], half ^ 1);
+        for (int r = 0; r < 4; ++r) {
+          if (valid[r]) store_std(t1, brow[r], dzv[r], dc_out[r], base_out[r], half ^ 1, !carry);
+          car_base[r] = base_out[r]; car_dc[r] = dc_out[r]; car_cn[r] = q[r].cp;
+        }
         emit_images(t1, T, dzv);
         emit_rowmax(t1, T, dzv);
       }

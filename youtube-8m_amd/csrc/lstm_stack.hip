@@ -1,5 +1,5 @@
 // lstm_stack.hip -- the whole MultiRNNCell([BasicLSTMCell] * L) under tf.nn.dynamic_rnn as TWO library calls (forward, backward):
-// W/all_frame_models/lstm_model.py:34-47 (lstm_memory_model.py:36-52 without its DropoutWrapper) and the gradient tf.gradients
+// W/all_frame_models/lstm_model.py:34-47 (lstm_memory_model.py:36-52, its DropoutWrapper included since round 6) and the gradient tf.gradients
 // builds through them (W/train.py:435-466), SURVEY.md section 8(b) last row, VERDICT r2 #9.
 //
 // Everything the measured headline step does for its recurrent stack lives here, behind the C ABI: the time partition (one
@@ -76,6 +76,8 @@ struct Plan {
   int64_t hsc;                                             // ... their device-side scale words: 256 B per layer
   int64_t hx0;                                             // ... and the float input's
   int64_t hrow, hrow_stride;                               // ... per-row scales of dz for dx (S then 1 / S), per layer
+  float keep;                                              // DropoutWrapper(input_keep_prob) around every layer (0: none); round 6
+  uint64_t seed[MAXL];
   int emit_max;                                            // the backward recurrences measure max |dz| per frame row and per part themselves
   int64_t rmax, rmax_stride;                               // ... [F B] words per layer
   int64_t cimg[MAXL], cimgs;                               // their column-sum partials: [img_rows x launches][4H] per layer
@@ -195,6 +197,14 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // form (a time step whose gradient has decayed by 2^-15 against the part's largest would lose precision under one scale per part),
   // and so does layer 0 (its uint8 products are three-product forms already).  YT8M_STACK_H2=0 keeps every product on the bf16 split.
   p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16) ? 1 : 0;
+  // DropoutWrapper(cell, input_keep_prob) (W/all_frame_models/lstm_memory_model.py:36-44): the mask is applied where each layer's operand
+  // images are built (yt8m_h2_split_dropout) and replayed on dx -- f16 product forms on a float input only; keep >= 0.3 keeps the
+  // dropped operands (x / keep) inside the half range under the scales measured on the undropped ones
+  p.keep = (d->input_keep_prob > 0.f && d->input_keep_prob < 1.f) ? d->input_keep_prob : 0.f;
+  for (int l = 0; l < MAXL; ++l) p.seed[l] = d->dropout_seed[l];
+  if (d->input_keep_prob < 0.f || d->input_keep_prob > 1.f) return "input_keep_prob must be in [0, 1]";
+  if (p.keep > 0.f && (p.u8 || !p.h2 || p.keep < 0.3f || (p.D % 4) != 0 || (p.H % 4) != 0))
+    return "input dropout: float input, f16 product forms (YT8M_STACK_H2), keep_prob >= 0.3, D % 4 == 0";
   p.img_rows = (knob("YT8M_STACK_FUSED_IMAGES", 0) && !p.bf16 && !p.h2) ? yt8m_lstm_persist_bwd_images_rows(p.B, p.H) : 0;
   const int64_t trows = p.img_rows ? p.FB : bmax;
   for (int l = 0; l < p.L; ++l) { p.dzT3[l] = o; o += up256(ib(H4, trows)); }
@@ -537,6 +547,9 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
         yt8m_gemm_problem pr = {M, H4, Din, at<char>(scratch, P.xi[l]), 0, wxt_img[l], 0, zc, H4, b[l], 0.0f};
         int grc;
         if (P.h2 && l >= 1) {                                // |out_{l-1}| < 1: static scale 2^13; the weights' inverse scale from the device
+          if (P.keep > 0.f)                                  // DropoutWrapper: the image of tf.nn.dropout(out_{l-1}); |x / keep| < 4: 2^15 under 2^13
+            RC(yt8m_h2_split_dropout(src, M, Din, H2_S, nullptr, at<char>(scratch, P.xi[l]), nullptr, P.keep, P.seed[l], t0 * B * Din, (yt8m_stream_t)s));
+          else
           RC(yt8m_h2_split(src, M, Din, Din, H2_S, nullptr, at<char>(scratch, P.xi[l]), nullptr, nullptr, (yt8m_stream_t)s));
           const float alpha = 1.0f / H2_S;
           const float* dsb = at<float>(scratch, P.hsc + 256 * l);
@@ -544,6 +557,9 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
         } else if (P.h2) {                                   // float input: both operands under device-measured scales
           const float* dsa = at<float>(scratch, P.hx0);
           const float* dsb = at<float>(scratch, P.hsc);
+          if (P.keep > 0.f)
+            RC(yt8m_h2_split_dropout(src, M, Din, 1.0f, dsa, at<char>(scratch, P.xi[0]), nullptr, P.keep, P.seed[0], t0 * B * Din, (yt8m_stream_t)s));
+          else
           RC(yt8m_h2_split(src, M, Din, Din, 1.0f, dsa, at<char>(scratch, P.xi[0]), nullptr, nullptr, (yt8m_stream_t)s));
           const float alpha = 1.0f;
           grc = yt8m_gemm_h2_nt_grouped(1, &pr, &alpha, &dsa, &dsb, gw, P.gws_bytes, (yt8m_stream_t)s);
@@ -626,7 +642,10 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     } else {
       const float* src = l ? at<float>(tape, P.out[l - 1]) : static_cast<const float*>(x);
       const int64_t Din = l ? H : D;
-      if (P.h2 && l >= 1) RC(yt8m_h2_split(src, FB, Din, Din, H2_S, nullptr, nullptr, at<char>(scratch, P.xT[l]), nullptr, (yt8m_stream_t)sw));
+      if (P.h2 && P.keep > 0.f)                            // dW_x = dropout(x)^T . dz: the mask of the forward pass, replayed
+        RC(yt8m_h2_split_dropout(src, FB, Din, l ? H2_S : 1.0f, l ? nullptr : at<float>(scratch, P.hx0), nullptr, at<char>(scratch, P.xT[l]),
+                                 P.keep, P.seed[l], 0, (yt8m_stream_t)sw));
+      else if (P.h2 && l >= 1) RC(yt8m_h2_split(src, FB, Din, Din, H2_S, nullptr, nullptr, at<char>(scratch, P.xT[l]), nullptr, (yt8m_stream_t)sw));
       else if (P.h2) RC(yt8m_h2_split(src, FB, Din, Din, 1.0f, at<float>(scratch, P.hx0), nullptr, at<char>(scratch, P.xT[0]), nullptr, (yt8m_stream_t)sw));
       else RC(split(src, FB, Din, Din, 1.0f, nullptr, at<char>(scratch, P.xT[l]), sw));
     }
@@ -783,6 +802,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
           float* dst = at<float>(scratch, P.dbuf[l - 1]) + t0 * B * H;
           RC(yt8m_gemm_h2_nt_ex(M, Din, H4, at<char>(scratch, P.dz3[l]), 0, at<char>(scratch, P.wx3[l]), 0, dst, Din, nullptr, 1.0f, nullptr,
                                 wword, rI, 0.0f, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, (yt8m_stream_t)sx));
+          if (P.keep > 0.f)                                  // d dropout(x) / dx: the same mask on the gradient, in place
+            RC(yt8m_dropout_f32(dst, dst, M * Din, P.keep, P.seed[l], t0 * B * Din, (yt8m_stream_t)sx));
           dx_ev = ev.record(sx);
           if (c == 0 && j == 0) last.push_back(dx_ev);
         } else {
@@ -804,6 +825,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         const int grc = gemm(1, &pr, at<char>(scratch, dx_stream ? P.gwx[l] : P.gws[l]), P.gws_bytes, sx);
         yt8m_x3_set_combine(0);
         RC(grc);
+        if (P.keep > 0.f) RC(yt8m_dropout_f32(dst, dst, M * Din, P.keep, P.seed[l], t0 * B * Din, (yt8m_stream_t)sx));
         dx_ev = ev.record(sx);
         if (c == 0 && j == 0) last.push_back(dx_ev);
         }

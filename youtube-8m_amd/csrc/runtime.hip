@@ -130,7 +130,7 @@ static void drain() {
 // ABI 2 (round 3 changes): the persistent-recurrence workspace starts with a sticky error word the host zeroes once
 // (control block 128 B further in, yt8m_lstm_persist_workspace_bytes larger), yt8m_lstm_persist_status clears the word it reads,
 // yt8m_gemm_problem.lda / ldb of the image products are K-block strides (0 = dense).  Round 4 adds entry points only.
-extern "C" int yt8m_abi_version(void) { return 3; }
+extern "C" int yt8m_abi_version(void) { return 4; }
 extern "C" const char* yt8m_last_error(void) { return yt8m::g_err; }
 extern "C" const char* yt8m_built_arch(void) { return "gfx950"; }
 

@@ -111,8 +111,14 @@ def _x3_wins(shapes, transA=False, transB=False):
     return bool(shapes) and all(_lib.lib().yt8m_gemm_x3_pays(int(M), int(N), int(K)) for M, N, K in shapes)
 
 
-def gemm_grouped(items, transA=False, transB=False):
+GEMM_ROLE_DW = 0x100          # include/yt8m_hip.h YT8M_GEMM_ROLE_DW
+
+
+def gemm_grouped(items, transA=False, transB=False, role=None):
     """items: list of dicts(A=, B=, out=None, bias=None, beta=0.0) sharing transA/transB -> list of outputs.
+    role="dw" DECLARES the products weight gradients x^T . dz (transA, neither operand a weight): the library may then run them as
+    three f16 products under one device-measured scale per operand (the "h2" contract of include/yt8m_hip.h); without it a
+    product keeps the six-product / fp32 forms whatever its transposition flags.
     fp32 operands either way; the library picks the kernel per product (yt8m_gemm_auto_grouped: large products run as six bf16
     MFMA products of three-plane split operands -- fp32-grade error at twice the rate --, the rest on the fp32 MFMA kernel) and
     groups the launches; the operand images live in a scratch tensor sized by the library's own query."""
@@ -123,6 +129,9 @@ def gemm_grouped(items, transA=False, transB=False):
         probs.append(pr)
         outs.append(out)
         keep.append(k)
+    if role not in (None, "dw"):
+        raise ValueError("role must be None or 'dw'")
+    ta = int(bool(transA)) | (GEMM_ROLE_DW if (role == "dw" and transA and not transB) else 0)
     ws = _workspace(outs[0].device)
     lib = _lib.lib()
     for lo in range(0, len(probs), 64):
@@ -133,15 +142,15 @@ def gemm_grouped(items, transA=False, transB=False):
                 sub = (_lib.GemmProblem * len(part[i:i + 4]))(*part[i:i + 4])
                 _lib.check(lib.yt8m_gemm_f32_grouped(int(transA), int(transB), len(part[i:i + 4]), sub, _p(ws), ws.numel() * 4, _stream()))
             continue
-        nb = lib.yt8m_gemm_auto_scratch_bytes(int(transA), int(transB), len(part), arr)
+        nb = lib.yt8m_gemm_auto_scratch_bytes(ta, int(transB), len(part), arr)
         img = torch.empty(nb, dtype=torch.uint8, device=outs[0].device) if nb else None
-        _lib.check(lib.yt8m_gemm_auto_grouped(int(transA), int(transB), len(part), arr, _p(ws), ws.numel() * 4, _p(img), nb, None, _stream()))
+        _lib.check(lib.yt8m_gemm_auto_grouped(ta, int(transB), len(part), arr, _p(ws), ws.numel() * 4, _p(img), nb, None, _stream()))
     return outs
 
 
-def gemm(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
-    """out[M,N] = op(A) . op(B) (+ bias) (+ out if beta == 1), through the persistent scheduler."""
-    return gemm_grouped([dict(A=A, B=B, out=out, bias=bias, beta=beta)], transA, transB)[0]
+def gemm(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0, role=None):
+    """out[M,N] = op(A) . op(B) (+ bias) (+ out if beta == 1), through the persistent scheduler (role: see gemm_grouped)."""
+    return gemm_grouped([dict(A=A, B=B, out=out, bias=bias, beta=beta)], transA, transB, role=role)[0]
 
 
 def gemm_simple(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0):
@@ -171,13 +180,13 @@ def cast_bf16(x, transpose=False):
     return out
 
 
-def gemm_any(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0, bf16=False):
+def gemm_any(A, B, out=None, transA=False, transB=False, bias=None, beta=0.0, bf16=False, role=None):
     """C = op(A) . op(B) (+ bias) (+ C); bf16=True takes bf16 copies of both operands (each cast into the K-contiguous layout the
     NT kernel wants) when the product is large enough to pay for the two cast passes, fp32 accumulate / output either way."""
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
     N = B.shape[0] if transB else B.shape[1]
     if not (bf16 and _use_bf16(True, M, N, K, weight_operand=False) and K >= 32):
-        return gemm(A, B, out=out, transA=transA, transB=transB, bias=bias, beta=beta)
+        return gemm(A, B, out=out, transA=transA, transB=transB, bias=bias, beta=beta, role=role)
     Ab = cast_bf16(A, transpose=transA)                # op(A)   [M, K]
     Bb = cast_bf16(B, transpose=not transB)            # op(B)^T [N, K]
     return gemm_bf16_nt_grouped([dict(A=Ab, B=Bb, out=out, bias=bias, beta=beta)])[0]
@@ -842,7 +851,7 @@ class _Linear(torch.autograd.Function):
                 gemm_bf16_nt_grouped([dict(A=cast_bf16(x, transpose=True), B=dyT, out=W.grad, beta=W.grad_beta())])
                 del dyT
             else:
-                gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta())
+                gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta(), role="dw")
         if b is not None and b.trainable and b.grad is not None:
             colsum(dy, b.grad.view(-1), beta=b.grad_beta())
         dx = None
@@ -943,7 +952,7 @@ class _LinearCat(torch.autograd.Function):
                 if dyg is None:
                     dyg = dy.view(-1, rep, N).sum(dim=1)              # [M / rep, N]
                 if wbeta is not None:
-                    gemm(p, dyg, out=W.grad[k0:k0 + K], transA=True, beta=wbeta)
+                    gemm(p, dyg, out=W.grad[k0:k0 + K], transA=True, beta=wbeta, role="dw")
                 dxs.append(gemm(dyg, Wi, transB=True) if need_dx else None)
             else:
                 sk = skinny_ok(M, K, N, p, dy)
@@ -951,7 +960,7 @@ class _LinearCat(torch.autograd.Function):
                     if sk:
                         skinny_dw(p, dy, W.grad[k0:k0 + K], beta=wbeta)
                     else:
-                        gemm(p, dy, out=W.grad[k0:k0 + K], transA=True, beta=wbeta)
+                        gemm(p, dy, out=W.grad[k0:k0 + K], transA=True, beta=wbeta, role="dw")
                 dxs.append((skinny_dx(dy, Wi) if sk else gemm(dy, Wi, transB=True)) if need_dx else None)
             k0 += K
         if wbeta is not None:
@@ -1325,7 +1334,7 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
             t.record_stream(side)                  # (their memory must not be handed out again before the side stream is done)
         bw, bwe, bbe = Wg.grad_beta(), We.grad_beta(), be.grad_beta()
         with torch.cuda.stream(side):
-            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw), dict(A=x, B=Ze, out=We.grad, beta=bwe)], transA=True)
+            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw), dict(A=x, B=Ze, out=We.grad, beta=bwe)], transA=True, role="dw")
             colsum(Ze, be.grad.view(-1), beta=bbe)
         if not hasattr(g, "side_pending") or g.side_pending is None:
             g.side_pending = []
@@ -1336,14 +1345,14 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
         return dx
     if Wg.grad is not None and We.grad is not None and not overlap:
         gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
-                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True)
+                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True, role="dw")
         Wg.grad_done()
         We.grad_done()
     elif Wg.grad is not None and We.grad is not None:
         # data-parallel: finish the big gate gradient first so its all-reduce rides under the expert GEMM
-        gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta())
+        gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta(), role="dw")
         Wg.grad_done()
-        gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta())
+        gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta(), role="dw")
         We.grad_done()
     if be.grad is not None:
         colsum(Ze, be.grad.view(-1), beta=be.grad_beta())

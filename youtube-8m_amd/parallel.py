@@ -153,13 +153,42 @@ def _rsag_torch(t, group):
 
 
 DP_ALGO = os.environ.get("YT8M_DP_ALGO", "allreduce")              # "allreduce" | "rs_ag"
-# CU headroom of the persistent recurrences for RCCL's kernels (0: none).  Measured on one MI355X with a 1-rank RCCL group
-# (profiles/r3_force_reducer.md): 32 reserved CUs chain the half-chip backward recurrences one at a time, +2.0 ms on a 24.4 ms step;
-# without a reserve a recurrence launched while a collective's kernels hold CUs spins on the part of its grid that is resident
-# until they leave -- bounded, never a deadlock (tests/test_gpu_round3.py::test_persistent_recurrences_next_to_a_cu_hogging_kernel).
-# The head's all-reduce (386 MB, launched ~0.3 ms into the backward pass) mostly runs beside the first, lone, half-chip recurrence,
-# so the default keeps the side-by-side schedule; set 32 on a node where the collectives are slow enough to collide with it.
-DP_RESERVED_CUS = int(os.environ.get("YT8M_DP_RESERVED_CUS", "0"))
+# CU headroom of the persistent recurrences for RCCL's kernels.  A reserve of R CUs makes the half-chip backward recurrences of the two
+# layers run one at a time instead of side by side (they no longer both fit): +2.0 ms on the 24 ms step of round 3, +2.7 ms on round 6's
+# 16 ms step (profiles/r6_force_reducer.md: 20.8 against 18.0 ms with an 8-GPU all-reduce's footprint emulated).  Without a reserve a recurrence launched while a collective's kernels hold CUs spins on the
+# part of its grid that is resident until they leave -- bounded, never a deadlock (the collective never waits for a recurrence;
+# tests/test_gpu_round3.py::test_persistent_recurrences_next_to_a_cu_hogging_kernel) -- so the price of NO reserve is the time a
+# collective is still on the wire when the side-by-side phase of the backward pass begins.
+#   YT8M_DP_RESERVED_CUS = <int>  : that many CUs, always
+#   YT8M_DP_RESERVED_CUS = auto   : (default) chosen by auto_reserve_cus() from the size of the first large bucket, the world size and an
+#                                   assumed bus bandwidth: the reserve is taken only when the collision it avoids costs more than it does
+_RES = os.environ.get("YT8M_DP_RESERVED_CUS", "auto")
+DP_RESERVED_CUS = None if _RES == "auto" else int(_RES)
+DP_BUSBW_GBPS = float(os.environ.get("YT8M_DP_BUSBW_GBPS", "300"))       # all-reduce bus bandwidth assumed by the auto rule (8 x MI355X over
+                                                                          # xGMI; no N > 1 measurement of this build exists: an assumption)
+# measured on one MI355X (profiles/r6_force_reducer.md): the head's bucket is enqueued ~0.3 ms into the backward pass and the first
+# side-by-side pair of recurrences starts ~1.9 ms later; chaining the recurrences (any reserve > 0) costs ~2.7 ms per step
+DP_LONE_WINDOW_MS = float(os.environ.get("YT8M_DP_LONE_WINDOW_MS", "1.9"))
+DP_RESERVE_COST_MS = float(os.environ.get("YT8M_DP_RESERVE_COST_MS", "2.7"))
+DP_RCCL_CUS = int(os.environ.get("YT8M_DP_RCCL_CUS", "32"))              # CUs an RCCL all-reduce of a large message holds (channels)
+
+
+def allreduce_ms(nbytes, world, busbw_gbps=None):
+    """Ring all-reduce time of nbytes on `world` ranks at a bus bandwidth: 2 (N - 1) / N x bytes / busbw."""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (world - 1) / world * nbytes / ((busbw_gbps or DP_BUSBW_GBPS) * 1e9) * 1e3
+
+
+def auto_reserve_cus(world, early_bucket_bytes, persistent_recurrences=True):
+    """CUs the persistent recurrences should leave to RCCL.  0 at world 1 and for graphs without persistent recurrences.  Otherwise
+    the collective of the gradients that are final when the backward pass of the recurrent stack begins (the head: `early_bucket_bytes`)
+    runs beside the first, lone, half-chip recurrence; what is still on the wire when the two layers' recurrences start running side
+    by side delays one of them by that remainder.  Reserve only if that remainder exceeds what chaining the recurrences costs."""
+    if world <= 1 or not persistent_recurrences:
+        return 0
+    collision_ms = max(0.0, allreduce_ms(early_bucket_bytes, world) - DP_LONE_WINDOW_MS)
+    return DP_RCCL_CUS if collision_ms > DP_RESERVE_COST_MS else 0
 
 
 class GradReducer(object):
@@ -176,8 +205,18 @@ class GradReducer(object):
         self.algo = algo or DP_ALGO
         if self.algo not in ("allreduce", "rs_ag"):
             raise ValueError("algo must be 'allreduce' or 'rs_ag'")
-        self.reserve_cus = DP_RESERVED_CUS if reserve_cus is None else int(reserve_cus)
+        self.reserve_cus = DP_RESERVED_CUS if reserve_cus is None else int(reserve_cus)     # None: chosen in attach() (auto rule)
+        self.reserve_rule = None
         self._prev_reserve = None
+        # YT8M_DP_EMULATE="cus:world[:busbw]" (bench.py --force-reducer on ONE GPU): every bucket's collective is followed on the
+        # collective's timeline by a kernel that holds `cus` CUs for the time a `world`-rank ring all-reduce of the bucket would take
+        # at the bus bandwidth -- the footprint a 1-rank RCCL group does not have.  Measurement aid only (profiles/r6_force_reducer.md).
+        self.emulate = None
+        emu = os.environ.get("YT8M_DP_EMULATE")
+        if emu:
+            f = emu.split(":")
+            self.emulate = (int(f[0]), int(f[1]), float(f[2]) if len(f) > 2 else DP_BUSBW_GBPS)
+        self._emu_stream = self._emu_out = None
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
@@ -208,6 +247,17 @@ class GradReducer(object):
         nv = len(graph.trainable_variables())
         self._ready = [False] * nv
         self._launched = [False] * nv
+        if self.reserve_cus is None:
+            # auto: from the gradients that are final when a recurrent stack's backward pass starts (everything behind the last
+            # recurrent variable in creation order = the head); graphs without persistent recurrences get 0
+            tv = graph.trainable_variables()
+            rec = [i for i, v in enumerate(tv) if "lstm_cell" in v.name or "/RNN/" in v.name or v.name.startswith("RNN/")]
+            early = sum(v.numel() * 4 for v in tv[max(rec) + 1:]) if rec else 0
+            w_eff = self.emulate[1] if (self.emulate and self.world == 1) else self.world
+            self.reserve_cus = auto_reserve_cus(w_eff if self.active else 1, early, bool(rec))
+            self.reserve_rule = {"rule": "auto", "early_bucket_MB": early / 1e6, "world": w_eff, "busbw_GBps": DP_BUSBW_GBPS,
+                                 "allreduce_ms": allreduce_ms(early, w_eff), "lone_window_ms": DP_LONE_WINDOW_MS,
+                                 "reserve_cost_ms": DP_RESERVE_COST_MS, "chosen": self.reserve_cus}
         if self.active and self.reserve_cus > 0 and torch.cuda.is_available():
             import ctypes
             from . import _lib
@@ -312,11 +362,32 @@ class GradReducer(object):
                     else:
                         hs.append(dist.all_reduce(self.graph.grads[pos:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     pos = end
+                if self.emulate is not None and torch.cuda.is_available():
+                    hs.append(self._emulate_footprint((hi - lo) * 4, hs))
                 self._trace_launch(lo, hi, hs)
                 self._handles.append((i, j + 1, hs))      # trainable variables [i, j+1) ride on these handles
                 for k in range(i, j + 1):
                     self._launched[k] = True
             i = j + 1
+
+    def _emulate_footprint(self, nbytes, hs):
+        """A kernel holding emulate[0] CUs for the ring all-reduce time of nbytes on emulate[1] ranks, behind the bucket's real
+        (1-rank) collective on a side stream; returns a handle the optimiser pass of the bucket waits for."""
+        import ctypes
+        from . import _lib
+        cus, world, busbw = self.emulate
+        if self._emu_stream is None:
+            self._emu_stream = torch.cuda.Stream()
+            self._emu_out = torch.zeros(2 * 1024, dtype=torch.int32, device="cuda")
+        ms = allreduce_ms(nbytes, world, busbw)
+        with torch.cuda.stream(self._emu_stream):
+            for h in hs:
+                h.wait()                                         # behind the real collective (stream order of the side stream)
+            _lib.check(_lib.lib().yt8m_probe_placement(ctypes.c_void_p(self._emu_out.data_ptr()), int(cus), int(ms * 1e5),
+                                                       ctypes.c_void_p(self._emu_stream.cuda_stream)))     # wall clock: 100 MHz
+            ev = torch.cuda.Event()
+            ev.record(self._emu_stream)
+        return _CabiHandle(ev)
 
     def finished_buckets(self):
         """Yields (lo, hi) ranges of trainable-variable indices in the order their all-reduces were launched, each

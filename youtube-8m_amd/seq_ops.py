@@ -63,8 +63,8 @@ class _LstmLayer(torch.autograd.Function):
         dz2 = dz.view(F * B, 4 * H)
         if W.grad is not None:
             beta = W.grad_beta()
-            ops.gemm(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=beta)
-            ops.gemm(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=beta)
+            ops.gemm(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=beta, role="dw")
+            ops.gemm(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=beta, role="dw")
             W.grad_done()
         if b.grad is not None:
             ops.colsum(dz2, b.grad.view(-1), beta=b.grad_beta())
@@ -134,13 +134,13 @@ class _GruLayer(torch.autograd.Function):
         bf = ctx.bf16
         if Wg.grad is not None:
             beta = Wg.grad_beta()
-            ops.gemm_any(x2, g2, out=Wg.grad[:Din], transA=True, beta=beta, bf16=bf)
-            ops.gemm_any(hs[:F].view(F * B, H), g2, out=Wg.grad[Din:], transA=True, beta=beta, bf16=bf)
+            ops.gemm_any(x2, g2, out=Wg.grad[:Din], transA=True, beta=beta, role="dw", bf16=bf)
+            ops.gemm_any(hs[:F].view(F * B, H), g2, out=Wg.grad[Din:], transA=True, beta=beta, role="dw", bf16=bf)
             Wg.grad_done()
         if Wc.grad is not None:
             beta = Wc.grad_beta()
-            ops.gemm_any(x2, c2, out=Wc.grad[:Din], transA=True, beta=beta, bf16=bf)
-            ops.gemm_any(rh.view(F * B, H), c2, out=Wc.grad[Din:], transA=True, beta=beta, bf16=bf)
+            ops.gemm_any(x2, c2, out=Wc.grad[:Din], transA=True, beta=beta, role="dw", bf16=bf)
+            ops.gemm_any(rh.view(F * B, H), c2, out=Wc.grad[Din:], transA=True, beta=beta, role="dw", bf16=bf)
             Wc.grad_done()
         if bg.grad is not None:
             ops.colsum(g2, bg.grad.view(-1), beta=bg.grad_beta())
@@ -218,8 +218,8 @@ class _LnLstmLayer(torch.autograd.Function):
         dz2 = dz.view(F * B, 4 * H)
         if W.grad is not None:
             b = W.grad_beta()
-            ops.gemm_any(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=b, bf16=ctx.bf16)
-            ops.gemm_any(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=b, bf16=ctx.bf16)
+            ops.gemm_any(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=b, role="dw", bf16=ctx.bf16)
+            ops.gemm_any(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=b, role="dw", bf16=ctx.bf16)
             W.grad_done()
         yb, yg = dyb.view(F * B, 5 * H), dyg.view(F * B, 5 * H)
         for k in range(5):
@@ -406,6 +406,7 @@ REC_BF16 = _os.environ.get("YT8M_REC_BF16", "1") != "0"       # compute_dtype=bf
 
 
 NATIVE_STACK = _os.environ.get("YT8M_LSTM_STACK_NATIVE", "1") != "0"   # whole stack behind yt8m_lstm_stack_fwd / _bwd (csrc/lstm_stack.hip)
+NATIVE_DROPOUT = _os.environ.get("YT8M_NATIVE_DROPOUT", "1") != "0"   # DropoutWrapper inside yt8m_lstm_stack_fwd / _bwd (round 6)
 _STACK_SCRATCH = {}   # (device, calling stream, description) -> zero-initialised scratch of the native stack (resident, like _PERSIST_WS)
 NATIVE_CALLS = {"fwd": 0, "bwd": 0}     # how often the native path ran (tests assert that it engaged)
 
@@ -417,20 +418,26 @@ NATIVE_CALLS = {"fwd": 0, "bwd": 0}     # how often the native path ran (tests a
 NATIVE_BF16 = _os.environ.get("YT8M_LSTM_STACK_BF16", "1") != "0"
 
 
-def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx, bf16=False):
+def _stack_desc(B, F, D, H, L, u8, forget_bias, need_dx, bf16=False, keep_prob=None, seeds=None):
     # 0 = the library's own partition (csrc/lstm_stack.hip: one forward launch per layer, three unequal backward parts) unless the
     # environment / a test names a number of parts
     fwd = PERSIST_FWD_CHUNKS if (PERSIST_FWD_CHUNKS != 1 or "YT8M_LSTM_PERSIST_FWD_CHUNKS" in _os.environ) else 0
     bwd = PERSIST_BWD_CHUNKS if (PERSIST_BWD_CHUNKS != 3 or "YT8M_LSTM_PERSIST_BWD_CHUNKS" in _os.environ) else 0
-    return _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)) | (2 if bf16 else 0), float(forget_bias), int(fwd),
-                              int(bwd), int(bool(need_dx)))                    # input_u8: bit 0 uint8 frames, bit 1 bf16 operand images
+    d = _lib.LstmStackDesc(int(B), int(F), int(D), int(H), int(L), int(bool(u8)) | (2 if bf16 else 0), float(forget_bias), int(fwd),
+                           int(bwd), int(bool(need_dx)))                       # input_u8: bit 0 uint8 frames, bit 1 bf16 operand images
+    if keep_prob is not None and float(keep_prob) < 1.0:                       # DropoutWrapper(input_keep_prob) inside the stack (ABI 4)
+        d.input_keep_prob = float(keep_prob)
+        for l, sd in enumerate(list(seeds)[:8]):
+            d.dropout_seed[l] = int(sd) & 0xFFFFFFFFFFFFFFFF
+    return d
 
 
 def _stack_scratch(dev, main, desc):
     # (the size is part of the key: the library's layout depends on its knobs too -- a test that flips YT8M_STACK_H2 in-process must
     # not be handed the other layout's buffer)
     need = _lib.lib().yt8m_lstm_stack_scratch_bytes(ctypes.byref(desc))
-    key = (dev.index, main.cuda_stream, need) + tuple(getattr(desc, f) for f, _ in desc._fields_ if f != "forget_bias")
+    key = (dev.index, main.cuda_stream, need) + tuple(getattr(desc, f) for f, _ in desc._fields_
+                                                      if f not in ("forget_bias", "input_keep_prob", "reserved0", "dropout_seed"))
     ent = _STACK_SCRATCH.get(key)
     if ent is not None:
         _STACK_SCRATCH[key] = _STACK_SCRATCH.pop(key)                # least recently USED goes first (dicts keep insertion order)
@@ -601,11 +608,17 @@ class _LstmStack(torch.autograd.Function):
         # tuning knobs) keeps the orchestration below, built from the same per-call entry points.
         drop_ = input_keep_prob is not None and float(input_keep_prob) < 1.0
         nat_ok = pers and _os.environ.get("YT8M_PERSIST_CUS") is None and (not bf16 or NATIVE_BF16)
-        if (NATIVE_STACK and nat_ok and X3 and PERSIST_BWD and PERSIST_STEP_IMAGES and not drop_ and not FWD_WAVEFRONT and
+        # (round 6: DropoutWrapper(input_keep_prob) stays on the native stack -- the mask is applied where the operand images are built,
+        # csrc/lstm_stack.hip -- for a float input on the f16 product forms; yt8m_lstm_stack_supported refuses the rest and the
+        # orchestration below takes over.  YT8M_NATIVE_DROPOUT=0 keeps dropout on the orchestration.)
+        u8_in = x_tm.dtype == torch.uint8
+        drop_native = drop_ and NATIVE_DROPOUT and not u8_in and not bf16 and L <= 8
+        if (NATIVE_STACK and nat_ok and X3 and PERSIST_BWD and PERSIST_STEP_IMAGES and (not drop_ or drop_native) and not FWD_WAVEFRONT and
                 PERSIST_FWD_CHUNKS > 0 and PERSIST_BWD_CHUNKS > 0 and BWD_CHUNKS == 0 and not BWD_PARTS and len(set(Hs)) == 1):
             u8 = x_tm.dtype == torch.uint8
             D0 = x_tm.shape[2]
-            desc = _stack_desc(B, F, D0, Hs[0], L, u8, forget_bias, (not u8) and bool(ctx.needs_input_grad[0]), bf16=bool(bf16))
+            desc = _stack_desc(B, F, D0, Hs[0], L, u8, forget_bias, (not u8) and bool(ctx.needs_input_grad[0]), bf16=bool(bf16),
+                               keep_prob=input_keep_prob if drop_ else None, seeds=seeds if drop_ else None)
             if (u8 or x_tm.dtype == torch.float32) and wb[0].data.shape[0] == D0 + Hs[0] and lib.yt8m_lstm_stack_supported(ctypes.byref(desc)):
                 return _LstmStack._native_forward(ctx, lib, desc, x_tm, nf, wb)
         if own and PERSIST_FWD_CHUNKS > 0:
@@ -1015,8 +1028,8 @@ class _LstmStack(torch.autograd.Function):
                             ops.gemm_x3_grouped([dict(A=xT3, B=dzT3, out=W.grad[:Din], beta=beta),
                                                  dict(A=hT3, B=dzT3, out=W.grad[Din:], beta=beta)])
                         else:
-                            ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta)
-                            ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta)
+                            ops.gemm(st["x"][t0:t0 + T].view(T * B, Din), dzc, out=W.grad[:Din], transA=True, beta=beta, role="dw")
+                            ops.gemm(st["hs"][t0:t0 + T].view(T * B, H), dzc, out=W.grad[Din:], transA=True, beta=beta, role="dw")
                     if b.grad is not None and ("dbrows" not in st or c == 0):
                         beta = wbeta.get(id(b))
                         if beta is None:
@@ -1248,7 +1261,7 @@ class _AttnLogitsU8(torch.autograd.Function):
             ws = ops._workspace(q.device)
             _lib.check(_lib.lib().yt8m_skinny_dw_u8(_p(q), D, _p(dy), N, _p(rs), _p(gx), gx.stride(0), B * F, D, N, float(wbeta),
                                                     _p(ws), ws.numel() * 4, _stream()))
-            ops.gemm(mean_x, dy.view(B, F, N).sum(dim=1), out=W.grad[D:], transA=True, beta=wbeta)
+            ops.gemm(mean_x, dy.view(B, F, N).sum(dim=1), out=W.grad[D:], transA=True, beta=wbeta, role="dw")
             W.grad_done()
         if b is not None and b.trainable and b.grad is not None:
             ops.colsum(dy, b.grad.view(-1), beta=b.grad_beta())
