@@ -619,7 +619,10 @@ int yt8m_lstm_persist_fwd_bf16(float* z, const float* Wh, int64_t ldw, float* cs
 /* backward: steps t0+T-1 down to t0; (gates, cs, dout, dz, work, phase) exactly as yt8m_lstm_steps_bwd.  The backward of
  * dynamic_rnn's while_loop (tf.gradients through W/all_frame_models/lstm_model.py:44-47).  dbias_rows (may be NULL):
  * [B,4H] running sums of dz over the processed steps, accumulated IN PLACE (zero it before the first chunk); the bias
- * gradient is its column sum -- saves the pass over the whole [F*B,4H] dz. */
+ * gradient is its column sum -- saves the pass over the whole [F*B,4H] dz.
+ * work (round 6): a persistent launch reads the running (dh, dc) from the half `phase` names and leaves them in the half of
+ * (phase + T) % 2 when it ends; the other half is scratch -- with one 16-row tile per epilogue wave the steps in between carry the
+ * state in registers and do not touch it. */
 /* Round 5: yt8m_lstm_persist_fwd with the recurrent product h_{t-1} . W_h (BasicLSTMCell._linear under dynamic_rnn,
  * W/all_frame_models/lstm_model.py:34-47) as THREE f16 products of two-half-plane splits instead of six bf16 products of three-plane splits:
  * the same fp32 grade, half the matrix instructions, 4 instead of 6 exchanged bytes per state element.  wh_absmax: device word with

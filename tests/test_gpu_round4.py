@@ -58,7 +58,11 @@ def test_recurrence_written_images_equal_the_split_pass_bit_for_bit(dev, scaled)
                             cp.data_ptr(), cps.data_ptr() if scaled else None)
     dz_i, work_i = run(im)
     dz_r, work_r = run(None)
-    assert torch.equal(dz_i, dz_r) and torch.equal(work_i, work_r)            # the images change nothing else
+    # the images change nothing else: dz, and the (dh, dc) the launch hands to the next one -- the half of `work` its last step writes
+    # (phase 0 + T steps).  (Round 6: the plain launch carries the running state in registers and no longer writes the OTHER half on the
+    # way; the image-writing epilogue, short of registers, still does.)
+    h = 2 * (T % 2)
+    assert torch.equal(dz_i, dz_r) and torch.equal(work_i[h:h + 2], work_r[h:h + 2])
     part = dz_r[t0:t0 + T].reshape(M, 4 * H)
     assert float(part.abs().max()) > 0
     ref_p = torch.zeros_like(plain)

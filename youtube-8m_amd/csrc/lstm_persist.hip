@@ -590,6 +590,11 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   // num_frames of this workgroup's rows, read ONCE: as a global load per item it sat last in the epilogue's load queue, and the gate math
   // of every item waited for it (tools/fwd_h2_check.py: 0.7 us of a 6.3 us step in the f16 form)
   __shared__ int lds_nf[MAX_LOCAL_TILES * 16];
+  // Round 6 (f16 form: its LDS is nearly empty): c_t / h_t of a (row, unit) pair are read back one step later by the lane that wrote them
+  // (a tile always meets the same epilogue wave) -- they travel through this lane-private LDS slot instead of two global reads per
+  // pair and step (tools: fwd_noch variant, 6.05 -> 5.55 us/step with those reads gone; profiles/r6_pmc_recur_tcc.txt)
+  constexpr int CARRY_T = F16 ? 4 : 1;                   // tiles per epilogue wave that can be carried
+  __shared__ float lds_ch[F16 ? 4 : 1][CARRY_T][2][2][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ug, g;
@@ -776,9 +781,15 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
   const int eunit = lane & 7;
   constexpr int JP = 2 / EPW;                            // (row, unit) pairs per lane
   __builtin_amdgcn_s_setprio(YT8M_EPI_PRIO);
+#ifdef YT8M_FWD_NO_CARRY
+  const bool carry = false;
+#else
+  const bool carry = F16 && (n_it + NEPI / EPW - 1) / (NEPI / EPW) <= CARRY_T;
+#endif
   for (int s = 0; s < a.T; ++s) {
     const int t = a.t0 + s;
     for (int it = EPW == 2 ? (ew >> 1) : ew; it < n_it; it += NEPI / EPW) {
+      const int li = carry ? it / (NEPI / EPW) : 0;       // this wave's local index of the tile
       const int k = s * n_it + it;
       const int T = g + it * RB;
       STAMP(0);
@@ -801,8 +812,13 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
 #if defined(YT8M_FWD_EPI_NOLOAD) || defined(YT8M_FWD_EPI_NOCH)
         cpre[jj] = 0.2f; hpre[jj] = 0.1f;
 #else
-        cpre[jj] = a.cs[idx];
-        hpre[jj] = a.hs[idx];
+        if (carry && s > 0) {
+          cpre[jj] = lds_ch[F16 ? ew : 0][li][0][jj][lane];
+          hpre[jj] = lds_ch[F16 ? ew : 0][li][1][jj][lane];
+        } else {
+          cpre[jj] = a.cs[idx];
+          hpre[jj] = a.hs[idx];
+        }
 #endif
         live[jj] = t < lds_nf[it * 16 + 8 * j + (lane >> 3)];
       }
@@ -852,6 +868,7 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         cn[j] = live[j] ? c1 : cpre[j];
         hn[j] = live[j] ? h1 : hpre[j];
         if (!evalid[j]) hn[j] = 0.f;
+        if (carry) { lds_ch[F16 ? ew : 0][li][0][j][lane] = cn[j]; lds_ch[F16 ? ew : 0][li][1][j][lane] = hn[j]; }
       }
       if (s + 1 < a.T) {                                 // publish h_t of this tile first, as three bf16 planes
         const __amdgpu_buffer_rsrc_t hxr = image(s + 1);
