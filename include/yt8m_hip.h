@@ -471,6 +471,10 @@ int yt8m_sqnorm_multi(const float* w, const float* g, const int32_t* chunks, int
                       const float* l2, float gscale, float* partial, float* norms, int64_t tensor_base,
                       int64_t ntensors, const int32_t* tensor_chunk_start, int64_t chunk_base,
                       yt8m_stream_t stream);
+/* tf.clip_by_norm of ONE tensor, the reference's own helper (W/utils.py:164-174 clip_gradient_norms): out = g * max_norm / max(||g||,
+ * max_norm); out may alias g; workspace: 256 floats.  For hosts that keep their own gradient list -- the training step clips inside the
+ * fused optimiser pass (yt8m_sqnorm_multi + yt8m_adam_multi_ex / yt8m_optimizer_ranges). */
+int yt8m_clip_by_norm_f32(const float* g, float* out, int64_t n, float max_norm, float* workspace, yt8m_stream_t stream);
 int yt8m_adam_multi(float* w, float* m, float* v, const float* g, const int32_t* chunks, int64_t nchunks,
                     const float* l2, float gscale, const float* norms, float clip,
                     float lr_t, float beta1, float beta2, float eps, yt8m_stream_t stream);

@@ -193,9 +193,10 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   // Round 5: the hoisted products of the layers above the first whose result is a sum over frame rows or whose operand rows share one
   // magnitude -- the input projection (outputs of the layer below: |h| < 1) and both weight gradients (h^T / out^T against dz^T) -- run
   // as THREE f16 products of two-plane half images (gemm_h2q_kernel: 1.6x the six-product kernel) with a static scale 2^13 on the
-  // bounded operand and a device-measured scale on the weights / on each backward part's dz.  dx = dz . W_x^T keeps the six-product
-  // form (a time step whose gradient has decayed by 2^-15 against the part's largest would lose precision under one scale per part),
-  // and so does layer 0 (its uint8 products are three-product forms already).  YT8M_STACK_H2=0 keeps every product on the bf16 split.
+  // bounded operand and a device-measured scale on the weights / on each backward part's dz.  dx = dz . W_x^T takes the same form with
+  // ONE POWER OF TWO PER FRAME ROW of dz (YT8M_STACK_H2_DX, default 1: a time step whose gradient has decayed by decades against the
+  // part's largest keeps its own 22 bits; =0 keeps dx on the six-product form); layer 0 on uint8 frames runs its own two- / three-product
+  // forms (h1x2).  YT8M_STACK_H2=0 keeps every product on the bf16 split.
   p.h2 = (knob("YT8M_STACK_H2", 1) && !p.bf16) ? 1 : 0;
   // DropoutWrapper(cell, input_keep_prob) (W/all_frame_models/lstm_memory_model.py:36-44): the mask is applied where each layer's operand
   // images are built (yt8m_h2_split_dropout) and replayed on dx -- f16 product forms on a float input only; keep >= 0.3 keeps the
@@ -219,7 +220,10 @@ const char* plan(const yt8m_lstm_stack_desc* d, Plan* P) {
   p.hrow_stride = up256(bmax * 4);
   p.hrow = o; o += p.h2 ? p.hrow_stride * 2 * MAXL : 0;   // per-row scales / inverses of a backward part's dz (dx operand), per layer
   // maxima of dz measured by the recurrence itself (yt8m_lstm_persist_bwd_ex): per frame row, per layer
-  p.emit_max = (p.h2 && knob("YT8M_STACK_DZ_MAXIMA", 1) && yt8m_lstm_persist_bwd_images_rows(p.B, p.H) > 0 && per_step) ? 1 : 0;
+  // (one absmax word per backward PART: words 1 .. 62 of the layer's block.  More parts than words, or sub-parts of a part -- the opt-in
+  // YT8M_STACK_SUB0 knobs -- would make launches share a word that the next recurrence raises while a weight-gradient product still
+  // reads it: the recurrences then leave the maxima to the separate passes / the sub-part knobs are ignored.  ADVICE r5)
+  p.emit_max = (p.h2 && knob("YT8M_STACK_DZ_MAXIMA", 1) && yt8m_lstm_persist_bwd_images_rows(p.B, p.H) > 0 && per_step && p.nb <= 61) ? 1 : 0;
   p.rmax_stride = up256(p.FB * 4);
   p.rmax = o; o += p.emit_max ? p.rmax_stride * p.L : 0;
   p.colparts = knob("YT8M_STACK_COLPARTS", 1) != 0;
@@ -519,6 +523,15 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
     }
   }
   std::vector<hipEvent_t> done((size_t)P.L * P.nf, nullptr);
+  // Forward layer wavefront (knob YT8M_STACK_FWD_HALF, default 0): half-chip forward recurrences (128 workgroups of eight
+  // 16-row tiles each on the f16 kernel) so that layer l's chunk c runs beside layer l - 1's chunk c + 1 (needs fwd_chunks > 1:
+  // YT8M_LSTM_PERSIST_FWD_CHUNKS).  Measured: profiles/r6_sched_knobs.md.
+  static const int fwd_half = knob("YT8M_STACK_FWD_HALF", 0);
+  struct CapGuard {
+    bool on;
+    explicit CapGuard(bool o) : on(o) { if (on) yt8m_lstm_persist_set_cus(128, -1); }
+    ~CapGuard() { if (on) yt8m_lstm_persist_set_cus(-1, -1); }
+  } cap_guard(fwd_half != 0 && P.L >= 2 && P.nf >= 2);
   for (int c = 0; c < P.nf; ++c) {
     const int64_t t0 = P.fp[c].t0, T = P.fp[c].T, M = T * B;
     for (int l = 0; l < P.L; ++l) {
@@ -576,7 +589,8 @@ extern "C" int yt8m_lstm_stack_fwd(const yt8m_lstm_stack_desc* desc, const void*
       // layer's max |W_h| measured above, on this stream): 6.1 against 7.1 us/step, 17.24 -> 16.76 ms/step.  Follows YT8M_STACK_H2 (with
       // the h2 products off, the stack stays bit for bit what the Python orchestration of the same launches computes); knob
       // YT8M_STACK_H2_RECUR_FWD overrides.
-      const int h2_recur_f = knob("YT8M_STACK_H2_RECUR_FWD", P.h2);
+      static const int h2_recur_f_env = knob("YT8M_STACK_H2_RECUR_FWD", -1);
+      const int h2_recur_f = h2_recur_f_env >= 0 ? h2_recur_f_env : P.h2;
       if (!bf && h2_recur_f)
         RC(yt8m_lstm_persist_fwd_h2(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), at<float>(tape, P.hs[l]),
                                     at<float>(tape, P.out[l]), num_frames, t0, T, B, H, desc->forget_bias,
@@ -699,7 +713,7 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
     hipEvent_t dx_ev = nullptr;
     for (int l = P.L - 1; l >= 0; --l) {
      Part sp[MAXP];
-     int nsub = (l == 0 && P.L > 1) ? std::min(sub0[c], MAXP) : 1;
+     int nsub = (l == 0 && P.L > 1 && !P.emit_max) ? std::min(sub0[c], MAXP) : 1;   // (sub-parts would share the part's absmax word)
      if (nsub > 1) {                                         // equal sub-parts on 16-frame-row boundaries, else the whole part
        const int64_t step = (P.bp[c].T + nsub - 1) / nsub;
        int k = 0;
@@ -746,11 +760,12 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // fp32 configuration: the recurrent product as three f16 products of two-half-plane splits (yt8m_lstm_persist_bwd_h2: fp32-grade,
         // 14.8 instead of 18.3 us per step; knob YT8M_STACK_H2_RECUR, default 1; falls back by itself where the shape cannot take it)
         static const int h2_recur = knob("YT8M_STACK_H2_RECUR", 1);
+        static const int h2_dx_rows = knob("YT8M_STACK_H2_DX", 1);
         if (P.emit_max)                                    // ... and measures max |dz| per frame row (dx operand) and of the part (dW operand)
           RC(yt8m_lstm_persist_bwd_ex(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
                                       at<float>(scratch, P.work[l]), phase[l], num_frames, t0, T, B, H,
                                       h2_recur ? at<char>(scratch, P.hsc + 256 * l + 252) : nullptr,
-                                      (l >= 1 && knob("YT8M_STACK_H2_DX", 1)) ? at<char>(scratch, P.rmax + l * P.rmax_stride) : nullptr,
+                                      (l >= 1 && h2_dx_rows) ? at<char>(scratch, P.rmax + l * P.rmax_stride) : nullptr,
                                       at<char>(scratch, P.hsc + 256 * l + 4 * (1 + std::min(c, 61))), at<char>(scratch, P.pws[l]), P.pws_bytes, s));
         else if (!bf && h2_recur)
           RC(yt8m_lstm_persist_bwd_h2(at<float>(tape, P.z[l]), W[l] + Din * H4, H4, at<float>(tape, P.cs[l]), dout, dz,
@@ -781,7 +796,8 @@ extern "C" int yt8m_lstm_stack_bwd(const yt8m_lstm_stack_desc* desc, const void*
         // weight-gradient stream then waits for this pass instead of reading dz again)
         fused_t = fuse_dz && dW[l] && !(l == 0 && P.u8);
         if (fused_t && dzT_free[l]) ev.wait(sx, dzT_free[l]);       // the previous part's products have read the image
-        const bool dx_h2 = P.h2 && l >= 1 && knob("YT8M_STACK_H2_DX", 1);
+        static const int h2_dx_knob = knob("YT8M_STACK_H2_DX", 1);
+        const bool dx_h2 = P.h2 && l >= 1 && h2_dx_knob;
         if (dx_h2) {
           // dx = dz . W_x^T as three f16 products: dz split ROW by ROW (one power of two per frame row: a time step whose gradient
           // has decayed by decades keeps its own 22 bits), W_x under the scale of its absmax word (measured by the forward pass)

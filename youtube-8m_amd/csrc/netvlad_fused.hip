@@ -1087,7 +1087,8 @@ Layout make_layout(int64_t B, int64_t F, int64_t D) {
 // dynamic LDS above 64 KiB has to be allowed per kernel
 template <typename K, typename A>
 void launch_lds(K kernel, dim3 grid, int lds_bytes, hipStream_t s, const A& args) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  // (a refused attribute shows up as the launch error launch_status reports right after: hipGetLastError is sticky)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return;
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, s, args);
 }
 
@@ -1120,9 +1121,9 @@ extern "C" int yt8m_netvlad_supported(int64_t B, int64_t F, int64_t D, int64_t K
 }
 
 // 1 when yt8m_netvlad_fwd_u8 runs the single-pass kernel (one workgroup per video: vlad_video_kernel) for this shape, 0 when it runs
-// the rows + cols pair.  Knob YT8M_NETVLAD_SINGLE=0 keeps the pair everywhere (A/B).
+// the rows + cols pair.  Default: the pair (the single pass measured slower, DESIGN_LOG 10.3); YT8M_NETVLAD_SINGLE=1 opts in.
 static std::atomic<int> g_single_mode{-1};
-extern "C" int yt8m_netvlad_set_single(int mode) {               // -1: environment / default (on), 0: rows + cols pair, 1: single pass
+extern "C" int yt8m_netvlad_set_single(int mode) {               // -1: environment / default (OFF: measured slower), 0: rows + cols pair, 1: single pass
   g_single_mode.store(mode < 0 ? -1 : (mode ? 1 : 0));
   return YT8M_OK;
 }
@@ -1175,10 +1176,10 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
     // SURVEY.md 8(d) bytes: the uint8 frames once + the parameters (the packed W_c)
     ProfScope pv(F_VLAD_ROWS, s, 4.0 * qbytes * NK, qbytes + (double)L.nblk * 4096 * 2 * nsplit);
     if (nsplit == 2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_video_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_video_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(vlad_video_kernel<2>, dim3((unsigned)B), dim3(512), lds, s, va);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_video_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      YT8M_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_video_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(vlad_video_kernel<1>, dim3((unsigned)B), dim3(512), lds, s, va);
     }
     return launch_status("yt8m_netvlad_fwd_u8 (single pass)");

@@ -354,3 +354,36 @@ extern "C" int yt8m_optimizer_ranges(const yt8m_opt_ranges* o, yt8m_stream_t str
   }
   return YT8M_OK;
 }
+
+// ---- tf.clip_by_norm of ONE tensor (W/utils.py:164-174 clip_gradient_norms: the reference's signature, for hosts that hold their own
+// gradient list; the training step clips inside the fused optimiser pass above) -----------------------------------------------------
+namespace {
+constexpr int CLIP_BLOCKS = 256;
+__global__ __launch_bounds__(256) void clip_sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)CLIP_BLOCKS * 256) acc += g[i] * g[i];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(const float* __restrict__ g, float* __restrict__ out, int64_t n,
+                                                         const float* __restrict__ partial, float max_norm) {
+  __shared__ float red[4];
+  const float tot = block_sum_256(partial[threadIdx.x], red);         // every workgroup sums the 256 partials in the same order
+  const float f = max_norm / fmaxf(sqrtf(tot), max_norm);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = g[i] * f;
+}
+}  // namespace
+
+// out = g * max_norm / max(||g||, max_norm) (out may alias g).  workspace: 256 floats.
+extern "C" int yt8m_clip_by_norm_f32(const float* g, float* out, int64_t n, float max_norm, float* workspace, yt8m_stream_t stream) {
+  YT8M_REQUIRE(n >= 0 && max_norm > 0.f, YT8M_E_BADARG, "n >= 0, max_norm > 0");
+  if (n == 0) return YT8M_OK;
+  YT8M_REQUIRE(g && out && workspace, YT8M_E_BADARG, "null operand");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_OPTIM, s);
+  hipLaunchKernelGGL(clip_sqnorm_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, s, g, n, workspace);
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, s, g, out, n, workspace, max_norm);
+  return launch_status("clip_by_norm");
+}

@@ -32,7 +32,16 @@ def clip_gradient_norms(gradients_to_variables, max_norm):
     Adam over the gradient arena (ops.sqnorm_and_adam -> yt8m_sqnorm_multi + yt8m_adam_multi), see gradient_norms()."""
     clipped_grads_and_vars = []
     for grad, var in gradients_to_variables:
-        if grad is not None:
+        if grad is not None and grad.is_cuda:                     # device tensors: the library's kernels (yt8m_clip_by_norm_f32)
+            import ctypes
+            from . import _lib
+            g = grad.to(torch.float32).contiguous()
+            out, ws = torch.empty_like(g), torch.empty(256, dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().yt8m_clip_by_norm_f32(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(out.data_ptr()), g.numel(),
+                                                        float(max_norm), ctypes.c_void_p(ws.data_ptr()),
+                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            grad = out
+        elif grad is not None:                                    # host tensors (lists a caller assembled on the CPU): plain arithmetic
             norm = torch.linalg.vector_norm(grad.to(torch.float32))
             grad = grad * (max_norm / torch.clamp(norm, min=max_norm))
         clipped_grads_and_vars.append((grad, var))
