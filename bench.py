@@ -290,20 +290,25 @@ def bwd_on_f16_pipe(lib, B, H):
             os.environ.get("YT8M_PERSIST_STEP_IMAGES", "1") != "0" and bool(lib.yt8m_lstm_persist_bwd_on_f16_pipe(B, H)))
 
 
-def exchange_view(row, B, H, cus, f16):
-    """What bounds the backward recurrence in its f16 form: every workgroup (one per CU: 16 units x 64 rows) fetches the dz of its 64
-    rows -- 4H values of 4 bytes, two half planes -- once per step through its CU's L2 port (64 B / clk, MI355X_MICROARCH.md)."""
+def exchange_view(row, B, H, cus, f16, pair=True):
+    """What bounds the backward recurrence in its f16 form (profiles/r6_pmc_recur_tcc.txt): a workgroup (one per CU) draws the dz its K
+    range needs for its 64 rows through the CU's vector-memory window -- the L1 keeps ~64 line requests (128 B each) in flight, so a CU
+    receives 64 x 128 B per mean request latency.  The counters give 277 cycles per request for this kernel (82 % L2 hits, 8 % fabric reads
+    at ~805 cycles); with every request an L2 hit (~230 cycles) the window delivers 64 x 128 / 230 = 35.6 B/clk: the bound quoted here.
+    (Earlier rounds quoted the L2 port's 64 B/clk, which no CU reaches at these latencies.)  Round 6's K-split pairs halve the bytes a
+    workgroup draws per step (pair=True): achieved is then measured on half of 64 rows x 4H x 4 B."""
     if not f16 or not row:
         return None
-    per_wg = 64.0 * 4 * H * 4
+    per_wg = 64.0 * 4 * H * 4 * (0.5 if pair else 1.0)
     steps_per_launch = row["algorithmic_flops_per_launch"] / (2.0 * B * H * 4 * H)
     us_per_step = row["avg_launch_ms"] * 1e3 / max(steps_per_launch, 1e-9)
     ach = per_wg / (us_per_step * 1e-6) / 1e9
-    peak = 64.0 * 2.1                                      # GB/s per CU at the ~2.1 GHz the kernel runs at
+    peak = 64.0 * 128.0 / 230.0 * 2.1                      # GB/s per CU: 64 requests x 128 B per 230-cycle L2 hit at ~2.1 GHz
     return {"bytes_per_workgroup_and_step": per_wg, "us_per_step": us_per_step, "achieved_GBps_per_cu": ach, "peak_GBps_per_cu": peak,
-            "frac": ach / peak, "workgroups": cus,
-            "is": "dz_t fetched by each of the launch's workgroups per time step over the launch's average step time, against one CU's "
-                  "64 B/clk L2 port at 2.1 GHz: the bound this kernel runs against (its matrix work is 1/5 of the fp32-pipe form's)"}
+            "frac": ach / peak, "workgroups": cus, "k_split_pairs": bool(pair),
+            "is": "dz_t drawn by each of the launch's workgroups per time step over the launch's average step time, against what one CU's "
+                  "64-request vector-memory window delivers when every request is an L2 hit (64 x 128 B / 230 cycles at 2.1 GHz; "
+                  "profiles/r6_pmc_recur_tcc.txt): the bound this kernel runs against"}
 
 
 def roofline_from(fam, flops, bf16, extra_note=None, bwd_cus=None, fwd_x3=False, step_ms=None, bwd_f16=False):
@@ -942,7 +947,8 @@ def main():
             bwd_f16 = a.workload == "lstm" and not bf16 and bwd_on_f16_pipe(lib, B, LSTM_H)
             roof = roofline_from(fam, cfg["flops"](B), bf16, bwd_cus=bwd_cus, fwd_x3=fwd_x3, step_ms=el / a.steps * 1e3, bwd_f16=bwd_f16)
             if roof and bwd_f16:
-                roof["exchange"] = exchange_view(roof.get("families", {}).get("lstm_recurrence_bwd"), B, LSTM_H, bwd_cus, True)
+                pair = os.environ.get("YT8M_PERSIST_BWD_PAIR", "0") != "0" and (B + 15) // 16 // 2 <= 8
+                roof["exchange"] = exchange_view(roof.get("families", {}).get("lstm_recurrence_bwd"), B, LSTM_H, bwd_cus, True, pair=pair)
             if a.workload == "moe" and B == 1024 and not bf16 and roof:
                 try:                   # HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_traffic.md)
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))

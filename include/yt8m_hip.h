@@ -658,6 +658,12 @@ int yt8m_lstm_persist_bwd_h2(const float* gates, const float* Wh, int64_t ldw, c
                              float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                              int64_t B, int64_t H, const void* wh_absmax, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H);
+/* Round 6: the f16 backward recurrence as K-SPLIT WORKGROUP PAIRS -- the two workgroups that share a line of gates each reduce HALF of
+ * K for the pair's 32 units (half the dz a CU draws per step) and hand the partner its partial tile through tagged 8-byte granules.
+ * Opt-in (stand-alone 13.7 vs 14.4 us/step, but slower inside the headline step where two recurrences and the dW products share the
+ * chip: profiles/r6_recur_ab.txt block 4); available wherever the f16 form runs with <= 8 tiles per workgroup; results equal the unpaired form to fp32 rounding (one more
+ * level in the fixed summation tree).  mode -1: environment (YT8M_PERSIST_BWD_PAIR, default 0), 0: off, 1: on.  Process-wide. */
+int yt8m_lstm_persist_set_pair(int mode);
 /* yt8m_lstm_persist_bwd (wh_absmax NULL) / yt8m_lstm_persist_bwd_h2 that also measures, while it writes dz, what the products after it
  * would otherwise measure in passes over dz (105-210 MB each at the headline shape): rowmax[t B + b] = max |dz[t, b, :]| as float bits ([F B]
  * words by absolute frame row, zeroed by the caller; the operand of yt8m_h2_split_rowmax) and / or partmax = max |dz| of the launch (one

@@ -142,3 +142,55 @@ def test_backward_recurrence_carries_its_running_state_in_registers(dev):
     dz3, w3 = run([(16, 8), (5, 11), (0, 5)])
     assert torch.equal(dz1, dz3) and torch.equal(w1, w3)
     assert float(dz1.abs().max()) > 0 and bool(torch.isfinite(dz1).all())
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_k_split_pair_form_of_the_backward_recurrence_equals_the_unpaired_form(dev, ragged):
+    """Round 6: lstm_persist_bwd_kernel<.., P2> -- two workgroups per 32 units, each over half of K, partial tiles handed over through
+    tagged granules -- against the unpaired f16 form on the same inputs: dz per (step) on its own scale to fp32 rounding, the final
+    (dh, dc) likewise, ended videos bit-exact zero; and bitwise reproducible run to run (fixed summation order across the pair)."""
+    lib = L.lib()
+    B, F, H = 128, 40, 1024
+    if not lib.yt8m_lstm_persist_bwd_on_f16_pipe(B, H):
+        pytest.skip("f16 backward recurrence not available on this device")
+    g = torch.Generator(device=dev).manual_seed(21)
+    gates = torch.rand((F, B, 4 * H), device=dev, generator=g)
+    Wh = (torch.rand((H, 4 * H), device=dev, generator=g) - 0.5) * 0.06
+    cs = torch.randn((F + 1, B, H), device=dev, generator=g) * 0.5
+    dout = torch.randn((F, B, H), device=dev, generator=g) * 0.01
+    nf = None
+    if ragged:
+        nf = torch.randint(0, F + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+        nf[0], nf[1] = F, 0
+    wword = ops.h2_absmax(Wh)
+    nbytes = lib.yt8m_lstm_persist_workspace_bytes_steps(B, H, F)
+
+    def run(pair):
+        L.check(lib.yt8m_lstm_persist_set_pair(pair))
+        try:
+            pws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            work = torch.zeros((4, B, H), device=dev)
+            work[0].normal_(generator=torch.Generator(device=dev).manual_seed(5))
+            dz = torch.zeros((F, B, 4 * H), device=dev)
+            phase = 0
+            for t0, T in [(25, 15), (0, 25)]:                      # two launches: the hand-off slots and tags are re-used across launches
+                L.check(lib.yt8m_lstm_persist_bwd_h2(_p(gates), _p(Wh), 4 * H, _p(cs), _p(dout), _p(dz), _p(work), phase, None, _p(nf), t0, T, B,
+                                                     H, _p(wword), _p(pws), pws.numel(), _st()))
+                phase = (phase + T) % 2
+            torch.cuda.synchronize()
+            L.check(lib.yt8m_lstm_persist_status(_p(pws), _st()))
+            return dz, work[2 * phase:2 * phase + 2].clone()
+        finally:
+            L.check(lib.yt8m_lstm_persist_set_pair(-1))
+
+    dz1, w1 = run(1)
+    dz1b, w1b = run(1)
+    dz0, w0 = run(0)
+    assert torch.equal(dz1, dz1b) and torch.equal(w1, w1b)
+    assert bool(torch.isfinite(dz1).all()) and float(dz1.abs().max()) > 0
+    d = (dz1 - dz0).abs().amax(dim=(1, 2)) / (dz0.abs().amax(dim=(1, 2)) + 1e-30)
+    assert float(d.max()) < 2e-6, float(d.max())
+    assert float((w1 - w0).abs().max()) <= 2e-6 * float(w0.abs().max())
+    if ragged:
+        dead = torch.arange(F, device=dev)[:, None] >= nf[None, :].long()
+        assert float(dz1[dead].abs().max()) == 0.0

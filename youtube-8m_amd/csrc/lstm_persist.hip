@@ -30,6 +30,7 @@
 // persistent launch of a device behind the previous one with an event (PersistGate), whatever stream the caller passes.
 // Measured behaviour, the s_memtime timeline tooling and what was tried and rejected: DESIGN.md section 7.1.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include "common.h"
 #include "x3_image.h"
@@ -961,6 +962,9 @@ struct PersistBwdArgs {
   unsigned* rowmax;     // rotated epilogue, or null: max |dz[t, b, :]| as float bits by absolute frame row t B + b (atomicMax over the 64
                         // producer workgroups of a row; zeroed by the caller) -- what yt8m_h2_rowscales would measure in a pass over dz
   unsigned* partmax;    // ... or null: max |dz| of the whole launch into one word (atomicMax; what yt8m_h2_absmax would measure)
+  unsigned* px;         // P2 (K-split workgroup pairs): partial-tile hand-off slots [2 parities][NT16][NUB][64 lanes][8 dwords] = {value, tag} granules
+  unsigned px_bytes;
+  unsigned nonce;       // ... a number no earlier launch on this workspace used: the tags of this launch are nonce * 8191 + step + 1
   unsigned long long* dbg;
   // IMG (rotated epilogue only): the operand images of this launch's dz written by the epilogue itself -- what yt8m_x3_split would
   // make of dz[t0 .. t0 + T) in separate passes (csrc/gemm_x3.hip image layout: 1 KiB blocks of 32 rows x 16 k per plane).
@@ -1017,18 +1021,30 @@ __device__ __forceinline__ void p_split3(float x, unsigned& h1, unsigned& h2, un
 //   K slot (block 2 p + uh, k-group kg, j) of the exchange = producer p's value (unit 8 uh + 2 kg + j / 4, gate j % 4): a lane of the
 //   epilogue (one unit x four gates per row) and its neighbour fill one 16-byte A fragment piece -- one DPP move per dword instead of the
 //   one-plane form's three-step gather.
-template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false, bool BF = false, bool H2 = false>
+// P2 (round 6): K-SPLIT WORKGROUP PAIRS of the H2 form.  What paces the H2 kernel is the CU's vector-memory window: 64 line requests in
+// flight x ~270 cycles each = ~31 B/clk, and every workgroup draws the dz of its 64 rows -- 1 MiB per step -- through it
+// (profiles/r6_pmc_recur_tcc.txt).  The two workgroups (pair, kh = 0 / 1) that share a 128-byte line of gates (same XCD) now share the
+// WORK differently: both compute the partial dh of the pair's 32 units, each over HALF of K (kh's 2H of the 4H dz columns = the producers
+// [32 kh, 32 kh + 32)) -- the same 256 KiB weight footprint ([2H x 32] instead of [4H x 16]: hi plane in registers, lo plane in LDS),
+// the same 48 MFMAs per item and wave, HALF the dz bytes per CU.  The price is one hand-off per item: each workgroup finishes its own 16
+// units and needs the partner's partial tile for them -- 1 KiB as sixty-four {value, tag} granule quads written with sc0 sc1 stores into
+// a slot the partner's epilogue wave polls with sc0 sc1 loads (no flag, no fence: the tag IS the arrival; MI355X_MICROARCH.md
+// "handoff-1to1").  Sum order: K-half 0 + K-half 1, whichever workgroup finishes the unit -- bitwise reproducible run to run.
+template <int NQB, bool PF, bool SH, bool ROT, bool IMG = false, bool BF = false, bool H2 = false, bool P2 = false>
 __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
+  static_assert(!P2 || (H2 && (NQB % 16) == 0), "K-split pairs are a form of the two-half-plane kernel");
   static_assert(!IMG || ROT, "the operand images are written by the rotated epilogue");
   static_assert(!BF || (PF && SH && ROT && !IMG && (NQB % 4) == 0), "the bf16-operand form: prefetching, one image per step, rotated epilogue");
   static_assert(!H2 || (PF && SH && ROT && !IMG && !BF && (NQB % 8) == 0), "the two-half-plane form: prefetching, one image per step, rotated epilogue");
   constexpr int HALF = NQB / 2;                          // q-groups per wave in registers (= in LDS = ring slots)
   constexpr unsigned EPW = ROT ? 1u : 4u;                // epilogue waves that read a partial-tile slot / publish a tile
-  __shared__ __attribute__((aligned(16))) float4 Wl[8][BF ? 1 : HALF][64];  // LDS-resident half of the weights: 8 * HALF KB (BF: none)
-  __shared__ __attribute__((aligned(16))) float red[NSLOT_B][8][4][64];    // [slot][wave][acc reg][lane]: 24 KB
+  constexpr int NSL = P2 ? 2 : NSLOT_B;                    // partial-tile slots (P2: two tiles of 16 x 32 per wave -> 16 KB per slot)
+  constexpr int NRR = P2 ? 8 : 4;                          // accumulator registers a wave leaves per item
+  __shared__ __attribute__((aligned(16))) float4 Wl[8][BF ? 1 : (P2 ? HALF - 1 : HALF)][64];  // LDS-resident half of the weights: 8 * HALF KB (BF: none; P2: one fragment per wave moves to registers)
+  __shared__ __attribute__((aligned(16))) float red[NSL][8][NRR][64];      // [slot][wave][acc reg][lane]: 24 KB (P2: 32 KB)
   __shared__ unsigned lds_cnt[NSLOT_B], lds_free[NSLOT_B];
   __shared__ unsigned lds_seen[MAX_LOCAL_TILES];           // see the forward kernel: only matrix wave 0 polls memory
-  __shared__ int lds_nf[ROT ? MAX_LOCAL_TILES * 16 : 1];   // rotated epilogue: num_frames of the workgroup's rows, read once (as the forward kernel)
+  __shared__ int lds_nf[ROT ? (P2 ? 8 : MAX_LOCAL_TILES) * 16 : 1];   // rotated epilogue: num_frames of the workgroup's rows, read once (as the forward kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ub, g;
@@ -1065,9 +1081,11 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   // (global block kbp = w NQB / 2 + kbl: producer kbp / 2, unit half kbp % 2), W_h[16 ub + n][gate (j % 4) H + 16 producer + 8 uh + 2 kg + j / 4]
   float h2_sw = 1.f;
   if constexpr (H2) h2_sw = yt8m_x3::pow2_scale_for(__uint_as_float(a.wword[0]), 14);
+  // P2: fragment f = 2 kbl + nt of a wave = K block kh 2 NQB + w NQB / 4 + kbl of the pair's unit tile nt (units 16 (2 pair + nt) ..)
   auto w_frag_h2 = [&](int kbl, u32x4& fhi, u32x4& flo) {
-    const int kbp = w * (NQB / 2) + kbl;
-    const float* q = a.Wh + (long long)(ub * 16 + i16) * a.ldw + 16 * (kbp >> 1) + 8 * (kbp & 1) + 2 * kq;
+    const int kbp = P2 ? (ub & 1) * 2 * NQB + w * (NQB / 4) + (kbl >> 1) : w * (NQB / 2) + kbl;
+    const int urow = P2 ? ((ub & ~1) + (kbl & 1)) * 16 + i16 : ub * 16 + i16;
+    const float* q = a.Wh + (long long)urow * a.ldw + 16 * (kbp >> 1) + 8 * (kbp & 1) + 2 * kq;
     unsigned hb[8], lb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) yt8m_x3::split_h2(q[(long long)(j & 3) * H + (j >> 2)] * h2_sw, hb[j], lb[j]);
@@ -1077,7 +1095,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
   if constexpr (H2) {
     if (w < 8) {
 #pragma unroll
-      for (int kbl = 0; kbl < HALF; ++kbl) {                // the lo plane of the whole slice lives in LDS, the hi plane in registers
+      for (int kbl = 0; kbl < (P2 ? HALF - 1 : HALF); ++kbl) {   // the lo plane of the whole slice lives in LDS, the hi plane in registers
         u32x4 fhi, flo;
         w_frag_h2(kbl, fhi, flo);
         Wl[w][kbl][lane] = as_f4(flo);
@@ -1176,6 +1194,134 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         for (int r = 0; r < 4; ++r) rw[r * 64] = acc0[r] + acc1[r];
         if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (++slot == NSLOT_B) { slot = 0; ++gen; }
+        if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
+      }
+      return;
+    }
+  } else if constexpr (H2 && P2) {
+    if (w < 8) {
+      // =============================== matrix waves, two half planes, K-split pair ===============================
+      constexpr int KW = NQB / 4, HK = KW / 2;             // K blocks per wave (8 at H = 1024) / per half item
+      constexpr int NPW = KW / 2, PH = NPW / 2;            // producers per wave (a producer = 2 K blocks) / per half item
+      static_assert(HK >= 2 && (HK % 2) == 0, "whole producers per half item");
+      const int kh = ub & 1;
+      u32x4 Wh_[HALF];                                     // hi plane: fragment f = 2 kbl + nt
+      u32x4 Wlast;                                         // lo plane of fragment HALF - 1 (the one that left the LDS)
+#pragma unroll
+      for (int f = 0; f < HALF; ++f) { u32x4 flo; w_frag_h2(f, Wh_[f], flo); if (f == HALF - 1) Wlast = flo; }
+      const float inv_sw = 1.0f / h2_sw;
+      const int lane_off = lane * 16;
+      const int kbp0 = kh * 2 * NQB + w * KW;              // first global K block of this wave
+      auto blk = [&](int T) -> int { return __builtin_amdgcn_readfirstlane((T * QH4 + 2 * kbp0) * 1024); };
+      const __amdgpu_buffer_rsrc_t scr = make_rsrc(a.sc, a.sc_bytes);
+      const int kq_off = kq * 4;
+      auto sc_off = [&](int s, int T, int pl) -> int {
+        return __builtin_amdgcn_readfirstlane(((s * NT16 + T) * a.NUB + (kbp0 >> 1) + pl) * 16);
+      };
+      u32x4 ring[2 * HK];                                  // half an item: HK K blocks x 2 planes
+      unsigned sc[PH];
+      int s_cur = 0, it_cur = 0, slot = 0, gen = 0;
+      auto seen_wait = [&](int it, int T, unsigned target) {
+        if (w == 0) {
+          wait_tile(a.ctl, T, target, lane);
+          if (lane == 0) __hip_atomic_store(&lds_seen[it], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          lds_wait_ge(&lds_seen[it], target, a.ctl);
+        }
+      };
+      {
+        seen_wait(0, g, arrivals);
+        const int b0 = blk(g);
+        const __amdgpu_buffer_rsrc_t dx0 = image(0);
+#pragma unroll
+        for (int q = 0; q < 2 * HK; ++q) ring[q] = __builtin_amdgcn_raw_buffer_load_b128(dx0, lane_off, b0 + q * 1024, 0);
+#pragma unroll
+        for (int pl = 0; pl < PH; ++pl) sc[pl] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(0, g, pl), 0);
+      }
+      auto lo_frag = [&](int f) -> u32x4 { return f == HALF - 1 ? Wlast : as_u4(Wl[w][f < HALF - 1 ? f : 0][lane]); };
+      u32x4 wl0 = lo_frag(0), wl1 = lo_frag(1);            // lo fragments of the NEXT K block (both unit tiles), one block ahead
+      auto rescale = [&](f32x4& acc, const f32x4& tmp, unsigned e4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(tmp[r], __uint_as_float(((e4 >> (8 * r)) & 0xFFu) << 23), acc[r]);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+      };
+      for (int k = 0; k < total; ++k) {
+        const int s = s_cur, T = g + it_cur * RB;
+        STAMP(0);
+        int s1 = s, it1 = it_cur + 1;
+        if (it1 == n_it) { it1 = 0; ++s1; }
+        const bool have1 = k + 1 < total;
+        const int T1 = have1 ? g + it1 * RB : T;
+        s1 = have1 ? s1 : s;
+        unsigned pv = 0;
+        const int bcur = blk(T);
+        const __amdgpu_buffer_rsrc_t dxr = image(s);
+        if (w == 0 && lane < NSH)
+          pv = __hip_atomic_load(a.ctl + CTL_HDR + (T1 * NSH + lane) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 tmp0 = {0.f, 0.f, 0.f, 0.f}, tmp1 = {0.f, 0.f, 0.f, 0.f};
+        unsigned e_cur = 0;
+        // one K block: its A fragments (hi, lo plane) against both unit tiles -- six MFMAs -- then the in-place refill of its two ring
+        // entries and the lo fragments of the next block
+        auto kblock = [&](int kbl, int kr, const __amdgpu_buffer_rsrc_t& rsrc, int rbase, bool refill, int sc_s, int sc_T, int sc_pl) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, ring[2 * kr]), al = __builtin_bit_cast(f16x8, ring[2 * kr + 1]);
+          const f16x8 bh0 = __builtin_bit_cast(f16x8, Wh_[2 * kbl]), bh1 = __builtin_bit_cast(f16x8, Wh_[2 * kbl + 1]);
+          const f16x8 bl0 = __builtin_bit_cast(f16x8, wl0), bl1 = __builtin_bit_cast(f16x8, wl1);
+          if ((kbl & 1) == 0) e_cur = sc[(kr >> 1)];
+          __builtin_amdgcn_sched_barrier(0);
+          if ((kbl & 1) == 0) {
+            tmp0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            tmp1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          } else {
+            tmp0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, tmp0, 0, 0, 0);
+            tmp1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, tmp1, 0, 0, 0);
+          }
+          tmp0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, tmp0, 0, 0, 0);
+          tmp1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, tmp1, 0, 0, 0);
+          tmp0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, tmp0, 0, 0, 0);
+          tmp1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, tmp1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          const int fn = (2 * (kbl + 1)) % HALF;             // (the last block of an item fetches block 0's of the next)
+          wl0 = lo_frag(fn);
+          wl1 = lo_frag(fn + 1);
+          if (refill) {
+            ring[2 * kr] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, rbase + (2 * kr) * 1024, 0);
+            ring[2 * kr + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, rbase + (2 * kr + 1) * 1024, 0);
+          }
+          if (kbl & 1) {
+            if (refill) sc[(kr >> 1)] = __builtin_amdgcn_raw_buffer_load_b32(scr, kq_off, sc_off(sc_s, sc_T, sc_pl), 0);
+            rescale(acc0, tmp0, e_cur);
+            rescale(acc1, tmp1, e_cur);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        // first half: ring entries are refilled with this item's second half
+#pragma unroll
+        for (int kb = 0; kb < HK; ++kb) kblock(kb, kb, dxr, bcur + 2 * HK * 1024, true, s, T, PH + (kb >> 1));
+        {
+          const int it1l = have1 ? it1 : it_cur;
+          if (w == 0) {
+            const unsigned tot = shard_sum(pv);
+            if (tot < (unsigned)(s1 + 1) * arrivals) wait_tile(a.ctl, T1, (unsigned)(s1 + 1) * arrivals, lane);
+            if (lane == 0) __hip_atomic_store(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            lds_wait_ge(&lds_seen[it1l], (unsigned)(s1 + 1) * arrivals, a.ctl);
+          }
+          STAMP(1);
+        }
+        const int bnext = blk(T1);
+        const __amdgpu_buffer_rsrc_t dxn = image(s1);
+        // second half: refilled with the next item's first half
+#pragma unroll
+        for (int kb = HK; kb < KW; ++kb) kblock(kb, kb - HK, dxn, bnext, true, s1, T1, (kb - HK) >> 1);
+        STAMP(2);
+        if (gen > 0) lds_wait_ge(&lds_free[slot], EPW * (unsigned)gen, a.ctl);
+        float* rw = &red[slot][w][0][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rw[r * 64] = acc0[r] * inv_sw; rw[(4 + r) * 64] = acc1[r] * inv_sw; }
+        if (lane == 0) __hip_atomic_fetch_add(&lds_cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        STAMP(3);
+        if (++slot == NSL) { slot = 0; ++gen; }
         if (++it_cur == n_it) { it_cur = 0; ++s_cur; }
       }
       return;
@@ -1734,7 +1880,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
       const int half = (a.phase + s + 1) & 1;
       for (int it = ew; it < n_it; it += 4) {
         const int k = s * n_it + it;                      // n_it % 4 == 0: item k is always this wave's
-        const int slot = k % NSLOT_B, gen = k / NSLOT_B;
+        const int slot = k % NSL, gen = k / NSL;
         const int T = g + it * RB;
         STAMP(0);
         float base[4], dc[4];
@@ -1759,6 +1905,59 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
         lds_wait_ge(&lds_cnt[slot], 8u * (unsigned)(gen + 1), a.ctl);
         STAMP(1);
         float p[4];
+        if constexpr (P2) {
+          // this workgroup's K half of BOTH unit tiles: keep the own tile's, hand the other to the partner, take the partner's half of
+          // the own tile.  Slot of (step parity, tile, DESTINATION workgroup): 64 lanes x {p0, tag, p1, tag | p2, tag, p3, tag}.
+          const int kh = ub & 1;
+          float q[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[r] = red[slot][0][4 * kh + r][lane];
+            q[r] = red[slot][0][4 * (kh ^ 1) + r][lane];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) { p[r] += red[slot][wv][4 * kh + r][lane]; q[r] += red[slot][wv][4 * (kh ^ 1) + r][lane]; }
+          }
+          if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const __amdgpu_buffer_rsrc_t pxr = make_rsrc(a.px, a.px_bytes);
+          const unsigned tag = a.nonce * 8191u + (unsigned)s + 1u;
+          const unsigned slot_b = (unsigned)(((s & 1) * NT16 + T) * a.NUB) * 2048u + (unsigned)lane * 32u;
+          {
+            u32x4 v0, v1;
+            v0.x = __float_as_uint(q[0]); v0.y = tag; v0.z = __float_as_uint(q[1]); v0.w = tag;
+            v1.x = __float_as_uint(q[2]); v1.y = tag; v1.z = __float_as_uint(q[3]); v1.w = tag;
+            const unsigned dst = slot_b + (unsigned)(ub ^ 1) * 2048u;
+            __builtin_amdgcn_raw_buffer_store_b128(v0, pxr, (int)dst, 0, YT8M_AUX_ST);
+            __builtin_amdgcn_raw_buffer_store_b128(v1, pxr, (int)(dst + 16u), 0, YT8M_AUX_ST);
+          }
+          const unsigned src = slot_b + (unsigned)ub * 2048u;
+          long long t_start = 0;
+          for (unsigned spins = 0;; ++spins) {
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(pxr, (int)src, 0, YT8M_AUX_LD);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(pxr, (int)(src + 16u), 0, YT8M_AUX_LD);
+            const bool ok = v0.y == tag && v0.w == tag && v1.y == tag && v1.w == tag;
+            if (__all(ok)) {
+              const float o0 = __uint_as_float(v0.x), o1 = __uint_as_float(v0.z), o2 = __uint_as_float(v1.x), o3 = __uint_as_float(v1.z);
+              if (kh == 0) { p[0] += o0; p[1] += o1; p[2] += o2; p[3] += o3; }       // K half 0 + K half 1, on either side
+              else { p[0] = o0 + p[0]; p[1] = o1 + p[1]; p[2] = o2 + p[2]; p[3] = o3 + p[3]; }
+              break;
+            }
+            if (spins >= 4) {
+              __builtin_amdgcn_s_sleep(2);
+              if ((spins & 63) == 4) {
+                if (__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                const long long now = wall_clock64();
+                if (t_start == 0) t_start = now;
+                else if (now - t_start > SPIN_TIMEOUT) {
+                  if (lane == 0) {
+                    __hip_atomic_store(a.ctl - CTL_STICKY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                  break;
+                }
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           p[r] = red[slot][0][r][lane];
@@ -1766,6 +1965,7 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
           for (int wv = 1; wv < 8; ++wv) p[r] += red[slot][wv][r][lane];
         }
         if (lane == 0) __hip_atomic_fetch_add(&lds_free[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         STAMP(2);
         if (last) {                                       // dL/dh_{t_lo - 1}: handed to the caller (next chunk / initial state)
 #pragma unroll
@@ -2016,6 +2216,7 @@ unsigned* stats_ptr(int dev) {
 
 // CUs a persistent launch may occupy: the whole chip, or YT8M_PERSIST_CUS of them (the rest stays free for kernels of other
 // streams -- the hoisted GEMMs of the layer pipeline -- to run beside the recurrence)
+std::atomic<int> g_pair_mode{-1};        // yt8m_lstm_persist_set_pair
 int g_cap_fwd = -1, g_cap_bwd = -1;      // yt8m_lstm_persist_set_cus (calling thread's choice for its next launches); -1: environment
 // CUs the gate keeps out of its residency arithmetic (yt8m_lstm_persist_reserve_cus): under data parallelism the RCCL kernels of
 // the gradient all-reduce occupy CUs during the backward recurrences -- two half-chip launches admitted side by side would then
@@ -2148,8 +2349,9 @@ extern "C" int64_t yt8m_lstm_persist_workspace_bytes_steps(int64_t B, int64_t H,
   Geometry geo;
   if (!persist_geometry(B, H, &geo)) return 0;
   // (+ the scale words of the f16 form of the backward recurrence: yt8m_lstm_persist_bwd_h2)
+  // ... + the hand-off slots of its K-split pair form (two parities x tiles x H / 16 workgroups x 2 KiB)
   return ctl_padded(geo.NT16) + std::max<int64_t>(T, 2) * geo.NT16 * 16 * 4 * H * 4 + ((std::max<int64_t>(T, 2) * geo.NT16 * (H / 16) * 16 + 255) / 256) * 256 +
-         DBG_BYTES;
+         (int64_t)2 * geo.NT16 * (H / 16) * 2048 + DBG_BYTES;
 }
 
 // Since the last reset on the current device: persistent launches, their workgroups, and how many of those did not run on the XCD
@@ -2363,7 +2565,8 @@ int launch_bwd_sh(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
   }
   if constexpr (SH && (NQB == 16 || NQB == 32)) {
     if (a.h2 && rot) {
-      hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, true, true, false, false, true>), dim3(grid), dim3(768), 0, s, a);
+      if (a.px) hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, true, true, false, false, true, true>), dim3(grid), dim3(768), 0, s, a);
+      else hipLaunchKernelGGL((lstm_persist_bwd_kernel<NQB, true, true, true, false, false, true>), dim3(grid), dim3(768), 0, s, a);
       return yt8m::launch_status("lstm_persist_bwd_kernel");
     }
   }
@@ -2377,6 +2580,13 @@ int launch_bwd(const PersistBwdArgs& a, unsigned grid, hipStream_t s) {
   return a.nimg >= a.T ? launch_bwd_sh<NQB, true>(a, grid, s) : launch_bwd_sh<NQB, false>(a, grid, s);
 }
 }  // namespace
+
+// K-split workgroup pairs of the f16 backward recurrence (lstm_persist_bwd_kernel<.., P2>): -1 = the environment's choice
+// (YT8M_PERSIST_BWD_PAIR, default OFF: 13.7 vs 14.4 us/step stand-alone, but +0.66 ms on the headline step -- profiles/r6_recur_ab.txt block 4), 0 = off, 1 = on where the launch can take it.  Process-wide; for A/B runs and tests.
+extern "C" int yt8m_lstm_persist_set_pair(int mode) {
+  g_pair_mode.store(mode < 0 ? -1 : (mode ? 1 : 0));
+  return YT8M_OK;
+}
 
 extern "C" int yt8m_lstm_persist_bwd_supported(int64_t B, int64_t H) {
   return (persist_geometry(B, H, nullptr) && persist_geometry_bwd(B, H, nullptr)) ? 1 : 0;
@@ -2508,6 +2718,7 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
                "row / launch maxima need the rotated backward epilogue on a per-step workspace (yt8m_lstm_persist_bwd_images_rows)");
   // H2: the scale words sit between the last exchange image and the debug tail; taken only when T images still fit in front of them
   a.h2 = 0; a.wword = nullptr; a.sc = nullptr; a.sc_bytes = 0;
+  a.px = nullptr; a.px_bytes = 0; a.nonce = 0;
   if (h2_wword && !img && !bf16 && (H == 512 || H == 1024)) {
     const int64_t scb = h2_scale_bytes(geo.NT16, H, T);
     if (scb < (1LL << 31) && images_in(workspace_bytes - scb, geo.NT16, 4 * H) >= T) {
@@ -2515,6 +2726,21 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
       a.wword = static_cast<const unsigned*>(h2_wword);
       a.sc = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES - scb);
       a.sc_bytes = (unsigned)scb;
+      // K-split workgroup pairs (P2): the two workgroups that share a 128-byte line of gates sit on one XCD (the paired block -> unit
+      // group map), every workgroup owns <= 8 tiles, and the hand-off slots fit in front of the scale words.  Opt-in: YT8M_PERSIST_BWD_PAIR=1
+      static const bool pair_env_off = getenv("YT8M_PERSIST_BWD_PAIR") == nullptr || atoi(getenv("YT8M_PERSIST_BWD_PAIR")) == 0;
+      const int pair_mode = g_pair_mode.load();
+      const bool pair_off = pair_mode < 0 ? pair_env_off : pair_mode == 0;
+      const int64_t pxb = (int64_t)2 * geo.NT16 * geo.NUB * 2048;
+      const int n_it_max = (geo.NT16 + geo.RB - 1) / geo.RB;
+      if (!pair_off && bwd_rot(geo.pf, geo.NT16, geo.RB) && geo.per > 0 && (geo.NUB % (2 * geo.per)) == 0 && n_it_max <= 8 &&
+          images_in(workspace_bytes - scb - pxb, geo.NT16, 4 * H) >= T) {
+        static std::atomic<unsigned> g_nonce{1};
+        a.px = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + workspace_bytes - DBG_BYTES - scb - pxb);
+        a.px_bytes = (unsigned)pxb;
+        a.nonce = g_nonce.fetch_add(1) & 0x7FFFFu;           // (nonce * 8191 + step + 1 < 2^32; reuse after 2^19 launches)
+        if (a.nonce == 0) a.nonce = g_nonce.fetch_add(1) & 0x7FFFFu;
+      }
     }
   }
   const unsigned grid = (unsigned)(geo.NUB * geo.RB);
