@@ -658,6 +658,26 @@ int yt8m_lstm_persist_bwd_h2(const float* gates, const float* Wh, int64_t ldw, c
                              float* work, int phase, float* dbias_rows, const int32_t* num_frames, int64_t t0, int64_t T,
                              int64_t B, int64_t H, const void* wh_absmax, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H);
+/* Round 6: tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn as ONE launch per (layer, time range) and direction on the persistent
+ * recurrences' exchange protocol (csrc/gru_persist.inl; reference W/all_frame_models/gru_pooling_model.py:34-47 -- replaces the
+ * 2 + 3 launches per time step of yt8m_gru_layer_fwd / _bwd).  A GRU step is two dependent products, so a step is two half-steps of the
+ * exchange: the workspace (yt8m_gru_persist_workspace_bytes) holds one exchange image per half-step.
+ *   fwd: zg [F,B,2H], zc [F,B,H] = hoisted input projections + biases on entry, activations r|u, c on exit; Wg_h / Wc_h = the recurrent
+ *        rows of gates/weights [H, >= 2H] and candidate/weights [H, >= H]; hs [F+1,B,H] with hs[t0] given; rh [F,B,H] = r * h_{t-1};
+ *        out [F,B,H] or NULL; rows with t >= num_frames[b] copy their state through and emit zeros.
+ *   bwd: steps t0 + T - 1 .. t0; work [B,H] = dL/dh entering the range's last step (in) / dL/dh_{t0-1} (out); writes dzg, dzc.
+ * Results equal the per-step entry points up to the K summation order of the recurrent products and the v_exp / v_rcp gate functions
+ * (<= ~1.5e-7 absolute per activation).  yt8m_lstm_persist_status(workspace) reports a timed-out launch, as for the LSTM kernels.
+ * Measured at B = 128, H = 1024 (profiles/r6_gru_persist.txt): forward 13.9 us/step against 17.6 for the per-step launches (the host
+ * mirror takes it by default), backward 28.6 against 20.3 (opt-in: YT8M_GRU_PERSIST_BWD=1 in the host mirror). */
+int yt8m_gru_persist_supported(int64_t B, int64_t H);
+int64_t yt8m_gru_persist_workspace_bytes(int64_t B, int64_t H, int64_t T);
+int yt8m_gru_persist_fwd(float* zg, float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc, float* hs, float* rh,
+                         float* out, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H, void* workspace,
+                         int64_t workspace_bytes, yt8m_stream_t stream);
+int yt8m_gru_persist_bwd(const float* zg, const float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc,
+                         const float* hs, const float* dout, float* dzg, float* dzc, float* work, const int32_t* num_frames, int64_t t0,
+                         int64_t T, int64_t B, int64_t H, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
 /* Round 6: the f16 backward recurrence as K-SPLIT WORKGROUP PAIRS -- the two workgroups that share a line of gates each reduce HALF of
  * K for the pair's 32 units (half the dz a CU draws per step) and hand the partner its partial tile through tagged 8-byte granules.
  * Opt-in (stand-alone 13.7 vs 14.4 us/step, but slower inside the headline step where two recurrences and the dW products share the

@@ -194,3 +194,116 @@ def test_k_split_pair_form_of_the_backward_recurrence_equals_the_unpaired_form(d
     if ragged:
         dead = torch.arange(F, device=dev)[:, None] >= nf[None, :].long()
         assert float(dz1[dead].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,F,H,parts", [(128, 12, 1024, [(0, 12)]), (128, 9, 1024, [(0, 4), (4, 5)]), (37, 6, 256, [(0, 6)]), (70, 5, 512, [(0, 2), (2, 3)])])
+def test_persistent_gru_equals_the_per_step_kernels(dev, B, F, H, parts):
+    """Round 6: GRUCell as one launch per direction on the persistent recurrences' exchange protocol
+    (csrc/gru_persist.inl; W/all_frame_models/gru_pooling_model.py:34-47) against the per-step kernels of csrc/cells.hip on the same
+    inputs: activations r | u, c, the states, r * h and the outputs to 2e-6; dzg / dzc / the final dL/dh to 1e-5 of their maxima; rows past
+    num_frames bit-exact (copied state, zero output, zero dz); chained launches over time ranges; bitwise reproducible run to run."""
+    lib = L.lib()
+    if not lib.yt8m_gru_persist_supported(B, H):
+        pytest.skip("persistent GRU not available for this shape on this device")
+    g = torch.Generator(device=dev).manual_seed(B + F + H)
+    zg0 = torch.randn((F, B, 2 * H), device=dev, generator=g) * 0.8 + 0.5
+    zc0 = torch.randn((F, B, H), device=dev, generator=g) * 0.8
+    Wg = (torch.rand((H, 2 * H), device=dev, generator=g) - 0.5) * 0.08
+    Wc = (torch.rand((H, H), device=dev, generator=g) - 0.5) * 0.08
+    h0 = torch.randn((B, H), device=dev, generator=g) * 0.3
+    nf = torch.randint(0, F + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+    nf[0], nf[1], nf[2] = F, 0, 1
+    dout = torch.randn((F, B, H), device=dev, generator=g) * 0.1
+    dhF = torch.randn((B, H), device=dev, generator=g) * 0.1
+    ws = ops._workspace(dev)
+
+    def per_step():
+        zg, zc = zg0.clone(), zc0.clone()
+        hs = torch.zeros((F + 1, B, H), device=dev)
+        hs[0] = h0
+        rh, out = torch.zeros((F, B, H), device=dev), torch.zeros((F, B, H), device=dev)
+        L.check(lib.yt8m_gru_layer_fwd(_p(zg), _p(zc), _p(Wg), 2 * H, _p(Wc), H, _p(hs), _p(rh), _p(out), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _st()))
+        dzg, dzc = torch.zeros((F, B, 2 * H), device=dev), torch.zeros((F, B, H), device=dev)
+        work = torch.zeros((3, B, H), device=dev)
+        L.check(lib.yt8m_gru_layer_bwd(_p(zg), _p(zc), _p(Wg), 2 * H, _p(Wc), H, _p(hs), _p(dout), _p(dhF), _p(dzg), _p(dzc), _p(work), _p(nf),
+                                       F, B, H, _p(ws), ws.numel() * 4, _st()))
+        torch.cuda.synchronize()
+        return zg, zc, hs, rh, out, dzg, dzc, work[F % 2].clone()
+
+    def persistent():
+        zg, zc = zg0.clone(), zc0.clone()
+        hs = torch.zeros((F + 1, B, H), device=dev)
+        hs[0] = h0
+        rh, out = torch.zeros((F, B, H), device=dev), torch.zeros((F, B, H), device=dev)
+        pws = torch.zeros(lib.yt8m_gru_persist_workspace_bytes(B, H, F), dtype=torch.uint8, device=dev)
+        for t0, T in parts:
+            L.check(lib.yt8m_gru_persist_fwd(_p(zg), _p(zc), _p(Wg), 2 * H, _p(Wc), H, _p(hs), _p(rh), _p(out), _p(nf), t0, T, B, H, _p(pws),
+                                             pws.numel(), _st()))
+        dzg, dzc = torch.zeros((F, B, 2 * H), device=dev), torch.zeros((F, B, H), device=dev)
+        work = dhF.clone()
+        for t0, T in reversed(parts):
+            L.check(lib.yt8m_gru_persist_bwd(_p(zg), _p(zc), _p(Wg), 2 * H, _p(Wc), H, _p(hs), _p(dout), _p(dzg), _p(dzc), _p(work), _p(nf), t0, T,
+                                             B, H, _p(pws), pws.numel(), _st()))
+        torch.cuda.synchronize()
+        L.check(lib.yt8m_lstm_persist_status(_p(pws), _st()))
+        return zg, zc, hs, rh, out, dzg, dzc, work
+
+    a = per_step()
+    b = persistent()
+    b2 = persistent()
+    for x, y in zip(b, b2):
+        assert torch.equal(x, y)
+    names = ["zg", "zc", "hs", "rh", "out"]
+    for n, x, y in zip(names, a[:5], b[:5]):
+        assert bool(torch.isfinite(y).all()), n
+        assert float((x - y).abs().max()) < 2e-6, (n, float((x - y).abs().max()))
+    for n, x, y in zip(["dzg", "dzc", "dh0"], a[5:], b[5:]):
+        assert float(x.abs().max()) > 0
+        assert float((x - y).abs().max()) < 1e-5 * float(x.abs().max()), (n, float((x - y).abs().max()), float(x.abs().max()))
+    t = torch.arange(F, device=dev)[:, None]
+    dead = t >= nf[None, :].long()
+    assert float(b[4][dead].abs().max()) == 0.0 and float(b[5][dead].abs().max()) == 0.0 and float(b[6][dead].abs().max()) == 0.0
+    hs = b[2]
+    assert torch.equal(hs[1:][dead], hs[:-1][dead])
+
+
+def test_gru_layer_op_with_persistent_recurrences_matches_the_per_step_op(dev):
+    """seq_ops.gru_layer with the persistent forward (default) and the opt-in persistent backward against the op on the per-step
+    kernels: two stacked layers sharing one exchange workspace, outputs and every gradient."""
+    from yt8m_amd.variables import ones
+    F, B, D, H = 10, 128, 64, 1024
+    if not L.lib().yt8m_gru_persist_supported(B, H):
+        pytest.skip("persistent GRU not available on this device")
+    old = seq_ops.GRU_PERSIST_FWD, seq_ops.GRU_PERSIST_BWD
+
+    def run(fwd, bwd):
+        seq_ops.GRU_PERSIST_FWD, seq_ops.GRU_PERSIST_BWD = fwd, bwd
+        g = reset_default_graph(device=dev, seed=0)
+        g.begin_step()
+        gen = torch.Generator(device=dev).manual_seed(3)
+        x = (torch.rand((F, B, D), device=dev, generator=gen) * 2 - 1).requires_grad_(True)
+        nf = torch.randint(0, F + 1, (B,), device=dev, generator=gen, dtype=torch.int32)
+        vs, d_in = [], D
+        for l in range(2):
+            vs.append((g.get_variable("l%d/wg" % l, (d_in + H, 2 * H), xavier_uniform), g.get_variable("l%d/bg" % l, (2 * H,), ones),
+                       g.get_variable("l%d/wc" % l, (d_in + H, H), xavier_uniform), g.get_variable("l%d/bc" % l, (H,), zeros)))
+            d_in = H
+        g.finalize()
+        h, finals = x, []
+        for l in range(2):
+            h, hf = seq_ops.gru_layer(h, *vs[l], nf)
+            finals.append(hf)
+        w = torch.randn((F, B, H), device=dev, generator=gen) * 0.01
+        ((h * w).sum() + (finals[0] * 0.01).sum()).backward()
+        torch.cuda.synchronize()
+        return [h.detach().clone(), x.grad.clone()] + [v.grad.clone() for lay in vs for v in lay]
+
+    try:
+        ref = run(False, False)
+        for fb in ((True, False), (True, True)):
+            got = run(*fb)
+            for a, b in zip(ref, got):
+                assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), fb
+    finally:
+        seq_ops.GRU_PERSIST_FWD, seq_ops.GRU_PERSIST_BWD = old
+    seq_ops.check_persist_errors()

@@ -276,6 +276,10 @@ SIGNATURES = {
     "yt8m_h2_degraded": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int, P]),
     "yt8m_clip_by_norm_f32": (c_int, [P, P, c_int64, c_float, P, P]),
     "yt8m_lstm_persist_set_pair": (c_int, [c_int]),
+    "yt8m_gru_persist_supported": (c_int, [c_int64, c_int64]),
+    "yt8m_gru_persist_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "yt8m_gru_persist_fwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
+    "yt8m_gru_persist_bwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P, c_int64, P]),
     "yt8m_h2_split_dropout": (c_int, [P, c_int64, c_int64, c_float, P, P, P, c_float, ctypes.c_uint64, c_int64, P]),
     "yt8m_h2_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P, P]),
     "yt8m_gemm_h1x2_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, P, c_float, c_float, P,

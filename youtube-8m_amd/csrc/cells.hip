@@ -128,6 +128,12 @@ __device__ __forceinline__ F4 block_sum4_256(F4 a, float* red /* 16 floats */) {
 }
 
 // one workgroup per batch row.  z row [4H] stays RAW (pre-normalisation): backward recomputes from it and `stats`.
+// Round 6: the kernel is a chain of dependent round trips on one wave per SIMD (128 workgroups at B = 128), so EVERYTHING it reads --
+// z, gamma / beta, c_prev, h_prev, num_frames -- is requested before the first reduction (it used to fetch gamma / beta / c_prev
+// behind the second one and the row's liveness in front of everything: 24 us per step against a 5 us launch floor), PT is the
+// compile-time units per thread (H <= 256 PT; the H = 1024 plugin shape runs PT = 4, not 8 half-masked slots), and the two
+// single-value reductions of the state normalisation ride on one barrier pair each.
+template <int PT>
 __global__ __launch_bounds__(256) void lnlstm_fwd_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ stats,
                                                          const float* __restrict__ c_prev, const float* __restrict__ h_prev,
@@ -137,31 +143,44 @@ __global__ __launch_bounds__(256) void lnlstm_fwd_kernel(const float* __restrict
   __shared__ float red[16];
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
-  const bool live = nf ? (t < nf[b]) : true;
-  if (!live) {
-    for (int64_t h = tid; h < H; h += 256) {
-      c_new[b * H + h] = c_prev[b * H + h];
-      h_new[b * H + h] = h_prev[b * H + h];
-      if (out) out[b * H + h] = 0.f;
+  const float* zr = z + b * 4 * H;
+  const float invH = 1.0f / (float)H;
+  float zv[4][PT], gm[5][PT], bt[5][PT], cpv[PT], hpv[PT];
+  const int nfb = nf ? nf[b] : 0x7fffffff;
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    const int64_t h = tid + p * 256;
+    const bool in = h < H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zv[g][p] = in ? zr[g * H + h] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { gm[g][p] = in ? gamma[g * H + h] : 0.f; bt[g][p] = in ? beta[g * H + h] : 0.f; }
+    cpv[p] = in ? c_prev[b * H + h] : 0.f;
+    hpv[p] = in ? h_prev[b * H + h] : 0.f;
+  }
+  if (t >= nfb) {                                                       // dynamic_rnn copy-through (block-uniform)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int64_t h = tid + p * 256;
+      if (h < H) {
+        c_new[b * H + h] = cpv[p];
+        h_new[b * H + h] = hpv[p];
+        if (out) out[b * H + h] = 0.f;
+      }
     }
     return;
   }
-  const float* zr = z + b * 4 * H;
-  const float invH = 1.0f / (float)H;
-  float zv[4][LN_PT];
   F4 s = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
-    const int64_t h = tid + p * 256;
+  for (int p = 0; p < PT; ++p)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { zv[g][p] = h < H ? zr[g * H + h] : 0.f; s.v[g] += zv[g][p]; }
-  }
+    for (int g = 0; g < 4; ++g) s.v[g] += zv[g][p];
   F4 mean = block_sum4_256(s, red);
 #pragma unroll
   for (int g = 0; g < 4; ++g) mean.v[g] *= invH;
   F4 q = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
+  for (int p = 0; p < PT; ++p) {
     const int64_t h = tid + p * 256;
 #pragma unroll
     for (int g = 0; g < 4; ++g) { const float d = zv[g][p] - mean.v[g]; if (h < H) q.v[g] += d * d; }
@@ -169,34 +188,34 @@ __global__ __launch_bounds__(256) void lnlstm_fwd_kernel(const float* __restrict
   F4 rstd = block_sum4_256(q, red);
 #pragma unroll
   for (int g = 0; g < 4; ++g) rstd.v[g] = rsqrtf(rstd.v[g] * invH + LN_EPS);
-  float cp[LN_PT], og[LN_PT];
+  float cp[PT], og[PT];
   float sc = 0.f;
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
+  for (int p = 0; p < PT; ++p) {
     const int64_t h = tid + p * 256;
     cp[p] = 0.f; og[p] = 0.f;
     if (h < H) {
       float y[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) y[g] = (zv[g][p] - mean.v[g]) * rstd.v[g] * gamma[g * H + h] + beta[g * H + h];
+      for (int g = 0; g < 4; ++g) y[g] = (zv[g][p] - mean.v[g]) * rstd.v[g] * gm[g][p] + bt[g][p];
       const float i = sigmoidf_(y[0]);
       const float gg = tanhf(y[1]) * keep_scale((uint64_t)(((int64_t)t * B + b) * H + h), seed, keep);
       const float f = sigmoidf_(y[2] + fb);
       og[p] = sigmoidf_(y[3]);
-      cp[p] = c_prev[b * H + h] * f + i * gg;
+      cp[p] = cpv[p] * f + i * gg;
       sc += cp[p];
     }
   }
   const float mean_s = block_sum_256(sc, red) * invH;
   float qs = 0.f;
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) { const int64_t h = tid + p * 256; const float d = cp[p] - mean_s; if (h < H) qs += d * d; }
+  for (int p = 0; p < PT; ++p) { const int64_t h = tid + p * 256; const float d = cp[p] - mean_s; if (h < H) qs += d * d; }
   const float rstd_s = rsqrtf(block_sum_256(qs, red) * invH + LN_EPS);
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
+  for (int p = 0; p < PT; ++p) {
     const int64_t h = tid + p * 256;
     if (h < H) {
-      const float cn = (cp[p] - mean_s) * rstd_s * gamma[4 * H + h] + beta[4 * H + h];
+      const float cn = (cp[p] - mean_s) * rstd_s * gm[4][p] + bt[4][p];
       const float hn = tanhf(cn) * og[p];
       c_new[b * H + h] = cn;
       h_new[b * H + h] = hn;
@@ -209,6 +228,7 @@ __global__ __launch_bounds__(256) void lnlstm_fwd_kernel(const float* __restrict
 
 // dyb[b, 5H] = gradient w.r.t. the five layer-norm OUTPUTS (-> dbeta by column sum), dyg = dyb * normalised input
 // (-> dgamma by column sum), dz[b,4H] = gradient w.r.t. the raw pre-activations.
+template <int PT>
 __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ stats,
                                                          const float* __restrict__ c_prev, const float* __restrict__ c_new,
@@ -221,37 +241,58 @@ __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict
   __shared__ float red[16];
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
-  const bool live = nf ? (t < nf[b]) : true;
-  if (!live) {
-    for (int64_t h = tid; h < H; h += 256) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) dz[b * 4 * H + g * H + h] = 0.f;
-#pragma unroll
-      for (int g = 0; g < 5; ++g) { dyb[b * 5 * H + g * H + h] = 0.f; dyg[b * 5 * H + g * H + h] = 0.f; }
-      dc_prev[b * H + h] = dc_cur[b * H + h];
-      dh_prev[b * H + h] = dh_cur[b * H + h];
-    }
-    return;
-  }
   const float* zr = z + b * 4 * H;
   const float invH = 1.0f / (float)H;
+  // every operand is requested up front (one round trip, not a chain of them behind the liveness word)
+  const int nfb = nf ? nf[b] : 0x7fffffff;
   float mean[5], rstd[5];
 #pragma unroll
   for (int g = 0; g < 5; ++g) { mean[g] = stats[b * 10 + 2 * g]; rstd[g] = stats[b * 10 + 2 * g + 1]; }
-  float n[4][LN_PT], dy[4][LN_PT], ns[LN_PT], dns[LN_PT], fv[LN_PT], iv[LN_PT], gv[LN_PT], tj[LN_PT], ks[LN_PT], cpv[LN_PT];
+  float zv[4][PT], gm[5][PT], bt[4][PT], cpv[PT], cnv[PT], dhv[PT], dcv[PT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    const int64_t h = tid + p * 256;
+    const bool in = h < H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { zv[g][p] = in ? zr[g * H + h] : 0.f; bt[g][p] = in ? beta[g * H + h] : 0.f; }
+#pragma unroll
+    for (int g = 0; g < 5; ++g) gm[g][p] = in ? gamma[g * H + h] : 0.f;
+    cpv[p] = in ? c_prev[b * H + h] : 0.f;
+    cnv[p] = in ? c_new[b * H + h] : 0.f;
+    dhv[p] = in ? dh_cur[b * H + h] : 0.f;
+    dcv[p] = in ? dc_cur[b * H + h] : 0.f;
+    if (dout && in && t < nfb) dhv[p] += dout[b * H + h];
+  }
+  if (t >= nfb) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int64_t h = tid + p * 256;
+      if (h < H) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dz[b * 4 * H + g * H + h] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) { dyb[b * 5 * H + g * H + h] = 0.f; dyg[b * 5 * H + g * H + h] = 0.f; }
+        dc_prev[b * H + h] = dcv[p];
+        dh_prev[b * H + h] = dhv[p];
+      }
+    }
+    return;
+  }
+  float n[4][PT], dy[4][PT], ns[PT], dns[PT], fv[PT], iv[PT], gv[PT], tj[PT], ks[PT];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
+  for (int p = 0; p < PT; ++p) {
     const int64_t h = tid + p * 256;
     ns[p] = dns[p] = 0.f;
+    fv[p] = iv[p] = gv[p] = tj[p] = ks[p] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) { n[g][p] = 0.f; dy[g][p] = 0.f; }
     if (h < H) {
       float y[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        n[g][p] = (zr[g * H + h] - mean[g]) * rstd[g];
-        y[g] = n[g][p] * gamma[g * H + h] + beta[g * H + h];
+        n[g][p] = (zv[g][p] - mean[g]) * rstd[g];
+        y[g] = n[g][p] * gm[g][p] + bt[g][p];
       }
       iv[p] = sigmoidf_(y[0]);
       tj[p] = tanhf(y[1]);
@@ -259,16 +300,15 @@ __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict
       gv[p] = tj[p] * ks[p];
       fv[p] = sigmoidf_(y[2] + fb);
       const float o = sigmoidf_(y[3]);
-      cpv[p] = c_prev[b * H + h];
       const float cpre = cpv[p] * fv[p] + iv[p] * gv[p];
       ns[p] = (cpre - mean[4]) * rstd[4];
-      const float tc = tanhf(c_new[b * H + h]);
-      const float dh = dh_cur[b * H + h] + (dout ? dout[b * H + h] : 0.f);
+      const float tc = tanhf(cnv[p]);
+      const float dh = dhv[p];
       dy[3][p] = dh * tc * o * (1.0f - o);
-      const float dcn = dc_cur[b * H + h] + dh * o * (1.0f - tc * tc);
+      const float dcn = dcv[p] + dh * o * (1.0f - tc * tc);
       dyb[b * 5 * H + 4 * H + h] = dcn;
       dyg[b * 5 * H + 4 * H + h] = dcn * ns[p];
-      dns[p] = dcn * gamma[4 * H + h];
+      dns[p] = dcn * gm[4][p];
       s1 += dns[p];
       s2 += dns[p] * ns[p];
     }
@@ -278,7 +318,7 @@ __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict
   const float m1 = a.v[0] * invH, m2 = a.v[1] * invH;
   F4 t1 = {{0.f, 0.f, 0.f, 0.f}}, t2 = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
+  for (int p = 0; p < PT; ++p) {
     const int64_t h = tid + p * 256;
     if (h < H) {
       const float dcp = rstd[4] * (dns[p] - m1 - ns[p] * m2);
@@ -291,7 +331,7 @@ __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict
       for (int g = 0; g < 4; ++g) {
         dyb[b * 5 * H + g * H + h] = dy[g][p];
         dyg[b * 5 * H + g * H + h] = dy[g][p] * n[g][p];
-        dy[g][p] *= gamma[g * H + h];                 // now d(normalised)
+        dy[g][p] *= gm[g][p];                         // now d(normalised)
         t1.v[g] += dy[g][p];
         t2.v[g] += dy[g][p] * n[g][p];
       }
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict
   t1 = block_sum4_256(t1, red);
   t2 = block_sum4_256(t2, red);
 #pragma unroll
-  for (int p = 0; p < LN_PT; ++p) {
+  for (int p = 0; p < PT; ++p) {
     const int64_t h = tid + p * 256;
     if (h < H) {
 #pragma unroll
@@ -469,7 +509,8 @@ extern "C" int yt8m_lnlstm_layer_fwd(float* z, const float* Wh, int64_t ldw, con
     }
     if (rc != YT8M_OK) return rc;
     ProfScope prof(F_LSTM, s);
-    hipLaunchKernelGGL(lnlstm_fwd_kernel, dim3((unsigned)B), dim3(256), 0, s, zt, gamma, beta, stats + t * B * 10, cs + t * BH,
+    auto kfn = H <= 512 ? lnlstm_fwd_kernel<2> : H <= 1024 ? lnlstm_fwd_kernel<4> : lnlstm_fwd_kernel<LN_PT>;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(256), 0, s, zt, gamma, beta, stats + t * B * 10, cs + t * BH,
                        hs + t * BH, cs + (t + 1) * BH, hs + (t + 1) * BH, out ? out + t * BH : nullptr, num_frames, (int)t, B, H,
                        forget_bias, keep_prob, seed);
   }
@@ -509,7 +550,8 @@ extern "C" int yt8m_lnlstm_layer_bwd(const float* z, const float* Wh, int64_t ld
     float* dzt = dz + t * B * 4 * H;
     {
       ProfScope prof(F_LSTM, s);
-      hipLaunchKernelGGL(lnlstm_bwd_kernel, dim3((unsigned)B), dim3(256), 0, s, z + t * B * 4 * H, gamma, beta,
+      auto kfn = H <= 512 ? lnlstm_bwd_kernel<2> : H <= 1024 ? lnlstm_bwd_kernel<4> : lnlstm_bwd_kernel<LN_PT>;
+      hipLaunchKernelGGL(kfn, dim3((unsigned)B), dim3(256), 0, s, z + t * B * 4 * H, gamma, beta,
                          stats + t * B * 10, cs + t * BH, cs + (t + 1) * BH, dh_cur, dc_cur, dout ? dout + t * BH : nullptr, dzt,
                          dyb + t * B * 5 * H, dyg + t * B * 5 * H, dc_prev, dh_prev, num_frames, (int)t, B, H, forget_bias,
                          keep_prob, seed);

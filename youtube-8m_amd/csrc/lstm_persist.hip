@@ -2166,6 +2166,8 @@ __global__ __launch_bounds__(768) void lstm_persist_bwd_kernel(PersistBwdArgs a)
 // workgroups resident, one per CU; a third grid taking CUs two others still wait for would hang all three).  The gate keeps the
 // last four launches (completion event, CUs); a new launch waits for every recorded one that does not fit beside it, newest
 // first.  Two half-chip backward recurrences of neighbouring layers thus run side by side, whole-chip forward launches chain.
+#include "gru_persist.inl"
+
 struct PersistGate {
   std::mutex mu;
   static constexpr int R = 4;
@@ -2767,3 +2769,152 @@ int persist_bwd_impl(const float* gates, const float* Wh, int64_t ldw, const flo
   return g_gate.done(dev, (int)grid, s);
 }
 }  // namespace
+
+
+// =====================================================================================================================
+// GRUCell on the persistent protocol (gru_persist.inl).  One launch runs T steps = 2T half-steps of a layer; the workspace holds the
+// control block and ONE exchange image per half-step (forward 2T + 1 images of [NT16 16, H]; backward T blocks of [NT16 16, 3H]).
+extern "C" int yt8m_gru_persist_supported(int64_t B, int64_t H) {
+  static const bool off = getenv("YT8M_GRU_PERSIST") != nullptr && atoi(getenv("YT8M_GRU_PERSIST")) == 0;
+  Geometry geo;
+  return (!off && persist_geometry(B, H, &geo) && geo.NQ >= 2) ? 1 : 0;
+}
+
+extern "C" int64_t yt8m_gru_persist_workspace_bytes(int64_t B, int64_t H, int64_t T) {
+  Geometry geo;
+  if (!persist_geometry(B, H, &geo)) return 0;
+  return ctl_padded(geo.NT16) + (3 * std::max<int64_t>(T, 1) + 3) * geo.NT16 * 16 * H * 4 + DBG_BYTES;
+}
+
+namespace {
+template <int NQ>
+int launch_gru_fwd(const GruFwdArgs& a, unsigned grid, hipStream_t s) {
+  if (a.pf >= 2) hipLaunchKernelGGL((gru_persist_fwd_kernel<NQ, 2>), dim3(grid), dim3(768), 0, s, a);
+  else if (a.pf == 1) hipLaunchKernelGGL((gru_persist_fwd_kernel<NQ, 1>), dim3(grid), dim3(768), 0, s, a);
+  else hipLaunchKernelGGL((gru_persist_fwd_kernel<NQ, 0>), dim3(grid), dim3(768), 0, s, a);
+  return yt8m::launch_status("gru_persist_fwd_kernel");
+}
+}  // namespace
+
+// Steps t0 .. t0 + T - 1 of one GRU layer.  zg [F,B,2H] / zc [F,B,H]: the hoisted input projections (+ biases) on entry, the
+// activations r | u / c on exit (what yt8m_gru_layer_fwd leaves there); hs [F+1,B,H] with hs[t0] given; rh [F,B,H]; out optional.
+// Same results as yt8m_gru_layer_fwd up to the K summation order of the recurrent products and the v_exp / v_rcp gate functions
+// (<= ~1.5e-7 absolute per activation).
+extern "C" int yt8m_gru_persist_fwd(float* zg, float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc, float* hs,
+                                    float* rh, float* out, const int32_t* num_frames, int64_t t0, int64_t T, int64_t B, int64_t H,
+                                    void* workspace, int64_t workspace_bytes, yt8m_stream_t stream) {
+  using namespace yt8m;
+  YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (T * B * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(zg && zc && Wg_h && Wc_h && hs && rh && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldg >= 2 * H && ldc >= H, YT8M_E_SHAPE, "leading dimension too small");
+  Geometry geo;
+  YT8M_REQUIRE(yt8m_gru_persist_supported(B, H) && persist_geometry(B, H, &geo), YT8M_E_SHAPE,
+               "shape not supported by the persistent GRU recurrence (see yt8m_gru_persist_supported)");
+  YT8M_REQUIRE(workspace_bytes >= yt8m_gru_persist_workspace_bytes(B, H, T), YT8M_E_SHAPE, "workspace too small");
+  YT8M_REQUIRE(T < (1 << 19), YT8M_E_SHAPE, "T too large");
+  hipStream_t s = as_stream(stream);
+  GruFwdArgs a;
+  a.zg = zg; a.zc = zc; a.Wg = Wg_h; a.Wc = Wc_h; a.ldg = ldg; a.ldc = ldc; a.hs = hs; a.rh = rh; a.out = out; a.nf = num_frames;
+  a.ctl = static_cast<unsigned*>(workspace) + CTL_STICKY;
+  a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + ctl_padded(geo.NT16));
+  a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H;
+  a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
+  const unsigned grid = (unsigned)(geo.NU * geo.RB);
+  int dev = 0;
+  device_cus(&dev);
+  a.stats = stats_ptr(dev);
+  ++g_stat_launches[dev];
+  g_stat_wgs[dev] += grid;
+  ProfScope prof(F_LSTM, s, 2.0 * (double)T * (double)B * (double)H * 3.0 * (double)H);
+  std::lock_guard<std::mutex> lk(g_gate.mu);
+  const int total_cus = device_cus(nullptr);
+  int grc = g_gate.admit(dev, (int)grid, std::max(0, total_cus - g_reserved_cus), s);
+  if (grc != YT8M_OK) return grc;
+  YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
+  hipLaunchKernelGGL(hx_pack_kernel, dim3(256), dim3(256), 0, s, hs + t0 * B * H, a.hx, (int)B, (int)H, geo.NT16);
+  int rc = launch_status("hx_pack_kernel");
+  if (rc != YT8M_OK) return rc;
+  switch (geo.NQ) {
+    case 2: rc = launch_gru_fwd<2>(a, grid, s); break;
+    case 4: rc = launch_gru_fwd<4>(a, grid, s); break;
+    case 6: rc = launch_gru_fwd<6>(a, grid, s); break;
+    default: rc = launch_gru_fwd<8>(a, grid, s); break;
+  }
+  if (rc != YT8M_OK) return rc;
+  return g_gate.done(dev, (int)grid, s);
+}
+
+// Backward of the same steps, last to first.  work [B,H]: dL/dh flowing into step t0 + T - 1 from later steps on entry (zeros, or
+// the final state's gradient), dL/dh_{t0 - 1} on exit -- launches over consecutive time ranges chain through it.  Writes dzg [F,B,2H]
+// and dzc [F,B,H] of the range (the operands of the hoisted weight-gradient / dx products), as yt8m_gru_layer_bwd does.
+extern "C" int yt8m_gru_persist_bwd(const float* zg, const float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc,
+                                    const float* hs, const float* dout, float* dzg, float* dzc, float* work, const int32_t* num_frames,
+                                    int64_t t0, int64_t T, int64_t B, int64_t H, void* workspace, int64_t workspace_bytes,
+                                    yt8m_stream_t stream) {
+  using namespace yt8m;
+  YT8M_REQUIRE(t0 >= 0 && T >= 0 && B >= 0 && H >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (T * B * H == 0) return YT8M_OK;
+  YT8M_REQUIRE(zg && zc && Wg_h && Wc_h && hs && dzg && dzc && work && workspace, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(ldg >= 2 * H && ldc >= H, YT8M_E_SHAPE, "leading dimension too small");
+  Geometry geo;
+  YT8M_REQUIRE(yt8m_gru_persist_supported(B, H) && persist_geometry(B, H, &geo), YT8M_E_SHAPE,
+               "shape not supported by the persistent GRU recurrence (see yt8m_gru_persist_supported)");
+  YT8M_REQUIRE(workspace_bytes >= yt8m_gru_persist_workspace_bytes(B, H, T), YT8M_E_SHAPE, "workspace too small");
+  YT8M_REQUIRE(T < (1 << 19), YT8M_E_SHAPE, "T too large");
+  hipStream_t s = as_stream(stream);
+  GruBwdArgs a;
+  a.zg = zg; a.zc = zc; a.Wg = Wg_h; a.Wc = Wc_h; a.ldg = ldg; a.ldc = ldc; a.hs = hs; a.dout = dout; a.dzg = dzg; a.dzc = dzc;
+  a.work = work; a.nf = num_frames;
+  a.ctl = static_cast<unsigned*>(workspace) + CTL_STICKY;
+  a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + ctl_padded(geo.NT16));
+  a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H;
+  a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
+  // YT8M_GRU_BWD_U=16: 16 units per workgroup (H / 16 unit groups, every result column of the MFMA tile used; row groups: as many as
+  // the CU budget YT8M_GRU_BWD_CUS allows while every workgroup keeps >= 2 tiles).  Default 8, the forward geometry (half of every B
+  // fragment zero, four tiles = four chains per workgroup at B = 128): 28.6 us/step against 36.7 (16 units, whole chip: two chains
+  // per workgroup leave every fragment fetch exposed) and 30.5 (16 units on 128 CUs) -- profiles/r6_gru_persist.txt.
+  static const int u_env = getenv("YT8M_GRU_BWD_U") ? atoi(getenv("YT8M_GRU_BWD_U")) : 8;
+  static const int cus_env = getenv("YT8M_GRU_BWD_CUS") ? atoi(getenv("YT8M_GRU_BWD_CUS")) : 0;
+  const bool u16 = u_env == 16;
+  if (u16) {
+    const int cus = device_cus(nullptr);
+    const int budget = (cus_env > 0 && cus_env < cus) ? cus_env : cus;
+    a.NU = (int)(H / 16);
+    int RB = std::max(1, budget / a.NU);
+    if (RB > geo.NT16 / 2) RB = std::max(1, geo.NT16 / 2);
+    a.RB = RB;
+    a.per = (RB <= 8 && (8 % RB) == 0 && (a.NU % (8 / RB)) == 0) ? 8 / RB : 0;
+    YT8M_REQUIRE((geo.NT16 + RB - 1) / RB <= MAX_LOCAL_TILES, YT8M_E_SHAPE, "batch too large for the persistent GRU recurrence");
+  }
+  const unsigned grid = (unsigned)(a.NU * a.RB);
+  int dev = 0;
+  device_cus(&dev);
+  a.stats = stats_ptr(dev);
+  ++g_stat_launches[dev];
+  g_stat_wgs[dev] += grid;
+  ProfScope prof(F_LSTM_BWD, s, 2.0 * (double)T * (double)B * (double)H * 3.0 * (double)H);
+  std::lock_guard<std::mutex> lk(g_gate.mu);
+  const int total_cus = device_cus(nullptr);
+  int grc = g_gate.admit(dev, (int)grid, std::max(0, total_cus - g_reserved_cus), s);
+  if (grc != YT8M_OK) return grc;
+  YT8M_HIP_CHECK(hipMemsetAsync(a.ctl, 0, (size_t)ctl_bytes(geo.NT16), s));
+  if (u16) {
+    switch (geo.NQ) {
+      case 2: hipLaunchKernelGGL((gru_persist_bwd_kernel<2, 16>), dim3(grid), dim3(768), 0, s, a); break;
+      case 4: hipLaunchKernelGGL((gru_persist_bwd_kernel<4, 16>), dim3(grid), dim3(768), 0, s, a); break;
+      case 6: hipLaunchKernelGGL((gru_persist_bwd_kernel<6, 16>), dim3(grid), dim3(768), 0, s, a); break;
+      default: hipLaunchKernelGGL((gru_persist_bwd_kernel<8, 16>), dim3(grid), dim3(768), 0, s, a); break;
+    }
+  } else {
+    switch (geo.NQ) {
+      case 2: hipLaunchKernelGGL((gru_persist_bwd_kernel<2, 8>), dim3(grid), dim3(768), 0, s, a); break;
+      case 4: hipLaunchKernelGGL((gru_persist_bwd_kernel<4, 8>), dim3(grid), dim3(768), 0, s, a); break;
+      case 6: hipLaunchKernelGGL((gru_persist_bwd_kernel<6, 8>), dim3(grid), dim3(768), 0, s, a); break;
+      default: hipLaunchKernelGGL((gru_persist_bwd_kernel<8, 8>), dim3(grid), dim3(768), 0, s, a); break;
+    }
+  }
+  int rc = launch_status("gru_persist_bwd_kernel");
+  if (rc != YT8M_OK) return rc;
+  return g_gate.done(dev, (int)grid, s);
+}

@@ -104,9 +104,20 @@ class _GruLayer(torch.autograd.Function):
         rh = torch.empty((F, B, H), dtype=torch.float32, device=dev)
         out = torch.empty((F, B, H), dtype=torch.float32, device=dev)
         nf = _nf(num_frames)
-        ws = ops._workspace(dev)
-        _lib.check(_lib.lib().yt8m_gru_layer_fwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(rh),
-                                                 _p(out), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _stream()))
+        L = _lib.lib()
+        # one persistent launch per direction (csrc/gru_persist.inl) where the shape allows it, else the per-step kernels (2 + 3 launches
+        # per time step); YT8M_GRU_PERSIST=0 forces the latter
+        ctx.pws = None
+        if F > 0 and L.yt8m_gru_persist_supported(B, H) and (GRU_PERSIST_FWD or GRU_PERSIST_BWD):
+            main = torch.cuda.current_stream(dev)
+            ctx.pws = _persist_ws(dev, main, "gru", L.yt8m_gru_persist_workspace_bytes(B, H, F))
+        if ctx.pws is not None and GRU_PERSIST_FWD:
+            _lib.check(L.yt8m_gru_persist_fwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(rh), _p(out),
+                                              _p(nf), 0, F, B, H, _p(ctx.pws), ctx.pws.numel(), _stream()))
+        else:
+            ws = ops._workspace(dev)
+            _lib.check(L.yt8m_gru_layer_fwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(rh),
+                                            _p(out), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _stream()))
         ctx.save_for_backward(x_tm)
         ctx.state = (zg, zc, hs, rh, nf, Wg, bg, Wc, bc)
         ctx.bf16 = bf
@@ -126,10 +137,20 @@ class _GruLayer(torch.autograd.Function):
         work = torch.empty((3, B, H), dtype=torch.float32, device=dev)
         dout = None if dout is None else _f32c(dout)
         dh_final = None if dh_final is None else _f32c(dh_final)
-        ws = ops._workspace(dev)
-        _lib.check(_lib.lib().yt8m_gru_layer_bwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(dout),
-                                                 _p(dh_final), _p(dzg), _p(dzc), _p(work), _p(nf), F, B, H, _p(ws),
-                                                 ws.numel() * 4, _stream()))
+        if ctx.pws is not None and GRU_PERSIST_BWD:
+            if dh_final is not None:
+                work[0].copy_(dh_final)
+            else:
+                work[0].zero_()
+            _lib.check(_lib.lib().yt8m_gru_persist_bwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(dout),
+                                                       _p(dzg), _p(dzc), _p(work), _p(nf), 0, F, B, H, _p(ctx.pws), ctx.pws.numel(),
+                                                       _stream()))
+            ctx.pws = None
+        else:
+            ws = ops._workspace(dev)
+            _lib.check(_lib.lib().yt8m_gru_layer_bwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(dout),
+                                                     _p(dh_final), _p(dzg), _p(dzc), _p(work), _p(nf), F, B, H, _p(ws),
+                                                     ws.numel() * 4, _stream()))
         x2, g2, c2 = x_tm.view(F * B, Din), dzg.view(F * B, 2 * H), dzc.view(F * B, H)
         bf = ctx.bf16
         if Wg.grad is not None:
@@ -398,6 +419,12 @@ def check_persist_errors():
     if err is not None:
         raise err
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
+# GRUCell on the persistent protocol (csrc/gru_persist.inl), per direction; the library switch YT8M_GRU_PERSIST=0 turns both off.
+# Measured at B = 128, H = 1024, F = 300 (profiles/r6_gru_persist.txt): forward 13.9 us/step in one launch against 17.6 in 600 -> ON;
+# backward 28.6 us/step against 20.3 for the three per-step launches (two exchange rounds per step on a K = 3H reduction: every
+# item's fragment fetch is exposed with four tiles per workgroup) -> parity-tested, OPT-IN.
+GRU_PERSIST_FWD = _os.environ.get("YT8M_GRU_PERSIST_FWD", "1") != "0"
+GRU_PERSIST_BWD = _os.environ.get("YT8M_GRU_PERSIST_BWD", "0") != "0"
 PERSIST_CHECK = _os.environ.get("YT8M_PERSIST_CHECK", "0") == "1"  # debug: synchronise + check the timeout word after each launch
 X3 = _os.environ.get("YT8M_GEMM_X3", "1") != "0"      # hoisted fp32 products on the bf16 pipe (three-plane split, csrc/gemm_x3.hip)
 X3_MIN_ROWS = 1024                                      # F * B below which the fp32-MFMA kernel's smaller tiles win
