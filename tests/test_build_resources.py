@@ -43,11 +43,37 @@ def remarks():
     return {**a, **b}
 
 
+def _scratch_loads(src, names):
+    """scratch_load instructions per function of `names` in the ISA of `src` (a stack object that is only ever STORED to -- the
+    compiler's dead copy of a few resident weight fragments in the round-6 GRU backward kernel -- costs a handful of stores in the
+    prologue and nothing in the loop; one that is loaded from is a spill by another name)."""
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "--cuda-device-only", "-S", src, "-o", "-"]
+    p = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out, cur = {}, None
+    for line in p.stdout.splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1) if m.group(1) in names else None
+            if cur:
+                out[cur] = 0
+        elif cur and "scratch_load" in line:
+            out[cur] += 1
+        elif cur and "s_endpgm" in line:
+            cur = None
+    return out
+
+
 def test_hot_kernels_do_not_spill(remarks):
     assert len(remarks) > 20
     # (SGPR spills go to VGPR lanes, not to memory: the image-writing backward variants have ~25 of them and no scratch)
-    spilled = {k: v for k, v in remarks.items() if v.get("VGPRs Spill", 0) or v.get("ScratchSize", 0)}
+    spilled = {k: v for k, v in remarks.items() if v.get("VGPRs Spill", 0)}
     assert not spilled, spilled
+    stack = {k for k, v in remarks.items() if v.get("ScratchSize", 0)}
+    assert all("gru_persist_bwd_kernel" in k for k in stack), stack            # nothing else may own a stack object at all
+    if stack:
+        loads = _scratch_loads("lstm_persist.hip", stack)
+        assert set(loads) == stack and not any(loads.values()), loads
 
 
 def test_recurrences_keep_three_waves_per_simd_and_gemms_two(remarks):

@@ -346,15 +346,11 @@ __global__ __launch_bounds__(768) void gru_persist_bwd_kernel(GruBwdArgs a) {
   // (k over 2H = (w NQG + q - NQ) 16 + ..; B[k][n] = Wg[ug U + n][k]); columns n >= U are zero.
   auto w_frag = [&](int q) -> float4 {
     const int i16 = lane & 15, kq = lane >> 4;
-    if (i16 >= U) return make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < NQ) {
-      const long long k = (long long)(w * NQ + q) * 16 + kq * 4;
-      const float* p = a.Wc + (long long)(ug * U + i16) * a.ldc + k;
-      return make_float4(p[0], p[1], p[2], p[3]);
-    }
-    const long long k = (long long)(w * NQG + (q - NQ)) * 16 + kq * 4;
-    const float* p = a.Wg + (long long)(ug * U + i16) * a.ldg + k;
-    return make_float4(p[0], p[1], p[2], p[3]);
+    const int n = i16 < U ? i16 : 0;                        // (branch-free: lanes of the zero columns load unit 0 and mask it)
+    const float msk = i16 < U ? 1.0f : 0.0f;
+    const float* p = q < NQ ? a.Wc + (long long)(ug * U + n) * a.ldc + (long long)(w * NQ + q) * 16 + kq * 4
+                            : a.Wg + (long long)(ug * U + n) * a.ldg + (long long)(w * NQG + (q - NQ)) * 16 + kq * 4;
+    return make_float4(p[0] * msk, p[1] * msk, p[2] * msk, p[3] * msk);
   };
   note_placement(a.ctl);
   if (tid < NSLOT) { lds_cnt[tid] = 0; lds_free[tid] = 0; }
@@ -371,7 +367,6 @@ __global__ __launch_bounds__(768) void gru_persist_bwd_kernel(GruBwdArgs a) {
     float4 Wr[HQ];
 #pragma unroll
     for (int q = 0; q < HQ; ++q) Wr[q] = w_frag(q);
-    auto wq = [&](int q) -> float4 { return q < HQ ? Wr[q < HQ ? q : 0] : Wl[w][q - HQ][lane]; };
     // ONE fragment buffer (16 float4 at H = 1024: two would not fit beside the resident weights at 12 waves per CU), refilled in
     // place: item k + 1's q-th fragment is requested into slot q right after item k's product has consumed it.  The image of item
     // k + 1 must be complete before the first refill: polled at the start of item k, waited for at q = RQ (the slots below RQ are
@@ -423,9 +418,13 @@ __global__ __launch_bounds__(768) void gru_persist_bwd_kernel(GruBwdArgs a) {
         }
         if (q < nq) {
           const float4 av = A[q];
+          // weights of q-group q: candidate slots [0, NQ), gate slots [NQ, 3 NQ) of the wave's table; slots below HQ are registers
           float4 bv;
-          if (gates) bv = wq(NQ + q);
-          else bv = wq(q < NQ ? q : 0);
+          if (gates) {
+            bv = (NQ + q) < HQ ? Wr[(NQ + q) < HQ ? (NQ + q) : 0] : Wl[w][(NQ + q) < HQ ? 0 : (NQ + q) - HQ][lane];
+          } else {
+            bv = q < HQ ? Wr[q < HQ ? q : 0] : Wl[w][q < HQ ? 0 : q - HQ][lane];
+          }
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
