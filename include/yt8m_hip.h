@@ -218,6 +218,21 @@ int yt8m_gemm_x1x3_nt_ex(int64_t M, int64_t N, int64_t K, const void* A1, int64_
  * yt8m_gemm_x3_nt_grouped (lda / ldb = K-block strides, 0 = exact). */
 int yt8m_bf16_image(const float* src, int64_t R, int64_t C, int64_t ld, float scale, void* plain, void* trans, yt8m_stream_t stream);
 int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs, void* workspace, int64_t workspace_bytes, yt8m_stream_t stream);
+/* Round 6: yt8m_gemm_b1_nt_grouped whose outputs flagged in c_bf16_mask (bit i = problem i) are bf16 matrices -- C points
+ * at bf16 elements, ldc counts them (ldc % 4 == 0, C 16-byte aligned), beta must be 0; accumulation stays fp32, one rounding to nearest even
+ * after the bias.  The MoE logits of the bf16 configuration (W/all_video_models/moe_model.py:54-64 under --compute_dtype=bfloat16): half
+ * the bytes written by the product and read by yt8m_moe_mix_fwd_bf16z / yt8m_moe_mix_bwd_bf16_images_z16 behind it.  The host mirror takes
+ * this form only with YT8M_Z16_LOGITS=1: -3 % on the configs[4] step, but one full-size gradient checksum of that configuration leaves the
+ * golden replay's bf16 tolerance (DESIGN_LOG 11.7). */
+int yt8m_gemm_b1_nt_grouped_bf16c(int nprob, const yt8m_gemm_problem* probs, unsigned c_bf16_mask, void* workspace, int64_t workspace_bytes,
+                                  yt8m_stream_t stream);
+/* p[B,V] = sum_m softmax(Zg[b,l,:])[m] sigmoid(Ze[b,l,m]) on bf16 logits Zg [B,3V], Ze [B,2V] (M == 2; B V % 4 == 0; 16-byte aligned). */
+int yt8m_moe_mix_fwd_bf16z(const void* Zg, const void* Ze, float* p, int64_t B, int64_t V, int M, yt8m_stream_t stream);
+/* yt8m_moe_mix_bwd_bf16_images reading bf16 logits. */
+int yt8m_moe_mix_bwd_bf16_images_z16(const void* Zg, const void* Ze, const float* dp, const void* labels, int label_dtype, int64_t B,
+                                     int64_t V, int M, float eps, float dscale, const float* upstream_dev, void* dZg_img, int64_t g_kb,
+                                     void* dZg_t_img, int64_t gt_kb, void* dZe_img, int64_t e_kb, void* dZe_t_img, int64_t et_kb,
+                                     float* be_part, yt8m_stream_t stream);
 /* one-plane forms of yt8m_x3_split_colsum and yt8m_gemm_x1x3_nt_ex (the recurrent stack in bf16-operand mode: hoisted products on
  * bf16 roundings of their operands, the recurrence itself stays fp32-grade) */
 int yt8m_bf16_image_colsum(const float* src, int64_t R, int64_t C, int64_t ld, float scale, const float* rowscale, void* plain,

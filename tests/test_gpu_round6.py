@@ -307,3 +307,41 @@ def test_gru_layer_op_with_persistent_recurrences_matches_the_per_step_op(dev):
     finally:
         seq_ops.GRU_PERSIST_FWD, seq_ops.GRU_PERSIST_BWD = old
     seq_ops.check_persist_errors()
+
+
+def test_bf16_logits_of_the_moe_head_product_and_the_mixing_passes_that_read_them(dev):
+    """Round 6 (W/all_video_models/moe_model.py:54-64 under --compute_dtype=bfloat16): the b1 product writes the logits as
+    bf16 (fp32 accumulation, ONE rounding after the bias) -- bit for bit the bf16 rounding of its fp32 output; the mixing pass and the
+    fused mixing backward that read bf16 logits equal the fp32-logit passes fed with those rounded logits bit for bit."""
+    lib = L.lib()
+    B, D, V, M = 512, 512, 1036, 2
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn((B, D), device=dev, generator=g)
+    Wg = torch.randn((D, 3 * V), device=dev, generator=g) * 0.05
+    We = torch.randn((D, 2 * V), device=dev, generator=g) * 0.05
+    be = torch.randn((2 * V,), device=dev, generator=g) * 0.1
+    xi = ops.bf16_image(x)
+    WgT, WeT = ops.bf16_image(Wg, transpose=True), ops.bf16_image(We, transpose=True)
+    Zg32, Ze32 = ops.gemm_b1_grouped([dict(A=xi, B=WgT), dict(A=xi, B=WeT, bias=be)])
+    Zg16, Ze16 = ops.gemm_b1_grouped([dict(A=xi, B=WgT, out_dtype=torch.bfloat16), dict(A=xi, B=WeT, bias=be, out_dtype=torch.bfloat16)])
+    assert Zg16.dtype == torch.bfloat16 and torch.equal(Zg16, Zg32.to(torch.bfloat16)) and torch.equal(Ze16, Ze32.to(torch.bfloat16))
+    # mixing forward
+    p16 = ops.moe_mix_fwd(Zg16, Ze16, V, M)
+    p32 = ops.moe_mix_fwd(Zg16.float(), Ze16.float(), V, M)
+    assert float((p16 - p32).abs().max()) <= 2e-7 and float(p16.min()) >= 0 and float(p16.max()) <= 1   # (same arithmetic; fma placement differs)
+    # fused mixing backward on images, from dp and from labels
+    kb = lambda K: (K + 15) // 16
+    mk = lambda rows, K: torch.zeros(max(lib.yt8m_x3_image_bytes(rows, K) // 3, 16), dtype=torch.uint8, device=dev)
+    dp = torch.randn((B, V), device=dev, generator=g) * 0.01
+    y = (torch.rand((B, V), device=dev, generator=g) < 0.01).to(torch.uint8)
+    for dpv, lab in ((dp, None), (None, y)):
+        outs = []
+        for fn, zg, ze in ((lib.yt8m_moe_mix_bwd_bf16_images_z16, Zg16, Ze16), (lib.yt8m_moe_mix_bwd_bf16_images, Zg16.float(), Ze16.float())):
+            imgs = [mk(B, 3 * V), mk(3 * V, B), mk(B, 2 * V), mk(2 * V, B)]
+            part = torch.zeros((lib.yt8m_moe_mix_bwd_bf16_partial_rows(B), 2 * V), device=dev)
+            L.check(fn(_p(zg), _p(ze), _p(dpv), _p(lab), 0, B, V, M, 1e-6, 1.0 / B, None, _p(imgs[0]), kb(3 * V), _p(imgs[1]), kb(B), _p(imgs[2]),
+                       kb(2 * V), _p(imgs[3]), kb(B), _p(part), _st()))
+            outs.append(imgs + [part])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert int(outs[0][0].long().sum()) != 0

@@ -92,6 +92,7 @@ SIGNATURES = {
                                      c_int64, P]),
     "yt8m_bf16_image": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "yt8m_gemm_b1_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
+    "yt8m_gemm_b1_nt_grouped_bf16c": (c_int, [c_int, ctypes.POINTER(GemmProblem), ctypes.c_uint, P, c_int64, P]),
     "yt8m_x3_split_ex": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "yt8m_x3_split_colsum": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P, P, P, P, P]),
     "yt8m_x3_set_combine": (c_int, [c_int]),
@@ -163,6 +164,9 @@ SIGNATURES = {
                                       P, c_int64, P, c_int64, P, P]),
     "yt8m_moe_mix_bwd_bf16_images": (c_int, [P, P, P, P, c_int, c_int64, c_int64, c_int, c_float, c_float, P, P, c_int64, P, c_int64,
                                       P, c_int64, P, c_int64, P, P]),
+    "yt8m_moe_mix_bwd_bf16_images_z16": (c_int, [P, P, P, P, c_int, c_int64, c_int64, c_int, c_float, c_float, P, P, c_int64, P, c_int64,
+                                      P, c_int64, P, c_int64, P, P]),
+    "yt8m_moe_mix_fwd_bf16z": (c_int, [P, P, P, c_int64, c_int64, c_int, P]),
     "yt8m_act_fwd_f32": (c_int, [c_int, P, P, c_int64, P]),
     "yt8m_act_bwd_f32": (c_int, [c_int, P, P, P, c_int64, P]),
     "yt8m_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),

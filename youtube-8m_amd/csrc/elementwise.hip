@@ -33,6 +33,36 @@ __global__ __launch_bounds__(256) void moe_mix_fwd_kernel(const float* __restric
   p[i] = num / den;
 }
 
+// The same mixing on bf16 logits (round 6: the b1 GEMM of the bf16 configuration writes them as bf16 -- yt8m_gemm_b1_nt_grouped_bf16c),
+// M = 2: a thread owns four consecutive labels = 12 gate + 8 expert logits = 24 + 16 contiguous bytes in, 16 out.
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__global__ __launch_bounds__(256) void moe_mix_fwd_bf16z_kernel(const unsigned short* __restrict__ Zg, const unsigned short* __restrict__ Ze,
+                                                                float* __restrict__ p, int64_t BV4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BV4) return;
+  const uint2* gp = reinterpret_cast<const uint2*>(Zg + i * 12);
+  const uint2 g0 = gp[0], g1 = gp[1], g2 = gp[2];
+  const uint4 ev = *reinterpret_cast<const uint4*>(Ze + i * 8);
+  const unsigned gw[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+  const unsigned ew[4] = {ev.x, ev.y, ev.z, ev.w};
+  float g[12], e[8];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { g[2 * k] = bf16_lo(gw[k]); g[2 * k + 1] = bf16_hi(gw[k]); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { e[2 * k] = bf16_lo(ew[k]); e[2 * k + 1] = bf16_hi(ew[k]); }
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = g[3 * j], a1 = g[3 * j + 1], a2 = g[3 * j + 2];
+    const float mx = fmaxf(a0, fmaxf(a1, a2));
+    const float x0 = expf(a0 - mx), x1 = expf(a1 - mx), x2 = expf(a2 - mx);
+    const float num = x0 * (1.0f / (1.0f + expf(-e[2 * j]))) + x1 * (1.0f / (1.0f + expf(-e[2 * j + 1])));
+    o[j] = num / (x0 + x1 + x2);
+  }
+  *reinterpret_cast<float4*>(p + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // in-place backward: Zg <- dL/dZg, Ze <- dL/dZe  
 template <int MT>
 __global__ __launch_bounds__(256) void moe_mix_bwd_kernel(float* __restrict__ Zg, float* __restrict__ Ze,
@@ -567,6 +597,23 @@ extern "C" int yt8m_moe_mix_fwd(const float* Zg, const float* Ze, float* p, int6
     default: hipLaunchKernelGGL((moe_mix_fwd_kernel<0>), grid, block, 0, s, Zg, Ze, p, BV, M); break;
   }
   return launch_status("moe_mix_fwd_kernel");
+}
+
+// p = mix(Zg, Ze) with bf16 logits Zg [B, 3V], Ze [B, 2V] (M = 2 only; B V % 4 == 0, 16-byte aligned operands)
+extern "C" int yt8m_moe_mix_fwd_bf16z(const void* Zg, const void* Ze, float* p, int64_t B, int64_t V, int M, yt8m_stream_t stream) {
+  YT8M_REQUIRE(M == 2, YT8M_E_BADARG, "the bf16-logit mixing pass is built for num_mixtures == 2");
+  YT8M_REQUIRE(B >= 0 && V >= 0, YT8M_E_SHAPE, "negative dimension");
+  if (B * V == 0) return YT8M_OK;
+  YT8M_REQUIRE(Zg && Ze && p, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(((B * V) & 3) == 0, YT8M_E_SHAPE, "B V must be a multiple of 4");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(Zg) | reinterpret_cast<uintptr_t>(Ze) | reinterpret_cast<uintptr_t>(p)) & 15) == 0, YT8M_E_BADARG,
+               "operands must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t n4 = B * V / 4;
+  hipLaunchKernelGGL(moe_mix_fwd_bf16z_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, static_cast<const unsigned short*>(Zg),
+                     static_cast<const unsigned short*>(Ze), p, n4);
+  return launch_status("moe_mix_fwd_bf16z_kernel");
 }
 
 extern "C" int yt8m_moe_mix_bwd(float* Zg, float* Ze, const float* dp, int64_t B, int64_t V, int M,

@@ -64,7 +64,32 @@ struct XArgs {
   // fold_device_scales
   const float* dsa;
   const float* dsb;
+  // round 6: C is a bf16 matrix (ldc in bf16 elements; beta = 0 only): the MoE logits of the bf16 configuration leave the b1 kernel at the
+  // configuration's own precision -- half the write here, half the read of the two mixing passes behind it (yt8m_gemm_b1_nt_grouped_bf16c)
+  int c_bf16;
 };
+// round-to-nearest-even bf16 bits of a float (NaN stays NaN)
+__device__ __forceinline__ unsigned c_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+// four consecutive elements of a row of C at element offset `off` (fp32: 16-byte store; bf16: 8-byte store)
+__device__ __forceinline__ void store_c4(const XArgs& g, int64_t off, float4 v) {
+  if (g.c_bf16) {
+    uint2 w;
+    w.x = c_bf16_bits(v.x) | (c_bf16_bits(v.y) << 16);
+    w.y = c_bf16_bits(v.z) | (c_bf16_bits(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + off) = w;
+  } else {
+    *reinterpret_cast<float4*>(g.C + off) = v;
+  }
+}
+__device__ __forceinline__ void store_c1(const XArgs& g, int64_t off, float v) {
+  if (g.c_bf16) reinterpret_cast<unsigned short*>(g.C)[off] = (unsigned short)c_bf16_bits(v);
+  else g.C[off] = v;
+}
 __device__ __forceinline__ float4 affine(const XArgs& g, float4 v, int row, int col) {
   if (g.cs) {                                                        // (N % 4 == 0 and 16-byte aligned cs: checked by the host)
     const float4 cv = *reinterpret_cast<const float4*>(g.cs + col);
@@ -167,7 +192,7 @@ __device__ __forceinline__ void finish_store(const XArgs& g, float4 v, int row, 
       const float4 o = *reinterpret_cast<const float4*>(c);
       v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
-    *reinterpret_cast<float4*>(c) = v;
+    store_c4(g, (int64_t)row * g.ldc + col, v);
     return;
   }
   const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -176,7 +201,7 @@ __device__ __forceinline__ void finish_store(const XArgs& g, float4 v, int row, 
     if (col + k < g.N) {
       float o = vv[k] + (g.bias ? g.bias[col + k] : 0.f);
       if (g.accumulate) o += c[k];
-      c[k] = o;
+      store_c1(g, (int64_t)row * g.ldc + col + k, o);
     }
   }
 }
@@ -273,7 +298,7 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
           w.x += bv.x; w.y += bv.y; w.z += bv.z; w.w += bv.w;
         }
         if (g.accumulate) { w.x += oldc[u].x; w.y += oldc[u].y; w.z += oldc[u].z; w.w += oldc[u].w; }
-        *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = w;
+        store_c4(g, (int64_t)row * g.ldc + col, w);
       }
     }
     return;
@@ -303,13 +328,13 @@ __device__ __forceinline__ void x_epilogue(const XGroup& G, const XArgs& g, f32x
             const float4 o = *reinterpret_cast<const float4*>(c);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
           }
-          *reinterpret_cast<float4*>(c) = v;
+          store_c4(g, (int64_t)row * g.ldc + col, v);
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int e = 0; e < 4 && col + e < g.N; ++e) {
             float t = vv[e] + (g.bias ? g.bias[col + e] : 0.f);
             if (g.accumulate) t += c[e];
-            c[e] = t;
+            store_c1(g, (int64_t)row * g.ldc + col + e, t);
           }
         }
       }
@@ -1562,7 +1587,7 @@ TileCounters g_cnt;
 template <int PA>
 int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, const float* cs, float cs_scale, float alpha,
               void* workspace, int64_t workspace_bytes, yt8m_stream_t stream, const float* const* dsa = nullptr,
-              const float* const* dsb = nullptr, const float* alphas = nullptr) {
+              const float* const* dsb = nullptr, const float* alphas = nullptr, unsigned c_bf16_mask = 0) {
   XGroup G;
   G.nprob = 0;
   // one 144 KiB workgroup per CU.  YT8M_X3_SLOTS (tuning aid): the CU count the K-part choice assumes -- beside a half-chip
@@ -1591,6 +1616,9 @@ int x3_launch(int nprob, const yt8m_gemm_problem* probs, const float* rscale, co
     g.accumulate = q.beta != 0.f;
     g.rscale = rscale; g.cs = cs; g.cs_scale = cs_scale; g.alpha = alphas ? alphas[i] : alpha;
     g.dsa = dsa ? dsa[i] : nullptr; g.dsb = dsb ? dsb[i] : nullptr;
+    g.c_bf16 = (int)((c_bf16_mask >> i) & 1u);
+    YT8M_REQUIRE(!g.c_bf16 || (q.beta == 0.f && (q.ldc & 3) == 0 && ((uintptr_t)q.C & 15) == 0), YT8M_E_BADARG,
+                 "a bf16 output takes beta = 0, ldc % 4 == 0 and a 16-byte aligned C");
     YT8M_REQUIRE(!(g.dsa || g.dsb || g.alpha != 1.0f) || (q.N % 4) == 0, YT8M_E_SHAPE, "a scaled product needs N % 4 == 0");
     // the last, partial round of this problem alone: S K-parts per tile; cost in K-steps = rounds x (steps per part + ramp)
     // + the fixup pass
@@ -1698,6 +1726,15 @@ extern "C" int yt8m_gemm_b1_nt_grouped(int nprob, const yt8m_gemm_problem* probs
                                        yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
   return x3_launch<0>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream);
+}
+
+// yt8m_gemm_b1_nt_grouped whose outputs flagged in `c_bf16_mask` (bit i = problem i) are bf16 matrices: C points at bf16 elements, ldc
+// counts them, beta must be 0.  Accumulation stays fp32; the value is rounded to nearest even once, after bias.  The logits of the MoE
+// heads in the bf16 configuration (configs[4]): half the bytes written here and read by the mixing passes.
+extern "C" int yt8m_gemm_b1_nt_grouped_bf16c(int nprob, const yt8m_gemm_problem* probs, unsigned c_bf16_mask, void* workspace,
+                                             int64_t workspace_bytes, yt8m_stream_t stream) {
+  YT8M_REQUIRE(nprob >= 1 && nprob <= 4 && probs, YT8M_E_BADARG, "1..4 problems per launch");
+  return x3_launch<0>(nprob, probs, nullptr, nullptr, 0.f, 1.0f, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, c_bf16_mask);
 }
 
 // C[M,N] (+)= alpha_i / (S_a S_b) . A . B^T (+ bias) from the h2 images of A ([M rows, K]) and B ([N rows, K]) (yt8m_h2_split):

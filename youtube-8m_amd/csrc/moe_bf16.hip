@@ -35,8 +35,9 @@ __device__ __forceinline__ int64_t img_piece(int64_t row, int64_t k8, int64_t KB
   const int r = (int)(row & 31);
   return ((row >> 5) * KB + (k8 >> 4)) * 512 + r * 16 + ((int)((k8 >> 3) & 1) ^ ((r >> 3) & 1)) * 8;
 }
-template <int MODE, typename LT, bool IMG>
-__global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __restrict__ Zg, const float* __restrict__ Ze,
+// ZT: float logits, or unsigned short = bf16 logits (round 6: written by yt8m_gemm_b1_nt_grouped_bf16c; V % 4 == 0)
+template <int MODE, typename LT, bool IMG, typename ZT = float>
+__global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const ZT* __restrict__ Zg, const ZT* __restrict__ Ze,
                                                                const float* __restrict__ dp, const LT* __restrict__ y,
                                                                int64_t B, int64_t V, float eps, float dscale,
                                                                const float* __restrict__ up_dev,
@@ -66,25 +67,43 @@ __global__ __launch_bounds__(256) void moe_mix_bwd_bf16_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 4; ++k) dd[it][k] = 0.f;
     if (b >= B || l0 >= V) continue;
-    const float* zg = Zg + b * V * 3 + l0 * 3;
-    const float* ze = Ze + b * V * 2 + l0 * 2;
+    const ZT* zg = Zg + b * V * 3 + l0 * 3;
+    const ZT* ze = Ze + b * V * 2 + l0 * 2;
     const bool full = l0 + 4 <= V;
+    if constexpr (sizeof(ZT) == 2) {
+      if (full && (reinterpret_cast<uintptr_t>(zg) & 7) == 0 && (reinterpret_cast<uintptr_t>(ze) & 15) == 0) {
+        const uint2* gp = reinterpret_cast<const uint2*>(zg);
+        const uint2 g0 = gp[0], g1 = gp[1], g2 = gp[2];
+        const uint4 ev = *reinterpret_cast<const uint4*>(ze);
+        const unsigned gw[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+        const unsigned ew[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { g[it][2 * k] = __uint_as_float(gw[k] << 16); g[it][2 * k + 1] = __uint_as_float(gw[k] & 0xffff0000u); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[it][2 * k] = __uint_as_float(ew[k] << 16); e[it][2 * k + 1] = __uint_as_float(ew[k] & 0xffff0000u); }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) if (l0 + k / 3 < V) g[it][k] = bf2f((unsigned short)zg[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (l0 + k / 2 < V) e[it][k] = bf2f((unsigned short)ze[k]);
+      }
+    } else
     if (full && ((reinterpret_cast<uintptr_t>(zg) | reinterpret_cast<uintptr_t>(ze)) & 15) == 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(zg + 4 * k);
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(zg) + 4 * k);
         g[it][4 * k] = v.x; g[it][4 * k + 1] = v.y; g[it][4 * k + 2] = v.z; g[it][4 * k + 3] = v.w;
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(ze + 4 * k);
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ze) + 4 * k);
         e[it][4 * k] = v.x; e[it][4 * k + 1] = v.y; e[it][4 * k + 2] = v.z; e[it][4 * k + 3] = v.w;
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 12; ++k) if (l0 + k / 3 < V) g[it][k] = zg[k];
+      for (int k = 0; k < 12; ++k) if (l0 + k / 3 < V) g[it][k] = (float)zg[k];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) if (l0 + k / 2 < V) e[it][k] = ze[k];
+      for (int k = 0; k < 8; ++k) if (l0 + k / 2 < V) e[it][k] = (float)ze[k];
     }
     if (MODE == 0) {
       const float* d = dp + b * V + l0;
@@ -218,13 +237,17 @@ using namespace yt8m;
 extern "C" int64_t yt8m_moe_mix_bwd_bf16_partial_rows(int64_t B) { return (B + TR - 1) / TR; }
 
 namespace {
-int mix_bwd_bf16_launch(bool img, const float* Zg, const float* Ze, const float* dp, const void* labels, int label_dtype, int64_t B, int64_t V,
+int mix_bwd_bf16_launch(bool img, const void* Zgv, const void* Zev, bool z16, const float* dp, const void* labels, int label_dtype, int64_t B, int64_t V,
                         int M, float eps, float dscale, const float* upstream_dev, void* dZg_b, int64_t gb_ld, void* dZg_t, int64_t gt_ld,
                         void* dZe_b, int64_t eb_ld, void* dZe_t, int64_t et_ld, float* be_part, yt8m_stream_t stream) {
   YT8M_REQUIRE(M == 2, YT8M_E_BADARG, "the bf16 mixing backward is built for num_mixtures == 2");
   YT8M_REQUIRE(B >= 0 && V >= 0, YT8M_E_SHAPE, "negative dimension");
   if (B * V == 0) return YT8M_OK;
-  YT8M_REQUIRE(Zg && Ze && (dp || labels) && dZg_b && dZg_t && dZe_b && dZe_t, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(Zgv && Zev && (dp || labels) && dZg_b && dZg_t && dZe_b && dZe_t, YT8M_E_BADARG, "null operand");
+  const float* Zg = static_cast<const float*>(Zgv);
+  const float* Ze = static_cast<const float*>(Zev);
+  const unsigned short* Zg16 = static_cast<const unsigned short*>(Zgv);
+  const unsigned short* Ze16 = static_cast<const unsigned short*>(Zev);
   YT8M_REQUIRE(!(dp && labels), YT8M_E_BADARG, "give either dp or labels");
   if (img) {
     YT8M_REQUIRE(gb_ld == (V * 3 + 15) / 16 && eb_ld == (V * 2 + 15) / 16 && gt_ld == (B + 15) / 16 && et_ld == (B + 15) / 16, YT8M_E_SHAPE,
@@ -241,8 +264,14 @@ int mix_bwd_bf16_launch(bool img, const float* Zg, const float* Ze, const float*
   unsigned short *gb = static_cast<unsigned short*>(dZg_b), *gt = static_cast<unsigned short*>(dZg_t);
   unsigned short *eb = static_cast<unsigned short*>(dZe_b), *et = static_cast<unsigned short*>(dZe_t);
 #define YT8M_MIX_LAUNCH(MODE, LT, IMGV, DP, LAB)                                                                                   \
-  hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<MODE, LT, IMGV>), grid, dim3(256), 0, s, Zg, Ze, DP, LAB, B, V, eps, dscale, upstream_dev, \
-                     gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld, be_part)
+  do {                                                                                                                            \
+    if (z16)                                                                                                                      \
+      hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<MODE, LT, IMGV, unsigned short>), grid, dim3(256), 0, s, Zg16, Ze16, DP, LAB, B, V, eps,  \
+                         dscale, upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld, be_part);                              \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((moe_mix_bwd_bf16_kernel<MODE, LT, IMGV, float>), grid, dim3(256), 0, s, Zg, Ze, DP, LAB, B, V, eps, dscale,       \
+                         upstream_dev, gb, gb_ld, gt, gt_ld, eb, eb_ld, et, et_ld, be_part);                                      \
+  } while (0)
   if (dp) {
     if (img) YT8M_MIX_LAUNCH(0, uint8_t, true, dp, (const uint8_t*)nullptr);
     else YT8M_MIX_LAUNCH(0, uint8_t, false, dp, (const uint8_t*)nullptr);
@@ -263,7 +292,7 @@ extern "C" int yt8m_moe_mix_bwd_bf16(const float* Zg, const float* Ze, const flo
                                      int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev, void* dZg_b,
                                      int64_t gb_ld, void* dZg_t, int64_t gt_ld, void* dZe_b, int64_t eb_ld, void* dZe_t,
                                      int64_t et_ld, float* be_part, yt8m_stream_t stream) {
-  return mix_bwd_bf16_launch(false, Zg, Ze, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_b, gb_ld, dZg_t, gt_ld, dZe_b,
+  return mix_bwd_bf16_launch(false, Zg, Ze, false, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_b, gb_ld, dZg_t, gt_ld, dZe_b,
                              eb_ld, dZe_t, et_ld, be_part, stream);
 }
 
@@ -273,6 +302,16 @@ extern "C" int yt8m_moe_mix_bwd_bf16_images(const float* Zg, const float* Ze, co
                                             int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev,
                                             void* dZg_img, int64_t g_kb, void* dZg_t_img, int64_t gt_kb, void* dZe_img, int64_t e_kb,
                                             void* dZe_t_img, int64_t et_kb, float* be_part, yt8m_stream_t stream) {
-  return mix_bwd_bf16_launch(true, Zg, Ze, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_img, g_kb, dZg_t_img, gt_kb,
+  return mix_bwd_bf16_launch(true, Zg, Ze, false, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_img, g_kb, dZg_t_img, gt_kb,
+                             dZe_img, e_kb, dZe_t_img, et_kb, be_part, stream);
+}
+
+// yt8m_moe_mix_bwd_bf16_images on bf16 logits (Zg [B, 3V], Ze [B, 2V] as written by yt8m_gemm_b1_nt_grouped_bf16c): 10 instead of 20 bytes
+// read per label.
+extern "C" int yt8m_moe_mix_bwd_bf16_images_z16(const void* Zg, const void* Ze, const float* dp, const void* labels, int label_dtype,
+                                                int64_t B, int64_t V, int M, float eps, float dscale, const float* upstream_dev,
+                                                void* dZg_img, int64_t g_kb, void* dZg_t_img, int64_t gt_kb, void* dZe_img, int64_t e_kb,
+                                                void* dZe_t_img, int64_t et_kb, float* be_part, yt8m_stream_t stream) {
+  return mix_bwd_bf16_launch(true, Zg, Ze, true, dp, labels, label_dtype, B, V, M, eps, dscale, upstream_dev, dZg_img, g_kb, dZg_t_img, gt_kb,
                              dZe_img, e_kb, dZe_t_img, et_kb, be_part, stream);
 }
