@@ -124,8 +124,14 @@ def main():
         if os.path.exists(os.path.join(O, f)):
             shutil.copy(os.path.join(O, f), os.path.join(P, t))
     line_path = os.path.join(O, "bench_line.json")
+    extra_path = os.path.join(O, "bench_extra.json")
+    if not os.path.exists(line_path) or os.path.getsize(line_path) == 0:
+        # the collection's own default run was the one that exposed the hanging all-cores CPU leg (DESIGN_LOG 11.9): the line is the
+        # default `python bench.py` of the fixed build (tools/r6_bench_default.sh, a later gpurun call of the same round)
+        line_path = os.path.join(R, "gpurun_out", "r6_bench_default.json")
+        extra_path = os.path.join(R, "gpurun_out", "r6_bench_extra.json")
     shutil.copy(line_path, os.path.join(P, "r6_bench_line.json"))            # the ONE line (<= 8 KB) ...
-    shutil.copy(os.path.join(O, "bench_extra.json"), os.path.join(P, "r6_bench_extra.json"))     # ... and the sidecar it names
+    shutil.copy(extra_path, os.path.join(P, "r6_bench_extra.json"))          # ... and the sidecar it names
     for f, t in (("netvlad_ab.txt", "r6_netvlad_single_pass_ab.txt"), ("netvlad_single_sections.txt", "r6_netvlad_single_pass_sections.txt")):
         if os.path.exists(os.path.join(O, f)):
             shutil.copy(os.path.join(O, f), os.path.join(P, t))
