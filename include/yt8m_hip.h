@@ -684,7 +684,7 @@ int yt8m_lstm_persist_bwd_on_f16_pipe(int64_t B, int64_t H);
  * Results equal the per-step entry points up to the K summation order of the recurrent products and the v_exp / v_rcp gate functions
  * (<= ~1.5e-7 absolute per activation).  yt8m_lstm_persist_status(workspace) reports a timed-out launch, as for the LSTM kernels.
  * Measured at B = 128, H = 1024 (profiles/r6_gru_persist.txt): forward 13.9 us/step against 17.6 for the per-step launches (the host
- * mirror takes it by default), backward 28.6 against 20.3 (opt-in: YT8M_GRU_PERSIST_BWD=1 in the host mirror). */
+ * mirror takes it by default), backward 29.0 against 20.3 (opt-in: YT8M_GRU_PERSIST_BWD=1 in the host mirror). */
 int yt8m_gru_persist_supported(int64_t B, int64_t H);
 int64_t yt8m_gru_persist_workspace_bytes(int64_t B, int64_t H, int64_t T);
 int yt8m_gru_persist_fwd(float* zg, float* zc, const float* Wg_h, int64_t ldg, const float* Wc_h, int64_t ldc, float* hs, float* rh,

@@ -2870,12 +2870,12 @@ extern "C" int yt8m_gru_persist_bwd(const float* zg, const float* zc, const floa
   a.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + ctl_padded(geo.NT16));
   a.t0 = (int)t0; a.T = (int)T; a.B = (int)B; a.H = (int)H;
   a.NU = geo.NU; a.RB = geo.RB; a.NT16 = geo.NT16; a.per = geo.per; a.pf = geo.pf;
-  // YT8M_GRU_BWD_U=16: 16 units per workgroup (H / 16 unit groups, every result column of the MFMA tile used; row groups: as many as
-  // the CU budget YT8M_GRU_BWD_CUS allows while every workgroup keeps >= 2 tiles).  Default 8, the forward geometry (half of every B
-  // fragment zero, four tiles = four chains per workgroup at B = 128): 28.6 us/step against 36.7 (16 units, whole chip: two chains
-  // per workgroup leave every fragment fetch exposed) and 30.5 (16 units on 128 CUs) -- profiles/r6_gru_persist.txt.
-  static const int u_env = getenv("YT8M_GRU_BWD_U") ? atoi(getenv("YT8M_GRU_BWD_U")) : 8;
-  static const int cus_env = getenv("YT8M_GRU_BWD_CUS") ? atoi(getenv("YT8M_GRU_BWD_CUS")) : 0;
+  // 16 units per workgroup (H / 16 unit groups, every result column of the MFMA tile used) on HALF the chip by default (YT8M_GRU_BWD_CUS,
+  // the LSTM backward kernel's policy: four tiles = four chains per workgroup at B = 128, the other 128 CUs stay free for the hoisted
+  // products): 29.0 us/step; the whole chip (two chains per workgroup) 31.5; YT8M_GRU_BWD_U=8, the forward geometry (half of every B
+  // fragment zero) on 256 workgroups: 30.3 -- profiles/r6_gru_persist.txt.
+  static const int u_env = getenv("YT8M_GRU_BWD_U") ? atoi(getenv("YT8M_GRU_BWD_U")) : 16;
+  static const int cus_env = getenv("YT8M_GRU_BWD_CUS") ? atoi(getenv("YT8M_GRU_BWD_CUS")) : 128;
   const bool u16 = u_env == 16;
   if (u16) {
     const int cus = device_cus(nullptr);

@@ -421,7 +421,7 @@ def check_persist_errors():
 PERSIST_BWD = _os.environ.get("YT8M_LSTM_PERSIST_BWD", "1") != "0"
 # GRUCell on the persistent protocol (csrc/gru_persist.inl), per direction; the library switch YT8M_GRU_PERSIST=0 turns both off.
 # Measured at B = 128, H = 1024, F = 300 (profiles/r6_gru_persist.txt): forward 13.9 us/step in one launch against 17.6 in 600 -> ON;
-# backward 28.6 us/step against 20.3 for the three per-step launches (two exchange rounds per step on a K = 3H reduction: every
+# backward 29.0 us/step against 20.3 for the three per-step launches (two exchange rounds per step on a K = 3H reduction: every
 # item's fragment fetch is exposed with four tiles per workgroup) -> parity-tested, OPT-IN.
 GRU_PERSIST_FWD = _os.environ.get("YT8M_GRU_PERSIST_FWD", "1") != "0"
 GRU_PERSIST_BWD = _os.environ.get("YT8M_GRU_PERSIST_BWD", "0") != "0"
