@@ -84,10 +84,15 @@ __global__ __launch_bounds__(256) void vlad_absmax_part_kernel(const float* __re
 //   feature d = 64 j + 16 (lane / 16) + 8 ks + i      cluster k = 16 ct + lane % 16
 // (the rows kernel's lane (m, kg) loads the 16 bytes q[row][64 j + 16 kg .. +16): bytes 0-7 feed K-step 0, 8-15 K-step 1)
 // cs_part[b][j][k] = sum over the block's 64 features of the ROUNDED weights (hi + lo) / scale.
+// p128 (round 6): the rows kernels walk D in 128-byte blocks -- lane (m, kg) loads the 32 bytes q[row][128 j' + 32 kg .. +32) once per PAIR
+// of packed blocks and feeds bytes 0-15 to block 2 j', 16-31 to block 2 j' + 1 -- so packed block j = 2 j' + h holds
+//   feature d = 128 j' + 32 (lane / 16) + 16 h + 8 ks + i.
+// (With 64-byte blocks a wave touched half of every 128-byte line per block and the other half one block later, by then evicted from the
+// L1: every line of the frames was requested twice -- 2.76 M of the rows kernel's 7.86 M requests at B = 1024, profiles/r6_netvlad_pmc.txt.)
 template <bool SRC_KD>   // false: src[b][d][k] (W_c, [D,64]);  true: src[b][k][d] (G = d agg, [64,D])
 __global__ __launch_bounds__(256) void vlad_pack_kernel(const float* __restrict__ src, int64_t bstride, int D,
                                                         const float* __restrict__ maxpart, float* __restrict__ scale,
-                                                        int nsplit, _Float16* __restrict__ Wp, float* __restrict__ cs_part) {
+                                                        int nsplit, _Float16* __restrict__ Wp, float* __restrict__ cs_part, int p128) {
   __shared__ float tile[64][65];
   const int j = blockIdx.x, b = blockIdx.y, nblk = gridDim.x;
   float mx = 0.f;
@@ -99,8 +104,10 @@ __global__ __launch_bounds__(256) void vlad_pack_kernel(const float* __restrict_
   for (int e = threadIdx.x; e < 4096; e += 256) {
     int dl, k;
     float v;
-    if (SRC_KD) { k = e >> 6; dl = e & 63; v = sp[(int64_t)k * D + 64 * j + dl]; }
-    else        { dl = e >> 6; k = e & 63; v = sp[(int64_t)(64 * j + dl) * NK + k]; }
+    if (SRC_KD) { k = e >> 6; dl = e & 63; }
+    else        { dl = e >> 6; k = e & 63; }
+    const int d = p128 ? 128 * (j >> 1) + 32 * (dl >> 4) + 16 * (j & 1) + (dl & 15) : 64 * j + dl;   // packed slot dl -> source feature
+    v = SRC_KD ? sp[(int64_t)k * D + d] : sp[(int64_t)d * NK + k];
     tile[dl][k] = v * S;
   }
   __syncthreads();
@@ -205,7 +212,7 @@ __device__ __forceinline__ float grp16_sum(float v) {
 // fragments FIRST -- that wait covers loads issued a whole block ago -- and only then W(j+1) / q(j+1) are issued; they fly
 // during the block's MFMAs.  (Loads through inline asm with counted waits were tried: the register allocator is free to
 // copy a not-yet-landed destination register, which it does.)
-template <int NSPLIT, bool BWD, int NT>
+template <int NSPLIT, bool BWD, int NT, bool P128 = false>
 __global__ __launch_bounds__(256, 2) void vlad_rows_kernel(RowsArgs g) {
   constexpr int WB = 8192 * NSPLIT;
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][WB] + reduction scratch
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void vlad_rows_kernel(RowsArgs g) {
   for (int t = 0; t < NT; ++t) {
     int f = f0 + 16 * (w + 4 * t) + m;
     f = f < g.F ? f : g.F - 1;                                       // rows beyond the video only feed outputs never stored
-    qrow[t] = g.q + ((int64_t)b * g.F + f) * g.D + 16 * kg;
+    qrow[t] = g.q + ((int64_t)b * g.F + f) * g.D + (P128 ? 32 : 16) * kg;
   }
   const int wave_off = (tid & ~63) * 16;
   auto issue_w = [&](int j, int stage) {
@@ -241,23 +248,16 @@ __global__ __launch_bounds__(256, 2) void vlad_rows_kernel(RowsArgs g) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0u;
 
-  u4 qc[NT];
 #ifdef NV_TIMING
   const uint64_t tm0 = __builtin_amdgcn_s_memtime();
 #endif
-  issue_w(0, 0);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) qc[t] = *reinterpret_cast<const u4*>(qrow[t]);
-
-  for (int j = 0; j < nblk; ++j) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                 // W(j) landed for every wave; the other stage is free again
-    h8 af[NT][2];
+  // bytes of one packed block (16 per lane and tile) -> f16 A fragments of its two K steps + the integer row sums
+  auto convert = [&](const u4 (&qsrc)[NT], h8 (&af)[NT][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const uint32_t d0 = qc[t][2 * ks], d1 = qc[t][2 * ks + 1];
+        const uint32_t d0 = qsrc[t][2 * ks], d1 = qsrc[t][2 * ks + 1];
         u4 av;
         av[0] = __builtin_amdgcn_perm(0x64646464u, d0, 0x04010400u);      // [0x64 b1 | 0x64 b0] = f16 (1024+b1, 1024+b0)
         av[1] = __builtin_amdgcn_perm(0x64646464u, d0, 0x04030402u);
@@ -270,35 +270,93 @@ __global__ __launch_bounds__(256, 2) void vlad_rows_kernel(RowsArgs g) {
         s2[t] = __builtin_amdgcn_udot4(d1, d1, s2[t], false);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (j + 1 < nblk) {
-      issue_w(j + 1, (j + 1) & 1);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) qc[t] = *reinterpret_cast<const u4*>(qrow[t] + 64 * (j + 1));
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the products of packed block j (its W fragments are in LDS stage j & 1)
+  auto products = [&](int j, const h8 (&af)[NT][2]) __attribute__((always_inline)) {
     const uint32_t so = (uint32_t)((j & 1) * WB);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      h8 bf[4][NSPLIT];
+      // W fragments in two halves of two cluster tiles when the 128-byte walk holds a second set of frame bytes in registers (NT = 5 ran
+      // out of them with all four tiles' fragments live); one group of four otherwise, as before
+      constexpr int CG = P128 ? 2 : 4;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int c0 = 0; c0 < 4; c0 += CG) {
+        h8 bf[CG][NSPLIT];
 #pragma unroll
-        for (int sp = 0; sp < NSPLIT; ++sp) bf[ct][sp] = lds_read_h8(wfrag + so + (uint32_t)(((ks * 4 + ct) * NSPLIT + sp) * 1024));
-      // the compiler does not track asm loads: wait, and tie the registers to the wait so their uses stay below it
+        for (int ct = 0; ct < CG; ++ct)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+          for (int sp = 0; sp < NSPLIT; ++sp) bf[ct][sp] = lds_read_h8(wfrag + so + (uint32_t)(((ks * 4 + c0 + ct) * NSPLIT + sp) * 1024));
+        // the compiler does not track asm loads: wait, and tie the registers to the wait so their uses stay below it
 #pragma unroll
-        for (int sp = 0; sp < NSPLIT; ++sp) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[ct][sp]) : : "memory");
+        for (int ct = 0; ct < CG; ++ct)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+          for (int sp = 0; sp < NSPLIT; ++sp) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[ct][sp]) : : "memory");
 #pragma unroll
-        for (int sp = 0; sp < NSPLIT; ++sp)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t][ks], bf[ct][sp], acc[t][ct], 0, 0, 0);
+          for (int sp = 0; sp < NSPLIT; ++sp)
+#pragma unroll
+            for (int ct = 0; ct < CG; ++ct)
+              acc[t][c0 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t][ks], bf[ct][sp], acc[t][c0 + ct], 0, 0, 0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (!P128) {
+    u4 qc[NT];
+    issue_w(0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) qc[t] = *reinterpret_cast<const u4*>(qrow[t]);
+    for (int j = 0; j < nblk; ++j) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                 // W(j) landed for every wave; the other stage is free again
+      h8 af[NT][2];
+      convert(qc, af);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < nblk) {
+        issue_w(j + 1, (j + 1) & 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qc[t] = *reinterpret_cast<const u4*>(qrow[t] + 64 * (j + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      products(j, af);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // 128-byte blocks: the two 16-byte loads of a lane hit the same line back to back (one L2 request per line of the frames), the
+    // pair's second half waits in registers for one block
+    u4 q0[NT], q1[NT];
+    issue_w(0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      q0[t] = *reinterpret_cast<const u4*>(qrow[t]);
+      q1[t] = *reinterpret_cast<const u4*>(qrow[t] + 16);
+    }
+    for (int j = 0; j < nblk; j += 2) {             // (nblk is even: D % 128 == 0)
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      h8 af[NT][2];
+      convert(q0, af);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w(j + 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      products(j, af);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      convert(q1, af);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < nblk) {
+        issue_w(j + 2, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          q0[t] = *reinterpret_cast<const u4*>(qrow[t] + 64 * (j + 2));
+          q1[t] = *reinterpret_cast<const u4*>(qrow[t] + 64 * (j + 2) + 16);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      products(j + 1, af);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   __syncthreads();                                                    // LDS is re-used as reduction scratch below
 #ifdef NV_TIMING
@@ -1092,11 +1150,30 @@ void launch_lds(K kernel, dim3 grid, int lds_bytes, hipStream_t s, const A& args
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, s, args);
 }
 
+// D in 128-byte blocks (see vlad_pack_kernel): OPT-IN, YT8M_NETVLAD_K128=1.  Measured at B = 1024 (profiles/r6_netvlad_pmc.txt): the rows
+// kernel's L2 requests drop from 7.85 M to 5.11 M as predicted -- and its duration does not move (2.149 M against 2.148 M GRBM cycles; 50
+// instead of 56 requests outstanding per CU): the window was full but not what the kernel waits for.  Forward call 0.36-0.37 against
+// 0.38 ms, backward call 0.58 against 0.55 (the per-video pack of dagg reads 64-byte runs in this order), configs[2] step unchanged.
+bool rows_p128(int64_t D) {
+  static const bool on = getenv("YT8M_NETVLAD_K128") != nullptr && atoi(getenv("YT8M_NETVLAD_K128")) != 0;
+  return on && (D % 128) == 0;
+}
+
 template <int NSPLIT, bool BWD>
 void launch_rows(const RowsArgs& a, int nt, int64_t ranges, hipStream_t s) {
   const dim3 grid((unsigned)ranges, (unsigned)a.B);
   const int lds = 2 * 8192 * NSPLIT + 4 * (NK + 1) * (int)sizeof(float);
   (void)nt;
+  if (rows_p128(a.D)) {
+    switch (nt) {
+      case 1: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 1, true>, grid, lds, s, a); break;
+      case 2: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 2, true>, grid, lds, s, a); break;
+      case 3: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 3, true>, grid, lds, s, a); break;
+      case 4: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 4, true>, grid, lds, s, a); break;
+      default: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 5, true>, grid, lds, s, a); break;
+    }
+    return;
+  }
   switch (nt) {
     case 1: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 1>, grid, lds, s, a); break;
     case 2: launch_lds(vlad_rows_kernel<NSPLIT, BWD, 2>, grid, lds, s, a); break;
@@ -1162,8 +1239,10 @@ extern "C" int yt8m_netvlad_fwd_u8(const uint8_t* q, const int32_t* num_frames, 
   float* maxpart = reinterpret_cast<float*>(ws + L.o_maxpart);
   float* colpart = reinterpret_cast<float*>(ws + L.o_colpart);
   hipLaunchKernelGGL(vlad_absmax_part_kernel, dim3(MAXP, 1), dim3(256), 0, s, Wc, D * NK, (int64_t)0, maxpart);
+  // (the single pass DMAs its frame blocks in the 64-byte order)
+  const int p128 = (rows_p128(D) && !yt8m_netvlad_single_pass(B, F, D, K)) ? 1 : 0;
   hipLaunchKernelGGL(vlad_pack_kernel<false>, dim3((unsigned)L.nblk, 1), dim3(256), 0, s, Wc, (int64_t)0, (int)D, maxpart, scale,
-                     nsplit, Wp, cs);
+                     nsplit, Wp, cs, p128);
   float* wgmax = reinterpret_cast<float*>(ws + L.o_wgmax);
   float* cssum = reinterpret_cast<float*>(ws + L.o_cssum);
   hipLaunchKernelGGL(vlad_cs_sum_kernel, dim3(1), dim3(256), 0, s, cs, (int)L.nblk, (int64_t)NK, cssum);
@@ -1235,7 +1314,7 @@ extern "C" int yt8m_netvlad_bwd_u8(const uint8_t* q, const int32_t* num_frames, 
   float* part2 = reinterpret_cast<float*>(ws + L.o_part2);
   hipLaunchKernelGGL(vlad_absmax_part_kernel, dim3(MAXP, (unsigned)B), dim3(256), 0, s, dagg, NK * D, NK * D, maxpart);
   hipLaunchKernelGGL(vlad_pack_kernel<true>, dim3((unsigned)L.nblk, (unsigned)B), dim3(256), 0, s, dagg, NK * D, (int)D, maxpart,
-                     scale, nsplit, Wp, cs);
+                     scale, nsplit, Wp, cs, rows_p128(D) ? 1 : 0);
   float* cssum = reinterpret_cast<float*>(ws + L.o_cssum);
   hipLaunchKernelGGL(vlad_cs_sum_kernel, dim3((unsigned)((B * NK + 255) / 256)), dim3(256), 0, s, cs, (int)L.nblk, B * NK, cssum);
   RowsArgs ra;
