@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__
 }
 
 // ========================================= LayerNormBasicLSTMCell ==========================================================
+// Gate non-linearities on v_exp_f32 / v_rcp_f32, as the persistent recurrences use them (<= ~1.5e-7 absolute per value against libm's
+// expf / tanhf, whose range checks and branches were most of these kernels' ~2 400 instructions on ONE wave per SIMD: round 6).
+__device__ __forceinline__ float ln_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float ln_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 constexpr int LN_PT = 8;                       // units per thread: H <= 256 * LN_PT
 constexpr float LN_EPS = 1e-12f;               // tf.contrib.layers.layer_norm variance_epsilon
 
@@ -198,10 +202,10 @@ __global__ __launch_bounds__(256) void lnlstm_fwd_kernel(const float* __restrict
       float y[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) y[g] = (zv[g][p] - mean.v[g]) * rstd.v[g] * gm[g][p] + bt[g][p];
-      const float i = sigmoidf_(y[0]);
-      const float gg = tanhf(y[1]) * keep_scale((uint64_t)(((int64_t)t * B + b) * H + h), seed, keep);
-      const float f = sigmoidf_(y[2] + fb);
-      og[p] = sigmoidf_(y[3]);
+      const float i = ln_sigmoid(y[0]);
+      const float gg = ln_tanh(y[1]) * keep_scale((uint64_t)(((int64_t)t * B + b) * H + h), seed, keep);
+      const float f = ln_sigmoid(y[2] + fb);
+      og[p] = ln_sigmoid(y[3]);
       cp[p] = cpv[p] * f + i * gg;
       sc += cp[p];
     }
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void lnlstm_fwd_kernel(const float* __restrict
     const int64_t h = tid + p * 256;
     if (h < H) {
       const float cn = (cp[p] - mean_s) * rstd_s * gm[4][p] + bt[4][p];
-      const float hn = tanhf(cn) * og[p];
+      const float hn = ln_tanh(cn) * og[p];
       c_new[b * H + h] = cn;
       h_new[b * H + h] = hn;
       if (out) out[b * H + h] = hn;
@@ -294,15 +298,15 @@ __global__ __launch_bounds__(256) void lnlstm_bwd_kernel(const float* __restrict
         n[g][p] = (zv[g][p] - mean[g]) * rstd[g];
         y[g] = n[g][p] * gm[g][p] + bt[g][p];
       }
-      iv[p] = sigmoidf_(y[0]);
-      tj[p] = tanhf(y[1]);
+      iv[p] = ln_sigmoid(y[0]);
+      tj[p] = ln_tanh(y[1]);
       ks[p] = keep_scale((uint64_t)(((int64_t)t * B + b) * H + h), seed, keep);
       gv[p] = tj[p] * ks[p];
-      fv[p] = sigmoidf_(y[2] + fb);
-      const float o = sigmoidf_(y[3]);
+      fv[p] = ln_sigmoid(y[2] + fb);
+      const float o = ln_sigmoid(y[3]);
       const float cpre = cpv[p] * fv[p] + iv[p] * gv[p];
       ns[p] = (cpre - mean[4]) * rstd[4];
-      const float tc = tanhf(cnv[p]);
+      const float tc = ln_tanh(cnv[p]);
       const float dh = dhv[p];
       dy[3][p] = dh * tc * o * (1.0f - o);
       const float dcn = dcv[p] + dh * o * (1.0f - tc * tc);
