@@ -188,6 +188,11 @@ int yt8m_x3_set_schedule(int mode);
  * 2^-38 below it flush to zero; products accumulate in fp32.  Without the flag a product never takes that form, whatever its
  * transposition flags (six bf16 products of exact three-plane splits, or the fp32-MFMA kernel: fp32-grade for every element). */
 #define YT8M_GEMM_ROLE_DW 0x100
+/* Round 6: the caller accepts the same three-f16-product form (same contract: one device-measured power-of-two scale per operand
+ * matrix) for a product of ANY orientation -- declared for the MoE head's logits x . [W_g | W_e] (W/all_video_models/moe_model.py:43-52),
+ * whose input is l2-normalised and whose operands are each one weight matrix: K = 1152 terms of comparable magnitude.  The operands'
+ * half-plane images are made per call (absmax + split; a weight's resident six-product image is not used). */
+#define YT8M_GEMM_ROLE_H2 0x200
 int yt8m_gemm_x3_pays(int64_t M, int64_t N, int64_t K);
 int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt8m_gemm_problem* probs);
 int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,

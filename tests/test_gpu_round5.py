@@ -95,8 +95,10 @@ def test_adam_tiles_equal_the_chunk_pass_and_the_split_pass_bit_for_bit(dev):
 
 
 def _run_moe(dev, enabled, steps, bf16, flags, inject_at=None):
+    import yt8m_amd.ops as _ops
     wimg.ENABLED = enabled
-    try:
+    h2_logits, _ops.MOE_LOGITS_H2 = _ops.MOE_LOGITS_H2, False        # (round 6: the fp32 head's logits default to per-call h2 images; the
+    try:                                                             #  resident six-product images are what this test is about)
         flags.reset()
         if bf16:
             flags.compute_dtype = "bfloat16"
@@ -117,6 +119,7 @@ def _run_moe(dev, enabled, steps, bf16, flags, inject_at=None):
         return losses, g.params.clone(), g.adam_m.clone(), g.adam_v.clone(), active, nimg
     finally:
         wimg.ENABLED = True
+        _ops.MOE_LOGITS_H2 = h2_logits
 
 
 @pytest.mark.parametrize("bf16", [False, True])

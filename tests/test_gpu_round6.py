@@ -345,3 +345,24 @@ def test_bf16_logits_of_the_moe_head_product_and_the_mixing_passes_that_read_the
         for a, b in zip(*outs):
             assert torch.equal(a, b)
         assert int(outs[0][0].long().sum()) != 0
+
+
+def test_declared_h2_role_of_the_moe_logits_product(dev):
+    """Round 6: yt8m_gemm_auto_grouped with YT8M_GEMM_ROLE_H2 (the MoE head's x . [W_g | W_e], W/all_video_models/moe_model.py:43-52) runs
+    three f16 products under one scale per operand matrix: against fp64 within the h2 contract (<= 4e-6 of the output scale at K = 1152,
+    the six-product form's own error being ~1e-6), bias added, and bitwise reproducible; without the flag the result is the six-product form's."""
+    g = torch.Generator(device=dev).manual_seed(12)
+    B, D, N1, N2 = 1024, 1152, 3 * 4716, 2 * 4716
+    x = torch.nn.functional.normalize(torch.rand((B, D), device=dev, generator=g) * 4 - 2, dim=1)
+    Wg = (torch.rand((D, N1), device=dev, generator=g) - 0.5) * 0.09
+    We = (torch.rand((D, N2), device=dev, generator=g) - 0.5) * 0.09
+    be = torch.randn((N2,), device=dev, generator=g) * 0.1
+    h2 = ops.gemm_grouped([dict(A=x, B=Wg), dict(A=x, B=We, bias=be)], role="h2")
+    h2b = ops.gemm_grouped([dict(A=x, B=Wg), dict(A=x, B=We, bias=be)], role="h2")
+    x3 = ops.gemm_grouped([dict(A=x, B=Wg), dict(A=x, B=We, bias=be)])
+    ref = [x.double() @ Wg.double(), x.double() @ We.double() + be.double()]
+    for a, b, c, r in zip(h2, h2b, x3, ref):
+        assert torch.equal(a, b)
+        scale = float(r.abs().max())
+        assert float((a.double() - r).abs().max()) <= 4e-6 * scale, float((a.double() - r).abs().max()) / scale
+        assert float((c.double() - r).abs().max()) <= 4e-6 * scale

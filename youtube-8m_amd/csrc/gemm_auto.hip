@@ -65,7 +65,9 @@ struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; bool h2
 bool h2_role(int transA_flags, int transB, int64_t K) {
   static const bool off = getenv("YT8M_GEMM_H2") != nullptr && atoi(getenv("YT8M_GEMM_H2")) == 0;
   static const int64_t mink = getenv("YT8M_GEMM_H2_MINK") ? atoll(getenv("YT8M_GEMM_H2_MINK")) : 512;
-  return !off && (transA_flags & YT8M_GEMM_ROLE_DW) != 0 && (transA_flags & 1) != 0 && transB == 0 && K >= mink;
+  if (off || K < mink) return false;
+  if ((transA_flags & YT8M_GEMM_ROLE_H2) != 0) return true;           // declared for this product whatever its orientation (round 6)
+  return (transA_flags & YT8M_GEMM_ROLE_DW) != 0 && (transA_flags & 1) != 0 && transB == 0;
 }
 constexpr int64_t H2_SCALE_BYTES = 256;                  // the operand's absmax word (yt8m_h2_absmax), in front of its h2 image in the scratch
 
@@ -103,7 +105,8 @@ extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, c
                                       int64_t workspace_bytes, void* image_scratch, int64_t image_scratch_bytes, uint64_t* used_x3,
                                       yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 64 && probs, YT8M_E_BADARG, "1..64 problems per call");
-  YT8M_REQUIRE((transA_flags & ~(1 | YT8M_GEMM_ROLE_DW)) == 0 && (transB & ~1) == 0, YT8M_E_BADARG, "transA: 0 / 1 (| YT8M_GEMM_ROLE_DW), transB: 0 / 1");
+  YT8M_REQUIRE((transA_flags & ~(1 | YT8M_GEMM_ROLE_DW | YT8M_GEMM_ROLE_H2)) == 0 && (transB & ~1) == 0, YT8M_E_BADARG,
+               "transA: 0 / 1 (| YT8M_GEMM_ROLE_DW | YT8M_GEMM_ROLE_H2), transB: 0 / 1");
   const int transA = transA_flags & 1;
   YT8M_REQUIRE((reinterpret_cast<uintptr_t>(image_scratch) & 255) == 0, YT8M_E_BADARG, "image scratch must be 256-byte aligned");
   std::vector<Img> imgs;

@@ -112,6 +112,7 @@ def _x3_wins(shapes, transA=False, transB=False):
 
 
 GEMM_ROLE_DW = 0x100          # include/yt8m_hip.h YT8M_GEMM_ROLE_DW
+GEMM_ROLE_H2 = 0x200          # include/yt8m_hip.h YT8M_GEMM_ROLE_H2
 
 
 def gemm_grouped(items, transA=False, transB=False, role=None):
@@ -129,9 +130,9 @@ def gemm_grouped(items, transA=False, transB=False, role=None):
         probs.append(pr)
         outs.append(out)
         keep.append(k)
-    if role not in (None, "dw"):
-        raise ValueError("role must be None or 'dw'")
-    ta = int(bool(transA)) | (GEMM_ROLE_DW if (role == "dw" and transA and not transB) else 0)
+    if role not in (None, "dw", "h2"):
+        raise ValueError("role must be None, 'dw' or 'h2'")
+    ta = int(bool(transA)) | (GEMM_ROLE_DW if (role == "dw" and transA and not transB) else 0) | (GEMM_ROLE_H2 if role == "h2" else 0)
     ws = _workspace(outs[0].device)
     lib = _lib.lib()
     for lo in range(0, len(probs), 64):
@@ -1200,6 +1201,7 @@ def _bf16_ok(x2):
 # products' operands -- to 8 significant bits is more than that gradient takes.  The kernels are exact in kind (bit for bit the fp32-logit
 # passes on rounded logits: tests/test_gpu_round6.py::test_bf16_logits_*).
 Z16_LOGITS = os.environ.get("YT8M_Z16_LOGITS", "0") != "0"
+MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
 
 
 def _z16_ok(x2, Wg, We, V, M, bf16, training):
@@ -1236,7 +1238,9 @@ def _moe_logits(x2, Wg, We, be, bf16, keep=None, z16=False):
         xb = cast_bf16(x2)
         return gemm_bf16_nt_grouped([dict(A=xb, B=cast_bf16(Wg.data, transpose=True)),
                                      dict(A=xb, B=cast_bf16(We.data, transpose=True), bias=be.data)])
-    return gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)])
+    # fp32 configuration: the logits product declares the h2 role (three f16 products under one scale per operand matrix) -- its input is
+    # l2-normalised or a bounded hidden activation, each operand one weight matrix (MOE_LOGITS_H2 / YT8M_MOE_LOGITS_H2=0: six-product form)
+    return gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)], role="h2" if MOE_LOGITS_H2 else None)
 
 
 class _MoeHeadXent(torch.autograd.Function):
