@@ -198,6 +198,12 @@ int64_t yt8m_gemm_auto_scratch_bytes(int transA, int transB, int nprob, const yt
 int yt8m_gemm_auto_grouped(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
                            int64_t workspace_bytes, void* image_scratch, int64_t image_scratch_bytes, uint64_t* used_x3,
                            yt8m_stream_t stream);
+/* Round 6: the same call with absmax words the caller already has -- absmaxA / absmaxB: NULL, or nprob entries, each NULL or a device word
+ * holding max |stored operand| as float bits (what yt8m_h2_absmax writes; e.g. from yt8m_moe_mix_xent_bwd_absmax).  An operand that takes
+ * the h2 form under such a word skips its memset + absmax pass; results are bitwise those of yt8m_gemm_auto_grouped. */
+int yt8m_gemm_auto_grouped_ex(int transA, int transB, int nprob, const yt8m_gemm_problem* probs, const float* const* absmaxA,
+                              const float* const* absmaxB, void* workspace, int64_t workspace_bytes, void* image_scratch,
+                              int64_t image_scratch_bytes, uint64_t* used_x3, yt8m_stream_t stream);
 /* The uint8 input projection on the same kernel ("readers.py uint8 -> float dequantise folded into the first GEMM",
  * W/readers.py:178-187 -> W/all_frame_models/lstm_model.py:34-47):
  *   C[M,N] = rowscale[m] * (A . B^T + colsum_scale * colsum[n]) + bias[n]
@@ -302,6 +308,10 @@ int yt8m_moe_mix_xent_fwd(const float* Zg, const float* Ze, const void* labels, 
                           yt8m_stream_t stream);
 int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev,
                           int64_t B, int64_t V, int M, float eps, float upstream, yt8m_stream_t stream);
+/* yt8m_moe_mix_xent_bwd that also leaves max |dL/dZg| and max |dL/dZe| as float bits in absmax2[0..1] (8 bytes, zeroed by the call): the
+ * scale words of the weight-gradient products' h2 operands (yt8m_gemm_auto_grouped_ex), measured while the gradients are written. */
+int yt8m_moe_mix_xent_bwd_absmax(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev, int64_t B, int64_t V,
+                                 int M, float eps, float upstream, void* absmax2, yt8m_stream_t stream);
 
 /* ---- whole-head entry points (yt8m_moe_fwd / yt8m_moe_bwd / yt8m_logistic_fwd_bwd) ---------------
  * MoeModel.create_model (moe_model.py:12-65) + CrossEntropyLoss (losses.py:110-130) in two calls for a non-Python host:

@@ -366,3 +366,43 @@ def test_declared_h2_role_of_the_moe_logits_product(dev):
         scale = float(r.abs().max())
         assert float((a.double() - r).abs().max()) <= 4e-6 * scale, float((a.double() - r).abs().max()) / scale
         assert float((c.double() - r).abs().max()) <= 4e-6 * scale
+
+
+def test_mixing_backward_measures_the_maxima_its_weight_gradient_products_split_under(dev, flags):
+    """Round 6: yt8m_moe_mix_xent_bwd_absmax leaves max |dZg| / max |dZe| as float bits while it writes the gradients;
+    yt8m_gemm_auto_grouped_ex takes them instead of two memset + absmax passes.  Same words, so the same images and the same products:
+    a MoeModel training step (B = 1024, BASELINE configs[1]) bit for bit with and without."""
+    import yt8m_amd.train as train
+    import yt8m_amd.video_level_models as vlm
+
+    def run(on):
+        old = ops.MIX_BWD_ABSMAX
+        ops.MIX_BWD_ABSMAX = on
+        try:
+            flags.reset()
+            B, D, V = 1024, 1152, 4716
+            g = reset_default_graph(device=dev, seed=0)
+            tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g)
+            gen = torch.Generator(device=dev).manual_seed(5)
+            losses = []
+            for _ in range(3):
+                x = torch.rand((B, D), device=dev, generator=gen) * 4.0 - 2.0
+                y = torch.rand((B, V), device=dev, generator=gen) < (3.4 / V)
+                losses.append(float(tg.step(x, y)["loss"]))
+            torch.cuda.synchronize()
+            return losses, g.params.clone(), g.adam_m.clone()
+        finally:
+            ops.MIX_BWD_ABSMAX = old
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # the words themselves against the stand-alone absmax pass
+    lib = L.lib()
+    gen = torch.Generator(device=dev).manual_seed(6)
+    Bv, V, M = 256, 1000, 2
+    Zg, Ze = torch.randn((Bv, 3 * V), device=dev, generator=gen), torch.randn((Bv, 2 * V), device=dev, generator=gen)
+    y = (torch.rand((Bv, V), device=dev, generator=gen) < 0.01).to(torch.uint8)
+    up = torch.ones(1, device=dev)
+    words = torch.empty(2, device=dev)
+    L.check(lib.yt8m_moe_mix_xent_bwd_absmax(_p(Zg), _p(Ze), _p(y), 0, _p(up), Bv, V, M, 1e-6, 1.0, _p(words), _st()))
+    assert float(words[0]) == float(Zg.abs().max()) and float(words[1]) == float(Ze.abs().max())

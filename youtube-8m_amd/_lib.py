@@ -84,6 +84,8 @@ SIGNATURES = {
     "yt8m_gemm_x3_pays": (c_int, [c_int64, c_int64, c_int64]),
     "yt8m_gemm_auto_scratch_bytes": (c_int64, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem)]),
     "yt8m_gemm_auto_grouped": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), P, c_int64, P, c_int64, ctypes.POINTER(ctypes.c_uint64), P]),
+    "yt8m_gemm_auto_grouped_ex": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmProblem), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                          P, c_int64, P, c_int64, ctypes.POINTER(ctypes.c_uint64), P]),
     "yt8m_x3_image_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_x3_split": (c_int, [P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "yt8m_gemm_x3_nt_grouped": (c_int, [c_int, ctypes.POINTER(GemmProblem), P, c_int64, P]),
@@ -134,6 +136,7 @@ SIGNATURES = {
     "yt8m_moe_mix_xent_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "yt8m_moe_mix_xent_fwd": (c_int, [P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_float, P, P]),
     "yt8m_moe_mix_xent_bwd": (c_int, [P, P, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P]),
+    "yt8m_moe_mix_xent_bwd_absmax": (c_int, [P, P, P, c_int, P, c_int64, c_int64, c_int, c_float, c_float, P, P]),
     "yt8m_skinny_supported": (c_int, [c_int64, c_int64, c_int64]),
     "yt8m_skinny_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "yt8m_skinny_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P]),

@@ -129,13 +129,17 @@ __global__ __launch_bounds__(256) void moe_mix_xent_fwd_kernel(const float* __re
   if (threadIdx.x == 0) partial[blockIdx.x] = ce;
 }
 
+// zmax (may be NULL; round 6): two words, max |dL/dZg| and max |dL/dZe| as float bits (atomic max; zeroed by the caller) -- what the
+// weight-gradient products' h2 split would otherwise measure in a pass of its own over each of the two gradients.
 template <int MT, typename LT>
 __global__ __launch_bounds__(256) void moe_mix_xent_bwd_kernel(float* __restrict__ Zg, float* __restrict__ Ze,
                                                                const LT* __restrict__ y, int64_t BV, int Mrt, float eps,
-                                                               float dscale, const float* __restrict__ up_dev) {
+                                                               float dscale, const float* __restrict__ up_dev, unsigned* __restrict__ zmax) {
+  __shared__ float redm[8];
   const int M = MT > 0 ? MT : Mrt;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= BV) return;
+  float mg = 0.f, me = 0.f;
+  if (i < BV) {
   if (up_dev) dscale *= up_dev[0];
   float* g = Zg + i * (M + 1);
   float* e = Ze + i * M;
@@ -158,8 +162,27 @@ __global__ __launch_bounds__(256) void moe_mix_xent_bwd_kernel(float* __restrict
   const float d = -(yv / (pv + eps) - (1.0f - yv) / (1.0f - pv + eps)) * dscale;
 #pragma unroll
   for (int m = 0; m <= M; ++m) {
-    g[m] = d * gs[m] * (es[m] - pv);
-    if (m < M) e[m] = d * gs[m] * es[m] * (1.0f - es[m]);
+    const float vg = d * gs[m] * (es[m] - pv);
+    g[m] = vg;
+    mg = fmaxf(mg, fabsf(vg));
+    if (m < M) {
+      const float ve = d * gs[m] * es[m] * (1.0f - es[m]);
+      e[m] = ve;
+      me = fmaxf(me, fabsf(ve));
+    }
+  }
+  }
+  if (zmax) {                                                        // (block-uniform)
+    mg = block_max_256(mg, redm);
+    me = block_max_256(me, redm + 4);
+    if (threadIdx.x == 0) {
+      // non-negative floats order like their bit patterns.  Look before the atomic: 19 k workgroups x 2 atomics on one line serialised
+      // (+0.34 ms on a 0.9 ms step when every workgroup issued them); the running maximum settles within the first few hundred
+      // workgroups, after which a relaxed read says "not larger" and nothing is issued.
+      const unsigned bg = __float_as_uint(mg), be = __float_as_uint(me);
+      if (bg > __hip_atomic_load(zmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(zmax, bg);
+      if (be > __hip_atomic_load(zmax + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(zmax + 1, be);
+    }
   }
 }
 
@@ -671,8 +694,25 @@ extern "C" int yt8m_moe_mix_xent_fwd(const float* Zg, const float* Ze, const voi
   return launch_status("moe_mix_xent_fwd_kernel");
 }
 
+namespace {
+int mix_xent_bwd_impl(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev, int64_t B, int64_t V, int M,
+                      float eps, float upstream, unsigned* zmax, yt8m_stream_t stream);
+}
 extern "C" int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev,
                                      int64_t B, int64_t V, int M, float eps, float upstream, yt8m_stream_t stream) {
+  return mix_xent_bwd_impl(Zg, Ze, labels, label_dtype, upstream_dev, B, V, M, eps, upstream, nullptr, stream);
+}
+// The same pass that also leaves max |dL/dZg| and max |dL/dZe| as float bits in absmax2[0..1] (zeroed here): the scale words the h2 form
+// of the weight-gradient products x^T . dZ takes (yt8m_gemm_auto_grouped_ex) -- two memsets and two passes over 58 + 39 MB at B = 1024 less.
+extern "C" int yt8m_moe_mix_xent_bwd_absmax(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev,
+                                            int64_t B, int64_t V, int M, float eps, float upstream, void* absmax2, yt8m_stream_t stream) {
+  YT8M_REQUIRE(absmax2, YT8M_E_BADARG, "null absmax words");
+  YT8M_HIP_CHECK(hipMemsetAsync(absmax2, 0, 8, as_stream(stream)));
+  return mix_xent_bwd_impl(Zg, Ze, labels, label_dtype, upstream_dev, B, V, M, eps, upstream, static_cast<unsigned*>(absmax2), stream);
+}
+namespace {
+int mix_xent_bwd_impl(float* Zg, float* Ze, const void* labels, int label_dtype, const float* upstream_dev, int64_t B, int64_t V, int M,
+                      float eps, float upstream, unsigned* zmax, yt8m_stream_t stream) {
   YT8M_REQUIRE(M >= 1 && M <= MAXM, YT8M_E_BADARG, "num_mixtures must be in [1,16]");
   YT8M_REQUIRE(B > 0 && V > 0, YT8M_E_SHAPE, "empty batch");
   YT8M_REQUIRE(Zg && Ze && labels, YT8M_E_BADARG, "null operand");
@@ -683,12 +723,13 @@ extern "C" int yt8m_moe_mix_xent_bwd(float* Zg, float* Ze, const void* labels, i
   dim3 grid((unsigned)((BV + 255) / 256)), block(256);
   const float dscale = upstream / (float)B;
   if (label_dtype == YT8M_LABEL_U8) {
-    YT8M_DISPATCH_M(moe_mix_xent_bwd_kernel, uint8_t, Zg, Ze, static_cast<const uint8_t*>(labels), BV, M, eps, dscale, upstream_dev)
+    YT8M_DISPATCH_M(moe_mix_xent_bwd_kernel, uint8_t, Zg, Ze, static_cast<const uint8_t*>(labels), BV, M, eps, dscale, upstream_dev, zmax)
   } else {
-    YT8M_DISPATCH_M(moe_mix_xent_bwd_kernel, float, Zg, Ze, static_cast<const float*>(labels), BV, M, eps, dscale, upstream_dev)
+    YT8M_DISPATCH_M(moe_mix_xent_bwd_kernel, float, Zg, Ze, static_cast<const float*>(labels), BV, M, eps, dscale, upstream_dev, zmax)
   }
   return launch_status("moe_mix_xent_bwd_kernel");
 }
+}  // namespace
 
 extern "C" int yt8m_act_fwd_f32(int act, const float* x, float* y, int64_t n, yt8m_stream_t stream) {
   YT8M_REQUIRE(act >= 0 && act <= YT8M_ACT_ELU, YT8M_E_BADARG, "unknown activation");

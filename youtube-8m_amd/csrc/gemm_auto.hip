@@ -49,7 +49,7 @@ bool x3_allowed(const yt8m_gemm_problem& q) {
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 
-struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; bool h2; };
+struct Img { const void* src; int64_t R, C, ld; bool trans; int64_t off; bool h2; const float* word; };   // word: the caller's absmax word (h2) or NULL
 
 // Round 5: a weight gradient dW = x^T . dz (transA, !transB) sums over the rows of BOTH stored operands, neither of which is a weight:
 // one power-of-two scale per operand, measured on the device, serves every term of every output element -- such a product runs as
@@ -104,6 +104,16 @@ extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA_flags, int transB, in
 extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, const yt8m_gemm_problem* probs, void* workspace,
                                       int64_t workspace_bytes, void* image_scratch, int64_t image_scratch_bytes, uint64_t* used_x3,
                                       yt8m_stream_t stream) {
+  return yt8m_gemm_auto_grouped_ex(transA_flags, transB, nprob, probs, nullptr, nullptr, workspace, workspace_bytes, image_scratch,
+                                   image_scratch_bytes, used_x3, stream);
+}
+
+// yt8m_gemm_auto_grouped with absmax words the caller already has (round 6): absmaxA / absmaxB (NULL, or nprob entries, each NULL or a
+// device word holding max |operand| as float bits, e.g. from yt8m_moe_mix_xent_bwd_absmax) -- an operand that takes the h2 form under
+// such a word skips its memset + yt8m_h2_absmax pass.  The word must cover the whole stored operand matrix.
+extern "C" int yt8m_gemm_auto_grouped_ex(int transA_flags, int transB, int nprob, const yt8m_gemm_problem* probs, const float* const* absmaxA,
+                                         const float* const* absmaxB, void* workspace, int64_t workspace_bytes, void* image_scratch,
+                                         int64_t image_scratch_bytes, uint64_t* used_x3, yt8m_stream_t stream) {
   YT8M_REQUIRE(nprob >= 1 && nprob <= 64 && probs, YT8M_E_BADARG, "1..64 problems per call");
   YT8M_REQUIRE((transA_flags & ~(1 | YT8M_GEMM_ROLE_DW | YT8M_GEMM_ROLE_H2)) == 0 && (transB & ~1) == 0, YT8M_E_BADARG,
                "transA: 0 / 1 (| YT8M_GEMM_ROLE_DW | YT8M_GEMM_ROLE_H2), transB: 0 / 1");
@@ -115,15 +125,22 @@ extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, c
   uint64_t mask = 0;
   int64_t off = 0;
   char* const base = static_cast<char*>(image_scratch);
-  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, bool h2, const void** at) -> bool {
+  // *word: where the operand's absmax word lives (h2): the caller's, or the slot in front of the image in the scratch
+  auto image_of = [&](const void* src, int64_t R, int64_t C, int64_t ld, bool trans, bool h2, const float* ext, const void** at,
+                      const float** word) -> bool {
     if (!h2)
       if (const void* r = resident(src, R, C, ld, trans)) { *at = r; return true; }    // a weight matrix with a resident image
     for (const Img& m : imgs)
-      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans && m.h2 == h2) { *at = base + m.off; return true; }
+      if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans && m.h2 == h2) {
+        *at = base + m.off;
+        *word = m.word ? m.word : reinterpret_cast<const float*>(base + m.off - H2_SCALE_BYTES);
+        return true;
+      }
     const int64_t bytes = up256(trans ? yt8m_x3_image_bytes(C, R) : yt8m_x3_image_bytes(R, C)) + (h2 ? H2_SCALE_BYTES : 0);
     if (!image_scratch || off + bytes > image_scratch_bytes) return false;
-    imgs.push_back({src, R, C, ld, trans, off + (h2 ? H2_SCALE_BYTES : 0), h2});      // (h2: [scale words | image])
+    imgs.push_back({src, R, C, ld, trans, off + (h2 ? H2_SCALE_BYTES : 0), h2, h2 ? ext : nullptr});      // (h2: [scale words | image])
     *at = base + off + (h2 ? H2_SCALE_BYTES : 0);
+    *word = (h2 && ext) ? ext : reinterpret_cast<const float*>(base + off);
     off += bytes;
     return true;
   };
@@ -133,12 +150,14 @@ extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, c
     const bool h2 = h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0;   // (the scaled epilogue stores float4: odd widths take the six-product form)
     const void* ia = nullptr;
     const void* ib = nullptr;
+    const float* wa = nullptr;
+    const float* wb = nullptr;
     if (x3) {
       const int64_t mark = off;
       const size_t nimg = imgs.size();
       // op(A) as [M rows, K]: A is stored [M,K] (plain) or [K,M] (transA: the transposing split); op(B)^T as [N rows, K]
-      x3 = image_of(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0, h2, &ia) &&
-           image_of(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0, h2, &ib);
+      x3 = image_of(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0, h2, absmaxA ? absmaxA[i] : nullptr, &ia, &wa) &&
+           image_of(q.B, transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0, h2, absmaxB ? absmaxB[i] : nullptr, &ib, &wb);
       if (!x3) { imgs.resize(nimg); off = mark; }          // not enough scratch for this one: fp32 kernel
     }
     if (x3) {
@@ -147,8 +166,8 @@ extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, c
       t.B = ib; t.ldb = 0;
       if (h2) {
         ph.push_back(t);
-        hda.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ia) - H2_SCALE_BYTES));
-        hdb.push_back(reinterpret_cast<const float*>(static_cast<const char*>(ib) - H2_SCALE_BYTES));
+        hda.push_back(wa);
+        hdb.push_back(wb);
       } else {
         px.push_back(t);
       }
@@ -161,10 +180,14 @@ extern "C" int yt8m_gemm_auto_grouped(int transA_flags, int transB, int nprob, c
     void* dst = static_cast<char*>(image_scratch) + m.off;
     int rc;
     if (m.h2) {                                            // scale measured on the device, then the two-plane half image under it
-      float* word = reinterpret_cast<float*>(static_cast<char*>(dst) - H2_SCALE_BYTES);    // max |src| as float bits
-      YT8M_HIP_CHECK(hipMemsetAsync(word, 0, 4, as_stream(stream)));
-      rc = yt8m_h2_absmax(static_cast<const float*>(m.src), m.R, m.C, m.ld, word, stream);
-      if (rc != YT8M_OK) return rc;
+      const float* word = m.word;                            // the caller's word, or measured here: max |src| as float bits
+      if (!word) {
+        float* w = reinterpret_cast<float*>(static_cast<char*>(dst) - H2_SCALE_BYTES);
+        YT8M_HIP_CHECK(hipMemsetAsync(w, 0, 4, as_stream(stream)));
+        rc = yt8m_h2_absmax(static_cast<const float*>(m.src), m.R, m.C, m.ld, w, stream);
+        if (rc != YT8M_OK) return rc;
+        word = w;
+      }
       rc = yt8m_h2_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, word, m.trans ? nullptr : dst, m.trans ? dst : nullptr, nullptr, stream);
     } else {
       rc = yt8m_x3_split(static_cast<const float*>(m.src), m.R, m.C, m.ld, 1.0f, m.trans ? nullptr : dst, m.trans ? dst : nullptr, stream);

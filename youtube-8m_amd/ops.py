@@ -145,7 +145,15 @@ def gemm_grouped(items, transA=False, transB=False, role=None):
             continue
         nb = lib.yt8m_gemm_auto_scratch_bytes(ta, int(transB), len(part), arr)
         img = torch.empty(nb, dtype=torch.uint8, device=outs[0].device) if nb else None
-        _lib.check(lib.yt8m_gemm_auto_grouped(ta, int(transB), len(part), arr, _p(ws), ws.numel() * 4, _p(img), nb, None, _stream()))
+        words = [(it.get("absmaxA"), it.get("absmaxB")) for it in items[lo:lo + 64]]
+        if any(a is not None or b is not None for a, b in words):
+            # operands whose maximum the caller already has on the device (a [1] float tensor holding it as float bits: yt8m_h2_absmax's
+            # form) skip their absmax pass when they take the h2 form
+            pa = (ctypes.c_void_p * len(part))(*[a.data_ptr() if a is not None else None for a, _ in words])
+            pb = (ctypes.c_void_p * len(part))(*[b.data_ptr() if b is not None else None for _, b in words])
+            _lib.check(lib.yt8m_gemm_auto_grouped_ex(ta, int(transB), len(part), arr, pa, pb, _p(ws), ws.numel() * 4, _p(img), nb, None, _stream()))
+        else:
+            _lib.check(lib.yt8m_gemm_auto_grouped(ta, int(transB), len(part), arr, _p(ws), ws.numel() * 4, _p(img), nb, None, _stream()))
     return outs
 
 
@@ -1202,6 +1210,7 @@ def _bf16_ok(x2):
 # passes on rounded logits: tests/test_gpu_round6.py::test_bf16_logits_*).
 Z16_LOGITS = os.environ.get("YT8M_Z16_LOGITS", "0") != "0"
 MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
+MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
 
 def _z16_ok(x2, Wg, We, V, M, bf16, training):
@@ -1285,9 +1294,15 @@ class _MoeHeadXent(torch.autograd.Function):
             dx = _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, labels=lab, ldt=ldt, dscale=1.0 / x.shape[0],
                                           up=_f32c(dloss.reshape(1)))
             return dx, None, None, None, None, None, None, None, None
-        _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
-                                                    XENT_EPS, 1.0, _stream()))
-        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
+        zmax = None
+        if MIX_BWD_ABSMAX:
+            zmax = torch.empty(2, dtype=torch.float32, device=Zg.device)  # max |dZg|, max |dZe| as float bits, written by the same pass
+            _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd_absmax(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
+                                                               XENT_EPS, 1.0, _p(zmax), _stream()))
+        else:
+            _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
+                                                        XENT_EPS, 1.0, _stream()))
+        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=zmax)
         return dx, None, None, None, None, None, None, None, None
 
 
@@ -1357,8 +1372,11 @@ def join_side_work(graph):
     graph.side_pending = []
 
 
-def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
-    """dW_g = x^T dZ_g, dW_e = x^T dZ_e, db_e = colsum(dZ_e), dx = dZ_g W_g^T + dZ_e W_e^T."""
+def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None):
+    """dW_g = x^T dZ_g, dW_e = x^T dZ_e, db_e = colsum(dZ_e), dx = dZ_g W_g^T + dZ_e W_e^T.
+    zmax (a [2] float tensor, optional): max |dZ_g|, max |dZ_e| as float bits, already measured by the pass that wrote them."""
+    mg = zmax[0:1] if zmax is not None else None
+    me = zmax[1:2] if zmax is not None else None
     if getattr(ctx, "bf16", False) and _bf16_ok(x):
         return _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be)
     dx = None
@@ -1375,7 +1393,8 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
             t.record_stream(side)                  # (their memory must not be handed out again before the side stream is done)
         bw, bwe, bbe = Wg.grad_beta(), We.grad_beta(), be.grad_beta()
         with torch.cuda.stream(side):
-            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw), dict(A=x, B=Ze, out=We.grad, beta=bwe)], transA=True, role="dw")
+            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw, absmaxB=mg), dict(A=x, B=Ze, out=We.grad, beta=bwe, absmaxB=me)],
+                         transA=True, role="dw")
             colsum(Ze, be.grad.view(-1), beta=bbe)
         if not hasattr(g, "side_pending") or g.side_pending is None:
             g.side_pending = []
@@ -1385,15 +1404,15 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be):
         be.grad_done()
         return dx
     if Wg.grad is not None and We.grad is not None and not overlap:
-        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta()),
-                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta())], transA=True, role="dw")
+        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta(), absmaxB=mg),
+                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta(), absmaxB=me)], transA=True, role="dw")
         Wg.grad_done()
         We.grad_done()
     elif Wg.grad is not None and We.grad is not None:
         # data-parallel: finish the big gate gradient first so its all-reduce rides under the expert GEMM
-        gemm(x, Zg, out=Wg.grad, transA=True, beta=Wg.grad_beta(), role="dw")
+        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta(), absmaxB=mg)], transA=True, role="dw")
         Wg.grad_done()
-        gemm(x, Ze, out=We.grad, transA=True, beta=We.grad_beta(), role="dw")
+        gemm_grouped([dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta(), absmaxB=me)], transA=True, role="dw")
         We.grad_done()
     if be.grad is not None:
         colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
