@@ -5,6 +5,7 @@
 // They only sequence existing launches (grouped GEMMs through the library's kernel dispatch -- csrc/gemm_auto.hip: the large products
 // run on the bf16 pipe as six products of split operands when the workspace holds their images --, fused mixing + loss, column
 // sums) on the caller's stream.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -12,6 +13,15 @@ using namespace yt8m;
 
 namespace {
 int64_t up256h(int64_t v) { return (v + 255) / 256 * 256; }
+// round 6: the logits product x . [W_g | W_e] declares the h2 role (include/yt8m_hip.h YT8M_GEMM_ROLE_H2), as the host mirror does
+// (ops._moe_logits); YT8M_MOE_LOGITS_H2=0: the six-product form
+// ... from YT8M_MOE_LOGITS_H2_MIN_ROWS rows on (default 1 024): the weights' half-plane images are made per call, which a B = 128 product
+// does not pay back
+int logits_role(int64_t B) {
+  static const bool off = getenv("YT8M_MOE_LOGITS_H2") != nullptr && atoi(getenv("YT8M_MOE_LOGITS_H2")) == 0;
+  static const int64_t min_rows = getenv("YT8M_MOE_LOGITS_H2_MIN_ROWS") ? atoll(getenv("YT8M_MOE_LOGITS_H2_MIN_ROWS")) : 1024;
+  return (off || B < min_rows) ? 0 : YT8M_GEMM_ROLE_H2;
+}
 // [ mix+xent partial sums | split-K workspace | operand images of the bf16-pipe products (whatever is left) ]
 struct HeadWs { char* mix; char* gemm; int64_t gemm_bytes; char* img; int64_t img_bytes; };
 HeadWs carve(void* workspace, int64_t workspace_bytes, int64_t mix_bytes) {
@@ -43,7 +53,7 @@ extern "C" int64_t yt8m_moe_workspace_bytes_ex(int64_t B, int64_t D, int64_t V, 
   const yt8m_gemm_problem f[2] = {{B, Ng, D, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}, {B, Ne, D, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}};
   const yt8m_gemm_problem x[2] = {{B, D, Ng, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}, {B, D, Ne, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 1.f}};
   const yt8m_gemm_problem w[2] = {{D, Ng, B, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}, {D, Ne, B, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0.f}};
-  const int64_t img = std::max(yt8m_gemm_auto_scratch_bytes(0, 0, 2, f),
+  const int64_t img = std::max(yt8m_gemm_auto_scratch_bytes(logits_role(B), 0, 2, f),
                                std::max(std::max(yt8m_gemm_auto_scratch_bytes(0, 1, 1, x), yt8m_gemm_auto_scratch_bytes(0, 1, 1, x + 1)),
                                         yt8m_gemm_auto_scratch_bytes(1 | YT8M_GEMM_ROLE_DW, 0, 2, w)));
   return up256h(yt8m_moe_mix_xent_workspace_bytes(B, V)) + up256h(yt8m_gemm_workspace_bytes()) + 256 + img;
@@ -61,7 +71,7 @@ extern "C" int yt8m_moe_fwd(const float* x, const float* Wg, const float* We, co
   const int64_t Ng = V * (M + 1), Ne = V * M;
   const HeadWs w = carve(workspace, workspace_bytes, yt8m_moe_mix_xent_workspace_bytes(B, V));
   yt8m_gemm_problem pr[2] = {{B, Ng, D, x, D, Wg, Ng, Zg, Ng, nullptr, 0.0f}, {B, Ne, D, x, D, We, Ne, Ze, Ne, be, 0.0f}};
-  int rc = yt8m_gemm_auto_grouped(0, 0, 2, pr, w.gemm, w.gemm_bytes, w.img, w.img_bytes, nullptr, stream);
+  int rc = yt8m_gemm_auto_grouped(logits_role(B), 0, 2, pr, w.gemm, w.gemm_bytes, w.img, w.img_bytes, nullptr, stream);
   if (rc != YT8M_OK) return rc;
   if (labels) return yt8m_moe_mix_xent_fwd(Zg, Ze, labels, label_dtype, p, loss_out, B, V, M, eps, w.mix, stream);
   return yt8m_moe_mix_fwd(Zg, Ze, p, B, V, M, stream);
@@ -80,7 +90,10 @@ extern "C" int yt8m_moe_bwd(const float* x, const float* Wg, const float* We, fl
   YT8M_REQUIRE(workspace_bytes >= yt8m_moe_workspace_bytes(B, V), YT8M_E_BADARG, "workspace too small");
   const int64_t Ng = V * (M + 1), Ne = V * M;
   const HeadWs w = carve(workspace, workspace_bytes, yt8m_moe_mix_xent_workspace_bytes(B, V));
-  int rc = yt8m_moe_mix_xent_bwd(Zg, Ze, labels, label_dtype, nullptr, B, V, M, eps, upstream, stream);
+  // the mixing backward leaves max |dZg| / max |dZe| in the first two words of the (otherwise idle) mix scratch: the weight-gradient
+  // products' h2 split takes them instead of measuring them again
+  float* zmax = reinterpret_cast<float*>(w.mix);
+  int rc = yt8m_moe_mix_xent_bwd_absmax(Zg, Ze, labels, label_dtype, nullptr, B, V, M, eps, upstream, zmax, stream);
   if (rc != YT8M_OK) return rc;
   if (dx) {                                               // dx = dZg Wg^T + dZe We^T (two launches: the second accumulates)
     yt8m_gemm_problem px = {B, D, Ng, Zg, Ng, Wg, Ng, dx, D, nullptr, 0.0f};
@@ -91,8 +104,10 @@ extern "C" int yt8m_moe_bwd(const float* x, const float* Wg, const float* We, fl
     if (rc != YT8M_OK) return rc;
   }
   yt8m_gemm_problem pw[2] = {{D, Ng, B, x, D, Zg, Ng, dWg, Ng, nullptr, beta}, {D, Ne, B, x, D, Ze, Ne, dWe, Ne, nullptr, beta}};
-  rc = yt8m_gemm_auto_grouped(1 | YT8M_GEMM_ROLE_DW, 0, 2, pw, w.gemm, w.gemm_bytes, w.img, w.img_bytes, nullptr, stream);
+  const float* wordsB[2] = {zmax, zmax + 1};
+  rc = yt8m_gemm_auto_grouped_ex(1 | YT8M_GEMM_ROLE_DW, 0, 2, pw, nullptr, wordsB, w.gemm, w.gemm_bytes, w.img, w.img_bytes, nullptr, stream);
   if (rc != YT8M_OK) return rc;
+  // (the column sums' scratch starts behind the two words: the products above read them on this stream before the sums overwrite)
   return yt8m_colsum_f32(Ze, B, Ne, Ne, dbe, beta, w.mix, up256h(yt8m_moe_mix_xent_workspace_bytes(B, V)), stream);
 }
 

@@ -1210,6 +1210,7 @@ def _bf16_ok(x2):
 # passes on rounded logits: tests/test_gpu_round6.py::test_bf16_logits_*).
 Z16_LOGITS = os.environ.get("YT8M_Z16_LOGITS", "0") != "0"
 MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
+MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "1024"))
 MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
 
@@ -1249,7 +1250,11 @@ def _moe_logits(x2, Wg, We, be, bf16, keep=None, z16=False):
                                      dict(A=xb, B=cast_bf16(We.data, transpose=True), bias=be.data)])
     # fp32 configuration: the logits product declares the h2 role (three f16 products under one scale per operand matrix) -- its input is
     # l2-normalised or a bounded hidden activation, each operand one weight matrix (MOE_LOGITS_H2 / YT8M_MOE_LOGITS_H2=0: six-product form)
-    return gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)], role="h2" if MOE_LOGITS_H2 else None)
+    # -- from MOE_LOGITS_H2_MIN_ROWS rows on: the weights' half-plane images are made per call (absmax + split of [D, 5V]), which a
+    # B = 128 product does not pay back (NetVLADModel at B = 128: 2.57 -> 2.88 ms/step with it; break-even by the split / product rates
+    # ~1 000 rows; measured -6 % at 1 024, -7 % at 8 192)
+    h2 = MOE_LOGITS_H2 and x2.shape[0] >= MOE_LOGITS_H2_MIN_ROWS
+    return gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)], role="h2" if h2 else None)
 
 
 class _MoeHeadXent(torch.autograd.Function):
