@@ -544,7 +544,11 @@ int64_t yt8m_wimg_demand_generation(const void* lo, const void* hi); /* demands 
  * row-major contiguous matrix [R, C]; tensor: its index into l2 / norms.  Each spec covers the row window [row0, row0 + rows)
  * (row0 % 64 == 0; rows % 64 == 0 or the window ends with the matrix -- the input rows [0, Din) of an LSTM weight [Din + H, 4H]):
  * plain = image of the window as an [rows, K = C] operand, trans = image of its transpose ([C rows, K = rows]); either may be NULL;
- * every element times `scale`; planes 3 or 1.  tile_base is filled by yt8m_wimg_jobs_layout. */
+ * every element times `scale`; planes 3 or 1 -- or 2 (round 6): two IEEE-half planes ("h2") under the power of two that the word 256 BYTES
+ * IN FRONT of the image gives (max |w| as float bits, the contract of yt8m_h2_absmax / yt8m_gemm_h2_nt_grouped's dsa / dsb): the caller
+ * allocates [256-byte header | image] and passes the image pointer; header word 1 receives the maximum the tile pass measures and
+ * yt8m_adam_tiles moves it into word 0 before its next pass (first build: put max |w| into word 1, call with do_adam = 0).  Such an image
+ * is registered / looked up with scale 0.  tile_base is filled by yt8m_wimg_jobs_layout. */
 typedef struct yt8m_wimg_spec {
   void* plain;
   void* trans;

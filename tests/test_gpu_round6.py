@@ -406,3 +406,47 @@ def test_mixing_backward_measures_the_maxima_its_weight_gradient_products_split_
     words = torch.empty(2, device=dev)
     L.check(lib.yt8m_moe_mix_xent_bwd_absmax(_p(Zg), _p(Ze), _p(y), 0, _p(up), Bv, V, M, 1e-6, 1.0, _p(words), _st()))
     assert float(words[0]) == float(Zg.abs().max()) and float(words[1]) == float(Ze.abs().max())
+
+
+def test_resident_half_plane_images_of_the_moe_weights(dev, flags):
+    """Round 6: the weights of a product that declared the h2 role get RESIDENT half-plane images (wimg.py planes = 2): the optimiser's
+    tile pass rewrites them under the maximum the previous pass measured (a word in front of the image) instead of an absmax + split
+    per step.  MoeModel B = 1024: the images exist from the third step on, and the run equals the one that re-splits per step -- the
+    scale is the same power of two unless max |w| crossed one between two steps, so: losses to 1e-6, weights to 1e-7 absolute."""
+    import yt8m_amd.train as train
+    import yt8m_amd.video_level_models as vlm
+    import yt8m_amd.wimg as wimg
+
+    def run(resident):
+        old = wimg.H2
+        wimg.H2 = resident
+        try:
+            flags.reset()
+            B, D, V = 1024, 1152, 4716
+            g = reset_default_graph(device=dev, seed=0)
+            tg = train.TrainGraph(vlm.MoeModel(), batch_size=B, graph=g)
+            gen = torch.Generator(device=dev).manual_seed(5)
+            losses = []
+            for _ in range(6):
+                x = torch.rand((B, D), device=dev, generator=gen) * 4.0 - 2.0
+                y = torch.rand((B, V), device=dev, generator=gen) < (3.4 / V)
+                losses.append(float(tg.step(x, y)["loss"]))
+            torch.cuda.synchronize()
+            nh2 = sum(1 for k in (g.wimg.keys if g.wimg is not None else {}) if k[4] == 2)
+            words = []
+            if g.wimg is not None:
+                for k, whole in g.wimg.h2_whole.items():
+                    w = whole[:8].view(torch.float32).cpu()
+                    v = g.trainable_variables()[k[0]]
+                    words.append((float(w[0]), float(w[1]), float(v.data.abs().max())))
+            return losses, g.params.clone(), nh2, words
+        finally:
+            wimg.H2 = old
+
+    a = run(True)
+    b = run(False)
+    assert a[2] >= 2 and b[2] == 0, (a[2], b[2])
+    for w0, w1, cur in a[3]:
+        assert w1 == cur and 0.25 * cur < w0 < 4.0 * cur, (w0, w1, cur)     # next maximum = the weights as they are; the scale word is last step's
+    assert all(abs(x - y) <= 1e-6 * abs(y) for x, y in zip(a[0], b[0])), (a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-7

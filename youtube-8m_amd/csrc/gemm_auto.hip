@@ -89,7 +89,10 @@ extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA_flags, int transB, in
     const yt8m_gemm_problem& q = probs[i];
     if (!x3_allowed(q)) continue;
     if (h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0) {   // (h2 images are 2/3 of these sizes; the scale words sit in front)
-      n += 2 * H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.M, q.K)) + up256(yt8m_x3_image_bytes(q.N, q.K));
+      if (!yt8m_wimg_lookup(static_cast<const float*>(q.A), transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA ? 1 : 0, 2, 0.0f))
+        n += H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.M, q.K));
+      if (!yt8m_wimg_lookup(static_cast<const float*>(q.B), transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0 ? 1 : 0, 2, 0.0f))
+        n += H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.N, q.K));
       continue;
     }
     if (!resident(q.A, transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA != 0)) n += up256(yt8m_x3_image_bytes(q.M, q.K));
@@ -130,6 +133,12 @@ extern "C" int yt8m_gemm_auto_grouped_ex(int transA_flags, int transB, int nprob
                       const float** word) -> bool {
     if (!h2)
       if (const void* r = resident(src, R, C, ld, trans)) { *at = r; return true; }    // a weight matrix with a resident image
+    if (h2 && !ext)                                        // ... or a resident half-plane image: its scale word sits in front of it
+      if (const void* r = yt8m_wimg_lookup(static_cast<const float*>(src), R, C, ld, trans ? 1 : 0, 2, 0.0f)) {
+        *at = r;
+        *word = reinterpret_cast<const float*>(static_cast<const char*>(r) - H2_SCALE_BYTES);
+        return true;
+      }
     for (const Img& m : imgs)
       if (m.src == src && m.R == R && m.C == C && m.ld == ld && m.trans == trans && m.h2 == h2) {
         *at = base + m.off;
@@ -182,6 +191,9 @@ extern "C" int yt8m_gemm_auto_grouped_ex(int transA_flags, int transB, int nprob
     if (m.h2) {                                            // scale measured on the device, then the two-plane half image under it
       const float* word = m.word;                            // the caller's word, or measured here: max |src| as float bits
       if (!word) {
+        // (a weight inside a watched parameter arena: its owner may keep this image resident from the next step on -- planes 2, scale 0
+        //  = "under the device word in front of the image", csrc/wimg.hip)
+        yt8m_wimg_note_demand(static_cast<const float*>(m.src), m.R, m.C, m.ld, m.trans ? 1 : 0, 2, 0.0f);
         float* w = reinterpret_cast<float*>(static_cast<char*>(dst) - H2_SCALE_BYTES);
         YT8M_HIP_CHECK(hipMemsetAsync(w, 0, 4, as_stream(stream)));
         rc = yt8m_h2_absmax(static_cast<const float*>(m.src), m.R, m.C, m.ld, w, stream);

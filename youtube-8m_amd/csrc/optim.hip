@@ -116,6 +116,22 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(float* __restrict__ w, 
 // and / or the transposed one ([C rows, K = rows]), three planes or one, times `scale`.  !ADAM: images only (first build / refresh
 // after a host-side write to the weights).  Window contract (checked by the host): row0 % 64 == 0 and (rows % 64 == 0 or the window
 // ends with the matrix), so a tile is wholly inside or wholly outside a window and rows beyond R are zeros in LDS.
+constexpr int WIMG_H2_HEADER = 256;      // bytes in front of an h2 image: word 0 = max |w| the image was made under, word 1 = the next one
+// Before a tile pass: every h2 image of the jobs takes the maximum the previous pass (or the owner's absmax pass before a first build)
+// measured as its scale word and starts a new measurement.
+__global__ __launch_bounds__(64) void wimg_roll_kernel(const yt8m_wimg_job* __restrict__ jobs) {
+  const yt8m_wimg_job& J = jobs[blockIdx.x];
+  const int si = threadIdx.x >> 1, which = threadIdx.x & 1;
+  if (si >= J.nspec) return;
+  const yt8m_wimg_spec& S = J.spec[si];
+  if (S.planes != 2) return;
+  void* img = which ? S.trans : S.plain;
+  if (!img) return;
+  unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(img) - WIMG_H2_HEADER);
+  hdr[0] = hdr[1];
+  hdr[1] = 0u;
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(256) void adam_tile_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                         const float* __restrict__ g, const yt8m_wimg_job* __restrict__ jobs, int njobs,
@@ -181,12 +197,42 @@ __global__ __launch_bounds__(256) void adam_tile_kernel(float* __restrict__ w, f
   }
   __syncthreads();
   const int a = t & 63, blk = t >> 6;                               // row of the image within the tile, K block within the tile
+  bool tmax_pending = true;
+  float tile_max = 0.f;                                             // (per wave: max |w| over its quarter of the tile's columns)
   for (int si = 0; si < J.nspec; ++si) {
     const yt8m_wimg_spec& S = J.spec[si];
     const int w0 = (int)S.row0, wr = (int)S.rows;
     if (r0 < w0 || r0 >= w0 + wr) continue;                         // tile outside this window (uniform per workgroup)
-    const float sc = S.scale;
+    float sc = S.scale;
     const int NPF = S.planes * yt8m_x3::RG_F;
+    // planes == 2 (round 6): two IEEE-half planes under the power of two the word IN FRONT of the image (256 bytes before it) gives --
+    // max |w| as float bits, as yt8m_h2_absmax leaves it and the consumers' epilogues read it (gemm_x3.hip fold_device_scales).  It is
+    // the maximum the PREVIOUS pass over these weights measured (wimg_roll_kernel moves it there): the split aims at 2^14 of a 2^16
+    // range, so the weights of this step fit unless they quadrupled.  This pass measures the new maximum into the header's second word.
+    const bool h2 = S.planes == 2;
+    if (h2) {
+      const unsigned* hdr = reinterpret_cast<const unsigned*>(static_cast<const char*>(S.plain ? S.plain : S.trans) - WIMG_H2_HEADER);
+      sc *= yt8m_x3::pow2_scale_for(__uint_as_float(hdr[0]), 14);
+    }
+    if (h2 && tmax_pending) {                                          // once per tile and header
+      tmax_pending = false;
+      float mx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) mx = fmaxf(mx, fabsf(T[a][blk * 16 + k]));
+      mx = wave_max(mx);
+      tile_max = mx;
+    }
+    if (h2 && (t & 63) == 0) {
+      const unsigned bits = __float_as_uint(tile_max);
+      if (S.plain) {
+        unsigned* nx = reinterpret_cast<unsigned*>(static_cast<char*>(S.plain) - WIMG_H2_HEADER) + 1;
+        if (bits > __hip_atomic_load(nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nx, bits);
+      }
+      if (S.trans) {
+        unsigned* nx = reinterpret_cast<unsigned*>(static_cast<char*>(S.trans) - WIMG_H2_HEADER) + 1;
+        if (bits > __hip_atomic_load(nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nx, bits);
+      }
+    }
     if (S.plain) {
       const int KB = (C + 15) >> 4;
       const int row = r0 - w0 + a, kb = (c0 >> 4) + blk;
@@ -196,6 +242,7 @@ __global__ __launch_bounds__(256) void adam_tile_kernel(float* __restrict__ w, f
         for (int k = 0; k < 16; ++k) e[k] = T[a][blk * 16 + k] * sc;
         float* dst = static_cast<float*>(S.plain) + ((int64_t)(row >> 5) * KB + kb) * NPF;
         if (S.planes == 3) yt8m_x3::store_block<3>(e, dst, row);
+        else if (h2) yt8m_x3::store_block_h2(e, dst, row);
         else yt8m_x3::store_block<1>(e, dst, row);
       }
     }
@@ -208,6 +255,7 @@ __global__ __launch_bounds__(256) void adam_tile_kernel(float* __restrict__ w, f
         for (int k = 0; k < 16; ++k) e[k] = T[blk * 16 + k][a] * sc;
         float* dst = static_cast<float*>(S.trans) + ((int64_t)(row >> 5) * KB + kb) * NPF;
         if (S.planes == 3) yt8m_x3::store_block<3>(e, dst, row);
+        else if (h2) yt8m_x3::store_block_h2(e, dst, row);
         else yt8m_x3::store_block<1>(e, dst, row);
       }
     }
@@ -272,7 +320,7 @@ extern "C" int64_t yt8m_wimg_jobs_layout(yt8m_wimg_job* jobs, int64_t njobs) {
     YT8M_REQUIRE(J.nspec >= 0 && J.nspec <= 4 && J.tensor >= 0, YT8M_E_BADARG, "0..4 image specs per job");
     for (int i = 0; i < J.nspec; ++i) {
       const yt8m_wimg_spec& S = J.spec[i];
-      YT8M_REQUIRE(S.planes == 1 || S.planes == 3, YT8M_E_BADARG, "planes must be 1 or 3");
+      YT8M_REQUIRE(S.planes == 1 || S.planes == 2 || S.planes == 3, YT8M_E_BADARG, "planes must be 1, 2 (h2: header in front of the image) or 3");
       YT8M_REQUIRE(S.plain || S.trans, YT8M_E_BADARG, "a spec needs an image");
       YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(S.plain) | reinterpret_cast<uintptr_t>(S.trans)) & 15) == 0, YT8M_E_BADARG,
                    "images must be 16-byte aligned");
@@ -302,6 +350,7 @@ extern "C" int yt8m_adam_tiles(float* w, float* m, float* v, const float* g, con
   hipStream_t s = as_stream(stream);
   ProfScope prof(F_OPTIM, s);
   AdamHyper h{gscale, clip, lr_t, beta1, beta2, eps};
+  hipLaunchKernelGGL(wimg_roll_kernel, dim3((unsigned)njobs), dim3(64), 0, s, jobs);        // (h2 images: scale word <- measured maximum)
   if (do_adam)
     hipLaunchKernelGGL(adam_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, w, m, v, g, jobs, (int)njobs, tile0, l2, norms, h);
   else

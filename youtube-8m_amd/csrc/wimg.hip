@@ -48,7 +48,7 @@ bool same(const Entry& e, const float* src, int64_t R, int64_t C, int64_t ld, in
 // -- with `planes` bf16 planes and every element multiplied by `scale` lives at `image` and is kept current by its owner.
 extern "C" int yt8m_wimg_register(const float* src, int64_t R, int64_t C, int64_t ld, int trans, int planes, float scale, void* image) {
   YT8M_REQUIRE(src && image && R >= 1 && C >= 1 && ld >= C, YT8M_E_BADARG, "bad image registration");
-  YT8M_REQUIRE((planes == 1 || planes == 3) && (trans == 0 || trans == 1), YT8M_E_BADARG, "planes in {1, 3}, trans in {0, 1}");
+  YT8M_REQUIRE((planes == 1 || planes == 2 || planes == 3) && (trans == 0 || trans == 1), YT8M_E_BADARG, "planes in {1, 2, 3}, trans in {0, 1}");
   YT8M_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, YT8M_E_BADARG, "images must be 16-byte aligned");
   std::lock_guard<std::mutex> lk(g_mu);
   for (Entry& e : g_reg)

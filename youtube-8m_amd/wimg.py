@@ -31,6 +31,12 @@ from . import _lib
 
 ENABLED = os.environ.get("YT8M_WIMG", "1") != "0"
 MIN_ELEMS = int(os.environ.get("YT8M_WIMG_MIN_ELEMS", 1 << 16))   # smaller matrices rarely reach the image kernels
+# Round 6: resident HALF-PLANE ("h2", planes = 2) images of weights -- two IEEE-half planes under a power-of-two scale derived from a word
+# that sits 256 bytes IN FRONT of the image: max |w| as the previous optimiser pass measured it (the split aims at 2^14 of the half
+# range's 2^16: this step's weights fit unless they quadrupled).  The word's second half collects the next maximum.  Demands come from the
+# products that declared the h2 role for a weight operand (yt8m_gemm_auto_grouped with YT8M_GEMM_ROLE_H2: the MoE logits).
+H2 = os.environ.get("YT8M_WIMG_H2", "1") != "0"
+H2_HEADER = 256
 BUFFERS = {}                   # image device pointer -> (uint8 tensor, rows, K, planes): what ops.* wrap as an X3Image
 STATS = {"builds": 0, "refreshes": 0, "tile_launches": 0}
 
@@ -53,6 +59,7 @@ class WeightImages(object):
         self.tile_base = [0]
         self.skip_dev = None
         self.rejected = set()
+        self.h2_whole = {}                  # key -> the [header | image] tensor of an h2 image (keys[k] is the view behind the header)
         self.watching = False
         if ENABLED and graph.params.is_cuda and graph.total > 0:
             _lib.check(_lib.lib().yt8m_wimg_watch(ctypes.c_void_p(self.lo), ctypes.c_void_p(self.hi), 1))
@@ -87,7 +94,7 @@ class WeightImages(object):
         row0, rows = rel // C, d.R
         if row0 % 64 != 0 or row0 + rows > R or not (rows % 64 == 0 or row0 + rows == R):
             return None
-        if d.planes not in (1, 3):
+        if d.planes not in (1, 3) and not (H2 and d.planes == 2 and d.scale == 0.0):
             return None
         return (v.index, int(row0), int(rows), int(d.trans), int(d.planes), float(d.scale))
 
@@ -152,7 +159,12 @@ class WeightImages(object):
             C = tv[t].data.shape[1]
             img_rows, K = (C, rows) if trans else (rows, C)
             nbytes = L.yt8m_x3_image_bytes(img_rows, K) // 3 * planes
-            buf = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.params.device)
+            if planes == 2:                                                # [256-byte header: scale word, next maximum | image]
+                whole = torch.zeros(H2_HEADER + max(nbytes, 16), dtype=torch.uint8, device=g.params.device)
+                buf = whole[H2_HEADER:]
+                self.h2_whole[k] = whole
+            else:
+                buf = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.params.device)
             self.keys[k] = buf
             BUFFERS[buf.data_ptr()] = (buf, img_rows, K, planes)
         self._layout()
@@ -184,7 +196,7 @@ class WeightImages(object):
                 sp = jobs[j].spec[i]
                 sp.plain = imgs[0].data_ptr() if 0 in imgs else None
                 sp.trans = imgs[1].data_ptr() if 1 in imgs else None
-                sp.row0, sp.rows, sp.scale, sp.planes = row0, rows, scale, planes
+                sp.row0, sp.rows, sp.scale, sp.planes = row0, rows, (1.0 if planes == 2 else scale), planes   # (h2: scale 0 = "device word")
         total = L.yt8m_wimg_jobs_layout(jobs, len(tensors))
         if total < 0:
             _lib.check(int(total))
@@ -216,6 +228,16 @@ class WeightImages(object):
         if self.jobs_dev is None:
             return
         from .ops import _stream
+        if self.h2_whole:                                                  # h2 images: the maximum of the weights as they are -> the header's
+            L = _lib.lib()                                                 # "next" word; the tile pass's roll makes it the scale word
+            tv = self.g.trainable_variables()
+            for k, whole in self.h2_whole.items():
+                t, row0, rows, trans, planes, scale = k
+                v = tv[t]
+                C = v.data.shape[1]
+                whole[:H2_HEADER].zero_()
+                src = ctypes.c_void_p(self.lo + 4 * (v.offset + row0 * C))
+                _lib.check(L.yt8m_h2_absmax(src, rows, C, C, ctypes.c_void_p(whole.data_ptr() + 4), _stream()))
         self._tiles(0, len(self.job_tensor), False, (1.0, 0.0, 0.0, 0.0, 0.0, 0.0), _stream())
         self.version = self.g.params._version
         STATS["refreshes"] += 1
@@ -244,6 +266,7 @@ class WeightImages(object):
         for buf in self.keys.values():
             BUFFERS.pop(buf.data_ptr(), None)
         self.keys = {}
+        self.h2_whole = {}
         self.jobs_dev = self.skip_dev = None
 
 
