@@ -450,3 +450,36 @@ def test_resident_half_plane_images_of_the_moe_weights(dev, flags):
         assert w1 == cur and 0.25 * cur < w0 < 4.0 * cur, (w0, w1, cur)     # next maximum = the weights as they are; the scale word is last step's
     assert all(abs(x - y) <= 1e-6 * abs(y) for x, y in zip(a[0], b[0])), (a[0], b[0])
     assert float((a[1] - b[1]).abs().max()) <= 1e-7
+
+
+def test_large_fully_connected_forward_in_the_declared_h2_role(dev, flags):
+    """Round 6: ops.linear over >= 1 024 rows declares the h2 role for its forward product (the NetVLAD hidden FC at B = 1024:
+    [1024, 73728] . [73728, 1024], Appendix B of SURVEY.md): against fp64 within 4e-6 of the output scale at K = 73 728 (the six-product
+    form: ~1e-6), gradients are those of the six-product run bit for bit (dx / dW keep their forms)."""
+    g = reset_default_graph(device=dev, seed=0)
+    g.begin_step()
+    K, N, M = 73728, 1024, 1024
+    W = g.get_variable("w", (K, N), xavier_uniform)
+    b = g.get_variable("b", (N,), zeros)
+    g.finalize()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.nn.functional.normalize(torch.randn((M, K), device=dev, generator=gen), dim=1)
+    dy = torch.randn((M, N), device=dev, generator=gen) * 1e-3
+    outs = {}
+    old = ops.LINEAR_FWD_H2
+    try:
+        for on in (True, False):
+            ops.LINEAR_FWD_H2 = on
+            xr = x.clone().requires_grad_(True)
+            g.grads.zero_()
+            y = ops.linear(xr, W, b)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            outs[on] = (y.detach().clone(), xr.grad.clone(), W.grad.clone())
+    finally:
+        ops.LINEAR_FWD_H2 = old
+    ref = (x[:64].double() @ W.data.double() + b.data.double())
+    scale = float(ref.abs().max())
+    assert float((outs[True][0][:64].double() - ref).abs().max()) <= 4e-6 * scale
+    assert float((outs[False][0][:64].double() - ref).abs().max()) <= 4e-6 * scale
+    assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][2], outs[False][2])

@@ -847,7 +847,11 @@ class _Linear(torch.autograd.Function):
             y, = gemm_bf16_nt_grouped([dict(A=cast_bf16(x2), B=cast_bf16(W.data, transpose=True),
                                             bias=None if b is None else b.data)])
         else:
-            y = gemm(x2, W.data, bias=None if b is None else b.data)
+            # round 6: a fully-connected layer over >= LINEAR_H2_MIN_ROWS rows declares the h2 role for its FORWARD product (activation x
+            # weight: one scale per operand matrix serves; the weight's half-plane image is resident, wimg.py) -- not for dx, whose dy
+            # rows may differ by decades (the recurrent stack gives those per-row scales)
+            role = "h2" if (LINEAR_FWD_H2 and M >= LINEAR_H2_MIN_ROWS and N % 4 == 0) else None
+            y = gemm(x2, W.data, bias=None if b is None else b.data, role=role)
         ctx.save_for_backward(x2)
         ctx.W, ctx.b, ctx.bf16 = W, b, bf16
         return y
@@ -1211,6 +1215,8 @@ def _bf16_ok(x2):
 Z16_LOGITS = os.environ.get("YT8M_Z16_LOGITS", "0") != "0"
 MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
 MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "1024"))
+LINEAR_FWD_H2 = os.environ.get("YT8M_LINEAR_FWD_H2", "1") != "0"
+LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "1024"))
 MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
 
