@@ -483,3 +483,22 @@ def test_large_fully_connected_forward_in_the_declared_h2_role(dev, flags):
     assert float((outs[True][0][:64].double() - ref).abs().max()) <= 4e-6 * scale
     assert float((outs[False][0][:64].double() - ref).abs().max()) <= 4e-6 * scale
     assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][2], outs[False][2])
+    # dx with dy split row by row (ops._linear_dx_h2_rows): rows of dy 2^-20 apart each keep fp32-grade RELATIVE precision
+    dyw = dy * torch.pow(2.0, -torch.arange(M, device=dev).float() % 21)[:, None]
+    olddx = ops.LINEAR_DX_H2
+    try:
+        got = {}
+        for on in (True, False):
+            ops.LINEAR_DX_H2 = on
+            xr = x.clone().requires_grad_(True)
+            g.grads.zero_()
+            ops.linear(xr, W, b).backward(dyw)
+            torch.cuda.synchronize()
+            got[on] = xr.grad.clone()
+    finally:
+        ops.LINEAR_DX_H2 = olddx
+    rows = [0, 5, 20, 41, 1023]
+    refdx = dyw[rows].double() @ W.data.double().t()
+    for on in (True, False):
+        rel = (got[on][rows].double() - refdx).abs().amax(dim=1) / refdx.abs().amax(dim=1)
+        assert float(rel.max()) <= 4e-6, (on, rel.tolist())

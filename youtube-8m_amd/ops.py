@@ -880,9 +880,46 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _use_bf16(ctx.bf16, M, K, N):                     # dx[M,K] = dy W^T: reduction over N
                 dx, = gemm_bf16_nt_grouped([dict(A=dyb if dyb is not None else cast_bf16(dy), B=cast_bf16(W.data))])
+            elif LINEAR_DX_H2 and M >= LINEAR_H2_MIN_ROWS and N >= 512 and K % 4 == 0 and W.data.is_contiguous():
+                dx = _linear_dx_h2_rows(dy, W)
             else:
                 dx = gemm(dy, W.data, transB=True)
         return dx, None, None, None, None
+
+
+def _linear_dx_h2_rows(dy, W):
+    """dx [M, K] = dy [M, N] . W [K, N]^T as three f16 products with dy split ROW BY ROW -- one power of two per row (yt8m_h2_rowscales /
+    _split_rows, undone by the product's rowscale): a row of dy whose gradient is decades below the largest keeps its own 22 bits, which
+    one scale per matrix would not give it (the form the recurrent stack's dx takes, csrc/lstm_stack.hip).  W as an [K rows, K' = N]
+    half-plane image: resident (wimg.py) or made here under its measured maximum."""
+    L = _lib.lib()
+    M, N = dy.shape
+    K = W.data.shape[0]
+    dev = dy.device
+    nb = lambda rows, kk: max(L.yt8m_x3_image_bytes(rows, kk) // 3 * 2, 16)
+    S = torch.empty(M, dtype=torch.float32, device=dev)
+    inv = torch.empty(M, dtype=torch.float32, device=dev)
+    _lib.check(L.yt8m_h2_rowscales(_p(dy), M, N, N, _p(S), _p(inv), _stream()))
+    dyi = torch.empty(nb(M, N), dtype=torch.uint8, device=dev)
+    _lib.check(L.yt8m_h2_split_rows(_p(dy), M, N, N, _p(S), _p(dyi), _stream()))
+    wp = ctypes.c_void_p(W.data.data_ptr())
+    ptr = L.yt8m_wimg_lookup(wp, K, N, N, 0, 2, 0.0)
+    keep = None
+    if ptr:
+        wimg_p, word_p = ctypes.c_void_p(ptr), ctypes.c_void_p(ptr - 256)          # (the scale word sits in front of a resident image)
+    else:
+        L.yt8m_wimg_note_demand(wp, K, N, N, 0, 2, 0.0)                            # its owner may keep it resident from the next step on
+        word = h2_absmax(W.data)
+        wi = torch.empty(nb(K, N), dtype=torch.uint8, device=dev)
+        _lib.check(L.yt8m_h2_split(wp, K, N, N, 1.0, _p(word), _p(wi), None, None, _stream()))
+        keep = (word, wi)
+        wimg_p, word_p = _p(wi), _p(word)
+    dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+    ws = _workspace(dev)
+    _lib.check(L.yt8m_gemm_h2_nt_ex(M, K, N, _p(dyi), 0, wimg_p, 0, _p(dx), K, None, 1.0, None, word_p, _p(inv), 0.0, _p(ws), ws.numel() * 4,
+                                    _stream()))
+    del keep
+    return dx
 
 
 SKINNY_MIN_ROWS = 2048       # below this the padded MFMA tiles are cheap enough
@@ -1217,6 +1254,7 @@ MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
 MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "1024"))
 LINEAR_FWD_H2 = os.environ.get("YT8M_LINEAR_FWD_H2", "1") != "0"
 LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "1024"))
+LINEAR_DX_H2 = os.environ.get("YT8M_LINEAR_DX_H2", "1") != "0"
 MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
 
