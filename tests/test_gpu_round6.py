@@ -502,3 +502,25 @@ def test_large_fully_connected_forward_in_the_declared_h2_role(dev, flags):
     for on in (True, False):
         rel = (got[on][rows].double() - refdx).abs().amax(dim=1) / refdx.abs().amax(dim=1)
         assert float(rel.max()) <= 4e-6, (on, rel.tolist())
+
+
+def test_moe_head_dx_as_row_scaled_h2_products(dev):
+    """Round 6: dx = dZg . Wg^T + dZe . We^T of the MoE head (W/all_video_models/moe_model.py:40-64 through tf.gradients) from 1 024 rows on:
+    two launches of ops._linear_dx_h2_rows, the second accumulating (beta = 1) -- against fp64 per row, rows 2^-16 apart."""
+    g = reset_default_graph(device=dev, seed=0)
+    g.begin_step()
+    D, V, B = 1024, 1036, 1024
+    Wg = g.get_variable("wg", (D, 3 * V), xavier_uniform)
+    We = g.get_variable("we", (D, 2 * V), xavier_uniform)
+    g.finalize()
+    gen = torch.Generator(device=dev).manual_seed(8)
+    rowmag = torch.pow(2.0, -(torch.arange(B, device=dev).float() % 17))[:, None]
+    Zg = torch.randn((B, 3 * V), device=dev, generator=gen) * 1e-3 * rowmag
+    Ze = torch.randn((B, 2 * V), device=dev, generator=gen) * 1e-3 * rowmag
+    dx = ops._linear_dx_h2_rows(Zg, Wg)
+    ops._linear_dx_h2_rows(Ze, We, out=dx, beta=1.0)
+    torch.cuda.synchronize()
+    rows = [0, 7, 16, 33, 1023]
+    ref = Zg[rows].double() @ Wg.data.double().t() + Ze[rows].double() @ We.data.double().t()
+    rel = (dx[rows].double() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+    assert float(rel.max()) <= 4e-6, rel.tolist()

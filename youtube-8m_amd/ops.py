@@ -887,7 +887,7 @@ class _Linear(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def _linear_dx_h2_rows(dy, W):
+def _linear_dx_h2_rows(dy, W, out=None, beta=0.0):
     """dx [M, K] = dy [M, N] . W [K, N]^T as three f16 products with dy split ROW BY ROW -- one power of two per row (yt8m_h2_rowscales /
     _split_rows, undone by the product's rowscale): a row of dy whose gradient is decades below the largest keeps its own 22 bits, which
     one scale per matrix would not give it (the form the recurrent stack's dx takes, csrc/lstm_stack.hip).  W as an [K rows, K' = N]
@@ -914,10 +914,10 @@ def _linear_dx_h2_rows(dy, W):
         _lib.check(L.yt8m_h2_split(wp, K, N, N, 1.0, _p(word), _p(wi), None, None, _stream()))
         keep = (word, wi)
         wimg_p, word_p = _p(wi), _p(word)
-    dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dev)
     ws = _workspace(dev)
-    _lib.check(L.yt8m_gemm_h2_nt_ex(M, K, N, _p(dyi), 0, wimg_p, 0, _p(dx), K, None, 1.0, None, word_p, _p(inv), 0.0, _p(ws), ws.numel() * 4,
-                                    _stream()))
+    _lib.check(L.yt8m_gemm_h2_nt_ex(M, K, N, _p(dyi), 0, wimg_p, 0, _p(dx), K, None, 1.0, None, word_p, _p(inv), float(beta), _p(ws),
+                                    ws.numel() * 4, _stream()))
     del keep
     return dx
 
@@ -1255,6 +1255,7 @@ MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "1024
 LINEAR_FWD_H2 = os.environ.get("YT8M_LINEAR_FWD_H2", "1") != "0"
 LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "1024"))
 LINEAR_DX_H2 = os.environ.get("YT8M_LINEAR_DX_H2", "1") != "0"
+MOE_DX_H2 = os.environ.get("YT8M_MOE_DX_H2", "1") != "0"
 MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
 
@@ -1430,8 +1431,15 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None):
         return _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be)
     dx = None
     if ctx.needs_input_grad[0]:                    # before the weights' gradient slots are released to an optimiser
-        dx = gemm(Zg, Wg.data, transB=True)
-        gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
+        if (MOE_DX_H2 and Zg.shape[0] >= LINEAR_H2_MIN_ROWS and Wg.data.shape[0] % 4 == 0 and Wg.data.is_contiguous()
+                and We.data.is_contiguous() and Zg.is_contiguous() and Ze.is_contiguous()):
+            # round 6: from 1 024 rows on, three f16 products with dZ split row by row against the weights' half-plane images (the form of
+            # ops._linear_dx_h2_rows) instead of the fp32-MFMA kernel these 16-tile, K ~ 14 000 products fell back to
+            dx = _linear_dx_h2_rows(Zg, Wg)
+            _linear_dx_h2_rows(Ze, We, out=dx, beta=1.0)
+        else:
+            dx = gemm(Zg, Wg.data, transB=True)
+            gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
     overlap = Wg._graph is not None and Wg._graph.grad_ready_hook is not None
     side = side_stream(Wg._graph) if (dx is not None and Wg.grad is not None and We.grad is not None and be.grad is not None) else None
     if side is not None:
