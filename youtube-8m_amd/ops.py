@@ -850,8 +850,10 @@ class _Linear(torch.autograd.Function):
             # round 6: a fully-connected layer over >= LINEAR_H2_MIN_ROWS rows declares the h2 role for its FORWARD product (activation x
             # weight: one scale per operand matrix serves; the weight's half-plane image is resident, wimg.py) -- not for dx, whose dy
             # rows may differ by decades (the recurrent stack gives those per-row scales)
-            role = "h2" if (LINEAR_FWD_H2 and M >= LINEAR_H2_MIN_ROWS and N % 4 == 0) else None
-            y = gemm(x2, W.data, bias=None if b is None else b.data, role=role)
+            role = "h2" if (LINEAR_FWD_H2 and M >= LINEAR_H2_MIN_ROWS and N % 4 == 0 and K >= 512) else None
+            # max |x| is measured ONCE: the forward product's split and the weight gradient's split of x^T both take the word
+            ctx.xmax = h2_absmax(x2).view(torch.float32) if role == "h2" else None
+            y = gemm_grouped([dict(A=x2, B=W.data, bias=None if b is None else b.data, absmaxA=ctx.xmax)], role=role)[0]
         ctx.save_for_backward(x2)
         ctx.W, ctx.b, ctx.bf16 = W, b, bf16
         return y
@@ -873,7 +875,7 @@ class _Linear(torch.autograd.Function):
                 gemm_bf16_nt_grouped([dict(A=cast_bf16(x, transpose=True), B=dyT, out=W.grad, beta=W.grad_beta())])
                 del dyT
             else:
-                gemm(x, dy, out=W.grad, transA=True, beta=W.grad_beta(), role="dw")
+                gemm_grouped([dict(A=x, B=dy, out=W.grad, beta=W.grad_beta(), absmaxA=getattr(ctx, "xmax", None))], transA=True, role="dw")
         if b is not None and b.trainable and b.grad is not None:
             colsum(dy, b.grad.view(-1), beta=b.grad_beta())
         dx = None
@@ -1275,7 +1277,7 @@ def _z16_ok(x2, Wg, We, V, M, bf16, training):
     return True
 
 
-def _moe_logits(x2, Wg, We, be, bf16, keep=None, z16=False):
+def _moe_logits(x2, Wg, We, be, bf16, keep=None, z16=False, words=None):
     """Zg = x.Wg, Ze = x.We + be as ONE persistent launch; bf16: operands are bf16 copies (x, Wg^T, We^T: both sides
     K-contiguous), accumulation and outputs stay fp32.  keep (a dict, training only): the image pass of x / Wg / We writes the
     OTHER orientation too -- what the backward products read (x^T for dW, W for dx) -- so each tensor is read once per step."""
@@ -1299,7 +1301,10 @@ def _moe_logits(x2, Wg, We, be, bf16, keep=None, z16=False):
     # B = 128 product does not pay back (NetVLADModel at B = 128: 2.57 -> 2.88 ms/step with it; break-even by the split / product rates
     # ~1 000 rows; measured -6 % at 1 024, -7 % at 8 192)
     h2 = MOE_LOGITS_H2 and x2.shape[0] >= MOE_LOGITS_H2_MIN_ROWS
-    return gemm_grouped([dict(A=x2, B=Wg.data), dict(A=x2, B=We.data, bias=be.data)], role="h2" if h2 else None)
+    xmax = h2_absmax(x2).view(torch.float32) if (h2 and words is not None) else None      # measured once: the weight gradient's split of
+    if xmax is not None:                                                                  # x^T takes the same word (words["x"])
+        words["x"] = xmax
+    return gemm_grouped([dict(A=x2, B=Wg.data, absmaxA=xmax), dict(A=x2, B=We.data, bias=be.data, absmaxA=xmax)], role="h2" if h2 else None)
 
 
 class _MoeHeadXent(torch.autograd.Function):
@@ -1310,7 +1315,8 @@ class _MoeHeadXent(torch.autograd.Function):
     def forward(ctx, x, token, Wg, We, be, labels, V, M, bf16):
         x2 = _f32c(x)
         ctx.images = {} if (bf16 and FUSED_MIX_BF16 and M == 2 and ctx.needs_input_grad[1]) else None
-        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images)
+        ctx.words = {}
+        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images, words=ctx.words)
         ctx.bf16 = bf16
         B = x2.shape[0]
         lab, ldt = _labels_arg(labels)
@@ -1352,7 +1358,7 @@ class _MoeHeadXent(torch.autograd.Function):
         else:
             _lib.check(_lib.lib().yt8m_moe_mix_xent_bwd(_p(Zg), _p(Ze), _p(lab), ldt, _p(_f32c(dloss.reshape(1))), x.shape[0], V, M,
                                                         XENT_EPS, 1.0, _stream()))
-        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=zmax)
+        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=zmax, xmax=ctx.words.get("x"))
         return dx, None, None, None, None, None, None, None, None
 
 
@@ -1422,7 +1428,7 @@ def join_side_work(graph):
     graph.side_pending = []
 
 
-def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None):
+def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None, xmax=None):
     """dW_g = x^T dZ_g, dW_e = x^T dZ_e, db_e = colsum(dZ_e), dx = dZ_g W_g^T + dZ_e W_e^T.
     zmax (a [2] float tensor, optional): max |dZ_g|, max |dZ_e| as float bits, already measured by the pass that wrote them."""
     mg = zmax[0:1] if zmax is not None else None
@@ -1450,7 +1456,7 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None):
             t.record_stream(side)                  # (their memory must not be handed out again before the side stream is done)
         bw, bwe, bbe = Wg.grad_beta(), We.grad_beta(), be.grad_beta()
         with torch.cuda.stream(side):
-            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw, absmaxB=mg), dict(A=x, B=Ze, out=We.grad, beta=bwe, absmaxB=me)],
+            gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=bw, absmaxA=xmax, absmaxB=mg), dict(A=x, B=Ze, out=We.grad, beta=bwe, absmaxA=xmax, absmaxB=me)],
                          transA=True, role="dw")
             colsum(Ze, be.grad.view(-1), beta=bbe)
         if not hasattr(g, "side_pending") or g.side_pending is None:
@@ -1461,15 +1467,15 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None):
         be.grad_done()
         return dx
     if Wg.grad is not None and We.grad is not None and not overlap:
-        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta(), absmaxB=mg),
-                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta(), absmaxB=me)], transA=True, role="dw")
+        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta(), absmaxA=xmax, absmaxB=mg),
+                      dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta(), absmaxA=xmax, absmaxB=me)], transA=True, role="dw")
         Wg.grad_done()
         We.grad_done()
     elif Wg.grad is not None and We.grad is not None:
         # data-parallel: finish the big gate gradient first so its all-reduce rides under the expert GEMM
-        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta(), absmaxB=mg)], transA=True, role="dw")
+        gemm_grouped([dict(A=x, B=Zg, out=Wg.grad, beta=Wg.grad_beta(), absmaxA=xmax, absmaxB=mg)], transA=True, role="dw")
         Wg.grad_done()
-        gemm_grouped([dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta(), absmaxB=me)], transA=True, role="dw")
+        gemm_grouped([dict(A=x, B=Ze, out=We.grad, beta=We.grad_beta(), absmaxA=xmax, absmaxB=me)], transA=True, role="dw")
         We.grad_done()
     if be.grad is not None:
         colsum(Ze, be.grad.view(-1), beta=be.grad_beta())
