@@ -47,7 +47,10 @@ CONFIGS = {
     "lstm_posattn": dict(model=flm.LstmPositionalAttentionMaxPoolingModel, B=128, frame=True),
     "cnn_chain": dict(model=flm.CnnDeepCombineChainModel, B=128, frame=True, multitask=True,
                       flags=dict(deep_chain_layers=3, deep_chain_relu_cells=128, support_type=",".join(["label"] * 3))),
-    "gru_pool": dict(model=flm.GruPoolingModel, B=128, frame=True),
+    # (lr: with the reference's default 0.01 this stack leaves the finite range within seven steps on the uniform-noise frames of this
+    #  harness -- the recurrence turns chaotic and dz reaches 1e38 in BOTH forms of the forward kernel, tools/gru_nan_debug.py; which
+    #  step overflows depends on rounding.  The timing does not care, a printed "loss nan" invites the wrong conclusion.)
+    "gru_pool": dict(model=flm.GruPoolingModel, B=128, frame=True, lr=0.001),
     "ln_lstm": dict(model=flm.LayerNormLstmMemoryModel, B=128, frame=True),
     "lstm_mem_dropout": dict(model=flm.LstmMemoryModel, B=128, frame=True, flags=dict(dropout=True, keep_prob=0.8)),
     "chain_dropout": dict(model=vlm.DeepCombineChainModel, B=512, frame=False, multitask=True,
@@ -69,7 +72,7 @@ def run(name, steps=5):
     B = cfg["B"]
     g = reset_default_graph(device=dev, seed=0)
     mt = cfg.get("multitask", False)
-    tg = train.TrainGraph(cfg["model"](), batch_size=B, graph=g, multitask=mt,
+    tg = train.TrainGraph(cfg["model"](), batch_size=B, graph=g, multitask=mt, base_learning_rate=cfg.get("lr", 0.01),
                           label_loss_fn=losses.MultiTaskCrossEntropyLoss() if mt else None)
     gen = torch.Generator(device=dev).manual_seed(1)
     if cfg["frame"]:

@@ -850,7 +850,7 @@ class _Linear(torch.autograd.Function):
             # round 6: a fully-connected layer over >= LINEAR_H2_MIN_ROWS rows declares the h2 role for its FORWARD product (activation x
             # weight: one scale per operand matrix serves; the weight's half-plane image is resident, wimg.py) -- not for dx, whose dy
             # rows may differ by decades (the recurrent stack gives those per-row scales)
-            role = "h2" if (LINEAR_FWD_H2 and M >= LINEAR_H2_MIN_ROWS and N % 4 == 0 and K >= 512) else None
+            role = "h2" if (LINEAR_FWD_H2 and _linear_h2_size(M, N, K) and N % 4 == 0 and K >= 512) else None
             # max |x| is measured ONCE: the forward product's split and the weight gradient's split of x^T both take the word
             ctx.xmax = h2_absmax(x2).view(torch.float32) if role == "h2" else None
             y = gemm_grouped([dict(A=x2, B=W.data, bias=None if b is None else b.data, absmaxA=ctx.xmax)], role=role)[0]
@@ -882,11 +882,18 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _use_bf16(ctx.bf16, M, K, N):                     # dx[M,K] = dy W^T: reduction over N
                 dx, = gemm_bf16_nt_grouped([dict(A=dyb if dyb is not None else cast_bf16(dy), B=cast_bf16(W.data))])
-            elif LINEAR_DX_H2 and M >= LINEAR_H2_MIN_ROWS and N >= 512 and K % 4 == 0 and W.data.is_contiguous():
+            elif LINEAR_DX_H2 and _linear_h2_size(M, N, K) and N >= 512 and K % 4 == 0 and W.data.is_contiguous():
                 dx = _linear_dx_h2_rows(dy, W)
             else:
                 dx = gemm(dy, W.data, transB=True)
         return dx, None, None, None, None
+
+
+def _linear_h2_size(M, N, K):
+    """A fully-connected layer takes the h2 forms from LINEAR_H2_MIN_ROWS rows on, or when its product is large whatever the row count
+    (LINEAR_H2_MIN_MNK: the NetVLAD / DBoF hidden layers at B = 128 -- K = 73 728 / 8 192 -- gain 12-14 % of their step; small layers do
+    not pay the per-call passes over their activations back: cnn_chain +3 % with every layer on it)."""
+    return M >= LINEAR_H2_MIN_ROWS or M * N * K >= LINEAR_H2_MIN_MNK
 
 
 def _linear_dx_h2_rows(dy, W, out=None, beta=0.0):
@@ -1255,8 +1262,9 @@ Z16_LOGITS = os.environ.get("YT8M_Z16_LOGITS", "0") != "0"
 MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
 MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "1024"))
 LINEAR_FWD_H2 = os.environ.get("YT8M_LINEAR_FWD_H2", "1") != "0"
-LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "1024"))
+LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "512"))
 LINEAR_DX_H2 = os.environ.get("YT8M_LINEAR_DX_H2", "1") != "0"
+LINEAR_H2_MIN_MNK = float(os.environ.get("YT8M_LINEAR_H2_MIN_MNK", "1e9"))
 MOE_DX_H2 = os.environ.get("YT8M_MOE_DX_H2", "1") != "0"
 MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
@@ -1437,7 +1445,7 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None, xmax=None):
         return _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be)
     dx = None
     if ctx.needs_input_grad[0]:                    # before the weights' gradient slots are released to an optimiser
-        if (MOE_DX_H2 and Zg.shape[0] >= LINEAR_H2_MIN_ROWS and Wg.data.shape[0] % 4 == 0 and Wg.data.is_contiguous()
+        if (MOE_DX_H2 and Zg.shape[0] >= MOE_LOGITS_H2_MIN_ROWS and Wg.data.shape[0] % 4 == 0 and Wg.data.is_contiguous()
                 and We.data.is_contiguous() and Zg.is_contiguous() and Ze.is_contiguous()):
             # round 6: from 1 024 rows on, three f16 products with dZ split row by row against the weights' half-plane images (the form of
             # ops._linear_dx_h2_rows) instead of the fp32-MFMA kernel these 16-tile, K ~ 14 000 products fell back to
