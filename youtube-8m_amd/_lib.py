@@ -319,6 +319,9 @@ def lib():
             raise Yt8mHipError(
                 "libyt8m_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C youtube-8m_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # torch first: its bundled HIP runtime must be the one the process initialises.  Loaded the other way round (build() then smoke()
+        # in one process on the GPU box) the library's launches fail with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
