@@ -15,11 +15,11 @@ namespace {
 int64_t up256h(int64_t v) { return (v + 255) / 256 * 256; }
 // round 6: the logits product x . [W_g | W_e] declares the h2 role (include/yt8m_hip.h YT8M_GEMM_ROLE_H2), as the host mirror does
 // (ops._moe_logits); YT8M_MOE_LOGITS_H2=0: the six-product form
-// ... from YT8M_MOE_LOGITS_H2_MIN_ROWS rows on (default 1 024): the weights' half-plane images are made per call, which a B = 128 product
-// does not pay back
+// ... from YT8M_MOE_LOGITS_H2_MIN_ROWS rows on (default 512, as the host mirror): the weights' half-plane images are made per call or kept
+// resident by the optimiser pass, which a B = 128 product does not pay back
 int logits_role(int64_t B) {
   static const bool off = getenv("YT8M_MOE_LOGITS_H2") != nullptr && atoi(getenv("YT8M_MOE_LOGITS_H2")) == 0;
-  static const int64_t min_rows = getenv("YT8M_MOE_LOGITS_H2_MIN_ROWS") ? atoll(getenv("YT8M_MOE_LOGITS_H2_MIN_ROWS")) : 1024;
+  static const int64_t min_rows = getenv("YT8M_MOE_LOGITS_H2_MIN_ROWS") ? atoll(getenv("YT8M_MOE_LOGITS_H2_MIN_ROWS")) : 512;
   return (off || B < min_rows) ? 0 : YT8M_GEMM_ROLE_H2;
 }
 // [ mix+xent partial sums | split-K workspace | operand images of the bf16-pipe products (whatever is left) ]

@@ -1260,7 +1260,7 @@ def _bf16_ok(x2):
 # passes on rounded logits: tests/test_gpu_round6.py::test_bf16_logits_*).
 Z16_LOGITS = os.environ.get("YT8M_Z16_LOGITS", "0") != "0"
 MOE_LOGITS_H2 = os.environ.get("YT8M_MOE_LOGITS_H2", "1") != "0"
-MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "1024"))
+MOE_LOGITS_H2_MIN_ROWS = int(os.environ.get("YT8M_MOE_LOGITS_H2_MIN_ROWS", "512"))   # 512: DeepCombineChain at B = 512 12.95 -> 12.03 ms/step (tools/r6_moe_rows.sh); B = 128 heads stay on the fp32 kernel (+0.3 ms on the headline with them)
 LINEAR_FWD_H2 = os.environ.get("YT8M_LINEAR_FWD_H2", "1") != "0"
 LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "512"))
 LINEAR_DX_H2 = os.environ.get("YT8M_LINEAR_DX_H2", "1") != "0"
@@ -1307,7 +1307,8 @@ def _moe_logits(x2, Wg, We, be, bf16, keep=None, z16=False, words=None):
     # l2-normalised or a bounded hidden activation, each operand one weight matrix (MOE_LOGITS_H2 / YT8M_MOE_LOGITS_H2=0: six-product form)
     # -- from MOE_LOGITS_H2_MIN_ROWS rows on: the weights' half-plane images are made per call (absmax + split of [D, 5V]), which a
     # B = 128 product does not pay back (NetVLADModel at B = 128: 2.57 -> 2.88 ms/step with it; break-even by the split / product rates
-    # ~1 000 rows; measured -6 % at 1 024, -7 % at 8 192)
+    # ~1 000 rows while the images were made per call; with them resident (wimg.py) 512 rows gain too: DeepCombineChain at B = 512
+    # 12.95 -> 12.03 ms/step; measured -6 % at 1 024, -7 % at 8 192)
     h2 = MOE_LOGITS_H2 and x2.shape[0] >= MOE_LOGITS_H2_MIN_ROWS
     xmax = h2_absmax(x2).view(torch.float32) if (h2 and words is not None) else None      # measured once: the weight gradient's split of
     if xmax is not None:                                                                  # x^T takes the same word (words["x"])
