@@ -806,6 +806,12 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
         const long long idx = ((long long)t * B + br) * H + ug * 8 + eunit;
 #if defined(YT8M_FWD_EPI_NOLOAD) || defined(YT8M_FWD_EPI_NOZ)     // timing experiments only (wrong results)
         for (int g4 = 0; g4 < 4; ++g4) zpre[jj][g4] = 0.1f * (float)(g4 + eunit);
+#elif defined(YT8M_FWD_ZPACK_T)   // timing experiment only (wrong results): the four gates of a (row, unit) pair as ONE 16-byte read, a row's
+        {                             // eight units of this workgroup = one full 128-byte line (layout [row][unit][gate] instead of [row][gate][unit])
+          const float4 zq = *reinterpret_cast<const float4*>(a.z + ((long long)t * B + br) * 4 * H + (ug * 8 + eunit) * 4);
+          zpre[jj][0] = zq.x; zpre[jj][1] = zq.y; zpre[jj][2] = zq.z; zpre[jj][3] = zq.w;
+          (void)zr;
+        }
 #else
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) zpre[jj][g4] = zr[g4 * H];
@@ -909,8 +915,12 @@ __global__ __launch_bounds__(768) void lstm_persist_fwd_x3_kernel(PersistFwdArgs
           const long long idx1 = ((long long)(t + 1) * B + brow) * H + ug * 8 + eunit;
 #ifndef YT8M_FWD_EPI_NOSTORE  // timing experiment only (wrong results)
           if (live[jj]) {
+#ifdef YT8M_FWD_ZPACK_T
+            *reinterpret_cast<float4*>(a.z + ((long long)t * B + brow) * 4 * H + (ug * 8 + eunit) * 4) = make_float4(gi[jj], gj[jj], gf[jj], go[jj]);
+#else
             float* zr = a.z + ((long long)t * B + brow) * 4 * H + ug * 8 + eunit;
             zr[0] = gi[jj]; zr[H] = gj[jj]; zr[2 * H] = gf[jj]; zr[3 * H] = go[jj];
+#endif
           }
           a.cs[idx1] = cn[jj];
           a.hs[idx1] = hn[jj];
