@@ -524,3 +524,70 @@ def test_moe_head_dx_as_row_scaled_h2_products(dev):
     ref = Zg[rows].double() @ Wg.data.double().t() + Ze[rows].double() @ We.data.double().t()
     rel = (dx[rows].double() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
     assert float(rel.max()) <= 4e-6, rel.tolist()
+
+
+def _run_frames_plugin(model, q, y, nf, dev, P=None, rs=None):
+    """A frame-level plugin on RAW uint8 frames through TrainGraph with the reference's DefaultTransformer: forward (creates the
+    variables), inject weights, forward + loss + backward."""
+    import yt8m_amd.train as train
+    g = reset_default_graph(device=dev, seed=0)
+    tg = train.TrainGraph(model, batch_size=q.shape[0], graph=g)
+    qd, yd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+    tg.forward(qd, yd, nfd)
+    g.finalize()
+    if P is None:
+        P = {k: (rs.randn(*v.shape) * 0.3).astype(np.float32) for k, v in g.vars.items()}
+    for k, v in P.items():
+        g.vars[k].data.copy_(torch.from_numpy(v).to(dev).view(g.vars[k].data.shape))
+    res = tg.forward(qd, yd, nfd)
+    loss = tg.loss(res, yd)
+    loss.backward()
+    grads = {k: v.grad.detach().cpu().numpy().astype(np.float64) for k, v in g.vars.items() if v.trainable}
+    return res["predictions"].detach().cpu().numpy().astype(np.float64), float(loss.detach()), grads, P
+
+
+@pytest.mark.parametrize("positional", [False, True])
+def test_attention_lstm_plugins_take_the_raw_uint8_frames(dev, flags, positional, monkeypatch):
+    """Round 6 (last session): LstmAttentionMaxPoolingModel / LstmPositionalAttentionMaxPoolingModel declare accepts_quantized_input --
+    the stack's layer-0 projection AND the attention FC on concat([x, ...]) read the reader's bytes (seq_ops.attention_logits_u8 with
+    per-frame and per-video parts), no fp32 [B,F,D] tensor.  Against (a) the same plugin on the dequantised float frames (the path the
+    reference's transformer feeds) with the same weights and (b) the fp64 restatement: predictions, loss, every gradient; ragged
+    num_frames >= 1 (an empty video's attention weights are 0 / 0 in the reference as well)."""
+    from oracle import np_ref, torch_ref
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.ops as ops_
+    monkeypatch.setattr(ops_, "SKINNY_MIN_ROWS", 1)                      # the attention FC's float parts on the streaming kernels too
+    rs = np.random.RandomState(11 + positional)
+    B, F, D, Hh, V, A, E = 8, 12, 64, 128, 13, 8, 8
+    flags.lstm_cells, flags.lstm_layers, flags.lstm_attentions, flags.positional_embedding_size = str(Hh), 2, A, E
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 1
+    y = rs.rand(B, V) < 0.2
+    cls = flm.LstmPositionalAttentionMaxPoolingModel if positional else flm.LstmAttentionMaxPoolingModel
+    qt = torch.from_numpy(q).to(dev)
+    assert seq_ops.u8_attention_supported(qt, A) and flm._lib_u8_ok(D), "the shape of this test must take the uint8 path"
+    pa, la, ga, P = _run_frames_plugin(cls(), q, y, nf, dev, rs=rs)
+    monkeypatch.setattr(cls, "accepts_quantized_input", False)          # the transformer dequantises: float frames into the plugin
+    pb, lb, gb, _ = _run_frames_plugin(cls(), q, y, nf, dev, P=P)
+    assert set(ga) == set(gb)
+    assert np.abs(pa - pb).max() < 2e-5 and abs(la - lb) < 1e-4 * max(1.0, abs(lb))
+    for k in ga:
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-4 * max(1.0, np.abs(gb[k]).max()), k
+    # fp64 restatement on the dequantised, masked, l2-normalised frames
+    x64 = torch.from_numpy(np_ref.dequant_l2norm_folded(q, nf))
+    tp = {k: torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for k, v in P.items()}
+    layers = [(tp["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % l], tp["RNN/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % l])
+              for l in range(2)]
+    head = (tp["attention-/weights"], tp["attention-/biases"], tp["gates-sub-moe/weights"], tp["experts-sub-moe/weights"],
+            tp["experts-sub-moe/biases"], 2)
+    if positional:
+        pr = torch_ref.lstm_positional_attention_max_pooling(x64, torch.from_numpy(nf), layers, tp["positional_embedding"], *head)
+    else:
+        pr = torch_ref.lstm_attention_max_pooling(x64, torch.from_numpy(nf), layers, *head)
+    lr = torch_ref.cross_entropy(pr, torch.from_numpy(y.astype(np.float64)))
+    lr.backward()
+    assert np.abs(pa - pr.detach().numpy()).max() < 1e-4
+    for k, t in tp.items():
+        if t.grad is not None:
+            assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k

@@ -204,19 +204,48 @@ class LayerNormLstmMemoryModel(models.BaseModel):
                                       **unused_params)
 
 
+def _u8_or_float(model_input, num_frames, num_attentions):
+    """(input, True) when the raw uint8 frames can go all the way (the stack's layer-0 projection and the attention FC both read bytes);
+    else the dequantised, l2-normalised float frames the reference's transformer would have handed over."""
+    if model_input.dtype != torch.uint8:
+        return model_input, False
+    if _lib_u8_ok(model_input.shape[2]) and seq_ops.u8_attention_supported(model_input, num_attentions):
+        return model_input.contiguous(), True
+    return ops.dequant_l2norm(model_input, num_frames), False
+
+
+def _attention_fc_u8(q, num_frames, parts, num_outputs, scope, l2_penalty, rs=None):
+    """slim.fully_connected(concat([x] + parts)) with x = the raw frames (same variables as video_level_models.fully_connected_cat);
+    parts: [B,F,K] per-frame tensors and [B,K] per-video vectors (tiled over the frames by the reference), in concatenation order."""
+    g = get_default_graph()
+    width = q.shape[2] + sum(p.shape[-1] for p in parts)
+    W = g.get_variable(scope + "/weights", (width, num_outputs), xavier_uniform, l2=l2_penalty)
+    b = g.get_variable(scope + "/biases", (num_outputs,), zeros)
+    if rs is None:
+        rs = seq_ops.u8_frame_scales(q, num_frames)                                 # [B,F]; 0 on the padding frames
+    return seq_ops.attention_logits_u8(q, rs, None, W, b, parts=parts)
+
+
 class LstmAttentionMaxPoolingModel(models.BaseModel):
     """W/all_frame_models/lstm_attention_max_pooling_model.py:10-98: LSTM outputs -> A attention poolings ->
-    MoE per attention -> max over attentions."""
+    MoE per attention -> max over attentions.  accepts_quantized_input: the stack (see _lstm_stack) and the attention FC read the raw
+    reader bytes; no fp32 [B,F,D] tensor."""
+    accepts_quantized_input = True
 
     def create_model(self, model_input, vocab_size, num_frames, num_mixtures=None, l2_penalty=1e-8, sub_scope="",
                      original_input=None, **unused_params):
         lstm_size = int(FLAGS.lstm_cells)
         number_of_layers = FLAGS.lstm_layers
         num_attentions = FLAGS.lstm_attentions
+        model_input, u8 = _u8_or_float(model_input, num_frames, num_attentions)
         out_tm, _ = _lstm_stack(model_input, num_frames, lstm_size, number_of_layers)
         outputs = out_tm.transpose(0, 1).contiguous()                               # [B,F,H]
-        attention_activations = video_level_models.fully_connected_cat(               # :51-56 FC on concat([input, outputs])
-            [model_input, outputs], num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
+        if u8:                                                                      # raw reader bytes into the stack AND the attention FC
+            attention_activations = _attention_fc_u8(model_input, num_frames, [outputs], num_attentions, "attention-" + sub_scope,
+                                                     l2_penalty)
+        else:
+            attention_activations = video_level_models.fully_connected_cat(           # :51-56 FC on concat([input, outputs])
+                [model_input, outputs], num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
         attention_weights = seq_ops.attention_weights(attention_activations, num_frames)   # [B,F,A]
         attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
         moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")
@@ -261,16 +290,26 @@ class LstmPositionalAttentionMaxPoolingModel(LstmAttentionMaxPoolingModel):
         lstm_size = int(FLAGS.lstm_cells)
         num_attentions = FLAGS.lstm_attentions
         B, F, D = model_input.shape
+        model_input, u8 = _u8_or_float(model_input, num_frames, num_attentions)
         out_tm, _ = _lstm_stack(model_input, num_frames, lstm_size, FLAGS.lstm_layers)
         outputs = out_tm.transpose(0, 1).contiguous()                               # [B,F,H]
         g = get_default_graph()
         emb = g.get_variable("positional_embedding", (1, F, FLAGS.positional_embedding_size), xavier_uniform, l2=l2_penalty)
         positional_embedding = ops.as_tensor(emb).expand(B, F, FLAGS.positional_embedding_size)
-        mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
-        mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
-        attention_activations = video_level_models.fully_connected_cat(
-            [model_input, positional_embedding, mean_input[:, None, :].expand(B, F, D), outputs],
-            num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
+        if u8:
+            # raw reader bytes: the masked mean frame from the bytes (rs is 0 on the padding frames), the FC on [x | emb | mean | outputs]
+            # with x read as bytes and the mean as ONE row per video
+            rs = seq_ops.u8_frame_scales(model_input, num_frames)
+            inv = 1.0 / num_frames.to(torch.float32)
+            mean_input = seq_ops.pool_u8_raw(inv.view(B, 1, 1).expand(B, F, 1).contiguous(), model_input, rs).view(B, D)
+            attention_activations = _attention_fc_u8(model_input, num_frames, [positional_embedding.contiguous(), mean_input, outputs],
+                                                     num_attentions, "attention-" + sub_scope, l2_penalty, rs=rs)
+        else:
+            mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
+            mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
+            attention_activations = video_level_models.fully_connected_cat(
+                [model_input, positional_embedding, mean_input[:, None, :].expand(B, F, D), outputs],
+                num_attentions, "attention-" + sub_scope, l2_penalty=l2_penalty)
         attention_weights = seq_ops.attention_weights(attention_activations, num_frames)   # [B,F,A]
         attention_outputs = seq_ops.pool_tn(attention_weights, outputs)                    # [B,A,H]
         moe_predictions = self.sub_moe(attention_outputs, vocab_size, sub_scope="sub-moe")

@@ -1255,49 +1255,90 @@ def pool_tn_u8(w, q, rs):
 
 
 class _AttnLogitsU8(torch.autograd.Function):
-    """act [B,F,A] = slim.fully_connected(concat(x, tile(mean_x))) of lstm_attention_max_pooling_model.py:51-56 with x from the
-    raw frames: W rows [0, D) meet the frames, rows [D, D + Dm) the per-video vector mean_x [B, Dm]."""
+    """act [B,F,A] = slim.fully_connected(concat(x, parts...)) of lstm_attention_max_pooling_model.py:51-56 /
+    lstm_positional_attention_max_pooling_model.py:77-84 with x from the raw frames: W rows [0, D) meet the frames, the following rows
+    the other parts in concatenation order -- kinds[i] = 0: a per-frame float tensor [B,F,K_i] (the LSTM outputs, a positional embedding),
+    kinds[i] = 1: a per-video vector [B,K_i] that the reference tiles over the frames (the mean frame)."""
 
     @staticmethod
-    def forward(ctx, token, W, b, q, rs, mean_x):
-        _dev(q, rs, mean_x)
+    def forward(ctx, token, W, b, q, rs, kinds, *parts):
+        _dev(q, rs)
         B, F, D = q.shape
         N = W.data.shape[1]
-        assert W.data.shape[0] == D + mean_x.shape[1]
-        Wx, Wm = W.data[:D], W.data[D:]
+        parts = [_f32c(p).reshape(B * F, p.shape[-1]) if k == 0 else _f32c(p) for k, p in zip(kinds, parts)]
+        assert W.data.shape[0] == D + sum(p.shape[1] for p in parts), "parts do not add up to the weight's input width"
+        Wx = W.data[:D]
         cs = Wx.sum(dim=0)
         y = torch.empty((B * F, N), dtype=torch.float32, device=q.device)
         _lib.check(_lib.lib().yt8m_skinny_fwd_u8(_p(q), D, _p(Wx), Wx.stride(0), _p(b.data if b is not None else None), _p(rs), _p(cs),
                                                  _p(y), N, B * F, D, N, 0.0, _stream()))
-        t = ops.gemm(mean_x, Wm)                                      # [B, N]: tiny
-        y.view(B, F, N).add_(t.view(B, 1, N))
-        ctx.save_for_backward(q, rs, mean_x)
-        ctx.W, ctx.b = W, b
+        k0 = D
+        for kind, p in zip(kinds, parts):
+            K = p.shape[1]
+            Wi = W.data[k0:k0 + K]
+            if kind == 1:
+                t = ops.gemm(p, Wi)                                   # [B, N]: tiny
+                y.view(B, F, N).add_(t.view(B, 1, N))
+            elif ops.skinny_ok(B * F, K, N, p):                       # per-frame float part: accumulates into y
+                ops.skinny_fwd(p, Wi, None, y, beta=1.0)
+            else:
+                ops.gemm(p, Wi, out=y, beta=1.0)
+            k0 += K
+        ctx.save_for_backward(q, rs, *parts)
+        ctx.W, ctx.b, ctx.kinds = W, b, tuple(kinds)
         return y.view(B, F, N)
 
     @staticmethod
     def backward(ctx, dy):
-        q, rs, mean_x = ctx.saved_tensors
-        W, b = ctx.W, ctx.b
+        q, rs = ctx.saved_tensors[:2]
+        parts = ctx.saved_tensors[2:]
+        W, b, kinds = ctx.W, ctx.b, ctx.kinds
         B, F, D = q.shape
         dy = _f32c(dy).view(B * F, -1)
         N = dy.shape[1]
-        if W.trainable and W.grad is not None:
-            wbeta = W.grad_beta()
+        wbeta = W.grad_beta() if (W.trainable and W.grad is not None) else None
+        if wbeta is not None:
             gx = W.grad[:D]
             ws = ops._workspace(q.device)
             _lib.check(_lib.lib().yt8m_skinny_dw_u8(_p(q), D, _p(dy), N, _p(rs), _p(gx), gx.stride(0), B * F, D, N, float(wbeta),
                                                     _p(ws), ws.numel() * 4, _stream()))
-            ops.gemm(mean_x, dy.view(B, F, N).sum(dim=1), out=W.grad[D:], transA=True, beta=wbeta, role="dw")
+        dparts = []
+        dyg = None
+        k0 = D
+        for i, (kind, p) in enumerate(zip(kinds, parts)):
+            K = p.shape[1]
+            Wi = W.data[k0:k0 + K]
+            need = ctx.needs_input_grad[6 + i]
+            if kind == 1:
+                if dyg is None:
+                    dyg = dy.view(B, F, N).sum(dim=1)                 # [B, N]
+                if wbeta is not None:
+                    ops.gemm(p, dyg, out=W.grad[k0:k0 + K], transA=True, beta=wbeta, role="dw")
+                dparts.append(ops.gemm(dyg, Wi, transB=True) if need else None)
+            else:
+                sk = ops.skinny_ok(B * F, K, N, p, dy)
+                if wbeta is not None:
+                    if sk:
+                        ops.skinny_dw(p, dy, W.grad[k0:k0 + K], beta=wbeta)
+                    else:
+                        ops.gemm(p, dy, out=W.grad[k0:k0 + K], transA=True, beta=wbeta, role="dw")
+                dparts.append(((ops.skinny_dx(dy, Wi) if sk else ops.gemm(dy, Wi, transB=True)).view(B, F, K)) if need else None)
+            k0 += K
+        if wbeta is not None:
             W.grad_done()
         if b is not None and b.trainable and b.grad is not None:
             ops.colsum(dy, b.grad.view(-1), beta=b.grad_beta())
             b.grad_done()
-        return None, None, None, None, None, None
+        return (None, None, None, None, None, None) + tuple(dparts)
 
 
-def attention_logits_u8(q, rs, mean_x, W, b):
-    return _AttnLogitsU8.apply(_token(W._graph), W, b, q, rs, mean_x)
+def attention_logits_u8(q, rs, mean_x, W, b, parts=None):
+    """Default form (parts None): concat(x, tile(mean_x)).  parts: the tensors that follow the frames in the concatenation, in order --
+    [B,F,K] per-frame float tensors and / or [B,K] per-video vectors (tiled over the frames)."""
+    if parts is None:
+        parts = [mean_x]
+    kinds = tuple(1 if p.dim() == 2 else 0 for p in parts)
+    return _AttnLogitsU8.apply(_token(W._graph), W, b, q, rs, kinds, *parts)
 
 
 def vlad_q_supported(D):
