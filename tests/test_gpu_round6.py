@@ -591,3 +591,39 @@ def test_attention_lstm_plugins_take_the_raw_uint8_frames(dev, flags, positional
     for k, t in tp.items():
         if t.grad is not None:
             assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k
+
+
+def test_parallel_lstm_plugin_takes_the_raw_uint8_frames(dev, flags, monkeypatch):
+    """LstmParallelFinaloutputModel on the reader's bytes: every stack reads ITS slice of the uint8 frames (row norms of the slice in the
+    projection's epilogue) -- l2_normalize(slice of l2_normalize(x)) = l2_normalize(slice of x).  A slice the uint8 projection does not
+    cover (width % 8 != 0) is dequantised; both against the float path with the same weights and against the fp64 restatement
+    (W/all_frame_models/lstm_parallel_finaloutput_model.py:13-73)."""
+    from oracle import np_ref, torch_ref
+    import yt8m_amd.frame_level_models as flm
+    rs = np.random.RandomState(21)
+    B, F, V = 8, 10, 13
+    fsz, hsz = [64, 32, 12], [128, 128, 128]
+    flags.feature_sizes, flags.lstm_cells, flags.lstm_layers = "64,32,12", "128,128,128", 2
+    q = rs.randint(0, 256, size=(B, F, sum(fsz))).astype(np.uint8)
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1], nf[2] = F, 1, 0
+    y = rs.rand(B, V) < 0.2
+    cls = flm.LstmParallelFinaloutputModel
+    pa, la, ga, P = _run_frames_plugin(cls(), q, y, nf, dev, rs=rs)
+    monkeypatch.setattr(cls, "accepts_quantized_input", False)
+    pb, lb, gb, _ = _run_frames_plugin(cls(), q, y, nf, dev, P=P)
+    assert np.abs(pa - pb).max() < 2e-5 and abs(la - lb) < 1e-4 * max(1.0, abs(lb))
+    for k in ga:
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-4 * max(1.0, np.abs(gb[k]).max()), k
+    x64 = torch.from_numpy(np_ref.dequant_l2norm_folded(q, nf))
+    tp = {k: torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for k, v in P.items()}
+    sets = [[(tp["RNN%d/multi_rnn_cell/cell_%d/basic_lstm_cell/weights" % (i, l)],
+              tp["RNN%d/multi_rnn_cell/cell_%d/basic_lstm_cell/biases" % (i, l)]) for l in range(2)] for i in range(3)]
+    st = torch_ref.lstm_parallel_finaloutput(x64, torch.from_numpy(nf), sets, fsz)
+    pr = torch_ref.moe(st, tp["gates/weights"], tp["experts/weights"], tp["experts/biases"], 2)
+    lr = torch_ref.cross_entropy(pr, torch.from_numpy(y.astype(np.float64)))
+    lr.backward()
+    assert np.abs(pa - pr.detach().numpy()).max() < 1e-4
+    for k, t in tp.items():
+        if t.grad is not None:
+            assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k

@@ -261,7 +261,11 @@ class LstmAttentionMaxPoolingModel(models.BaseModel):
 
 class LstmParallelFinaloutputModel(models.BaseModel):
     """W/all_frame_models/lstm_parallel_finaloutput_model.py:13-73: one LSTM stack per input feature (rgb / audio: the
-    input is split by --feature_sizes, each part re-normalised), head input = concat of every layer's final h."""
+    input is split by --feature_sizes, each part re-normalised), head input = concat of every layer's final h.
+    accepts_quantized_input: l2_normalize(slice of l2_normalize(x)) = l2_normalize(slice of x), so a stack whose slice the uint8
+    projection covers reads the reader's bytes of that slice (its own row norms folded into the GEMM epilogue, see _lstm_stack); the
+    other slices are dequantised and normalised as floats."""
+    accepts_quantized_input = True
 
     def create_model(self, model_input, vocab_size, num_frames, **unused_params):
         number_of_layers = FLAGS.lstm_layers
@@ -272,7 +276,11 @@ class LstmParallelFinaloutputModel(models.BaseModel):
         assert sum(feature_sizes) == model_input.shape[2], "feature_sizes do not add up to the input width"
         states, off = [], 0
         for i, (fs, hs) in enumerate(zip(feature_sizes, lstm_sizes)):
-            sub_input = ops.l2_normalize(model_input[:, :, off:off + fs].contiguous())
+            sub_input = model_input[:, :, off:off + fs].contiguous()
+            if sub_input.dtype != torch.uint8:
+                sub_input = ops.l2_normalize(sub_input)
+            elif not _lib_u8_ok(fs):                                  # (dequant_l2norm normalises the slice and zeroes the padding frames)
+                sub_input = ops.dequant_l2norm(sub_input, num_frames)
             off += fs
             _, finals = _lstm_stack(sub_input, num_frames, hs, number_of_layers, scope="RNN%d" % i)
             states.extend(h for _, h in finals)
