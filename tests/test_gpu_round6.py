@@ -627,3 +627,62 @@ def test_parallel_lstm_plugin_takes_the_raw_uint8_frames(dev, flags, monkeypatch
     for k, t in tp.items():
         if t.grad is not None:
             assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k
+
+
+def test_cnn_chain_plugin_takes_the_raw_uint8_frames(dev, flags, monkeypatch):
+    """CnnDeepCombineChainModel on the reader's bytes (seq_ops.u8_cnn): every (filter, shift) product of the einsum CNN reads the same
+    half image of the frames at a row offset, the weight gradients come from the transposed byte image -- against the float path (the
+    concatenated shifted inputs through ops.linear) with the same weights, and against the fp64 restatement
+    (W/all_frame_models/cnn_deep_combine_chain_model.py:10-140) under the multitask loss; ragged num_frames >= 1, F > the filter lengths."""
+    from oracle import np_ref, torch_ref
+    import yt8m_amd.frame_level_models as flm
+    import yt8m_amd.losses as losses
+    import yt8m_amd.train as train
+    rs = np.random.RandomState(31)
+    B, F, D, V, Lc, cells = 16, 7, 32, 12, 2, 8
+    flags.deep_chain_layers, flags.deep_chain_relu_cells = Lc, cells
+    flags.support_type = ",".join(["label"] * Lc)
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 1
+    y = rs.rand(B, V) < 0.2
+    qt = torch.from_numpy(q).to(dev)
+    assert seq_ops.u8_cnn_supported(qt) and seq_ops.u8_attention_supported(qt, 1), "the shape of this test must take the uint8 path"
+
+    def run(model, P=None):
+        g = reset_default_graph(device=dev, seed=0)
+        tg = train.TrainGraph(model, batch_size=B, graph=g, multitask=True, label_loss_fn=losses.MultiTaskCrossEntropyLoss())
+        qd, yd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(nf).to(dev)
+        tg.forward(qd, yd, nfd)
+        g.finalize()
+        if P is None:
+            P = {k: (rs.randn(*v.shape) * 0.3).astype(np.float32) for k, v in g.vars.items()}
+        for k, v in P.items():
+            g.vars[k].data.copy_(torch.from_numpy(v).to(dev).view(g.vars[k].data.shape))
+        res = tg.forward(qd, yd, nfd)
+        loss = tg.loss(res, yd)
+        loss.backward()
+        grads = {k: v.grad.detach().cpu().numpy().astype(np.float64) for k, v in g.vars.items() if v.trainable}
+        return (res["predictions"].detach().cpu().numpy().astype(np.float64), res["support_predictions"].detach().cpu().numpy().astype(np.float64),
+                float(loss.detach()), grads, P)
+
+    cls = flm.CnnDeepCombineChainModel
+    pa, sa, la, ga, P = run(cls())
+    monkeypatch.setattr(cls, "accepts_quantized_input", False)
+    pb, sb, lb, gb, _ = run(cls(), P)
+    assert set(ga) == set(gb)
+    assert np.abs(pa - pb).max() < 2e-5 and np.abs(sa - sb).max() < 2e-5 and abs(la - lb) < 1e-4 * max(1.0, abs(lb))
+    for k in ga:
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-4 * max(1.0, np.abs(gb[k]).max()), k
+    x64 = torch.from_numpy(np_ref.dequant_l2norm_folded(q, nf))
+    tp = {k: torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for k, v in P.items()}
+    main, sup = torch_ref.cnn_deep_combine_chain(x64, torch.from_numpy(nf), tp, Lc, 2, cells)
+    assert np.abs(pa - main.detach().numpy()).max() < 1e-4 and np.abs(sa - sup.detach().numpy()).max() < 1e-4
+    sp = flags.support_loss_percent
+    y64 = torch.from_numpy(y.astype(np.float64))
+    lr = (1 - sp) * torch_ref.cross_entropy(main, y64) + sp * torch_ref.cross_entropy(sup, y64.repeat(1, Lc))
+    lr.backward()
+    assert abs(la - lr.item()) < 1e-4 * abs(lr.item())
+    for k, t in tp.items():
+        if t.grad is not None:
+            assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k

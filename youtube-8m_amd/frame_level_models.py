@@ -328,7 +328,11 @@ class LstmPositionalAttentionMaxPoolingModel(LstmAttentionMaxPoolingModel):
 class CnnDeepCombineChainModel(models.BaseModel):
     """W/all_frame_models/cnn_deep_combine_chain_model.py:10-140: chain of MoE sub-predictions whose inputs are max-pooled
     "einsum CNNs" over the frames (filter lengths 1,2,3 = GEMMs on the input concatenated with its 1- and 2-frame shifts),
-    the masked mean input and the l2-normalised relu projections of the previous predictions."""
+    the masked mean input and the l2-normalised relu projections of the previous predictions.
+    accepts_quantized_input: on the reader's bytes every CNN of the chain reads ONE half image of the frames (seq_ops.u8_cnn: a shift by
+    i frames is a row offset in time-major order -- no concatenated [B,F,2D] / [B,F,3D] tensors, no fp32 copy of the frames), the mean
+    frame comes from the bytes too."""
+    accepts_quantized_input = True
 
     def cnn(self, model_input, l2_penalty=1e-8, num_filters=(1024, 1024, 1024), filter_sizes=(1, 2, 3), sub_scope="",
             **unused_params):
@@ -349,15 +353,32 @@ class CnnDeepCombineChainModel(models.BaseModel):
         num_layers = FLAGS.deep_chain_layers
         relu_cells = FLAGS.deep_chain_relu_cells
         B, F, D = model_input.shape
-        mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
-        mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
+        frames = None
+        if model_input.dtype == torch.uint8:
+            if seq_ops.u8_cnn_supported(model_input) and seq_ops.u8_attention_supported(model_input, 1):
+                frames = seq_ops.U8FrameImages(model_input, num_frames)         # one byte image for every CNN of the chain
+            else:
+                model_input = ops.dequant_l2norm(model_input, num_frames)
+        if frames is not None:
+            rs = seq_ops.u8_frame_scales(frames.q, num_frames)                  # [B,F]; 0 on the padding frames
+            inv = 1.0 / num_frames.to(torch.float32)
+            mean_input = seq_ops.pool_u8_raw(inv.view(B, 1, 1).expand(B, F, 1).contiguous(), frames.q, rs).view(B, D)
+        else:
+            mask = (torch.arange(F, device=model_input.device)[None, :] < num_frames[:, None]).to(model_input.dtype)
+            mean_input = (model_input * mask[:, :, None]).sum(dim=1) / num_frames.to(model_input.dtype)[:, None]
         mean_relu = video_level_models.fully_connected(mean_input, relu_cells, sub_scope + "mean-relu", activation="relu",
                                                        l2_penalty=l2_penalty)
         relu_layers = [ops.l2_normalize(mean_relu)]
         filters = dict(num_filters=[relu_cells, relu_cells, relu_cells * 2], filter_sizes=[1, 2, 3])
 
         def pooled_cnn(scope):
-            cnn_output = self.cnn(model_input, sub_scope=scope, l2_penalty=l2_penalty, **filters)
+            if frames is not None:
+                g = get_default_graph()
+                fvars = [g.get_variable(scope + "cnn-filter-len%d" % fs, (D * fs, nfl), random_normal(0.1), l2=l2_penalty)
+                         for nfl, fs in zip(filters["num_filters"], filters["filter_sizes"])]
+                cnn_output = seq_ops.u8_cnn(frames, fvars)
+            else:
+                cnn_output = self.cnn(model_input, sub_scope=scope, l2_penalty=l2_penalty, **filters)
             return ops.l2_normalize(ops.frame_pool(cnn_output, "max"))      # reduce_max over ALL max_frames rows, as the reference
 
         next_input = pooled_cnn(sub_scope + "cnn0")

@@ -1341,6 +1341,129 @@ def attention_logits_u8(q, rs, mean_x, W, b, parts=None):
     return _AttnLogitsU8.apply(_token(W._graph), W, b, q, rs, kinds, *parts)
 
 
+U8_ALPHA = 4.0 / 255.0
+
+
+def u8_cnn_supported(q):
+    """The einsum CNN of W/all_frame_models/cnn_deep_combine_chain_model.py:60-82 straight from the reader's bytes (u8_cnn): the frame
+    image kernels want D % 16 == 0, the shifted weight-gradient products whole K blocks per shift (B % 16 == 0)."""
+    if q.dtype != torch.uint8 or q.dim() != 3 or not q.is_cuda:
+        return False
+    B, F, D = q.shape
+    return bool(D % 16 == 0 and 16 <= D <= 2048 and B % 16 == 0 and F >= 1 and _lib.lib().yt8m_u8_proj_supported(D))
+
+
+class U8FrameImages(object):
+    """Operand images of one batch of raw frames q [B,F,D] uint8, made ONCE per step and shared by every product that reads the frames:
+    `img` = (q - 128) as a one-plane half image in TIME-major row order t B + b (exact; yt8m_u8_frames_image_f16), `r` [F B] = 1 / ||a0 q + c0||
+    per frame (0 on the padding frames), `trans()` = the transposed image (K = frame rows) for weight gradients, made on first use."""
+
+    def __init__(self, q, num_frames, eps=1e-12):
+        q = q.contiguous()
+        _dev(q)
+        self.q, self.nf = q, _nf(num_frames)
+        self.B, self.F, self.D = q.shape
+        M = self.F * self.B
+        self.img = torch.empty(((M + 31) // 32) * (self.D // 16) * 1024, dtype=torch.uint8, device=q.device)
+        self.r = torch.empty((M,), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().yt8m_u8_frames_image_f16(_p(q), _p(self.nf), self.B, self.F, self.D, float(eps), _p(self.img), None, _p(self.r),
+                                                       _stream()))
+        self._t = None
+
+    def trans(self):
+        if self._t is None:
+            M = self.F * self.B
+            self._t = torch.empty(((self.D + 31) // 32) * ((M + 15) // 16) * 1024, dtype=torch.uint8, device=self.q.device)
+            _lib.check(_lib.lib().yt8m_u8_frames_image_t_f16(_p(self.q), _p(self.nf), self.B, self.F, self.D, _p(self._t), _stream()))
+        return self._t
+
+
+class _CnnU8(torch.autograd.Function):
+    """cnn_output [B,F,sum N_k] of cnn_deep_combine_chain_model.py:60-82 -- for every filter k of length fs_k, einsum("ijk,kl->ijl") of
+    concat(x, x shifted by 1 frame, ..., by fs_k - 1 frames) with W_k [fs_k D, N_k] -- without the concatenations and without a float
+    copy of the frames: in time-major row order a shift by i frames is a row offset of i B, so
+        y_k[rows i B ..] += (x[rows .. M - i B]) . W_k[i D : (i + 1) D]
+    is one product per (filter, shift) on the SAME one-plane half image of the bytes (two f16 products against the slice's half-plane
+    image, the dequantise / l2-normalise affine in the epilogue: yt8m_gemm_h1x2_nt_ex), accumulated in place.  Backward: the slice's
+    weight gradient x[.. M - i B]^T . dy_k[i B ..] from the transposed byte image at K offset 0 (the recurrent stack's layer-0 form).  The
+    frames are data: no dx."""
+
+    @staticmethod
+    def forward(ctx, token, frames, *filters):
+        B, F, D = frames.B, frames.F, frames.D
+        M = F * B
+        dev = frames.q.device
+        lib = _lib.lib()
+        Ntot = sum(W.data.shape[1] for W in filters)
+        y = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+        ws = ops._workspace(dev)
+        c0 = 0
+        for W in filters:
+            assert W.data.shape[0] % D == 0 and W.data.is_contiguous(), "cnn filter must be [fs * D, N]"
+            fs, N = W.data.shape[0] // D, W.data.shape[1]
+            for i in range(fs):
+                rows = M - i * B
+                if rows <= 0:
+                    continue
+                Wi = W.data[i * D:(i + 1) * D]
+                _, w2 = ops.h2_split(Wi, plain=False, trans=True, scale=U8_ALPHA, dynamic=True)     # (alpha W_i)^T under a device-measured scale
+                cs = torch.empty((N,), dtype=torch.float32, device=dev)
+                ops.colsum(Wi, cs)
+                cptr = ctypes.c_void_p(y.data_ptr() + (i * B * Ntot + c0) * 4)
+                _lib.check(lib.yt8m_gemm_h1x2_nt_ex(rows, N, D, _p(frames.img), 0, _p(w2.buf), 0, cptr, Ntot, None, 1.0, _p(w2.dinv),
+                                                    _p(frames.r), _p(cs), U8_BETA, 1.0 if i else 0.0, _p(ws), ws.numel() * 4, _stream()))
+            c0 += N
+        ctx.frames, ctx.filters = frames, filters
+        return y.view(F, B, Ntot).transpose(0, 1).contiguous()          # [B,F,N] (layout glue)
+
+    @staticmethod
+    def backward(ctx, dy):
+        frames, filters = ctx.frames, ctx.filters
+        B, F, D = frames.B, frames.F, frames.D
+        M = F * B
+        dev = dy.device
+        lib = _lib.lib()
+        Ntot = dy.shape[2]
+        dyt = _f32c(dy).transpose(0, 1).contiguous().view(M, Ntot)      # time-major rows, as the images
+        ws = ops._workspace(dev)
+        nb = lambda rows_, K: max(lib.yt8m_x3_image_bytes(rows_, K) // 3 * 2, 16)
+        qT = None
+        c0 = 0
+        for W in filters:
+            fs, N = W.data.shape[0] // D, W.data.shape[1]
+            if W.trainable and W.grad is not None:
+                wbeta = float(W.grad_beta())
+                if qT is None:
+                    qT = frames.trans()
+                for i in range(fs):
+                    rows = M - i * B
+                    gW = W.grad[i * D:(i + 1) * D]
+                    if rows <= 0:
+                        if wbeta == 0.0:
+                            gW.zero_()
+                        continue
+                    part = dyt[i * B:, c0:c0 + N].contiguous()          # dy of the frames that saw this shift
+                    word = ops.h2_absmax(part)
+                    dzT = torch.empty(nb(N, rows), dtype=torch.uint8, device=dev)
+                    dzTs = torch.empty(nb(N, rows), dtype=torch.uint8, device=dev)
+                    ntile = (rows + 63) // 64
+                    cp = torch.empty((ntile, N), dtype=torch.float32, device=dev)
+                    cps = torch.empty((ntile, N), dtype=torch.float32, device=dev)
+                    _lib.check(lib.yt8m_h2_split_ex(_p(part), rows, N, N, 1.0, _p(word), _p(frames.r), None, _p(dzT), _p(dzTs), _p(cp),
+                                                    _p(cps), _stream()))
+                    csr = cps.sum(0).contiguous()
+                    _lib.check(lib.yt8m_gemm_h1x2_nt_ex(D, N, rows, _p(qT), (M + 15) // 16, _p(dzTs), 0, _p(gW), N, None, U8_ALPHA, _p(word),
+                                                        None, _p(csr), U8_BETA / U8_ALPHA, wbeta, _p(ws), ws.numel() * 4, _stream()))
+                W.grad_done()
+            c0 += N
+        return (None, None) + (None,) * len(filters)
+
+
+def u8_cnn(frames, filters):
+    """frames: U8FrameImages; filters: the cnn-filter Variables [fs_k D, N_k] in output-column order -> cnn_output [B,F,sum N_k]."""
+    return _CnnU8.apply(_token(filters[0]._graph), frames, *filters)
+
+
 def vlad_q_supported(D):
     """The intra-normalisation can hand out q = ||vlad[b,k,:]||^2 (csrc/netvlad.hip, register-resident kernels)."""
     return bool(_lib.lib().yt8m_vlad_finish_q_supported(int(D)))
