@@ -159,6 +159,20 @@ int yt8m_h2_split_rows(const float* src, int64_t R, int64_t C, int64_t ld, const
 int yt8m_gemm_h2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A2, int64_t ska, const void* B2, int64_t skb, float* C, int64_t ldc,
                        const float* bias, float alpha, const void* dsa, const void* dsb, const float* rowscale, float beta, void* workspace,
                        int64_t workspace_bytes, yt8m_stream_t stream);
+/* The max-pooled einsum CNN of W/all_frame_models/cnn_deep_combine_chain_model.py:60-82,100-106 on raw uint8 frames (csrc/cnn_pool.hip; the
+ * dense products are yt8m_gemm_h1x2_nt_ex launches on the yt8m_u8_frames_image_f16 image, one per (filter, frame shift), at time-major row
+ * offsets -- youtube-8m_amd/seq_ops.py _PooledCnnU8).
+ *   yt8m_timepool_max_f32 : y [F B rows (t B + b), N] (row stride ldy) -> out [B, N] = tf.reduce_max over the frames, idx [B, N] = the FIRST
+ *                           frame that attains it (row stride ldo for both).  N, ldy, ldo multiples of 4; 16-byte aligned operands.
+ *   yt8m_u8_cnn_pool_dw   : the filter's gradient through the pooling: dW [fs D, N] (beta = 0 / 1: overwrite / accumulate)
+ *                           dW[i D + d, n] (+)= sum_b g[b, n] x[idx[b, n] - i, b, d]   (terms with idx - i < 0 dropped),
+ *                           x = the dequantised, l2-normalised, padding-masked frames of q [B, F, D] uint8 (W/utils.py:23-38 +
+ *                           default_transformer.py:4-8) recomputed from the bytes: r_tm [F B] by row t B + b is yt8m_u8_frames_image_f16's
+ *                           r_out.  g, idx: [B, N] with row stride ldg.  B gathered rows per column instead of a [D, F B] x [F B, N] product. */
+int yt8m_timepool_max_f32(const float* y, int64_t F, int64_t B, int64_t N, int64_t ldy, float* out, int32_t* idx, int64_t ldo,
+                          yt8m_stream_t stream);
+int yt8m_u8_cnn_pool_dw(const uint8_t* q, const float* r_tm, const int32_t* idx, const float* g, int64_t ldg, int64_t B, int64_t F, int64_t D,
+                        int64_t N, int64_t fs, float* dW, float beta, yt8m_stream_t stream);
 int yt8m_u8_frames_image_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,
                              float* x_tm, float* r_out, yt8m_stream_t stream);
 int yt8m_u8_frames_image_t_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, void* image_t,

@@ -686,3 +686,50 @@ def test_cnn_chain_plugin_takes_the_raw_uint8_frames(dev, flags, monkeypatch):
     for k, t in tp.items():
         if t.grad is not None:
             assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k
+
+
+def test_pooled_u8_cnn_equals_the_pooled_output_of_the_unpooled_op(dev):
+    """seq_ops.u8_cnn_maxpool (time-major pooling with the argmax kept, per-column gathered weight gradient: csrc/cnn_pool.hip) against
+    seq_ops.u8_cnn followed by a max over the frames (dense weight-gradient products on the transposed byte image), and both against fp64:
+    pooled values, and the filters' gradients of a random linear functional of them.  Ragged videos incl. an empty one and one frame."""
+    from oracle import np_ref
+    rs = np.random.RandomState(41)
+    B, F, D = 32, 9, 48
+    shapes = [(1, 8), (2, 8), (3, 12)]                                   # (filter length, columns)
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1], nf[2] = F, 1, 0
+    qd, nfd = torch.from_numpy(q).to(dev), torch.from_numpy(nf).to(dev)
+    assert seq_ops.u8_cnn_supported(qd)
+    Ws = [(rs.randn(fs * D, n) * 0.1).astype(np.float32) for fs, n in shapes]
+    coef = rs.randn(B, sum(n for _, n in shapes)).astype(np.float32)
+    out = {}
+    for mode in ("pooled", "dense"):
+        g = reset_default_graph(device=dev, seed=0)
+        fv = [g.get_variable("f%d" % k, W.shape, zeros) for k, W in enumerate(Ws)]
+        g.finalize()
+        for v, W in zip(fv, Ws):
+            v.data.copy_(torch.from_numpy(W).to(dev))
+        g.begin_step()
+        frames = seq_ops.U8FrameImages(qd, nfd)
+        if mode == "pooled":
+            p = seq_ops.u8_cnn_maxpool(frames, fv)
+        else:
+            p = seq_ops.u8_cnn(frames, fv).max(dim=1).values
+        (p * torch.from_numpy(coef).to(dev)).sum().backward()
+        out[mode] = (p.detach().cpu().numpy().astype(np.float64), [v.grad.detach().cpu().numpy().astype(np.float64) for v in fv])
+    assert np.abs(out["pooled"][0] - out["dense"][0]).max() < 1e-6
+    for a, b in zip(out["pooled"][1], out["dense"][1]):
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max())
+    # fp64: concat of the shifted inputs, einsum, max over ALL frames
+    x = torch.from_numpy(np_ref.dequant_l2norm_folded(q, nf))
+    tw = [torch.from_numpy(W.astype(np.float64)).requires_grad_(True) for W in Ws]
+    cols = []
+    for (fs, n), W in zip(shapes, tw):
+        sh = [x] + [torch.cat([x.new_zeros(B, i, D), x[:, :F - i]], dim=1) for i in range(1, fs)]
+        cols.append(torch.cat(sh, dim=2) @ W)
+    pr = torch.cat(cols, dim=2).max(dim=1).values
+    (pr * torch.from_numpy(coef.astype(np.float64))).sum().backward()
+    assert np.abs(out["pooled"][0] - pr.detach().numpy()).max() < 2e-6 * max(1.0, float(pr.detach().abs().max()))
+    for a, t in zip(out["pooled"][1], tw):
+        assert np.abs(a - t.grad.numpy()).max() <= 5e-6 * max(1.0, float(t.grad.abs().max()))

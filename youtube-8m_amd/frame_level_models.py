@@ -376,6 +376,8 @@ class CnnDeepCombineChainModel(models.BaseModel):
                 g = get_default_graph()
                 fvars = [g.get_variable(scope + "cnn-filter-len%d" % fs, (D * fs, nfl), random_normal(0.1), l2=l2_penalty)
                          for nfl, fs in zip(filters["num_filters"], filters["filter_sizes"])]
+                if sum(filters["num_filters"]) % 4 == 0:                          # pooled in time-major order, sparse weight gradient
+                    return ops.l2_normalize(seq_ops.u8_cnn_maxpool(frames, fvars))
                 cnn_output = seq_ops.u8_cnn(frames, fvars)
             else:
                 cnn_output = self.cnn(model_input, sub_scope=scope, l2_penalty=l2_penalty, **filters)

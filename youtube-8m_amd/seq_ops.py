@@ -1378,43 +1378,52 @@ class U8FrameImages(object):
         return self._t
 
 
+def _u8_cnn_dense(frames, filters):
+    """y [F B rows (t B + b), sum N_k]: for every filter k and shift i < fs_k
+        y_k[rows i B ..] += x[rows .. M - i B] . W_k[i D : (i + 1) D]
+    as ONE yt8m_gemm_h1x2_nt_ex launch on the frames' half image (two f16 products against the K range [i D, (i + 1) D) of the filter's
+    half-plane image (alpha W_k)^T -- one image and one device-measured scale per filter --, dequantise / l2-normalise affine in the
+    epilogue), accumulated in place: in time-major row order a shift by i frames is a row offset of i B."""
+    B, F, D = frames.B, frames.F, frames.D
+    M = F * B
+    dev = frames.q.device
+    lib = _lib.lib()
+    Ntot = sum(W.data.shape[1] for W in filters)
+    y = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
+    ws = ops._workspace(dev)
+    c0 = 0
+    for W in filters:
+        assert W.data.shape[0] % D == 0 and W.data.is_contiguous(), "cnn filter must be [fs * D, N]"
+        fs, N = W.data.shape[0] // D, W.data.shape[1]
+        _, w2 = ops.h2_split(W.data, plain=False, trans=True, scale=U8_ALPHA, dynamic=True)     # [N rows, K = fs D]
+        cs = torch.empty((fs, N), dtype=torch.float32, device=dev)                                  # column sums per shift slice
+        for i in range(fs):
+            ops.colsum(W.data[i * D:(i + 1) * D], cs[i])
+        for i in range(fs):
+            rows = M - i * B
+            if rows <= 0:
+                continue
+            bptr = ctypes.c_void_p(w2.buf.data_ptr() + i * (D // 16) * 2048)                    # K blocks of 16: two 1 KiB half planes each
+            cptr = ctypes.c_void_p(y.data_ptr() + (i * B * Ntot + c0) * 4)
+            _lib.check(lib.yt8m_gemm_h1x2_nt_ex(rows, N, D, _p(frames.img), 0, bptr, fs * D // 16 if fs > 1 else 0, cptr, Ntot, None, 1.0,
+                                                _p(w2.dinv), _p(frames.r), _p(cs[i]), U8_BETA, 1.0 if i else 0.0, _p(ws), ws.numel() * 4,
+                                                _stream()))
+        c0 += N
+    return y
+
+
 class _CnnU8(torch.autograd.Function):
     """cnn_output [B,F,sum N_k] of cnn_deep_combine_chain_model.py:60-82 -- for every filter k of length fs_k, einsum("ijk,kl->ijl") of
     concat(x, x shifted by 1 frame, ..., by fs_k - 1 frames) with W_k [fs_k D, N_k] -- without the concatenations and without a float
-    copy of the frames: in time-major row order a shift by i frames is a row offset of i B, so
-        y_k[rows i B ..] += (x[rows .. M - i B]) . W_k[i D : (i + 1) D]
-    is one product per (filter, shift) on the SAME one-plane half image of the bytes (two f16 products against the slice's half-plane
-    image, the dequantise / l2-normalise affine in the epilogue: yt8m_gemm_h1x2_nt_ex), accumulated in place.  Backward: the slice's
-    weight gradient x[.. M - i B]^T . dy_k[i B ..] from the transposed byte image at K offset 0 (the recurrent stack's layer-0 form).  The
-    frames are data: no dx."""
+    copy of the frames (_u8_cnn_dense).  Backward: the slice's weight gradient x[.. M - i B]^T . dy_k[i B ..] from the transposed byte
+    image at K offset 0 (the recurrent stack's layer-0 form).  The frames are data: no dx.  (The model pools this output over the frames:
+    _PooledCnnU8 is the form it uses; this one is the plain `cnn` of the reference class.)"""
 
     @staticmethod
     def forward(ctx, token, frames, *filters):
-        B, F, D = frames.B, frames.F, frames.D
-        M = F * B
-        dev = frames.q.device
-        lib = _lib.lib()
-        Ntot = sum(W.data.shape[1] for W in filters)
-        y = torch.empty((M, Ntot), dtype=torch.float32, device=dev)
-        ws = ops._workspace(dev)
-        c0 = 0
-        for W in filters:
-            assert W.data.shape[0] % D == 0 and W.data.is_contiguous(), "cnn filter must be [fs * D, N]"
-            fs, N = W.data.shape[0] // D, W.data.shape[1]
-            for i in range(fs):
-                rows = M - i * B
-                if rows <= 0:
-                    continue
-                Wi = W.data[i * D:(i + 1) * D]
-                _, w2 = ops.h2_split(Wi, plain=False, trans=True, scale=U8_ALPHA, dynamic=True)     # (alpha W_i)^T under a device-measured scale
-                cs = torch.empty((N,), dtype=torch.float32, device=dev)
-                ops.colsum(Wi, cs)
-                cptr = ctypes.c_void_p(y.data_ptr() + (i * B * Ntot + c0) * 4)
-                _lib.check(lib.yt8m_gemm_h1x2_nt_ex(rows, N, D, _p(frames.img), 0, _p(w2.buf), 0, cptr, Ntot, None, 1.0, _p(w2.dinv),
-                                                    _p(frames.r), _p(cs), U8_BETA, 1.0 if i else 0.0, _p(ws), ws.numel() * 4, _stream()))
-            c0 += N
+        y = _u8_cnn_dense(frames, filters)
         ctx.frames, ctx.filters = frames, filters
-        return y.view(F, B, Ntot).transpose(0, 1).contiguous()          # [B,F,N] (layout glue)
+        return y.view(frames.F, frames.B, y.shape[1]).transpose(0, 1).contiguous()          # [B,F,N] (layout glue)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1459,9 +1468,52 @@ class _CnnU8(torch.autograd.Function):
         return (None, None) + (None,) * len(filters)
 
 
+class _PooledCnnU8(torch.autograd.Function):
+    """tf.reduce_max(cnn_output, axis=1) of cnn_deep_combine_chain_model.py:100-106 on the raw frames: the dense products of
+    _u8_cnn_dense, the pooling in time-major order with the argmax kept (yt8m_timepool_max_f32), and a backward that uses what the
+    pooling did to the gradient -- it is non-zero at ONE frame per (video, column), so each filter slice's gradient is B gathered frame
+    rows per column (yt8m_u8_cnn_pool_dw) instead of a [D, F B] x [F B, N] product."""
+
+    @staticmethod
+    def forward(ctx, token, frames, *filters):
+        y = _u8_cnn_dense(frames, filters)
+        B, F = frames.B, frames.F
+        Ntot = y.shape[1]
+        out = torch.empty((B, Ntot), dtype=torch.float32, device=y.device)
+        idx = torch.empty((B, Ntot), dtype=torch.int32, device=y.device)
+        _lib.check(_lib.lib().yt8m_timepool_max_f32(_p(y), F, B, Ntot, Ntot, _p(out), _p(idx), Ntot, _stream()))
+        ctx.frames, ctx.filters, ctx.idx = frames, filters, idx
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        frames, filters, idx = ctx.frames, ctx.filters, ctx.idx
+        ctx.idx = None
+        B, F, D = frames.B, frames.F, frames.D
+        g = _f32c(g)
+        Ntot = g.shape[1]
+        lib = _lib.lib()
+        c0 = 0
+        for W in filters:
+            fs, N = W.data.shape[0] // D, W.data.shape[1]
+            if W.trainable and W.grad is not None:
+                wbeta = float(W.grad_beta())
+                _lib.check(lib.yt8m_u8_cnn_pool_dw(_p(frames.q), _p(frames.r), ctypes.c_void_p(idx.data_ptr() + c0 * 4),
+                                                   ctypes.c_void_p(g.data_ptr() + c0 * 4), Ntot, B, F, D, N, fs, _p(W.grad), wbeta,
+                                                   _stream()))
+                W.grad_done()
+            c0 += N
+        return (None, None) + (None,) * len(filters)
+
+
 def u8_cnn(frames, filters):
     """frames: U8FrameImages; filters: the cnn-filter Variables [fs_k D, N_k] in output-column order -> cnn_output [B,F,sum N_k]."""
     return _CnnU8.apply(_token(filters[0]._graph), frames, *filters)
+
+
+def u8_cnn_maxpool(frames, filters):
+    """... -> reduce_max over the frames of that output, [B, sum N_k] (needs sum N_k % 4 == 0: else pool u8_cnn's output)."""
+    return _PooledCnnU8.apply(_token(filters[0]._graph), frames, *filters)
 
 
 def vlad_q_supported(D):
