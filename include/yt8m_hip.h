@@ -171,6 +171,11 @@ int yt8m_gemm_h2_nt_ex(int64_t M, int64_t N, int64_t K, const void* A2, int64_t 
  *                           r_out.  g, idx: [B, N] with row stride ldg.  B gathered rows per column instead of a [D, F B] x [F B, N] product. */
 int yt8m_timepool_max_f32(const float* y, int64_t F, int64_t B, int64_t N, int64_t ldy, float* out, int32_t* idx, int64_t ldo,
                           yt8m_stream_t stream);
+ /* yt8m_timepool_shiftmax_f32: the pooling over PER-SHIFT partial outputs of ONE product for the whole CNN: z [F B rows, ldz], columns of
+ * filter k (fs[k] shifts, ncol[k] columns, k < nfilt <= 8; host arrays) at sum_{j<k} fs[j] ncol[j] + i ncol[k] + n hold x[t, b] . W_k[i D : (i + 1) D][:, n];
+ * cnn_output[t, b, k, n] = sum_i z[(t - i) B + b, .] (i ascending, t - i >= 0), out / idx [B, sum ncol] as yt8m_timepool_max_f32. */
+int yt8m_timepool_shiftmax_f32(const float* z, int64_t F, int64_t B, int64_t ldz, int nfilt, const int32_t* fs, const int32_t* ncol, float* out,
+                               int32_t* idx, int64_t ldo, yt8m_stream_t stream);
 int yt8m_u8_cnn_pool_dw(const uint8_t* q, const float* r_tm, const int32_t* idx, const float* g, int64_t ldg, int64_t B, int64_t F, int64_t D,
                         int64_t N, int64_t fs, float* dW, float beta, yt8m_stream_t stream);
 int yt8m_u8_frames_image_f16(const uint8_t* q, const int32_t* num_frames, int64_t B, int64_t F, int64_t D, float eps, void* image,

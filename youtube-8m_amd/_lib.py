@@ -295,6 +295,8 @@ SIGNATURES = {
     "yt8m_h2_split_rows": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
     "yt8m_gemm_h2_nt_ex": (c_int, [c_int64, c_int64, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_float, P, P, P, c_float, P, c_int64, P]),
     "yt8m_timepool_max_f32": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P, c_int64, P]),
+    "yt8m_timepool_shiftmax_f32": (c_int, [P, c_int64, c_int64, c_int64, c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), P, P,
+                                           c_int64, P]),
     "yt8m_u8_cnn_pool_dw": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, P, c_float, P]),
     "yt8m_u8_frames_image_f16": (c_int, [P, P, c_int64, c_int64, c_int64, c_float, P, P, P, P]),
     "yt8m_u8_frames_image_t_f16": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),

@@ -35,21 +35,56 @@ __global__ __launch_bounds__(256) void timepool_max_kernel(const float* __restri
   *reinterpret_cast<int4*>(idx + (int64_t)b * ldo + c) = at;
 }
 
-// block = (column n, shift i); thread = four consecutive features (uchar4 of a frame row), up to two groups per thread (D <= 2048).
+// The same pooling over the per-shift partial outputs z[t B + b, zbase_k + i N_k + n] = x[t, b] . W_k[i D : (i + 1) D][:, n] of ONE product
+// for the whole CNN: cnn_output[t, b, k, n] = sum_i z[(t - i) B + b, .] (i ascending: the order the in-place accumulation of the
+// per-shift products uses), maximum over t and its first frame.  Every element of z is read once.
+struct PoolDesc {
+  int nfilt;
+  int fs[8], ncol[8], zbase[8], obase[8];
+};
+__global__ __launch_bounds__(256) void timepool_shiftmax_kernel(const float* __restrict__ z, int F, int B, int64_t ldz, PoolDesc d, int Ntot,
+                                                                float* __restrict__ out, int32_t* __restrict__ idx, int64_t ldo) {
+  const int n4 = Ntot >> 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * n4) return;
+  const int b = (int)(e / n4), c = (int)(e - (int64_t)b * n4) * 4;
+  int k = 0;
+  while (k + 1 < d.nfilt && c >= d.obase[k + 1]) ++k;
+  const int fs = d.fs[k], nk = d.ncol[k];
+  const float* p = z + (int64_t)b * ldz + d.zbase[k] + (c - d.obase[k]);
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 at = make_int4(0, 0, 0, 0);
+  for (int t = 0; t < F; ++t) {
+    float4 v = *reinterpret_cast<const float4*>(p + (int64_t)t * B * ldz);
+    for (int i = 1; i < fs && i <= t; ++i) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (int64_t)(t - i) * B * ldz + (int64_t)i * nk);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (t == 0) { m = v; continue; }
+    if (v.x > m.x) { m.x = v.x; at.x = t; }
+    if (v.y > m.y) { m.y = v.y; at.y = t; }
+    if (v.z > m.z) { m.z = v.z; at.z = t; }
+    if (v.w > m.w) { m.w = v.w; at.w = t; }
+  }
+  *reinterpret_cast<float4*>(out + (int64_t)b * ldo + c) = m;
+  *reinterpret_cast<int4*>(idx + (int64_t)b * ldo + c) = at;
+}
+
+// block = (column n, shift i); thread = four consecutive features (uchar4 of a frame row; D / 4 threads rounded up to whole waves).
 // The B (coefficient, frame row) pairs of the column go through LDS first: the gather loop then has no dependent address chain.
-__global__ __launch_bounds__(256) void u8_cnn_pool_dw_kernel(const uint8_t* __restrict__ q, const float* __restrict__ r_tm,
+__global__ __launch_bounds__(512) void u8_cnn_pool_dw_kernel(const uint8_t* __restrict__ q, const float* __restrict__ r_tm,
                                                              const int32_t* __restrict__ idx, const float* __restrict__ g, int64_t ldg,
                                                              int B, int F, int D, int N, float* __restrict__ dW, float beta) {
-  __shared__ float s_coef[256];
-  __shared__ int s_row[256];
+  __shared__ float s_coef[512];
+  __shared__ int s_row[512];
   const int n = blockIdx.x, i = blockIdx.y;
-  const int d4 = D >> 2;
-  const int t0 = threadIdx.x, t1 = threadIdx.x + 256;
-  const bool h0 = t0 < d4, h1 = t1 < d4;
-  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  const int d4 = D >> 2, nt = (int)blockDim.x;
+  const int t0 = threadIdx.x;
+  const bool h0 = t0 < d4;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;                                                   // sum of the coefficients: the affine remainder
-  for (int b0 = 0; b0 < B; b0 += 256) {
-    const int b = b0 + (int)threadIdx.x;
+  for (int b0 = 0; b0 < B; b0 += nt) {
+    const int b = b0 + t0;
     float coef = 0.f;
     int row = 0;
     if (b < B) {
@@ -59,25 +94,32 @@ __global__ __launch_bounds__(256) void u8_cnn_pool_dw_kernel(const uint8_t* __re
         row = b * F + t;
       }
     }
-    s_coef[threadIdx.x] = coef;
-    s_row[threadIdx.x] = row;
+    s_coef[t0] = coef;
+    s_row[t0] = row;
     __syncthreads();
-    const int nb = min(256, B - b0);
-#pragma unroll 4
-    for (int j = 0; j < nb; ++j) {
+    const int nb = min(nt, B - b0);
+    int j = 0;
+    for (; j + 8 <= nb; j += 8) {                                     // eight independent row requests in flight per thread
+      uint32_t u[8];
+      float c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c[k] = s_coef[j + k];
+        u[k] = h0 ? reinterpret_cast<const uint32_t*>(q + (int64_t)s_row[j + k] * D)[t0] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        csum += c[k];
+        a0[0] += c[k] * (float)(u[k] & 255u); a0[1] += c[k] * (float)((u[k] >> 8) & 255u);
+        a0[2] += c[k] * (float)((u[k] >> 16) & 255u); a0[3] += c[k] * (float)(u[k] >> 24);
+      }
+    }
+    for (; j < nb; ++j) {
       const float c = s_coef[j];
-      const uint32_t* rp = reinterpret_cast<const uint32_t*>(q + (int64_t)s_row[j] * D);
+      const uint32_t u = h0 ? reinterpret_cast<const uint32_t*>(q + (int64_t)s_row[j] * D)[t0] : 0u;
       csum += c;
-      if (h0) {
-        const uint32_t u = rp[t0];
-        a0[0] += c * (float)(u & 255u); a0[1] += c * (float)((u >> 8) & 255u);
-        a0[2] += c * (float)((u >> 16) & 255u); a0[3] += c * (float)(u >> 24);
-      }
-      if (h1) {
-        const uint32_t u = rp[t1];
-        a1[0] += c * (float)(u & 255u); a1[1] += c * (float)((u >> 8) & 255u);
-        a1[2] += c * (float)((u >> 16) & 255u); a1[3] += c * (float)(u >> 24);
-      }
+      a0[0] += c * (float)(u & 255u); a0[1] += c * (float)((u >> 8) & 255u);
+      a0[2] += c * (float)((u >> 16) & 255u); a0[3] += c * (float)(u >> 24);
     }
     __syncthreads();
   }
@@ -89,14 +131,6 @@ __global__ __launch_bounds__(256) void u8_cnn_pool_dw_kernel(const uint8_t* __re
     for (int k = 0; k < 4; ++k) {
       float* o = col + (int64_t)(4 * t0 + k) * N;
       const float v = DQ_ALPHA * a0[k] + rem;
-      *o = beta != 0.f ? beta * *o + v : v;
-    }
-  }
-  if (h1) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float* o = col + (int64_t)(4 * t1 + k) * N;
-      const float v = DQ_ALPHA * a1[k] + rem;
       *o = beta != 0.f ? beta * *o + v : v;
     }
   }
@@ -121,6 +155,31 @@ extern "C" int yt8m_timepool_max_f32(const float* y, int64_t F, int64_t B, int64
   return launch_status("timepool_max_kernel");
 }
 
+extern "C" int yt8m_timepool_shiftmax_f32(const float* z, int64_t F, int64_t B, int64_t ldz, int nfilt, const int32_t* fs, const int32_t* ncol,
+                                          float* out, int32_t* idx, int64_t ldo, yt8m_stream_t stream) {
+  YT8M_REQUIRE(F >= 1 && B >= 0 && nfilt >= 1 && nfilt <= 8 && fs && ncol, YT8M_E_SHAPE, "1..8 filters");
+  PoolDesc d;
+  d.nfilt = nfilt;
+  int zb = 0, ob = 0;
+  for (int k = 0; k < nfilt; ++k) {
+    YT8M_REQUIRE(fs[k] >= 1 && ncol[k] >= 4 && (ncol[k] % 4) == 0, YT8M_E_SHAPE, "filter columns must be multiples of 4");
+    d.fs[k] = fs[k]; d.ncol[k] = ncol[k]; d.zbase[k] = zb; d.obase[k] = ob;
+    zb += fs[k] * ncol[k];
+    ob += ncol[k];
+  }
+  for (int k = nfilt; k < 8; ++k) { d.fs[k] = 1; d.ncol[k] = 4; d.zbase[k] = zb; d.obase[k] = ob; }
+  if (B == 0) return YT8M_OK;
+  YT8M_REQUIRE((ldz % 4) == 0 && (ldo % 4) == 0 && ldz >= zb && ldo >= ob, YT8M_E_SHAPE, "ldz / ldo too small or not multiples of 4");
+  YT8M_REQUIRE(z && out && idx, YT8M_E_BADARG, "null operand");
+  YT8M_REQUIRE(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0,
+               YT8M_E_BADARG, "operands must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ProfScope prof(F_ELEMENTWISE, s);
+  const int64_t n = B * (ob / 4);
+  hipLaunchKernelGGL(timepool_shiftmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, (int)F, (int)B, ldz, d, ob, out, idx, ldo);
+  return launch_status("timepool_shiftmax_kernel");
+}
+
 extern "C" int yt8m_u8_cnn_pool_dw(const uint8_t* q, const float* r_tm, const int32_t* idx, const float* g, int64_t ldg, int64_t B, int64_t F,
                                    int64_t D, int64_t N, int64_t fs, float* dW, float beta, yt8m_stream_t stream) {
   YT8M_REQUIRE(B >= 0 && F >= 1 && D >= 4 && N >= 0 && fs >= 1 && fs <= 16, YT8M_E_SHAPE, "bad dimension");
@@ -131,7 +190,8 @@ extern "C" int yt8m_u8_cnn_pool_dw(const uint8_t* q, const float* r_tm, const in
   YT8M_REQUIRE((reinterpret_cast<uintptr_t>(q) & 3) == 0, YT8M_E_BADARG, "frames must be 4-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  hipLaunchKernelGGL(u8_cnn_pool_dw_kernel, dim3((unsigned)N, (unsigned)fs), dim3(256), 0, s, q, r_tm, idx, g, ldg, (int)B, (int)F, (int)D,
+  const unsigned nt = (unsigned)(((D / 4) + 63) / 64 * 64);
+  hipLaunchKernelGGL(u8_cnn_pool_dw_kernel, dim3((unsigned)N, (unsigned)fs), dim3(nt), 0, s, q, r_tm, idx, g, ldg, (int)B, (int)F, (int)D,
                      (int)N, dW, beta);
   return launch_status("u8_cnn_pool_dw_kernel");
 }

@@ -1468,6 +1468,38 @@ class _CnnU8(torch.autograd.Function):
         return (None, None) + (None,) * len(filters)
 
 
+def _u8_cnn_partials(frames, filters):
+    """z [F B rows (t B + b), sum_k fs_k N_k] with z[., zbase_k + i N_k + n] = x . W_k[i D : (i + 1) D][:, n]: ONE product for the whole CNN
+    (every filter's shift slices side by side as the rows of one half-plane image under one device-measured scale; N = 1152 instead of
+    six launches of N = 128 / 256 on 256-wide tiles), the shifts are summed by the pooling pass (yt8m_timepool_shiftmax_f32).  Needs
+    N_k % 32 == 0 (a slice then is a whole number of the image's 32-row groups)."""
+    B, F, D = frames.B, frames.F, frames.D
+    M = F * B
+    dev = frames.q.device
+    lib = _lib.lib()
+    Ntz = sum(W.data.shape[0] // D * W.data.shape[1] for W in filters)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    for W in filters:                                                                            # max |W| over all filters (atomicMax)
+        _lib.check(lib.yt8m_h2_absmax(_p(W.data), W.data.shape[0], W.data.shape[1], W.data.shape[1], _p(word), _stream()))
+    nbytes = lambda rows, K: lib.yt8m_x3_image_bytes(rows, K) // 3 * 2
+    img = torch.empty(sum(W.data.shape[0] // D * nbytes(W.data.shape[1], D) for W in filters), dtype=torch.uint8, device=dev)
+    cs = torch.empty((Ntz,), dtype=torch.float32, device=dev)
+    off, c = 0, 0
+    for W in filters:
+        fs, N = W.data.shape[0] // D, W.data.shape[1]
+        for i in range(fs):
+            Wi = W.data[i * D:(i + 1) * D]
+            _lib.check(lib.yt8m_h2_split(_p(Wi), D, N, N, U8_ALPHA, _p(word), None, ctypes.c_void_p(img.data_ptr() + off), None, _stream()))
+            ops.colsum(Wi, cs[c:c + N])
+            off += nbytes(N, D)
+            c += N
+    z = torch.empty((M, Ntz), dtype=torch.float32, device=dev)
+    ws = ops._workspace(dev)
+    _lib.check(lib.yt8m_gemm_h1x2_nt_ex(M, Ntz, D, _p(frames.img), 0, _p(img), 0, _p(z), Ntz, None, 1.0, _p(word), _p(frames.r), _p(cs), U8_BETA,
+                                        0.0, _p(ws), ws.numel() * 4, _stream()))
+    return z
+
+
 class _PooledCnnU8(torch.autograd.Function):
     """tf.reduce_max(cnn_output, axis=1) of cnn_deep_combine_chain_model.py:100-106 on the raw frames: the dense products of
     _u8_cnn_dense, the pooling in time-major order with the argmax kept (yt8m_timepool_max_f32), and a backward that uses what the
@@ -1476,12 +1508,19 @@ class _PooledCnnU8(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, token, frames, *filters):
-        y = _u8_cnn_dense(frames, filters)
-        B, F = frames.B, frames.F
-        Ntot = y.shape[1]
-        out = torch.empty((B, Ntot), dtype=torch.float32, device=y.device)
-        idx = torch.empty((B, Ntot), dtype=torch.int32, device=y.device)
-        _lib.check(_lib.lib().yt8m_timepool_max_f32(_p(y), F, B, Ntot, Ntot, _p(out), _p(idx), Ntot, _stream()))
+        B, F, D = frames.B, frames.F, frames.D
+        dev = frames.q.device
+        Ntot = sum(W.data.shape[1] for W in filters)
+        out = torch.empty((B, Ntot), dtype=torch.float32, device=dev)
+        idx = torch.empty((B, Ntot), dtype=torch.int32, device=dev)
+        if all(W.data.shape[1] % 32 == 0 for W in filters) and len(filters) <= 8:
+            z = _u8_cnn_partials(frames, filters)                     # one product; the pooling pass sums the shifts
+            fs = (ctypes.c_int32 * len(filters))(*[W.data.shape[0] // D for W in filters])
+            nc = (ctypes.c_int32 * len(filters))(*[W.data.shape[1] for W in filters])
+            _lib.check(_lib.lib().yt8m_timepool_shiftmax_f32(_p(z), F, B, z.shape[1], len(filters), fs, nc, _p(out), _p(idx), Ntot, _stream()))
+        else:
+            y = _u8_cnn_dense(frames, filters)                        # one product per (filter, shift), accumulated in place
+            _lib.check(_lib.lib().yt8m_timepool_max_f32(_p(y), F, B, Ntot, Ntot, _p(out), _p(idx), Ntot, _stream()))
         ctx.frames, ctx.filters, ctx.idx = frames, filters, idx
         return out
 
