@@ -14,60 +14,60 @@ namespace {
 constexpr float DQ_ALPHA = 4.0f / 255.0f;                              // x = r (alpha (q - 128) + beta')
 constexpr float DQ_BETA = 128.0f * 4.0f / 255.0f + (4.0f / 512.0f - 2.0f);
 
-// one thread = four consecutive columns of one video; rows t B + b are N floats apart per video and B N per frame: coalesced along n
-__global__ __launch_bounds__(256) void timepool_max_kernel(const float* __restrict__ y, int F, int B, int N, int64_t ldy,
-                                                           float* __restrict__ out, int32_t* __restrict__ idx, int64_t ldo) {
-  const int n4 = N >> 2;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)B * n4) return;
-  const int b = (int)(e / n4), c = (int)(e - (int64_t)b * n4) * 4;
-  const float* p = y + (int64_t)b * ldy + c;
-  float4 m = *reinterpret_cast<const float4*>(p);
-  int4 at = make_int4(0, 0, 0, 0);
-  for (int t = 1; t < F; ++t) {
-    const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)t * B * ldy);
-    if (v.x > m.x) { m.x = v.x; at.x = t; }                           // strict: the FIRST frame that attains the maximum
-    if (v.y > m.y) { m.y = v.y; at.y = t; }
-    if (v.z > m.z) { m.z = v.z; at.z = t; }
-    if (v.w > m.w) { m.w = v.w; at.w = t; }
-  }
-  *reinterpret_cast<float4*>(out + (int64_t)b * ldo + c) = m;
-  *reinterpret_cast<int4*>(idx + (int64_t)b * ldo + c) = at;
-}
-
-// The same pooling over the per-shift partial outputs z[t B + b, zbase_k + i N_k + n] = x[t, b] . W_k[i D : (i + 1) D][:, n] of ONE product
+// The pooling over the per-shift partial outputs z[t B + b, zbase_k + i N_k + n] = x[t, b] . W_k[i D : (i + 1) D][:, n] of ONE product
 // for the whole CNN: cnn_output[t, b, k, n] = sum_i z[(t - i) B + b, .] (i ascending: the order the in-place accumulation of the
-// per-shift products uses), maximum over t and its first frame.  Every element of z is read once.
+// per-shift products uses), maximum over t and its first frame.  Every element of z is read once.  (A column group of four never
+// straddles two filters: ncol[k] % 4 == 0.)
 struct PoolDesc {
   int nfilt;
   int fs[8], ncol[8], zbase[8], obase[8];
 };
+// block = (64 output columns, video): 16 column groups of four x 16 frame classes (t mod 16); a class keeps the first frame of its own
+// maximum, the classes are merged through LDS (larger value, the earlier frame on a tie) -- 300 frames on one thread per column group
+// left three quarters of the chip idle.
 __global__ __launch_bounds__(256) void timepool_shiftmax_kernel(const float* __restrict__ z, int F, int B, int64_t ldz, PoolDesc d, int Ntot,
                                                                 float* __restrict__ out, int32_t* __restrict__ idx, int64_t ldo) {
-  const int n4 = Ntot >> 2;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)B * n4) return;
-  const int b = (int)(e / n4), c = (int)(e - (int64_t)b * n4) * 4;
+  __shared__ float4 s_m[16][16];
+  __shared__ int4 s_t[16][16];
+  const int cg = threadIdx.x & 15, tg = threadIdx.x >> 4;
+  const int b = blockIdx.y, c = blockIdx.x * 64 + 4 * cg;
+  const bool live = c < Ntot;
   int k = 0;
   while (k + 1 < d.nfilt && c >= d.obase[k + 1]) ++k;
   const int fs = d.fs[k], nk = d.ncol[k];
   const float* p = z + (int64_t)b * ldz + d.zbase[k] + (c - d.obase[k]);
-  float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-  int4 at = make_int4(0, 0, 0, 0);
-  for (int t = 0; t < F; ++t) {
-    float4 v = *reinterpret_cast<const float4*>(p + (int64_t)t * B * ldz);
-    for (int i = 1; i < fs && i <= t; ++i) {
-      const float4 u = *reinterpret_cast<const float4*>(p + (int64_t)(t - i) * B * ldz + (int64_t)i * nk);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  const float NEG = -3.402823466e38f;
+  float4 m = make_float4(NEG, NEG, NEG, NEG);
+  int4 at = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+  if (live) {
+    for (int t = tg; t < F; t += 16) {
+      float4 v = *reinterpret_cast<const float4*>(p + (int64_t)t * B * ldz);
+      for (int i = 1; i < fs && i <= t; ++i) {
+        const float4 u = *reinterpret_cast<const float4*>(p + (int64_t)(t - i) * B * ldz + (int64_t)i * nk);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (v.x > m.x || at.x == 0x7fffffff) { m.x = v.x; at.x = t; }   // (the first frame of the class always enters: NaN-free data or not)
+      if (v.y > m.y || at.y == 0x7fffffff) { m.y = v.y; at.y = t; }
+      if (v.z > m.z || at.z == 0x7fffffff) { m.z = v.z; at.z = t; }
+      if (v.w > m.w || at.w == 0x7fffffff) { m.w = v.w; at.w = t; }
     }
-    if (t == 0) { m = v; continue; }
-    if (v.x > m.x) { m.x = v.x; at.x = t; }
-    if (v.y > m.y) { m.y = v.y; at.y = t; }
-    if (v.z > m.z) { m.z = v.z; at.z = t; }
-    if (v.w > m.w) { m.w = v.w; at.w = t; }
   }
-  *reinterpret_cast<float4*>(out + (int64_t)b * ldo + c) = m;
-  *reinterpret_cast<int4*>(idx + (int64_t)b * ldo + c) = at;
+  s_m[tg][cg] = m;
+  s_t[tg][cg] = at;
+  __syncthreads();
+  if (tg == 0 && live) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 v = s_m[j][cg];
+      const int4 w = s_t[j][cg];
+      if (w.x != 0x7fffffff && (v.x > m.x || (v.x == m.x && w.x < at.x))) { m.x = v.x; at.x = w.x; }
+      if (w.y != 0x7fffffff && (v.y > m.y || (v.y == m.y && w.y < at.y))) { m.y = v.y; at.y = w.y; }
+      if (w.z != 0x7fffffff && (v.z > m.z || (v.z == m.z && w.z < at.z))) { m.z = v.z; at.z = w.z; }
+      if (w.w != 0x7fffffff && (v.w > m.w || (v.w == m.w && w.w < at.w))) { m.w = v.w; at.w = w.w; }
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)b * ldo + c) = m;
+    *reinterpret_cast<int4*>(idx + (int64_t)b * ldo + c) = at;
+  }
 }
 
 // block = (column n, shift i); thread = four consecutive features (uchar4 of a frame row; D / 4 threads rounded up to whole waves).
@@ -150,9 +150,12 @@ extern "C" int yt8m_timepool_max_f32(const float* y, int64_t F, int64_t B, int64
                YT8M_E_BADARG, "operands must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  const int64_t n = B * (N / 4);
-  hipLaunchKernelGGL(timepool_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, (int)F, (int)B, (int)N, ldy, out, idx, ldo);
-  return launch_status("timepool_max_kernel");
+  PoolDesc d;                                                         // one "filter" of length 1: the plain maximum over the frames
+  d.nfilt = 1;
+  for (int k = 0; k < 8; ++k) { d.fs[k] = 1; d.ncol[k] = (int)N; d.zbase[k] = 0; d.obase[k] = 0; }
+  hipLaunchKernelGGL(timepool_shiftmax_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)B), dim3(256), 0, s, y, (int)F, (int)B, ldy, d, (int)N, out,
+                     idx, ldo);
+  return launch_status("timepool_shiftmax_kernel");
 }
 
 extern "C" int yt8m_timepool_shiftmax_f32(const float* z, int64_t F, int64_t B, int64_t ldz, int nfilt, const int32_t* fs, const int32_t* ncol,
@@ -175,8 +178,8 @@ extern "C" int yt8m_timepool_shiftmax_f32(const float* z, int64_t F, int64_t B, 
                YT8M_E_BADARG, "operands must be 16-byte aligned");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   ProfScope prof(F_ELEMENTWISE, s);
-  const int64_t n = B * (ob / 4);
-  hipLaunchKernelGGL(timepool_shiftmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, (int)F, (int)B, ldz, d, ob, out, idx, ldo);
+  hipLaunchKernelGGL(timepool_shiftmax_kernel, dim3((unsigned)((ob + 63) / 64), (unsigned)B), dim3(256), 0, s, z, (int)F, (int)B, ldz, d, ob, out,
+                     idx, ldo);
   return launch_status("timepool_shiftmax_kernel");
 }
 
