@@ -1,6 +1,6 @@
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-YT8M_NO_PROF=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/cnn_prof -o cnn -- python $R/tools/model_bench.py cnn_chain > $R/gpurun_out/cnn_prof.txt 2>&1
+YT8M_NO_PROF=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/cnn_prof -o cnn -- python $R/tools/model_bench.py ${1:-cnn_chain} > $R/gpurun_out/cnn_prof.txt 2>&1
 f=$(find $R/gpurun_out/cnn_prof -name "*kernel_stats.csv" | head -1)
 python - <<PY
 import csv

@@ -896,6 +896,12 @@ def _linear_h2_size(M, N, K):
     return M >= LINEAR_H2_MIN_ROWS or M * N * K >= LINEAR_H2_MIN_MNK
 
 
+def _hoisted_role(M, N, K, bf16=False):
+    """Role of a recurrent layer's hoisted input projection x . W_x over all time steps (GRU / LayerNorm-LSTM layers outside the native
+    stack): "h2" under the fully-connected layers' size rule -- its input is the l2-normalised frames or a bounded recurrent output."""
+    return "h2" if (LINEAR_FWD_H2 and not bf16 and _linear_h2_size(M, N, K) and N % 4 == 0 and K >= 512) else None
+
+
 def _linear_dx_h2_rows(dy, W, out=None, beta=0.0):
     """dx [M, K] = dy [M, N] . W [K, N]^T as three f16 products with dy split ROW BY ROW -- one power of two per row (yt8m_h2_rowscales /
     _split_rows, undone by the product's rowscale): a row of dy whose gradient is decades below the largest keeps its own 22 bits, which

@@ -97,8 +97,10 @@ class _GruLayer(torch.autograd.Function):
         zg = torch.empty((F, B, 2 * H), dtype=torch.float32, device=dev)
         zc = torch.empty((F, B, H), dtype=torch.float32, device=dev)
         bf = ops.FLAGS.compute_dtype == "bfloat16"
-        ops.gemm_any(x2, Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data, bf16=bf)
-        ops.gemm_any(x2, Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data, bf16=bf)
+        # the hoisted input projections declare the h2 role like the LSTM stack's (l2-normalised frames / GRU outputs |h| <= 1 against one
+        # weight matrix: three f16 products instead of six bf16 ones; ops._hoisted_role)
+        ops.gemm_any(x2, Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data, bf16=bf, role=ops._hoisted_role(F * B, 2 * H, Din, bf))
+        ops.gemm_any(x2, Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data, bf16=bf, role=ops._hoisted_role(F * B, H, Din, bf))
         hs = torch.empty((F + 1, B, H), dtype=torch.float32, device=dev)
         hs[0].zero_()
         rh = torch.empty((F, B, H), dtype=torch.float32, device=dev)
@@ -197,7 +199,7 @@ class _LnLstmLayer(torch.autograd.Function):
         assert W.data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
         dev = x_tm.device
         bf = ops.FLAGS.compute_dtype == "bfloat16"
-        z = ops.gemm_any(x_tm.view(F * B, Din), W.data[:Din], bf16=bf).view(F, B, 4 * H)
+        z = ops.gemm_any(x_tm.view(F * B, Din), W.data[:Din], bf16=bf, role=ops._hoisted_role(F * B, 4 * H, Din, bf)).view(F, B, 4 * H)
         gamma = torch.stack([v.data for v in gammas]).contiguous()
         beta = torch.stack([v.data for v in betas]).contiguous()
         stats = torch.zeros((F, B, 10), dtype=torch.float32, device=dev)
