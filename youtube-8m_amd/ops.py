@@ -902,6 +902,24 @@ def _hoisted_role(M, N, K, bf16=False):
     return "h2" if (LINEAR_FWD_H2 and not bf16 and _linear_h2_size(M, N, K) and N % 4 == 0 and K >= 512) else None
 
 
+class _RowWindow(object):
+    """The first rows of a weight matrix as the `W` of _linear_dx_h2_rows (a recurrent layer's input half W[:in] of its [in + H, .] weights)."""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        self.data = data
+
+
+def hoisted_dx(dy, Wrows, out=None, beta=0.0, bf16=False):
+    """dx [M, K] (+)= dy [M, N] . Wrows [K, N]^T of a recurrent layer's hoisted input projection: row-scaled three-f16-product form under the
+    fully-connected layers' size rule (time steps whose gradients differ by decades keep their own precision), else the generic product."""
+    M, N = dy.shape
+    K = Wrows.shape[0]
+    if (LINEAR_DX_H2 and not bf16 and _linear_h2_size(M, N, K) and N >= 512 and K % 4 == 0 and Wrows.is_contiguous() and dy.is_contiguous()):
+        return _linear_dx_h2_rows(dy, _RowWindow(Wrows), out=out, beta=beta)
+    return gemm_any(dy, Wrows, out=out, transB=True, beta=beta, bf16=bf16)
+
+
 def _linear_dx_h2_rows(dy, W, out=None, beta=0.0):
     """dx [M, K] = dy [M, N] . W [K, N]^T as three f16 products with dy split ROW BY ROW -- one power of two per row (yt8m_h2_rowscales /
     _split_rows, undone by the product's rowscale): a row of dy whose gradient is decades below the largest keeps its own 22 bits, which

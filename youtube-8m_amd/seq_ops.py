@@ -173,8 +173,8 @@ class _GruLayer(torch.autograd.Function):
             bc.grad_done()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_any(g2, Wg.data[:Din], transB=True, bf16=bf)
-            ops.gemm_any(c2, Wc.data[:Din], out=dx, transB=True, beta=1.0, bf16=bf)
+            dx = ops.hoisted_dx(g2, Wg.data[:Din], bf16=bf)
+            ops.hoisted_dx(c2, Wc.data[:Din], out=dx, beta=1.0, bf16=bf)
             dx = dx.view(F, B, Din)
         return dx, None, None, None, None, None, None
 
@@ -252,7 +252,7 @@ class _LnLstmLayer(torch.autograd.Function):
                     v.grad_done()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_any(dz2, W.data[:Din], transB=True, bf16=ctx.bf16).view(F, B, Din)
+            dx = ops.hoisted_dx(dz2, W.data[:Din], bf16=ctx.bf16).view(F, B, Din)
         return dx, None, None, None, None, None, None, None, None
 
 
