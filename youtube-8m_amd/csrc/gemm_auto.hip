@@ -20,7 +20,9 @@ namespace {
 // measured: fp32-equivalent FLOP/s of either kernel, bytes/s of the split pass (profiles/r2_x3_check.txt)
 constexpr double X3_RATE = 195e12, F32_RATE = 110e12, SPLIT_RATE = 3.2e12;
 
-bool x3_pays(int64_t M, int64_t N, int64_t K) {
+// rate_mul / split_bytes: the three-f16-product form of a declared-h2 product runs 1.65x the six-product kernel (profiles/r6_x3_check.txt)
+// and its operand passes move 8 instead of 10 bytes per element
+bool image_form_pays(int64_t M, int64_t N, int64_t K, double rate_mul, double split_bytes) {
   if (M <= 0 || N <= 0 || K <= 0) return false;
   const double fl = 2.0 * (double)M * (double)N * (double)K;
   const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
@@ -35,16 +37,22 @@ bool x3_pays(int64_t M, int64_t N, int64_t K) {
   const double tiles = (double)(tm * tn);
   double occ = std::min(1.0, tiles * (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 128)) / 256.0);
   if (occ < 1.0 && K >= 32768 && tiles >= 16.0) occ = std::max(occ, 0.7 * std::min(1.0, tiles * 16.0 / 256.0));
-  const double tx3 = fl / (X3_RATE * eff * occ) + ((double)M * K + (double)N * K) * 10.0 / SPLIT_RATE + 2e-5;
+  const double tx3 = fl / (X3_RATE * rate_mul * eff * occ) + ((double)M * K + (double)N * K) * split_bytes / SPLIT_RATE + 2e-5;
   const double t32 = fl / (F32_RATE * std::min(1.0, (double)(((M + 127) / 128) * ((N + 127) / 128)) *
                                                         (double)std::max<int64_t>(1, std::min<int64_t>(8, K / 256)) / 768.0));
   return tx3 < 0.9 * t32;
 }
+bool x3_pays(int64_t M, int64_t N, int64_t K) { return image_form_pays(M, N, K, 1.0, 10.0); }
 
-bool x3_allowed(const yt8m_gemm_problem& q) {
+// h2: the product will take the three-f16-product form (declared role): priced at that kernel's rate -- the weight gradients of the
+// MoE heads at 512 rows ([1152..2176 x 512] . [512 x 23 580]) lost to the fp32 kernel by 3 us on the six-product price and run 1.5x
+// faster on the form they actually take (DeepCombineChainModel at B = 512; knob YT8M_GEMM_H2_PRICE=0: the six-product price for all)
+bool x3_allowed(const yt8m_gemm_problem& q, bool h2 = false) {
   static const bool off = getenv("YT8M_GEMM_X3") != nullptr && atoi(getenv("YT8M_GEMM_X3")) == 0;
+  static const bool h2_price = !(getenv("YT8M_GEMM_H2_PRICE") != nullptr && atoi(getenv("YT8M_GEMM_H2_PRICE")) == 0);
   // the x3 launch takes beta in {0, 1} and its split pass at most 64 * 65535 rows per operand
-  return !off && (q.beta == 0.f || q.beta == 1.f) && std::max(q.M, std::max(q.N, q.K)) < 64LL * 65535 && x3_pays(q.M, q.N, q.K);
+  return !off && (q.beta == 0.f || q.beta == 1.f) && std::max(q.M, std::max(q.N, q.K)) < 64LL * 65535 &&
+         ((h2 && h2_price) ? image_form_pays(q.M, q.N, q.K, 1.65, 8.0) : x3_pays(q.M, q.N, q.K));
 }
 
 int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
@@ -87,8 +95,9 @@ extern "C" int64_t yt8m_gemm_auto_scratch_bytes(int transA_flags, int transB, in
   int64_t n = 0;
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
-    if (!x3_allowed(q)) continue;
-    if (h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0) {   // (h2 images are 2/3 of these sizes; the scale words sit in front)
+    const bool h2q = h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0;
+    if (!x3_allowed(q, h2q)) continue;
+    if (h2q) {                                                    // (h2 images are 2/3 of these sizes; the scale words sit in front)
       if (!yt8m_wimg_lookup(static_cast<const float*>(q.A), transA ? q.K : q.M, transA ? q.M : q.K, q.lda, transA ? 1 : 0, 2, 0.0f))
         n += H2_SCALE_BYTES + up256(yt8m_x3_image_bytes(q.M, q.K));
       if (!yt8m_wimg_lookup(static_cast<const float*>(q.B), transB ? q.N : q.K, transB ? q.K : q.N, q.ldb, transB == 0 ? 1 : 0, 2, 0.0f))
@@ -155,8 +164,8 @@ extern "C" int yt8m_gemm_auto_grouped_ex(int transA_flags, int transB, int nprob
   };
   for (int i = 0; i < nprob; ++i) {
     const yt8m_gemm_problem& q = probs[i];
-    bool x3 = q.M > 0 && q.N > 0 && x3_allowed(q) && q.A && q.B;
     const bool h2 = h2_role(transA_flags, transB, q.K) && (q.N % 4) == 0;   // (the scaled epilogue stores float4: odd widths take the six-product form)
+    bool x3 = q.M > 0 && q.N > 0 && x3_allowed(q, h2) && q.A && q.B;
     const void* ia = nullptr;
     const void* ib = nullptr;
     const float* wa = nullptr;
