@@ -733,3 +733,40 @@ def test_pooled_u8_cnn_equals_the_pooled_output_of_the_unpooled_op(dev, shapes):
     assert np.abs(out["pooled"][0] - pr.detach().numpy()).max() < 2e-6 * max(1.0, float(pr.detach().abs().max()))
     for a, t in zip(out["pooled"][1], tw):
         assert np.abs(a - t.grad.numpy()).max() <= 5e-6 * max(1.0, float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B", [64, 512])
+def test_moe_head_skips_the_input_gradient_of_its_data_columns(dev, flags, B):
+    """ops.moe_head(dx_from=k): the first k columns of the head's input are data (the chain models keep the model input in front of what
+    they learned, W/all_video_models/deep_combine_chain_model.py:66-70); dx is computed for columns [k, K) only -- the row window [k, K)
+    of the weights (whole 32-row groups of the resident half-plane image at 512 rows, a row slice on the fp32 kernel at 64).  The
+    learned part's gradient and every parameter gradient equal the full computation's; the data columns of dx are zeros."""
+    rs = np.random.RandomState(51 + B)
+    K, k0, V, M = 1152 + 128, 1152, 24, 2
+    x = torch.from_numpy(rs.randn(B, K).astype(np.float32)).to(dev)
+    coef = torch.from_numpy(rs.randn(B, V).astype(np.float32)).to(dev)
+    res = {}
+    for dx_from in (0, k0):
+        g = reset_default_graph(device=dev, seed=0)
+        Wg = g.get_variable("g", (K, V * (M + 1)), xavier_uniform)
+        We = g.get_variable("e", (K, V * M), xavier_uniform)
+        be = g.get_variable("b", (V * M,), zeros)
+        g.finalize()
+        g.begin_step()
+        data = x[:, :k0].clone()
+        learned = x[:, k0:].clone().requires_grad_(True)
+        p = ops.moe_head(torch.cat([data, learned], dim=1), Wg, We, be, V, M, dx_from=dx_from)
+        (p * coef).sum().backward()
+        res[dx_from] = [t.detach().cpu().numpy().astype(np.float64) for t in (p, learned.grad, Wg.grad, We.grad, be.grad)]
+    for a, b in zip(res[0], res[k0]):
+        assert np.abs(a - b).max() <= 1e-6 * max(1e-6, np.abs(a).max())
+    # the op's own dx: zeros in the data columns
+    g = reset_default_graph(device=dev, seed=0)
+    Wg = g.get_variable("g", (K, V * (M + 1)), xavier_uniform)
+    We = g.get_variable("e", (K, V * M), xavier_uniform)
+    be = g.get_variable("b", (V * M,), zeros)
+    g.finalize()
+    g.begin_step()
+    xx = x.clone().requires_grad_(True)
+    (ops.moe_head(xx, Wg, We, be, V, M, dx_from=k0) * coef).sum().backward()
+    assert float(xx.grad[:, :k0].abs().max()) == 0.0 and float(xx.grad[:, k0:].abs().max()) > 0.0

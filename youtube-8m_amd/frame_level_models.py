@@ -384,22 +384,24 @@ class CnnDeepCombineChainModel(models.BaseModel):
             return ops.l2_normalize(ops.frame_pool(cnn_output, "max"))      # reduce_max over ALL max_frames rows, as the reference
 
         next_input = pooled_cnn(sub_scope + "cnn0")
+        frozen = 0
         support_predictions = []
         for layer in range(num_layers):
-            sub_prediction = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "prediction-%d" % layer)
+            sub_prediction = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "prediction-%d" % layer, frozen_cols=frozen)
             support_predictions.append(sub_prediction)
             sub_relu = video_level_models.fully_connected(sub_prediction, relu_cells, sub_scope + "relu-%d" % layer,
                                                           activation="relu", l2_penalty=l2_penalty)
             relu_layers.append(ops.l2_normalize(sub_relu))
             normalized_cnn_output = pooled_cnn(sub_scope + "cnn%d" % (layer + 1))
             next_input = torch.cat([mean_input, normalized_cnn_output] + relu_layers, dim=1)
-        main_predictions = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "-main")
+            frozen = 0 if mean_input.requires_grad else D           # the mean frame in front of the stage's input is data
+        main_predictions = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "-main", frozen_cols=frozen)
         return {"predictions": main_predictions, "support_predictions": torch.cat(support_predictions, dim=1)}
 
-    def sub_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", **unused_params):
+    def sub_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", frozen_cols=0, **unused_params):
         num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
         return video_level_models.moe_block(model_input, vocab_size, num_mixtures, l2_penalty,
-                                            "gates-" + sub_scope, "experts-" + sub_scope)
+                                            "gates-" + sub_scope, "experts-" + sub_scope, frozen_cols=frozen_cols)
 
 
 def _batch_norm(x, scope, is_training, eps=1e-3, decay=0.999):

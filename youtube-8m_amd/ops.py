@@ -920,14 +920,16 @@ def hoisted_dx(dy, Wrows, out=None, beta=0.0, bf16=False):
     return gemm_any(dy, Wrows, out=out, transB=True, beta=beta, bf16=bf16)
 
 
-def _linear_dx_h2_rows(dy, W, out=None, beta=0.0):
+def _linear_dx_h2_rows(dy, W, out=None, beta=0.0, row0=0):
     """dx [M, K] = dy [M, N] . W [K, N]^T as three f16 products with dy split ROW BY ROW -- one power of two per row (yt8m_h2_rowscales /
     _split_rows, undone by the product's rowscale): a row of dy whose gradient is decades below the largest keeps its own 22 bits, which
     one scale per matrix would not give it (the form the recurrent stack's dx takes, csrc/lstm_stack.hip).  W as an [K rows, K' = N]
-    half-plane image: resident (wimg.py) or made here under its measured maximum."""
+    half-plane image: resident (wimg.py) or made here under its measured maximum.  row0 (a multiple of 32): only the columns [row0, K) of
+    dx are computed -- rows [row0, K) of W are whole 32-row groups of its image --, a fresh dx holds zeros in front of them."""
     L = _lib.lib()
     M, N = dy.shape
     K = W.data.shape[0]
+    assert row0 % 32 == 0 and 0 <= row0 < K
     dev = dy.device
     nb = lambda rows, kk: max(L.yt8m_x3_image_bytes(rows, kk) // 3 * 2, 16)
     S = torch.empty(M, dtype=torch.float32, device=dev)
@@ -947,10 +949,15 @@ def _linear_dx_h2_rows(dy, W, out=None, beta=0.0):
         _lib.check(L.yt8m_h2_split(wp, K, N, N, 1.0, _p(word), _p(wi), None, None, _stream()))
         keep = (word, wi)
         wimg_p, word_p = _p(wi), _p(word)
-    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dev)
+    if out is not None:
+        dx = out
+    else:
+        dx = (torch.zeros if row0 else torch.empty)((M, K), dtype=torch.float32, device=dev)
     ws = _workspace(dev)
-    _lib.check(L.yt8m_gemm_h2_nt_ex(M, K, N, _p(dyi), 0, wimg_p, 0, _p(dx), K, None, 1.0, None, word_p, _p(inv), float(beta), _p(ws),
-                                    ws.numel() * 4, _stream()))
+    if row0:                                                     # (a K block of an h2 image: two 1 KiB half planes)
+        wimg_p = ctypes.c_void_p(wimg_p.value + (row0 // 32) * ((N + 15) // 16) * 2048)
+    _lib.check(L.yt8m_gemm_h2_nt_ex(M, K - row0, N, _p(dyi), 0, wimg_p, 0, ctypes.c_void_p(dx.data_ptr() + row0 * 4), K, None, 1.0, None,
+                                    word_p, _p(inv), float(beta), _p(ws), ws.numel() * 4, _stream()))
     del keep
     return dx
 
@@ -1153,11 +1160,12 @@ class _MoeHead(torch.autograd.Function):
     """MoE block of W/all_video_models/moe_model.py:40-64: two GEMMs + mixing kernel; backward per Appendix G."""
 
     @staticmethod
-    def forward(ctx, x, token, Wg, We, be, V, M, bf16):
+    def forward(ctx, x, token, Wg, We, be, V, M, bf16, dx_from=0):
         x2 = _f32c(x)
         ctx.images = {} if (bf16 and FUSED_MIX_BF16 and M == 2 and ctx.needs_input_grad[1]) else None
         Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images, z16=_z16_ok(x2, Wg, We, V, M, bf16, ctx.images is not None))
         ctx.bf16 = bf16
+        ctx.dx_from = dx_from
         p = moe_mix_fwd(Zg, Ze, V, M)
         ctx.save_for_backward(x2)
         ctx.Z = (Zg, Ze)
@@ -1177,10 +1185,10 @@ class _MoeHead(torch.autograd.Function):
             Zg, Ze = Zg.float(), Ze.float()         # (not reached with _z16_ok's predicates; the fp32 passes below read fp32 logits)
         if _fused_mix_bf16_ok(ctx, x, Zg, Ze, M):
             dx = _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, dp=_f32c(dp))
-            return dx, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
         dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 FUSED_MIX_BF16 = True     # compute_dtype=bfloat16, M == 2: mixing backward writes the bf16 GEMM operands itself (csrc/moe_bf16.hip)
@@ -1290,6 +1298,7 @@ LINEAR_H2_MIN_ROWS = int(os.environ.get("YT8M_LINEAR_H2_MIN_ROWS", "512"))
 LINEAR_DX_H2 = os.environ.get("YT8M_LINEAR_DX_H2", "1") != "0"
 LINEAR_H2_MIN_MNK = float(os.environ.get("YT8M_LINEAR_H2_MIN_MNK", "1e9"))
 MOE_DX_H2 = os.environ.get("YT8M_MOE_DX_H2", "1") != "0"
+MOE_DX_FROM = os.environ.get("YT8M_MOE_DX_FROM", "1") != "0"           # chain models: no dx for the data columns in front of a head's input
 MIX_BWD_ABSMAX = os.environ.get("YT8M_MIX_BWD_ABSMAX", "1") != "0"     # the mixing backward measures max |dZ| for the dW products' h2 split
 
 
@@ -1470,12 +1479,19 @@ def _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, zmax=None, xmax=None):
         return _moe_head_param_grads_bf16(ctx, x, Zg, Ze, Wg, We, be)
     dx = None
     if ctx.needs_input_grad[0]:                    # before the weights' gradient slots are released to an optimiser
+        # columns [0, k0) of x are data (moe_head's dx_from): no gradient is computed for them -- k0 on a 32-row group of the weights' images
+        k0 = int(getattr(ctx, "dx_from", 0) or 0)
+        k0 = k0 if (MOE_DX_FROM and 0 < k0 < Wg.data.shape[0] and k0 % 32 == 0) else 0
         if (MOE_DX_H2 and Zg.shape[0] >= MOE_LOGITS_H2_MIN_ROWS and Wg.data.shape[0] % 4 == 0 and Wg.data.is_contiguous()
                 and We.data.is_contiguous() and Zg.is_contiguous() and Ze.is_contiguous()):
             # round 6: from 1 024 rows on, three f16 products with dZ split row by row against the weights' half-plane images (the form of
             # ops._linear_dx_h2_rows) instead of the fp32-MFMA kernel these 16-tile, K ~ 14 000 products fell back to
-            dx = _linear_dx_h2_rows(Zg, Wg)
-            _linear_dx_h2_rows(Ze, We, out=dx, beta=1.0)
+            dx = _linear_dx_h2_rows(Zg, Wg, row0=k0)
+            _linear_dx_h2_rows(Ze, We, out=dx, beta=1.0, row0=k0)
+        elif k0:
+            dx = torch.zeros((Zg.shape[0], Wg.data.shape[0]), dtype=torch.float32, device=Zg.device)
+            gemm(Zg, Wg.data[k0:], transB=True, out=dx[:, k0:])
+            gemm(Ze, We.data[k0:], out=dx[:, k0:], transB=True, beta=1.0)
         else:
             dx = gemm(Zg, Wg.data, transB=True)
             gemm(Ze, We.data, out=dx, transB=True, beta=1.0)
@@ -1520,8 +1536,10 @@ def moe_head_xent(x, Wg, We, be, labels, vocab_size, num_mixtures, bf16=False):
     return _MoeHeadXent.apply(x, _token(Wg._graph), Wg, We, be, labels, vocab_size, num_mixtures, bool(bf16))
 
 
-def moe_head(x, Wg, We, be, vocab_size, num_mixtures, bf16=False):
-    return _MoeHead.apply(x, _token(Wg._graph), Wg, We, be, vocab_size, num_mixtures, bool(bf16))
+def moe_head(x, Wg, We, be, vocab_size, num_mixtures, bf16=False, dx_from=0):
+    """dx_from: the first `dx_from` columns of x are DATA (the chain models concatenate the model input in front of what they learned:
+    deep_combine_chain_model.py:66-70) -- their gradient is not computed (fp32 configuration; the returned dx holds zeros there)."""
+    return _MoeHead.apply(x, _token(Wg._graph), Wg, We, be, vocab_size, num_mixtures, bool(bf16), int(dx_from))
 
 
 class _Xent(torch.autograd.Function):

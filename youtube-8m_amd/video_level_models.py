@@ -41,9 +41,10 @@ def fully_connected_cat(parts, num_outputs, scope, activation=None, use_bias=Tru
     return ops.activation(y, activation) if activation else y
 
 
-def moe_block(model_input, vocab_size, num_mixtures, l2_penalty, gate_scope, expert_scope):
+def moe_block(model_input, vocab_size, num_mixtures, l2_penalty, gate_scope, expert_scope, frozen_cols=0):
     """The MoE block shared by MoeModel, the chain models' sub_model and the attention model's sub_moe
-    (W/all_video_models/moe_model.py:40-64).  Gate FC has no bias; column l*(M+1)+m = gate m of label l."""
+    (W/all_video_models/moe_model.py:40-64).  Gate FC has no bias; column l*(M+1)+m = gate m of label l.
+    frozen_cols: the leading columns of model_input that are data (ops.moe_head dx_from)."""
     g = get_default_graph()
     d_in = model_input.shape[-1]
     M = num_mixtures
@@ -51,7 +52,7 @@ def moe_block(model_input, vocab_size, num_mixtures, l2_penalty, gate_scope, exp
     We = g.get_variable(expert_scope + "/weights", (d_in, vocab_size * M), xavier_uniform, l2=l2_penalty)
     be = g.get_variable(expert_scope + "/biases", (vocab_size * M,), zeros)
     lead = model_input.shape[:-1]
-    p = ops.moe_head(model_input.reshape(-1, d_in), Wg, We, be, vocab_size, M, bf16=FLAGS.compute_dtype == "bfloat16")
+    p = ops.moe_head(model_input.reshape(-1, d_in), Wg, We, be, vocab_size, M, bf16=FLAGS.compute_dtype == "bfloat16", dx_from=frozen_cols)
     return p.view(-1, vocab_size) if len(lead) <= 1 else p.view(-1, vocab_size)
 
 
@@ -99,10 +100,12 @@ class DeepCombineChainModel(models.BaseModel):
         relu_cells = FLAGS.deep_chain_relu_cells
         relu_type = FLAGS.deep_chain_relu_type
         next_input = model_input
+        # the model input stays in front of every later stage's input (:66-70): when it is data, no head computes a gradient for it
+        frozen = 0 if model_input.requires_grad else int(model_input.shape[1])
         support_predictions = []
         for layer in range(num_layers):
             sub_prediction = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "prediction-%d" % layer,
-                                            dropout=dropout, keep_prob=keep_prob, noise_level=noise_level)
+                                            dropout=dropout, keep_prob=keep_prob, noise_level=noise_level, frozen_cols=frozen)
             sub_activation = fully_connected(sub_prediction, relu_cells, sub_scope + "relu-%d" % layer, l2_penalty=l2_penalty)
             sub_relu = ops.activation(sub_activation, "elu" if relu_type == "elu" else "relu")
             if noise_level is not None:
@@ -110,12 +113,13 @@ class DeepCombineChainModel(models.BaseModel):
             relu_norm = ops.l2_normalize(sub_relu)
             next_input = torch.cat([next_input, relu_norm], dim=1)
             support_predictions.append(sub_prediction if support_pool is None else support_pool(sub_prediction))
-        main_predictions = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "-main")
+        main_predictions = self.sub_model(next_input, vocab_size, sub_scope=sub_scope + "-main", frozen_cols=frozen)
         return {"predictions": main_predictions, "support_predictions": torch.cat(support_predictions, dim=1)}
 
     def sub_model(self, model_input, vocab_size, num_mixtures=None, l2_penalty=1e-8, sub_scope="", dropout=False,
-                  keep_prob=None, noise_level=None, **unused_params):
+                  keep_prob=None, noise_level=None, frozen_cols=0, **unused_params):
         num_mixtures = num_mixtures or FLAGS.moe_num_mixtures
         if dropout:                                                 # :57-58 tf.nn.dropout on the (grown) chain input
             model_input = ops.dropout(model_input, 1.0 if keep_prob is None else keep_prob)
-        return moe_block(model_input, vocab_size, num_mixtures, l2_penalty, "gates-" + sub_scope, "experts-" + sub_scope)
+        return moe_block(model_input, vocab_size, num_mixtures, l2_penalty, "gates-" + sub_scope, "experts-" + sub_scope,
+                         frozen_cols=frozen_cols)
