@@ -1163,7 +1163,9 @@ class _MoeHead(torch.autograd.Function):
     def forward(ctx, x, token, Wg, We, be, V, M, bf16, dx_from=0):
         x2 = _f32c(x)
         ctx.images = {} if (bf16 and FUSED_MIX_BF16 and M == 2 and ctx.needs_input_grad[1]) else None
-        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images, z16=_z16_ok(x2, Wg, We, V, M, bf16, ctx.images is not None))
+        ctx.words = {}                                  # max |x| measured once: the weight gradient's split of x^T takes the same word
+        Zg, Ze = _moe_logits(x2, Wg, We, be, bf16, keep=ctx.images, z16=_z16_ok(x2, Wg, We, V, M, bf16, ctx.images is not None),
+                             words=ctx.words)
         ctx.bf16 = bf16
         ctx.dx_from = dx_from
         p = moe_mix_fwd(Zg, Ze, V, M)
@@ -1187,7 +1189,7 @@ class _MoeHead(torch.autograd.Function):
             dx = _moe_head_bwd_bf16_fused(ctx, x, Zg, Ze, Wg, We, be, V, M, dp=_f32c(dp))
             return dx, None, None, None, None, None, None, None, None
         moe_mix_bwd_(Zg, Ze, dp, V, M)            # in place: Zg <- dL/dZg, Ze <- dL/dZe
-        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be)
+        dx = _moe_head_param_grads(ctx, x, Zg, Ze, Wg, We, be, xmax=(getattr(ctx, "words", None) or {}).get("x"))
         return dx, None, None, None, None, None, None, None, None
 
 
