@@ -688,14 +688,15 @@ def test_cnn_chain_plugin_takes_the_raw_uint8_frames(dev, flags, monkeypatch):
             assert np.abs(ga[k] - t.grad.numpy()).max() <= 5e-4 * max(1.0, np.abs(t.grad.numpy()).max()), k
 
 
-@pytest.mark.parametrize("shapes", [[(1, 8), (2, 8), (3, 12)], [(1, 32), (2, 64), (3, 32)]])     # (filter length, columns); the second set
-def test_pooled_u8_cnn_equals_the_pooled_output_of_the_unpooled_op(dev, shapes):                   # takes the one-product form
+@pytest.mark.parametrize("F,shapes", [(9, [(1, 8), (2, 8), (3, 12)]), (9, [(1, 32), (2, 64), (3, 32)]),   # (filter length, columns); the
+                                      (2, [(1, 32), (2, 32), (4, 64)]), (1, [(1, 8), (3, 8)])])            # 32-multiples: one-product form;
+def test_pooled_u8_cnn_equals_the_pooled_output_of_the_unpooled_op(dev, F, shapes):                        # F below the filter length
     """seq_ops.u8_cnn_maxpool (time-major pooling with the argmax kept, per-column gathered weight gradient: csrc/cnn_pool.hip) against
     seq_ops.u8_cnn followed by a max over the frames (dense weight-gradient products on the transposed byte image), and both against fp64:
     pooled values, and the filters' gradients of a random linear functional of them.  Ragged videos incl. an empty one and one frame."""
     from oracle import np_ref
     rs = np.random.RandomState(41)
-    B, F, D = 32, 9, 48
+    B, D = 32, 48
     q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
     nf = rs.randint(1, F + 1, size=B).astype(np.int32)
     nf[0], nf[1], nf[2] = F, 1, 0
@@ -726,7 +727,7 @@ def test_pooled_u8_cnn_equals_the_pooled_output_of_the_unpooled_op(dev, shapes):
     tw = [torch.from_numpy(W.astype(np.float64)).requires_grad_(True) for W in Ws]
     cols = []
     for (fs, n), W in zip(shapes, tw):
-        sh = [x] + [torch.cat([x.new_zeros(B, i, D), x[:, :F - i]], dim=1) for i in range(1, fs)]
+        sh = [x] + [torch.cat([x.new_zeros(B, min(i, F), D), x[:, :max(F - i, 0)]], dim=1) for i in range(1, fs)]
         cols.append(torch.cat(sh, dim=2) @ W)
     pr = torch.cat(cols, dim=2).max(dim=1).values
     (pr * torch.from_numpy(coef.astype(np.float64))).sum().backward()
