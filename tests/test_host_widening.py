@@ -232,3 +232,28 @@ def test_auto_cu_reserve_rule_of_the_data_parallel_reducer():
     if parallel.DP_RESERVED_CUS is None:
         red.attach(g)
         assert red.reserve_cus == 0 and red.reserve_rule["rule"] == "auto"
+
+
+def test_host_rules_of_the_byte_reading_plugins_and_the_hoisted_h2_roles():
+    """Host-side decisions added in the last session of round 6 (no GPU work): which recurrent layers' hoisted projections declare the h2
+    role (ops._hoisted_role: the fully-connected layers' size rule, never in the bf16 configuration), and that the byte paths of the
+    plugins refuse what their kernels do not cover (seq_ops.u8_cnn_supported / u8_attention_supported: device tensors of uint8 frames
+    only -- a CPU tensor falls back to the dequantised float path instead of reaching the library)."""
+    import yt8m_amd.ops as ops
+    import yt8m_amd.seq_ops as seq_ops
+    assert ops._hoisted_role(38400, 4096, 1152) == "h2" and ops._hoisted_role(38400, 2048, 1024) == "h2"
+    assert ops._hoisted_role(38400, 4096, 256) is None          # short reduction: not worth the operand passes
+    assert ops._hoisted_role(300, 4094, 1152) is None           # N % 4 != 0: the scaled epilogue stores float4
+    assert ops._hoisted_role(64, 64, 512) is None               # small layer
+    assert ops._hoisted_role(38400, 4096, 1152, bf16=True) is None
+    q = torch.zeros((16, 4, 32), dtype=torch.uint8)
+    assert not seq_ops.u8_cnn_supported(q) and not seq_ops.u8_attention_supported(q, 8)
+    assert not seq_ops.u8_cnn_supported(torch.zeros((16, 4, 32)))
+    w = ops._RowWindow(torch.zeros((4, 8)))
+    assert tuple(w.data.shape) == (4, 8)
+    import yt8m_amd.frame_level_models as flm
+    for cls in (flm.LstmModel, flm.LstmMemoryModel, flm.LstmAttentionMaxPoolingModel, flm.LstmPositionalAttentionMaxPoolingModel,
+                flm.LstmParallelFinaloutputModel, flm.CnnDeepCombineChainModel, flm.DbofModel, flm.NetVLADModel):
+        assert getattr(cls, "accepts_quantized_input", False), cls.__name__
+    for cls in (flm.GruPoolingModel, flm.LayerNormLstmMemoryModel, flm.FrameLevelLogisticModel):
+        assert not getattr(cls, "accepts_quantized_input", False), cls.__name__
