@@ -771,3 +771,31 @@ def test_moe_head_skips_the_input_gradient_of_its_data_columns(dev, flags, B):
     xx = x.clone().requires_grad_(True)
     (ops.moe_head(xx, Wg, We, be, V, M, dx_from=k0) * coef).sum().backward()
     assert float(xx.grad[:, :k0].abs().max()) == 0.0 and float(xx.grad[:, k0:].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("which", ["gru_pool", "gru_with_pool", "ln_lstm"])
+def test_gru_and_layernorm_lstm_plugins_take_the_raw_uint8_frames(dev, flags, which, monkeypatch):
+    """GruPoolingModel / GruWithPoolingModel / LayerNormLstmMemoryModel on the reader's bytes: layer 0's hoisted input projection and
+    its weight gradient read the byte images (seq_ops.u8_hoisted_fwd / _dw, the forms of the native LSTM stack's layer 0), no dx for
+    the data.  Against the same plugin on the dequantised float frames with the same weights: predictions, loss, every gradient."""
+    import yt8m_amd.frame_level_models as flm
+    rs = np.random.RandomState(61)
+    B, F, D, Hh, V = 16, 8, 32, 128, 13
+    flags.gru_cells, flags.gru_layers, flags.lstm_cells, flags.lstm_layers = Hh, 2, str(Hh), 2
+    q = rs.randint(0, 256, size=(B, F, D)).astype(np.uint8)
+    nf = rs.randint(1, F + 1, size=B).astype(np.int32)
+    nf[0], nf[1] = F, 1
+    y = rs.rand(B, V) < 0.2
+    cls = {"gru_pool": flm.GruPoolingModel, "gru_with_pool": flm.GruWithPoolingModel, "ln_lstm": flm.LayerNormLstmMemoryModel}[which]
+    assert seq_ops.u8_hoisted_supported(torch.from_numpy(q).to(dev))
+    P0 = None
+    if which == "ln_lstm":                                              # gammas near 1 (a random gamma ~ N(0, 0.3) is a degenerate cell)
+        pa0, _, _, P0 = _run_frames_plugin(cls(), q, y, nf, dev, rs=rs)
+        P0 = {k: (np.abs(v) + 0.5).astype(np.float32) if k.endswith("gamma") else v for k, v in P0.items()}
+    pa, la, ga, P = _run_frames_plugin(cls(), q, y, nf, dev, P=P0, rs=rs)
+    monkeypatch.setattr(cls, "accepts_quantized_input", False)
+    pb, lb, gb, _ = _run_frames_plugin(cls(), q, y, nf, dev, P=P)
+    assert set(ga) == set(gb)
+    assert np.abs(pa - pb).max() < 2e-5 and abs(la - lb) < 1e-4 * max(1.0, abs(lb))
+    for k in ga:
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-4 * max(1.0, np.abs(gb[k]).max()), k

@@ -16,6 +16,11 @@ def main():
     mb.FLAGS.reset()
     for k, v in cfg.get("flags", {}).items():
         setattr(mb.FLAGS, k, v)
+    for kv in os.environ.get("YT8M_SET", "").split(","):           # e.g. YT8M_SET=fold_dequant=0: the float-frames path of a plugin
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            cur = getattr(mb.FLAGS, k)
+            setattr(mb.FLAGS, k, (v == "1") if isinstance(cur, bool) else type(cur)(v))
     B = cfg["B"]
     g = mb.reset_default_graph(device=mb.dev, seed=0)
     mt = cfg.get("multitask", False)

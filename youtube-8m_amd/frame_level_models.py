@@ -120,14 +120,25 @@ class LstmMemoryModel(models.BaseModel):
                                       num_frames=num_frames, **unused_params)
 
 
+def _recurrent_input(model_input, num_frames):
+    """Layer-0 input of a GRU / LayerNorm-LSTM stack: the reader's bytes as operand images (seq_ops.U8FrameImages: the hoisted input
+    projection and its weight gradient read them, no fp32 [B,F,D] tensor) where the byte products cover the shape, else the float
+    frames time-major [F,B,D] (dequantised first when they arrive as bytes)."""
+    if model_input.dtype == torch.uint8:
+        if seq_ops.u8_hoisted_supported(model_input):
+            return seq_ops.U8FrameImages(model_input, num_frames)
+        model_input = ops.dequant_l2norm(model_input, num_frames)
+    return model_input.transpose(0, 1).contiguous()          # (layout glue)
+
+
 def _gru_stack(model_input, num_frames, gru_size, number_of_layers):
     """MultiRNNCell([GRUCell(H)] * L, state_is_tuple=False) under tf.nn.dynamic_rnn in variable_scope("RNN")
     (W/all_frame_models/gru_pooling_model.py:34-47).  TF-1.0 names: RNN/multi_rnn_cell/cell_<l>/gru_cell/{gates,candidate}/
     {weights,biases}; the gate bias starts at 1.  Returns (top outputs time-major [F,B,H], [h_l final])."""
     g = get_default_graph()
-    x_tm = model_input.transpose(0, 1).contiguous()
+    x_tm = _recurrent_input(model_input, num_frames)
     finals = []
-    d_in = x_tm.shape[2]
+    d_in = model_input.shape[2]
     with g.variable_scope("RNN"):
         for l in range(number_of_layers):
             scope = "multi_rnn_cell/cell_%d/gru_cell" % l
@@ -153,6 +164,7 @@ class GruPoolingModel(models.BaseModel):
     """W/all_frame_models/gru_pooling_model.py:13-58: GRU stack, head input = outputs averaged over the video's frames.
     (The reference file divides by tf.maximum(num_frames, tf.ones([batch_size, 1])) with `batch_size` undefined -- it raises
     NameError at graph construction; built here with the evident meaning.)"""
+    accepts_quantized_input = True                         # _recurrent_input: layer 0 reads the reader's bytes
 
     def create_model(self, model_input, vocab_size, num_frames, **unused_params):
         out_tm, _ = _gru_stack(model_input, num_frames, FLAGS.gru_cells, FLAGS.gru_layers)
@@ -164,6 +176,7 @@ class GruPoolingModel(models.BaseModel):
 class GruWithPoolingModel(models.BaseModel):
     """W/all_frame_models/gru_with_pooling_model.py:13-60: head input = [mean-pooled outputs || final state of every layer]
     (state_is_tuple=False: [h_0 || h_1 ...]).  Same `batch_size` NameError in the reference as GruPoolingModel."""
+    accepts_quantized_input = True                         # _recurrent_input: layer 0 reads the reader's bytes
 
     def create_model(self, model_input, vocab_size, num_frames, **unused_params):
         out_tm, finals = _gru_stack(model_input, num_frames, FLAGS.gru_cells, FLAGS.gru_layers)
@@ -179,14 +192,15 @@ class LayerNormLstmMemoryModel(models.BaseModel):
     """W/all_frame_models/layernorm_lstm_memory_model.py:13-72: MultiRNNCell([LayerNormBasicLSTMCell(H)] * L); with --dropout the
     cells get dropout_keep_prob=keep_prob (recurrent dropout on the candidate); head input = concat of the (normalised) c
     states.  TF-1.0 names: RNN/multi_rnn_cell/cell_<l>/layer_norm_basic_lstm_cell/{weights, <gate>/gamma, <gate>/beta}."""
+    accepts_quantized_input = True                         # _recurrent_input: layer 0 reads the reader's bytes
 
     def create_model(self, model_input, vocab_size, num_frames, dropout=False, keep_prob=None, noise_level=None,
                      **unused_params):
         lstm_size = int(FLAGS.lstm_cells)
         g = get_default_graph()
-        x_tm = model_input.transpose(0, 1).contiguous()
+        x_tm = _recurrent_input(model_input, num_frames)
         cs = []
-        d_in = x_tm.shape[2]
+        d_in = model_input.shape[2]
         with g.variable_scope("RNN"):
             for l in range(FLAGS.lstm_layers):
                 scope = "multi_rnn_cell/cell_%d/layer_norm_basic_lstm_cell" % l

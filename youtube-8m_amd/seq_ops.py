@@ -87,20 +87,29 @@ class _GruLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_tm, token, Wg, bg, Wc, bc, num_frames):
-        x_tm = _f32c(x_tm)
-        _dev(x_tm)
-        F, B, Din = x_tm.shape
+        frames = x_tm if isinstance(x_tm, U8FrameImages) else None     # the reader's bytes (layer 0): see u8_hoisted_fwd
+        if frames is None:
+            x_tm = _f32c(x_tm)
+            _dev(x_tm)
+            F, B, Din = x_tm.shape
+            dev = x_tm.device
+        else:
+            F, B, Din = frames.F, frames.B, frames.D
+            dev = frames.q.device
         H = Wc.data.shape[1]
         assert Wg.data.shape == (Din + H, 2 * H) and Wc.data.shape[0] == Din + H, "GRU weights must be [in + H, 2H] / [in + H, H]"
-        dev = x_tm.device
-        x2 = x_tm.view(F * B, Din)
+        x2 = x_tm.view(F * B, Din) if frames is None else None
         zg = torch.empty((F, B, 2 * H), dtype=torch.float32, device=dev)
         zc = torch.empty((F, B, H), dtype=torch.float32, device=dev)
         bf = ops.FLAGS.compute_dtype == "bfloat16"
         # the hoisted input projections declare the h2 role like the LSTM stack's (l2-normalised frames / GRU outputs |h| <= 1 against one
         # weight matrix: three f16 products instead of six bf16 ones; ops._hoisted_role)
-        ops.gemm_any(x2, Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data, bf16=bf, role=ops._hoisted_role(F * B, 2 * H, Din, bf))
-        ops.gemm_any(x2, Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data, bf16=bf, role=ops._hoisted_role(F * B, H, Din, bf))
+        if frames is not None:
+            u8_hoisted_fwd(frames, Wg.data[:Din], bg.data, zg.view(F * B, 2 * H))
+            u8_hoisted_fwd(frames, Wc.data[:Din], bc.data, zc.view(F * B, H))
+        else:
+            ops.gemm_any(x2, Wg.data[:Din], out=zg.view(F * B, 2 * H), bias=bg.data, bf16=bf, role=ops._hoisted_role(F * B, 2 * H, Din, bf))
+            ops.gemm_any(x2, Wc.data[:Din], out=zc.view(F * B, H), bias=bc.data, bf16=bf, role=ops._hoisted_role(F * B, H, Din, bf))
         hs = torch.empty((F + 1, B, H), dtype=torch.float32, device=dev)
         hs[0].zero_()
         rh = torch.empty((F, B, H), dtype=torch.float32, device=dev)
@@ -120,7 +129,8 @@ class _GruLayer(torch.autograd.Function):
             ws = ops._workspace(dev)
             _lib.check(L.yt8m_gru_layer_fwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(rh),
                                             _p(out), _p(nf), F, B, H, _p(ws), ws.numel() * 4, _stream()))
-        ctx.save_for_backward(x_tm)
+        ctx.save_for_backward(x_tm if frames is None else frames.r)
+        ctx.frames, ctx.dims = frames, (F, B, Din)
         ctx.state = (zg, zc, hs, rh, nf, Wg, bg, Wc, bc)
         ctx.bf16 = bf
         ctx.set_materialize_grads(False)
@@ -129,9 +139,10 @@ class _GruLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dh_final):
         (x_tm,) = ctx.saved_tensors
+        frames = ctx.frames
         zg, zc, hs, rh, nf, Wg, bg, Wc, bc = ctx.state
         ctx.state = None
-        F, B, Din = x_tm.shape
+        F, B, Din = ctx.dims
         H = Wc.data.shape[1]
         dev = x_tm.device
         dzg = torch.empty((F, B, 2 * H), dtype=torch.float32, device=dev)
@@ -153,16 +164,23 @@ class _GruLayer(torch.autograd.Function):
             _lib.check(_lib.lib().yt8m_gru_layer_bwd(_p(zg), _p(zc), _p(Wg.data[Din:]), 2 * H, _p(Wc.data[Din:]), H, _p(hs), _p(dout),
                                                      _p(dh_final), _p(dzg), _p(dzc), _p(work), _p(nf), F, B, H, _p(ws),
                                                      ws.numel() * 4, _stream()))
-        x2, g2, c2 = x_tm.view(F * B, Din), dzg.view(F * B, 2 * H), dzc.view(F * B, H)
+        x2 = x_tm.view(F * B, Din) if frames is None else None
+        g2, c2 = dzg.view(F * B, 2 * H), dzc.view(F * B, H)
         bf = ctx.bf16
         if Wg.grad is not None:
             beta = Wg.grad_beta()
-            ops.gemm_any(x2, g2, out=Wg.grad[:Din], transA=True, beta=beta, role="dw", bf16=bf)
+            if frames is not None:
+                u8_hoisted_dw(frames, g2, Wg.grad[:Din], beta)
+            else:
+                ops.gemm_any(x2, g2, out=Wg.grad[:Din], transA=True, beta=beta, role="dw", bf16=bf)
             ops.gemm_any(hs[:F].view(F * B, H), g2, out=Wg.grad[Din:], transA=True, beta=beta, role="dw", bf16=bf)
             Wg.grad_done()
         if Wc.grad is not None:
             beta = Wc.grad_beta()
-            ops.gemm_any(x2, c2, out=Wc.grad[:Din], transA=True, beta=beta, role="dw", bf16=bf)
+            if frames is not None:
+                u8_hoisted_dw(frames, c2, Wc.grad[:Din], beta)
+            else:
+                ops.gemm_any(x2, c2, out=Wc.grad[:Din], transA=True, beta=beta, role="dw", bf16=bf)
             ops.gemm_any(rh.view(F * B, H), c2, out=Wc.grad[Din:], transA=True, beta=beta, role="dw", bf16=bf)
             Wc.grad_done()
         if bg.grad is not None:
@@ -172,7 +190,7 @@ class _GruLayer(torch.autograd.Function):
             ops.colsum(c2, bc.grad.view(-1), beta=bc.grad_beta())
             bc.grad_done()
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and frames is None:
             dx = ops.hoisted_dx(g2, Wg.data[:Din], bf16=bf)
             ops.hoisted_dx(c2, Wc.data[:Din], out=dx, beta=1.0, bf16=bf)
             dx = dx.view(F, B, Din)
@@ -192,14 +210,23 @@ class _LnLstmLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_tm, token, W, gammas, betas, num_frames, forget_bias, keep_prob, seed):
-        x_tm = _f32c(x_tm)
-        _dev(x_tm)
-        F, B, Din = x_tm.shape
+        frames = x_tm if isinstance(x_tm, U8FrameImages) else None     # the reader's bytes (layer 0): see u8_hoisted_fwd
+        if frames is None:
+            x_tm = _f32c(x_tm)
+            _dev(x_tm)
+            F, B, Din = x_tm.shape
+            dev = x_tm.device
+        else:
+            F, B, Din = frames.F, frames.B, frames.D
+            dev = frames.q.device
         H = W.data.shape[1] // 4
         assert W.data.shape[0] == Din + H, "cell weights must be [in + H, 4H]"
-        dev = x_tm.device
         bf = ops.FLAGS.compute_dtype == "bfloat16"
-        z = ops.gemm_any(x_tm.view(F * B, Din), W.data[:Din], bf16=bf, role=ops._hoisted_role(F * B, 4 * H, Din, bf)).view(F, B, 4 * H)
+        if frames is not None:
+            z = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
+            u8_hoisted_fwd(frames, W.data[:Din], None, z.view(F * B, 4 * H))
+        else:
+            z = ops.gemm_any(x_tm.view(F * B, Din), W.data[:Din], bf16=bf, role=ops._hoisted_role(F * B, 4 * H, Din, bf)).view(F, B, 4 * H)
         gamma = torch.stack([v.data for v in gammas]).contiguous()
         beta = torch.stack([v.data for v in betas]).contiguous()
         stats = torch.zeros((F, B, 10), dtype=torch.float32, device=dev)
@@ -213,7 +240,8 @@ class _LnLstmLayer(torch.autograd.Function):
         _lib.check(_lib.lib().yt8m_lnlstm_layer_fwd(_p(z), _p(W.data[Din:]), 4 * H, _p(gamma), _p(beta), _p(stats), _p(cs), _p(hs),
                                                     _p(out), _p(nf), F, B, H, float(forget_bias), float(keep_prob), int(seed),
                                                     _p(ws), ws.numel() * 4, _stream()))
-        ctx.save_for_backward(x_tm)
+        ctx.save_for_backward(x_tm if frames is None else frames.r)
+        ctx.frames, ctx.dims = frames, (F, B, Din)
         ctx.state = (z, gamma, beta, stats, cs, hs, nf, W, gammas, betas, float(forget_bias), float(keep_prob), int(seed))
         ctx.bf16 = bf
         ctx.set_materialize_grads(False)
@@ -222,9 +250,10 @@ class _LnLstmLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dc_final, dh_final):
         (x_tm,) = ctx.saved_tensors
+        frames = ctx.frames
         z, gamma, beta, stats, cs, hs, nf, W, gammas, betas, fb, keep, seed = ctx.state
         ctx.state = None
-        F, B, Din = x_tm.shape
+        F, B, Din = ctx.dims
         H = W.data.shape[1] // 4
         dev = x_tm.device
         dz = torch.empty((F, B, 4 * H), dtype=torch.float32, device=dev)
@@ -241,7 +270,10 @@ class _LnLstmLayer(torch.autograd.Function):
         dz2 = dz.view(F * B, 4 * H)
         if W.grad is not None:
             b = W.grad_beta()
-            ops.gemm_any(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=b, role="dw", bf16=ctx.bf16)
+            if frames is not None:
+                u8_hoisted_dw(frames, dz2, W.grad[:Din], b)
+            else:
+                ops.gemm_any(x_tm.view(F * B, Din), dz2, out=W.grad[:Din], transA=True, beta=b, role="dw", bf16=ctx.bf16)
             ops.gemm_any(hs[:F].view(F * B, H), dz2, out=W.grad[Din:], transA=True, beta=b, role="dw", bf16=ctx.bf16)
             W.grad_done()
         yb, yg = dyb.view(F * B, 5 * H), dyg.view(F * B, 5 * H)
@@ -251,7 +283,7 @@ class _LnLstmLayer(torch.autograd.Function):
                     ops.colsum(src[:, k * H:(k + 1) * H], v.grad.view(-1), beta=v.grad_beta())
                     v.grad_done()
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and frames is None:
             dx = ops.hoisted_dx(dz2, W.data[:Din], bf16=ctx.bf16).view(F, B, Din)
         return dx, None, None, None, None, None, None, None, None
 
@@ -1412,6 +1444,52 @@ def _u8_cnn_dense(frames, filters):
                                                 _stream()))
         c0 += N
     return y
+
+
+def u8_hoisted_supported(q):
+    """A recurrent layer's hoisted input projection straight from the reader's bytes (u8_hoisted_fwd / _dw: GRU and LayerNorm-LSTM layers
+    outside the native stack): D % 16 == 0, whole K blocks of frame rows for the weight gradient (F B % 16 == 0)."""
+    if q.dtype != torch.uint8 or q.dim() != 3 or not q.is_cuda:
+        return False
+    B, F, D = q.shape
+    return bool(D % 16 == 0 and 16 <= D <= 2048 and (F * B) % 16 == 0 and F >= 1 and _lib.lib().yt8m_u8_proj_supported(D))
+
+
+def u8_hoisted_fwd(frames, Wrows, bias, out2d):
+    """out2d [F B rows (t B + b), N] = x . Wrows (+ bias), x = the dequantised, l2-normalised, padding-masked frames (W/utils.py:23-38,
+    readers.py:178-187, default_transformer.py:4-8): two f16 products of the frames' half image against (alpha Wrows)^T under a
+    device-measured scale, the affine remainder in the epilogue (yt8m_gemm_h1x2_nt_ex) -- the form the native LSTM stack's layer 0 takes."""
+    M, D = frames.F * frames.B, frames.D
+    N = Wrows.shape[1]
+    dev = frames.q.device
+    _, w2 = ops.h2_split(Wrows, plain=False, trans=True, scale=U8_ALPHA, dynamic=True)
+    cs = torch.empty((N,), dtype=torch.float32, device=dev)
+    ops.colsum(Wrows, cs)
+    ws = ops._workspace(dev)
+    _lib.check(_lib.lib().yt8m_gemm_h1x2_nt_ex(M, N, D, _p(frames.img), 0, _p(w2.buf), 0, _p(out2d), N, _p(bias), 1.0, _p(w2.dinv),
+                                               _p(frames.r), _p(cs), U8_BETA, 0.0, _p(ws), ws.numel() * 4, _stream()))
+
+
+def u8_hoisted_dw(frames, dz2d, gWrows, beta):
+    """gWrows [D, N] (beta = 0 / 1: overwrite / accumulate) (+)= x^T . dz2d: the transposed byte image against (r (.) dz)^T written by one
+    pass over dz (yt8m_h2_split_ex), the affine remainder as a rank-1 term of the epilogue."""
+    M, D = frames.F * frames.B, frames.D
+    N = dz2d.shape[1]
+    dev = dz2d.device
+    lib = _lib.lib()
+    nb = max(lib.yt8m_x3_image_bytes(N, M) // 3 * 2, 16)
+    word = ops.h2_absmax(dz2d)
+    dzT = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dzTs = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ntile = (M + 63) // 64
+    cp = torch.empty((ntile, N), dtype=torch.float32, device=dev)
+    cps = torch.empty((ntile, N), dtype=torch.float32, device=dev)
+    _lib.check(lib.yt8m_h2_split_ex(_p(dz2d), M, N, N, 1.0, _p(word), _p(frames.r), None, _p(dzT), _p(dzTs), _p(cp), _p(cps), _stream()))
+    csr = torch.empty((N,), dtype=torch.float32, device=dev)
+    ops.colsum(cps, csr)
+    ws = ops._workspace(dev)
+    _lib.check(lib.yt8m_gemm_h1x2_nt_ex(D, N, M, _p(frames.trans()), (M + 15) // 16, _p(dzTs), 0, _p(gWrows), N, None, U8_ALPHA, _p(word), None,
+                                        _p(csr), U8_BETA / U8_ALPHA, float(beta), _p(ws), ws.numel() * 4, _stream()))
 
 
 class _CnnU8(torch.autograd.Function):
