@@ -773,7 +773,7 @@ def test_moe_head_skips_the_input_gradient_of_its_data_columns(dev, flags, B):
     assert float(xx.grad[:, :k0].abs().max()) == 0.0 and float(xx.grad[:, k0:].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("which", ["gru_pool", "gru_with_pool", "ln_lstm"])
+@pytest.mark.parametrize("which", ["gru_pool", "gru_with_pool", "ln_lstm", "frame_logistic"])
 def test_gru_and_layernorm_lstm_plugins_take_the_raw_uint8_frames(dev, flags, which, monkeypatch):
     """GruPoolingModel / GruWithPoolingModel / LayerNormLstmMemoryModel on the reader's bytes: layer 0's hoisted input projection and
     its weight gradient read the byte images (seq_ops.u8_hoisted_fwd / _dw, the forms of the native LSTM stack's layer 0), no dx for
@@ -786,8 +786,9 @@ def test_gru_and_layernorm_lstm_plugins_take_the_raw_uint8_frames(dev, flags, wh
     nf = rs.randint(1, F + 1, size=B).astype(np.int32)
     nf[0], nf[1] = F, 1
     y = rs.rand(B, V) < 0.2
-    cls = {"gru_pool": flm.GruPoolingModel, "gru_with_pool": flm.GruWithPoolingModel, "ln_lstm": flm.LayerNormLstmMemoryModel}[which]
-    assert seq_ops.u8_hoisted_supported(torch.from_numpy(q).to(dev))
+    cls = {"gru_pool": flm.GruPoolingModel, "gru_with_pool": flm.GruWithPoolingModel, "ln_lstm": flm.LayerNormLstmMemoryModel,
+           "frame_logistic": flm.FrameLevelLogisticModel}[which]        # (the frame-level logistic model: its average over the frames)
+    assert seq_ops.u8_hoisted_supported(torch.from_numpy(q).to(dev)) and seq_ops.u8_attention_supported(torch.from_numpy(q).to(dev), 1)
     P0 = None
     if which == "ln_lstm":                                              # gammas near 1 (a random gamma ~ N(0, 0.3) is a degenerate cell)
         pa0, _, _, P0 = _run_frames_plugin(cls(), q, y, nf, dev, rs=rs)

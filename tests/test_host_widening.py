@@ -254,7 +254,6 @@ def test_host_rules_of_the_byte_reading_plugins_and_the_hoisted_h2_roles():
     import yt8m_amd.frame_level_models as flm
     for cls in (flm.LstmModel, flm.LstmMemoryModel, flm.LstmAttentionMaxPoolingModel, flm.LstmPositionalAttentionMaxPoolingModel,
                 flm.LstmParallelFinaloutputModel, flm.CnnDeepCombineChainModel, flm.DbofModel, flm.NetVLADModel, flm.GruPoolingModel,
-                flm.GruWithPoolingModel, flm.LayerNormLstmMemoryModel):
+                flm.GruWithPoolingModel, flm.LayerNormLstmMemoryModel, flm.FrameLevelLogisticModel):
         assert getattr(cls, "accepts_quantized_input", False), cls.__name__
-    assert not getattr(flm.FrameLevelLogisticModel, "accepts_quantized_input", False)
     assert not seq_ops.u8_hoisted_supported(q)

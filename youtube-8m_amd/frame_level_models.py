@@ -80,9 +80,21 @@ def _lstm_stack(model_input, num_frames, lstm_size, number_of_layers, scope="RNN
 class FrameLevelLogisticModel(models.BaseModel):
     """W/all_frame_models/logistic_model.py:13-46: logistic classifier over the num_frames-average of the frames."""
 
+    accepts_quantized_input = True
+
     def create_model(self, model_input, vocab_size, num_frames, **unused_params):
-        denominators = num_frames.to(torch.float32).unsqueeze(1)
-        avg_pooled = model_input.sum(dim=1) / denominators     # input is data: no gradient flows here
+        if model_input.dtype == torch.uint8 and seq_ops.u8_attention_supported(model_input, 1):
+            # the reader's bytes: sum_f x[b, f] / num_frames as one weighted pooling pass over them (rs is 0 on the padding frames)
+            B, F, D = model_input.shape
+            q = model_input.contiguous()
+            rs = seq_ops.u8_frame_scales(q, num_frames)
+            inv = 1.0 / num_frames.to(torch.float32)
+            avg_pooled = seq_ops.pool_u8_raw(inv.view(B, 1, 1).expand(B, F, 1).contiguous(), q, rs).view(B, D)
+        else:
+            if model_input.dtype == torch.uint8:
+                model_input = ops.dequant_l2norm(model_input, num_frames)
+            denominators = num_frames.to(torch.float32).unsqueeze(1)
+            avg_pooled = model_input.sum(dim=1) / denominators     # input is data: no gradient flows here
         output = video_level_models.fully_connected(avg_pooled, vocab_size, "fully_connected", activation="sigmoid",
                                                     l2_penalty=1e-8)
         return {"predictions": output}
